@@ -1,0 +1,314 @@
+"""fmsi_amd -- thin Python binding (ctypes) over libfmsi_hip.so, the MI355X `fmsi query` hot path.
+
+The product is the C-ABI shared library (include/fmsi_hip.h) and the `fmsi` CLI built from
+fmsi_amd/csrc; this module only mirrors the library for test drivers and bench.py.  There is no CPU
+fallback anywhere in this package: if the library is missing or no HIP device is usable the calls
+raise.  Nothing here imports or calls oracle/.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from pathlib import Path
+
+import numpy as np
+
+_PKG = Path(__file__).resolve().parent
+REPO = _PKG.parent
+LIB_PATH = _PKG / "lib" / "libfmsi_hip.so"
+CLI_PATH = _PKG / "bin" / "fmsi"
+
+# ---- constants of include/fmsi_hip.h ------------------------------------------------------------
+MODE_OR = 0x0
+MODE_ALL = 0x1
+STRICT = 0x2
+ORDERS = 0x4
+DEVICE_PTRS = 0x8
+KERNEL_LOCKSTEP = 0x10
+KERNEL_REFILL = 0x20
+NO_PREFIX_TABLE = 0x100
+N_COUNTERS = 8
+
+E_INVAL, E_NODEV, E_HIP, E_NOMEM, E_IO, E_RANGE, E_COMM = -1, -2, -3, -4, -5, -6, -7
+
+
+class FmsiError(RuntimeError):
+    def __init__(self, code: int, message: str):
+        super().__init__(f"libfmsi_hip error {code}: {message}")
+        self.code = code
+
+
+class IndexView(C.Structure):
+    _fields_ = [
+        ("ac_gt", C.c_void_p), ("ac_gt_bits", C.c_uint64),
+        ("ac", C.c_void_p), ("ac_bits", C.c_uint64),
+        ("gt", C.c_void_p), ("gt_bits", C.c_uint64),
+        ("mask", C.c_void_p), ("mask_bits", C.c_uint64),
+        ("klcp", C.c_void_p), ("klcp_bits", C.c_uint64),
+        ("counts", C.c_uint64 * 4),
+        ("dollar_position", C.c_uint64),
+        ("k", C.c_int32),
+        ("prefix_len", C.c_int32),
+    ]
+
+
+class IndexInfo(C.Structure):
+    _fields_ = [
+        ("n", C.c_uint64), ("k", C.c_int32), ("has_klcp", C.c_int32), ("device", C.c_int32),
+        ("prefix_len", C.c_int32), ("block_bytes", C.c_uint64), ("block_symbols", C.c_uint64),
+        ("n_blocks", C.c_uint64), ("device_bytes", C.c_uint64),
+    ]
+
+
+def build(verbose: bool = False) -> None:
+    """Compile libfmsi_hip.so and the fmsi CLI for gfx950 (hipcc cross-compiles without a GPU)."""
+    cmd = ["make", "-C", str(_PKG / "csrc")]
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if verbose or res.returncode != 0:
+        print(res.stdout)
+        print(res.stderr)
+    if res.returncode != 0:
+        raise RuntimeError("building libfmsi_hip.so failed")
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """Load libfmsi_hip.so (fails loudly if it has not been built)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise FileNotFoundError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                                f"(or make -C fmsi_amd/csrc); there is no fallback path")
+    L = C.CDLL(str(LIB_PATH))
+    vp, u64, i32, u32 = C.c_void_p, C.c_uint64, C.c_int, C.c_uint32
+    L.fmsi_hip_last_error.restype = C.c_char_p
+    L.fmsi_hip_abi_version.restype = i32
+    L.fmsi_hip_device_count.restype = i32
+    L.fmsi_hip_index_create.argtypes = [C.POINTER(IndexView), i32, C.POINTER(vp)]
+    L.fmsi_hip_index_destroy.argtypes = [vp]
+    L.fmsi_hip_index_destroy.restype = None
+    L.fmsi_hip_index_get_info.argtypes = [vp, C.POINTER(IndexInfo)]
+    L.fmsi_hip_query_kmers.argtypes = [vp, vp, u64, i32, u32, vp, vp, vp]
+    L.fmsi_hip_query_windows.argtypes = [vp, vp, u64, vp, u64, i32, u32, vp, vp, vp]
+    L.fmsi_hip_query_stream.argtypes = [vp, vp, u64, vp, vp, u64, u64, i32, u32, vp, vp, vp]
+    L.fmsi_hip_sync.argtypes = [vp, vp]
+    L.fmsi_hip_profile_enable.argtypes = [vp, i32]
+    L.fmsi_hip_profile_read.argtypes = [vp, C.POINTER(u64), C.POINTER(C.c_double), i32]
+    L.fmsi_host_index_load.argtypes = [C.c_char_p, i32, C.POINTER(vp)]
+    L.fmsi_host_index_free.argtypes = [vp]
+    L.fmsi_host_index_free.restype = None
+    L.fmsi_host_index_view.argtypes = [vp, C.POINTER(IndexView)]
+    L.fmsi_host_layout_blocks.argtypes = [C.POINTER(IndexView)]
+    L.fmsi_host_layout_blocks.restype = u64
+    L.fmsi_host_layout_build.argtypes = [C.POINTER(IndexView), vp, vp]
+    L.fmsi_host_pack_2bit.argtypes = [C.c_char_p, u64, vp]
+    L.fmsi_host_pack_2bit.restype = u64
+    L.fmsi_cli_query.argtypes = [i32, C.POINTER(C.c_char_p), i32]
+    _lib = L
+    return L
+
+
+def _check(rc: int) -> None:
+    if rc != 0:
+        raise FmsiError(rc, lib().fmsi_hip_last_error().decode(errors="replace"))
+
+
+def device_count() -> int:
+    return lib().fmsi_hip_device_count()
+
+
+_CODE = np.full(256, 4, dtype=np.uint8)
+for _ch, _v in (("A", 0), ("C", 1), ("G", 2), ("T", 3)):
+    _CODE[ord(_ch)] = _v
+    _CODE[ord(_ch.lower())] = _v
+
+
+def pack_kmers(kmers, k: int) -> np.ndarray:
+    """2-bit pack equal-length k-mers (k <= 32): base t (0 = leftmost) in bits [2t, 2t+1]."""
+    if isinstance(kmers, (bytes, bytearray)):
+        raw = np.frombuffer(kmers, dtype=np.uint8)
+    elif isinstance(kmers, np.ndarray):
+        raw = kmers.reshape(-1).view(np.uint8)
+    else:
+        raw = np.frombuffer("".join(kmers).encode(), dtype=np.uint8)
+    assert k <= 32 and raw.size % k == 0
+    codes = _CODE[raw].reshape(-1, k).astype(np.uint64)
+    if (codes > 3).any():
+        raise ValueError("invalid character in k-mer")
+    shifts = (2 * np.arange(k, dtype=np.uint64))
+    return np.bitwise_or.reduce(codes << shifts, axis=1).astype(np.uint64)
+
+
+def pack_sequence(seq: bytes) -> np.ndarray:
+    """2-bit pack a sequence: base p in bits [2(p%32), 2(p%32)+1] of word p//32 (+2 pad words)."""
+    words = np.zeros(len(seq) // 32 + 2, dtype=np.uint64)
+    bad = lib().fmsi_host_pack_2bit(seq, len(seq), words.ctypes.data)
+    if bad != len(seq):
+        raise ValueError(f"invalid character at {bad}")
+    return words
+
+
+class HostIndex:
+    """Parsed <prefix>.fmsi.* files (loader half of load_index, reference src/fms_index.h:502-526)."""
+
+    def __init__(self, prefix: str, use_klcp: bool = False):
+        self._h = C.c_void_p()
+        _check(lib().fmsi_host_index_load(os.fsencode(prefix), int(use_klcp), C.byref(self._h)))
+        self.view = IndexView()
+        _check(lib().fmsi_host_index_view(self._h, C.byref(self.view)))
+
+    @property
+    def n(self) -> int:
+        return int(self.view.mask_bits)
+
+    @property
+    def k(self) -> int:
+        return int(self.view.k)
+
+    def bits(self, which: str) -> np.ndarray:
+        """Copy of one bit-vector as a uint8 array of 0/1 (test helper)."""
+        ptr = getattr(self.view, which)
+        nbits = int(getattr(self.view, which + "_bits"))
+        if not ptr or nbits == 0:
+            return np.zeros(0, dtype=np.uint8)
+        nw = (nbits + 63) // 64
+        words = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint64)), shape=(nw,)).copy()
+        return np.unpackbits(words.view(np.uint8), bitorder="little")[:nbits]
+
+    def layout(self):
+        """(blocks[n_blocks,16] u32, mrank[n_blocks+1] u32): the device layout, built on the host."""
+        nb = int(lib().fmsi_host_layout_blocks(C.byref(self.view)))
+        blocks = np.zeros((nb, 16), dtype=np.uint32)
+        mrank = np.zeros(nb + 1, dtype=np.uint32)
+        _check(lib().fmsi_host_layout_build(C.byref(self.view), blocks.ctypes.data, mrank.ctypes.data))
+        return blocks, mrank
+
+    def close(self):
+        if self._h:
+            lib().fmsi_host_index_free(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def view_from_arrays(ac_gt, ac, gt, mask, counts, dollar_position, k, klcp=None, prefix_len=0):
+    """IndexView over numpy uint64 word arrays given as (words, nbits) pairs.  Returns (view, keepalive)."""
+    v = IndexView()
+    keep = []
+    for name, pair in (("ac_gt", ac_gt), ("ac", ac), ("gt", gt), ("mask", mask), ("klcp", klcp)):
+        if pair is None:
+            continue
+        words, nbits = pair
+        words = np.ascontiguousarray(words, dtype=np.uint64)
+        keep.append(words)
+        setattr(v, name, words.ctypes.data)
+        setattr(v, name + "_bits", int(nbits))
+    for i in range(4):
+        v.counts[i] = int(counts[i])
+    v.dollar_position = int(dollar_position)
+    v.k = int(k)
+    v.prefix_len = int(prefix_len)
+    return v, keep
+
+
+class DeviceIndex:
+    """Device-resident index (fmsi_hip_index).  Raises FmsiError(E_NODEV) when no GPU is usable."""
+
+    def __init__(self, view: IndexView, device: int = 0, keepalive=None):
+        self._h = C.c_void_p()
+        self._keep = keepalive
+        _check(lib().fmsi_hip_index_create(C.byref(view), device, C.byref(self._h)))
+        self.info = IndexInfo()
+        _check(lib().fmsi_hip_index_get_info(self._h, C.byref(self.info)))
+
+    @classmethod
+    def from_files(cls, prefix: str, use_klcp: bool = False, device: int = 0, prefix_len: int = 0):
+        host = HostIndex(prefix, use_klcp)
+        host.view.prefix_len = prefix_len
+        return cls(host.view, device, keepalive=host)
+
+    # -- host-pointer calls (library stages through its own device buffers) --
+    def query_kmers(self, kmers: np.ndarray, k: int, flags: int = MODE_OR, counters: bool = False):
+        kmers = np.ascontiguousarray(kmers, dtype=np.uint64)
+        n = kmers.size
+        out = self._alloc_out(n, flags)
+        cn = np.zeros(N_COUNTERS, dtype=np.uint64) if counters else None
+        _check(lib().fmsi_hip_query_kmers(self._h, kmers.ctypes.data, n, k, flags, out.ctypes.data,
+                                          cn.ctypes.data if counters else None, None))
+        self.sync()
+        return (out, cn) if counters else out
+
+    def query_windows(self, packed: np.ndarray, seq_bases: int, k: int, flags: int = MODE_OR,
+                      window_start: np.ndarray | None = None, n_windows: int | None = None, counters: bool = False):
+        packed = np.ascontiguousarray(packed, dtype=np.uint64)
+        if window_start is not None:
+            window_start = np.ascontiguousarray(window_start, dtype=np.uint64)
+            n = window_start.size
+        else:
+            n = n_windows if n_windows is not None else max(0, seq_bases - k + 1)
+        out = self._alloc_out(n, flags)
+        cn = np.zeros(N_COUNTERS, dtype=np.uint64) if counters else None
+        _check(lib().fmsi_hip_query_windows(self._h, packed.ctypes.data, seq_bases,
+                                            window_start.ctypes.data if window_start is not None else None, n, k, flags,
+                                            out.ctypes.data, cn.ctypes.data if counters else None, None))
+        self.sync()
+        return (out, cn) if counters else out
+
+    # -- device-pointer calls (buffers already resident in HBM, e.g. torch tensors' data_ptr()) --
+    def query_kmers_dev(self, kmers_ptr: int, n: int, k: int, flags: int, out_ptr: int, counters_ptr: int = 0, stream: int = 0):
+        _check(lib().fmsi_hip_query_kmers(self._h, kmers_ptr, n, k, flags | DEVICE_PTRS, out_ptr, counters_ptr or None,
+                                          stream or None))
+
+    def query_windows_dev(self, packed_ptr: int, seq_bases: int, wstart_ptr: int, n: int, k: int, flags: int, out_ptr: int,
+                          counters_ptr: int = 0, stream: int = 0):
+        _check(lib().fmsi_hip_query_windows(self._h, packed_ptr, seq_bases, wstart_ptr or None, n, k, flags | DEVICE_PTRS,
+                                            out_ptr, counters_ptr or None, stream or None))
+
+    def sync(self, stream: int = 0):
+        _check(lib().fmsi_hip_sync(self._h, stream or None))
+
+    def profile(self, on: bool):
+        _check(lib().fmsi_hip_profile_enable(self._h, int(on)))
+
+    def profile_read(self, reset: bool = True):
+        n, ms = C.c_uint64(), C.c_double()
+        _check(lib().fmsi_hip_profile_read(self._h, C.byref(n), C.byref(ms), int(reset)))
+        return int(n.value), float(ms.value)
+
+    @staticmethod
+    def _alloc_out(n: int, flags: int) -> np.ndarray:
+        if flags & ORDERS:
+            return np.zeros((n, 2) if flags & STRICT else n, dtype=np.int64)
+        return np.zeros(n, dtype=np.uint8)
+
+    def close(self):
+        if self._h:
+            lib().fmsi_hip_index_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def decode_strict(out: np.ndarray):
+    """Split STRICT presence bytes into (fwd, rc) int8 arrays with values in {-1, 0, 1}."""
+    return (out & 3).astype(np.int8) - 1, ((out >> 2) & 3).astype(np.int8) - 1
+
+
+def run_cli(args, stdin: bytes | None = None):
+    """Run the built `fmsi` CLI; returns (returncode, stdout bytes, stderr bytes)."""
+    if not CLI_PATH.exists():
+        raise FileNotFoundError(f"{CLI_PATH} is missing: build first")
+    res = subprocess.run([str(CLI_PATH), *args], input=stdin, capture_output=True)
+    return res.returncode, res.stdout, res.stderr

@@ -1,0 +1,102 @@
+#include "fastx.h"
+
+#include <cctype>
+#include <cstdio>
+#include <cstring>
+#include <stdexcept>
+
+namespace fmsi {
+
+namespace {
+constexpr size_t kBufSize = 1 << 18;
+}
+
+FastxReader::FastxReader(const std::string& path) : buf_(kBufSize) {
+    if (path == "-") {
+        fp_ = gzdopen(fileno(stdin), "r");
+    } else {
+        FILE* f = std::fopen(path.c_str(), "r");
+        if (!f) throw std::invalid_argument("couldn't open file " + path);
+        fp_ = gzdopen(fileno(f), "r");   // plain files are read transparently, as in the reference
+    }
+    if (!fp_) throw std::invalid_argument("couldn't open file " + path);
+    gzbuffer(fp_, 1 << 20);
+}
+
+FastxReader::~FastxReader() {
+    if (fp_) gzclose(fp_);
+}
+
+bool FastxReader::fill_() {
+    if (eof_) return false;
+    begin_ = 0;
+    int n = gzread(fp_, buf_.data(), static_cast<unsigned>(buf_.size()));
+    if (n <= 0) {
+        end_ = 0;
+        eof_ = true;
+        return false;
+    }
+    end_ = static_cast<size_t>(n);
+    return true;
+}
+
+int FastxReader::getc_() {
+    if (begin_ >= end_ && !fill_()) return -1;
+    return buf_[begin_++];
+}
+
+bool FastxReader::until_(bool line, std::string* dst, int* delim, size_t* counted) {
+    bool gotany = false;
+    if (delim) *delim = 0;
+    for (;;) {
+        if (begin_ >= end_ && !fill_()) break;
+        size_t i;
+        if (line) {
+            const void* nl = std::memchr(buf_.data() + begin_, '\n', end_ - begin_);
+            i = nl ? static_cast<size_t>(static_cast<const unsigned char*>(nl) - buf_.data()) : end_;
+        } else {
+            for (i = begin_; i < end_; ++i)
+                if (std::isspace(buf_[i])) break;
+        }
+        gotany = true;
+        if (dst) dst->append(reinterpret_cast<const char*>(buf_.data() + begin_), i - begin_);
+        if (counted) *counted += i - begin_;
+        const size_t at = i;
+        begin_ = i + 1;
+        if (at < end_) {
+            if (delim) *delim = buf_[at];
+            break;
+        }
+    }
+    if (!gotany) return false;
+    if (line && dst && dst->size() > 1 && dst->back() == '\r') dst->pop_back();   // src/kseq.h:146
+    return true;
+}
+
+bool FastxReader::next() {
+    int c;
+    if (last_char_ == 0) {   // jump to the next header line
+        while ((c = getc_()) >= 0 && c != '>' && c != '@') {}
+        if (c < 0) return false;
+        last_char_ = c;
+    }
+    name.clear();
+    seq.clear();
+    if (!until_(false, &name, &c, nullptr)) return false;
+    if (c != '\n') until_(true, nullptr, nullptr, nullptr);   // comment
+    while ((c = getc_()) >= 0 && c != '>' && c != '+' && c != '@') {
+        if (c == '\n') continue;
+        seq.push_back(static_cast<char>(c));
+        until_(true, &seq, nullptr, nullptr);
+    }
+    if (c == '>' || c == '@') last_char_ = c;
+    if (c != '+') return true;   // FASTA
+    while ((c = getc_()) >= 0 && c != '\n') {}
+    if (c < 0) return false;     // no quality string (-2 in the reference)
+    std::string qual;
+    while (until_(true, &qual, nullptr, nullptr) && qual.size() < seq.size()) {}
+    last_char_ = 0;
+    return qual.size() == seq.size();
+}
+
+}  // namespace fmsi

@@ -1,0 +1,44 @@
+// FASTA/FASTQ (plain or gzip) record reader for the query side of the boundary.
+// Behaviour follows the reference's reader, klib kseq over zlib (src/kseq.h:183-226, src/parser.h:14-27):
+// name = header up to the first whitespace, multi-line sequences, '>'/'@' record starts, FASTQ quality
+// skipped, a truncated FASTQ record ends the stream.
+#pragma once
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include <zlib.h>
+
+namespace fmsi {
+
+class FastxReader {
+public:
+    // path "-" = stdin.  Throws std::invalid_argument when the file cannot be opened, like
+    // OpenFile() in the reference (src/parser.h:22).
+    explicit FastxReader(const std::string& path);
+    ~FastxReader();
+    FastxReader(const FastxReader&) = delete;
+    FastxReader& operator=(const FastxReader&) = delete;
+
+    // Reads the next record into name/seq.  Returns false at end of input (or on the reference's
+    // error returns -2/-3, which also end its loop, src/main.cpp:328).
+    bool next();
+
+    std::string name;
+    std::string seq;
+
+private:
+    int getc_();
+    // append bytes up to (not including) the next '\n' / whitespace; returns false at EOF with nothing read
+    bool until_(bool line, std::string* dst, int* delim, size_t* counted);
+    bool fill_();
+
+    gzFile fp_ = nullptr;
+    std::vector<unsigned char> buf_;
+    size_t begin_ = 0, end_ = 0;
+    bool eof_ = false;
+    int last_char_ = 0;
+};
+
+}  // namespace fmsi

@@ -1,0 +1,44 @@
+// `fmsi` command-line entry for the MI355X query path.  Only the sub-commands on the hot path are
+// provided (`query`, `lookup`; reference dispatcher: src/main.cpp:668-699); everything else of the
+// reference's CLI (index construction, set operations, export, ...) is out of scope of this build and
+// says so instead of silently doing something different.
+#include <cstring>
+#include <iostream>
+#include <string>
+
+#include "../../include/fmsi_hip.h"
+
+#define FMSI_AMD_VERSION "0.4.0-mi355x.1"
+
+static int usage() {
+    std::cerr << std::endl;
+    std::cerr << "Program: FMSI (MI355X query path) - k-mer membership queries on masked-superstring indexes." << std::endl;
+    std::cerr << "Version: " << FMSI_AMD_VERSION << std::endl << std::endl;
+    std::cerr << "Usage:   fmsi <command> [options]" << std::endl << std::endl;
+    std::cerr << "Command:" << std::endl;
+    std::cerr << "    query   - Queries k-mers against an index (reads the reference's .fmsi.* files)." << std::endl;
+    std::cerr << "    lookup  - Return unique hashes of present k-mers." << std::endl << std::endl;
+    std::cerr << "Indexes are built with the reference `fmsi index`; this build does not construct them." << std::endl << std::endl;
+    return 1;
+}
+
+int main(int argc, char* argv[]) {
+    if (argc < 2) return usage();
+    const std::string op = argv[1];
+    if (op == "query") return fmsi_cli_query(argc - 1, argv + 1, 0);
+    if (op == "lookup") return fmsi_cli_query(argc - 1, argv + 1, 1);
+    if (op == "-v") {
+        std::cout << FMSI_AMD_VERSION << std::endl;
+        return 0;
+    }
+    if (op == "-h") {
+        usage();
+        return 0;
+    }
+    if (op == "index" || op == "export" || op == "merge" || op == "compact" || op == "normalize" || op == "clean" ||
+        op == "union" || op == "inter" || op == "diff" || op == "symdiff") {
+        std::cerr << "ERROR: `fmsi " << op << "` is not part of the MI355X query path; use the reference build for it." << std::endl;
+        return 1;
+    }
+    return usage();
+}

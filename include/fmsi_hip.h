@@ -1,0 +1,171 @@
+/* fmsi_hip.h -- C-ABI of libfmsi_hip.so: the MI355X (gfx950) drop-in for the `fmsi query` hot path.
+ *
+ * The reference (OndrejSladky/fmsi, single-threaded C++) has no FFI; the path sits behind one C++
+ * call, `query_kmers<mode>(fms_index&, char* seq, size_t len, int k, bool has_klcp, std::ostream&,
+ * bool output_orders, f)` (src/fms_index.h:333-342, called per chunk from src/main.cpp:344-350), fed
+ * by `load_index(prefix, use_klcp)` (src/fms_index.h:502-526).  This header is what a maintainer of
+ * the reference would bind instead (see INTEGRATION.md for the stub): plain pointers and sizes, no
+ * C++ types, no exceptions, no torch types.  All citations are relative to the reference root.
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative FMSI_HIP_E* code; the message is available
+ *     from fmsi_hip_last_error() (thread-local);
+ *   - the library owns device memory behind opaque handles; the caller owns every buffer it passes;
+ *   - calls on one handle are not re-entrant; different handles may be driven from different threads;
+ *   - query calls are asynchronous on `stream` (a hipStream_t passed as void*, NULL = default
+ *     stream); `out` is valid after the stream is synchronised (fmsi_hip_sync);
+ *   - there is NO CPU fallback: without a usable HIP device every call fails with FMSI_HIP_ENODEV.
+ */
+#ifndef FMSI_HIP_H
+#define FMSI_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FMSI_HIP_ABI_VERSION 1
+
+/* error codes */
+#define FMSI_HIP_OK 0
+#define FMSI_HIP_EINVAL (-1)   /* bad argument */
+#define FMSI_HIP_ENODEV (-2)   /* no HIP device / device index out of range */
+#define FMSI_HIP_EHIP (-3)     /* a HIP runtime call failed */
+#define FMSI_HIP_ENOMEM (-4)
+#define FMSI_HIP_EIO (-5)      /* index files missing / malformed */
+#define FMSI_HIP_ERANGE (-6)   /* index too large for this build (rows >= 2^32) or k unsupported */
+#define FMSI_HIP_ECOMM (-7)    /* RCCL failure */
+
+/* ---- query flags ------------------------------------------------------------------------------ */
+/* demasking mode: exactly one of OR / ALL.
+ *   OR  = query_mode::orr  (default `fmsi query`): k-mer present iff any occurrence (either strand) is ON.
+ *   ALL = query_mode::all  (`fmsi query -O`): first row of the SA interval decides (src/fms_index.h:129-131). */
+#define FMSI_HIP_MODE_OR 0x0u
+#define FMSI_HIP_MODE_ALL 0x1u
+/* STRICT: search BOTH strands of every window and return both ternary results so that the host can
+ * replay the reference's strand predictor (src/fms_index.h:18-49, 268, 312-315) and reproduce its
+ * output even when `-O` is used on a mask that is not max-ones.  Without STRICT the forward strand is
+ * searched first and the reverse complement only when needed (OR: result != 1; ALL: result == -1),
+ * which equals the reference's output for OR always and for ALL under its documented precondition
+ * (src/main.cpp:111-112). */
+#define FMSI_HIP_STRICT 0x2u
+/* ORDERS: `fmsi lookup` -- per window the rank of the ON occurrence (src/fms_index.h:146-156), -1 if absent.
+ * Output element is int64_t (STRICT: two int64_t, forward then reverse-complement strand). */
+#define FMSI_HIP_ORDERS 0x4u
+/* query/out/counters pointers are DEVICE pointers (already resident in HBM); default: host pointers,
+ * staged through library-owned device buffers. */
+#define FMSI_HIP_DEVICE_PTRS 0x8u
+/* kernel selection (diagnostics / A-B runs); default = FMSI_HIP_KERNEL_AUTO */
+#define FMSI_HIP_KERNEL_AUTO 0x00u
+#define FMSI_HIP_KERNEL_LOCKSTEP 0x10u   /* one lane per k-mer, wave walks the k LF steps in lock-step */
+#define FMSI_HIP_KERNEL_REFILL 0x20u     /* persistent lanes: a lane that finishes pulls the next k-mer (ballot/mbcnt) */
+#define FMSI_HIP_KERNEL_MASK 0xF0u
+/* do not use the private prefix table even if the handle has one (canonical-step accounting runs) */
+#define FMSI_HIP_NO_PREFIX_TABLE 0x100u
+
+/* ---- index creation flags --------------------------------------------------------------------- */
+/* build a 4^t-entry prefix table that jumps the first t LF steps (private optimisation: the final SA
+ * interval is unchanged).  t is given by fmsi_index_view.prefix_len (0 = none). */
+
+/* Output encoding of the non-ORDERS query calls: one byte per window.
+ *   non-STRICT: 0 / 1  (what the reference prints: '0' / '1')
+ *   STRICT    : (fwd + 1) | ((rc + 1) << 2), fwd/rc in {-1, 0, 1} = infer_presence() of each strand. */
+
+/* ---- host-side view of a loaded index (what load_index() holds, src/fms_index.h:52-66) -------- */
+typedef struct {
+    const uint64_t* ac_gt; uint64_t ac_gt_bits;   /* .fmsi.ac_gt payload: LSB-first u64 words (sdsl int_vector<1>) */
+    const uint64_t* ac;    uint64_t ac_bits;      /* .fmsi.ac */
+    const uint64_t* gt;    uint64_t gt_bits;      /* .fmsi.gt */
+    const uint64_t* mask;  uint64_t mask_bits;    /* SA-transformed mask, DECODED from the rrr_vector<63> to plain bits (n bits) */
+    const uint64_t* klcp;  uint64_t klcp_bits;    /* .fmsi.klcp, optional (NULL / 0) */
+    uint64_t counts[4];                           /* .fmsi.misc lines 2-5 */
+    uint64_t dollar_position;                     /* .fmsi.misc line 1 */
+    int32_t k;                                    /* .fmsi.misc line 6 */
+    int32_t prefix_len;                           /* private prefix table length t (0 = none, <= 14) */
+} fmsi_index_view;
+
+typedef struct fmsi_hip_index fmsi_hip_index;     /* device-resident index (opaque) */
+typedef struct fmsi_host_index fmsi_host_index;   /* host-resident parsed .fmsi.* files (opaque) */
+
+typedef struct {
+    uint64_t n;                 /* BWT rows = |MS| + 1 */
+    int32_t k;
+    int32_t has_klcp;
+    int32_t device;
+    int32_t prefix_len;
+    uint64_t block_bytes;       /* bytes per interleaved block */
+    uint64_t block_symbols;     /* BWT positions per block */
+    uint64_t n_blocks;
+    uint64_t device_bytes;      /* total HBM footprint of the handle */
+} fmsi_hip_index_info;
+
+/* counters written by query calls when `counters` != NULL (8 x u64, accumulated, caller zeroes):
+ *   [0] LF steps executed (update_range with i != j, src/fms_index.h:98-103)
+ *   [1] interleaved blocks read (64-B units)          [2] mask probes / strand searches ending non-empty
+ *   [3] strand searches started                       [4] prefix-table lookups   [5] kLCP words scanned
+ *   [6] windows answered                              [7] reserved */
+#define FMSI_HIP_N_COUNTERS 8
+
+/* ---- device side ------------------------------------------------------------------------------ */
+int fmsi_hip_device_count(void);
+int fmsi_hip_index_create(const fmsi_index_view* view, int device, fmsi_hip_index** out);
+void fmsi_hip_index_destroy(fmsi_hip_index* idx);
+int fmsi_hip_index_get_info(const fmsi_hip_index* idx, fmsi_hip_index_info* info);
+
+/* Replaces query_kmers<orr|all>() without kLCP (query_kmers_single, src/fms_index.h:263-331) for
+ * isolated k-mers, k <= 32.  kmers[q] holds k-mer q 2-bit packed (A=0,C=1,G=2,T=3 as in src/kmers.h:3-20),
+ * base t (0 = leftmost) in bits [2t, 2t+1]. */
+int fmsi_hip_query_kmers(fmsi_hip_index* idx, const uint64_t* kmers, uint64_t n_kmers, int k, uint32_t flags,
+                         void* out, uint64_t* counters, void* stream);
+
+/* Same, for windows of a 2-bit packed sequence (base p in bits [2(p%32), 2(p%32)+1] of word p/32; the
+ * buffer must be readable for one word past the last base).  Window w is the k-mer starting at base
+ * window_start[w]; window_start == NULL means windows 0 .. n_windows-1 start at bases 0 .. n_windows-1. */
+int fmsi_hip_query_windows(fmsi_hip_index* idx, const uint64_t* packed_seq, uint64_t seq_bases,
+                           const uint64_t* window_start, uint64_t n_windows, int k, uint32_t flags,
+                           void* out, uint64_t* counters, void* stream);
+
+/* Replaces query_kmers_streaming<>() (`-S`, src/fms_index.h:181-254): runs of consecutive windows walked
+ * right-to-left with the kLCP extension (src/fms_index.h:106-115).  Run r covers windows starting at bases
+ * run_start[r] .. run_start[r] + run_windows[r] - 1; results are written consecutively in run order. */
+int fmsi_hip_query_stream(fmsi_hip_index* idx, const uint64_t* packed_seq, uint64_t seq_bases,
+                          const uint64_t* run_start, const uint32_t* run_windows, uint64_t n_runs,
+                          uint64_t n_windows, int k, uint32_t flags, void* out, uint64_t* counters, void* stream);
+
+int fmsi_hip_sync(fmsi_hip_index* idx, void* stream);
+
+/* per-handle kernel timing with HIP events recorded on the launch stream around every kernel launch */
+int fmsi_hip_profile_enable(fmsi_hip_index* idx, int on);
+int fmsi_hip_profile_read(fmsi_hip_index* idx, uint64_t* n_launches, double* total_ms, int reset);
+
+const char* fmsi_hip_last_error(void);
+int fmsi_hip_abi_version(void);
+
+/* ---- host side: the loader half of load_index() (src/fms_index.h:502-526) --------------------- */
+/* Parses <prefix>.fmsi.{ac_gt,ac,gt,mask,misc} (+ .klcp iff use_klcp and the file exists), decodes the
+ * rrr_vector<63> mask to plain bits.  Pure host code (no HIP). */
+int fmsi_host_index_load(const char* prefix, int use_klcp, fmsi_host_index** out);
+void fmsi_host_index_free(fmsi_host_index* h);
+int fmsi_host_index_view(const fmsi_host_index* h, fmsi_index_view* view);
+
+/* The interleaved device layout built on the host (what fmsi_hip_index_create uploads): n_blocks blocks of
+ * 16 dwords (64 B) covering 128 rows each -- dw0-3 cumulative #A,#C,#G,#T before the block, dw4-7 hi plane
+ * (ac_gt), dw8-11 lo plane (ac / gt bit scattered back to row order), dw12-15 mask plane -- and n_blocks+1
+ * cumulative mask popcounts.  Exposed so that the layout can be verified without a GPU. */
+uint64_t fmsi_host_layout_blocks(const fmsi_index_view* view);
+int fmsi_host_layout_build(const fmsi_index_view* view, uint32_t* blocks /* n_blocks*16 */, uint32_t* mrank /* n_blocks+1 */);
+
+/* 2-bit pack `len` ACGT/acgt characters (src/kmers.h:3-20 codes) into words (caller provides
+ * len/32 + 2 words).  Returns the index of the first invalid character or len. */
+uint64_t fmsi_host_pack_2bit(const char* seq, uint64_t len, uint64_t* words);
+
+/* The `fmsi query` / `fmsi lookup` command (ms_query, src/main.cpp:238-375) on the GPU; argv as the
+ * reference's sub-command sees it (argv[0] = "query").  Returns the process exit code. */
+int fmsi_cli_query(int argc, char** argv, int output_orders);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FMSI_HIP_H */

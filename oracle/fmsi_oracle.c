@@ -741,6 +741,23 @@ void orc_kmer_ternaries(orc_index* ix, const char* kmer, int k, int maximized_on
     free(r);
 }
 
+void orc_kmers_ternaries_bulk(orc_index* ix, const char* kmers, uint64_t n, int k, int maximized_ones,
+                               int8_t* fwd, int8_t* rc, int64_t* ord_fwd, int64_t* ord_rc) {
+    /* per k-mer, both strands, no predictor: infer_presence (and kmer_order_if_present when ord_* != NULL) */
+    for (uint64_t q = 0; q < n; ++q) {
+        const char* kmer = kmers + q * (uint64_t)k;
+        char* r = reverse_complement(kmer, (uint64_t)k);
+        uint64_t a, b;
+        orc_get_range_with_pattern(ix, kmer, k, &a, &b);
+        fwd[q] = (int8_t)orc_infer_presence(ix, maximized_ones, a, b);
+        if (ord_fwd) ord_fwd[q] = orc_kmer_order_if_present(ix, a, b);
+        orc_get_range_with_pattern(ix, r, k, &a, &b);
+        rc[q] = (int8_t)orc_infer_presence(ix, maximized_ones, a, b);
+        if (ord_rc) ord_rc[q] = orc_kmer_order_if_present(ix, a, b);
+        free(r);
+    }
+}
+
 static void query_kmers_streaming(orc_index* ix, const char* sequence, const char* rc_sequence, uint64_t sequence_length,
                                   int k, int maximized_ones, int output_orders, orc_obuf* of) { /* :181-254 */
     uint64_t nres = sequence_length - (uint64_t)k + 1;

@@ -130,6 +130,9 @@ void orc_query_kmers_streaming(orc_index* ix, const char* seq, uint64_t len, int
 /* both strands' ternary results of one k-mer, independent of the predictor (for strict-mode checks) */
 void orc_kmer_ternaries(orc_index* ix, const char* kmer, int k, int maximized_ones, int* fwd, int* rc);
 
+void orc_kmers_ternaries_bulk(orc_index* ix, const char* kmers, uint64_t n, int k, int maximized_ones,
+                               int8_t* fwd, int8_t* rc, int64_t* ord_fwd, int64_t* ord_rc);
+
 /* record loop of ms_query (src/main.cpp:328-373) over a FASTA/FASTQ (optionally gz) file */
 int64_t orc_query_file(orc_index* ix, const char* query_fn, int k, int has_klcp, int mode,
                        int output_orders, orc_obuf* of, double* query_seconds, uint64_t* windows);

@@ -1,0 +1,214 @@
+"""GPU parity tests (run with `-m gpu` on an MI355X): the HIP path, called through the C-ABI of
+libfmsi_hip.so (and through the `fmsi` CLI), against the CPU oracle and the committed golden outputs of
+the real reference.  Everything is integer work: the bar is bit-exact.
+"""
+import random
+
+import numpy as np
+import pytest
+
+import oracle_py
+from conftest import DATASETS, GOLDEN, MODES, golden_out, index_prefix, mixed_kmers, query_file, revcomp, synthetic_ms
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def fm(product_built):
+    if product_built.device_count() < 1:
+        pytest.fail("no HIP device visible: the gpu tests must run on an MI355X")
+    return product_built
+
+
+def expected_fast(fwd, rc, mode_all):
+    """Forward strand first, reverse complement only when needed (src/fms_index.h:289-299 without swap)."""
+    if mode_all:
+        return np.where(fwd != -1, fwd, rc) == 1
+    return (fwd == 1) | (rc == 1)
+
+
+@pytest.mark.parametrize("name", list(DATASETS))
+def test_both_strands_equal_oracle(fm, oracle_built, name):
+    k = DATASETS[name][0]
+    orc = oracle_py.Oracle.load(index_prefix(name))
+    dev = fm.DeviceIndex.from_files(index_prefix(name))
+    ms_file = {"integration_a": "ref_data/integration_a.fa", "integration_b": "ref_data/integration_b.fa",
+               "sars_k13": "ref_data/GCF_009858895.2_ASM985889v3_genomic.fna.ms.k13",
+               "sars_k31": "ref_data/GCF_test2_ones.fna.ms.k31", "mixed_k11": "mixed.fa"}[name]
+    ms = "".join(l.strip() for l in open(GOLDEN / ms_file) if not l.startswith(">"))
+    kmers = mixed_kmers(ms, k, 3000, seed=17)
+    if k <= 6:   # exhaustive for tiny k
+        import itertools
+        kmers = ["".join(p) for p in itertools.product("ACGT", repeat=k)]
+    raw = "".join(kmers).encode()
+    packed = fm.pack_kmers(kmers, k)
+    for mode_all in (False, True):
+        flag = fm.MODE_ALL if mode_all else fm.MODE_OR
+        fwd, rc = orc.ternaries_bulk(raw, len(kmers), k, mode_all)
+        got_f, got_r = fm.decode_strict(dev.query_kmers(packed, k, flag | fm.STRICT))
+        assert np.array_equal(got_f, fwd) and np.array_equal(got_r, rc)
+        fast = dev.query_kmers(packed, k, flag)
+        assert np.array_equal(fast.astype(bool), expected_fast(fwd, rc, mode_all))
+    # lookup (orders)
+    fwd, rc, of, orc_r = orc.ternaries_bulk(raw, len(kmers), k, False, orders=True)
+    got = dev.query_kmers(packed, k, fm.ORDERS | fm.STRICT)
+    assert np.array_equal(got[:, 0], of) and np.array_equal(got[:, 1], orc_r)
+    got1 = dev.query_kmers(packed, k, fm.ORDERS)
+    assert np.array_equal(got1, np.where(of >= 0, of, orc_r))
+
+
+def test_windows_equal_kmers_and_oracle(fm, oracle_built):
+    name, k = "sars_k31", 31
+    orc = oracle_py.Oracle.load(index_prefix(name))
+    dev = fm.DeviceIndex.from_files(index_prefix(name))
+    ms = "".join(l.strip() for l in open(GOLDEN / "ref_data" / "GCF_test2_ones.fna.ms.k31") if not l.startswith(">")).upper()
+    rng = random.Random(5)
+    seq = ms[2000:6000] + "".join(rng.choice("ACGT") for _ in range(500)) + revcomp(ms[9000:12000])
+    nwin = len(seq) - k + 1
+    kmers = [seq[i:i + k] for i in range(nwin)]
+    fwd, rc = orc.ternaries_bulk("".join(kmers).encode(), nwin, k, True)
+    words = fm.pack_sequence(seq.encode())
+    got = dev.query_windows(words, len(seq), k, fm.MODE_ALL | fm.STRICT)
+    gf, gr = fm.decode_strict(got)
+    assert np.array_equal(gf, fwd) and np.array_equal(gr, rc)
+    starts = np.array(rng.sample(range(nwin), 1000), dtype=np.uint64)
+    got2 = dev.query_windows(words, len(seq), k, fm.MODE_ALL | fm.STRICT, window_start=starts)
+    assert np.array_equal(got2, got[starts.astype(np.int64)])
+    # the same windows as isolated k-mers
+    got3 = dev.query_kmers(fm.pack_kmers(kmers, k), k, fm.MODE_ALL | fm.STRICT)
+    assert np.array_equal(got3, got)
+
+
+def test_empty_and_argument_errors(fm):
+    dev = fm.DeviceIndex.from_files(index_prefix("sars_k31"))
+    assert dev.query_kmers(np.zeros(0, dtype=np.uint64), 31).size == 0
+    with pytest.raises(fm.FmsiError) as e:
+        dev.query_kmers(np.zeros(4, dtype=np.uint64), 33)
+    assert e.value.code == fm.E_RANGE
+    with pytest.raises(fm.FmsiError):
+        dev.query_windows(np.zeros(4, dtype=np.uint64), 40, 31, n_windows=100)   # runs past the sequence
+    info = dev.info
+    assert info.n == 29900 and info.k == 31 and info.block_bytes == 64 and info.block_symbols == 128
+
+
+def test_lf_step_counter_equals_oracle(fm, oracle_built):
+    """The in-kernel LF-step counter (roofline input) equals the oracle's count of
+    update_range calls with i != j under the same strand schedule (both strands of every k-mer)."""
+    name, k = "sars_k13", 13
+    orc = oracle_py.Oracle.load(index_prefix(name))
+    dev = fm.DeviceIndex.from_files(index_prefix(name))
+    ms = "".join(l.strip() for l in open(GOLDEN / "ref_data" / "GCF_009858895.2_ASM985889v3_genomic.fna.ms.k13") if not l.startswith(">"))
+    kmers = mixed_kmers(ms, k, 5000, seed=3)
+    orc.counters_reset()
+    orc.ternaries_bulk("".join(kmers).encode(), len(kmers), k, True)
+    want = orc.counters()
+    out, cn = dev.query_kmers(fm.pack_kmers(kmers, k), k, fm.MODE_ALL | fm.STRICT, counters=True)
+    assert int(cn[0]) == want["lf_steps"]
+    assert int(cn[3]) == want["strand_searches"] == 2 * len(kmers)
+    assert int(cn[2]) == want["mask_probes"]
+    assert int(cn[6]) == len(kmers)
+
+
+CASES = [(n, kind, mode) for n, (k, kinds) in DATASETS.items() for kind in kinds for mode in MODES]
+
+
+@pytest.mark.parametrize("name,kind,mode", CASES)
+def test_cli_equals_reference_golden(fm, name, kind, mode):
+    """`fmsi query|lookup` on the GPU reproduces the real reference's stdout byte for byte (default = exact
+    replay of the strand predictor), incl. the non-max-ones `-O` cases whose output is order dependent."""
+    k = DATASETS[name][0]
+    args = MODES[mode][0]
+    rc, out, err = fm.run_cli([*args, "-k", str(k), "-q", str(query_file(name, kind)), index_prefix(name)])
+    assert rc == 0, err.decode()
+    assert out == golden_out(name, kind, mode)
+
+
+@pytest.mark.parametrize("mode", ["or", "or_S", "all", "all_S"])
+def test_cli_fast_mode(fm, mode):
+    """--fast is exact for OR always and for -O on the max-ones fixture."""
+    name, k = "sars_k31", 31
+    rc, out, err = fm.run_cli([*MODES[mode][0], "--fast", "-k", str(k), "-q", str(query_file(name, "rand")), index_prefix(name)])
+    assert rc == 0, err.decode()
+    assert out == golden_out(name, "rand", mode)
+    rc, out, err = fm.run_cli([*MODES["or"][0], "--fast", "-q", str(query_file("mixed_k11", "rand")), index_prefix("mixed_k11")])
+    assert rc == 0 and out == golden_out("mixed_k11", "rand", "or")
+
+
+def test_cli_stdin_gzip_and_small_batches(fm, tmp_path):
+    import gzip
+    name, k = "sars_k13", 13
+    data = query_file(name, "rand").read_bytes()
+    gz = tmp_path / "q.fa.gz"
+    gz.write_bytes(gzip.compress(data))
+    want = golden_out(name, "rand", "all_S")
+    rc, out, err = fm.run_cli(["query", "-S", "-O", "-q", str(gz), "--batch", "1024", index_prefix(name)])
+    assert rc == 0 and out == want
+    rc, out, err = fm.run_cli(["query", "-S", "-O", index_prefix(name)], stdin=data)
+    assert rc == 0 and out == want
+    rc, out, err = fm.run_cli(["query", "-q", str(tmp_path / "missing.fa"), index_prefix(name)])
+    assert rc == -6 or rc == 134   # uncaught std::invalid_argument -> abort, like the reference
+
+
+@pytest.fixture(scope="module")
+def synthetic_index(oracle_built, tmp_path_factory):
+    """1.2 M-row max-ones index built by the oracle (oracle index bytes == reference bytes, test_oracle.py)."""
+    k = 31
+    ms = synthetic_ms(1_200_000, k, seed=12345)
+    d = tmp_path_factory.mktemp("syn")
+    orc = oracle_py.Oracle.construct(ms, k, use_klcp=True)
+    orc.dump(str(d / "syn"))
+    return ms, k, str(d / "syn"), orc
+
+
+def test_synthetic_random_queries_equal_oracle(fm, synthetic_index):
+    ms, k, prefix, orc = synthetic_index
+    dev = fm.DeviceIndex.from_files(prefix)
+    kmers = mixed_kmers(ms, k, 200_000, seed=42)
+    raw = "".join(kmers).encode()
+    orc.predictor_reset()
+    _, want = orc.time_isolated_kmers(raw, len(kmers), k, oracle_py.MODE_ALL)   # the reference loop incl. predictor
+    packed = fm.pack_kmers(kmers, k)
+    got = dev.query_kmers(packed, k, fm.MODE_ALL)
+    assert np.array_equal(got, want)
+    assert 0.45 < got.mean() < 0.55
+    orc.predictor_reset()
+    _, want_or = orc.time_isolated_kmers(raw, len(kmers), k, oracle_py.MODE_OR)
+    assert np.array_equal(dev.query_kmers(packed, k, fm.MODE_OR), want_or)
+
+
+def test_properties_at_scale(fm, synthetic_index):
+    """Size-independent properties on 16 M queries (no oracle needed):
+    every k-mer of a max-ones superstring is present on both strands; reverse-complement symmetry;
+    launches are deterministic; windows == isolated k-mers."""
+    ms, k, prefix, _ = synthetic_index
+    dev = fm.DeviceIndex.from_files(prefix)
+    up = ms.upper().encode()
+    words = fm.pack_sequence(up)
+    nwin = len(up) - k + 1
+    pos = dev.query_windows(words, len(up), k, fm.MODE_ALL | fm.STRICT)
+    f, r = fm.decode_strict(pos)
+    assert (f == 1).all()                       # all superstring k-mers are ON occurrences
+    assert ((r == 1) | (r == -1)).all()         # the RC strand is either absent or ON (max-ones)
+    rng = np.random.default_rng(7)
+    n = 16_000_000
+    kmers = rng.integers(0, 1 << 62, size=n, dtype=np.uint64)
+    starts = rng.integers(0, nwin, size=n // 2, dtype=np.uint64)
+    a = dev.query_kmers(kmers, k, fm.MODE_OR | fm.STRICT)
+    dev.profile(True)
+    b = dev.query_kmers(kmers, k, fm.MODE_OR | fm.STRICT)
+    launches, ms_total = dev.profile_read()
+    dev.profile(False)
+    print(f"\n[perf] lockstep strict: {n} random 31-mers in {ms_total:.3f} ms ({launches} launch) = {n / ms_total / 1e3:.1f} M k-mers/s")
+    assert np.array_equal(a, b)
+    # reverse complement of a packed k-mer, on the host
+    sub = kmers[:500_000]
+    c = ((sub[:, None] >> (2 * np.arange(k, dtype=np.uint64))) & np.uint64(3))
+    rcodes = (np.uint64(3) - c)[:, ::-1]
+    rck = np.bitwise_or.reduce(rcodes << (2 * np.arange(k, dtype=np.uint64)), axis=1)
+    fa, ra = fm.decode_strict(a[:500_000])
+    fb, rb = fm.decode_strict(dev.query_kmers(rck, k, fm.MODE_OR | fm.STRICT))
+    assert np.array_equal(fa, rb) and np.array_equal(ra, fb)
+    # random 31-mers are (almost surely) absent from a 1.2 M-char text
+    assert (fa == 1).mean() < 1e-3
+    w = dev.query_windows(words, len(up), k, fm.MODE_ALL, window_start=starts)
+    assert (w == 1).all()

@@ -1,0 +1,183 @@
+"""CPU tests of the product's host side: the C-ABI library loads and exports what include/fmsi_hip.h
+declares, the .fmsi.* loader + RRR-63 decoder, the interleaved device layout (checked by emulating the
+kernel's rank arithmetic in numpy against the oracle), 2-bit packing, the CLI's option handling -- and
+that the product fails LOUDLY without a GPU instead of falling back to anything.
+"""
+import ctypes as C
+import re
+import random
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle_py
+from conftest import DATASETS, GOLDEN, REPO, index_prefix, synthetic_ms
+
+
+def declared_functions():
+    text = (REPO / "include" / "fmsi_hip.h").read_text()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(fmsi_(?:hip|host|cli)_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol(product_built):
+    lib = product_built.lib()
+    names = declared_functions()
+    assert len(names) >= 18
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/fmsi_hip.h but not exported"
+    assert lib.fmsi_hip_abi_version() == 1
+
+
+def test_no_oracle_in_product():
+    """The product must not link, import or call anything under oracle/."""
+    for p in list((REPO / "fmsi_amd").rglob("*.py")) + list((REPO / "fmsi_amd" / "csrc").glob("*")):
+        if p.is_file() and p.suffix in {".py", ".cpp", ".h", ".hip", ""}:
+            t = p.read_text(errors="ignore")
+            assert "oracle_py" not in t and "liboracle" not in t and "fmsi_oracle" not in t and "_ref/" not in t, p
+    out = subprocess.run(["ldd", str(REPO / "fmsi_amd" / "lib" / "libfmsi_hip.so")], capture_output=True, text=True).stdout
+    assert "oracle" not in out and "fmsi_ref" not in out
+
+
+@pytest.mark.parametrize("name", list(DATASETS))
+def test_loader_matches_oracle(product_built, oracle_built, name):
+    host = product_built.HostIndex(index_prefix(name), use_klcp=True)
+    orc = oracle_py.Oracle.load(index_prefix(name), use_klcp=True)
+    assert host.n == orc.n and host.k == orc.k == DATASETS[name][0]
+    assert list(host.view.counts) == orc.counts() and host.view.dollar_position == orc.dollar()
+    for which, key in ((0, "ac_gt"), (1, "ac"), (2, "gt"), (3, "klcp")):
+        words, nbits = orc.words(which)
+        want = np.unpackbits(words.view(np.uint8), bitorder="little")[:nbits]
+        assert np.array_equal(host.bits(key), want), key
+    assert np.array_equal(host.bits("mask"), orc.mask_bits())     # RRR-63 decode
+    nok = product_built.HostIndex(index_prefix(name), use_klcp=False)
+    assert nok.view.klcp_bits == 0
+
+
+def test_loader_errors(product_built, tmp_path):
+    with pytest.raises(product_built.FmsiError) as e:
+        product_built.HostIndex(str(tmp_path / "missing"))
+    assert e.value.code == product_built.E_IO
+    # truncated mask
+    for part in ("ac_gt", "ac", "gt", "misc"):
+        (tmp_path / f"t.fmsi.{part}").write_bytes((GOLDEN / "idx" / f"sars_k13.fmsi.{part}").read_bytes())
+    (tmp_path / "t.fmsi.mask").write_bytes((GOLDEN / "idx" / "sars_k13.fmsi.mask").read_bytes()[:100])
+    with pytest.raises(product_built.FmsiError):
+        product_built.HostIndex(str(tmp_path / "t"))
+
+
+def emulate_rank(blocks, counts, dollar, i, c, upper):
+    """numpy restatement of the kernel's rank_in_block()/lf_step() address and popcount arithmetic."""
+    if upper:
+        b = (i - 1) >> 7
+        p = i - (b << 7)
+    else:
+        b = i >> 7
+        p = i & 127
+    blk = blocks[b]
+    r = int(blk[c])
+    for w in range(4):
+        s = min(max(p - 32 * w, 0), 32)
+        pm = (1 << s) - 1
+        h, l = int(blk[4 + w]), int(blk[8 + w])
+        m = (h if c & 2 else ~h) & (l if c & 1 else ~l) & pm & 0xFFFFFFFF
+        r += bin(m).count("1")
+    if c == 0 and i > dollar:
+        r -= 1
+    return r
+
+
+@pytest.mark.parametrize("name", ["integration_a", "sars_k13", "mixed_k11"])
+def test_layout_rank_equals_oracle(product_built, oracle_built, name):
+    host = product_built.HostIndex(index_prefix(name))
+    orc = oracle_py.Oracle.load(index_prefix(name))
+    blocks, mrank = host.layout()
+    n = host.n
+    assert blocks.shape == (((n + 127) >> 7) + 1, 16)
+    rng = random.Random(1)
+    pos = list(range(min(n + 1, 300))) + [rng.randrange(0, n + 1) for _ in range(1500)] + [n, n - 1, max(0, n - 127)]
+    dollar = host.view.dollar_position
+    for i in pos:
+        for c in range(4):
+            want = orc.rank(i, c)
+            if i < n:
+                assert emulate_rank(blocks, None, dollar, i, c, upper=False) == want
+            if i > 0:
+                assert emulate_rank(blocks, None, dollar, i, c, upper=True) == want
+    mask = orc.mask_bits()
+    pref = np.concatenate([[0], np.cumsum(mask)])
+    for b in range(blocks.shape[0]):
+        assert mrank[b] == pref[min(n, b * 128)]
+    got_mask = np.unpackbits(blocks[:, 12:16].copy().view(np.uint8).reshape(-1), bitorder="little")[:n]
+    assert np.array_equal(got_mask, mask)
+
+
+def test_layout_sizes_around_block_boundaries(product_built, oracle_built, tmp_path):
+    """n = 127, 128, 129, 255, 256, 257 ... rows: last-block padding, n % 64 == 0, n % 128 == 0."""
+    for length in (126, 127, 128, 191, 254, 255, 256, 383, 511, 512):
+        k = 5
+        ms = synthetic_ms(length, k, seed=length, mask="mixed")
+        orc = oracle_py.Oracle.construct(ms, k)
+        prefix = str(tmp_path / f"n{length}")
+        orc.dump(prefix)
+        host = product_built.HostIndex(prefix)
+        blocks, _ = host.layout()
+        n = host.n
+        assert n == length + 1
+        for i in range(n + 1):
+            for c in range(4):
+                want = orc.rank(i, c)
+                if i < n:
+                    assert emulate_rank(blocks, None, host.view.dollar_position, i, c, False) == want
+                if i > 0:
+                    assert emulate_rank(blocks, None, host.view.dollar_position, i, c, True) == want
+
+
+def test_pack(product_built):
+    k = 31
+    s = "ACGTTGCAAACCGGTTACGTACGTAGCTAGC"
+    w = product_built.pack_kmers([s, s.lower()], k)
+    assert w[0] == w[1]
+    codes = {"A": 0, "C": 1, "G": 2, "T": 3}
+    assert int(w[0]) == sum(codes[ch] << (2 * t) for t, ch in enumerate(s))
+    seq = ("ACGT" * 40).encode()
+    words = product_built.pack_sequence(seq)
+    assert int(words[0]) & 0xFF == 0b11100100
+    with pytest.raises(ValueError):
+        product_built.pack_sequence(b"ACGNACGT")
+
+
+def test_product_fails_loudly_without_gpu(product_built):
+    """No CPU fallback: on a box without a HIP device index creation must fail with ENODEV."""
+    if product_built.device_count() > 0:
+        pytest.skip("a GPU is present")
+    host = product_built.HostIndex(index_prefix("sars_k31"))
+    with pytest.raises(product_built.FmsiError) as e:
+        product_built.DeviceIndex(host.view)
+    assert e.value.code == product_built.E_NODEV
+    rc, out, err = product_built.run_cli(["query", "-q", str(GOLDEN / "rand_sars_k31.fa"), index_prefix("sars_k31")])
+    assert rc == 1 and out == b"" and b"cannot create the device index" in err
+
+
+def test_cli_option_handling(product_built):
+    """Exit codes and messages of ms_query's validation (reference src/main.cpp:288-320)."""
+    run = product_built.run_cli
+    rc, out, err = run(["query", "-h"])
+    assert rc == 0 and b"Usage:   fmsi query [options] <index-prefix>" in err
+    rc, out, err = run(["lookup", "-h"])
+    assert rc == 0 and b"Usage:   fmsi lookup" in err
+    rc, out, err = run(["query"])
+    assert rc == 1 and b"required argument" in err
+    rc, out, err = run(["query", "-k", "5", index_prefix("sars_k31")])
+    assert rc == 1 and b"Mismatch. Provided k (5) does not match the k of the index (31)" in err
+    rc, out, err = run(["query", str(GOLDEN / "idx" / "nope")])
+    assert rc == 1 and b"index not correctly loaded" in err
+    rc, out, err = run(["query", "-f", "xor", index_prefix("sars_k31")])
+    assert rc == 1 and b"not available on the GPU path" in err
+    rc, out, err = run(["-v"])
+    assert rc == 0 and out.strip()
+    rc, out, err = run(["index", "x"])
+    assert rc == 1 and b"not part of the MI355X query path" in err
+    rc, out, err = run([])
+    assert rc == 1
