@@ -92,6 +92,13 @@ def lib() -> C.CDLL:
     L.fmsi_hip_index_destroy.argtypes = [vp]
     L.fmsi_hip_index_destroy.restype = None
     L.fmsi_hip_index_get_info.argtypes = [vp, C.POINTER(IndexInfo)]
+    L.fmsi_hip_index_download_layout.argtypes = [vp, vp, vp]
+    L.fmsi_hip_index_build.argtypes = [C.c_char_p, u64, i32, i32, i32, i32, C.POINTER(vp)]
+    L.fmsi_hip_index_build_synthetic.argtypes = [u64, u64, i32, i32, i32, i32, C.POINTER(vp)]
+    L.fmsi_hip_synthetic_text_word.argtypes = [u64, u64]
+    L.fmsi_hip_synthetic_text_word.restype = u64
+    L.fmsi_hip_synthetic_queries.argtypes = [vp, i32, u64, u64, u64, vp, vp]
+    L.fmsi_hip_index_download_text.argtypes = [vp, vp]
     L.fmsi_hip_query_kmers.argtypes = [vp, vp, u64, i32, u32, vp, vp, vp]
     L.fmsi_hip_query_windows.argtypes = [vp, vp, u64, vp, u64, i32, u32, vp, vp, vp]
     L.fmsi_hip_query_stream.argtypes = [vp, vp, u64, vp, vp, u64, u64, i32, u32, vp, vp, vp]
@@ -222,12 +229,44 @@ def view_from_arrays(ac_gt, ac, gt, mask, counts, dollar_position, k, klcp=None,
 class DeviceIndex:
     """Device-resident index (fmsi_hip_index).  Raises FmsiError(E_NODEV) when no GPU is usable."""
 
-    def __init__(self, view: IndexView, device: int = 0, keepalive=None):
+    def __init__(self, view: IndexView | None, device: int = 0, keepalive=None, _handle=None):
         self._h = C.c_void_p()
         self._keep = keepalive
-        _check(lib().fmsi_hip_index_create(C.byref(view), device, C.byref(self._h)))
+        if _handle is not None:
+            self._h = _handle
+        else:
+            _check(lib().fmsi_hip_index_create(C.byref(view), device, C.byref(self._h)))
         self.info = IndexInfo()
         _check(lib().fmsi_hip_index_get_info(self._h, C.byref(self.info)))
+
+    @classmethod
+    def build(cls, ms: bytes, k: int, with_klcp: bool = False, device: int = 0, prefix_len: int = 0):
+        """On-device construction from a masked superstring (upper case = ON)."""
+        h = C.c_void_p()
+        _check(lib().fmsi_hip_index_build(ms, len(ms), k, int(with_klcp), device, prefix_len, C.byref(h)))
+        return cls(None, device, _handle=h)
+
+    @classmethod
+    def build_synthetic(cls, length: int, seed: int, k: int, with_klcp: bool = False, device: int = 0, prefix_len: int = 0):
+        """Synthetic max-ones superstring generated and indexed in HBM (see include/fmsi_hip.h)."""
+        h = C.c_void_p()
+        _check(lib().fmsi_hip_index_build_synthetic(length, seed, k, int(with_klcp), device, prefix_len, C.byref(h)))
+        return cls(None, device, _handle=h)
+
+    def download_layout(self):
+        nb = int(self.info.n_blocks)
+        blocks = np.zeros((nb, 16), dtype=np.uint32)
+        mrank = np.zeros(nb + 1, dtype=np.uint32)
+        _check(lib().fmsi_hip_index_download_layout(self._h, blocks.ctypes.data, mrank.ctypes.data))
+        return blocks, mrank
+
+    def download_text(self, length: int) -> np.ndarray:
+        words = np.zeros(length // 32 + 2, dtype=np.uint64)
+        _check(lib().fmsi_hip_index_download_text(self._h, words.ctypes.data))
+        return words
+
+    def synthetic_queries_dev(self, k: int, seed: int, first: int, n: int, kmers_ptr: int, stream: int = 0):
+        _check(lib().fmsi_hip_synthetic_queries(self._h, k, seed, first, n, kmers_ptr, stream or None))
 
     @classmethod
     def from_files(cls, prefix: str, use_klcp: bool = False, device: int = 0, prefix_len: int = 0):
@@ -299,6 +338,40 @@ class DeviceIndex:
             self.close()
         except Exception:
             pass
+
+
+_M64 = (1 << 64) - 1
+
+
+def _splitmix64(x: np.ndarray) -> np.ndarray:
+    x = (x + np.uint64(0x9E3779B97F4A7C15))
+    x = (x ^ (x >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+    x = (x ^ (x >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+    return x ^ (x >> np.uint64(31))
+
+
+def synthetic_text_words(length: int, seed: int) -> np.ndarray:
+    """Host (numpy) restatement of the builder's synthetic superstring: 2-bit words, zero past `length`."""
+    nw = length // 32 + 2
+    with np.errstate(over="ignore"):
+        w = np.arange(nw, dtype=np.uint64)
+        words = _splitmix64(np.uint64(seed) ^ (w * np.uint64(0xD1B54A32D192ED03)))
+    first = np.arange(nw, dtype=np.int64) * 32
+    words[first >= length] = 0
+    part = np.nonzero((first < length) & (first + 32 > length))[0]
+    for i in part:
+        words[i] &= np.uint64((1 << (2 * (length - int(first[i])))) - 1)
+    return words
+
+
+def synthetic_text(length: int, seed: int, k: int) -> bytes:
+    """The synthetic masked superstring as text (positions 0..length-k upper case)."""
+    words = synthetic_text_words(length, seed)
+    codes = ((words[:, None] >> (2 * np.arange(32, dtype=np.uint64))) & np.uint64(3)).reshape(-1)[:length].astype(np.uint8)
+    up = np.frombuffer(b"ACGT", dtype=np.uint8)[codes]
+    lo = np.frombuffer(b"acgt", dtype=np.uint8)[codes]
+    out = np.where(np.arange(length) + k <= length, up, lo)
+    return out.tobytes()
 
 
 def decode_strict(out: np.ndarray):

@@ -1,0 +1,107 @@
+// Device-side FM primitives over the interleaved block layout (common.h).  Included by the query
+// kernels and by the prefix-table builder.  Citations are relative to the reference root.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "index_priv.h"
+
+namespace fmsi {
+
+// Keeps a value opaque to the optimiser.  Without it hipcc folds a chain of selects over the four
+// components of a uint4 into a dynamically indexed vector, which it then spills to scratch
+// (cdna_hip_programming.md rule 20).
+__device__ __forceinline__ uint32_t opaque(uint32_t x) {
+    asm volatile("" : "+v"(x));
+    return x;
+}
+
+__device__ __forceinline__ uint32_t sel4(uint32_t c, uint32_t a0, uint32_t a1, uint32_t a2, uint32_t a3) {
+    const uint32_t lo = (c & 1u) ? a1 : a0;
+    const uint32_t hi = (c & 1u) ? a3 : a2;
+    return (c & 2u) ? hi : lo;
+}
+
+// ones in bit positions [0, s) of a 32-bit word, s may be <= 0 or >= 32
+__device__ __forceinline__ uint32_t prefix32(int s) {
+    return s >= 32 ? 0xFFFFFFFFu : (s <= 0 ? 0u : ((1u << s) - 1u));
+}
+
+// occurrences of symbol c among the first p rows (p in [0,128]) of a block, plus the block's base count:
+// rank() of src/fms_index.h:68-86 (two dependent rank_support_v5 probes there) on one 64-byte block.
+__device__ __forceinline__ uint32_t rank_in_block(const uint4 cnt, const uint4 h, const uint4 l, uint32_t c, uint32_t p) {
+    const uint32_t xh = (c & 2u) ? 0u : 0xFFFFFFFFu;
+    const uint32_t xl = (c & 1u) ? 0u : 0xFFFFFFFFu;
+    uint32_t r = sel4(c, opaque(cnt.x), opaque(cnt.y), opaque(cnt.z), opaque(cnt.w));
+    const int s = static_cast<int>(p);
+    r += __popc((h.x ^ xh) & (l.x ^ xl) & prefix32(s));
+    r += __popc((h.y ^ xh) & (l.y ^ xl) & prefix32(s - 32));
+    r += __popc((h.z ^ xh) & (l.z ^ xl) & prefix32(s - 64));
+    r += __popc((h.w ^ xh) & (l.w ^ xl) & prefix32(s - 96));
+    return r;
+}
+
+__device__ __forceinline__ uint32_t popc_prefix128(const uint4 m, uint32_t p) {
+    const int s = static_cast<int>(p);
+    return __popc(m.x & prefix32(s)) + __popc(m.y & prefix32(s - 32)) + __popc(m.z & prefix32(s - 64)) +
+           __popc(m.w & prefix32(s - 96));
+}
+
+// One LF step on a non-empty [i, j): update_range, src/fms_index.h:98-103.
+// The upper boundary is ranked through the block of row j-1 (offset 1..128), so a single-row interval
+// touches ONE block; both fetches are issued unconditionally (same cache line when bj == bi).
+__device__ __forceinline__ void lf_step(const DevIndex& ix, uint32_t c, uint32_t& i, uint32_t& j, uint32_t& blocks_read) {
+    const uint32_t bi = i >> kBlockRowsLog2;
+    const uint32_t bj = (j - 1u) >> kBlockRowsLog2;
+    const uint4* pi = ix.blocks + (static_cast<size_t>(bi) << 2);
+    const uint4* pj = ix.blocks + (static_cast<size_t>(bj) << 2);
+    const uint4 ci = pi[0], hi = pi[1], li = pi[2];
+    const uint4 cj = pj[0], hj = pj[1], lj = pj[2];
+    blocks_read += 1u + (bj != bi);
+    uint32_t ri = rank_in_block(ci, hi, li, c, i & (kBlockRows - 1u));
+    uint32_t rj = rank_in_block(cj, hj, lj, c, j - (bj << kBlockRowsLog2));
+    if (c == 0u) {   // the '$' slot is stored as an 'A' and subtracted here (src/fms_index.h:81)
+        ri -= (i > ix.dollar);
+        rj -= (j > ix.dollar);
+    }
+    const uint32_t base = sel4(c, ix.C0, ix.C1, ix.C2, ix.C3);
+    i = base + ri;
+    j = base + rj;
+}
+
+// rank1 on the SA-transformed mask through block b with in-block offset p (0..128)
+__device__ __forceinline__ uint32_t mask_rank(const DevIndex& ix, uint32_t b, uint32_t p) {
+    const uint4 m = ix.blocks[(static_cast<size_t>(b) << 2) + 3];
+    return ix.mrank[b] + popc_prefix128(m, p);
+}
+
+__device__ __forceinline__ uint32_t mask_bit(const DevIndex& ix, uint32_t row) {
+    const uint32_t* w = reinterpret_cast<const uint32_t*>(ix.blocks) + (static_cast<size_t>(row >> kBlockRowsLog2) << 4) + 12u;
+    return (w[(row & (kBlockRows - 1u)) >> 5] >> (row & 31u)) & 1u;
+}
+
+// reverse complement of a 2-bit packed k-mer (base t in bits [2t,2t+1]); ReverseComplementString, src/kmers.h:53-59
+__device__ __forceinline__ uint64_t revcomp_2bit(uint64_t f, int k) {
+    uint64_t x = ~f;                                                               // complement: 3 - c
+    x = __brevll(x);                                                               // reverse all bits ...
+    x = ((x & 0xAAAAAAAAAAAAAAAAull) >> 1) | ((x & 0x5555555555555555ull) << 1);   // ... restoring the order inside each pair
+    x >>= (64 - 2 * k);
+    return k == 32 ? x : (x & ((1ull << (2 * k)) - 1ull));
+}
+
+__device__ __forceinline__ uint64_t window_kmer(const uint64_t* __restrict__ seq, uint64_t start, int k) {
+    const uint64_t w = start >> 5;
+    const uint32_t sh = static_cast<uint32_t>(start & 31u) * 2u;
+    uint64_t f = seq[w] >> sh;
+    if (sh) f |= seq[w + 1] << (64u - sh);
+    return k == 32 ? f : (f & ((1ull << (2 * k)) - 1ull));
+}
+
+// lanes below this one in a 64-bit ballot mask
+__device__ __forceinline__ uint32_t lanes_below(uint64_t mask) {
+    return __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(mask >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(mask), 0u));
+}
+
+}  // namespace fmsi

@@ -17,110 +17,33 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
-#include <thread>
 #include <vector>
 
 #include "../../include/fmsi_hip.h"
 #include "common.h"
+#include "device_fm.h"
+#include "index_priv.h"
 #include "layout.h"
 
 namespace fmsi {
 
-// ------------------------------------------------------------------------------------------------
-// device-visible index descriptor (passed by value as a kernel argument -> SGPRs)
-// ------------------------------------------------------------------------------------------------
-struct DevIndex {
-    const uint4* blocks;      // n_blocks x 64 B, layout in common.h
-    const uint32_t* mrank;    // n_blocks + 1 cumulative mask popcounts (OR-mode interval test, ORDERS)
-    uint32_t n;               // BWT rows
-    uint32_t dollar;          // dollar_position
-    uint32_t C0, C1, C2, C3;  // counts[] (src/fms_index.h:451)
-};
-
-// ones in bit positions [0, s) of a 32-bit word, s may be <= 0 or >= 32
-__device__ __forceinline__ uint32_t prefix32(int s) {
-    return s >= 32 ? 0xFFFFFFFFu : (s <= 0 ? 0u : ((1u << s) - 1u));
-}
-
-// Keeps a value opaque to the optimiser.  Without it hipcc folds a chain of selects over the four
-// components of a uint4 into a dynamically indexed vector, which it then spills to scratch
-// (cdna_hip_programming.md rule 20).
-__device__ __forceinline__ uint32_t opaque(uint32_t x) {
-    asm volatile("" : "+v"(x));
-    return x;
-}
-
-__device__ __forceinline__ uint32_t sel4(uint32_t c, uint32_t a0, uint32_t a1, uint32_t a2, uint32_t a3) {
-    const uint32_t lo = (c & 1u) ? a1 : a0;
-    const uint32_t hi = (c & 1u) ? a3 : a2;
-    return (c & 2u) ? hi : lo;
-}
-
-// occurrences of symbol c among the first p rows (p in [0,128]) of the block, plus the block's base count
-__device__ __forceinline__ uint32_t rank_in_block(const uint4 cnt, const uint4 h, const uint4 l, uint32_t c, uint32_t p) {
-    const uint32_t xh = (c & 2u) ? 0u : 0xFFFFFFFFu;
-    const uint32_t xl = (c & 1u) ? 0u : 0xFFFFFFFFu;
-    uint32_t r = sel4(c, opaque(cnt.x), opaque(cnt.y), opaque(cnt.z), opaque(cnt.w));
-    const int s = static_cast<int>(p);
-    r += __popc((h.x ^ xh) & (l.x ^ xl) & prefix32(s));
-    r += __popc((h.y ^ xh) & (l.y ^ xl) & prefix32(s - 32));
-    r += __popc((h.z ^ xh) & (l.z ^ xl) & prefix32(s - 64));
-    r += __popc((h.w ^ xh) & (l.w ^ xl) & prefix32(s - 96));
-    return r;
-}
-
-// One LF step on [i, j), i < j (update_range, src/fms_index.h:98-103 with rank() of :68-86).
-// The upper boundary is ranked through the block of row j-1 (offset 1..128) so that a single-row
-// interval needs ONE block.
-__device__ __forceinline__ void lf_step(const DevIndex& ix, uint32_t c, uint32_t& i, uint32_t& j, uint32_t& blocks_read) {
-    const uint32_t bi = i >> kBlockRowsLog2;
-    const uint32_t bj = (j - 1u) >> kBlockRowsLog2;
-    const uint4* pi = ix.blocks + (static_cast<size_t>(bi) << 2);
-    const uint4* pj = ix.blocks + (static_cast<size_t>(bj) << 2);
-    // both boundaries are fetched unconditionally: when bj == bi the second fetch is the same cache line
-    const uint4 ci = pi[0], hi = pi[1], li = pi[2];
-    const uint4 cj = pj[0], hj = pj[1], lj = pj[2];
-    blocks_read += 1u + (bj != bi);
-    uint32_t ri = rank_in_block(ci, hi, li, c, i & (kBlockRows - 1u));
-    uint32_t rj = rank_in_block(cj, hj, lj, c, j - (bj << kBlockRowsLog2));
-    if (c == 0u) {   // the '$' slot is stored as an 'A' and subtracted here (src/fms_index.h:81)
-        ri -= (i > ix.dollar);
-        rj -= (j > ix.dollar);
-    }
-    const uint32_t base = sel4(c, ix.C0, ix.C1, ix.C2, ix.C3);
-    i = base + ri;
-    j = base + rj;
-}
-
-// rank1 on the SA-transformed mask for a lower boundary (row x, offset 0..127) or an upper boundary
-// (through row x-1, offset 1..128)
-__device__ __forceinline__ uint32_t mask_rank(const DevIndex& ix, uint32_t b, uint32_t p) {
-    const uint4 m = ix.blocks[(static_cast<size_t>(b) << 2) + 3];
-    const int s = static_cast<int>(p);
-    return ix.mrank[b] + __popc(m.x & prefix32(s)) + __popc(m.y & prefix32(s - 32)) + __popc(m.z & prefix32(s - 64)) +
-           __popc(m.w & prefix32(s - 96));
-}
-
-__device__ __forceinline__ uint32_t mask_bit(const DevIndex& ix, uint32_t row) {
-    const uint32_t* w = reinterpret_cast<const uint32_t*>(ix.blocks) + (static_cast<size_t>(row >> kBlockRowsLog2) << 4) + 12u;
-    return (w[(row & (kBlockRows - 1u)) >> 5] >> (row & 31u)) & 1u;
-}
-
-// reverse complement of a 2-bit packed k-mer (base t in bits [2t,2t+1]); ReverseComplementString of src/kmers.h:53-59
-__device__ __forceinline__ uint64_t revcomp_2bit(uint64_t f, int k) {
-    uint64_t x = ~f;                                    // complement: 3 - c
-    x = __brevll(x);                                    // reverse all bits ...
-    x = ((x & 0xAAAAAAAAAAAAAAAAull) >> 1) | ((x & 0x5555555555555555ull) << 1);   // ... and restore the order inside each pair
-    x >>= (64 - 2 * k);
-    return k == 32 ? x : (x & ((1ull << (2 * k)) - 1ull));
-}
-
 struct LaneCounters {
-    uint32_t lf_steps = 0, blocks = 0, probes = 0, searches = 0;
+    uint32_t lf_steps = 0, blocks = 0, probes = 0, searches = 0, lookups = 0;
 };
 
-// get_range_with_pattern + infer_presence for one strand.  Returns the ternary result (-1 empty, 0, 1);
-// `order` receives kmer_order_if_present when ORDERS.
+__device__ __forceinline__ void flush_counters(const LaneCounters& cn, unsigned long long* counters, uint32_t windows_done) {
+    // wave reduction, then one atomic per wave and counter
+    uint32_t v[6] = {cn.lf_steps, cn.blocks, cn.probes, cn.searches, cn.lookups, windows_done};
+    const int slot[6] = {0, 1, 2, 3, 4, 6};
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+        uint32_t x = v[q];
+        for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+        if ((threadIdx.x & 63) == 0 && x) atomicAdd(&counters[slot[q]], static_cast<unsigned long long>(x));
+    }
+}
+
+// get_range_with_pattern + infer_presence for one strand, plain SIMT form (lockstep kernel).
 __device__ __forceinline__ int search_strand(const DevIndex& ix, uint64_t cur, int k, uint32_t mode_all, uint32_t want_orders,
                                              long long& order, LaneCounters& cn) {
     uint32_t i = 0, j = ix.n;
@@ -143,34 +66,37 @@ __device__ __forceinline__ int search_strand(const DevIndex& ix, uint64_t cur, i
     return any;
 }
 
-__device__ __forceinline__ uint64_t window_kmer(const uint64_t* __restrict__ seq, uint64_t start, int k) {
-    const uint64_t w = start >> 5;
-    const uint32_t sh = static_cast<uint32_t>(start & 31u) * 2u;
-    uint64_t f = seq[w] >> sh;
-    if (sh) f |= seq[w + 1] << (64u - sh);
-    return k == 32 ? f : (f & ((1ull << (2 * k)) - 1ull));
+// second strand needed?  src/fms_index.h:283-299 (first strand = forward, i.e. no predictor swap)
+__device__ __forceinline__ bool need_second(uint32_t strict, uint32_t orders, uint32_t mode_all, int res, long long ord) {
+    if (strict) return true;
+    if (orders) return ord < 0;
+    if (mode_all) return res == -1;
+    return res != 1;
 }
 
-__device__ __forceinline__ void flush_counters(const LaneCounters& cn, unsigned long long* counters, bool valid) {
-    // wave reduction then one atomic per wave and counter
-    uint32_t v[4] = {cn.lf_steps, cn.blocks, cn.probes, cn.searches};
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        uint32_t x = v[q];
-        for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
-        if ((threadIdx.x & 63) == 0 && x) atomicAdd(&counters[q], static_cast<unsigned long long>(x));
+__device__ __forceinline__ void write_result(uint64_t q, uint32_t strict, uint32_t orders, bool second, int res_f, int res_r,
+                                             long long ord_f, long long ord_r, uint8_t* __restrict__ out,
+                                             long long* __restrict__ out_orders) {
+    if (orders) {
+        if (strict) {
+            out_orders[2 * q] = ord_f;
+            out_orders[2 * q + 1] = ord_r;
+        } else {
+            out_orders[q] = second ? ord_r : ord_f;
+        }
+    } else if (strict) {
+        out[q] = static_cast<uint8_t>((res_f + 1) | ((res_r + 1) << 2));
+    } else {
+        out[q] = static_cast<uint8_t>((second ? res_r : res_f) == 1);
     }
-    unsigned long long w = __popcll(__ballot(valid));
-    if ((threadIdx.x & 63) == 0 && w) atomicAdd(&counters[6], w);
 }
 
 // ------------------------------------------------------------------------------------------------
-// Kernel 1 ("lockstep"): one lane per window; the wave walks the k LF steps in lock-step and leaves the
-// loop when its last lane is done.  INPUT 0: packed k-mers, 1: windows of a packed sequence.
+// Kernel 1 ("lockstep"): one lane per k-mer; the wave walks the k LF steps in lock-step and leaves the
+// loop when its last lane is done.  Kept as the simple baseline for A/B runs.
 // ------------------------------------------------------------------------------------------------
-template <bool COUNT, int INPUT>
-__global__ __launch_bounds__(256) void query_lockstep_kernel(DevIndex ix, const uint64_t* __restrict__ in,
-                                                             const uint64_t* __restrict__ window_start, uint64_t n_windows,
+template <bool COUNT>
+__global__ __launch_bounds__(256) void query_lockstep_kernel(DevIndex ix, const uint64_t* __restrict__ kmers, uint64_t n_windows,
                                                              int k, uint32_t flags, uint8_t* __restrict__ out,
                                                              long long* __restrict__ out_orders,
                                                              unsigned long long* __restrict__ counters) {
@@ -181,73 +107,247 @@ __global__ __launch_bounds__(256) void query_lockstep_kernel(DevIndex ix, const 
     const uint32_t orders = flags & FMSI_HIP_ORDERS;
     LaneCounters cn;
     if (valid) {
-        uint64_t f;
-        if (INPUT == 0) f = in[q];
-        else f = window_kmer(in, window_start ? window_start[q] : q, k);
+        const uint64_t f = kmers[q];
         long long ord_f = -1, ord_r = -1;
-        int res_f = search_strand(ix, f, k, mode_all, orders, ord_f, cn);
+        const int res_f = search_strand(ix, f, k, mode_all, orders, ord_f, cn);
         int res_r = -1;
-        bool second;
-        if (strict) second = true;
-        else if (orders) second = ord_f < 0;          // src/fms_index.h:283-288
-        else if (mode_all) second = res_f == -1;      // src/fms_index.h:295-298
-        else second = res_f != 1;                     // src/fms_index.h:290-293
+        const bool second = need_second(strict, orders, mode_all, res_f, ord_f);
         if (second) res_r = search_strand(ix, revcomp_2bit(f, k), k, mode_all, orders, ord_r, cn);
-        if (orders) {
-            if (strict) {
-                out_orders[2 * q] = ord_f;
-                out_orders[2 * q + 1] = ord_r;
-            } else {
-                out_orders[q] = second ? ord_r : ord_f;
-            }
-        } else if (strict) {
-            out[q] = static_cast<uint8_t>((res_f + 1) | ((res_r + 1) << 2));
-        } else {
-            out[q] = static_cast<uint8_t>((second ? res_r : res_f) == 1);
-        }
+        write_result(q, strict, orders, second, res_f, res_r, ord_f, ord_r, out, out_orders);
     }
-    if (COUNT) flush_counters(cn, counters, valid);
+    if (COUNT) flush_counters(cn, counters, valid ? 1u : 0u);
 }
 
 // ------------------------------------------------------------------------------------------------
-// host side: handle, layout builder, C-ABI
+// Kernel 2 ("refill"): persistent lanes.  A wave owns a contiguous chunk of k-mers; every lane runs a
+// small state machine in which EVERY iteration issues exactly one round of independent memory reads
+// (prefix-table line, or the interleaved block(s) of its interval, whose mask plane also serves the final
+// probe).  A lane that finishes takes its prefetched next k-mer immediately; new k-mers are handed out
+// with wavefront ballot + mbcnt prefix ranks from a wave-uniform cursor -- no atomics, no LDS.  So no
+// lane idles while a neighbour still walks, and the k-mer fetch latency hides under the block reads.
 // ------------------------------------------------------------------------------------------------
-#define HIP_TRY(expr)                                                                                      \
-    do {                                                                                                   \
-        hipError_t e_ = (expr);                                                                            \
-        if (e_ != hipSuccess) {                                                                            \
-            set_last_error(std::string(#expr) + ": " + hipGetErrorString(e_));                            \
-            return FMSI_HIP_EHIP;                                                                          \
-        }                                                                                                  \
-    } while (0)
+enum : uint32_t { ST_IDLE = 0, ST_LOOKUP = 1, ST_LF = 2, ST_PROBE = 3 };
+
+template <bool COUNT, bool PTABLE>
+__global__ __launch_bounds__(256) void query_refill_kernel(DevIndex ix, const uint64_t* __restrict__ kmers, uint64_t n_windows,
+                                                           int k, uint32_t flags, uint32_t chunk, uint8_t* __restrict__ out,
+                                                           long long* __restrict__ out_orders,
+                                                           unsigned long long* __restrict__ counters) {
+    const uint32_t mode_all = flags & FMSI_HIP_MODE_ALL;
+    const uint32_t strict = flags & FMSI_HIP_STRICT;
+    const uint32_t orders = flags & FMSI_HIP_ORDERS;
+    const uint64_t wave = (static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
+    uint64_t next = wave * chunk;                                   // wave-uniform cursor
+    const uint64_t end = min(n_windows, next + static_cast<uint64_t>(chunk));
+    const int T = PTABLE ? static_cast<int>(ix.ptable_len) : 0;
+
+    uint64_t f = 0, cur = 0, f_next = 0, q = 0, q_next = 0;
+    uint32_t i = 0, j = 0, st = ST_IDLE, phase = 0, done = 0;
+    int t = 0, res_f = -1;
+    long long ord_f = -1;
+    bool has_next = false;
+    LaneCounters cn;
+
+    auto start_strand = [&](uint64_t kmer) {
+        cur = kmer;
+        if (COUNT) cn.searches++;
+        if (PTABLE) {
+            st = ST_LOOKUP;
+        } else {
+            i = 0;
+            j = ix.n;
+            t = k - 1;
+            st = ST_LF;
+        }
+    };
+    // result of the strand just searched: src/fms_index.h:263-331 with the forward strand first
+    auto finalize = [&](int res, long long ord) {
+        if (phase == 0) {
+            if (need_second(strict, orders, mode_all, res, ord)) {
+                res_f = res;
+                ord_f = ord;
+                phase = 1;
+                start_strand(revcomp_2bit(f, k));
+                return;
+            }
+            write_result(q, strict, orders, false, res, -1, ord, -1, out, out_orders);
+        } else {
+            write_result(q, strict, orders, true, res_f, res, ord_f, ord, out, out_orders);
+        }
+        st = ST_IDLE;
+        done++;
+    };
+
+    for (;;) {
+        // (1) idle lanes start their prefetched k-mer
+        if (st == ST_IDLE && has_next) {
+            f = f_next;
+            q = q_next;
+            has_next = false;
+            phase = 0;
+            start_strand(f);
+        }
+        // (2) lanes without a prefetched k-mer draw the next indices of the wave's chunk: ballot + mbcnt prefix
+        {
+            const bool want = !has_next;
+            const uint64_t m = __ballot(want);
+            if (m) {
+                const uint64_t cand = next + lanes_below(m);
+                if (want && cand < end) {
+                    q_next = cand;
+                    f_next = kmers[cand];   // consumed one iteration later at the earliest: latency hides under (3)
+                    has_next = true;
+                }
+                next += static_cast<uint64_t>(__popcll(m));
+            }
+        }
+        if (!__any(st != ST_IDLE)) {
+            if (!__any(has_next)) break;
+            continue;
+        }
+        // (3) one round of reads per active lane
+        if (st != ST_IDLE) {
+            const uint4* pi;
+            const uint4* pj;
+            uint32_t bi = 0, bj = 0, tidx = 0;
+            if (PTABLE && st == ST_LOOKUP) {
+                tidx = static_cast<uint32_t>(cur >> (2 * (k - T))) & ((1u << (2 * T)) - 1u);
+                pi = reinterpret_cast<const uint4*>(ix.ptable + (tidx & ~7u));   // the 64-B line holding the entry
+                pj = pi;
+            } else {
+                bi = i >> kBlockRowsLog2;
+                bj = (j - 1u) >> kBlockRowsLog2;
+                pi = ix.blocks + (static_cast<size_t>(bi) << 2);
+                pj = ix.blocks + (static_cast<size_t>(bj) << 2);
+            }
+            const uint4 a0 = pi[0], a1 = pi[1], a2 = pi[2], a3 = pi[3];
+            uint4 b0 = a0, b1 = a1, b2 = a2;
+            if (pj != pi) {
+                b0 = pj[0];
+                b1 = pj[1];
+                b2 = pj[2];
+            }
+            if (COUNT) cn.blocks += 1u + (pj != pi);
+            if (st == ST_LF) {
+                const uint32_t c = static_cast<uint32_t>(cur >> (2 * t)) & 3u;
+                uint32_t ri = rank_in_block(a0, a1, a2, c, i & (kBlockRows - 1u));
+                uint32_t rj = rank_in_block(b0, b1, b2, c, j - (bj << kBlockRowsLog2));
+                if (c == 0u) {
+                    ri -= (i > ix.dollar);
+                    rj -= (j > ix.dollar);
+                }
+                const uint32_t base = sel4(c, ix.C0, ix.C1, ix.C2, ix.C3);
+                i = base + ri;
+                j = base + rj;
+                --t;
+                if (COUNT) cn.lf_steps++;
+                if (i == j) finalize(-1, -1);
+                else if (t < 0) st = ST_PROBE;
+            } else if (st == ST_PROBE) {
+                if (COUNT) cn.probes++;
+                const uint32_t pi_off = i & (kBlockRows - 1u);
+                int res;
+                long long ord = -1;
+                if (mode_all && !orders) {
+                    const uint32_t w = sel4(pi_off >> 5, opaque(a3.x), opaque(a3.y), opaque(a3.z), opaque(a3.w));
+                    res = static_cast<int>((w >> (pi_off & 31u)) & 1u);
+                } else {
+                    uint32_t ones;
+                    const uint32_t pj_off = j - (bj << kBlockRowsLog2);
+                    if (bj == bi) {
+                        ones = popc_prefix128(a3, pj_off) - popc_prefix128(a3, pi_off);
+                    } else {   // interval spans blocks (long repeats): rank difference through the side array
+                        ones = mask_rank(ix, bj, pj_off) - (ix.mrank[bi] + popc_prefix128(a3, pi_off));
+                    }
+                    res = ones > 0u;
+                    if (orders && res) ord = static_cast<long long>(ix.mrank[bi] + popc_prefix128(a3, pi_off));
+                }
+                finalize(res, ord);
+            } else {   // ST_LOOKUP
+                if (COUNT) cn.lookups++;
+                const uint32_t e = (tidx & 7u) >> 1;
+                const uint32_t x0 = sel4(e, opaque(a0.x), opaque(a1.x), opaque(a2.x), opaque(a3.x));
+                const uint32_t x1 = sel4(e, opaque(a0.y), opaque(a1.y), opaque(a2.y), opaque(a3.y));
+                const uint32_t x2 = sel4(e, opaque(a0.z), opaque(a1.z), opaque(a2.z), opaque(a3.z));
+                const uint32_t x3 = sel4(e, opaque(a0.w), opaque(a1.w), opaque(a2.w), opaque(a3.w));
+                i = (tidx & 1u) ? x2 : x0;
+                j = (tidx & 1u) ? x3 : x1;
+                t = k - 1 - T;
+                if (i == j) finalize(-1, -1);
+                else st = t < 0 ? ST_PROBE : ST_LF;
+            }
+        }
+    }
+    if (COUNT) flush_counters(cn, counters, done);
+}
+
+// windows of a 2-bit packed sequence -> packed k-mers (streaming, 8 B out per window)
+__global__ __launch_bounds__(256) void extract_kmers_kernel(const uint64_t* __restrict__ seq, const uint64_t* __restrict__ window_start,
+                                                            uint64_t n_windows, int k, uint64_t* __restrict__ kmers) {
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
+    for (uint64_t q = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; q < n_windows; q += stride)
+        kmers[q] = window_kmer(seq, window_start ? window_start[q] : q, k);
+}
+
+// one level of the prefix table: entry idx of level L = LF step with base (idx & 3) on entry idx >> 2 of level L-1
+__global__ __launch_bounds__(256) void ptable_level_kernel(DevIndex ix, const uint2* __restrict__ prev, uint2* __restrict__ cur,
+                                                           uint64_t count) {
+    const uint64_t idx = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (idx >= count) return;
+    uint2 e = prev ? prev[idx >> 2] : make_uint2(0u, ix.n);
+    if (e.x != e.y) {
+        uint32_t dummy = 0;
+        lf_step(ix, static_cast<uint32_t>(idx & 3u), e.x, e.y, dummy);
+    }
+    cur[idx] = e;
+}
+
+int build_prefix_table(fmsi_hip_index* idx, int t) {
+    if (t <= 0) return 0;
+    if (t > 15) {
+        set_last_error("prefix_len must be <= 15");
+        return FMSI_HIP_EINVAL;
+    }
+    const uint64_t final_count = 1ull << (2 * t);
+    uint2 *a = nullptr, *b = nullptr;
+    // +64 B so that reading the whole line of the last entry stays inside the allocation
+    FMSI_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&a), final_count * sizeof(uint2) + 64));
+    if (t > 1) {
+        if (hipMalloc(reinterpret_cast<void**>(&b), (final_count / 4) * sizeof(uint2) + 64) != hipSuccess) {
+            (void)hipFree(a);
+            set_last_error("hipMalloc failed for the prefix table");
+            return FMSI_HIP_ENOMEM;
+        }
+    }
+    // levels alternate between the two buffers so that the last level lands in `a`
+    uint2* bufs[2] = {a, b};
+    int cur = (t % 2 == 1) ? 0 : 1;
+    const uint2* prev = nullptr;
+    for (int level = 1; level <= t; ++level) {
+        const uint64_t count = 1ull << (2 * level);
+        const uint32_t blocks = static_cast<uint32_t>((count + 255) / 256);
+        hipLaunchKernelGGL(ptable_level_kernel, dim3(blocks), dim3(256), 0, 0, idx->dev, prev, bufs[cur], count);
+        prev = bufs[cur];
+        cur ^= 1;
+    }
+    hipError_t e = hipDeviceSynchronize();
+    if (b) (void)hipFree(b);
+    if (e != hipSuccess) {
+        (void)hipFree(a);
+        set_last_error(std::string("prefix table build: ") + hipGetErrorString(e));
+        return FMSI_HIP_EHIP;
+    }
+    idx->d_ptable = a;
+    idx->dev.ptable = a;
+    idx->dev.ptable_len = static_cast<uint32_t>(t);
+    idx->prefix_len = t;
+    idx->device_bytes += final_count * sizeof(uint2) + 64;
+    return 0;
+}
 
 }  // namespace fmsi
 
 using namespace fmsi;
-
-struct fmsi_hip_index {
-    int device = 0;
-    DevIndex dev{};
-    uint64_t n = 0;
-    int k = 0;
-    int has_klcp = 0;
-    int prefix_len = 0;
-    uint64_t n_blocks = 0;
-    uint64_t device_bytes = 0;
-    void* d_blocks = nullptr;
-    void* d_mrank = nullptr;
-    // staging for host-pointer calls
-    void* d_in = nullptr; size_t d_in_cap = 0;
-    void* d_aux = nullptr; size_t d_aux_cap = 0;
-    void* d_out = nullptr; size_t d_out_cap = 0;
-    unsigned long long* d_counters = nullptr;
-    // profiling
-    bool profiling = false;
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
-    size_t events_used = 0;
-    double prof_ms = 0;
-    uint64_t prof_launches = 0;
-};
 
 namespace {
 
@@ -257,7 +357,7 @@ int ensure_cap(void** p, size_t* cap, size_t need) {
     *p = nullptr;
     *cap = 0;
     size_t want = std::max<size_t>(need, 1 << 20);
-    HIP_TRY(hipMalloc(p, want));
+    FMSI_HIP_TRY(hipMalloc(p, want));
     *cap = want;
     return 0;
 }
@@ -267,43 +367,65 @@ int prof_begin(fmsi_hip_index* idx, hipStream_t s, size_t* slot) {
     if (!idx->profiling) return 0;
     if (idx->events_used == idx->events.size()) {
         hipEvent_t a, b;
-        HIP_TRY(hipEventCreate(&a));
-        HIP_TRY(hipEventCreate(&b));
+        FMSI_HIP_TRY(hipEventCreate(&a));
+        FMSI_HIP_TRY(hipEventCreate(&b));
         idx->events.emplace_back(a, b);
     }
     *slot = idx->events_used++;
-    HIP_TRY(hipEventRecord(idx->events[*slot].first, s));
+    FMSI_HIP_TRY(hipEventRecord(idx->events[*slot].first, s));
     return 0;
 }
 int prof_end(fmsi_hip_index* idx, hipStream_t s, size_t slot) {
     if (slot == static_cast<size_t>(-1)) return 0;
-    HIP_TRY(hipEventRecord(idx->events[slot].second, s));
+    FMSI_HIP_TRY(hipEventRecord(idx->events[slot].second, s));
     return 0;
 }
 
-template <int INPUT>
-int launch_query(fmsi_hip_index* idx, const uint64_t* d_in, const uint64_t* d_wstart, uint64_t n_windows, int k, uint32_t flags,
-                 void* d_out, unsigned long long* d_counters, hipStream_t s) {
+template <bool COUNT, bool PTABLE>
+void launch_refill(fmsi_hip_index* idx, const uint64_t* d_kmers, uint64_t n, int k, uint32_t flags, uint8_t* o8, long long* o64,
+                   unsigned long long* d_counters, hipStream_t s) {
+    // chunk per wave: enough waves to fill the chip several times over, chunks long enough to amortise the drain
+    uint64_t chunk = n / (256ull * 32 * 8);
+    chunk = std::min<uint64_t>(std::max<uint64_t>(chunk, 256), 4096);
+    const uint64_t waves = (n + chunk - 1) / chunk;
+    const uint32_t blocks = static_cast<uint32_t>((waves + 3) / 4);
+    hipLaunchKernelGGL((query_refill_kernel<COUNT, PTABLE>), dim3(blocks), dim3(256), 0, s, idx->dev, d_kmers, n, k, flags,
+                       static_cast<uint32_t>(chunk), o8, o64, d_counters);
+}
+
+int launch_query(fmsi_hip_index* idx, const uint64_t* d_kmers, uint64_t n_windows, int k, uint32_t flags, void* d_out,
+                 unsigned long long* d_counters, hipStream_t s) {
     if (n_windows == 0) return 0;
-    const uint32_t threads = 256;
-    const uint64_t blocks64 = (n_windows + threads - 1) / threads;
-    if (blocks64 > 0x7FFFFFFFull) {
+    if (n_windows > (1ull << 38)) {
         set_last_error("too many windows for one launch");
         return FMSI_HIP_ERANGE;
     }
-    const dim3 grid(static_cast<uint32_t>(blocks64)), block(threads);
     uint8_t* o8 = static_cast<uint8_t*>(d_out);
     long long* o64 = static_cast<long long*>(d_out);
+    const uint32_t kernel = flags & FMSI_HIP_KERNEL_MASK;
+    const bool use_table = idx->d_ptable && !(flags & FMSI_HIP_NO_PREFIX_TABLE) && k >= idx->prefix_len;
     size_t slot;
     int rc = prof_begin(idx, s, &slot);
     if (rc) return rc;
-    if (d_counters)
-        hipLaunchKernelGGL((query_lockstep_kernel<true, INPUT>), grid, block, 0, s, idx->dev, d_in, d_wstart, n_windows, k, flags, o8,
-                           o64, d_counters);
-    else
-        hipLaunchKernelGGL((query_lockstep_kernel<false, INPUT>), grid, block, 0, s, idx->dev, d_in, d_wstart, n_windows, k, flags, o8,
-                           o64, d_counters);
-    HIP_TRY(hipGetLastError());
+    if (kernel == FMSI_HIP_KERNEL_LOCKSTEP) {
+        const uint64_t blocks64 = (n_windows + 255) / 256;
+        if (blocks64 > 0x7FFFFFFFull) {
+            set_last_error("too many windows for one lockstep launch");
+            return FMSI_HIP_ERANGE;
+        }
+        const dim3 grid(static_cast<uint32_t>(blocks64)), block(256);
+        if (d_counters)
+            hipLaunchKernelGGL((query_lockstep_kernel<true>), grid, block, 0, s, idx->dev, d_kmers, n_windows, k, flags, o8, o64, d_counters);
+        else
+            hipLaunchKernelGGL((query_lockstep_kernel<false>), grid, block, 0, s, idx->dev, d_kmers, n_windows, k, flags, o8, o64, d_counters);
+    } else if (use_table) {
+        if (d_counters) launch_refill<true, true>(idx, d_kmers, n_windows, k, flags, o8, o64, d_counters, s);
+        else launch_refill<false, true>(idx, d_kmers, n_windows, k, flags, o8, o64, d_counters, s);
+    } else {
+        if (d_counters) launch_refill<true, false>(idx, d_kmers, n_windows, k, flags, o8, o64, d_counters, s);
+        else launch_refill<false, false>(idx, d_kmers, n_windows, k, flags, o8, o64, d_counters, s);
+    }
+    FMSI_HIP_TRY(hipGetLastError());
     return prof_end(idx, s, slot);
 }
 
@@ -312,7 +434,7 @@ size_t out_elem_bytes(uint32_t flags) {
     return 1;
 }
 
-int check_query_args(const fmsi_hip_index* idx, const void* in, const void* out, int k, uint32_t flags) {
+int check_query_args(const fmsi_hip_index* idx, const void* in, const void* out, int k) {
     if (!idx || !in || !out) {
         set_last_error("null argument");
         return FMSI_HIP_EINVAL;
@@ -321,7 +443,52 @@ int check_query_args(const fmsi_hip_index* idx, const void* in, const void* out,
         set_last_error("k must be in [1, 32] in this build");
         return FMSI_HIP_ERANGE;
     }
-    (void)flags;
+    return 0;
+}
+
+// Common path of the query entry points.  input_kind 0: `in` = packed k-mers; 1: `in` = packed sequence (+ window starts)
+int run_query(fmsi_hip_index* idx, int input_kind, const uint64_t* in, size_t in_bytes, const uint64_t* wstart, uint64_t n_windows,
+              int k, uint32_t flags, void* out, uint64_t* counters, void* stream) {
+    FMSI_HIP_TRY(hipSetDevice(idx->device));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const size_t out_bytes = n_windows * out_elem_bytes(flags);
+    const uint64_t* d_in = in;
+    const uint64_t* d_ws = wstart;
+    void* d_out = out;
+    unsigned long long* d_cnt = reinterpret_cast<unsigned long long*>(counters);
+    const bool dev_ptrs = flags & FMSI_HIP_DEVICE_PTRS;
+    int rc;
+    if (!dev_ptrs) {
+        if ((rc = ensure_cap(&idx->d_in, &idx->d_in_cap, in_bytes))) return rc;
+        if ((rc = ensure_cap(&idx->d_out, &idx->d_out_cap, out_bytes))) return rc;
+        FMSI_HIP_TRY(hipMemcpyAsync(idx->d_in, in, in_bytes, hipMemcpyHostToDevice, s));
+        d_in = static_cast<const uint64_t*>(idx->d_in);
+        if (wstart) {
+            if ((rc = ensure_cap(&idx->d_aux, &idx->d_aux_cap, n_windows * 8))) return rc;
+            FMSI_HIP_TRY(hipMemcpyAsync(idx->d_aux, wstart, n_windows * 8, hipMemcpyHostToDevice, s));
+            d_ws = static_cast<const uint64_t*>(idx->d_aux);
+        }
+        d_out = idx->d_out;
+        if (counters) {
+            FMSI_HIP_TRY(hipMemcpyAsync(idx->d_counters, counters, FMSI_HIP_N_COUNTERS * 8, hipMemcpyHostToDevice, s));
+            d_cnt = idx->d_counters;
+        }
+    }
+    const uint64_t* d_kmers = d_in;
+    if (input_kind == 1) {
+        // windows -> packed k-mers in a library-owned buffer (8 B per window, streaming)
+        if ((rc = ensure_cap(&idx->d_kmers, &idx->d_kmers_cap, n_windows * 8))) return rc;
+        const uint32_t blocks = static_cast<uint32_t>(std::min<uint64_t>((n_windows + 255) / 256, 256 * 16));
+        hipLaunchKernelGGL(extract_kmers_kernel, dim3(blocks), dim3(256), 0, s, d_in, d_ws, n_windows, k,
+                           static_cast<uint64_t*>(idx->d_kmers));
+        FMSI_HIP_TRY(hipGetLastError());
+        d_kmers = static_cast<const uint64_t*>(idx->d_kmers);
+    }
+    if ((rc = launch_query(idx, d_kmers, n_windows, k, flags, d_out, d_cnt, s))) return rc;
+    if (!dev_ptrs) {
+        if (out_bytes) FMSI_HIP_TRY(hipMemcpyAsync(out, idx->d_out, out_bytes, hipMemcpyDeviceToHost, s));
+        if (counters) FMSI_HIP_TRY(hipMemcpyAsync(counters, idx->d_counters, FMSI_HIP_N_COUNTERS * 8, hipMemcpyDeviceToHost, s));
+    }
     return 0;
 }
 
@@ -356,7 +523,7 @@ int fmsi_hip_index_create(const fmsi_index_view* view, int device, fmsi_hip_inde
         set_last_error("no usable HIP device (libfmsi_hip has no CPU fallback)");
         return FMSI_HIP_ENODEV;
     }
-    HIP_TRY(hipSetDevice(device));
+    FMSI_HIP_TRY(hipSetDevice(device));
     HostLayout L;
     int rc = build_layout(*view, L);
     if (rc) return rc;
@@ -383,12 +550,28 @@ int fmsi_hip_index_create(const fmsi_index_view* view, int device, fmsi_hip_inde
     idx->device_bytes = blocks_bytes + mrank_bytes;
     idx->dev.blocks = static_cast<const uint4*>(idx->d_blocks);
     idx->dev.mrank = static_cast<const uint32_t*>(idx->d_mrank);
+    idx->dev.ptable = nullptr;
+    idx->dev.ptable_len = 0;
     idx->dev.n = static_cast<uint32_t>(idx->n);
     idx->dev.dollar = static_cast<uint32_t>(view->dollar_position);
     idx->dev.C0 = static_cast<uint32_t>(view->counts[0]);
     idx->dev.C1 = static_cast<uint32_t>(view->counts[1]);
     idx->dev.C2 = static_cast<uint32_t>(view->counts[2]);
     idx->dev.C3 = static_cast<uint32_t>(view->counts[3]);
+    if (view->klcp && view->klcp_bits) {
+        const size_t kb = ((view->klcp_bits + 63) / 64 + 1) * 8;
+        if (hipMalloc(&idx->d_klcp, kb) != hipSuccess ||
+            hipMemcpy(idx->d_klcp, view->klcp, ((view->klcp_bits + 63) / 64) * 8, hipMemcpyHostToDevice) != hipSuccess) {
+            set_last_error("uploading the kLCP array failed");
+            return fail(FMSI_HIP_EHIP);
+        }
+        idx->has_klcp = 1;
+        idx->device_bytes += kb;
+    }
+    if (view->prefix_len > 0) {
+        rc = build_prefix_table(idx, view->prefix_len);
+        if (rc) return fail(rc);
+    }
     *out = idx;
     return 0;
 }
@@ -396,7 +579,8 @@ int fmsi_hip_index_create(const fmsi_index_view* view, int device, fmsi_hip_inde
 void fmsi_hip_index_destroy(fmsi_hip_index* idx) {
     if (!idx) return;
     (void)hipSetDevice(idx->device);
-    for (void* p : {idx->d_blocks, idx->d_mrank, idx->d_in, idx->d_aux, idx->d_out, static_cast<void*>(idx->d_counters)})
+    for (void* p : {idx->d_blocks, idx->d_mrank, idx->d_ptable, idx->d_klcp, idx->d_text2, idx->d_in, idx->d_aux, idx->d_out,
+                    idx->d_kmers, static_cast<void*>(idx->d_counters)})
         if (p) (void)hipFree(p);
     for (auto& e : idx->events) {
         (void)hipEventDestroy(e.first);
@@ -419,47 +603,18 @@ int fmsi_hip_index_get_info(const fmsi_hip_index* idx, fmsi_hip_index_info* info
     return 0;
 }
 
-static int run_query(fmsi_hip_index* idx, int input_kind, const uint64_t* in, size_t in_bytes, const uint64_t* wstart,
-                     uint64_t n_windows, int k, uint32_t flags, void* out, uint64_t* counters, void* stream) {
-    HIP_TRY(hipSetDevice(idx->device));
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    const size_t out_bytes = n_windows * out_elem_bytes(flags);
-    const uint64_t* d_in = in;
-    const uint64_t* d_ws = wstart;
-    void* d_out = out;
-    unsigned long long* d_cnt = reinterpret_cast<unsigned long long*>(counters);
-    const bool dev_ptrs = flags & FMSI_HIP_DEVICE_PTRS;
-    if (!dev_ptrs) {
-        int rc;
-        if ((rc = ensure_cap(&idx->d_in, &idx->d_in_cap, in_bytes))) return rc;
-        if ((rc = ensure_cap(&idx->d_out, &idx->d_out_cap, out_bytes))) return rc;
-        HIP_TRY(hipMemcpyAsync(idx->d_in, in, in_bytes, hipMemcpyHostToDevice, s));
-        d_in = static_cast<const uint64_t*>(idx->d_in);
-        if (wstart) {
-            if ((rc = ensure_cap(&idx->d_aux, &idx->d_aux_cap, n_windows * 8))) return rc;
-            HIP_TRY(hipMemcpyAsync(idx->d_aux, wstart, n_windows * 8, hipMemcpyHostToDevice, s));
-            d_ws = static_cast<const uint64_t*>(idx->d_aux);
-        }
-        d_out = idx->d_out;
-        if (counters) {
-            HIP_TRY(hipMemcpyAsync(idx->d_counters, counters, FMSI_HIP_N_COUNTERS * 8, hipMemcpyHostToDevice, s));
-            d_cnt = idx->d_counters;
-        }
-    }
-    int rc = input_kind == 0 ? launch_query<0>(idx, d_in, d_ws, n_windows, k, flags, d_out, d_cnt, s)
-                             : launch_query<1>(idx, d_in, d_ws, n_windows, k, flags, d_out, d_cnt, s);
-    if (rc) return rc;
-    if (!dev_ptrs) {
-        if (out_bytes) HIP_TRY(hipMemcpyAsync(out, idx->d_out, out_bytes, hipMemcpyDeviceToHost, s));
-        if (counters) HIP_TRY(hipMemcpyAsync(counters, idx->d_counters, FMSI_HIP_N_COUNTERS * 8, hipMemcpyDeviceToHost, s));
-    }
+int fmsi_hip_index_download_layout(const fmsi_hip_index* idx, uint32_t* blocks, uint32_t* mrank) {
+    if (!idx || !blocks || !mrank) return FMSI_HIP_EINVAL;
+    FMSI_HIP_TRY(hipSetDevice(idx->device));
+    FMSI_HIP_TRY(hipMemcpy(blocks, idx->d_blocks, idx->n_blocks * kBlockBytes, hipMemcpyDeviceToHost));
+    FMSI_HIP_TRY(hipMemcpy(mrank, idx->d_mrank, (idx->n_blocks + 1) * 4, hipMemcpyDeviceToHost));
     return 0;
 }
 
 int fmsi_hip_query_kmers(fmsi_hip_index* idx, const uint64_t* kmers, uint64_t n_kmers, int k, uint32_t flags, void* out,
                          uint64_t* counters, void* stream) {
     if (n_kmers == 0) return 0;
-    int rc = check_query_args(idx, kmers, out, k, flags);
+    int rc = check_query_args(idx, kmers, out, k);
     if (rc) return rc;
     return run_query(idx, 0, kmers, n_kmers * 8, nullptr, n_kmers, k, flags, out, counters, stream);
 }
@@ -467,7 +622,7 @@ int fmsi_hip_query_kmers(fmsi_hip_index* idx, const uint64_t* kmers, uint64_t n_
 int fmsi_hip_query_windows(fmsi_hip_index* idx, const uint64_t* packed_seq, uint64_t seq_bases, const uint64_t* window_start,
                            uint64_t n_windows, int k, uint32_t flags, void* out, uint64_t* counters, void* stream) {
     if (n_windows == 0) return 0;
-    int rc = check_query_args(idx, packed_seq, out, k, flags);
+    int rc = check_query_args(idx, packed_seq, out, k);
     if (rc) return rc;
     if (!window_start && n_windows + static_cast<uint64_t>(k) - 1 > seq_bases) {
         set_last_error("implicit windows run past the end of the sequence");
@@ -487,8 +642,8 @@ int fmsi_hip_query_stream(fmsi_hip_index* idx, const uint64_t* packed_seq, uint6
 
 int fmsi_hip_sync(fmsi_hip_index* idx, void* stream) {
     if (!idx) return FMSI_HIP_EINVAL;
-    HIP_TRY(hipSetDevice(idx->device));
-    HIP_TRY(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+    FMSI_HIP_TRY(hipSetDevice(idx->device));
+    FMSI_HIP_TRY(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
     return 0;
 }
 
@@ -500,11 +655,11 @@ int fmsi_hip_profile_enable(fmsi_hip_index* idx, int on) {
 
 int fmsi_hip_profile_read(fmsi_hip_index* idx, uint64_t* n_launches, double* total_ms, int reset) {
     if (!idx) return FMSI_HIP_EINVAL;
-    HIP_TRY(hipSetDevice(idx->device));
+    FMSI_HIP_TRY(hipSetDevice(idx->device));
     for (size_t e = 0; e < idx->events_used; ++e) {
-        HIP_TRY(hipEventSynchronize(idx->events[e].second));
+        FMSI_HIP_TRY(hipEventSynchronize(idx->events[e].second));
         float ms = 0;
-        HIP_TRY(hipEventElapsedTime(&ms, idx->events[e].first, idx->events[e].second));
+        FMSI_HIP_TRY(hipEventElapsedTime(&ms, idx->events[e].first, idx->events[e].second));
         idx->prof_ms += ms;
         idx->prof_launches++;
     }

@@ -83,7 +83,7 @@ typedef struct {
     uint64_t counts[4];                           /* .fmsi.misc lines 2-5 */
     uint64_t dollar_position;                     /* .fmsi.misc line 1 */
     int32_t k;                                    /* .fmsi.misc line 6 */
-    int32_t prefix_len;                           /* private prefix table length t (0 = none, <= 14) */
+    int32_t prefix_len;                           /* private prefix table length t (0 = none, <= 15) */
 } fmsi_index_view;
 
 typedef struct fmsi_hip_index fmsi_hip_index;     /* device-resident index (opaque) */
@@ -113,6 +113,26 @@ int fmsi_hip_device_count(void);
 int fmsi_hip_index_create(const fmsi_index_view* view, int device, fmsi_hip_index** out);
 void fmsi_hip_index_destroy(fmsi_hip_index* idx);
 int fmsi_hip_index_get_info(const fmsi_hip_index* idx, fmsi_hip_index_info* info);
+
+/* On-device construction -- counterpart of construct<T>() (src/fms_index.h:397-460) producing the device layout
+ * directly: 2-bit text -> GPU suffix sort -> BWT / SA-transformed mask / kLCP -> interleaved blocks.
+ * `ms` is the masked superstring (upper case = mask 1, src/kmers.h:71-73).  with_klcp needs k <= 33. */
+int fmsi_hip_index_build(const char* ms, uint64_t len, int k, int with_klcp, int device, int prefix_len, fmsi_hip_index** out);
+
+/* Synthetic workloads (no network on the GPU box, so no real genomes): the superstring is
+ * generated in HBM from a counter-based PRNG -- word w (bases 32w .. 32w+31, base p in bits [2(p%32), +1]) is
+ * fmsi_hip_synthetic_text_word(seed, w) -- with every k-mer ON (positions 0..len-k upper case: a valid max-ones
+ * masked superstring).  The text stays resident so that query k-mers can be drawn from it on the device. */
+int fmsi_hip_index_build_synthetic(uint64_t len, uint64_t seed, int k, int with_klcp, int device, int prefix_len, fmsi_hip_index** out);
+uint64_t fmsi_hip_synthetic_text_word(uint64_t seed, uint64_t w);
+/* Fills d_kmers[0..n) (DEVICE pointer) with queries first..first+n-1 of the seeded stream: with probability 1/2 a
+ * k-mer of the superstring (half of those reverse-complemented), else a uniform random k-mer. */
+int fmsi_hip_synthetic_queries(fmsi_hip_index* idx, int k, uint64_t seed, uint64_t first, uint64_t n, uint64_t* d_kmers, void* stream);
+/* 2-bit text kept by the builder -> host (len/32 + 2 words) */
+int fmsi_hip_index_download_text(const fmsi_hip_index* idx, uint64_t* words);
+
+/* Copies the device layout back (n_blocks*16 dwords, n_blocks+1 dwords) -- verification aid. */
+int fmsi_hip_index_download_layout(const fmsi_hip_index* idx, uint32_t* blocks, uint32_t* mrank);
 
 /* Replaces query_kmers<orr|all>() without kLCP (query_kmers_single, src/fms_index.h:263-331) for
  * isolated k-mers, k <= 32.  kmers[q] holds k-mer q 2-bit packed (A=0,C=1,G=2,T=3 as in src/kmers.h:3-20),

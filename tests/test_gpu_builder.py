@@ -1,0 +1,102 @@
+"""GPU tests of the on-device index builder (fmsi_hip_index_build*, counterpart of construct<T>(),
+reference src/fms_index.h:397-460): the layout it leaves in HBM must equal, dword for dword, the layout
+the host builds from the oracle's (== the reference's) index files."""
+import random
+
+import numpy as np
+import pytest
+
+import oracle_py
+from conftest import GOLDEN, mixed_kmers, synthetic_ms
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def fm(product_built):
+    if product_built.device_count() < 1:
+        pytest.fail("no HIP device visible")
+    return product_built
+
+
+def host_layout_from_oracle(fm, tmp_path, ms: str, k: int, tag: str):
+    orc = oracle_py.Oracle.construct(ms, k, use_klcp=True)
+    prefix = str(tmp_path / tag)
+    orc.dump(prefix)
+    host = fm.HostIndex(prefix, use_klcp=True)
+    return orc, host, prefix
+
+
+def check_equal_layout(fm, dev, host):
+    want_blocks, want_mrank = host.layout()
+    got_blocks, got_mrank = dev.download_layout()
+    assert got_blocks.shape == want_blocks.shape
+    assert np.array_equal(got_mrank, want_mrank)
+    bad = np.nonzero((got_blocks != want_blocks).any(axis=1))[0]
+    assert bad.size == 0, f"first differing block {bad[:5]}"
+    assert dev.info.n == host.n
+
+
+CASES = [
+    ("tiny", "CaGGTag", 3),
+    ("repeat", "ACGT" * 300 + "acg", 4),                       # every 32-mer key tied: host tie-break path
+    ("polyA", "A" * 500 + "C" + "A" * 300 + "ca", 3),
+    ("n127", None, 5), ("n128", None, 5), ("n255", None, 7), ("n256", None, 7), ("n4096", None, 9),
+]
+
+
+@pytest.mark.parametrize("tag,ms,k", CASES)
+def test_build_from_text_equals_oracle_layout(fm, oracle_built, tmp_path, tag, ms, k):
+    if ms is None:
+        ms = synthetic_ms(int(tag[1:]) - 1, k, seed=len(tag) * 7 + k, mask="mixed")
+    orc, host, prefix = host_layout_from_oracle(fm, tmp_path, ms, k, tag)
+    dev = fm.DeviceIndex.build(ms.encode(), k, with_klcp=True)
+    check_equal_layout(fm, dev, host)
+    # and it answers like the oracle
+    kmers = mixed_kmers(ms, k, 500, seed=1) if len(ms) > 2 * k else ["ACG", "CAG", "GGT", "TAG", "AAA"]
+    fwd, rc = orc.ternaries_bulk("".join(kmers).encode(), len(kmers), k, False)
+    gf, gr = fm.decode_strict(dev.query_kmers(fm.pack_kmers(kmers, k), k, fm.MODE_OR | fm.STRICT))
+    assert np.array_equal(gf, fwd) and np.array_equal(gr, rc)
+
+
+def test_build_mixed_fixture_equals_reference_index(fm):
+    """Device-built layout of the mixed-mask fixture == layout from the REAL reference's index files."""
+    ms = "".join(l.strip() for l in open(GOLDEN / "mixed.fa") if not l.startswith(">"))
+    host = fm.HostIndex(str(GOLDEN / "idx" / "mixed_k11"), use_klcp=True)
+    dev = fm.DeviceIndex.build(ms.encode(), 11, with_klcp=True)
+    check_equal_layout(fm, dev, host)
+    ms = "".join(l.strip() for l in open(GOLDEN / "ref_data" / "GCF_test2_ones.fna.ms.k31") if not l.startswith(">"))
+    host = fm.HostIndex(str(GOLDEN / "idx" / "sars_k31"), use_klcp=True)
+    dev = fm.DeviceIndex.build(ms.encode(), 31, with_klcp=True)
+    check_equal_layout(fm, dev, host)
+
+
+def test_synthetic_build_equals_oracle(fm, oracle_built, tmp_path):
+    n, seed, k = 300_000, 12345, 31
+    dev = fm.DeviceIndex.build_synthetic(n, seed, k, with_klcp=True, prefix_len=8)
+    text = fm.synthetic_text(n, seed, k)
+    assert np.array_equal(dev.download_text(n), fm.synthetic_text_words(n, seed))
+    orc, host, prefix = host_layout_from_oracle(fm, tmp_path, text.decode(), k, "syn")
+    check_equal_layout(fm, dev, host)
+    # device-generated queries: ~half positive, bit-exact vs the oracle on the same packed k-mers
+    import torch
+    nq = 100_000
+    d_kmers = torch.empty(nq, dtype=torch.int64, device="cuda")
+    d_out = torch.empty(nq, dtype=torch.uint8, device="cuda")
+    s = torch.cuda.current_stream().cuda_stream
+    dev.synthetic_queries_dev(k, 42, 0, nq, d_kmers.data_ptr(), s)
+    dev.query_kmers_dev(d_kmers.data_ptr(), nq, k, fm.MODE_ALL | fm.STRICT, d_out.data_ptr(), stream=s)
+    torch.cuda.synchronize()
+    kmers = d_kmers.cpu().numpy().view(np.uint64)
+    got_f, got_r = fm.decode_strict(d_out.cpu().numpy())
+    codes = ((kmers[:, None] >> (2 * np.arange(k, dtype=np.uint64))) & np.uint64(3)).astype(np.uint8)
+    raw = np.frombuffer(b"ACGT", dtype=np.uint8)[codes].tobytes()
+    fwd, rc = orc.ternaries_bulk(raw, nq, k, True)
+    assert np.array_equal(got_f, fwd) and np.array_equal(got_r, rc)
+    pos = ((fwd == 1) | (rc == 1)).mean()
+    assert 0.45 < pos < 0.55
+    # the stream of queries is a pure function of (seed, index): a second draw of a sub-range agrees
+    d2 = torch.empty(1000, dtype=torch.int64, device="cuda")
+    dev.synthetic_queries_dev(k, 42, 5000, 1000, d2.data_ptr(), s)
+    torch.cuda.synchronize()
+    assert np.array_equal(d2.cpu().numpy().view(np.uint64), kmers[5000:6000])

@@ -42,19 +42,23 @@ def test_both_strands_equal_oracle(fm, oracle_built, name):
         kmers = ["".join(p) for p in itertools.product("ACGT", repeat=k)]
     raw = "".join(kmers).encode()
     packed = fm.pack_kmers(kmers, k)
+    dev_t = fm.DeviceIndex.from_files(index_prefix(name), prefix_len=min(k, 6))   # private prefix table of min(k, 6) steps
+    variants = [(dev, fm.KERNEL_LOCKSTEP), (dev, fm.KERNEL_REFILL), (dev_t, fm.KERNEL_REFILL)]
     for mode_all in (False, True):
         flag = fm.MODE_ALL if mode_all else fm.MODE_OR
         fwd, rc = orc.ternaries_bulk(raw, len(kmers), k, mode_all)
-        got_f, got_r = fm.decode_strict(dev.query_kmers(packed, k, flag | fm.STRICT))
-        assert np.array_equal(got_f, fwd) and np.array_equal(got_r, rc)
-        fast = dev.query_kmers(packed, k, flag)
-        assert np.array_equal(fast.astype(bool), expected_fast(fwd, rc, mode_all))
+        for d, kern in variants:
+            got_f, got_r = fm.decode_strict(d.query_kmers(packed, k, flag | fm.STRICT | kern))
+            assert np.array_equal(got_f, fwd) and np.array_equal(got_r, rc)
+            fast = d.query_kmers(packed, k, flag | kern)
+            assert np.array_equal(fast.astype(bool), expected_fast(fwd, rc, mode_all))
     # lookup (orders)
     fwd, rc, of, orc_r = orc.ternaries_bulk(raw, len(kmers), k, False, orders=True)
-    got = dev.query_kmers(packed, k, fm.ORDERS | fm.STRICT)
-    assert np.array_equal(got[:, 0], of) and np.array_equal(got[:, 1], orc_r)
-    got1 = dev.query_kmers(packed, k, fm.ORDERS)
-    assert np.array_equal(got1, np.where(of >= 0, of, orc_r))
+    for d, kern in variants:
+        got = d.query_kmers(packed, k, fm.ORDERS | fm.STRICT | kern)
+        assert np.array_equal(got[:, 0], of) and np.array_equal(got[:, 1], orc_r)
+        got1 = d.query_kmers(packed, k, fm.ORDERS | kern)
+        assert np.array_equal(got1, np.where(of >= 0, of, orc_r))
 
 
 def test_windows_equal_kmers_and_oracle(fm, oracle_built):
@@ -102,11 +106,19 @@ def test_lf_step_counter_equals_oracle(fm, oracle_built):
     orc.counters_reset()
     orc.ternaries_bulk("".join(kmers).encode(), len(kmers), k, True)
     want = orc.counters()
-    out, cn = dev.query_kmers(fm.pack_kmers(kmers, k), k, fm.MODE_ALL | fm.STRICT, counters=True)
-    assert int(cn[0]) == want["lf_steps"]
-    assert int(cn[3]) == want["strand_searches"] == 2 * len(kmers)
-    assert int(cn[2]) == want["mask_probes"]
-    assert int(cn[6]) == len(kmers)
+    for kern in (fm.KERNEL_LOCKSTEP, fm.KERNEL_REFILL):
+        out, cn = dev.query_kmers(fm.pack_kmers(kmers, k), k, fm.MODE_ALL | fm.STRICT | kern, counters=True)
+        assert int(cn[0]) == want["lf_steps"]
+        assert int(cn[3]) == want["strand_searches"] == 2 * len(kmers)
+        assert int(cn[2]) == want["mask_probes"]
+        assert int(cn[6]) == len(kmers)
+    # with a t-step prefix table the walk starts t steps in: fewer LF steps, one lookup per strand search
+    dev_t = fm.DeviceIndex.from_files(index_prefix(name), prefix_len=5)
+    out_t, cn_t = dev_t.query_kmers(fm.pack_kmers(kmers, k), k, fm.MODE_ALL | fm.STRICT, counters=True)
+    assert np.array_equal(out_t, out)
+    assert int(cn_t[4]) == 2 * len(kmers) and int(cn_t[0]) < want["lf_steps"] - 4 * len(kmers)
+    out_n, cn_n = dev_t.query_kmers(fm.pack_kmers(kmers, k), k, fm.MODE_ALL | fm.STRICT | fm.NO_PREFIX_TABLE, counters=True)
+    assert np.array_equal(out_n, out) and int(cn_n[0]) == want["lf_steps"] and int(cn_n[4]) == 0
 
 
 CASES = [(n, kind, mode) for n, (k, kinds) in DATASETS.items() for kind in kinds for mode in MODES]
@@ -198,7 +210,7 @@ def test_properties_at_scale(fm, synthetic_index):
     b = dev.query_kmers(kmers, k, fm.MODE_OR | fm.STRICT)
     launches, ms_total = dev.profile_read()
     dev.profile(False)
-    print(f"\n[perf] lockstep strict: {n} random 31-mers in {ms_total:.3f} ms ({launches} launch) = {n / ms_total / 1e3:.1f} M k-mers/s")
+    print(f"\n[perf] refill strict: {n} random 31-mers in {ms_total:.3f} ms ({launches} launch) = {n / ms_total / 1e3:.1f} M k-mers/s")
     assert np.array_equal(a, b)
     # reverse complement of a packed k-mer, on the host
     sub = kmers[:500_000]
