@@ -83,6 +83,14 @@ def lib() -> C.CDLL:
     if not LIB_PATH.exists():
         raise FileNotFoundError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                                 f"(or make -C fmsi_amd/csrc); there is no fallback path")
+    # One HIP runtime per process: the torch wheel bundles its own libamdhip64.so (SONAME libamdhip64.so.7,
+    # the SONAME libfmsi_hip.so needs).  Importing torch first makes the loader reuse that copy for us; the
+    # other order would load the system runtime here and torch's copy later, and the second one finds no GPU.
+    # (The C++ CLI never loads torch and uses the system runtime.)
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(str(LIB_PATH))
     vp, u64, i32, u32 = C.c_void_p, C.c_uint64, C.c_int, C.c_uint32
     L.fmsi_hip_last_error.restype = C.c_char_p
