@@ -600,6 +600,11 @@ int fmsi_hip_index_get_info(const fmsi_hip_index* idx, fmsi_hip_index_info* info
     info->block_symbols = kBlockRows;
     info->n_blocks = idx->n_blocks;
     info->device_bytes = idx->device_bytes;
+    info->counts[0] = idx->dev.C0;
+    info->counts[1] = idx->dev.C1;
+    info->counts[2] = idx->dev.C2;
+    info->counts[3] = idx->dev.C3;
+    info->dollar_position = idx->dev.dollar;
     return 0;
 }
 

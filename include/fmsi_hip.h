@@ -99,6 +99,8 @@ typedef struct {
     uint64_t block_symbols;     /* BWT positions per block */
     uint64_t n_blocks;
     uint64_t device_bytes;      /* total HBM footprint of the handle */
+    uint64_t counts[4];         /* C array of the index ({1, #A+1, #A+#C+1, #A+#C+#G+1}, src/fms_index.h:451) */
+    uint64_t dollar_position;
 } fmsi_hip_index_info;
 
 /* counters written by query calls when `counters` != NULL (8 x u64, accumulated, caller zeroes):

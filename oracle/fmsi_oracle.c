@@ -541,6 +541,45 @@ orc_index* orc_index_literal(const uint8_t* ac_gt, uint64_t n_ac_gt, const uint8
     return ix;
 }
 
+/* Index from row-order bit planes (hi = ac_gt bit, lo = second wavelet-tree level bit of the row, mask =
+ * SA-transformed mask), n rows each, given as u64 words.  Used by bench.py's cpu_baseline leg to hand the CPU
+ * reference the very index the GPU built: ac/gt are the lo bits of the rows with hi = 0 / 1, in row order
+ * (the split of src/fms_index.h:427-450). */
+orc_index* orc_index_from_planes(const uint64_t* hi, const uint64_t* lo, const uint64_t* mask, uint64_t n,
+                                 const uint64_t* counts4, uint64_t dollar_position, int k) {
+    tables_init();
+    orc_index* ix = (orc_index*)calloc(1, sizeof *ix);
+    bv_alloc(&ix->ac_gt, n);
+    uint64_t words = (n + 63) >> 6, gt_count = 0;
+    for (uint64_t w = 0; w < words; ++w) {
+        uint64_t v = hi[w];
+        if (w == words - 1 && (n & 63)) v &= lo_set((unsigned)(n & 63));
+        ix->ac_gt.w[w] = v;
+        gt_count += (uint64_t)__builtin_popcountll(v);
+    }
+    bv_alloc(&ix->ac, n - gt_count);
+    bv_alloc(&ix->gt, gt_count);
+    uint64_t ai = 0, gi = 0;
+    for (uint64_t r = 0; r < n; ++r) {
+        int h = (int)((hi[r >> 6] >> (r & 63)) & 1), l = (int)((lo[r >> 6] >> (r & 63)) & 1);
+        if (h) { if (l) ix->gt.w[gi >> 6] |= 1ull << (gi & 63); ++gi; }
+        else { if (l) ix->ac.w[ai >> 6] |= 1ull << (ai & 63); ++ai; }
+    }
+    orc_bitvec m;
+    bv_alloc(&m, n);
+    for (uint64_t w = 0; w < words; ++w) m.w[w] = mask[w];
+    if (n & 63) m.w[words - 1] &= lo_set((unsigned)(n & 63));
+    orc_rrr_build(&ix->mask, &m);
+    bv_free(&m);
+    bv_alloc(&ix->klcp, 0);
+    for (int i = 0; i < 4; ++i) ix->counts[i] = counts4[i];
+    ix->dollar_position = dollar_position;
+    ix->k = k;
+    build_ranks(ix);
+    orc_predictor_reset(ix);
+    return ix;
+}
+
 void orc_index_free(orc_index* ix) {
     if (!ix) return;
     bv_free(&ix->ac_gt); bv_free(&ix->ac); bv_free(&ix->gt); bv_free(&ix->klcp);

@@ -97,6 +97,8 @@ void orc_rrr_decode_all(const orc_rrr63* v, orc_bitvec* out);
 orc_index* orc_index_load(const char* prefix, int use_klcp);       /* fms_index.h:502-526 */
 int orc_index_dump(const orc_index* ix, const char* prefix);         /* fms_index.h:484-500 */
 orc_index* orc_index_construct(const char* ms, uint64_t len, int k, int use_klcp); /* fms_index.h:397-460 */
+orc_index* orc_index_from_planes(const uint64_t* hi, const uint64_t* lo, const uint64_t* mask, uint64_t n,
+                                 const uint64_t* counts4, uint64_t dollar_position, int k);
 orc_index* orc_index_literal(const uint8_t* ac_gt, uint64_t n_ac_gt, const uint8_t* ac, uint64_t n_ac,
                              const uint8_t* gt, uint64_t n_gt, const uint8_t* mask, uint64_t n_mask,
                              const uint64_t* counts4, uint64_t dollar_position,
