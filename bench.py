@@ -160,7 +160,7 @@ def main():
             canon_bytes = 256 * int(canonical[0]) + 64 * int(canonical[2]) + 8 * batch + batch // 8
             ach = bytes_launch / avg_kernel_s / 1e9
             roof = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                    "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(args, n, batch, k),
                     "kernel": f"query_{args.kernel}_kernel", "avg_kernel_ms": round(avg_kernel_s * 1e3, 4), "launches": launches,
                     "algorithmic_bytes_per_launch": bytes_launch,
                     "bytes_per_kmer": round(bytes_launch / batch, 1),
@@ -193,6 +193,26 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def pmc_traffic(args, n, batch, k):
+    """HBM bytes per launch of the timed kernel from the rocprofv3 PMC passes committed under profiles/
+    (FETCH_SIZE and WRITE_SIZE in separate passes, calibrated on random 64-B reads: profiles/README.md).
+    bench.py cannot collect PMC counters itself; the figure is attached only when the run's configuration is
+    the one that was profiled, otherwise null."""
+    best = None   # returns bytes per launch (FETCH_SIZE + WRITE_SIZE) or None
+    for p in sorted((REPO / "profiles").glob("r*_traffic.json")):
+        try:
+            t = json.loads(p.read_text())
+        except (OSError, ValueError):
+            continue
+        c = t.get("config", {})
+        if (c.get("n"), c.get("batch"), c.get("k"), c.get("prefix_len"), c.get("mode")) == (n, batch, k, args.prefix_len, args.mode) \
+                and args.kernel in t.get("kernel", ""):
+            best = t
+    if best is None:
+        return None
+    return best["hbm_bytes_per_launch"]
 
 
 def cpu_baseline(args, index, n, k):

@@ -63,6 +63,16 @@ def _forked_rate(obj, text: bytes, n_each: int, k: int, mode: int, workers: int)
     return workers * n_each / max(secs), max(secs), wall
 
 
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def run(args, index, n, k):
     import ctypes as C
     import torch
@@ -71,6 +81,14 @@ def run(args, index, n, k):
 
     mode = oracle_py.MODE_ALL if args.mode == "all" else oracle_py.MODE_OR
     cores_socket = max(1, (os.cpu_count() or 2) // 4)       # 2 sockets x SMT2 on the gpurun box -> physical cores of one socket
+    quota = None
+    try:                                                      # the box's container may cap CPU time (cgroup v2 cpu.max)
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            quota = max(1, int(q) // int(per))
+            cores_socket = min(cores_socket, quota)
+    except (OSError, ValueError):
+        pass
     sample = args.cpu_sample
     if sample < 0:
         # ~10-20 s of single-thread work: ~15 us per k-mer at human scale, ~3 us when the index is cache resident
@@ -125,5 +143,5 @@ def run(args, index, n, k):
         "seconds": round(sec1, 3), "matches_gpu": agree,
         "socket_value": rate_socket, "socket_cores": cores_socket,
         "socket_sample": f"{cores_socket} forked workers x {per_worker} further k-mers each, shared read-only index, slowest worker {sec_max:.2f} s",
-        "index_export_seconds": round(prep_s, 1), "host": os.uname().nodename,
+        "index_export_seconds": round(prep_s, 1), "cpu_model": _cpu_model(), "logical_cpus": os.cpu_count(), "cgroup_cpu_quota": quota,
     }
