@@ -309,6 +309,28 @@ class DeviceIndex:
         self.sync()
         return (out, cn) if counters else out
 
+    def query_stream(self, packed: np.ndarray, seq_bases: int, run_start, run_windows, k: int, flags: int = MODE_OR,
+                     counters: bool = False):
+        """kLCP streaming queries (`-S`): runs of consecutive windows; results in run order."""
+        packed = np.ascontiguousarray(packed, dtype=np.uint64)
+        run_start = np.ascontiguousarray(run_start, dtype=np.uint64)
+        run_windows = np.ascontiguousarray(run_windows, dtype=np.uint32)
+        n = int(run_windows.sum())
+        out = self._alloc_out(n, flags)
+        cn = np.zeros(N_COUNTERS, dtype=np.uint64) if counters else None
+        _check(lib().fmsi_hip_query_stream(self._h, packed.ctypes.data, seq_bases, run_start.ctypes.data, run_windows.ctypes.data,
+                                           run_start.size, n, k, flags, out.ctypes.data, cn.ctypes.data if counters else None, None))
+        self.sync()
+        return (out, cn) if counters else out
+
+    def query_stream_dev(self, packed_ptr: int, seq_bases: int, run_start, run_windows, k: int, flags: int, out_ptr: int,
+                         counters_ptr: int = 0, stream: int = 0):
+        """Same with the sequence / results resident in HBM; the run arrays are host arrays in every mode."""
+        run_start = np.ascontiguousarray(run_start, dtype=np.uint64)
+        run_windows = np.ascontiguousarray(run_windows, dtype=np.uint32)
+        _check(lib().fmsi_hip_query_stream(self._h, packed_ptr, seq_bases, run_start.ctypes.data, run_windows.ctypes.data, run_start.size,
+                                           int(run_windows.sum()), k, flags | DEVICE_PTRS, out_ptr, counters_ptr or None, stream or None))
+
     # -- device-pointer calls (buffers already resident in HBM, e.g. torch tensors' data_ptr()) --
     def query_kmers_dev(self, kmers_ptr: int, n: int, k: int, flags: int, out_ptr: int, counters_ptr: int = 0, stream: int = 0):
         _check(lib().fmsi_hip_query_kmers(self._h, kmers_ptr, n, k, flags | DEVICE_PTRS, out_ptr, counters_ptr or None,

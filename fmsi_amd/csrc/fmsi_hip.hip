@@ -220,14 +220,23 @@ __global__ __launch_bounds__(256) void query_refill_kernel(DevIndex ix, const ui
                 pi = ix.blocks + (static_cast<size_t>(bi) << 2);
                 pj = ix.blocks + (static_cast<size_t>(bj) << 2);
             }
-            const uint4 a0 = pi[0], a1 = pi[1], a2 = pi[2], a3 = pi[3];
-            uint4 b0 = a0, b1 = a1, b2 = a2;
-            if (pj != pi) {
+            // All reads of the round are issued before anything waits: the (predicated) second block first, then
+            // the first block; only afterwards are lanes with a single block given copies.  Writing `b = a` before
+            // the predicated loads makes hipcc wait for `a` in between, which serialises the two reads.
+            const bool two = pj != pi;
+            uint4 b0 = make_uint4(0, 0, 0, 0), b1 = b0, b2 = b0;
+            if (two) {
                 b0 = pj[0];
                 b1 = pj[1];
                 b2 = pj[2];
             }
-            if (COUNT) cn.blocks += 1u + (pj != pi);
+            const uint4 a0 = pi[0], a1 = pi[1], a2 = pi[2], a3 = pi[3];
+            if (!two) {
+                b0 = a0;
+                b1 = a1;
+                b2 = a2;
+            }
+            if (COUNT) cn.blocks += 1u + (two ? 1u : 0u);
             if (st == ST_LF) {
                 const uint32_t c = static_cast<uint32_t>(cur >> (2 * t)) & 3u;
                 uint32_t ri = rank_in_block(a0, a1, a2, c, i & (kBlockRows - 1u));
@@ -350,36 +359,6 @@ int build_prefix_table(fmsi_hip_index* idx, int t) {
 using namespace fmsi;
 
 namespace {
-
-int ensure_cap(void** p, size_t* cap, size_t need) {
-    if (need <= *cap) return 0;
-    if (*p) (void)hipFree(*p);
-    *p = nullptr;
-    *cap = 0;
-    size_t want = std::max<size_t>(need, 1 << 20);
-    FMSI_HIP_TRY(hipMalloc(p, want));
-    *cap = want;
-    return 0;
-}
-
-int prof_begin(fmsi_hip_index* idx, hipStream_t s, size_t* slot) {
-    *slot = static_cast<size_t>(-1);
-    if (!idx->profiling) return 0;
-    if (idx->events_used == idx->events.size()) {
-        hipEvent_t a, b;
-        FMSI_HIP_TRY(hipEventCreate(&a));
-        FMSI_HIP_TRY(hipEventCreate(&b));
-        idx->events.emplace_back(a, b);
-    }
-    *slot = idx->events_used++;
-    FMSI_HIP_TRY(hipEventRecord(idx->events[*slot].first, s));
-    return 0;
-}
-int prof_end(fmsi_hip_index* idx, hipStream_t s, size_t slot) {
-    if (slot == static_cast<size_t>(-1)) return 0;
-    FMSI_HIP_TRY(hipEventRecord(idx->events[slot].second, s));
-    return 0;
-}
 
 template <bool COUNT, bool PTABLE>
 void launch_refill(fmsi_hip_index* idx, const uint64_t* d_kmers, uint64_t n, int k, uint32_t flags, uint8_t* o8, long long* o64,
@@ -636,14 +615,7 @@ int fmsi_hip_query_windows(fmsi_hip_index* idx, const uint64_t* packed_seq, uint
     return run_query(idx, 1, packed_seq, (seq_bases / 32 + 2) * 8, window_start, n_windows, k, flags, out, counters, stream);
 }
 
-int fmsi_hip_query_stream(fmsi_hip_index* idx, const uint64_t* packed_seq, uint64_t seq_bases, const uint64_t* run_start,
-                          const uint32_t* run_windows, uint64_t n_runs, uint64_t n_windows, int k, uint32_t flags, void* out,
-                          uint64_t* counters, void* stream) {
-    (void)idx; (void)packed_seq; (void)seq_bases; (void)run_start; (void)run_windows; (void)n_runs; (void)n_windows;
-    (void)k; (void)flags; (void)out; (void)counters; (void)stream;
-    set_last_error("fmsi_hip_query_stream: kLCP streaming kernel not built yet");
-    return FMSI_HIP_EINVAL;
-}
+// fmsi_hip_query_stream: fmsi_stream.hip
 
 int fmsi_hip_sync(fmsi_hip_index* idx, void* stream) {
     if (!idx) return FMSI_HIP_EINVAL;

@@ -1,0 +1,535 @@
+// kLCP streaming queries on the device: counterpart of query_kmers_streaming<>() (reference
+// src/fms_index.h:181-254) with extend_range_with_klcp() (:106-115).
+//
+// The reference walks the windows of a chunk right-to-left on the first strand (fresh k-step search when the
+// previous interval is empty, otherwise kLCP extension + ONE LF step), then left-to-right on the other strand
+// for the windows still undecided.  Here a *task* is a run of <= 64 consecutive windows; one lane runs a task
+// exactly that way (forward strand right-to-left, then reverse-complement strand left-to-right, skipping decided
+// windows unless STRICT), keeping the first pass' results in two 64-bit registers.  Intervals are the same as
+// fresh searches would give (the kLCP extension yields exactly the (k-1)-mer interval), so results are
+// independent of how a sequence is cut into tasks; only the cost changes.
+//
+// Memory rounds per lane and iteration, as in the refill kernel: one round of independent reads -- the
+// interleaved block(s) of the interval (whose mask plane answers the current window and whose planes rank the
+// step to the next window) together with the kLCP word(s) around i-1 and j-1.  A positive window therefore
+// costs ONE block read + ONE kLCP word instead of k block reads.  Tasks are staged by a preparation kernel as
+// 64-byte records (128 bases of sequence + output index), prefetched one iteration ahead and handed out with
+// ballot + mbcnt prefix ranks.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "../../include/fmsi_hip.h"
+#include "common.h"
+#include "device_fm.h"
+#include "index_priv.h"
+
+namespace fmsi {
+namespace {
+
+constexpr uint32_t kTaskWindows = 64;
+
+struct TaskDesc {    // host-built
+    uint64_t base;   // first base of the task's first window in the packed sequence
+    uint64_t out;    // result index of the task's first window
+    uint32_t n;      // windows in the task (1..64)
+    uint32_t pad;
+};
+static_assert(sizeof(TaskDesc) == 24, "TaskDesc layout");
+
+struct alignas(64) TaskRec {   // device-built, one cache line
+    uint64_t s[4];             // bases base .. base+127, base+m in bits [2(m%32), +1] of s[m/32]
+    uint64_t out;
+    uint32_t n;
+    uint32_t pad;
+    uint64_t pad2[2];
+};
+static_assert(sizeof(TaskRec) == 64, "TaskRec layout");
+
+__global__ __launch_bounds__(256) void stream_prep_kernel(const uint64_t* __restrict__ seq, const TaskDesc* __restrict__ desc,
+                                                          uint64_t n_tasks, uint64_t seq_words, TaskRec* __restrict__ rec) {
+    const uint64_t t = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (t >= n_tasks) return;
+    const TaskDesc d = desc[t];
+    const uint64_t w = d.base >> 5;
+    const uint32_t sh = static_cast<uint32_t>(d.base & 31u) * 2u;
+    TaskRec r;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {   // never reads past the caller's buffer (seq_words = seq_bases/32 + 2)
+        uint64_t v = (w + q < seq_words ? seq[w + q] : 0ull) >> sh;
+        if (sh && w + q + 1 < seq_words) v |= seq[w + q + 1] << (64u - sh);
+        r.s[q] = v;
+    }
+    r.out = d.out;
+    r.n = d.n;
+    r.pad = 0;
+    r.pad2[0] = r.pad2[1] = 0;
+    rec[t] = r;
+}
+
+enum : uint32_t { SS_IDLE = 0, SS_LOOKUP = 1, SS_LF = 2, SS_HAVE = 3, SS_EXTSCAN = 4, SS_EXTLF = 5 };
+
+struct StreamCounters {
+    uint32_t lf_steps = 0, blocks = 0, probes = 0, searches = 0, lookups = 0, klcp_words = 0;
+};
+
+// 2-bit base m (0..127) of a task's sequence words
+__device__ __forceinline__ uint32_t task_base(uint64_t s0, uint64_t s1, uint64_t s2, uint64_t s3, uint32_t m) {
+    const uint32_t q = m >> 5;
+    const uint64_t lo = (q & 1u) ? s1 : s0, hi = (q & 1u) ? s3 : s2;
+    const uint64_t w = (q & 2u) ? hi : lo;
+    return static_cast<uint32_t>(w >> (2u * (m & 31u))) & 3u;
+}
+// k bases starting at base m (m + k <= 128), base m in bits 0..1
+__device__ __forceinline__ uint64_t task_kmer(uint64_t s0, uint64_t s1, uint64_t s2, uint64_t s3, uint32_t m, int k) {
+    const uint32_t q = m >> 5, sh = (m & 31u) * 2u;
+    const uint64_t w0 = q == 0 ? s0 : (q == 1 ? s1 : (q == 2 ? s2 : s3));
+    const uint64_t w1 = q == 0 ? s1 : (q == 1 ? s2 : (q == 2 ? s3 : 0ull));
+    uint64_t f = w0 >> sh;
+    if (sh) f |= w1 << (64u - sh);
+    return k == 32 ? f : (f & ((1ull << (2 * k)) - 1ull));
+}
+
+template <bool COUNT, bool PTABLE>
+__global__ __launch_bounds__(256) void query_stream_kernel(DevIndex ix, const uint64_t* __restrict__ klcp, const TaskRec* __restrict__ tasks,
+                                                           uint64_t n_tasks, int k, uint32_t flags, uint32_t chunk,
+                                                           uint8_t* __restrict__ out, long long* __restrict__ out_orders,
+                                                           unsigned long long* __restrict__ counters) {
+    const uint32_t mode_all = flags & FMSI_HIP_MODE_ALL;
+    const uint32_t strict = flags & FMSI_HIP_STRICT;
+    const uint32_t orders = flags & FMSI_HIP_ORDERS;
+    const uint64_t wave = (static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
+    uint64_t next = wave * chunk;
+    const uint64_t end = min(n_tasks, next + static_cast<uint64_t>(chunk));
+    const int T = PTABLE ? static_cast<int>(ix.ptable_len) : 0;
+    const uint64_t kmask = k == 32 ? ~0ull : ((1ull << (2 * k)) - 1ull);
+
+    // current task
+    uint64_t s0 = 0, s1 = 0, s2 = 0, s3 = 0, obase = 0;
+    uint32_t n = 0;
+    // prefetched task
+    uint64_t ns0 = 0, ns1 = 0, ns2 = 0, ns3 = 0, nobase = 0;
+    uint32_t nn = 0;
+    bool has_next = false;
+    // walk state
+    uint64_t kmer = 0;            // k-mer of the current window on the current strand (base t in bits [2t, 2t+1])
+    uint64_t rf_lo = 0, rf_hi = 0;   // pass-0 result + 1 of window w: bit w of rf_lo / rf_hi (0 = empty interval)
+    uint64_t todo = 0;            // pass 1: windows still to visit
+    uint32_t i = 0, j = 0, st = SS_IDLE, pass = 0, widx = 0;
+    uint32_t scan_i = 0, scan_j = 0;   // EXTSCAN: sides still extending
+    int t = 0;
+    StreamCounters cn;
+
+    auto fresh = [&]() {   // start a fresh k-step search for `kmer`
+        if (COUNT) cn.searches++;
+        if (PTABLE) {
+            st = SS_LOOKUP;
+        } else {
+            i = 0;
+            j = ix.n;
+            t = k - 1;
+            st = SS_LF;
+        }
+    };
+    auto final_byte = [&](int f, int r) -> uint8_t {
+        if (strict) return static_cast<uint8_t>((f + 1) | ((r + 1) << 2));
+        if (mode_all) return static_cast<uint8_t>((f != -1 ? f : r) == 1);
+        return static_cast<uint8_t>(f == 1 || r == 1);
+    };
+    // begin pass 1 (reverse-complement strand, windows ascending) or finish the task
+    auto begin_pass1 = [&]() {
+        pass = 1;
+        const uint64_t all = n == 64 ? ~0ull : ((1ull << n) - 1ull);
+        if (strict) todo = all;
+        else if (orders || !mode_all) todo = all & ~(rf_hi & ~rf_lo);   // OR / orders: only a forward result of 1 decides (rf = 2)
+        else todo = all & ~(rf_lo | rf_hi);                            // ALL: any non-empty forward interval decides
+        if (!todo) {
+            st = SS_IDLE;
+            return;
+        }
+        widx = static_cast<uint32_t>(__ffsll(static_cast<unsigned long long>(todo))) - 1u;
+        todo &= todo - 1;
+        kmer = revcomp_2bit(task_kmer(s0, s1, s2, s3, widx, k), k);
+        fresh();
+    };
+    // the current window's result on the current strand is known
+    auto window_done = [&](int res, long long ord) {
+        if (pass == 0) {
+            const uint64_t bit = 1ull << widx;
+            const uint32_t v = static_cast<uint32_t>(res + 1);
+            if (v & 1u) rf_lo |= bit;
+            if (v & 2u) rf_hi |= bit;
+            if (orders) {
+                if (strict) out_orders[2 * (obase + widx)] = ord;
+                else out_orders[obase + widx] = ord;
+            } else if (!strict) {
+                // decided windows are final now; undecided ones are rewritten by pass 1
+                out[obase + widx] = final_byte(res, -1);
+            }
+        } else {
+            const int f = static_cast<int>(((rf_lo >> widx) & 1ull) | (((rf_hi >> widx) & 1ull) << 1)) - 1;
+            if (orders) {
+                if (strict) out_orders[2 * (obase + widx) + 1] = ord;
+                else out_orders[obase + widx] = ord;   // visited only when the forward strand had no order
+            } else {
+                out[obase + widx] = final_byte(f, res);
+            }
+        }
+    };
+    // move to the next window of the pass; `have` = the current window's interval [i, j) is non-empty.
+    // Returns true when the walk continues by streaming (extension + one LF step from [i, j)).
+    auto advance = [&](bool have) -> bool {
+        if (pass == 0) {
+            if (widx == 0) {
+                begin_pass1();
+                return false;
+            }
+            --widx;
+            kmer = ((kmer << 2) | task_base(s0, s1, s2, s3, widx)) & kmask;              // prepend S[p]
+            if (have) return true;
+            fresh();
+            return false;
+        }
+        if (!todo) {
+            st = SS_IDLE;
+            return false;
+        }
+        const uint32_t nw = static_cast<uint32_t>(__ffsll(static_cast<unsigned long long>(todo))) - 1u;
+        todo &= todo - 1;
+        if (nw == widx + 1u) {
+            kmer = ((kmer << 2) | (3u - task_base(s0, s1, s2, s3, widx + static_cast<uint32_t>(k)))) & kmask;   // prepend comp(S[p+k])
+            widx = nw;
+            if (have) return true;
+        } else {   // skipped windows: the reference resets the interval (fms_index.h:212-216)
+            widx = nw;
+            kmer = revcomp_2bit(task_kmer(s0, s1, s2, s3, widx, k), k);
+        }
+        fresh();
+        return false;
+    };
+
+    for (;;) {
+        if (st == SS_IDLE && has_next) {
+            s0 = ns0; s1 = ns1; s2 = ns2; s3 = ns3; obase = nobase; n = nn;
+            has_next = false;
+            pass = 0;
+            rf_lo = rf_hi = 0;
+            widx = n - 1u;
+            kmer = task_kmer(s0, s1, s2, s3, widx, k);
+            fresh();
+        }
+        {
+            const bool want = !has_next;
+            const uint64_t m = __ballot(want);
+            if (m) {
+                const uint64_t cand = next + lanes_below(m);
+                if (want && cand < end) {
+                    const uint4* p = reinterpret_cast<const uint4*>(tasks + cand);
+                    const uint4 r0 = p[0], r1 = p[1], r2 = p[2];
+                    ns0 = (static_cast<uint64_t>(r0.y) << 32) | r0.x;
+                    ns1 = (static_cast<uint64_t>(r0.w) << 32) | r0.z;
+                    ns2 = (static_cast<uint64_t>(r1.y) << 32) | r1.x;
+                    ns3 = (static_cast<uint64_t>(r1.w) << 32) | r1.z;
+                    nobase = (static_cast<uint64_t>(r2.y) << 32) | r2.x;
+                    nn = r2.z;
+                    has_next = true;
+                }
+                next += static_cast<uint64_t>(__popcll(m));
+            }
+        }
+        if (!__any(st != SS_IDLE)) {
+            if (!__any(has_next)) break;
+            continue;
+        }
+        if (st != SS_IDLE) {
+            // ---- one round of reads ----
+            const uint4* pi = ix.blocks;
+            const uint4* pj = ix.blocks;
+            uint32_t bi = 0, bj = 0, tidx = 0;
+            const bool need_blocks = st != SS_EXTSCAN;
+            if (PTABLE && st == SS_LOOKUP) {
+                tidx = static_cast<uint32_t>(kmer >> (2 * (k - T))) & ((1u << (2 * T)) - 1u);
+                pi = reinterpret_cast<const uint4*>(ix.ptable + (tidx & ~7u));
+                pj = pi;
+            } else if (need_blocks) {
+                bi = i >> kBlockRowsLog2;
+                bj = (j - 1u) >> kBlockRowsLog2;
+                pi = ix.blocks + (static_cast<size_t>(bi) << 2);
+                pj = ix.blocks + (static_cast<size_t>(bj) << 2);
+            }
+            const bool two = need_blocks && pj != pi;
+            uint4 b0 = make_uint4(0, 0, 0, 0), b1 = b0, b2 = b0, b3 = b0;
+            uint4 a0 = b0, a1 = b0, a2 = b0, a3 = b0;
+            uint64_t kwi = 0, kwj = 0;
+            // kLCP words: around i-1 / j-1 for a window that will be extended, or the next words of a running scan
+            const bool more = pass == 0 ? widx > 0 : (todo != 0 && (static_cast<uint32_t>(__ffsll(static_cast<unsigned long long>(todo))) - 1u) == widx + 1u);
+            const bool want_klcp = st == SS_HAVE && more;
+            uint32_t wi_idx = 0, wj_idx = 0;
+            if (want_klcp) {
+                wi_idx = (i - 1u) >> 6;
+                wj_idx = (j - 1u) >> 6;
+            } else if (st == SS_EXTSCAN) {
+                wi_idx = (i - 1u) >> 6;   // i, j already moved to the frontier of the scan
+                wj_idx = (j - 1u) >> 6;
+            }
+            if (two) {
+                b0 = pj[0];
+                b1 = pj[1];
+                b2 = pj[2];
+                b3 = pj[3];
+            }
+            if (need_blocks) {
+                a0 = pi[0];
+                a1 = pi[1];
+                a2 = pi[2];
+                a3 = pi[3];
+            }
+            if (want_klcp || (st == SS_EXTSCAN && scan_i)) kwi = klcp[wi_idx];
+            if (want_klcp || (st == SS_EXTSCAN && scan_j)) kwj = klcp[wj_idx];
+            if (need_blocks && !two) {
+                b0 = a0;
+                b1 = a1;
+                b2 = a2;
+                b3 = a3;
+            }
+            if (COUNT) {
+                cn.blocks += (need_blocks ? 1u : 0u) + (two ? 1u : 0u);
+                cn.klcp_words += (want_klcp ? 1u + (wi_idx != wj_idx) : 0u) + (st == SS_EXTSCAN ? scan_i + scan_j : 0u);
+            }
+
+            // ---- arithmetic ----
+            bool do_lf = false;       // perform the LF step of the walk with the loaded blocks
+            uint32_t c = 0;
+            if (st == SS_LOOKUP) {
+                if (COUNT) cn.lookups++;
+                const uint32_t e = (tidx & 7u) >> 1;
+                const uint32_t x0 = sel4(e, opaque(a0.x), opaque(a1.x), opaque(a2.x), opaque(a3.x));
+                const uint32_t x1 = sel4(e, opaque(a0.y), opaque(a1.y), opaque(a2.y), opaque(a3.y));
+                const uint32_t x2 = sel4(e, opaque(a0.z), opaque(a1.z), opaque(a2.z), opaque(a3.z));
+                const uint32_t x3 = sel4(e, opaque(a0.w), opaque(a1.w), opaque(a2.w), opaque(a3.w));
+                i = (tidx & 1u) ? x2 : x0;
+                j = (tidx & 1u) ? x3 : x1;
+                t = k - 1 - T;
+                if (i == j) {
+                    window_done(-1, -1);
+                    advance(false);
+                } else {
+                    st = t < 0 ? SS_HAVE : SS_LF;
+                }
+            } else if (st == SS_LF) {
+                do_lf = true;
+                c = static_cast<uint32_t>(kmer >> (2 * t)) & 3u;
+            } else if (st == SS_EXTLF) {
+                do_lf = true;
+                c = static_cast<uint32_t>(kmer) & 3u;   // kmer already is the next window's: its first base is the new one
+            } else if (st == SS_HAVE) {
+                // result of the current window from the mask plane (infer_presence, fms_index.h:126-144)
+                if (COUNT) cn.probes++;
+                const uint32_t pi_off = i & (kBlockRows - 1u);
+                int res;
+                long long ord = -1;
+                if (mode_all && !orders) {
+                    const uint32_t w = sel4(pi_off >> 5, opaque(a3.x), opaque(a3.y), opaque(a3.z), opaque(a3.w));
+                    res = static_cast<int>((w >> (pi_off & 31u)) & 1u);
+                } else {
+                    uint32_t ones;
+                    const uint32_t pj_off = j - (bj << kBlockRowsLog2);
+                    if (bj == bi) ones = popc_prefix128(a3, pj_off) - popc_prefix128(a3, pi_off);
+                    else ones = (ix.mrank[bj] + popc_prefix128(b3, pj_off)) - (ix.mrank[bi] + popc_prefix128(a3, pi_off));
+                    res = ones > 0u;
+                    if (orders && res) ord = static_cast<long long>(ix.mrank[bi] + popc_prefix128(a3, pi_off));
+                }
+                window_done(res, ord);
+                if (advance(true)) {
+                    // extend_range_with_klcp (fms_index.h:106-115): j grows while klcp[j-1], i shrinks while klcp[i-1]
+                    const uint32_t pj = (j - 1u) & 63u, pi_ = (i - 1u) & 63u;
+                    const uint64_t up = kwj >> pj;                       // bit 0 = klcp[j-1]
+                    const uint32_t run_j = static_cast<uint32_t>(__ffsll(static_cast<unsigned long long>(~up))) - 1u;   // consecutive ones; ~up != 0 unless all 64 set
+                    const uint32_t lim_j = 64u - pj;
+                    const uint64_t dn = kwi << (63u - pi_);              // bit 63 = klcp[i-1]
+                    const uint32_t run_i = static_cast<uint32_t>(__clzll(static_cast<long long>(~dn)));
+                    const uint32_t lim_i = pi_ + 1u;
+                    const uint32_t rj = (~up == 0ull || run_j > lim_j) ? lim_j : run_j;
+                    const uint32_t ri = (~dn == 0ull || run_i > lim_i) ? lim_i : run_i;
+                    scan_j = rj == lim_j ? 1u : 0u;   // ran into the word boundary: keep scanning in the next word
+                    scan_i = (ri == lim_i && i - ri > 0u) ? 1u : 0u;
+                    if (rj == 0u && ri == 0u) {
+                        do_lf = true;                 // common case: same interval, blocks already loaded
+                        c = static_cast<uint32_t>(kmer) & 3u;
+                    } else {
+                        j += rj;
+                        i -= ri;
+                        st = (scan_i | scan_j) ? SS_EXTSCAN : SS_EXTLF;
+                    }
+                }
+            } else if (st == SS_EXTSCAN) {
+                if (scan_j) {
+                    const uint32_t pj = (j - 1u) & 63u;   // 0 by construction
+                    const uint64_t up = kwj >> pj;
+                    const uint32_t run = static_cast<uint32_t>(__ffsll(static_cast<unsigned long long>(~up))) - 1u;
+                    const uint32_t lim = 64u - pj;
+                    const uint32_t r = (~up == 0ull || run > lim) ? lim : run;
+                    j += r;
+                    scan_j = r == lim ? 1u : 0u;
+                }
+                if (scan_i) {
+                    const uint32_t pi_ = (i - 1u) & 63u;  // 63 by construction
+                    const uint64_t dn = kwi << (63u - pi_);
+                    const uint32_t run = static_cast<uint32_t>(__clzll(static_cast<long long>(~dn)));
+                    const uint32_t lim = pi_ + 1u;
+                    const uint32_t r = (~dn == 0ull || run > lim) ? lim : run;
+                    i -= r;
+                    scan_i = (r == lim && i > 0u) ? 1u : 0u;
+                }
+                if (!(scan_i | scan_j)) st = SS_EXTLF;
+            }
+            if (do_lf) {
+                uint32_t ri = rank_in_block(a0, a1, a2, c, i & (kBlockRows - 1u));
+                uint32_t rj = rank_in_block(b0, b1, b2, c, j - (bj << kBlockRowsLog2));
+                if (c == 0u) {
+                    ri -= (i > ix.dollar);
+                    rj -= (j > ix.dollar);
+                }
+                const uint32_t base = sel4(c, ix.C0, ix.C1, ix.C2, ix.C3);
+                i = base + ri;
+                j = base + rj;
+                if (COUNT) cn.lf_steps++;
+                if (st == SS_LF) {
+                    --t;
+                    if (i == j) {
+                        window_done(-1, -1);
+                        advance(false);
+                    } else if (t < 0) {
+                        st = SS_HAVE;
+                    }
+                } else {   // the single step of a streamed window (from SS_HAVE or SS_EXTLF)
+                    if (i == j) {
+                        window_done(-1, -1);
+                        advance(false);
+                    } else {
+                        st = SS_HAVE;
+                    }
+                }
+            }
+        }
+    }
+    if (COUNT) {
+        uint32_t v[7] = {cn.lf_steps, cn.blocks, cn.probes, cn.searches, cn.lookups, cn.klcp_words, 0};
+        const int slot[6] = {0, 1, 2, 3, 4, 5};
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+            uint32_t x = v[q];
+            for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+            if ((threadIdx.x & 63) == 0 && x) atomicAdd(&counters[slot[q]], static_cast<unsigned long long>(x));
+        }
+    }
+}
+
+template <bool COUNT, bool PTABLE>
+void launch_stream(fmsi_hip_index* idx, const TaskRec* recs, uint64_t n_tasks, int k, uint32_t flags, uint8_t* o8, long long* o64,
+                   unsigned long long* d_counters, hipStream_t s) {
+    uint64_t chunk = n_tasks / (256ull * 32 * 8);
+    chunk = std::min<uint64_t>(std::max<uint64_t>(chunk, 64), 1024);
+    const uint64_t waves = (n_tasks + chunk - 1) / chunk;
+    const uint32_t blocks = static_cast<uint32_t>((waves + 3) / 4);
+    hipLaunchKernelGGL((query_stream_kernel<COUNT, PTABLE>), dim3(blocks), dim3(256), 0, s, idx->dev,
+                       static_cast<const uint64_t*>(idx->d_klcp), recs, n_tasks, k, flags, static_cast<uint32_t>(chunk), o8, o64,
+                       d_counters);
+}
+
+}  // namespace
+}  // namespace fmsi
+
+using namespace fmsi;
+
+extern "C" int fmsi_hip_query_stream(fmsi_hip_index* idx, const uint64_t* packed_seq, uint64_t seq_bases, const uint64_t* run_start,
+                                     const uint32_t* run_windows, uint64_t n_runs, uint64_t n_windows, int k, uint32_t flags,
+                                     void* out, uint64_t* counters, void* stream) {
+    if (n_windows == 0 || n_runs == 0) return 0;
+    if (!idx || !packed_seq || !run_start || !run_windows || !out) {
+        set_last_error("null argument");
+        return FMSI_HIP_EINVAL;
+    }
+    if (!idx->d_klcp) {
+        set_last_error("streaming queries need an index created with its kLCP array");
+        return FMSI_HIP_EINVAL;
+    }
+    if (k < 1 || k > 32) {
+        set_last_error("k must be in [1, 32] in this build");
+        return FMSI_HIP_ERANGE;
+    }
+    FMSI_HIP_TRY(hipSetDevice(idx->device));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    // run_start / run_windows are HOST arrays in every mode (one entry per run); tasks are cut here
+    std::vector<TaskDesc> desc;
+    desc.reserve(n_windows / kTaskWindows + n_runs);
+    uint64_t out_pos = 0;
+    for (uint64_t r = 0; r < n_runs; ++r) {
+        uint64_t left = run_windows[r], base = run_start[r];
+        if (base + left + static_cast<uint64_t>(k) - 1 > seq_bases) {
+            set_last_error("a run of windows extends past the end of the sequence");
+            return FMSI_HIP_EINVAL;
+        }
+        while (left) {
+            const uint32_t take = static_cast<uint32_t>(std::min<uint64_t>(left, kTaskWindows));
+            desc.push_back(TaskDesc{base, out_pos, take, 0});
+            base += take;
+            out_pos += take;
+            left -= take;
+        }
+    }
+    if (out_pos != n_windows) {
+        set_last_error("n_windows does not equal the sum of run_windows");
+        return FMSI_HIP_EINVAL;
+    }
+    const uint64_t n_tasks = desc.size();
+    const bool dev_ptrs = flags & FMSI_HIP_DEVICE_PTRS;
+    const size_t out_bytes = n_windows * ((flags & FMSI_HIP_ORDERS) ? ((flags & FMSI_HIP_STRICT) ? 16 : 8) : 1);
+    const size_t seq_bytes = (seq_bases / 32 + 2) * 8;
+    int rc;
+    const uint64_t* d_seq = packed_seq;
+    void* d_out = out;
+    unsigned long long* d_cnt = reinterpret_cast<unsigned long long*>(counters);
+    if (!dev_ptrs) {
+        if ((rc = ensure_cap(&idx->d_in, &idx->d_in_cap, seq_bytes))) return rc;
+        if ((rc = ensure_cap(&idx->d_out, &idx->d_out_cap, out_bytes))) return rc;
+        FMSI_HIP_TRY(hipMemcpyAsync(idx->d_in, packed_seq, seq_bytes, hipMemcpyHostToDevice, s));
+        d_seq = static_cast<const uint64_t*>(idx->d_in);
+        d_out = idx->d_out;
+        if (counters) {
+            FMSI_HIP_TRY(hipMemcpyAsync(idx->d_counters, counters, FMSI_HIP_N_COUNTERS * 8, hipMemcpyHostToDevice, s));
+            d_cnt = idx->d_counters;
+        }
+    }
+    // descriptors, then records, in one staging buffer
+    const size_t desc_bytes = (n_tasks * sizeof(TaskDesc) + 63) / 64 * 64;
+    if ((rc = ensure_cap(&idx->d_tasks, &idx->d_tasks_cap, desc_bytes + n_tasks * sizeof(TaskRec)))) return rc;
+    auto* d_desc = static_cast<TaskDesc*>(idx->d_tasks);
+    auto* d_rec = reinterpret_cast<TaskRec*>(static_cast<char*>(idx->d_tasks) + desc_bytes);
+    FMSI_HIP_TRY(hipMemcpyAsync(d_desc, desc.data(), n_tasks * sizeof(TaskDesc), hipMemcpyHostToDevice, s));
+    FMSI_HIP_TRY(hipStreamSynchronize(s));   // `desc` is a local vector: the copy must finish before it dies
+    hipLaunchKernelGGL(stream_prep_kernel, dim3(static_cast<uint32_t>((n_tasks + 255) / 256)), dim3(256), 0, s, d_seq, d_desc, n_tasks,
+                       seq_bases / 32 + 2, d_rec);
+    FMSI_HIP_TRY(hipGetLastError());
+    const bool use_table = idx->d_ptable && !(flags & FMSI_HIP_NO_PREFIX_TABLE) && k >= idx->prefix_len;
+    size_t slot;
+    if ((rc = prof_begin(idx, s, &slot))) return rc;
+    uint8_t* o8 = static_cast<uint8_t*>(d_out);
+    long long* o64 = static_cast<long long*>(d_out);
+    if (use_table) {
+        if (d_cnt) launch_stream<true, true>(idx, d_rec, n_tasks, k, flags, o8, o64, d_cnt, s);
+        else launch_stream<false, true>(idx, d_rec, n_tasks, k, flags, o8, o64, d_cnt, s);
+    } else {
+        if (d_cnt) launch_stream<true, false>(idx, d_rec, n_tasks, k, flags, o8, o64, d_cnt, s);
+        else launch_stream<false, false>(idx, d_rec, n_tasks, k, flags, o8, o64, d_cnt, s);
+    }
+    FMSI_HIP_TRY(hipGetLastError());
+    if ((rc = prof_end(idx, s, slot))) return rc;
+    if (!dev_ptrs) {
+        FMSI_HIP_TRY(hipMemcpyAsync(out, idx->d_out, out_bytes, hipMemcpyDeviceToHost, s));
+        if (counters) FMSI_HIP_TRY(hipMemcpyAsync(counters, idx->d_counters, FMSI_HIP_N_COUNTERS * 8, hipMemcpyDeviceToHost, s));
+    }
+    return 0;
+}

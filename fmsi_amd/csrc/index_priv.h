@@ -56,6 +56,7 @@ struct fmsi_hip_index {
     void* d_aux = nullptr; size_t d_aux_cap = 0;
     void* d_out = nullptr; size_t d_out_cap = 0;
     void* d_kmers = nullptr; size_t d_kmers_cap = 0;   // windows -> packed k-mers
+    void* d_tasks = nullptr; size_t d_tasks_cap = 0;   // streaming task descriptors + records
     unsigned long long* d_counters = nullptr;
     // profiling
     bool profiling = false;
@@ -68,4 +69,36 @@ struct fmsi_hip_index {
 namespace fmsi {
 // builds the optional prefix table on the device (fmsi_hip.hip)
 int build_prefix_table(fmsi_hip_index* idx, int t);
+
+// grow-only device staging buffer
+inline int ensure_cap(void** p, size_t* cap, size_t need) {
+    if (need <= *cap) return 0;
+    if (*p) (void)hipFree(*p);
+    *p = nullptr;
+    *cap = 0;
+    const size_t want = need > (size_t(1) << 20) ? need : (size_t(1) << 20);
+    FMSI_HIP_TRY(hipMalloc(p, want));
+    *cap = want;
+    return 0;
 }
+
+// HIP events around a kernel launch on the launch stream (fmsi_hip_profile_*)
+inline int prof_begin(fmsi_hip_index* idx, hipStream_t s, size_t* slot) {
+    *slot = static_cast<size_t>(-1);
+    if (!idx->profiling) return 0;
+    if (idx->events_used == idx->events.size()) {
+        hipEvent_t a, b;
+        FMSI_HIP_TRY(hipEventCreate(&a));
+        FMSI_HIP_TRY(hipEventCreate(&b));
+        idx->events.emplace_back(a, b);
+    }
+    *slot = idx->events_used++;
+    FMSI_HIP_TRY(hipEventRecord(idx->events[*slot].first, s));
+    return 0;
+}
+inline int prof_end(fmsi_hip_index* idx, hipStream_t s, size_t slot) {
+    if (slot == static_cast<size_t>(-1)) return 0;
+    FMSI_HIP_TRY(hipEventRecord(idx->events[slot].second, s));
+    return 0;
+}
+}  // namespace fmsi

@@ -98,11 +98,15 @@ struct Batch {
     std::vector<uint64_t> packed;        // 2-bit bases of all runs, concatenated
     uint64_t bases = 0;
     std::vector<uint64_t> window_start;  // per window: first base in `packed`
+    std::vector<uint64_t> run_start;     // per run of consecutive windows: first base / number of windows (-S kernel)
+    std::vector<uint32_t> run_windows;
     void clear() {
         records.clear();
         packed.assign(2, 0);
         bases = 0;
         window_start.clear();
+        run_start.clear();
+        run_windows.clear();
     }
 };
 
@@ -142,6 +146,10 @@ void plan_record(Batch& b, const std::string& name, const std::string& seq, int 
             const uint64_t base0 = b.bases;
             append_bases(b, sequence, static_cast<uint64_t>(current_length));
             for (uint64_t w = 0; w < windows; ++w) b.window_start.push_back(base0 + w);
+            for (uint64_t w = 0; w < windows; w += 0x40000000ull) {   // run lengths are 32-bit in the C-ABI
+                b.run_start.push_back(base0 + w);
+                b.run_windows.push_back(static_cast<uint32_t>(std::min<uint64_t>(windows - w, 0x40000000ull)));
+            }
             rp.ops.push_back({true, windows});
             // the reference consumes chunk_length - k + 1 characters per chunk: k - 1 remain
             sequence += windows;
@@ -363,10 +371,15 @@ extern "C" int fmsi_cli_query(int argc, char** argv, int output_orders_i) {
             else R.bytes.resize(nw);
             auto t0 = clock::now();
             if (nw) {
-                check(fmsi_hip_query_windows(dev, batch.packed.data(), batch.bases, batch.window_start.data(), nw, k, flags,
-                                             output_orders ? static_cast<void*>(R.orders.data()) : static_cast<void*>(R.bytes.data()),
-                                             nullptr, nullptr),
-                      "fmsi_hip_query_windows");
+                void* dst = output_orders ? static_cast<void*>(R.orders.data()) : static_cast<void*>(R.bytes.data());
+                if (opt.has_klcp)   // -S: kLCP streaming kernel (query_kmers_streaming, src/fms_index.h:181-254)
+                    check(fmsi_hip_query_stream(dev, batch.packed.data(), batch.bases, batch.run_start.data(), batch.run_windows.data(),
+                                                batch.run_start.size(), nw, k, flags, dst, nullptr, nullptr),
+                          "fmsi_hip_query_stream");
+                else
+                    check(fmsi_hip_query_windows(dev, batch.packed.data(), batch.bases, batch.window_start.data(), nw, k, flags, dst,
+                                                 nullptr, nullptr),
+                          "fmsi_hip_query_windows");
                 check(fmsi_hip_sync(dev, nullptr), "fmsi_hip_sync");
             }
             gpu_s += std::chrono::duration<double>(clock::now() - t0).count();

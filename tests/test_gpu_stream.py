@@ -1,0 +1,134 @@
+"""GPU tests of the kLCP streaming kernel (fmsi_hip_query_stream, counterpart of query_kmers_streaming<>(),
+reference src/fms_index.h:181-254): per-window results must equal fresh searches of both strands (oracle), for
+any cut of the sequences into runs, incl. indexes with long kLCP runs (repeats) that exercise the multi-word scan."""
+import random
+
+import numpy as np
+import pytest
+
+import oracle_py
+from conftest import DATASETS, GOLDEN, index_prefix, mixed_kmers, revcomp, synthetic_ms
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def fm(product_built):
+    if product_built.device_count() < 1:
+        pytest.fail("no HIP device visible")
+    return product_built
+
+
+def expected_fast(fwd, rc, mode_all):
+    if mode_all:
+        return np.where(fwd != -1, fwd, rc) == 1
+    return (fwd == 1) | (rc == 1)
+
+
+def run_case(fm, orc, dev, reads, k, check_orders=True):
+    """reads: list of ACGT strings (len >= k).  Packs them back to back, one run per read."""
+    seq = "".join(reads)
+    words = fm.pack_sequence(seq.encode())
+    starts, wins, kmers = [], [], []
+    pos = 0
+    for r in reads:
+        starts.append(pos)
+        wins.append(len(r) - k + 1)
+        kmers += [r[i:i + k] for i in range(len(r) - k + 1)]
+        pos += len(r)
+    raw = "".join(kmers).encode()
+    n = len(kmers)
+    for mode_all in (False, True):
+        flag = fm.MODE_ALL if mode_all else fm.MODE_OR
+        fwd, rc = orc.ternaries_bulk(raw, n, k, mode_all)
+        gf, gr = fm.decode_strict(dev.query_stream(words, len(seq), starts, wins, k, flag | fm.STRICT))
+        assert np.array_equal(gf, fwd), (mode_all, np.nonzero(gf != fwd)[0][:10])
+        assert np.array_equal(gr, rc), (mode_all, np.nonzero(gr != rc)[0][:10])
+        fast = dev.query_stream(words, len(seq), starts, wins, k, flag)
+        assert np.array_equal(fast.astype(bool), expected_fast(fwd, rc, mode_all))
+        # same answers without the prefix table and from the non-streaming kernel
+        assert np.array_equal(dev.query_stream(words, len(seq), starts, wins, k, flag | fm.NO_PREFIX_TABLE), fast)
+        assert np.array_equal(dev.query_kmers(fm.pack_kmers(kmers, k), k, flag), fast)
+    if check_orders:
+        fwd, rc, of, orr = orc.ternaries_bulk(raw, n, k, False, orders=True)
+        got = dev.query_stream(words, len(seq), starts, wins, k, fm.ORDERS | fm.STRICT)
+        assert np.array_equal(got[:, 0], of) and np.array_equal(got[:, 1], orr)
+        got1 = dev.query_stream(words, len(seq), starts, wins, k, fm.ORDERS)
+        assert np.array_equal(got1, np.where(of >= 0, of, orr))
+
+
+def ms_of(name):
+    f = {"integration_a": "ref_data/integration_a.fa", "integration_b": "ref_data/integration_b.fa",
+         "sars_k13": "ref_data/GCF_009858895.2_ASM985889v3_genomic.fna.ms.k13", "sars_k31": "ref_data/GCF_test2_ones.fna.ms.k31",
+         "mixed_k11": "mixed.fa"}[name]
+    return "".join(l.strip() for l in open(GOLDEN / f) if not l.startswith(">"))
+
+
+@pytest.mark.parametrize("name", ["sars_k13", "sars_k31", "mixed_k11", "integration_a"])
+def test_stream_equals_oracle(fm, oracle_built, name):
+    k = DATASETS[name][0]
+    orc = oracle_py.Oracle.load(index_prefix(name))
+    dev = fm.DeviceIndex.from_files(index_prefix(name), use_klcp=True, prefix_len=min(k, 5))
+    ms = ms_of(name).upper()
+    rng = random.Random(11)
+    reads = []
+    if len(ms) > 500:
+        for _ in range(60):
+            L = rng.choice([k, k + 1, k + 5, 63 + k, 64 + k, 65 + k, 150, 400])
+            p = rng.randrange(0, len(ms) - L)
+            r = ms[p:p + L]
+            if rng.random() < 0.5:
+                r = revcomp(r)
+            if rng.random() < 0.5:   # a few substitutions: mixes hit and miss stretches
+                r = "".join(rng.choice("ACGT") if rng.random() < 0.02 else ch for ch in r)
+            reads.append(r)
+        reads += ["".join(rng.choice("ACGT") for _ in range(200)) for _ in range(5)]
+        reads.append(ms[100:100 + 3000])              # a long run: many tasks
+        reads.append(revcomp(ms[4000:4000 + 2500]))
+    else:
+        reads = ["ACGTACGTACG", "TACGTAC", "ACG", "GGGGGGG", "CGTACGTA" * 20]
+    run_case(fm, orc, dev, reads, k)
+
+
+def test_stream_on_repetitive_index(fm, oracle_built, tmp_path):
+    """Long runs of set kLCP bits (many rows sharing a (k-1)-mer): the extension crosses 64-bit words and blocks."""
+    k = 9
+    rng = random.Random(3)
+    unit = "".join(rng.choice("ACGT") for _ in range(40))
+    ms = unit * 150 + "".join(rng.choice("ACGT") for _ in range(3000)) + "A" * 700 + unit[:20] * 30
+    ms = "".join(ch if rng.random() < 0.7 else ch.lower() for ch in ms)
+    ms = ms[: len(ms) - (k - 1)].rstrip() + ms[len(ms) - (k - 1):].lower()
+    orc = oracle_py.Oracle.construct(ms, k, use_klcp=True)
+    prefix = str(tmp_path / "rep")
+    orc.dump(prefix)
+    dev = fm.DeviceIndex.from_files(prefix, use_klcp=True, prefix_len=4)
+    up = ms.upper()
+    reads = [up[0:400], up[5990:6300], revcomp(up[100:500]), "A" * 100, up[9000:9400], revcomp(up[9100:9700]), unit * 3,
+             "".join(rng.choice("ACGT") for _ in range(300))]
+    run_case(fm, orc, dev, reads, k)
+
+
+def test_stream_argument_errors(fm):
+    dev_no = fm.DeviceIndex.from_files(index_prefix("sars_k31"), use_klcp=False)
+    words = fm.pack_sequence(b"ACGT" * 20)
+    with pytest.raises(fm.FmsiError):
+        dev_no.query_stream(words, 80, [0], [50], 31)            # no kLCP in the handle
+    dev = fm.DeviceIndex.from_files(index_prefix("sars_k31"), use_klcp=True)
+    with pytest.raises(fm.FmsiError):
+        dev.query_stream(words, 80, [0], [51], 31)               # run past the end
+    assert dev.query_stream(words, 80, [], [], 31).size == 0
+
+
+def test_stream_counters_positive_read(fm, oracle_built):
+    """On a read taken from the superstring a streamed window costs one LF step: the kernel's step counter must
+    be close to one per window (plus one fresh search per 64-window task and strand)."""
+    name, k = "sars_k31", 31
+    dev = fm.DeviceIndex.from_files(index_prefix(name), use_klcp=True)
+    ms = ms_of(name).upper()
+    read = ms[1000:1000 + 6400 + k - 1]
+    words = fm.pack_sequence(read.encode())
+    out, cn = dev.query_stream(words, len(read), [0], [6400], k, fm.MODE_ALL, counters=True)
+    assert (out == 1).all()
+    assert 6400 <= int(cn[0]) <= 6400 + 100 * (k + 1)
+    out2, cn2 = dev.query_windows(words, len(read), k, fm.MODE_ALL, counters=True)
+    assert np.array_equal(out, out2) and int(cn2[0]) == 6400 * k
