@@ -2,27 +2,31 @@
 """bench.py -- k-mer membership queries/s (k = 31) of the MI355X `fmsi query` hot path.
 
 Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 it is launched by
-torch.distributed.run with one rank per GPU.  One "step" = one pass of the hot path (fmsi_hip_query_kmers,
-`-O` semantics, forward strand first) over one batch of synthetic isolated 31-mers that is already
-resident in HBM; W untimed steps, then exactly K timed steps bracketed by barrier + synchronize, MAX over
-ranks, one JSON line from rank 0.
+torch.distributed.run with one rank per GPU.  One "step" = one pass of the hot path over one batch of
+synthetic queries that is already resident in HBM; W untimed steps, then exactly K timed steps bracketed by
+barrier + synchronize, MAX over ranks, one JSON line from rank 0.
 
-Workload (BASELINE.json: human-genome-scale masked superstring, isolated random 31-mers, half of them
-present): a synthetic max-ones superstring of --n bases generated and indexed on the device
-(fmsi_hip_index_build_synthetic), replicated per GPU; the query stream (seeded, counter based) is sharded
-across ranks by contiguous ranges -- weak scaling, no collective on the data path; the results of the
-last step are gathered to rank 0 over RCCL after the timed region (that is the reference's stdout order).
+Workloads (BASELINE.json configs; all on a synthetic max-ones masked superstring of --n bases that is
+generated and indexed on the device, replicated per GPU):
+  --workload kmers   (default; configs 2/3/5) isolated random 31-mers, half of them present (half of those as the
+                     reverse complement), `fmsi query -O` semantics: fmsi_hip_query_kmers, forward strand first.
+  --workload stream  (config 4) reads of --read-len bases (half substrings of the superstring, half of those
+                     reverse-complemented; half uniform random), `fmsi query -S -O`: fmsi_hip_query_stream (kLCP).
+The seeded, counter-based query stream is sharded across ranks by contiguous ranges -- weak scaling, no collective
+on the data path; the results of the last step are gathered to rank 0 over RCCL after the timed region.
 
 Extra objects on the JSON line:
-  roofline     -- HBM bound.  `achieved` = algorithmic bytes of one launch / average kernel duration, where the
-                  bytes are 64 B x (interleaved blocks + prefix-table lines the kernel's own counters report for
-                  this layout) + 8 B k-mer in + 1 B result out per window, and the duration comes from HIP events
-                  recorded on the launch stream inside the library.  `canonical_achieved` applies SURVEY 8(d)'s
-                  reference-layout formula (256 B per LF step the REFERENCE algorithm would execute for the same
-                  queries + 64 B per mask probe + in/out) to the same time; it can exceed the HBM peak because the
-                  fused layout and the prefix table touch far fewer bytes than the reference's structures.
+  roofline     -- HBM bound.  `achieved` = algorithmic bytes of one launch / average kernel duration.  The bytes are
+                  what this layout must touch, counted by the kernel itself: 64 B per interleaved block or prefix-table
+                  line read (+ 8 B per kLCP word when streaming) + query bytes in + 1 B result out per window; the
+                  duration comes from HIP events recorded on the launch stream inside the library.
+                  `canonical_achieved` applies SURVEY 8(d)'s reference-layout formula (256 B per LF step the REFERENCE
+                  algorithm executes for the same queries + 64 B per mask probe + in/out) to the same time; it can
+                  exceed the HBM peak because the fused layout and the prefix table touch far fewer bytes.
+                  `traffic` = HBM bytes per launch from the rocprofv3 PMC passes committed under profiles/ (only when
+                  the profiled configuration is the one being run).
   cpu_baseline -- the real reference (oracle/_ref, kind "reference") or the C restatement (kind "port") timed on
-                  this box's host cores on a bounded sample of the same queries against the same index.
+                  this box's host cores on a bounded sample of the same queries against the same index (bench_cpu.py).
 """
 import argparse
 import json
@@ -42,17 +46,38 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", choices=["kmers", "stream"], default="kmers")
     ap.add_argument("--n", type=float, default=2.8e9, help="superstring length in bases (human scale: 2.8e9)")
-    ap.add_argument("--batch", type=float, default=float(1 << 27), help="query k-mers per step and GPU")
+    ap.add_argument("--batch", type=float, default=float(1 << 27), help="query windows per step and GPU")
     ap.add_argument("--k", type=int, default=31)
     ap.add_argument("--prefix-len", type=int, default=12, help="private prefix table length t (0 = none)")
     ap.add_argument("--kernel", choices=["refill", "lockstep"], default="refill")
     ap.add_argument("--mode", choices=["all", "or"], default="all")
+    ap.add_argument("--read-len", type=int, default=10000, help="stream workload: bases per read")
+    ap.add_argument("--subst-ppm", type=int, default=0, help="stream workload: substitutions per million bases of positive reads")
     ap.add_argument("--seed", type=int, default=12345)
     ap.add_argument("--query-seed", type=int, default=42)
-    ap.add_argument("--cpu-sample", type=int, default=-1, help="k-mers for the CPU baseline (-1 = auto, 0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=-1, help="windows for the CPU baseline (-1 = auto, 0 = skip)")
     ap.add_argument("--no-counters", action="store_true")
     return ap.parse_args()
+
+
+def pmc_traffic(args, n, batch, k):
+    """HBM bytes per launch of the timed kernel from the rocprofv3 PMC passes committed under profiles/
+    (FETCH_SIZE and WRITE_SIZE in separate passes, calibrated on random 64-B reads: profiles/README.md).
+    bench.py cannot collect PMC counters itself; the figure is attached only when the run's configuration is
+    the one that was profiled, otherwise null."""
+    best = None
+    for p in sorted((REPO / "profiles").glob("r*_traffic*.json")):
+        try:
+            t = json.loads(p.read_text())
+        except (OSError, ValueError):
+            continue
+        c = t.get("config", {})
+        if (c.get("workload", "kmers"), c.get("n"), c.get("batch"), c.get("k"), c.get("prefix_len"), c.get("mode")) == \
+                (args.workload, n, batch, k, args.prefix_len, args.mode) and args.kernel in t.get("kernel", args.kernel):
+            best = t
+    return None if best is None else best["hbm_bytes_per_launch"]
 
 
 def main():
@@ -72,62 +97,81 @@ def main():
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
     torch.cuda.set_device(local_rank)
     dev_t = torch.device("cuda", local_rank)
+    stream_mode = args.workload == "stream"
 
     n = int(args.n)
     k = args.k
-    batch = int(args.batch)
     t0 = time.time()
-    index = fm.DeviceIndex.build_synthetic(n, args.seed, k, with_klcp=False, device=local_rank, prefix_len=args.prefix_len)
+    index = fm.DeviceIndex.build_synthetic(n, args.seed, k, with_klcp=stream_mode, device=local_rank, prefix_len=args.prefix_len)
     build_s = time.time() - t0
     flags = fm.MODE_ALL if args.mode == "all" else fm.MODE_OR
-    flags |= fm.KERNEL_LOCKSTEP if args.kernel == "lockstep" else fm.KERNEL_REFILL
-
+    if not stream_mode:
+        flags |= fm.KERNEL_LOCKSTEP if args.kernel == "lockstep" else fm.KERNEL_REFILL
     stream = torch.cuda.current_stream().cuda_stream
-    d_kmers = torch.empty(batch, dtype=torch.int64, device=dev_t)
+
+    # ---- one step's input, resident in HBM ----------------------------------------------------------------
+    if stream_mode:
+        L = args.read_len
+        n_reads = max(1, int(args.batch) // (L - k + 1))
+        batch = n_reads * (L - k + 1)                       # windows per step and GPU
+        run_start = np.arange(n_reads, dtype=np.uint64) * np.uint64(L)
+        run_windows = np.full(n_reads, L - k + 1, dtype=np.uint32)
+        in_words = n_reads * L // 32 + 2
+        in_bytes = n_reads * L / 4.0
+
+        def make_input(step, buf):
+            index.synthetic_reads_dev(L, args.query_seed, (step * world + rank) * n_reads, n_reads, buf.data_ptr(), args.subst_ppm, stream)
+
+        def launch(buf, out, counters_ptr=0, extra=0):
+            index.query_stream_dev(buf.data_ptr(), n_reads * L, run_start, run_windows, k, flags | extra, out.data_ptr(), counters_ptr, stream)
+    else:
+        batch = int(args.batch)
+        in_words = batch
+        in_bytes = 8.0 * batch
+
+        def make_input(step, buf):
+            # rank r owns the contiguous range [r*batch, (r+1)*batch) of every step's global batch (weak scaling)
+            index.synthetic_queries_dev(k, args.query_seed, (step * world + rank) * batch, batch, buf.data_ptr(), stream)
+
+        def launch(buf, out, counters_ptr=0, extra=0):
+            index.query_kmers_dev(buf.data_ptr(), batch, k, flags | extra, out.data_ptr(), counters_ptr, stream)
+
     d_out = torch.empty(batch, dtype=torch.uint8, device=dev_t)
     d_cnt = torch.zeros(fm.N_COUNTERS, dtype=torch.int64, device=dev_t)
-
-    def gen(step):
-        # rank r owns the contiguous range [r*batch, (r+1)*batch) of every step's global batch (weak scaling)
-        first = (step * world + rank) * batch
-        index.synthetic_queries_dev(k, args.query_seed, first, batch, d_kmers.data_ptr(), stream)
+    n_buf = max(1, min(args.steps, 4))
+    bufs = [torch.empty(in_words, dtype=torch.int64, device=dev_t) for _ in range(n_buf)]
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    # warmup (also: one counted launch to obtain the algorithmic byte counts for this query distribution)
-    gen(0)
-    for w in range(max(args.warmup, 1)):
-        index.query_kmers_dev(d_kmers.data_ptr(), batch, k, flags, d_out.data_ptr(), stream=stream)
-    counters = None
+    # ---- warmup, plus counted launches that supply the algorithmic byte counts ----------------------------
+    make_input(0, bufs[0])
+    for _ in range(max(args.warmup, 1)):
+        launch(bufs[0], d_out)
+    counters = canonical = None
     if not args.no_counters:
         d_cnt.zero_()
-        index.query_kmers_dev(d_kmers.data_ptr(), batch, k, flags, d_out.data_ptr(), counters_ptr=d_cnt.data_ptr(), stream=stream)
+        launch(bufs[0], d_out, d_cnt.data_ptr())
         torch.cuda.synchronize()
         counters = d_cnt.cpu().numpy().astype(np.int64)
-    # canonical step count: what the reference algorithm (no prefix table) executes for the same queries
-    canonical = None
-    if not args.no_counters:
+        # what the reference algorithm executes for the same queries: no prefix table (and, for the stream workload,
+        # its own chunking is longer than a 64-window task, so this is an upper bound on its steps)
         d_cnt.zero_()
-        index.query_kmers_dev(d_kmers.data_ptr(), batch, k, flags | fm.NO_PREFIX_TABLE, d_out.data_ptr(), counters_ptr=d_cnt.data_ptr(),
-                              stream=stream)
+        launch(bufs[0], d_out, d_cnt.data_ptr(), fm.NO_PREFIX_TABLE)
         torch.cuda.synchronize()
         canonical = d_cnt.cpu().numpy().astype(np.int64)
     positives = float(d_out.to(torch.float32).mean().item())
 
-    # the query batches of the timed steps are generated before the timed region (inputs resident in HBM)
-    n_buf = min(args.steps, 4)
-    bufs = [torch.empty(batch, dtype=torch.int64, device=dev_t) for _ in range(n_buf)]
     for s in range(n_buf):
-        index.synthetic_queries_dev(k, args.query_seed, ((s + 1) * world + rank) * batch, batch, bufs[s].data_ptr(), stream)
+        make_input(s + 1, bufs[s])
     index.profile(True)
     index.profile_read(reset=True)
     barrier()
     t0 = time.perf_counter()
     for s in range(args.steps):
-        index.query_kmers_dev(bufs[s % n_buf].data_ptr(), batch, k, flags, d_out.data_ptr(), stream=stream)
+        launch(bufs[s % n_buf], d_out)
     barrier()
     elapsed = time.perf_counter() - t0
     launches, kernel_ms = index.profile_read(reset=True)
@@ -139,14 +183,9 @@ def main():
     elapsed_max = float(el.item())
 
     # gather the last step's results to rank 0 (rank order = output order); outside the timed region
-    gathered = None
     if world > 1:
         parts = [torch.empty_like(d_out) for _ in range(world)] if rank == 0 else None
         dist.gather(d_out, parts, dst=0)
-        if rank == 0:
-            gathered = torch.cat(parts)
-    else:
-        gathered = d_out
 
     if rank == 0:
         total_q = batch * world * args.steps
@@ -154,71 +193,54 @@ def main():
         avg_kernel_s = kernel_ms / max(launches, 1) / 1e3
         roof = None
         if counters is not None:
-            blocks_read, lookups = int(counters[1]), int(counters[4])
+            blocks_read, lookups, klcp_words = int(counters[1]), int(counters[4]), int(counters[5])
             # blocks_read already contains the prefix-table lines (one 64-B line per lookup)
-            bytes_launch = 64 * blocks_read + 8 * batch + 1 * batch
-            canon_bytes = 256 * int(canonical[0]) + 64 * int(canonical[2]) + 8 * batch + batch // 8
+            bytes_launch = 64 * blocks_read + 8 * klcp_words + in_bytes + 1 * batch
+            canon_bytes = 256 * int(canonical[0]) + 64 * int(canonical[2]) + 8 * int(canonical[5]) + in_bytes + batch // 8
             ach = bytes_launch / avg_kernel_s / 1e9
             roof = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(args, n, batch, k),
-                    "kernel": f"query_{args.kernel}_kernel", "avg_kernel_ms": round(avg_kernel_s * 1e3, 4), "launches": launches,
-                    "algorithmic_bytes_per_launch": bytes_launch,
+                    "kernel": "query_stream_kernel" if stream_mode else f"query_{args.kernel}_kernel",
+                    "avg_kernel_ms": round(avg_kernel_s * 1e3, 4), "launches": launches,
+                    "algorithmic_bytes_per_launch": int(bytes_launch),
                     "bytes_per_kmer": round(bytes_launch / batch, 1),
                     "lf_steps_per_kmer": round(int(counters[0]) / batch, 3),
                     "blocks_per_kmer": round(blocks_read / batch, 3), "table_lookups_per_kmer": round(lookups / batch, 3),
-                    "random_requests_per_s": round(blocks_read / avg_kernel_s / 1e9, 2),
+                    "klcp_words_per_kmer": round(klcp_words / batch, 3),
+                    "random_requests_per_s": round((blocks_read + klcp_words) / avg_kernel_s / 1e9, 2),
                     "canonical_lf_steps_per_kmer": round(int(canonical[0]) / batch, 3),
                     "canonical_achieved": round(canon_bytes / avg_kernel_s / 1e9, 1),
                     "canonical_frac": round(canon_bytes / avg_kernel_s / 1e9 / HBM_PEAK_GBS, 4)}
         info = index.info
+        if stream_mode:
+            wl = (f"synthetic max-ones masked superstring n={n} (human-genome scale), reads of {args.read_len} bases (50% from the "
+                  f"superstring, half of those reverse-complemented, {args.subst_ppm} substitutions per million), every {k}-mer window, "
+                  f"fmsi query -S -O semantics (kLCP streaming)")
+        else:
+            wl = (f"synthetic max-ones masked superstring n={n} (human-genome scale), isolated random {k}-mers 50% present, "
+                  f"fmsi query -O semantics")
         line = {
             "metric": "k-mer membership queries/sec (k=31)", "value": value, "unit": "k-mers/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed_max / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
-            "config": {"workload": f"synthetic max-ones masked superstring n={n} (human-genome scale), isolated random {k}-mers "
-                                   f"50% present, fmsi query -O semantics", "index_rows": int(info.n), "k": k,
-                       "queries_per_step_per_gpu": batch, "mode": args.mode, "kernel": args.kernel,
-                       "prefix_table_len": int(info.prefix_len), "index_bytes_hbm": int(info.device_bytes),
-                       "block_bytes": int(info.block_bytes), "parallelism": f"query-sharded x{world}, index replicated",
-                       "positive_fraction": round(positives, 4), "index_build_seconds": round(build_s, 2)},
+            "config": {"workload": wl, "index_rows": int(info.n), "k": k, "queries_per_step_per_gpu": batch, "mode": args.mode,
+                       "kernel": "stream" if stream_mode else args.kernel, "prefix_table_len": int(info.prefix_len),
+                       "index_bytes_hbm": int(info.device_bytes), "block_bytes": int(info.block_bytes),
+                       "parallelism": f"query-sharded x{world}, index replicated", "positive_fraction": round(positives, 4),
+                       "index_build_seconds": round(build_s, 2)},
             "roofline": roof,
             "cpu_baseline": None,
         }
         if args.cpu_sample != 0:
             try:
-                line["cpu_baseline"] = cpu_baseline(args, index, n, k)
+                import bench_cpu   # the only part of the benchmark that touches oracle/
+                line["cpu_baseline"] = bench_cpu.run_stream(args, index, n, k) if stream_mode else bench_cpu.run(args, index, n, k)
             except Exception as e:   # the baseline is a reported figure, never a reason to lose the GPU line
                 line["cpu_baseline"] = {"error": repr(e)}
         print(json.dumps(line))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
-
-
-def pmc_traffic(args, n, batch, k):
-    """HBM bytes per launch of the timed kernel from the rocprofv3 PMC passes committed under profiles/
-    (FETCH_SIZE and WRITE_SIZE in separate passes, calibrated on random 64-B reads: profiles/README.md).
-    bench.py cannot collect PMC counters itself; the figure is attached only when the run's configuration is
-    the one that was profiled, otherwise null."""
-    best = None   # returns bytes per launch (FETCH_SIZE + WRITE_SIZE) or None
-    for p in sorted((REPO / "profiles").glob("r*_traffic.json")):
-        try:
-            t = json.loads(p.read_text())
-        except (OSError, ValueError):
-            continue
-        c = t.get("config", {})
-        if (c.get("n"), c.get("batch"), c.get("k"), c.get("prefix_len"), c.get("mode")) == (n, batch, k, args.prefix_len, args.mode) \
-                and args.kernel in t.get("kernel", ""):
-            best = t
-    if best is None:
-        return None
-    return best["hbm_bytes_per_launch"]
-
-
-def cpu_baseline(args, index, n, k):
-    """Filled in by oracle-side code (bench_cpu.py); kept separate so the GPU path never imports oracle/."""
-    import bench_cpu
-    return bench_cpu.run(args, index, n, k)
 
 
 if __name__ == "__main__":

@@ -5,9 +5,11 @@ draws a bounded sample of the same seeded query stream, and times
   kind "reference": the real reference's query_kmers() loop (oracle/_ref, built from /root/reference in the build
                     container and shipped as a binary), or
   kind "port"     : the oracle's C restatement, when oracle/_ref is not present,
-single-threaded (the reference has no threading) and, as `socket_value`, with one forked worker per core of one
-socket on disjoint query shards over the shared read-only index.  It also checks the sample against the GPU.
+single-threaded (the reference has no threading) and, as `socket_value`, with one forked worker per core the box
+grants (one socket's physical cores, capped by the container's cgroup CPU quota) on disjoint query shards over the
+shared read-only index.  It also checks the sample against the GPU's answers.
 """
+import ctypes as C
 import os
 import sys
 import tempfile
@@ -20,49 +22,6 @@ REPO = Path(__file__).resolve().parent
 sys.path.insert(0, str(REPO / "oracle"))
 
 
-def _planes(index):
-    blocks, _ = index.download_layout()
-    n = int(index.info.n)
-    words = (n + 63) // 64 + 1
-    out = []
-    for lo in (4, 8, 12):
-        plane = np.ascontiguousarray(blocks[:, lo:lo + 4]).reshape(-1).view(np.uint64)
-        out.append(np.ascontiguousarray(plane[:words]))
-    return out, n
-
-
-def _kmers_to_text(kmers: np.ndarray, k: int) -> bytes:
-    codes = ((kmers[:, None] >> (2 * np.arange(k, dtype=np.uint64))) & np.uint64(3)).astype(np.uint8)
-    return np.frombuffer(b"ACGT", dtype=np.uint8)[codes].tobytes()
-
-
-def _forked_rate(obj, text: bytes, n_each: int, k: int, mode: int, workers: int):
-    """One forked worker per core on disjoint shards; returns aggregate k-mers/s (max worker time)."""
-    pipes = []
-    t0 = time.perf_counter()
-    for w in range(workers):
-        r, wr = os.pipe()
-        pid = os.fork()
-        if pid == 0:
-            os.close(r)
-            try:
-                shard = text[w * n_each * k:(w + 1) * n_each * k]
-                sec, _ = obj.time_isolated_kmers(shard, n_each, k, mode)
-                os.write(wr, f"{sec}".encode())
-            finally:
-                os._exit(0)
-        os.close(wr)
-        pipes.append((pid, r))
-    secs = []
-    for pid, r in pipes:
-        data = os.read(r, 64)
-        os.close(r)
-        os.waitpid(pid, 0)
-        secs.append(float(data.decode() or "nan"))
-    wall = time.perf_counter() - t0
-    return workers * n_each / max(secs), max(secs), wall
-
-
 def _cpu_model():
     try:
         for line in open("/proc/cpuinfo"):
@@ -73,75 +32,188 @@ def _cpu_model():
     return "unknown"
 
 
+def _cores():
+    """(workers to fork, cgroup quota or None): physical cores of one socket (2 sockets x SMT2 on the gpurun box),
+    capped by the container's cgroup v2 CPU quota."""
+    cores = max(1, (os.cpu_count() or 2) // 4)
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            quota = max(1, int(q) // int(per))
+            cores = min(cores, quota)
+    except (OSError, ValueError):
+        pass
+    return cores, quota
+
+
+def _export_index(index, k, with_klcp):
+    """GPU-built index -> oracle structure -> (reference-format files ->) the real reference if it is available."""
+    import oracle_py
+    blocks, _ = index.download_layout()
+    rows = int(index.info.n)
+    words = (rows + 63) // 64 + 1
+    planes = [np.ascontiguousarray(np.ascontiguousarray(blocks[:, lo:lo + 4]).reshape(-1).view(np.uint64)[:words]) for lo in (4, 8, 12)]
+    del blocks
+    L = oracle_py.oracle_lib()
+    L.orc_index_from_planes.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_int]
+    L.orc_index_from_planes.restype = C.c_void_p
+    L.orc_index_set_klcp.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
+    L.orc_index_set_klcp.restype = None
+    counts = np.array(list(index.info.counts), dtype=np.uint64)
+    h = L.orc_index_from_planes(planes[0].ctypes.data, planes[1].ctypes.data, planes[2].ctypes.data, rows, counts.ctypes.data,
+                                int(index.info.dollar_position), k)
+    if with_klcp:
+        kl = index.download_klcp()
+        L.orc_index_set_klcp(h, kl.ctypes.data, rows)
+    orc = oracle_py.Oracle(L, h)
+    del planes
+    if not oracle_py.ref_available():
+        return orc, "port", None
+    tmp = tempfile.TemporaryDirectory(dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    prefix = os.path.join(tmp.name, "bench")
+    orc.dump(prefix)
+    orc.close()
+    return oracle_py.Reference.load(prefix, use_klcp=with_klcp), "reference", tmp
+
+
+def _kmers_to_text(kmers: np.ndarray, k: int) -> bytes:
+    codes = ((kmers[:, None] >> (2 * np.arange(k, dtype=np.uint64))) & np.uint64(3)).astype(np.uint8)
+    return np.frombuffer(b"ACGT", dtype=np.uint8)[codes].tobytes()
+
+
+def _fork_workers(workers, fn):
+    """Run fn(w) -> seconds in `workers` forked children; returns the list of seconds."""
+    pipes = []
+    for w in range(workers):
+        r, wr = os.pipe()
+        pid = os.fork()
+        if pid == 0:
+            os.close(r)
+            try:
+                os.write(wr, f"{fn(w)}".encode())
+            finally:
+                os._exit(0)
+        os.close(wr)
+        pipes.append((pid, r))
+    secs = []
+    for pid, r in pipes:
+        data = os.read(r, 64)
+        os.close(r)
+        os.waitpid(pid, 0)
+        secs.append(float(data.decode() or "nan"))
+    return secs
+
+
 def run(args, index, n, k):
-    import ctypes as C
+    """Isolated k-mers (workload kmers)."""
     import torch
     import fmsi_amd as fm
     import oracle_py
 
     mode = oracle_py.MODE_ALL if args.mode == "all" else oracle_py.MODE_OR
-    cores_socket = max(1, (os.cpu_count() or 2) // 4)       # 2 sockets x SMT2 on the gpurun box -> physical cores of one socket
-    quota = None
-    try:                                                      # the box's container may cap CPU time (cgroup v2 cpu.max)
-        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
-        if q != "max":
-            quota = max(1, int(q) // int(per))
-            cores_socket = min(cores_socket, quota)
-    except (OSError, ValueError):
-        pass
+    cores, quota = _cores()
     sample = args.cpu_sample
-    if sample < 0:
-        # ~10-20 s of single-thread work: ~15 us per k-mer at human scale, ~3 us when the index is cache resident
+    if sample < 0:   # ~10 s of single-thread work: ~9 us per k-mer at human scale, ~1.5 us when the index is cache resident
         sample = 1_000_000 if n >= 2e8 else 3_000_000
     per_worker = max(20_000, sample // 8)
-    total = sample + cores_socket * per_worker
+    total = sample + cores * per_worker
 
-    # the same seeded query stream the GPU steps consume, drawn on the device and copied out
     d = torch.empty(total, dtype=torch.int64, device="cuda")
     d_out = torch.empty(total, dtype=torch.uint8, device="cuda")
     s = torch.cuda.current_stream().cuda_stream
-    index.synthetic_queries_dev(k, args.query_seed, 0, total, d.data_ptr(), s)
-    gflags = (fm.MODE_ALL if args.mode == "all" else fm.MODE_OR)
-    index.query_kmers_dev(d.data_ptr(), total, k, gflags, d_out.data_ptr(), stream=s)
+    index.synthetic_queries_dev(k, args.query_seed, 0, total, d.data_ptr(), s)   # the stream the GPU steps consume
+    index.query_kmers_dev(d.data_ptr(), total, k, fm.MODE_ALL if args.mode == "all" else fm.MODE_OR, d_out.data_ptr(), stream=s)
     torch.cuda.synchronize()
-    kmers = d.cpu().numpy().view(np.uint64)
+    text = _kmers_to_text(d.cpu().numpy().view(np.uint64), k)
     gpu_bits = d_out.cpu().numpy()
-    text = _kmers_to_text(kmers, k)
 
     t0 = time.time()
-    (hi, lo, mask), rows = _planes(index)
-    L = oracle_py.oracle_lib()
-    L.orc_index_from_planes.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_int]
-    L.orc_index_from_planes.restype = C.c_void_p
-    counts = np.array(list(index.info.counts), dtype=np.uint64)
-    h = L.orc_index_from_planes(hi.ctypes.data, lo.ctypes.data, mask.ctypes.data, rows, counts.ctypes.data,
-                                int(index.info.dollar_position), k)
-    orc = oracle_py.Oracle(L, h)
-    del hi, lo, mask
-    kind = "port"
-    obj = orc
-    tmp = None
-    if oracle_py.ref_available():
-        tmp = tempfile.TemporaryDirectory(dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
-        prefix = os.path.join(tmp.name, "bench")
-        orc.dump(prefix)
-        obj = oracle_py.Reference.load(prefix, use_klcp=False)
-        kind = "reference"
+    obj, kind, tmp = _export_index(index, k, with_klcp=False)
     prep_s = time.time() - t0
-
     sec1, bits = obj.time_isolated_kmers(text[:sample * k], sample, k, mode)
     agree = bool(np.array_equal(bits, gpu_bits[:sample]))
-    rate1 = sample / sec1
-    rate_socket, sec_max, _ = _forked_rate(obj, text[sample * k:], per_worker, k, mode, cores_socket)
+    rest = text[sample * k:]
+    secs = _fork_workers(cores, lambda w: obj.time_isolated_kmers(rest[w * per_worker * k:(w + 1) * per_worker * k], per_worker, k, mode)[0])
     if tmp is not None:
         tmp.cleanup()
     return {
-        "value": rate1, "unit": "k-mers/s", "cores": 1, "kind": kind,
-        "sample": f"first {sample} k-mers of the benchmark's seeded query stream against the same {rows}-row index "
-                  f"(exported from the GPU build in the reference's .fmsi format); query_kmers() per k-mer, -O3-free as-shipped "
-                  f"flags (-O2), query loop only",
+        "value": sample / sec1, "unit": "k-mers/s", "cores": 1, "kind": kind,
+        "sample": f"first {sample} k-mers of the benchmark's seeded query stream against the same {int(index.info.n)}-row index "
+                  f"(exported from the GPU build in the reference's .fmsi format); query_kmers() per k-mer, as-shipped flags "
+                  f"(-g -O2), query loop only",
         "seconds": round(sec1, 3), "matches_gpu": agree,
-        "socket_value": rate_socket, "socket_cores": cores_socket,
-        "socket_sample": f"{cores_socket} forked workers x {per_worker} further k-mers each, shared read-only index, slowest worker {sec_max:.2f} s",
+        "socket_value": cores * per_worker / max(secs), "socket_cores": cores,
+        "socket_sample": f"{cores} forked workers x {per_worker} further k-mers each, shared read-only index, slowest worker {max(secs):.2f} s",
+        "index_export_seconds": round(prep_s, 1), "cpu_model": _cpu_model(), "logical_cpus": os.cpu_count(), "cgroup_cpu_quota": quota,
+    }
+
+
+def run_stream(args, index, n, k):
+    """Reads with kLCP streaming (workload stream): the reference's record loop with -S over a FASTA of sample reads."""
+    import torch
+    import fmsi_amd as fm
+    import oracle_py
+
+    mode = oracle_py.MODE_ALL if args.mode == "all" else oracle_py.MODE_OR
+    cores, quota = _cores()
+    L = args.read_len
+    wins = L - k + 1
+    sample_w = args.cpu_sample
+    if sample_w < 0:   # ~10 s single-threaded: ~4 us per window at human scale with -S
+        sample_w = 3_000_000
+    reads1 = max(1, sample_w // wins)
+    per_worker = max(1, reads1 // 8)
+    total_reads = reads1 + cores * per_worker
+
+    words = total_reads * L // 32 + 2
+    d = torch.empty(words, dtype=torch.int64, device="cuda")
+    d_out = torch.empty(total_reads * wins, dtype=torch.uint8, device="cuda")
+    s = torch.cuda.current_stream().cuda_stream
+    index.synthetic_reads_dev(L, args.query_seed, 0, total_reads, d.data_ptr(), args.subst_ppm, s)
+    run_start = np.arange(total_reads, dtype=np.uint64) * np.uint64(L)
+    run_windows = np.full(total_reads, wins, dtype=np.uint32)
+    index.query_stream_dev(d.data_ptr(), total_reads * L, run_start, run_windows, k, fm.MODE_ALL if args.mode == "all" else fm.MODE_OR,
+                           d_out.data_ptr(), stream=s)
+    torch.cuda.synchronize()
+    packed = d.cpu().numpy().view(np.uint64)
+    codes = ((packed[:, None] >> (2 * np.arange(32, dtype=np.uint64))) & np.uint64(3)).astype(np.uint8).reshape(-1)[:total_reads * L]
+    bases = np.frombuffer(b"ACGT", dtype=np.uint8)[codes].reshape(total_reads, L)
+    gpu_bits = d_out.cpu().numpy().reshape(total_reads, wins)
+
+    t0 = time.time()
+    obj, kind, tmp = _export_index(index, k, with_klcp=True)
+    prep_s = time.time() - t0
+    work = tempfile.TemporaryDirectory(dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+
+    def write_fasta(path, lo, hi):
+        with open(path, "wb") as f:
+            for r in range(lo, hi):
+                f.write(b">r%d\n" % r)
+                f.write(bases[r].tobytes())
+                f.write(b"\n")
+
+    f1 = os.path.join(work.name, "s.fa")
+    write_fasta(f1, 0, reads1)
+    text, sec1 = obj.query_file(f1, k, has_klcp=True, mode=mode, cap=reads1 * (wins + 32) + 4096)
+    got = np.array([np.frombuffer(line.split("\t")[1].encode(), dtype=np.uint8) - ord("0") for line in text.splitlines()])
+    agree = bool(np.array_equal(got, gpu_bits[:reads1]))
+    shard_files = []
+    for w in range(cores):
+        p = os.path.join(work.name, f"w{w}.fa")
+        write_fasta(p, reads1 + w * per_worker, reads1 + (w + 1) * per_worker)
+        shard_files.append(p)
+    secs = _fork_workers(cores, lambda w: obj.query_file(shard_files[w], k, has_klcp=True, mode=mode, cap=per_worker * (wins + 32) + 4096)[1])
+    work.cleanup()
+    if tmp is not None:
+        tmp.cleanup()
+    return {
+        "value": reads1 * wins / sec1, "unit": "k-mers/s", "cores": 1, "kind": kind,
+        "sample": f"first {reads1} reads ({reads1 * wins} windows) of the benchmark's seeded read stream against the same "
+                  f"{int(index.info.n)}-row index incl. its kLCP array; query_kmers<all>(..., has_klcp=true) through the reference's "
+                  f"record loop and chunking, as-shipped flags (-g -O2), query loop only",
+        "seconds": round(sec1, 3), "matches_gpu": agree,
+        "socket_value": cores * per_worker * wins / max(secs), "socket_cores": cores,
+        "socket_sample": f"{cores} forked workers x {per_worker} further reads each, slowest worker {max(secs):.2f} s",
         "index_export_seconds": round(prep_s, 1), "cpu_model": _cpu_model(), "logical_cpus": os.cpu_count(), "cgroup_cpu_quota": quota,
     }

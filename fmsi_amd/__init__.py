@@ -107,6 +107,8 @@ def lib() -> C.CDLL:
     L.fmsi_hip_synthetic_text_word.restype = u64
     L.fmsi_hip_synthetic_queries.argtypes = [vp, i32, u64, u64, u64, vp, vp]
     L.fmsi_hip_index_download_text.argtypes = [vp, vp]
+    L.fmsi_hip_index_download_klcp.argtypes = [vp, vp]
+    L.fmsi_hip_synthetic_reads.argtypes = [vp, u64, u64, u64, u64, u32, vp, vp]
     L.fmsi_hip_query_kmers.argtypes = [vp, vp, u64, i32, u32, vp, vp, vp]
     L.fmsi_hip_query_windows.argtypes = [vp, vp, u64, vp, u64, i32, u32, vp, vp, vp]
     L.fmsi_hip_query_stream.argtypes = [vp, vp, u64, vp, vp, u64, u64, i32, u32, vp, vp, vp]
@@ -268,10 +270,19 @@ class DeviceIndex:
         _check(lib().fmsi_hip_index_download_layout(self._h, blocks.ctypes.data, mrank.ctypes.data))
         return blocks, mrank
 
+    def download_klcp(self) -> np.ndarray:
+        words = np.zeros((int(self.info.n) + 63) // 64 + 1, dtype=np.uint64)
+        _check(lib().fmsi_hip_index_download_klcp(self._h, words.ctypes.data))
+        return words
+
     def download_text(self, length: int) -> np.ndarray:
         words = np.zeros(length // 32 + 2, dtype=np.uint64)
         _check(lib().fmsi_hip_index_download_text(self._h, words.ctypes.data))
         return words
+
+    def synthetic_reads_dev(self, read_len: int, seed: int, first_read: int, n_reads: int, packed_ptr: int,
+                            subst_per_million: int = 0, stream: int = 0):
+        _check(lib().fmsi_hip_synthetic_reads(self._h, read_len, seed, first_read, n_reads, subst_per_million, packed_ptr, stream or None))
 
     def synthetic_queries_dev(self, k: int, seed: int, first: int, n: int, kmers_ptr: int, stream: int = 0):
         _check(lib().fmsi_hip_synthetic_queries(self._h, k, seed, first, n, kmers_ptr, stream or None))

@@ -379,6 +379,40 @@ __global__ void synth_queries_kernel(const uint64_t* __restrict__ text2, uint64_
     kmers[q] = f;
 }
 
+// synthetic reads: see fmsi_hip_synthetic_reads in the header.  One thread per 32-base output word.
+__global__ void synth_reads_kernel(const uint64_t* __restrict__ text2, uint64_t len, uint64_t read_len, uint64_t seed, uint64_t first_read,
+                                   uint64_t n_reads, uint32_t subst_per_million, uint64_t n_words, uint64_t* __restrict__ packed) {
+    const uint64_t w = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (w >= n_words) return;
+    uint64_t v = 0;
+    const uint64_t total = n_reads * read_len;
+    for (uint32_t b = 0; b < 32; ++b) {
+        const uint64_t pos = w * 32 + b;
+        if (pos >= total) break;
+        const uint64_t r = pos / read_len, off = pos - r * read_len;
+        const uint64_t h = splitmix64(seed ^ ((first_read + r) * 0xA24BAED4963EE407ull));
+        uint32_t c;
+        if (h & 1ull) {                                   // a substring of the superstring ...
+            const uint64_t p0 = splitmix64(h) % (len - read_len + 1);
+            if (h & 2ull) {                               // ... half of them reverse-complemented
+                const uint64_t p = p0 + (read_len - 1 - off);
+                c = 3u - (static_cast<uint32_t>(text2[p >> 5] >> (2 * (p & 31))) & 3u);
+            } else {
+                const uint64_t p = p0 + off;
+                c = static_cast<uint32_t>(text2[p >> 5] >> (2 * (p & 31))) & 3u;
+            }
+            if (subst_per_million) {
+                const uint64_t hs = splitmix64(h ^ (off * 0x9E3779B97F4A7C15ull));
+                if (hs % 1000000ull < subst_per_million) c = static_cast<uint32_t>(hs >> 40) & 3u;
+            }
+        } else {
+            c = static_cast<uint32_t>(splitmix64(h ^ (off * 0xC2B2AE3D27D4EB4Full)) >> 17) & 3u;   // uniform random read
+        }
+        v |= static_cast<uint64_t>(c) << (2 * b);
+    }
+    packed[w] = v;
+}
+
 }  // namespace
 }  // namespace fmsi
 
@@ -442,6 +476,22 @@ int fmsi_hip_synthetic_queries(fmsi_hip_index* idx, int k, uint64_t seed, uint64
     FMSI_HIP_TRY(hipSetDevice(idx->device));
     hipLaunchKernelGGL(synth_queries_kernel, dim3(grid_for(n)), dim3(256), 0, static_cast<hipStream_t>(stream),
                        static_cast<const uint64_t*>(idx->d_text2), idx->text_len, k, seed, first, n, d_kmers);
+    FMSI_HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int fmsi_hip_synthetic_reads(fmsi_hip_index* idx, uint64_t read_len, uint64_t seed, uint64_t first_read, uint64_t n_reads,
+                             uint32_t subst_per_million, uint64_t* d_packed, void* stream) {
+    if (!idx || !d_packed || !idx->d_text2 || read_len == 0 || idx->text_len < read_len) {
+        set_last_error("synthetic reads need an index built by fmsi_hip_index_build* and read_len <= |MS|");
+        return FMSI_HIP_EINVAL;
+    }
+    if (n_reads == 0) return 0;
+    FMSI_HIP_TRY(hipSetDevice(idx->device));
+    const uint64_t n_words = (n_reads * read_len) / 32 + 2;
+    hipLaunchKernelGGL(synth_reads_kernel, dim3(grid_for(n_words)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       static_cast<const uint64_t*>(idx->d_text2), idx->text_len, read_len, seed, first_read, n_reads, subst_per_million,
+                       n_words, d_packed);
     FMSI_HIP_TRY(hipGetLastError());
     return 0;
 }

@@ -595,6 +595,16 @@ int fmsi_hip_index_download_layout(const fmsi_hip_index* idx, uint32_t* blocks, 
     return 0;
 }
 
+int fmsi_hip_index_download_klcp(const fmsi_hip_index* idx, uint64_t* words) {
+    if (!idx || !words || !idx->d_klcp) {
+        set_last_error("the handle holds no kLCP array");
+        return FMSI_HIP_EINVAL;
+    }
+    FMSI_HIP_TRY(hipSetDevice(idx->device));
+    FMSI_HIP_TRY(hipMemcpy(words, idx->d_klcp, ((idx->n + 63) / 64) * 8, hipMemcpyDeviceToHost));
+    return 0;
+}
+
 int fmsi_hip_query_kmers(fmsi_hip_index* idx, const uint64_t* kmers, uint64_t n_kmers, int k, uint32_t flags, void* out,
                          uint64_t* counters, void* stream) {
     if (n_kmers == 0) return 0;

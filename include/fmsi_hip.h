@@ -130,11 +130,19 @@ uint64_t fmsi_hip_synthetic_text_word(uint64_t seed, uint64_t w);
 /* Fills d_kmers[0..n) (DEVICE pointer) with queries first..first+n-1 of the seeded stream: with probability 1/2 a
  * k-mer of the superstring (half of those reverse-complemented), else a uniform random k-mer. */
 int fmsi_hip_synthetic_queries(fmsi_hip_index* idx, int k, uint64_t seed, uint64_t first, uint64_t n, uint64_t* d_kmers, void* stream);
+/* Fills d_packed (DEVICE pointer, n_reads*read_len/32 + 2 words) with n_reads reads of read_len bases, 2-bit packed back
+ * to back: read r (global number first_read + r) is with probability 1/2 a substring of the superstring (half of those
+ * reverse-complemented, each base substituted with probability subst_per_million / 10^6), else uniform random. */
+int fmsi_hip_synthetic_reads(fmsi_hip_index* idx, uint64_t read_len, uint64_t seed, uint64_t first_read, uint64_t n_reads,
+                             uint32_t subst_per_million, uint64_t* d_packed, void* stream);
 /* 2-bit text kept by the builder -> host (len/32 + 2 words) */
 int fmsi_hip_index_download_text(const fmsi_hip_index* idx, uint64_t* words);
 
 /* Copies the device layout back (n_blocks*16 dwords, n_blocks+1 dwords) -- verification aid. */
 int fmsi_hip_index_download_layout(const fmsi_hip_index* idx, uint32_t* blocks, uint32_t* mrank);
+
+/* Copies the handle's kLCP bit-vector back (ceil(n/64) words); fails when the handle has none. */
+int fmsi_hip_index_download_klcp(const fmsi_hip_index* idx, uint64_t* words);
 
 /* Replaces query_kmers<orr|all>() without kLCP (query_kmers_single, src/fms_index.h:263-331) for
  * isolated k-mers, k <= 32.  kmers[q] holds k-mer q 2-bit packed (A=0,C=1,G=2,T=3 as in src/kmers.h:3-20),

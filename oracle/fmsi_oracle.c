@@ -580,6 +580,15 @@ orc_index* orc_index_from_planes(const uint64_t* hi, const uint64_t* lo, const u
     return ix;
 }
 
+/* attach a kLCP bit-vector (n bits as u64 words) to an index made by orc_index_from_planes */
+void orc_index_set_klcp(orc_index* ix, const uint64_t* klcp, uint64_t n) {
+    bv_free(&ix->klcp);
+    bv_alloc(&ix->klcp, n);
+    uint64_t words = (n + 63) >> 6;
+    for (uint64_t w = 0; w < words; ++w) ix->klcp.w[w] = klcp[w];
+    if (n & 63) ix->klcp.w[words - 1] &= lo_set((unsigned)(n & 63));
+}
+
 void orc_index_free(orc_index* ix) {
     if (!ix) return;
     bv_free(&ix->ac_gt); bv_free(&ix->ac); bv_free(&ix->gt); bv_free(&ix->klcp);
