@@ -51,7 +51,7 @@ def parse_args():
     ap.add_argument("--batch", type=float, default=float(1 << 27), help="query windows per step and GPU")
     ap.add_argument("--k", type=int, default=31)
     ap.add_argument("--prefix-len", type=int, default=12, help="private prefix table length t (0 = none)")
-    ap.add_argument("--kernel", choices=["refill", "lockstep"], default="refill")
+    ap.add_argument("--kernel", choices=["pair", "refill", "lockstep"], default="pair")
     ap.add_argument("--mode", choices=["all", "or"], default="all")
     ap.add_argument("--read-len", type=int, default=10000, help="stream workload: bases per read")
     ap.add_argument("--subst-ppm", type=int, default=0, help="stream workload: substitutions per million bases of positive reads")
@@ -106,7 +106,11 @@ def main():
     build_s = time.time() - t0
     flags = fm.MODE_ALL if args.mode == "all" else fm.MODE_OR
     if not stream_mode:
-        flags |= fm.KERNEL_LOCKSTEP if args.kernel == "lockstep" else fm.KERNEL_REFILL
+        if args.kernel == "pair":
+            t0 = time.time()
+            index.enable_pair_layout()
+            build_s += time.time() - t0
+        flags |= {"pair": fm.KERNEL_PAIR, "refill": fm.KERNEL_REFILL, "lockstep": fm.KERNEL_LOCKSTEP}[args.kernel]
     stream = torch.cuda.current_stream().cuda_stream
 
     # ---- one step's input, resident in HBM ----------------------------------------------------------------
@@ -194,8 +198,9 @@ def main():
         roof = None
         if counters is not None:
             blocks_read, lookups, klcp_words = int(counters[1]), int(counters[4]), int(counters[5])
-            # blocks_read already contains the prefix-table lines (one 64-B line per lookup)
-            bytes_launch = 64 * blocks_read + 8 * klcp_words + in_bytes + 1 * batch
+            # blocks_read already contains the prefix-table lines (one 64-B line per lookup); the pair layout reads 128-B blocks
+            block_b = 128 if (args.kernel == "pair" and not stream_mode) else 64
+            bytes_launch = block_b * (blocks_read - lookups) + 64 * lookups + 8 * klcp_words + in_bytes + 1 * batch
             canon_bytes = 256 * int(canonical[0]) + 64 * int(canonical[2]) + 8 * int(canonical[5]) + in_bytes + batch // 8
             ach = bytes_launch / avg_kernel_s / 1e9
             roof = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -225,7 +230,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
             "config": {"workload": wl, "index_rows": int(info.n), "k": k, "queries_per_step_per_gpu": batch, "mode": args.mode,
                        "kernel": "stream" if stream_mode else args.kernel, "prefix_table_len": int(info.prefix_len),
-                       "index_bytes_hbm": int(info.device_bytes), "block_bytes": int(info.block_bytes),
+                       "index_bytes_hbm": int(info.device_bytes), "block_bytes": 128 if (args.kernel == "pair" and not stream_mode) else 64,
                        "parallelism": f"query-sharded x{world}, index replicated", "positive_fraction": round(positives, 4),
                        "index_build_seconds": round(build_s, 2)},
             "roofline": roof,

@@ -27,6 +27,7 @@ ORDERS = 0x4
 DEVICE_PTRS = 0x8
 KERNEL_LOCKSTEP = 0x10
 KERNEL_REFILL = 0x20
+KERNEL_PAIR = 0x30
 NO_PREFIX_TABLE = 0x100
 N_COUNTERS = 8
 
@@ -108,6 +109,7 @@ def lib() -> C.CDLL:
     L.fmsi_hip_synthetic_queries.argtypes = [vp, i32, u64, u64, u64, vp, vp]
     L.fmsi_hip_index_download_text.argtypes = [vp, vp]
     L.fmsi_hip_index_download_klcp.argtypes = [vp, vp]
+    L.fmsi_hip_index_enable_pair_layout.argtypes = [vp]
     L.fmsi_hip_synthetic_reads.argtypes = [vp, u64, u64, u64, u64, u32, vp, vp]
     L.fmsi_hip_query_kmers.argtypes = [vp, vp, u64, i32, u32, vp, vp, vp]
     L.fmsi_hip_query_windows.argtypes = [vp, vp, u64, vp, u64, i32, u32, vp, vp, vp]
@@ -269,6 +271,12 @@ class DeviceIndex:
         mrank = np.zeros(nb + 1, dtype=np.uint32)
         _check(lib().fmsi_hip_index_download_layout(self._h, blocks.ctypes.data, mrank.ctypes.data))
         return blocks, mrank
+
+    def enable_pair_layout(self):
+        """Add the 128-B two-base-step layout (fmsi_hip_index_enable_pair_layout); AUTO kernels then use it."""
+        _check(lib().fmsi_hip_index_enable_pair_layout(self._h))
+        _check(lib().fmsi_hip_index_get_info(self._h, C.byref(self.info)))
+        return self
 
     def download_klcp(self) -> np.ndarray:
         words = np.zeros((int(self.info.n) + 63) // 64 + 1, dtype=np.uint64)

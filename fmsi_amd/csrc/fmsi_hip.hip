@@ -397,6 +397,12 @@ int launch_query(fmsi_hip_index* idx, const uint64_t* d_kmers, uint64_t n_window
             hipLaunchKernelGGL((query_lockstep_kernel<true>), grid, block, 0, s, idx->dev, d_kmers, n_windows, k, flags, o8, o64, d_counters);
         else
             hipLaunchKernelGGL((query_lockstep_kernel<false>), grid, block, 0, s, idx->dev, d_kmers, n_windows, k, flags, o8, o64, d_counters);
+    } else if (kernel == FMSI_HIP_KERNEL_PAIR || (kernel == FMSI_HIP_KERNEL_AUTO && idx->d_pblocks)) {
+        if (!idx->d_pblocks) {
+            set_last_error("FMSI_HIP_KERNEL_PAIR needs fmsi_hip_index_enable_pair_layout() on this handle");
+            return FMSI_HIP_EINVAL;
+        }
+        launch_pair_query(idx, d_kmers, n_windows, k, flags, use_table, o8, o64, d_counters, s);
     } else if (use_table) {
         if (d_counters) launch_refill<true, true>(idx, d_kmers, n_windows, k, flags, o8, o64, d_counters, s);
         else launch_refill<false, true>(idx, d_kmers, n_windows, k, flags, o8, o64, d_counters, s);
@@ -559,7 +565,7 @@ void fmsi_hip_index_destroy(fmsi_hip_index* idx) {
     if (!idx) return;
     (void)hipSetDevice(idx->device);
     for (void* p : {idx->d_blocks, idx->d_mrank, idx->d_ptable, idx->d_klcp, idx->d_text2, idx->d_in, idx->d_aux, idx->d_out,
-                    idx->d_kmers, static_cast<void*>(idx->d_counters)})
+                    idx->d_kmers, idx->d_tasks, idx->d_pblocks, idx->d_sbt, idx->d_c2, static_cast<void*>(idx->d_counters)})
         if (p) (void)hipFree(p);
     for (auto& e : idx->events) {
         (void)hipEventDestroy(e.first);

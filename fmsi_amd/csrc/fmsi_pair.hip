@@ -1,0 +1,521 @@
+// Two-base LF steps over 128-byte blocks ("pair layout") -- the request-count optimisation of the query path.
+//
+// Why: the chip serves ~52-57 G random block reads/s whether a block is 64 B or 128 B, as long as the randomly
+// accessed footprint stays below ~3.2 GB (profiles/r01_gather_ceiling.md).  The single-step kernels already run at
+// that request ceiling, so the only way up is fewer requests per k-mer.  A 128-byte block can carry what TWO
+// consecutive backward-search steps need: for every row r (suffix start s = SA[r]) both preceding symbols
+// c1 = T[s-1] (the BWT symbol) and c2 = T[s-2], plus cumulative counts of the 16 (c2, c1) pairs.  Then
+//     [i, j)  --(prepend "c2 c1")-->  [C2[c2,c1] + rank_pair(i), C2[c2,c1] + rank_pair(j))
+// is ONE block read per boundary -- exactly the interval two update_range() calls (reference
+// src/fms_index.h:98-103) produce, so the final SA interval, the early exit on an empty interval and therefore
+// every result are unchanged.  c2 is derived on the device from the single-step layout alone (c2(r) = BWT[LF(r)]),
+// so the layout can be added to any handle, whether it was loaded from the reference's files or built on the device.
+//
+// Block = 128 B = 128 rows (32 dwords):
+//   dw  0..7   low 16 bits of the 16 pair counts (two per dword), relative to the superblock start
+//   dw  8..11  high 8 bits of the 16 pair counts (four per dword)            -> 24-bit relative counts
+//   dw 12..15  mask plane (SA-transformed mask)
+//   dw 16..19  c1 hi plane   dw 20..23  c1 lo plane   dw 24..27  c2 hi plane   dw 28..31  c2 lo plane
+// pair index p = c2 | c1 << 2.  Superblock = 2^23 rows; `sbt` holds the 16 absolute counts at each superblock start
+// (21 KB at human scale: cache resident).  Rows without a c1 / c2 (suffix starts 0 and 1) are stored as 'A' and
+// subtracted in the rank, like the '$' slot of the reference (src/fms_index.h:81).
+#include <hip/hip_runtime.h>
+#include <rocprim/device/device_scan.hpp>
+
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "../../include/fmsi_hip.h"
+#include "common.h"
+#include "device_fm.h"
+#include "index_priv.h"
+
+namespace fmsi {
+
+constexpr uint32_t kPairBlockDwords = 32;
+constexpr uint32_t kSuperLog2 = 23;                       // rows per superblock
+constexpr uint32_t kSuperBlocksLog2 = kSuperLog2 - kBlockRowsLog2;
+
+struct PairIndex {
+    const uint32_t* pb;       // n_blocks x 32 dwords
+    const uint32_t* sbt;      // n_super x 16 absolute pair counts
+    const uint32_t* c2;       // 16 x C2[p]
+    const uint32_t* mrank;    // n_blocks + 1 cumulative mask popcounts (shared with the single-step layout)
+    const uint2* ptable;
+    uint32_t ptable_len;
+    uint32_t n, r0, r1, p1;   // rows; row of suffix 0 ('$' slot); row of suffix 1; pair index stored for r1
+    uint32_t C0, C1, C2_, C3;
+};
+
+namespace {
+
+struct U16 {
+    uint32_t v[16];
+};
+struct U16Plus {
+    __host__ __device__ U16 operator()(const U16& a, const U16& b) const {
+        U16 r;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) r.v[q] = a.v[q] + b.v[q];
+        return r;
+    }
+};
+
+// ---- layout construction -----------------------------------------------------------------------------------
+// One thread per row (256 threads = 2 blocks): c1 from the single-step block, c2 = BWT[LF(row)].
+__global__ __launch_bounds__(256) void pair_emit_kernel(DevIndex ix, uint32_t* __restrict__ pb, U16* __restrict__ counts,
+                                                        uint32_t* __restrict__ specials /* [0] = r1, [1] = c1(r1) */) {
+    __shared__ uint32_t s_cnt[4][16];
+    const uint64_t row64 = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    const bool valid = row64 < ix.n;
+    const uint32_t row = static_cast<uint32_t>(row64);
+    uint32_t c1 = 0, c2 = 0, mbit = 0;
+    if (valid) {
+        const uint32_t* blk = reinterpret_cast<const uint32_t*>(ix.blocks) + (static_cast<size_t>(row >> kBlockRowsLog2) << 4);
+        const uint32_t o = row & (kBlockRows - 1u), w = o >> 5, sh = o & 31u;
+        c1 = (((blk[4 + w] >> sh) & 1u) << 1) | ((blk[8 + w] >> sh) & 1u);
+        mbit = (blk[12 + w] >> sh) & 1u;
+        if (row != ix.dollar) {
+            uint32_t a = row, b = row + 1u, dummy = 0;
+            lf_step(ix, c1, a, b, dummy);                 // a = LF(row)
+            if (a == ix.dollar) {                         // suffix 1: its predecessor is the '$' slot -> no c2
+                specials[0] = row;
+                specials[1] = c1;
+            } else {
+                const uint32_t* tb = reinterpret_cast<const uint32_t*>(ix.blocks) + (static_cast<size_t>(a >> kBlockRowsLog2) << 4);
+                const uint32_t o2 = a & (kBlockRows - 1u), w2 = o2 >> 5, sh2 = o2 & 31u;
+                c2 = (((tb[4 + w2] >> sh2) & 1u) << 1) | ((tb[8 + w2] >> sh2) & 1u);
+            }
+        }
+    }
+    const uint64_t h1 = __ballot(valid && (c1 & 2u)), l1 = __ballot(valid && (c1 & 1u));
+    const uint64_t h2 = __ballot(valid && (c2 & 2u)), l2 = __ballot(valid && (c2 & 1u));
+    const uint64_t mm = __ballot(valid && mbit), vv = __ballot(valid);
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    if (lane == 0 && vv) {
+        const uint64_t w = row64 >> 6;
+        uint32_t* blk = pb + (w >> 1) * kPairBlockDwords;
+        const uint32_t half = static_cast<uint32_t>(w & 1) * 2;
+        blk[12 + half] = static_cast<uint32_t>(mm);  blk[13 + half] = static_cast<uint32_t>(mm >> 32);
+        blk[16 + half] = static_cast<uint32_t>(h1);  blk[17 + half] = static_cast<uint32_t>(h1 >> 32);
+        blk[20 + half] = static_cast<uint32_t>(l1);  blk[21 + half] = static_cast<uint32_t>(l1 >> 32);
+        blk[24 + half] = static_cast<uint32_t>(h2);  blk[25 + half] = static_cast<uint32_t>(h2 >> 32);
+        blk[28 + half] = static_cast<uint32_t>(l2);  blk[29 + half] = static_cast<uint32_t>(l2 >> 32);
+    }
+    if (lane < 16) {   // lane p counts pair p = c2 | c1 << 2 of its wave
+        const uint64_t m = vv & ((lane & 8u) ? h1 : ~h1) & ((lane & 4u) ? l1 : ~l1) & ((lane & 2u) ? h2 : ~h2) & ((lane & 1u) ? l2 : ~l2);
+        s_cnt[wave][lane] = static_cast<uint32_t>(__popcll(m));
+    }
+    __syncthreads();
+    if (threadIdx.x < 32) {
+        const uint32_t which = threadIdx.x >> 4, p = threadIdx.x & 15u;
+        counts[static_cast<uint64_t>(blockIdx.x) * 2 + which].v[p] = s_cnt[2 * which][p] + s_cnt[2 * which + 1][p];
+    }
+}
+
+// per block: 24-bit counts relative to the superblock start; absolute counts of each superblock start
+__global__ void pair_counts_kernel(const U16* __restrict__ scanned, uint64_t n_blocks, uint32_t* __restrict__ pb, uint32_t* __restrict__ sbt) {
+    const uint64_t b = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (b >= n_blocks) return;
+    const U16 a = scanned[b];
+    const uint64_t sb = b >> kSuperBlocksLog2;
+    const U16 base = scanned[sb << kSuperBlocksLog2];
+    uint32_t lo[8] = {0, 0, 0, 0, 0, 0, 0, 0}, hi[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int p = 0; p < 16; ++p) {
+        const uint32_t rel = a.v[p] - base.v[p];
+        lo[p >> 1] |= (rel & 0xFFFFu) << (16 * (p & 1));
+        hi[p >> 2] |= ((rel >> 16) & 0xFFu) << (8 * (p & 3));
+    }
+    uint32_t* blk = pb + b * kPairBlockDwords;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) blk[q] = lo[q];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) blk[8 + q] = hi[q];
+    if ((b & ((1ull << kSuperBlocksLog2) - 1)) == 0) {
+#pragma unroll
+        for (int p = 0; p < 16; ++p) sbt[sb * 16 + p] = a.v[p];
+    }
+}
+
+// ---- query kernel -----------------------------------------------------------------------------------------
+enum : uint32_t { PS_IDLE = 0, PS_LOOKUP = 1, PS_STEP = 2, PS_PROBE = 3 };
+
+struct PairLoads {
+    uint32_t lowA, lowB, high;
+    uint4 sb4;
+    uint4 q0, q1, q2, q3;   // c1 hi, c1 lo, c2 hi, c2 lo planes -- or the four quarters of a prefix-table line
+};
+
+__device__ __forceinline__ uint32_t bytes_sum(uint32_t x) { return (x & 0xFFu) + ((x >> 8) & 0xFFu) + ((x >> 16) & 0xFFu) + (x >> 24); }
+
+// rank of pair p (single == false) or of symbol y = p >> 2 over all four c2 (single == true) among the first `o`
+// rows of the block, plus the block's cumulative count
+__device__ __forceinline__ uint32_t pair_rank(const PairLoads& L, uint32_t p, bool single, uint32_t o) {
+    uint32_t cnt;
+    if (single) {
+        const uint32_t lows = (L.lowA & 0xFFFFu) + (L.lowA >> 16) + (L.lowB & 0xFFFFu) + (L.lowB >> 16);
+        cnt = lows + (bytes_sum(L.high) << 16) + L.sb4.x + L.sb4.y + L.sb4.z + L.sb4.w;
+    } else {
+        const uint32_t rel = ((L.lowA >> (16u * (p & 1u))) & 0xFFFFu) | (((L.high >> (8u * (p & 3u))) & 0xFFu) << 16);
+        cnt = rel + sel4(p & 3u, opaque(L.sb4.x), opaque(L.sb4.y), opaque(L.sb4.z), opaque(L.sb4.w));
+    }
+    const uint32_t x1h = (p & 8u) ? 0u : 0xFFFFFFFFu, x1l = (p & 4u) ? 0u : 0xFFFFFFFFu;
+    const uint32_t x2h = (p & 2u) ? 0u : 0xFFFFFFFFu, x2l = (p & 1u) ? 0u : 0xFFFFFFFFu;
+    const uint32_t all = single ? 0xFFFFFFFFu : 0u;   // single step: the c2 planes do not restrict
+    const int s = static_cast<int>(o);
+    cnt += __popc((L.q0.x ^ x1h) & (L.q1.x ^ x1l) & ((L.q2.x ^ x2h) | all) & ((L.q3.x ^ x2l) | all) & prefix32(s));
+    cnt += __popc((L.q0.y ^ x1h) & (L.q1.y ^ x1l) & ((L.q2.y ^ x2h) | all) & ((L.q3.y ^ x2l) | all) & prefix32(s - 32));
+    cnt += __popc((L.q0.z ^ x1h) & (L.q1.z ^ x1l) & ((L.q2.z ^ x2h) | all) & ((L.q3.z ^ x2l) | all) & prefix32(s - 64));
+    cnt += __popc((L.q0.w ^ x1h) & (L.q1.w ^ x1l) & ((L.q2.w ^ x2h) | all) & ((L.q3.w ^ x2l) | all) & prefix32(s - 96));
+    return cnt;
+}
+
+struct PairCounters {
+    uint32_t lf_steps = 0, blocks = 0, probes = 0, searches = 0, lookups = 0;
+};
+
+template <bool COUNT, bool PTABLE>
+__global__ __launch_bounds__(256) void query_pair_kernel(PairIndex ix, const uint64_t* __restrict__ kmers, uint64_t n_windows, int k,
+                                                         uint32_t flags, uint32_t chunk, uint8_t* __restrict__ out,
+                                                         long long* __restrict__ out_orders, unsigned long long* __restrict__ counters) {
+    const uint32_t mode_all = flags & FMSI_HIP_MODE_ALL;
+    const uint32_t strict = flags & FMSI_HIP_STRICT;
+    const uint32_t orders = flags & FMSI_HIP_ORDERS;
+    const uint64_t wave = (static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
+    uint64_t next = wave * chunk;
+    const uint64_t end = min(n_windows, next + static_cast<uint64_t>(chunk));
+    const int T = PTABLE ? static_cast<int>(ix.ptable_len) : 0;
+
+    uint64_t f = 0, cur = 0, f_next = 0, q = 0, q_next = 0;
+    uint32_t i = 0, j = 0, st = PS_IDLE, phase = 0, done = 0;
+    int t = 0, res_f = -1;
+    long long ord_f = -1;
+    bool has_next = false;
+    PairCounters cn;
+
+    auto start_strand = [&](uint64_t kmer) {
+        cur = kmer;
+        if (COUNT) cn.searches++;
+        if (PTABLE) {
+            st = PS_LOOKUP;
+        } else {
+            i = 0;
+            j = ix.n;
+            t = k - 1;
+            st = PS_STEP;
+        }
+    };
+    auto finalize = [&](int res, long long ord) {
+        bool second;
+        if (strict) second = true;
+        else if (orders) second = ord < 0;
+        else if (mode_all) second = res == -1;
+        else second = res != 1;
+        if (phase == 0 && second) {
+            res_f = res;
+            ord_f = ord;
+            phase = 1;
+            start_strand(revcomp_2bit(f, k));
+            return;
+        }
+        const bool was_second = phase == 1;
+        const int rf = was_second ? res_f : res, rr = was_second ? res : -1;
+        const long long of = was_second ? ord_f : ord, orr = was_second ? ord : -1;
+        if (orders) {
+            if (strict) {
+                out_orders[2 * q] = of;
+                out_orders[2 * q + 1] = orr;
+            } else {
+                out_orders[q] = was_second ? orr : of;
+            }
+        } else if (strict) {
+            out[q] = static_cast<uint8_t>((rf + 1) | ((rr + 1) << 2));
+        } else {
+            out[q] = static_cast<uint8_t>((was_second ? rr : rf) == 1);
+        }
+        st = PS_IDLE;
+        done++;
+    };
+
+    for (;;) {
+        if (st == PS_IDLE && has_next) {
+            f = f_next;
+            q = q_next;
+            has_next = false;
+            phase = 0;
+            start_strand(f);
+        }
+        {
+            const bool want = !has_next;
+            const uint64_t m = __ballot(want);
+            if (m) {
+                const uint64_t cand = next + lanes_below(m);
+                if (want && cand < end) {
+                    q_next = cand;
+                    f_next = kmers[cand];
+                    has_next = true;
+                }
+                next += static_cast<uint64_t>(__popcll(m));
+            }
+        }
+        if (!__any(st != PS_IDLE)) {
+            if (!__any(has_next)) break;
+            continue;
+        }
+        if (st != PS_IDLE) {
+            // ---- addresses of this round ----
+            const bool single = st == PS_STEP && ((t + 1) & 1);          // odd number of bases left: one single-base step first
+            uint32_t p = 0;                                              // pair index c2 | c1 << 2 (single: c1 << 2)
+            if (st == PS_STEP) {
+                const uint32_t c1 = static_cast<uint32_t>(cur >> (2 * t)) & 3u;
+                const uint32_t c2 = single ? 0u : (static_cast<uint32_t>(cur >> (2 * (t - 1))) & 3u);
+                p = c2 | (c1 << 2);
+            }
+            const uint32_t bi = i >> kBlockRowsLog2, bj = (j - 1u) >> kBlockRowsLog2;
+            const uint32_t* wi = ix.pb + static_cast<size_t>(bi) * kPairBlockDwords;
+            const uint32_t* wj = ix.pb + static_cast<size_t>(bj) * kPairBlockDwords;
+            const uint4* pi4 = reinterpret_cast<const uint4*>(wi) + 4;   // planes
+            const uint4* pj4 = reinterpret_cast<const uint4*>(wj) + 4;
+            uint32_t tidx = 0;
+            if (PTABLE && st == PS_LOOKUP) {
+                tidx = static_cast<uint32_t>(cur >> (2 * (k - T))) & ((1u << (2 * T)) - 1u);
+                pi4 = reinterpret_cast<const uint4*>(ix.ptable + (tidx & ~7u));
+                pj4 = pi4;
+            }
+            // count dwords: pair -> (p >> 1, 8 + (p >> 2)); single -> (2y, 2y + 1, 8 + y); probe -> mask dword of row i
+            uint32_t la = p >> 1, lb = p >> 1, hd = 8u + (p >> 2);
+            if (single) {
+                la = (p >> 2) * 2u;
+                lb = la + 1u;
+            }
+            if (st == PS_PROBE) la = 12u + ((i & (kBlockRows - 1u)) >> 5);
+            const bool blocks_round = st != PS_LOOKUP;
+            const bool two = blocks_round && st == PS_STEP && bj != bi;
+            const uint4* sbi = reinterpret_cast<const uint4*>(ix.sbt) + (static_cast<size_t>(i >> kSuperLog2) << 2) + (p >> 2);
+            const uint4* sbj = reinterpret_cast<const uint4*>(ix.sbt) + (static_cast<size_t>((j - 1u) >> kSuperLog2) << 2) + (p >> 2);
+            PairLoads A, B;
+            A.lowA = A.lowB = A.high = 0; A.sb4 = make_uint4(0, 0, 0, 0);
+            B = A;
+            B.q0 = B.q1 = B.q2 = B.q3 = make_uint4(0, 0, 0, 0);
+            if (two) {
+                B.lowA = wj[la]; B.lowB = wj[lb]; B.high = wj[hd];
+                B.q0 = pj4[0]; B.q1 = pj4[1]; B.q2 = pj4[2]; B.q3 = pj4[3];
+            }
+            A.q0 = pi4[0]; A.q1 = pi4[1]; A.q2 = pi4[2]; A.q3 = pi4[3];
+            if (blocks_round) {
+                A.lowA = wi[la]; A.lowB = wi[lb]; A.high = wi[hd];
+            }
+            uint32_t c2base = 0;
+            if (st == PS_STEP) {
+                A.sb4 = *sbi;
+                B.sb4 = *sbj;                          // tiny, cache-resident table: not a random HBM request
+                if (!single) c2base = ix.c2[p];
+            }
+            if (blocks_round && !two) {
+                B.lowA = A.lowA; B.lowB = A.lowB; B.high = A.high;
+                B.q0 = A.q0; B.q1 = A.q1; B.q2 = A.q2; B.q3 = A.q3;
+            }
+            if (COUNT) cn.blocks += 1u + (two ? 1u : 0u);
+
+            // ---- arithmetic ----
+            if (st == PS_STEP) {
+                const uint32_t oi = i & (kBlockRows - 1u), oj = j - (bj << kBlockRowsLog2);
+                uint32_t ri = pair_rank(A, p, single, oi);
+                uint32_t rj = pair_rank(B, p, single, oj);
+                if (single) {
+                    const uint32_t y = p >> 2;
+                    if (y == 0u) {   // the '$' slot is stored as c1 = 'A'
+                        ri -= (i > ix.r0);
+                        rj -= (j > ix.r0);
+                    }
+                    const uint32_t base = sel4(y, ix.C0, ix.C1, ix.C2_, ix.C3);
+                    i = base + ri;
+                    j = base + rj;
+                    t -= 1;
+                    if (COUNT) cn.lf_steps += 1;
+                } else {
+                    if (p == 0u) {   // '$' slot stored as (A, A)
+                        ri -= (i > ix.r0);
+                        rj -= (j > ix.r0);
+                    }
+                    if (p == ix.p1) {   // the row of suffix 1 has no c2: stored as (A, T[0])
+                        ri -= (i > ix.r1);
+                        rj -= (j > ix.r1);
+                    }
+                    i = c2base + ri;
+                    j = c2base + rj;
+                    t -= 2;
+                    if (COUNT) cn.lf_steps += 2;
+                }
+                if (i == j) finalize(-1, -1);
+                else if (t < 0) st = PS_PROBE;
+            } else if (st == PS_PROBE) {
+                if (COUNT) cn.probes++;
+                const uint32_t oi = i & (kBlockRows - 1u);
+                int res;
+                long long ord = -1;
+                if (mode_all && !orders) {
+                    res = static_cast<int>((A.lowA >> (oi & 31u)) & 1u);
+                } else {
+                    const uint4 mi = reinterpret_cast<const uint4*>(wi)[3];
+                    const uint32_t oj = j - (bj << kBlockRowsLog2);
+                    uint32_t ones;
+                    if (bj == bi) {
+                        ones = popc_prefix128(mi, oj) - popc_prefix128(mi, oi);
+                    } else {
+                        const uint4 mj = reinterpret_cast<const uint4*>(wj)[3];
+                        ones = (ix.mrank[bj] + popc_prefix128(mj, oj)) - (ix.mrank[bi] + popc_prefix128(mi, oi));
+                    }
+                    res = ones > 0u;
+                    if (orders && res) ord = static_cast<long long>(ix.mrank[bi] + popc_prefix128(mi, oi));
+                }
+                finalize(res, ord);
+            } else {   // PS_LOOKUP
+                if (COUNT) cn.lookups++;
+                const uint32_t e = (tidx & 7u) >> 1;
+                const uint32_t x0 = sel4(e, opaque(A.q0.x), opaque(A.q1.x), opaque(A.q2.x), opaque(A.q3.x));
+                const uint32_t x1 = sel4(e, opaque(A.q0.y), opaque(A.q1.y), opaque(A.q2.y), opaque(A.q3.y));
+                const uint32_t x2 = sel4(e, opaque(A.q0.z), opaque(A.q1.z), opaque(A.q2.z), opaque(A.q3.z));
+                const uint32_t x3 = sel4(e, opaque(A.q0.w), opaque(A.q1.w), opaque(A.q2.w), opaque(A.q3.w));
+                i = (tidx & 1u) ? x2 : x0;
+                j = (tidx & 1u) ? x3 : x1;
+                t = k - 1 - T;
+                if (i == j) finalize(-1, -1);
+                else st = t < 0 ? PS_PROBE : PS_STEP;
+            }
+        }
+    }
+    if (COUNT) {
+        uint32_t v[6] = {cn.lf_steps, cn.blocks, cn.probes, cn.searches, cn.lookups, done};
+        const int slot[6] = {0, 1, 2, 3, 4, 6};
+#pragma unroll
+        for (int qq = 0; qq < 6; ++qq) {
+            uint32_t x = v[qq];
+            for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+            if ((threadIdx.x & 63) == 0 && x) atomicAdd(&counters[slot[qq]], static_cast<unsigned long long>(x));
+        }
+    }
+}
+
+PairIndex make_pair_index(const fmsi_hip_index* idx) {
+    PairIndex p;
+    p.pb = static_cast<const uint32_t*>(idx->d_pblocks);
+    p.sbt = static_cast<const uint32_t*>(idx->d_sbt);
+    p.c2 = static_cast<const uint32_t*>(idx->d_c2);
+    p.mrank = idx->dev.mrank;
+    p.ptable = idx->dev.ptable;
+    p.ptable_len = idx->dev.ptable_len;
+    p.n = idx->dev.n;
+    p.r0 = idx->dev.dollar;
+    p.r1 = idx->pair_r1;
+    p.p1 = idx->pair_p1;
+    p.C0 = idx->dev.C0; p.C1 = idx->dev.C1; p.C2_ = idx->dev.C2; p.C3 = idx->dev.C3;
+    return p;
+}
+
+template <bool COUNT, bool PTABLE>
+void launch_pair_t(fmsi_hip_index* idx, const uint64_t* d_kmers, uint64_t n, int k, uint32_t flags, uint8_t* o8, long long* o64,
+                   unsigned long long* d_counters, hipStream_t s) {
+    uint64_t chunk = n / (256ull * 32 * 8);
+    chunk = std::min<uint64_t>(std::max<uint64_t>(chunk, 256), 4096);
+    const uint64_t waves = (n + chunk - 1) / chunk;
+    const uint32_t blocks = static_cast<uint32_t>((waves + 3) / 4);
+    hipLaunchKernelGGL((query_pair_kernel<COUNT, PTABLE>), dim3(blocks), dim3(256), 0, s, make_pair_index(idx), d_kmers, n, k, flags,
+                       static_cast<uint32_t>(chunk), o8, o64, d_counters);
+}
+
+}  // namespace
+
+void launch_pair_query(fmsi_hip_index* idx, const uint64_t* d_kmers, uint64_t n, int k, uint32_t flags, bool use_table, uint8_t* o8,
+                       long long* o64, unsigned long long* d_counters, hipStream_t s) {
+    if (use_table) {
+        if (d_counters) launch_pair_t<true, true>(idx, d_kmers, n, k, flags, o8, o64, d_counters, s);
+        else launch_pair_t<false, true>(idx, d_kmers, n, k, flags, o8, o64, d_counters, s);
+    } else {
+        if (d_counters) launch_pair_t<true, false>(idx, d_kmers, n, k, flags, o8, o64, d_counters, s);
+        else launch_pair_t<false, false>(idx, d_kmers, n, k, flags, o8, o64, d_counters, s);
+    }
+}
+
+}  // namespace fmsi
+
+using namespace fmsi;
+
+extern "C" int fmsi_hip_index_enable_pair_layout(fmsi_hip_index* idx) {
+    if (!idx) return FMSI_HIP_EINVAL;
+    if (idx->d_pblocks) return 0;
+    FMSI_HIP_TRY(hipSetDevice(idx->device));
+    const uint64_t n_blocks = idx->n_blocks;
+    const uint64_t n_super = ((n_blocks - 1) >> kSuperBlocksLog2) + 1;
+    void *pb = nullptr, *counts = nullptr, *scanned = nullptr, *sbt = nullptr, *c2 = nullptr, *spec = nullptr, *temp = nullptr;
+    auto cleanup = [&]() {
+        for (void* p : {counts, scanned, spec, temp})
+            if (p) (void)hipFree(p);
+    };
+    auto fail = [&](int code, const char* msg) {
+        cleanup();
+        for (void* p : {pb, sbt, c2})
+            if (p) (void)hipFree(p);
+        set_last_error(msg);
+        return code;
+    };
+    const size_t pb_bytes = n_blocks * kPairBlockDwords * 4;
+    if (hipMalloc(&pb, pb_bytes) != hipSuccess || hipMalloc(&counts, (n_blocks + 1) * sizeof(U16)) != hipSuccess ||
+        hipMalloc(&scanned, (n_blocks + 1) * sizeof(U16)) != hipSuccess || hipMalloc(&sbt, n_super * 64) != hipSuccess ||
+        hipMalloc(&c2, 64) != hipSuccess || hipMalloc(&spec, 8) != hipSuccess)
+        return fail(FMSI_HIP_ENOMEM, "hipMalloc failed for the pair layout");
+    if (hipMemset(pb, 0, pb_bytes) != hipSuccess || hipMemset(counts, 0, (n_blocks + 1) * sizeof(U16)) != hipSuccess ||
+        hipMemset(spec, 0xFF, 8) != hipSuccess)
+        return fail(FMSI_HIP_EHIP, "hipMemset failed for the pair layout");
+    const uint32_t grid = static_cast<uint32_t>((idx->n + 255) / 256);
+    hipLaunchKernelGGL(pair_emit_kernel, dim3(grid), dim3(256), 0, 0, idx->dev, static_cast<uint32_t*>(pb), static_cast<U16*>(counts),
+                       static_cast<uint32_t*>(spec));
+    size_t tb = 0;
+    U16 zero{};
+    if (rocprim::exclusive_scan(nullptr, tb, static_cast<U16*>(counts), static_cast<U16*>(scanned), zero, static_cast<size_t>(n_blocks + 1),
+                                U16Plus()) != hipSuccess ||
+        hipMalloc(&temp, tb) != hipSuccess ||
+        rocprim::exclusive_scan(temp, tb, static_cast<U16*>(counts), static_cast<U16*>(scanned), zero, static_cast<size_t>(n_blocks + 1),
+                                U16Plus()) != hipSuccess)
+        return fail(FMSI_HIP_EHIP, "pair layout: prefix sums failed");
+    hipLaunchKernelGGL(pair_counts_kernel, dim3(static_cast<uint32_t>((n_blocks + 255) / 256)), dim3(256), 0, 0, static_cast<const U16*>(scanned),
+                       n_blocks, static_cast<uint32_t*>(pb), static_cast<uint32_t*>(sbt));
+    U16 totals;
+    uint32_t specials[2] = {0, 0}, block0[16];
+    if (hipMemcpy(&totals, static_cast<U16*>(scanned) + n_blocks, sizeof(U16), hipMemcpyDeviceToHost) != hipSuccess ||
+        hipMemcpy(specials, spec, 8, hipMemcpyDeviceToHost) != hipSuccess ||
+        hipMemcpy(block0, idx->d_blocks, 64, hipMemcpyDeviceToHost) != hipSuccess || hipDeviceSynchronize() != hipSuccess)
+        return fail(FMSI_HIP_EHIP, "pair layout: device work failed");
+    // C2[c2 | c1 << 2] = rows whose suffix is smaller than any suffix starting with "c2 c1":
+    //   C[c2] + [last text symbol == c2] + sum over y' < c1 of #(text positions with T[p] = c2, T[p+1] = y')
+    uint32_t pairs[16];
+    for (int p = 0; p < 16; ++p) pairs[p] = totals.v[p];
+    pairs[0] -= 1;                                                // the '$' slot, stored as (A, A)
+    uint32_t r1 = 0xFFFFFFFFu, p1 = 0xFFFFFFFFu;
+    if (specials[0] != 0xFFFFFFFFu) {
+        r1 = specials[0];
+        p1 = specials[1] << 2;                                    // stored as (A, T[0])
+        pairs[p1] -= 1;
+    }
+    const uint32_t last_sym = ((block0[4] & 1u) << 1) | (block0[8] & 1u);   // c1 of row 0 (the empty suffix) = T[N-1]
+    const uint32_t C[4] = {idx->dev.C0, idx->dev.C1, idx->dev.C2, idx->dev.C3};
+    uint32_t c2h[16];
+    for (uint32_t a = 0; a < 4; ++a) {
+        uint32_t run = C[a] + (idx->n > 1 && last_sym == a ? 1u : 0u);
+        for (uint32_t y = 0; y < 4; ++y) {
+            c2h[a | (y << 2)] = run;
+            run += pairs[a | (y << 2)];
+        }
+    }
+    if (hipMemcpy(c2, c2h, 64, hipMemcpyHostToDevice) != hipSuccess) return fail(FMSI_HIP_EHIP, "pair layout: upload failed");
+    cleanup();
+    idx->d_pblocks = pb;
+    idx->d_sbt = sbt;
+    idx->d_c2 = c2;
+    idx->pair_r1 = r1;
+    idx->pair_p1 = p1;
+    idx->device_bytes += pb_bytes + n_super * 64 + 64;
+    return 0;
+}

@@ -49,6 +49,11 @@ struct fmsi_hip_index {
     void* d_mrank = nullptr;
     void* d_ptable = nullptr;
     void* d_klcp = nullptr;      // plain kLCP bit-vector (n bits, u64 words), when present
+    // optional pair layout (fmsi_pair.hip): 128-B blocks for two-base LF steps
+    void* d_pblocks = nullptr;
+    void* d_sbt = nullptr;
+    void* d_c2 = nullptr;
+    uint32_t pair_r1 = 0xFFFFFFFFu, pair_p1 = 0xFFFFFFFFu;
     void* d_text2 = nullptr;     // 2-bit packed superstring kept by the on-device builder (synthetic workloads)
     uint64_t text_len = 0;
     // staging for host-pointer calls
@@ -69,6 +74,10 @@ struct fmsi_hip_index {
 namespace fmsi {
 // builds the optional prefix table on the device (fmsi_hip.hip)
 int build_prefix_table(fmsi_hip_index* idx, int t);
+
+// two-base-step kernel over the pair layout (fmsi_pair.hip); requires idx->d_pblocks
+void launch_pair_query(fmsi_hip_index* idx, const uint64_t* d_kmers, uint64_t n, int k, uint32_t flags, bool use_table, uint8_t* o8,
+                       long long* o64, unsigned long long* d_counters, hipStream_t s);
 
 // grow-only device staging buffer
 inline int ensure_cap(void** p, size_t* cap, size_t need) {

@@ -61,6 +61,8 @@ extern "C" {
 #define FMSI_HIP_KERNEL_AUTO 0x00u
 #define FMSI_HIP_KERNEL_LOCKSTEP 0x10u   /* one lane per k-mer, wave walks the k LF steps in lock-step */
 #define FMSI_HIP_KERNEL_REFILL 0x20u     /* persistent lanes: a lane that finishes pulls the next k-mer (ballot/mbcnt) */
+#define FMSI_HIP_KERNEL_PAIR 0x30u       /* persistent lanes + two-base LF steps over the 128-B pair layout (needs
+                                            fmsi_hip_index_enable_pair_layout); AUTO picks it when the layout exists */
 #define FMSI_HIP_KERNEL_MASK 0xF0u
 /* do not use the private prefix table even if the handle has one (canonical-step accounting runs) */
 #define FMSI_HIP_NO_PREFIX_TABLE 0x100u
@@ -140,6 +142,13 @@ int fmsi_hip_index_download_text(const fmsi_hip_index* idx, uint64_t* words);
 
 /* Copies the device layout back (n_blocks*16 dwords, n_blocks+1 dwords) -- verification aid. */
 int fmsi_hip_index_download_layout(const fmsi_hip_index* idx, uint32_t* blocks, uint32_t* mrank);
+
+/* Adds the optional "pair layout" to a handle (built on the device from the single-step layout, so it works for
+ * handles made by fmsi_hip_index_create and by fmsi_hip_index_build*): 128-byte blocks holding, per row, both
+ * preceding text symbols and cumulative counts of the 16 symbol pairs, so that ONE block read performs TWO
+ * update_range() steps (src/fms_index.h:98-103).  Final intervals and results are unchanged; the number of random
+ * block reads per k-mer roughly halves.  Costs 1 byte per row of HBM.  Idempotent. */
+int fmsi_hip_index_enable_pair_layout(fmsi_hip_index* idx);
 
 /* Copies the handle's kLCP bit-vector back (ceil(n/64) words); fails when the handle has none. */
 int fmsi_hip_index_download_klcp(const fmsi_hip_index* idx, uint64_t* words);

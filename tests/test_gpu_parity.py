@@ -44,6 +44,11 @@ def test_both_strands_equal_oracle(fm, oracle_built, name):
     packed = fm.pack_kmers(kmers, k)
     dev_t = fm.DeviceIndex.from_files(index_prefix(name), prefix_len=min(k, 6))   # private prefix table of min(k, 6) steps
     variants = [(dev, fm.KERNEL_LOCKSTEP), (dev, fm.KERNEL_REFILL), (dev_t, fm.KERNEL_REFILL)]
+    # two-base-step kernel over the 128-B pair layout: no table, and tables of both parities of k - t
+    dev_p = fm.DeviceIndex.from_files(index_prefix(name)).enable_pair_layout()
+    dev_pe = fm.DeviceIndex.from_files(index_prefix(name), prefix_len=min(k, 6)).enable_pair_layout()
+    dev_po = fm.DeviceIndex.from_files(index_prefix(name), prefix_len=max(1, min(k, 6) - 1)).enable_pair_layout()
+    variants += [(dev_p, fm.KERNEL_PAIR), (dev_pe, fm.KERNEL_PAIR), (dev_po, 0), (dev_pe, fm.KERNEL_REFILL)]
     for mode_all in (False, True):
         flag = fm.MODE_ALL if mode_all else fm.MODE_OR
         fwd, rc = orc.ternaries_bulk(raw, len(kmers), k, mode_all)
