@@ -1,24 +1,32 @@
-// Two-base LF steps over 128-byte blocks ("pair layout") -- the request-count optimisation of the query path.
+// Two-base LF steps over 128-byte blocks ("pair layout"), read cooperatively by quads of lanes -- the
+// request-count optimisation of the query path.
 //
-// Why: the chip serves ~52-57 G random block reads/s whether a block is 64 B or 128 B, as long as the randomly
-// accessed footprint stays below ~3.2 GB (profiles/r01_gather_ceiling.md).  The single-step kernels already run at
-// that request ceiling, so the only way up is fewer requests per k-mer.  A 128-byte block can carry what TWO
-// consecutive backward-search steps need: for every row r (suffix start s = SA[r]) both preceding symbols
-// c1 = T[s-1] (the BWT symbol) and c2 = T[s-2], plus cumulative counts of the 16 (c2, c1) pairs.  Then
+// Why: the chip serves ~52 G random block reads/s whether a block is 64 B or 128 B, as long as the randomly
+// accessed footprint stays below ~3.2 GB and a wave keeps <= ~8 dwordx4 loads in flight per lane
+// (profiles/r01_gather_ceiling.md).  The single-step kernels already run at that request ceiling, so the only way
+// up is fewer requests per k-mer.  A 128-byte block can carry what TWO consecutive backward-search steps need: for
+// every row r (suffix start s = SA[r]) both preceding symbols c1 = T[s-1] (the BWT symbol) and c2 = T[s-2], plus
+// cumulative counts of the 16 (c2, c1) pairs.  Then
 //     [i, j)  --(prepend "c2 c1")-->  [C2[c2,c1] + rank_pair(i), C2[c2,c1] + rank_pair(j))
 // is ONE block read per boundary -- exactly the interval two update_range() calls (reference
 // src/fms_index.h:98-103) produce, so the final SA interval, the early exit on an empty interval and therefore
 // every result are unchanged.  c2 is derived on the device from the single-step layout alone (c2(r) = BWT[LF(r)]),
 // so the layout can be added to any handle, whether it was loaded from the reference's files or built on the device.
 //
-// Block = 128 B = 128 rows (32 dwords):
-//   dw  0..7   low 16 bits of the 16 pair counts (two per dword), relative to the superblock start
-//   dw  8..11  high 8 bits of the 16 pair counts (four per dword)            -> 24-bit relative counts
-//   dw 12..15  mask plane (SA-transformed mask)
-//   dw 16..19  c1 hi plane   dw 20..23  c1 lo plane   dw 24..27  c2 hi plane   dw 28..31  c2 lo plane
-// pair index p = c2 | c1 << 2.  Superblock = 2^23 rows; `sbt` holds the 16 absolute counts at each superblock start
-// (21 KB at human scale: cache resident).  Rows without a c1 / c2 (suffix starts 0 and 1) are stored as 'A' and
-// subtracted in the rank, like the '$' slot of the reference (src/fms_index.h:81).
+// Block = 128 B = 128 rows = four 32-byte QUARTERS; quarter s covers rows 32s .. 32s+31 and is read by lane s of a
+// quad with two dwordx4 loads (the quad's four loads coalesce into one 128-B request):
+//   dw 0  c1 hi plane   dw 1  c1 lo plane   dw 2  c2 hi plane   dw 3  c2 lo plane      (32 rows each)
+//   dw 4  mask plane (SA-transformed mask, 32 rows)
+//   dw 5..7  the four cumulative counts of the pairs with c1 = s (pair index p = c2 | c1 << 2 = 4s .. 4s+3),
+//            24 bits each, relative to the superblock start
+// Superblock = 2^23 rows; `sbt` holds the 16 absolute counts at each superblock start (21 KB at human scale: cache
+// resident).  Rows without a c1 / c2 (suffix starts 0 and 1) are stored as 'A' and subtracted in the rank, like the
+// '$' slot of the reference (src/fms_index.h:81).
+//
+// Kernel: the persistent-lane state machine of query_refill_kernel with a QUAD per k-mer: the four lanes hold the
+// same state, each ranks its 32 rows, partial popcounts are summed with two quad shuffles and the count / mask bit /
+// table entry owned by one lane is broadcast with one wave shuffle.  16 k-mers per wave, <= 4 dwordx4 in flight per
+// lane, ~60 VGPRs.
 #include <hip/hip_runtime.h>
 #include <rocprim/device/device_scan.hpp>
 
@@ -93,15 +101,16 @@ __global__ __launch_bounds__(256) void pair_emit_kernel(DevIndex ix, uint32_t* _
     const uint64_t h2 = __ballot(valid && (c2 & 2u)), l2 = __ballot(valid && (c2 & 1u));
     const uint64_t mm = __ballot(valid && mbit), vv = __ballot(valid);
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    if (lane == 0 && vv) {
-        const uint64_t w = row64 >> 6;
-        uint32_t* blk = pb + (w >> 1) * kPairBlockDwords;
-        const uint32_t half = static_cast<uint32_t>(w & 1) * 2;
-        blk[12 + half] = static_cast<uint32_t>(mm);  blk[13 + half] = static_cast<uint32_t>(mm >> 32);
-        blk[16 + half] = static_cast<uint32_t>(h1);  blk[17 + half] = static_cast<uint32_t>(h1 >> 32);
-        blk[20 + half] = static_cast<uint32_t>(l1);  blk[21 + half] = static_cast<uint32_t>(l1 >> 32);
-        blk[24 + half] = static_cast<uint32_t>(h2);  blk[25 + half] = static_cast<uint32_t>(h2 >> 32);
-        blk[28 + half] = static_cast<uint32_t>(l2);  blk[29 + half] = static_cast<uint32_t>(l2 >> 32);
+    if (lane < 2 && vv) {   // lane 0: rows 0..31 of the wave, lane 1: rows 32..63 -> one quarter each
+        const uint64_t w = row64 >> 6;                                   // 64-row word of the index
+        const uint32_t quarter = static_cast<uint32_t>(w & 1) * 2u + lane;
+        uint32_t* qd = pb + (w >> 1) * kPairBlockDwords + quarter * 8u;
+        const uint32_t sh = lane * 32u;
+        qd[0] = static_cast<uint32_t>(h1 >> sh);
+        qd[1] = static_cast<uint32_t>(l1 >> sh);
+        qd[2] = static_cast<uint32_t>(h2 >> sh);
+        qd[3] = static_cast<uint32_t>(l2 >> sh);
+        qd[4] = static_cast<uint32_t>(mm >> sh);
     }
     if (lane < 16) {   // lane p counts pair p = c2 | c1 << 2 of its wave
         const uint64_t m = vv & ((lane & 8u) ? h1 : ~h1) & ((lane & 4u) ? l1 : ~l1) & ((lane & 2u) ? h2 : ~h2) & ((lane & 1u) ? l2 : ~l2);
@@ -121,18 +130,15 @@ __global__ void pair_counts_kernel(const U16* __restrict__ scanned, uint64_t n_b
     const U16 a = scanned[b];
     const uint64_t sb = b >> kSuperBlocksLog2;
     const U16 base = scanned[sb << kSuperBlocksLog2];
-    uint32_t lo[8] = {0, 0, 0, 0, 0, 0, 0, 0}, hi[4] = {0, 0, 0, 0};
-#pragma unroll
-    for (int p = 0; p < 16; ++p) {
-        const uint32_t rel = a.v[p] - base.v[p];
-        lo[p >> 1] |= (rel & 0xFFFFu) << (16 * (p & 1));
-        hi[p >> 2] |= ((rel >> 16) & 0xFFu) << (8 * (p & 3));
-    }
     uint32_t* blk = pb + b * kPairBlockDwords;
 #pragma unroll
-    for (int q = 0; q < 8; ++q) blk[q] = lo[q];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) blk[8 + q] = hi[q];
+    for (int s = 0; s < 4; ++s) {
+        const uint32_t r0 = a.v[4 * s] - base.v[4 * s], r1 = a.v[4 * s + 1] - base.v[4 * s + 1];
+        const uint32_t r2 = a.v[4 * s + 2] - base.v[4 * s + 2], r3 = a.v[4 * s + 3] - base.v[4 * s + 3];
+        blk[8 * s + 5] = (r0 & 0xFFFFFFu) | (r1 << 24);
+        blk[8 * s + 6] = ((r1 >> 8) & 0xFFFFu) | (r2 << 16);
+        blk[8 * s + 7] = ((r2 >> 16) & 0xFFu) | (r3 << 8);
+    }
     if ((b & ((1ull << kSuperBlocksLog2) - 1)) == 0) {
 #pragma unroll
         for (int p = 0; p < 16; ++p) sbt[sb * 16 + p] = a.v[p];
@@ -142,34 +148,16 @@ __global__ void pair_counts_kernel(const U16* __restrict__ scanned, uint64_t n_b
 // ---- query kernel -----------------------------------------------------------------------------------------
 enum : uint32_t { PS_IDLE = 0, PS_LOOKUP = 1, PS_STEP = 2, PS_PROBE = 3 };
 
-struct PairLoads {
-    uint32_t lowA, lowB, high;
-    uint4 sb4;
-    uint4 q0, q1, q2, q3;   // c1 hi, c1 lo, c2 hi, c2 lo planes -- or the four quarters of a prefix-table line
-};
+__device__ __forceinline__ uint32_t quad_sum(uint32_t x) {
+    x += __shfl_xor(x, 1, 64);
+    x += __shfl_xor(x, 2, 64);
+    return x;
+}
 
-__device__ __forceinline__ uint32_t bytes_sum(uint32_t x) { return (x & 0xFFu) + ((x >> 8) & 0xFFu) + ((x >> 16) & 0xFFu) + (x >> 24); }
-
-// rank of pair p (single == false) or of symbol y = p >> 2 over all four c2 (single == true) among the first `o`
-// rows of the block, plus the block's cumulative count
-__device__ __forceinline__ uint32_t pair_rank(const PairLoads& L, uint32_t p, bool single, uint32_t o) {
-    uint32_t cnt;
-    if (single) {
-        const uint32_t lows = (L.lowA & 0xFFFFu) + (L.lowA >> 16) + (L.lowB & 0xFFFFu) + (L.lowB >> 16);
-        cnt = lows + (bytes_sum(L.high) << 16) + L.sb4.x + L.sb4.y + L.sb4.z + L.sb4.w;
-    } else {
-        const uint32_t rel = ((L.lowA >> (16u * (p & 1u))) & 0xFFFFu) | (((L.high >> (8u * (p & 3u))) & 0xFFu) << 16);
-        cnt = rel + sel4(p & 3u, opaque(L.sb4.x), opaque(L.sb4.y), opaque(L.sb4.z), opaque(L.sb4.w));
-    }
-    const uint32_t x1h = (p & 8u) ? 0u : 0xFFFFFFFFu, x1l = (p & 4u) ? 0u : 0xFFFFFFFFu;
-    const uint32_t x2h = (p & 2u) ? 0u : 0xFFFFFFFFu, x2l = (p & 1u) ? 0u : 0xFFFFFFFFu;
-    const uint32_t all = single ? 0xFFFFFFFFu : 0u;   // single step: the c2 planes do not restrict
-    const int s = static_cast<int>(o);
-    cnt += __popc((L.q0.x ^ x1h) & (L.q1.x ^ x1l) & ((L.q2.x ^ x2h) | all) & ((L.q3.x ^ x2l) | all) & prefix32(s));
-    cnt += __popc((L.q0.y ^ x1h) & (L.q1.y ^ x1l) & ((L.q2.y ^ x2h) | all) & ((L.q3.y ^ x2l) | all) & prefix32(s - 32));
-    cnt += __popc((L.q0.z ^ x1h) & (L.q1.z ^ x1l) & ((L.q2.z ^ x2h) | all) & ((L.q3.z ^ x2l) | all) & prefix32(s - 64));
-    cnt += __popc((L.q0.w ^ x1h) & (L.q1.w ^ x1l) & ((L.q2.w ^ x2h) | all) & ((L.q3.w ^ x2l) | all) & prefix32(s - 96));
-    return cnt;
+// count m (0..3) of a quarter's packed 24-bit counts, or their sum
+__device__ __forceinline__ uint32_t quarter_count(uint32_t a, uint32_t b, uint32_t c, uint32_t m, bool sum) {
+    const uint32_t c0 = a & 0xFFFFFFu, c1 = (a >> 24) | ((b & 0xFFFFu) << 8), c2 = (b >> 16) | ((c & 0xFFu) << 16), c3 = c >> 8;
+    return sum ? c0 + c1 + c2 + c3 : sel4(m, c0, c1, c2, c3);
 }
 
 struct PairCounters {
@@ -183,11 +171,16 @@ __global__ __launch_bounds__(256) void query_pair_kernel(PairIndex ix, const uin
     const uint32_t mode_all = flags & FMSI_HIP_MODE_ALL;
     const uint32_t strict = flags & FMSI_HIP_STRICT;
     const uint32_t orders = flags & FMSI_HIP_ORDERS;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t sub = lane & 3u;                 // my quarter
+    const uint32_t qbase = lane & ~3u;              // first lane of my quad
+    const uint64_t quads_below = (1ull << qbase) - 1ull;
     const uint64_t wave = (static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
     uint64_t next = wave * chunk;
     const uint64_t end = min(n_windows, next + static_cast<uint64_t>(chunk));
     const int T = PTABLE ? static_cast<int>(ix.ptable_len) : 0;
 
+    // all four lanes of a quad carry the same state
     uint64_t f = 0, cur = 0, f_next = 0, q = 0, q_next = 0;
     uint32_t i = 0, j = 0, st = PS_IDLE, phase = 0, done = 0;
     int t = 0, res_f = -1;
@@ -223,17 +216,19 @@ __global__ __launch_bounds__(256) void query_pair_kernel(PairIndex ix, const uin
         const bool was_second = phase == 1;
         const int rf = was_second ? res_f : res, rr = was_second ? res : -1;
         const long long of = was_second ? ord_f : ord, orr = was_second ? ord : -1;
-        if (orders) {
-            if (strict) {
-                out_orders[2 * q] = of;
-                out_orders[2 * q + 1] = orr;
+        if (sub == 0) {
+            if (orders) {
+                if (strict) {
+                    out_orders[2 * q] = of;
+                    out_orders[2 * q + 1] = orr;
+                } else {
+                    out_orders[q] = was_second ? orr : of;
+                }
+            } else if (strict) {
+                out[q] = static_cast<uint8_t>((rf + 1) | ((rr + 1) << 2));
             } else {
-                out_orders[q] = was_second ? orr : of;
+                out[q] = static_cast<uint8_t>((was_second ? rr : rf) == 1);
             }
-        } else if (strict) {
-            out[q] = static_cast<uint8_t>((rf + 1) | ((rr + 1) << 2));
-        } else {
-            out[q] = static_cast<uint8_t>((was_second ? rr : rf) == 1);
         }
         st = PS_IDLE;
         done++;
@@ -249,12 +244,12 @@ __global__ __launch_bounds__(256) void query_pair_kernel(PairIndex ix, const uin
         }
         {
             const bool want = !has_next;
-            const uint64_t m = __ballot(want);
+            const uint64_t m = __ballot(want) & 0x1111111111111111ull;   // one bit per quad
             if (m) {
-                const uint64_t cand = next + lanes_below(m);
+                const uint64_t cand = next + static_cast<uint64_t>(__popcll(m & quads_below));
                 if (want && cand < end) {
                     q_next = cand;
-                    f_next = kmers[cand];
+                    f_next = kmers[cand];   // the quad reads one address: a single request
                     has_next = true;
                 }
                 next += static_cast<uint64_t>(__popcll(m));
@@ -265,7 +260,6 @@ __global__ __launch_bounds__(256) void query_pair_kernel(PairIndex ix, const uin
             continue;
         }
         if (st != PS_IDLE) {
-            // ---- addresses of this round ----
             const bool single = st == PS_STEP && ((t + 1) & 1);          // odd number of bases left: one single-base step first
             uint32_t p = 0;                                              // pair index c2 | c1 << 2 (single: c1 << 2)
             if (st == PS_STEP) {
@@ -274,57 +268,56 @@ __global__ __launch_bounds__(256) void query_pair_kernel(PairIndex ix, const uin
                 p = c2 | (c1 << 2);
             }
             const uint32_t bi = i >> kBlockRowsLog2, bj = (j - 1u) >> kBlockRowsLog2;
-            const uint32_t* wi = ix.pb + static_cast<size_t>(bi) * kPairBlockDwords;
-            const uint32_t* wj = ix.pb + static_cast<size_t>(bj) * kPairBlockDwords;
-            const uint4* pi4 = reinterpret_cast<const uint4*>(wi) + 4;   // planes
-            const uint4* pj4 = reinterpret_cast<const uint4*>(wj) + 4;
+            // my 32-byte quarter of each boundary's block -- or my 16 bytes of the prefix-table line
+            const uint4* pi4 = reinterpret_cast<const uint4*>(ix.pb + static_cast<size_t>(bi) * kPairBlockDwords) + sub * 2u;
+            const uint4* pj4 = reinterpret_cast<const uint4*>(ix.pb + static_cast<size_t>(bj) * kPairBlockDwords) + sub * 2u;
             uint32_t tidx = 0;
-            if (PTABLE && st == PS_LOOKUP) {
+            const bool lookup = PTABLE && st == PS_LOOKUP;
+            if (lookup) {
                 tidx = static_cast<uint32_t>(cur >> (2 * (k - T))) & ((1u << (2 * T)) - 1u);
-                pi4 = reinterpret_cast<const uint4*>(ix.ptable + (tidx & ~7u));
-                pj4 = pi4;
+                pi4 = reinterpret_cast<const uint4*>(ix.ptable + (tidx & ~7u)) + sub;
             }
-            // count dwords: pair -> (p >> 1, 8 + (p >> 2)); single -> (2y, 2y + 1, 8 + y); probe -> mask dword of row i
-            uint32_t la = p >> 1, lb = p >> 1, hd = 8u + (p >> 2);
-            if (single) {
-                la = (p >> 2) * 2u;
-                lb = la + 1u;
-            }
-            if (st == PS_PROBE) la = 12u + ((i & (kBlockRows - 1u)) >> 5);
-            const bool blocks_round = st != PS_LOOKUP;
-            const bool two = blocks_round && st == PS_STEP && bj != bi;
-            const uint4* sbi = reinterpret_cast<const uint4*>(ix.sbt) + (static_cast<size_t>(i >> kSuperLog2) << 2) + (p >> 2);
-            const uint4* sbj = reinterpret_cast<const uint4*>(ix.sbt) + (static_cast<size_t>((j - 1u) >> kSuperLog2) << 2) + (p >> 2);
-            PairLoads A, B;
-            A.lowA = A.lowB = A.high = 0; A.sb4 = make_uint4(0, 0, 0, 0);
-            B = A;
-            B.q0 = B.q1 = B.q2 = B.q3 = make_uint4(0, 0, 0, 0);
+            const bool two = st == PS_STEP && bj != bi;
+            uint4 b0 = make_uint4(0, 0, 0, 0), b1 = b0, a1 = b0;
+            uint32_t sbi = 0, sbj = 0, c2base = 0;
             if (two) {
-                B.lowA = wj[la]; B.lowB = wj[lb]; B.high = wj[hd];
-                B.q0 = pj4[0]; B.q1 = pj4[1]; B.q2 = pj4[2]; B.q3 = pj4[3];
+                b0 = pj4[0];
+                b1 = pj4[1];
             }
-            A.q0 = pi4[0]; A.q1 = pi4[1]; A.q2 = pi4[2]; A.q3 = pi4[3];
-            if (blocks_round) {
-                A.lowA = wi[la]; A.lowB = wi[lb]; A.high = wi[hd];
+            const uint4 a0 = pi4[0];
+            if (!lookup) a1 = pi4[1];
+            if (st == PS_STEP) {   // tiny cache-resident tables: not random HBM requests.  One unconditional load each:
+                // pair step -> count p; single step -> my quarter's share of the four counts with c1 = p >> 2 (summed below)
+                const uint32_t se = single ? ((p & 12u) + sub) : p;
+                sbi = ix.sbt[(static_cast<size_t>(i >> kSuperLog2) << 4) + se];
+                sbj = ix.sbt[(static_cast<size_t>((j - 1u) >> kSuperLog2) << 4) + se];
+                c2base = ix.c2[p];
             }
-            uint32_t c2base = 0;
-            if (st == PS_STEP) {
-                A.sb4 = *sbi;
-                B.sb4 = *sbj;                          // tiny, cache-resident table: not a random HBM request
-                if (!single) c2base = ix.c2[p];
+            if (!two) {
+                b0 = a0;
+                b1 = a1;
             }
-            if (blocks_round && !two) {
-                B.lowA = A.lowA; B.lowB = A.lowB; B.high = A.high;
-                B.q0 = A.q0; B.q1 = A.q1; B.q2 = A.q2; B.q3 = A.q3;
-            }
-            if (COUNT) cn.blocks += 1u + (two ? 1u : 0u);
+            if (COUNT && sub == 0) cn.blocks += 1u + (two ? 1u : 0u);
 
-            // ---- arithmetic ----
             if (st == PS_STEP) {
                 const uint32_t oi = i & (kBlockRows - 1u), oj = j - (bj << kBlockRowsLog2);
-                uint32_t ri = pair_rank(A, p, single, oi);
-                uint32_t rj = pair_rank(B, p, single, oj);
+                const uint32_t x1h = (p & 8u) ? 0u : 0xFFFFFFFFu, x1l = (p & 4u) ? 0u : 0xFFFFFFFFu;
+                const uint32_t x2h = (p & 2u) ? 0u : 0xFFFFFFFFu, x2l = (p & 1u) ? 0u : 0xFFFFFFFFu;
+                const uint32_t all = single ? 0xFFFFFFFFu : 0u;   // single step: the c2 planes do not restrict
+                const uint32_t mi = (a0.x ^ x1h) & (a0.y ^ x1l) & ((a0.z ^ x2h) | all) & ((a0.w ^ x2l) | all);
+                const uint32_t mj = (b0.x ^ x1h) & (b0.y ^ x1l) & ((b0.z ^ x2h) | all) & ((b0.w ^ x2l) | all);
+                const int shift = static_cast<int>(sub * 32u);
+                uint32_t ri = quad_sum(__popc(mi & prefix32(static_cast<int>(oi) - shift)));
+                uint32_t rj = quad_sum(__popc(mj & prefix32(static_cast<int>(oj) - shift)));
+                // cumulative counts live in the quarter of c1 = p >> 2
+                const uint32_t owner = qbase | (p >> 2);
+                const uint32_t ci = quarter_count(a1.y, a1.z, a1.w, p & 3u, single);
+                const uint32_t cj = quarter_count(b1.y, b1.z, b1.w, p & 3u, single);
+                ri += static_cast<uint32_t>(__shfl(static_cast<int>(ci), static_cast<int>(owner), 64));
+                rj += static_cast<uint32_t>(__shfl(static_cast<int>(cj), static_cast<int>(owner), 64));
                 if (single) {
+                    ri += quad_sum(sbi);
+                    rj += quad_sum(sbj);
                     const uint32_t y = p >> 2;
                     if (y == 0u) {   // the '$' slot is stored as c1 = 'A'
                         ri -= (i > ix.r0);
@@ -334,8 +327,10 @@ __global__ __launch_bounds__(256) void query_pair_kernel(PairIndex ix, const uin
                     i = base + ri;
                     j = base + rj;
                     t -= 1;
-                    if (COUNT) cn.lf_steps += 1;
+                    if (COUNT && sub == 0) cn.lf_steps += 1;
                 } else {
+                    ri += sbi;
+                    rj += sbj;
                     if (p == 0u) {   // '$' slot stored as (A, A)
                         ri -= (i > ix.r0);
                         rj -= (j > ix.r0);
@@ -347,40 +342,40 @@ __global__ __launch_bounds__(256) void query_pair_kernel(PairIndex ix, const uin
                     i = c2base + ri;
                     j = c2base + rj;
                     t -= 2;
-                    if (COUNT) cn.lf_steps += 2;
+                    if (COUNT && sub == 0) cn.lf_steps += 2;
                 }
                 if (i == j) finalize(-1, -1);
                 else if (t < 0) st = PS_PROBE;
             } else if (st == PS_PROBE) {
-                if (COUNT) cn.probes++;
+                if (COUNT && sub == 0) cn.probes++;
                 const uint32_t oi = i & (kBlockRows - 1u);
+                const int shift = static_cast<int>(sub * 32u);
                 int res;
                 long long ord = -1;
                 if (mode_all && !orders) {
-                    res = static_cast<int>((A.lowA >> (oi & 31u)) & 1u);
+                    const uint32_t bit = (a1.x >> (oi & 31u)) & 1u;            // valid in the lane that owns row i
+                    res = __shfl(static_cast<int>(bit), static_cast<int>(qbase | (oi >> 5)), 64);
                 } else {
-                    const uint4 mi = reinterpret_cast<const uint4*>(wi)[3];
                     const uint32_t oj = j - (bj << kBlockRowsLog2);
+                    const uint32_t below_i = quad_sum(__popc(a1.x & prefix32(static_cast<int>(oi) - shift)));
                     uint32_t ones;
                     if (bj == bi) {
-                        ones = popc_prefix128(mi, oj) - popc_prefix128(mi, oi);
-                    } else {
-                        const uint4 mj = reinterpret_cast<const uint4*>(wj)[3];
-                        ones = (ix.mrank[bj] + popc_prefix128(mj, oj)) - (ix.mrank[bi] + popc_prefix128(mi, oi));
+                        ones = quad_sum(__popc(a1.x & prefix32(static_cast<int>(oj) - shift))) - below_i;
+                    } else {   // interval spans blocks (long repeats): rank difference through the side array
+                        const uint32_t mjq = ix.pb[static_cast<size_t>(bj) * kPairBlockDwords + sub * 8u + 4u];
+                        ones = (ix.mrank[bj] + quad_sum(__popc(mjq & prefix32(static_cast<int>(oj) - shift)))) - (ix.mrank[bi] + below_i);
                     }
                     res = ones > 0u;
-                    if (orders && res) ord = static_cast<long long>(ix.mrank[bi] + popc_prefix128(mi, oi));
+                    if (orders && res) ord = static_cast<long long>(ix.mrank[bi] + below_i);
                 }
                 finalize(res, ord);
-            } else {   // PS_LOOKUP
-                if (COUNT) cn.lookups++;
-                const uint32_t e = (tidx & 7u) >> 1;
-                const uint32_t x0 = sel4(e, opaque(A.q0.x), opaque(A.q1.x), opaque(A.q2.x), opaque(A.q3.x));
-                const uint32_t x1 = sel4(e, opaque(A.q0.y), opaque(A.q1.y), opaque(A.q2.y), opaque(A.q3.y));
-                const uint32_t x2 = sel4(e, opaque(A.q0.z), opaque(A.q1.z), opaque(A.q2.z), opaque(A.q3.z));
-                const uint32_t x3 = sel4(e, opaque(A.q0.w), opaque(A.q1.w), opaque(A.q2.w), opaque(A.q3.w));
-                i = (tidx & 1u) ? x2 : x0;
-                j = (tidx & 1u) ? x3 : x1;
+            } else {   // PS_LOOKUP: entry e of the 8-entry line sits in lane e >> 1 of the quad
+                if (COUNT && sub == 0) cn.lookups++;
+                const uint32_t e = tidx & 7u;
+                const uint32_t xi = (e & 1u) ? a0.z : a0.x, xj = (e & 1u) ? a0.w : a0.y;
+                const int src = static_cast<int>(qbase | (e >> 1));
+                i = static_cast<uint32_t>(__shfl(static_cast<int>(xi), src, 64));
+                j = static_cast<uint32_t>(__shfl(static_cast<int>(xj), src, 64));
                 t = k - 1 - T;
                 if (i == j) finalize(-1, -1);
                 else st = t < 0 ? PS_PROBE : PS_STEP;
@@ -388,13 +383,13 @@ __global__ __launch_bounds__(256) void query_pair_kernel(PairIndex ix, const uin
         }
     }
     if (COUNT) {
-        uint32_t v[6] = {cn.lf_steps, cn.blocks, cn.probes, cn.searches, cn.lookups, done};
+        uint32_t v[6] = {cn.lf_steps, cn.blocks, cn.probes, sub == 0 ? cn.searches : 0u, cn.lookups, sub == 0 ? done : 0u};
         const int slot[6] = {0, 1, 2, 3, 4, 6};
 #pragma unroll
         for (int qq = 0; qq < 6; ++qq) {
             uint32_t x = v[qq];
             for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
-            if ((threadIdx.x & 63) == 0 && x) atomicAdd(&counters[slot[qq]], static_cast<unsigned long long>(x));
+            if (lane == 0 && x) atomicAdd(&counters[slot[qq]], static_cast<unsigned long long>(x));
         }
     }
 }
@@ -418,8 +413,9 @@ PairIndex make_pair_index(const fmsi_hip_index* idx) {
 template <bool COUNT, bool PTABLE>
 void launch_pair_t(fmsi_hip_index* idx, const uint64_t* d_kmers, uint64_t n, int k, uint32_t flags, uint8_t* o8, long long* o64,
                    unsigned long long* d_counters, hipStream_t s) {
-    uint64_t chunk = n / (256ull * 32 * 8);
-    chunk = std::min<uint64_t>(std::max<uint64_t>(chunk, 256), 4096);
+    // 16 k-mers in flight per wave: chunks are a quarter of the single-lane kernels'
+    uint64_t chunk = n / (256ull * 32 * 8 * 4);
+    chunk = std::min<uint64_t>(std::max<uint64_t>(chunk, 128), 2048);
     const uint64_t waves = (n + chunk - 1) / chunk;
     const uint32_t blocks = static_cast<uint32_t>((waves + 3) / 4);
     hipLaunchKernelGGL((query_pair_kernel<COUNT, PTABLE>), dim3(blocks), dim3(256), 0, s, make_pair_index(idx), d_kmers, n, k, flags,
