@@ -1,11 +1,11 @@
-// Two-base LF steps over 128-byte blocks ("pair layout"), read cooperatively by quads of lanes -- the
+// Two-base LF steps over 128-byte blocks ("pair layout"), read cooperatively by PAIRS of lanes -- the
 // request-count optimisation of the query path.
 //
 // Why: the chip serves ~52 G random block reads/s whether a block is 64 B or 128 B, as long as the randomly
 // accessed footprint stays below ~3.2 GB and a wave keeps <= ~8 dwordx4 loads in flight per lane
-// (profiles/r01_gather_ceiling.md).  The single-step kernels already run at that request ceiling, so the only way
-// up is fewer requests per k-mer.  A 128-byte block can carry what TWO consecutive backward-search steps need: for
-// every row r (suffix start s = SA[r]) both preceding symbols c1 = T[s-1] (the BWT symbol) and c2 = T[s-2], plus
+// (profiles/r01_gather_ceiling.md).  The single-step kernels run at that request ceiling, so the only way up is
+// fewer requests per k-mer.  A 128-byte block can carry what TWO consecutive backward-search steps need: for every
+// row r (suffix start s = SA[r]) both preceding symbols c1 = T[s-1] (the BWT symbol) and c2 = T[s-2], plus
 // cumulative counts of the 16 (c2, c1) pairs.  Then
 //     [i, j)  --(prepend "c2 c1")-->  [C2[c2,c1] + rank_pair(i), C2[c2,c1] + rank_pair(j))
 // is ONE block read per boundary -- exactly the interval two update_range() calls (reference
@@ -13,20 +13,21 @@
 // every result are unchanged.  c2 is derived on the device from the single-step layout alone (c2(r) = BWT[LF(r)]),
 // so the layout can be added to any handle, whether it was loaded from the reference's files or built on the device.
 //
-// Block = 128 B = 128 rows = four 32-byte QUARTERS; quarter s covers rows 32s .. 32s+31 and is read by lane s of a
-// quad with two dwordx4 loads (the quad's four loads coalesce into one 128-B request):
-//   dw 0  c1 hi plane   dw 1  c1 lo plane   dw 2  c2 hi plane   dw 3  c2 lo plane      (32 rows each)
-//   dw 4  mask plane (SA-transformed mask, 32 rows)
-//   dw 5..7  the four cumulative counts of the pairs with c1 = s (pair index p = c2 | c1 << 2 = 4s .. 4s+3),
-//            24 bits each, relative to the superblock start
+// Block = 128 B = 128 rows = two 64-byte HALVES; half h covers rows 64h .. 64h+63 and is read by lane h of a lane
+// pair with four dwordx4 loads (the pair's loads coalesce into one 128-B request):
+//   dw 0,1  c1 hi plane   dw 2,3  c1 lo plane   dw 4,5  c2 hi plane   dw 6,7  c2 lo plane      (64 rows each)
+//   dw 8,9  mask plane (SA-transformed mask, 64 rows)
+//   dw 10..13  low 16 bits, dw 14,15 high 8 bits of the eight cumulative counts of the pairs with c1 in {2h, 2h+1}
+//              (pair index p = c2 | c1 << 2 = 8h .. 8h+7): 24-bit counts relative to the superblock start
 // Superblock = 2^23 rows; `sbt` holds the 16 absolute counts at each superblock start (21 KB at human scale: cache
 // resident).  Rows without a c1 / c2 (suffix starts 0 and 1) are stored as 'A' and subtracted in the rank, like the
 // '$' slot of the reference (src/fms_index.h:81).
 //
-// Kernel: the persistent-lane state machine of query_refill_kernel with a QUAD per k-mer: the four lanes hold the
-// same state, each ranks its 32 rows, partial popcounts are summed with two quad shuffles and the count / mask bit /
-// table entry owned by one lane is broadcast with one wave shuffle.  16 k-mers per wave, <= 4 dwordx4 in flight per
-// lane, ~60 VGPRs.
+// Kernel: the persistent-lane state machine of query_refill_kernel with a lane PAIR per k-mer: both lanes hold the
+// same state, each ranks its 64 rows, the partial popcounts are added with one lane-swap and the count / mask bit /
+// table entry owned by one lane is broadcast with one wave shuffle.  32 k-mers per wave and <= 8 dwordx4 in flight
+// per lane: measured against the alternatives (one lane per k-mer: too many load instructions in flight, TA-bound at
+// ~36 G requests/s; four lanes per k-mer: the state machine's VALU work per k-mer quadruples, VALU-bound at ~36 G/s).
 #include <hip/hip_runtime.h>
 #include <rocprim/device/device_scan.hpp>
 
@@ -71,7 +72,8 @@ struct U16Plus {
 };
 
 // ---- layout construction -----------------------------------------------------------------------------------
-// One thread per row (256 threads = 2 blocks): c1 from the single-step block, c2 = BWT[LF(row)].
+// One thread per row (256 threads = 4 waves = 2 blocks; one wave = one half): c1 from the single-step block,
+// c2 = BWT[LF(row)].
 __global__ __launch_bounds__(256) void pair_emit_kernel(DevIndex ix, uint32_t* __restrict__ pb, U16* __restrict__ counts,
                                                         uint32_t* __restrict__ specials /* [0] = r1, [1] = c1(r1) */) {
     __shared__ uint32_t s_cnt[4][16];
@@ -101,16 +103,14 @@ __global__ __launch_bounds__(256) void pair_emit_kernel(DevIndex ix, uint32_t* _
     const uint64_t h2 = __ballot(valid && (c2 & 2u)), l2 = __ballot(valid && (c2 & 1u));
     const uint64_t mm = __ballot(valid && mbit), vv = __ballot(valid);
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    if (lane < 2 && vv) {   // lane 0: rows 0..31 of the wave, lane 1: rows 32..63 -> one quarter each
-        const uint64_t w = row64 >> 6;                                   // 64-row word of the index
-        const uint32_t quarter = static_cast<uint32_t>(w & 1) * 2u + lane;
-        uint32_t* qd = pb + (w >> 1) * kPairBlockDwords + quarter * 8u;
-        const uint32_t sh = lane * 32u;
-        qd[0] = static_cast<uint32_t>(h1 >> sh);
-        qd[1] = static_cast<uint32_t>(l1 >> sh);
-        qd[2] = static_cast<uint32_t>(h2 >> sh);
-        qd[3] = static_cast<uint32_t>(l2 >> sh);
-        qd[4] = static_cast<uint32_t>(mm >> sh);
+    if (lane == 0 && vv) {
+        const uint64_t w = row64 >> 6;                                   // 64-row word of the index = one half
+        uint64_t* hd = reinterpret_cast<uint64_t*>(pb + (w >> 1) * kPairBlockDwords + static_cast<uint32_t>(w & 1) * 16u);
+        hd[0] = h1;
+        hd[1] = l1;
+        hd[2] = h2;
+        hd[3] = l2;
+        hd[4] = mm;
     }
     if (lane < 16) {   // lane p counts pair p = c2 | c1 << 2 of its wave
         const uint64_t m = vv & ((lane & 8u) ? h1 : ~h1) & ((lane & 4u) ? l1 : ~l1) & ((lane & 2u) ? h2 : ~h2) & ((lane & 1u) ? l2 : ~l2);
@@ -132,12 +132,18 @@ __global__ void pair_counts_kernel(const U16* __restrict__ scanned, uint64_t n_b
     const U16 base = scanned[sb << kSuperBlocksLog2];
     uint32_t* blk = pb + b * kPairBlockDwords;
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        const uint32_t r0 = a.v[4 * s] - base.v[4 * s], r1 = a.v[4 * s + 1] - base.v[4 * s + 1];
-        const uint32_t r2 = a.v[4 * s + 2] - base.v[4 * s + 2], r3 = a.v[4 * s + 3] - base.v[4 * s + 3];
-        blk[8 * s + 5] = (r0 & 0xFFFFFFu) | (r1 << 24);
-        blk[8 * s + 6] = ((r1 >> 8) & 0xFFFFu) | (r2 << 16);
-        blk[8 * s + 7] = ((r2 >> 16) & 0xFFu) | (r3 << 8);
+    for (int h = 0; h < 2; ++h) {
+        uint32_t lo[4] = {0, 0, 0, 0}, hi[2] = {0, 0};
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            const uint32_t rel = a.v[8 * h + m] - base.v[8 * h + m];
+            lo[m >> 1] |= (rel & 0xFFFFu) << (16 * (m & 1));
+            hi[m >> 2] |= ((rel >> 16) & 0xFFu) << (8 * (m & 3));
+        }
+#pragma unroll
+        for (int d = 0; d < 4; ++d) blk[16 * h + 10 + d] = lo[d];
+        blk[16 * h + 14] = hi[0];
+        blk[16 * h + 15] = hi[1];
     }
     if ((b & ((1ull << kSuperBlocksLog2) - 1)) == 0) {
 #pragma unroll
@@ -148,16 +154,34 @@ __global__ void pair_counts_kernel(const U16* __restrict__ scanned, uint64_t n_b
 // ---- query kernel -----------------------------------------------------------------------------------------
 enum : uint32_t { PS_IDLE = 0, PS_LOOKUP = 1, PS_STEP = 2, PS_PROBE = 3 };
 
-__device__ __forceinline__ uint32_t quad_sum(uint32_t x) {
-    x += __shfl_xor(x, 1, 64);
-    x += __shfl_xor(x, 2, 64);
-    return x;
+__device__ __forceinline__ uint32_t pair_sum(uint32_t x) { return x + static_cast<uint32_t>(__shfl_xor(static_cast<int>(x), 1, 64)); }
+__device__ __forceinline__ uint32_t bytes_sum(uint32_t x) { return (x & 0xFFu) + ((x >> 8) & 0xFFu) + ((x >> 16) & 0xFFu) + (x >> 24); }
+
+// one half as loaded by a lane
+struct Half {
+    uint4 u0, u1, u2, u3;   // {c1hi0 c1hi1 c1lo0 c1lo1} {c2hi0 c2hi1 c2lo0 c2lo1} {mask0 mask1 lo01 lo23} {lo45 lo67 hi0123 hi4567}
+};
+
+// count m (0..7) of this half, or (sum) the four counts m = 4g .. 4g+3 of group g = m >> 2
+__device__ __forceinline__ uint32_t half_count(const Half& H, uint32_t m, bool sum) {
+    if (sum) {
+        const uint32_t l0 = (m & 4u) ? H.u3.x : H.u2.z, l1 = (m & 4u) ? H.u3.y : H.u2.w;
+        const uint32_t hb = (m & 4u) ? H.u3.w : H.u3.z;
+        return (l0 & 0xFFFFu) + (l0 >> 16) + (l1 & 0xFFFFu) + (l1 >> 16) + (bytes_sum(hb) << 16);
+    }
+    const uint32_t lw = sel4(m >> 1, opaque(H.u2.z), opaque(H.u2.w), opaque(H.u3.x), opaque(H.u3.y));
+    const uint32_t hw = (m & 4u) ? H.u3.w : H.u3.z;
+    return ((lw >> (16u * (m & 1u))) & 0xFFFFu) | (((hw >> (8u * (m & 3u))) & 0xFFu) << 16);
 }
 
-// count m (0..3) of a quarter's packed 24-bit counts, or their sum
-__device__ __forceinline__ uint32_t quarter_count(uint32_t a, uint32_t b, uint32_t c, uint32_t m, bool sum) {
-    const uint32_t c0 = a & 0xFFFFFFu, c1 = (a >> 24) | ((b & 0xFFFFu) << 8), c2 = (b >> 16) | ((c & 0xFFu) << 16), c3 = c >> 8;
-    return sum ? c0 + c1 + c2 + c3 : sel4(m, c0, c1, c2, c3);
+// rows of this half matching pair p (or symbol c1 = p >> 2 when single) among its first `o` rows (o may be <= 0 or >= 64)
+__device__ __forceinline__ uint32_t half_match(const Half& H, uint32_t p, bool single, int o) {
+    const uint32_t x1h = (p & 8u) ? 0u : 0xFFFFFFFFu, x1l = (p & 4u) ? 0u : 0xFFFFFFFFu;
+    const uint32_t x2h = (p & 2u) ? 0u : 0xFFFFFFFFu, x2l = (p & 1u) ? 0u : 0xFFFFFFFFu;
+    const uint32_t all = single ? 0xFFFFFFFFu : 0u;   // single step: the c2 planes do not restrict
+    const uint32_t m0 = (H.u0.x ^ x1h) & (H.u0.z ^ x1l) & ((H.u1.x ^ x2h) | all) & ((H.u1.z ^ x2l) | all);
+    const uint32_t m1 = (H.u0.y ^ x1h) & (H.u0.w ^ x1l) & ((H.u1.y ^ x2h) | all) & ((H.u1.w ^ x2l) | all);
+    return __popc(m0 & prefix32(o)) + __popc(m1 & prefix32(o - 32));
 }
 
 struct PairCounters {
@@ -166,21 +190,28 @@ struct PairCounters {
 
 template <bool COUNT, bool PTABLE>
 __global__ __launch_bounds__(256) void query_pair_kernel(PairIndex ix, const uint64_t* __restrict__ kmers, uint64_t n_windows, int k,
-                                                         uint32_t flags, uint32_t chunk, uint8_t* __restrict__ out,
+                                                         uint32_t flags, uint32_t chunk, uint32_t n_super, uint8_t* __restrict__ out,
                                                          long long* __restrict__ out_orders, unsigned long long* __restrict__ counters) {
+    // C2[16] and the superblock table are staged in LDS: every step needs three of their words, and even as cache hits
+    // those loads would compete with the block reads for the memory pipeline
+    extern __shared__ uint32_t lds[];   // [0,16) = C2, [16, 16 + 16 * n_super) = sbt
+    for (uint32_t w = threadIdx.x; w < 16u + 16u * n_super + 1u; w += blockDim.x)
+        lds[w] = w < 16u ? ix.c2[w] : (w < 16u + 16u * n_super ? ix.sbt[w - 16u] : 0u);
+    __syncthreads();
     const uint32_t mode_all = flags & FMSI_HIP_MODE_ALL;
     const uint32_t strict = flags & FMSI_HIP_STRICT;
     const uint32_t orders = flags & FMSI_HIP_ORDERS;
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t sub = lane & 3u;                 // my quarter
-    const uint32_t qbase = lane & ~3u;              // first lane of my quad
-    const uint64_t quads_below = (1ull << qbase) - 1ull;
+    const uint32_t sub = lane & 1u;                 // my half
+    const uint32_t pbase = lane & ~1u;              // first lane of my pair
+    const uint64_t pairs_below = (1ull << pbase) - 1ull;
     const uint64_t wave = (static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
     uint64_t next = wave * chunk;
     const uint64_t end = min(n_windows, next + static_cast<uint64_t>(chunk));
     const int T = PTABLE ? static_cast<int>(ix.ptable_len) : 0;
+    const int shift = static_cast<int>(sub * 64u);  // first row of my half within the block
 
-    // all four lanes of a quad carry the same state
+    // both lanes of a pair carry the same state
     uint64_t f = 0, cur = 0, f_next = 0, q = 0, q_next = 0;
     uint32_t i = 0, j = 0, st = PS_IDLE, phase = 0, done = 0;
     int t = 0, res_f = -1;
@@ -244,12 +275,12 @@ __global__ __launch_bounds__(256) void query_pair_kernel(PairIndex ix, const uin
         }
         {
             const bool want = !has_next;
-            const uint64_t m = __ballot(want) & 0x1111111111111111ull;   // one bit per quad
+            const uint64_t m = __ballot(want) & 0x5555555555555555ull;   // one bit per lane pair
             if (m) {
-                const uint64_t cand = next + static_cast<uint64_t>(__popcll(m & quads_below));
+                const uint64_t cand = next + static_cast<uint64_t>(__popcll(m & pairs_below));
                 if (want && cand < end) {
                     q_next = cand;
-                    f_next = kmers[cand];   // the quad reads one address: a single request
+                    f_next = kmers[cand];   // both lanes read one address: a single request
                     has_next = true;
                 }
                 next += static_cast<uint64_t>(__popcll(m));
@@ -268,56 +299,60 @@ __global__ __launch_bounds__(256) void query_pair_kernel(PairIndex ix, const uin
                 p = c2 | (c1 << 2);
             }
             const uint32_t bi = i >> kBlockRowsLog2, bj = (j - 1u) >> kBlockRowsLog2;
-            // my 32-byte quarter of each boundary's block -- or my 16 bytes of the prefix-table line
-            const uint4* pi4 = reinterpret_cast<const uint4*>(ix.pb + static_cast<size_t>(bi) * kPairBlockDwords) + sub * 2u;
-            const uint4* pj4 = reinterpret_cast<const uint4*>(ix.pb + static_cast<size_t>(bj) * kPairBlockDwords) + sub * 2u;
+            // my 64-byte half of each boundary's block -- or my 32 bytes of the prefix-table line
+            const uint4* pi4 = reinterpret_cast<const uint4*>(ix.pb + static_cast<size_t>(bi) * kPairBlockDwords) + sub * 4u;
+            const uint4* pj4 = reinterpret_cast<const uint4*>(ix.pb + static_cast<size_t>(bj) * kPairBlockDwords) + sub * 4u;
             uint32_t tidx = 0;
             const bool lookup = PTABLE && st == PS_LOOKUP;
             if (lookup) {
                 tidx = static_cast<uint32_t>(cur >> (2 * (k - T))) & ((1u << (2 * T)) - 1u);
-                pi4 = reinterpret_cast<const uint4*>(ix.ptable + (tidx & ~7u)) + sub;
+                pi4 = reinterpret_cast<const uint4*>(ix.ptable + (tidx & ~7u)) + sub * 2u;
             }
             const bool two = st == PS_STEP && bj != bi;
-            uint4 b0 = make_uint4(0, 0, 0, 0), b1 = b0, a1 = b0;
+            const uint4 z = make_uint4(0, 0, 0, 0);
+            Half A, B;
+            A.u2 = A.u3 = z;
+            B.u0 = B.u1 = B.u2 = B.u3 = z;
             uint32_t sbi = 0, sbj = 0, c2base = 0;
             if (two) {
-                b0 = pj4[0];
-                b1 = pj4[1];
+                B.u0 = pj4[0];
+                B.u1 = pj4[1];
+                B.u2 = pj4[2];
+                B.u3 = pj4[3];
             }
-            const uint4 a0 = pi4[0];
-            if (!lookup) a1 = pi4[1];
-            if (st == PS_STEP) {   // tiny cache-resident tables: not random HBM requests.  One unconditional load each:
-                // pair step -> count p; single step -> my quarter's share of the four counts with c1 = p >> 2 (summed below)
-                const uint32_t se = single ? ((p & 12u) + sub) : p;
-                sbi = ix.sbt[(static_cast<size_t>(i >> kSuperLog2) << 4) + se];
-                sbj = ix.sbt[(static_cast<size_t>((j - 1u) >> kSuperLog2) << 4) + se];
-                c2base = ix.c2[p];
+            A.u0 = pi4[0];
+            A.u1 = pi4[1];
+            if (!lookup) {
+                A.u2 = pi4[2];
+                A.u3 = pi4[3];
             }
-            if (!two) {
-                b0 = a0;
-                b1 = a1;
+            if (st == PS_STEP) {   // C2 and the superblock table come from LDS
+                // pair step -> count p; single step -> my half's share of the four counts with c1 = p >> 2 (summed below)
+                const uint32_t se = single ? ((p & 12u) + 2u * sub) : p;
+                const uint32_t* si = lds + 16u + ((i >> kSuperLog2) << 4) + se;
+                const uint32_t* sj = lds + 16u + (((j - 1u) >> kSuperLog2) << 4) + se;
+                sbi = si[0];
+                sbj = sj[0];
+                if (single) {
+                    sbi += si[1];
+                    sbj += sj[1];
+                }
+                c2base = lds[p];
             }
+            if (!two) B = A;
             if (COUNT && sub == 0) cn.blocks += 1u + (two ? 1u : 0u);
 
             if (st == PS_STEP) {
-                const uint32_t oi = i & (kBlockRows - 1u), oj = j - (bj << kBlockRowsLog2);
-                const uint32_t x1h = (p & 8u) ? 0u : 0xFFFFFFFFu, x1l = (p & 4u) ? 0u : 0xFFFFFFFFu;
-                const uint32_t x2h = (p & 2u) ? 0u : 0xFFFFFFFFu, x2l = (p & 1u) ? 0u : 0xFFFFFFFFu;
-                const uint32_t all = single ? 0xFFFFFFFFu : 0u;   // single step: the c2 planes do not restrict
-                const uint32_t mi = (a0.x ^ x1h) & (a0.y ^ x1l) & ((a0.z ^ x2h) | all) & ((a0.w ^ x2l) | all);
-                const uint32_t mj = (b0.x ^ x1h) & (b0.y ^ x1l) & ((b0.z ^ x2h) | all) & ((b0.w ^ x2l) | all);
-                const int shift = static_cast<int>(sub * 32u);
-                uint32_t ri = quad_sum(__popc(mi & prefix32(static_cast<int>(oi) - shift)));
-                uint32_t rj = quad_sum(__popc(mj & prefix32(static_cast<int>(oj) - shift)));
-                // cumulative counts live in the quarter of c1 = p >> 2
-                const uint32_t owner = qbase | (p >> 2);
-                const uint32_t ci = quarter_count(a1.y, a1.z, a1.w, p & 3u, single);
-                const uint32_t cj = quarter_count(b1.y, b1.z, b1.w, p & 3u, single);
-                ri += static_cast<uint32_t>(__shfl(static_cast<int>(ci), static_cast<int>(owner), 64));
-                rj += static_cast<uint32_t>(__shfl(static_cast<int>(cj), static_cast<int>(owner), 64));
+                const int oi = static_cast<int>(i & (kBlockRows - 1u)) - shift, oj = static_cast<int>(j - (bj << kBlockRowsLog2)) - shift;
+                uint32_t ri = pair_sum(half_match(A, p, single, oi));
+                uint32_t rj = pair_sum(half_match(B, p, single, oj));
+                // cumulative counts live in the half of c1 = p >> 2: half (p >> 3), slot p & 7
+                const int owner = static_cast<int>(pbase | (p >> 3));
+                ri += static_cast<uint32_t>(__shfl(static_cast<int>(half_count(A, p & 7u, single)), owner, 64));
+                rj += static_cast<uint32_t>(__shfl(static_cast<int>(half_count(B, p & 7u, single)), owner, 64));
                 if (single) {
-                    ri += quad_sum(sbi);
-                    rj += quad_sum(sbj);
+                    ri += pair_sum(sbi);
+                    rj += pair_sum(sbj);
                     const uint32_t y = p >> 2;
                     if (y == 0u) {   // the '$' slot is stored as c1 = 'A'
                         ri -= (i > ix.r0);
@@ -348,32 +383,35 @@ __global__ __launch_bounds__(256) void query_pair_kernel(PairIndex ix, const uin
                 else if (t < 0) st = PS_PROBE;
             } else if (st == PS_PROBE) {
                 if (COUNT && sub == 0) cn.probes++;
-                const uint32_t oi = i & (kBlockRows - 1u);
-                const int shift = static_cast<int>(sub * 32u);
+                const uint32_t o = i & (kBlockRows - 1u);
+                const int oi = static_cast<int>(o) - shift;
                 int res;
                 long long ord = -1;
                 if (mode_all && !orders) {
-                    const uint32_t bit = (a1.x >> (oi & 31u)) & 1u;            // valid in the lane that owns row i
-                    res = __shfl(static_cast<int>(bit), static_cast<int>(qbase | (oi >> 5)), 64);
+                    const uint32_t mw = (o & 32u) ? A.u2.y : A.u2.x;                // valid in the lane that owns row i
+                    const uint32_t bit = (mw >> (o & 31u)) & 1u;
+                    res = __shfl(static_cast<int>(bit), static_cast<int>(pbase | (o >> 6)), 64);
                 } else {
-                    const uint32_t oj = j - (bj << kBlockRowsLog2);
-                    const uint32_t below_i = quad_sum(__popc(a1.x & prefix32(static_cast<int>(oi) - shift)));
+                    const int oj = static_cast<int>(j - (bj << kBlockRowsLog2)) - shift;
+                    const uint32_t below_i = pair_sum(__popc(A.u2.x & prefix32(oi)) + __popc(A.u2.y & prefix32(oi - 32)));
                     uint32_t ones;
                     if (bj == bi) {
-                        ones = quad_sum(__popc(a1.x & prefix32(static_cast<int>(oj) - shift))) - below_i;
+                        ones = pair_sum(__popc(A.u2.x & prefix32(oj)) + __popc(A.u2.y & prefix32(oj - 32))) - below_i;
                     } else {   // interval spans blocks (long repeats): rank difference through the side array
-                        const uint32_t mjq = ix.pb[static_cast<size_t>(bj) * kPairBlockDwords + sub * 8u + 4u];
-                        ones = (ix.mrank[bj] + quad_sum(__popc(mjq & prefix32(static_cast<int>(oj) - shift)))) - (ix.mrank[bi] + below_i);
+                        const uint32_t* mjp = ix.pb + static_cast<size_t>(bj) * kPairBlockDwords + sub * 16u + 8u;
+                        const uint32_t mj0 = mjp[0], mj1 = mjp[1];
+                        ones = (ix.mrank[bj] + pair_sum(__popc(mj0 & prefix32(oj)) + __popc(mj1 & prefix32(oj - 32)))) - (ix.mrank[bi] + below_i);
                     }
                     res = ones > 0u;
                     if (orders && res) ord = static_cast<long long>(ix.mrank[bi] + below_i);
                 }
                 finalize(res, ord);
-            } else {   // PS_LOOKUP: entry e of the 8-entry line sits in lane e >> 1 of the quad
+            } else {   // PS_LOOKUP: entry e of the 8-entry line sits in lane e >> 2 of the pair, slot e & 3 of its 32 bytes
                 if (COUNT && sub == 0) cn.lookups++;
                 const uint32_t e = tidx & 7u;
-                const uint32_t xi = (e & 1u) ? a0.z : a0.x, xj = (e & 1u) ? a0.w : a0.y;
-                const int src = static_cast<int>(qbase | (e >> 1));
+                const uint4 v = (e & 2u) ? A.u1 : A.u0;
+                const uint32_t xi = (e & 1u) ? v.z : v.x, xj = (e & 1u) ? v.w : v.y;
+                const int src = static_cast<int>(pbase | (e >> 2));
                 i = static_cast<uint32_t>(__shfl(static_cast<int>(xi), src, 64));
                 j = static_cast<uint32_t>(__shfl(static_cast<int>(xj), src, 64));
                 t = k - 1 - T;
@@ -413,13 +451,15 @@ PairIndex make_pair_index(const fmsi_hip_index* idx) {
 template <bool COUNT, bool PTABLE>
 void launch_pair_t(fmsi_hip_index* idx, const uint64_t* d_kmers, uint64_t n, int k, uint32_t flags, uint8_t* o8, long long* o64,
                    unsigned long long* d_counters, hipStream_t s) {
-    // 16 k-mers in flight per wave: chunks are a quarter of the single-lane kernels'
-    uint64_t chunk = n / (256ull * 32 * 8 * 4);
+    // 32 k-mers in flight per wave: chunks are half of the single-lane kernels'
+    uint64_t chunk = n / (256ull * 32 * 8 * 2);
     chunk = std::min<uint64_t>(std::max<uint64_t>(chunk, 128), 2048);
     const uint64_t waves = (n + chunk - 1) / chunk;
     const uint32_t blocks = static_cast<uint32_t>((waves + 3) / 4);
-    hipLaunchKernelGGL((query_pair_kernel<COUNT, PTABLE>), dim3(blocks), dim3(256), 0, s, make_pair_index(idx), d_kmers, n, k, flags,
-                       static_cast<uint32_t>(chunk), o8, o64, d_counters);
+    const uint32_t n_super = static_cast<uint32_t>(((idx->n_blocks - 1) >> kSuperBlocksLog2) + 1);
+    const size_t lds_bytes = (16 + 16 * static_cast<size_t>(n_super) + 1) * 4;   // <= 33 KB for any n < 2^32
+    hipLaunchKernelGGL((query_pair_kernel<COUNT, PTABLE>), dim3(blocks), dim3(256), lds_bytes, s, make_pair_index(idx), d_kmers, n, k, flags,
+                       static_cast<uint32_t>(chunk), n_super, o8, o64, d_counters);
 }
 
 }  // namespace
@@ -459,11 +499,11 @@ extern "C" int fmsi_hip_index_enable_pair_layout(fmsi_hip_index* idx) {
     };
     const size_t pb_bytes = n_blocks * kPairBlockDwords * 4;
     if (hipMalloc(&pb, pb_bytes) != hipSuccess || hipMalloc(&counts, (n_blocks + 1) * sizeof(U16)) != hipSuccess ||
-        hipMalloc(&scanned, (n_blocks + 1) * sizeof(U16)) != hipSuccess || hipMalloc(&sbt, n_super * 64) != hipSuccess ||
+        hipMalloc(&scanned, (n_blocks + 1) * sizeof(U16)) != hipSuccess || hipMalloc(&sbt, n_super * 64 + 64) != hipSuccess ||
         hipMalloc(&c2, 64) != hipSuccess || hipMalloc(&spec, 8) != hipSuccess)
         return fail(FMSI_HIP_ENOMEM, "hipMalloc failed for the pair layout");
     if (hipMemset(pb, 0, pb_bytes) != hipSuccess || hipMemset(counts, 0, (n_blocks + 1) * sizeof(U16)) != hipSuccess ||
-        hipMemset(spec, 0xFF, 8) != hipSuccess)
+        hipMemset(spec, 0xFF, 8) != hipSuccess || hipMemset(sbt, 0, n_super * 64 + 64) != hipSuccess)
         return fail(FMSI_HIP_EHIP, "hipMemset failed for the pair layout");
     const uint32_t grid = static_cast<uint32_t>((idx->n + 255) / 256);
     hipLaunchKernelGGL(pair_emit_kernel, dim3(grid), dim3(256), 0, 0, idx->dev, static_cast<uint32_t*>(pb), static_cast<U16*>(counts),

@@ -76,9 +76,8 @@ __global__ __launch_bounds__(256) void gather_coop(const uint4* __restrict__ buf
 }
 
 template <int GRAN, int ILP, int COOP>
-void run_coop(const uint4* buf, uint64_t bytes, uint64_t* out) {
+void run_coop(const uint4* buf, uint64_t bytes, uint64_t* out, int blocks = 8192, int iters = 64) {
     const uint64_t n_blocks = bytes / GRAN;
-    const int iters = 64, blocks = 8192;
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
     gather_coop<GRAN, ILP, COOP><<<blocks, 256>>>(buf, n_blocks, 4, out);
     hipDeviceSynchronize();
@@ -87,7 +86,7 @@ void run_coop(const uint4* buf, uint64_t bytes, uint64_t* out) {
     hipEventRecord(b); hipEventSynchronize(b);
     float ms; hipEventElapsedTime(&ms, a, b);
     const double reads = (double)blocks * 256 / COOP * ILP * iters;
-    printf("buf %.2f GB  coop %d  gran %3d B  ilp %d : %.3f ms  %.2f G reads/s  %.2f TB/s\n", bytes / 1e9, COOP, GRAN, ILP, ms, reads / ms / 1e6,
+    printf("buf %.2f GB  grid %5d  coop %d  gran %3d B  ilp %d : %.3f ms  %.2f G reads/s  %.2f TB/s\n", bytes / 1e9, blocks, COOP, GRAN, ILP, ms, reads / ms / 1e6,
            reads * GRAN / ms / 1e9);
 }
 
@@ -125,6 +124,19 @@ int main(int argc, char** argv) {
         run_coop<128, 1, 2>(buf, bytes, out); run_coop<128, 2, 2>(buf, bytes, out); run_coop<128, 4, 2>(buf, bytes, out);
         run_coop<128, 1, 4>(buf, bytes, out); run_coop<128, 2, 4>(buf, bytes, out); run_coop<128, 4, 4>(buf, bytes, out); run_coop<128, 8, 4>(buf, bytes, out);
         run_coop<128, 1, 8>(buf, bytes, out); run_coop<128, 2, 8>(buf, bytes, out); run_coop<128, 4, 8>(buf, bytes, out); run_coop<128, 8, 8>(buf, bytes, out);
+        return 0;
+    }
+    if (argc > 2 && std::string(argv[1]) == "inflight") {   // resident waves per SIMD = grid / 256 (all workgroups resident)
+        const double gb = atof(argv[2]);
+        const uint64_t bytes = (uint64_t)(gb * 1e9) / 512 * 512;
+        uint4* buf; uint64_t* out;
+        hipMalloc(&buf, bytes + 4096); hipMalloc(&out, 8);
+        hipMemset(buf, 1, bytes + 4096);
+        for (int w : {1, 2, 3, 4, 5, 6, 8}) {
+            run_coop<64, 1, 1>(buf, bytes, out, 256 * w, 2048);
+            run_coop<128, 1, 2>(buf, bytes, out, 256 * w, 2048);
+            run_coop<128, 2, 2>(buf, bytes, out, 256 * w, 1024);
+        }
         return 0;
     }
     if (argc > 2 && std::string(argv[1]) == "occ") {
