@@ -192,31 +192,38 @@ template <bool COUNT, bool PTABLE>
 __global__ __launch_bounds__(256) void query_pair_kernel(PairIndex ix, const uint64_t* __restrict__ kmers, uint64_t n_windows, int k,
                                                          uint32_t flags, uint32_t chunk, uint32_t n_super, uint8_t* __restrict__ out,
                                                          long long* __restrict__ out_orders, unsigned long long* __restrict__ counters) {
-    // C2[16] and the superblock table are staged in LDS: every step needs three of their words, and even as cache hits
-    // those loads would compete with the block reads for the memory pipeline
-    extern __shared__ uint32_t lds[];   // [0,16) = C2, [16, 16 + 16 * n_super) = sbt
-    for (uint32_t w = threadIdx.x; w < 16u + 16u * n_super + 1u; w += blockDim.x)
+    // LDS: C2[16] and the superblock table (every step needs three of their words; as global loads -- even cache hits --
+    // they compete with the block reads for the memory pipeline), and per wave a ring of 128 k-mers and the chunk's
+    // result bytes, so that k-mers arrive and results leave in whole cache lines instead of one request each.
+    extern __shared__ uint32_t lds[];   // [0,16) = C2, [16, 16 + 16 * n_super) = sbt, then 4 x (ring 1 KB + results 2 KB)
+    const uint32_t tbl_words = (16u + 16u * n_super + 1u + 1u) & ~1u;
+    for (uint32_t w = threadIdx.x; w < tbl_words; w += blockDim.x)
         lds[w] = w < 16u ? ix.c2[w] : (w < 16u + 16u * n_super ? ix.sbt[w - 16u] : 0u);
     __syncthreads();
     const uint32_t mode_all = flags & FMSI_HIP_MODE_ALL;
     const uint32_t strict = flags & FMSI_HIP_STRICT;
     const uint32_t orders = flags & FMSI_HIP_ORDERS;
     const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wib = threadIdx.x >> 6;          // wave in block
+    uint64_t* ring = reinterpret_cast<uint64_t*>(lds + tbl_words) + wib * 128u;
+    uint8_t* obuf = reinterpret_cast<uint8_t*>(lds + tbl_words + 4u * 256u) + wib * 2048u;
     const uint32_t sub = lane & 1u;                 // my half
     const uint32_t pbase = lane & ~1u;              // first lane of my pair
     const uint64_t pairs_below = (1ull << pbase) - 1ull;
     const uint64_t wave = (static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
-    uint64_t next = wave * chunk;
-    const uint64_t end = min(n_windows, next + static_cast<uint64_t>(chunk));
+    const uint64_t start = wave * chunk;                                               // my chunk: [start, start + len)
+    const uint32_t len = start < n_windows ? static_cast<uint32_t>(min(static_cast<uint64_t>(chunk), n_windows - start)) : 0u;
+    uint32_t next = 0, loaded = 0;                  // wave-uniform: handed out / landed in the ring (relative to start)
+    uint64_t pend = 0;                              // k-mer batch in flight from global memory
+    bool pend_valid = false;
     const int T = PTABLE ? static_cast<int>(ix.ptable_len) : 0;
     const int shift = static_cast<int>(sub * 64u);  // first row of my half within the block
 
     // both lanes of a pair carry the same state
-    uint64_t f = 0, cur = 0, f_next = 0, q = 0, q_next = 0;
-    uint32_t i = 0, j = 0, st = PS_IDLE, phase = 0, done = 0;
+    uint64_t f = 0, cur = 0;
+    uint32_t q = 0, i = 0, j = 0, st = PS_IDLE, phase = 0, done = 0;
     int t = 0, res_f = -1;
     long long ord_f = -1;
-    bool has_next = false;
     PairCounters cn;
 
     auto start_strand = [&](uint64_t kmer) {
@@ -249,16 +256,17 @@ __global__ __launch_bounds__(256) void query_pair_kernel(PairIndex ix, const uin
         const long long of = was_second ? ord_f : ord, orr = was_second ? ord : -1;
         if (sub == 0) {
             if (orders) {
+                const uint64_t qa = start + q;
                 if (strict) {
-                    out_orders[2 * q] = of;
-                    out_orders[2 * q + 1] = orr;
+                    out_orders[2 * qa] = of;
+                    out_orders[2 * qa + 1] = orr;
                 } else {
-                    out_orders[q] = was_second ? orr : of;
+                    out_orders[qa] = was_second ? orr : of;
                 }
             } else if (strict) {
-                out[q] = static_cast<uint8_t>((rf + 1) | ((rr + 1) << 2));
+                obuf[q] = static_cast<uint8_t>((rf + 1) | ((rr + 1) << 2));
             } else {
-                out[q] = static_cast<uint8_t>((was_second ? rr : rf) == 1);
+                obuf[q] = static_cast<uint8_t>((was_second ? rr : rf) == 1);
             }
         }
         st = PS_IDLE;
@@ -266,28 +274,36 @@ __global__ __launch_bounds__(256) void query_pair_kernel(PairIndex ix, const uin
     };
 
     for (;;) {
-        if (st == PS_IDLE && has_next) {
-            f = f_next;
-            q = q_next;
-            has_next = false;
-            phase = 0;
-            start_strand(f);
+        // (0) the batch of k-mers requested last iteration has arrived: land it in the ring
+        if (pend_valid) {
+            ring[(loaded + lane) & 127u] = pend;
+            loaded = min(len, loaded + 64u);
+            pend_valid = false;
         }
+        // (1) idle lane pairs draw the next k-mers of the chunk: ballot + prefix rank over a wave-uniform cursor
         {
-            const bool want = !has_next;
+            const bool want = st == PS_IDLE;
             const uint64_t m = __ballot(want) & 0x5555555555555555ull;   // one bit per lane pair
             if (m) {
-                const uint64_t cand = next + static_cast<uint64_t>(__popcll(m & pairs_below));
-                if (want && cand < end) {
-                    q_next = cand;
-                    f_next = kmers[cand];   // both lanes read one address: a single request
-                    has_next = true;
+                const uint32_t rank = static_cast<uint32_t>(__popcll(m & pairs_below));
+                const uint32_t avail = loaded - next;
+                if (want && rank < avail) {
+                    q = next + rank;
+                    f = ring[q & 127u];
+                    phase = 0;
+                    start_strand(f);
                 }
-                next += static_cast<uint64_t>(__popcll(m));
+                next += min(static_cast<uint32_t>(__popcll(m)), avail);
             }
         }
+        // (2) keep the ring ahead of the cursor: one coalesced 512-byte read per 64 k-mers, consumed next iteration
+        if (!pend_valid && loaded < len && loaded - next <= 64u) {
+            const uint32_t idx = loaded + lane;
+            pend = idx < len ? kmers[start + idx] : 0ull;
+            pend_valid = true;
+        }
         if (!__any(st != PS_IDLE)) {
-            if (!__any(has_next)) break;
+            if (next >= len && !pend_valid) break;
             continue;
         }
         if (st != PS_IDLE) {
@@ -420,6 +436,17 @@ __global__ __launch_bounds__(256) void query_pair_kernel(PairIndex ix, const uin
             }
         }
     }
+    if (!orders && len) {   // the chunk's result bytes leave in 16-byte pieces (whole lines), not one request per k-mer
+        uint8_t* dst = out + start;
+        const bool aligned = (reinterpret_cast<uintptr_t>(dst) & 15u) == 0;
+        for (uint32_t off = lane * 16u; off < len; off += 64u * 16u) {
+            if (aligned && off + 16u <= len) {
+                *reinterpret_cast<uint4*>(dst + off) = *reinterpret_cast<const uint4*>(obuf + off);
+            } else {
+                for (uint32_t b = off; b < min(len, off + 16u); ++b) dst[b] = obuf[b];
+            }
+        }
+    }
     if (COUNT) {
         uint32_t v[6] = {cn.lf_steps, cn.blocks, cn.probes, sub == 0 ? cn.searches : 0u, cn.lookups, sub == 0 ? done : 0u};
         const int slot[6] = {0, 1, 2, 3, 4, 6};
@@ -457,7 +484,8 @@ void launch_pair_t(fmsi_hip_index* idx, const uint64_t* d_kmers, uint64_t n, int
     const uint64_t waves = (n + chunk - 1) / chunk;
     const uint32_t blocks = static_cast<uint32_t>((waves + 3) / 4);
     const uint32_t n_super = static_cast<uint32_t>(((idx->n_blocks - 1) >> kSuperBlocksLog2) + 1);
-    const size_t lds_bytes = (16 + 16 * static_cast<size_t>(n_super) + 1) * 4;   // <= 33 KB for any n < 2^32
+    // tables (<= 33 KB for any n < 2^32) + per wave: 1 KB k-mer ring + 2 KB result bytes (chunk <= 2048)
+    const size_t lds_bytes = (((16 + 16 * static_cast<size_t>(n_super) + 2) & ~size_t(1)) + 4 * 256 + 4 * 512) * 4;
     hipLaunchKernelGGL((query_pair_kernel<COUNT, PTABLE>), dim3(blocks), dim3(256), lds_bytes, s, make_pair_index(idx), d_kmers, n, k, flags,
                        static_cast<uint32_t>(chunk), n_super, o8, o64, d_counters);
 }
