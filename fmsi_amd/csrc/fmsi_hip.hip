@@ -133,19 +133,29 @@ __global__ __launch_bounds__(256) void query_refill_kernel(DevIndex ix, const ui
                                                            int k, uint32_t flags, uint32_t chunk, uint8_t* __restrict__ out,
                                                            long long* __restrict__ out_orders,
                                                            unsigned long long* __restrict__ counters) {
+    // Per wave in LDS: a ring of 128 k-mers and the chunk's result bytes.  Every memory request -- cached or not --
+    // counts against the chip's random-request ceiling, so k-mers arrive as one coalesced 512-byte read per 64 and
+    // results leave as 16 bytes per lane at the end of the chunk instead of one request per k-mer each way.
+    __shared__ uint64_t s_ring[4][128];
+    __shared__ __attribute__((aligned(16))) uint8_t s_out[4][4096];
     const uint32_t mode_all = flags & FMSI_HIP_MODE_ALL;
     const uint32_t strict = flags & FMSI_HIP_STRICT;
     const uint32_t orders = flags & FMSI_HIP_ORDERS;
+    const uint32_t lane = threadIdx.x & 63u;
+    uint64_t* ring = s_ring[threadIdx.x >> 6];
+    uint8_t* obuf = s_out[threadIdx.x >> 6];
     const uint64_t wave = (static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
-    uint64_t next = wave * chunk;                                   // wave-uniform cursor
-    const uint64_t end = min(n_windows, next + static_cast<uint64_t>(chunk));
+    const uint64_t start = wave * chunk;                            // my chunk: [start, start + len), len <= 4096
+    const uint32_t len = start < n_windows ? static_cast<uint32_t>(min(static_cast<uint64_t>(chunk), n_windows - start)) : 0u;
+    uint32_t next = 0, loaded = 0;                                  // wave-uniform: handed out / landed in the ring
+    uint64_t pend = 0;                                              // k-mer batch in flight from global memory
+    bool pend_valid = false;
     const int T = PTABLE ? static_cast<int>(ix.ptable_len) : 0;
 
-    uint64_t f = 0, cur = 0, f_next = 0, q = 0, q_next = 0;
-    uint32_t i = 0, j = 0, st = ST_IDLE, phase = 0, done = 0;
+    uint64_t f = 0, cur = 0;
+    uint32_t q = 0, i = 0, j = 0, st = ST_IDLE, phase = 0, done = 0;
     int t = 0, res_f = -1;
     long long ord_f = -1;
-    bool has_next = false;
     LaneCounters cn;
 
     auto start_strand = [&](uint64_t kmer) {
@@ -162,6 +172,7 @@ __global__ __launch_bounds__(256) void query_refill_kernel(DevIndex ix, const ui
     };
     // result of the strand just searched: src/fms_index.h:263-331 with the forward strand first
     auto finalize = [&](int res, long long ord) {
+        bool second = false;
         if (phase == 0) {
             if (need_second(strict, orders, mode_all, res, ord)) {
                 res_f = res;
@@ -170,39 +181,48 @@ __global__ __launch_bounds__(256) void query_refill_kernel(DevIndex ix, const ui
                 start_strand(revcomp_2bit(f, k));
                 return;
             }
-            write_result(q, strict, orders, false, res, -1, ord, -1, out, out_orders);
         } else {
-            write_result(q, strict, orders, true, res_f, res, ord_f, ord, out, out_orders);
+            second = true;
         }
+        const int rf = second ? res_f : res, rr = second ? res : -1;
+        if (orders) write_result(start + q, strict, orders, second, rf, rr, second ? ord_f : ord, second ? ord : -1, out, out_orders);
+        else if (strict) obuf[q] = static_cast<uint8_t>((rf + 1) | ((rr + 1) << 2));
+        else obuf[q] = static_cast<uint8_t>((second ? rr : rf) == 1);
         st = ST_IDLE;
         done++;
     };
 
     for (;;) {
-        // (1) idle lanes start their prefetched k-mer
-        if (st == ST_IDLE && has_next) {
-            f = f_next;
-            q = q_next;
-            has_next = false;
-            phase = 0;
-            start_strand(f);
+        // (0) the batch of k-mers requested last iteration has arrived: land it in the ring
+        if (pend_valid) {
+            ring[(loaded + lane) & 127u] = pend;
+            loaded = min(len, loaded + 64u);
+            pend_valid = false;
         }
-        // (2) lanes without a prefetched k-mer draw the next indices of the wave's chunk: ballot + mbcnt prefix
+        // (1) idle lanes draw the next k-mers of the chunk: ballot + mbcnt prefix rank over a wave-uniform cursor
         {
-            const bool want = !has_next;
+            const bool want = st == ST_IDLE;
             const uint64_t m = __ballot(want);
             if (m) {
-                const uint64_t cand = next + lanes_below(m);
-                if (want && cand < end) {
-                    q_next = cand;
-                    f_next = kmers[cand];   // consumed one iteration later at the earliest: latency hides under (3)
-                    has_next = true;
+                const uint32_t rank = lanes_below(m);
+                const uint32_t avail = loaded - next;
+                if (want && rank < avail) {
+                    q = next + rank;
+                    f = ring[q & 127u];
+                    phase = 0;
+                    start_strand(f);
                 }
-                next += static_cast<uint64_t>(__popcll(m));
+                next += min(static_cast<uint32_t>(__popcll(m)), avail);
             }
         }
+        // (2) keep the ring ahead of the cursor: consumed next iteration, so the latency hides under (3)
+        if (!pend_valid && loaded < len && loaded - next <= 64u) {
+            const uint32_t idx = loaded + lane;
+            pend = idx < len ? kmers[start + idx] : 0ull;
+            pend_valid = true;
+        }
         if (!__any(st != ST_IDLE)) {
-            if (!__any(has_next)) break;
+            if (next >= len && !pend_valid) break;
             continue;
         }
         // (3) one round of reads per active lane
@@ -284,6 +304,17 @@ __global__ __launch_bounds__(256) void query_refill_kernel(DevIndex ix, const ui
                 t = k - 1 - T;
                 if (i == j) finalize(-1, -1);
                 else st = t < 0 ? ST_PROBE : ST_LF;
+            }
+        }
+    }
+    if (!orders && len) {
+        uint8_t* dst = out + start;
+        const bool aligned = (reinterpret_cast<uintptr_t>(dst) & 15u) == 0;
+        for (uint32_t off = lane * 16u; off < len; off += 64u * 16u) {
+            if (aligned && off + 16u <= len) {
+                *reinterpret_cast<uint4*>(dst + off) = *reinterpret_cast<const uint4*>(obuf + off);
+            } else {
+                for (uint32_t b = off; b < min(len, off + 16u); ++b) dst[b] = obuf[b];
             }
         }
     }
