@@ -69,6 +69,17 @@ __global__ __launch_bounds__(256) void stream_prep_kernel(const uint64_t* __rest
     rec[t] = r;
 }
 
+// slots[task] (one aligned 64-byte line of result bytes per task) -> the caller's contiguous result array
+__global__ __launch_bounds__(256) void stream_compact_kernel(const uint8_t* __restrict__ slots, const TaskDesc* __restrict__ desc,
+                                                             uint64_t n_tasks, uint8_t* __restrict__ out) {
+    const uint64_t g = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    const uint64_t t = g >> 6;
+    const uint32_t w = static_cast<uint32_t>(g & 63u);
+    if (t >= n_tasks) return;
+    const TaskDesc d = desc[t];
+    if (w < d.n) out[d.out + w] = slots[(t << 6) + w];
+}
+
 enum : uint32_t { SS_IDLE = 0, SS_LOOKUP = 1, SS_LF = 2, SS_HAVE = 3, SS_EXTSCAN = 4, SS_EXTLF = 5 };
 
 struct StreamCounters {
@@ -95,8 +106,13 @@ __device__ __forceinline__ uint64_t task_kmer(uint64_t s0, uint64_t s1, uint64_t
 template <bool COUNT, bool PTABLE>
 __global__ __launch_bounds__(256) void query_stream_kernel(DevIndex ix, const uint64_t* __restrict__ klcp, const TaskRec* __restrict__ tasks,
                                                            uint64_t n_tasks, int k, uint32_t flags, uint32_t chunk,
-                                                           uint8_t* __restrict__ out, long long* __restrict__ out_orders,
+                                                           uint4* __restrict__ slots, long long* __restrict__ out_orders,
                                                            unsigned long long* __restrict__ counters) {
+    // A task's <= 64 result bytes are collected in the lane's LDS row and leave as ONE aligned 64-byte line
+    // (slots[task]); stream_compact_kernel moves them to their final positions.  One store request per window would
+    // otherwise be a third of a streamed window's memory requests.
+    __shared__ uint4 s_res[256][4];
+    uint8_t* my_res = reinterpret_cast<uint8_t*>(s_res[threadIdx.x]);
     const uint32_t mode_all = flags & FMSI_HIP_MODE_ALL;
     const uint32_t strict = flags & FMSI_HIP_STRICT;
     const uint32_t orders = flags & FMSI_HIP_ORDERS;
@@ -118,6 +134,7 @@ __global__ __launch_bounds__(256) void query_stream_kernel(DevIndex ix, const ui
     uint64_t rf_lo = 0, rf_hi = 0;   // pass-0 result + 1 of window w: bit w of rf_lo / rf_hi (0 = empty interval)
     uint64_t todo = 0;            // pass 1: windows still to visit
     uint32_t i = 0, j = 0, st = SS_IDLE, pass = 0, widx = 0;
+    uint64_t task_id = 0, ntask_id = 0;
     uint32_t scan_i = 0, scan_j = 0;   // EXTSCAN: sides still extending
     int t = 0;
     StreamCounters cn;
@@ -138,6 +155,16 @@ __global__ __launch_bounds__(256) void query_stream_kernel(DevIndex ix, const ui
         if (mode_all) return static_cast<uint8_t>((f != -1 ? f : r) == 1);
         return static_cast<uint8_t>(f == 1 || r == 1);
     };
+    auto end_task = [&]() {
+        if (!orders) {
+            uint4* dst = slots + (task_id << 2);
+            dst[0] = s_res[threadIdx.x][0];
+            dst[1] = s_res[threadIdx.x][1];
+            dst[2] = s_res[threadIdx.x][2];
+            dst[3] = s_res[threadIdx.x][3];
+        }
+        st = SS_IDLE;
+    };
     // begin pass 1 (reverse-complement strand, windows ascending) or finish the task
     auto begin_pass1 = [&]() {
         pass = 1;
@@ -146,7 +173,7 @@ __global__ __launch_bounds__(256) void query_stream_kernel(DevIndex ix, const ui
         else if (orders || !mode_all) todo = all & ~(rf_hi & ~rf_lo);   // OR / orders: only a forward result of 1 decides (rf = 2)
         else todo = all & ~(rf_lo | rf_hi);                            // ALL: any non-empty forward interval decides
         if (!todo) {
-            st = SS_IDLE;
+            end_task();
             return;
         }
         widx = static_cast<uint32_t>(__ffsll(static_cast<unsigned long long>(todo))) - 1u;
@@ -166,7 +193,7 @@ __global__ __launch_bounds__(256) void query_stream_kernel(DevIndex ix, const ui
                 else out_orders[obase + widx] = ord;
             } else if (!strict) {
                 // decided windows are final now; undecided ones are rewritten by pass 1
-                out[obase + widx] = final_byte(res, -1);
+                my_res[widx] = final_byte(res, -1);
             }
         } else {
             const int f = static_cast<int>(((rf_lo >> widx) & 1ull) | (((rf_hi >> widx) & 1ull) << 1)) - 1;
@@ -174,7 +201,7 @@ __global__ __launch_bounds__(256) void query_stream_kernel(DevIndex ix, const ui
                 if (strict) out_orders[2 * (obase + widx) + 1] = ord;
                 else out_orders[obase + widx] = ord;   // visited only when the forward strand had no order
             } else {
-                out[obase + widx] = final_byte(f, res);
+                my_res[widx] = final_byte(f, res);
             }
         }
     };
@@ -193,7 +220,7 @@ __global__ __launch_bounds__(256) void query_stream_kernel(DevIndex ix, const ui
             return false;
         }
         if (!todo) {
-            st = SS_IDLE;
+            end_task();
             return false;
         }
         const uint32_t nw = static_cast<uint32_t>(__ffsll(static_cast<unsigned long long>(todo))) - 1u;
@@ -213,6 +240,7 @@ __global__ __launch_bounds__(256) void query_stream_kernel(DevIndex ix, const ui
     for (;;) {
         if (st == SS_IDLE && has_next) {
             s0 = ns0; s1 = ns1; s2 = ns2; s3 = ns3; obase = nobase; n = nn;
+            task_id = ntask_id;
             has_next = false;
             pass = 0;
             rf_lo = rf_hi = 0;
@@ -234,6 +262,7 @@ __global__ __launch_bounds__(256) void query_stream_kernel(DevIndex ix, const ui
                     ns3 = (static_cast<uint64_t>(r1.w) << 32) | r1.z;
                     nobase = (static_cast<uint64_t>(r2.y) << 32) | r2.x;
                     nn = r2.z;
+                    ntask_id = cand;
                     has_next = true;
                 }
                 next += static_cast<uint64_t>(__popcll(m));
@@ -428,7 +457,7 @@ __global__ __launch_bounds__(256) void query_stream_kernel(DevIndex ix, const ui
 }
 
 template <bool COUNT, bool PTABLE>
-void launch_stream(fmsi_hip_index* idx, const TaskRec* recs, uint64_t n_tasks, int k, uint32_t flags, uint8_t* o8, long long* o64,
+void launch_stream(fmsi_hip_index* idx, const TaskRec* recs, uint64_t n_tasks, int k, uint32_t flags, uint4* o8, long long* o64,
                    unsigned long long* d_counters, hipStream_t s) {
     uint64_t chunk = n_tasks / (256ull * 32 * 8);
     chunk = std::min<uint64_t>(std::max<uint64_t>(chunk, 64), 1024);
@@ -505,9 +534,10 @@ extern "C" int fmsi_hip_query_stream(fmsi_hip_index* idx, const uint64_t* packed
     }
     // descriptors, then records, in one staging buffer
     const size_t desc_bytes = (n_tasks * sizeof(TaskDesc) + 63) / 64 * 64;
-    if ((rc = ensure_cap(&idx->d_tasks, &idx->d_tasks_cap, desc_bytes + n_tasks * sizeof(TaskRec)))) return rc;
+    if ((rc = ensure_cap(&idx->d_tasks, &idx->d_tasks_cap, desc_bytes + 2 * n_tasks * sizeof(TaskRec)))) return rc;
     auto* d_desc = static_cast<TaskDesc*>(idx->d_tasks);
     auto* d_rec = reinterpret_cast<TaskRec*>(static_cast<char*>(idx->d_tasks) + desc_bytes);
+    auto* d_slots = reinterpret_cast<uint4*>(d_rec + n_tasks);   // one 64-byte line of result bytes per task
     FMSI_HIP_TRY(hipMemcpyAsync(d_desc, desc.data(), n_tasks * sizeof(TaskDesc), hipMemcpyHostToDevice, s));
     FMSI_HIP_TRY(hipStreamSynchronize(s));   // `desc` is a local vector: the copy must finish before it dies
     hipLaunchKernelGGL(stream_prep_kernel, dim3(static_cast<uint32_t>((n_tasks + 255) / 256)), dim3(256), 0, s, d_seq, d_desc, n_tasks,
@@ -516,17 +546,22 @@ extern "C" int fmsi_hip_query_stream(fmsi_hip_index* idx, const uint64_t* packed
     const bool use_table = idx->d_ptable && !(flags & FMSI_HIP_NO_PREFIX_TABLE) && k >= idx->prefix_len;
     size_t slot;
     if ((rc = prof_begin(idx, s, &slot))) return rc;
-    uint8_t* o8 = static_cast<uint8_t*>(d_out);
     long long* o64 = static_cast<long long*>(d_out);
     if (use_table) {
-        if (d_cnt) launch_stream<true, true>(idx, d_rec, n_tasks, k, flags, o8, o64, d_cnt, s);
-        else launch_stream<false, true>(idx, d_rec, n_tasks, k, flags, o8, o64, d_cnt, s);
+        if (d_cnt) launch_stream<true, true>(idx, d_rec, n_tasks, k, flags, d_slots, o64, d_cnt, s);
+        else launch_stream<false, true>(idx, d_rec, n_tasks, k, flags, d_slots, o64, d_cnt, s);
     } else {
-        if (d_cnt) launch_stream<true, false>(idx, d_rec, n_tasks, k, flags, o8, o64, d_cnt, s);
-        else launch_stream<false, false>(idx, d_rec, n_tasks, k, flags, o8, o64, d_cnt, s);
+        if (d_cnt) launch_stream<true, false>(idx, d_rec, n_tasks, k, flags, d_slots, o64, d_cnt, s);
+        else launch_stream<false, false>(idx, d_rec, n_tasks, k, flags, d_slots, o64, d_cnt, s);
     }
     FMSI_HIP_TRY(hipGetLastError());
     if ((rc = prof_end(idx, s, slot))) return rc;
+    if (!(flags & FMSI_HIP_ORDERS)) {
+        const uint64_t threads = n_tasks * 64;
+        hipLaunchKernelGGL(stream_compact_kernel, dim3(static_cast<uint32_t>((threads + 255) / 256)), dim3(256), 0, s,
+                           reinterpret_cast<const uint8_t*>(d_slots), d_desc, n_tasks, static_cast<uint8_t*>(d_out));
+        FMSI_HIP_TRY(hipGetLastError());
+    }
     if (!dev_ptrs) {
         FMSI_HIP_TRY(hipMemcpyAsync(out, idx->d_out, out_bytes, hipMemcpyDeviceToHost, s));
         if (counters) FMSI_HIP_TRY(hipMemcpyAsync(counters, idx->d_counters, FMSI_HIP_N_COUNTERS * 8, hipMemcpyDeviceToHost, s));
