@@ -127,6 +127,9 @@ def lib() -> C.CDLL:
     L.fmsi_host_pack_2bit.argtypes = [C.c_char_p, u64, vp]
     L.fmsi_host_pack_2bit.restype = u64
     L.fmsi_cli_query.argtypes = [i32, C.POINTER(C.c_char_p), i32]
+    L.fmsi_cli_index.argtypes = [i32, C.POINTER(C.c_char_p)]
+    L.fmsi_host_index_write.argtypes = [C.c_char_p, C.POINTER(IndexView)]
+    L.fmsi_hip_index_write_files.argtypes = [vp, C.c_char_p]
     _lib = L
     return L
 
@@ -197,6 +200,10 @@ class HostIndex:
         nw = (nbits + 63) // 64
         words = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint64)), shape=(nw,)).copy()
         return np.unpackbits(words.view(np.uint8), bitorder="little")[:nbits]
+
+    def write(self, prefix: str) -> None:
+        """Write <prefix>.fmsi.* again (dump_index, reference src/fms_index.h:484-500); the mask is re-encoded as RRR-63."""
+        _check(lib().fmsi_host_index_write(os.fsencode(prefix), C.byref(self.view)))
 
     def layout(self):
         """(blocks[n_blocks,16] u32, mrank[n_blocks+1] u32): the device layout, built on the host."""
@@ -271,6 +278,10 @@ class DeviceIndex:
         mrank = np.zeros(nb + 1, dtype=np.uint32)
         _check(lib().fmsi_hip_index_download_layout(self._h, blocks.ctypes.data, mrank.ctypes.data))
         return blocks, mrank
+
+    def write_files(self, prefix: str) -> None:
+        """Write the index as the reference's <prefix>.fmsi.* files (fmsi_hip_index_write_files)."""
+        _check(lib().fmsi_hip_index_write_files(self._h, os.fsencode(prefix)))
 
     def enable_pair_layout(self):
         """Add the 128-B two-base-step layout (fmsi_hip_index_enable_pair_layout); AUTO kernels then use it."""

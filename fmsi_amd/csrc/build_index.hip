@@ -94,18 +94,42 @@ struct U4Plus {
     __host__ __device__ U4 operator()(const U4& x, const U4& y) const { return U4{x.a + y.a, x.c + y.c, x.g + y.g, x.t + y.t}; }
 };
 
+// kLCP bit of row r: the suffixes of rows r and r+1 share their first k-1 bases (construct_klcp, src/fms_index.h:357-385;
+// rows whose suffix is shorter than k-1 get 0).  One thread per row, one 64-bit ballot per wave.  Kept apart from
+// emit_rows_kernel: fused into it, the compare gave run-to-run differing bits on gfx950 for rows >= 2^16
+// (tests/test_gpu_builder.py::test_klcp_equals_oracle pins this kernel).
+__global__ __launch_bounds__(256) void klcp_kernel(const uint64_t* __restrict__ text2, const uint32_t* __restrict__ sa_sorted,
+                                                   uint64_t len, int k, uint64_t* __restrict__ klcp) {
+    const uint64_t row = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    bool kbit = false;
+    if (row < len) {
+        const uint64_t s = row == 0 ? len : sa_sorted[row - 1];
+        const uint64_t s2 = sa_sorted[row];
+        const uint64_t km1 = static_cast<uint64_t>(k - 1);
+        if (km1 <= len && s <= len - km1 && s2 <= len - km1) {
+            const uint64_t m = km1 >= 32 ? ~0ull : ((1ull << (2 * km1)) - 1ull);
+            kbit = km1 == 0 || ((bases_at(text2, s) ^ bases_at(text2, s2)) & m) == 0;
+            if (kbit && km1 > 32) {   // k in 34..64: the reference switches to __uint128_t k-mers (src/main.cpp:229-230)
+                const uint64_t m2 = km1 >= 64 ? ~0ull : ((1ull << (2 * (km1 - 32))) - 1ull);
+                kbit = ((bases_at(text2, s + 32) ^ bases_at(text2, s2 + 32)) & m2) == 0;
+            }
+        }
+    }
+    const uint64_t kk = __ballot(kbit);
+    if ((threadIdx.x & 63) == 0 && row <= len) klcp[row >> 6] = kk;
+}
+
 // One thread per row.  sa_sorted[r] (r = 0..N-1) are the suffixes 0..N-1 in order; row 0 is the empty suffix.
 // 256 threads = 4 waves = 2 blocks of the layout.
 __global__ __launch_bounds__(256) void emit_rows_kernel(const uint64_t* __restrict__ text2, const uint64_t* __restrict__ mask_text,
                                                         const uint32_t* __restrict__ sa_sorted, uint64_t len, int k, int all_ones_mask,
                                                         uint32_t* __restrict__ blocks, U4* __restrict__ block_counts,
-                                                        uint32_t* __restrict__ mask_counts, uint64_t* __restrict__ klcp,
-                                                        uint32_t* __restrict__ dollar_row) {
+                                                        uint32_t* __restrict__ mask_counts, uint32_t* __restrict__ dollar_row) {
     __shared__ uint32_t s_cnt[4][5];
     const uint64_t n = len + 1;
     const uint64_t row = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     const uint32_t wave_in_block = threadIdx.x >> 6;
-    uint32_t sym = 0, mbit = 0, kbit = 0;
+    uint32_t sym = 0, mbit = 0;
     const bool valid = row < n;
     if (valid) {
         const uint64_t s = row == 0 ? len : sa_sorted[row - 1];
@@ -115,19 +139,10 @@ __global__ __launch_bounds__(256) void emit_rows_kernel(const uint64_t* __restri
             if (all_ones_mask) mbit = s + static_cast<uint64_t>(k) <= len;            // synthetic MS: every k-mer ON
             else mbit = static_cast<uint32_t>(mask_text[s >> 6] >> (s & 63)) & 1u;
         }
-        if (klcp && row < len) {                                                      // construct_klcp, :357-385
-            const uint64_t s2 = sa_sorted[row];
-            const uint64_t km1 = static_cast<uint64_t>(k - 1);
-            if (km1 <= len && s <= len - km1 && s2 <= len - km1) {
-                const uint64_t m = km1 >= 32 ? ~0ull : ((1ull << (2 * km1)) - 1ull);
-                kbit = km1 == 0 || ((bases_at(text2, s) ^ bases_at(text2, s2)) & m) == 0;
-            }
-        }
     }
     const uint64_t hi = __ballot(valid && (sym & 2u));
     const uint64_t lo = __ballot(valid && (sym & 1u));
     const uint64_t mm = __ballot(valid && mbit);
-    const uint64_t kk = __ballot(valid && kbit);
     const uint64_t vv = __ballot(valid);
     if ((threadIdx.x & 63) == 0) {
         const uint64_t w = row >> 6;          // 64-row word index
@@ -140,7 +155,6 @@ __global__ __launch_bounds__(256) void emit_rows_kernel(const uint64_t* __restri
             blk[9 + half] = static_cast<uint32_t>(lo >> 32);
             blk[12 + half] = static_cast<uint32_t>(mm);
             blk[13 + half] = static_cast<uint32_t>(mm >> 32);
-            if (klcp) klcp[w] = kk;
         }
         s_cnt[wave_in_block][0] = __popcll(vv & ~hi & ~lo);
         s_cnt[wave_in_block][1] = __popcll(vv & ~hi & lo);
@@ -286,8 +300,12 @@ int build_from_device_text(DevBuf& text2, uint64_t len, DevBuf* mask_text, int k
     const uint32_t emit_grid = grid_for(n);   // 256 rows = 2 layout blocks per workgroup; grid covers <= n_blocks - 1 blocks
     hipLaunchKernelGGL(emit_rows_kernel, dim3(emit_grid), dim3(256), 0, 0, text2.as<uint64_t>(),
                        mask_text ? mask_text->as<uint64_t>() : nullptr, sorted_pos, len, k, mask_text ? 0 : 1, blocks.as<uint32_t>(),
-                       counts.as<U4>(), mcounts.as<uint32_t>(), with_klcp ? klcp.as<uint64_t>() : nullptr, dollar.as<uint32_t>());
+                       counts.as<U4>(), mcounts.as<uint32_t>(), dollar.as<uint32_t>());
     FMSI_HIP_TRY(hipGetLastError());
+    if (with_klcp) {
+        hipLaunchKernelGGL(klcp_kernel, dim3(emit_grid), dim3(256), 0, 0, text2.as<uint64_t>(), sorted_pos, len, k, klcp.as<uint64_t>());
+        FMSI_HIP_TRY(hipGetLastError());
+    }
     // exclusive prefix sums over blocks (+1 element: totals)
     size_t st_bytes = 0;
     FMSI_HIP_TRY(rocprim::exclusive_scan(nullptr, st_bytes, counts.as<U4>(), counts_scanned.as<U4>(), U4{0, 0, 0, 0},
@@ -421,8 +439,8 @@ using namespace fmsi;
 extern "C" {
 
 int fmsi_hip_index_build(const char* ms, uint64_t len, int k, int with_klcp, int device, int prefix_len, fmsi_hip_index** out) {
-    if (!ms || !out || k < 1 || (with_klcp && k > 33)) {
-        set_last_error("bad argument (on-device kLCP construction needs k <= 33)");
+    if (!ms || !out || k < 1 || (with_klcp && k > 64)) {
+        set_last_error("bad argument (on-device kLCP construction needs k <= 64)");
         return FMSI_HIP_EINVAL;
     }
     int rc = check_device(device);
@@ -451,8 +469,8 @@ int fmsi_hip_index_build(const char* ms, uint64_t len, int k, int with_klcp, int
 }
 
 int fmsi_hip_index_build_synthetic(uint64_t len, uint64_t seed, int k, int with_klcp, int device, int prefix_len, fmsi_hip_index** out) {
-    if (!out || k < 1 || len < static_cast<uint64_t>(k) || (with_klcp && k > 33)) {
-        set_last_error("bad argument (on-device kLCP construction needs k <= 33)");
+    if (!out || k < 1 || len < static_cast<uint64_t>(k) || (with_klcp && k > 64)) {
+        set_last_error("bad argument (on-device kLCP construction needs k <= 64)");
         return FMSI_HIP_EINVAL;
     }
     int rc = check_device(device);

@@ -23,6 +23,7 @@
 #include "common.h"
 #include "device_fm.h"
 #include "index_priv.h"
+#include "index_writer.h"
 #include "layout.h"
 
 namespace fmsi {
@@ -630,6 +631,39 @@ int fmsi_hip_index_download_layout(const fmsi_hip_index* idx, uint32_t* blocks, 
     FMSI_HIP_TRY(hipMemcpy(blocks, idx->d_blocks, idx->n_blocks * kBlockBytes, hipMemcpyDeviceToHost));
     FMSI_HIP_TRY(hipMemcpy(mrank, idx->d_mrank, (idx->n_blocks + 1) * 4, hipMemcpyDeviceToHost));
     return 0;
+}
+
+int fmsi_hip_index_write_files(const fmsi_hip_index* idx, const char* prefix) {
+    if (!idx || !prefix) return FMSI_HIP_EINVAL;
+    FMSI_HIP_TRY(hipSetDevice(idx->device));
+    std::vector<uint32_t> blocks(idx->n_blocks * kBlockDwords);
+    FMSI_HIP_TRY(hipMemcpy(blocks.data(), idx->d_blocks, blocks.size() * 4, hipMemcpyDeviceToHost));
+    HostVectors hv;
+    vectors_from_blocks(blocks.data(), idx->n, hv);
+    blocks.clear();
+    blocks.shrink_to_fit();
+    std::vector<uint64_t> klcp;
+    if (idx->d_klcp) {
+        klcp.assign((idx->n + 63) / 64 + 2, 0);
+        FMSI_HIP_TRY(hipMemcpy(klcp.data(), idx->d_klcp, ((idx->n + 63) / 64) * 8, hipMemcpyDeviceToHost));
+    }
+    fmsi_index_view v;
+    std::memset(&v, 0, sizeof v);
+    v.ac_gt = hv.ac_gt.data(); v.ac_gt_bits = hv.n;
+    v.ac = hv.ac.data(); v.ac_bits = hv.ac_bits;
+    v.gt = hv.gt.data(); v.gt_bits = hv.gt_bits;
+    v.mask = hv.mask.data(); v.mask_bits = hv.n;
+    if (!klcp.empty()) {
+        v.klcp = klcp.data();
+        v.klcp_bits = idx->n;
+    }
+    v.counts[0] = idx->dev.C0; v.counts[1] = idx->dev.C1; v.counts[2] = idx->dev.C2; v.counts[3] = idx->dev.C3;
+    v.dollar_position = idx->dev.dollar;
+    v.k = idx->k;
+    std::string err;
+    int rc = write_index_files(prefix, v, err);
+    if (rc) set_last_error(err);
+    return rc;
 }
 
 int fmsi_hip_index_download_klcp(const fmsi_hip_index* idx, uint64_t* words) {

@@ -1,0 +1,117 @@
+// `fmsi index` on the GPU: counterpart of ms_index (reference src/main.cpp:172-236).  The masked superstring is
+// read exactly as the reference reads it (first FASTA record, k inferred from the trailing lower-case run,
+// src/parser.h:31-55), the suffix sort / BWT / SA-transformed mask / kLCP are computed on the device
+// (build_index.hip) and the six files are written in the reference's format (index_writer.cpp): byte-identical
+// to `fmsi index` of the reference (tests/test_gpu_index_cli.py).
+#include <getopt.h>
+
+#include <cstdlib>
+#include <iostream>
+#include <stdexcept>
+#include <string>
+
+#include "../../include/fmsi_hip.h"
+#include "common.h"
+#include "fastx.h"
+
+namespace {
+
+int usage_index() {
+    std::cerr << std::endl;
+    std::cerr << "Usage:   fmsi index [options] <masked-superstring-input>" << std::endl << std::endl;
+    std::cerr << "Options:" << std::endl;
+    std::cerr << "    -k INT  - size of k-mers [recommended, default: number of mask trailing zeros - 1]" << std::endl;
+    std::cerr << "    -x      - do not compute the kLCP array used for faster streaming queries." << std::endl;
+    std::cerr << "    --device INT - HIP device to use [default: 0]" << std::endl << std::endl;
+    std::cerr << "Note: `fmsi index` accepts only masked superstrings - these can be computed e.g. by KmerCamel from any FASTA file."
+              << std::endl << std::endl;
+    return 1;
+}
+
+inline bool is_upper(char c) { return c >= 'A' && c <= 'Z'; }   // src/kmers.h:71-73
+
+}  // namespace
+
+namespace {
+int run_index(int argc, char** argv) {
+    bool usage = false, no_streaming = false;
+    int k = 0, device = 0, c;
+    std::string fn;
+    if (argc > 1 && std::string(argv[argc - 1]) != "-h") {   // last argument = input, as in the reference (:177-180)
+        fn = argv[argc - 1];
+        argc--;
+    }
+    static const option long_opts[] = {{"device", required_argument, nullptr, 1000}, {nullptr, 0, nullptr, 0}};
+    optind = 1;
+    while ((c = getopt_long(argc, argv, "hk:x", long_opts, nullptr)) >= 0) {
+        switch (c) {
+        case 'h': usage = true; break;
+        case 'k': k = atoi(optarg); break;
+        case 'x': no_streaming = true; break;
+        case 1000: device = atoi(optarg); break;
+        default: return usage_index();
+        }
+    }
+    if (usage) {
+        usage_index();
+        return 0;
+    } else if (fn.empty()) {
+        std::cerr << "ERROR: Path to the masked superstring is a required argument." << std::endl;
+        return usage_index();
+    }
+    std::cerr << "Starting " << fn << std::endl;
+    std::string ms;
+    {
+        fmsi::FastxReader reader(fn);   // throws std::invalid_argument like OpenFile(), src/parser.h:22
+        if (!reader.next()) throw std::invalid_argument("Error reading the fasta file. The fasta file should contain a single entry - the masked superstring.");
+        ms.swap(reader.seq);
+        if (reader.next()) std::cerr << "Warning: The fasta file contains more than one entry. Only the first entry will be used." << std::endl;
+    }
+    if (ms.empty()) {
+        std::cerr << "ERROR: The file '" << fn
+                  << "' is in incorrect format. It is supposed to be a fasta file with a single entry, the masked superstring" << std::endl;
+        return usage_index();
+    }
+    std::cerr << "Read masked superstring of length " << ms.size() << std::endl;
+    int inferred_k = 1;                                       // infer_k, src/parser.h:31-37
+    while (static_cast<size_t>(inferred_k) <= ms.size() && !is_upper(ms[ms.size() - inferred_k])) inferred_k++;
+    if (k == 0) {
+        k = inferred_k;
+        std::cerr << "Inferred k from the masked case convention: " << k << std::endl;
+    }
+    if (k != inferred_k) {
+        std::cerr << "WARNING: The provided k (" << k << ") does not match the k inferred from the mask convention (" << inferred_k
+                  << "). The provided k is used but we recommend double checking that it is correct." << std::endl;
+    }
+    if (k > 64 && !no_streaming) {
+        std::cerr << "WARNING: Construction of kLCP array for streaming support is only available for k <= 64. The index will be "
+                     "constructed without streaming support, which results in slower positive streaming queries." << std::endl;
+        no_streaming = true;
+    }
+    fmsi_hip_index* dev = nullptr;
+    if (fmsi_hip_index_build(ms.data(), ms.size(), k, !no_streaming, device, 0, &dev) != 0) {
+        std::cerr << "ERROR: cannot construct the index on the device: " << fmsi_hip_last_error() << std::endl;
+        return 1;
+    }
+    std::cerr << "Constructed index" << std::endl;
+    const int rc = fmsi_hip_index_write_files(dev, fn.c_str());
+    fmsi_hip_index_destroy(dev);
+    if (rc != 0) {
+        std::cerr << "ERROR: cannot write the index: " << fmsi_hip_last_error() << std::endl;
+        return 1;
+    }
+    std::cerr << "Written index" << std::endl;
+    return 0;
+}
+}  // namespace
+
+// No exception crosses the C boundary: the reference lets std::invalid_argument from its parser terminate the
+// process (src/parser.h:22-29); here the message is printed and the exit code is 1.
+extern "C" int fmsi_cli_index(int argc, char** argv) {
+    try {
+        return run_index(argc, argv);
+    } catch (const std::exception& e) {
+        std::cerr << "ERROR: " << e.what() << std::endl;
+        return 1;
+    }
+}

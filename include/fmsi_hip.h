@@ -120,7 +120,7 @@ int fmsi_hip_index_get_info(const fmsi_hip_index* idx, fmsi_hip_index_info* info
 
 /* On-device construction -- counterpart of construct<T>() (src/fms_index.h:397-460) producing the device layout
  * directly: 2-bit text -> GPU suffix sort -> BWT / SA-transformed mask / kLCP -> interleaved blocks.
- * `ms` is the masked superstring (upper case = mask 1, src/kmers.h:71-73).  with_klcp needs k <= 33. */
+ * `ms` is the masked superstring (upper case = mask 1, src/kmers.h:71-73).  with_klcp needs k <= 64 (as the reference, src/main.cpp:223-226). */
 int fmsi_hip_index_build(const char* ms, uint64_t len, int k, int with_klcp, int device, int prefix_len, fmsi_hip_index** out);
 
 /* Synthetic workloads (no network on the GPU box, so no real genomes): the superstring is
@@ -149,6 +149,15 @@ int fmsi_hip_index_download_layout(const fmsi_hip_index* idx, uint32_t* blocks, 
  * update_range() steps (src/fms_index.h:98-103).  Final intervals and results are unchanged; the number of random
  * block reads per k-mer roughly halves.  Costs 1 byte per row of HBM.  Idempotent. */
 int fmsi_hip_index_enable_pair_layout(fmsi_hip_index* idx);
+
+/* Writes the handle's index in the reference's on-disk format, <prefix>.fmsi.{ac_gt,ac,gt,mask,misc} (+ .klcp when
+ * the handle has a kLCP array): the writer half of dump_index() (src/fms_index.h:484-500), byte-identical files. */
+int fmsi_hip_index_write_files(const fmsi_hip_index* idx, const char* prefix);
+/* Same from host bit-vectors (mask = plain bits; it is RRR-63 encoded here). */
+int fmsi_host_index_write(const char* prefix, const fmsi_index_view* view);
+/* The `fmsi index` command (ms_index, src/main.cpp:172-236) with the suffix sort on the GPU; argv as the reference's
+ * sub-command sees it (argv[0] = "index").  Returns the process exit code. */
+int fmsi_cli_index(int argc, char** argv);
 
 /* Copies the handle's kLCP bit-vector back (ceil(n/64) words); fails when the handle has none. */
 int fmsi_hip_index_download_klcp(const fmsi_hip_index* idx, uint64_t* words);

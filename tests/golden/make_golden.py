@@ -121,6 +121,37 @@ def main():
         dst.unlink()
         for part in sorted(idx.glob(name + ".fmsi.*")):
             md5[part.name] = hashlib.md5(part.read_bytes()).hexdigest()
+    # 3b. index-only fixtures for `fmsi index` with k > 32 (the reference switches to __uint128_t k-mers for the kLCP,
+    # src/main.cpp:229-230): a superstring with planted repeats of 20..90 bases so that the kLCP differs between k.
+    rng = random.Random(7)
+    segs, text = [], ""
+    for _ in range(160):
+        if segs and rng.random() < 0.55:
+            src_seg = rng.choice(segs)
+            a = rng.randrange(0, len(src_seg) - 20)
+            piece = src_seg[a:a + rng.randrange(20, 91)]
+            if rng.random() < 0.3:
+                piece = revcomp(piece)
+        else:
+            piece = "".join(rng.choice("ACGT") for _ in range(rng.randrange(60, 200)))
+            segs.append(piece)
+        text += piece
+    k_rep = 40
+    text = "".join(ch if rng.random() < 0.8 else ch.lower() for ch in text[:-k_rep]) + text[-k_rep] + text[-(k_rep - 1):].lower()
+    (HERE / "repeats.fa").write_text(f">repeats k={k_rep}\n{text}\n")
+    for name, extra in (("repeats_k40", []), ("repeats_k33", ["-k", 33]), ("repeats_k34", ["-k", 34]), ("repeats_k64", ["-k", 64]),
+                        ("repeats_k40x", ["-x"])):
+        dst = idx / name
+        shutil.copy(HERE / "repeats.fa", dst)
+        run([REF_CLI, "index", *extra, dst])
+        dst.unlink()
+        for part in sorted(idx.glob(name + ".fmsi.*")):
+            md5[part.name] = hashlib.md5(part.read_bytes()).hexdigest()
+            if name != "repeats_k40" and part.suffix not in (".klcp", ".misc"):   # identical to repeats_k40's: keep one copy
+                assert part.read_bytes() == (idx / ("repeats_k40" + part.name[len(name):])).read_bytes()
+                part.unlink()
+    assert not (idx / "repeats_k40x.fmsi.klcp").exists()
+    assert len({md5[f"repeats_k{k}.fmsi.klcp"] for k in (33, 34, 40, 64)}) == 4
     (idx / "md5.json").write_text(json.dumps(md5, indent=1, sort_keys=True) + "\n")
 
     # 4. query files

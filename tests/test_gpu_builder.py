@@ -100,3 +100,43 @@ def test_synthetic_build_equals_oracle(fm, oracle_built, tmp_path):
     dev.synthetic_queries_dev(k, 42, 5000, 1000, d2.data_ptr(), s)
     torch.cuda.synchronize()
     assert np.array_equal(d2.cpu().numpy().view(np.uint64), kmers[5000:6000])
+
+
+def klcp_bits(words, nbits):
+    return np.unpackbits(np.ascontiguousarray(words).view(np.uint8), bitorder="little")[:nbits]
+
+
+@pytest.mark.parametrize("n,k,mask", [(5_000, 7, "mixed"), (100_000, 9, "mixed"), (300_000, 9, "mixed"), (300_000, 13, "mixed"),
+                                      (700_001, 12, "ones"), (200_000, 40, "mixed"), (200_000, 64, "ones")])
+def test_klcp_equals_oracle(fm, oracle_built, n, k, mask):
+    """The device-built kLCP array (klcp_kernel, construct_klcp src/fms_index.h:357-385) bit for bit against the oracle, on
+    texts large enough to put many workgroups on every CU (dense at k = 9: ~half of the bits set) -- and the same bits again
+    on a second build (an earlier fused version of the kernel was not run-to-run stable beyond 2^16 rows)."""
+    ms = synthetic_ms(n, k, seed=n % 1000 + k, mask=mask)
+    if k >= 33:      # plant repeats so that long (k-1)-mers are shared at all
+        rng = random.Random(k)
+        parts = [ms[:5000]]
+        while sum(map(len, parts)) < n:
+            a = rng.randrange(0, 4900)
+            parts.append(ms[a:a + rng.randrange(30, 100)].upper() if rng.random() < 0.7 else
+                         "".join(rng.choice("ACGT") for _ in range(rng.randrange(30, 200))))
+        ms = "".join(parts)
+        ms = ms[:len(ms) - (k - 1)] + ms[len(ms) - (k - 1):].lower()
+    orc = oracle_py.Oracle.construct(ms, k, use_klcp=True)
+    words, nbits = orc.words(3)
+    want = klcp_bits(words, nbits)
+    assert want.sum() > 100
+    for rep in range(2):
+        dev = fm.DeviceIndex.build(ms.encode(), k, with_klcp=True)
+        got = klcp_bits(dev.download_klcp(), nbits)
+        bad = np.nonzero(got != want)[0]
+        assert bad.size == 0, f"rep {rep}: {bad.size} kLCP bits differ, first rows {bad[:8]}"
+
+
+def test_build_is_deterministic_at_scale(fm):
+    """Two builds of a 5 M-base synthetic superstring leave identical bytes in HBM (layout, mask ranks, kLCP)."""
+    a = fm.DeviceIndex.build_synthetic(5_000_000, 3, 23, with_klcp=True)
+    b = fm.DeviceIndex.build_synthetic(5_000_000, 3, 23, with_klcp=True)
+    (ba, ma), (bb, mb) = a.download_layout(), b.download_layout()
+    assert np.array_equal(ba, bb) and np.array_equal(ma, mb)
+    assert np.array_equal(a.download_klcp(), b.download_klcp())

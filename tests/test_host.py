@@ -12,7 +12,7 @@ import numpy as np
 import pytest
 
 import oracle_py
-from conftest import DATASETS, GOLDEN, REPO, index_prefix, synthetic_ms
+from conftest import DATASETS, GOLDEN, INDEX_PARTS, REPO, golden_index_part, index_prefix, synthetic_ms
 
 
 def declared_functions():
@@ -53,6 +53,49 @@ def test_loader_matches_oracle(product_built, oracle_built, name):
     assert np.array_equal(host.bits("mask"), orc.mask_bits())     # RRR-63 decode
     nok = product_built.HostIndex(index_prefix(name), use_klcp=False)
     assert nok.view.klcp_bits == 0
+
+
+@pytest.mark.parametrize("name", list(DATASETS) + ["repeats_k40"])
+def test_writer_reproduces_reference_files(product_built, tmp_path, name):
+    """load -> fmsi_host_index_write == the reference's dump_index() bytes (src/fms_index.h:484-500): pins the RRR-63
+    encoder (class / offset / sample layout of sdsl rrr_vector<63>) and the int_vector framing."""
+    host = product_built.HostIndex(index_prefix(name), use_klcp=True)
+    host.write(str(tmp_path / name))
+    for part in INDEX_PARTS:
+        assert (tmp_path / f"{name}.fmsi.{part}").read_bytes() == golden_index_part(name, part), part
+    nok = product_built.HostIndex(index_prefix(name), use_klcp=False)
+    nok.write(str(tmp_path / "nok"))
+    assert not (tmp_path / "nok.fmsi.klcp").exists()
+
+
+def test_writer_rrr_edge_lengths(product_built, oracle_built, tmp_path):
+    """Mask lengths around the 63-bit block and 32-block superblock boundaries, several densities: written by the
+    product, read back by the oracle's independent RRR decoder."""
+    rng = np.random.default_rng(5)
+    for n in (1, 2, 62, 63, 64, 125, 126, 127, 63 * 32 - 1, 63 * 32, 63 * 32 + 1, 63 * 64, 5000):
+        for density in (0.0, 0.03, 0.5, 0.97, 1.0):
+            bits = (rng.random(n) < density).astype(np.uint8)
+            sym = rng.integers(0, 4, n)
+            sym[0] = 0
+            planes = {}
+            hi, lo = (sym >> 1).astype(np.uint8), (sym & 1).astype(np.uint8)
+            planes["ac_gt"] = hi
+            planes["ac"] = lo[hi == 0]
+            planes["gt"] = lo[hi == 1]
+            arrs = {}
+            for key, b in list(planes.items()) + [("mask", bits)]:
+                w = np.zeros((len(b) + 63) // 64 + 1, dtype=np.uint64)
+                packed = np.packbits(b, bitorder="little")
+                w.view(np.uint8)[:len(packed)] = packed
+                arrs[key] = (w, len(b))
+            cnt = [1, 1 + int((sym == 0).sum()), 1 + int((sym <= 1).sum()), 1 + int((sym <= 2).sum())]
+            view, keep = product_built.view_from_arrays(arrs["ac_gt"], arrs["ac"], arrs["gt"], arrs["mask"], cnt, 0, 5)
+            rc = product_built.lib().fmsi_host_index_write(str(tmp_path / "e").encode(), C.byref(view))
+            assert rc == 0
+            orc = oracle_py.Oracle.load(str(tmp_path / "e"), use_klcp=False)
+            assert orc.n == n and np.array_equal(orc.mask_bits(), bits), (n, density)
+            back = product_built.HostIndex(str(tmp_path / "e"))
+            assert np.array_equal(back.bits("mask"), bits) and np.array_equal(back.bits("ac_gt"), hi)
 
 
 def test_loader_errors(product_built, tmp_path):
@@ -177,7 +220,7 @@ def test_cli_option_handling(product_built):
     assert rc == 1 and b"not available on the GPU path" in err
     rc, out, err = run(["-v"])
     assert rc == 0 and out.strip()
-    rc, out, err = run(["index", "x"])
+    rc, out, err = run(["export", "x"])
     assert rc == 1 and b"not part of the MI355X query path" in err
     rc, out, err = run([])
     assert rc == 1

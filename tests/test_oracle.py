@@ -13,7 +13,8 @@ import numpy as np
 import pytest
 
 import oracle_py
-from conftest import DATASETS, GOLDEN, MODES, golden_out, index_prefix, mixed_kmers, query_file, synthetic_ms
+from conftest import (DATASETS, GOLDEN, INDEX_CASES, INDEX_PARTS, MODES, golden_index_part, golden_out, index_prefix, mixed_kmers,
+                      query_file, synthetic_ms)
 
 
 def make(cls, kat, name):
@@ -85,21 +86,23 @@ def test_construct_kat(oracle_built, kat):
         assert np.unpackbits(words.view(np.uint8), bitorder="little")[:nbits].tolist() == bits
 
 
-@pytest.mark.parametrize("name", list(DATASETS))
+@pytest.mark.parametrize("name", list(INDEX_CASES))
 def test_index_bytes_equal_reference(oracle_built, tmp_path, name):
-    """oracle construct()+dump == bytes written by the real reference (tests/golden/idx/md5.json)."""
+    """oracle construct()+dump == bytes written by the real reference (tests/golden/idx, md5.json), incl. k > 32 and -x."""
     md5 = json.loads((GOLDEN / "idx" / "md5.json").read_text())
-    src = {"integration_a": GOLDEN / "ref_data" / "integration_a.fa", "integration_b": GOLDEN / "ref_data" / "integration_b.fa",
-           "sars_k13": GOLDEN / "ref_data" / "GCF_009858895.2_ASM985889v3_genomic.fna.ms.k13",
-           "sars_k31": GOLDEN / "ref_data" / "GCF_test2_ones.fna.ms.k31", "mixed_k11": GOLDEN / "mixed.fa"}[name]
+    src, extra = INDEX_CASES[name]
     dst = tmp_path / name
-    dst.write_bytes(src.read_bytes())
-    rc, _, err = oracle_py.run_cli(oracle_py.ORACLE_CLI, ["index", str(dst)])
+    dst.write_bytes((GOLDEN / src).read_bytes())
+    rc, _, err = oracle_py.run_cli(oracle_py.ORACLE_CLI, ["index", *extra, str(dst)])
     assert rc == 0, err
-    for part in ("ac_gt", "ac", "gt", "mask", "klcp", "misc"):
-        got = hashlib.md5((tmp_path / f"{name}.fmsi.{part}").read_bytes()).hexdigest()
-        assert got == md5[f"{name}.fmsi.{part}"], part
-        assert (tmp_path / f"{name}.fmsi.{part}").read_bytes() == (GOLDEN / "idx" / f"{name}.fmsi.{part}").read_bytes()
+    for part in INDEX_PARTS:
+        want = golden_index_part(name, part)
+        f = tmp_path / f"{name}.fmsi.{part}"
+        if want is None:
+            assert not f.exists()
+            continue
+        assert f.read_bytes() == want, part
+        assert hashlib.md5(want).hexdigest() == md5[f"{name}.fmsi.{part}"], part
 
 
 def test_survey_md5_of_k31_fixture():
