@@ -451,13 +451,13 @@ size_t out_elem_bytes(uint32_t flags) {
     return 1;
 }
 
-int check_query_args(const fmsi_hip_index* idx, const void* in, const void* out, int k) {
+int check_query_args(const fmsi_hip_index* idx, const void* in, const void* out, int k, int k_max) {
     if (!idx || !in || !out) {
         set_last_error("null argument");
         return FMSI_HIP_EINVAL;
     }
-    if (k < 1 || k > 32) {
-        set_last_error("k must be in [1, 32] in this build");
+    if (k < 1 || k > k_max) {
+        set_last_error("k must be in [1, " + std::to_string(k_max) + "] for this entry point");
         return FMSI_HIP_ERANGE;
     }
     return 0;
@@ -492,6 +492,20 @@ int run_query(fmsi_hip_index* idx, int input_kind, const uint64_t* in, size_t in
         }
     }
     const uint64_t* d_kmers = d_in;
+    if (input_kind == 1 && k > 32) {
+        // the k-mer does not fit a register pair: walk the window off the packed sequence (fmsi_longk.hip)
+        if (n_windows == 0) return 0;
+        size_t slot;
+        if ((rc = prof_begin(idx, s, &slot))) return rc;
+        launch_longk_query(idx, d_in, d_ws, n_windows, k, flags, static_cast<uint8_t*>(d_out), static_cast<long long*>(d_out), d_cnt, s);
+        FMSI_HIP_TRY(hipGetLastError());
+        if ((rc = prof_end(idx, s, slot))) return rc;
+        if (!dev_ptrs) {
+            if (out_bytes) FMSI_HIP_TRY(hipMemcpyAsync(out, idx->d_out, out_bytes, hipMemcpyDeviceToHost, s));
+            if (counters) FMSI_HIP_TRY(hipMemcpyAsync(counters, idx->d_counters, FMSI_HIP_N_COUNTERS * 8, hipMemcpyDeviceToHost, s));
+        }
+        return 0;
+    }
     if (input_kind == 1) {
         // windows -> packed k-mers in a library-owned buffer (8 B per window, streaming)
         if ((rc = ensure_cap(&idx->d_kmers, &idx->d_kmers_cap, n_windows * 8))) return rc;
@@ -679,7 +693,7 @@ int fmsi_hip_index_download_klcp(const fmsi_hip_index* idx, uint64_t* words) {
 int fmsi_hip_query_kmers(fmsi_hip_index* idx, const uint64_t* kmers, uint64_t n_kmers, int k, uint32_t flags, void* out,
                          uint64_t* counters, void* stream) {
     if (n_kmers == 0) return 0;
-    int rc = check_query_args(idx, kmers, out, k);
+    int rc = check_query_args(idx, kmers, out, k, 32);
     if (rc) return rc;
     return run_query(idx, 0, kmers, n_kmers * 8, nullptr, n_kmers, k, flags, out, counters, stream);
 }
@@ -687,7 +701,7 @@ int fmsi_hip_query_kmers(fmsi_hip_index* idx, const uint64_t* kmers, uint64_t n_
 int fmsi_hip_query_windows(fmsi_hip_index* idx, const uint64_t* packed_seq, uint64_t seq_bases, const uint64_t* window_start,
                            uint64_t n_windows, int k, uint32_t flags, void* out, uint64_t* counters, void* stream) {
     if (n_windows == 0) return 0;
-    int rc = check_query_args(idx, packed_seq, out, k);
+    int rc = check_query_args(idx, packed_seq, out, k, 1 << 20);
     if (rc) return rc;
     if (!window_start && n_windows + static_cast<uint64_t>(k) - 1 > seq_bases) {
         set_last_error("implicit windows run past the end of the sequence");

@@ -103,7 +103,10 @@ __device__ __forceinline__ uint64_t task_kmer(uint64_t s0, uint64_t s1, uint64_t
     return k == 32 ? f : (f & ((1ull << (2 * k)) - 1ull));
 }
 
-template <bool COUNT, bool PTABLE>
+// WIDE (33 <= k <= 64, the reference's __uint128_t k-mers): no k-mer register; the bases of the current window are taken
+// from the task's 128 bases when needed -- base t of the forward k-mer of window w is S[w + t], of its reverse
+// complement 3 - S[w + k-1-t].
+template <bool COUNT, bool PTABLE, bool WIDE>
 __global__ __launch_bounds__(256) void query_stream_kernel(DevIndex ix, const uint64_t* __restrict__ klcp, const TaskRec* __restrict__ tasks,
                                                            uint64_t n_tasks, int k, uint32_t flags, uint32_t chunk,
                                                            uint4* __restrict__ slots, long long* __restrict__ out_orders,
@@ -120,7 +123,7 @@ __global__ __launch_bounds__(256) void query_stream_kernel(DevIndex ix, const ui
     uint64_t next = wave * chunk;
     const uint64_t end = min(n_tasks, next + static_cast<uint64_t>(chunk));
     const int T = PTABLE ? static_cast<int>(ix.ptable_len) : 0;
-    const uint64_t kmask = k == 32 ? ~0ull : ((1ull << (2 * k)) - 1ull);
+    const uint64_t kmask = (WIDE || k == 32) ? ~0ull : ((1ull << (2 * k)) - 1ull);
 
     // current task
     uint64_t s0 = 0, s1 = 0, s2 = 0, s3 = 0, obase = 0;
@@ -139,6 +142,22 @@ __global__ __launch_bounds__(256) void query_stream_kernel(DevIndex ix, const ui
     int t = 0;
     StreamCounters cn;
 
+    // ---- the current window's k-mer on the current strand ----
+    auto kmer_base = [&](int tt) -> uint32_t {        // base tt (0 = first)
+        if (WIDE) return pass == 0 ? task_base(s0, s1, s2, s3, widx + static_cast<uint32_t>(tt))
+                                   : 3u - task_base(s0, s1, s2, s3, widx + static_cast<uint32_t>(k - 1 - tt));
+        return static_cast<uint32_t>(kmer >> (2 * tt)) & 3u;
+    };
+    auto kmer_table_index = [&](int T_) -> uint32_t {   // its last T_ bases
+        if (WIDE) return static_cast<uint32_t>(pass == 0 ? task_kmer(s0, s1, s2, s3, widx + static_cast<uint32_t>(k - T_), T_)
+                                                         : revcomp_2bit(task_kmer(s0, s1, s2, s3, widx, T_), T_));
+        return static_cast<uint32_t>(kmer >> (2 * (k - T_))) & ((1u << (2 * T_)) - 1u);
+    };
+    auto load_kmer = [&]() {                          // (re)load it for window widx
+        if (WIDE) return;
+        const uint64_t f = task_kmer(s0, s1, s2, s3, widx, k);
+        kmer = pass == 0 ? f : revcomp_2bit(f, k);
+    };
     auto fresh = [&]() {   // start a fresh k-step search for `kmer`
         if (COUNT) cn.searches++;
         if (PTABLE) {
@@ -178,7 +197,7 @@ __global__ __launch_bounds__(256) void query_stream_kernel(DevIndex ix, const ui
         }
         widx = static_cast<uint32_t>(__ffsll(static_cast<unsigned long long>(todo))) - 1u;
         todo &= todo - 1;
-        kmer = revcomp_2bit(task_kmer(s0, s1, s2, s3, widx, k), k);
+        load_kmer();
         fresh();
     };
     // the current window's result on the current strand is known
@@ -214,7 +233,7 @@ __global__ __launch_bounds__(256) void query_stream_kernel(DevIndex ix, const ui
                 return false;
             }
             --widx;
-            kmer = ((kmer << 2) | task_base(s0, s1, s2, s3, widx)) & kmask;              // prepend S[p]
+            if (!WIDE) kmer = ((kmer << 2) | task_base(s0, s1, s2, s3, widx)) & kmask;   // prepend S[p]
             if (have) return true;
             fresh();
             return false;
@@ -226,12 +245,12 @@ __global__ __launch_bounds__(256) void query_stream_kernel(DevIndex ix, const ui
         const uint32_t nw = static_cast<uint32_t>(__ffsll(static_cast<unsigned long long>(todo))) - 1u;
         todo &= todo - 1;
         if (nw == widx + 1u) {
-            kmer = ((kmer << 2) | (3u - task_base(s0, s1, s2, s3, widx + static_cast<uint32_t>(k)))) & kmask;   // prepend comp(S[p+k])
+            if (!WIDE) kmer = ((kmer << 2) | (3u - task_base(s0, s1, s2, s3, widx + static_cast<uint32_t>(k)))) & kmask;   // prepend comp(S[p+k])
             widx = nw;
             if (have) return true;
         } else {   // skipped windows: the reference resets the interval (fms_index.h:212-216)
             widx = nw;
-            kmer = revcomp_2bit(task_kmer(s0, s1, s2, s3, widx, k), k);
+            load_kmer();
         }
         fresh();
         return false;
@@ -245,7 +264,7 @@ __global__ __launch_bounds__(256) void query_stream_kernel(DevIndex ix, const ui
             pass = 0;
             rf_lo = rf_hi = 0;
             widx = n - 1u;
-            kmer = task_kmer(s0, s1, s2, s3, widx, k);
+            load_kmer();
             fresh();
         }
         {
@@ -279,7 +298,7 @@ __global__ __launch_bounds__(256) void query_stream_kernel(DevIndex ix, const ui
             uint32_t bi = 0, bj = 0, tidx = 0;
             const bool need_blocks = st != SS_EXTSCAN;
             if (PTABLE && st == SS_LOOKUP) {
-                tidx = static_cast<uint32_t>(kmer >> (2 * (k - T))) & ((1u << (2 * T)) - 1u);
+                tidx = kmer_table_index(T);
                 pi = reinterpret_cast<const uint4*>(ix.ptable + (tidx & ~7u));
                 pj = pi;
             } else if (need_blocks) {
@@ -349,10 +368,10 @@ __global__ __launch_bounds__(256) void query_stream_kernel(DevIndex ix, const ui
                 }
             } else if (st == SS_LF) {
                 do_lf = true;
-                c = static_cast<uint32_t>(kmer >> (2 * t)) & 3u;
+                c = kmer_base(t);
             } else if (st == SS_EXTLF) {
                 do_lf = true;
-                c = static_cast<uint32_t>(kmer) & 3u;   // kmer already is the next window's: its first base is the new one
+                c = kmer_base(0);   // the k-mer already is the next window's: its first base is the new one
             } else if (st == SS_HAVE) {
                 // result of the current window from the mask plane (infer_presence, fms_index.h:126-144)
                 if (COUNT) cn.probes++;
@@ -386,7 +405,7 @@ __global__ __launch_bounds__(256) void query_stream_kernel(DevIndex ix, const ui
                     scan_i = (ri == lim_i && i - ri > 0u) ? 1u : 0u;
                     if (rj == 0u && ri == 0u) {
                         do_lf = true;                 // common case: same interval, blocks already loaded
-                        c = static_cast<uint32_t>(kmer) & 3u;
+                        c = kmer_base(0);
                     } else {
                         j += rj;
                         i -= ri;
@@ -456,14 +475,14 @@ __global__ __launch_bounds__(256) void query_stream_kernel(DevIndex ix, const ui
     }
 }
 
-template <bool COUNT, bool PTABLE>
+template <bool COUNT, bool PTABLE, bool WIDE>
 void launch_stream(fmsi_hip_index* idx, const TaskRec* recs, uint64_t n_tasks, int k, uint32_t flags, uint4* o8, long long* o64,
                    unsigned long long* d_counters, hipStream_t s) {
     uint64_t chunk = n_tasks / (256ull * 32 * 8);
     chunk = std::min<uint64_t>(std::max<uint64_t>(chunk, 64), 1024);
     const uint64_t waves = (n_tasks + chunk - 1) / chunk;
     const uint32_t blocks = static_cast<uint32_t>((waves + 3) / 4);
-    hipLaunchKernelGGL((query_stream_kernel<COUNT, PTABLE>), dim3(blocks), dim3(256), 0, s, idx->dev,
+    hipLaunchKernelGGL((query_stream_kernel<COUNT, PTABLE, WIDE>), dim3(blocks), dim3(256), 0, s, idx->dev,
                        static_cast<const uint64_t*>(idx->d_klcp), recs, n_tasks, k, flags, static_cast<uint32_t>(chunk), o8, o64,
                        d_counters);
 }
@@ -485,8 +504,8 @@ extern "C" int fmsi_hip_query_stream(fmsi_hip_index* idx, const uint64_t* packed
         set_last_error("streaming queries need an index created with its kLCP array");
         return FMSI_HIP_EINVAL;
     }
-    if (k < 1 || k > 32) {
-        set_last_error("k must be in [1, 32] in this build");
+    if (k < 1 || k > 64) {   // a kLCP array exists for k <= 64 only (reference src/main.cpp:223-226)
+        set_last_error("streaming queries need 1 <= k <= 64");
         return FMSI_HIP_ERANGE;
     }
     FMSI_HIP_TRY(hipSetDevice(idx->device));
@@ -547,12 +566,20 @@ extern "C" int fmsi_hip_query_stream(fmsi_hip_index* idx, const uint64_t* packed
     size_t slot;
     if ((rc = prof_begin(idx, s, &slot))) return rc;
     long long* o64 = static_cast<long long*>(d_out);
-    if (use_table) {
-        if (d_cnt) launch_stream<true, true>(idx, d_rec, n_tasks, k, flags, d_slots, o64, d_cnt, s);
-        else launch_stream<false, true>(idx, d_rec, n_tasks, k, flags, d_slots, o64, d_cnt, s);
+    if (k > 32) {
+        if (use_table) {
+            if (d_cnt) launch_stream<true, true, true>(idx, d_rec, n_tasks, k, flags, d_slots, o64, d_cnt, s);
+            else launch_stream<false, true, true>(idx, d_rec, n_tasks, k, flags, d_slots, o64, d_cnt, s);
+        } else {
+            if (d_cnt) launch_stream<true, false, true>(idx, d_rec, n_tasks, k, flags, d_slots, o64, d_cnt, s);
+            else launch_stream<false, false, true>(idx, d_rec, n_tasks, k, flags, d_slots, o64, d_cnt, s);
+        }
+    } else if (use_table) {
+        if (d_cnt) launch_stream<true, true, false>(idx, d_rec, n_tasks, k, flags, d_slots, o64, d_cnt, s);
+        else launch_stream<false, true, false>(idx, d_rec, n_tasks, k, flags, d_slots, o64, d_cnt, s);
     } else {
-        if (d_cnt) launch_stream<true, false>(idx, d_rec, n_tasks, k, flags, d_slots, o64, d_cnt, s);
-        else launch_stream<false, false>(idx, d_rec, n_tasks, k, flags, d_slots, o64, d_cnt, s);
+        if (d_cnt) launch_stream<true, false, false>(idx, d_rec, n_tasks, k, flags, d_slots, o64, d_cnt, s);
+        else launch_stream<false, false, false>(idx, d_rec, n_tasks, k, flags, d_slots, o64, d_cnt, s);
     }
     FMSI_HIP_TRY(hipGetLastError());
     if ((rc = prof_end(idx, s, slot))) return rc;

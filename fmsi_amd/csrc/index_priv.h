@@ -79,6 +79,10 @@ int build_prefix_table(fmsi_hip_index* idx, int t);
 void launch_pair_query(fmsi_hip_index* idx, const uint64_t* d_kmers, uint64_t n, int k, uint32_t flags, bool use_table, uint8_t* o8,
                        long long* o64, unsigned long long* d_counters, hipStream_t s);
 
+// k > 32: windows searched straight off the packed sequence (fmsi_longk.hip)
+void launch_longk_query(fmsi_hip_index* idx, const uint64_t* d_seq, const uint64_t* d_window_start, uint64_t n, int k, uint32_t flags,
+                        uint8_t* o8, long long* o64, unsigned long long* d_counters, hipStream_t s);
+
 // grow-only device staging buffer
 inline int ensure_cap(void** p, size_t* cap, size_t need) {
     if (need <= *cap) return 0;

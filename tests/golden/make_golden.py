@@ -147,9 +147,6 @@ def main():
         dst.unlink()
         for part in sorted(idx.glob(name + ".fmsi.*")):
             md5[part.name] = hashlib.md5(part.read_bytes()).hexdigest()
-            if name != "repeats_k40" and part.suffix not in (".klcp", ".misc"):   # identical to repeats_k40's: keep one copy
-                assert part.read_bytes() == (idx / ("repeats_k40" + part.name[len(name):])).read_bytes()
-                part.unlink()
     assert not (idx / "repeats_k40x.fmsi.klcp").exists()
     assert len({md5[f"repeats_k{k}.fmsi.klcp"] for k in (33, 34, 40, 64)}) == 4
     (idx / "md5.json").write_text(json.dumps(md5, indent=1, sort_keys=True) + "\n")
@@ -163,12 +160,17 @@ def main():
     (HERE / "edge_queries.fa").write_text(edge)
     qfiles = {"integration_a": ["queries", "edge"], "integration_b": ["queries", "edge"]}
     rng = random.Random(42)
-    for name, length, n in (("sars_k13", 62, 300), ("sars_k31", 90, 300), ("mixed_k11", 200, 300)):
+    datasets["repeats_k40"] = (HERE / "repeats.fa", 40)
+    datasets["repeats_k64"] = (HERE / "repeats.fa", 64)
+    for name, length, n in (("sars_k13", 62, 300), ("sars_k31", 90, 300), ("mixed_k11", 200, 300), ("repeats_k40", 150, 200),
+                            ("repeats_k64", 200, 150)):
         src, k = datasets[name]
         text = random_reads(read_ms(src), n, length, rng, sub_rate=0.01 if name == "mixed_k11" else 0.0)
         # a few long reads and some with invalid characters
         up = read_ms(src).upper()
         text += f">long0\n{up[1000:3500]}\n>long1\n{revcomp(up[5000:7700])}\n>longN\n{up[100:400]}N{up[400:450]}NN{up[450:900]}\n"
+        if name.startswith("repeats"):   # reads shorter than k, exactly k, and k +- 1
+            text += "".join(f">short{d}\n{up[700:700 + k + d]}\n" for d in (-1, 0, 1)) + f">tiny\n{up[10:40]}\n"
         (HERE / f"rand_{name}.fa").write_text(text)
         qfiles[name] = ["rand"]
 

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 import oracle_py
-from conftest import DATASETS, GOLDEN, MODES, golden_out, index_prefix, mixed_kmers, query_file, revcomp, synthetic_ms
+from conftest import CLI_DATASETS, DATASETS, GOLDEN, MODES, golden_out, index_prefix, mixed_kmers, query_file, revcomp, synthetic_ms
 
 pytestmark = pytest.mark.gpu
 
@@ -126,14 +126,14 @@ def test_lf_step_counter_equals_oracle(fm, oracle_built):
     assert np.array_equal(out_n, out) and int(cn_n[0]) == want["lf_steps"] and int(cn_n[4]) == 0
 
 
-CASES = [(n, kind, mode) for n, (k, kinds) in DATASETS.items() for kind in kinds for mode in MODES]
+CASES = [(n, kind, mode) for n, (k, kinds) in CLI_DATASETS.items() for kind in kinds for mode in MODES]
 
 
 @pytest.mark.parametrize("name,kind,mode", CASES)
 def test_cli_equals_reference_golden(fm, name, kind, mode):
     """`fmsi query|lookup` on the GPU reproduces the real reference's stdout byte for byte (default = exact
     replay of the strand predictor), incl. the non-max-ones `-O` cases whose output is order dependent."""
-    k = DATASETS[name][0]
+    k = CLI_DATASETS[name][0]
     args = MODES[mode][0]
     rc, out, err = fm.run_cli([*args, "-k", str(k), "-q", str(query_file(name, kind)), index_prefix(name)])
     assert rc == 0, err.decode()

@@ -13,7 +13,7 @@ import numpy as np
 import pytest
 
 import oracle_py
-from conftest import (DATASETS, GOLDEN, INDEX_CASES, INDEX_PARTS, MODES, golden_index_part, golden_out, index_prefix, mixed_kmers,
+from conftest import (CLI_DATASETS, DATASETS, GOLDEN, INDEX_CASES, INDEX_PARTS, MODES, golden_index_part, golden_out, index_prefix, mixed_kmers,
                       query_file, synthetic_ms)
 
 
@@ -116,12 +116,12 @@ def test_survey_md5_of_k31_fixture():
     assert (GOLDEN / "idx" / "integration_a.fmsi.mask").stat().st_size == 91
 
 
-CASES = [(n, kind, mode) for n, (k, kinds) in DATASETS.items() for kind in kinds for mode in MODES]
+CASES = [(n, kind, mode) for n, (k, kinds) in CLI_DATASETS.items() for kind in kinds for mode in MODES]
 
 
 @pytest.mark.parametrize("name,kind,mode", CASES)
 def test_cli_output_equals_reference(oracle_built, name, kind, mode):
-    k, _ = DATASETS[name]
+    k, _ = CLI_DATASETS[name]
     args, _, _, _ = MODES[mode]
     rc, out, err = oracle_py.run_cli(oracle_py.ORACLE_CLI, [*args, "-k", str(k), "-q", str(query_file(name, kind)), index_prefix(name)])
     assert rc == 0, err
