@@ -114,6 +114,7 @@ def lib() -> C.CDLL:
     L.fmsi_hip_query_kmers.argtypes = [vp, vp, u64, i32, u32, vp, vp, vp]
     L.fmsi_hip_query_windows.argtypes = [vp, vp, u64, vp, u64, i32, u32, vp, vp, vp]
     L.fmsi_hip_query_stream.argtypes = [vp, vp, u64, vp, vp, u64, u64, i32, u32, vp, vp, vp]
+    L.fmsi_hip_query_runs.argtypes = [vp, vp, u64, vp, vp, u64, u64, i32, u32, vp, vp, vp]
     L.fmsi_hip_sync.argtypes = [vp, vp]
     L.fmsi_hip_profile_enable.argtypes = [vp, i32]
     L.fmsi_hip_profile_read.argtypes = [vp, C.POINTER(u64), C.POINTER(C.c_double), i32]
@@ -339,8 +340,13 @@ class DeviceIndex:
         self.sync()
         return (out, cn) if counters else out
 
+    def query_runs(self, packed: np.ndarray, seq_bases: int, run_start, run_windows, k: int, flags: int = MODE_OR,
+                   counters: bool = False):
+        """Non-streaming queries over runs of consecutive windows (window starts expanded on the device)."""
+        return self.query_stream(packed, seq_bases, run_start, run_windows, k, flags, counters, _fn="fmsi_hip_query_runs")
+
     def query_stream(self, packed: np.ndarray, seq_bases: int, run_start, run_windows, k: int, flags: int = MODE_OR,
-                     counters: bool = False):
+                     counters: bool = False, _fn: str = "fmsi_hip_query_stream"):
         """kLCP streaming queries (`-S`): runs of consecutive windows; results in run order."""
         packed = np.ascontiguousarray(packed, dtype=np.uint64)
         run_start = np.ascontiguousarray(run_start, dtype=np.uint64)
@@ -348,8 +354,8 @@ class DeviceIndex:
         n = int(run_windows.sum())
         out = self._alloc_out(n, flags)
         cn = np.zeros(N_COUNTERS, dtype=np.uint64) if counters else None
-        _check(lib().fmsi_hip_query_stream(self._h, packed.ctypes.data, seq_bases, run_start.ctypes.data, run_windows.ctypes.data,
-                                           run_start.size, n, k, flags, out.ctypes.data, cn.ctypes.data if counters else None, None))
+        _check(getattr(lib(), _fn)(self._h, packed.ctypes.data, seq_bases, run_start.ctypes.data, run_windows.ctypes.data,
+                                   run_start.size, n, k, flags, out.ctypes.data, cn.ctypes.data if counters else None, None))
         self.sync()
         return (out, cn) if counters else out
 

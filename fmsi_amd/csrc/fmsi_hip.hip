@@ -330,6 +330,25 @@ __global__ __launch_bounds__(256) void extract_kmers_kernel(const uint64_t* __re
         kmers[q] = window_kmer(seq, window_start ? window_start[q] : q, k);
 }
 
+// runs of consecutive windows -> per-window packed k-mers (KMERS) or window starts: window q belongs to the run r with
+// run_off[r] <= q < run_off[r + 1] (binary search; neighbouring lanes walk the same path, so the probes are cache hits)
+template <bool KMERS>
+__global__ __launch_bounds__(256) void expand_runs_kernel(const uint64_t* __restrict__ seq, const uint64_t* __restrict__ run_start,
+                                                          const uint64_t* __restrict__ run_off, uint64_t n_runs, uint64_t n_windows,
+                                                          int k, uint64_t* __restrict__ dst) {
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
+    for (uint64_t q = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; q < n_windows; q += stride) {
+        uint64_t lo = 0, hi = n_runs;   // invariant: run_off[lo] <= q < run_off[hi]
+        while (hi - lo > 1) {
+            const uint64_t mid = (lo + hi) >> 1;
+            if (run_off[mid] <= q) lo = mid;
+            else hi = mid;
+        }
+        const uint64_t start = run_start[lo] + (q - run_off[lo]);
+        dst[q] = KMERS ? window_kmer(seq, start, k) : start;
+    }
+}
+
 // one level of the prefix table: entry idx of level L = LF step with base (idx & 3) on entry idx >> 2 of level L-1
 __global__ __launch_bounds__(256) void ptable_level_kernel(DevIndex ix, const uint2* __restrict__ prev, uint2* __restrict__ cur,
                                                            uint64_t count) {
@@ -696,6 +715,83 @@ int fmsi_hip_query_kmers(fmsi_hip_index* idx, const uint64_t* kmers, uint64_t n_
     int rc = check_query_args(idx, kmers, out, k, 32);
     if (rc) return rc;
     return run_query(idx, 0, kmers, n_kmers * 8, nullptr, n_kmers, k, flags, out, counters, stream);
+}
+
+int fmsi_hip_query_runs(fmsi_hip_index* idx, const uint64_t* packed_seq, uint64_t seq_bases, const uint64_t* run_start,
+                        const uint32_t* run_windows, uint64_t n_runs, uint64_t n_windows, int k, uint32_t flags, void* out,
+                        uint64_t* counters, void* stream) {
+    if (n_windows == 0 || n_runs == 0) return 0;
+    int rc = check_query_args(idx, packed_seq, out, k, 1 << 20);
+    if (rc) return rc;
+    if (!run_start || !run_windows) {
+        set_last_error("null argument");
+        return FMSI_HIP_EINVAL;
+    }
+    // [0, n_runs): run starts, [n_runs, 2 n_runs + 1): exclusive prefix sums of the run lengths
+    std::vector<uint64_t> meta(2 * n_runs + 1);
+    uint64_t total = 0;
+    for (uint64_t r = 0; r < n_runs; ++r) {
+        if (run_windows[r] == 0 || run_start[r] + run_windows[r] + static_cast<uint64_t>(k) - 1 > seq_bases) {
+            set_last_error("an empty run, or a run of windows that extends past the end of the sequence");
+            return FMSI_HIP_EINVAL;
+        }
+        meta[r] = run_start[r];
+        meta[n_runs + r] = total;
+        total += run_windows[r];
+    }
+    meta[2 * n_runs] = total;
+    if (total != n_windows) {
+        set_last_error("n_windows does not equal the sum of run_windows");
+        return FMSI_HIP_EINVAL;
+    }
+    FMSI_HIP_TRY(hipSetDevice(idx->device));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const size_t out_bytes = n_windows * out_elem_bytes(flags);
+    const size_t seq_bytes = (seq_bases / 32 + 2) * 8;
+    const bool dev_ptrs = flags & FMSI_HIP_DEVICE_PTRS;
+    const uint64_t* d_seq = packed_seq;
+    void* d_out = out;
+    unsigned long long* d_cnt = reinterpret_cast<unsigned long long*>(counters);
+    if (!dev_ptrs) {
+        if ((rc = ensure_cap(&idx->d_in, &idx->d_in_cap, seq_bytes))) return rc;
+        if ((rc = ensure_cap(&idx->d_out, &idx->d_out_cap, out_bytes))) return rc;
+        FMSI_HIP_TRY(hipMemcpyAsync(idx->d_in, packed_seq, seq_bytes, hipMemcpyHostToDevice, s));
+        d_seq = static_cast<const uint64_t*>(idx->d_in);
+        d_out = idx->d_out;
+        if (counters) {
+            FMSI_HIP_TRY(hipMemcpyAsync(idx->d_counters, counters, FMSI_HIP_N_COUNTERS * 8, hipMemcpyHostToDevice, s));
+            d_cnt = idx->d_counters;
+        }
+    }
+    if ((rc = ensure_cap(&idx->d_tasks, &idx->d_tasks_cap, meta.size() * 8))) return rc;
+    FMSI_HIP_TRY(hipMemcpyAsync(idx->d_tasks, meta.data(), meta.size() * 8, hipMemcpyHostToDevice, s));
+    FMSI_HIP_TRY(hipStreamSynchronize(s));   // `meta` is a local vector
+    const uint64_t* d_rs = static_cast<const uint64_t*>(idx->d_tasks);
+    const uint64_t* d_ro = d_rs + n_runs;
+    const uint32_t blocks = static_cast<uint32_t>(std::min<uint64_t>((n_windows + 255) / 256, 256 * 16));
+    if (k > 32) {
+        if ((rc = ensure_cap(&idx->d_aux, &idx->d_aux_cap, n_windows * 8))) return rc;
+        hipLaunchKernelGGL((expand_runs_kernel<false>), dim3(blocks), dim3(256), 0, s, d_seq, d_rs, d_ro, n_runs, n_windows, k,
+                           static_cast<uint64_t*>(idx->d_aux));
+        FMSI_HIP_TRY(hipGetLastError());
+        size_t slot;
+        if ((rc = prof_begin(idx, s, &slot))) return rc;
+        launch_longk_query(idx, d_seq, static_cast<const uint64_t*>(idx->d_aux), n_windows, k, flags, static_cast<uint8_t*>(d_out),
+                           static_cast<long long*>(d_out), d_cnt, s);
+        FMSI_HIP_TRY(hipGetLastError());
+        if ((rc = prof_end(idx, s, slot))) return rc;
+    } else {
+        if ((rc = ensure_cap(&idx->d_kmers, &idx->d_kmers_cap, n_windows * 8))) return rc;
+        hipLaunchKernelGGL((expand_runs_kernel<true>), dim3(blocks), dim3(256), 0, s, d_seq, d_rs, d_ro, n_runs, n_windows, k,
+                           static_cast<uint64_t*>(idx->d_kmers));
+        FMSI_HIP_TRY(hipGetLastError());
+        if ((rc = launch_query(idx, static_cast<const uint64_t*>(idx->d_kmers), n_windows, k, flags, d_out, d_cnt, s))) return rc;
+    }
+    if (!dev_ptrs) {
+        if (out_bytes) FMSI_HIP_TRY(hipMemcpyAsync(out, idx->d_out, out_bytes, hipMemcpyDeviceToHost, s));
+        if (counters) FMSI_HIP_TRY(hipMemcpyAsync(counters, idx->d_counters, FMSI_HIP_N_COUNTERS * 8, hipMemcpyDeviceToHost, s));
+    }
+    return 0;
 }
 
 int fmsi_hip_query_windows(fmsi_hip_index* idx, const uint64_t* packed_seq, uint64_t seq_bases, const uint64_t* window_start,

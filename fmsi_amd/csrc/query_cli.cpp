@@ -5,16 +5,31 @@
 // stdout grammar -- and hands the k-mer windows to libfmsi_hip through the C-ABI (include/fmsi_hip.h).
 // Output is byte-identical to the reference: per-window results of both strands come back from the
 // device and the sequential strand predictor (src/fms_index.h:18-49) is replayed here.
+//
+// Host pipeline: reader thread (FASTA/FASTQ, gzip) -> batches of raw records -> main thread:
+// planning + 2-bit packing on a team of threads, one device call per batch, predictor replay (sequential by
+// nature) -> writer thread: formatting on a team of threads + one fwrite per batch.  Batches flow through bounded
+// queues, so parsing, device work and printing of consecutive batches overlap and the output order is the input order.
 #include <getopt.h>
 
+#include <sched.h>
+
 #include <algorithm>
+#include <charconv>
 #include <chrono>
 #include <cmath>
+#include <condition_variable>
 #include <cstdio>
 #include <cstring>
+#include <deque>
+#include <exception>
+#include <fstream>
 #include <iostream>
+#include <memory>
+#include <mutex>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/fmsi_hip.h"
@@ -54,7 +69,8 @@ struct Options {
     bool fast = false;        // --fast: skip the second strand when the first decides (exact for OR; for -O under its precondition)
     bool stats = false;       // --stats: timings on stderr
     int device = 0;
-    uint64_t batch_windows = 1ull << 24;
+    uint64_t batch_windows = 1ull << 26;   // bases of query sequence per batch (>= windows)
+    unsigned threads = 0;                  // 0 = all CPUs this process may use, at most 16
 };
 
 int usage_query(bool lookup) {
@@ -74,128 +90,286 @@ int usage_query(bool lookup) {
     std::cerr << "  --device INT - HIP device to use [default: 0]" << std::endl;
     std::cerr << "  --fast       - search the reverse strand only when the forward strand does not decide;" << std::endl;
     std::cerr << "                 identical output for the default mode, and for -O on max-ones masks" << std::endl;
-    std::cerr << "  --batch INT  - k-mer windows per device batch [default: 16777216]" << std::endl;
+    std::cerr << "  --batch INT  - bases of query sequence per device batch [default: 67108864]" << std::endl;
+    std::cerr << "  --threads INT - host threads for packing and formatting [default: available CPUs, at most 16]" << std::endl;
     std::cerr << "  --stats      - print timings to stderr" << std::endl;
     std::cerr << std::endl;
     return 1;
 }
 
+// ---- threading helpers ---------------------------------------------------------------------------
+unsigned available_cpus() {
+    unsigned n = std::max(1u, std::thread::hardware_concurrency());
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof set, &set) == 0) n = std::max(1, CPU_COUNT(&set));
+    std::ifstream f("/sys/fs/cgroup/cpu.max");   // "<quota> <period>" or "max <period>"
+    std::string quota;
+    double period = 0;
+    if (f >> quota >> period && quota != "max" && period > 0) {
+        const double q = std::atof(quota.c_str()) / period;
+        if (q >= 1) n = std::min<unsigned>(n, static_cast<unsigned>(q + 0.999));
+    }
+    return std::max(1u, n);
+}
+
+template <class F>
+void parallel_for(unsigned team, F&& fn) {   // fn(t) for t in [0, team); t = 0 runs on the caller
+    if (team <= 1) {
+        fn(0u);
+        return;
+    }
+    std::vector<std::thread> th;
+    std::vector<std::exception_ptr> err(team);
+    th.reserve(team - 1);
+    for (unsigned t = 1; t < team; ++t)
+        th.emplace_back([&, t] {
+            try { fn(t); } catch (...) { err[t] = std::current_exception(); }
+        });
+    try { fn(0u); } catch (...) { err[0] = std::current_exception(); }
+    for (auto& x : th) x.join();
+    for (auto& e : err)
+        if (e) std::rethrow_exception(e);
+}
+
+template <class T>
+class BoundedQueue {
+public:
+    explicit BoundedQueue(size_t cap) : cap_(cap) {}
+    bool push(T&& v) {   // false: the consumer has gone away
+        std::unique_lock<std::mutex> lk(m_);
+        not_full_.wait(lk, [&] { return q_.size() < cap_ || closed_; });
+        if (closed_) return false;
+        q_.push_back(std::move(v));
+        not_empty_.notify_one();
+        return true;
+    }
+    bool pop(T& v) {     // false: closed and drained
+        std::unique_lock<std::mutex> lk(m_);
+        not_empty_.wait(lk, [&] { return !q_.empty() || closed_; });
+        if (q_.empty()) return false;
+        v = std::move(q_.front());
+        q_.pop_front();
+        not_full_.notify_one();
+        return true;
+    }
+    void close() {       // producer: no more items; consumer: stop the producer
+        std::lock_guard<std::mutex> lk(m_);
+        closed_ = true;
+        not_full_.notify_all();
+        not_empty_.notify_all();
+    }
+    void abort() {
+        std::lock_guard<std::mutex> lk(m_);
+        closed_ = true;
+        q_.clear();
+        not_full_.notify_all();
+        not_empty_.notify_all();
+    }
+
+private:
+    std::mutex m_;
+    std::condition_variable not_full_, not_empty_;
+    std::deque<T> q_;
+    size_t cap_;
+    bool closed_ = false;
+};
+
+// ---- batches -----------------------------------------------------------------------------------
 // What one record prints, in order: runs of windows (results come from the device) and fills of
 // '0' / '-1' after invalid characters (src/main.cpp:359-370).
 struct Op {
-    bool is_run;
     uint64_t count;
+    bool is_run;
 };
-struct RecordPlan {
-    std::string name;
-    int64_t max_chunk;       // k + max(10, min(400, 2*sqrt(L))), src/main.cpp:330-331
-    std::vector<Op> ops;
-    uint64_t first_result;   // offset of the record's first window in the batch results
+struct RecRef {
+    uint64_t name_off, seq_off, seq_len;
+    uint32_t name_len;
 };
-
-struct Batch {
-    std::vector<RecordPlan> records;
-    std::vector<uint64_t> packed;        // 2-bit bases of all runs, concatenated
-    uint64_t bases = 0;
-    std::vector<uint64_t> window_start;  // per window: first base in `packed`
-    std::vector<uint64_t> run_start;     // per run of consecutive windows: first base / number of windows (-S kernel)
+struct RawBatch {
+    std::string text;            // names and sequences, as read
+    std::vector<RecRef> recs;
+    uint64_t seq_bytes = 0;
+};
+struct Prepared {
+    RawBatch raw;
+    std::vector<Op> ops;                  // all records' ops, record r owns [rec_ops[r], rec_ops[r+1])
+    std::vector<uint64_t> rec_ops;
+    std::vector<uint64_t> rec_first;      // first result (window) index of record r; [recs] = total
+    std::vector<uint64_t> rec_out;        // presence modes: byte offset of record r's line in the batch output; [recs] = total
+    std::vector<uint64_t> run_start;      // device runs: first base (a multiple of 32: runs are word aligned in `packed`)
     std::vector<uint32_t> run_windows;
-    void clear() {
-        records.clear();
-        packed.assign(2, 0);
-        bases = 0;
-        window_start.clear();
-        run_start.clear();
-        run_windows.clear();
-    }
+    std::vector<uint64_t> packed;
+    uint64_t bases = 0, windows = 0;
+    std::vector<uint8_t> bytes;           // device results, then (after the replay) the final 0/1 per window
+    std::vector<int64_t> orders;          // lookup: device results, then the final order per window
 };
 
-inline int code_of(unsigned char ch) {   // nucleotideToInt, src/kmers.h:3-20
-    switch (ch) {
-    case 'A': case 'a': return 0;
-    case 'C': case 'c': return 1;
-    case 'G': case 'g': return 2;
-    case 'T': case 't': return 3;
-    default: return 4;
+struct CodeTable {   // nucleotideToInt, src/kmers.h:3-20 (4 = invalid)
+    uint8_t t[256];
+    CodeTable() {
+        std::memset(t, 4, sizeof t);
+        t['A'] = t['a'] = 0;
+        t['C'] = t['c'] = 1;
+        t['G'] = t['g'] = 2;
+        t['T'] = t['t'] = 3;
+    }
+};
+const CodeTable kCode;
+
+// 2-bit packing of `len` VALID bases into zeroed words: base i in bits [2(i%32), +1] of dst[i/32].
+// For valid characters the code is ((c >> 1) & 3) ^ ((c >> 2) & 1): A/a 0, C/c 1, G/g 2, T/t 3.
+__attribute__((target("bmi2"))) void pack_run(const char* s, uint64_t len, uint64_t* dst) {
+    uint64_t i = 0;
+    for (; i + 32 <= len; i += 32) {
+        uint64_t w = 0;
+        for (int q = 0; q < 4; ++q) {
+            uint64_t v;
+            std::memcpy(&v, s + i + 8 * q, 8);
+            const uint64_t x = ((v >> 1) & 0x0303030303030303ull) ^ ((v >> 2) & 0x0101010101010101ull);
+            w |= __builtin_ia32_pext_di(x, 0x0303030303030303ull) << (16 * q);
+        }
+        dst[i >> 5] = w;
+    }
+    if (i < len) {
+        uint64_t w = 0;
+        for (uint64_t j = i; j < len; ++j) w |= static_cast<uint64_t>(kCode.t[static_cast<unsigned char>(s[j])] & 3u) << (2 * (j - i));
+        dst[i >> 5] = w;
     }
 }
 
-void append_bases(Batch& b, const char* s, uint64_t len) {
-    const uint64_t need_words = (b.bases + len) / 32 + 2;
-    if (b.packed.size() < need_words) b.packed.resize(std::max<uint64_t>(need_words, b.packed.size() * 2), 0);
-    for (uint64_t i = 0; i < len; ++i) {
-        const uint64_t p = b.bases + i;
-        b.packed[p >> 5] |= static_cast<uint64_t>(code_of(static_cast<unsigned char>(s[i]))) << (2 * (p & 31));
-    }
-    b.bases += len;
-}
+struct TeamPlan {   // what one thread of the team found in its records
+    std::vector<Op> ops;
+    std::vector<uint32_t> rec_nops;
+    std::vector<uint64_t> rec_windows, rec_symbols;
+    std::vector<std::pair<uint64_t, uint64_t>> runs;   // (offset in raw.text, length in bases >= k)
+    uint64_t windows = 0, words = 0, dev_runs = 0;
+};
+
+constexpr uint64_t kMaxRunWindows = 0x40000000ull;   // run lengths are 32-bit in the C-ABI
 
 // Walk of one record exactly as src/main.cpp:337-371 does it, recording instead of querying.
-void plan_record(Batch& b, const std::string& name, const std::string& seq, int k) {
-    RecordPlan rp;
-    rp.name = name;
-    int64_t sequence_length = static_cast<int64_t>(seq.size());
-    rp.max_chunk = k + std::max<int64_t>(10, std::min<int64_t>(400, 2 * static_cast<int64_t>(std::sqrt(sequence_length))));
-    rp.first_result = b.window_start.size();
-    const char* sequence = seq.data();
+inline void plan_record(const char* sequence, int64_t sequence_length, uint64_t text_off, int k, TeamPlan& tp) {
+    uint32_t nops = 0;
+    uint64_t windows_total = 0, symbols = 0;
     while (sequence_length > 0) {
         int64_t current_length = 0;   // next_invalid_character_or_end, src/parser.h:57-64
-        while (current_length < sequence_length && code_of(static_cast<unsigned char>(sequence[current_length])) != 4) ++current_length;
+        while (current_length < sequence_length && kCode.t[static_cast<unsigned char>(sequence[current_length])] != 4) ++current_length;
         if (current_length >= k) {
             const uint64_t windows = static_cast<uint64_t>(current_length - k + 1);
-            const uint64_t base0 = b.bases;
-            append_bases(b, sequence, static_cast<uint64_t>(current_length));
-            for (uint64_t w = 0; w < windows; ++w) b.window_start.push_back(base0 + w);
-            for (uint64_t w = 0; w < windows; w += 0x40000000ull) {   // run lengths are 32-bit in the C-ABI
-                b.run_start.push_back(base0 + w);
-                b.run_windows.push_back(static_cast<uint32_t>(std::min<uint64_t>(windows - w, 0x40000000ull)));
-            }
-            rp.ops.push_back({true, windows});
+            tp.runs.emplace_back(text_off, static_cast<uint64_t>(current_length));
+            tp.words += (static_cast<uint64_t>(current_length) + 31) / 32;
+            tp.dev_runs += (windows + kMaxRunWindows - 1) / kMaxRunWindows;
+            tp.ops.push_back({windows, true});
+            ++nops;
+            windows_total += windows;
+            symbols += windows;
             // the reference consumes chunk_length - k + 1 characters per chunk: k - 1 remain
             sequence += windows;
+            text_off += windows;
             sequence_length -= static_cast<int64_t>(windows);
             current_length -= static_cast<int64_t>(windows);
         }
         sequence_length -= current_length + 1;
         sequence += current_length + 1;
-        if (sequence_length >= 0) rp.ops.push_back({false, static_cast<uint64_t>(std::min<int64_t>(k, current_length + 1))});
+        text_off += static_cast<uint64_t>(current_length + 1);
+        if (sequence_length >= 0) {
+            const uint64_t fill = static_cast<uint64_t>(std::min<int64_t>(k, current_length + 1));
+            tp.ops.push_back({fill, false});
+            ++nops;
+            symbols += fill;
+        }
     }
-    b.records.push_back(std::move(rp));
+    tp.rec_nops.push_back(nops);
+    tp.rec_windows.push_back(windows_total);
+    tp.rec_symbols.push_back(symbols);
+    tp.windows += windows_total;
 }
 
-struct Emitter {
-    std::string out;
-    bool orders;
-    bool first_in_record = true;
-    void begin_record(const std::string& name) {
-        out += name;
-        out += '\t';
-        first_in_record = true;
+// records -> ops, device runs and the packed sequence, on `team` threads
+void prepare_batch(Prepared& P, int k, unsigned team) {
+    const size_t nrec = P.raw.recs.size();
+    team = static_cast<unsigned>(std::max<size_t>(1, std::min<size_t>(team, nrec / 64 + 1)));
+    // contiguous record ranges of about equal sequence length
+    std::vector<size_t> cut(team + 1, nrec);
+    cut[0] = 0;
+    {
+        const uint64_t per = P.raw.seq_bytes / team + 1;
+        uint64_t acc = 0;
+        unsigned t = 1;
+        for (size_t r = 0; r < nrec && t < team; ++r) {
+            acc += P.raw.recs[r].seq_len;
+            if (acc >= per * t) cut[t++] = r + 1;
+        }
     }
-    void bit(bool one) { out += one ? '1' : '0'; }
-    void order(int64_t v) {
-        if (!first_in_record) out += ',';
-        first_in_record = false;
-        out += std::to_string(v);
+    std::vector<TeamPlan> tp(team);
+    const char* text = P.raw.text.data();
+    parallel_for(team, [&](unsigned t) {
+        for (size_t r = cut[t]; r < cut[t + 1]; ++r) {
+            const RecRef& rr = P.raw.recs[r];
+            plan_record(text + rr.seq_off, static_cast<int64_t>(rr.seq_len), rr.seq_off, k, tp[t]);
+        }
+    });
+    // offsets of every thread's share
+    std::vector<uint64_t> ops_at(team + 1, 0), win_at(team + 1, 0), word_at(team + 1, 0), run_at(team + 1, 0);
+    for (unsigned t = 0; t < team; ++t) {
+        ops_at[t + 1] = ops_at[t] + tp[t].ops.size();
+        win_at[t + 1] = win_at[t] + tp[t].windows;
+        word_at[t + 1] = word_at[t] + tp[t].words;
+        run_at[t + 1] = run_at[t] + tp[t].dev_runs;
     }
-    void end_record() { out += '\n'; }
-    void flush() {
-        if (!out.empty()) std::fwrite(out.data(), 1, out.size(), stdout);
-        out.clear();
+    P.ops.resize(ops_at[team]);
+    P.rec_ops.resize(nrec + 1);
+    P.rec_first.resize(nrec + 1);
+    P.rec_out.resize(nrec + 1);
+    P.run_start.resize(run_at[team]);
+    P.run_windows.resize(run_at[team]);
+    P.packed.assign(word_at[team] + 2, 0);
+    P.windows = win_at[team];
+    P.bases = word_at[team] * 32;
+    // byte offsets of the records' output lines (presence modes): name + '\t' + symbols + '\n'
+    std::vector<uint64_t> out_at(team + 1, 0);
+    for (unsigned t = 0; t < team; ++t) {
+        uint64_t b = 0;
+        for (size_t r = cut[t]; r < cut[t + 1]; ++r) b += P.raw.recs[r].name_len + 2 + tp[t].rec_symbols[r - cut[t]];
+        out_at[t + 1] = out_at[t] + b;
     }
-};
+    parallel_for(team, [&](unsigned t) {
+        std::copy(tp[t].ops.begin(), tp[t].ops.end(), P.ops.begin() + static_cast<std::ptrdiff_t>(ops_at[t]));
+        uint64_t o = ops_at[t], w = win_at[t], b = out_at[t];
+        for (size_t r = cut[t]; r < cut[t + 1]; ++r) {
+            P.rec_ops[r] = o;
+            P.rec_first[r] = w;
+            P.rec_out[r] = b;
+            o += tp[t].rec_nops[r - cut[t]];
+            w += tp[t].rec_windows[r - cut[t]];
+            b += P.raw.recs[r].name_len + 2 + tp[t].rec_symbols[r - cut[t]];
+        }
+        uint64_t word = word_at[t], run = run_at[t];
+        for (const auto& [off, len] : tp[t].runs) {
+            pack_run(text + off, len, P.packed.data() + word);
+            uint64_t windows = len - static_cast<uint64_t>(k) + 1, base = word * 32;
+            while (windows) {
+                const uint64_t take = std::min(windows, kMaxRunWindows);
+                P.run_start[run] = base;
+                P.run_windows[run] = static_cast<uint32_t>(take);
+                ++run;
+                base += take;
+                windows -= take;
+            }
+            word += (len + 31) / 32;
+        }
+    });
+    P.rec_ops[nrec] = ops_at[team];
+    P.rec_first[nrec] = win_at[team];
+    P.rec_out[nrec] = out_at[team];
+}
 
-// Per-window device results of one batch.
-struct Results {
-    std::vector<uint8_t> bytes;      // presence modes: fast -> 0/1 ; strict -> (fwd+1)|((rc+1)<<2)
-    std::vector<int64_t> orders;     // lookup: fast -> order ; strict -> {fwd, rc}
-    bool strict = true;
-    int fwd(uint64_t w) const { return static_cast<int>(bytes[w] & 3) - 1; }
-    int rc(uint64_t w) const { return static_cast<int>((bytes[w] >> 2) & 3) - 1; }
-};
+// ---- predictor replay: device results of both strands -> what the reference prints ------------------
+inline int fwd_of(uint8_t b) { return static_cast<int>(b & 3) - 1; }
+inline int rc_of(uint8_t b) { return static_cast<int>((b >> 2) & 3) - 1; }
 
 // query_kmers_single<mode> for one window given both strands' results (src/fms_index.h:263-331).
-inline void replay_single(StrandPredictor& p, Mode mode, bool orders, int64_t f, int64_t r, int64_t* got_out) {
+inline int64_t replay_single(StrandPredictor& p, Mode mode, bool orders, int64_t f, int64_t r) {
     const bool should_swap = p.predict_swap();
     const int64_t first = should_swap ? r : f, second = should_swap ? f : r;
     int fpr = 0, bpr = 0;
@@ -211,31 +385,32 @@ inline void replay_single(StrandPredictor& p, Mode mode, bool orders, int64_t f,
     }
     if (should_swap) std::swap(fpr, bpr);
     p.log_result(fpr, bpr);
-    *got_out = got;
+    return got;
 }
 
-// query_kmers_streaming<> for one chunk of `n` windows starting at result index w0 (src/fms_index.h:181-254).
-void replay_streaming_chunk(StrandPredictor& p, Mode mode, bool orders, const Results& R, uint64_t w0, uint64_t n, Emitter& em) {
+// query_kmers_streaming<> for one chunk of `n` windows starting at result index w0 (src/fms_index.h:181-254);
+// the final values replace the device results in place (element w0 + i <- window i of the chunk).
+void replay_streaming_chunk(StrandPredictor& p, Mode mode, bool orders, Prepared& P, uint64_t w0, uint64_t n, std::vector<int64_t>& result) {
     const bool should_swap = p.predict_swap();
     const bool maximized_ones = mode == Mode::All;
     int fpr = 0, bpr = 0;
-    std::vector<int64_t> result(n);
+    result.resize(n);
     for (uint64_t i = 0; i < n; ++i) {
         // result[] is indexed in the orientation of the (possibly swapped) first strand; window w of the
         // forward string is window n-1-w of the reverse-complement string
         const uint64_t w = should_swap ? (n - 1 - i) : i;
-        const int64_t first = orders ? (should_swap ? R.orders[2 * (w0 + w) + 1] : R.orders[2 * (w0 + w)])
-                                     : (should_swap ? R.rc(w0 + w) : R.fwd(w0 + w));
+        const int64_t first = orders ? (should_swap ? P.orders[2 * (w0 + w) + 1] : P.orders[2 * (w0 + w)])
+                                     : (should_swap ? rc_of(P.bytes[w0 + w]) : fwd_of(P.bytes[w0 + w]));
         result[i] = first;
         if (orders) fpr += first >= 0 ? 1 : -1;
         else fpr += static_cast<int>(first);
     }
     for (uint64_t i = 0; i < n; ++i) {
         if ((result[i] >= 0 && orders) || result[i] == 1 || (result[i] == 0 && maximized_ones)) continue;
-        // second pass walks the other strand's string: its window i_back pairs with result[i]
+        // second pass walks the other strand's string: its window pairs with result[i]
         const uint64_t w = should_swap ? (n - 1 - i) : i;
-        const int64_t second = orders ? (should_swap ? R.orders[2 * (w0 + w)] : R.orders[2 * (w0 + w) + 1])
-                                      : (should_swap ? R.fwd(w0 + w) : R.rc(w0 + w));
+        const int64_t second = orders ? (should_swap ? P.orders[2 * (w0 + w)] : P.orders[2 * (w0 + w) + 1])
+                                      : (should_swap ? fwd_of(P.bytes[w0 + w]) : rc_of(P.bytes[w0 + w]));
         if (orders) bpr += second >= 0 ? 1 : -1;
         else bpr += static_cast<int>(second);
         result[i] = std::max(result[i], second);
@@ -245,10 +420,117 @@ void replay_streaming_chunk(StrandPredictor& p, Mode mode, bool orders, const Re
         std::swap(fpr, bpr);
     }
     p.log_result(fpr, bpr);
+    // window w0 + i: final value.  In-place is safe for orders: element w0 + i <= 2 (w0 + i), and the chunk's
+    // strict pairs [2 w0, 2 (w0 + n)) have all been read above.
     for (uint64_t i = 0; i < n; ++i) {
-        if (orders) em.order(result[i]);
-        else em.bit(result[i] == 1);
+        if (orders) P.orders[w0 + i] = result[i];
+        else P.bytes[w0 + i] = static_cast<uint8_t>(result[i] == 1);
     }
+}
+
+// strict results (both strands per window) -> final per-window values, in the order the reference visits them
+void replay_batch(Prepared& P, StrandPredictor& predictor, Mode mode, bool orders, bool streaming, int k) {
+    if (!streaming) {
+        // one predictor step per window, in output order == result order; fills do not touch the predictor
+        for (uint64_t w = 0; w < P.windows; ++w) {
+            const int64_t f = orders ? P.orders[2 * w] : fwd_of(P.bytes[w]);
+            const int64_t r = orders ? P.orders[2 * w + 1] : rc_of(P.bytes[w]);
+            const int64_t got = replay_single(predictor, mode, orders, f, r);
+            if (orders) P.orders[w] = got;
+            else P.bytes[w] = static_cast<uint8_t>(got == 1);
+        }
+        return;
+    }
+    std::vector<int64_t> scratch;
+    for (size_t r = 0; r + 1 < P.rec_ops.size(); ++r) {
+        const uint64_t L = P.raw.recs[r].seq_len;
+        const int64_t max_chunk = k + std::max<int64_t>(10, std::min<int64_t>(400, 2 * static_cast<int64_t>(std::sqrt(static_cast<int64_t>(L)))));   // src/main.cpp:330-331
+        uint64_t w = P.rec_first[r];
+        for (uint64_t o = P.rec_ops[r]; o < P.rec_ops[r + 1]; ++o) {
+            if (!P.ops[o].is_run) continue;
+            // chunks of the run as src/main.cpp:340-354 cuts them
+            int64_t current_length = static_cast<int64_t>(P.ops[o].count) + k - 1;
+            while (current_length >= k) {
+                const int64_t chunk_length = std::min<int64_t>(current_length, max_chunk);
+                const uint64_t n = static_cast<uint64_t>(chunk_length - k + 1);
+                replay_streaming_chunk(predictor, mode, orders, P, w, n, scratch);
+                w += n;
+                current_length -= static_cast<int64_t>(n);
+            }
+        }
+    }
+}
+
+// ---- formatting ----------------------------------------------------------------------------------
+// presence modes: every line has a known length, the team writes straight into one buffer
+void format_bits(const Prepared& P, unsigned team, std::vector<char>& out) {
+    const size_t nrec = P.raw.recs.size();
+    out.resize(P.rec_out[nrec]);
+    team = static_cast<unsigned>(std::max<size_t>(1, std::min<size_t>(team, nrec / 64 + 1)));
+    const char* text = P.raw.text.data();
+    parallel_for(team, [&](unsigned t) {
+        // ranges of about equal output size
+        const uint64_t lo = P.rec_out[nrec] / team * t, hi = t + 1 == team ? P.rec_out[nrec] : P.rec_out[nrec] / team * (t + 1);
+        size_t r = static_cast<size_t>(std::lower_bound(P.rec_out.begin(), P.rec_out.begin() + static_cast<std::ptrdiff_t>(nrec), lo) - P.rec_out.begin());
+        for (; r < nrec && P.rec_out[r] < hi; ++r) {
+            char* dst = out.data() + P.rec_out[r];
+            const RecRef& rr = P.raw.recs[r];
+            std::memcpy(dst, text + rr.name_off, rr.name_len);
+            dst += rr.name_len;
+            *dst++ = '\t';
+            uint64_t w = P.rec_first[r];
+            for (uint64_t o = P.rec_ops[r]; o < P.rec_ops[r + 1]; ++o) {
+                const uint64_t c = P.ops[o].count;
+                if (P.ops[o].is_run) {
+                    const uint8_t* src = P.bytes.data() + w;
+                    for (uint64_t i = 0; i < c; ++i) dst[i] = static_cast<char>('0' + (src[i] != 0));
+                    w += c;
+                } else {
+                    std::memset(dst, '0', c);
+                }
+                dst += c;
+            }
+            *dst = '\n';
+        }
+    });
+}
+
+// lookup: comma separated integers (src/main.cpp:341-342,361-365); every thread formats a range of records
+void format_orders(const Prepared& P, unsigned team, std::vector<std::string>& parts) {
+    const size_t nrec = P.raw.recs.size();
+    team = static_cast<unsigned>(std::max<size_t>(1, std::min<size_t>(team, nrec / 64 + 1)));
+    parts.assign(team, std::string());
+    const char* text = P.raw.text.data();
+    const uint64_t total = P.rec_first[nrec] + nrec;   // balance by windows (+1 per record)
+    parallel_for(team, [&](unsigned t) {
+        std::string& s = parts[t];
+        const uint64_t lo = total / team * t, hi = t + 1 == team ? total + 1 : total / team * (t + 1);
+        char num[24];
+        for (size_t r = 0; r < nrec; ++r) {
+            const uint64_t key = P.rec_first[r] + r;
+            if (key < lo) continue;
+            if (key >= hi) break;
+            const RecRef& rr = P.raw.recs[r];
+            s.append(text + rr.name_off, rr.name_len);
+            s += '\t';
+            bool first = true;
+            uint64_t w = P.rec_first[r];
+            for (uint64_t o = P.rec_ops[r]; o < P.rec_ops[r + 1]; ++o) {
+                for (uint64_t i = 0; i < P.ops[o].count; ++i) {
+                    if (!first) s += ',';
+                    first = false;
+                    if (P.ops[o].is_run) {
+                        const auto res = std::to_chars(num, num + sizeof num, P.orders[w + i]);
+                        s.append(num, static_cast<size_t>(res.ptr - num));
+                    } else {
+                        s += "-1";
+                    }
+                }
+                if (P.ops[o].is_run) w += P.ops[o].count;
+            }
+            s += '\n';
+        }
+    });
 }
 
 void check(int rc, const char* what) {
@@ -273,7 +555,8 @@ extern "C" int fmsi_cli_query(int argc, char** argv, int output_orders_i) {
     }
     static const option long_opts[] = {{"device", required_argument, nullptr, 1000}, {"fast", no_argument, nullptr, 1001},
                                        {"batch", required_argument, nullptr, 1002},  {"stats", no_argument, nullptr, 1003},
-                                       {"strict", no_argument, nullptr, 1004},       {nullptr, 0, nullptr, 0}};
+                                       {"strict", no_argument, nullptr, 1004},       {"threads", required_argument, nullptr, 1005},
+                                       {nullptr, 0, nullptr, 0}};
     optind = 1;
     int c;
     while ((c = getopt_long(argc, argv, "f:hq:k:OS", long_opts, nullptr)) >= 0) {
@@ -298,6 +581,7 @@ extern "C" int fmsi_cli_query(int argc, char** argv, int output_orders_i) {
         case 1002: opt.batch_windows = std::max<uint64_t>(1024, strtoull(optarg, nullptr, 10)); break;
         case 1003: opt.stats = true; break;
         case 1004: opt.fast = false; break;
+        case 1005: opt.threads = static_cast<unsigned>(std::max(1, atoi(optarg))); break;
         default: return usage_query(output_orders);
         }
     }
@@ -358,104 +642,138 @@ extern "C" int fmsi_cli_query(int argc, char** argv, int output_orders_i) {
     if (output_orders) flags |= FMSI_HIP_ORDERS;
 
     int exit_code = 0;
-    double gpu_s = 0;
+    double gpu_s = 0, prep_s = 0, replay_s = 0, format_s = 0, write_s = 0, read_s = 0;
     uint64_t total_windows = 0;
+    const unsigned team = opt.threads ? opt.threads : std::min(16u, available_cpus());
+    std::unique_ptr<FastxReader> reader;
     try {
-        FastxReader reader(opt.query_fn);   // throws std::invalid_argument like OpenFile(), src/parser.h:22
-        StrandPredictor predictor;
-        Batch batch;
-        batch.clear();
-        Results R;
-        R.strict = strict;
-        Emitter em;
-        em.orders = output_orders;
-
-        auto run_batch = [&]() {
-            const uint64_t nw = batch.window_start.size();
-            const size_t elem = output_orders ? (strict ? 2 : 1) : 1;
-            if (output_orders) R.orders.resize(nw * elem);
-            else R.bytes.resize(nw);
-            auto t0 = clock::now();
-            if (nw) {
-                void* dst = output_orders ? static_cast<void*>(R.orders.data()) : static_cast<void*>(R.bytes.data());
-                if (opt.has_klcp)   // -S: kLCP streaming kernel (query_kmers_streaming, src/fms_index.h:181-254)
-                    check(fmsi_hip_query_stream(dev, batch.packed.data(), batch.bases, batch.run_start.data(), batch.run_windows.data(),
-                                                batch.run_start.size(), nw, k, flags, dst, nullptr, nullptr),
-                          "fmsi_hip_query_stream");
-                else
-                    check(fmsi_hip_query_windows(dev, batch.packed.data(), batch.bases, batch.window_start.data(), nw, k, flags, dst,
-                                                 nullptr, nullptr),
-                          "fmsi_hip_query_windows");
-                check(fmsi_hip_sync(dev, nullptr), "fmsi_hip_sync");
-            }
-            gpu_s += std::chrono::duration<double>(clock::now() - t0).count();
-            total_windows += nw;
-            for (const RecordPlan& rp : batch.records) {
-                em.begin_record(rp.name);
-                uint64_t w = rp.first_result;
-                for (const Op& op : rp.ops) {
-                    if (!op.is_run) {
-                        for (uint64_t i = 0; i < op.count; ++i) {
-                            if (output_orders) em.order(-1);
-                            else em.bit(false);
-                        }
-                        continue;
-                    }
-                    if (!strict) {
-                        // the device already applied the strand schedule
-                        for (uint64_t i = 0; i < op.count; ++i) {
-                            if (output_orders) em.order(R.orders[w + i]);
-                            else em.bit(R.bytes[w + i] != 0);
-                        }
-                    } else if (!opt.has_klcp) {
-                        for (uint64_t i = 0; i < op.count; ++i) {
-                            int64_t got;
-                            const int64_t f = output_orders ? R.orders[2 * (w + i)] : R.fwd(w + i);
-                            const int64_t r = output_orders ? R.orders[2 * (w + i) + 1] : R.rc(w + i);
-                            replay_single(predictor, opt.mode, output_orders, f, r, &got);
-                            if (output_orders) em.order(got);
-                            else em.bit(got == 1);
-                        }
-                    } else {
-                        // chunks of the run as src/main.cpp:340-354 cuts them
-                        int64_t current_length = static_cast<int64_t>(op.count) + k - 1;
-                        uint64_t cw = w;
-                        while (current_length >= k) {
-                            const int64_t chunk_length = std::min<int64_t>(current_length, rp.max_chunk);
-                            const uint64_t n = static_cast<uint64_t>(chunk_length - k + 1);
-                            replay_streaming_chunk(predictor, opt.mode, output_orders, R, cw, n, em);
-                            cw += n;
-                            current_length -= static_cast<int64_t>(n);
-                        }
-                    }
-                    w += op.count;
-                }
-                em.end_record();
-                if (em.out.size() > (1u << 22)) em.flush();
-            }
-            em.flush();
-            batch.clear();
-        };
-
-        while (reader.next()) {
-            plan_record(batch, reader.name, reader.seq, k);
-            if (batch.window_start.size() >= opt.batch_windows) run_batch();
-        }
-        run_batch();
-        std::fflush(stdout);
+        reader = std::make_unique<FastxReader>(opt.query_fn);   // throws std::invalid_argument like OpenFile(), src/parser.h:22
     } catch (const std::invalid_argument&) {
         fmsi_hip_index_destroy(dev);
         fmsi_host_index_free(host);
         throw;   // uncaught in the reference too: abort, exit status 134
+    }
+    BoundedQueue<std::unique_ptr<RawBatch>> raw_q(2);
+    BoundedQueue<std::unique_ptr<Prepared>> out_q(2);
+    std::exception_ptr reader_err, writer_err;
+
+    std::thread reader_thread([&] {
+        try {
+            auto b = std::make_unique<RawBatch>();
+            auto t0 = clock::now();
+            while (reader->next()) {
+                RecRef rr;
+                rr.name_off = b->text.size();
+                rr.name_len = static_cast<uint32_t>(reader->name.size());
+                b->text += reader->name;
+                rr.seq_off = b->text.size();
+                rr.seq_len = reader->seq.size();
+                b->text += reader->seq;
+                b->recs.push_back(rr);
+                b->seq_bytes += rr.seq_len;
+                if (b->seq_bytes >= opt.batch_windows || b->recs.size() >= (1u << 23)) {
+                    read_s += std::chrono::duration<double>(clock::now() - t0).count();
+                    if (!raw_q.push(std::move(b))) return;
+                    b = std::make_unique<RawBatch>();
+                    t0 = clock::now();
+                }
+            }
+            read_s += std::chrono::duration<double>(clock::now() - t0).count();
+            if (!b->recs.empty()) raw_q.push(std::move(b));
+        } catch (...) {
+            reader_err = std::current_exception();
+        }
+        raw_q.close();
+    });
+
+    std::thread writer_thread([&] {
+        try {
+            std::unique_ptr<Prepared> P;
+            std::vector<char> buf;
+            std::vector<std::string> parts;
+            while (out_q.pop(P)) {
+                auto t0 = clock::now();
+                if (output_orders) format_orders(*P, team, parts);
+                else format_bits(*P, team, buf);
+                auto t1 = clock::now();
+                if (output_orders) {
+                    for (const std::string& s : parts)
+                        if (!s.empty() && std::fwrite(s.data(), 1, s.size(), stdout) != s.size()) throw std::runtime_error("write to stdout failed");
+                } else if (!buf.empty() && std::fwrite(buf.data(), 1, buf.size(), stdout) != buf.size()) {
+                    throw std::runtime_error("write to stdout failed");
+                }
+                format_s += std::chrono::duration<double>(t1 - t0).count();
+                write_s += std::chrono::duration<double>(clock::now() - t1).count();
+                P.reset();
+            }
+            std::fflush(stdout);
+        } catch (...) {
+            writer_err = std::current_exception();
+            out_q.abort();
+        }
+    });
+
+    try {
+        StrandPredictor predictor;
+        std::unique_ptr<RawBatch> raw;
+        while (raw_q.pop(raw)) {
+            auto P = std::make_unique<Prepared>();
+            P->raw = std::move(*raw);
+            raw.reset();
+            auto t0 = clock::now();
+            prepare_batch(*P, k, team);
+            auto t1 = clock::now();
+            const uint64_t nw = P->windows;
+            if (output_orders) P->orders.resize(nw * (strict ? 2 : 1));
+            else P->bytes.resize(nw);
+            if (nw) {
+                void* dst = output_orders ? static_cast<void*>(P->orders.data()) : static_cast<void*>(P->bytes.data());
+                if (opt.has_klcp)   // -S: kLCP streaming kernel (query_kmers_streaming, src/fms_index.h:181-254)
+                    check(fmsi_hip_query_stream(dev, P->packed.data(), P->bases, P->run_start.data(), P->run_windows.data(),
+                                                P->run_start.size(), nw, k, flags, dst, nullptr, nullptr),
+                          "fmsi_hip_query_stream");
+                else
+                    check(fmsi_hip_query_runs(dev, P->packed.data(), P->bases, P->run_start.data(), P->run_windows.data(),
+                                              P->run_start.size(), nw, k, flags, dst, nullptr, nullptr),
+                          "fmsi_hip_query_runs");
+                check(fmsi_hip_sync(dev, nullptr), "fmsi_hip_sync");
+            }
+            auto t2 = clock::now();
+            std::vector<uint64_t>().swap(P->packed);
+            if (strict) replay_batch(*P, predictor, opt.mode, output_orders, opt.has_klcp, k);
+            auto t3 = clock::now();
+            prep_s += std::chrono::duration<double>(t1 - t0).count();
+            gpu_s += std::chrono::duration<double>(t2 - t1).count();
+            replay_s += std::chrono::duration<double>(t3 - t2).count();
+            total_windows += nw;
+            if (!out_q.push(std::move(P))) break;   // the writer failed
+        }
     } catch (const std::exception& e) {
         std::cerr << "ERROR: " << e.what() << std::endl;
         exit_code = 1;
+        raw_q.abort();
+    }
+    out_q.close();
+    reader_thread.join();
+    writer_thread.join();
+    for (const std::exception_ptr& ep : {reader_err, writer_err}) {
+        if (!ep) continue;
+        try {
+            std::rethrow_exception(ep);
+        } catch (const std::exception& e) {
+            std::cerr << "ERROR: " << e.what() << std::endl;
+            exit_code = 1;
+        }
     }
     if (opt.stats) {
         const double total = std::chrono::duration<double>(clock::now() - t_start).count();
         const double load = std::chrono::duration<double>(t_loaded - t_start).count();
-        fprintf(stderr, "{\"windows\": %llu, \"total_seconds\": %.6f, \"load_seconds\": %.6f, \"device_seconds\": %.6f, \"strict\": %s}\n",
-                static_cast<unsigned long long>(total_windows), total, load, gpu_s, strict ? "true" : "false");
+        fprintf(stderr,
+                "{\"windows\": %llu, \"total_seconds\": %.6f, \"load_seconds\": %.6f, \"device_seconds\": %.6f, \"read_seconds\": %.6f, "
+                "\"prepare_seconds\": %.6f, \"replay_seconds\": %.6f, \"format_seconds\": %.6f, \"write_seconds\": %.6f, \"threads\": %u, "
+                "\"strict\": %s}\n",
+                static_cast<unsigned long long>(total_windows), total, load, gpu_s, read_s, prep_s, replay_s, format_s, write_s, team,
+                strict ? "true" : "false");
     }
     fmsi_hip_index_destroy(dev);
     fmsi_host_index_free(host);

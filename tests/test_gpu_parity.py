@@ -151,6 +151,20 @@ def test_cli_fast_mode(fm, mode):
     assert rc == 0 and out == golden_out("mixed_k11", "rand", "or")
 
 
+@pytest.mark.parametrize("mode", list(MODES))
+@pytest.mark.parametrize("name,kind", [("sars_k13", "rand"), ("mixed_k11", "rand"), ("repeats_k40", "rand"), ("integration_a", "edge")])
+@pytest.mark.parametrize("threads,batch", [(1, 1024), (3, 5000), (16, 1 << 26)])
+def test_cli_pipeline_is_batch_and_thread_invariant(fm, name, kind, mode, threads, batch):
+    """The host pipeline (reader -> team packing -> device -> replay -> team formatting) must not change a byte whatever
+    the batch cut and the team size: the predictor state crosses batches, runs are re-packed word aligned, and the
+    output lines are assembled by several threads."""
+    k = CLI_DATASETS[name][0]
+    rc, out, err = fm.run_cli([*MODES[mode][0], "-k", str(k), "--threads", str(threads), "--batch", str(batch), "-q",
+                               str(query_file(name, kind)), index_prefix(name)])
+    assert rc == 0, err.decode()
+    assert out == golden_out(name, kind, mode)
+
+
 def test_cli_stdin_gzip_and_small_batches(fm, tmp_path):
     import gzip
     name, k = "sars_k13", 13

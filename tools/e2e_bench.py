@@ -1,0 +1,154 @@
+#!/usr/bin/env python3
+"""End-to-end `fmsi query` wall time: index load + FASTA parse + device + print.
+
+Builds a synthetic masked superstring index on the GPU, writes it in the reference's .fmsi.* format, draws reads on
+the device (half substrings of the superstring, half uniform), writes them as FASTA into /dev/shm, then runs the
+product CLI in the requested modes with --stats and reports windows/s (whole process and without the index load).
+A sample of the reads also goes through the real reference CLI (oracle/_ref, if it travelled) to (a) check that the
+outputs are byte-identical and (b) put its single-threaded rate beside the product's.
+
+    python tools/e2e_bench.py [--n 100000000] [--reads 20000] [--read-len 10000] [--k 31] [--modes or,all,all_fast,all_S]
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+REPO = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(REPO))
+
+MODES = {
+    "or": ["query"],
+    "all": ["query", "-O"],
+    "all_fast": ["query", "-O", "--fast"],
+    "or_S": ["query", "-S"],
+    "all_S": ["query", "-S", "-O"],
+    "all_S_fast": ["query", "-S", "-O", "--fast"],
+    "lookup": ["lookup"],
+}
+
+
+def write_fasta(path: Path, packed: np.ndarray, n_reads: int, read_len: int, first: int) -> None:
+    lut = np.frombuffer(b"ACGT", dtype=np.uint8)
+    with open(path, "ab") as f:
+        step = max(1, (64 << 20) // read_len)
+        for r0 in range(0, n_reads, step):
+            r1 = min(n_reads, r0 + step)
+            b0, b1 = r0 * read_len, r1 * read_len
+            w0, w1 = b0 // 32, (b1 + 31) // 32
+            codes = ((packed[w0:w1, None] >> (2 * np.arange(32, dtype=np.uint64))) & np.uint64(3)).astype(np.uint8).reshape(-1)
+            codes = codes[b0 - w0 * 32: b0 - w0 * 32 + (b1 - b0)]
+            seqs = lut[codes].reshape(r1 - r0, read_len)
+            out = bytearray()
+            for i in range(r1 - r0):
+                out += b">r%d\n" % (first + r0 + i)
+                out += seqs[i].tobytes()
+                out += b"\n"
+            f.write(out)
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--n", type=int, default=100_000_000)
+    ap.add_argument("--reads", type=int, default=20_000)
+    ap.add_argument("--read-len", type=int, default=10_000)
+    ap.add_argument("--k", type=int, default=31)
+    ap.add_argument("--modes", default="or,all,all_fast,all_S,all_S_fast")
+    ap.add_argument("--ref-reads", type=int, default=40, help="reads of the sample that also go through the reference CLI")
+    ap.add_argument("--dir", default="/dev/shm/fmsi_e2e")
+    ap.add_argument("--out", default=None, help="write the JSON report here")
+    a = ap.parse_args()
+
+    import torch
+    import fmsi_amd as fm
+
+    work = Path(a.dir)
+    work.mkdir(parents=True, exist_ok=True)
+    prefix = str(work / "idx")
+    report = {"n": a.n, "k": a.k, "reads": a.reads, "read_len": a.read_len, "modes": {}}
+
+    t0 = time.time()
+    dev = fm.DeviceIndex.build_synthetic(a.n, 12345, a.k, with_klcp=True)
+    torch.cuda.synchronize()
+    report["build_seconds"] = round(time.time() - t0, 3)
+    t0 = time.time()
+    dev.write_files(prefix)
+    report["write_seconds"] = round(time.time() - t0, 3)
+    report["index_bytes"] = sum(os.path.getsize(f"{prefix}.fmsi.{p}") for p in ("ac_gt", "ac", "gt", "mask", "klcp", "misc"))
+
+    fasta = work / "reads.fa"
+    fasta.unlink(missing_ok=True)
+    t0 = time.time()
+    step = max(1, (1 << 30) // a.read_len)           # <= 1 G bases per device draw
+    for r0 in range(0, a.reads, step):
+        nr = min(step, a.reads - r0)
+        words = (nr * a.read_len) // 32 + 2
+        d = torch.empty(words, dtype=torch.int64, device="cuda")
+        dev.synthetic_reads_dev(a.read_len, 42, r0, nr, d.data_ptr(), 0, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        write_fasta(fasta, d.cpu().numpy().view(np.uint64), nr, a.read_len, r0)
+        del d
+    report["fasta_bytes"] = fasta.stat().st_size
+    report["fasta_seconds"] = round(time.time() - t0, 3)
+    dev.close()
+    del dev
+    torch.cuda.empty_cache()
+
+    # sample for the reference
+    sample = work / "sample.fa"
+    with open(fasta, "rb") as f, open(sample, "wb") as g:
+        for _ in range(2 * a.ref_reads):
+            g.write(f.readline())
+    ref_cli = REPO / "oracle" / "_ref" / "fmsi_ref"
+    windows_per_read = max(0, a.read_len - a.k + 1)
+
+    for mode in a.modes.split(","):
+        args = MODES[mode]
+        outp = work / f"out_{mode}.txt"
+        t0 = time.time()
+        with open(outp, "wb") as so:
+            p = subprocess.run([str(fm.CLI_PATH), *args, "--stats", "-q", str(fasta), prefix], stdout=so, stderr=subprocess.PIPE)
+        wall = time.time() - t0
+        entry = {"rc": p.returncode, "wall_seconds": round(wall, 3)}
+        for line in p.stderr.decode().splitlines():
+            if line.startswith("{"):
+                entry.update(json.loads(line))
+        if p.returncode != 0:
+            entry["stderr"] = p.stderr.decode()[-400:]
+        w = entry.get("windows", 0)
+        if w:
+            entry["windows_per_s_wall"] = round(w / wall)
+            entry["windows_per_s_after_load"] = round(w / max(1e-9, entry["total_seconds"] - entry["load_seconds"]))
+        entry["output_bytes"] = outp.stat().st_size
+        # reference on the sample: identical bytes?
+        ref_args = [x for x in args if x not in ("--fast",)]
+        if ref_cli.exists() and a.ref_reads:
+            t0 = time.time()
+            r = subprocess.run([str(ref_cli), *ref_args, "-k", str(a.k), "-q", str(sample), prefix], capture_output=True)
+            ref_s = time.time() - t0
+            g = subprocess.run([str(fm.CLI_PATH), *args, "-q", str(sample), prefix], capture_output=True)
+            entry["sample_identical_to_reference"] = bool(r.returncode == 0 and r.stdout == g.stdout)
+            entry["reference_windows_per_s"] = round(a.ref_reads * windows_per_read / ref_s)
+            with open(outp, "rb") as f:
+                head = f.read(len(r.stdout))
+            entry["full_run_prefix_identical"] = bool(head == r.stdout)
+        report["modes"][mode] = entry
+        print(mode, json.dumps(entry), flush=True)
+        outp.unlink()
+
+    print(json.dumps(report))
+    if a.out:
+        Path(a.out).parent.mkdir(parents=True, exist_ok=True)
+        Path(a.out).write_text(json.dumps(report, indent=1) + "\n")
+    for f in work.iterdir():
+        f.unlink()
+    work.rmdir()
+
+
+if __name__ == "__main__":
+    main()
