@@ -5,13 +5,15 @@
 //
 // Pipeline (N = |MS|, n = N + 1 rows):
 //   1. 2-bit text in HBM (uploaded, or generated in place from a counter-based PRNG for synthetic runs)
-//   2. key[p] = the 32 bases starting at p, first base in the top bits (zero padded past the end)
+//   2. key[p] = the 29 bases starting at p, first base in the top bits (zero padded past the end), and in the low
+//      6 bits min(N - p, 29): a suffix that ends inside the window sorts before every longer one ('$' is smallest)
 //   3. rocPRIM radix sort of (key, p) pairs -- a library sort, not part of the query hot path
-//   4. rows whose key equals a neighbour's key (true repeats longer than 32, or padding ambiguity at the
-//      text end) are re-sorted on the host by full suffix comparison.  Random texts have a handful of
-//      such rows; highly repetitive inputs make this step slow (GPU prefix doubling is the follow-up)
-//   5. one pass over the suffix array emits BWT symbol, SA-transformed mask bit and kLCP bit per row;
-//      wave ballots pack them into the block planes; per-block counts are prefix-summed on the device.
+//   4. rows whose key equals a neighbour's (repeats of 29 bases or more) are refined by prefix doubling on the
+//      device (Manber-Myers on the tied rows only): rank[p] = first row of p's group; round with depth L sorts the
+//      tied rows by (group, rank[p + L]), splits the groups, updates the ranks, L doubles.  <= log2(N / 29) rounds
+//      whatever the input; random texts need one
+//   5. one pass over the suffix array emits BWT symbol and SA-transformed mask bit per row, wave ballots pack them
+//      into the block planes, per-block counts are prefix-summed on the device; a second pass makes the kLCP bits.
 #include <hip/hip_runtime.h>
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
@@ -61,34 +63,71 @@ __device__ __forceinline__ uint64_t to_lex_key(uint64_t f) {   // first base to 
     return ((x & 0xAAAAAAAAAAAAAAAAull) >> 1) | ((x & 0x5555555555555555ull) << 1);
 }
 
+constexpr uint64_t kKeyBases = 29;   // bases per round-0 key; the low 6 bits hold min(remaining length, 29)
+
 __global__ void make_keys_kernel(const uint64_t* __restrict__ text2, uint64_t len, uint64_t* __restrict__ keys, uint32_t* __restrict__ pos) {
     const uint64_t p = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     if (p >= len) return;
-    keys[p] = to_lex_key(bases_at(text2, p));   // text2 is zero past `len`, so short suffixes are zero padded
+    const uint64_t rem = len - p < kKeyBases ? len - p : kKeyBases;
+    keys[p] = (to_lex_key(bases_at(text2, p)) & ~63ull) | rem;   // text2 is zero past `len`
     pos[p] = static_cast<uint32_t>(p);
 }
 
-// flags rows of the sorted order whose key equals a neighbour's
-__global__ void count_ties_kernel(const uint64_t* __restrict__ keys, uint64_t len, unsigned long long* __restrict__ n_ties) {
-    const uint64_t r = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-    bool tie = false;
-    if (r < len) {
-        const uint64_t kk = keys[r];
-        tie = (r > 0 && keys[r - 1] == kk) || (r + 1 < len && keys[r + 1] == kk);
-    }
-    const unsigned long long m = __ballot(tie);
-    if ((threadIdx.x & 63) == 0 && m) atomicAdd(n_ties, static_cast<unsigned long long>(__popcll(m)));
+// ---- prefix doubling on the tied rows ---------------------------------------------------------------------------
+// head[i] = element i starts a group (its key differs from its predecessor's); start[i] = its own row if so, else 0
+// (an inclusive max-scan of start[] then gives every element the first row of its group)
+__global__ void group_heads_kernel(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ rows /* or null: row = i */,
+                                   uint64_t count, uint32_t* __restrict__ start) {
+    const uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const bool head = i == 0 || keys[i] != keys[i - 1];
+    start[i] = head ? (rows ? rows[i] : static_cast<uint32_t>(i)) : 0u;
 }
-__global__ void collect_ties_kernel(const uint64_t* __restrict__ keys, uint64_t len, uint32_t* __restrict__ rows,
-                                    unsigned long long* __restrict__ cursor) {
-    const uint64_t r = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-    if (r >= len) return;
-    const uint64_t kk = keys[r];
-    if ((r > 0 && keys[r - 1] == kk) || (r + 1 < len && keys[r + 1] == kk)) rows[atomicAdd(cursor, 1ull)] = static_cast<uint32_t>(r);
+// rank of a suffix = 1 + first row of its group (0 is the empty suffix); tied[i] = its group has more than one element.
+// grp[] is non-decreasing and equal exactly within a group, so neighbours tell.
+__global__ void rank_and_ties_kernel(const uint32_t* __restrict__ grp, const uint32_t* __restrict__ pos, uint64_t count,
+                                     uint32_t* __restrict__ rank, uint32_t* __restrict__ tied) {
+    const uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const uint32_t g = grp[i];
+    rank[pos[i]] = g + 1u;
+    tied[i] = (i > 0 && grp[i - 1] == g) || (i + 1 < count && grp[i + 1] == g);
+}
+// keeps the tied elements: (row, position, group) triples, order preserved
+__global__ void compact_ties_kernel(const uint32_t* __restrict__ tied, const uint32_t* __restrict__ slot, const uint32_t* __restrict__ rows,
+                                    const uint32_t* __restrict__ pos, const uint32_t* __restrict__ grp, uint64_t count,
+                                    uint32_t* __restrict__ out_rows, uint32_t* __restrict__ out_pos, uint32_t* __restrict__ out_grp) {
+    const uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= count || !tied[i]) return;
+    const uint32_t o = slot[i];
+    out_rows[o] = rows ? rows[i] : static_cast<uint32_t>(i);
+    out_pos[o] = pos[i];
+    out_grp[o] = grp[i];
+}
+// key of a tied suffix in the round of depth L: (its group, rank of the suffix L bases further on)
+__global__ void doubling_keys_kernel(const uint32_t* __restrict__ pos, const uint32_t* __restrict__ grp, const uint32_t* __restrict__ rank,
+                                     uint64_t count, uint64_t depth, uint64_t* __restrict__ keys, uint32_t* __restrict__ idx) {
+    const uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    // a tied suffix is at least `depth` long (shorter ones were unique by their length field), so pos + depth <= len
+    keys[i] = (static_cast<uint64_t>(grp[i]) << 32) | rank[static_cast<uint64_t>(pos[i]) + depth];
+    idx[i] = static_cast<uint32_t>(i);
+}
+// the tied rows keep their rows (ascending, groups contiguous); the sorted positions go back into the suffix array
+__global__ void apply_order_kernel(const uint32_t* __restrict__ order, const uint32_t* __restrict__ pos, const uint32_t* __restrict__ rows,
+                                   uint64_t count, uint32_t* __restrict__ new_pos, uint32_t* __restrict__ sa) {
+    const uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const uint32_t p = pos[order[i]];
+    new_pos[i] = p;
+    sa[rows[i]] = p;
 }
 
 struct U4 {
     uint32_t a, c, g, t;
+};
+struct U32Max {
+    __host__ __device__ uint32_t operator()(uint32_t a, uint32_t b) const { return a > b ? a : b; }
 };
 struct U4Plus {
     __host__ __device__ U4 operator()(const U4& x, const U4& y) const { return U4{x.a + y.a, x.c + y.c, x.g + y.g, x.t + y.t}; }
@@ -204,19 +243,6 @@ struct DevBuf {
     }
 };
 
-inline unsigned host_base(const uint64_t* text2, uint64_t p) { return static_cast<unsigned>(text2[p >> 5] >> (2 * (p & 31))) & 3u; }
-
-// a < b for suffixes a != b of the text ('$' = end of text is the smallest symbol)
-bool suffix_less(const uint64_t* text2, uint64_t len, uint64_t a, uint64_t b) {
-    while (a < len && b < len) {
-        const unsigned x = host_base(text2, a), y = host_base(text2, b);
-        if (x != y) return x < y;
-        ++a;
-        ++b;
-    }
-    return a == len && b != len;
-}
-
 uint32_t grid_for(uint64_t items, uint32_t threads = 256) { return static_cast<uint32_t>((items + threads - 1) / threads); }
 
 // Shared tail of both entry points: text2 (device, zero padded, + mask_text or all-ones) -> device index.
@@ -229,10 +255,8 @@ int build_from_device_text(DevBuf& text2, uint64_t len, DevBuf* mask_text, int k
     }
     const uint64_t n_blocks = ((n + kBlockRows - 1) >> kBlockRowsLog2) + 1;
     int rc;
-    DevBuf keys_a, keys_b, pos_a, pos_b, temp, ties;
-    if ((rc = keys_a.alloc(len * 8)) || (rc = keys_b.alloc(len * 8)) || (rc = pos_a.alloc(len * 4)) || (rc = pos_b.alloc(len * 4)) ||
-        (rc = ties.alloc(16)))
-        return rc;
+    DevBuf keys_a, keys_b, pos_a, pos_b, temp;
+    if ((rc = keys_a.alloc(len * 8)) || (rc = keys_b.alloc(len * 8)) || (rc = pos_a.alloc(len * 4)) || (rc = pos_b.alloc(len * 4))) return rc;
     hipLaunchKernelGGL(make_keys_kernel, dim3(grid_for(len)), dim3(256), 0, 0, text2.as<uint64_t>(), len, keys_a.as<uint64_t>(),
                        pos_a.as<uint32_t>());
     rocprim::double_buffer<uint64_t> dk(keys_a.as<uint64_t>(), keys_b.as<uint64_t>());
@@ -244,47 +268,83 @@ int build_from_device_text(DevBuf& text2, uint64_t len, DevBuf* mask_text, int k
     uint64_t* sorted_keys = dk.current();
     uint32_t* sorted_pos = dv.current();
 
-    // ties -> host resolution
-    FMSI_HIP_TRY(hipMemset(ties.p, 0, 16));
-    hipLaunchKernelGGL(count_ties_kernel, dim3(grid_for(len)), dim3(256), 0, 0, sorted_keys, len, ties.as<unsigned long long>());
-    unsigned long long n_ties = 0;
-    FMSI_HIP_TRY(hipMemcpy(&n_ties, ties.p, 8, hipMemcpyDeviceToHost));
-    if (n_ties) {
-        DevBuf rows;
-        if ((rc = rows.alloc(n_ties * 4))) return rc;
-        hipLaunchKernelGGL(collect_ties_kernel, dim3(grid_for(len)), dim3(256), 0, 0, sorted_keys, len, rows.as<uint32_t>(),
-                           ties.as<unsigned long long>() + 1);
-        std::vector<uint32_t> h_rows(n_ties);
-        FMSI_HIP_TRY(hipMemcpy(h_rows.data(), rows.p, n_ties * 4, hipMemcpyDeviceToHost));
-        std::sort(h_rows.begin(), h_rows.end());
-        std::vector<uint64_t> h_text((len >> 5) + 2);
-        FMSI_HIP_TRY(hipMemcpy(h_text.data(), text2.p, h_text.size() * 8, hipMemcpyDeviceToHost));
-        // consecutive rows form groups of equal keys (a group never contains a gap, by construction)
-        std::vector<uint32_t> grp;
-        size_t a = 0;
-        while (a < h_rows.size()) {
-            size_t b = a + 1;
-            while (b < h_rows.size() && h_rows[b] == h_rows[b - 1] + 1) ++b;
-            // rows a..b-1 are contiguous, but may hold several key groups back to back: fetch keys to split
-            const size_t cnt = b - a;
-            std::vector<uint64_t> gk(cnt);
-            grp.resize(cnt);
-            FMSI_HIP_TRY(hipMemcpy(gk.data(), sorted_keys + h_rows[a], cnt * 8, hipMemcpyDeviceToHost));
-            FMSI_HIP_TRY(hipMemcpy(grp.data(), sorted_pos + h_rows[a], cnt * 4, hipMemcpyDeviceToHost));
-            size_t g0 = 0;
-            while (g0 < cnt) {
-                size_t g1 = g0 + 1;
-                while (g1 < cnt && gk[g1] == gk[g0]) ++g1;
-                std::sort(grp.begin() + g0, grp.begin() + g1,
-                          [&](uint32_t x, uint32_t y) { return suffix_less(h_text.data(), len, x, y); });
-                g0 = g1;
+    // ---- ties: prefix doubling on the tied rows --------------------------------------------------------------------
+    {
+        DevBuf start, grp, tied, slot, rank;
+        if ((rc = start.alloc(len * 4)) || (rc = grp.alloc(len * 4)) || (rc = tied.alloc((len + 1) * 4)) || (rc = slot.alloc((len + 1) * 4)) ||
+            (rc = rank.alloc((len + 1) * 4)))
+            return rc;
+        size_t sb1 = 0, sb2 = 0;
+        FMSI_HIP_TRY(rocprim::inclusive_scan(nullptr, sb1, start.as<uint32_t>(), grp.as<uint32_t>(), static_cast<size_t>(len), U32Max()));
+        FMSI_HIP_TRY(rocprim::exclusive_scan(nullptr, sb2, tied.as<uint32_t>(), slot.as<uint32_t>(), 0u, static_cast<size_t>(len + 1),
+                                             rocprim::plus<uint32_t>()));
+        DevBuf scan_tmp;
+        if ((rc = scan_tmp.alloc(std::max(sb1, sb2)))) return rc;
+        auto group_and_compact = [&](const uint64_t* d_keys, const uint32_t* d_rows, const uint32_t* d_pos, uint64_t count, DevBuf& o_rows,
+                                     DevBuf& o_pos, DevBuf& o_grp, uint64_t* n_tied) -> int {
+            // groups of equal keys -> ranks; the elements of groups with more than one member are kept for the next round
+            hipLaunchKernelGGL(group_heads_kernel, dim3(grid_for(count)), dim3(256), 0, 0, d_keys, d_rows, count, start.as<uint32_t>());
+            size_t b1 = sb1, b2 = sb2;
+            FMSI_HIP_TRY(rocprim::inclusive_scan(scan_tmp.p, b1, start.as<uint32_t>(), grp.as<uint32_t>(), static_cast<size_t>(count), U32Max()));
+            hipLaunchKernelGGL(rank_and_ties_kernel, dim3(grid_for(count)), dim3(256), 0, 0, grp.as<uint32_t>(), d_pos, count,
+                               rank.as<uint32_t>(), tied.as<uint32_t>());
+            FMSI_HIP_TRY(hipMemsetAsync(tied.as<uint32_t>() + count, 0, 4, 0));
+            FMSI_HIP_TRY(rocprim::exclusive_scan(scan_tmp.p, b2, tied.as<uint32_t>(), slot.as<uint32_t>(), 0u, static_cast<size_t>(count + 1),
+                                                 rocprim::plus<uint32_t>()));
+            uint32_t t = 0;
+            FMSI_HIP_TRY(hipMemcpy(&t, slot.as<uint32_t>() + count, 4, hipMemcpyDeviceToHost));
+            *n_tied = t;
+            if (!t) return 0;
+            int rc2;
+            if ((rc2 = o_rows.alloc(static_cast<size_t>(t) * 4)) || (rc2 = o_pos.alloc(static_cast<size_t>(t) * 4)) ||
+                (rc2 = o_grp.alloc(static_cast<size_t>(t) * 4)))
+                return rc2;
+            hipLaunchKernelGGL(compact_ties_kernel, dim3(grid_for(count)), dim3(256), 0, 0, tied.as<uint32_t>(), slot.as<uint32_t>(), d_rows, d_pos,
+                               grp.as<uint32_t>(), count, o_rows.as<uint32_t>(), o_pos.as<uint32_t>(), o_grp.as<uint32_t>());
+            FMSI_HIP_TRY(hipGetLastError());
+            return 0;
+        };
+        FMSI_HIP_TRY(hipMemset(rank.p, 0, (len + 1) * 4));   // rank[len] = 0: the empty suffix
+        DevBuf t_rows, t_pos, t_grp;
+        uint64_t n_tied = 0;
+        if ((rc = group_and_compact(sorted_keys, nullptr, sorted_pos, len, t_rows, t_pos, t_grp, &n_tied))) return rc;
+        // round 0's key buffers are free now (22 GB each at human scale); the one that is not the suffix array's
+        // neighbour keeps serving as scratch for nothing -- drop both
+        FMSI_HIP_TRY(hipDeviceSynchronize());
+        const bool pos_in_a = sorted_pos == pos_a.as<uint32_t>();
+        (void)hipFree(keys_a.release());
+        (void)hipFree(keys_b.release());
+        (void)hipFree(pos_in_a ? pos_b.release() : pos_a.release());
+        for (uint64_t depth = kKeyBases; n_tied; depth *= 2) {
+            DevBuf k_a, k_b, i_a, i_b, new_pos, sort_tmp, n_rows, n_pos, n_grp;
+            if ((rc = k_a.alloc(n_tied * 8)) || (rc = k_b.alloc(n_tied * 8)) || (rc = i_a.alloc(n_tied * 4)) || (rc = i_b.alloc(n_tied * 4)) ||
+                (rc = new_pos.alloc(n_tied * 4)))
+                return rc;
+            hipLaunchKernelGGL(doubling_keys_kernel, dim3(grid_for(n_tied)), dim3(256), 0, 0, t_pos.as<uint32_t>(), t_grp.as<uint32_t>(),
+                               rank.as<uint32_t>(), n_tied, depth, k_a.as<uint64_t>(), i_a.as<uint32_t>());
+            rocprim::double_buffer<uint64_t> dk2(k_a.as<uint64_t>(), k_b.as<uint64_t>());
+            rocprim::double_buffer<uint32_t> dv2(i_a.as<uint32_t>(), i_b.as<uint32_t>());
+            size_t tb = 0;
+            FMSI_HIP_TRY(rocprim::radix_sort_pairs(nullptr, tb, dk2, dv2, static_cast<size_t>(n_tied), 0, 64, 0));
+            if ((rc = sort_tmp.alloc(tb))) return rc;
+            FMSI_HIP_TRY(rocprim::radix_sort_pairs(sort_tmp.p, tb, dk2, dv2, static_cast<size_t>(n_tied), 0, 64, 0));
+            hipLaunchKernelGGL(apply_order_kernel, dim3(grid_for(n_tied)), dim3(256), 0, 0, dv2.current(), t_pos.as<uint32_t>(),
+                               t_rows.as<uint32_t>(), n_tied, new_pos.as<uint32_t>(), sorted_pos);
+            uint64_t still = 0;
+            if ((rc = group_and_compact(dk2.current(), t_rows.as<uint32_t>(), new_pos.as<uint32_t>(), n_tied, n_rows, n_pos, n_grp, &still)))
+                return rc;
+            FMSI_HIP_TRY(hipDeviceSynchronize());
+            std::swap(t_rows.p, n_rows.p);
+            std::swap(t_pos.p, n_pos.p);
+            std::swap(t_grp.p, n_grp.p);
+            n_tied = still;
+            if (depth > 2 * len) {
+                set_last_error("suffix sort: prefix doubling did not converge");
+                return FMSI_HIP_EHIP;
             }
-            FMSI_HIP_TRY(hipMemcpy(sorted_pos + h_rows[a], grp.data(), cnt * 4, hipMemcpyHostToDevice));
-            a = b;
         }
     }
-    // the keys are no longer needed: reuse nothing, just drop them before the layout allocations
-    // (sorted_pos lives in pos_a or pos_b)
+    (void)hipFree(temp.release());
     DevBuf blocks, counts, counts_scanned, mcounts, mrank, klcp, dollar, scan_temp;
     const size_t blocks_bytes = n_blocks * kBlockBytes;
     if ((rc = blocks.alloc(blocks_bytes)) || (rc = counts.alloc((n_blocks + 1) * sizeof(U4))) ||

@@ -140,3 +140,49 @@ def test_build_is_deterministic_at_scale(fm):
     (ba, ma), (bb, mb) = a.download_layout(), b.download_layout()
     assert np.array_equal(ba, bb) and np.array_equal(ma, mb)
     assert np.array_equal(a.download_klcp(), b.download_klcp())
+
+
+def repetitive_cases():
+    rng = random.Random(99)
+    unit = "".join(rng.choice("ACGT") for _ in range(5000))
+    fib_a, fib_b = "A", "AC"
+    while len(fib_b) < 150_000:
+        fib_a, fib_b = fib_b, fib_b + fib_a
+    mutated = lambda s: "".join(rng.choice("ACGT") if rng.random() < 0.001 else ch for ch in s)
+    return {
+        "period4": ("ACGT" * 60_000, 5),                                   # every suffix tied until its end: log2(n/29) rounds
+        "polyA": ("A" * 100_000 + "C" + "A" * 70_000, 4),
+        "fibonacci": (fib_b[:150_000], 6),
+        "tandem_5k": (unit * 30 + "".join(rng.choice("ACGT") for _ in range(20_000)) + unit[:2500] * 8, 11),
+        "diverged_copies": ("".join(mutated(unit * 6) for _ in range(5)), 13),     # long repeats broken by rare substitutions
+        "short_then_long": ("".join(rng.choice("ACGT") for _ in range(200_000)) + unit[:700] * 2, 31),
+    }
+
+
+@pytest.mark.parametrize("tag", list(repetitive_cases()))
+def test_build_repetitive_text_equals_reference(fm, oracle_built, tmp_path, tag):
+    """Repeats far longer than the 29 bases of the first sort key: the tied rows are ordered by prefix doubling on the
+    device.  Checked dword for dword against the layout of the index the REAL reference (Larsson-Sadakane qsufsort)
+    writes for the same superstring -- or the oracle's comparison sort where oracle/_ref did not travel."""
+    ms, k = repetitive_cases()[tag]
+    rng = random.Random(len(ms))
+    ms = "".join(ch if rng.random() < 0.7 else ch.lower() for ch in ms)
+    ms = ms[:len(ms) - (k - 1)] + ms[len(ms) - (k - 1):].lower()
+    fa = tmp_path / tag
+    fa.write_text(f">{tag}\n{ms}\n")
+    if oracle_py.REF_CLI.exists():
+        rc, _, err = oracle_py.run_cli(oracle_py.REF_CLI, ["index", "-k", str(k), str(fa)])
+    else:
+        rc, _, err = oracle_py.run_cli(oracle_py.ORACLE_CLI, ["index", "-k", str(k), str(fa)])
+    assert rc == 0, err
+    host = fm.HostIndex(str(fa), use_klcp=True)
+    dev = fm.DeviceIndex.build(ms.encode(), k, with_klcp=True)
+    check_equal_layout(fm, dev, host)
+    assert np.array_equal(klcp_bits(dev.download_klcp(), host.n), host.bits("klcp"))
+    # and the product's own `fmsi index` writes the same files
+    fb = tmp_path / (tag + "_gpu")
+    fb.write_text(f">{tag}\n{ms}\n")
+    rc, _, err = fm.run_cli(["index", "-k", str(k), str(fb)])
+    assert rc == 0, err
+    for part in ("ac_gt", "ac", "gt", "mask", "klcp", "misc"):
+        assert (tmp_path / f"{tag}_gpu.fmsi.{part}").read_bytes() == (tmp_path / f"{tag}.fmsi.{part}").read_bytes(), part
