@@ -137,6 +137,15 @@ __global__ __launch_bounds__(256) void query_stream_kernel(DevIndex ix, const ui
     uint64_t rf_lo = 0, rf_hi = 0;   // pass-0 result + 1 of window w: bit w of rf_lo / rf_hi (0 = empty interval)
     uint64_t todo = 0;            // pass 1: windows still to visit
     uint32_t i = 0, j = 0, st = SS_IDLE, pass = 0, widx = 0;
+    // Strand order of the task.  Pass 0 walks ALL windows on one strand, pass 1 the undecided ones on the other.
+    // Default: forward strand first (right-to-left), like the reference without its predictor.  Without STRICT the
+    // answer does not depend on the order, so when the task's last window is absent on the forward strand but present
+    // as reverse complement (one extra search per task) the read is taken to be reverse-complement oriented and the
+    // RC strand goes first (left-to-right) -- otherwise every window of such a read would pay a failed forward search
+    // before the RC pass streams through it.  This is the job the reference gives its strand predictor.
+    bool cur_rc = false;          // strand of the current pass
+    bool probing = false;         // the RC probe of the last window is running
+    uint32_t special = 0;         // set by window_done for advance(): 1 start the probe, 2 probe hit -> RC pass first
     uint64_t task_id = 0, ntask_id = 0;
     uint32_t scan_i = 0, scan_j = 0;   // EXTSCAN: sides still extending
     int t = 0;
@@ -144,19 +153,19 @@ __global__ __launch_bounds__(256) void query_stream_kernel(DevIndex ix, const ui
 
     // ---- the current window's k-mer on the current strand ----
     auto kmer_base = [&](int tt) -> uint32_t {        // base tt (0 = first)
-        if (WIDE) return pass == 0 ? task_base(s0, s1, s2, s3, widx + static_cast<uint32_t>(tt))
+        if (WIDE) return !cur_rc ? task_base(s0, s1, s2, s3, widx + static_cast<uint32_t>(tt))
                                    : 3u - task_base(s0, s1, s2, s3, widx + static_cast<uint32_t>(k - 1 - tt));
         return static_cast<uint32_t>(kmer >> (2 * tt)) & 3u;
     };
     auto kmer_table_index = [&](int T_) -> uint32_t {   // its last T_ bases
-        if (WIDE) return static_cast<uint32_t>(pass == 0 ? task_kmer(s0, s1, s2, s3, widx + static_cast<uint32_t>(k - T_), T_)
+        if (WIDE) return static_cast<uint32_t>(!cur_rc ? task_kmer(s0, s1, s2, s3, widx + static_cast<uint32_t>(k - T_), T_)
                                                          : revcomp_2bit(task_kmer(s0, s1, s2, s3, widx, T_), T_));
         return static_cast<uint32_t>(kmer >> (2 * (k - T_))) & ((1u << (2 * T_)) - 1u);
     };
     auto load_kmer = [&]() {                          // (re)load it for window widx
         if (WIDE) return;
         const uint64_t f = task_kmer(s0, s1, s2, s3, widx, k);
-        kmer = pass == 0 ? f : revcomp_2bit(f, k);
+        kmer = !cur_rc ? f : revcomp_2bit(f, k);
     };
     auto fresh = [&]() {   // start a fresh k-step search for `kmer`
         if (COUNT) cn.searches++;
@@ -184,9 +193,10 @@ __global__ __launch_bounds__(256) void query_stream_kernel(DevIndex ix, const ui
         }
         st = SS_IDLE;
     };
-    // begin pass 1 (reverse-complement strand, windows ascending) or finish the task
+    // begin pass 1 (the other strand: reverse complement = windows ascending, forward = descending) or finish the task
     auto begin_pass1 = [&]() {
         pass = 1;
+        cur_rc = !cur_rc;
         const uint64_t all = n == 64 ? ~0ull : ((1ull << n) - 1ull);
         if (strict) todo = all;
         else if (orders || !mode_all) todo = all & ~(rf_hi & ~rf_lo);   // OR / orders: only a forward result of 1 decides (rf = 2)
@@ -195,13 +205,35 @@ __global__ __launch_bounds__(256) void query_stream_kernel(DevIndex ix, const ui
             end_task();
             return;
         }
-        widx = static_cast<uint32_t>(__ffsll(static_cast<unsigned long long>(todo))) - 1u;
-        todo &= todo - 1;
+        if (cur_rc) {
+            widx = static_cast<uint32_t>(__ffsll(static_cast<unsigned long long>(todo))) - 1u;
+            todo &= todo - 1;
+        } else {
+            widx = 63u - static_cast<uint32_t>(__clzll(static_cast<long long>(todo)));
+            todo &= ~(1ull << widx);
+        }
         load_kmer();
         fresh();
     };
     // the current window's result on the current strand is known
     auto window_done = [&](int res, long long ord) {
+        if (!strict && pass == 0 && n > 1u) {
+            if (probing) {
+                probing = false;
+                if (res != -1) {          // present as reverse complement: restart the task with the RC strand first
+                    special = 2;
+                    return;
+                }
+                cur_rc = false;           // absent on both strands: carry on forward-first with the forward result (-1)
+                load_kmer();
+                res = -1;
+                ord = -1;
+            } else if (!cur_rc && res == -1 && widx == n - 1u) {
+                probing = true;
+                special = 1;
+                return;
+            }
+        }
         if (pass == 0) {
             const uint64_t bit = 1ull << widx;
             const uint32_t v = static_cast<uint32_t>(res + 1);
@@ -226,14 +258,38 @@ __global__ __launch_bounds__(256) void query_stream_kernel(DevIndex ix, const ui
     };
     // move to the next window of the pass; `have` = the current window's interval [i, j) is non-empty.
     // Returns true when the walk continues by streaming (extension + one LF step from [i, j)).
+    auto shift_fwd = [&](uint32_t w) {      // forward k-mer of window w from that of window w + 1: prepend S[w]
+        if (!WIDE) kmer = ((kmer << 2) | task_base(s0, s1, s2, s3, w)) & kmask;
+    };
+    auto shift_rc = [&](uint32_t w) {       // RC k-mer of window w + 1 from that of window w: prepend comp(S[w + k])
+        if (!WIDE) kmer = ((kmer << 2) | (3u - task_base(s0, s1, s2, s3, w + static_cast<uint32_t>(k)))) & kmask;
+    };
     auto advance = [&](bool have) -> bool {
+        if (special) {
+            const uint32_t sp = special;
+            special = 0;
+            cur_rc = true;
+            if (sp == 2) widx = 0;          // the probe hit: RC pass over all windows, ascending
+            load_kmer();
+            fresh();
+            return false;
+        }
         if (pass == 0) {
-            if (widx == 0) {
-                begin_pass1();
-                return false;
+            if (!cur_rc) {
+                if (widx == 0) {
+                    begin_pass1();
+                    return false;
+                }
+                --widx;
+                shift_fwd(widx);
+            } else {
+                if (widx + 1u == n) {
+                    begin_pass1();
+                    return false;
+                }
+                shift_rc(widx);
+                ++widx;
             }
-            --widx;
-            if (!WIDE) kmer = ((kmer << 2) | task_base(s0, s1, s2, s3, widx)) & kmask;   // prepend S[p]
             if (have) return true;
             fresh();
             return false;
@@ -242,14 +298,23 @@ __global__ __launch_bounds__(256) void query_stream_kernel(DevIndex ix, const ui
             end_task();
             return false;
         }
-        const uint32_t nw = static_cast<uint32_t>(__ffsll(static_cast<unsigned long long>(todo))) - 1u;
-        todo &= todo - 1;
-        if (nw == widx + 1u) {
-            if (!WIDE) kmer = ((kmer << 2) | (3u - task_base(s0, s1, s2, s3, widx + static_cast<uint32_t>(k)))) & kmask;   // prepend comp(S[p+k])
-            widx = nw;
+        uint32_t nw;
+        bool adjacent;
+        if (cur_rc) {
+            nw = static_cast<uint32_t>(__ffsll(static_cast<unsigned long long>(todo))) - 1u;
+            todo &= todo - 1;
+            adjacent = nw == widx + 1u;
+            if (adjacent) shift_rc(widx);
+        } else {
+            nw = 63u - static_cast<uint32_t>(__clzll(static_cast<long long>(todo)));
+            todo &= ~(1ull << nw);
+            adjacent = nw + 1u == widx;
+            if (adjacent) shift_fwd(nw);
+        }
+        widx = nw;
+        if (adjacent) {
             if (have) return true;
         } else {   // skipped windows: the reference resets the interval (fms_index.h:212-216)
-            widx = nw;
             load_kmer();
         }
         fresh();
@@ -262,6 +327,9 @@ __global__ __launch_bounds__(256) void query_stream_kernel(DevIndex ix, const ui
             task_id = ntask_id;
             has_next = false;
             pass = 0;
+            cur_rc = false;
+            probing = false;
+            special = 0;
             rf_lo = rf_hi = 0;
             widx = n - 1u;
             load_kmer();
@@ -312,7 +380,9 @@ __global__ __launch_bounds__(256) void query_stream_kernel(DevIndex ix, const ui
             uint4 a0 = b0, a1 = b0, a2 = b0, a3 = b0;
             uint64_t kwi = 0, kwj = 0;
             // kLCP words: around i-1 / j-1 for a window that will be extended, or the next words of a running scan
-            const bool more = pass == 0 ? widx > 0 : (todo != 0 && (static_cast<uint32_t>(__ffsll(static_cast<unsigned long long>(todo))) - 1u) == widx + 1u);
+            const bool more = pass == 0 ? (cur_rc ? widx + 1u < n : widx > 0u)
+                                        : (todo != 0 && (cur_rc ? (static_cast<uint32_t>(__ffsll(static_cast<unsigned long long>(todo))) - 1u) == widx + 1u
+                                                                : 64u - static_cast<uint32_t>(__clzll(static_cast<long long>(todo))) == widx));
             const bool want_klcp = st == SS_HAVE && more;
             uint32_t wi_idx = 0, wj_idx = 0;
             if (want_klcp) {

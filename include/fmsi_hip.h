@@ -185,7 +185,11 @@ int fmsi_hip_query_runs(fmsi_hip_index* idx, const uint64_t* packed_seq, uint64_
 
 /* Replaces query_kmers_streaming<>() (`-S`, src/fms_index.h:181-254): runs of consecutive windows walked
  * right-to-left with the kLCP extension (src/fms_index.h:106-115).  Run r covers windows starting at bases
- * run_start[r] .. run_start[r] + run_windows[r] - 1; results are written consecutively in run order. */
+ * run_start[r] .. run_start[r] + run_windows[r] - 1; results are written consecutively in run order.
+ * Without FMSI_HIP_STRICT the strand order is chosen per task of <= 64 consecutive windows, the way the reference's
+ * strand predictor chooses it per chunk: forward strand first, unless the task's last window is absent on the forward
+ * strand and present as reverse complement -- then the reverse-complement strand goes first.  As with the reference's
+ * predictor this cannot change an OR-mode answer, nor an ALL-mode answer under the max-ones precondition. */
 int fmsi_hip_query_stream(fmsi_hip_index* idx, const uint64_t* packed_seq, uint64_t seq_bases,
                           const uint64_t* run_start, const uint32_t* run_windows, uint64_t n_runs,
                           uint64_t n_windows, int k, uint32_t flags, void* out, uint64_t* counters, void* stream);

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 import oracle_py
-from conftest import LONGK_DATASETS, index_prefix, ms_of, revcomp, synthetic_ms
+from conftest import LONGK_DATASETS, index_prefix, ms_of, revcomp, stream_expected_fast, stream_expected_orders, synthetic_ms
 
 pytestmark = pytest.mark.gpu
 
@@ -73,13 +73,14 @@ def check(fm, orc, dev, reads, k, stream):
         assert np.array_equal(gf, fwd), (mode_all, np.nonzero(gf != fwd)[0][:10])
         assert np.array_equal(gr, rc), (mode_all, np.nonzero(gr != rc)[0][:10])
         fast = run(flag)
-        assert np.array_equal(fast.astype(bool), expected_fast(fwd, rc, mode_all))
+        want_fast = stream_expected_fast(fwd, rc, wins, mode_all) if stream else expected_fast(fwd, rc, mode_all)
+        assert np.array_equal(fast.astype(bool), want_fast)
         assert np.array_equal(run(flag | fm.NO_PREFIX_TABLE), fast)
         assert 0.05 < fast.mean() < 0.95
     fwd, rc, of, orr = orc.ternaries_bulk(raw, n, k, False, orders=True)
     got = run(fm.ORDERS | fm.STRICT)
     assert np.array_equal(got[:, 0], of) and np.array_equal(got[:, 1], orr)
-    assert np.array_equal(run(fm.ORDERS), np.where(of >= 0, of, orr))
+    assert np.array_equal(run(fm.ORDERS), stream_expected_orders(fwd, rc, of, orr, wins) if stream else np.where(of >= 0, of, orr))
     if not stream:   # LF-step accounting of the both-strands schedule equals the oracle's
         orc.counters_reset()
         orc.ternaries_bulk(raw, n, k, True)

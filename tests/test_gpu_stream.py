@@ -7,7 +7,8 @@ import numpy as np
 import pytest
 
 import oracle_py
-from conftest import DATASETS, GOLDEN, index_prefix, mixed_kmers, revcomp, synthetic_ms
+from conftest import (DATASETS, GOLDEN, index_prefix, mixed_kmers, revcomp, stream_expected_fast, stream_expected_orders,
+                      synthetic_ms)
 
 pytestmark = pytest.mark.gpu
 
@@ -45,16 +46,16 @@ def run_case(fm, orc, dev, reads, k, check_orders=True):
         assert np.array_equal(gf, fwd), (mode_all, np.nonzero(gf != fwd)[0][:10])
         assert np.array_equal(gr, rc), (mode_all, np.nonzero(gr != rc)[0][:10])
         fast = dev.query_stream(words, len(seq), starts, wins, k, flag)
-        assert np.array_equal(fast.astype(bool), expected_fast(fwd, rc, mode_all))
-        # same answers without the prefix table and from the non-streaming kernel
+        assert np.array_equal(fast.astype(bool), stream_expected_fast(fwd, rc, wins, mode_all))
+        # same answers without the prefix table and (forward strand first everywhere) from the non-streaming kernel
         assert np.array_equal(dev.query_stream(words, len(seq), starts, wins, k, flag | fm.NO_PREFIX_TABLE), fast)
-        assert np.array_equal(dev.query_kmers(fm.pack_kmers(kmers, k), k, flag), fast)
+        assert np.array_equal(dev.query_kmers(fm.pack_kmers(kmers, k), k, flag).astype(bool), expected_fast(fwd, rc, mode_all))
     if check_orders:
         fwd, rc, of, orr = orc.ternaries_bulk(raw, n, k, False, orders=True)
         got = dev.query_stream(words, len(seq), starts, wins, k, fm.ORDERS | fm.STRICT)
         assert np.array_equal(got[:, 0], of) and np.array_equal(got[:, 1], orr)
         got1 = dev.query_stream(words, len(seq), starts, wins, k, fm.ORDERS)
-        assert np.array_equal(got1, np.where(of >= 0, of, orr))
+        assert np.array_equal(got1, stream_expected_orders(fwd, rc, of, orr, wins))
 
 
 def ms_of(name):
