@@ -50,7 +50,8 @@ def parse_args():
     ap.add_argument("--n", type=float, default=2.8e9, help="superstring length in bases (human scale: 2.8e9)")
     ap.add_argument("--batch", type=float, default=float(1 << 27), help="query windows per step and GPU")
     ap.add_argument("--k", type=int, default=31)
-    ap.add_argument("--prefix-len", type=int, default=12, help="private prefix table length t (0 = none)")
+    ap.add_argument("--prefix-len", type=int, default=-1,
+                    help="private prefix table length t (0 = none; default: 15 for isolated k-mers, 13 for streaming, less while 4^t > 2n)")
     ap.add_argument("--kernel", choices=["pair", "refill", "lockstep"], default="pair")
     ap.add_argument("--mode", choices=["all", "or"], default="all")
     ap.add_argument("--read-len", type=int, default=10000, help="stream workload: bases per read")
@@ -75,7 +76,8 @@ def pmc_traffic(args, n, batch, k):
             continue
         c = t.get("config", {})
         if (c.get("workload", "kmers"), c.get("n"), c.get("batch"), c.get("k"), c.get("prefix_len"), c.get("mode")) == \
-                (args.workload, n, batch, k, args.prefix_len, args.mode) and args.kernel in t.get("kernel", args.kernel):
+                (args.workload, n, batch, k, args.prefix_len, args.mode) and \
+                ("stream" if args.workload == "stream" else args.kernel) in t.get("kernel", ""):
             best = t
     return None if best is None else best["hbm_bytes_per_launch"]
 
@@ -101,6 +103,10 @@ def main():
 
     n = int(args.n)
     k = args.k
+    if args.prefix_len < 0:   # measured on the human-scale index: t = 15 / 13 are the fastest that are worth their HBM
+        args.prefix_len = min(k, 13 if stream_mode else 15)
+        while args.prefix_len > 0 and 4 ** args.prefix_len > 2 * n:
+            args.prefix_len -= 1
     t0 = time.time()
     index = fm.DeviceIndex.build_synthetic(n, args.seed, k, with_klcp=stream_mode, device=local_rank, prefix_len=args.prefix_len)
     build_s = time.time() - t0

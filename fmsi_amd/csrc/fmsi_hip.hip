@@ -232,7 +232,7 @@ __global__ __launch_bounds__(256) void query_refill_kernel(DevIndex ix, const ui
             const uint4* pj;
             uint32_t bi = 0, bj = 0, tidx = 0;
             if (PTABLE && st == ST_LOOKUP) {
-                tidx = static_cast<uint32_t>(cur >> (2 * (k - T))) & ((1u << (2 * T)) - 1u);
+                tidx = static_cast<uint32_t>(cur >> (2 * (k - T))) & static_cast<uint32_t>((1ull << (2 * T)) - 1ull);
                 pi = reinterpret_cast<const uint4*>(ix.ptable + (tidx & ~7u));   // the 64-B line holding the entry
                 pj = pi;
             } else {
@@ -352,20 +352,21 @@ __global__ __launch_bounds__(256) void expand_runs_kernel(const uint64_t* __rest
 // one level of the prefix table: entry idx of level L = LF step with base (idx & 3) on entry idx >> 2 of level L-1
 __global__ __launch_bounds__(256) void ptable_level_kernel(DevIndex ix, const uint2* __restrict__ prev, uint2* __restrict__ cur,
                                                            uint64_t count) {
-    const uint64_t idx = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-    if (idx >= count) return;
-    uint2 e = prev ? prev[idx >> 2] : make_uint2(0u, ix.n);
-    if (e.x != e.y) {
-        uint32_t dummy = 0;
-        lf_step(ix, static_cast<uint32_t>(idx & 3u), e.x, e.y, dummy);
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;   // a launch holds < 2^32 threads; level 16 has 2^32 entries
+    for (uint64_t idx = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; idx < count; idx += stride) {
+        uint2 e = prev ? prev[idx >> 2] : make_uint2(0u, ix.n);
+        if (e.x != e.y) {
+            uint32_t dummy = 0;
+            lf_step(ix, static_cast<uint32_t>(idx & 3u), e.x, e.y, dummy);
+        }
+        cur[idx] = e;
     }
-    cur[idx] = e;
 }
 
 int build_prefix_table(fmsi_hip_index* idx, int t) {
     if (t <= 0) return 0;
-    if (t > 15) {
-        set_last_error("prefix_len must be <= 15");
+    if (t > 16) {
+        set_last_error("prefix_len must be <= 16");
         return FMSI_HIP_EINVAL;
     }
     const uint64_t final_count = 1ull << (2 * t);
@@ -385,8 +386,14 @@ int build_prefix_table(fmsi_hip_index* idx, int t) {
     const uint2* prev = nullptr;
     for (int level = 1; level <= t; ++level) {
         const uint64_t count = 1ull << (2 * level);
-        const uint32_t blocks = static_cast<uint32_t>((count + 255) / 256);
+        const uint32_t blocks = static_cast<uint32_t>(std::min<uint64_t>((count + 255) / 256, 1u << 22));
         hipLaunchKernelGGL(ptable_level_kernel, dim3(blocks), dim3(256), 0, 0, idx->dev, prev, bufs[cur], count);
+        if (hipGetLastError() != hipSuccess) {
+            (void)hipFree(a);
+            if (b) (void)hipFree(b);
+            set_last_error("prefix table build: kernel launch failed");
+            return FMSI_HIP_EHIP;
+        }
         prev = bufs[cur];
         cur ^= 1;
     }

@@ -321,7 +321,7 @@ __global__ __launch_bounds__(256) void query_pair_kernel(PairIndex ix, const uin
             uint32_t tidx = 0;
             const bool lookup = PTABLE && st == PS_LOOKUP;
             if (lookup) {
-                tidx = static_cast<uint32_t>(cur >> (2 * (k - T))) & ((1u << (2 * T)) - 1u);
+                tidx = static_cast<uint32_t>(cur >> (2 * (k - T))) & static_cast<uint32_t>((1ull << (2 * T)) - 1ull);
                 pi4 = reinterpret_cast<const uint4*>(ix.ptable + (tidx & ~7u)) + sub * 2u;
             }
             const bool two = st == PS_STEP && bj != bi;
@@ -538,12 +538,18 @@ extern "C" int fmsi_hip_index_enable_pair_layout(fmsi_hip_index* idx) {
                        static_cast<uint32_t*>(spec));
     size_t tb = 0;
     U16 zero{};
-    if (rocprim::exclusive_scan(nullptr, tb, static_cast<U16*>(counts), static_cast<U16*>(scanned), zero, static_cast<size_t>(n_blocks + 1),
-                                U16Plus()) != hipSuccess ||
-        hipMalloc(&temp, tb) != hipSuccess ||
-        rocprim::exclusive_scan(temp, tb, static_cast<U16*>(counts), static_cast<U16*>(scanned), zero, static_cast<size_t>(n_blocks + 1),
-                                U16Plus()) != hipSuccess)
-        return fail(FMSI_HIP_EHIP, "pair layout: prefix sums failed");
+    hipError_t e1 = hipGetLastError();   // pair_emit_kernel's launch
+    if (e1 == hipSuccess)
+        e1 = rocprim::exclusive_scan(nullptr, tb, static_cast<U16*>(counts), static_cast<U16*>(scanned), zero, static_cast<size_t>(n_blocks + 1),
+                                     U16Plus());
+    if (e1 == hipSuccess) e1 = hipMalloc(&temp, tb);
+    if (e1 == hipSuccess)
+        e1 = rocprim::exclusive_scan(temp, tb, static_cast<U16*>(counts), static_cast<U16*>(scanned), zero, static_cast<size_t>(n_blocks + 1),
+                                     U16Plus());
+    if (e1 != hipSuccess) {
+        const std::string msg = std::string("pair layout: prefix sums failed: ") + hipGetErrorString(e1);
+        return fail(FMSI_HIP_EHIP, msg.c_str());
+    }
     hipLaunchKernelGGL(pair_counts_kernel, dim3(static_cast<uint32_t>((n_blocks + 255) / 256)), dim3(256), 0, 0, static_cast<const U16*>(scanned),
                        n_blocks, static_cast<uint32_t*>(pb), static_cast<uint32_t*>(sbt));
     U16 totals;

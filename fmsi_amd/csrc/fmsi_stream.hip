@@ -31,30 +31,33 @@ namespace {
 
 constexpr uint32_t kTaskWindows = 64;
 
-struct TaskDesc {    // host-built
-    uint64_t base;   // first base of the task's first window in the packed sequence
-    uint64_t out;    // result index of the task's first window
-    uint32_t n;      // windows in the task (1..64)
-    uint32_t pad;
-};
-static_assert(sizeof(TaskDesc) == 24, "TaskDesc layout");
-
 struct alignas(64) TaskRec {   // device-built, one cache line
     uint64_t s[4];             // bases base .. base+127, base+m in bits [2(m%32), +1] of s[m/32]
-    uint64_t out;
-    uint32_t n;
+    uint64_t out;              // result index of the task's first window
+    uint32_t n;                // windows in the task (1..64)
     uint32_t pad;
     uint64_t pad2[2];
 };
 static_assert(sizeof(TaskRec) == 64, "TaskRec layout");
 
-__global__ __launch_bounds__(256) void stream_prep_kernel(const uint64_t* __restrict__ seq, const TaskDesc* __restrict__ desc,
-                                                          uint64_t n_tasks, uint64_t seq_words, TaskRec* __restrict__ rec) {
+// Runs -> tasks of <= 64 windows.  Per run the host supplies only its first base, first task and first result index
+// (24 bytes per run; a 10-kb read is 156 tasks); task t belongs to the run r with task_off[r] <= t < task_off[r + 1].
+__global__ __launch_bounds__(256) void stream_prep_kernel(const uint64_t* __restrict__ seq, const uint64_t* __restrict__ run_start,
+                                                          const uint64_t* __restrict__ task_off, const uint64_t* __restrict__ out_off,
+                                                          uint64_t n_runs, uint64_t n_tasks, uint64_t seq_words, TaskRec* __restrict__ rec) {
     const uint64_t t = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     if (t >= n_tasks) return;
-    const TaskDesc d = desc[t];
-    const uint64_t w = d.base >> 5;
-    const uint32_t sh = static_cast<uint32_t>(d.base & 31u) * 2u;
+    uint64_t lo = 0, hi = n_runs;   // invariant: task_off[lo] <= t < task_off[hi]
+    while (hi - lo > 1) {
+        const uint64_t mid = (lo + hi) >> 1;
+        if (task_off[mid] <= t) lo = mid;
+        else hi = mid;
+    }
+    const uint64_t j = t - task_off[lo];
+    const uint64_t run_windows = out_off[lo + 1] - out_off[lo];
+    const uint64_t base = run_start[lo] + j * kTaskWindows;
+    const uint64_t w = base >> 5;
+    const uint32_t sh = static_cast<uint32_t>(base & 31u) * 2u;
     TaskRec r;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {   // never reads past the caller's buffer (seq_words = seq_bases/32 + 2)
@@ -62,22 +65,22 @@ __global__ __launch_bounds__(256) void stream_prep_kernel(const uint64_t* __rest
         if (sh && w + q + 1 < seq_words) v |= seq[w + q + 1] << (64u - sh);
         r.s[q] = v;
     }
-    r.out = d.out;
-    r.n = d.n;
+    r.out = out_off[lo] + j * kTaskWindows;
+    r.n = static_cast<uint32_t>(min(static_cast<uint64_t>(kTaskWindows), run_windows - j * kTaskWindows));
     r.pad = 0;
     r.pad2[0] = r.pad2[1] = 0;
     rec[t] = r;
 }
 
 // slots[task] (one aligned 64-byte line of result bytes per task) -> the caller's contiguous result array
-__global__ __launch_bounds__(256) void stream_compact_kernel(const uint8_t* __restrict__ slots, const TaskDesc* __restrict__ desc,
+__global__ __launch_bounds__(256) void stream_compact_kernel(const uint8_t* __restrict__ slots, const TaskRec* __restrict__ rec,
                                                              uint64_t n_tasks, uint8_t* __restrict__ out) {
     const uint64_t g = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     const uint64_t t = g >> 6;
     const uint32_t w = static_cast<uint32_t>(g & 63u);
     if (t >= n_tasks) return;
-    const TaskDesc d = desc[t];
-    if (w < d.n) out[d.out + w] = slots[(t << 6) + w];
+    const uint64_t o = rec[t].out;
+    if (w < rec[t].n) out[o + w] = slots[(t << 6) + w];
 }
 
 enum : uint32_t { SS_IDLE = 0, SS_LOOKUP = 1, SS_LF = 2, SS_HAVE = 3, SS_EXTSCAN = 4, SS_EXTLF = 5 };
@@ -160,7 +163,7 @@ __global__ __launch_bounds__(256) void query_stream_kernel(DevIndex ix, const ui
     auto kmer_table_index = [&](int T_) -> uint32_t {   // its last T_ bases
         if (WIDE) return static_cast<uint32_t>(!cur_rc ? task_kmer(s0, s1, s2, s3, widx + static_cast<uint32_t>(k - T_), T_)
                                                          : revcomp_2bit(task_kmer(s0, s1, s2, s3, widx, T_), T_));
-        return static_cast<uint32_t>(kmer >> (2 * (k - T_))) & ((1u << (2 * T_)) - 1u);
+        return static_cast<uint32_t>(kmer >> (2 * (k - T_))) & static_cast<uint32_t>((1ull << (2 * T_)) - 1ull);
     };
     auto load_kmer = [&]() {                          // (re)load it for window widx
         if (WIDE) return;
@@ -580,29 +583,30 @@ extern "C" int fmsi_hip_query_stream(fmsi_hip_index* idx, const uint64_t* packed
     }
     FMSI_HIP_TRY(hipSetDevice(idx->device));
     hipStream_t s = static_cast<hipStream_t>(stream);
-    // run_start / run_windows are HOST arrays in every mode (one entry per run); tasks are cut here
-    std::vector<TaskDesc> desc;
-    desc.reserve(n_windows / kTaskWindows + n_runs);
-    uint64_t out_pos = 0;
+    // run_start / run_windows are HOST arrays in every mode (one entry per run); per run the device gets its first base,
+    // first task and first result index, and cuts the tasks itself (stream_prep_kernel)
+    std::vector<uint64_t> meta(3 * n_runs + 2);   // [0, R): run_start   [R, 2R]: task_off   [2R + 1, 3R + 1]: out_off
+    uint64_t* h_task_off = meta.data() + n_runs;
+    uint64_t* h_out_off = meta.data() + 2 * n_runs + 1;
+    uint64_t n_tasks = 0, out_pos = 0;
     for (uint64_t r = 0; r < n_runs; ++r) {
-        uint64_t left = run_windows[r], base = run_start[r];
-        if (base + left + static_cast<uint64_t>(k) - 1 > seq_bases) {
-            set_last_error("a run of windows extends past the end of the sequence");
+        const uint64_t w = run_windows[r];
+        if (w == 0 || run_start[r] + w + static_cast<uint64_t>(k) - 1 > seq_bases) {
+            set_last_error("an empty run, or a run of windows that extends past the end of the sequence");
             return FMSI_HIP_EINVAL;
         }
-        while (left) {
-            const uint32_t take = static_cast<uint32_t>(std::min<uint64_t>(left, kTaskWindows));
-            desc.push_back(TaskDesc{base, out_pos, take, 0});
-            base += take;
-            out_pos += take;
-            left -= take;
-        }
+        meta[r] = run_start[r];
+        h_task_off[r] = n_tasks;
+        h_out_off[r] = out_pos;
+        n_tasks += (w + kTaskWindows - 1) / kTaskWindows;
+        out_pos += w;
     }
+    h_task_off[n_runs] = n_tasks;
+    h_out_off[n_runs] = out_pos;
     if (out_pos != n_windows) {
         set_last_error("n_windows does not equal the sum of run_windows");
         return FMSI_HIP_EINVAL;
     }
-    const uint64_t n_tasks = desc.size();
     const bool dev_ptrs = flags & FMSI_HIP_DEVICE_PTRS;
     const size_t out_bytes = n_windows * ((flags & FMSI_HIP_ORDERS) ? ((flags & FMSI_HIP_STRICT) ? 16 : 8) : 1);
     const size_t seq_bytes = (seq_bases / 32 + 2) * 8;
@@ -621,16 +625,16 @@ extern "C" int fmsi_hip_query_stream(fmsi_hip_index* idx, const uint64_t* packed
             d_cnt = idx->d_counters;
         }
     }
-    // descriptors, then records, in one staging buffer
-    const size_t desc_bytes = (n_tasks * sizeof(TaskDesc) + 63) / 64 * 64;
-    if ((rc = ensure_cap(&idx->d_tasks, &idx->d_tasks_cap, desc_bytes + 2 * n_tasks * sizeof(TaskRec)))) return rc;
-    auto* d_desc = static_cast<TaskDesc*>(idx->d_tasks);
-    auto* d_rec = reinterpret_cast<TaskRec*>(static_cast<char*>(idx->d_tasks) + desc_bytes);
+    // run metadata, then the task records and the result slots, in one staging buffer
+    const size_t meta_bytes = (meta.size() * 8 + 63) / 64 * 64;
+    if ((rc = ensure_cap(&idx->d_tasks, &idx->d_tasks_cap, meta_bytes + 2 * n_tasks * sizeof(TaskRec)))) return rc;
+    auto* d_meta = static_cast<uint64_t*>(idx->d_tasks);
+    auto* d_rec = reinterpret_cast<TaskRec*>(static_cast<char*>(idx->d_tasks) + meta_bytes);
     auto* d_slots = reinterpret_cast<uint4*>(d_rec + n_tasks);   // one 64-byte line of result bytes per task
-    FMSI_HIP_TRY(hipMemcpyAsync(d_desc, desc.data(), n_tasks * sizeof(TaskDesc), hipMemcpyHostToDevice, s));
-    FMSI_HIP_TRY(hipStreamSynchronize(s));   // `desc` is a local vector: the copy must finish before it dies
-    hipLaunchKernelGGL(stream_prep_kernel, dim3(static_cast<uint32_t>((n_tasks + 255) / 256)), dim3(256), 0, s, d_seq, d_desc, n_tasks,
-                       seq_bases / 32 + 2, d_rec);
+    FMSI_HIP_TRY(hipMemcpyAsync(d_meta, meta.data(), meta.size() * 8, hipMemcpyHostToDevice, s));
+    FMSI_HIP_TRY(hipStreamSynchronize(s));   // `meta` is a local vector: the copy must finish before it dies
+    hipLaunchKernelGGL(stream_prep_kernel, dim3(static_cast<uint32_t>((n_tasks + 255) / 256)), dim3(256), 0, s, d_seq, d_meta, d_meta + n_runs,
+                       d_meta + 2 * n_runs + 1, n_runs, n_tasks, seq_bases / 32 + 2, d_rec);
     FMSI_HIP_TRY(hipGetLastError());
     const bool use_table = idx->d_ptable && !(flags & FMSI_HIP_NO_PREFIX_TABLE) && k >= idx->prefix_len;
     size_t slot;
@@ -656,7 +660,7 @@ extern "C" int fmsi_hip_query_stream(fmsi_hip_index* idx, const uint64_t* packed
     if (!(flags & FMSI_HIP_ORDERS)) {
         const uint64_t threads = n_tasks * 64;
         hipLaunchKernelGGL(stream_compact_kernel, dim3(static_cast<uint32_t>((threads + 255) / 256)), dim3(256), 0, s,
-                           reinterpret_cast<const uint8_t*>(d_slots), d_desc, n_tasks, static_cast<uint8_t*>(d_out));
+                           reinterpret_cast<const uint8_t*>(d_slots), d_rec, n_tasks, static_cast<uint8_t*>(d_out));
         FMSI_HIP_TRY(hipGetLastError());
     }
     if (!dev_ptrs) {

@@ -85,7 +85,7 @@ typedef struct {
     uint64_t counts[4];                           /* .fmsi.misc lines 2-5 */
     uint64_t dollar_position;                     /* .fmsi.misc line 1 */
     int32_t k;                                    /* .fmsi.misc line 6 */
-    int32_t prefix_len;                           /* private prefix table length t (0 = none, <= 15) */
+    int32_t prefix_len;                           /* private prefix table length t (0 = none, <= 16: 4^t entries of 8 bytes) */
 } fmsi_index_view;
 
 typedef struct fmsi_hip_index fmsi_hip_index;     /* device-resident index (opaque) */

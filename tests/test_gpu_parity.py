@@ -243,3 +243,34 @@ def test_properties_at_scale(fm, synthetic_index):
     assert (fa == 1).mean() < 1e-3
     w = dev.query_windows(words, len(up), k, fm.MODE_ALL, window_start=starts)
     assert (w == 1).all()
+
+
+@pytest.mark.parametrize("t", [13, 16])
+def test_large_prefix_tables(fm, oracle_built, t):
+    """Prefix tables far larger than the index (4^13 = 67 M and 4^16 = 4.3 G entries, 34 GB): same answers as the oracle
+    from every kernel that takes the table -- single steps, pair steps (both parities of k - t) and streaming."""
+    name, k = "sars_k31", 31
+    orc = oracle_py.Oracle.load(index_prefix(name), use_klcp=True)
+    ms = "".join(l.strip() for l in open(GOLDEN / "ref_data" / "GCF_test2_ones.fna.ms.k31") if not l.startswith(">"))
+    kmers = mixed_kmers(ms, k, 20000, seed=t)
+    raw = "".join(kmers).encode()
+    packed = fm.pack_kmers(kmers, k)
+    dev = fm.DeviceIndex.from_files(index_prefix(name), use_klcp=True, prefix_len=t).enable_pair_layout()
+    assert dev.info.prefix_len == t
+    for mode_all in (False, True):
+        flag = fm.MODE_ALL if mode_all else fm.MODE_OR
+        fwd, rc = orc.ternaries_bulk(raw, len(kmers), k, mode_all)
+        for kern in (fm.KERNEL_PAIR, fm.KERNEL_REFILL):
+            gf, gr = fm.decode_strict(dev.query_kmers(packed, k, flag | fm.STRICT | kern))
+            assert np.array_equal(gf, fwd) and np.array_equal(gr, rc)
+    up = ms.upper()
+    reads = [up[100:700], revcomp(up[2000:2900]), up[5000:5031]]
+    seq = "".join(reads)
+    starts = np.cumsum([0] + [len(r) for r in reads[:-1]])
+    wins = [len(r) - k + 1 for r in reads]
+    wk = [r[i:i + k] for r in reads for i in range(len(r) - k + 1)]
+    fwd, rc = orc.ternaries_bulk("".join(wk).encode(), len(wk), k, True)
+    gf, gr = fm.decode_strict(dev.query_stream(fm.pack_sequence(seq.encode()), len(seq), starts, wins, k, fm.MODE_ALL | fm.STRICT))
+    assert np.array_equal(gf, fwd) and np.array_equal(gr, rc)
+    gf, gr = fm.decode_strict(dev.query_runs(fm.pack_sequence(seq.encode()), len(seq), starts, wins, k, fm.MODE_ALL | fm.STRICT))
+    assert np.array_equal(gf, fwd) and np.array_equal(gr, rc)

@@ -1,0 +1,84 @@
+#!/usr/bin/env python3
+"""Condenses the rocprofv3 outputs of tools/profile_round.sh: per (pass, kernel, counter) the number of dispatches and
+the average per dispatch for the query kernels, the kernel-stats tables, and traffic.json = HBM bytes per launch of
+the timed kernel next to the algorithmic bytes bench.py counted for the same configuration.
+
+FETCH_SIZE / WRITE_SIZE are in KiB.  gfx950 tallies a 128-byte request at 64 B in FETCH_SIZE (MI355X_MICROARCH.md, HBM
+section; re-measured with tools/gather_bench: 0.50x for random 128-B reads, 1.015x for random 64-B reads), so for the
+pair kernel corrected fetch = raw + 64 B x (128-B block reads per launch, from the kernel's own counters)."""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+
+def main(out_dir: str) -> None:
+    rows = []
+    for pass_dir in sorted(glob.glob(os.path.join(out_dir, "pmc_*"))):
+        if not os.path.isdir(pass_dir):
+            continue
+        acc = defaultdict(lambda: [0, 0.0])
+        per_dispatch = defaultdict(lambda: defaultdict(float))
+        for f in glob.glob(os.path.join(pass_dir, "**", "*_counter_collection.csv"), recursive=True):
+            with open(f, newline="") as fh:
+                for r in csv.DictReader(fh):
+                    name = r["Kernel_Name"]
+                    if "query_" not in name:
+                        continue
+                    per_dispatch[(name, r["Counter_Name"])][r["Dispatch_Id"]] += float(r["Counter_Value"])
+        for (name, counter), d in per_dispatch.items():
+            acc[(name, counter)] = [len(d), sum(d.values()) / len(d)]
+        for (name, counter), (cnt, avg) in sorted(acc.items()):
+            rows.append((os.path.basename(pass_dir), name, counter, cnt, avg))
+    with open(os.path.join(out_dir, "pmc_summary.csv"), "w", newline="") as fh:
+        w = csv.writer(fh)
+        w.writerow(["pass", "kernel", "counter", "dispatches", "avg_per_dispatch"])
+        for r in rows:
+            w.writerow([r[0], r[1], r[2], r[3], round(r[4], 3)])
+    for tag in ("trace", "trace_stream"):
+        for f in glob.glob(os.path.join(out_dir, tag, "**", "*_kernel_stats.csv"), recursive=True):
+            os.replace(f, os.path.join(out_dir, f"{tag}_kernel_stats.csv"))
+
+    def avg(pass_name, kernel_sub, counter):
+        c = [r for r in rows if r[0] == pass_name and kernel_sub in r[1] and r[2] == counter and "<false" in r[1]]
+        return max(c, key=lambda r: r[3])[4] if c else None
+
+    for wl, bench_file, kernel_sub, fetch_pass in (("kmers", "bench_default.json", "query_pair_kernel", "pmc_fetch"),
+                                                   ("stream", "bench_stream.json", "query_stream_kernel", "pmc_fetch_stream")):
+        try:
+            line = [l for l in open(os.path.join(out_dir, bench_file)) if l.startswith("{")][-1]
+            b = json.loads(line)
+        except (OSError, IndexError, ValueError):
+            continue
+        roof = b["roofline"]
+        raw = avg(fetch_pass, kernel_sub, "FETCH_SIZE")
+        if raw is None:
+            continue
+        raw_bytes = raw * 1024.0
+        batch = b["config"]["queries_per_step_per_gpu"]
+        t = {"kernel": kernel_sub, "config": {"workload": wl, "n": b["config"]["index_rows"] - 1, "batch": batch, "k": b["config"]["k"],
+                                                "prefix_len": b["config"]["prefix_table_len"], "mode": b["config"]["mode"]},
+             "fetch_size_raw_bytes_per_launch": raw_bytes,
+             "algorithmic_bytes_per_launch": roof["algorithmic_bytes_per_launch"]}
+        if wl == "kmers":
+            block_reads = (roof["blocks_per_kmer"] - roof["table_lookups_per_kmer"]) * batch   # 128-B requests
+            wr = avg("pmc_write", kernel_sub, "WRITE_SIZE")
+            t["write_bytes_per_launch"] = (wr or 0.0) * 1024.0
+            t["fetch_bytes_per_launch"] = raw_bytes + 64.0 * block_reads
+            t["hbm_bytes_per_launch"] = t["fetch_bytes_per_launch"] + t["write_bytes_per_launch"]
+            t["tcc_hit_per_launch"] = avg("pmc_write", kernel_sub, "TCC_HIT_sum")
+            t["tcc_miss_per_launch"] = avg("pmc_write", kernel_sub, "TCC_MISS_sum")
+            t["correction"] = "raw FETCH_SIZE + 64 B x 128-B block reads per launch (gfx950 tallies a 128-B request at 64 B)"
+        else:
+            t["fetch_bytes_per_launch"] = raw_bytes / 1.015   # random 64-B reads are tallied at 1.015x (gather_bench calibration)
+            t["hbm_bytes_per_launch"] = t["fetch_bytes_per_launch"]
+            t["correction"] = "raw FETCH_SIZE / 1.015 (64-B requests); result bytes leave through stream_compact_kernel, not this kernel"
+        with open(os.path.join(out_dir, f"traffic_{wl}.json"), "w") as fh:
+            json.dump(t, fh, indent=1)
+            fh.write("\n")
+
+
+if __name__ == "__main__":
+    main(sys.argv[1])
