@@ -388,60 +388,110 @@ inline int64_t replay_single(StrandPredictor& p, Mode mode, bool orders, int64_t
     return got;
 }
 
-// query_kmers_streaming<> for one chunk of `n` windows starting at result index w0 (src/fms_index.h:181-254);
-// the final values replace the device results in place (element w0 + i <- window i of the chunk).
-void replay_streaming_chunk(StrandPredictor& p, Mode mode, bool orders, Prepared& P, uint64_t w0, uint64_t n, std::vector<int64_t>& result) {
+// query_kmers_streaming<> for one chunk of `n` windows starting at result index w0 (src/fms_index.h:181-254); the
+// final values replace the device results in place (element w0 + i <- window i of the chunk).
+// The reference fills result[] in the orientation of the first strand (reversed when the strands are swapped), sums
+// the first strand's results over all windows and the second strand's over the undecided ones, reverses result[] back
+// and logs the two sums in forward / reverse order.  Per window that is: first = the first strand's result,
+// decided = it settles the window, value = decided ? first : max(first, second) -- independent of the walk order,
+// so one pass in window order gives the same sums and the same output.
+void replay_streaming_chunk(StrandPredictor& p, Mode mode, bool orders, Prepared& P, uint64_t w0, uint64_t n) {
     const bool should_swap = p.predict_swap();
     const bool maximized_ones = mode == Mode::All;
-    int fpr = 0, bpr = 0;
-    result.resize(n);
-    for (uint64_t i = 0; i < n; ++i) {
-        // result[] is indexed in the orientation of the (possibly swapped) first strand; window w of the
-        // forward string is window n-1-w of the reverse-complement string
-        const uint64_t w = should_swap ? (n - 1 - i) : i;
-        const int64_t first = orders ? (should_swap ? P.orders[2 * (w0 + w) + 1] : P.orders[2 * (w0 + w)])
-                                     : (should_swap ? rc_of(P.bytes[w0 + w]) : fwd_of(P.bytes[w0 + w]));
-        result[i] = first;
-        if (orders) fpr += first >= 0 ? 1 : -1;
-        else fpr += static_cast<int>(first);
+    int first_sum = 0, second_sum = 0;
+    if (orders) {
+        // In-place is safe: element w0 + i <= 2 (w0 + i), and the pair of window i is read before element w0 + i is written
+        // (for i = 0 the pair is read first; for i > 0 element w0 + i lies below the pair of window i).
+        for (uint64_t i = 0; i < n; ++i) {
+            const int64_t f = P.orders[2 * (w0 + i)], r = P.orders[2 * (w0 + i) + 1];
+            const int64_t first = should_swap ? r : f, second = should_swap ? f : r;
+            first_sum += first >= 0 ? 1 : -1;
+            int64_t v = first;
+            if (first < 0) {
+                second_sum += second >= 0 ? 1 : -1;
+                v = std::max(first, second);
+            }
+            P.orders[w0 + i] = v;
+        }
+    } else {
+        uint8_t* b = P.bytes.data() + w0;
+        for (uint64_t i = 0; i < n; ++i) {
+            const int f = fwd_of(b[i]), r = rc_of(b[i]);
+            const int first = should_swap ? r : f, second = should_swap ? f : r;
+            const bool decided = first == 1 || (first == 0 && maximized_ones);
+            first_sum += first;
+            second_sum += decided ? 0 : second;
+            b[i] = static_cast<uint8_t>((decided ? first : std::max(first, second)) == 1);
+        }
     }
-    for (uint64_t i = 0; i < n; ++i) {
-        if ((result[i] >= 0 && orders) || result[i] == 1 || (result[i] == 0 && maximized_ones)) continue;
-        // second pass walks the other strand's string: its window pairs with result[i]
-        const uint64_t w = should_swap ? (n - 1 - i) : i;
-        const int64_t second = orders ? (should_swap ? P.orders[2 * (w0 + w)] : P.orders[2 * (w0 + w) + 1])
-                                      : (should_swap ? fwd_of(P.bytes[w0 + w]) : rc_of(P.bytes[w0 + w]));
-        if (orders) bpr += second >= 0 ? 1 : -1;
-        else bpr += static_cast<int>(second);
-        result[i] = std::max(result[i], second);
+    if (should_swap) p.log_result(second_sum, first_sum);
+    else p.log_result(first_sum, second_sum);
+}
+
+inline bool same_state(const StrandPredictor& a, const StrandPredictor& b) {
+    return a.score == b.score && a.result_scores[0] == b.result_scores[0] && a.result_scores[1] == b.result_scores[1] && a.previous == b.previous;
+}
+
+// first index >= from whose byte differs from `v` (or n)
+inline uint64_t run_end(const uint8_t* p, uint64_t from, uint64_t n, uint8_t v) {
+    const uint64_t pat = 0x0101010101010101ull * v;
+    uint64_t e = from;
+    while (e + 8 <= n) {
+        uint64_t x;
+        std::memcpy(&x, p + e, 8);
+        x ^= pat;
+        if (x) return e + static_cast<uint64_t>(__builtin_ctzll(x) >> 3);
+        e += 8;
     }
-    if (should_swap) {
-        std::reverse(result.begin(), result.end());
-        std::swap(fpr, bpr);
-    }
-    p.log_result(fpr, bpr);
-    // window w0 + i: final value.  In-place is safe for orders: element w0 + i <= 2 (w0 + i), and the chunk's
-    // strict pairs [2 w0, 2 (w0 + n)) have all been read above.
-    for (uint64_t i = 0; i < n; ++i) {
-        if (orders) P.orders[w0 + i] = result[i];
-        else P.bytes[w0 + i] = static_cast<uint8_t>(result[i] == 1);
-    }
+    while (e < n && p[e] == v) ++e;
+    return e;
 }
 
 // strict results (both strands per window) -> final per-window values, in the order the reference visits them
 void replay_batch(Prepared& P, StrandPredictor& predictor, Mode mode, bool orders, bool streaming, int k) {
     if (!streaming) {
-        // one predictor step per window, in output order == result order; fills do not touch the predictor
-        for (uint64_t w = 0; w < P.windows; ++w) {
-            const int64_t f = orders ? P.orders[2 * w] : fwd_of(P.bytes[w]);
-            const int64_t r = orders ? P.orders[2 * w + 1] : rc_of(P.bytes[w]);
-            const int64_t got = replay_single(predictor, mode, orders, f, r);
-            if (orders) P.orders[w] = got;
-            else P.bytes[w] = static_cast<uint8_t>(got == 1);
+        // One predictor step per window, in output order == result order; fills do not touch the predictor.  The
+        // predictor is a small saturating state machine: when a step leaves it unchanged, every following window with
+        // the same input (the same pair of strand results; for lookup the same pair of signs) leaves it unchanged too
+        // and takes the same decision -- such runs (reads that lie on one strand, absent reads) are skipped over.
+        const uint64_t nw = P.windows;
+        uint64_t w = 0;
+        if (!orders) {
+            uint8_t* b = P.bytes.data();
+            while (w < nw) {
+                const uint8_t in = b[w];
+                const StrandPredictor before = predictor;
+                const uint8_t got = static_cast<uint8_t>(replay_single(predictor, mode, false, fwd_of(in), rc_of(in)) == 1);
+                b[w++] = got;
+                if (same_state(before, predictor)) {
+                    const uint64_t e = run_end(b, w, nw, in);
+                    std::memset(b + w, got, e - w);
+                    w = e;
+                }
+            }
+            return;
+        }
+        int64_t* o = P.orders.data();
+        while (w < nw) {
+            const int64_t f = o[2 * w], r = o[2 * w + 1];
+            const StrandPredictor before = predictor;
+            o[w++] = replay_single(predictor, mode, true, f, r);
+            if (same_state(before, predictor)) {
+                // the decision looks at the first strand's order truncated to int and at the sign of the second's
+                // (src/fms_index.h:281-287), so that is what "the same input" means here
+                auto cls = [](int64_t x, int64_t y) {
+                    return (static_cast<int>(x) >= 0 ? 1 : 0) | (x >= 0 ? 2 : 0) | (static_cast<int>(y) >= 0 ? 4 : 0) | (y >= 0 ? 8 : 0);
+                };
+                const int c0 = cls(f, r);
+                const bool swap = predictor.predict_swap();
+                while (w < nw && cls(o[2 * w], o[2 * w + 1]) == c0) {
+                    const int64_t first = swap ? o[2 * w + 1] : o[2 * w], second = swap ? o[2 * w] : o[2 * w + 1];
+                    o[w++] = static_cast<int>(first) >= 0 ? first : second;
+                }
+            }
         }
         return;
     }
-    std::vector<int64_t> scratch;
     for (size_t r = 0; r + 1 < P.rec_ops.size(); ++r) {
         const uint64_t L = P.raw.recs[r].seq_len;
         const int64_t max_chunk = k + std::max<int64_t>(10, std::min<int64_t>(400, 2 * static_cast<int64_t>(std::sqrt(static_cast<int64_t>(L)))));   // src/main.cpp:330-331
@@ -453,7 +503,7 @@ void replay_batch(Prepared& P, StrandPredictor& predictor, Mode mode, bool order
             while (current_length >= k) {
                 const int64_t chunk_length = std::min<int64_t>(current_length, max_chunk);
                 const uint64_t n = static_cast<uint64_t>(chunk_length - k + 1);
-                replay_streaming_chunk(predictor, mode, orders, P, w, n, scratch);
+                replay_streaming_chunk(predictor, mode, orders, P, w, n);
                 w += n;
                 current_length -= static_cast<int64_t>(n);
             }
