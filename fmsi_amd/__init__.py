@@ -129,6 +129,8 @@ def lib() -> C.CDLL:
     L.fmsi_host_pack_2bit.restype = u64
     L.fmsi_cli_query.argtypes = [i32, C.POINTER(C.c_char_p), i32]
     L.fmsi_cli_index.argtypes = [i32, C.POINTER(C.c_char_p)]
+    L.fmsi_cli_export.argtypes = [i32, C.POINTER(C.c_char_p)]
+    L.fmsi_hip_index_export.argtypes = [vp, vp, u64, C.POINTER(u64)]
     L.fmsi_host_index_write.argtypes = [C.c_char_p, C.POINTER(IndexView)]
     L.fmsi_hip_index_write_files.argtypes = [vp, C.c_char_p]
     _lib = L
@@ -279,6 +281,14 @@ class DeviceIndex:
         mrank = np.zeros(nb + 1, dtype=np.uint32)
         _check(lib().fmsi_hip_index_download_layout(self._h, blocks.ctypes.data, mrank.ctypes.data))
         return blocks, mrank
+
+    def export(self) -> bytes:
+        """The masked superstring of the index (export_ms, reference src/fms_index.h:462-473), walked on the device."""
+        n = int(self.info.n) - 1
+        buf = C.create_string_buffer(max(1, n))
+        got = C.c_uint64()
+        _check(lib().fmsi_hip_index_export(self._h, buf, n, C.byref(got)))
+        return buf.raw[:int(got.value)]
 
     def write_files(self, prefix: str) -> None:
         """Write the index as the reference's <prefix>.fmsi.* files (fmsi_hip_index_write_files)."""

@@ -1,0 +1,135 @@
+// `fmsi export` on the device: counterpart of export_ms() (reference src/fms_index.h:462-473), SURVEY.md 8(f).4.
+//
+// The reference walks ONE chain: row 0 (the empty suffix) -> LF -> ... N steps, writing the text back to front
+// (letter = access(row), case = mask bit of the row it lands on).  The walk is a single path through all rows, so it
+// can be cut anywhere: every S-th row starts a chain that walks until it lands on another start row (or on the '$'
+// row, the end of the path).  Chain lengths are geometric with mean S because consecutive text positions sit at
+// unrelated rows.  Pass 1 measures every chain (length, landing row); the host strings the chains together from row 0
+// (one pointer chase per chain) and hands each its offset in the text; pass 2 walks again and writes the letters.
+// 2 N dependent 64-byte block reads spread over about a million lanes instead of N on one core.
+#include <hip/hip_runtime.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/fmsi_hip.h"
+#include "common.h"
+#include "device_fm.h"
+#include "index_priv.h"
+
+namespace fmsi {
+namespace {
+
+struct StepOut {
+    uint32_t letter, next_row, mask_at_next;
+};
+
+// access() + one LF step + the mask bit of the landing row (src/fms_index.h:88-95, 98-103, 468-470)
+__device__ __forceinline__ StepOut export_step(const DevIndex& ix, uint32_t row) {
+    const uint32_t* blk = reinterpret_cast<const uint32_t*>(ix.blocks) + (static_cast<size_t>(row >> kBlockRowsLog2) << 4);
+    const uint32_t o = row & (kBlockRows - 1u), w = o >> 5, sh = o & 31u;
+    StepOut s;
+    s.letter = (((blk[4 + w] >> sh) & 1u) << 1) | ((blk[8 + w] >> sh) & 1u);
+    uint32_t a = row, b = row + 1u, dummy = 0;
+    lf_step(ix, s.letter, a, b, dummy);
+    s.next_row = a;
+    s.mask_at_next = mask_bit(ix, a);
+    return s;
+}
+
+// chain c starts at row c * stride; it ends when it lands on a start row or on the '$' row
+__global__ __launch_bounds__(256) void export_measure_kernel(DevIndex ix, uint32_t stride, uint64_t n_chains, uint32_t* __restrict__ len,
+                                                             uint32_t* __restrict__ landing) {
+    const uint64_t c = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (c >= n_chains) return;
+    uint32_t row = static_cast<uint32_t>(c * stride), steps = 0;
+    if (row != ix.dollar) {
+        do {
+            row = export_step(ix, row).next_row;
+            ++steps;
+        } while (row != ix.dollar && row % stride != 0u);
+    }
+    len[c] = steps;
+    landing[c] = row;
+}
+
+// the chain's i-th letter is text position  last[c] - i  (last[c] = N - 1 - offset of the chain along the walk)
+__global__ __launch_bounds__(256) void export_write_kernel(DevIndex ix, uint32_t stride, uint64_t n_chains, const uint32_t* __restrict__ len,
+                                                           const uint64_t* __restrict__ last, char* __restrict__ out) {
+    const uint64_t c = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (c >= n_chains) return;
+    const uint32_t steps = len[c];
+    uint32_t row = static_cast<uint32_t>(c * stride);
+    uint64_t p = last[c];
+    for (uint32_t i = 0; i < steps; ++i, --p) {
+        const StepOut s = export_step(ix, row);
+        // masked_letters = "acgtACGT", src/fms_index.h:463
+        const uint32_t lower = s.letter == 0u ? 'a' : (s.letter == 1u ? 'c' : (s.letter == 2u ? 'g' : 't'));
+        out[p] = static_cast<char>(s.mask_at_next ? lower - 32u : lower);
+        row = s.next_row;
+    }
+}
+
+}  // namespace
+}  // namespace fmsi
+
+using namespace fmsi;
+
+extern "C" int fmsi_hip_index_export(const fmsi_hip_index* idx, char* out, uint64_t out_capacity, uint64_t* out_len) {
+    if (!idx || !out || !out_len) {
+        set_last_error("null argument");
+        return FMSI_HIP_EINVAL;
+    }
+    const uint64_t n = idx->n, text_len = n - 1;
+    *out_len = text_len;
+    if (out_capacity < text_len) {
+        set_last_error("output buffer too small: the superstring has " + std::to_string(text_len) + " bases");
+        return FMSI_HIP_EINVAL;
+    }
+    if (text_len == 0) return 0;
+    FMSI_HIP_TRY(hipSetDevice(idx->device));
+    // about a million chains, at least 64 rows apart
+    uint64_t stride64 = 64;
+    while ((n + stride64 - 1) / stride64 > (1ull << 20)) stride64 *= 2;
+    const uint32_t stride = static_cast<uint32_t>(stride64);
+    const uint64_t n_chains = (n + stride64 - 1) / stride64;
+    uint32_t *d_len = nullptr, *d_landing = nullptr;
+    uint64_t* d_last = nullptr;
+    char* d_out = nullptr;
+    auto cleanup = [&]() {
+        for (void* p : {static_cast<void*>(d_len), static_cast<void*>(d_landing), static_cast<void*>(d_last), static_cast<void*>(d_out)})
+            if (p) (void)hipFree(p);
+    };
+    auto fail = [&](int code, const std::string& msg) {
+        cleanup();
+        set_last_error(msg);
+        return code;
+    };
+    if (hipMalloc(reinterpret_cast<void**>(&d_len), n_chains * 4) != hipSuccess || hipMalloc(reinterpret_cast<void**>(&d_landing), n_chains * 4) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void**>(&d_last), n_chains * 8) != hipSuccess || hipMalloc(reinterpret_cast<void**>(&d_out), text_len) != hipSuccess)
+        return fail(FMSI_HIP_ENOMEM, "hipMalloc failed for the export buffers");
+    const dim3 grid(static_cast<uint32_t>((n_chains + 255) / 256)), block(256);
+    hipLaunchKernelGGL(export_measure_kernel, grid, block, 0, 0, idx->dev, stride, n_chains, d_len, d_landing);
+    std::vector<uint32_t> len(n_chains), landing(n_chains);
+    if (hipGetLastError() != hipSuccess || hipMemcpy(len.data(), d_len, n_chains * 4, hipMemcpyDeviceToHost) != hipSuccess ||
+        hipMemcpy(landing.data(), d_landing, n_chains * 4, hipMemcpyDeviceToHost) != hipSuccess)
+        return fail(FMSI_HIP_EHIP, "export: measuring the chains failed");
+    // string the chains together from row 0: chain c covers walk steps [offset, offset + len[c])
+    std::vector<uint64_t> last(n_chains, 0);
+    uint64_t offset = 0, c = 0, visited = 0;
+    for (;;) {
+        last[c] = text_len - 1 - offset;
+        offset += len[c];
+        ++visited;
+        const uint32_t row = landing[c];
+        if (row == idx->dev.dollar || visited > n_chains) break;
+        c = row / stride;
+    }
+    if (offset != text_len) return fail(FMSI_HIP_EHIP, "export: the LF walk from row 0 does not cover the text (corrupt index?)");
+    if (hipMemcpy(d_last, last.data(), n_chains * 8, hipMemcpyHostToDevice) != hipSuccess) return fail(FMSI_HIP_EHIP, "export: upload failed");
+    hipLaunchKernelGGL(export_write_kernel, grid, block, 0, 0, idx->dev, stride, n_chains, d_len, d_last, d_out);
+    if (hipGetLastError() != hipSuccess || hipMemcpy(out, d_out, text_len, hipMemcpyDeviceToHost) != hipSuccess)
+        return fail(FMSI_HIP_EHIP, "export: writing the text failed");
+    cleanup();
+    return 0;
+}

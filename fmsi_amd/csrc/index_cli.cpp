@@ -115,3 +115,71 @@ extern "C" int fmsi_cli_index(int argc, char** argv) {
         return 1;
     }
 }
+
+// ---- `fmsi export` (ms_export, reference src/main.cpp:508-541) ------------------------------------------------------
+#include "host_index.h"
+
+namespace {
+int usage_export() {
+    std::cerr << std::endl << "Usage:   fmsi export <index-prefix>" << std::endl << std::endl;
+    return 1;
+}
+
+int run_export(int argc, char** argv) {
+    bool usage = false;
+    int c;
+    std::string fn;
+    if (argc > 1 && std::string(argv[argc - 1]) != "-h") {
+        fn = argv[argc - 1];
+        argc--;
+    }
+    int device = 0;
+    static const option long_opts[] = {{"device", required_argument, nullptr, 1000}, {nullptr, 0, nullptr, 0}};
+    optind = 1;
+    while ((c = getopt_long(argc, argv, "h", long_opts, nullptr)) >= 0) {
+        switch (c) {
+        case 'h': usage = true; break;
+        case 1000: device = atoi(optarg); break;
+        default: return usage_export();
+        }
+    }
+    if (usage) {
+        usage_export();
+        return 0;
+    }
+    fmsi_host_index* host = nullptr;
+    if (fmsi_host_index_load(fn.c_str(), 0, &host) != 0 || host->ix.n() == 0) {
+        std::cerr << "ERROR: index not correctly loaded. Ensure that you correctly call `fmsi index` before." << std::endl;
+        return usage_export();
+    }
+    fmsi_index_view view;
+    fmsi_host_index_view(host, &view);
+    fmsi_hip_index* dev = nullptr;
+    if (fmsi_hip_index_create(&view, device, &dev) != 0) {
+        std::cerr << "ERROR: cannot create the device index: " << fmsi_hip_last_error() << std::endl;
+        fmsi_host_index_free(host);
+        return 1;
+    }
+    std::string ms(host->ix.n() - 1, '\0');
+    uint64_t len = 0;
+    const int rc = fmsi_hip_index_export(dev, ms.data(), ms.size(), &len);
+    fmsi_hip_index_destroy(dev);
+    fmsi_host_index_free(host);
+    if (rc != 0) {
+        std::cerr << "ERROR: export failed: " << fmsi_hip_last_error() << std::endl;
+        return 1;
+    }
+    std::cout << ">exported masked superstring" << std::endl;
+    std::cout << ms << std::endl;
+    return 0;
+}
+}  // namespace
+
+extern "C" int fmsi_cli_export(int argc, char** argv) {
+    try {
+        return run_export(argc, argv);
+    } catch (const std::exception& e) {
+        std::cerr << "ERROR: " << e.what() << std::endl;
+        return 1;
+    }
+}

@@ -1,5 +1,5 @@
 // `fmsi` command-line entry for the MI355X query path.  Only the sub-commands on the hot path are
-// provided (`index`, `query`, `lookup`; reference dispatcher: src/main.cpp:668-699); everything else of the
+// provided (`index`, `query`, `lookup`, `export`; reference dispatcher: src/main.cpp:668-699); everything else of the
 // reference's CLI (index construction, set operations, export, ...) is out of scope of this build and
 // says so instead of silently doing something different.
 #include <cstring>
@@ -18,7 +18,8 @@ static int usage() {
     std::cerr << "Command:" << std::endl;
     std::cerr << "    index   - Creates a BWT based index of the given masked superstring (suffix sort on the GPU)." << std::endl;
     std::cerr << "    query   - Queries k-mers against an index (reads the reference's .fmsi.* files)." << std::endl;
-    std::cerr << "    lookup  - Return unique hashes of present k-mers." << std::endl << std::endl;
+    std::cerr << "    lookup  - Return unique hashes of present k-mers." << std::endl;
+    std::cerr << "    export  - Export the underlying masked superstring." << std::endl << std::endl;
     std::cerr << "The index files are the reference's .fmsi.* format, in both directions." << std::endl << std::endl;
     return 1;
 }
@@ -29,6 +30,7 @@ int main(int argc, char* argv[]) {
     if (op == "query") return fmsi_cli_query(argc - 1, argv + 1, 0);
     if (op == "lookup") return fmsi_cli_query(argc - 1, argv + 1, 1);
     if (op == "index") return fmsi_cli_index(argc - 1, argv + 1);
+    if (op == "export") return fmsi_cli_export(argc - 1, argv + 1);
     if (op == "-v") {
         std::cout << FMSI_AMD_VERSION << std::endl;
         return 0;
@@ -37,7 +39,7 @@ int main(int argc, char* argv[]) {
         usage();
         return 0;
     }
-    if (op == "export" || op == "merge" || op == "compact" || op == "normalize" || op == "clean" ||
+    if (op == "merge" || op == "compact" || op == "normalize" || op == "clean" ||
         op == "union" || op == "inter" || op == "diff" || op == "symdiff") {
         std::cerr << "ERROR: `fmsi " << op << "` is not part of the MI355X query path; use the reference build for it." << std::endl;
         return 1;

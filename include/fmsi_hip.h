@@ -159,6 +159,13 @@ int fmsi_host_index_write(const char* prefix, const fmsi_index_view* view);
  * sub-command sees it (argv[0] = "index").  Returns the process exit code. */
 int fmsi_cli_index(int argc, char** argv);
 
+/* Replaces export_ms() (src/fms_index.h:462-473): the masked superstring of the index (upper case = mask 1), written
+ * to out[0 .. *out_len) without a terminator.  The reference's single LF chain of |MS| steps is cut into about a million
+ * chains walked concurrently on the device.  *out_len is set even when out_capacity is too small (FMSI_HIP_EINVAL). */
+int fmsi_hip_index_export(const fmsi_hip_index* idx, char* out, uint64_t out_capacity, uint64_t* out_len);
+/* The `fmsi export` command (ms_export, src/main.cpp:508-541); argv as the sub-command sees it. */
+int fmsi_cli_export(int argc, char** argv);
+
 /* Copies the handle's kLCP bit-vector back (ceil(n/64) words); fails when the handle has none. */
 int fmsi_hip_index_download_klcp(const fmsi_hip_index* idx, uint64_t* words);
 

@@ -151,6 +151,12 @@ def main():
     assert len({md5[f"repeats_k{k}.fmsi.klcp"] for k in (33, 34, 40, 64)}) == 4
     (idx / "md5.json").write_text(json.dumps(md5, indent=1, sort_keys=True) + "\n")
 
+    # 3c. `fmsi export` of every golden index gives the masked superstring back, case included (export_ms,
+    # src/fms_index.h:462-473) -- so the superstring files themselves are the goldens of export
+    for name, (src, k) in {**datasets, "repeats_k40": (HERE / "repeats.fa", 40)}.items():
+        res = run([REF_CLI, "export", idx / name])
+        assert res.stdout.decode() == ">exported masked superstring\n" + read_ms(src) + "\n", name
+
     # 4. query files
     edge = (
         ">e0\nACGN\n>e1\nACNAC\n>e2\nAC\n>e3 lower and invalid\nacgtNNacgta\n>e4\n\n>e5\nNACG\n>e6\nACGTACGTACG\n"

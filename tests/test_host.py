@@ -220,7 +220,9 @@ def test_cli_option_handling(product_built):
     assert rc == 1 and b"not available on the GPU path" in err
     rc, out, err = run(["-v"])
     assert rc == 0 and out.strip()
-    rc, out, err = run(["export", "x"])
+    rc, out, err = run(["merge", "x"])
     assert rc == 1 and b"not part of the MI355X query path" in err
+    rc, out, err = run(["export", "-h"])
+    assert rc == 0 and b"Usage:   fmsi export <index-prefix>" in err
     rc, out, err = run([])
     assert rc == 1
