@@ -51,7 +51,7 @@ def parse_args():
     ap.add_argument("--batch", type=float, default=float(1 << 27), help="query windows per step and GPU")
     ap.add_argument("--k", type=int, default=31)
     ap.add_argument("--prefix-len", type=int, default=-1,
-                    help="private prefix table length t (0 = none; default: 15 for isolated k-mers, 14 for streaming, less while 4^t > 2n)")
+                    help="private prefix table length t (0 = none; default: 16, less while 4^t > 4n)")
     ap.add_argument("--kernel", choices=["pair", "refill", "lockstep"], default="pair")
     ap.add_argument("--mode", choices=["all", "or"], default="all")
     ap.add_argument("--read-len", type=int, default=10000, help="stream workload: bases per read")
@@ -103,9 +103,9 @@ def main():
 
     n = int(args.n)
     k = args.k
-    if args.prefix_len < 0:   # measured on the human-scale index: t = 15 / 14 are the fastest (streaming loses request rate beyond 14)
-        args.prefix_len = min(k, 14 if stream_mode else 15)
-        while args.prefix_len > 0 and 4 ** args.prefix_len > 2 * n:
+    if args.prefix_len < 0:   # measured on the human-scale index: the largest table, t = 16 (34 GB), is the fastest
+        args.prefix_len = min(k, 16)
+        while args.prefix_len > 0 and 4 ** args.prefix_len > 4 * n:
             args.prefix_len -= 1
     t0 = time.time()
     index = fm.DeviceIndex.build_synthetic(n, args.seed, k, with_klcp=stream_mode, device=local_rank, prefix_len=args.prefix_len)

@@ -410,6 +410,7 @@ int build_from_device_text(DevBuf& text2, uint64_t len, DevBuf* mask_text, int k
     idx->dev.mrank = static_cast<const uint32_t*>(idx->d_mrank);
     idx->dev.ptable = nullptr;
     idx->dev.ptable_len = 0;
+    idx->dev.ptable_packed = 0;
     idx->dev.n = static_cast<uint32_t>(n);
     idx->dev.dollar = dollar_row;
     idx->dev.C0 = 1;                                            // counts = {1, #A+1, ...}, fms_index.h:451

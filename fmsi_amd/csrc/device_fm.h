@@ -82,6 +82,30 @@ __device__ __forceinline__ uint32_t mask_bit(const DevIndex& ix, uint32_t row) {
     return (w[(row & (kBlockRows - 1u)) >> 5] >> (row & 31u)) & 1u;
 }
 
+// Prefix-table entry -> interval [i, j).  Packed format (ptable_packed): x = i; y = tag << 30 | ...
+//   tag 0: y = j - i (< 2^30)
+//   tag 1: 1..3 rows; y = 1 << 30 | rows << 24 | sig2 << 16 | sig1 << 8 | sig0, where sig_m = the four text symbols
+//          preceding the suffix of row i + m (c1 << 6 | c2 << 4 | c3 << 2 | c4, c1 = BWT[row] = the next base the
+//          backward search consumes).  If the query still has >= 4 bases to go (have4) and its next four (q4, same
+//          packing) equal none of the signatures, the interval would be empty within four more update_range() calls --
+//          get_range_with_pattern() would return an empty range either way (src/fms_index.h:117-124), so it is returned
+//          empty right here and the block reads of those steps never happen.  A row whose preceding text is shorter
+//          than four symbols carries an arbitrary signature (a false match only costs the ordinary steps).
+__device__ __forceinline__ void decode_table_entry(uint32_t x, uint32_t y, uint32_t packed, bool have4, uint32_t q4, uint32_t& i, uint32_t& j) {
+    i = x;
+    if (!packed) {
+        j = y;
+        return;
+    }
+    if ((y >> 30) == 0u) {
+        j = x + y;
+        return;
+    }
+    const uint32_t rows = (y >> 24) & 3u;
+    const bool hit = (y & 0xFFu) == q4 || (rows > 1u && ((y >> 8) & 0xFFu) == q4) || (rows > 2u && ((y >> 16) & 0xFFu) == q4);
+    j = (have4 && !hit) ? x : x + rows;
+}
+
 // reverse complement of a 2-bit packed k-mer (base t in bits [2t,2t+1]); ReverseComplementString, src/kmers.h:53-59
 __device__ __forceinline__ uint64_t revcomp_2bit(uint64_t f, int k) {
     uint64_t x = ~f;                                                               // complement: 3 - c

@@ -300,9 +300,9 @@ __global__ __launch_bounds__(256) void query_refill_kernel(DevIndex ix, const ui
                 const uint32_t x1 = sel4(e, opaque(a0.y), opaque(a1.y), opaque(a2.y), opaque(a3.y));
                 const uint32_t x2 = sel4(e, opaque(a0.z), opaque(a1.z), opaque(a2.z), opaque(a3.z));
                 const uint32_t x3 = sel4(e, opaque(a0.w), opaque(a1.w), opaque(a2.w), opaque(a3.w));
-                i = (tidx & 1u) ? x2 : x0;
-                j = (tidx & 1u) ? x3 : x1;
                 t = k - 1 - T;
+                decode_table_entry((tidx & 1u) ? x2 : x0, (tidx & 1u) ? x3 : x1, ix.ptable_packed, t >= 3,
+                                   t >= 3 ? static_cast<uint32_t>(cur >> (2 * (t - 3))) & 0xFFu : 0u, i, j);
                 if (i == j) finalize(-1, -1);
                 else st = t < 0 ? ST_PROBE : ST_LF;
             }
@@ -363,6 +363,51 @@ __global__ __launch_bounds__(256) void ptable_level_kernel(DevIndex ix, const ui
     }
 }
 
+// longest interval of the final level (decides whether the packed entry format fits: lengths < 2^30)
+__global__ __launch_bounds__(256) void ptable_maxlen_kernel(const uint2* __restrict__ tab, uint64_t count, uint32_t* __restrict__ max_len) {
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
+    uint32_t m = 0;
+    for (uint64_t idx = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; idx < count; idx += stride) {
+        const uint2 e = tab[idx];
+        m = max(m, e.y - e.x);
+    }
+    for (int off = 32; off > 0; off >>= 1) m = max(m, static_cast<uint32_t>(__shfl_down(static_cast<int>(m), off, 64)));
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(max_len, m);
+}
+
+// (i, j) -> packed entries (decode_table_entry): intervals of 1..3 rows get the signatures of their rows
+__global__ __launch_bounds__(256) void ptable_pack_kernel(DevIndex ix, uint2* __restrict__ tab, uint64_t count) {
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
+    for (uint64_t idx = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; idx < count; idx += stride) {
+        const uint2 e = tab[idx];
+        const uint32_t len = e.y - e.x;
+        uint32_t y = len;
+        if (len >= 1u && len <= 3u) {
+            y = (1u << 30) | (len << 24);
+            for (uint32_t m = 0; m < len; ++m) {
+                uint32_t row = e.x + m, sig = 0;
+                bool alive = true;
+                for (int step = 0; step < 4; ++step) {
+                    uint32_t c = 0;
+                    if (alive && row != ix.dollar) {
+                        const uint32_t* blk = reinterpret_cast<const uint32_t*>(ix.blocks) + (static_cast<size_t>(row >> kBlockRowsLog2) << 4);
+                        const uint32_t o = row & (kBlockRows - 1u), w = o >> 5, sh = o & 31u;
+                        c = (((blk[4 + w] >> sh) & 1u) << 1) | ((blk[8 + w] >> sh) & 1u);   // access(), src/fms_index.h:88-95
+                        uint32_t a = row, b = row + 1u, dummy = 0;
+                        lf_step(ix, c, a, b, dummy);
+                        row = a;
+                    } else {
+                        alive = false;   // the text starts here: no such k-mer; any signature will do
+                    }
+                    sig = (sig << 2) | c;
+                }
+                y |= sig << (8u * m);
+            }
+        }
+        tab[idx] = make_uint2(e.x, y);
+    }
+}
+
 int build_prefix_table(fmsi_hip_index* idx, int t) {
     if (t <= 0) return 0;
     if (t > 16) {
@@ -403,6 +448,32 @@ int build_prefix_table(fmsi_hip_index* idx, int t) {
         (void)hipFree(a);
         set_last_error(std::string("prefix table build: ") + hipGetErrorString(e));
         return FMSI_HIP_EHIP;
+    }
+    // packed entries with next-base signatures, unless some interval is too long for the 30-bit length field
+    {
+        uint32_t* d_max = nullptr;
+        uint32_t h_max = 0;
+        const uint32_t blocks = static_cast<uint32_t>(std::min<uint64_t>((final_count + 255) / 256, 1u << 20));
+        if (hipMalloc(reinterpret_cast<void**>(&d_max), 4) != hipSuccess || hipMemset(d_max, 0, 4) != hipSuccess) {
+            (void)hipFree(a);
+            set_last_error("hipMalloc failed");
+            return FMSI_HIP_ENOMEM;
+        }
+        hipLaunchKernelGGL(ptable_maxlen_kernel, dim3(blocks), dim3(256), 0, 0, a, final_count, d_max);
+        hipError_t e2 = hipMemcpy(&h_max, d_max, 4, hipMemcpyDeviceToHost);
+        (void)hipFree(d_max);
+        idx->dev.ptable_packed = 0;
+        if (e2 == hipSuccess && h_max < (1u << 30)) {
+            hipLaunchKernelGGL(ptable_pack_kernel, dim3(blocks), dim3(256), 0, 0, idx->dev, a, final_count);
+            e2 = hipGetLastError();
+            if (e2 == hipSuccess) e2 = hipDeviceSynchronize();
+            idx->dev.ptable_packed = 1;
+        }
+        if (e2 != hipSuccess) {
+            (void)hipFree(a);
+            set_last_error(std::string("prefix table packing: ") + hipGetErrorString(e2));
+            return FMSI_HIP_EHIP;
+        }
     }
     idx->d_ptable = a;
     idx->dev.ptable = a;
@@ -609,6 +680,7 @@ int fmsi_hip_index_create(const fmsi_index_view* view, int device, fmsi_hip_inde
     idx->dev.mrank = static_cast<const uint32_t*>(idx->d_mrank);
     idx->dev.ptable = nullptr;
     idx->dev.ptable_len = 0;
+    idx->dev.ptable_packed = 0;
     idx->dev.n = static_cast<uint32_t>(idx->n);
     idx->dev.dollar = static_cast<uint32_t>(view->dollar_position);
     idx->dev.C0 = static_cast<uint32_t>(view->counts[0]);

@@ -52,7 +52,7 @@ struct PairIndex {
     const uint32_t* c2;       // 16 x C2[p]
     const uint32_t* mrank;    // n_blocks + 1 cumulative mask popcounts (shared with the single-step layout)
     const uint2* ptable;
-    uint32_t ptable_len;
+    uint32_t ptable_len, ptable_packed;
     uint32_t n, r0, r1, p1;   // rows; row of suffix 0 ('$' slot); row of suffix 1; pair index stored for r1
     uint32_t C0, C1, C2_, C3;
 };
@@ -428,9 +428,9 @@ __global__ __launch_bounds__(256) void query_pair_kernel(PairIndex ix, const uin
                 const uint4 v = (e & 2u) ? A.u1 : A.u0;
                 const uint32_t xi = (e & 1u) ? v.z : v.x, xj = (e & 1u) ? v.w : v.y;
                 const int src = static_cast<int>(pbase | (e >> 2));
-                i = static_cast<uint32_t>(__shfl(static_cast<int>(xi), src, 64));
-                j = static_cast<uint32_t>(__shfl(static_cast<int>(xj), src, 64));
                 t = k - 1 - T;
+                decode_table_entry(static_cast<uint32_t>(__shfl(static_cast<int>(xi), src, 64)), static_cast<uint32_t>(__shfl(static_cast<int>(xj), src, 64)),
+                                   ix.ptable_packed, t >= 3, t >= 3 ? static_cast<uint32_t>(cur >> (2 * (t - 3))) & 0xFFu : 0u, i, j);
                 if (i == j) finalize(-1, -1);
                 else st = t < 0 ? PS_PROBE : PS_STEP;
             }
@@ -467,6 +467,7 @@ PairIndex make_pair_index(const fmsi_hip_index* idx) {
     p.mrank = idx->dev.mrank;
     p.ptable = idx->dev.ptable;
     p.ptable_len = idx->dev.ptable_len;
+    p.ptable_packed = idx->dev.ptable_packed;
     p.n = idx->dev.n;
     p.r0 = idx->dev.dollar;
     p.r1 = idx->pair_r1;

@@ -430,9 +430,10 @@ __global__ __launch_bounds__(256) void query_stream_kernel(DevIndex ix, const ui
                 const uint32_t x1 = sel4(e, opaque(a0.y), opaque(a1.y), opaque(a2.y), opaque(a3.y));
                 const uint32_t x2 = sel4(e, opaque(a0.z), opaque(a1.z), opaque(a2.z), opaque(a3.z));
                 const uint32_t x3 = sel4(e, opaque(a0.w), opaque(a1.w), opaque(a2.w), opaque(a3.w));
-                i = (tidx & 1u) ? x2 : x0;
-                j = (tidx & 1u) ? x3 : x1;
                 t = k - 1 - T;
+                uint32_t q4 = 0;
+                if (t >= 3) q4 = kmer_base(t - 3) | (kmer_base(t - 2) << 2) | (kmer_base(t - 1) << 4) | (kmer_base(t) << 6);
+                decode_table_entry((tidx & 1u) ? x2 : x0, (tidx & 1u) ? x3 : x1, ix.ptable_packed, t >= 3, q4, i, j);
                 if (i == j) {
                     window_done(-1, -1);
                     advance(false);

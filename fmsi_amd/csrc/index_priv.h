@@ -23,6 +23,7 @@ struct DevIndex {
     uint32_t dollar;          // dollar_position
     uint32_t C0, C1, C2, C3;  // counts[] (src/fms_index.h:451)
     uint32_t ptable_len;      // t
+    uint32_t ptable_packed;   // entry format: 0 = (i, j); 1 = (i, tagged word) with next-base signatures, see decode_table_entry
 };
 
 #define FMSI_HIP_TRY(expr)                                                                                 \

@@ -670,11 +670,11 @@ extern "C" int fmsi_cli_query(int argc, char** argv, int output_orders_i) {
     fmsi_hip_index* dev = nullptr;
     fmsi_index_view view;
     fmsi_host_index_view(host, &view);
-    // private accelerators (results unchanged): a prefix table of up to 15 (streaming: 14) steps -- the sizes measured
-    // fastest at human scale; 4^t entries of 8 bytes, smaller while the table would have more than 2n
-    // entries -- and, for non-streaming queries, the two-base-step pair layout
-    int t = std::min(k, opt.has_klcp ? 14 : 15);
-    while (t > 0 && (1ull << (2 * t)) > 2 * host->ix.n()) --t;
+    // private accelerators (results unchanged): a prefix table of up to 16 steps (4^t entries of 8 bytes with next-base
+    // signatures; smaller while the table would have more than 4n entries) and, for non-streaming queries,
+    // the two-base-step pair layout
+    int t = std::min(k, 16);
+    while (t > 0 && (1ull << (2 * t)) > 4 * host->ix.n()) --t;
     view.prefix_len = t;
     if (fmsi_hip_index_create(&view, opt.device, &dev) != 0 || (!opt.has_klcp && fmsi_hip_index_enable_pair_layout(dev) != 0)) {
         std::cerr << "ERROR: cannot create the device index: " << fmsi_hip_last_error() << std::endl;
