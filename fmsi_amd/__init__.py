@@ -28,6 +28,7 @@ DEVICE_PTRS = 0x8
 KERNEL_LOCKSTEP = 0x10
 KERNEL_REFILL = 0x20
 KERNEL_PAIR = 0x30
+KERNEL_PHASED = 0x40
 NO_PREFIX_TABLE = 0x100
 N_COUNTERS = 8
 

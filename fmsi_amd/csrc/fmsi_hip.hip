@@ -526,7 +526,10 @@ int launch_query(fmsi_hip_index* idx, const uint64_t* d_kmers, uint64_t n_window
             hipLaunchKernelGGL((query_lockstep_kernel<true>), grid, block, 0, s, idx->dev, d_kmers, n_windows, k, flags, o8, o64, d_counters);
         else
             hipLaunchKernelGGL((query_lockstep_kernel<false>), grid, block, 0, s, idx->dev, d_kmers, n_windows, k, flags, o8, o64, d_counters);
-    } else if (kernel == FMSI_HIP_KERNEL_PAIR || (kernel == FMSI_HIP_KERNEL_AUTO && idx->d_pblocks)) {
+    } else if ((kernel == FMSI_HIP_KERNEL_PHASED || kernel == FMSI_HIP_KERNEL_AUTO) && idx->d_pblocks && use_table) {
+        if ((rc = launch_phased_query(idx, d_kmers, n_windows, k, flags, o8, o64, d_counters, s))) return rc;
+    } else if (kernel == FMSI_HIP_KERNEL_PAIR || kernel == FMSI_HIP_KERNEL_PHASED || (kernel == FMSI_HIP_KERNEL_AUTO && idx->d_pblocks)) {
+        // (PHASED without a usable table is the one-kernel form)
         if (!idx->d_pblocks) {
             set_last_error("FMSI_HIP_KERNEL_PAIR needs fmsi_hip_index_enable_pair_layout() on this handle");
             return FMSI_HIP_EINVAL;

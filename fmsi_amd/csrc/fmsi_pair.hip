@@ -51,6 +51,7 @@ struct PairIndex {
     const uint32_t* sbt;      // n_super x 16 absolute pair counts
     const uint32_t* c2;       // 16 x C2[p]
     const uint32_t* mrank;    // n_blocks + 1 cumulative mask popcounts (shared with the single-step layout)
+    const uint4* sblocks;     // the single-step layout (its mask plane serves the explicit probes)
     const uint2* ptable;
     uint32_t ptable_len, ptable_packed;
     uint32_t n, r0, r1, p1;   // rows; row of suffix 0 ('$' slot); row of suffix 1; pair index stored for r1
@@ -80,12 +81,11 @@ __global__ __launch_bounds__(256) void pair_emit_kernel(DevIndex ix, uint32_t* _
     const uint64_t row64 = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     const bool valid = row64 < ix.n;
     const uint32_t row = static_cast<uint32_t>(row64);
-    uint32_t c1 = 0, c2 = 0, mbit = 0;
+    uint32_t c1 = 0, c2 = 0, mbit = 0;   // mbit = mask[LF2(row)]: the mask bit of the row a pair step through this row lands on
     if (valid) {
         const uint32_t* blk = reinterpret_cast<const uint32_t*>(ix.blocks) + (static_cast<size_t>(row >> kBlockRowsLog2) << 4);
         const uint32_t o = row & (kBlockRows - 1u), w = o >> 5, sh = o & 31u;
         c1 = (((blk[4 + w] >> sh) & 1u) << 1) | ((blk[8 + w] >> sh) & 1u);
-        mbit = (blk[12 + w] >> sh) & 1u;
         if (row != ix.dollar) {
             uint32_t a = row, b = row + 1u, dummy = 0;
             lf_step(ix, c1, a, b, dummy);                 // a = LF(row)
@@ -96,6 +96,9 @@ __global__ __launch_bounds__(256) void pair_emit_kernel(DevIndex ix, uint32_t* _
                 const uint32_t* tb = reinterpret_cast<const uint32_t*>(ix.blocks) + (static_cast<size_t>(a >> kBlockRowsLog2) << 4);
                 const uint32_t o2 = a & (kBlockRows - 1u), w2 = o2 >> 5, sh2 = o2 & 31u;
                 c2 = (((tb[4 + w2] >> sh2) & 1u) << 1) | ((tb[8 + w2] >> sh2) & 1u);
+                uint32_t a2 = a, b2 = a + 1u;
+                lf_step(ix, c2, a2, b2, dummy);               // a2 = LF(LF(row))
+                mbit = mask_bit(ix, a2);
             }
         }
     }
@@ -151,6 +154,91 @@ __global__ void pair_counts_kernel(const U16* __restrict__ scanned, uint64_t n_b
     }
 }
 
+// ---- phase 1 of the phased path: the table lookups ------------------------------------------------------------------
+// With the next-base signatures in the table most absent k-mers are settled by their two lookups.  Doing the lookups
+// in a kernel of their own -- dense, no state machine -- and handing only the searches that are still alive to the
+// stepping kernel keeps that kernel's lanes in one state (measured: the one-kernel form spends its time serialising
+// lookup / step / finalize branches and reaches 40 G requests/s on a half-absent batch, against 50 G/s on all-present
+// and 44 G/s on all-absent ones).
+// A lookup is done by a LANE PAIR, each lane loading its 32 bytes of the entry's 64-byte line: measured on this table
+// (34 GB, random lines) 46 G lookups/s, against 17 G/s when every lane fetches a line of its own -- two adjacent
+// lanes on one line cost the memory path one request, 64 different lines per instruction cost it more than twice 32.
+// Result per k-mer: one 8-byte record, (i, j) of the strand that is alive after the table -- stored as (j, i) when that
+// is the reverse complement (the forward strand died in the table) -- or (0, 0) when both strands died.
+template <bool COUNT>
+__global__ __launch_bounds__(256) void pair_lookup_kernel(PairIndex ix, const uint64_t* __restrict__ kmers, uint64_t n_windows, int k, uint32_t flags,
+                                                          long long* __restrict__ out_orders, uint2* __restrict__ rec,
+                                                          unsigned long long* __restrict__ counters) {
+    const uint32_t strict = flags & FMSI_HIP_STRICT;
+    const uint32_t orders = flags & FMSI_HIP_ORDERS;
+    const int T = static_cast<int>(ix.ptable_len);
+    const int t = k - 1 - T;
+    const uint32_t tmask = static_cast<uint32_t>((1ull << (2 * T)) - 1ull);
+    const uint64_t stride = (static_cast<uint64_t>(gridDim.x) * blockDim.x) >> 1;
+    const uint32_t sub = threadIdx.x & 1u;
+    const int pbase = static_cast<int>(threadIdx.x & 63u & ~1u);
+    uint32_t n_lookups = 0, n_final = 0;
+    const uint64_t n_round = (n_windows + 31) & ~31ull;   // whole waves stay in the loop: the shuffles below need both lanes of a pair
+    for (uint64_t q = (static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 1; q < n_round; q += stride) {
+        const bool valid = q < n_windows;
+        const uint64_t f = valid ? kmers[q] : 0ull;
+        uint32_t i = 0, j = 0;
+        uint64_t cur = f;
+        bool alive = false, second = false;
+        for (int strand = 0; strand < 2; ++strand) {
+            const bool go = valid && !alive;   // every mode searches the reverse complement when the forward strand is absent (src/fms_index.h:283-299)
+            if (!__any(go)) break;
+            const uint32_t tidx = static_cast<uint32_t>(cur >> (2 * (k - T))) & tmask;
+            const uint4* p4 = reinterpret_cast<const uint4*>(ix.ptable + (tidx & ~7u)) + sub * 2u;
+            uint4 u0 = make_uint4(0, 0, 0, 0), u1 = u0;
+            if (go) {
+                u0 = p4[0];
+                u1 = p4[1];
+            }
+            // entry e of the 8-entry line sits in lane e >> 2 of the pair, slot e & 3 of its 32 bytes
+            const uint32_t e = tidx & 7u;
+            const uint4 v = (e & 2u) ? u1 : u0;
+            const uint32_t xi = (e & 1u) ? v.z : v.x, xj = (e & 1u) ? v.w : v.y;
+            const int src = pbase | static_cast<int>(e >> 2);
+            const uint32_t ex = static_cast<uint32_t>(__shfl(static_cast<int>(xi), src, 64)), ey = static_cast<uint32_t>(__shfl(static_cast<int>(xj), src, 64));
+            if (go) {
+                decode_table_entry(ex, ey, ix.ptable_packed, t >= 3, t >= 3 ? static_cast<uint32_t>(cur >> (2 * (t - 3))) & 0xFFu : 0u, i, j);
+                alive = i != j;
+                second = strand == 1;
+                if (sub == 0u) n_lookups++;
+                cur = revcomp_2bit(f, k);
+            }
+        }
+        if (valid && sub == 0u) {
+            rec[q] = alive ? (second ? make_uint2(j, i) : make_uint2(i, j)) : make_uint2(0u, 0u);
+            if (!alive) {
+                n_final++;
+                if (orders) {   // presence modes: the stepping kernel writes the 0 with its chunk's other result bytes
+                    if (strict) {
+                        out_orders[2 * q] = -1;
+                        out_orders[2 * q + 1] = -1;
+                    } else {
+                        out_orders[q] = -1;
+                    }
+                }
+            }
+        }
+    }
+    if (COUNT) {
+        uint32_t v[3] = {n_lookups, n_lookups, n_final};   // strand searches started = table lookups = lines read
+        const int slot[3] = {3, 4, 6};
+#pragma unroll
+        for (int qq = 0; qq < 3; ++qq) {
+            uint32_t x = v[qq];
+            for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+            if ((threadIdx.x & 63u) == 0 && x) {
+                atomicAdd(&counters[slot[qq]], static_cast<unsigned long long>(x));
+                if (qq == 0) atomicAdd(&counters[1], static_cast<unsigned long long>(x));   // [1] counts the table lines with the blocks
+            }
+        }
+    }
+}
+
 // ---- query kernel -----------------------------------------------------------------------------------------
 enum : uint32_t { PS_IDLE = 0, PS_LOOKUP = 1, PS_STEP = 2, PS_PROBE = 3 };
 
@@ -174,24 +262,42 @@ __device__ __forceinline__ uint32_t half_count(const Half& H, uint32_t m, bool s
     return ((lw >> (16u * (m & 1u))) & 0xFFFFu) | (((hw >> (8u * (m & 3u))) & 0xFFu) << 16);
 }
 
-// rows of this half matching pair p (or symbol c1 = p >> 2 when single) among its first `o` rows (o may be <= 0 or >= 64)
-__device__ __forceinline__ uint32_t half_match(const Half& H, uint32_t p, bool single, int o) {
+// rows of this half matching pair p (or symbol c1 = p >> 2 when single): one bit per row
+__device__ __forceinline__ void half_bits(const Half& H, uint32_t p, bool single, uint32_t& m0, uint32_t& m1) {
     const uint32_t x1h = (p & 8u) ? 0u : 0xFFFFFFFFu, x1l = (p & 4u) ? 0u : 0xFFFFFFFFu;
     const uint32_t x2h = (p & 2u) ? 0u : 0xFFFFFFFFu, x2l = (p & 1u) ? 0u : 0xFFFFFFFFu;
     const uint32_t all = single ? 0xFFFFFFFFu : 0u;   // single step: the c2 planes do not restrict
-    const uint32_t m0 = (H.u0.x ^ x1h) & (H.u0.z ^ x1l) & ((H.u1.x ^ x2h) | all) & ((H.u1.z ^ x2l) | all);
-    const uint32_t m1 = (H.u0.y ^ x1h) & (H.u0.w ^ x1l) & ((H.u1.y ^ x2h) | all) & ((H.u1.w ^ x2l) | all);
-    return __popc(m0 & prefix32(o)) + __popc(m1 & prefix32(o - 32));
+    m0 = (H.u0.x ^ x1h) & (H.u0.z ^ x1l) & ((H.u1.x ^ x2h) | all) & ((H.u1.z ^ x2l) | all);
+    m1 = (H.u0.y ^ x1h) & (H.u0.w ^ x1l) & ((H.u1.y ^ x2h) | all) & ((H.u1.w ^ x2l) | all);
+}
+// ... among the half's first `o` rows (o may be <= 0 or >= 64)
+__device__ __forceinline__ uint32_t bits_below(uint32_t m0, uint32_t m1, int o) { return __popc(m0 & prefix32(o)) + __popc(m1 & prefix32(o - 32)); }
+// drops row `row` from my half's bits of block `blk` (rows that are stored as 'A' but stand for no symbol)
+__device__ __forceinline__ void drop_row(uint32_t row, uint32_t blk, uint32_t sub, uint32_t& m0, uint32_t& m1) {
+    if ((row >> kBlockRowsLog2) == blk && ((row >> 6) & 1u) == sub) {
+        const uint32_t b = row & 63u;
+        if (b < 32u) m0 &= ~(1u << b);
+        else m1 &= ~(1u << (b - 32u));
+    }
+}
+// first set bit of (r0, r1) -> 2 | mask bit at that row; 0 if none
+__device__ __forceinline__ uint32_t first_hit(uint32_t r0, uint32_t r1, uint32_t k0, uint32_t k1) {
+    if (r0) return 2u | ((k0 >> (__ffs(static_cast<int>(r0)) - 1)) & 1u);
+    if (r1) return 2u | ((k1 >> (__ffs(static_cast<int>(r1)) - 1)) & 1u);
+    return 0u;
 }
 
 struct PairCounters {
     uint32_t lf_steps = 0, blocks = 0, probes = 0, searches = 0, lookups = 0;
 };
 
-template <bool COUNT, bool PTABLE>
+// LIST: phase 2 of the phased path -- rec[q] holds what pair_lookup_kernel found for k-mer q; the k-mers whose record is
+// dead get their 0 here, the others enter the state machine after their table lookup.
+template <bool COUNT, bool PTABLE, bool LIST>
 __global__ __launch_bounds__(256) void query_pair_kernel(PairIndex ix, const uint64_t* __restrict__ kmers, uint64_t n_windows, int k,
                                                          uint32_t flags, uint32_t chunk, uint32_t n_super, uint8_t* __restrict__ out,
-                                                         long long* __restrict__ out_orders, unsigned long long* __restrict__ counters) {
+                                                         long long* __restrict__ out_orders, unsigned long long* __restrict__ counters,
+                                                         const uint2* __restrict__ rec) {
     // LDS: C2[16] and the superblock table (every step needs three of their words; as global loads -- even cache hits --
     // they compete with the block reads for the memory pipeline), and per wave a ring of 128 k-mers and the chunk's
     // result bytes, so that k-mers arrive and results leave in whole cache lines instead of one request each.
@@ -205,8 +311,10 @@ __global__ __launch_bounds__(256) void query_pair_kernel(PairIndex ix, const uin
     const uint32_t orders = flags & FMSI_HIP_ORDERS;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wib = threadIdx.x >> 6;          // wave in block
-    uint64_t* ring = reinterpret_cast<uint64_t*>(lds + tbl_words) + wib * 128u;
-    uint8_t* obuf = reinterpret_cast<uint8_t*>(lds + tbl_words + 4u * 256u) + wib * 2048u;
+    constexpr uint32_t kRingWords = LIST ? 640u : 256u;   // per wave: 128 k-mers (+ LIST: their (i, j) and chunk-relative index)
+    uint64_t* ring = reinterpret_cast<uint64_t*>(lds + tbl_words) + wib * (kRingWords / 2u);
+    uint8_t* obuf = reinterpret_cast<uint8_t*>(lds + tbl_words + 4u * kRingWords) + wib * 2048u;
+    uint32_t* ring_ql = reinterpret_cast<uint32_t*>(ring + 256);   // LIST only
     const uint32_t sub = lane & 1u;                 // my half
     const uint32_t pbase = lane & ~1u;              // first lane of my pair
     const uint64_t pairs_below = (1ull << pbase) - 1ull;
@@ -214,8 +322,10 @@ __global__ __launch_bounds__(256) void query_pair_kernel(PairIndex ix, const uin
     const uint64_t start = wave * chunk;                                               // my chunk: [start, start + len)
     const uint32_t len = start < n_windows ? static_cast<uint32_t>(min(static_cast<uint64_t>(chunk), n_windows - start)) : 0u;
     uint32_t next = 0, loaded = 0;                  // wave-uniform: handed out / landed in the ring (relative to start)
-    uint64_t pend = 0;                              // k-mer batch in flight from global memory
+    uint64_t pend = 0, pend_ij = 0;                 // k-mer (+ LIST: record) batch in flight from global memory
     bool pend_valid = false;
+    uint32_t fetched = 0;                           // LIST: records consumed from the chunk (`loaded` then counts the live ones)
+    const uint64_t lanes_lt = (1ull << lane) - 1ull;
     const int T = PTABLE ? static_cast<int>(ix.ptable_len) : 0;
     const int shift = static_cast<int>(sub * 64u);  // first row of my half within the block
 
@@ -276,8 +386,24 @@ __global__ __launch_bounds__(256) void query_pair_kernel(PairIndex ix, const uin
     for (;;) {
         // (0) the batch of k-mers requested last iteration has arrived: land it in the ring
         if (pend_valid) {
-            ring[(loaded + lane) & 127u] = pend;
-            loaded = min(len, loaded + 64u);
+            if (LIST) {   // only the k-mers still alive after the table enter the ring; the others are absent: result 0
+                const uint32_t idx = fetched + lane;
+                const bool in = idx < len;
+                const bool alive = in && static_cast<uint32_t>(pend_ij) != static_cast<uint32_t>(pend_ij >> 32);
+                if (in && !alive && !orders) obuf[idx] = 0;   // also the STRICT code of (-1, -1)
+                const uint64_t m = __ballot(alive);
+                if (alive) {
+                    const uint32_t pos = (loaded + static_cast<uint32_t>(__popcll(m & lanes_lt))) & 127u;
+                    ring[pos] = pend;
+                    ring[128u + pos] = pend_ij;
+                    ring_ql[pos] = idx;
+                }
+                loaded += static_cast<uint32_t>(__popcll(m));
+                fetched = min(len, fetched + 64u);
+            } else {
+                ring[(loaded + lane) & 127u] = pend;
+                loaded = min(len, loaded + 64u);
+            }
             pend_valid = false;
         }
         // (1) idle lane pairs draw the next k-mers of the chunk: ballot + prefix rank over a wave-uniform cursor
@@ -288,22 +414,41 @@ __global__ __launch_bounds__(256) void query_pair_kernel(PairIndex ix, const uin
                 const uint32_t rank = static_cast<uint32_t>(__popcll(m & pairs_below));
                 const uint32_t avail = loaded - next;
                 if (want && rank < avail) {
-                    q = next + rank;
-                    f = ring[q & 127u];
+                    const uint32_t slot = (next + rank) & 127u;
+                    f = ring[slot];
                     phase = 0;
-                    start_strand(f);
+                    if (LIST) {   // the strand's table lookup is done: straight to the steps
+                        const uint64_t ij = ring[128u + slot];
+                        q = ring_ql[slot];
+                        const uint32_t x = static_cast<uint32_t>(ij), y = static_cast<uint32_t>(ij >> 32);
+                        phase = x > y ? 1u : 0u;       // (j, i): the forward strand died in the table, this is the reverse complement
+                        i = min(x, y);
+                        j = max(x, y);
+                        cur = phase ? revcomp_2bit(f, k) : f;
+                        res_f = -1;
+                        ord_f = -1;
+                        t = k - 1 - T;
+                        st = t < 0 ? PS_PROBE : PS_STEP;
+                    } else {
+                        q = next + rank;
+                        start_strand(f);
+                    }
                 }
                 next += min(static_cast<uint32_t>(__popcll(m)), avail);
             }
         }
         // (2) keep the ring ahead of the cursor: one coalesced 512-byte read per 64 k-mers, consumed next iteration
-        if (!pend_valid && loaded < len && loaded - next <= 64u) {
-            const uint32_t idx = loaded + lane;
+        if (!pend_valid && (LIST ? fetched : loaded) < len && loaded - next <= 64u) {
+            const uint32_t idx = (LIST ? fetched : loaded) + lane;
             pend = idx < len ? kmers[start + idx] : 0ull;
+            if (LIST) {
+                const uint2 r = idx < len ? rec[start + idx] : make_uint2(0u, 0u);
+                pend_ij = static_cast<uint64_t>(r.x) | (static_cast<uint64_t>(r.y) << 32);
+            }
             pend_valid = true;
         }
         if (!__any(st != PS_IDLE)) {
-            if (next >= len && !pend_valid) break;
+            if (LIST ? (fetched >= len && next >= loaded && !pend_valid) : (next >= len && !pend_valid)) break;
             continue;
         }
         if (st != PS_IDLE) {
@@ -336,11 +481,16 @@ __global__ __launch_bounds__(256) void query_pair_kernel(PairIndex ix, const uin
                 B.u2 = pj4[2];
                 B.u3 = pj4[3];
             }
-            A.u0 = pi4[0];
-            A.u1 = pi4[1];
-            if (!lookup) {
-                A.u2 = pi4[2];
-                A.u3 = pi4[3];
+            if (st == PS_PROBE) {   // explicit probe: the mask plane (128 rows) of the single-step block of row i
+                A.u0 = A.u1 = z;
+                A.u2 = ix.sblocks[(static_cast<size_t>(bi) << 2) + 3u];
+            } else {
+                A.u0 = pi4[0];
+                A.u1 = pi4[1];
+                if (!lookup) {
+                    A.u2 = pi4[2];
+                    A.u3 = pi4[3];
+                }
             }
             if (st == PS_STEP) {   // C2 and the superblock table come from LDS
                 // pair step -> count p; single step -> my half's share of the four counts with c1 = p >> 2 (summed below)
@@ -360,8 +510,38 @@ __global__ __launch_bounds__(256) void query_pair_kernel(PairIndex ix, const uin
 
             if (st == PS_STEP) {
                 const int oi = static_cast<int>(i & (kBlockRows - 1u)) - shift, oj = static_cast<int>(j - (bj << kBlockRowsLog2)) - shift;
-                uint32_t ri = pair_sum(half_match(A, p, single, oi));
-                uint32_t rj = pair_sum(half_match(B, p, single, oj));
+                uint32_t ma0, ma1, mb0, mb1;
+                half_bits(A, p, single, ma0, ma1);
+                half_bits(B, p, single, mb0, mb1);
+                uint32_t ri = pair_sum(bits_below(ma0, ma1, oi));
+                uint32_t rj = pair_sum(bits_below(mb0, mb1, oj));
+                // The last step of a search also answers it when the block(s) at hand cover the whole interval: the
+                // rows of [i, j) that match the pair are exactly the rows of the new interval, in order, and the block's
+                // mask plane holds mask[LF2(row)] -- infer_presence() (src/fms_index.h:126-144) without another read.
+                int folded = -2;   // -2: not folded
+                if (!single && t == 1 && !orders && bj - bi <= 1u) {
+                    const uint32_t same = two ? 0u : 0xFFFFFFFFu;
+                    uint32_t ra0 = ma0 & ~prefix32(oi) & (prefix32(oj) | ~same), ra1 = ma1 & ~prefix32(oi - 32) & (prefix32(oj - 32) | ~same);
+                    uint32_t rb0 = two ? (mb0 & prefix32(oj)) : 0u, rb1 = two ? (mb1 & prefix32(oj - 32)) : 0u;
+                    drop_row(ix.r0, bi, sub, ra0, ra1);
+                    drop_row(ix.r1, bi, sub, ra0, ra1);
+                    drop_row(ix.r0, bj, sub, rb0, rb1);
+                    drop_row(ix.r1, bj, sub, rb0, rb1);
+                    if (mode_all) {   // mask bit of the interval's first row
+                        const uint32_t mine = first_hit(ra0, ra1, A.u2.x, A.u2.y), mineb = first_hit(rb0, rb1, B.u2.x, B.u2.y);
+                        const uint32_t packed = mine | (mineb << 2);
+                        const uint32_t other = static_cast<uint32_t>(__shfl_xor(static_cast<int>(packed), 1, 64));
+                        const uint32_t lo = sub == 0u ? packed : other, hi = sub == 0u ? other : packed;   // rows 0-63, rows 64-127
+                        const uint32_t h = (lo & 2u) ? lo : ((hi & 2u) ? hi : (((lo >> 2) & 2u) ? (lo >> 2) : (hi >> 2)));
+                        if (h & 2u) folded = static_cast<int>(h & 1u);
+                    } else {          // any ON row in the interval
+                        const uint32_t any = (ra0 & A.u2.x) | (ra1 & A.u2.y) | (rb0 & B.u2.x) | (rb1 & B.u2.y);
+                        const uint32_t have = ra0 | ra1 | rb0 | rb1;
+                        const uint32_t packed = (any ? 1u : 0u) | (have ? 2u : 0u);
+                        const uint32_t both = packed | static_cast<uint32_t>(__shfl_xor(static_cast<int>(packed), 1, 64));
+                        if (both & 2u) folded = static_cast<int>(both & 1u);
+                    }
+                }
                 // cumulative counts live in the half of c1 = p >> 2: half (p >> 3), slot p & 7
                 const int owner = static_cast<int>(pbase | (p >> 3));
                 ri += static_cast<uint32_t>(__shfl(static_cast<int>(half_count(A, p & 7u, single)), owner, 64));
@@ -395,28 +575,35 @@ __global__ __launch_bounds__(256) void query_pair_kernel(PairIndex ix, const uin
                     t -= 2;
                     if (COUNT && sub == 0) cn.lf_steps += 2;
                 }
-                if (i == j) finalize(-1, -1);
-                else if (t < 0) st = PS_PROBE;
+                if (i == j) {
+                    finalize(-1, -1);
+                } else if (t < 0) {
+                    if (folded >= 0) {
+                        if (COUNT && sub == 0) cn.probes++;
+                        finalize(folded, -1);
+                    } else {
+                        st = PS_PROBE;
+                    }
+                }
             } else if (st == PS_PROBE) {
                 if (COUNT && sub == 0) cn.probes++;
+                // Only what the last step could not answer itself comes here: lookup (the order needs the landing row's
+                // rank), intervals spanning more than two blocks, searches that end on a single-base step or in the table.
                 const uint32_t o = i & (kBlockRows - 1u);
-                const int oi = static_cast<int>(o) - shift;
                 int res;
                 long long ord = -1;
                 if (mode_all && !orders) {
-                    const uint32_t mw = (o & 32u) ? A.u2.y : A.u2.x;                // valid in the lane that owns row i
-                    const uint32_t bit = (mw >> (o & 31u)) & 1u;
-                    res = __shfl(static_cast<int>(bit), static_cast<int>(pbase | (o >> 6)), 64);
+                    const uint32_t mw = sel4(o >> 5, opaque(A.u2.x), opaque(A.u2.y), opaque(A.u2.z), opaque(A.u2.w));
+                    res = static_cast<int>((mw >> (o & 31u)) & 1u);
                 } else {
-                    const int oj = static_cast<int>(j - (bj << kBlockRowsLog2)) - shift;
-                    const uint32_t below_i = pair_sum(__popc(A.u2.x & prefix32(oi)) + __popc(A.u2.y & prefix32(oi - 32)));
+                    const uint32_t oj = j - (bj << kBlockRowsLog2);
+                    const uint32_t below_i = popc_prefix128(A.u2, o);
                     uint32_t ones;
                     if (bj == bi) {
-                        ones = pair_sum(__popc(A.u2.x & prefix32(oj)) + __popc(A.u2.y & prefix32(oj - 32))) - below_i;
+                        ones = popc_prefix128(A.u2, oj) - below_i;
                     } else {   // interval spans blocks (long repeats): rank difference through the side array
-                        const uint32_t* mjp = ix.pb + static_cast<size_t>(bj) * kPairBlockDwords + sub * 16u + 8u;
-                        const uint32_t mj0 = mjp[0], mj1 = mjp[1];
-                        ones = (ix.mrank[bj] + pair_sum(__popc(mj0 & prefix32(oj)) + __popc(mj1 & prefix32(oj - 32)))) - (ix.mrank[bi] + below_i);
+                        const uint4 mj = ix.sblocks[(static_cast<size_t>(bj) << 2) + 3u];
+                        ones = (ix.mrank[bj] + popc_prefix128(mj, oj)) - (ix.mrank[bi] + below_i);
                     }
                     res = ones > 0u;
                     if (orders && res) ord = static_cast<long long>(ix.mrank[bi] + below_i);
@@ -465,6 +652,7 @@ PairIndex make_pair_index(const fmsi_hip_index* idx) {
     p.sbt = static_cast<const uint32_t*>(idx->d_sbt);
     p.c2 = static_cast<const uint32_t*>(idx->d_c2);
     p.mrank = idx->dev.mrank;
+    p.sblocks = idx->dev.blocks;
     p.ptable = idx->dev.ptable;
     p.ptable_len = idx->dev.ptable_len;
     p.ptable_packed = idx->dev.ptable_packed;
@@ -474,6 +662,28 @@ PairIndex make_pair_index(const fmsi_hip_index* idx) {
     p.p1 = idx->pair_p1;
     p.C0 = idx->dev.C0; p.C1 = idx->dev.C1; p.C2_ = idx->dev.C2; p.C3 = idx->dev.C3;
     return p;
+}
+
+template <bool COUNT>
+int launch_phased_t(fmsi_hip_index* idx, const uint64_t* d_kmers, uint64_t n, int k, uint32_t flags, uint8_t* o8, long long* o64,
+                    unsigned long long* d_counters, hipStream_t s) {
+    int rc = ensure_cap(&idx->d_tasks, &idx->d_tasks_cap, n * sizeof(uint2));   // one record per k-mer
+    if (rc) return rc;
+    auto* d_rec = static_cast<uint2*>(idx->d_tasks);
+    const PairIndex pix = make_pair_index(idx);
+    const uint32_t lb = static_cast<uint32_t>(std::min<uint64_t>((2 * n + 255) / 256, 1u << 23));
+    hipLaunchKernelGGL((pair_lookup_kernel<COUNT>), dim3(lb), dim3(256), 0, s, pix, d_kmers, n, k, flags, o64, d_rec, d_counters);
+    FMSI_HIP_TRY(hipGetLastError());
+    uint64_t chunk = n / (256ull * 32 * 8 * 2);
+    chunk = std::min<uint64_t>(std::max<uint64_t>(chunk, 128), 2048);
+    const uint64_t waves = (n + chunk - 1) / chunk;
+    const uint32_t blocks = static_cast<uint32_t>((waves + 3) / 4);
+    const uint32_t n_super = static_cast<uint32_t>(((idx->n_blocks - 1) >> kSuperBlocksLog2) + 1);
+    const size_t lds_bytes = (((16 + 16 * static_cast<size_t>(n_super) + 2) & ~size_t(1)) + 4 * 640 + 4 * 512) * 4;
+    hipLaunchKernelGGL((query_pair_kernel<COUNT, true, true>), dim3(blocks), dim3(256), lds_bytes, s, pix, d_kmers, n, k, flags,
+                       static_cast<uint32_t>(chunk), n_super, o8, o64, d_counters, d_rec);
+    FMSI_HIP_TRY(hipGetLastError());
+    return 0;
 }
 
 template <bool COUNT, bool PTABLE>
@@ -487,11 +697,17 @@ void launch_pair_t(fmsi_hip_index* idx, const uint64_t* d_kmers, uint64_t n, int
     const uint32_t n_super = static_cast<uint32_t>(((idx->n_blocks - 1) >> kSuperBlocksLog2) + 1);
     // tables (<= 33 KB for any n < 2^32) + per wave: 1 KB k-mer ring + 2 KB result bytes (chunk <= 2048)
     const size_t lds_bytes = (((16 + 16 * static_cast<size_t>(n_super) + 2) & ~size_t(1)) + 4 * 256 + 4 * 512) * 4;
-    hipLaunchKernelGGL((query_pair_kernel<COUNT, PTABLE>), dim3(blocks), dim3(256), lds_bytes, s, make_pair_index(idx), d_kmers, n, k, flags,
-                       static_cast<uint32_t>(chunk), n_super, o8, o64, d_counters);
+    hipLaunchKernelGGL((query_pair_kernel<COUNT, PTABLE, false>), dim3(blocks), dim3(256), lds_bytes, s, make_pair_index(idx), d_kmers, n, k, flags,
+                       static_cast<uint32_t>(chunk), n_super, o8, o64, d_counters, nullptr);
 }
 
 }  // namespace
+
+int launch_phased_query(fmsi_hip_index* idx, const uint64_t* d_kmers, uint64_t n, int k, uint32_t flags, uint8_t* o8, long long* o64,
+                        unsigned long long* d_counters, hipStream_t s) {
+    return d_counters ? launch_phased_t<true>(idx, d_kmers, n, k, flags, o8, o64, d_counters, s)
+                      : launch_phased_t<false>(idx, d_kmers, n, k, flags, o8, o64, d_counters, s);
+}
 
 void launch_pair_query(fmsi_hip_index* idx, const uint64_t* d_kmers, uint64_t n, int k, uint32_t flags, bool use_table, uint8_t* o8,
                        long long* o64, unsigned long long* d_counters, hipStream_t s) {

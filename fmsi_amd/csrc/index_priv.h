@@ -84,6 +84,11 @@ void launch_pair_query(fmsi_hip_index* idx, const uint64_t* d_kmers, uint64_t n,
 void launch_longk_query(fmsi_hip_index* idx, const uint64_t* d_seq, const uint64_t* d_window_start, uint64_t n, int k, uint32_t flags,
                         uint8_t* o8, long long* o64, unsigned long long* d_counters, hipStream_t s);
 
+// phased form of the same (fmsi_pair.hip): table lookups in a kernel of their own, the searches still alive in a second;
+// needs the pair layout and a prefix table with k >= t
+int launch_phased_query(fmsi_hip_index* idx, const uint64_t* d_kmers, uint64_t n, int k, uint32_t flags, uint8_t* o8, long long* o64,
+                        unsigned long long* d_counters, hipStream_t s);
+
 // grow-only device staging buffer
 inline int ensure_cap(void** p, size_t* cap, size_t need) {
     if (need <= *cap) return 0;

@@ -63,6 +63,9 @@ extern "C" {
 #define FMSI_HIP_KERNEL_REFILL 0x20u     /* persistent lanes: a lane that finishes pulls the next k-mer (ballot/mbcnt) */
 #define FMSI_HIP_KERNEL_PAIR 0x30u       /* persistent lanes + two-base LF steps over the 128-B pair layout (needs
                                             fmsi_hip_index_enable_pair_layout); AUTO picks it when the layout exists */
+#define FMSI_HIP_KERNEL_PHASED 0x40u     /* pair layout + prefix table: the table lookups run in a kernel of their own and only the
+                                            searches they leave alive go to the stepping kernel; AUTO picks it when both exist;
+                                            without a usable table it is KERNEL_PAIR */
 #define FMSI_HIP_KERNEL_MASK 0xF0u
 /* do not use the private prefix table even if the handle has one (canonical-step accounting runs) */
 #define FMSI_HIP_NO_PREFIX_TABLE 0x100u

@@ -48,7 +48,9 @@ def test_both_strands_equal_oracle(fm, oracle_built, name):
     dev_p = fm.DeviceIndex.from_files(index_prefix(name)).enable_pair_layout()
     dev_pe = fm.DeviceIndex.from_files(index_prefix(name), prefix_len=min(k, 6)).enable_pair_layout()
     dev_po = fm.DeviceIndex.from_files(index_prefix(name), prefix_len=max(1, min(k, 6) - 1)).enable_pair_layout()
-    variants += [(dev_p, fm.KERNEL_PAIR), (dev_pe, fm.KERNEL_PAIR), (dev_po, 0), (dev_pe, fm.KERNEL_REFILL)]
+    variants += [(dev_p, fm.KERNEL_PAIR), (dev_pe, fm.KERNEL_PAIR), (dev_po, fm.KERNEL_PAIR), (dev_pe, fm.KERNEL_REFILL)]
+    # phased form (table lookups in a kernel of their own; what AUTO picks with a pair layout and a table)
+    variants += [(dev_pe, fm.KERNEL_PHASED), (dev_po, fm.KERNEL_PHASED), (dev_po, 0)]
     for mode_all in (False, True):
         flag = fm.MODE_ALL if mode_all else fm.MODE_OR
         fwd, rc = orc.ternaries_bulk(raw, len(kmers), k, mode_all)
@@ -260,9 +262,11 @@ def test_large_prefix_tables(fm, oracle_built, t):
     for mode_all in (False, True):
         flag = fm.MODE_ALL if mode_all else fm.MODE_OR
         fwd, rc = orc.ternaries_bulk(raw, len(kmers), k, mode_all)
-        for kern in (fm.KERNEL_PAIR, fm.KERNEL_REFILL):
+        for kern in (fm.KERNEL_PHASED, fm.KERNEL_PAIR, fm.KERNEL_REFILL):
             gf, gr = fm.decode_strict(dev.query_kmers(packed, k, flag | fm.STRICT | kern))
             assert np.array_equal(gf, fwd) and np.array_equal(gr, rc)
+            fast = dev.query_kmers(packed, k, flag | kern)
+            assert np.array_equal(fast.astype(bool), expected_fast(fwd, rc, mode_all))
     up = ms.upper()
     reads = [up[100:700], revcomp(up[2000:2900]), up[5000:5031]]
     seq = "".join(reads)
