@@ -437,12 +437,10 @@ int check_device(int device) {
 
 // synthetic queries: see fmsi_hip_synthetic_queries in the header
 __global__ void synth_queries_kernel(const uint64_t* __restrict__ text2, uint64_t len, int k, uint64_t seed, uint64_t first, uint64_t n,
-                                     uint64_t* __restrict__ kmers, int dbg) {
+                                     uint64_t* __restrict__ kmers) {
     const uint64_t q = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     if (q >= n) return;
-    uint64_t r = splitmix64(seed ^ ((first + q) * 0x9FB21C651E98DF25ull));
-    if (dbg == 1) r = (r | 1ull) & ~2ull;   // all forward positives
-    if (dbg == 2) r = r & ~1ull;            // all negatives
+    const uint64_t r = splitmix64(seed ^ ((first + q) * 0x9FB21C651E98DF25ull));
     const uint64_t r2 = splitmix64(r);
     const uint64_t m = k == 32 ? ~0ull : ((1ull << (2 * k)) - 1ull);
     uint64_t f;
@@ -556,8 +554,7 @@ int fmsi_hip_synthetic_queries(fmsi_hip_index* idx, int k, uint64_t seed, uint64
     if (n == 0) return 0;
     FMSI_HIP_TRY(hipSetDevice(idx->device));
     hipLaunchKernelGGL(synth_queries_kernel, dim3(grid_for(n)), dim3(256), 0, static_cast<hipStream_t>(stream),
-                       static_cast<const uint64_t*>(idx->d_text2), idx->text_len, k, seed, first, n, d_kmers,
-                       getenv("FMSI_DBG_POS") ? atoi(getenv("FMSI_DBG_POS")) : 0);
+                       static_cast<const uint64_t*>(idx->d_text2), idx->text_len, k, seed, first, n, d_kmers);
     FMSI_HIP_TRY(hipGetLastError());
     return 0;
 }

@@ -362,23 +362,46 @@ __global__ __launch_bounds__(256) void query_stream_kernel(DevIndex ix, const ui
             if (!__any(has_next)) break;
             continue;
         }
-        if (st != SS_IDLE) {
+        {   // every lane of the wave takes part (idle lanes with all predicates false): the table lines are fetched by lane
+            // pairs, so a lane whose partner is idle still needs the partner's loads and shuffles
             // ---- one round of reads ----
             const uint4* pi = ix.blocks;
             const uint4* pj = ix.blocks;
             uint32_t bi = 0, bj = 0, tidx = 0;
-            const bool need_blocks = st != SS_EXTSCAN;
-            if (PTABLE && st == SS_LOOKUP) {
+            const bool need_blocks = st != SS_IDLE && st != SS_EXTSCAN;
+            const bool lk = PTABLE && st == SS_LOOKUP;
+            if (lk) {
                 tidx = kmer_table_index(T);
-                pi = reinterpret_cast<const uint4*>(ix.ptable + (tidx & ~7u));
-                pj = pi;
             } else if (need_blocks) {
                 bi = i >> kBlockRowsLog2;
                 bj = (j - 1u) >> kBlockRowsLog2;
                 pi = ix.blocks + (static_cast<size_t>(bi) << 2);
                 pj = ix.blocks + (static_cast<size_t>(bj) << 2);
             }
-            const bool two = need_blocks && pj != pi;
+            const bool two = need_blocks && !lk && pj != pi;
+            // Table lines are fetched by LANE PAIRS: both lanes of a pair load their 32-byte half of the line of each lane
+            // of the pair that is looking up (two adjacent lanes on one line are one request; 64 lanes on 64 different
+            // lines of a 34 GB table run at a third of the rate -- measured in fmsi_pair.hip's lookup kernel).
+            uint4 te0 = make_uint4(0, 0, 0, 0), te1 = te0, to0 = te0, to1 = te0;
+            uint32_t t_even = 0, t_odd = 0;
+            if (PTABLE) {
+                const uint32_t ln = threadIdx.x & 63u, sub = ln & 1u;
+                const uint64_t lkm = __ballot(lk);
+                if (lkm) {
+                    t_even = static_cast<uint32_t>(__shfl(static_cast<int>(tidx), static_cast<int>(ln & ~1u), 64));
+                    t_odd = static_cast<uint32_t>(__shfl(static_cast<int>(tidx), static_cast<int>(ln | 1u), 64));
+                    if ((lkm >> (ln & ~1u)) & 1ull) {
+                        const uint4* p4 = reinterpret_cast<const uint4*>(ix.ptable + (t_even & ~7u)) + sub * 2u;
+                        te0 = p4[0];
+                        te1 = p4[1];
+                    }
+                    if ((lkm >> (ln | 1u)) & 1ull) {
+                        const uint4* p4 = reinterpret_cast<const uint4*>(ix.ptable + (t_odd & ~7u)) + sub * 2u;
+                        to0 = p4[0];
+                        to1 = p4[1];
+                    }
+                }
+            }
             uint4 b0 = make_uint4(0, 0, 0, 0), b1 = b0, b2 = b0, b3 = b0;
             uint4 a0 = b0, a1 = b0, a2 = b0, a3 = b0;
             uint64_t kwi = 0, kwj = 0;
@@ -401,7 +424,7 @@ __global__ __launch_bounds__(256) void query_stream_kernel(DevIndex ix, const ui
                 b2 = pj[2];
                 b3 = pj[3];
             }
-            if (need_blocks) {
+            if (need_blocks && !lk) {
                 a0 = pi[0];
                 a1 = pi[1];
                 a2 = pi[2];
@@ -423,17 +446,27 @@ __global__ __launch_bounds__(256) void query_stream_kernel(DevIndex ix, const ui
             // ---- arithmetic ----
             bool do_lf = false;       // perform the LF step of the walk with the loaded blocks
             uint32_t c = 0;
+            // the looked-up entries travel from the half that holds them to their owners: entry e of a line is slot e & 3 of
+            // the 32 bytes held by lane e >> 2 of the pair
+            uint32_t ent_x = 0, ent_y = 0;
+            if (PTABLE && __any(lk)) {
+                const uint32_t ln = threadIdx.x & 63u, sub = ln & 1u, pb = ln & ~1u;
+                const uint32_t ee = t_even & 7u, eo = t_odd & 7u;
+                const uint4 ve = (ee & 2u) ? te1 : te0, vo = (eo & 2u) ? to1 : to0;
+                const uint32_t vex = (ee & 1u) ? ve.z : ve.x, vey = (ee & 1u) ? ve.w : ve.y;
+                const uint32_t vox = (eo & 1u) ? vo.z : vo.x, voy = (eo & 1u) ? vo.w : vo.y;
+                const int src = static_cast<int>(pb | ((sub ? eo : ee) >> 2));
+                const uint32_t gex = static_cast<uint32_t>(__shfl(static_cast<int>(vex), src, 64)), gey = static_cast<uint32_t>(__shfl(static_cast<int>(vey), src, 64));
+                const uint32_t gox = static_cast<uint32_t>(__shfl(static_cast<int>(vox), src, 64)), goy = static_cast<uint32_t>(__shfl(static_cast<int>(voy), src, 64));
+                ent_x = sub ? gox : gex;
+                ent_y = sub ? goy : gey;
+            }
             if (st == SS_LOOKUP) {
                 if (COUNT) cn.lookups++;
-                const uint32_t e = (tidx & 7u) >> 1;
-                const uint32_t x0 = sel4(e, opaque(a0.x), opaque(a1.x), opaque(a2.x), opaque(a3.x));
-                const uint32_t x1 = sel4(e, opaque(a0.y), opaque(a1.y), opaque(a2.y), opaque(a3.y));
-                const uint32_t x2 = sel4(e, opaque(a0.z), opaque(a1.z), opaque(a2.z), opaque(a3.z));
-                const uint32_t x3 = sel4(e, opaque(a0.w), opaque(a1.w), opaque(a2.w), opaque(a3.w));
                 t = k - 1 - T;
                 uint32_t q4 = 0;
                 if (t >= 3) q4 = kmer_base(t - 3) | (kmer_base(t - 2) << 2) | (kmer_base(t - 1) << 4) | (kmer_base(t) << 6);
-                decode_table_entry((tidx & 1u) ? x2 : x0, (tidx & 1u) ? x3 : x1, ix.ptable_packed, t >= 3, q4, i, j);
+                decode_table_entry(ent_x, ent_y, ix.ptable_packed, t >= 3, q4, i, j);
                 if (i == j) {
                     window_done(-1, -1);
                     advance(false);
