@@ -1,9 +1,8 @@
 // Two-base LF steps over 128-byte blocks ("pair layout"), read cooperatively by PAIRS of lanes -- the
 // request-count optimisation of the query path.
 //
-// Why: the chip serves ~52 G random block reads/s whether a block is 64 B or 128 B, as long as the randomly
-// accessed footprint stays below ~3.2 GB and a wave keeps <= ~8 dwordx4 loads in flight per lane
-// (profiles/r01_gather_ceiling.md).  The single-step kernels run at that request ceiling, so the only way up is
+// Why: the chip serves ~50 G random block reads/s whether a block is 64 B or 128 B, as long as adjacent lanes share
+// lines and a wave keeps <= ~8 dwordx4 loads in flight per lane (profiles/r01_gather_ceiling.md).  The single-step kernels run at that request ceiling, so the only way up is
 // fewer requests per k-mer.  A 128-byte block can carry what TWO consecutive backward-search steps need: for every
 // row r (suffix start s = SA[r]) both preceding symbols c1 = T[s-1] (the BWT symbol) and c2 = T[s-2], plus
 // cumulative counts of the 16 (c2, c1) pairs.  Then
@@ -16,7 +15,9 @@
 // Block = 128 B = 128 rows = two 64-byte HALVES; half h covers rows 64h .. 64h+63 and is read by lane h of a lane
 // pair with four dwordx4 loads (the pair's loads coalesce into one 128-B request):
 //   dw 0,1  c1 hi plane   dw 2,3  c1 lo plane   dw 4,5  c2 hi plane   dw 6,7  c2 lo plane      (64 rows each)
-//   dw 8,9  mask plane (SA-transformed mask, 64 rows)
+//   dw 8,9  pre-mapped mask plane: bit r = mask[LF2(r)], the SA-transformed mask bit of the row a pair step through row r
+//           lands on -- the rows of [i, j) that match the pair ARE the new interval, so the last step of a search reads
+//           infer_presence() off the block it already holds (explicit probes use the single-step layout's mask plane)
 //   dw 10..13  low 16 bits, dw 14,15 high 8 bits of the eight cumulative counts of the pairs with c1 in {2h, 2h+1}
 //              (pair index p = c2 | c1 << 2 = 8h .. 8h+7): 24-bit counts relative to the superblock start
 // Superblock = 2^23 rows; `sbt` holds the 16 absolute counts at each superblock start (21 KB at human scale: cache
