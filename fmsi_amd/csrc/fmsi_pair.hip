@@ -497,25 +497,46 @@ __global__ __launch_bounds__(256) void query_pair_kernel(PairIndex ix, const uin
                 // pair step -> count p; single step -> my half's share of the four counts with c1 = p >> 2 (summed below)
                 const uint32_t se = single ? ((p & 12u) + 2u * sub) : p;
                 const uint32_t* si = lds + 16u + ((i >> kSuperLog2) << 4) + se;
-                const uint32_t* sj = lds + 16u + (((j - 1u) >> kSuperLog2) << 4) + se;
                 sbi = si[0];
-                sbj = sj[0];
-                if (single) {
-                    sbi += si[1];
-                    sbj += sj[1];
-                }
+                if (single) sbi += si[1];
+                sbj = sbi;
                 c2base = lds[p];
             }
-            if (!two) B = A;
+            // After the table an interval is a few rows: both boundaries almost always sit in ONE block, and then the
+            // upper rank is the lower one plus the matching rows in between.  The second block's share of the work (its
+            // superblock counts, match bits, cumulative count and the copy A -> B) is done only in the iterations in
+            // which some lane of the wave really has two blocks.
+            const bool wave_two = __any(two);
+            if (wave_two) {
+                if (st == PS_STEP) {
+                    const uint32_t se = single ? ((p & 12u) + 2u * sub) : p;
+                    const uint32_t* sj = lds + 16u + (((j - 1u) >> kSuperLog2) << 4) + se;
+                    sbj = sj[0];
+                    if (single) sbj += sj[1];
+                }
+                if (!two) B = A;
+            }
             if (COUNT && sub == 0) cn.blocks += 1u + (two ? 1u : 0u);
 
             if (st == PS_STEP) {
                 const int oi = static_cast<int>(i & (kBlockRows - 1u)) - shift, oj = static_cast<int>(j - (bj << kBlockRowsLog2)) - shift;
                 uint32_t ma0, ma1, mb0, mb1;
                 half_bits(A, p, single, ma0, ma1);
-                half_bits(B, p, single, mb0, mb1);
-                uint32_t ri = pair_sum(bits_below(ma0, ma1, oi));
-                uint32_t rj = pair_sum(bits_below(mb0, mb1, oj));
+                const uint32_t below_i = bits_below(ma0, ma1, oi);
+                uint32_t ri = pair_sum(below_i), rj;
+                // cumulative counts live in the half of c1 = p >> 2: half (p >> 3), slot p & 7
+                const int owner = static_cast<int>(pbase | (p >> 3));
+                const uint32_t cnt_i = static_cast<uint32_t>(__shfl(static_cast<int>(half_count(A, p & 7u, single)), owner, 64));
+                uint32_t cnt_j = cnt_i;
+                if (wave_two) {
+                    half_bits(B, p, single, mb0, mb1);
+                    rj = pair_sum(bits_below(mb0, mb1, oj));
+                    cnt_j = static_cast<uint32_t>(__shfl(static_cast<int>(half_count(B, p & 7u, single)), owner, 64));
+                } else {
+                    mb0 = ma0;
+                    mb1 = ma1;
+                    rj = ri + pair_sum(bits_below(ma0, ma1, oj) - below_i);
+                }
                 // The last step of a search also answers it when the block(s) at hand cover the whole interval: the
                 // rows of [i, j) that match the pair are exactly the rows of the new interval, in order, and the block's
                 // mask plane holds mask[LF2(row)] -- infer_presence() (src/fms_index.h:126-144) without another read.
@@ -543,10 +564,8 @@ __global__ __launch_bounds__(256) void query_pair_kernel(PairIndex ix, const uin
                         if (both & 2u) folded = static_cast<int>(both & 1u);
                     }
                 }
-                // cumulative counts live in the half of c1 = p >> 2: half (p >> 3), slot p & 7
-                const int owner = static_cast<int>(pbase | (p >> 3));
-                ri += static_cast<uint32_t>(__shfl(static_cast<int>(half_count(A, p & 7u, single)), owner, 64));
-                rj += static_cast<uint32_t>(__shfl(static_cast<int>(half_count(B, p & 7u, single)), owner, 64));
+                ri += cnt_i;
+                rj += cnt_j;
                 if (single) {
                     ri += pair_sum(sbi);
                     rj += pair_sum(sbj);
