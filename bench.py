@@ -61,6 +61,7 @@ def parse_args():
     ap.add_argument("--query-seed", type=int, default=42)
     ap.add_argument("--cpu-sample", type=int, default=-1, help="windows for the CPU baseline (-1 = auto, 0 = skip)")
     ap.add_argument("--no-counters", action="store_true")
+    ap.add_argument("--no-verify", action="store_true", help="phased kernel without text verification of one-row table intervals")
     return ap.parse_args()
 
 
@@ -116,6 +117,8 @@ def main():
         if args.kernel in ("pair", "phased"):
             t0 = time.time()
             index.enable_pair_layout()
+            if args.kernel == "phased" and 0 < args.prefix_len < k and not args.no_verify:
+                index.enable_verify()
             build_s += time.time() - t0
         flags |= {"phased": fm.KERNEL_PHASED, "pair": fm.KERNEL_PAIR, "refill": fm.KERNEL_REFILL, "lockstep": fm.KERNEL_LOCKSTEP}[args.kernel]
     stream = torch.cuda.current_stream().cuda_stream
@@ -205,9 +208,11 @@ def main():
         roof = None
         if counters is not None:
             blocks_read, lookups, klcp_words = int(counters[1]), int(counters[4]), int(counters[5])
+            verify_reads = int(counters[7])   # text verification: 4-byte position + 8..16 bytes of text, two requests per verified search
             # blocks_read already contains the prefix-table lines (one 64-B line per lookup); the pair layout reads 128-B blocks
             block_b = 128 if (args.kernel in ("pair", "phased") and not stream_mode) else 64
             bytes_launch = block_b * (blocks_read - lookups) + 64 * lookups + 8 * klcp_words + in_bytes + 1 * batch
+            bytes_launch += 32 * verify_reads   # counted as two 32-byte sectors per verification
             if args.kernel == "phased" and not stream_mode and args.prefix_len > 0:
                 bytes_launch += 24 * batch   # the lookup kernel's 8-byte record per k-mer (written, read back) + the k-mer read a second time
             canon_bytes = 256 * int(canonical[0]) + 64 * int(canonical[2]) + 8 * int(canonical[5]) + in_bytes + batch // 8
@@ -221,8 +226,8 @@ def main():
                     "bytes_per_kmer": round(bytes_launch / batch, 1),
                     "lf_steps_per_kmer": round(int(counters[0]) / batch, 3),
                     "blocks_per_kmer": round(blocks_read / batch, 3), "table_lookups_per_kmer": round(lookups / batch, 3),
-                    "klcp_words_per_kmer": round(klcp_words / batch, 3),
-                    "random_requests_per_s": round((blocks_read + klcp_words) / avg_kernel_s / 1e9, 2),
+                    "klcp_words_per_kmer": round(klcp_words / batch, 3), "verify_reads_per_kmer": round(verify_reads / batch, 3),
+                    "random_requests_per_s": round((blocks_read + klcp_words + verify_reads) / avg_kernel_s / 1e9, 2),
                     "canonical_lf_steps_per_kmer": round(int(canonical[0]) / batch, 3),
                     "canonical_achieved": round(canon_bytes / avg_kernel_s / 1e9, 1),
                     "canonical_frac": round(canon_bytes / avg_kernel_s / 1e9 / HBM_PEAK_GBS, 4)}

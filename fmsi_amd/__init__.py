@@ -111,6 +111,7 @@ def lib() -> C.CDLL:
     L.fmsi_hip_index_download_text.argtypes = [vp, vp]
     L.fmsi_hip_index_download_klcp.argtypes = [vp, vp]
     L.fmsi_hip_index_enable_pair_layout.argtypes = [vp]
+    L.fmsi_hip_index_enable_verify.argtypes = [vp]
     L.fmsi_hip_synthetic_reads.argtypes = [vp, u64, u64, u64, u64, u32, vp, vp]
     L.fmsi_hip_query_kmers.argtypes = [vp, vp, u64, i32, u32, vp, vp, vp]
     L.fmsi_hip_query_windows.argtypes = [vp, vp, u64, vp, u64, i32, u32, vp, vp, vp]
@@ -298,6 +299,12 @@ class DeviceIndex:
     def enable_pair_layout(self):
         """Add the 128-B two-base-step layout (fmsi_hip_index_enable_pair_layout); AUTO kernels then use it."""
         _check(lib().fmsi_hip_index_enable_pair_layout(self._h))
+        _check(lib().fmsi_hip_index_get_info(self._h, C.byref(self.info)))
+        return self
+
+    def enable_verify(self):
+        """Add text verification for one-row table intervals (fmsi_hip_index_enable_verify); used by the phased kernels."""
+        _check(lib().fmsi_hip_index_enable_verify(self._h))
         _check(lib().fmsi_hip_index_get_info(self._h, C.byref(self.info)))
         return self
 

@@ -55,7 +55,8 @@ __global__ __launch_bounds__(256) void export_measure_kernel(DevIndex ix, uint32
 
 // the chain's i-th letter is text position  last[c] - i  (last[c] = N - 1 - offset of the chain along the walk)
 __global__ __launch_bounds__(256) void export_write_kernel(DevIndex ix, uint32_t stride, uint64_t n_chains, const uint32_t* __restrict__ len,
-                                                           const uint64_t* __restrict__ last, char* __restrict__ out) {
+                                                           const uint64_t* __restrict__ last, char* __restrict__ out,
+                                                           uint32_t* __restrict__ sa /* optional: sa[row] = text position of the row's suffix */) {
     const uint64_t c = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     if (c >= n_chains) return;
     const uint32_t steps = len[c];
@@ -66,6 +67,7 @@ __global__ __launch_bounds__(256) void export_write_kernel(DevIndex ix, uint32_t
         // masked_letters = "acgtACGT", src/fms_index.h:463
         const uint32_t lower = s.letter == 0u ? 'a' : (s.letter == 1u ? 'c' : (s.letter == 2u ? 'g' : 't'));
         out[p] = static_cast<char>(s.mask_at_next ? lower - 32u : lower);
+        if (sa) sa[row] = static_cast<uint32_t>(p + 1u);   // the letter before the suffix of `row` sits at p
         row = s.next_row;
     }
 }
@@ -75,19 +77,12 @@ __global__ __launch_bounds__(256) void export_write_kernel(DevIndex ix, uint32_t
 
 using namespace fmsi;
 
-extern "C" int fmsi_hip_index_export(const fmsi_hip_index* idx, char* out, uint64_t out_capacity, uint64_t* out_len) {
-    if (!idx || !out || !out_len) {
-        set_last_error("null argument");
-        return FMSI_HIP_EINVAL;
-    }
+namespace fmsi {
+
+// The walk: letters (with the mask's case) into d_chars[0 .. n-2], and optionally sa[row] for every row (sa[dollar row] = 0).
+int export_walk(const fmsi_hip_index* idx, char* d_chars, uint32_t* d_sa) {
     const uint64_t n = idx->n, text_len = n - 1;
-    *out_len = text_len;
-    if (out_capacity < text_len) {
-        set_last_error("output buffer too small: the superstring has " + std::to_string(text_len) + " bases");
-        return FMSI_HIP_EINVAL;
-    }
     if (text_len == 0) return 0;
-    FMSI_HIP_TRY(hipSetDevice(idx->device));
     // about a million chains, at least 64 rows apart
     uint64_t stride64 = 64;
     while ((n + stride64 - 1) / stride64 > (1ull << 20)) stride64 *= 2;
@@ -95,9 +90,8 @@ extern "C" int fmsi_hip_index_export(const fmsi_hip_index* idx, char* out, uint6
     const uint64_t n_chains = (n + stride64 - 1) / stride64;
     uint32_t *d_len = nullptr, *d_landing = nullptr;
     uint64_t* d_last = nullptr;
-    char* d_out = nullptr;
     auto cleanup = [&]() {
-        for (void* p : {static_cast<void*>(d_len), static_cast<void*>(d_landing), static_cast<void*>(d_last), static_cast<void*>(d_out)})
+        for (void* p : {static_cast<void*>(d_len), static_cast<void*>(d_landing), static_cast<void*>(d_last)})
             if (p) (void)hipFree(p);
     };
     auto fail = [&](int code, const std::string& msg) {
@@ -106,7 +100,7 @@ extern "C" int fmsi_hip_index_export(const fmsi_hip_index* idx, char* out, uint6
         return code;
     };
     if (hipMalloc(reinterpret_cast<void**>(&d_len), n_chains * 4) != hipSuccess || hipMalloc(reinterpret_cast<void**>(&d_landing), n_chains * 4) != hipSuccess ||
-        hipMalloc(reinterpret_cast<void**>(&d_last), n_chains * 8) != hipSuccess || hipMalloc(reinterpret_cast<void**>(&d_out), text_len) != hipSuccess)
+        hipMalloc(reinterpret_cast<void**>(&d_last), n_chains * 8) != hipSuccess)
         return fail(FMSI_HIP_ENOMEM, "hipMalloc failed for the export buffers");
     const dim3 grid(static_cast<uint32_t>((n_chains + 255) / 256)), block(256);
     hipLaunchKernelGGL(export_measure_kernel, grid, block, 0, 0, idx->dev, stride, n_chains, d_len, d_landing);
@@ -127,9 +121,38 @@ extern "C" int fmsi_hip_index_export(const fmsi_hip_index* idx, char* out, uint6
     }
     if (offset != text_len) return fail(FMSI_HIP_EHIP, "export: the LF walk from row 0 does not cover the text (corrupt index?)");
     if (hipMemcpy(d_last, last.data(), n_chains * 8, hipMemcpyHostToDevice) != hipSuccess) return fail(FMSI_HIP_EHIP, "export: upload failed");
-    hipLaunchKernelGGL(export_write_kernel, grid, block, 0, 0, idx->dev, stride, n_chains, d_len, d_last, d_out);
-    if (hipGetLastError() != hipSuccess || hipMemcpy(out, d_out, text_len, hipMemcpyDeviceToHost) != hipSuccess)
-        return fail(FMSI_HIP_EHIP, "export: writing the text failed");
+    if (d_sa && hipMemset(d_sa + idx->dev.dollar, 0, 4) != hipSuccess) return fail(FMSI_HIP_EHIP, "export: memset failed");
+    hipLaunchKernelGGL(export_write_kernel, grid, block, 0, 0, idx->dev, stride, n_chains, d_len, d_last, d_chars, d_sa);
+    if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess) return fail(FMSI_HIP_EHIP, "export: writing the text failed");
     cleanup();
     return 0;
+}
+
+}  // namespace fmsi
+
+extern "C" int fmsi_hip_index_export(const fmsi_hip_index* idx, char* out, uint64_t out_capacity, uint64_t* out_len) {
+    if (!idx || !out || !out_len) {
+        set_last_error("null argument");
+        return FMSI_HIP_EINVAL;
+    }
+    const uint64_t text_len = idx->n - 1;
+    *out_len = text_len;
+    if (out_capacity < text_len) {
+        set_last_error("output buffer too small: the superstring has " + std::to_string(text_len) + " bases");
+        return FMSI_HIP_EINVAL;
+    }
+    if (text_len == 0) return 0;
+    FMSI_HIP_TRY(hipSetDevice(idx->device));
+    char* d_out = nullptr;
+    if (hipMalloc(reinterpret_cast<void**>(&d_out), text_len) != hipSuccess) {
+        set_last_error("hipMalloc failed for the export buffers");
+        return FMSI_HIP_ENOMEM;
+    }
+    int rc = export_walk(idx, d_out, nullptr);
+    if (rc == 0 && hipMemcpy(out, d_out, text_len, hipMemcpyDeviceToHost) != hipSuccess) {
+        set_last_error("export: copying the text back failed");
+        rc = FMSI_HIP_EHIP;
+    }
+    (void)hipFree(d_out);
+    return rc;
 }

@@ -54,6 +54,8 @@ struct PairIndex {
     const uint32_t* mrank;    // n_blocks + 1 cumulative mask popcounts (shared with the single-step layout)
     const uint4* sblocks;     // the single-step layout (its mask plane serves the explicit probes)
     const uint2* ptable;
+    const uint32_t* stable;   // text verification (fmsi_hip_index_enable_verify) or nullptr: text position of one-row entries
+    const uint64_t* text2;    // ... and the 2-bit packed superstring
     uint32_t ptable_len, ptable_packed;
     uint32_t n, r0, r1, p1;   // rows; row of suffix 0 ('$' slot); row of suffix 1; pair index stored for r1
     uint32_t C0, C1, C2_, C3;
@@ -166,55 +168,90 @@ __global__ void pair_counts_kernel(const U16* __restrict__ scanned, uint64_t n_b
 // lanes on one line cost the memory path one request, 64 different lines per instruction cost it more than twice 32.
 // Result per k-mer: one 8-byte record, (i, j) of the strand that is alive after the table -- stored as (j, i) when that
 // is the reverse complement (the forward strand died in the table) -- or (0, 0) when both strands died.
+// Record of a k-mer: (i, j) with i < j = forward strand alive after the table; (j, i) = reverse complement alive, forward
+// strand absent; (c, c) = settled here, c = (forward result + 1) | (reverse-complement result + 1) << 2 -- (0, 0) = absent
+// on both strands.
+// Text verification (ix.stable): an interval of exactly ONE row leaves one candidate occurrence; its text position is
+// stored per table entry, so the remaining k - t bases are compared with the text itself -- present iff they match, with
+// the mask bit of that occurrence kept in the entry (bit 26) -- instead of (k - t) / 2 dependent block reads.  This is
+// infer_presence() of the interval get_range_with_pattern() would end with (src/fms_index.h:117-144): one row, that mask
+// bit; or the empty interval.
 template <bool COUNT>
 __global__ __launch_bounds__(256) void pair_lookup_kernel(PairIndex ix, const uint64_t* __restrict__ kmers, uint64_t n_windows, int k, uint32_t flags,
                                                           long long* __restrict__ out_orders, uint2* __restrict__ rec,
                                                           unsigned long long* __restrict__ counters) {
     const uint32_t strict = flags & FMSI_HIP_STRICT;
     const uint32_t orders = flags & FMSI_HIP_ORDERS;
+    const uint32_t mode_all = flags & FMSI_HIP_MODE_ALL;
     const int T = static_cast<int>(ix.ptable_len);
     const int t = k - 1 - T;
+    const uint32_t R = static_cast<uint32_t>(k - T);                       // bases left after the table
+    const uint64_t rmask = R >= 32u ? ~0ull : ((1ull << (2u * R)) - 1ull);
+    const bool verify = ix.stable != nullptr && ix.ptable_packed && !orders && R >= 1u && R <= 32u;
     const uint32_t tmask = static_cast<uint32_t>((1ull << (2 * T)) - 1ull);
     const uint64_t stride = (static_cast<uint64_t>(gridDim.x) * blockDim.x) >> 1;
     const uint32_t sub = threadIdx.x & 1u;
     const int pbase = static_cast<int>(threadIdx.x & 63u & ~1u);
-    uint32_t n_lookups = 0, n_final = 0;
+    uint32_t n_lookups = 0, n_final = 0, n_vreads = 0;
     const uint64_t n_round = (n_windows + 31) & ~31ull;   // whole waves stay in the loop: the shuffles below need both lanes of a pair
+
+    // one strand: table lookup (+ verification).  state 0 = absent, 1 = alive (needs the stepping kernel), 2 = settled (res)
+    auto strand = [&](uint64_t cur, bool go, uint32_t& i, uint32_t& j, int& res) -> uint32_t {
+        const uint32_t tidx = static_cast<uint32_t>(cur >> (2 * (k - T))) & tmask;
+        const uint4* p4 = reinterpret_cast<const uint4*>(ix.ptable + (tidx & ~7u)) + sub * 2u;
+        uint4 u0 = make_uint4(0, 0, 0, 0), u1 = u0;
+        if (go) {
+            u0 = p4[0];
+            u1 = p4[1];
+        }
+        // entry e of the 8-entry line sits in lane e >> 2 of the pair, slot e & 3 of its 32 bytes
+        const uint32_t e = tidx & 7u;
+        const uint4 v = (e & 2u) ? u1 : u0;
+        const uint32_t xi = (e & 1u) ? v.z : v.x, xj = (e & 1u) ? v.w : v.y;
+        const int src = pbase | static_cast<int>(e >> 2);
+        const uint32_t ex = static_cast<uint32_t>(__shfl(static_cast<int>(xi), src, 64)), ey = static_cast<uint32_t>(__shfl(static_cast<int>(xj), src, 64));
+        res = -1;
+        i = j = 0;
+        if (!go) return 0u;
+        decode_table_entry(ex, ey, ix.ptable_packed, t >= 3, t >= 3 ? static_cast<uint32_t>(cur >> (2 * (t - 3))) & 0xFFu : 0u, i, j);
+        if (sub == 0u) n_lookups++;
+        if (i == j) return 0u;
+        if (!(verify && (ey >> 30) == 1u && ((ey >> 24) & 3u) == 1u)) return 1u;
+        // one row: its text position, then the text in front of it
+        const uint32_t pos = ix.stable[tidx];
+        bool match = false;
+        if (pos >= R) {
+            const uint64_t p0 = static_cast<uint64_t>(pos - R), w = p0 >> 5;
+            const uint32_t sh = static_cast<uint32_t>(p0 & 31u) * 2u;
+            uint64_t tx = ix.text2[w] >> sh;
+            if (sh) tx |= ix.text2[w + 1] << (64u - sh);
+            match = ((tx ^ cur) & rmask) == 0ull;
+        }
+        if (sub == 0u) n_vreads += 2u;
+        res = match ? static_cast<int>((ey >> 26) & 1u) : -1;
+        return 2u;
+    };
+
     for (uint64_t q = (static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 1; q < n_round; q += stride) {
         const bool valid = q < n_windows;
         const uint64_t f = valid ? kmers[q] : 0ull;
-        uint32_t i = 0, j = 0;
-        uint64_t cur = f;
-        bool alive = false, second = false;
-        for (int strand = 0; strand < 2; ++strand) {
-            const bool go = valid && !alive;   // every mode searches the reverse complement when the forward strand is absent (src/fms_index.h:283-299)
-            if (!__any(go)) break;
-            const uint32_t tidx = static_cast<uint32_t>(cur >> (2 * (k - T))) & tmask;
-            const uint4* p4 = reinterpret_cast<const uint4*>(ix.ptable + (tidx & ~7u)) + sub * 2u;
-            uint4 u0 = make_uint4(0, 0, 0, 0), u1 = u0;
-            if (go) {
-                u0 = p4[0];
-                u1 = p4[1];
-            }
-            // entry e of the 8-entry line sits in lane e >> 2 of the pair, slot e & 3 of its 32 bytes
-            const uint32_t e = tidx & 7u;
-            const uint4 v = (e & 2u) ? u1 : u0;
-            const uint32_t xi = (e & 1u) ? v.z : v.x, xj = (e & 1u) ? v.w : v.y;
-            const int src = pbase | static_cast<int>(e >> 2);
-            const uint32_t ex = static_cast<uint32_t>(__shfl(static_cast<int>(xi), src, 64)), ey = static_cast<uint32_t>(__shfl(static_cast<int>(xj), src, 64));
-            if (go) {
-                decode_table_entry(ex, ey, ix.ptable_packed, t >= 3, t >= 3 ? static_cast<uint32_t>(cur >> (2 * (t - 3))) & 0xFFu : 0u, i, j);
-                alive = i != j;
-                second = strand == 1;
-                if (sub == 0u) n_lookups++;
-                cur = revcomp_2bit(f, k);
-            }
-        }
+        uint32_t i_f, j_f, i_r = 0, j_r = 0;
+        int res_f, res_r = -1;
+        const uint32_t sf = strand(f, valid, i_f, j_f, res_f);
+        // the reverse complement is searched when the forward strand does not decide (src/fms_index.h:283-299); a forward
+        // strand that still needs steps (state 1) leaves that decision to the stepping kernel
+        const bool need_rc = valid && sf != 1u && (strict || (mode_all && !orders ? res_f == -1 : res_f != 1));
+        uint32_t sr = 0;
+        if (__any(need_rc)) sr = strand(revcomp_2bit(f, k), need_rc, i_r, j_r, res_r);
         if (valid && sub == 0u) {
-            rec[q] = alive ? (second ? make_uint2(j, i) : make_uint2(i, j)) : make_uint2(0u, 0u);
-            if (!alive) {
+            uint2 r;
+            if (sf == 1u) r = make_uint2(i_f, j_f);
+            else if (sr == 1u) r = res_f == -1 ? make_uint2(j_r, i_r) : make_uint2(i_f, j_f);   // a settled forward 0 / 1 cannot ride along: redo it by steps
+            else {
+                const uint32_t c = static_cast<uint32_t>(res_f + 1) | (static_cast<uint32_t>(res_r + 1) << 2);
+                r = make_uint2(c, c);
                 n_final++;
-                if (orders) {   // presence modes: the stepping kernel writes the 0 with its chunk's other result bytes
+                if (orders) {   // (verification is off for lookup: both strands absent)
                     if (strict) {
                         out_orders[2 * q] = -1;
                         out_orders[2 * q + 1] = -1;
@@ -223,13 +260,14 @@ __global__ __launch_bounds__(256) void pair_lookup_kernel(PairIndex ix, const ui
                     }
                 }
             }
+            rec[q] = r;
         }
     }
     if (COUNT) {
-        uint32_t v[3] = {n_lookups, n_lookups, n_final};   // strand searches started = table lookups = lines read
-        const int slot[3] = {3, 4, 6};
+        uint32_t v[4] = {n_lookups, n_lookups, n_final, n_vreads};   // strand searches started = table lookups = lines read
+        const int slot[4] = {3, 4, 6, 7};
 #pragma unroll
-        for (int qq = 0; qq < 3; ++qq) {
+        for (int qq = 0; qq < 4; ++qq) {
             uint32_t x = v[qq];
             for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
             if ((threadIdx.x & 63u) == 0 && x) {
@@ -391,7 +429,11 @@ __global__ __launch_bounds__(256) void query_pair_kernel(PairIndex ix, const uin
                 const uint32_t idx = fetched + lane;
                 const bool in = idx < len;
                 const bool alive = in && static_cast<uint32_t>(pend_ij) != static_cast<uint32_t>(pend_ij >> 32);
-                if (in && !alive && !orders) obuf[idx] = 0;   // also the STRICT code of (-1, -1)
+                if (in && !alive && !orders) {   // settled by the lookup kernel: (c, c), c = (forward + 1) | (reverse complement + 1) << 2
+                    const uint32_t c = static_cast<uint32_t>(pend_ij);
+                    const int rf = static_cast<int>(c & 3u) - 1, rr = static_cast<int>((c >> 2) & 3u) - 1;
+                    obuf[idx] = strict ? static_cast<uint8_t>(c) : static_cast<uint8_t>(mode_all ? (rf != -1 ? rf : rr) == 1 : (rf == 1 || rr == 1));
+                }
                 const uint64_t m = __ballot(alive);
                 if (alive) {
                     const uint32_t pos = (loaded + static_cast<uint32_t>(__popcll(m & lanes_lt))) & 127u;
@@ -676,6 +718,8 @@ PairIndex make_pair_index(const fmsi_hip_index* idx) {
     p.ptable = idx->dev.ptable;
     p.ptable_len = idx->dev.ptable_len;
     p.ptable_packed = idx->dev.ptable_packed;
+    p.stable = static_cast<const uint32_t*>(idx->d_stable);
+    p.text2 = static_cast<const uint64_t*>(idx->d_text2);
     p.n = idx->dev.n;
     p.r0 = idx->dev.dollar;
     p.r1 = idx->pair_r1;
@@ -824,5 +868,90 @@ extern "C" int fmsi_hip_index_enable_pair_layout(fmsi_hip_index* idx) {
     idx->pair_r1 = r1;
     idx->pair_p1 = p1;
     idx->device_bytes += pb_bytes + n_super * 64 + 64;
+    return 0;
+}
+
+// ---- text verification (fmsi_hip_index_enable_verify) ----------------------------------------------------------------
+namespace fmsi {
+namespace {
+
+// letters (any case) -> 2-bit packed text, one thread per 32-base word; zero past the end
+__global__ __launch_bounds__(256) void chars_to_text2_kernel(const char* __restrict__ chars, uint64_t len, uint64_t n_words, uint64_t* __restrict__ text2) {
+    const uint64_t w = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (w >= n_words) return;
+    uint64_t v = 0;
+    for (uint32_t b = 0; b < 32u; ++b) {
+        const uint64_t p = w * 32u + b;
+        if (p >= len) break;
+        const uint32_t ch = static_cast<uint8_t>(chars[p]) | 0x20u;   // lower case
+        const uint64_t c = ch == 'a' ? 0u : (ch == 'c' ? 1u : (ch == 'g' ? 2u : 3u));
+        v |= c << (2u * b);
+    }
+    text2[w] = v;
+}
+
+// one-row table entries get their row's text position and, in bit 26 of the entry, the mask bit of the k-mer that would end there
+__global__ __launch_bounds__(256) void verify_fill_kernel(uint2* __restrict__ tab, uint64_t count, const uint32_t* __restrict__ sa,
+                                                          const char* __restrict__ chars, uint32_t R, uint32_t* __restrict__ stable) {
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
+    for (uint64_t idx = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; idx < count; idx += stride) {
+        const uint2 e = tab[idx];
+        uint32_t pos = 0;
+        if ((e.y >> 30) == 1u && ((e.y >> 24) & 3u) == 1u) {
+            pos = sa[e.x];
+            if (pos >= R) {
+                const char ch = chars[pos - R];
+                if (ch >= 'A' && ch <= 'Z') tab[idx] = make_uint2(e.x, e.y | (1u << 26));   // is_upper = mask 1, src/kmers.h:71-73
+            }
+        }
+        stable[idx] = pos;
+    }
+}
+
+}  // namespace
+}  // namespace fmsi
+
+extern "C" int fmsi_hip_index_enable_verify(fmsi_hip_index* idx) {
+    if (!idx) return FMSI_HIP_EINVAL;
+    if (idx->d_stable) return 0;
+    const int T = idx->prefix_len, R = idx->k - T;
+    if (!idx->d_ptable || !idx->dev.ptable_packed || idx->k > 32 || R < 1) {
+        set_last_error("text verification needs a packed prefix table with t < k <= 32");
+        return FMSI_HIP_EINVAL;
+    }
+    FMSI_HIP_TRY(hipSetDevice(idx->device));
+    const uint64_t n = idx->n, len = n - 1, count = 1ull << (2 * T);
+    char* d_chars = nullptr;
+    uint32_t *d_sa = nullptr, *d_stable = nullptr;
+    uint64_t* d_text2 = nullptr;
+    auto fail = [&](int code, const char* msg) {
+        for (void* p : {static_cast<void*>(d_chars), static_cast<void*>(d_sa), static_cast<void*>(d_stable), static_cast<void*>(d_text2)})
+            if (p) (void)hipFree(p);
+        if (msg) set_last_error(msg);
+        return code;
+    };
+    if (hipMalloc(reinterpret_cast<void**>(&d_chars), len + 1) != hipSuccess || hipMalloc(reinterpret_cast<void**>(&d_sa), n * 4) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void**>(&d_stable), count * 4) != hipSuccess)
+        return fail(FMSI_HIP_ENOMEM, "hipMalloc failed for the text verification tables");
+    int rc = export_walk(idx, d_chars, d_sa);
+    if (rc) return fail(rc, nullptr);
+    const uint64_t n_words = (len >> 5) + 2;
+    if (!idx->d_text2) {
+        if (hipMalloc(reinterpret_cast<void**>(&d_text2), n_words * 8) != hipSuccess) return fail(FMSI_HIP_ENOMEM, "hipMalloc failed for the text");
+        hipLaunchKernelGGL(chars_to_text2_kernel, dim3(static_cast<uint32_t>((n_words + 255) / 256)), dim3(256), 0, 0, d_chars, len, n_words, d_text2);
+    }
+    const uint32_t blocks = static_cast<uint32_t>(std::min<uint64_t>((count + 255) / 256, 1u << 20));
+    hipLaunchKernelGGL(verify_fill_kernel, dim3(blocks), dim3(256), 0, 0, static_cast<uint2*>(idx->d_ptable), count, d_sa, d_chars,
+                       static_cast<uint32_t>(R), d_stable);
+    if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess) return fail(FMSI_HIP_EHIP, "text verification: device work failed");
+    (void)hipFree(d_chars);
+    (void)hipFree(d_sa);
+    if (d_text2) {
+        idx->d_text2 = d_text2;
+        idx->text_len = len;
+        idx->device_bytes += n_words * 8;
+    }
+    idx->d_stable = d_stable;
+    idx->device_bytes += count * 4;
     return 0;
 }

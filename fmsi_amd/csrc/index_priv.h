@@ -55,7 +55,8 @@ struct fmsi_hip_index {
     void* d_sbt = nullptr;
     void* d_c2 = nullptr;
     uint32_t pair_r1 = 0xFFFFFFFFu, pair_p1 = 0xFFFFFFFFu;
-    void* d_text2 = nullptr;     // 2-bit packed superstring kept by the on-device builder (synthetic workloads)
+    void* d_text2 = nullptr;     // 2-bit packed superstring (kept by the on-device builder, or rebuilt by fmsi_hip_index_enable_verify)
+    void* d_stable = nullptr;    // text verification: per prefix-table entry the text position of its row when it has exactly one
     uint64_t text_len = 0;
     // staging for host-pointer calls
     void* d_in = nullptr; size_t d_in_cap = 0;
@@ -88,6 +89,10 @@ void launch_longk_query(fmsi_hip_index* idx, const uint64_t* d_seq, const uint64
 // needs the pair layout and a prefix table with k >= t
 int launch_phased_query(fmsi_hip_index* idx, const uint64_t* d_kmers, uint64_t n, int k, uint32_t flags, uint8_t* o8, long long* o64,
                         unsigned long long* d_counters, hipStream_t s);
+
+// the LF walk of `fmsi export` (fmsi_export.hip): letters with the mask's case into d_chars[0 .. n-2] (device), and
+// optionally sa[row] = text position of the row's suffix for every row (device, n entries)
+int export_walk(const fmsi_hip_index* idx, char* d_chars, uint32_t* d_sa);
 
 // grow-only device staging buffer
 inline int ensure_cap(void** p, size_t* cap, size_t need) {

@@ -676,7 +676,10 @@ extern "C" int fmsi_cli_query(int argc, char** argv, int output_orders_i) {
     int t = std::min(k, 16);
     while (t > 0 && (1ull << (2 * t)) > 4 * host->ix.n()) --t;
     view.prefix_len = t;
-    if (fmsi_hip_index_create(&view, opt.device, &dev) != 0 || (!opt.has_klcp && fmsi_hip_index_enable_pair_layout(dev) != 0)) {
+    // ... and, for presence queries, text verification of the intervals that leave the table with one row
+    const bool want_verify = !opt.has_klcp && !output_orders && t > 0 && t < k && k <= 32;
+    if (fmsi_hip_index_create(&view, opt.device, &dev) != 0 || (!opt.has_klcp && fmsi_hip_index_enable_pair_layout(dev) != 0) ||
+        (want_verify && fmsi_hip_index_enable_verify(dev) != 0)) {
         std::cerr << "ERROR: cannot create the device index: " << fmsi_hip_last_error() << std::endl;
         if (dev) fmsi_hip_index_destroy(dev);
         fmsi_host_index_free(host);

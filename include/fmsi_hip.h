@@ -112,7 +112,7 @@ typedef struct {
  *   [0] LF steps executed (update_range with i != j, src/fms_index.h:98-103)
  *   [1] interleaved blocks read (64-B units)          [2] mask probes / strand searches ending non-empty
  *   [3] strand searches started                       [4] prefix-table lookups   [5] kLCP words scanned
- *   [6] windows answered                              [7] reserved */
+ *   [6] windows answered                              [7] text-verification reads (position + text) */
 #define FMSI_HIP_N_COUNTERS 8
 
 /* ---- device side ------------------------------------------------------------------------------ */
@@ -161,6 +161,15 @@ int fmsi_host_index_write(const char* prefix, const fmsi_index_view* view);
 /* The `fmsi index` command (ms_index, src/main.cpp:172-236) with the suffix sort on the GPU; argv as the reference's
  * sub-command sees it (argv[0] = "index").  Returns the process exit code. */
 int fmsi_cli_index(int argc, char** argv);
+
+/* Adds text verification to a handle that has a prefix table and the pair layout (private optimisation, results
+ * unchanged): for every table entry whose interval is ONE row the text position of that row is kept, together with the
+ * 2-bit superstring.  A search that comes out of the table with such an interval is then settled by comparing the
+ * remaining k - t bases with the text directly (one read of the position, one of the text) instead of (k - t) / 2
+ * dependent block reads: the k-mer occurs iff the text matches, and the occurrence's mask bit is stored in the entry.
+ * Positions and text come from the LF walk of fmsi_hip_index_export, so any handle can add it.  Used by the phased
+ * kernels for the presence modes (not ORDERS).  4^t x 4 bytes + n / 4 bytes of HBM.  Idempotent. */
+int fmsi_hip_index_enable_verify(fmsi_hip_index* idx);
 
 /* Replaces export_ms() (src/fms_index.h:462-473): the masked superstring of the index (upper case = mask 1), written
  * to out[0 .. *out_len) without a terminator.  The reference's single LF chain of |MS| steps is cut into about a million

@@ -51,6 +51,12 @@ def test_both_strands_equal_oracle(fm, oracle_built, name):
     variants += [(dev_p, fm.KERNEL_PAIR), (dev_pe, fm.KERNEL_PAIR), (dev_po, fm.KERNEL_PAIR), (dev_pe, fm.KERNEL_REFILL)]
     # phased form (table lookups in a kernel of their own; what AUTO picks with a pair layout and a table)
     variants += [(dev_pe, fm.KERNEL_PHASED), (dev_po, fm.KERNEL_PHASED), (dev_po, 0)]
+    # ... with text verification of one-row table intervals (needs t < k)
+    dev_pv = fm.DeviceIndex.from_files(index_prefix(name), prefix_len=max(1, min(k, 6) - 1)).enable_pair_layout().enable_verify()
+    variants += [(dev_pv, fm.KERNEL_PHASED), (dev_pv, 0), (dev_pv, fm.KERNEL_PAIR)]
+    if k > 8:
+        dev_pv8 = fm.DeviceIndex.from_files(index_prefix(name), prefix_len=8).enable_pair_layout().enable_verify()
+        variants += [(dev_pv8, fm.KERNEL_PHASED)]
     for mode_all in (False, True):
         flag = fm.MODE_ALL if mode_all else fm.MODE_OR
         fwd, rc = orc.ternaries_bulk(raw, len(kmers), k, mode_all)
@@ -257,7 +263,7 @@ def test_large_prefix_tables(fm, oracle_built, t):
     kmers = mixed_kmers(ms, k, 20000, seed=t)
     raw = "".join(kmers).encode()
     packed = fm.pack_kmers(kmers, k)
-    dev = fm.DeviceIndex.from_files(index_prefix(name), use_klcp=True, prefix_len=t).enable_pair_layout()
+    dev = fm.DeviceIndex.from_files(index_prefix(name), use_klcp=True, prefix_len=t).enable_pair_layout().enable_verify()
     assert dev.info.prefix_len == t
     for mode_all in (False, True):
         flag = fm.MODE_ALL if mode_all else fm.MODE_OR
