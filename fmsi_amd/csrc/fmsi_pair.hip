@@ -171,11 +171,11 @@ __global__ void pair_counts_kernel(const U16* __restrict__ scanned, uint64_t n_b
 // Record of a k-mer: (i, j) with i < j = forward strand alive after the table; (j, i) = reverse complement alive, forward
 // strand absent; (c, c) = settled here, c = (forward result + 1) | (reverse-complement result + 1) << 2 -- (0, 0) = absent
 // on both strands.
-// Text verification (ix.stable): an interval of exactly ONE row leaves one candidate occurrence; its text position is
-// stored per table entry, so the remaining k - t bases are compared with the text itself -- present iff they match, with
-// the mask bit of that occurrence kept in the entry (bit 26) -- instead of (k - t) / 2 dependent block reads.  This is
-// infer_presence() of the interval get_range_with_pattern() would end with (src/fms_index.h:117-144): one row, that mask
-// bit; or the empty interval.
+// Text verification (ix.stable): an interval of one to three rows leaves that many candidate occurrences; their text
+// positions are stored per table entry, so the remaining k - t bases are compared with the text itself -- the candidates
+// that match are the rows of the interval get_range_with_pattern() would end with, their mask bits are kept in the entry
+// (bits 26-28) -- instead of (k - t) / 2 dependent block reads: infer_presence() (src/fms_index.h:117-144) from 1 + rows
+// reads.
 template <bool COUNT>
 __global__ __launch_bounds__(256) void pair_lookup_kernel(PairIndex ix, const uint64_t* __restrict__ kmers, uint64_t n_windows, int k, uint32_t flags,
                                                           long long* __restrict__ out_orders, uint2* __restrict__ rec,
@@ -216,19 +216,27 @@ __global__ __launch_bounds__(256) void pair_lookup_kernel(PairIndex ix, const ui
         decode_table_entry(ex, ey, ix.ptable_packed, t >= 3, t >= 3 ? static_cast<uint32_t>(cur >> (2 * (t - 3))) & 0xFFu : 0u, i, j);
         if (sub == 0u) n_lookups++;
         if (i == j) return 0u;
-        if (!(verify && (ey >> 30) == 1u && ((ey >> 24) & 3u) == 1u)) return 1u;
-        // one row: its text position, then the text in front of it
-        const uint32_t pos = ix.stable[tidx];
-        bool match = false;
-        if (pos >= R) {
+        if (!(verify && (ey >> 30) == 1u)) return 1u;
+        // one to three rows: their text positions (one 12-byte read), then the text in front of each (independent reads).
+        // Candidates that match are the rows of the final interval, in the same order (an equal prefix does not change the
+        // order of two suffixes): ALL takes the mask bit of the first, OR any mask bit (src/fms_index.h:126-144).
+        const uint32_t rows = (ey >> 24) & 3u;
+        const uint32_t* sp = ix.stable + 3ull * tidx;
+        const uint32_t pos0 = sp[0], pos1 = sp[1], pos2 = sp[2];
+        auto text_matches = [&](uint32_t pos) -> bool {
+            if (pos < R) return false;
             const uint64_t p0 = static_cast<uint64_t>(pos - R), w = p0 >> 5;
             const uint32_t sh = static_cast<uint32_t>(p0 & 31u) * 2u;
             uint64_t tx = ix.text2[w] >> sh;
             if (sh) tx |= ix.text2[w + 1] << (64u - sh);
-            match = ((tx ^ cur) & rmask) == 0ull;
-        }
-        if (sub == 0u) n_vreads += 2u;
-        res = match ? static_cast<int>((ey >> 26) & 1u) : -1;
+            return ((tx ^ cur) & rmask) == 0ull;
+        };
+        const bool m0 = text_matches(pos0), m1 = rows > 1u && text_matches(pos1), m2 = rows > 2u && text_matches(pos2);
+        if (sub == 0u) n_vreads += 1u + rows;
+        const uint32_t k0 = (ey >> 26) & 1u, k1 = (ey >> 27) & 1u, k2 = (ey >> 28) & 1u;
+        if (!(m0 || m1 || m2)) res = -1;
+        else if (mode_all) res = static_cast<int>(m0 ? k0 : (m1 ? k1 : k2));
+        else res = static_cast<int>((m0 && k0) || (m1 && k1) || (m2 && k2));
         return 2u;
     };
 
@@ -890,21 +898,29 @@ __global__ __launch_bounds__(256) void chars_to_text2_kernel(const char* __restr
     text2[w] = v;
 }
 
-// one-row table entries get their row's text position and, in bit 26 of the entry, the mask bit of the k-mer that would end there
+// table entries of one to three rows get their rows' text positions and, in bits 26-28 of the entry, the mask bits of the
+// k-mers that would end there
 __global__ __launch_bounds__(256) void verify_fill_kernel(uint2* __restrict__ tab, uint64_t count, const uint32_t* __restrict__ sa,
                                                           const char* __restrict__ chars, uint32_t R, uint32_t* __restrict__ stable) {
     const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
     for (uint64_t idx = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; idx < count; idx += stride) {
         const uint2 e = tab[idx];
-        uint32_t pos = 0;
-        if ((e.y >> 30) == 1u && ((e.y >> 24) & 3u) == 1u) {
-            pos = sa[e.x];
-            if (pos >= R) {
-                const char ch = chars[pos - R];
-                if (ch >= 'A' && ch <= 'Z') tab[idx] = make_uint2(e.x, e.y | (1u << 26));   // is_upper = mask 1, src/kmers.h:71-73
+        uint32_t pos[3] = {0, 0, 0};
+        if ((e.y >> 30) == 1u) {
+            const uint32_t rows = (e.y >> 24) & 3u;
+            uint32_t y = e.y;
+            for (uint32_t m = 0; m < rows; ++m) {
+                pos[m] = sa[e.x + m];
+                if (pos[m] >= R) {
+                    const char ch = chars[pos[m] - R];
+                    if (ch >= 'A' && ch <= 'Z') y |= 1u << (26u + m);   // is_upper = mask 1, src/kmers.h:71-73
+                }
             }
+            if (y != e.y) tab[idx] = make_uint2(e.x, y);
         }
-        stable[idx] = pos;
+        stable[3 * idx] = pos[0];
+        stable[3 * idx + 1] = pos[1];
+        stable[3 * idx + 2] = pos[2];
     }
 }
 
@@ -931,7 +947,7 @@ extern "C" int fmsi_hip_index_enable_verify(fmsi_hip_index* idx) {
         return code;
     };
     if (hipMalloc(reinterpret_cast<void**>(&d_chars), len + 1) != hipSuccess || hipMalloc(reinterpret_cast<void**>(&d_sa), n * 4) != hipSuccess ||
-        hipMalloc(reinterpret_cast<void**>(&d_stable), count * 4) != hipSuccess)
+        hipMalloc(reinterpret_cast<void**>(&d_stable), count * 12) != hipSuccess)
         return fail(FMSI_HIP_ENOMEM, "hipMalloc failed for the text verification tables");
     int rc = export_walk(idx, d_chars, d_sa);
     if (rc) return fail(rc, nullptr);
@@ -952,6 +968,6 @@ extern "C" int fmsi_hip_index_enable_verify(fmsi_hip_index* idx) {
         idx->device_bytes += n_words * 8;
     }
     idx->d_stable = d_stable;
-    idx->device_bytes += count * 4;
+    idx->device_bytes += count * 12;
     return 0;
 }

@@ -163,12 +163,13 @@ int fmsi_host_index_write(const char* prefix, const fmsi_index_view* view);
 int fmsi_cli_index(int argc, char** argv);
 
 /* Adds text verification to a handle that has a prefix table and the pair layout (private optimisation, results
- * unchanged): for every table entry whose interval is ONE row the text position of that row is kept, together with the
- * 2-bit superstring.  A search that comes out of the table with such an interval is then settled by comparing the
- * remaining k - t bases with the text directly (one read of the position, one of the text) instead of (k - t) / 2
- * dependent block reads: the k-mer occurs iff the text matches, and the occurrence's mask bit is stored in the entry.
+ * unchanged): for every table entry whose interval has one to three rows the text positions of those rows are kept,
+ * together with the 2-bit superstring.  A search that comes out of the table with such an interval is then settled by
+ * comparing the remaining k - t bases with the text directly (one read of the positions, one of the text per row)
+ * instead of (k - t) / 2 dependent block reads: the rows that match are the final interval, and their mask bits are
+ * stored in the entry.
  * Positions and text come from the LF walk of fmsi_hip_index_export, so any handle can add it.  Used by the phased
- * kernels for the presence modes (not ORDERS).  4^t x 4 bytes + n / 4 bytes of HBM.  Idempotent. */
+ * kernels for the presence modes (not ORDERS).  4^t x 12 bytes + n / 4 bytes of HBM.  Idempotent. */
 int fmsi_hip_index_enable_verify(fmsi_hip_index* idx);
 
 /* Replaces export_ms() (src/fms_index.h:462-473): the masked superstring of the index (upper case = mask 1), written
