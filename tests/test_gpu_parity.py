@@ -284,3 +284,44 @@ def test_large_prefix_tables(fm, oracle_built, t):
     assert np.array_equal(gf, fwd) and np.array_equal(gr, rc)
     gf, gr = fm.decode_strict(dev.query_runs(fm.pack_sequence(seq.encode()), len(seq), starts, wins, k, fm.MODE_ALL | fm.STRICT))
     assert np.array_equal(gf, fwd) and np.array_equal(gr, rc)
+
+
+@pytest.mark.parametrize("t,k", [(3, 9), (4, 12), (5, 7), (6, 31), (7, 8)])
+def test_text_verification_on_repeats_and_text_start(fm, oracle_built, t, k):
+    """Text verification (fmsi_hip_index_enable_verify) where it is delicate: k-mers that occur two and three times with
+    DIFFERENT mask bits (the first match decides -O, any match the default mode), candidates that fail only in their
+    last base, k-mers at the very start of the text (position < k - t), reverse complements, and table depths that leave
+    1..3 rows often.  Every mode against the oracle, strand by strand."""
+    rng = random.Random(100 * t + k)
+    core = "".join(rng.choice("ACGT") for _ in range(k + 6))
+    parts = []
+    for rep in range(3):   # the same stretch three times, with different case (mask) each time and different neighbours
+        piece = core.upper() if rep == 0 else (core.lower() if rep == 1 else "".join(c.upper() if rng.random() < 0.5 else c.lower() for c in core))
+        parts.append("".join(rng.choice("ACGTacgt") for _ in range(rng.randrange(20, 60))) + piece)
+    near = core[:k - 1] + ("A" if core[k - 1] != "A" else "C") + core[k:]   # equal but for one base
+    ms = core[:k + 2].upper() + "".join(parts) + near.lower() + "".join(rng.choice("ACGTacgt") for _ in range(400))
+    ms = ms[:len(ms) - (k - 1)] + ms[len(ms) - (k - 1):].lower()
+    orc = oracle_py.Oracle.construct(ms, k, use_klcp=False)
+    dev = fm.DeviceIndex.build(ms.encode(), k, prefix_len=t).enable_pair_layout().enable_verify()
+    up = ms.upper()
+    kmers = [up[p:p + k] for p in range(len(up) - k + 1)]
+    kmers += [revcomp(x) for x in kmers]
+    kmers += ["".join(rng.choice("ACGT") for _ in range(k)) for _ in range(500)]
+    kmers += [x[:-1] + rng.choice("ACGT") for x in kmers[:300]] + [rng.choice("ACGT") + x[1:] for x in kmers[:300]]
+    raw = "".join(kmers).encode()
+    packed = fm.pack_kmers(kmers, k)
+    for mode_all in (False, True):
+        flag = fm.MODE_ALL if mode_all else fm.MODE_OR
+        fwd, rc = orc.ternaries_bulk(raw, len(kmers), k, mode_all)
+        for kern in (fm.KERNEL_PHASED, 0):
+            gf, gr = fm.decode_strict(dev.query_kmers(packed, k, flag | fm.STRICT | kern))
+            assert np.array_equal(gf, fwd), np.nonzero(gf != fwd)[0][:10]
+            assert np.array_equal(gr, rc), np.nonzero(gr != rc)[0][:10]
+            fast = dev.query_kmers(packed, k, flag | kern)
+            assert np.array_equal(fast.astype(bool), expected_fast(fwd, rc, mode_all))
+    assert (fwd == 0).any() and (fwd == 1).any() and (rc == 1).any()
+    _, cn = dev.query_kmers(packed, k, fm.MODE_ALL | fm.STRICT, counters=True)
+    assert int(cn[7]) > 0        # verification reads happened
+    fwd, rc, of, orr = orc.ternaries_bulk(raw, len(kmers), k, False, orders=True)
+    got = dev.query_kmers(packed, k, fm.ORDERS | fm.STRICT)   # lookup never verifies: ranks come from the steps
+    assert np.array_equal(got[:, 0], of) and np.array_equal(got[:, 1], orr)
