@@ -417,7 +417,11 @@ int build_prefix_table(fmsi_hip_index* idx, int t) {
     const uint64_t final_count = 1ull << (2 * t);
     uint2 *a = nullptr, *b = nullptr;
     // +64 B so that reading the whole line of the last entry stays inside the allocation
-    FMSI_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&a), final_count * sizeof(uint2) + 64));
+    if (hipMalloc(reinterpret_cast<void**>(&a), final_count * sizeof(uint2) + 64) != hipSuccess) {
+        (void)hipGetLastError();
+        set_last_error("hipMalloc failed for the prefix table (" + std::to_string(final_count * sizeof(uint2) >> 20) + " MiB)");
+        return FMSI_HIP_ENOMEM;
+    }
     if (t > 1) {
         if (hipMalloc(reinterpret_cast<void**>(&b), (final_count / 4) * sizeof(uint2) + 64) != hipSuccess) {
             (void)hipFree(a);

@@ -675,16 +675,26 @@ extern "C" int fmsi_cli_query(int argc, char** argv, int output_orders_i) {
     // the two-base-step pair layout
     int t = std::min(k, 16);
     while (t > 0 && (1ull << (2 * t)) > 4 * host->ix.n()) --t;
-    view.prefix_len = t;
-    // ... and, for presence queries, text verification of the intervals that leave the table with one row
-    const bool want_verify = !opt.has_klcp && !output_orders && t > 0 && t < k && k <= 32;
-    if (fmsi_hip_index_create(&view, opt.device, &dev) != 0 || (!opt.has_klcp && fmsi_hip_index_enable_pair_layout(dev) != 0) ||
-        (want_verify && fmsi_hip_index_enable_verify(dev) != 0)) {
+    // ... and, for presence queries, text verification of the intervals that leave the table with one to three rows.
+    // The accelerators are large (34 GB + 52 GB at human scale): when HBM is short -- the GPU shared with other work --
+    // the table shrinks and the verification is left out; only a failure of the index proper is an error.
+    int rc_create = FMSI_HIP_ENOMEM;
+    for (; t >= 0; t -= 2) {
+        view.prefix_len = std::max(t, 0);
+        rc_create = fmsi_hip_index_create(&view, opt.device, &dev);
+        if (rc_create != FMSI_HIP_ENOMEM || t == 0) break;
+        std::cerr << "WARNING: not enough device memory for a prefix table of depth " << t << ", trying " << std::max(t - 2, 0) << std::endl;
+    }
+    t = std::max(t, 0);
+    if (rc_create != 0 || (!opt.has_klcp && fmsi_hip_index_enable_pair_layout(dev) != 0)) {
         std::cerr << "ERROR: cannot create the device index: " << fmsi_hip_last_error() << std::endl;
         if (dev) fmsi_hip_index_destroy(dev);
         fmsi_host_index_free(host);
         return 1;
     }
+    const bool want_verify = !opt.has_klcp && !output_orders && t > 0 && t < k && k <= 32;
+    if (want_verify && fmsi_hip_index_enable_verify(dev) != 0)
+        std::cerr << "WARNING: text verification is off (" << fmsi_hip_last_error() << "); results are unaffected" << std::endl;
     auto t_loaded = clock::now();
 
     // OR-mode presence output does not depend on the strand order, so the cheaper schedule is exact;
