@@ -213,8 +213,7 @@ def main():
             block_b = 128 if (args.kernel in ("pair", "phased") and not stream_mode) else 64
             bytes_launch = block_b * (blocks_read - lookups) + 64 * lookups + 8 * klcp_words + in_bytes + 1 * batch
             bytes_launch += 32 * verify_reads   # counted as two 32-byte sectors per verification
-            if args.kernel == "phased" and not stream_mode and args.prefix_len > 0:
-                bytes_launch += 24 * batch   # the lookup kernel's 8-byte record per k-mer (written, read back) + the k-mer read a second time
+            # (phased form: the work items of the searches left to the stepping kernel -- 48 bytes for about 3 % of the k-mers -- are not counted)
             canon_bytes = 256 * int(canonical[0]) + 64 * int(canonical[2]) + 8 * int(canonical[5]) + in_bytes + batch // 8
             ach = bytes_launch / avg_kernel_s / 1e9
             roof = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -157,6 +157,13 @@ __global__ void pair_counts_kernel(const U16* __restrict__ scanned, uint64_t n_b
     }
 }
 
+struct alignas(8) WorkItem {   // a search the lookup kernel leaves to the stepping kernel
+    uint64_t f;        // the k-mer (forward orientation)
+    uint32_t x, y;     // (i, j): forward strand alive after the table; (j, i): the reverse complement is, the forward strand is absent
+    uint32_t ql, pad;  // index of the k-mer in its wave's chunk
+};
+static_assert(sizeof(WorkItem) == 24, "WorkItem layout");
+
 // ---- phase 1 of the phased path: the table lookups ------------------------------------------------------------------
 // With the next-base signatures in the table most absent k-mers are settled by their two lookups.  Doing the lookups
 // in a kernel of their own -- dense, no state machine -- and handing only the searches that are still alive to the
@@ -168,9 +175,10 @@ __global__ void pair_counts_kernel(const U16* __restrict__ scanned, uint64_t n_b
 // lanes on one line cost the memory path one request, 64 different lines per instruction cost it more than twice 32.
 // Result per k-mer: one 8-byte record, (i, j) of the strand that is alive after the table -- stored as (j, i) when that
 // is the reverse complement (the forward strand died in the table) -- or (0, 0) when both strands died.
-// Record of a k-mer: (i, j) with i < j = forward strand alive after the table; (j, i) = reverse complement alive, forward
-// strand absent; (c, c) = settled here, c = (forward result + 1) | (reverse-complement result + 1) << 2 -- (0, 0) = absent
-// on both strands.
+// A wave owns a contiguous chunk of k-mers (the same chunks as the stepping kernel's waves).  K-mers that are settled here
+// get their result written at once; the others go to the wave's PRIVATE work list -- list[chunk start + count++], no
+// atomics -- as (k-mer, interval, index in the chunk), the interval (i, j) with i < j when the forward strand is alive
+// after the table and (j, i) when that is the reverse complement (forward strand absent).
 // Text verification (ix.stable): an interval of one to three rows leaves that many candidate occurrences; their text
 // positions are stored per table entry, so the remaining k - t bases are compared with the text itself -- the candidates
 // that match are the rows of the interval get_range_with_pattern() would end with, their mask bits are kept in the entry
@@ -178,7 +186,8 @@ __global__ void pair_counts_kernel(const U16* __restrict__ scanned, uint64_t n_b
 // reads.
 template <bool COUNT>
 __global__ __launch_bounds__(256) void pair_lookup_kernel(PairIndex ix, const uint64_t* __restrict__ kmers, uint64_t n_windows, int k, uint32_t flags,
-                                                          long long* __restrict__ out_orders, uint2* __restrict__ rec,
+                                                          uint32_t chunk, uint8_t* __restrict__ out, long long* __restrict__ out_orders,
+                                                          WorkItem* __restrict__ list, uint32_t* __restrict__ list_count,
                                                           unsigned long long* __restrict__ counters) {
     const uint32_t strict = flags & FMSI_HIP_STRICT;
     const uint32_t orders = flags & FMSI_HIP_ORDERS;
@@ -189,11 +198,14 @@ __global__ __launch_bounds__(256) void pair_lookup_kernel(PairIndex ix, const ui
     const uint64_t rmask = R >= 32u ? ~0ull : ((1ull << (2u * R)) - 1ull);
     const bool verify = ix.stable != nullptr && ix.ptable_packed && !orders && R >= 1u && R <= 32u;
     const uint32_t tmask = static_cast<uint32_t>((1ull << (2 * T)) - 1ull);
-    const uint64_t stride = (static_cast<uint64_t>(gridDim.x) * blockDim.x) >> 1;
-    const uint32_t sub = threadIdx.x & 1u;
-    const int pbase = static_cast<int>(threadIdx.x & 63u & ~1u);
+    const uint32_t lane = threadIdx.x & 63u, sub = lane & 1u;
+    const int pbase = static_cast<int>(lane & ~1u);
+    const uint64_t pairs_below = (1ull << (lane & ~1u)) - 1ull;
     uint32_t n_lookups = 0, n_final = 0, n_vreads = 0;
-    const uint64_t n_round = (n_windows + 31) & ~31ull;   // whole waves stay in the loop: the shuffles below need both lanes of a pair
+    const uint64_t wave = (static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t start = wave * chunk;
+    const uint32_t len = start < n_windows ? static_cast<uint32_t>(min(static_cast<uint64_t>(chunk), n_windows - start)) : 0u;
+    uint32_t count = 0;   // wave-uniform: work items written so far
 
     // one strand: table lookup (+ verification).  state 0 = absent, 1 = alive (needs the stepping kernel), 2 = settled (res)
     auto strand = [&](uint64_t cur, bool go, uint32_t& i, uint32_t& j, int& res) -> uint32_t {
@@ -240,8 +252,10 @@ __global__ __launch_bounds__(256) void pair_lookup_kernel(PairIndex ix, const ui
         return 2u;
     };
 
-    for (uint64_t q = (static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 1; q < n_round; q += stride) {
-        const bool valid = q < n_windows;
+    for (uint32_t base = 0; base < len; base += 32u) {   // 32 k-mers per round, one per lane pair; whole waves stay in the loop
+        const uint32_t ql = base + (lane >> 1);
+        const bool valid = ql < len;
+        const uint64_t q = start + ql;
         const uint64_t f = valid ? kmers[q] : 0ull;
         uint32_t i_f, j_f, i_r = 0, j_r = 0;
         int res_f, res_r = -1;
@@ -251,26 +265,39 @@ __global__ __launch_bounds__(256) void pair_lookup_kernel(PairIndex ix, const ui
         const bool need_rc = valid && sf != 1u && (strict || (mode_all && !orders ? res_f == -1 : res_f != 1));
         uint32_t sr = 0;
         if (__any(need_rc)) sr = strand(revcomp_2bit(f, k), need_rc, i_r, j_r, res_r);
-        if (valid && sub == 0u) {
-            uint2 r;
-            if (sf == 1u) r = make_uint2(i_f, j_f);
-            else if (sr == 1u) r = res_f == -1 ? make_uint2(j_r, i_r) : make_uint2(i_f, j_f);   // a settled forward 0 / 1 cannot ride along: redo it by steps
-            else {
-                const uint32_t c = static_cast<uint32_t>(res_f + 1) | (static_cast<uint32_t>(res_r + 1) << 2);
-                r = make_uint2(c, c);
-                n_final++;
-                if (orders) {   // (verification is off for lookup: both strands absent)
-                    if (strict) {
-                        out_orders[2 * q] = -1;
-                        out_orders[2 * q + 1] = -1;
-                    } else {
-                        out_orders[q] = -1;
-                    }
+        const bool alive = valid && (sf == 1u || sr == 1u);
+        if (valid && !alive && sub == 0u) {   // settled: the result leaves here
+            n_final++;
+            if (orders) {   // (verification is off for lookup: both strands absent)
+                if (strict) {
+                    out_orders[2 * q] = -1;
+                    out_orders[2 * q + 1] = -1;
+                } else {
+                    out_orders[q] = -1;
                 }
+            } else if (strict) {
+                out[q] = static_cast<uint8_t>(static_cast<uint32_t>(res_f + 1) | (static_cast<uint32_t>(res_r + 1) << 2));
+            } else {
+                out[q] = static_cast<uint8_t>(mode_all ? (res_f != -1 ? res_f : res_r) == 1 : (res_f == 1 || res_r == 1));
             }
-            rec[q] = r;
+        }
+        const uint64_t m = __ballot(alive) & 0x5555555555555555ull;   // one bit per lane pair
+        if (m) {
+            if (alive && sub == 0u) {
+                WorkItem w;
+                w.f = f;
+                // a settled forward 0 / 1 cannot ride along with a reverse complement that needs steps: the forward strand is redone
+                const bool fwd_item = sf == 1u || res_f != -1;
+                w.x = fwd_item ? i_f : j_r;
+                w.y = fwd_item ? j_f : i_r;
+                w.ql = ql;
+                w.pad = 0;
+                list[start + count + static_cast<uint32_t>(__popcll(m & pairs_below))] = w;
+            }
+            count += static_cast<uint32_t>(__popcll(m));
         }
     }
+    if (lane == 0u && start < n_windows) list_count[wave] = count;
     if (COUNT) {
         uint32_t v[4] = {n_lookups, n_lookups, n_final, n_vreads};   // strand searches started = table lookups = lines read
         const int slot[4] = {3, 4, 6, 7};
@@ -338,13 +365,14 @@ struct PairCounters {
     uint32_t lf_steps = 0, blocks = 0, probes = 0, searches = 0, lookups = 0;
 };
 
-// LIST: phase 2 of the phased path -- rec[q] holds what pair_lookup_kernel found for k-mer q; the k-mers whose record is
-// dead get their 0 here, the others enter the state machine after their table lookup.
+// LIST: phase 2 of the phased path -- the wave's work items are the searches pair_lookup_kernel left alive in the same
+// chunk (list[chunk start ..], list_count[wave] of them); they enter the state machine after their table lookup and
+// their results go straight to their k-mers' places.
 template <bool COUNT, bool PTABLE, bool LIST>
 __global__ __launch_bounds__(256) void query_pair_kernel(PairIndex ix, const uint64_t* __restrict__ kmers, uint64_t n_windows, int k,
                                                          uint32_t flags, uint32_t chunk, uint32_t n_super, uint8_t* __restrict__ out,
                                                          long long* __restrict__ out_orders, unsigned long long* __restrict__ counters,
-                                                         const uint2* __restrict__ rec) {
+                                                         const WorkItem* __restrict__ list, const uint32_t* __restrict__ list_count) {
     // LDS: C2[16] and the superblock table (every step needs three of their words; as global loads -- even cache hits --
     // they compete with the block reads for the memory pipeline), and per wave a ring of 128 k-mers and the chunk's
     // result bytes, so that k-mers arrive and results leave in whole cache lines instead of one request each.
@@ -367,12 +395,26 @@ __global__ __launch_bounds__(256) void query_pair_kernel(PairIndex ix, const uin
     const uint64_t pairs_below = (1ull << pbase) - 1ull;
     const uint64_t wave = (static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
     const uint64_t start = wave * chunk;                                               // my chunk: [start, start + len)
-    const uint32_t len = start < n_windows ? static_cast<uint32_t>(min(static_cast<uint64_t>(chunk), n_windows - start)) : 0u;
+    const uint32_t len = start >= n_windows ? 0u
+                         : (LIST ? list_count[wave] : static_cast<uint32_t>(min(static_cast<uint64_t>(chunk), n_windows - start)));
+    // LIST: the chunk's result bytes -- the lookup kernel wrote the settled ones -- are taken into LDS, overlaid with this
+    // wave's results and written back as whole lines (a chunk with nothing left to search is not touched)
+    const uint32_t clen = start < n_windows ? static_cast<uint32_t>(min(static_cast<uint64_t>(chunk), n_windows - start)) : 0u;
+    if (LIST && len && !orders) {
+        const uint8_t* src = out + start;
+        const bool aligned = (reinterpret_cast<uintptr_t>(src) & 15u) == 0;
+        for (uint32_t off = lane * 16u; off < clen; off += 64u * 16u) {
+            if (aligned && off + 16u <= clen) {
+                *reinterpret_cast<uint4*>(obuf + off) = *reinterpret_cast<const uint4*>(src + off);
+            } else {
+                for (uint32_t b = off; b < min(clen, off + 16u); ++b) obuf[b] = src[b];
+            }
+        }
+    }
     uint32_t next = 0, loaded = 0;                  // wave-uniform: handed out / landed in the ring (relative to start)
     uint64_t pend = 0, pend_ij = 0;                 // k-mer (+ LIST: record) batch in flight from global memory
     bool pend_valid = false;
-    uint32_t fetched = 0;                           // LIST: records consumed from the chunk (`loaded` then counts the live ones)
-    const uint64_t lanes_lt = (1ull << lane) - 1ull;
+    uint32_t pend_ql = 0;
     const int T = PTABLE ? static_cast<int>(ix.ptable_len) : 0;
     const int shift = static_cast<int>(sub * 64u);  // first row of my half within the block
 
@@ -420,10 +462,9 @@ __global__ __launch_bounds__(256) void query_pair_kernel(PairIndex ix, const uin
                 } else {
                     out_orders[qa] = was_second ? orr : of;
                 }
-            } else if (strict) {
-                obuf[q] = static_cast<uint8_t>((rf + 1) | ((rr + 1) << 2));
             } else {
-                obuf[q] = static_cast<uint8_t>((was_second ? rr : rf) == 1);
+                const uint8_t byte = strict ? static_cast<uint8_t>((rf + 1) | ((rr + 1) << 2)) : static_cast<uint8_t>((was_second ? rr : rf) == 1);
+                obuf[q] = byte;
             }
         }
         st = PS_IDLE;
@@ -433,28 +474,12 @@ __global__ __launch_bounds__(256) void query_pair_kernel(PairIndex ix, const uin
     for (;;) {
         // (0) the batch of k-mers requested last iteration has arrived: land it in the ring
         if (pend_valid) {
-            if (LIST) {   // only the k-mers still alive after the table enter the ring; the others are absent: result 0
-                const uint32_t idx = fetched + lane;
-                const bool in = idx < len;
-                const bool alive = in && static_cast<uint32_t>(pend_ij) != static_cast<uint32_t>(pend_ij >> 32);
-                if (in && !alive && !orders) {   // settled by the lookup kernel: (c, c), c = (forward + 1) | (reverse complement + 1) << 2
-                    const uint32_t c = static_cast<uint32_t>(pend_ij);
-                    const int rf = static_cast<int>(c & 3u) - 1, rr = static_cast<int>((c >> 2) & 3u) - 1;
-                    obuf[idx] = strict ? static_cast<uint8_t>(c) : static_cast<uint8_t>(mode_all ? (rf != -1 ? rf : rr) == 1 : (rf == 1 || rr == 1));
-                }
-                const uint64_t m = __ballot(alive);
-                if (alive) {
-                    const uint32_t pos = (loaded + static_cast<uint32_t>(__popcll(m & lanes_lt))) & 127u;
-                    ring[pos] = pend;
-                    ring[128u + pos] = pend_ij;
-                    ring_ql[pos] = idx;
-                }
-                loaded += static_cast<uint32_t>(__popcll(m));
-                fetched = min(len, fetched + 64u);
-            } else {
-                ring[(loaded + lane) & 127u] = pend;
-                loaded = min(len, loaded + 64u);
+            ring[(loaded + lane) & 127u] = pend;
+            if (LIST) {
+                ring[128u + ((loaded + lane) & 127u)] = pend_ij;
+                ring_ql[(loaded + lane) & 127u] = pend_ql;
             }
+            loaded = min(len, loaded + 64u);
             pend_valid = false;
         }
         // (1) idle lane pairs draw the next k-mers of the chunk: ballot + prefix rank over a wave-uniform cursor
@@ -489,17 +514,20 @@ __global__ __launch_bounds__(256) void query_pair_kernel(PairIndex ix, const uin
             }
         }
         // (2) keep the ring ahead of the cursor: one coalesced 512-byte read per 64 k-mers, consumed next iteration
-        if (!pend_valid && (LIST ? fetched : loaded) < len && loaded - next <= 64u) {
-            const uint32_t idx = (LIST ? fetched : loaded) + lane;
-            pend = idx < len ? kmers[start + idx] : 0ull;
+        if (!pend_valid && loaded < len && loaded - next <= 64u) {
+            const uint32_t idx = loaded + lane;
             if (LIST) {
-                const uint2 r = idx < len ? rec[start + idx] : make_uint2(0u, 0u);
-                pend_ij = static_cast<uint64_t>(r.x) | (static_cast<uint64_t>(r.y) << 32);
+                const uint64_t* w = reinterpret_cast<const uint64_t*>(list + start + (idx < len ? idx : 0u));
+                pend = w[0];
+                pend_ij = w[1];
+                pend_ql = static_cast<uint32_t>(w[2]);
+            } else {
+                pend = idx < len ? kmers[start + idx] : 0ull;
             }
             pend_valid = true;
         }
         if (!__any(st != PS_IDLE)) {
-            if (LIST ? (fetched >= len && next >= loaded && !pend_valid) : (next >= len && !pend_valid)) break;
+            if (next >= len && !pend_valid) break;
             continue;
         }
         if (st != PS_IDLE) {
@@ -695,12 +723,13 @@ __global__ __launch_bounds__(256) void query_pair_kernel(PairIndex ix, const uin
     }
     if (!orders && len) {   // the chunk's result bytes leave in 16-byte pieces (whole lines), not one request per k-mer
         uint8_t* dst = out + start;
+        const uint32_t olen = LIST ? clen : len;
         const bool aligned = (reinterpret_cast<uintptr_t>(dst) & 15u) == 0;
-        for (uint32_t off = lane * 16u; off < len; off += 64u * 16u) {
-            if (aligned && off + 16u <= len) {
+        for (uint32_t off = lane * 16u; off < olen; off += 64u * 16u) {
+            if (aligned && off + 16u <= olen) {
                 *reinterpret_cast<uint4*>(dst + off) = *reinterpret_cast<const uint4*>(obuf + off);
             } else {
-                for (uint32_t b = off; b < min(len, off + 16u); ++b) dst[b] = obuf[b];
+                for (uint32_t b = off; b < min(olen, off + 16u); ++b) dst[b] = obuf[b];
             }
         }
     }
@@ -739,21 +768,25 @@ PairIndex make_pair_index(const fmsi_hip_index* idx) {
 template <bool COUNT>
 int launch_phased_t(fmsi_hip_index* idx, const uint64_t* d_kmers, uint64_t n, int k, uint32_t flags, uint8_t* o8, long long* o64,
                     unsigned long long* d_counters, hipStream_t s) {
-    int rc = ensure_cap(&idx->d_tasks, &idx->d_tasks_cap, n * sizeof(uint2));   // one record per k-mer
-    if (rc) return rc;
-    auto* d_rec = static_cast<uint2*>(idx->d_tasks);
-    const PairIndex pix = make_pair_index(idx);
-    const uint32_t lb = static_cast<uint32_t>(std::min<uint64_t>((2 * n + 255) / 256, 1u << 23));
-    hipLaunchKernelGGL((pair_lookup_kernel<COUNT>), dim3(lb), dim3(256), 0, s, pix, d_kmers, n, k, flags, o64, d_rec, d_counters);
-    FMSI_HIP_TRY(hipGetLastError());
+    // both kernels cut the batch into the same chunks, one per wave
     uint64_t chunk = n / (256ull * 32 * 8 * 2);
     chunk = std::min<uint64_t>(std::max<uint64_t>(chunk, 128), 2048);
     const uint64_t waves = (n + chunk - 1) / chunk;
     const uint32_t blocks = static_cast<uint32_t>((waves + 3) / 4);
+    // per wave a private work list with room for its whole chunk, and its length
+    const size_t list_bytes = (n * sizeof(WorkItem) + 63) / 64 * 64;
+    int rc = ensure_cap(&idx->d_tasks, &idx->d_tasks_cap, list_bytes + waves * 4);
+    if (rc) return rc;
+    auto* d_list = static_cast<WorkItem*>(idx->d_tasks);
+    auto* d_count = reinterpret_cast<uint32_t*>(static_cast<char*>(idx->d_tasks) + list_bytes);
+    const PairIndex pix = make_pair_index(idx);
+    hipLaunchKernelGGL((pair_lookup_kernel<COUNT>), dim3(blocks), dim3(256), 0, s, pix, d_kmers, n, k, flags, static_cast<uint32_t>(chunk), o8, o64,
+                       d_list, d_count, d_counters);
+    FMSI_HIP_TRY(hipGetLastError());
     const uint32_t n_super = static_cast<uint32_t>(((idx->n_blocks - 1) >> kSuperBlocksLog2) + 1);
     const size_t lds_bytes = (((16 + 16 * static_cast<size_t>(n_super) + 2) & ~size_t(1)) + 4 * 640 + 4 * 512) * 4;
     hipLaunchKernelGGL((query_pair_kernel<COUNT, true, true>), dim3(blocks), dim3(256), lds_bytes, s, pix, d_kmers, n, k, flags,
-                       static_cast<uint32_t>(chunk), n_super, o8, o64, d_counters, d_rec);
+                       static_cast<uint32_t>(chunk), n_super, o8, o64, d_counters, d_list, d_count);
     FMSI_HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -770,7 +803,7 @@ void launch_pair_t(fmsi_hip_index* idx, const uint64_t* d_kmers, uint64_t n, int
     // tables (<= 33 KB for any n < 2^32) + per wave: 1 KB k-mer ring + 2 KB result bytes (chunk <= 2048)
     const size_t lds_bytes = (((16 + 16 * static_cast<size_t>(n_super) + 2) & ~size_t(1)) + 4 * 256 + 4 * 512) * 4;
     hipLaunchKernelGGL((query_pair_kernel<COUNT, PTABLE, false>), dim3(blocks), dim3(256), lds_bytes, s, make_pair_index(idx), d_kmers, n, k, flags,
-                       static_cast<uint32_t>(chunk), n_super, o8, o64, d_counters, nullptr);
+                       static_cast<uint32_t>(chunk), n_super, o8, o64, d_counters, nullptr, nullptr);
 }
 
 }  // namespace
