@@ -54,8 +54,10 @@ struct PairIndex {
     const uint32_t* mrank;    // n_blocks + 1 cumulative mask popcounts (shared with the single-step layout)
     const uint4* sblocks;     // the single-step layout (its mask plane serves the explicit probes)
     const uint2* ptable;
-    const uint32_t* stable;   // text verification (fmsi_hip_index_enable_verify) or nullptr: text position of one-row entries
+    const uint32_t* stable;   // text verification (fmsi_hip_index_enable_verify) or nullptr: three words per table entry, see verify_bases
     const uint64_t* text2;    // ... and the 2-bit packed superstring
+    uint32_t verify_bases;    // 1: the words ARE the k - t bases in front of each row (k - t <= 15; bit 31 = no such k-mer);
+                              // 0: the words are text positions and the bases are read from text2
     uint32_t ptable_len, ptable_packed;
     uint32_t n, r0, r1, p1;   // rows; row of suffix 0 ('$' slot); row of suffix 1; pair index stored for r1
     uint32_t C0, C1, C2_, C3;
@@ -243,8 +245,19 @@ __global__ __launch_bounds__(256) void pair_lookup_kernel(PairIndex ix, const ui
             if (sh) tx |= ix.text2[w + 1] << (64u - sh);
             return ((tx ^ cur) & rmask) == 0ull;
         };
-        const bool m0 = text_matches(pos0), m1 = rows > 1u && text_matches(pos1), m2 = rows > 2u && text_matches(pos2);
-        if (sub == 0u) n_vreads += 1u + rows;
+        bool m0, m1, m2;
+        if (ix.verify_bases) {   // the words hold the bases themselves: no text read
+            const uint32_t want = static_cast<uint32_t>(cur & rmask);
+            m0 = pos0 == want;
+            m1 = rows > 1u && pos1 == want;
+            m2 = rows > 2u && pos2 == want;
+            if (sub == 0u) n_vreads += 1u;
+        } else {
+            m0 = text_matches(pos0);
+            m1 = rows > 1u && text_matches(pos1);
+            m2 = rows > 2u && text_matches(pos2);
+            if (sub == 0u) n_vreads += 1u + rows;
+        }
         const uint32_t k0 = (ey >> 26) & 1u, k1 = (ey >> 27) & 1u, k2 = (ey >> 28) & 1u;
         if (!(m0 || m1 || m2)) res = -1;
         else if (mode_all) res = static_cast<int>(m0 ? k0 : (m1 ? k1 : k2));
@@ -756,6 +769,7 @@ PairIndex make_pair_index(const fmsi_hip_index* idx) {
     p.ptable_len = idx->dev.ptable_len;
     p.ptable_packed = idx->dev.ptable_packed;
     p.stable = static_cast<const uint32_t*>(idx->d_stable);
+    p.verify_bases = (idx->k - idx->prefix_len) <= 15 ? 1u : 0u;
     p.text2 = static_cast<const uint64_t*>(idx->d_text2);
     p.n = idx->dev.n;
     p.r0 = idx->dev.dollar;
@@ -934,7 +948,8 @@ __global__ __launch_bounds__(256) void chars_to_text2_kernel(const char* __restr
 // table entries of one to three rows get their rows' text positions and, in bits 26-28 of the entry, the mask bits of the
 // k-mers that would end there
 __global__ __launch_bounds__(256) void verify_fill_kernel(uint2* __restrict__ tab, uint64_t count, const uint32_t* __restrict__ sa,
-                                                          const char* __restrict__ chars, uint32_t R, uint32_t* __restrict__ stable) {
+                                                          const char* __restrict__ chars, uint32_t R, uint32_t bases_mode,
+                                                          uint32_t* __restrict__ stable) {
     const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
     for (uint64_t idx = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; idx < count; idx += stride) {
         const uint2 e = tab[idx];
@@ -950,6 +965,19 @@ __global__ __launch_bounds__(256) void verify_fill_kernel(uint2* __restrict__ ta
                 }
             }
             if (y != e.y) tab[idx] = make_uint2(e.x, y);
+            if (bases_mode) {   // R <= 15: the R bases in front of each row, base pos - R in bits 0..1 -- or bit 31 when the text starts too late
+                for (uint32_t m = 0; m < rows; ++m) {
+                    uint32_t v = 0x80000000u;
+                    if (pos[m] >= R) {
+                        v = 0;
+                        for (uint32_t b = 0; b < R; ++b) {
+                            const uint32_t ch = static_cast<uint8_t>(chars[pos[m] - R + b]) | 0x20u;
+                            v |= (ch == 'a' ? 0u : (ch == 'c' ? 1u : (ch == 'g' ? 2u : 3u))) << (2u * b);
+                        }
+                    }
+                    pos[m] = v;
+                }
+            }
         }
         stable[3 * idx] = pos[0];
         stable[3 * idx + 1] = pos[1];
@@ -991,7 +1019,7 @@ extern "C" int fmsi_hip_index_enable_verify(fmsi_hip_index* idx) {
     }
     const uint32_t blocks = static_cast<uint32_t>(std::min<uint64_t>((count + 255) / 256, 1u << 20));
     hipLaunchKernelGGL(verify_fill_kernel, dim3(blocks), dim3(256), 0, 0, static_cast<uint2*>(idx->d_ptable), count, d_sa, d_chars,
-                       static_cast<uint32_t>(R), d_stable);
+                       static_cast<uint32_t>(R), R <= 15 ? 1u : 0u, d_stable);
     if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess) return fail(FMSI_HIP_EHIP, "text verification: device work failed");
     (void)hipFree(d_chars);
     (void)hipFree(d_sa);
