@@ -54,7 +54,9 @@ struct PairIndex {
     const uint32_t* mrank;    // n_blocks + 1 cumulative mask popcounts (shared with the single-step layout)
     const uint4* sblocks;     // the single-step layout (its mask plane serves the explicit probes)
     const uint2* ptable;
-    const uint32_t* stable;   // text verification (fmsi_hip_index_enable_verify) or nullptr: three words per table entry, see verify_bases
+    const uint4* vtable;      // text verification (fmsi_hip_index_enable_verify) or nullptr: the lookup kernel's own copy of the
+                              // table, 16 bytes per entry: (i, tagged word + mask bits 26-28, candidate 0, candidate 1)
+    const uint32_t* stable;   // ... candidate 2 per entry (intervals of three rows)
     const uint64_t* text2;    // ... and the 2-bit packed superstring
     uint32_t verify_bases;    // 1: the words ARE the k - t bases in front of each row (k - t <= 15; bit 31 = no such k-mer);
                               // 0: the words are text positions and the bases are read from text2
@@ -198,7 +200,7 @@ __global__ __launch_bounds__(256) void pair_lookup_kernel(PairIndex ix, const ui
     const int t = k - 1 - T;
     const uint32_t R = static_cast<uint32_t>(k - T);                       // bases left after the table
     const uint64_t rmask = R >= 32u ? ~0ull : ((1ull << (2u * R)) - 1ull);
-    const bool verify = ix.stable != nullptr && ix.ptable_packed && !orders && R >= 1u && R <= 32u;
+    const bool verify = ix.vtable != nullptr && ix.ptable_packed && !orders && R >= 1u && R <= 32u;
     const uint32_t tmask = static_cast<uint32_t>((1ull << (2 * T)) - 1ull);
     const uint32_t lane = threadIdx.x & 63u, sub = lane & 1u;
     const int pbase = static_cast<int>(lane & ~1u);
@@ -212,18 +214,36 @@ __global__ __launch_bounds__(256) void pair_lookup_kernel(PairIndex ix, const ui
     // one strand: table lookup (+ verification).  state 0 = absent, 1 = alive (needs the stepping kernel), 2 = settled (res)
     auto strand = [&](uint64_t cur, bool go, uint32_t& i, uint32_t& j, int& res) -> uint32_t {
         const uint32_t tidx = static_cast<uint32_t>(cur >> (2 * (k - T))) & tmask;
-        const uint4* p4 = reinterpret_cast<const uint4*>(ix.ptable + (tidx & ~7u)) + sub * 2u;
         uint4 u0 = make_uint4(0, 0, 0, 0), u1 = u0;
-        if (go) {
-            u0 = p4[0];
-            u1 = p4[1];
+        uint32_t ex, ey, cand0 = 0, cand1 = 0;
+        if (verify) {
+            // the lookup kernel's 16-byte entries: four to a line, entry e in lane e >> 1 of the pair, register e & 1
+            const uint4* p4 = ix.vtable + (tidx & ~3u) + sub * 2u;
+            if (go) {
+                u0 = p4[0];
+                u1 = p4[1];
+            }
+            const uint32_t e = tidx & 3u;
+            const uint4 v = (e & 1u) ? u1 : u0;
+            const int src = pbase | static_cast<int>(e >> 1);
+            ex = static_cast<uint32_t>(__shfl(static_cast<int>(v.x), src, 64));
+            ey = static_cast<uint32_t>(__shfl(static_cast<int>(v.y), src, 64));
+            cand0 = static_cast<uint32_t>(__shfl(static_cast<int>(v.z), src, 64));
+            cand1 = static_cast<uint32_t>(__shfl(static_cast<int>(v.w), src, 64));
+        } else {
+            const uint4* p4 = reinterpret_cast<const uint4*>(ix.ptable + (tidx & ~7u)) + sub * 2u;
+            if (go) {
+                u0 = p4[0];
+                u1 = p4[1];
+            }
+            // entry e of the 8-entry line sits in lane e >> 2 of the pair, slot e & 3 of its 32 bytes
+            const uint32_t e = tidx & 7u;
+            const uint4 v = (e & 2u) ? u1 : u0;
+            const uint32_t xi = (e & 1u) ? v.z : v.x, xj = (e & 1u) ? v.w : v.y;
+            const int src = pbase | static_cast<int>(e >> 2);
+            ex = static_cast<uint32_t>(__shfl(static_cast<int>(xi), src, 64));
+            ey = static_cast<uint32_t>(__shfl(static_cast<int>(xj), src, 64));
         }
-        // entry e of the 8-entry line sits in lane e >> 2 of the pair, slot e & 3 of its 32 bytes
-        const uint32_t e = tidx & 7u;
-        const uint4 v = (e & 2u) ? u1 : u0;
-        const uint32_t xi = (e & 1u) ? v.z : v.x, xj = (e & 1u) ? v.w : v.y;
-        const int src = pbase | static_cast<int>(e >> 2);
-        const uint32_t ex = static_cast<uint32_t>(__shfl(static_cast<int>(xi), src, 64)), ey = static_cast<uint32_t>(__shfl(static_cast<int>(xj), src, 64));
         res = -1;
         i = j = 0;
         if (!go) return 0u;
@@ -231,12 +251,11 @@ __global__ __launch_bounds__(256) void pair_lookup_kernel(PairIndex ix, const ui
         if (sub == 0u) n_lookups++;
         if (i == j) return 0u;
         if (!(verify && (ey >> 30) == 1u)) return 1u;
-        // one to three rows: their text positions (one 12-byte read), then the text in front of each (independent reads).
-        // Candidates that match are the rows of the final interval, in the same order (an equal prefix does not change the
-        // order of two suffixes): ALL takes the mask bit of the first, OR any mask bit (src/fms_index.h:126-144).
+        // one to three rows: candidates 0 and 1 came with the entry, the third is read on demand.  Candidates that match are
+        // the rows of the final interval, in the same order (an equal prefix does not change the order of two suffixes):
+        // ALL takes the mask bit of the first, OR any mask bit (src/fms_index.h:126-144).
         const uint32_t rows = (ey >> 24) & 3u;
-        const uint32_t* sp = ix.stable + 3ull * tidx;
-        const uint32_t pos0 = sp[0], pos1 = sp[1], pos2 = sp[2];
+        const uint32_t pos0 = cand0, pos1 = cand1, pos2 = rows > 2u ? ix.stable[tidx] : 0u;
         auto text_matches = [&](uint32_t pos) -> bool {
             if (pos < R) return false;
             const uint64_t p0 = static_cast<uint64_t>(pos - R), w = p0 >> 5;
@@ -251,12 +270,12 @@ __global__ __launch_bounds__(256) void pair_lookup_kernel(PairIndex ix, const ui
             m0 = pos0 == want;
             m1 = rows > 1u && pos1 == want;
             m2 = rows > 2u && pos2 == want;
-            if (sub == 0u) n_vreads += 1u;
+            if (sub == 0u && rows > 2u) n_vreads += 1u;
         } else {
             m0 = text_matches(pos0);
             m1 = rows > 1u && text_matches(pos1);
             m2 = rows > 2u && text_matches(pos2);
-            if (sub == 0u) n_vreads += 1u + rows;
+            if (sub == 0u) n_vreads += rows + (rows > 2u ? 1u : 0u);
         }
         const uint32_t k0 = (ey >> 26) & 1u, k1 = (ey >> 27) & 1u, k2 = (ey >> 28) & 1u;
         if (!(m0 || m1 || m2)) res = -1;
@@ -768,6 +787,7 @@ PairIndex make_pair_index(const fmsi_hip_index* idx) {
     p.ptable = idx->dev.ptable;
     p.ptable_len = idx->dev.ptable_len;
     p.ptable_packed = idx->dev.ptable_packed;
+    p.vtable = static_cast<const uint4*>(idx->d_vtable);
     p.stable = static_cast<const uint32_t*>(idx->d_stable);
     p.verify_bases = (idx->k - idx->prefix_len) <= 15 ? 1u : 0u;
     p.text2 = static_cast<const uint64_t*>(idx->d_text2);
@@ -947,12 +967,12 @@ __global__ __launch_bounds__(256) void chars_to_text2_kernel(const char* __restr
 
 // table entries of one to three rows get their rows' text positions and, in bits 26-28 of the entry, the mask bits of the
 // k-mers that would end there
-__global__ __launch_bounds__(256) void verify_fill_kernel(uint2* __restrict__ tab, uint64_t count, const uint32_t* __restrict__ sa,
+__global__ __launch_bounds__(256) void verify_fill_kernel(const uint2* __restrict__ tab, uint64_t count, const uint32_t* __restrict__ sa,
                                                           const char* __restrict__ chars, uint32_t R, uint32_t bases_mode,
-                                                          uint32_t* __restrict__ stable) {
+                                                          uint4* __restrict__ vtable, uint32_t* __restrict__ stable) {
     const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
     for (uint64_t idx = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; idx < count; idx += stride) {
-        const uint2 e = tab[idx];
+        uint2 e = tab[idx];
         uint32_t pos[3] = {0, 0, 0};
         if ((e.y >> 30) == 1u) {
             const uint32_t rows = (e.y >> 24) & 3u;
@@ -964,7 +984,7 @@ __global__ __launch_bounds__(256) void verify_fill_kernel(uint2* __restrict__ ta
                     if (ch >= 'A' && ch <= 'Z') y |= 1u << (26u + m);   // is_upper = mask 1, src/kmers.h:71-73
                 }
             }
-            if (y != e.y) tab[idx] = make_uint2(e.x, y);
+            e.y = y;   // (the 8-byte table stays as it is: the mask bits live in the lookup kernel's copy)
             if (bases_mode) {   // R <= 15: the R bases in front of each row, base pos - R in bits 0..1 -- or bit 31 when the text starts too late
                 for (uint32_t m = 0; m < rows; ++m) {
                     uint32_t v = 0x80000000u;
@@ -979,9 +999,8 @@ __global__ __launch_bounds__(256) void verify_fill_kernel(uint2* __restrict__ ta
                 }
             }
         }
-        stable[3 * idx] = pos[0];
-        stable[3 * idx + 1] = pos[1];
-        stable[3 * idx + 2] = pos[2];
+        vtable[idx] = make_uint4(e.x, e.y, pos[0], pos[1]);
+        stable[idx] = pos[2];
     }
 }
 
@@ -1000,15 +1019,17 @@ extern "C" int fmsi_hip_index_enable_verify(fmsi_hip_index* idx) {
     const uint64_t n = idx->n, len = n - 1, count = 1ull << (2 * T);
     char* d_chars = nullptr;
     uint32_t *d_sa = nullptr, *d_stable = nullptr;
+    uint4* d_vtable = nullptr;
     uint64_t* d_text2 = nullptr;
     auto fail = [&](int code, const char* msg) {
-        for (void* p : {static_cast<void*>(d_chars), static_cast<void*>(d_sa), static_cast<void*>(d_stable), static_cast<void*>(d_text2)})
+        for (void* p : {static_cast<void*>(d_chars), static_cast<void*>(d_sa), static_cast<void*>(d_stable), static_cast<void*>(d_text2),
+                        static_cast<void*>(d_vtable)})
             if (p) (void)hipFree(p);
         if (msg) set_last_error(msg);
         return code;
     };
     if (hipMalloc(reinterpret_cast<void**>(&d_chars), len + 1) != hipSuccess || hipMalloc(reinterpret_cast<void**>(&d_sa), n * 4) != hipSuccess ||
-        hipMalloc(reinterpret_cast<void**>(&d_stable), count * 12) != hipSuccess)
+        hipMalloc(reinterpret_cast<void**>(&d_stable), count * 4) != hipSuccess || hipMalloc(reinterpret_cast<void**>(&d_vtable), count * 16 + 64) != hipSuccess)
         return fail(FMSI_HIP_ENOMEM, "hipMalloc failed for the text verification tables");
     int rc = export_walk(idx, d_chars, d_sa);
     if (rc) return fail(rc, nullptr);
@@ -1018,8 +1039,8 @@ extern "C" int fmsi_hip_index_enable_verify(fmsi_hip_index* idx) {
         hipLaunchKernelGGL(chars_to_text2_kernel, dim3(static_cast<uint32_t>((n_words + 255) / 256)), dim3(256), 0, 0, d_chars, len, n_words, d_text2);
     }
     const uint32_t blocks = static_cast<uint32_t>(std::min<uint64_t>((count + 255) / 256, 1u << 20));
-    hipLaunchKernelGGL(verify_fill_kernel, dim3(blocks), dim3(256), 0, 0, static_cast<uint2*>(idx->d_ptable), count, d_sa, d_chars,
-                       static_cast<uint32_t>(R), R <= 15 ? 1u : 0u, d_stable);
+    hipLaunchKernelGGL(verify_fill_kernel, dim3(blocks), dim3(256), 0, 0, static_cast<const uint2*>(idx->d_ptable), count, d_sa, d_chars,
+                       static_cast<uint32_t>(R), R <= 15 ? 1u : 0u, d_vtable, d_stable);
     if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess) return fail(FMSI_HIP_EHIP, "text verification: device work failed");
     (void)hipFree(d_chars);
     (void)hipFree(d_sa);
@@ -1029,6 +1050,7 @@ extern "C" int fmsi_hip_index_enable_verify(fmsi_hip_index* idx) {
         idx->device_bytes += n_words * 8;
     }
     idx->d_stable = d_stable;
-    idx->device_bytes += count * 12;
+    idx->d_vtable = d_vtable;
+    idx->device_bytes += count * 20 + 64;
     return 0;
 }

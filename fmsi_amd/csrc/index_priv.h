@@ -56,7 +56,8 @@ struct fmsi_hip_index {
     void* d_c2 = nullptr;
     uint32_t pair_r1 = 0xFFFFFFFFu, pair_p1 = 0xFFFFFFFFu;
     void* d_text2 = nullptr;     // 2-bit packed superstring (kept by the on-device builder, or rebuilt by fmsi_hip_index_enable_verify)
-    void* d_stable = nullptr;    // text verification: per prefix-table entry the text position of its row when it has exactly one
+    void* d_vtable = nullptr;    // text verification: the lookup kernel's 16-byte copy of the table entries with candidates 0 and 1
+    void* d_stable = nullptr;    // ... and candidate 2 per entry
     uint64_t text_len = 0;
     // staging for host-pointer calls
     void* d_in = nullptr; size_t d_in_cap = 0;

@@ -169,7 +169,7 @@ int fmsi_cli_index(int argc, char** argv);
  * instead of (k - t) / 2 dependent block reads: the rows that match are the final interval, and their mask bits are
  * stored in the entry.
  * Positions and text come from the LF walk of fmsi_hip_index_export, so any handle can add it.  Used by the phased
- * kernels for the presence modes (not ORDERS).  4^t x 12 bytes + n / 4 bytes of HBM.  Idempotent. */
+ * kernels for the presence modes (not ORDERS).  4^t x 20 bytes + n / 4 bytes of HBM.  Idempotent. */
 int fmsi_hip_index_enable_verify(fmsi_hip_index* idx);
 
 /* Replaces export_ms() (src/fms_index.h:462-473): the masked superstring of the index (upper case = mask 1), written
