@@ -250,7 +250,7 @@ def main():
             "roofline": roof,
             "cpu_baseline": None,
         }
-        if args.cpu_sample != 0:
+        if args.cpu_sample != 0 and world == 1:   # reported baseline: rank 0 of the 1-GPU run only
             try:
                 import bench_cpu   # the only part of the benchmark that touches oracle/
                 line["cpu_baseline"] = bench_cpu.run_stream(args, index, n, k) if stream_mode else bench_cpu.run(args, index, n, k)
