@@ -45,7 +45,7 @@ int FastxReader::getc_() {
     return buf_[begin_++];
 }
 
-bool FastxReader::until_(bool line, std::string* dst, int* delim, size_t* counted) {
+bool FastxReader::until_(bool line, std::string* dst, int* delim, size_t* counted, size_t floor) {
     bool gotany = false;
     if (delim) *delim = 0;
     for (;;) {
@@ -69,7 +69,7 @@ bool FastxReader::until_(bool line, std::string* dst, int* delim, size_t* counte
         }
     }
     if (!gotany) return false;
-    if (line && dst && dst->size() > 1 && dst->back() == '\r') dst->pop_back();   // src/kseq.h:146
+    if (line && dst && dst->size() - floor > 1 && dst->back() == '\r') dst->pop_back();   // src/kseq.h:146
     return true;
 }
 
@@ -97,6 +97,35 @@ bool FastxReader::next() {
     while (until_(true, &qual, nullptr, nullptr) && qual.size() < seq.size()) {}
     last_char_ = 0;
     return qual.size() == seq.size();
+}
+
+bool FastxReader::next_append(std::string& text, size_t* name_off, size_t* name_len, size_t* seq_off, size_t* seq_len) {
+    // next() with both strings living in `text`; every rule of next() is kept (the CR rule looks at the sequence only)
+    int c;
+    if (last_char_ == 0) {
+        while ((c = getc_()) >= 0 && c != '>' && c != '@') {}
+        if (c < 0) return false;
+        last_char_ = c;
+    }
+    *name_off = text.size();
+    if (!until_(false, &text, &c, nullptr, *name_off)) return false;
+    *name_len = text.size() - *name_off;
+    if (c != '\n') until_(true, nullptr, nullptr, nullptr);   // comment
+    *seq_off = text.size();
+    while ((c = getc_()) >= 0 && c != '>' && c != '+' && c != '@') {
+        if (c == '\n') continue;
+        text.push_back(static_cast<char>(c));
+        until_(true, &text, nullptr, nullptr, *seq_off);
+    }
+    *seq_len = text.size() - *seq_off;
+    if (c == '>' || c == '@') last_char_ = c;
+    if (c != '+') return true;   // FASTA
+    while ((c = getc_()) >= 0 && c != '\n') {}
+    if (c < 0) return false;     // no quality string (-2 in the reference)
+    qual_.clear();
+    while (until_(true, &qual_, nullptr, nullptr) && qual_.size() < *seq_len) {}
+    last_char_ = 0;
+    return qual_.size() == *seq_len;
 }
 
 }  // namespace fmsi

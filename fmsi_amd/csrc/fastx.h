@@ -25,13 +25,19 @@ public:
     // error returns -2/-3, which also end its loop, src/main.cpp:328).
     bool next();
 
+    // Same, but the name and the sequence are APPENDED to `text` (first the name, then the sequence: the caller's batch
+    // buffer), saving the copy out of name / seq.  Offsets and lengths are returned; on false `text` may hold a partial
+    // record past its old size, which the caller truncates.
+    bool next_append(std::string& text, size_t* name_off, size_t* name_len, size_t* seq_off, size_t* seq_len);
+
     std::string name;
     std::string seq;
 
 private:
     int getc_();
     // append bytes up to (not including) the next '\n' / whitespace; returns false at EOF with nothing read
-    bool until_(bool line, std::string* dst, int* delim, size_t* counted);
+    // `floor`: size of *dst below which the trailing-CR rule must not look (the start of the string being built)
+    bool until_(bool line, std::string* dst, int* delim, size_t* counted, size_t floor = 0);
     bool fill_();
 
     gzFile fp_ = nullptr;
@@ -39,6 +45,7 @@ private:
     size_t begin_ = 0, end_ = 0;
     bool eof_ = false;
     int last_char_ = 0;
+    std::string qual_;
 };
 
 }  // namespace fmsi

@@ -725,14 +725,18 @@ extern "C" int fmsi_cli_query(int argc, char** argv, int output_orders_i) {
         try {
             auto b = std::make_unique<RawBatch>();
             auto t0 = clock::now();
-            while (reader->next()) {
+            for (;;) {
                 RecRef rr;
-                rr.name_off = b->text.size();
-                rr.name_len = static_cast<uint32_t>(reader->name.size());
-                b->text += reader->name;
-                rr.seq_off = b->text.size();
-                rr.seq_len = reader->seq.size();
-                b->text += reader->seq;
+                const size_t before = b->text.size();
+                size_t name_off, name_len, seq_off, seq_len;
+                if (!reader->next_append(b->text, &name_off, &name_len, &seq_off, &seq_len)) {
+                    b->text.resize(before);   // a partial record (truncated FASTQ) ends the stream, as in the reference
+                    break;
+                }
+                rr.name_off = name_off;
+                rr.name_len = static_cast<uint32_t>(name_len);
+                rr.seq_off = seq_off;
+                rr.seq_len = seq_len;
                 b->recs.push_back(rr);
                 b->seq_bytes += rr.seq_len;
                 if (b->seq_bytes >= opt.batch_windows || b->recs.size() >= (1u << 23)) {
