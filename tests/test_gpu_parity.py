@@ -325,3 +325,52 @@ def test_text_verification_on_repeats_and_text_start(fm, oracle_built, t, k):
     fwd, rc, of, orr = orc.ternaries_bulk(raw, len(kmers), k, False, orders=True)
     got = dev.query_kmers(packed, k, fm.ORDERS | fm.STRICT)   # lookup never verifies: ranks come from the steps
     assert np.array_equal(got[:, 0], of) and np.array_equal(got[:, 1], orr)
+
+
+def test_full_scale_cross_kernel_agreement(fm):
+    """BASELINE.json's full size (human-genome scale, n = 2.8 G rows) with the production configuration (t = 16 signature
+    table, pair layout, text verification): no CPU checker finishes here, so the size-independent property is that four
+    independent algorithms agree bit for bit, strand by strand, on 4 M seeded k-mers (half present) -- lookups + candidate
+    comparison (phased), lookups + two-base steps (one-kernel pair), single steps over the 64-byte layout (refill) and
+    plain lock-step search without any table -- plus: every k-mer drawn from the superstring is found on its strand, and
+    streaming a read gives what its isolated windows give.  (bench.py checks a sample of the same stream against the
+    real reference on the host: cpu_baseline.matches_gpu.)"""
+    import torch
+    n, k, nq = 2_800_000_000, 31, 1 << 22
+    dev = fm.DeviceIndex.build_synthetic(n, 12345, k, with_klcp=True, prefix_len=16).enable_pair_layout().enable_verify()
+    s = torch.cuda.current_stream().cuda_stream
+    d_kmers = torch.empty(nq, dtype=torch.int64, device="cuda")
+    dev.synthetic_queries_dev(k, 42, 0, nq, d_kmers.data_ptr(), s)
+    outs = {}
+    for name, kern in (("phased", fm.KERNEL_PHASED), ("pair", fm.KERNEL_PAIR), ("refill", fm.KERNEL_REFILL),
+                       ("lockstep", fm.KERNEL_LOCKSTEP | fm.NO_PREFIX_TABLE)):
+        d_out = torch.empty(nq, dtype=torch.uint8, device="cuda")
+        dev.query_kmers_dev(d_kmers.data_ptr(), nq, k, fm.MODE_ALL | fm.STRICT | kern, d_out.data_ptr(), stream=s)
+        torch.cuda.synchronize()
+        outs[name] = d_out.cpu().numpy()
+    for name in ("pair", "refill", "lockstep"):
+        assert np.array_equal(outs["phased"], outs[name]), name
+    f, r = fm.decode_strict(outs["phased"])
+    present = (f == 1) | (r == 1)
+    assert 0.49 < present.mean() < 0.51 and not ((f == 1) & (r == 1)).any()
+    assert ((f == 0) | (r == 0)).sum() == 0          # max-ones superstring: an occurrence is always ON
+    # fast schedule == what the strict results imply
+    d_out = torch.empty(nq, dtype=torch.uint8, device="cuda")
+    dev.query_kmers_dev(d_kmers.data_ptr(), nq, k, fm.MODE_ALL, d_out.data_ptr(), stream=s)
+    torch.cuda.synchronize()
+    assert np.array_equal(d_out.cpu().numpy().astype(bool), present)
+    # reads from the superstring (both orientations) and random reads: streaming == runs == isolated windows
+    L, n_reads = 1000, 512
+    words = (n_reads * L) // 32 + 2
+    d_reads = torch.empty(words, dtype=torch.int64, device="cuda")
+    dev.synthetic_reads_dev(L, 7, 0, n_reads, d_reads.data_ptr(), 0, s)
+    torch.cuda.synchronize()
+    packed = d_reads.cpu().numpy().view(np.uint64)
+    starts = np.arange(n_reads, dtype=np.uint64) * np.uint64(L)
+    wins = np.full(n_reads, L - k + 1, dtype=np.uint32)
+    a = dev.query_stream(packed, n_reads * L, starts, wins, k, fm.MODE_ALL | fm.STRICT)
+    b = dev.query_runs(packed, n_reads * L, starts, wins, k, fm.MODE_ALL | fm.STRICT)
+    assert np.array_equal(a, b)
+    per_read = ((a & 3) == 2) | (((a >> 2) & 3) == 2)
+    frac = per_read.reshape(n_reads, -1).mean(axis=1)
+    assert ((frac == 0) | (frac == 1)).all() and 0.35 < (frac == 1).mean() < 0.65   # a read is from the superstring or it is not
