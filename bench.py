@@ -118,7 +118,10 @@ def main():
             t0 = time.time()
             index.enable_pair_layout()
             if args.kernel == "phased" and 0 < args.prefix_len < k and not args.no_verify:
-                index.enable_verify()
+                try:
+                    index.enable_verify()
+                except fm.FmsiError as e:   # an accelerator: without it the run is slower, not wrong
+                    print(f"warning: text verification is off ({e})", file=sys.stderr)
             build_s += time.time() - t0
         flags |= {"phased": fm.KERNEL_PHASED, "pair": fm.KERNEL_PAIR, "refill": fm.KERNEL_REFILL, "lockstep": fm.KERNEL_LOCKSTEP}[args.kernel]
     stream = torch.cuda.current_stream().cuda_stream
