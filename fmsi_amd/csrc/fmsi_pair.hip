@@ -211,8 +211,18 @@ __global__ __launch_bounds__(256) void pair_lookup_kernel(PairIndex ix, const ui
     const uint32_t len = start < n_windows ? static_cast<uint32_t>(min(static_cast<uint64_t>(chunk), n_windows - start)) : 0u;
     uint32_t count = 0;   // wave-uniform: work items written so far
 
-    // one strand: table lookup (+ verification).  state 0 = absent, 1 = alive (needs the stepping kernel), 2 = settled (res)
-    auto strand = [&](uint64_t cur, bool go, uint32_t& i, uint32_t& j, int& res) -> uint32_t {
+    // presence from candidate slots [lo, hi): the matching ones are the rows of the final interval in their order --
+    // ALL takes the mask bit of the first, OR any mask bit (src/fms_index.h:126-144); none = the empty interval
+    auto slots_result = [&](uint32_t lo, uint32_t hi, bool m0, bool m1, bool m2, uint32_t ey) -> int {
+        const bool a0 = m0 && lo == 0u && hi > 0u, a1 = m1 && lo <= 1u && hi > 1u, a2 = m2 && lo <= 2u && hi > 2u;
+        const uint32_t k0 = (ey >> 26) & 1u, k1 = (ey >> 27) & 1u, k2 = (ey >> 28) & 1u;
+        if (!(a0 || a1 || a2)) return -1;
+        if (mode_all) return static_cast<int>(a0 ? k0 : (a1 ? k1 : k2));
+        return static_cast<int>((a0 && k0) || (a1 && k1) || (a2 && k2));
+    };
+    // one strand: table lookup (+ verification).  state 0 = absent, 1 = alive (needs the stepping kernel), 2 = settled (res),
+    // 3 = this entry settled BOTH strands (res, res_other) -- only asked for on the forward strand's lookup
+    auto strand = [&](uint64_t cur, bool go, bool want_both, uint32_t& i, uint32_t& j, int& res, int& res_other) -> uint32_t {
         const uint32_t tidx = static_cast<uint32_t>(cur >> (2 * (k - T))) & tmask;
         uint4 u0 = make_uint4(0, 0, 0, 0), u1 = u0;
         uint32_t ex, ey, cand0 = 0, cand1 = 0;
@@ -244,9 +254,30 @@ __global__ __launch_bounds__(256) void pair_lookup_kernel(PairIndex ix, const ui
             ex = static_cast<uint32_t>(__shfl(static_cast<int>(xi), src, 64));
             ey = static_cast<uint32_t>(__shfl(static_cast<int>(xj), src, 64));
         }
+        if (!go) return 0u;   // (results of a lane that sits this lookup out stay as they are)
         res = -1;
+        res_other = -1;
         i = j = 0;
-        if (!go) return 0u;
+        if (verify && (ey >> 30) == 2u) {
+            // double-stranded entry: slots [0, nf) are the occurrences of this key in the text (this strand), slots
+            // [nf, nf + nr) its occurrences in the text's reverse complement -- i.e. the OTHER strand's candidates, stored as
+            // the bases that precede the key there.  Both are compared with the same remaining bases of the query.
+            if (sub == 0u) n_lookups++;
+            const uint32_t nf = (ey >> 24) & 3u, nr = (ey >> 22) & 3u, total = nf + nr;
+            const uint32_t need = want_both ? total : nf;
+            const uint32_t cand2 = need > 2u ? ix.stable[tidx] : 0u;
+            if (sub == 0u && need > 2u) n_vreads += 1u;
+            const uint32_t want = static_cast<uint32_t>(cur & rmask);
+            const bool m0 = cand0 == want, m1 = cand1 == want, m2 = cand2 == want;
+            i = ex;
+            j = ex + nf;
+            res = slots_result(0u, nf, m0, m1, m2, ey);
+            if (want_both) {
+                res_other = slots_result(nf, total, m0, m1, m2, ey);
+                return 3u;
+            }
+            return nf == 0u ? 0u : 2u;
+        }
         decode_table_entry(ex, ey, ix.ptable_packed, t >= 3, t >= 3 ? static_cast<uint32_t>(cur >> (2 * (t - 3))) & 0xFFu : 0u, i, j);
         if (sub == 0u) n_lookups++;
         if (i == j) return 0u;
@@ -277,10 +308,7 @@ __global__ __launch_bounds__(256) void pair_lookup_kernel(PairIndex ix, const ui
             m2 = rows > 2u && text_matches(pos2);
             if (sub == 0u) n_vreads += rows + (rows > 2u ? 1u : 0u);
         }
-        const uint32_t k0 = (ey >> 26) & 1u, k1 = (ey >> 27) & 1u, k2 = (ey >> 28) & 1u;
-        if (!(m0 || m1 || m2)) res = -1;
-        else if (mode_all) res = static_cast<int>(m0 ? k0 : (m1 ? k1 : k2));
-        else res = static_cast<int>((m0 && k0) || (m1 && k1) || (m2 && k2));
+        res = slots_result(0u, 3u, m0, m1, m2, ey);
         return 2u;
     };
 
@@ -289,14 +317,14 @@ __global__ __launch_bounds__(256) void pair_lookup_kernel(PairIndex ix, const ui
         const bool valid = ql < len;
         const uint64_t q = start + ql;
         const uint64_t f = valid ? kmers[q] : 0ull;
-        uint32_t i_f, j_f, i_r = 0, j_r = 0;
-        int res_f, res_r = -1;
-        const uint32_t sf = strand(f, valid, i_f, j_f, res_f);
+        uint32_t i_f = 0, j_f = 0, i_r = 0, j_r = 0;
+        int res_f = -1, res_r = -1, unused = -1;
+        const uint32_t sf = strand(f, valid, true, i_f, j_f, res_f, res_r);
         // the reverse complement is searched when the forward strand does not decide (src/fms_index.h:283-299); a forward
-        // strand that still needs steps (state 1) leaves that decision to the stepping kernel
-        const bool need_rc = valid && sf != 1u && (strict || (mode_all && !orders ? res_f == -1 : res_f != 1));
+        // strand that still needs steps (state 1) leaves that decision to the stepping kernel; state 3 brought both results
+        const bool need_rc = valid && sf != 1u && sf != 3u && (strict || (mode_all && !orders ? res_f == -1 : res_f != 1));
         uint32_t sr = 0;
-        if (__any(need_rc)) sr = strand(revcomp_2bit(f, k), need_rc, i_r, j_r, res_r);
+        if (__any(need_rc)) sr = strand(revcomp_2bit(f, k), need_rc, false, i_r, j_r, res_r, unused);
         const bool alive = valid && (sf == 1u || sr == 1u);
         if (valid && !alive && sub == 0u) {   // settled: the result leaves here
             n_final++;
@@ -965,42 +993,78 @@ __global__ __launch_bounds__(256) void chars_to_text2_kernel(const char* __restr
     text2[w] = v;
 }
 
-// table entries of one to three rows get their rows' text positions and, in bits 26-28 of the entry, the mask bits of the
-// k-mers that would end there
+// The lookup kernel's table (16-byte entries + a third candidate per entry), from the 8-byte table, the suffix array of
+// the LF walk and the text.  Entry K (a t-mer):
+//   * double-stranded (tag 2), bases mode only: when K occurs nf times in the text and its reverse complement nr times,
+//     nf + nr <= 3, the entry lists all of them -- forward candidates = the R bases in front of each occurrence of K,
+//     reverse candidates = the reverse complement of the R bases BEHIND each occurrence of rc(K), i.e. the bases in front
+//     of K on the other strand -- with the mask bit of the k-mer each would complete.  One lookup then settles a k-mer
+//     ending in K on both strands (nf = nr = 0: absent on both).
+//   * otherwise a copy of the 8-byte entry, with the forward candidates and mask bits when it has 1..3 rows.
 __global__ __launch_bounds__(256) void verify_fill_kernel(const uint2* __restrict__ tab, uint64_t count, const uint32_t* __restrict__ sa,
-                                                          const char* __restrict__ chars, uint32_t R, uint32_t bases_mode,
-                                                          uint4* __restrict__ vtable, uint32_t* __restrict__ stable) {
+                                                          const char* __restrict__ chars, uint64_t text_len, uint32_t T, uint32_t R,
+                                                          uint32_t bases_mode, uint4* __restrict__ vtable, uint32_t* __restrict__ stable) {
     const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
+    auto code_of = [](char c) -> uint32_t {
+        const uint32_t ch = static_cast<uint8_t>(c) | 0x20u;
+        return ch == 'a' ? 0u : (ch == 'c' ? 1u : (ch == 'g' ? 2u : 3u));
+    };
+    auto rows_of = [](uint2 e) -> uint32_t { return (e.y >> 30) == 1u ? ((e.y >> 24) & 3u) : e.y; };   // 8-byte format: tag 0 = length
     for (uint64_t idx = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; idx < count; idx += stride) {
         uint2 e = tab[idx];
-        uint32_t pos[3] = {0, 0, 0};
-        if ((e.y >> 30) == 1u) {
+        uint32_t cand[3] = {0, 0, 0};
+        const uint32_t nf = rows_of(e);
+        bool done = false;
+        if (bases_mode && nf <= 3u) {
+            const uint2 er = tab[revcomp_2bit(idx, static_cast<int>(T))];
+            const uint32_t nr = rows_of(er);
+            if (nf + nr <= 3u) {
+                uint32_t y = (2u << 30) | (nf << 24) | (nr << 22), slot = 0;
+                for (uint32_t m = 0; m < nf; ++m, ++slot) {            // this strand: the R bases in front of the occurrence
+                    const uint32_t pos = sa[e.x + m];
+                    uint32_t v = 0x80000000u;                          // no k-mer ends here (the text starts too late)
+                    if (pos >= R) {
+                        v = 0;
+                        for (uint32_t b = 0; b < R; ++b) v |= code_of(chars[pos - R + b]) << (2u * b);
+                        if (chars[pos - R] >= 'A' && chars[pos - R] <= 'Z') y |= 1u << (26u + slot);   // is_upper = mask 1, src/kmers.h:71-73
+                    }
+                    cand[slot] = v;
+                }
+                for (uint32_t m = 0; m < nr; ++m, ++slot) {            // the other strand: rc of the R bases behind the occurrence of rc(K)
+                    const uint64_t p = sa[er.x + m];
+                    uint32_t v = 0x80000000u;
+                    if (p + T + R <= text_len) {
+                        uint64_t w = 0;
+                        for (uint32_t b = 0; b < R; ++b) w |= static_cast<uint64_t>(code_of(chars[p + T + b])) << (2u * b);
+                        v = static_cast<uint32_t>(revcomp_2bit(w, static_cast<int>(R)));
+                        if (chars[p] >= 'A' && chars[p] <= 'Z') y |= 1u << (26u + slot);               // the k-mer rc(query) starts at p
+                    }
+                    cand[slot] = v;
+                }
+                e.y = y;
+                done = true;
+            }
+        }
+        if (!done && (e.y >> 30) == 1u) {
             const uint32_t rows = (e.y >> 24) & 3u;
             uint32_t y = e.y;
             for (uint32_t m = 0; m < rows; ++m) {
-                pos[m] = sa[e.x + m];
-                if (pos[m] >= R) {
-                    const char ch = chars[pos[m] - R];
-                    if (ch >= 'A' && ch <= 'Z') y |= 1u << (26u + m);   // is_upper = mask 1, src/kmers.h:71-73
+                const uint32_t pos = sa[e.x + m];
+                cand[m] = pos;
+                if (pos >= R && chars[pos - R] >= 'A' && chars[pos - R] <= 'Z') y |= 1u << (26u + m);
+                if (bases_mode) {   // R <= 15: the R bases in front of the row -- or bit 31 when the text starts too late
+                    uint32_t v = 0x80000000u;
+                    if (pos >= R) {
+                        v = 0;
+                        for (uint32_t b = 0; b < R; ++b) v |= code_of(chars[pos - R + b]) << (2u * b);
+                    }
+                    cand[m] = v;
                 }
             }
             e.y = y;   // (the 8-byte table stays as it is: the mask bits live in the lookup kernel's copy)
-            if (bases_mode) {   // R <= 15: the R bases in front of each row, base pos - R in bits 0..1 -- or bit 31 when the text starts too late
-                for (uint32_t m = 0; m < rows; ++m) {
-                    uint32_t v = 0x80000000u;
-                    if (pos[m] >= R) {
-                        v = 0;
-                        for (uint32_t b = 0; b < R; ++b) {
-                            const uint32_t ch = static_cast<uint8_t>(chars[pos[m] - R + b]) | 0x20u;
-                            v |= (ch == 'a' ? 0u : (ch == 'c' ? 1u : (ch == 'g' ? 2u : 3u))) << (2u * b);
-                        }
-                    }
-                    pos[m] = v;
-                }
-            }
         }
-        vtable[idx] = make_uint4(e.x, e.y, pos[0], pos[1]);
-        stable[idx] = pos[2];
+        vtable[idx] = make_uint4(e.x, e.y, cand[0], cand[1]);
+        stable[idx] = cand[2];
     }
 }
 
@@ -1039,8 +1103,8 @@ extern "C" int fmsi_hip_index_enable_verify(fmsi_hip_index* idx) {
         hipLaunchKernelGGL(chars_to_text2_kernel, dim3(static_cast<uint32_t>((n_words + 255) / 256)), dim3(256), 0, 0, d_chars, len, n_words, d_text2);
     }
     const uint32_t blocks = static_cast<uint32_t>(std::min<uint64_t>((count + 255) / 256, 1u << 20));
-    hipLaunchKernelGGL(verify_fill_kernel, dim3(blocks), dim3(256), 0, 0, static_cast<const uint2*>(idx->d_ptable), count, d_sa, d_chars,
-                       static_cast<uint32_t>(R), R <= 15 ? 1u : 0u, d_vtable, d_stable);
+    hipLaunchKernelGGL(verify_fill_kernel, dim3(blocks), dim3(256), 0, 0, static_cast<const uint2*>(idx->d_ptable), count, d_sa, d_chars, len,
+                       static_cast<uint32_t>(T), static_cast<uint32_t>(R), R <= 15 ? 1u : 0u, d_vtable, d_stable);
     if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess) return fail(FMSI_HIP_EHIP, "text verification: device work failed");
     (void)hipFree(d_chars);
     (void)hipFree(d_sa);
