@@ -263,14 +263,10 @@ __global__ __launch_bounds__(256) void pair_lookup_kernel(PairIndex ix, const ui
             // [nf, nf + nr) its occurrences in the text's reverse complement -- i.e. the OTHER strand's candidates, stored as
             // the bases that precede the key there.  Both are compared with the same remaining bases of the query.
             if (sub == 0u) n_lookups++;
+            // (such an entry never needs its interval, so its first word is the third candidate)
             const uint32_t nf = (ey >> 24) & 3u, nr = (ey >> 22) & 3u, total = nf + nr;
-            const uint32_t need = want_both ? total : nf;
-            const uint32_t cand2 = need > 2u ? ix.stable[tidx] : 0u;
-            if (sub == 0u && need > 2u) n_vreads += 1u;
             const uint32_t want = static_cast<uint32_t>(cur & rmask);
-            const bool m0 = cand0 == want, m1 = cand1 == want, m2 = cand2 == want;
-            i = ex;
-            j = ex + nf;
+            const bool m0 = cand0 == want, m1 = cand1 == want, m2 = ex == want;
             res = slots_result(0u, nf, m0, m1, m2, ey);
             if (want_both) {
                 res_other = slots_result(nf, total, m0, m1, m2, ey);
@@ -1041,6 +1037,7 @@ __global__ __launch_bounds__(256) void verify_fill_kernel(const uint2* __restric
                     }
                     cand[slot] = v;
                 }
+                e.x = cand[2];   // no interval is ever needed from a double-stranded entry: the third candidate rides in its place
                 e.y = y;
                 done = true;
             }

@@ -321,7 +321,8 @@ def test_text_verification_on_repeats_and_text_start(fm, oracle_built, t, k):
             assert np.array_equal(fast.astype(bool), expected_fast(fwd, rc, mode_all))
     assert (fwd == 0).any() and (fwd == 1).any() and (rc == 1).any()
     _, cn = dev.query_kmers(packed, k, fm.MODE_ALL | fm.STRICT, counters=True)
-    assert int(cn[7]) > 0        # verification reads happened
+    _, cn_steps = dev.query_kmers(packed, k, fm.MODE_ALL | fm.STRICT | fm.KERNEL_PAIR, counters=True)
+    assert int(cn[6]) == len(kmers) and int(cn[0]) < int(cn_steps[0])   # candidates settled searches that otherwise take steps
     fwd, rc, of, orr = orc.ternaries_bulk(raw, len(kmers), k, False, orders=True)
     got = dev.query_kmers(packed, k, fm.ORDERS | fm.STRICT)   # lookup never verifies: ranks come from the steps
     assert np.array_equal(got[:, 0], of) and np.array_equal(got[:, 1], orr)
