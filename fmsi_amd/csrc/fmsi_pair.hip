@@ -444,7 +444,8 @@ __global__ __launch_bounds__(256) void query_pair_kernel(PairIndex ix, const uin
     const uint32_t wib = threadIdx.x >> 6;          // wave in block
     constexpr uint32_t kRingWords = LIST ? 640u : 256u;   // per wave: 128 k-mers (+ LIST: their (i, j) and chunk-relative index)
     uint64_t* ring = reinterpret_cast<uint64_t*>(lds + tbl_words) + wib * (kRingWords / 2u);
-    uint8_t* obuf = reinterpret_cast<uint8_t*>(lds + tbl_words + 4u * kRingWords) + wib * 2048u;
+    const uint32_t out_bytes = LIST ? ((chunk + 127u) & ~127u) : 2048u;   // the chunk's result bytes live here
+    uint8_t* obuf = reinterpret_cast<uint8_t*>(lds + tbl_words + 4u * kRingWords) + wib * out_bytes;
     uint32_t* ring_ql = reinterpret_cast<uint32_t*>(ring + 256);   // LIST only
     const uint32_t sub = lane & 1u;                 // my half
     const uint32_t pbase = lane & ~1u;              // first lane of my pair
@@ -826,9 +827,12 @@ PairIndex make_pair_index(const fmsi_hip_index* idx) {
 template <bool COUNT>
 int launch_phased_t(fmsi_hip_index* idx, const uint64_t* d_kmers, uint64_t n, int k, uint32_t flags, uint8_t* o8, long long* o64,
                     unsigned long long* d_counters, hipStream_t s) {
-    // both kernels cut the batch into the same chunks, one per wave
-    uint64_t chunk = n / (256ull * 32 * 8 * 2);
-    chunk = std::min<uint64_t>(std::max<uint64_t>(chunk, 128), 2048);
+    // both kernels cut the batch into the same chunks, one per wave.  Long chunks: the stepping kernel has little left to
+    // do per chunk, and its fixed cost per workgroup (the tables into LDS) should be paid seldom
+    // (4096 with the candidate tables, which leave it a few per cent of the searches; 1024 -- more workgroups per CU --
+    // when it has to do the bulk of them)
+    uint64_t chunk = n / (256ull * 4 * 2);
+    chunk = std::min<uint64_t>(std::max<uint64_t>(chunk, 128), idx->d_vtable && !(flags & FMSI_HIP_ORDERS) ? 4096 : 1024) & ~127ull;
     const uint64_t waves = (n + chunk - 1) / chunk;
     const uint32_t blocks = static_cast<uint32_t>((waves + 3) / 4);
     // per wave a private work list with room for its whole chunk, and its length
@@ -842,7 +846,10 @@ int launch_phased_t(fmsi_hip_index* idx, const uint64_t* d_kmers, uint64_t n, in
                        d_list, d_count, d_counters);
     FMSI_HIP_TRY(hipGetLastError());
     const uint32_t n_super = static_cast<uint32_t>(((idx->n_blocks - 1) >> kSuperBlocksLog2) + 1);
-    const size_t lds_bytes = (((16 + 16 * static_cast<size_t>(n_super) + 2) & ~size_t(1)) + 4 * 640 + 4 * 512) * 4;
+    const size_t lds_bytes = (((16 + 16 * static_cast<size_t>(n_super) + 2) & ~size_t(1)) + 4 * 640 + static_cast<size_t>(chunk)) * 4;
+    if (lds_bytes > 64 * 1024)   // 160 KB of LDS per CU on gfx950; more than 64 KB per workgroup has to be asked for
+        FMSI_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&query_pair_kernel<COUNT, true, true>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_bytes)));
     hipLaunchKernelGGL((query_pair_kernel<COUNT, true, true>), dim3(blocks), dim3(256), lds_bytes, s, pix, d_kmers, n, k, flags,
                        static_cast<uint32_t>(chunk), n_super, o8, o64, d_counters, d_list, d_count);
     FMSI_HIP_TRY(hipGetLastError());
