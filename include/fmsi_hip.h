@@ -162,14 +162,15 @@ int fmsi_host_index_write(const char* prefix, const fmsi_index_view* view);
  * sub-command sees it (argv[0] = "index").  Returns the process exit code. */
 int fmsi_cli_index(int argc, char** argv);
 
-/* Adds text verification to a handle that has a prefix table and the pair layout (private optimisation, results
- * unchanged): for every table entry whose interval has one to three rows the text positions of those rows are kept,
- * together with the 2-bit superstring.  A search that comes out of the table with such an interval is then settled by
- * comparing the remaining k - t bases with the text directly (one read of the positions, one of the text per row)
- * instead of (k - t) / 2 dependent block reads: the rows that match are the final interval, and their mask bits are
- * stored in the entry.
- * Positions and text come from the LF walk of fmsi_hip_index_export, so any handle can add it.  Used by the phased
- * kernels for the presence modes (not ORDERS).  4^t x 20 bytes + n / 4 bytes of HBM.  Idempotent. */
+/* Adds the candidate tables to a handle that has a prefix table (private optimisation, results unchanged): the lookup
+ * kernel of the phased path gets its own 16-byte copy of the table entries in which every occurrence of a key -- on both
+ * strands when the key and its reverse complement occur at most three times together, else the forward ones of an
+ * interval of up to three rows -- is represented by the k - t bases in front of it and the mask bit of the k-mer it would
+ * complete.  A search that comes out of the table with such an entry is settled by comparing its remaining bases with the
+ * candidates (one request) instead of (k - t) / 2 dependent block reads: the candidates that match are the rows of the
+ * final interval(s), in order.  For k - t > 15 the entries hold text positions and the bases are read from the 2-bit
+ * superstring.  Everything comes from the LF walk of fmsi_hip_index_export, so any handle can add it.  Used for the
+ * presence modes (not ORDERS).  4^t x 20 bytes + n / 4 bytes of HBM.  Idempotent. */
 int fmsi_hip_index_enable_verify(fmsi_hip_index* idx);
 
 /* Replaces export_ms() (src/fms_index.h:462-473): the masked superstring of the index (upper case = mask 1), written
