@@ -58,6 +58,7 @@ struct PairIndex {
                               // table, 16 bytes per entry: (i, tagged word + mask bits 26-28, candidate 0, candidate 1)
     const uint32_t* stable;   // ... candidate 2 per entry (intervals of three rows)
     const uint64_t* text2;    // ... and the 2-bit packed superstring
+    int verify_k;             // the k the candidate tables were made for (the index's): a query with another k does not use them
     uint32_t verify_bases;    // 1: the words ARE the k - t bases in front of each row (k - t <= 15; bit 31 = no such k-mer);
                               // 0: the words are text positions and the bases are read from text2
     uint32_t ptable_len, ptable_packed;
@@ -200,7 +201,7 @@ __global__ __launch_bounds__(256) void pair_lookup_kernel(PairIndex ix, const ui
     const int t = k - 1 - T;
     const uint32_t R = static_cast<uint32_t>(k - T);                       // bases left after the table
     const uint64_t rmask = R >= 32u ? ~0ull : ((1ull << (2u * R)) - 1ull);
-    const bool verify = ix.vtable != nullptr && ix.ptable_packed && !orders && R >= 1u && R <= 32u;
+    const bool verify = ix.vtable != nullptr && ix.ptable_packed && !orders && k == ix.verify_k && R >= 1u && R <= 32u;
     const uint32_t tmask = static_cast<uint32_t>((1ull << (2 * T)) - 1ull);
     const uint32_t lane = threadIdx.x & 63u, sub = lane & 1u;
     const int pbase = static_cast<int>(lane & ~1u);
@@ -814,6 +815,7 @@ PairIndex make_pair_index(const fmsi_hip_index* idx) {
     p.ptable_packed = idx->dev.ptable_packed;
     p.vtable = static_cast<const uint4*>(idx->d_vtable);
     p.stable = static_cast<const uint32_t*>(idx->d_stable);
+    p.verify_k = idx->k;
     p.verify_bases = (idx->k - idx->prefix_len) <= 15 ? 1u : 0u;
     p.text2 = static_cast<const uint64_t*>(idx->d_text2);
     p.n = idx->dev.n;

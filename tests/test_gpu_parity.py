@@ -375,3 +375,17 @@ def test_full_scale_cross_kernel_agreement(fm):
     per_read = ((a & 3) == 2) | (((a >> 2) & 3) == 2)
     frac = per_read.reshape(n_reads, -1).mean(axis=1)
     assert ((frac == 0) | (frac == 1)).all() and 0.35 < (frac == 1).mean() < 0.65   # a read is from the superstring or it is not
+
+
+def test_candidate_tables_are_for_the_index_k_only(fm, oracle_built):
+    """The search itself is k-agnostic (any pattern length can be asked of a handle); the candidate tables are made for
+    the index's k, so a query with another k must not touch them."""
+    name, k = "sars_k31", 31
+    orc = oracle_py.Oracle.load(index_prefix(name))
+    dev = fm.DeviceIndex.from_files(index_prefix(name), prefix_len=8).enable_pair_layout().enable_verify()
+    ms = "".join(l.strip() for l in open(GOLDEN / "ref_data" / "GCF_test2_ones.fna.ms.k31") if not l.startswith(">"))
+    for kq in (31, 27, 19, 9):
+        kmers = mixed_kmers(ms, kq, 3000, seed=kq)
+        fwd, rc = orc.ternaries_bulk("".join(kmers).encode(), len(kmers), kq, True)
+        gf, gr = fm.decode_strict(dev.query_kmers(fm.pack_kmers(kmers, kq), kq, fm.MODE_ALL | fm.STRICT))
+        assert np.array_equal(gf, fwd) and np.array_equal(gr, rc), kq
