@@ -611,6 +611,10 @@ extern "C" int fmsi_hip_query_stream(fmsi_hip_index* idx, const uint64_t* packed
         set_last_error("streaming queries need an index created with its kLCP array");
         return FMSI_HIP_EINVAL;
     }
+    if (k != idx->k) {       // the kLCP bits say "these two rows share k - 1 bases" for the index's k and no other
+        set_last_error("streaming queries need k = " + std::to_string(idx->k) + ", the k the kLCP array was built for");
+        return FMSI_HIP_EINVAL;
+    }
     if (k < 1 || k > 64) {   // a kLCP array exists for k <= 64 only (reference src/main.cpp:223-226)
         set_last_error("streaming queries need 1 <= k <= 64");
         return FMSI_HIP_ERANGE;
