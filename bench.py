@@ -17,9 +17,12 @@ on the data path; the results of the last step are gathered to rank 0 over RCCL 
 
 Extra objects on the JSON line:
   roofline     -- HBM bound.  `achieved` = algorithmic bytes of one launch / average kernel duration.  The bytes are
-                  what this layout must touch, counted by the kernel itself: 64 B per interleaved block or prefix-table
-                  line read (+ 8 B per kLCP word when streaming) + query bytes in + 1 B result out per window; the
-                  duration comes from HIP events recorded on the launch stream inside the library.
+                  what this layout must touch, counted by the kernels themselves: 64 B per table line, 128 B per
+                  pair-layout block (64 B per single-step block), 32 B per candidate / text read, 8 B per kLCP word
+                  when streaming, + query bytes in + 1 B result out per window; the duration comes from HIP events
+                  recorded on the launch stream inside the library, around the launch's kernels (the default `phased`
+                  form is two: lookup + stepping).  `random_requests_per_s` is the figure the path is really bound by
+                  (DESIGN.md 3, 5): dependent random requests, not bytes.
                   `canonical_achieved` applies SURVEY 8(d)'s reference-layout formula (256 B per LF step the REFERENCE
                   algorithm executes for the same queries + 64 B per mask probe + in/out) to the same time; it can
                   exceed the HBM peak because the fused layout and the prefix table touch far fewer bytes.
