@@ -65,6 +65,9 @@ def parse_args():
     ap.add_argument("--cpu-sample", type=int, default=-1, help="windows for the CPU baseline (-1 = auto, 0 = skip)")
     ap.add_argument("--no-counters", action="store_true")
     ap.add_argument("--no-verify", action="store_true", help="phased kernel without text verification of one-row table intervals")
+    ap.add_argument("--stream-via", choices=["klcp", "runs"], default="klcp",
+                    help="stream workload: klcp = fmsi_hip_query_stream (the kLCP kernel, what -S means in the reference); runs = the same "
+                         "windows through fmsi_hip_query_runs (phased kernels + candidate tables; same answers)")
     return ap.parse_args()
 
 
@@ -82,7 +85,9 @@ def pmc_traffic(args, n, batch, k):
         c = t.get("config", {})
         if (c.get("workload", "kmers"), c.get("n"), c.get("batch"), c.get("k"), c.get("prefix_len"), c.get("mode")) == \
                 (args.workload, n, batch, k, args.prefix_len, args.mode) and \
-                ("stream" if args.workload == "stream" else ("pair" if args.kernel == "phased" else args.kernel)) in t.get("kernel", ""):
+                ("stream" if (args.workload == "stream" and args.stream_via == "klcp") else
+                 ("pair" if (args.kernel == "phased" or args.workload == "stream") else args.kernel)) in t.get("kernel", "") and \
+                c.get("stream_via", "klcp") == (args.stream_via if args.workload == "stream" else "klcp"):
             best = t
     return None if best is None else best["hbm_bytes_per_launch"]
 
@@ -116,6 +121,10 @@ def main():
     index = fm.DeviceIndex.build_synthetic(n, args.seed, k, with_klcp=stream_mode, device=local_rank, prefix_len=args.prefix_len)
     build_s = time.time() - t0
     flags = fm.MODE_ALL if args.mode == "all" else fm.MODE_OR
+    if stream_mode and args.stream_via == "runs":
+        index.enable_pair_layout()
+        if 0 < args.prefix_len < k and not args.no_verify:
+            index.enable_verify()
     if not stream_mode:
         if args.kernel in ("pair", "phased"):
             t0 = time.time()
@@ -143,7 +152,8 @@ def main():
             index.synthetic_reads_dev(L, args.query_seed, (step * world + rank) * n_reads, n_reads, buf.data_ptr(), args.subst_ppm, stream)
 
         def launch(buf, out, counters_ptr=0, extra=0):
-            index.query_stream_dev(buf.data_ptr(), n_reads * L, run_start, run_windows, k, flags | extra, out.data_ptr(), counters_ptr, stream)
+            fn = index.query_runs_dev if args.stream_via == "runs" else index.query_stream_dev
+            fn(buf.data_ptr(), n_reads * L, run_start, run_windows, k, flags | extra, out.data_ptr(), counters_ptr, stream)
     else:
         batch = int(args.batch)
         in_words = batch
@@ -216,7 +226,8 @@ def main():
             blocks_read, lookups, klcp_words = int(counters[1]), int(counters[4]), int(counters[5])
             verify_reads = int(counters[7])   # text verification: 4-byte position + 8..16 bytes of text, two requests per verified search
             # blocks_read already contains the prefix-table lines (one 64-B line per lookup); the pair layout reads 128-B blocks
-            block_b = 128 if (args.kernel in ("pair", "phased") and not stream_mode) else 64
+            pair_blocks = (args.kernel in ("pair", "phased") and not stream_mode) or (stream_mode and args.stream_via == "runs")
+            block_b = 128 if pair_blocks else 64
             bytes_launch = block_b * (blocks_read - lookups) + 64 * lookups + 8 * klcp_words + in_bytes + 1 * batch
             bytes_launch += 32 * verify_reads   # counted as two 32-byte sectors per verification
             # (phased form: the work items of the searches left to the stepping kernel -- 48 bytes for about 3 % of the k-mers -- are not counted)
@@ -224,8 +235,9 @@ def main():
             ach = bytes_launch / avg_kernel_s / 1e9
             roof = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(args, n, batch, k),
-                    "kernel": "query_stream_kernel" if stream_mode else ("pair_lookup_kernel + query_pair_kernel" if args.kernel == "phased"
-                                                                        else f"query_{args.kernel}_kernel"),
+                    "kernel": ("pair_lookup_kernel<RUNS> + query_pair_kernel" if stream_mode and args.stream_via == "runs" else
+                               "query_stream_kernel" if stream_mode else
+                               "pair_lookup_kernel + query_pair_kernel" if args.kernel == "phased" else f"query_{args.kernel}_kernel"),
                     "avg_kernel_ms": round(avg_kernel_s * 1e3, 4), "launches": launches,
                     "algorithmic_bytes_per_launch": int(bytes_launch),
                     "bytes_per_kmer": round(bytes_launch / batch, 1),
@@ -249,8 +261,9 @@ def main():
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed_max / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
             "config": {"workload": wl, "index_rows": int(info.n), "k": k, "queries_per_step_per_gpu": batch, "mode": args.mode,
-                       "kernel": "stream" if stream_mode else args.kernel, "prefix_table_len": int(info.prefix_len),
-                       "index_bytes_hbm": int(info.device_bytes), "block_bytes": 128 if (args.kernel in ("pair", "phased") and not stream_mode) else 64,
+                       "kernel": ("phased-runs" if args.stream_via == "runs" else "stream") if stream_mode else args.kernel,
+                       "prefix_table_len": int(info.prefix_len), "index_bytes_hbm": int(info.device_bytes),
+                       "block_bytes": 128 if (args.kernel in ("pair", "phased") and not stream_mode) or (stream_mode and args.stream_via == "runs") else 64,
                        "parallelism": f"query-sharded x{world}, index replicated", "positive_fraction": round(positives, 4),
                        "index_build_seconds": round(build_s, 2)},
             "roofline": roof,

@@ -378,12 +378,17 @@ class DeviceIndex:
         return (out, cn) if counters else out
 
     def query_stream_dev(self, packed_ptr: int, seq_bases: int, run_start, run_windows, k: int, flags: int, out_ptr: int,
-                         counters_ptr: int = 0, stream: int = 0):
+                         counters_ptr: int = 0, stream: int = 0, _fn: str = "fmsi_hip_query_stream"):
         """Same with the sequence / results resident in HBM; the run arrays are host arrays in every mode."""
         run_start = np.ascontiguousarray(run_start, dtype=np.uint64)
         run_windows = np.ascontiguousarray(run_windows, dtype=np.uint32)
-        _check(lib().fmsi_hip_query_stream(self._h, packed_ptr, seq_bases, run_start.ctypes.data, run_windows.ctypes.data, run_start.size,
-                                           int(run_windows.sum()), k, flags | DEVICE_PTRS, out_ptr, counters_ptr or None, stream or None))
+        _check(getattr(lib(), _fn)(self._h, packed_ptr, seq_bases, run_start.ctypes.data, run_windows.ctypes.data, run_start.size,
+                                   int(run_windows.sum()), k, flags | DEVICE_PTRS, out_ptr, counters_ptr or None, stream or None))
+
+    def query_runs_dev(self, packed_ptr: int, seq_bases: int, run_start, run_windows, k: int, flags: int, out_ptr: int,
+                       counters_ptr: int = 0, stream: int = 0):
+        """Runs of windows through the non-streaming kernels, sequence / results resident in HBM."""
+        self.query_stream_dev(packed_ptr, seq_bases, run_start, run_windows, k, flags, out_ptr, counters_ptr, stream, _fn="fmsi_hip_query_runs")
 
     # -- device-pointer calls (buffers already resident in HBM, e.g. torch tensors' data_ptr()) --
     def query_kmers_dev(self, kmers_ptr: int, n: int, k: int, flags: int, out_ptr: int, counters_ptr: int = 0, stream: int = 0):

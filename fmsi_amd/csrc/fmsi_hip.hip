@@ -849,6 +849,22 @@ int fmsi_hip_query_runs(fmsi_hip_index* idx, const uint64_t* packed_seq, uint64_
             d_cnt = idx->d_counters;
         }
     }
+    const uint32_t kernel = flags & FMSI_HIP_KERNEL_MASK;
+    if (k <= 32 && (kernel == FMSI_HIP_KERNEL_PHASED || kernel == FMSI_HIP_KERNEL_AUTO) && idx->d_pblocks && idx->d_ptable &&
+        !(flags & FMSI_HIP_NO_PREFIX_TABLE) && k >= idx->prefix_len && n_windows <= (1ull << 38)) {
+        // the phased kernels cut the windows themselves: no pass that writes 8 bytes per window and reads them back
+        size_t slot;
+        if ((rc = prof_begin(idx, s, &slot))) return rc;
+        if ((rc = launch_phased_query(idx, d_seq, n_windows, k, flags, static_cast<uint8_t*>(d_out), static_cast<long long*>(d_out), d_cnt, s,
+                                      meta.data(), n_runs)))
+            return rc;
+        if ((rc = prof_end(idx, s, slot))) return rc;
+        if (!dev_ptrs) {
+            if (out_bytes) FMSI_HIP_TRY(hipMemcpyAsync(out, idx->d_out, out_bytes, hipMemcpyDeviceToHost, s));
+            if (counters) FMSI_HIP_TRY(hipMemcpyAsync(counters, idx->d_counters, FMSI_HIP_N_COUNTERS * 8, hipMemcpyDeviceToHost, s));
+        }
+        return 0;
+    }
     if ((rc = ensure_cap(&idx->d_tasks, &idx->d_tasks_cap, meta.size() * 8))) return rc;
     FMSI_HIP_TRY(hipMemcpyAsync(idx->d_tasks, meta.data(), meta.size() * 8, hipMemcpyHostToDevice, s));
     FMSI_HIP_TRY(hipStreamSynchronize(s));   // `meta` is a local vector

@@ -189,11 +189,14 @@ static_assert(sizeof(WorkItem) == 24, "WorkItem layout");
 // that match are the rows of the interval get_range_with_pattern() would end with, their mask bits are kept in the entry
 // (bits 26-28) -- instead of (k - t) / 2 dependent block reads: infer_presence() (src/fms_index.h:117-144) from 1 + rows
 // reads.
-template <bool COUNT>
+// RUNS: `kmers` is a 2-bit packed sequence and window q is base run_start[r] + q - run_off[r] of it, r the run with
+// run_off[r] <= q < run_off[r + 1] (fmsi_hip_query_runs): the windows are cut here instead of by a pass of their own.
+template <bool COUNT, bool RUNS>
 __global__ __launch_bounds__(256) void pair_lookup_kernel(PairIndex ix, const uint64_t* __restrict__ kmers, uint64_t n_windows, int k, uint32_t flags,
                                                           uint32_t chunk, uint8_t* __restrict__ out, long long* __restrict__ out_orders,
                                                           WorkItem* __restrict__ list, uint32_t* __restrict__ list_count,
-                                                          unsigned long long* __restrict__ counters) {
+                                                          unsigned long long* __restrict__ counters, const uint64_t* __restrict__ run_start,
+                                                          const uint64_t* __restrict__ run_off, uint64_t n_runs) {
     const uint32_t strict = flags & FMSI_HIP_STRICT;
     const uint32_t orders = flags & FMSI_HIP_ORDERS;
     const uint32_t mode_all = flags & FMSI_HIP_MODE_ALL;
@@ -211,6 +214,22 @@ __global__ __launch_bounds__(256) void pair_lookup_kernel(PairIndex ix, const ui
     const uint64_t start = wave * chunk;
     const uint32_t len = start < n_windows ? static_cast<uint32_t>(min(static_cast<uint64_t>(chunk), n_windows - start)) : 0u;
     uint32_t count = 0;   // wave-uniform: work items written so far
+    // RUNS: the run of this lane's current window -- windows only move forward, so the search restarts from the last run
+    uint64_t run = 0, run_last = 0, run_end = 0, run_delta = 0;   // run_end = run_off[run + 1], run_delta = run_start[run] - run_off[run]
+    auto find_run = [&](uint64_t lo, uint64_t hi, uint64_t q) -> uint64_t {   // run_off[lo] <= q < run_off[hi]
+        while (hi - lo > 1) {
+            const uint64_t mid = (lo + hi) >> 1;
+            if (run_off[mid] <= q) lo = mid;
+            else hi = mid;
+        }
+        return lo;
+    };
+    if (RUNS && len) {
+        run = find_run(0, n_runs, start);
+        run_last = find_run(run, n_runs, start + len - 1u);
+        run_end = run_off[run + 1];
+        run_delta = run_start[run] - run_off[run];
+    }
 
     // presence from candidate slots [lo, hi): the matching ones are the rows of the final interval in their order --
     // ALL takes the mask bit of the first, OR any mask bit (src/fms_index.h:126-144); none = the empty interval
@@ -313,7 +332,19 @@ __global__ __launch_bounds__(256) void pair_lookup_kernel(PairIndex ix, const ui
         const uint32_t ql = base + (lane >> 1);
         const bool valid = ql < len;
         const uint64_t q = start + ql;
-        const uint64_t f = valid ? kmers[q] : 0ull;
+        uint64_t f = 0ull;
+        if (RUNS) {
+            if (valid) {
+                if (q >= run_end) {
+                    run = find_run(run + 1, run_last + 1, q);
+                    run_end = run_off[run + 1];
+                    run_delta = run_start[run] - run_off[run];
+                }
+                f = window_kmer(kmers, q + run_delta, k);
+            }
+        } else if (valid) {
+            f = kmers[q];
+        }
         uint32_t i_f = 0, j_f = 0, i_r = 0, j_r = 0;
         int res_f = -1, res_r = -1, unused = -1;
         const uint32_t sf = strand(f, valid, true, i_f, j_f, res_f, res_r);
@@ -826,9 +857,9 @@ PairIndex make_pair_index(const fmsi_hip_index* idx) {
     return p;
 }
 
-template <bool COUNT>
+template <bool COUNT, bool RUNS>
 int launch_phased_t(fmsi_hip_index* idx, const uint64_t* d_kmers, uint64_t n, int k, uint32_t flags, uint8_t* o8, long long* o64,
-                    unsigned long long* d_counters, hipStream_t s) {
+                    unsigned long long* d_counters, hipStream_t s, const uint64_t* h_runs, uint64_t n_runs) {
     // both kernels cut the batch into the same chunks, one per wave.  Long chunks: the stepping kernel has little left to
     // do per chunk, and its fixed cost per workgroup (the tables into LDS) should be paid seldom
     // (4096 with the candidate tables, which leave it a few per cent of the searches; 1024 -- more workgroups per CU --
@@ -839,13 +870,20 @@ int launch_phased_t(fmsi_hip_index* idx, const uint64_t* d_kmers, uint64_t n, in
     const uint32_t blocks = static_cast<uint32_t>((waves + 3) / 4);
     // per wave a private work list with room for its whole chunk, and its length
     const size_t list_bytes = (n * sizeof(WorkItem) + 63) / 64 * 64;
-    int rc = ensure_cap(&idx->d_tasks, &idx->d_tasks_cap, list_bytes + waves * 4);
+    // (RUNS: and behind them the run table -- n_runs starts, n_runs + 1 offsets)
+    const size_t count_bytes = (waves * 4 + 63) / 64 * 64;
+    int rc = ensure_cap(&idx->d_tasks, &idx->d_tasks_cap, list_bytes + count_bytes + (RUNS ? (2 * n_runs + 1) * 8 : 0));
     if (rc) return rc;
     auto* d_list = static_cast<WorkItem*>(idx->d_tasks);
     auto* d_count = reinterpret_cast<uint32_t*>(static_cast<char*>(idx->d_tasks) + list_bytes);
+    auto* d_runs = reinterpret_cast<uint64_t*>(static_cast<char*>(idx->d_tasks) + list_bytes + count_bytes);
+    if (RUNS) {
+        FMSI_HIP_TRY(hipMemcpyAsync(d_runs, h_runs, (2 * n_runs + 1) * 8, hipMemcpyHostToDevice, s));
+        FMSI_HIP_TRY(hipStreamSynchronize(s));   // the caller's table may be a local
+    }
     const PairIndex pix = make_pair_index(idx);
-    hipLaunchKernelGGL((pair_lookup_kernel<COUNT>), dim3(blocks), dim3(256), 0, s, pix, d_kmers, n, k, flags, static_cast<uint32_t>(chunk), o8, o64,
-                       d_list, d_count, d_counters);
+    hipLaunchKernelGGL((pair_lookup_kernel<COUNT, RUNS>), dim3(blocks), dim3(256), 0, s, pix, d_kmers, n, k, flags, static_cast<uint32_t>(chunk), o8,
+                       o64, d_list, d_count, d_counters, d_runs, d_runs + n_runs, n_runs);
     FMSI_HIP_TRY(hipGetLastError());
     const uint32_t n_super = static_cast<uint32_t>(((idx->n_blocks - 1) >> kSuperBlocksLog2) + 1);
     const size_t lds_bytes = (((16 + 16 * static_cast<size_t>(n_super) + 2) & ~size_t(1)) + 4 * 640 + static_cast<size_t>(chunk)) * 4;
@@ -876,9 +914,12 @@ void launch_pair_t(fmsi_hip_index* idx, const uint64_t* d_kmers, uint64_t n, int
 }  // namespace
 
 int launch_phased_query(fmsi_hip_index* idx, const uint64_t* d_kmers, uint64_t n, int k, uint32_t flags, uint8_t* o8, long long* o64,
-                        unsigned long long* d_counters, hipStream_t s) {
-    return d_counters ? launch_phased_t<true>(idx, d_kmers, n, k, flags, o8, o64, d_counters, s)
-                      : launch_phased_t<false>(idx, d_kmers, n, k, flags, o8, o64, d_counters, s);
+                        unsigned long long* d_counters, hipStream_t s, const uint64_t* h_runs, uint64_t n_runs) {
+    if (h_runs)
+        return d_counters ? launch_phased_t<true, true>(idx, d_kmers, n, k, flags, o8, o64, d_counters, s, h_runs, n_runs)
+                          : launch_phased_t<false, true>(idx, d_kmers, n, k, flags, o8, o64, d_counters, s, h_runs, n_runs);
+    return d_counters ? launch_phased_t<true, false>(idx, d_kmers, n, k, flags, o8, o64, d_counters, s, nullptr, 0)
+                      : launch_phased_t<false, false>(idx, d_kmers, n, k, flags, o8, o64, d_counters, s, nullptr, 0);
 }
 
 void launch_pair_query(fmsi_hip_index* idx, const uint64_t* d_kmers, uint64_t n, int k, uint32_t flags, bool use_table, uint8_t* o8,

@@ -87,9 +87,11 @@ void launch_longk_query(fmsi_hip_index* idx, const uint64_t* d_seq, const uint64
                         uint8_t* o8, long long* o64, unsigned long long* d_counters, hipStream_t s);
 
 // phased form of the same (fmsi_pair.hip): table lookups in a kernel of their own, the searches still alive in a second;
-// needs the pair layout and a prefix table with k >= t
+// needs the pair layout and a prefix table with k >= t.  h_runs != nullptr: d_kmers is a packed sequence and the n windows
+// are runs of consecutive windows of it -- h_runs (HOST) = n_runs first bases, then n_runs + 1 exclusive prefix sums of
+// the run lengths; the lookup kernel cuts the windows itself
 int launch_phased_query(fmsi_hip_index* idx, const uint64_t* d_kmers, uint64_t n, int k, uint32_t flags, uint8_t* o8, long long* o64,
-                        unsigned long long* d_counters, hipStream_t s);
+                        unsigned long long* d_counters, hipStream_t s, const uint64_t* h_runs = nullptr, uint64_t n_runs = 0);
 
 // the LF walk of `fmsi export` (fmsi_export.hip): letters with the mask's case into d_chars[0 .. n-2] (device), and
 // optionally sa[row] = text position of the row's suffix for every row (device, n entries)

@@ -199,7 +199,9 @@ int fmsi_hip_query_windows(fmsi_hip_index* idx, const uint64_t* packed_seq, uint
 /* Same windows, given as RUNS of consecutive windows (what a chunk of query_kmers() is, src/main.cpp:337-354): run r
  * covers the windows starting at bases run_start[r] .. run_start[r] + run_windows[r] - 1; results are written
  * consecutively in run order.  run_start / run_windows are HOST arrays in every mode (12 bytes per run instead of
- * 8 bytes per window); the window starts are expanded on the device. */
+ * 8 bytes per window); the windows are cut on the device (by the lookup kernel itself on the phased path, by a pass
+ * of its own before the other kernels).  With the candidate tables this is also the quickest way to the presence
+ * answers of `-S` batches, which do not depend on the kLCP array. */
 int fmsi_hip_query_runs(fmsi_hip_index* idx, const uint64_t* packed_seq, uint64_t seq_bases,
                         const uint64_t* run_start, const uint32_t* run_windows, uint64_t n_runs, uint64_t n_windows,
                         int k, uint32_t flags, void* out, uint64_t* counters, void* stream);

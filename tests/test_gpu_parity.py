@@ -377,6 +377,64 @@ def test_full_scale_cross_kernel_agreement(fm):
     assert ((frac == 0) | (frac == 1)).all() and 0.35 < (frac == 1).mean() < 0.65   # a read is from the superstring or it is not
 
 
+@pytest.mark.parametrize("verify", [False, True])
+@pytest.mark.parametrize("k,t", [(31, 8), (31, 10), (19, 7), (32, 9)])
+def test_runs_cut_inside_the_lookup_kernel(fm, oracle_built, k, t, verify):
+    """fmsi_hip_query_runs on the phased kernels cuts the windows inside the lookup kernel (no expanded k-mer array):
+    ragged runs -- single windows, runs that straddle the kernel's chunks, overlapping and out-of-order starts -- must give,
+    window by window, what the same k-mers give as isolated packed k-mers and what the oracle gives, in every mode."""
+    rng = np.random.default_rng(1000 * k + t + verify)
+    ms = synthetic_ms(60_000, k, seed=k + t, mask="mixed")
+    orc = oracle_py.Oracle.construct(ms, k)
+    dev = fm.DeviceIndex.build(ms.encode(), k, prefix_len=t).enable_pair_layout()
+    if verify:
+        dev.enable_verify()
+    up = ms.upper()
+    pieces = []
+    while sum(map(len, pieces)) < 150_000:
+        L = int(rng.choice([k, k + 1, k + 5, 200, 3000, 9000]))
+        if rng.random() < 0.5:
+            p0 = int(rng.integers(0, len(up) - L))
+            piece = up[p0:p0 + L]
+            if rng.random() < 0.5:
+                piece = revcomp(piece)
+        else:
+            piece = "".join(np.array(list("ACGT"))[rng.integers(0, 4, L)])
+        pieces.append(piece)
+    seq = "".join(pieces)
+    bounds = np.cumsum([0] + [len(x) for x in pieces])
+    starts, wins = [], []
+    for a, b in zip(bounds[:-1], bounds[1:]):
+        # a run per piece -- sometimes split into two runs that overlap by a few windows, sometimes cut short
+        w = int(b - a) - k + 1
+        if w > 10 and rng.random() < 0.3:
+            cut = int(rng.integers(1, w))
+            starts += [int(a), int(a) + max(0, cut - 3)]
+            wins += [cut, w - max(0, cut - 3)]
+        else:
+            starts.append(int(a))
+            wins.append(w if rng.random() < 0.8 else max(1, w // 2))
+    order = rng.permutation(len(starts))
+    starts = np.asarray(starts, dtype=np.uint64)[order]
+    wins = np.asarray(wins, dtype=np.uint32)[order]
+    wk = [seq[int(s0) + i:int(s0) + i + k] for s0, w in zip(starts, wins) for i in range(int(w))]
+    fwd, rc = orc.ternaries_bulk("".join(wk).encode(), len(wk), k, True)
+    fwd_or, rc_or = orc.ternaries_bulk("".join(wk).encode(), len(wk), k, False)
+    packed_seq = fm.pack_sequence(seq.encode())
+    packed_kmers = fm.pack_kmers(wk, k)
+    for kern in (0, fm.KERNEL_PHASED):
+        gf, gr = fm.decode_strict(dev.query_runs(packed_seq, len(seq), starts, wins, k, fm.MODE_ALL | fm.STRICT | kern))
+        assert np.array_equal(gf, fwd) and np.array_equal(gr, rc)
+        gf, gr = fm.decode_strict(dev.query_runs(packed_seq, len(seq), starts, wins, k, fm.MODE_OR | fm.STRICT | kern))
+        assert np.array_equal(gf, fwd_or) and np.array_equal(gr, rc_or)
+        for flag, mode_all, f_, r_ in ((fm.MODE_ALL, True, fwd, rc), (fm.MODE_OR, False, fwd_or, rc_or)):
+            got = dev.query_runs(packed_seq, len(seq), starts, wins, k, flag | kern)
+            assert np.array_equal(got.astype(bool), expected_fast(f_, r_, mode_all))
+            assert np.array_equal(got, dev.query_kmers(packed_kmers, k, flag | kern))
+    a, cn = dev.query_runs(packed_seq, len(seq), starts, wins, k, fm.MODE_ALL, counters=True)
+    assert cn[6] == len(wk) and np.array_equal(a.astype(bool), expected_fast(fwd, rc, True))
+
+
 def test_candidate_tables_are_for_the_index_k_only(fm, oracle_built):
     """The search itself is k-agnostic (any pattern length can be asked of a handle); the candidate tables are made for
     the index's k, so a query with another k must not touch them."""
