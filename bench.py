@@ -65,6 +65,9 @@ def parse_args():
     ap.add_argument("--cpu-sample", type=int, default=-1, help="windows for the CPU baseline (-1 = auto, 0 = skip)")
     ap.add_argument("--no-counters", action="store_true")
     ap.add_argument("--no-verify", action="store_true", help="phased kernel without text verification of one-row table intervals")
+    ap.add_argument("--abi-gather", action="store_true",
+                    help="after the timed region, also gather the results through fmsi_hip_gather (C-ABI, own RCCL communicator) and "
+                         "compare with torch.distributed's gather")
     ap.add_argument("--stream-via", choices=["klcp", "runs"], default="klcp",
                     help="stream workload: klcp = fmsi_hip_query_stream (the kLCP kernel, what -S means in the reference); runs = the same "
                          "windows through fmsi_hip_query_runs (phased kernels + candidate tables; same answers)")
@@ -94,6 +97,11 @@ def pmc_traffic(args, n, batch, k):
 
 def main():
     args = parse_args()
+    # stdout carries the ONE JSON line and nothing else: libraries that print to the C stdout (RCCL's version banner at
+    # communicator creation, flushed at exit) are sent to stderr for the whole run
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -213,9 +221,29 @@ def main():
     elapsed_max = float(el.item())
 
     # gather the last step's results to rank 0 (rank order = output order); outside the timed region
+    gather_note = None
     if world > 1:
         parts = [torch.empty_like(d_out) for _ in range(world)] if rank == 0 else None
         dist.gather(d_out, parts, dst=0)
+    if args.abi_gather:
+        # the same gather through the C-ABI (fmsi_hip_gather over its own RCCL communicator), checked against the above
+        from fmsi_amd import sharding
+        try:
+            if world > 1:
+                comm = sharding.comm_from_process_group(local_rank)
+            else:
+                comm = fm.Comm(fm.Comm.unique_id(), 1, 0, local_rank)
+            t_g = time.perf_counter()
+            whole = sharding.gather_to_root_abi(comm, d_out, d_out.numel() * world, dst=0)
+            torch.cuda.synchronize()
+            t_g = time.perf_counter() - t_g
+            if rank == 0:
+                same = torch.equal(whole, torch.cat(parts) if world > 1 else d_out)
+                gather_note = {"fmsi_hip_gather": "matches torch.distributed.gather" if same else "MISMATCH",
+                               "bytes": int(whole.numel()), "seconds": round(t_g, 4)}
+            comm.close()
+        except Exception as e:   # the bench line must still be printed
+            gather_note = {"fmsi_hip_gather": f"failed: {e}"}
 
     if rank == 0:
         total_q = batch * world * args.steps
@@ -269,13 +297,16 @@ def main():
             "roofline": roof,
             "cpu_baseline": None,
         }
+        if gather_note is not None:
+            line["config"]["gather"] = gather_note
         if args.cpu_sample != 0 and world == 1:   # reported baseline: rank 0 of the 1-GPU run only
             try:
                 import bench_cpu   # the only part of the benchmark that touches oracle/
                 line["cpu_baseline"] = bench_cpu.run_stream(args, index, n, k) if stream_mode else bench_cpu.run(args, index, n, k)
             except Exception as e:   # the baseline is a reported figure, never a reason to lose the GPU line
                 line["cpu_baseline"] = {"error": repr(e)}
-        print(json.dumps(line))
+        os.write(json_fd, (json.dumps(line) + "\n").encode())
+    os.close(json_fd)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -135,6 +135,11 @@ def lib() -> C.CDLL:
     L.fmsi_hip_index_export.argtypes = [vp, vp, u64, C.POINTER(u64)]
     L.fmsi_host_index_write.argtypes = [C.c_char_p, C.POINTER(IndexView)]
     L.fmsi_hip_index_write_files.argtypes = [vp, C.c_char_p]
+    L.fmsi_hip_comm_unique_id.argtypes = [vp]
+    L.fmsi_hip_comm_create.argtypes = [vp, i32, i32, i32, C.POINTER(vp)]
+    L.fmsi_hip_comm_destroy.argtypes = [vp]
+    L.fmsi_hip_comm_destroy.restype = None
+    L.fmsi_hip_gather.argtypes = [vp, vp, u64, vp, vp, i32, vp]
     _lib = L
     return L
 
@@ -474,3 +479,45 @@ def run_cli(args, stdin: bytes | None = None):
         raise FileNotFoundError(f"{CLI_PATH} is missing: build first")
     res = subprocess.run([str(CLI_PATH), *args], input=stdin, capture_output=True)
     return res.returncode, res.stdout, res.stderr
+
+
+COMM_ID_BYTES = 128
+
+
+class Comm:
+    """RCCL communicator of the result gather (fmsi_hip_comm_*): one per process / GPU."""
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = (C.c_uint8 * COMM_ID_BYTES)()
+        _check(lib().fmsi_hip_comm_unique_id(buf))
+        return bytes(buf)
+
+    def __init__(self, unique_id: bytes, world: int, rank: int, device: int = 0):
+        if len(unique_id) != COMM_ID_BYTES:
+            raise ValueError("unique id must be COMM_ID_BYTES long")
+        self.world, self.rank, self.device = world, rank, device
+        self._id = (C.c_uint8 * COMM_ID_BYTES).from_buffer_copy(unique_id)
+        h = C.c_void_p()
+        _check(lib().fmsi_hip_comm_create(self._id, world, rank, device, C.byref(h)))
+        self._h = h
+
+    def gather(self, send_ptr: int, recv_ptr: int, bytes_per_rank, root: int = 0, stream: int = 0) -> None:
+        """Device buffers: rank r's bytes_per_rank[r] bytes at send_ptr land at recv_ptr + sum(bytes_per_rank[:r]) on root."""
+        sizes = np.ascontiguousarray(bytes_per_rank, dtype=np.uint64)
+        if sizes.size != self.world:
+            raise ValueError("bytes_per_rank needs one entry per rank")
+        _check(lib().fmsi_hip_gather(self._h, send_ptr or None, int(sizes[self.rank]), recv_ptr or None, sizes.ctypes.data, root,
+                                     stream or None))
+
+    def close(self) -> None:
+        if self._h:
+            lib().fmsi_hip_comm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+

@@ -46,6 +46,34 @@ def gather_to_root(local, n_items: int, dst: int = 0, group=None):
     return torch.cat([p[:s] for p, s in zip(parts, sizes)])
 
 
+def comm_from_process_group(device_index: int, group=None):
+    """An fmsi_hip_comm over the ranks of a torch.distributed group: rank 0 draws the RCCL unique id and the group's
+    own channel carries its 128 bytes to the others (any launcher-side channel would do; include/fmsi_hip.h)."""
+    import torch.distributed as dist
+
+    import fmsi_amd as fm
+
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    box = [fm.Comm.unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0, group=group)
+    return fm.Comm(box[0], world, rank, device_index)
+
+
+def gather_to_root_abi(comm, local, n_items: int, dst: int = 0, stream: int = 0):
+    """gather_to_root() through the C-ABI (fmsi_hip_gather): `local` is this rank's 1-D device tensor of
+    shard_sizes(n_items)[rank] elements; returns the concatenation on `dst` (rank order = output order), None elsewhere.
+    No padding: every peer's bytes go straight to their place."""
+    import torch
+
+    sizes = shard_sizes(n_items, comm.world)
+    assert local.is_cuda and local.is_contiguous() and local.numel() == sizes[comm.rank], (local.numel(), sizes[comm.rank])
+    item = local.element_size()
+    out = torch.empty(n_items if comm.rank == dst else 0, dtype=local.dtype, device=local.device)
+    comm.gather(local.data_ptr() if local.numel() else 0, out.data_ptr() if out.numel() else 0, [s * item for s in sizes], root=dst,
+                stream=stream)
+    return out if comm.rank == dst else None
+
+
 def sharded_query(kmers: np.ndarray, compute: Callable[[np.ndarray], np.ndarray], device=None, dst: int = 0, group=None):
     """Every rank holds (or can produce) the same global k-mer array; rank r answers its contiguous range with
     `compute` and the byte results are gathered to `dst` in rank order.  Returns the full result array on

@@ -226,6 +226,25 @@ int fmsi_hip_profile_read(fmsi_hip_index* idx, uint64_t* n_launches, double* tot
 const char* fmsi_hip_last_error(void);
 int fmsi_hip_abi_version(void);
 
+/* ---- multi-GPU: the result gather -------------------------------------------- */
+/* One process per GPU; the index is replicated and each rank answers a contiguous, order-preserving range of the
+ * windows (the reference is single-threaded: src/main.cpp:328-373 is one loop; nothing replaces it but the order of
+ * its output).  There is no exchange inside the search; the one collective of the path brings the per-rank result
+ * buffers to the root over RCCL (xGMI), rank order = output order.
+ * fmsi_hip_comm_unique_id: called on ONE rank; the 128 bytes reach the others by the launcher's means (MPI, a file,
+ * torch.distributed's store).  fmsi_hip_comm_create: collective over all `world` ranks, each with its own device.
+ * RCCL is dlopen()ed on first use: FMSI_HIP_ECOMM when it is absent or reports an error. */
+typedef struct fmsi_hip_comm fmsi_hip_comm;
+#define FMSI_HIP_COMM_ID_BYTES 128
+int fmsi_hip_comm_unique_id(uint8_t* id /* FMSI_HIP_COMM_ID_BYTES */);
+int fmsi_hip_comm_create(const uint8_t* id, int world, int rank, int device, fmsi_hip_comm** out);
+void fmsi_hip_comm_destroy(fmsi_hip_comm* comm);
+/* Rank r's d_send[0, bytes_per_rank[r]) (DEVICE memory) lands at d_recv + sum(bytes_per_rank[0..r)) on `root`
+ * (d_recv: device memory of the root, ignored elsewhere).  bytes_per_rank: HOST array of `world` entries, the same on
+ * every rank; send_bytes must equal this rank's entry.  Asynchronous on `stream`; sizes may differ and may be 0. */
+int fmsi_hip_gather(fmsi_hip_comm* comm, const void* d_send, uint64_t send_bytes, void* d_recv, const uint64_t* bytes_per_rank,
+                    int root, void* stream);
+
 /* ---- host side: the loader half of load_index() (src/fms_index.h:502-526) --------------------- */
 /* Parses <prefix>.fmsi.{ac_gt,ac,gt,mask,misc} (+ .klcp iff use_klcp and the file exists), decodes the
  * rrr_vector<63> mask to plain bits.  Pure host code (no HIP). */

@@ -1,0 +1,68 @@
+"""GPU test of the result gather of the multi-GPU path (fmsi_hip_comm_*, fmsi_hip_gather).
+The GPU box has one device, so the communicator here has one rank (RCCL refuses two ranks on one GPU); the rank
+arithmetic of the gather is covered on CPU with gloo in tests/test_distributed.py, the N > 1 run by bench.py --abi-gather."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def fm(product_built):
+    if product_built.device_count() < 1:
+        pytest.fail("no HIP device visible")
+    return product_built
+
+
+def test_single_rank_gather_moves_the_results(fm):
+    import torch
+
+    comm = fm.Comm(fm.Comm.unique_id(), 1, 0, 0)
+    src = torch.arange(1_000_003, dtype=torch.int64, device="cuda").to(torch.uint8)
+    dst = torch.zeros_like(src)
+    comm.gather(src.data_ptr(), dst.data_ptr(), [src.numel()])
+    torch.cuda.synchronize()
+    assert torch.equal(src, dst)
+    # in place, and nothing to send
+    comm.gather(dst.data_ptr(), dst.data_ptr(), [dst.numel()])
+    comm.gather(0, 0, [0])
+    torch.cuda.synchronize()
+    assert torch.equal(src, dst)
+    with pytest.raises(RuntimeError, match="root"):
+        comm.gather(src.data_ptr(), dst.data_ptr(), [src.numel()], root=1)
+    with pytest.raises(RuntimeError, match="receive buffer"):
+        comm.gather(src.data_ptr(), 0, [src.numel()])
+    comm.close()
+
+
+def test_gather_of_sharded_query_results(fm, oracle_built, tmp_path):
+    """The sharded query driver with the C-ABI gather, on a one-rank process group: the answers of the product for the
+    whole batch arrive on the root in order."""
+    import torch
+    import torch.distributed as dist
+
+    import oracle_py
+    from conftest import mixed_kmers, synthetic_ms
+    from fmsi_amd import sharding
+
+    k = 31
+    ms = synthetic_ms(40_000, k, seed=5, mask="mixed")
+    dev = fm.DeviceIndex.build(ms.encode(), k, prefix_len=8).enable_pair_layout()
+    kmers = mixed_kmers(ms, k, 20_001, seed=9)
+    packed = fm.pack_kmers(kmers, k)
+    dist.init_process_group("gloo", init_method=f"file://{tmp_path}/pg", world_size=1, rank=0)
+    try:
+        comm = sharding.comm_from_process_group(0)
+        a, b = sharding.shard_range(len(kmers), comm.rank, comm.world)
+        d_in = torch.from_numpy(packed[a:b].view(np.int64)).cuda()
+        d_out = torch.empty(b - a, dtype=torch.uint8, device="cuda")
+        dev.query_kmers_dev(d_in.data_ptr(), b - a, k, fm.MODE_ALL, d_out.data_ptr())
+        got = sharding.gather_to_root_abi(comm, d_out, len(kmers))
+        torch.cuda.synchronize()
+        comm.close()
+    finally:
+        dist.destroy_process_group()
+    orc = oracle_py.Oracle.construct(ms, k)
+    fwd, rc = orc.ternaries_bulk("".join(kmers).encode(), len(kmers), k, True)
+    want = np.where(fwd != -1, fwd, rc) == 1
+    assert np.array_equal(got.cpu().numpy().astype(bool), want)

@@ -226,3 +226,22 @@ def test_cli_option_handling(product_built):
     assert rc == 0 and b"Usage:   fmsi export <index-prefix>" in err
     rc, out, err = run([])
     assert rc == 1
+
+
+def test_gather_argument_errors_without_a_gpu(product_built):
+    """fmsi_hip_gather / fmsi_hip_comm_create reject bad arguments before RCCL or a device is touched."""
+    import ctypes as C
+
+    fm = product_built
+    L = fm.lib()
+    h = C.c_void_p()
+    ident = (C.c_uint8 * fm.COMM_ID_BYTES)()
+    assert L.fmsi_hip_comm_create(ident, 0, 0, 0, C.byref(h)) == -1            # world < 1
+    assert L.fmsi_hip_comm_create(ident, 2, 2, 0, C.byref(h)) == -1            # rank outside the world
+    assert L.fmsi_hip_comm_create(None, 1, 0, 0, C.byref(h)) == -1
+    assert L.fmsi_hip_comm_unique_id(None) == -1
+    sizes = (C.c_uint64 * 1)(0)
+    assert L.fmsi_hip_gather(None, None, 0, None, sizes, 0, None) == -1
+    assert b"bad argument" in L.fmsi_hip_last_error()
+    L.fmsi_hip_comm_destroy(None)                                              # a no-op
+
