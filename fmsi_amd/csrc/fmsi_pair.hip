@@ -33,6 +33,7 @@
 #include <rocprim/device/device_scan.hpp>
 
 #include <algorithm>
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -394,6 +395,258 @@ __global__ __launch_bounds__(256) void pair_lookup_kernel(PairIndex ix, const ui
             uint32_t x = v[qq];
             for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
             if ((threadIdx.x & 63u) == 0 && x) {
+                atomicAdd(&counters[slot[qq]], static_cast<unsigned long long>(x));
+                if (qq == 0) atomicAdd(&counters[1], static_cast<unsigned long long>(x));   // [1] counts the table lines with the blocks
+            }
+        }
+    }
+}
+
+// ---- phase 1 with candidate tables: ONE LANE PER K-MER ----------------------------------------------------------------
+// With the 16-byte candidate entries a k-mer needs 16 bytes of the table, and a lane that issues ONE 16-byte load per
+// lookup costs the memory path one request and one translation per line whether or not a neighbour shares the line
+// (tools/gather_bench entry 69: 48 G lookups/s for 1, 2 or 4 lanes per entry -- the 17 G/s of one lane per line that
+// pair_lookup_kernel's comment quotes was a lane reading its line with FOUR loads).  So here a wave looks 64 k-mers up
+// per round instead of 32, which doubles the lines it keeps in flight, and everything that would make the whole wave
+// wait a second time inside a round -- the reverse complement's lookup (6 % of the k-mers: every round has one), the
+// third candidate's read -- is deferred: such k-mers go to a per-wave queue in LDS and are done 64 at a time in dense
+// "slow" rounds.  A fast round is: k-mers in (one coalesced 512-B read), one table load per lane, decide.
+//   fast round, per entry: double-stranded -> both strands settled; forward alive (needs steps) -> work item; forward
+//   absent and the reverse complement wanted -> queue (RC); anything else that needs more (third candidate, text read, a
+//   settled forward result that may have to be redone) -> queue (FULL: the slow round starts from the forward lookup).
+// The chunk's result bytes are collected in LDS and leave as 16 bytes per lane.
+// Same contract as pair_lookup_kernel (work items, list_count, result bytes of settled k-mers, counters).
+template <bool COUNT, bool RUNS>
+__global__ __launch_bounds__(256) void lookup_lane_kernel(PairIndex ix, const uint64_t* __restrict__ kmers, uint64_t n_windows, int k, uint32_t flags,
+                                                          uint32_t chunk, uint8_t* __restrict__ out, WorkItem* __restrict__ list,
+                                                          uint32_t* __restrict__ list_count, unsigned long long* __restrict__ counters,
+                                                          const uint64_t* __restrict__ run_start, const uint64_t* __restrict__ run_off, uint64_t n_runs) {
+    constexpr uint32_t kMaxChunk = 4096u, kQueue = 128u;
+    __shared__ uint64_t s_qf[4][kQueue];
+    __shared__ uint32_t s_qi[4][kQueue];
+    __shared__ __attribute__((aligned(16))) uint8_t s_res[4][kMaxChunk];
+    const uint32_t strict = flags & FMSI_HIP_STRICT;
+    const uint32_t mode_all = flags & FMSI_HIP_MODE_ALL;
+    const int T = static_cast<int>(ix.ptable_len);
+    const int t = k - 1 - T;
+    const uint32_t R = static_cast<uint32_t>(k - T);                       // bases left after the table
+    const uint64_t rmask = R >= 32u ? ~0ull : ((1ull << (2u * R)) - 1ull);
+    const uint32_t tmask = static_cast<uint32_t>((1ull << (2 * T)) - 1ull);
+    const uint32_t lane = threadIdx.x & 63u, wib = threadIdx.x >> 6;
+    uint64_t* qf = s_qf[wib];
+    uint32_t* qi = s_qi[wib];
+    uint8_t* res = s_res[wib];
+    uint32_t n_lookups = 0, n_final = 0, n_vreads = 0;
+    const uint64_t wave = (static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t start = wave * chunk;
+    const uint32_t len = start < n_windows ? static_cast<uint32_t>(min(static_cast<uint64_t>(chunk), n_windows - start)) : 0u;
+    uint32_t count = 0;            // wave-uniform: work items written so far
+    uint32_t qhead = 0, qtail = 0; // wave-uniform: the queue holds [qhead, qtail), positions mod kQueue
+    uint64_t run = 0, run_last = 0, run_end = 0, run_delta = 0;
+    auto find_run = [&](uint64_t lo, uint64_t hi, uint64_t q) -> uint64_t {   // run_off[lo] <= q < run_off[hi]
+        while (hi - lo > 1) {
+            const uint64_t mid = (lo + hi) >> 1;
+            if (run_off[mid] <= q) lo = mid;
+            else hi = mid;
+        }
+        return lo;
+    };
+    if (RUNS && len) {
+        run = find_run(0, n_runs, start);
+        run_last = find_run(run, n_runs, start + len - 1u);
+        run_end = run_off[run + 1];
+        run_delta = run_start[run] - run_off[run];
+    }
+    auto slots_result = [&](uint32_t lo, uint32_t hi, bool m0, bool m1, bool m2, uint32_t ey) -> int {
+        const bool a0 = m0 && lo == 0u && hi > 0u, a1 = m1 && lo <= 1u && hi > 1u, a2 = m2 && lo <= 2u && hi > 2u;
+        const uint32_t k0 = (ey >> 26) & 1u, k1 = (ey >> 27) & 1u, k2 = (ey >> 28) & 1u;
+        if (!(a0 || a1 || a2)) return -1;
+        if (mode_all) return static_cast<int>(a0 ? k0 : (a1 ? k1 : k2));
+        return static_cast<int>((a0 && k0) || (a1 && k1) || (a2 && k2));
+    };
+    // what a strand's table entry says.  0 = absent, 1 = alive (needs the stepping kernel), 2 = settled (res), 3 = the
+    // entry settled BOTH strands (res, res_other; only when want_both), 4 = needs a further read and `full` is false
+    auto eval = [&](uint64_t cur, uint32_t tidx, const uint4& v, bool want_both, bool full, uint32_t& i, uint32_t& j, int& r, int& r_other) -> uint32_t {
+        const uint32_t ex = v.x, ey = v.y, cand0 = v.z, cand1 = v.w;
+        r = -1;
+        r_other = -1;
+        i = j = 0;
+        if ((ey >> 30) == 2u) {   // double-stranded entry (see pair_lookup_kernel)
+            const uint32_t nf = (ey >> 24) & 3u, nr = (ey >> 22) & 3u, total = nf + nr;
+            const uint32_t want = static_cast<uint32_t>(cur & rmask);
+            const bool m0 = cand0 == want, m1 = cand1 == want, m2 = ex == want;
+            r = slots_result(0u, nf, m0, m1, m2, ey);
+            if (want_both) {
+                r_other = slots_result(nf, total, m0, m1, m2, ey);
+                return 3u;
+            }
+            return nf == 0u ? 0u : 2u;
+        }
+        decode_table_entry(ex, ey, 1u, t >= 3, t >= 3 ? static_cast<uint32_t>(cur >> (2 * (t - 3))) & 0xFFu : 0u, i, j);
+        if (i == j) return 0u;
+        if ((ey >> 30) != 1u) return 1u;
+        const uint32_t rows = (ey >> 24) & 3u;
+        if (!full && (rows > 2u || !ix.verify_bases)) return 4u;
+        const uint32_t pos0 = cand0, pos1 = cand1, pos2 = rows > 2u ? ix.stable[tidx] : 0u;
+        auto text_matches = [&](uint32_t pos) -> bool {
+            if (pos < R) return false;
+            const uint64_t p0 = static_cast<uint64_t>(pos - R), w = p0 >> 5;
+            const uint32_t sh = static_cast<uint32_t>(p0 & 31u) * 2u;
+            uint64_t tx = ix.text2[w] >> sh;
+            if (sh) tx |= ix.text2[w + 1] << (64u - sh);
+            return ((tx ^ cur) & rmask) == 0ull;
+        };
+        bool m0, m1, m2;
+        if (ix.verify_bases) {
+            const uint32_t want = static_cast<uint32_t>(cur & rmask);
+            m0 = pos0 == want;
+            m1 = rows > 1u && pos1 == want;
+            m2 = rows > 2u && pos2 == want;
+            if (rows > 2u) n_vreads += 1u;
+        } else {
+            m0 = text_matches(pos0);
+            m1 = rows > 1u && text_matches(pos1);
+            m2 = rows > 2u && text_matches(pos2);
+            n_vreads += rows + (rows > 2u ? 1u : 0u);
+        }
+        r = slots_result(0u, 3u, m0, m1, m2, ey);
+        return 2u;
+    };
+    auto encode = [&](int res_f, int res_r) -> uint8_t {
+        if (strict) return static_cast<uint8_t>(static_cast<uint32_t>(res_f + 1) | (static_cast<uint32_t>(res_r + 1) << 2));
+        return static_cast<uint8_t>(mode_all ? (res_f != -1 ? res_f : res_r) == 1 : (res_f == 1 || res_r == 1));
+    };
+    auto emit_items = [&](bool alive, uint64_t f, uint32_t x, uint32_t y, uint32_t ql) {
+        const uint64_t m = __ballot(alive);
+        if (m) {
+            if (alive) {
+                WorkItem w;
+                w.f = f;
+                w.x = x;
+                w.y = y;
+                w.ql = ql;
+                w.pad = 0;
+                list[start + count + lanes_below(m)] = w;
+            }
+            count += static_cast<uint32_t>(__popcll(m));
+        }
+    };
+    // a dense round over the first `items` queue entries
+    auto slow_round = [&](uint32_t items) {
+        const bool active = lane < items;
+        const uint32_t pos = (qhead + lane) & (kQueue - 1u);
+        const uint64_t f = active ? qf[pos] : 0ull;
+        const uint32_t info = active ? qi[pos] : 0u;
+        const uint32_t ql = info & 0xFFFFu;
+        const bool redo = (info >> 16) & 1u;
+        uint32_t i_f = 0, j_f = 0, i_r = 0, j_r = 0, sf = 0;
+        int res_f = -1, res_r = -1, unused = -1;
+        if (__any(active && redo)) {
+            const uint32_t tidx = static_cast<uint32_t>(f >> (2u * R)) & tmask;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (active && redo) {
+                v = ix.vtable[tidx];
+                n_lookups++;
+                sf = eval(f, tidx, v, false, true, i_f, j_f, res_f, unused);
+            }
+        }
+        const bool need_rc = active && sf != 1u && (strict || (mode_all ? res_f == -1 : res_f != 1));
+        uint32_t sr = 0;
+        if (__any(need_rc)) {
+            const uint64_t rc = revcomp_2bit(f, k);
+            const uint32_t tidx = static_cast<uint32_t>(rc >> (2u * R)) & tmask;
+            if (need_rc) {
+                const uint4 v = ix.vtable[tidx];
+                n_lookups++;
+                sr = eval(rc, tidx, v, false, true, i_r, j_r, res_r, unused);
+            }
+        }
+        const bool alive = active && (sf == 1u || sr == 1u);
+        if (active && !alive) {
+            n_final++;
+            res[ql] = encode(res_f, res_r);
+        }
+        // a settled forward 0 / 1 cannot ride along with a reverse complement that needs steps: the forward strand is redone
+        const bool fwd_item = sf == 1u || res_f != -1;
+        emit_items(alive, f, fwd_item ? i_f : j_r, fwd_item ? j_f : i_r, ql);
+        qhead += items;
+    };
+
+    for (uint32_t base = 0; base < len; base += 64u) {
+        const uint32_t ql = base + lane;
+        const bool valid = ql < len;
+        const uint64_t q = start + ql;
+        uint64_t f = 0ull;
+        if (RUNS) {
+            if (valid) {
+                if (q >= run_end) {
+                    run = find_run(run + 1, run_last + 1, q);
+                    run_end = run_off[run + 1];
+                    run_delta = run_start[run] - run_off[run];
+                }
+                f = window_kmer(kmers, q + run_delta, k);
+            }
+        } else if (valid) {
+            f = kmers[q];
+        }
+        const uint32_t tidx = static_cast<uint32_t>(f >> (2u * R)) & tmask;
+        uint32_t i_f = 0, j_f = 0, sf = 0;
+        int res_f = -1, res_r = -1;
+        bool fin = false, alive = false, slow = false, redo = false;
+        if (valid) {
+            const uint4 v = ix.vtable[tidx];
+            n_lookups++;
+            sf = eval(f, tidx, v, true, false, i_f, j_f, res_f, res_r);
+            if (sf == 3u) {
+                fin = true;
+            } else if (sf == 1u) {
+                alive = true;
+            } else if (sf == 4u) {
+                slow = redo = true;
+            } else if (strict || (mode_all ? res_f == -1 : res_f != 1)) {   // the reverse complement is wanted (src/fms_index.h:283-299)
+                slow = true;
+                redo = res_f != -1;   // (the slow round needs the forward interval then)
+            } else {
+                fin = true;
+            }
+        }
+        if (fin) {
+            n_final++;
+            res[ql] = encode(res_f, res_r);
+        }
+        emit_items(alive, f, i_f, j_f, ql);
+        const uint64_t m = __ballot(slow);
+        if (m) {
+            if (slow) {
+                const uint32_t pos = (qtail + lanes_below(m)) & (kQueue - 1u);
+                qf[pos] = f;
+                qi[pos] = ql | (redo ? 0x10000u : 0u);
+            }
+            qtail += static_cast<uint32_t>(__popcll(m));
+            while (qtail - qhead >= 64u) slow_round(64u);
+        }
+    }
+    if (qtail != qhead) slow_round(qtail - qhead);
+    if (lane == 0u && start < n_windows) list_count[wave] = count;
+    if (len) {   // the chunk's result bytes leave in 16-byte pieces; those of the work items are the stepping kernel's to overlay
+        uint8_t* dst = out + start;
+        const bool aligned = (reinterpret_cast<uintptr_t>(dst) & 15u) == 0;
+        for (uint32_t off = lane * 16u; off < len; off += 64u * 16u) {
+            if (aligned && off + 16u <= len) {
+                *reinterpret_cast<uint4*>(dst + off) = *reinterpret_cast<const uint4*>(res + off);
+            } else {
+                for (uint32_t b = off; b < min(len, off + 16u); ++b) dst[b] = res[b];
+            }
+        }
+    }
+    if (COUNT) {
+        uint32_t v[4] = {n_lookups, n_lookups, n_final, n_vreads};   // strand searches started = table lookups = lines read
+        const int slot[4] = {3, 4, 6, 7};
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) {
+            uint32_t x = v[qq];
+            for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+            if (lane == 0 && x) {
                 atomicAdd(&counters[slot[qq]], static_cast<unsigned long long>(x));
                 if (qq == 0) atomicAdd(&counters[1], static_cast<unsigned long long>(x));   // [1] counts the table lines with the blocks
             }
@@ -882,8 +1135,17 @@ int launch_phased_t(fmsi_hip_index* idx, const uint64_t* d_kmers, uint64_t n, in
         FMSI_HIP_TRY(hipStreamSynchronize(s));   // the caller's table may be a local
     }
     const PairIndex pix = make_pair_index(idx);
-    hipLaunchKernelGGL((pair_lookup_kernel<COUNT, RUNS>), dim3(blocks), dim3(256), 0, s, pix, d_kmers, n, k, flags, static_cast<uint32_t>(chunk), o8,
-                       o64, d_list, d_count, d_counters, d_runs, d_runs + n_runs, n_runs);
+    // candidate tables in play (the condition pair_lookup_kernel calls `verify`): one lane per k-mer
+    const int rest = k - static_cast<int>(pix.ptable_len);
+    static const bool force_pairs = std::getenv("FMSI_HIP_LOOKUP_PAIRS") != nullptr;   // A/B switch for measurements
+    const bool lane_lookup = pix.vtable && pix.ptable_packed && !(flags & FMSI_HIP_ORDERS) && k == pix.verify_k && rest >= 1 && rest <= 32 &&
+                             chunk <= 4096 && !force_pairs;
+    if (lane_lookup)
+        hipLaunchKernelGGL((lookup_lane_kernel<COUNT, RUNS>), dim3(blocks), dim3(256), 0, s, pix, d_kmers, n, k, flags, static_cast<uint32_t>(chunk), o8,
+                           d_list, d_count, d_counters, d_runs, d_runs + n_runs, n_runs);
+    else
+        hipLaunchKernelGGL((pair_lookup_kernel<COUNT, RUNS>), dim3(blocks), dim3(256), 0, s, pix, d_kmers, n, k, flags, static_cast<uint32_t>(chunk), o8,
+                           o64, d_list, d_count, d_counters, d_runs, d_runs + n_runs, n_runs);
     FMSI_HIP_TRY(hipGetLastError());
     const uint32_t n_super = static_cast<uint32_t>(((idx->n_blocks - 1) >> kSuperBlocksLog2) + 1);
     const size_t lds_bytes = (((16 + 16 * static_cast<size_t>(n_super) + 2) & ~size_t(1)) + 4 * 640 + static_cast<size_t>(chunk)) * 4;

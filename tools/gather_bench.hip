@@ -126,6 +126,23 @@ int main(int argc, char** argv) {
         run_coop<128, 1, 8>(buf, bytes, out); run_coop<128, 2, 8>(buf, bytes, out); run_coop<128, 4, 8>(buf, bytes, out); run_coop<128, 8, 8>(buf, bytes, out);
         return 0;
     }
+    if (argc > 2 && std::string(argv[1]) == "entry") {
+        // table lookups of the phased path: one 16-byte entry per key out of a table of `GB`; who loads what?
+        //   <16,*,1> one lane per entry (64 lines per instruction)        <64,*,2> lane pair, 32 B each = the whole 64-B line (2 instr)
+        //   <32,*,2> lane pair, 16 B each = the entry's 32-B half line      <64,*,4> lane quad, 16 B each = the whole line (1 instr)
+        const double gb = atof(argv[2]);
+        const uint64_t bytes = (uint64_t)(gb * 1e9) / 512 * 512;
+        uint4* buf; uint64_t* out;
+        if (hipMalloc(&buf, bytes + 4096) != hipSuccess) { printf("cannot allocate %.1f GB\n", gb); return 1; }
+        hipMalloc(&out, 8);
+        hipMemset(buf, 1, bytes + 4096);
+        run_coop<16, 1, 1>(buf, bytes, out); run_coop<16, 2, 1>(buf, bytes, out); run_coop<16, 4, 1>(buf, bytes, out);
+        run_coop<64, 1, 2>(buf, bytes, out); run_coop<64, 2, 2>(buf, bytes, out);
+        run_coop<32, 1, 2>(buf, bytes, out); run_coop<32, 2, 2>(buf, bytes, out); run_coop<32, 4, 2>(buf, bytes, out);
+        run_coop<64, 1, 4>(buf, bytes, out); run_coop<64, 2, 4>(buf, bytes, out); run_coop<64, 4, 4>(buf, bytes, out);
+        run_coop<128, 1, 8>(buf, bytes, out); run_coop<128, 2, 8>(buf, bytes, out);
+        return 0;
+    }
     if (argc > 2 && std::string(argv[1]) == "inflight") {   // resident waves per SIMD = grid / 256 (all workgroups resident)
         const double gb = atof(argv[2]);
         const uint64_t bytes = (uint64_t)(gb * 1e9) / 512 * 512;
