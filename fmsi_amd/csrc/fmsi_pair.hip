@@ -163,6 +163,8 @@ __global__ void pair_counts_kernel(const U16* __restrict__ scanned, uint64_t n_b
     }
 }
 
+constexpr uint32_t kFlagOverlay = 0x40000000u;   // kernel-internal flag bit (never part of the ABI's flags)
+
 struct alignas(8) WorkItem {   // a search the lookup kernel leaves to the stepping kernel
     uint64_t f;        // the k-mer (forward orientation)
     uint32_t x, y;     // (i, j): forward strand alive after the table; (j, i): the reverse complement is, the forward strand is absent
@@ -729,7 +731,10 @@ __global__ __launch_bounds__(256) void query_pair_kernel(PairIndex ix, const uin
     const uint32_t wib = threadIdx.x >> 6;          // wave in block
     constexpr uint32_t kRingWords = LIST ? 640u : 256u;   // per wave: 128 k-mers (+ LIST: their (i, j) and chunk-relative index)
     uint64_t* ring = reinterpret_cast<uint64_t*>(lds + tbl_words) + wib * (kRingWords / 2u);
-    const uint32_t out_bytes = LIST ? ((chunk + 127u) & ~127u) : 2048u;   // the chunk's result bytes live here
+    // the chunk's result bytes live here.  LIST: only when the launcher asks for it (overlay) -- with the candidate tables a few
+    // per cent of the chunk are left, and their own byte stores cost less than the occupancy the overlay's LDS takes
+    const bool overlay = LIST && (flags & kFlagOverlay);
+    const uint32_t out_bytes = LIST ? (overlay ? ((chunk + 127u) & ~127u) : 0u) : 2048u;
     uint8_t* obuf = reinterpret_cast<uint8_t*>(lds + tbl_words + 4u * kRingWords) + wib * out_bytes;
     uint32_t* ring_ql = reinterpret_cast<uint32_t*>(ring + 256);   // LIST only
     const uint32_t sub = lane & 1u;                 // my half
@@ -739,10 +744,10 @@ __global__ __launch_bounds__(256) void query_pair_kernel(PairIndex ix, const uin
     const uint64_t start = wave * chunk;                                               // my chunk: [start, start + len)
     const uint32_t len = start >= n_windows ? 0u
                          : (LIST ? list_count[wave] : static_cast<uint32_t>(min(static_cast<uint64_t>(chunk), n_windows - start)));
-    // LIST: the chunk's result bytes -- the lookup kernel wrote the settled ones -- are taken into LDS, overlaid with this
-    // wave's results and written back as whole lines (a chunk with nothing left to search is not touched)
+    // LIST with overlay: the chunk's result bytes -- the lookup kernel wrote the settled ones -- are taken into LDS, overlaid with
+    // this wave's results and written back as whole lines (a chunk with nothing left to search is not touched)
     const uint32_t clen = start < n_windows ? static_cast<uint32_t>(min(static_cast<uint64_t>(chunk), n_windows - start)) : 0u;
-    if (LIST && len && !orders) {
+    if (overlay && len && !orders) {
         const uint8_t* src = out + start;
         const bool aligned = (reinterpret_cast<uintptr_t>(src) & 15u) == 0;
         for (uint32_t off = lane * 16u; off < clen; off += 64u * 16u) {
@@ -806,7 +811,8 @@ __global__ __launch_bounds__(256) void query_pair_kernel(PairIndex ix, const uin
                 }
             } else {
                 const uint8_t byte = strict ? static_cast<uint8_t>((rf + 1) | ((rr + 1) << 2)) : static_cast<uint8_t>((was_second ? rr : rf) == 1);
-                obuf[q] = byte;
+                if (LIST && !overlay) out[start + q] = byte;
+                else obuf[q] = byte;
             }
         }
         st = PS_IDLE;
@@ -1063,7 +1069,7 @@ __global__ __launch_bounds__(256) void query_pair_kernel(PairIndex ix, const uin
             }
         }
     }
-    if (!orders && len) {   // the chunk's result bytes leave in 16-byte pieces (whole lines), not one request per k-mer
+    if ((!LIST || overlay) && !orders && len) {   // the chunk's result bytes leave in 16-byte pieces (whole lines), not one request per k-mer
         uint8_t* dst = out + start;
         const uint32_t olen = LIST ? clen : len;
         const bool aligned = (reinterpret_cast<uintptr_t>(dst) & 15u) == 0;
@@ -1138,7 +1144,9 @@ int launch_phased_t(fmsi_hip_index* idx, const uint64_t* d_kmers, uint64_t n, in
     // candidate tables in play (the condition pair_lookup_kernel calls `verify`): one lane per k-mer
     const int rest = k - static_cast<int>(pix.ptable_len);
     static const bool force_pairs = std::getenv("FMSI_HIP_LOOKUP_PAIRS") != nullptr;   // A/B switch for measurements
-    const bool lane_lookup = pix.vtable && pix.ptable_packed && !(flags & FMSI_HIP_ORDERS) && k == pix.verify_k && rest >= 1 && rest <= 32 &&
+    // (... whose words are the bases themselves, k - t <= 15: with text positions every candidate is a read of its own, which
+    // the one-lane kernel defers, and the lane pairs are the faster form -- measured at n = 4.7 M, t = 12: 26.3 vs 24.6 G k-mers/s)
+    const bool lane_lookup = pix.vtable && pix.ptable_packed && !(flags & FMSI_HIP_ORDERS) && k == pix.verify_k && rest >= 1 && rest <= 15 &&
                              chunk <= 4096 && !force_pairs;
     if (lane_lookup)
         hipLaunchKernelGGL((lookup_lane_kernel<COUNT, RUNS>), dim3(blocks), dim3(256), 0, s, pix, d_kmers, n, k, flags, static_cast<uint32_t>(chunk), o8,
@@ -1148,11 +1156,13 @@ int launch_phased_t(fmsi_hip_index* idx, const uint64_t* d_kmers, uint64_t n, in
                            o64, d_list, d_count, d_counters, d_runs, d_runs + n_runs, n_runs);
     FMSI_HIP_TRY(hipGetLastError());
     const uint32_t n_super = static_cast<uint32_t>(((idx->n_blocks - 1) >> kSuperBlocksLog2) + 1);
-    const size_t lds_bytes = (((16 + 16 * static_cast<size_t>(n_super) + 2) & ~size_t(1)) + 4 * 640 + static_cast<size_t>(chunk)) * 4;
+    // (the result overlay in LDS only when the stepping kernel has the bulk of the chunk to answer)
+    const bool overlay = !lane_lookup && !(flags & FMSI_HIP_ORDERS);
+    const size_t lds_bytes = (((16 + 16 * static_cast<size_t>(n_super) + 2) & ~size_t(1)) + 4 * 640 + (overlay ? static_cast<size_t>(chunk) : 0)) * 4;
     if (lds_bytes > 64 * 1024)   // 160 KB of LDS per CU on gfx950; more than 64 KB per workgroup has to be asked for
         FMSI_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&query_pair_kernel<COUNT, true, true>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_bytes)));
-    hipLaunchKernelGGL((query_pair_kernel<COUNT, true, true>), dim3(blocks), dim3(256), lds_bytes, s, pix, d_kmers, n, k, flags,
+    hipLaunchKernelGGL((query_pair_kernel<COUNT, true, true>), dim3(blocks), dim3(256), lds_bytes, s, pix, d_kmers, n, k, flags | (overlay ? kFlagOverlay : 0u),
                        static_cast<uint32_t>(chunk), n_super, o8, o64, d_counters, d_list, d_count);
     FMSI_HIP_TRY(hipGetLastError());
     return 0;
