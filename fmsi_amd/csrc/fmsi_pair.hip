@@ -60,6 +60,7 @@ struct PairIndex {
     const uint32_t* stable;   // ... candidate 2 per entry (intervals of three rows)
     const uint64_t* text2;    // ... and the 2-bit packed superstring
     int verify_k;             // the k the candidate tables were made for (the index's): a query with another k does not use them
+    uint32_t vwide;           // 1: vtable holds 32-byte entries (double-stranded entries of up to seven occurrences; lookup_lane_kernel<.., WIDE>)
     uint32_t verify_bases;    // 1: the words ARE the k - t bases in front of each row (k - t <= 15; bit 31 = no such k-mer);
                               // 0: the words are text positions and the bases are read from text2
     uint32_t ptable_len, ptable_packed;
@@ -207,7 +208,7 @@ __global__ __launch_bounds__(256) void pair_lookup_kernel(PairIndex ix, const ui
     const int t = k - 1 - T;
     const uint32_t R = static_cast<uint32_t>(k - T);                       // bases left after the table
     const uint64_t rmask = R >= 32u ? ~0ull : ((1ull << (2u * R)) - 1ull);
-    const bool verify = ix.vtable != nullptr && ix.ptable_packed && !orders && k == ix.verify_k && R >= 1u && R <= 32u;
+    const bool verify = ix.vtable != nullptr && !ix.vwide && ix.ptable_packed && !orders && k == ix.verify_k && R >= 1u && R <= 32u;
     const uint32_t tmask = static_cast<uint32_t>((1ull << (2 * T)) - 1ull);
     const uint32_t lane = threadIdx.x & 63u, sub = lane & 1u;
     const int pbase = static_cast<int>(lane & ~1u);
@@ -416,9 +417,15 @@ __global__ __launch_bounds__(256) void pair_lookup_kernel(PairIndex ix, const ui
 //   fast round, per entry: double-stranded -> both strands settled; forward alive (needs steps) -> work item; forward
 //   absent and the reverse complement wanted -> queue (RC); anything else that needs more (third candidate, text read, a
 //   settled forward result that may have to be redone) -> queue (FULL: the slow round starts from the forward lookup).
+// Only for candidate words that are the bases themselves (k - t <= 15; the launcher checks).
+// WIDE: 32-byte entries whose double-stranded form lists up to SEVEN occurrences (fmsi_hip_index_enable_verify makes them when
+// the HBM is there: 137 GB at t = 16) -- nearly every key of a random text is then settled by its one line.  A lane must not
+// fetch its 32 bytes with two loads of its own (tools/gather_bench: the memory path pays per instruction and distinct line,
+// 38 G/s instead of 48 G/s), so the two lanes of a pair fetch the even lane's entry together, then the odd lane's, 16 bytes
+// each, and swap the halves they hold for each other: two instructions of 32 lines per 64 k-mers.
 // The chunk's result bytes are collected in LDS and leave as 16 bytes per lane.
 // Same contract as pair_lookup_kernel (work items, list_count, result bytes of settled k-mers, counters).
-template <bool COUNT, bool RUNS>
+template <bool COUNT, bool RUNS, bool WIDE>
 __global__ __launch_bounds__(256) void lookup_lane_kernel(PairIndex ix, const uint64_t* __restrict__ kmers, uint64_t n_windows, int k, uint32_t flags,
                                                           uint32_t chunk, uint8_t* __restrict__ out, WorkItem* __restrict__ list,
                                                           uint32_t* __restrict__ list_count, unsigned long long* __restrict__ counters,
@@ -434,7 +441,8 @@ __global__ __launch_bounds__(256) void lookup_lane_kernel(PairIndex ix, const ui
     const uint32_t R = static_cast<uint32_t>(k - T);                       // bases left after the table
     const uint64_t rmask = R >= 32u ? ~0ull : ((1ull << (2u * R)) - 1ull);
     const uint32_t tmask = static_cast<uint32_t>((1ull << (2 * T)) - 1ull);
-    const uint32_t lane = threadIdx.x & 63u, wib = threadIdx.x >> 6;
+    const uint32_t lane = threadIdx.x & 63u, wib = threadIdx.x >> 6, sub = lane & 1u;
+    const int peven = static_cast<int>(lane & ~1u);
     uint64_t* qf = s_qf[wib];
     uint32_t* qi = s_qi[wib];
     uint8_t* res = s_res[wib];
@@ -459,27 +467,63 @@ __global__ __launch_bounds__(256) void lookup_lane_kernel(PairIndex ix, const ui
         run_end = run_off[run + 1];
         run_delta = run_start[run] - run_off[run];
     }
-    auto slots_result = [&](uint32_t lo, uint32_t hi, bool m0, bool m1, bool m2, uint32_t ey) -> int {
-        const bool a0 = m0 && lo == 0u && hi > 0u, a1 = m1 && lo <= 1u && hi > 1u, a2 = m2 && lo <= 2u && hi > 2u;
-        const uint32_t k0 = (ey >> 26) & 1u, k1 = (ey >> 27) & 1u, k2 = (ey >> 28) & 1u;
-        if (!(a0 || a1 || a2)) return -1;
-        if (mode_all) return static_cast<int>(a0 ? k0 : (a1 ? k1 : k2));
-        return static_cast<int>((a0 && k0) || (a1 && k1) || (a2 && k2));
+    // presence from the candidate slots [lo, hi): mm = slots equal to the query's remaining bases, kb = their mask bits.  The
+    // matching ones are the rows of the final interval in their order -- ALL takes the mask bit of the first, OR any mask bit
+    // (src/fms_index.h:126-144); none = the empty interval
+    auto pick = [&](uint32_t mm, uint32_t kb, uint32_t lo, uint32_t hi) -> int {
+        const uint32_t sel = mm & ((1u << hi) - 1u) & ~((1u << lo) - 1u);
+        if (!sel) return -1;
+        if (mode_all) return static_cast<int>((kb >> (__ffs(static_cast<int>(sel)) - 1)) & 1u);
+        return static_cast<int>((sel & kb) != 0u);
+    };
+    // the table entries of 64 k-mers: one 16-byte load per lane -- WIDE: two, shared with the neighbour (see above); every lane
+    // of the wave comes here, `go` says whose entry is wanted
+    auto load_entry = [&](uint32_t tidx, bool go, uint4& lo, uint4& hi) {
+        lo = hi = make_uint4(0, 0, 0, 0);
+        if (!WIDE) {
+            if (go) lo = ix.vtable[tidx];
+            return;
+        }
+        const uint32_t t_even = static_cast<uint32_t>(__shfl(static_cast<int>(tidx), peven, 64));
+        const uint32_t t_odd = static_cast<uint32_t>(__shfl(static_cast<int>(tidx), peven | 1, 64));
+        const bool g_even = __shfl(static_cast<int>(go), peven, 64) != 0, g_odd = __shfl(static_cast<int>(go), peven | 1, 64) != 0;
+        uint4 a = make_uint4(0, 0, 0, 0), b = a;
+        if (g_even) a = ix.vtable[2ull * t_even + sub];
+        if (g_odd) b = ix.vtable[2ull * t_odd + sub];
+        const uint4 give = sub ? a : b;   // the odd lane holds the even entry's second half, the even lane the odd entry's first
+        uint4 got;
+        got.x = static_cast<uint32_t>(__shfl_xor(static_cast<int>(give.x), 1, 64));
+        got.y = static_cast<uint32_t>(__shfl_xor(static_cast<int>(give.y), 1, 64));
+        got.z = static_cast<uint32_t>(__shfl_xor(static_cast<int>(give.z), 1, 64));
+        got.w = static_cast<uint32_t>(__shfl_xor(static_cast<int>(give.w), 1, 64));
+        lo = sub ? got : a;
+        hi = sub ? b : got;
     };
     // what a strand's table entry says.  0 = absent, 1 = alive (needs the stepping kernel), 2 = settled (res), 3 = the
     // entry settled BOTH strands (res, res_other; only when want_both), 4 = needs a further read and `full` is false
-    auto eval = [&](uint64_t cur, uint32_t tidx, const uint4& v, bool want_both, bool full, uint32_t& i, uint32_t& j, int& r, int& r_other) -> uint32_t {
+    auto eval = [&](uint64_t cur, uint32_t tidx, const uint4& v, const uint4& vh, bool want_both, bool full, uint32_t& i, uint32_t& j, int& r,
+                    int& r_other) -> uint32_t {
         const uint32_t ex = v.x, ey = v.y, cand0 = v.z, cand1 = v.w;
         r = -1;
         r_other = -1;
         i = j = 0;
         if ((ey >> 30) == 2u) {   // double-stranded entry (see pair_lookup_kernel)
-            const uint32_t nf = (ey >> 24) & 3u, nr = (ey >> 22) & 3u, total = nf + nr;
             const uint32_t want = static_cast<uint32_t>(cur & rmask);
-            const bool m0 = cand0 == want, m1 = cand1 == want, m2 = ex == want;
-            r = slots_result(0u, nf, m0, m1, m2, ey);
+            uint32_t mm = (cand0 == want ? 1u : 0u) | (cand1 == want ? 2u : 0u) | (ex == want ? 4u : 0u);
+            uint32_t nf, nr, kb;
+            if (WIDE) {   // (tag, nf in bits 0-2, nr in bits 3-5, the seven mask bits from bit 8)
+                nf = ey & 7u;
+                nr = (ey >> 3) & 7u;
+                kb = (ey >> 8) & 0x7Fu;
+                mm |= (vh.x == want ? 8u : 0u) | (vh.y == want ? 16u : 0u) | (vh.z == want ? 32u : 0u) | (vh.w == want ? 64u : 0u);
+            } else {
+                nf = (ey >> 24) & 3u;
+                nr = (ey >> 22) & 3u;
+                kb = (ey >> 26) & 7u;
+            }
+            r = pick(mm, kb, 0u, nf);
             if (want_both) {
-                r_other = slots_result(nf, total, m0, m1, m2, ey);
+                r_other = pick(mm, kb, nf, nf + nr);
                 return 3u;
             }
             return nf == 0u ? 0u : 2u;
@@ -488,30 +532,15 @@ __global__ __launch_bounds__(256) void lookup_lane_kernel(PairIndex ix, const ui
         if (i == j) return 0u;
         if ((ey >> 30) != 1u) return 1u;
         const uint32_t rows = (ey >> 24) & 3u;
-        if (!full && (rows > 2u || !ix.verify_bases)) return 4u;
-        const uint32_t pos0 = cand0, pos1 = cand1, pos2 = rows > 2u ? ix.stable[tidx] : 0u;
-        auto text_matches = [&](uint32_t pos) -> bool {
-            if (pos < R) return false;
-            const uint64_t p0 = static_cast<uint64_t>(pos - R), w = p0 >> 5;
-            const uint32_t sh = static_cast<uint32_t>(p0 & 31u) * 2u;
-            uint64_t tx = ix.text2[w] >> sh;
-            if (sh) tx |= ix.text2[w + 1] << (64u - sh);
-            return ((tx ^ cur) & rmask) == 0ull;
-        };
-        bool m0, m1, m2;
-        if (ix.verify_bases) {
-            const uint32_t want = static_cast<uint32_t>(cur & rmask);
-            m0 = pos0 == want;
-            m1 = rows > 1u && pos1 == want;
-            m2 = rows > 2u && pos2 == want;
-            if (rows > 2u) n_vreads += 1u;
-        } else {
-            m0 = text_matches(pos0);
-            m1 = rows > 1u && text_matches(pos1);
-            m2 = rows > 2u && text_matches(pos2);
-            n_vreads += rows + (rows > 2u ? 1u : 0u);
+        if (!full && rows > 2u) return 4u;
+        // (the launcher sends only k - t <= 15 here: the candidate words are the bases themselves)
+        const uint32_t want = static_cast<uint32_t>(cur & rmask);
+        uint32_t mm = (cand0 == want ? 1u : 0u) | (rows > 1u && cand1 == want ? 2u : 0u);
+        if (rows > 2u) {
+            mm |= ix.stable[tidx] == want ? 4u : 0u;
+            n_vreads += 1u;
         }
-        r = slots_result(0u, 3u, m0, m1, m2, ey);
+        r = pick(mm, (ey >> 26) & 7u, 0u, 3u);
         return 2u;
     };
     auto encode = [&](int res_f, int res_r) -> uint8_t {
@@ -545,11 +574,11 @@ __global__ __launch_bounds__(256) void lookup_lane_kernel(PairIndex ix, const ui
         int res_f = -1, res_r = -1, unused = -1;
         if (__any(active && redo)) {
             const uint32_t tidx = static_cast<uint32_t>(f >> (2u * R)) & tmask;
-            uint4 v = make_uint4(0, 0, 0, 0);
+            uint4 v, vh;
+            load_entry(tidx, active && redo, v, vh);
             if (active && redo) {
-                v = ix.vtable[tidx];
                 n_lookups++;
-                sf = eval(f, tidx, v, false, true, i_f, j_f, res_f, unused);
+                sf = eval(f, tidx, v, vh, false, true, i_f, j_f, res_f, unused);
             }
         }
         const bool need_rc = active && sf != 1u && (strict || (mode_all ? res_f == -1 : res_f != 1));
@@ -557,10 +586,11 @@ __global__ __launch_bounds__(256) void lookup_lane_kernel(PairIndex ix, const ui
         if (__any(need_rc)) {
             const uint64_t rc = revcomp_2bit(f, k);
             const uint32_t tidx = static_cast<uint32_t>(rc >> (2u * R)) & tmask;
+            uint4 v, vh;
+            load_entry(tidx, need_rc, v, vh);
             if (need_rc) {
-                const uint4 v = ix.vtable[tidx];
                 n_lookups++;
-                sr = eval(rc, tidx, v, false, true, i_r, j_r, res_r, unused);
+                sr = eval(rc, tidx, v, vh, false, true, i_r, j_r, res_r, unused);
             }
         }
         const bool alive = active && (sf == 1u || sr == 1u);
@@ -595,10 +625,11 @@ __global__ __launch_bounds__(256) void lookup_lane_kernel(PairIndex ix, const ui
         uint32_t i_f = 0, j_f = 0, sf = 0;
         int res_f = -1, res_r = -1;
         bool fin = false, alive = false, slow = false, redo = false;
+        uint4 v, vh;
+        load_entry(tidx, valid, v, vh);
         if (valid) {
-            const uint4 v = ix.vtable[tidx];
             n_lookups++;
-            sf = eval(f, tidx, v, true, false, i_f, j_f, res_f, res_r);
+            sf = eval(f, tidx, v, vh, true, false, i_f, j_f, res_f, res_r);
             if (sf == 3u) {
                 fin = true;
             } else if (sf == 1u) {
@@ -1105,6 +1136,7 @@ PairIndex make_pair_index(const fmsi_hip_index* idx) {
     p.ptable_packed = idx->dev.ptable_packed;
     p.vtable = static_cast<const uint4*>(idx->d_vtable);
     p.stable = static_cast<const uint32_t*>(idx->d_stable);
+    p.vwide = idx->vwide ? 1u : 0u;
     p.verify_k = idx->k;
     p.verify_bases = (idx->k - idx->prefix_len) <= 15 ? 1u : 0u;
     p.text2 = static_cast<const uint64_t*>(idx->d_text2);
@@ -1147,9 +1179,12 @@ int launch_phased_t(fmsi_hip_index* idx, const uint64_t* d_kmers, uint64_t n, in
     // (... whose words are the bases themselves, k - t <= 15: with text positions every candidate is a read of its own, which
     // the one-lane kernel defers, and the lane pairs are the faster form -- measured at n = 4.7 M, t = 12: 26.3 vs 24.6 G k-mers/s)
     const bool lane_lookup = pix.vtable && pix.ptable_packed && !(flags & FMSI_HIP_ORDERS) && k == pix.verify_k && rest >= 1 && rest <= 15 &&
-                             chunk <= 4096 && !force_pairs;
-    if (lane_lookup)
-        hipLaunchKernelGGL((lookup_lane_kernel<COUNT, RUNS>), dim3(blocks), dim3(256), 0, s, pix, d_kmers, n, k, flags, static_cast<uint32_t>(chunk), o8,
+                             chunk <= 4096 && (!force_pairs || pix.vwide);
+    if (lane_lookup && pix.vwide)
+        hipLaunchKernelGGL((lookup_lane_kernel<COUNT, RUNS, true>), dim3(blocks), dim3(256), 0, s, pix, d_kmers, n, k, flags, static_cast<uint32_t>(chunk), o8,
+                           d_list, d_count, d_counters, d_runs, d_runs + n_runs, n_runs);
+    else if (lane_lookup)
+        hipLaunchKernelGGL((lookup_lane_kernel<COUNT, RUNS, false>), dim3(blocks), dim3(256), 0, s, pix, d_kmers, n, k, flags, static_cast<uint32_t>(chunk), o8,
                            d_list, d_count, d_counters, d_runs, d_runs + n_runs, n_runs);
     else
         hipLaunchKernelGGL((pair_lookup_kernel<COUNT, RUNS>), dim3(blocks), dim3(256), 0, s, pix, d_kmers, n, k, flags, static_cast<uint32_t>(chunk), o8,
@@ -1321,7 +1356,8 @@ __global__ __launch_bounds__(256) void chars_to_text2_kernel(const char* __restr
 //   * otherwise a copy of the 8-byte entry, with the forward candidates and mask bits when it has 1..3 rows.
 __global__ __launch_bounds__(256) void verify_fill_kernel(const uint2* __restrict__ tab, uint64_t count, const uint32_t* __restrict__ sa,
                                                           const char* __restrict__ chars, uint64_t text_len, uint32_t T, uint32_t R,
-                                                          uint32_t bases_mode, uint4* __restrict__ vtable, uint32_t* __restrict__ stable) {
+                                                          uint32_t bases_mode, uint32_t wide, uint4* __restrict__ vtable, uint32_t* __restrict__ stable) {
+    const uint32_t max_total = wide ? 7u : 3u;   // occurrences a double-stranded entry can list
     const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
     auto code_of = [](char c) -> uint32_t {
         const uint32_t ch = static_cast<uint8_t>(c) | 0x20u;
@@ -1330,21 +1366,23 @@ __global__ __launch_bounds__(256) void verify_fill_kernel(const uint2* __restric
     auto rows_of = [](uint2 e) -> uint32_t { return (e.y >> 30) == 1u ? ((e.y >> 24) & 3u) : e.y; };   // 8-byte format: tag 0 = length
     for (uint64_t idx = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; idx < count; idx += stride) {
         uint2 e = tab[idx];
-        uint32_t cand[3] = {0, 0, 0};
+        uint32_t cand[7] = {0, 0, 0, 0, 0, 0, 0};
         const uint32_t nf = rows_of(e);
         bool done = false;
-        if (bases_mode && nf <= 3u) {
+        if (bases_mode && nf <= max_total) {
             const uint2 er = tab[revcomp_2bit(idx, static_cast<int>(T))];
             const uint32_t nr = rows_of(er);
-            if (nf + nr <= 3u) {
-                uint32_t y = (2u << 30) | (nf << 24) | (nr << 22), slot = 0;
+            if (nf + nr <= max_total) {
+                // narrow: nf in bits 24-25, nr in bits 22-23, mask bits from bit 26; wide: nf bits 0-2, nr bits 3-5, mask bits from bit 8
+                const uint32_t mbit = wide ? 8u : 26u;
+                uint32_t y = (2u << 30) | (wide ? (nf | (nr << 3)) : ((nf << 24) | (nr << 22))), slot = 0;
                 for (uint32_t m = 0; m < nf; ++m, ++slot) {            // this strand: the R bases in front of the occurrence
                     const uint32_t pos = sa[e.x + m];
                     uint32_t v = 0x80000000u;                          // no k-mer ends here (the text starts too late)
                     if (pos >= R) {
                         v = 0;
                         for (uint32_t b = 0; b < R; ++b) v |= code_of(chars[pos - R + b]) << (2u * b);
-                        if (chars[pos - R] >= 'A' && chars[pos - R] <= 'Z') y |= 1u << (26u + slot);   // is_upper = mask 1, src/kmers.h:71-73
+                        if (chars[pos - R] >= 'A' && chars[pos - R] <= 'Z') y |= 1u << (mbit + slot);   // is_upper = mask 1, src/kmers.h:71-73
                     }
                     cand[slot] = v;
                 }
@@ -1355,7 +1393,7 @@ __global__ __launch_bounds__(256) void verify_fill_kernel(const uint2* __restric
                         uint64_t w = 0;
                         for (uint32_t b = 0; b < R; ++b) w |= static_cast<uint64_t>(code_of(chars[p + T + b])) << (2u * b);
                         v = static_cast<uint32_t>(revcomp_2bit(w, static_cast<int>(R)));
-                        if (chars[p] >= 'A' && chars[p] <= 'Z') y |= 1u << (26u + slot);               // the k-mer rc(query) starts at p
+                        if (chars[p] >= 'A' && chars[p] <= 'Z') y |= 1u << (mbit + slot);               // the k-mer rc(query) starts at p
                     }
                     cand[slot] = v;
                 }
@@ -1382,7 +1420,12 @@ __global__ __launch_bounds__(256) void verify_fill_kernel(const uint2* __restric
             }
             e.y = y;   // (the 8-byte table stays as it is: the mask bits live in the lookup kernel's copy)
         }
-        vtable[idx] = make_uint4(e.x, e.y, cand[0], cand[1]);
+        if (wide) {
+            vtable[2 * idx] = make_uint4(e.x, e.y, cand[0], cand[1]);
+            vtable[2 * idx + 1] = make_uint4(cand[3], cand[4], cand[5], cand[6]);
+        } else {
+            vtable[idx] = make_uint4(e.x, e.y, cand[0], cand[1]);
+        }
         stable[idx] = cand[2];
     }
 }
@@ -1411,8 +1454,18 @@ extern "C" int fmsi_hip_index_enable_verify(fmsi_hip_index* idx) {
         if (msg) set_last_error(msg);
         return code;
     };
+    // 32-byte entries (double-stranded entries of up to seven occurrences, lookup_lane_kernel<.., WIDE>) when the candidate words
+    // are bases and the device has the room -- tables, the walk's temporaries and 16 GB to spare for the caller's batches
+    bool wide = R <= 15 && !std::getenv("FMSI_HIP_NARROW_CANDIDATES") && !std::getenv("FMSI_HIP_LOOKUP_PAIRS");
+    if (wide) {
+        size_t free_b = 0, total_b = 0;
+        const uint64_t need = count * 36 + (len + 1) + n * 4 + ((len >> 5) + 2) * 8 + (16ull << 30);
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < need) wide = false;
+    }
+    const uint64_t entry_bytes = wide ? 32 : 16;
     if (hipMalloc(reinterpret_cast<void**>(&d_chars), len + 1) != hipSuccess || hipMalloc(reinterpret_cast<void**>(&d_sa), n * 4) != hipSuccess ||
-        hipMalloc(reinterpret_cast<void**>(&d_stable), count * 4) != hipSuccess || hipMalloc(reinterpret_cast<void**>(&d_vtable), count * 16 + 64) != hipSuccess)
+        hipMalloc(reinterpret_cast<void**>(&d_stable), count * 4) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void**>(&d_vtable), count * entry_bytes + 64) != hipSuccess)
         return fail(FMSI_HIP_ENOMEM, "hipMalloc failed for the text verification tables");
     int rc = export_walk(idx, d_chars, d_sa);
     if (rc) return fail(rc, nullptr);
@@ -1423,7 +1476,7 @@ extern "C" int fmsi_hip_index_enable_verify(fmsi_hip_index* idx) {
     }
     const uint32_t blocks = static_cast<uint32_t>(std::min<uint64_t>((count + 255) / 256, 1u << 20));
     hipLaunchKernelGGL(verify_fill_kernel, dim3(blocks), dim3(256), 0, 0, static_cast<const uint2*>(idx->d_ptable), count, d_sa, d_chars, len,
-                       static_cast<uint32_t>(T), static_cast<uint32_t>(R), R <= 15 ? 1u : 0u, d_vtable, d_stable);
+                       static_cast<uint32_t>(T), static_cast<uint32_t>(R), R <= 15 ? 1u : 0u, wide ? 1u : 0u, d_vtable, d_stable);
     if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess) return fail(FMSI_HIP_EHIP, "text verification: device work failed");
     (void)hipFree(d_chars);
     (void)hipFree(d_sa);
@@ -1434,6 +1487,7 @@ extern "C" int fmsi_hip_index_enable_verify(fmsi_hip_index* idx) {
     }
     idx->d_stable = d_stable;
     idx->d_vtable = d_vtable;
-    idx->device_bytes += count * 20 + 64;
+    idx->vwide = wide;
+    idx->device_bytes += count * (entry_bytes + 4) + 64;
     return 0;
 }

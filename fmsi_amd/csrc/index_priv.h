@@ -58,6 +58,7 @@ struct fmsi_hip_index {
     void* d_text2 = nullptr;     // 2-bit packed superstring (kept by the on-device builder, or rebuilt by fmsi_hip_index_enable_verify)
     void* d_vtable = nullptr;    // text verification: the lookup kernel's 16-byte copy of the table entries with candidates 0 and 1
     void* d_stable = nullptr;    // ... and candidate 2 per entry
+    bool vwide = false;          // d_vtable holds 32-byte entries (up to seven candidates in a double-stranded entry)
     uint64_t text_len = 0;
     // staging for host-pointer calls
     void* d_in = nullptr; size_t d_in_cap = 0;

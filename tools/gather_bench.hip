@@ -141,6 +141,9 @@ int main(int argc, char** argv) {
         run_coop<32, 1, 2>(buf, bytes, out); run_coop<32, 2, 2>(buf, bytes, out); run_coop<32, 4, 2>(buf, bytes, out);
         run_coop<64, 1, 4>(buf, bytes, out); run_coop<64, 2, 4>(buf, bytes, out); run_coop<64, 4, 4>(buf, bytes, out);
         run_coop<128, 1, 8>(buf, bytes, out); run_coop<128, 2, 8>(buf, bytes, out);
+        // one lane reading a 32-byte (64-byte) entry with two (four) loads of its own
+        run_coop<32, 1, 1>(buf, bytes, out); run_coop<32, 2, 1>(buf, bytes, out);
+        run_coop<64, 1, 1>(buf, bytes, out); run_coop<64, 2, 1>(buf, bytes, out);
         return 0;
     }
     if (argc > 2 && std::string(argv[1]) == "inflight") {   // resident waves per SIMD = grid / 256 (all workgroups resident)
