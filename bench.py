@@ -22,7 +22,10 @@ Extra objects on the JSON line:
                   when streaming, + query bytes in + 1 B result out per window; the duration comes from HIP events
                   recorded on the launch stream inside the library, around the launch's kernels (the default `phased`
                   form is two: lookup + stepping).  `random_requests_per_s` is the figure the path is really bound by
-                  (DESIGN.md 3, 5): dependent random requests, not bytes.
+                  (DESIGN.md 3, 5): random requests, not bytes -- `request_roofline` prices it against the chip's measured
+                  ceiling of 48 G random line requests/s (tools/gather_bench entry, profiles/r01k_gather_entry.txt).  A table
+                  line counts 64 B (the smallest HBM access) although the entry used is 16 or 32 bytes: `useful_*` counts
+                  the entry's bytes instead.
                   `canonical_achieved` applies SURVEY 8(d)'s reference-layout formula (256 B per LF step the REFERENCE
                   algorithm executes for the same queries + 64 B per mask probe + in/out) to the same time; it can
                   exceed the HBM peak because the fused layout and the prefix table touch far fewer bytes.
@@ -87,7 +90,7 @@ def pmc_traffic(args, n, batch, k):
             continue
         c = t.get("config", {})
         if (c.get("workload", "kmers"), c.get("n"), c.get("batch"), c.get("k"), c.get("prefix_len"), c.get("mode")) == \
-                (args.workload, n, batch, k, args.prefix_len, args.mode) and \
+                (args.workload, n, batch, k, args.prefix_len, args.mode) and c.get("subst_ppm", 0) == args.subst_ppm and \
                 ("stream" if (args.workload == "stream" and args.stream_via == "klcp") else
                  ("pair" if (args.kernel == "phased" or args.workload == "stream") else args.kernel)) in t.get("kernel", "") and \
                 c.get("stream_via", "klcp") == (args.stream_via if args.workload == "stream" else "klcp"):
@@ -256,16 +259,23 @@ def main():
             # blocks_read already contains the prefix-table lines (one 64-B line per lookup); the pair layout reads 128-B blocks
             pair_blocks = (args.kernel in ("pair", "phased") and not stream_mode) or (stream_mode and args.stream_via == "runs")
             block_b = 128 if pair_blocks else 64
-            bytes_launch = block_b * (blocks_read - lookups) + 64 * lookups + 8 * klcp_words + in_bytes + 1 * batch
+            # a table lookup is one 64-byte HBM access whatever the entry's size (8, 16 or 32 bytes): the memory delivers
+            # nothing smaller (PMC, profiles/r01k_traffic_kmers.json: 60 B fetched per lookup of a 32-byte entry), so the line is
+            # what is counted; useful_* below counts the entry's own bytes instead
+            entry_b = int(index.info.candidate_entry_bytes)
+            lane_lookups = (not stream_mode or args.stream_via == "runs") and args.kernel == "phased" and entry_b and k - int(index.info.prefix_len) <= 15
+            lookup_b = 64
+            entry_used_b = entry_b if lane_lookups else 64
+            bytes_launch = block_b * (blocks_read - lookups) + lookup_b * lookups + 8 * klcp_words + in_bytes + 1 * batch
             bytes_launch += 32 * verify_reads   # counted as two 32-byte sectors per verification
             # (phased form: the work items of the searches left to the stepping kernel -- 48 bytes for about 3 % of the k-mers -- are not counted)
             canon_bytes = 256 * int(canonical[0]) + 64 * int(canonical[2]) + 8 * int(canonical[5]) + in_bytes + batch // 8
             ach = bytes_launch / avg_kernel_s / 1e9
             roof = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(args, n, batch, k),
-                    "kernel": ("pair_lookup_kernel<RUNS> + query_pair_kernel" if stream_mode and args.stream_via == "runs" else
-                               "query_stream_kernel" if stream_mode else
-                               "pair_lookup_kernel + query_pair_kernel" if args.kernel == "phased" else f"query_{args.kernel}_kernel"),
+                    "kernel": ("query_stream_kernel" if stream_mode and args.stream_via == "klcp" else
+                               ("lookup_lane_kernel" if lane_lookups else "pair_lookup_kernel") + " + query_pair_kernel"
+                               if args.kernel == "phased" or stream_mode else f"query_{args.kernel}_kernel"),
                     "avg_kernel_ms": round(avg_kernel_s * 1e3, 4), "launches": launches,
                     "algorithmic_bytes_per_launch": int(bytes_launch),
                     "bytes_per_kmer": round(bytes_launch / batch, 1),
@@ -273,6 +283,16 @@ def main():
                     "blocks_per_kmer": round(blocks_read / batch, 3), "table_lookups_per_kmer": round(lookups / batch, 3),
                     "klcp_words_per_kmer": round(klcp_words / batch, 3), "verify_reads_per_kmer": round(verify_reads / batch, 3),
                     "random_requests_per_s": round((blocks_read + klcp_words + verify_reads) / avg_kernel_s / 1e9, 2),
+                    # the ceiling this path runs against: random line requests per second, measured with
+                    # tools/gather_bench on the same footprint (profiles/r01k_gather_entry.txt: 48 G/s for 16..64-byte reads on 69-137 GB)
+                    # (an index that fits the caches -- E. coli scale -- is not bound by it: null)
+                    "request_roofline": None if int(index.info.device_bytes) < (2 << 30) else
+                                        {"achieved": round((blocks_read + klcp_words + verify_reads) / avg_kernel_s / 1e9, 2), "peak": 48.0,
+                                         "unit": "G random requests/s",
+                                         "frac": round((blocks_read + klcp_words + verify_reads) / avg_kernel_s / 1e9 / 48.0, 4)},
+                    "table_entry_bytes": entry_used_b,
+                    "useful_bytes_per_kmer": round((bytes_launch - (lookup_b - entry_used_b) * lookups) / batch, 1),
+                    "useful_frac": round((bytes_launch - (lookup_b - entry_used_b) * lookups) / avg_kernel_s / 1e9 / HBM_PEAK_GBS, 4),
                     "canonical_lf_steps_per_kmer": round(int(canonical[0]) / batch, 3),
                     "canonical_achieved": round(canon_bytes / avg_kernel_s / 1e9, 1),
                     "canonical_frac": round(canon_bytes / avg_kernel_s / 1e9 / HBM_PEAK_GBS, 4)}
@@ -291,6 +311,7 @@ def main():
             "config": {"workload": wl, "index_rows": int(info.n), "k": k, "queries_per_step_per_gpu": batch, "mode": args.mode,
                        "kernel": ("phased-runs" if args.stream_via == "runs" else "stream") if stream_mode else args.kernel,
                        "prefix_table_len": int(info.prefix_len), "index_bytes_hbm": int(info.device_bytes),
+                       "candidate_entry_bytes": int(info.candidate_entry_bytes),
                        "block_bytes": 128 if (args.kernel in ("pair", "phased") and not stream_mode) or (stream_mode and args.stream_via == "runs") else 64,
                        "parallelism": f"query-sharded x{world}, index replicated", "positive_fraction": round(positives, 4),
                        "index_build_seconds": round(build_s, 2)},

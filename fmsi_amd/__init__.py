@@ -60,6 +60,7 @@ class IndexInfo(C.Structure):
         ("n", C.c_uint64), ("k", C.c_int32), ("has_klcp", C.c_int32), ("device", C.c_int32),
         ("prefix_len", C.c_int32), ("block_bytes", C.c_uint64), ("block_symbols", C.c_uint64),
         ("n_blocks", C.c_uint64), ("device_bytes", C.c_uint64), ("counts", C.c_uint64 * 4), ("dollar_position", C.c_uint64),
+        ("candidate_entry_bytes", C.c_uint64),
     ]
 
 

@@ -741,6 +741,7 @@ int fmsi_hip_index_get_info(const fmsi_hip_index* idx, fmsi_hip_index_info* info
     info->counts[2] = idx->dev.C2;
     info->counts[3] = idx->dev.C3;
     info->dollar_position = idx->dev.dollar;
+    info->candidate_entry_bytes = idx->d_vtable ? (idx->vwide ? 32u : 16u) : 0u;
     return 0;
 }
 

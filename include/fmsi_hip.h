@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define FMSI_HIP_ABI_VERSION 1
+#define FMSI_HIP_ABI_VERSION 2   /* 2: fmsi_hip_index_info.candidate_entry_bytes, fmsi_hip_comm_*, fmsi_hip_gather */
 
 /* error codes */
 #define FMSI_HIP_OK 0
@@ -106,6 +106,7 @@ typedef struct {
     uint64_t device_bytes;      /* total HBM footprint of the handle */
     uint64_t counts[4];         /* C array of the index ({1, #A+1, #A+#C+1, #A+#C+#G+1}, src/fms_index.h:451) */
     uint64_t dollar_position;
+    uint64_t candidate_entry_bytes; /* 0 = no candidate tables (fmsi_hip_index_enable_verify), else 16 or 32 bytes per table entry */
 } fmsi_hip_index_info;
 
 /* counters written by query calls when `counters` != NULL (8 x u64, accumulated, caller zeroes):

@@ -328,6 +328,61 @@ def test_text_verification_on_repeats_and_text_start(fm, oracle_built, t, k):
     assert np.array_equal(got[:, 0], of) and np.array_equal(got[:, 1], orr)
 
 
+@pytest.mark.parametrize("narrow", [False, True])
+@pytest.mark.parametrize("t,k", [(4, 11), (6, 21), (8, 23)])
+def test_candidate_entries_of_up_to_seven_occurrences(fm, oracle_built, t, k, narrow, monkeypatch):
+    """The lookup kernel's one-lane form (k - t <= 15) on keys that occur 1..9 times over both strands with mixed mask
+    bits: the 32-byte entries list up to seven occurrences (forward copies, then reverse-complement copies), the
+    16-byte ones (FMSI_HIP_NARROW_CANDIDATES) three, and what exceeds them goes to the stepping kernel.  Every mode
+    against the oracle strand by strand, isolated k-mers and runs."""
+    if narrow:
+        monkeypatch.setenv("FMSI_HIP_NARROW_CANDIDATES", "1")
+    rng = random.Random(1000 * t + k + (7 if narrow else 0))
+    rnd = lambda a, b: "".join(rng.choice("ACGTacgt") for _ in range(rng.randrange(a, b)))
+    ms = rnd(30, 50)
+    cores = []
+    for m_f, m_r in [(4, 0), (2, 3), (7, 0), (3, 4), (5, 4), (0, 5), (1, 1), (6, 1), (8, 0)]:
+        core = "".join(rng.choice("ACGT") for _ in range(k + 5))
+        cores.append(core)
+        copies = [core] * m_f + [revcomp(core)] * m_r
+        rng.shuffle(copies)
+        for c in copies:   # each copy with its own case pattern (mask bits) and neighbours
+            ms += "".join(ch.upper() if rng.random() < 0.5 else ch.lower() for ch in c) + rnd(3, 25)
+    ms += rnd(300, 400)
+    ms = ms[:len(ms) - (k - 1)] + ms[len(ms) - (k - 1):].lower()
+    orc = oracle_py.Oracle.construct(ms, k, use_klcp=False)
+    dev = fm.DeviceIndex.build(ms.encode(), k, prefix_len=t).enable_pair_layout().enable_verify()
+    assert int(dev.info.candidate_entry_bytes) == (16 if narrow else 32)
+    up = ms.upper()
+    kmers = [up[p:p + k] for p in range(len(up) - k + 1)]
+    kmers += [revcomp(x) for x in kmers]
+    kmers += ["".join(rng.choice("ACGT") for _ in range(k)) for _ in range(400)]
+    kmers += [x[:-1] + rng.choice("ACGT") for x in kmers[:400]] + [rng.choice("ACGT") + x[1:] for x in kmers[:400]]
+    raw = "".join(kmers).encode()
+    packed = fm.pack_kmers(kmers, k)
+    for mode_all in (False, True):
+        flag = fm.MODE_ALL if mode_all else fm.MODE_OR
+        fwd, rc = orc.ternaries_bulk(raw, len(kmers), k, mode_all)
+        gf, gr = fm.decode_strict(dev.query_kmers(packed, k, flag | fm.STRICT | fm.KERNEL_PHASED))
+        assert np.array_equal(gf, fwd), np.nonzero(gf != fwd)[0][:10]
+        assert np.array_equal(gr, rc), np.nonzero(gr != rc)[0][:10]
+        fast = dev.query_kmers(packed, k, flag | fm.KERNEL_PHASED)
+        assert np.array_equal(fast.astype(bool), expected_fast(fwd, rc, mode_all))
+    assert (fwd == 0).any() and (fwd == 1).any() and (rc == 0).any() and (rc == 1).any()
+    # the same windows as runs of the superstring itself and of its reverse complement
+    seq = up + revcomp(up)
+    starts = np.array([0, len(up)], dtype=np.uint64)
+    wins = np.array([len(up) - k + 1] * 2, dtype=np.uint32)
+    wk = [seq[s:s + k] for s0 in (0, len(up)) for s in range(s0, s0 + len(up) - k + 1)]
+    fwd, rc = orc.ternaries_bulk("".join(wk).encode(), len(wk), k, True)
+    gf, gr = fm.decode_strict(dev.query_runs(fm.pack_sequence(seq.encode()), len(seq), starts, wins, k, fm.MODE_ALL | fm.STRICT))
+    assert np.array_equal(gf, fwd) and np.array_equal(gr, rc)
+    # the candidates settle what would otherwise take steps; with seven slots more than with three
+    _, cn = dev.query_kmers(packed, k, fm.MODE_ALL | fm.STRICT, counters=True)
+    _, cn_steps = dev.query_kmers(packed, k, fm.MODE_ALL | fm.STRICT | fm.KERNEL_PAIR, counters=True)
+    assert int(cn[6]) == len(kmers) and int(cn[0]) < int(cn_steps[0])
+
+
 def test_full_scale_cross_kernel_agreement(fm):
     """BASELINE.json's full size (human-genome scale, n = 2.8 G rows) with the production configuration (t = 16 signature
     table, pair layout, text verification): no CPU checker finishes here, so the size-independent property is that four

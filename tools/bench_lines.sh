@@ -1,0 +1,19 @@
+#!/bin/bash
+# The round's bench lines beyond the default one (run through gpurun from the repo root): tools/bench_lines.sh r01k
+TAG=${1:-rXX}
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+O=$R/gpurun_out/lines_$TAG.jsonl
+: > "$O"
+run() { timeout 400 python3 "$R/bench.py" "$@" 2>> "$R/gpurun_out/lines_$TAG.err" < /dev/null | python3 -c "
+import json,sys
+for l in sys.stdin:
+    if l.startswith('{'):
+        d=json.loads(l); d['_command']='python bench.py $*'; print(json.dumps(d))" >> "$O"; }
+run --steps 10 --abi-gather
+run --workload stream --steps 10
+run --workload stream --stream-via runs --steps 10
+run --workload stream --subst-ppm 10000 --steps 10
+run --workload stream --stream-via runs --subst-ppm 10000 --steps 10
+run --n 4.7e6 --steps 10
+run --n 1.4e9 --steps 10
+wc -l "$O"

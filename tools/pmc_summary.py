@@ -25,7 +25,7 @@ def main(out_dir: str) -> None:
             with open(f, newline="") as fh:
                 for r in csv.DictReader(fh):
                     name = r["Kernel_Name"]
-                    if "query_" not in name and "pair_lookup" not in name:
+                    if "query_" not in name and "pair_lookup" not in name and "lookup_lane" not in name:
                         continue
                     per_dispatch[(name, r["Counter_Name"])][r["Dispatch_Id"]] += float(r["Counter_Value"])
         for (name, counter), d in per_dispatch.items():
@@ -57,7 +57,9 @@ def main(out_dir: str) -> None:
         if raw is None:
             continue
         raw_bytes = raw * 1024.0
-        lookup_raw = avg(fetch_pass, "pair_lookup_kernel", "FETCH_SIZE") if wl == "kmers" else None   # phased form: its first kernel
+        # phased form: its first kernel (one lane per k-mer with the candidate tables of k - t <= 15, lane pairs otherwise)
+        lookup_name = "lookup_lane_kernel" if avg(fetch_pass, "lookup_lane_kernel", "FETCH_SIZE") is not None else "pair_lookup_kernel"
+        lookup_raw = avg(fetch_pass, lookup_name, "FETCH_SIZE") if wl == "kmers" else None
         batch = b["config"]["queries_per_step_per_gpu"]
         t = {"kernel": kernel_sub, "config": {"workload": wl, "n": b["config"]["index_rows"] - 1, "batch": batch, "k": b["config"]["k"],
                                                 "prefix_len": b["config"]["prefix_table_len"], "mode": b["config"]["mode"]},
@@ -66,11 +68,11 @@ def main(out_dir: str) -> None:
         if wl == "kmers":
             block_reads = (roof["blocks_per_kmer"] - roof["table_lookups_per_kmer"]) * batch   # 128-B requests
             wr = avg("pmc_write", kernel_sub, "WRITE_SIZE")
-            wr_lookup = avg("pmc_write", "pair_lookup_kernel", "WRITE_SIZE")
+            wr_lookup = avg("pmc_write", lookup_name, "WRITE_SIZE")
             t["write_bytes_per_launch"] = ((wr or 0.0) + (wr_lookup or 0.0)) * 1024.0
             t["fetch_bytes_per_launch"] = raw_bytes + 64.0 * block_reads
             if lookup_raw is not None:
-                t["kernel"] = "pair_lookup_kernel + query_pair_kernel"
+                t["kernel"] = lookup_name + " + query_pair_kernel"
                 t["lookup_kernel_fetch_bytes_per_launch"] = lookup_raw * 1024.0
                 t["fetch_bytes_per_launch"] += lookup_raw * 1024.0
             t["hbm_bytes_per_launch"] = t["fetch_bytes_per_launch"] + t["write_bytes_per_launch"]
