@@ -424,7 +424,11 @@ __global__ __launch_bounds__(256) void pair_lookup_kernel(PairIndex ix, const ui
 // 38 G/s instead of 48 G/s), so the two lanes of a pair fetch the even lane's entry together, then the odd lane's, 16 bytes
 // each, and swap the halves they hold for each other: two instructions of 32 lines per 64 k-mers.
 // The chunk's result bytes are collected in LDS and leave as 16 bytes per lane.
-// Same contract as pair_lookup_kernel (work items, list_count, result bytes of settled k-mers, counters).
+// Same contract as pair_lookup_kernel (work items, result bytes of settled k-mers, counters) but for the work lists: so few
+// searches are left that the four waves of a workgroup share ONE list (list[first k-mer of the workgroup ..], its length
+// in list_count[workgroup], items appended through a counter in LDS, ql relative to the workgroup's first k-mer), and the
+// stepping kernel is launched with chunks four times as long -- a quarter of its workgroups, whose fixed cost (the
+// tables into LDS) is most of what it has left to do.
 template <bool COUNT, bool RUNS, bool WIDE>
 __global__ __launch_bounds__(256) void lookup_lane_kernel(PairIndex ix, const uint64_t* __restrict__ kmers, uint64_t n_windows, int k, uint32_t flags,
                                                           uint32_t chunk, uint8_t* __restrict__ out, WorkItem* __restrict__ list,
@@ -434,6 +438,9 @@ __global__ __launch_bounds__(256) void lookup_lane_kernel(PairIndex ix, const ui
     __shared__ uint64_t s_qf[4][kQueue];
     __shared__ uint32_t s_qi[4][kQueue];
     __shared__ __attribute__((aligned(16))) uint8_t s_res[4][kMaxChunk];
+    __shared__ uint32_t s_items;   // work items of the workgroup so far
+    if (threadIdx.x == 0) s_items = 0;
+    __syncthreads();
     const uint32_t strict = flags & FMSI_HIP_STRICT;
     const uint32_t mode_all = flags & FMSI_HIP_MODE_ALL;
     const int T = static_cast<int>(ix.ptable_len);
@@ -450,7 +457,8 @@ __global__ __launch_bounds__(256) void lookup_lane_kernel(PairIndex ix, const ui
     const uint64_t wave = (static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
     const uint64_t start = wave * chunk;
     const uint32_t len = start < n_windows ? static_cast<uint32_t>(min(static_cast<uint64_t>(chunk), n_windows - start)) : 0u;
-    uint32_t count = 0;            // wave-uniform: work items written so far
+    const uint64_t group_start = static_cast<uint64_t>(blockIdx.x) * 4u * chunk;   // first k-mer of the workgroup
+    const uint32_t ql_base = wib * chunk;
     uint32_t qhead = 0, qtail = 0; // wave-uniform: the queue holds [qhead, qtail), positions mod kQueue
     uint64_t run = 0, run_last = 0, run_end = 0, run_delta = 0;
     auto find_run = [&](uint64_t lo, uint64_t hi, uint64_t q) -> uint64_t {   // run_off[lo] <= q < run_off[hi]
@@ -550,16 +558,18 @@ __global__ __launch_bounds__(256) void lookup_lane_kernel(PairIndex ix, const ui
     auto emit_items = [&](bool alive, uint64_t f, uint32_t x, uint32_t y, uint32_t ql) {
         const uint64_t m = __ballot(alive);
         if (m) {
+            uint32_t at = 0;
+            if (lane == 0u) at = atomicAdd(&s_items, static_cast<uint32_t>(__popcll(m)));
+            at = static_cast<uint32_t>(__shfl(static_cast<int>(at), 0, 64));
             if (alive) {
                 WorkItem w;
                 w.f = f;
                 w.x = x;
                 w.y = y;
-                w.ql = ql;
+                w.ql = ql_base + ql;
                 w.pad = 0;
-                list[start + count + lanes_below(m)] = w;
+                list[group_start + at + lanes_below(m)] = w;
             }
-            count += static_cast<uint32_t>(__popcll(m));
         }
     };
     // a dense round over the first `items` queue entries
@@ -660,7 +670,8 @@ __global__ __launch_bounds__(256) void lookup_lane_kernel(PairIndex ix, const ui
         }
     }
     if (qtail != qhead) slow_round(qtail - qhead);
-    if (lane == 0u && start < n_windows) list_count[wave] = count;
+    __syncthreads();   // (every wave of the workgroup comes here)
+    if (threadIdx.x == 0 && group_start < n_windows) list_count[blockIdx.x] = s_items;
     if (len) {   // the chunk's result bytes leave in 16-byte pieces; those of the work items are the stepping kernel's to overlay
         uint8_t* dst = out + start;
         const bool aligned = (reinterpret_cast<uintptr_t>(dst) & 15u) == 0;
@@ -1197,8 +1208,11 @@ int launch_phased_t(fmsi_hip_index* idx, const uint64_t* d_kmers, uint64_t n, in
     if (lds_bytes > 64 * 1024)   // 160 KB of LDS per CU on gfx950; more than 64 KB per workgroup has to be asked for
         FMSI_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&query_pair_kernel<COUNT, true, true>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_bytes)));
-    hipLaunchKernelGGL((query_pair_kernel<COUNT, true, true>), dim3(blocks), dim3(256), lds_bytes, s, pix, d_kmers, n, k, flags | (overlay ? kFlagOverlay : 0u),
-                       static_cast<uint32_t>(chunk), n_super, o8, o64, d_counters, d_list, d_count);
+    // (after lookup_lane_kernel the work lists are per lookup workgroup: four chunks each)
+    const uint32_t step_chunk = static_cast<uint32_t>(lane_lookup ? 4 * chunk : chunk);
+    const uint32_t step_blocks = lane_lookup ? (blocks + 3) / 4 : blocks;
+    hipLaunchKernelGGL((query_pair_kernel<COUNT, true, true>), dim3(step_blocks), dim3(256), lds_bytes, s, pix, d_kmers, n, k,
+                       flags | (overlay ? kFlagOverlay : 0u), step_chunk, n_super, o8, o64, d_counters, d_list, d_count);
     FMSI_HIP_TRY(hipGetLastError());
     return 0;
 }
