@@ -209,6 +209,7 @@ def main():
         make_input(s + 1, bufs[s])
     index.profile(True)
     index.profile_read(reset=True)
+    barrier()   # (the first collective of the run also builds RCCL's communicator: twice, so that the timed one is warm)
     barrier()
     t0 = time.perf_counter()
     for s in range(args.steps):

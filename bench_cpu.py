@@ -135,9 +135,21 @@ def run(args, index, n, k):
     agree = bool(np.array_equal(bits, gpu_bits[:sample]))
     rest = text[sample * k:]
     secs = _fork_workers(cores, lambda w: obj.time_isolated_kmers(rest[w * per_worker * k:(w + 1) * per_worker * k], per_worker, k, mode)[0])
+    tuned = {}
+    if kind == "reference" and oracle_py.REF_TUNED_LIB.exists():
+        # the same sources with tuned flags (oracle/Makefile.ref), same files, same k-mers, one thread
+        try:
+            obj_t = oracle_py.Reference.load_tuned(os.path.join(tmp.name, "bench"))
+            sec_t, bits_t = obj_t.time_isolated_kmers(text[:sample * k], sample, k, mode)
+            obj_t.close()
+            tuned = {"tuned_value": sample / sec_t, "tuned_flags": "-O3 -DNDEBUG -march=x86-64-v3", "tuned_seconds": round(sec_t, 3),
+                     "tuned_matches_gpu": bool(np.array_equal(bits_t, gpu_bits[:sample]))}
+        except Exception as e:   # a reported extra, never a reason to lose the baseline
+            tuned = {"tuned_error": repr(e)}
     if tmp is not None:
         tmp.cleanup()
     return {
+        **tuned,
         "value": sample / sec1, "unit": "k-mers/s", "cores": 1, "kind": kind,
         "sample": f"first {sample} k-mers of the benchmark's seeded query stream against the same {int(index.info.n)}-row index "
                   f"(exported from the GPU build in the reference's .fmsi format); query_kmers() per k-mer, as-shipped flags "

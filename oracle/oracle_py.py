@@ -18,6 +18,7 @@ ORACLE_LIB = HERE / "_build" / "liboracle.so"
 ORACLE_CLI = HERE / "_build" / "fmsi_oracle"
 REF_LIB = HERE / "_ref" / "libfmsi_ref.so"
 REF_CLI = HERE / "_ref" / "fmsi_ref"
+REF_TUNED_LIB = HERE / "_ref" / "libfmsi_ref_tuned.so"   # same sources, -O3 -DNDEBUG -march=x86-64-v3 (Makefile.ref)
 REFERENCE_ROOT = Path("/root/reference")
 
 MODE_OR, MODE_ALL = 0, 1
@@ -215,6 +216,19 @@ def ref_available() -> bool:
     return REF_LIB.exists()
 
 
+_ref_tuned_lib = None
+
+
+def ref_tuned_lib() -> C.CDLL:
+    """The reference built with tuned flags (timing only; the parity checks use the as-shipped build)."""
+    global _ref_tuned_lib
+    if _ref_tuned_lib is None:
+        L = C.CDLL(str(REF_TUNED_LIB))
+        _proto(L, "ref_")
+        _ref_tuned_lib = L
+    return _ref_tuned_lib
+
+
 def ref_lib() -> C.CDLL:
     global _ref_lib
     if _ref_lib is None:
@@ -317,6 +331,11 @@ class Reference(_Base):
     @classmethod
     def load(cls, prefix: str, use_klcp=False):
         L = ref_lib()
+        return cls(L, L.ref_index_load(os.fsencode(prefix), int(use_klcp)))
+
+    @classmethod
+    def load_tuned(cls, prefix: str, use_klcp=False):
+        L = ref_tuned_lib()
         return cls(L, L.ref_index_load(os.fsencode(prefix), int(use_klcp)))
 
     @classmethod

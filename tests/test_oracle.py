@@ -181,3 +181,25 @@ def test_oracle_equals_real_reference_on_random_input(oracle_built, tmp_path):
                 orc.predictor_reset(); ref.predictor_reset()
                 for r in reads:
                     assert orc.query_kmers(r, k, has_klcp, mode, orders) == ref.query_kmers(r, k, has_klcp, mode, orders)
+
+
+@pytest.mark.skipif(not (oracle_py.ref_available() and oracle_py.REF_TUNED_LIB.exists()), reason="oracle/_ref not built")
+def test_tuned_reference_build_answers_like_the_shipped_one(oracle_built, tmp_path):
+    """bench_cpu.py's tuned_value times the reference's sources with -O3 -DNDEBUG -march=x86-64-v3 (oracle/Makefile.ref):
+    the flags must not change a single answer."""
+    k = 17
+    ms = synthetic_ms(40000, k, seed=23, mask="mixed")
+    p = tmp_path / "ms.fa"
+    p.write_text(">ms\n" + ms + "\n")
+    rc, _, err = oracle_py.run_cli(oracle_py.REF_CLI, ["index", "-k", str(k), str(p)])
+    assert rc == 0, err
+    ref = oracle_py.Reference.load(str(p))
+    tuned = oracle_py.Reference.load_tuned(str(p))
+    kmers = mixed_kmers(ms, k, 20000, seed=9)
+    raw = "".join(kmers).encode()
+    for mode in (oracle_py.MODE_OR, oracle_py.MODE_ALL):
+        _, a = ref.time_isolated_kmers(raw, len(kmers), k, mode)
+        _, b = tuned.time_isolated_kmers(raw, len(kmers), k, mode)
+        assert np.array_equal(a, b) and a.any() and not a.all()
+    ref.close()
+    tuned.close()
