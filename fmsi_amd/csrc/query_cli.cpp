@@ -11,6 +11,7 @@
 // nature) -> writer thread: formatting on a team of threads + one fwrite per batch.  Batches flow through bounded
 // queues, so parsing, device work and printing of consecutive batches overlap and the output order is the input order.
 #include <getopt.h>
+#include <sys/stat.h>
 
 #include <sched.h>
 
@@ -71,6 +72,8 @@ struct Options {
     int device = 0;
     uint64_t batch_windows = 1ull << 26;   // bases of query sequence per batch (>= windows)
     unsigned threads = 0;                  // 0 = all CPUs this process may use, at most 16
+    bool full_tables = false;              // --tables full: the 16-deep prefix table and the candidate tables (what bench.py measures)
+    bool tables_given = false;             // (--tables on the command line: no choice by the size of the query file)
 };
 
 int usage_query(bool lookup) {
@@ -93,6 +96,10 @@ int usage_query(bool lookup) {
     std::cerr << "  --batch INT  - bases of query sequence per device batch [default: 67108864]" << std::endl;
     std::cerr << "  --threads INT - host threads for packing and formatting [default: available CPUs, at most 16]" << std::endl;
     std::cerr << "  --stats      - print timings to stderr" << std::endl;
+    std::cerr << "  --tables auto|full - device-side accelerators (results unaffected).  auto [default]: a prefix table of up to 14" << std::endl;
+    std::cerr << "                 bases, which keeps the device about level with this program's reader and loads seconds faster" << std::endl;
+    std::cerr << "                 (query files of 30 GB and more get `full`); full: 16 bases plus the candidate tables (up to" << std::endl;
+    std::cerr << "                 190 GB of HBM), the fastest device path" << std::endl;
     std::cerr << std::endl;
     return 1;
 }
@@ -606,7 +613,7 @@ extern "C" int fmsi_cli_query(int argc, char** argv, int output_orders_i) {
     static const option long_opts[] = {{"device", required_argument, nullptr, 1000}, {"fast", no_argument, nullptr, 1001},
                                        {"batch", required_argument, nullptr, 1002},  {"stats", no_argument, nullptr, 1003},
                                        {"strict", no_argument, nullptr, 1004},       {"threads", required_argument, nullptr, 1005},
-                                       {nullptr, 0, nullptr, 0}};
+                                       {"tables", required_argument, nullptr, 1006}, {nullptr, 0, nullptr, 0}};
     optind = 1;
     int c;
     while ((c = getopt_long(argc, argv, "f:hq:k:OS", long_opts, nullptr)) >= 0) {
@@ -632,6 +639,10 @@ extern "C" int fmsi_cli_query(int argc, char** argv, int output_orders_i) {
         case 1003: opt.stats = true; break;
         case 1004: opt.fast = false; break;
         case 1005: opt.threads = static_cast<unsigned>(std::max(1, atoi(optarg))); break;
+        case 1006:
+            if (std::string(optarg) == "full") opt.full_tables = opt.tables_given = true;
+            else if (std::string(optarg) != "auto") return usage_query(output_orders);
+            break;
         default: return usage_query(output_orders);
         }
     }
@@ -673,7 +684,21 @@ extern "C" int fmsi_cli_query(int argc, char** argv, int output_orders_i) {
     // private accelerators (results unchanged): a prefix table of up to 16 steps (4^t entries of 8 bytes with next-base
     // signatures; smaller while the table would have more than 4n entries) and, for non-streaming queries,
     // the two-base-step pair layout
-    int t = std::min(k, 16);
+    // How much of them: this program delivers about 1.5 G windows/s (its record reader), and the device stays ahead of that
+    // with a 14-deep table (about 5 G k-mers/s at human scale, half of that when both strands are wanted); the 16-deep
+    // table and the candidate tables (40 G k-mers/s) would add a second of load time to every run and buy nothing here.
+    // --tables full builds them all the same (callers of the library with resident batches want them: bench.py).
+    // Measured end to end at human scale (profiles/r01k_e2e_cli_human_scale.json): 1.4 G windows/s after a 1.2 s load against
+    // 1.7 G windows/s after a 5.4 s load with everything -- the full set pays from about 30 G windows on, so a query file
+    // of that size (uncompressed bytes ~ windows) gets it without being asked.
+    if (!opt.tables_given && opt.query_fn != "-") {
+        struct stat st;
+        const bool gz = opt.query_fn.size() > 3 && opt.query_fn.compare(opt.query_fn.size() - 3, 3, ".gz") == 0;
+        if (stat(opt.query_fn.c_str(), &st) == 0 && S_ISREG(st.st_mode) &&
+            static_cast<uint64_t>(st.st_size) * (gz ? 4u : 1u) >= 30000000000ull)
+            opt.full_tables = true;
+    }
+    int t = std::min(k, opt.full_tables ? 16 : 14);
     while (t > 0 && (1ull << (2 * t)) > 4 * host->ix.n()) --t;
     // ... and, for presence queries, text verification of the intervals that leave the table with one to three rows.
     // The accelerators are large (34 GB + 52 GB at human scale): when HBM is short -- the GPU shared with other work --
@@ -692,7 +717,7 @@ extern "C" int fmsi_cli_query(int argc, char** argv, int output_orders_i) {
         fmsi_host_index_free(host);
         return 1;
     }
-    const bool want_verify = !opt.has_klcp && !output_orders && t > 0 && t < k && k <= 32;
+    const bool want_verify = opt.full_tables && !opt.has_klcp && !output_orders && t > 0 && t < k && k <= 32;
     if (want_verify && fmsi_hip_index_enable_verify(dev) != 0)
         std::cerr << "WARNING: text verification is off (" << fmsi_hip_last_error() << "); results are unaffected" << std::endl;
     auto t_loaded = clock::now();

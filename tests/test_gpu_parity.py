@@ -148,6 +148,18 @@ def test_cli_equals_reference_golden(fm, name, kind, mode):
     assert out == golden_out(name, kind, mode)
 
 
+@pytest.mark.parametrize("name,kind,mode", [c for c in CASES if c[2] in ("or", "all")])
+def test_cli_with_full_tables_equals_reference_golden(fm, name, kind, mode):
+    """--tables full (16-deep prefix table + candidate tables, the configuration bench.py measures) changes the device
+    path of the presence modes and not a byte of the output; an unknown value is a usage error."""
+    k = CLI_DATASETS[name][0]
+    rc, out, err = fm.run_cli([*MODES[mode][0], "--tables", "full", "-k", str(k), "-q", str(query_file(name, kind)), index_prefix(name)])
+    assert rc == 0, err.decode()
+    assert out == golden_out(name, kind, mode)
+    rc, out, err = fm.run_cli([*MODES[mode][0], "--tables", "huge", "-k", str(k), "-q", str(query_file(name, kind)), index_prefix(name)])
+    assert rc == 1 and out == b""
+
+
 @pytest.mark.parametrize("mode", ["or", "or_S", "all", "all_S"])
 def test_cli_fast_mode(fm, mode):
     """--fast is exact for OR always and for -O on the max-ones fixture."""

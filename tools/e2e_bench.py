@@ -30,6 +30,9 @@ MODES = {
     "all_S": ["query", "-S", "-O"],
     "all_S_fast": ["query", "-S", "-O", "--fast"],
     "lookup": ["lookup"],
+    # the same with every device-side accelerator (--tables full: 16-deep table + candidate tables), for comparison
+    "or_full": ["query", "--tables", "full"],
+    "all_full": ["query", "-O", "--tables", "full"],
 }
 
 
@@ -126,7 +129,7 @@ def main() -> None:
             entry["windows_per_s_after_load"] = round(w / max(1e-9, entry["total_seconds"] - entry["load_seconds"]))
         entry["output_bytes"] = outp.stat().st_size
         # reference on the sample: identical bytes?
-        ref_args = [x for x in args if x not in ("--fast",)]
+        ref_args = [x for x in args if x not in ("--fast", "--tables", "full")]
         if ref_cli.exists() and a.ref_reads:
             t0 = time.time()
             r = subprocess.run([str(ref_cli), *ref_args, "-k", str(a.k), "-q", str(sample), prefix], capture_output=True)
