@@ -540,13 +540,17 @@ __global__ __launch_bounds__(256) void lookup_lane_kernel(PairIndex ix, const ui
         if (i == j) return 0u;
         if ((ey >> 30) != 1u) return 1u;
         const uint32_t rows = (ey >> 24) & 3u;
-        if (!full && rows > 2u) return 4u;
+        if (!WIDE && !full && rows > 2u) return 4u;
         // (the launcher sends only k - t <= 15 here: the candidate words are the bases themselves)
         const uint32_t want = static_cast<uint32_t>(cur & rmask);
         uint32_t mm = (cand0 == want ? 1u : 0u) | (rows > 1u && cand1 == want ? 2u : 0u);
         if (rows > 2u) {
-            mm |= ix.stable[tidx] == want ? 4u : 0u;
-            n_vreads += 1u;
+            if (WIDE) {   // the third candidate rides in the entry's second half
+                mm |= vh.x == want ? 4u : 0u;
+            } else {
+                mm |= ix.stable[tidx] == want ? 4u : 0u;
+                n_vreads += 1u;
+            }
         }
         r = pick(mm, (ey >> 26) & 7u, 0u, 3u);
         return 2u;
@@ -1434,13 +1438,13 @@ __global__ __launch_bounds__(256) void verify_fill_kernel(const uint2* __restric
             }
             e.y = y;   // (the 8-byte table stays as it is: the mask bits live in the lookup kernel's copy)
         }
-        if (wide) {
+        if (wide) {   // (no side array: an interval entry's third candidate sits where a double-stranded entry has its fourth)
             vtable[2 * idx] = make_uint4(e.x, e.y, cand[0], cand[1]);
-            vtable[2 * idx + 1] = make_uint4(cand[3], cand[4], cand[5], cand[6]);
+            vtable[2 * idx + 1] = done ? make_uint4(cand[3], cand[4], cand[5], cand[6]) : make_uint4(cand[2], 0, 0, 0);
         } else {
             vtable[idx] = make_uint4(e.x, e.y, cand[0], cand[1]);
+            stable[idx] = cand[2];
         }
-        stable[idx] = cand[2];
     }
 }
 
@@ -1449,7 +1453,7 @@ __global__ __launch_bounds__(256) void verify_fill_kernel(const uint2* __restric
 
 extern "C" int fmsi_hip_index_enable_verify(fmsi_hip_index* idx) {
     if (!idx) return FMSI_HIP_EINVAL;
-    if (idx->d_stable) return 0;
+    if (idx->d_vtable) return 0;
     const int T = idx->prefix_len, R = idx->k - T;
     if (!idx->d_ptable || !idx->dev.ptable_packed || idx->k > 32 || R < 1) {
         set_last_error("text verification needs a packed prefix table with t < k <= 32");
@@ -1473,12 +1477,12 @@ extern "C" int fmsi_hip_index_enable_verify(fmsi_hip_index* idx) {
     bool wide = R <= 15 && !std::getenv("FMSI_HIP_NARROW_CANDIDATES") && !std::getenv("FMSI_HIP_LOOKUP_PAIRS");
     if (wide) {
         size_t free_b = 0, total_b = 0;
-        const uint64_t need = count * 36 + (len + 1) + n * 4 + ((len >> 5) + 2) * 8 + (16ull << 30);
+        const uint64_t need = count * 32 + (len + 1) + n * 4 + ((len >> 5) + 2) * 8 + (16ull << 30);
         if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < need) wide = false;
     }
     const uint64_t entry_bytes = wide ? 32 : 16;
     if (hipMalloc(reinterpret_cast<void**>(&d_chars), len + 1) != hipSuccess || hipMalloc(reinterpret_cast<void**>(&d_sa), n * 4) != hipSuccess ||
-        hipMalloc(reinterpret_cast<void**>(&d_stable), count * 4) != hipSuccess ||
+        (!wide && hipMalloc(reinterpret_cast<void**>(&d_stable), count * 4) != hipSuccess) ||
         hipMalloc(reinterpret_cast<void**>(&d_vtable), count * entry_bytes + 64) != hipSuccess)
         return fail(FMSI_HIP_ENOMEM, "hipMalloc failed for the text verification tables");
     int rc = export_walk(idx, d_chars, d_sa);
@@ -1502,6 +1506,6 @@ extern "C" int fmsi_hip_index_enable_verify(fmsi_hip_index* idx) {
     idx->d_stable = d_stable;
     idx->d_vtable = d_vtable;
     idx->vwide = wide;
-    idx->device_bytes += count * (entry_bytes + 4) + 64;
+    idx->device_bytes += count * (entry_bytes + (wide ? 0 : 4)) + 64;
     return 0;
 }

@@ -165,14 +165,14 @@ int fmsi_cli_index(int argc, char** argv);
 
 /* Adds the candidate tables to a handle that has a prefix table (private optimisation, results unchanged): the lookup
  * kernel of the phased path gets its own copy of the table entries -- 32 bytes each when k - t <= 15 and the device has
- * the room (4^t x 36 bytes + 16 GB to spare), else 16 bytes; fmsi_hip_index_info.candidate_entry_bytes tells -- in which
+ * the room (4^t x 32 bytes + 16 GB to spare), else 16 bytes + a 4-byte side array; fmsi_hip_index_info.candidate_entry_bytes tells -- in which
  * every occurrence of a key -- on both strands when the key and its reverse complement occur at most seven (16-byte
  * entries: three) times together, else the forward ones of an interval of up to three rows -- is represented by the
  * k - t bases in front of it and the mask bit of the k-mer it would complete.  A search that comes out of the table with such an entry is settled by comparing its remaining bases with the
  * candidates (one request) instead of (k - t) / 2 dependent block reads: the candidates that match are the rows of the
  * final interval(s), in order.  For k - t > 15 the entries hold text positions and the bases are read from the 2-bit
  * superstring.  Everything comes from the LF walk of fmsi_hip_index_export, so any handle can add it.  Used for the
- * presence modes (not ORDERS).  4^t x 36 (or 20) bytes + n / 4 bytes of HBM.  Idempotent.
+ * presence modes (not ORDERS).  4^t x 32 (or 20) bytes + n / 4 bytes of HBM.  Idempotent.
  * Environment: FMSI_HIP_NARROW_CANDIDATES forces the 16-byte entries, FMSI_HIP_LOOKUP_PAIRS additionally the lane-pair
  * lookup kernel (A/B measurements). */
 int fmsi_hip_index_enable_verify(fmsi_hip_index* idx);
