@@ -99,7 +99,7 @@ int usage_query(bool lookup) {
     std::cerr << "  --tables auto|full - device-side accelerators (results unaffected).  auto [default]: a prefix table of up to 14" << std::endl;
     std::cerr << "                 bases, which keeps the device about level with this program's reader and loads seconds faster" << std::endl;
     std::cerr << "                 (query files of 30 GB and more get `full`); full: 16 bases plus the candidate tables (up to" << std::endl;
-    std::cerr << "                 190 GB of HBM), the fastest device path" << std::endl;
+    std::cerr << "                 180 GB of HBM), the fastest device path" << std::endl;
     std::cerr << std::endl;
     return 1;
 }
