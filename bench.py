@@ -68,6 +68,11 @@ def parse_args():
     ap.add_argument("--cpu-sample", type=int, default=-1, help="windows for the CPU baseline (-1 = auto, 0 = skip)")
     ap.add_argument("--no-counters", action="store_true")
     ap.add_argument("--no-verify", action="store_true", help="phased kernel without text verification of one-row table intervals")
+    ap.add_argument("--repeat-permille", type=int, default=0,
+                    help="share (per 1000) of the superstring's 2048-base segments that are diverged copies of a repeat family "
+                         "(fmsi_hip_index_build_synthetic_repeats): prefix-table keys with tens of occurrences, as in a real genome")
+    ap.add_argument("--repeat-families", type=int, default=1000)
+    ap.add_argument("--repeat-divergence-permille", type=int, default=100)
     ap.add_argument("--abi-gather", action="store_true",
                     help="after the timed region, also gather the results through fmsi_hip_gather (C-ABI, own RCCL communicator) and "
                          "compare with torch.distributed's gather")
@@ -91,6 +96,7 @@ def pmc_traffic(args, n, batch, k):
         c = t.get("config", {})
         if (c.get("workload", "kmers"), c.get("n"), c.get("batch"), c.get("k"), c.get("prefix_len"), c.get("mode")) == \
                 (args.workload, n, batch, k, args.prefix_len, args.mode) and c.get("subst_ppm", 0) == args.subst_ppm and \
+                args.repeat_permille == 0 and \
                 ("stream" if (args.workload == "stream" and args.stream_via == "klcp") else
                  ("pair" if (args.kernel == "phased" or args.workload == "stream") else args.kernel)) in t.get("kernel", "") and \
                 c.get("stream_via", "klcp") == (args.stream_via if args.workload == "stream" else "klcp"):
@@ -129,7 +135,8 @@ def main():
         while args.prefix_len > 0 and 4 ** args.prefix_len > 4 * n:
             args.prefix_len -= 1
     t0 = time.time()
-    index = fm.DeviceIndex.build_synthetic(n, args.seed, k, with_klcp=stream_mode, device=local_rank, prefix_len=args.prefix_len)
+    index = fm.DeviceIndex.build_synthetic(n, args.seed, k, with_klcp=stream_mode, device=local_rank, prefix_len=args.prefix_len,
+                                           repeats=(args.repeat_permille, args.repeat_families, args.repeat_divergence_permille))
     build_s = time.time() - t0
     flags = fm.MODE_ALL if args.mode == "all" else fm.MODE_OR
     if stream_mode and args.stream_via == "runs":
@@ -305,6 +312,9 @@ def main():
         else:
             wl = (f"synthetic max-ones masked superstring n={n} (human-genome scale), isolated random {k}-mers 50% present, "
                   f"fmsi query -O semantics")
+        if args.repeat_permille:
+            wl += (f"; {args.repeat_permille / 10:.0f}% of the superstring's 2048-base segments are copies of {args.repeat_families} repeat "
+                   f"families at {args.repeat_divergence_permille / 10:.0f}% divergence")
         line = {
             "metric": "k-mer membership queries/sec (k=31)", "value": value, "unit": "k-mers/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed_max / args.steps * 1e3,

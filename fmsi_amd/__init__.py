@@ -106,6 +106,9 @@ def lib() -> C.CDLL:
     L.fmsi_hip_index_download_layout.argtypes = [vp, vp, vp]
     L.fmsi_hip_index_build.argtypes = [C.c_char_p, u64, i32, i32, i32, i32, C.POINTER(vp)]
     L.fmsi_hip_index_build_synthetic.argtypes = [u64, u64, i32, i32, i32, i32, C.POINTER(vp)]
+    L.fmsi_hip_index_build_synthetic_repeats.argtypes = [u64, u64, i32, i32, i32, i32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(vp)]
+    L.fmsi_hip_synthetic_text_word_repeats.argtypes = [u64, u64, C.c_uint32, C.c_uint32, C.c_uint32]
+    L.fmsi_hip_synthetic_text_word_repeats.restype = u64
     L.fmsi_hip_synthetic_text_word.argtypes = [u64, u64]
     L.fmsi_hip_synthetic_text_word.restype = u64
     L.fmsi_hip_synthetic_queries.argtypes = [vp, i32, u64, u64, u64, vp, vp]
@@ -277,10 +280,14 @@ class DeviceIndex:
         return cls(None, device, _handle=h)
 
     @classmethod
-    def build_synthetic(cls, length: int, seed: int, k: int, with_klcp: bool = False, device: int = 0, prefix_len: int = 0):
-        """Synthetic max-ones superstring generated and indexed in HBM (see include/fmsi_hip.h)."""
+    def build_synthetic(cls, length: int, seed: int, k: int, with_klcp: bool = False, device: int = 0, prefix_len: int = 0,
+                        repeats=(0, 0, 0)):
+        """Synthetic max-ones superstring generated and indexed in HBM (see include/fmsi_hip.h).
+        repeats = (repeat_permille, families, divergence_permille): share of 2048-base segments that are diverged copies of
+        one of `families` consensus segments (fmsi_hip_index_build_synthetic_repeats)."""
         h = C.c_void_p()
-        _check(lib().fmsi_hip_index_build_synthetic(length, seed, k, int(with_klcp), device, prefix_len, C.byref(h)))
+        rp, fam, div = (int(x) for x in repeats)
+        _check(lib().fmsi_hip_index_build_synthetic_repeats(length, seed, k, int(with_klcp), device, prefix_len, rp, fam, div, C.byref(h)))
         return cls(None, device, _handle=h)
 
     def download_layout(self):

@@ -40,10 +40,32 @@ __host__ __device__ inline uint64_t splitmix64(uint64_t x) {
 // word w of the synthetic superstring: 32 uniform bases (see fmsi_hip_synthetic_text_word in the header)
 __host__ __device__ inline uint64_t synth_word(uint64_t seed, uint64_t w) { return splitmix64(seed ^ (w * 0xD1B54A32D192ED03ull)); }
 
-__global__ void synth_text_kernel(uint64_t* __restrict__ text2, uint64_t n_words, uint64_t len, uint64_t seed) {
+// ... or, with repeat families (fmsi_hip_index_build_synthetic_repeats), of a text in which a share of the 2048-base
+// segments are diverged copies of one of `families` consensus segments: a stand-in for the skewed k-mer spectrum of a
+// real genome, where many distinct k-mers share their last t bases (the prefix-table key) -- which uniform text lacks.
+__host__ __device__ inline uint64_t synth_word_repeats(uint64_t seed, uint64_t w, uint32_t repeat_permille, uint32_t families,
+                                                       uint32_t divergence_permille) {
+    const uint64_t seg = w >> 6;   // 64 words = 2048 bases
+    const uint64_t h = splitmix64(seed ^ 0x5EC7105EEDull ^ (seg * 0xA24BAED4963EE407ull));
+    if (repeat_permille == 0 || families == 0 || (h % 1000u) >= repeat_permille) return synth_word(seed, w);
+    const uint64_t fam = (h >> 20) % families;
+    uint64_t v = synth_word(seed ^ 0xFA3117ull, fam * 64u + (w & 63u));   // the family's consensus word
+    for (uint32_t b = 0; b < 32u; ++b) {                                  // this copy's substitutions
+        const uint64_t r = splitmix64(seed ^ 0xD17E26Eull ^ ((w * 32u + b) * 0x9E3779B97F4A7C15ull));
+        if ((r % 1000u) < divergence_permille) {
+            const uint64_t c = (v >> (2u * b)) & 3u;
+            const uint64_t d = (c + 1u + ((r >> 32) % 3u)) & 3u;          // one of the three other bases
+            v = (v & ~(3ull << (2u * b))) | (d << (2u * b));
+        }
+    }
+    return v;
+}
+
+__global__ void synth_text_kernel(uint64_t* __restrict__ text2, uint64_t n_words, uint64_t len, uint64_t seed, uint32_t repeat_permille,
+                                  uint32_t families, uint32_t divergence_permille) {
     const uint64_t w = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     if (w >= n_words) return;
-    uint64_t v = synth_word(seed, w);
+    uint64_t v = synth_word_repeats(seed, w, repeat_permille, families, divergence_permille);
     const uint64_t first = w * 32;
     if (first >= len) v = 0;
     else if (first + 32 > len) v &= (1ull << (2 * (len - first))) - 1ull;
@@ -530,7 +552,12 @@ int fmsi_hip_index_build(const char* ms, uint64_t len, int k, int with_klcp, int
 }
 
 int fmsi_hip_index_build_synthetic(uint64_t len, uint64_t seed, int k, int with_klcp, int device, int prefix_len, fmsi_hip_index** out) {
-    if (!out || k < 1 || len < static_cast<uint64_t>(k) || (with_klcp && k > 64)) {
+    return fmsi_hip_index_build_synthetic_repeats(len, seed, k, with_klcp, device, prefix_len, 0, 0, 0, out);
+}
+
+int fmsi_hip_index_build_synthetic_repeats(uint64_t len, uint64_t seed, int k, int with_klcp, int device, int prefix_len,
+                                           uint32_t repeat_permille, uint32_t families, uint32_t divergence_permille, fmsi_hip_index** out) {
+    if (!out || k < 1 || len < static_cast<uint64_t>(k) || (with_klcp && k > 64) || repeat_permille > 1000 || divergence_permille > 1000) {
         set_last_error("bad argument (on-device kLCP construction needs k <= 64)");
         return FMSI_HIP_EINVAL;
     }
@@ -539,12 +566,16 @@ int fmsi_hip_index_build_synthetic(uint64_t len, uint64_t seed, int k, int with_
     const uint64_t n_words = (len >> 5) + 2;
     DevBuf text2;
     if ((rc = text2.alloc(n_words * 8))) return rc;
-    hipLaunchKernelGGL(synth_text_kernel, dim3(grid_for(n_words)), dim3(256), 0, 0, text2.as<uint64_t>(), n_words, len, seed);
+    hipLaunchKernelGGL(synth_text_kernel, dim3(grid_for(n_words)), dim3(256), 0, 0, text2.as<uint64_t>(), n_words, len, seed, repeat_permille,
+                       families, divergence_permille);
     FMSI_HIP_TRY(hipGetLastError());
     return build_from_device_text(text2, len, nullptr, k, with_klcp, device, prefix_len, out);
 }
 
 uint64_t fmsi_hip_synthetic_text_word(uint64_t seed, uint64_t w) { return synth_word(seed, w); }
+uint64_t fmsi_hip_synthetic_text_word_repeats(uint64_t seed, uint64_t w, uint32_t repeat_permille, uint32_t families, uint32_t divergence_permille) {
+    return synth_word_repeats(seed, w, repeat_permille, families, divergence_permille);
+}
 
 int fmsi_hip_synthetic_queries(fmsi_hip_index* idx, int k, uint64_t seed, uint64_t first, uint64_t n, uint64_t* d_kmers, void* stream) {
     if (!idx || !d_kmers || !idx->d_text2 || k < 1 || k > 32 || idx->text_len < static_cast<uint64_t>(k)) {

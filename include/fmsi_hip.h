@@ -133,6 +133,13 @@ int fmsi_hip_index_build(const char* ms, uint64_t len, int k, int with_klcp, int
  * masked superstring).  The text stays resident so that query k-mers can be drawn from it on the device. */
 int fmsi_hip_index_build_synthetic(uint64_t len, uint64_t seed, int k, int with_klcp, int device, int prefix_len, fmsi_hip_index** out);
 uint64_t fmsi_hip_synthetic_text_word(uint64_t seed, uint64_t w);
+/* The same with repeat families, for a text whose k-mer spectrum is skewed like a genome's: each 2048-base segment is with
+ * probability repeat_permille / 1000 a copy of one of `families` consensus segments in which every base is substituted with
+ * probability divergence_permille / 1000 (else uniform as above).  Many distinct k-mers then share their last t bases --
+ * prefix-table keys with tens of occurrences, which uniform text does not have.  Still every k-mer ON. */
+int fmsi_hip_index_build_synthetic_repeats(uint64_t len, uint64_t seed, int k, int with_klcp, int device, int prefix_len,
+                                           uint32_t repeat_permille, uint32_t families, uint32_t divergence_permille, fmsi_hip_index** out);
+uint64_t fmsi_hip_synthetic_text_word_repeats(uint64_t seed, uint64_t w, uint32_t repeat_permille, uint32_t families, uint32_t divergence_permille);
 /* Fills d_kmers[0..n) (DEVICE pointer) with queries first..first+n-1 of the seeded stream: with probability 1/2 a
  * k-mer of the superstring (half of those reverse-complemented), else a uniform random k-mer. */
 int fmsi_hip_synthetic_queries(fmsi_hip_index* idx, int k, uint64_t seed, uint64_t first, uint64_t n, uint64_t* d_kmers, void* stream);

@@ -186,3 +186,44 @@ def test_build_repetitive_text_equals_reference(fm, oracle_built, tmp_path, tag)
     assert rc == 0, err
     for part in ("ac_gt", "ac", "gt", "mask", "klcp", "misc"):
         assert (tmp_path / f"{tag}_gpu.fmsi.{part}").read_bytes() == (tmp_path / f"{tag}.fmsi.{part}").read_bytes(), part
+
+
+def test_synthetic_repeat_families_equal_oracle(fm, oracle_built, tmp_path):
+    """fmsi_hip_index_build_synthetic_repeats (bench.py --repeat-permille): a text with repeat families -- prefix-table
+    keys with tens of occurrences -- is indexed like any other (layout == the oracle's from the same text), the host
+    restatement of a word agrees with the device's, and every query path answers it like the oracle, candidate tables
+    included (their entries overflow here, so the stepping kernel gets real work)."""
+    import torch
+    n, seed, k = 400_000, 777, 25
+    rep = (400, 5, 80)   # 40 % of the segments from 5 families at 8 % divergence: ~16 copies per family
+    dev = fm.DeviceIndex.build_synthetic(n, seed, k, with_klcp=True, prefix_len=8, repeats=rep)
+    words = dev.download_text(n)
+    L = fm.lib()
+    for w in (0, 63, 64, 1000, 5000, n // 32 - 1):
+        assert int(words[w]) == int(L.fmsi_hip_synthetic_text_word_repeats(seed, w, *rep))
+    plain = fm.synthetic_text_words(n, seed)
+    assert 0.25 < float((words[:n // 32] != plain[:n // 32]).mean()) < 0.55          # the repeat segments differ from the uniform text
+    codes = ((words[:, None] >> (2 * np.arange(32, dtype=np.uint64))) & np.uint64(3)).reshape(-1)[:n].astype(np.uint8)
+    up = np.frombuffer(b"ACGT", dtype=np.uint8)[codes]
+    lo = np.frombuffer(b"acgt", dtype=np.uint8)[codes]
+    text = np.where(np.arange(n) + k <= n, up, lo).tobytes().decode()
+    orc, host, prefix = host_layout_from_oracle(fm, tmp_path, text, k, "rep")
+    check_equal_layout(fm, dev, host)
+    nq = 60_000
+    d_kmers = torch.empty(nq, dtype=torch.int64, device="cuda")
+    s = torch.cuda.current_stream().cuda_stream
+    dev.synthetic_queries_dev(k, 42, 0, nq, d_kmers.data_ptr(), s)
+    torch.cuda.synchronize()
+    kmers = d_kmers.cpu().numpy().view(np.uint64)
+    kc = ((kmers[:, None] >> (2 * np.arange(k, dtype=np.uint64))) & np.uint64(3)).astype(np.uint8)
+    raw = np.frombuffer(b"ACGT", dtype=np.uint8)[kc].tobytes()
+    fwd, rc = orc.ternaries_bulk(raw, nq, k, True)
+    # k - t = 15: the one-lane lookup kernel with 32-byte entries (4^10 keys for 4 x 10^5 rows: uniform keys fit their
+    # entry, the keys of the families -- about 16 copies x 0.92^10 -- overflow it)
+    dev_c = fm.DeviceIndex.build_synthetic(n, seed, k, prefix_len=10, repeats=rep).enable_pair_layout().enable_verify()
+    assert int(dev_c.info.candidate_entry_bytes) == 32
+    for d in (dev, dev_c):
+        got, cn = d.query_kmers(kmers, k, fm.MODE_ALL | fm.STRICT, counters=True)
+        gf, gr = fm.decode_strict(got)
+        assert np.array_equal(gf, fwd) and np.array_equal(gr, rc)
+    assert int(cn[0]) > 0.02 * nq          # LF steps were needed: the candidate entries did not hold every key

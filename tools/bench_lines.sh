@@ -14,6 +14,8 @@ run --workload stream --steps 10
 run --workload stream --stream-via runs --steps 10
 run --workload stream --subst-ppm 10000 --steps 10
 run --workload stream --stream-via runs --subst-ppm 10000 --steps 10
+run --repeat-permille 300 --steps 10
+run --repeat-permille 300 --repeat-divergence-permille 20 --steps 10
 run --n 4.7e6 --steps 10
 run --n 1.4e9 --steps 10
 wc -l "$O"
