@@ -444,6 +444,40 @@ def test_full_scale_cross_kernel_agreement(fm):
     assert ((frac == 0) | (frac == 1)).all() and 0.35 < (frac == 1).mean() < 0.65   # a read is from the superstring or it is not
 
 
+def test_cross_kernel_agreement_on_repeat_families(fm):
+    """The same property on a text with repeat families (2 x 10^8 rows, 30 % of its segments copies of 100 families at 2 %
+    divergence: prefix-table keys with tens of occurrences, so the candidate entries overflow and the stepping kernel
+    answers a tenth of the k-mers): the four algorithms agree strand by strand, and the two candidate formats agree."""
+    import torch
+    n, k, nq = 200_000_000, 31, 1 << 21
+    rep = (300, 100, 20)
+    dev = fm.DeviceIndex.build_synthetic(n, 99, k, prefix_len=16, repeats=rep).enable_pair_layout().enable_verify()
+    s = torch.cuda.current_stream().cuda_stream
+    d_kmers = torch.empty(nq, dtype=torch.int64, device="cuda")
+    dev.synthetic_queries_dev(k, 42, 0, nq, d_kmers.data_ptr(), s)
+    d_cnt = torch.zeros(fm.N_COUNTERS, dtype=torch.int64, device="cuda")
+    outs = {}
+    for name, kern in (("phased", fm.KERNEL_PHASED), ("pair", fm.KERNEL_PAIR), ("refill", fm.KERNEL_REFILL),
+                       ("lockstep", fm.KERNEL_LOCKSTEP | fm.NO_PREFIX_TABLE)):
+        d_out = torch.empty(nq, dtype=torch.uint8, device="cuda")
+        dev.query_kmers_dev(d_kmers.data_ptr(), nq, k, fm.MODE_ALL | fm.STRICT | kern, d_out.data_ptr(),
+                            counters_ptr=d_cnt.data_ptr() if name == "phased" else 0, stream=s)
+        torch.cuda.synchronize()
+        outs[name] = d_out.cpu().numpy()
+    for name in ("pair", "refill", "lockstep"):
+        assert np.array_equal(outs["phased"], outs[name]), name
+    cn = d_cnt.cpu().numpy()
+    assert int(cn[0]) > 0.3 * nq            # LF steps: the stepping kernel had real work
+    f, r = fm.decode_strict(outs["phased"])
+    present = (f == 1) | (r == 1)
+    assert 0.49 < present.mean() < 0.52     # (a random k-mer is never in the text; a drawn one always)
+    for mode in (fm.MODE_ALL, fm.MODE_OR):
+        d_out = torch.empty(nq, dtype=torch.uint8, device="cuda")
+        dev.query_kmers_dev(d_kmers.data_ptr(), nq, k, mode, d_out.data_ptr(), stream=s)
+        torch.cuda.synchronize()
+        assert np.array_equal(d_out.cpu().numpy().astype(bool), present)
+
+
 @pytest.mark.parametrize("verify", [False, True])
 @pytest.mark.parametrize("k,t", [(31, 8), (31, 10), (19, 7), (32, 9)])
 def test_runs_cut_inside_the_lookup_kernel(fm, oracle_built, k, t, verify):
