@@ -45,7 +45,7 @@ __global__ __launch_bounds__(256) void gather(const uint4* __restrict__ buf, uin
 
 // COOP lanes share one chain: each lane reads GRAN/COOP bytes of the block (consecutive 16-B pieces), so one
 // wave instruction touches 64/COOP distinct lines instead of 64.
-template <int GRAN, int ILP, int COOP>
+template <int GRAN, int ILP, int COOP, bool NT = false>
 __global__ __launch_bounds__(256) void gather_coop(const uint4* __restrict__ buf, uint64_t n_blocks, int iters, uint64_t* out) {
     const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t sub = threadIdx.x % COOP;
@@ -59,7 +59,15 @@ __global__ __launch_bounds__(256) void gather_coop(const uint4* __restrict__ buf
         for (int c = 0; c < ILP; ++c) {
             const uint4* p = buf + (state[c] % n_blocks) * (GRAN / 16) + sub * PIECES;
 #pragma unroll
-            for (int q = 0; q < PIECES; ++q) v[c][q] = p[q];
+            for (int q = 0; q < PIECES; ++q) {
+                if (NT) {   // non-temporal: the line is not wanted in the caches again
+                    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+                    const u4 t = __builtin_nontemporal_load(reinterpret_cast<const u4*>(p + q));
+                    v[c][q] = make_uint4(t.x, t.y, t.z, t.w);
+                } else {
+                    v[c][q] = p[q];
+                }
+            }
         }
 #pragma unroll
         for (int c = 0; c < ILP; ++c) {
@@ -75,18 +83,18 @@ __global__ __launch_bounds__(256) void gather_coop(const uint4* __restrict__ buf
     if (acc == 0x12345678u) out[0] = acc;
 }
 
-template <int GRAN, int ILP, int COOP>
+template <int GRAN, int ILP, int COOP, bool NT = false>
 void run_coop(const uint4* buf, uint64_t bytes, uint64_t* out, int blocks = 8192, int iters = 64) {
     const uint64_t n_blocks = bytes / GRAN;
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
-    gather_coop<GRAN, ILP, COOP><<<blocks, 256>>>(buf, n_blocks, 4, out);
+    gather_coop<GRAN, ILP, COOP, NT><<<blocks, 256>>>(buf, n_blocks, 4, out);
     hipDeviceSynchronize();
     hipEventRecord(a);
-    gather_coop<GRAN, ILP, COOP><<<blocks, 256>>>(buf, n_blocks, iters, out);
+    gather_coop<GRAN, ILP, COOP, NT><<<blocks, 256>>>(buf, n_blocks, iters, out);
     hipEventRecord(b); hipEventSynchronize(b);
     float ms; hipEventElapsedTime(&ms, a, b);
     const double reads = (double)blocks * 256 / COOP * ILP * iters;
-    printf("buf %.2f GB  grid %5d  coop %d  gran %3d B  ilp %d : %.3f ms  %.2f G reads/s  %.2f TB/s\n", bytes / 1e9, blocks, COOP, GRAN, ILP, ms, reads / ms / 1e6,
+    printf("buf %.2f GB  grid %5d  coop %d%s gran %3d B  ilp %d : %.3f ms  %.2f G reads/s  %.2f TB/s\n", bytes / 1e9, blocks, COOP, NT ? " nt" : "   ", GRAN, ILP, ms, reads / ms / 1e6,
            reads * GRAN / ms / 1e9);
 }
 
@@ -141,6 +149,10 @@ int main(int argc, char** argv) {
         run_coop<32, 1, 2>(buf, bytes, out); run_coop<32, 2, 2>(buf, bytes, out); run_coop<32, 4, 2>(buf, bytes, out);
         run_coop<64, 1, 4>(buf, bytes, out); run_coop<64, 2, 4>(buf, bytes, out); run_coop<64, 4, 4>(buf, bytes, out);
         run_coop<128, 1, 8>(buf, bytes, out); run_coop<128, 2, 8>(buf, bytes, out);
+        // non-temporal loads
+        run_coop<16, 1, 1, true>(buf, bytes, out); run_coop<16, 2, 1, true>(buf, bytes, out);
+        run_coop<32, 1, 2, true>(buf, bytes, out); run_coop<32, 2, 2, true>(buf, bytes, out);
+        run_coop<128, 2, 8, true>(buf, bytes, out);
         // one lane reading a 32-byte (64-byte) entry with two (four) loads of its own
         run_coop<32, 1, 1>(buf, bytes, out); run_coop<32, 2, 1>(buf, bytes, out);
         run_coop<64, 1, 1>(buf, bytes, out); run_coop<64, 2, 1>(buf, bytes, out);
