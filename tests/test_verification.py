@@ -1,0 +1,115 @@
+"""Counterpart of the reference's verification test (tests/verify.py driven by tests/Makefile:21-25):
+presence is re-derived by brute force from the masked superstring itself -- a k-mer is present iff it, or its reverse
+complement, occurs somewhere with the mask bit of that occurrence ON (verify.py:11-20, 45-46) -- and compared with what
+the programs print for seeded reads sent over a pipe (`-q -`), half of them substrings of the superstring and half
+uniform (verify.py:98-107).  Same data sets and read shapes as the reference's runs (SARS-CoV-2 k = 13, 100 reads of 62;
+GCF_test2_ones k = 31 with -O, 100 reads of 90), plus what it leaves out: `-S`, and reads with lower case and N.
+
+This checker shares nothing with the oracle or the product: it pins the ORACLE on CPU and the PRODUCT CLI on the GPU.
+"""
+import random
+
+import pytest
+
+import oracle_py
+from conftest import GOLDEN, index_prefix, revcomp
+
+RUNS = [
+    # name, masked superstring, k, reads, read length, extra CLI args
+    ("sars_k13", "GCF_009858895.2_ASM985889v3_genomic.fna.ms.k13", 13, 100, 62, []),
+    ("sars_k31", "GCF_test2_ones.fna.ms.k31", 31, 100, 90, ["-O"]),
+    ("sars_k13", "GCF_009858895.2_ASM985889v3_genomic.fna.ms.k13", 13, 60, 200, ["-S"]),
+    ("sars_k31", "GCF_test2_ones.fna.ms.k31", 31, 60, 300, ["-S", "-O"]),
+]
+
+
+def masked_superstring(fname: str) -> str:
+    return "".join(l.strip() for l in open(GOLDEN / "ref_data" / fname) if not l.startswith(">"))
+
+
+def on_kmers(ms: str, k: int) -> set:
+    """k-mers with at least one ON occurrence (upper case first letter = mask 1, src/kmers.h:71-73)."""
+    up = ms.upper()
+    return {up[p:p + k] for p in range(len(ms) - k + 1) if ms[p].isupper()}
+
+
+def brute_force_line(read: str, on: set, k: int) -> str:
+    """What `fmsi query` must print for one record: one character per window; a window with a non-ACGT letter is 0
+    (and the reference over-prints after an invalid character exactly as many zeros, src/main.cpp:351-360, so the
+    line has one character per window there too for reads longer than k)."""
+    out = []
+    up = read.upper()
+    for i in range(len(up) - k + 1):
+        w = up[i:i + k]
+        if any(c not in "ACGT" for c in w):
+            out.append("0")
+        else:
+            out.append("1" if (w in on or revcomp(w) in on) else "0")
+    return "".join(out)
+
+
+def seeded_reads(ms: str, n: int, length: int, seed: int, dirty: bool = False):
+    rng = random.Random(seed)
+    up = ms.upper()
+    reads = []
+    for _ in range(n):
+        if rng.random() < 0.5:
+            s = rng.randrange(0, len(up) - length + 1)
+            r = up[s:s + length]
+            if rng.random() < 0.5:
+                r = revcomp(r)
+        else:
+            r = "".join(rng.choice("ACGT") for _ in range(length))
+        if dirty:   # lower case is valid; an N kills the windows that contain it
+            r = "".join(c.lower() if rng.random() < 0.3 else c for c in r)
+            if rng.random() < 0.5:
+                p = rng.randrange(0, length)
+                r = r[:p] + "N" + r[p + 1:]
+        reads.append(r)
+    return reads
+
+
+def check_cli(run, name, fname, k, n_reads, length, extra, dirty=False):
+    ms = masked_superstring(fname)
+    on = on_kmers(ms, k)
+    reads = seeded_reads(ms, n_reads, length, seed=42, dirty=dirty)
+    stdin = "".join(f">header some comment\n{r}\n" for r in reads).encode()
+    rc, out, err = run(["query", "-q", "-", "-k", str(k), *extra, index_prefix(name)], stdin)
+    assert rc == 0, err.decode()
+    lines = out.decode().split("\n")
+    assert lines[-1] == "" and len(lines) == n_reads + 1
+    n_pos = 0
+    for read, line in zip(reads, lines):
+        header, _, bits = line.partition("\t")
+        assert header == "header"
+        want = brute_force_line(read, on, k)
+        if "N" in read:   # the over-print quirk can add zeros after the last invalid character: compare the windows
+            assert bits[:len(want)] == want and set(bits[len(want):]) <= {"0"}
+        else:
+            assert bits == want
+        n_pos += want.count("1")
+    assert n_pos > 0.2 * n_reads * (length - k + 1)   # the positives were really there
+
+
+@pytest.mark.parametrize("name,fname,k,n_reads,length,extra", RUNS)
+@pytest.mark.parametrize("dirty", [False, True])
+def test_oracle_cli_against_brute_force(oracle_built, name, fname, k, n_reads, length, extra, dirty):
+    check_cli(lambda args, stdin: oracle_py.run_cli(oracle_py.ORACLE_CLI, args, stdin), name, fname, k, n_reads, length, extra, dirty)
+
+
+@pytest.mark.skipif(not oracle_py.ref_available(), reason="oracle/_ref not built")
+@pytest.mark.parametrize("name,fname,k,n_reads,length,extra", RUNS[:2])
+def test_reference_cli_against_brute_force(name, fname, k, n_reads, length, extra):
+    """(the checker itself, held against the real reference on the reference's own two runs)"""
+    check_cli(lambda args, stdin: oracle_py.run_cli(oracle_py.REF_CLI, args, stdin), name, fname, k, n_reads, length, extra)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tables", [[], ["--tables", "full"]])
+@pytest.mark.parametrize("name,fname,k,n_reads,length,extra", RUNS)
+@pytest.mark.parametrize("dirty", [False, True])
+def test_product_cli_against_brute_force(product_built, name, fname, k, n_reads, length, extra, dirty, tables):
+    fm = product_built
+    if tables and "-S" in extra:
+        pytest.skip("--tables full changes nothing for -S")
+    check_cli(lambda args, stdin: fm.run_cli([*args[:-1], *tables, args[-1]], stdin), name, fname, k, n_reads, length, extra, dirty)
