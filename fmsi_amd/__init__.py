@@ -105,6 +105,10 @@ def lib() -> C.CDLL:
     L.fmsi_hip_index_get_info.argtypes = [vp, C.POINTER(IndexInfo)]
     L.fmsi_hip_index_download_layout.argtypes = [vp, vp, vp]
     L.fmsi_hip_index_build.argtypes = [C.c_char_p, u64, i32, i32, i32, i32, C.POINTER(vp)]
+    L.fmsi_hip_host_alloc.argtypes = [u64]
+    L.fmsi_hip_host_alloc.restype = vp
+    L.fmsi_hip_host_free.argtypes = [vp]
+    L.fmsi_hip_host_free.restype = None
     L.fmsi_hip_index_build_synthetic.argtypes = [u64, u64, i32, i32, i32, i32, C.POINTER(vp)]
     L.fmsi_hip_index_build_synthetic_repeats.argtypes = [u64, u64, i32, i32, i32, i32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(vp)]
     L.fmsi_hip_synthetic_text_word_repeats.argtypes = [u64, u64, C.c_uint32, C.c_uint32, C.c_uint32]

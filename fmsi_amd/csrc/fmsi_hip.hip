@@ -918,6 +918,20 @@ int fmsi_hip_sync(fmsi_hip_index* idx, void* stream) {
     return 0;
 }
 
+void* fmsi_hip_host_alloc(uint64_t bytes) {
+    void* p = nullptr;
+    if (bytes == 0 || hipHostMalloc(&p, bytes, hipHostMallocPortable) != hipSuccess) {
+        (void)hipGetLastError();
+        set_last_error("hipHostMalloc failed");
+        return nullptr;
+    }
+    return p;
+}
+
+void fmsi_hip_host_free(void* p) {
+    if (p) (void)hipHostFree(p);
+}
+
 int fmsi_hip_profile_enable(fmsi_hip_index* idx, int on) {
     if (!idx) return FMSI_HIP_EINVAL;
     idx->profiling = on != 0;

@@ -21,13 +21,16 @@
 #include <cmath>
 #include <condition_variable>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <deque>
 #include <exception>
 #include <fstream>
 #include <iostream>
+#include <map>
 #include <memory>
 #include <mutex>
+#include <new>
 #include <stdexcept>
 #include <string>
 #include <thread>
@@ -192,6 +195,73 @@ struct RecRef {
     uint64_t name_off, seq_off, seq_len;
     uint32_t name_len;
 };
+// Page-locked memory for what crosses the link every batch (packed bases in, result bytes / orders out): blocks come from
+// fmsi_hip_host_alloc and are kept in a small cache by size, since pinning costs far more than a batch's copy.  Small or
+// failed requests fall back to the heap.  resize() does not clear: the device writes every element before it is read.
+class PinnedPool {
+public:
+    static constexpr size_t kMin = 1u << 20;
+    static size_t bucket(size_t bytes) {
+        size_t b = kMin;
+        while (b < bytes) b <<= 1;
+        return b;
+    }
+    static void* get(size_t bytes) {
+        if (bytes < kMin) return std::malloc(bytes ? bytes : 1);
+        const size_t b = bucket(bytes);
+        {
+            std::lock_guard<std::mutex> lock(mutex());
+            auto& v = cache()[b];
+            if (!v.empty()) {
+                void* p = v.back();
+                v.pop_back();
+                return p;
+            }
+        }
+        void* p = fmsi_hip_host_alloc(b);
+        if (p) {
+            std::lock_guard<std::mutex> lock(mutex());
+            pinned().push_back(p);
+            return p;
+        }
+        return std::malloc(b);
+    }
+    static void put(void* p, size_t bytes) {
+        if (bytes < kMin) {
+            std::free(p);
+            return;
+        }
+        std::lock_guard<std::mutex> lock(mutex());
+        if (std::find(pinned().begin(), pinned().end(), p) == pinned().end()) {
+            std::free(p);
+            return;
+        }
+        cache()[bucket(bytes)].push_back(p);   // (kept until the process ends)
+    }
+
+private:
+    static std::mutex& mutex() { static std::mutex m; return m; }
+    static std::map<size_t, std::vector<void*>>& cache() { static auto* c = new std::map<size_t, std::vector<void*>>; return *c; }
+    static std::vector<void*>& pinned() { static auto* v = new std::vector<void*>; return *v; }
+};
+template <class T>
+struct PinnedAlloc {
+    using value_type = T;
+    PinnedAlloc() = default;
+    template <class U> PinnedAlloc(const PinnedAlloc<U>&) {}
+    T* allocate(size_t n) {
+        void* p = PinnedPool::get(n * sizeof(T));
+        if (!p) throw std::bad_alloc();
+        return static_cast<T*>(p);
+    }
+    void deallocate(T* p, size_t n) { PinnedPool::put(p, n * sizeof(T)); }
+    template <class U> void construct(U*) {}   // resize(): no clearing
+    template <class U, class... A> void construct(U* p, A&&... a) { ::new (static_cast<void*>(p)) U(std::forward<A>(a)...); }
+    template <class U> bool operator==(const PinnedAlloc<U>&) const { return true; }
+    template <class U> bool operator!=(const PinnedAlloc<U>&) const { return false; }
+};
+template <class T> using PinVec = std::vector<T, PinnedAlloc<T>>;
+
 struct RawBatch {
     std::string text;            // names and sequences, as read
     std::vector<RecRef> recs;
@@ -205,10 +275,10 @@ struct Prepared {
     std::vector<uint64_t> rec_out;        // presence modes: byte offset of record r's line in the batch output; [recs] = total
     std::vector<uint64_t> run_start;      // device runs: first base (a multiple of 32: runs are word aligned in `packed`)
     std::vector<uint32_t> run_windows;
-    std::vector<uint64_t> packed;
+    PinVec<uint64_t> packed;
     uint64_t bases = 0, windows = 0;
-    std::vector<uint8_t> bytes;           // device results, then (after the replay) the final 0/1 per window
-    std::vector<int64_t> orders;          // lookup: device results, then the final order per window
+    PinVec<uint8_t> bytes;                // device results, then (after the replay) the final 0/1 per window
+    PinVec<int64_t> orders;               // lookup: device results, then the final order per window
 };
 
 struct CodeTable {   // nucleotideToInt, src/kmers.h:3-20 (4 = invalid)
@@ -832,7 +902,7 @@ extern "C" int fmsi_cli_query(int argc, char** argv, int output_orders_i) {
                 check(fmsi_hip_sync(dev, nullptr), "fmsi_hip_sync");
             }
             auto t2 = clock::now();
-            std::vector<uint64_t>().swap(P->packed);
+            PinVec<uint64_t>().swap(P->packed);
             if (strict) replay_batch(*P, predictor, opt.mode, output_orders, opt.has_klcp, k);
             auto t3 = clock::now();
             prep_s += std::chrono::duration<double>(t1 - t0).count();

@@ -229,6 +229,11 @@ int fmsi_hip_query_stream(fmsi_hip_index* idx, const uint64_t* packed_seq, uint6
                           uint64_t n_windows, int k, uint32_t flags, void* out, uint64_t* counters, void* stream);
 
 int fmsi_hip_sync(fmsi_hip_index* idx, void* stream);
+/* Page-locked host memory for the caller's batch buffers (hipHostMalloc / hipHostFree).  Any host memory works with the
+ * query calls; from page-locked memory the copies to and from the device run at the link's rate instead of through the
+ * driver's staging (the CLI's device stage: 0.4-0.6 s -> see DESIGN.md 8 per 10^9 windows).  NULL when it cannot be had. */
+void* fmsi_hip_host_alloc(uint64_t bytes);
+void fmsi_hip_host_free(void* p);
 
 /* per-handle kernel timing with HIP events recorded on the launch stream around every kernel launch */
 int fmsi_hip_profile_enable(fmsi_hip_index* idx, int on);
