@@ -11,7 +11,10 @@ namespace {
 constexpr size_t kBufSize = 1 << 18;
 }
 
-FastxReader::FastxReader(const std::string& path) : buf_(kBufSize) {
+FastxReader::FastxReader(const unsigned char* data, size_t len) : buf_(data), begin_(0), end_(len) {}
+
+FastxReader::FastxReader(const std::string& path) : own_(kBufSize) {
+    buf_ = own_.data();
     if (path == "-") {
         fp_ = gzdopen(fileno(stdin), "r");
     } else {
@@ -29,8 +32,13 @@ FastxReader::~FastxReader() {
 
 bool FastxReader::fill_() {
     if (eof_) return false;
+    if (!fp_) {   // memory mode: the range is all there is
+        begin_ = end_ = 0;
+        eof_ = true;
+        return false;
+    }
     begin_ = 0;
-    int n = gzread(fp_, buf_.data(), static_cast<unsigned>(buf_.size()));
+    int n = gzread(fp_, own_.data(), static_cast<unsigned>(own_.size()));
     if (n <= 0) {
         end_ = 0;
         eof_ = true;
@@ -52,14 +60,14 @@ bool FastxReader::until_(bool line, std::string* dst, int* delim, size_t* counte
         if (begin_ >= end_ && !fill_()) break;
         size_t i;
         if (line) {
-            const void* nl = std::memchr(buf_.data() + begin_, '\n', end_ - begin_);
-            i = nl ? static_cast<size_t>(static_cast<const unsigned char*>(nl) - buf_.data()) : end_;
+            const void* nl = std::memchr(buf_ + begin_, '\n', end_ - begin_);
+            i = nl ? static_cast<size_t>(static_cast<const unsigned char*>(nl) - buf_) : end_;
         } else {
             for (i = begin_; i < end_; ++i)
                 if (std::isspace(buf_[i])) break;
         }
         gotany = true;
-        if (dst) dst->append(reinterpret_cast<const char*>(buf_.data() + begin_), i - begin_);
+        if (dst) dst->append(reinterpret_cast<const char*>(buf_ + begin_), i - begin_);
         if (counted) *counted += i - begin_;
         const size_t at = i;
         begin_ = i + 1;
@@ -91,6 +99,7 @@ bool FastxReader::next() {
     }
     if (c == '>' || c == '@') last_char_ = c;
     if (c != '+') return true;   // FASTA
+    fastq_seen_ = true;
     while ((c = getc_()) >= 0 && c != '\n') {}
     if (c < 0) return false;     // no quality string (-2 in the reference)
     std::string qual;
@@ -120,6 +129,7 @@ bool FastxReader::next_append(std::string& text, size_t* name_off, size_t* name_
     *seq_len = text.size() - *seq_off;
     if (c == '>' || c == '@') last_char_ = c;
     if (c != '+') return true;   // FASTA
+    fastq_seen_ = true;
     while ((c = getc_()) >= 0 && c != '\n') {}
     if (c < 0) return false;     // no quality string (-2 in the reference)
     qual_.clear();

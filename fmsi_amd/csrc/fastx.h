@@ -17,6 +17,11 @@ public:
     // path "-" = stdin.  Throws std::invalid_argument when the file cannot be opened, like
     // OpenFile() in the reference (src/parser.h:22).
     explicit FastxReader(const std::string& path);
+    // The same reader over bytes already in memory (a range of a mapped file that starts at a record): the block-parallel
+    // reader of the CLI runs one per range.  saw_fastq() tells whether a '+' separator line was met -- then `>` at a line
+    // start is not necessarily a record start and the file must not be cut at such lines.
+    FastxReader(const unsigned char* data, size_t len);
+    bool saw_fastq() const { return fastq_seen_; }
     ~FastxReader();
     FastxReader(const FastxReader&) = delete;
     FastxReader& operator=(const FastxReader&) = delete;
@@ -41,9 +46,11 @@ private:
     bool fill_();
 
     gzFile fp_ = nullptr;
-    std::vector<unsigned char> buf_;
+    std::vector<unsigned char> own_;      // gz mode: the read buffer
+    const unsigned char* buf_ = nullptr;  // own_.data(), or the caller's bytes (memory mode: fp_ == nullptr)
     size_t begin_ = 0, end_ = 0;
     bool eof_ = false;
+    bool fastq_seen_ = false;
     int last_char_ = 0;
     std::string qual_;
 };

@@ -12,6 +12,9 @@
 // queues, so parsing, device work and printing of consecutive batches overlap and the output order is the input order.
 #include <getopt.h>
 #include <sys/stat.h>
+#include <unistd.h>
+#include <sys/mman.h>
+#include <fcntl.h>
 
 #include <sched.h>
 
@@ -263,10 +266,82 @@ struct PinnedAlloc {
 template <class T> using PinVec = std::vector<T, PinnedAlloc<T>>;
 
 struct RawBatch {
-    std::string text;            // names and sequences, as read
+    std::string text;            // names and sequences, as read ...
+    std::unique_ptr<char[]> ext; // ... or here (block-parallel reader: the workers' parts at the offsets of their file ranges)
     std::vector<RecRef> recs;
     uint64_t seq_bytes = 0;
+    const char* base() const { return ext ? ext.get() : text.data(); }
 };
+
+// ---- block-parallel reader ---------------------------------------------------------------------------------------
+// A plain (not gzipped) FASTA file is mapped and cut at lines that start with '>' into ranges of about a batch; a range
+// is cut again the same way into one part per worker, and every worker runs the ordinary reader (fastx.cpp, the
+// reference's kseq rules) over its part.  That is the sequential parse exactly, as long as no '+' separator line occurs:
+// a line-start '>' is then always a record start (src/kseq.h:183-226: only a FASTQ quality string can hold one that is
+// not).  A worker that meets a '+' line says so, and the range is parsed again by ONE reader that then goes on to the
+// end of the file -- ranges before it held no '+' line, so its start is a record start of the sequential parse too.
+struct MappedFile {
+    const unsigned char* data = nullptr;
+    size_t size = 0;
+    ~MappedFile() {
+        if (data) munmap(const_cast<unsigned char*>(data), size);
+    }
+};
+// the query file as a mapping, if it is a regular, uncompressed file that starts with a FASTA header and is worth it
+bool map_plain_fasta(const std::string& path, MappedFile& m) {
+    if (path == "-" || std::getenv("FMSI_HIP_SERIAL_READER")) return false;
+    const int fd = open(path.c_str(), O_RDONLY);
+    if (fd < 0) return false;
+    struct stat st;
+    // (FMSI_HIP_READER_MIN_BYTES: the tests send small files through here)
+    const char* min_env = std::getenv("FMSI_HIP_READER_MIN_BYTES");
+    const long long min_bytes = min_env ? std::max(1ll, atoll(min_env)) : (8ll << 20);
+    bool ok = fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && st.st_size >= min_bytes;
+    if (ok) {
+        void* p = mmap(nullptr, static_cast<size_t>(st.st_size), PROT_READ, MAP_PRIVATE, fd, 0);
+        ok = p != MAP_FAILED;
+        if (ok) {
+            m.data = static_cast<const unsigned char*>(p);
+            m.size = static_cast<size_t>(st.st_size);
+            (void)madvise(p, m.size, MADV_SEQUENTIAL);
+            if (m.data[0] != '>') ok = false;   // (a gzip stream starts with 0x1f 0x8b, a FASTQ file with '@')
+        }
+    }
+    close(fd);
+    return ok;
+}
+// first position >= from (and < end) of a '>' that starts a line; `end` if there is none
+size_t next_record_start(const unsigned char* d, size_t from, size_t end) {
+    while (from < end) {
+        const void* g = std::memchr(d + from, '>', end - from);
+        if (!g) return end;
+        const size_t at = static_cast<size_t>(static_cast<const unsigned char*>(g) - d);
+        if (at == 0 || d[at - 1] == '\n') return at;
+        from = at + 1;
+    }
+    return end;
+}
+// all records of d[lo, hi) (lo at a record start) through the ordinary reader; offsets relative to `text`
+bool parse_range(const unsigned char* d, size_t lo, size_t hi, std::string& text, std::vector<RecRef>& recs, uint64_t& seq_bytes) {
+    FastxReader r(d + lo, hi - lo);
+    text.reserve(hi - lo);
+    for (;;) {
+        RecRef rr;
+        const size_t before = text.size();
+        size_t name_off, name_len, seq_off, seq_len;
+        if (!r.next_append(text, &name_off, &name_len, &seq_off, &seq_len)) {
+            text.resize(before);
+            break;
+        }
+        rr.name_off = name_off;
+        rr.name_len = static_cast<uint32_t>(name_len);
+        rr.seq_off = seq_off;
+        rr.seq_len = seq_len;
+        recs.push_back(rr);
+        seq_bytes += seq_len;
+    }
+    return !r.saw_fastq();
+}
 struct Prepared {
     RawBatch raw;
     std::vector<Op> ops;                  // all records' ops, record r owns [rec_ops[r], rec_ops[r+1])
@@ -379,7 +454,7 @@ void prepare_batch(Prepared& P, int k, unsigned team) {
         }
     }
     std::vector<TeamPlan> tp(team);
-    const char* text = P.raw.text.data();
+    const char* text = P.raw.base();
     parallel_for(team, [&](unsigned t) {
         for (size_t r = cut[t]; r < cut[t + 1]; ++r) {
             const RecRef& rr = P.raw.recs[r];
@@ -594,7 +669,7 @@ void format_bits(const Prepared& P, unsigned team, std::vector<char>& out) {
     const size_t nrec = P.raw.recs.size();
     out.resize(P.rec_out[nrec]);
     team = static_cast<unsigned>(std::max<size_t>(1, std::min<size_t>(team, nrec / 64 + 1)));
-    const char* text = P.raw.text.data();
+    const char* text = P.raw.base();
     parallel_for(team, [&](unsigned t) {
         // ranges of about equal output size
         const uint64_t lo = P.rec_out[nrec] / team * t, hi = t + 1 == team ? P.rec_out[nrec] : P.rec_out[nrec] / team * (t + 1);
@@ -627,7 +702,7 @@ void format_orders(const Prepared& P, unsigned team, std::vector<std::string>& p
     const size_t nrec = P.raw.recs.size();
     team = static_cast<unsigned>(std::max<size_t>(1, std::min<size_t>(team, nrec / 64 + 1)));
     parts.assign(team, std::string());
-    const char* text = P.raw.text.data();
+    const char* text = P.raw.base();
     const uint64_t total = P.rec_first[nrec] + nrec;   // balance by windows (+1 per record)
     parallel_for(team, [&](unsigned t) {
         std::string& s = parts[t];
@@ -754,13 +829,12 @@ extern "C" int fmsi_cli_query(int argc, char** argv, int output_orders_i) {
     // private accelerators (results unchanged): a prefix table of up to 16 steps (4^t entries of 8 bytes with next-base
     // signatures; smaller while the table would have more than 4n entries) and, for non-streaming queries,
     // the two-base-step pair layout
-    // How much of them: this program delivers about 1.5 G windows/s (its record reader), and the device stays ahead of that
-    // with a 14-deep table (about 5 G k-mers/s at human scale, half of that when both strands are wanted); the 16-deep
-    // table and the candidate tables (40 G k-mers/s) would add a second of load time to every run and buy nothing here.
-    // --tables full builds them all the same (callers of the library with resident batches want them: bench.py).
-    // Measured end to end at human scale (profiles/r01k_e2e_cli_human_scale.json): 1.4 G windows/s after a 1.2 s load against
-    // 1.7 G windows/s after a 5.4 s load with everything -- the full set pays from about 30 G windows on, so a query file
-    // of that size (uncompressed bytes ~ windows) gets it without being asked.
+    // How much of them: end to end this program moves 2-3 G windows/s (reader, copies, formatting), and with a
+    // 14-deep table the device stage -- kernels at about 5 G k-mers/s at human scale plus the copies -- is level with that.
+    // The 16-deep table and the candidate tables (40 G k-mers/s on resident batches: bench.py) take seconds more to
+    // load -- 190 GB of fresh HBM -- and buy little here: measured at human scale (profiles/r01m_e2e_cli_human_scale.json)
+    // 2.8 G windows/s after a 1.2 s load against 3.0 G windows/s after a 6.4 s load.  So they are built when asked for
+    // (--tables full) or when the query file is so large (30 GB; uncompressed bytes ~ windows) that the difference adds up.
     if (!opt.tables_given && opt.query_fn != "-") {
         struct stat st;
         const bool gz = opt.query_fn.size() > 3 && opt.query_fn.compare(opt.query_fn.size() - 3, 3, ".gz") == 0;
@@ -816,10 +890,79 @@ extern "C" int fmsi_cli_query(int argc, char** argv, int output_orders_i) {
     BoundedQueue<std::unique_ptr<Prepared>> out_q(2);
     std::exception_ptr reader_err, writer_err;
 
+    MappedFile mapped;
+    const bool parallel_read = map_plain_fasta(opt.query_fn, mapped);
     std::thread reader_thread([&] {
         try {
             auto b = std::make_unique<RawBatch>();
             auto t0 = clock::now();
+            size_t resume_at = 0;   // block-parallel reader: where the ordinary reader takes over (a '+' line was met)
+            if (parallel_read) {
+                const unsigned workers = std::max(1u, std::min(8u, team / 2));
+                const unsigned char* d = mapped.data;
+                size_t pos = 0;
+                bool serial = false;
+                while (pos < mapped.size && !serial) {
+                    // a range of about a batch, ending at a record start (or the end of the file)
+                    size_t end = mapped.size;
+                    if (mapped.size - pos > opt.batch_windows + (opt.batch_windows >> 3))
+                        end = next_record_start(d, pos + opt.batch_windows, mapped.size);
+                    std::vector<size_t> cuts{pos};
+                    for (unsigned w = 1; w < workers; ++w) {
+                        const size_t c = next_record_start(d, pos + (end - pos) / workers * w, end);
+                        if (c > cuts.back() && c < end) cuts.push_back(c);
+                    }
+                    cuts.push_back(end);
+                    const size_t parts = cuts.size() - 1;
+                    std::vector<std::string> texts(parts);
+                    std::vector<std::vector<RecRef>> recs(parts);
+                    std::vector<uint64_t> seq_bytes(parts, 0);
+                    std::vector<char> clean(parts, 1);
+                    auto nb = std::make_unique<RawBatch>();
+                    nb->ext.reset(new char[end - pos + 1]);   // a part's names and sequences are shorter than its range
+                    std::vector<std::thread> pool;
+                    for (size_t w = 0; w < parts; ++w)
+                        pool.emplace_back([&, w] {
+                            clean[w] = parse_range(d, cuts[w], cuts[w + 1], texts[w], recs[w], seq_bytes[w]) ? 1 : 0;
+                            const size_t shift = cuts[w] - pos;
+                            std::memcpy(nb->ext.get() + shift, texts[w].data(), texts[w].size());
+                            for (RecRef& r : recs[w]) {
+                                r.name_off += shift;
+                                r.seq_off += shift;
+                            }
+                        });
+                    for (std::thread& t : pool) t.join();
+                    if (std::find(clean.begin(), clean.end(), 0) != clean.end()) {   // a FASTQ record: the ordinary reader from here on
+                        serial = true;
+                        resume_at = pos;
+                        break;
+                    }
+                    size_t total = 0;
+                    for (size_t w = 0; w < parts; ++w) total += recs[w].size();
+                    nb->recs.reserve(total);
+                    for (size_t w = 0; w < parts; ++w) {
+                        nb->recs.insert(nb->recs.end(), recs[w].begin(), recs[w].end());
+                        nb->seq_bytes += seq_bytes[w];
+                    }
+                    pos = end;
+                    if (nb->recs.empty()) continue;
+                    // (the stages behind count records in 32 bits per batch like the ordinary reader's batches: at most 2^23)
+                    if (nb->recs.size() > (1u << 23)) {
+                        serial = true;
+                        resume_at = cuts[0];
+                        break;
+                    }
+                    read_s += std::chrono::duration<double>(clock::now() - t0).count();
+                    if (!raw_q.push(std::move(nb))) return;
+                    t0 = clock::now();
+                }
+                if (!serial) {
+                    read_s += std::chrono::duration<double>(clock::now() - t0).count();
+                    raw_q.close();
+                    return;
+                }
+                reader = std::make_unique<FastxReader>(mapped.data + resume_at, mapped.size - resume_at);
+            }
             for (;;) {
                 RecRef rr;
                 const size_t before = b->text.size();

@@ -548,3 +548,64 @@ def test_candidate_tables_are_for_the_index_k_only(fm, oracle_built):
         fwd, rc = orc.ternaries_bulk("".join(kmers).encode(), len(kmers), kq, True)
         gf, gr = fm.decode_strict(dev.query_kmers(fm.pack_kmers(kmers, kq), kq, fm.MODE_ALL | fm.STRICT))
         assert np.array_equal(gf, fwd) and np.array_equal(gr, rc), kq
+
+
+def _messy_fasta(ms: str, rng, fastq_at=None) -> bytes:
+    """Records of every shape the reader has rules for (src/kseq.h:183-226): multi-line sequences, CRLF, header comments,
+    empty records, lower case, N, '@' headers -- and optionally FASTQ records from record `fastq_at` on,
+    with '>' and '@' at the start of quality lines."""
+    up = ms.upper()
+    out = []
+    for r in range(400):
+        L = rng.choice([0, 5, 13, 40, 90, 200, 700])
+        if rng.random() < 0.6 and L:
+            s0 = rng.randrange(0, len(up) - L)
+            seq = up[s0:s0 + L]
+        else:
+            seq = "".join(rng.choice("ACGT") for _ in range(L))
+        if rng.random() < 0.2:
+            seq = "".join(c.lower() if rng.random() < 0.5 else c for c in seq)
+        if rng.random() < 0.15 and L:
+            q = rng.randrange(L)
+            seq = seq[:q] + "N" + seq[q + 1:]
+        nl = "\r\n" if rng.random() < 0.2 else "\n"
+        head = f"r{r}" + (" a comment > with @ signs" if rng.random() < 0.3 else "")
+        if fastq_at is not None and r >= fastq_at and L:
+            qual = "".join(rng.choice(">@+IIIII#") for _ in range(L))
+            out.append(f"@{head}{nl}{seq}{nl}+{nl}{qual}{nl}")
+            continue
+        width = rng.choice([0, 7, 60])
+        body = seq if not width else nl.join(seq[i:i + width] for i in range(0, len(seq), width))
+        out.append((">" if rng.random() < 0.85 else "@") + head + nl + body + (nl if body or rng.random() < 0.5 else ""))
+        if rng.random() < 0.05:
+            out.append(nl)
+    return "".join(out).encode()
+
+
+@pytest.mark.parametrize("fastq_at", [None, 150, 0])
+@pytest.mark.parametrize("mode", ["or", "all_S", "lookup"])
+def test_block_parallel_reader_equals_the_ordinary_one(fm, oracle_built, tmp_path, monkeypatch, mode, fastq_at):
+    """The CLI's block-parallel FASTA reader (mapped file cut at '>' lines, one ordinary reader per part) against the
+    ordinary reader and against the oracle's restatement of kseq, on a file of awkward records and with ranges of a few
+    kilobytes so that cuts fall everywhere; with FASTQ records from some point on it has to hand over to the ordinary
+    reader at the right record."""
+    name, k = "sars_k13", 13
+    ms = "".join(l.strip() for l in open(GOLDEN / "ref_data" / "GCF_009858895.2_ASM985889v3_genomic.fna.ms.k13") if not l.startswith(">"))
+    data = _messy_fasta(ms, random.Random(31 + (fastq_at or 7)), fastq_at)
+    if fastq_at == 0:
+        data = data[data.index(b"@"):]        # a file that starts as FASTQ never takes the parallel path
+    q = tmp_path / "messy.fa"
+    q.write_bytes(data)
+    args = [*MODES[mode][0], "-k", str(k), "--batch", "4096", "-q", str(q), index_prefix(name)]
+    monkeypatch.setenv("FMSI_HIP_SERIAL_READER", "1")
+    rc, want, err = fm.run_cli(args)
+    assert rc == 0, err.decode()
+    monkeypatch.delenv("FMSI_HIP_SERIAL_READER")
+    monkeypatch.setenv("FMSI_HIP_READER_MIN_BYTES", "1")
+    rc, got, err = fm.run_cli(args)
+    assert rc == 0, err.decode()
+    assert got == want
+    checker = oracle_py.REF_CLI if oracle_py.ref_available() else oracle_py.ORACLE_CLI   # the real reference when it is there
+    rc, ref, err = oracle_py.run_cli(checker, [a for a in args if a not in ("--batch", "4096")])
+    assert rc == 0 and got == ref
+    assert got.count(b"\n") > (100 if fastq_at != 0 else 50)
