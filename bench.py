@@ -268,7 +268,7 @@ def main():
             pair_blocks = (args.kernel in ("pair", "phased") and not stream_mode) or (stream_mode and args.stream_via == "runs")
             block_b = 128 if pair_blocks else 64
             # a table lookup is one 64-byte HBM access whatever the entry's size (8, 16 or 32 bytes): the memory delivers
-            # nothing smaller (PMC, profiles/r01l_traffic_kmers.json: 60 B fetched per lookup of a 32-byte entry), so the line is
+            # nothing smaller (PMC, profiles/r01m_traffic_kmers.json: 60 B fetched per lookup of a 32-byte entry), so the line is
             # what is counted; useful_* below counts the entry's own bytes instead
             entry_b = int(index.info.candidate_entry_bytes)
             lane_lookups = (not stream_mode or args.stream_via == "runs") and args.kernel == "phased" and entry_b and k - int(index.info.prefix_len) <= 15
