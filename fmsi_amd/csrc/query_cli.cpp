@@ -600,7 +600,7 @@ inline uint64_t run_end(const uint8_t* p, uint64_t from, uint64_t n, uint8_t v) 
 }
 
 // strict results (both strands per window) -> final per-window values, in the order the reference visits them
-void replay_batch(Prepared& P, StrandPredictor& predictor, Mode mode, bool orders, bool streaming, int k) {
+void replay_batch(Prepared& P, StrandPredictor& predictor, Mode mode, bool orders, bool streaming, int k, unsigned team) {
     if (!streaming) {
         // One predictor step per window, in output order == result order; fills do not touch the predictor.  The
         // predictor is a small saturating state machine: when a step leaves it unchanged, every following window with
@@ -644,6 +644,19 @@ void replay_batch(Prepared& P, StrandPredictor& predictor, Mode mode, bool order
         }
         return;
     }
+    // -S: the predictor steps once per CHUNK (src/fms_index.h:181-254), on the sums of the chunk's strand results.
+    // Presence modes, in two phases: (A) the team takes the chunks in parallel -- what the predictor will be told for either
+    // strand order (the two pairs of sums), and the chunk's output bytes, which do not depend on the order unless a window
+    // has one strand 0 and the other 1 under -O (then the first strand searched decides: such chunks are left for B);
+    // (B) one pass over the chunks with the predictor itself.  Same sums, same decisions, same bytes as the walk chunk by
+    // chunk; `lookup -S` keeps that walk.
+    struct Chunk {
+        uint64_t w0;
+        uint32_t n;
+        int16_t sums[2][2];   // [swap][first, second]
+        bool order_matters;
+    };
+    std::vector<Chunk> chunks;
     for (size_t r = 0; r + 1 < P.rec_ops.size(); ++r) {
         const uint64_t L = P.raw.recs[r].seq_len;
         const int64_t max_chunk = k + std::max<int64_t>(10, std::min<int64_t>(400, 2 * static_cast<int64_t>(std::sqrt(static_cast<int64_t>(L)))));   // src/main.cpp:330-331
@@ -655,11 +668,55 @@ void replay_batch(Prepared& P, StrandPredictor& predictor, Mode mode, bool order
             while (current_length >= k) {
                 const int64_t chunk_length = std::min<int64_t>(current_length, max_chunk);
                 const uint64_t n = static_cast<uint64_t>(chunk_length - k + 1);
-                replay_streaming_chunk(predictor, mode, orders, P, w, n);
+                if (orders) replay_streaming_chunk(predictor, mode, orders, P, w, n);
+                else chunks.push_back(Chunk{w, static_cast<uint32_t>(n), {{0, 0}, {0, 0}}, false});
                 w += n;
                 current_length -= static_cast<int64_t>(n);
             }
         }
+    }
+    if (orders || chunks.empty()) return;
+    const bool maximized_ones = mode == Mode::All;
+    const size_t nc = chunks.size();
+    team = static_cast<unsigned>(std::max<size_t>(1, std::min<size_t>(team, nc / 256 + 1)));
+    parallel_for(team, [&](unsigned t) {
+        for (size_t c = nc / team * t, hi = t + 1 == team ? nc : nc / team * (t + 1); c < hi; ++c) {
+            Chunk& ch = chunks[c];
+            uint8_t* b = P.bytes.data() + ch.w0;
+            int fs[2] = {0, 0}, ss[2] = {0, 0};
+            bool matters = false;
+            for (uint32_t i = 0; i < ch.n; ++i) {
+                const int f = fwd_of(b[i]), r = rc_of(b[i]);
+                // no swap: first = f; swap: first = r (replay_streaming_chunk above)
+                const bool dec0 = f == 1 || (f == 0 && maximized_ones), dec1 = r == 1 || (r == 0 && maximized_ones);
+                fs[0] += f;
+                ss[0] += dec0 ? 0 : r;
+                fs[1] += r;
+                ss[1] += dec1 ? 0 : f;
+                const int v0 = dec0 ? f : std::max(f, r), v1 = dec1 ? r : std::max(r, f);
+                matters |= (v0 == 1) != (v1 == 1);
+            }
+            ch.sums[0][0] = static_cast<int16_t>(fs[0]);
+            ch.sums[0][1] = static_cast<int16_t>(ss[0]);
+            ch.sums[1][0] = static_cast<int16_t>(fs[1]);
+            ch.sums[1][1] = static_cast<int16_t>(ss[1]);
+            ch.order_matters = matters;
+            if (!matters)
+                for (uint32_t i = 0; i < ch.n; ++i) {
+                    const int f = fwd_of(b[i]), r = rc_of(b[i]);
+                    b[i] = static_cast<uint8_t>((f == 1 || (f == 0 && maximized_ones) ? f : std::max(f, r)) == 1);
+                }
+        }
+    });
+    for (Chunk& ch : chunks) {
+        if (ch.order_matters) {   // (non-max-ones masks under -O only)
+            replay_streaming_chunk(predictor, mode, false, P, ch.w0, ch.n);
+            continue;
+        }
+        const bool swap = predictor.predict_swap();
+        const int first_sum = ch.sums[swap][0], second_sum = ch.sums[swap][1];
+        if (swap) predictor.log_result(second_sum, first_sum);
+        else predictor.log_result(first_sum, second_sum);
     }
 }
 
@@ -1046,7 +1103,7 @@ extern "C" int fmsi_cli_query(int argc, char** argv, int output_orders_i) {
             }
             auto t2 = clock::now();
             PinVec<uint64_t>().swap(P->packed);
-            if (strict) replay_batch(*P, predictor, opt.mode, output_orders, opt.has_klcp, k);
+            if (strict) replay_batch(*P, predictor, opt.mode, output_orders, opt.has_klcp, k, team);
             auto t3 = clock::now();
             prep_s += std::chrono::duration<double>(t1 - t0).count();
             gpu_s += std::chrono::duration<double>(t2 - t1).count();
