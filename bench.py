@@ -73,6 +73,9 @@ def parse_args():
                          "(fmsi_hip_index_build_synthetic_repeats): prefix-table keys with tens of occurrences, as in a real genome")
     ap.add_argument("--repeat-families", type=int, default=1000)
     ap.add_argument("--repeat-divergence-permille", type=int, default=100)
+    ap.add_argument("--force-dist", action="store_true",
+                    help="run the multi-rank code path (process group over RCCL, barriers, MAX over ranks, gather) with one rank too: "
+                         "a check of that path on a 1-GPU box, under torch.distributed.run --nproc-per-node 1")
     ap.add_argument("--abi-gather", action="store_true",
                     help="after the timed region, also gather the results through fmsi_hip_gather (C-ABI, own RCCL communicator) and "
                          "compare with torch.distributed's gather")
@@ -119,8 +122,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    multi = world > 1 or args.force_dist   # the multi-rank code path
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     if args.gpus != world and rank == 0 and world > 1:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
@@ -190,7 +197,7 @@ def main():
     bufs = [torch.empty(in_words, dtype=torch.int64, device=dev_t) for _ in range(n_buf)]
 
     def barrier():
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -227,20 +234,22 @@ def main():
     index.profile(False)
 
     el = torch.tensor([elapsed], dtype=torch.float64, device=dev_t)
-    if world > 1:
+    if multi:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed_max = float(el.item())
 
     # gather the last step's results to rank 0 (rank order = output order); outside the timed region
     gather_note = None
-    if world > 1:
+    if multi:
         parts = [torch.empty_like(d_out) for _ in range(world)] if rank == 0 else None
         dist.gather(d_out, parts, dst=0)
+        if rank == 0 and not torch.equal(parts[0], d_out):
+            raise RuntimeError("gathered results differ from rank 0's own")
     if args.abi_gather:
         # the same gather through the C-ABI (fmsi_hip_gather over its own RCCL communicator), checked against the above
         from fmsi_amd import sharding
         try:
-            if world > 1:
+            if multi:
                 comm = sharding.comm_from_process_group(local_rank)
             else:
                 comm = fm.Comm(fm.Comm.unique_id(), 1, 0, local_rank)
@@ -249,7 +258,7 @@ def main():
             torch.cuda.synchronize()
             t_g = time.perf_counter() - t_g
             if rank == 0:
-                same = torch.equal(whole, torch.cat(parts) if world > 1 else d_out)
+                same = torch.equal(whole, torch.cat(parts) if multi else d_out)
                 gather_note = {"fmsi_hip_gather": "matches torch.distributed.gather" if same else "MISMATCH",
                                "bytes": int(whole.numel()), "seconds": round(t_g, 4)}
             comm.close()
@@ -339,7 +348,7 @@ def main():
                 line["cpu_baseline"] = {"error": repr(e)}
         os.write(json_fd, (json.dumps(line) + "\n").encode())
     os.close(json_fd)
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -66,3 +66,28 @@ def test_gather_of_sharded_query_results(fm, oracle_built, tmp_path):
     fwd, rc = orc.ternaries_bulk("".join(kmers).encode(), len(kmers), k, True)
     want = np.where(fwd != -1, fwd, rc) == 1
     assert np.array_equal(got.cpu().numpy().astype(bool), want)
+
+
+def test_bench_multi_rank_path_with_one_rank(fm):
+    """bench.py's multi-rank code path -- process group over RCCL with a device id, barriers, MAX over ranks, the gather of
+    the results through torch.distributed and through fmsi_hip_gather -- launched the way the driver launches it, with the
+    one rank a 1-GPU box allows (--force-dist), on a small index: exactly one JSON line on stdout, the two gathers agree."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    repo = Path(__file__).resolve().parent.parent
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", "29547", str(repo / "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--n", "3e6", "--batch", "262144",
+           "--force-dist", "--abi-gather", "--cpu-sample", "0"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=str(repo))
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [l for l in res.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, res.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 1 and line["steps"] == 3 and line["value"] > 0 and line["scaling"] == "weak"
+    assert line["config"]["gather"]["fmsi_hip_gather"] == "matches torch.distributed.gather"
+    assert line["roofline"]["bound"] == "hbm" and line["roofline"]["launches"] == 3
