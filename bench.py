@@ -53,7 +53,7 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", choices=["kmers", "stream"], default="kmers")
-    ap.add_argument("--n", type=float, default=2.8e9, help="superstring length in bases (human scale: 2.8e9)")
+    ap.add_argument("--n", "--index-bases", dest="n", type=float, default=2.8e9, help="superstring length in bases (human scale: 2.8e9)")
     ap.add_argument("--batch", type=float, default=float(1 << 27), help="query windows per step and GPU")
     ap.add_argument("--k", type=int, default=31)
     ap.add_argument("--prefix-len", type=int, default=-1,
