@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 import oracle_py
-from conftest import CLI_DATASETS, DATASETS, GOLDEN, MODES, golden_out, index_prefix, mixed_kmers, query_file, revcomp, synthetic_ms
+from conftest import CLI_DATASETS, DATASETS, GOLDEN, MODES, golden_out, index_prefix, messy_fasta, mixed_kmers, query_file, revcomp, synthetic_ms
 
 pytestmark = pytest.mark.gpu
 
@@ -550,38 +550,6 @@ def test_candidate_tables_are_for_the_index_k_only(fm, oracle_built):
         assert np.array_equal(gf, fwd) and np.array_equal(gr, rc), kq
 
 
-def _messy_fasta(ms: str, rng, fastq_at=None) -> bytes:
-    """Records of every shape the reader has rules for (src/kseq.h:183-226): multi-line sequences, CRLF, header comments,
-    empty records, lower case, N, '@' headers -- and optionally FASTQ records from record `fastq_at` on,
-    with '>' and '@' at the start of quality lines."""
-    up = ms.upper()
-    out = []
-    for r in range(400):
-        L = rng.choice([0, 5, 13, 40, 90, 200, 700])
-        if rng.random() < 0.6 and L:
-            s0 = rng.randrange(0, len(up) - L)
-            seq = up[s0:s0 + L]
-        else:
-            seq = "".join(rng.choice("ACGT") for _ in range(L))
-        if rng.random() < 0.2:
-            seq = "".join(c.lower() if rng.random() < 0.5 else c for c in seq)
-        if rng.random() < 0.15 and L:
-            q = rng.randrange(L)
-            seq = seq[:q] + "N" + seq[q + 1:]
-        nl = "\r\n" if rng.random() < 0.2 else "\n"
-        head = f"r{r}" + (" a comment > with @ signs" if rng.random() < 0.3 else "")
-        if fastq_at is not None and r >= fastq_at and L:
-            qual = "".join(rng.choice(">@+IIIII#") for _ in range(L))
-            out.append(f"@{head}{nl}{seq}{nl}+{nl}{qual}{nl}")
-            continue
-        width = rng.choice([0, 7, 60])
-        body = seq if not width else nl.join(seq[i:i + width] for i in range(0, len(seq), width))
-        out.append((">" if rng.random() < 0.85 else "@") + head + nl + body + (nl if body or rng.random() < 0.5 else ""))
-        if rng.random() < 0.05:
-            out.append(nl)
-    return "".join(out).encode()
-
-
 @pytest.mark.parametrize("fastq_at", [None, 150, 0])
 @pytest.mark.parametrize("mode", ["or", "all_S", "lookup"])
 def test_block_parallel_reader_equals_the_ordinary_one(fm, oracle_built, tmp_path, monkeypatch, mode, fastq_at):
@@ -591,7 +559,7 @@ def test_block_parallel_reader_equals_the_ordinary_one(fm, oracle_built, tmp_pat
     reader at the right record."""
     name, k = "sars_k13", 13
     ms = "".join(l.strip() for l in open(GOLDEN / "ref_data" / "GCF_009858895.2_ASM985889v3_genomic.fna.ms.k13") if not l.startswith(">"))
-    data = _messy_fasta(ms, random.Random(31 + (fastq_at or 7)), fastq_at)
+    data = messy_fasta(ms, random.Random(31 + (fastq_at or 7)), fastq_at)
     if fastq_at == 0:
         data = data[data.index(b"@"):]        # a file that starts as FASTQ never takes the parallel path
     q = tmp_path / "messy.fa"

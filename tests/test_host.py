@@ -245,3 +245,32 @@ def test_gather_argument_errors_without_a_gpu(product_built):
     assert b"bad argument" in L.fmsi_hip_last_error()
     L.fmsi_hip_comm_destroy(None)                                              # a no-op
 
+
+
+def test_host_code_under_sanitizers(tmp_path):
+    """The host-only code of the library -- index file parser + RRR-63 decoder, writer + RRR-63 encoder, the FASTA/FASTQ
+    reader in file and in memory mode -- built with AddressSanitizer + UBSan (tests/native/host_sanitize.cpp, g++, no HIP):
+    clean runs, the files it writes back are the golden bytes, and a file cut at its '>' lines reads like the whole."""
+    from pathlib import Path
+    from conftest import messy_fasta
+
+    repo = REPO
+    src = repo / "fmsi_amd" / "csrc"
+    exe = tmp_path / "host_sanitize"
+    cmd = ["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-fno-omit-frame-pointer",
+           f"-I{repo / 'include'}", str(repo / "tests" / "native" / "host_sanitize.cpp"), str(src / "host_index.cpp"), str(src / "index_writer.cpp"),
+           str(src / "layout.cpp"), str(src / "fastx.cpp"), "-o", str(exe), "-lz", "-lpthread"]
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr[-3000:]
+    ms = "".join(l.strip() for l in open(GOLDEN / "ref_data" / "GCF_009858895.2_ASM985889v3_genomic.fna.ms.k13") if not l.startswith(">"))
+    fastas = {}
+    for tag, fq in (("fasta", None), ("mixed", 150)):
+        fastas[tag] = tmp_path / f"{tag}.fa"
+        fastas[tag].write_bytes(messy_fasta(ms, random.Random(5), fq))
+    for name, klcp, tag in (("sars_k31", 1, "fasta"), ("mixed_k11", 1, "mixed"), ("repeats_k64", 1, "fasta"), ("integration_a", 0, "fasta")):
+        out = tmp_path / f"w_{name}"
+        res = subprocess.run([str(exe), str(GOLDEN / "idx" / name), str(klcp), str(out), str(fastas[tag])], capture_output=True, text=True)
+        assert res.returncode == 0, (res.stdout + res.stderr)[-3000:]
+        assert "400 records" in res.stdout and ("fastq=1" in res.stdout) == (tag == "mixed")
+        for part in ("ac_gt", "ac", "gt", "mask", "misc") + (("klcp",) if klcp else ()):
+            assert (GOLDEN / "idx" / f"{name}.fmsi.{part}").read_bytes() == Path(f"{out}.fmsi.{part}").read_bytes(), (name, part)
