@@ -57,7 +57,7 @@ def parse_args():
     ap.add_argument("--batch", type=float, default=float(1 << 27), help="query windows per step and GPU")
     ap.add_argument("--k", type=int, default=31)
     ap.add_argument("--prefix-len", type=int, default=-1,
-                    help="private prefix table length t (0 = none; default: 16, less while 4^t > 4n)")
+                    help="private prefix table length t (0 = none; default: 16; without candidate tables less while 4^t > 4n)")
     ap.add_argument("--kernel", choices=["phased", "pair", "refill", "lockstep"], default="phased",
                     help="phased = pair layout, table lookups in their own kernel (default); pair = the same in one kernel")
     ap.add_argument("--mode", choices=["all", "or"], default="all")
@@ -137,9 +137,15 @@ def main():
 
     n = int(args.n)
     k = args.k
-    if args.prefix_len < 0:   # measured on the human-scale index: the largest table, t = 16 (34 GB), is the fastest
+    if args.prefix_len < 0:
+        # Measured: the largest table, t = 16, is the fastest, and with the candidate tables (k - t <= 15: one
+        # line settles a k-mer) that holds for ANY index size -- E. coli scale: 44 G k-mers/s with the 172 GB of t = 16 tables
+        # against 26 G/s with cache-resident t = 12 ones.  The kLCP kernel and the table-less kernels keep the rule "no more
+        # entries than 4 x rows".
         args.prefix_len = min(k, 16)
-        while args.prefix_len > 0 and 4 ** args.prefix_len > 4 * n:
+        candidates = args.kernel == "phased" and not args.no_verify and (args.workload == "kmers" or args.stream_via == "runs") and \
+            1 <= k - args.prefix_len <= 15
+        while not candidates and args.prefix_len > 0 and 4 ** args.prefix_len > 4 * n:
             args.prefix_len -= 1
     t0 = time.time()
     index = fm.DeviceIndex.build_synthetic(n, args.seed, k, with_klcp=stream_mode, device=local_rank, prefix_len=args.prefix_len,
