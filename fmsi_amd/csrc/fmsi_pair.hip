@@ -180,8 +180,10 @@ static_assert(sizeof(WorkItem) == 24, "WorkItem layout");
 // lookup / step / finalize branches and reaches 40 G requests/s on a half-absent batch, against 50 G/s on all-present
 // and 44 G/s on all-absent ones).
 // A lookup is done by a LANE PAIR, each lane loading its 32 bytes of the entry's 64-byte line: measured on this table
-// (34 GB, random lines) 46 G lookups/s, against 17 G/s when every lane fetches a line of its own -- two adjacent
-// lanes on one line cost the memory path one request, 64 different lines per instruction cost it more than twice 32.
+// (34 GB, random lines) 46 G lookups/s, against 17 G/s when every lane fetches the whole line itself (four loads) -- the
+// memory path pays per load instruction and distinct line (tools/gather_bench entry), and two adjacent
+// lanes on one line are one request.  (Where 16 bytes per k-mer are enough -- the candidate tables of k - t <= 15 --
+// lookup_lane_kernel below does the lookups with one lane and one load each.)
 // Result per k-mer: one 8-byte record, (i, j) of the strand that is alive after the table -- stored as (j, i) when that
 // is the reverse complement (the forward strand died in the table) -- or (0, 0) when both strands died.
 // A wave owns a contiguous chunk of k-mers (the same chunks as the stepping kernel's waves).  K-mers that are settled here
