@@ -44,7 +44,7 @@ int build_layout(const fmsi_index_view& v, HostLayout& L) {
     const uint64_t n_words = (n + 63) >> 6;
     const uint64_t n_blocks = ((n + kBlockRows - 1) >> kBlockRowsLog2) + 1;
     L.n_blocks = n_blocks;
-    L.blocks.assign(n_blocks * kBlockDwords, 0);
+    L.blocks.resize(n_blocks * kBlockDwords);   // (not cleared: pass 2 writes every dword)
     L.mrank.assign(n_blocks + 1, 0);
     const bool hw_pdep = __builtin_cpu_supports("bmi2");
 
@@ -81,6 +81,7 @@ int build_layout(const fmsi_index_view& v, HostLayout& L) {
                 gt_pos += cg;
                 uint32_t* blk = &L.blocks[(w >> 1) * kBlockDwords];
                 const unsigned half = (w & 1) * 2;
+                if (half == 0) std::fill(blk, blk + kBlockDwords, 0u);   // (a block's two words belong to one chunk)
                 blk[4 + half] = static_cast<uint32_t>(g);
                 blk[5 + half] = static_cast<uint32_t>(g >> 32);
                 blk[8 + half] = static_cast<uint32_t>(lo);
@@ -95,29 +96,64 @@ int build_layout(const fmsi_index_view& v, HostLayout& L) {
             }
         }
     };
+    // blocks past the last word (the padding block, and the second half's block of an odd word count is covered above)
+    const uint64_t blocks_filled = (n_words + 1) >> 1;
+    std::fill(L.blocks.begin() + static_cast<std::ptrdiff_t>(blocks_filled * kBlockDwords), L.blocks.end(), 0u);
+    // pass 3: exclusive prefix sums of the per-block counts (dw 0..3) and inclusive ones of the mask popcounts -- per range of
+    // blocks in parallel: totals per range, offsets from a scan over the ranges, then each range scans itself
     unsigned hw = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
-    if (n_chunks < 4 || hw == 1) {
-        fill(0, n_chunks);
-    } else {
+    if (n_chunks < 4) hw = 1;
+    const uint64_t per = (n_chunks + hw - 1) / hw;
+    const uint64_t blocks_per_chunk = chunk_words / 2;
+    struct Range {
+        uint64_t c0, c1, b0, b1;
+        uint32_t tot[5];
+    };
+    std::vector<Range> ranges;
+    for (unsigned t = 0; t < hw; ++t) {
+        const uint64_t a = std::min(n_chunks, per * t), b = std::min(n_chunks, per * (t + 1));
+        if (a >= b) continue;
+        Range r{a, b, a * blocks_per_chunk, b == n_chunks ? n_blocks : b * blocks_per_chunk, {0, 0, 0, 0, 0}};
+        ranges.push_back(r);
+    }
+    auto run_all = [&](auto&& fn) {
+        if (ranges.size() == 1) {
+            fn(ranges[0]);
+            return;
+        }
         std::vector<std::thread> pool;
-        const uint64_t per = (n_chunks + hw - 1) / hw;
-        for (unsigned t = 0; t < hw; ++t) {
-            const uint64_t a = std::min(n_chunks, per * t), b = std::min(n_chunks, per * (t + 1));
-            if (a < b) pool.emplace_back(fill, a, b);
-        }
+        for (Range& r : ranges) pool.emplace_back([&fn, &r] { fn(r); });
         for (auto& th : pool) th.join();
-    }
-    // pass 3: exclusive prefix sums
-    uint32_t run[4] = {0, 0, 0, 0};
-    for (uint64_t b = 0; b < n_blocks; ++b) {
-        uint32_t* blk = &L.blocks[b * kBlockDwords];
-        for (int s = 0; s < 4; ++s) {
-            const uint32_t here = blk[s];
-            blk[s] = run[s];
-            run[s] += here;
+    };
+    run_all([&](Range& r) {
+        fill(r.c0, r.c1);
+        for (uint64_t b = r.b0; b < r.b1; ++b) {
+            const uint32_t* blk = &L.blocks[b * kBlockDwords];
+            for (int s = 0; s < 4; ++s) r.tot[s] += blk[s];
+            r.tot[4] += L.mrank[b + 1];
         }
-    }
-    for (uint64_t b = 0; b < n_blocks; ++b) L.mrank[b + 1] += L.mrank[b];
+    });
+    uint32_t off[5] = {0, 0, 0, 0, 0};
+    for (Range& r : ranges)
+        for (int s = 0; s < 5; ++s) {
+            const uint32_t t = r.tot[s];
+            r.tot[s] = off[s];   // now: what lies before the range
+            off[s] += t;
+        }
+    run_all([&](Range& r) {
+        uint32_t run[4] = {r.tot[0], r.tot[1], r.tot[2], r.tot[3]};
+        uint32_t mr = r.tot[4];
+        for (uint64_t b = r.b0; b < r.b1; ++b) {
+            uint32_t* blk = &L.blocks[b * kBlockDwords];
+            for (int s = 0; s < 4; ++s) {
+                const uint32_t here = blk[s];
+                blk[s] = run[s];
+                run[s] += here;
+            }
+            mr += L.mrank[b + 1];
+            L.mrank[b + 1] = mr;
+        }
+    });
     return 0;
 }
 

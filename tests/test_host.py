@@ -274,3 +274,42 @@ def test_host_code_under_sanitizers(tmp_path):
         assert "400 records" in res.stdout and ("fastq=1" in res.stdout) == (tag == "mixed")
         for part in ("ac_gt", "ac", "gt", "mask", "misc") + (("klcp",) if klcp else ()):
             assert (GOLDEN / "idx" / f"{name}.fmsi.{part}").read_bytes() == Path(f"{out}.fmsi.{part}").read_bytes(), (name, part)
+
+
+def test_layout_of_many_chunks_equals_numpy(product_built):
+    """build_layout() at a size where its threads take several chunks each (6.3 M rows: the per-range totals, the scan over
+    the ranges and the per-range prefix sums all matter), on random bit-vectors, against a plain numpy computation of the
+    planes and of every block's cumulative counts."""
+    fm = product_built
+    rng = np.random.default_rng(77)
+    n = 6_300_001
+    sym = rng.integers(0, 4, size=n, dtype=np.uint8)            # BWT symbol per row: 0 A, 1 C, 2 G, 3 T
+    maskbits = rng.integers(0, 2, size=n, dtype=np.uint8)
+    hi = (sym >> 1).astype(np.uint8)                              # ac_gt: 1 for G/T
+    lo = (sym & 1).astype(np.uint8)
+    ac = lo[hi == 0]
+    gt = lo[hi == 1]
+
+    def words(bits):
+        pad = (-len(bits)) % 64
+        b = np.concatenate([bits, np.zeros(pad + 64, dtype=np.uint8)])
+        return np.packbits(b.reshape(-1, 8), axis=1, bitorder="little").reshape(-1).view(np.uint64).copy(), len(bits)
+
+    view, keep = fm.view_from_arrays(words(hi), words(ac), words(gt), words(maskbits), [1, 2, 3, 4], 0, 31)
+    nb = int(fm.lib().fmsi_host_layout_blocks(C.byref(view)))
+    blocks = np.zeros((nb, 16), dtype=np.uint32)
+    mrank = np.zeros(nb + 1, dtype=np.uint32)
+    assert fm.lib().fmsi_host_layout_build(C.byref(view), blocks.ctypes.data, mrank.ctypes.data) == 0
+    assert nb == (n + 127) // 128 + 1
+    rows = nb * 128
+    pad = lambda a: np.concatenate([a, np.zeros(rows - n, dtype=np.uint8)])
+    onehot = np.zeros((rows, 4), dtype=np.int64)
+    onehot[np.arange(n), sym] = 1
+    cum = np.concatenate([np.zeros((1, 4), dtype=np.int64), np.cumsum(onehot.reshape(nb, 128, 4).sum(axis=1), axis=0)])
+    assert np.array_equal(blocks[:, 0:4].astype(np.int64), cum[:-1])
+    plane = lambda bits: np.packbits(pad(bits).reshape(-1, 8), axis=1, bitorder="little").reshape(-1).view(np.uint32).reshape(nb, 4)
+    assert np.array_equal(blocks[:, 4:8], plane(hi))
+    assert np.array_equal(blocks[:, 8:12], plane(lo))
+    assert np.array_equal(blocks[:, 12:16], plane(maskbits))
+    mcum = np.concatenate([[0], np.cumsum(pad(maskbits).reshape(nb, 128).sum(axis=1))])
+    assert np.array_equal(mrank.astype(np.int64), mcum)
