@@ -182,36 +182,49 @@ int decode_rrr63(const uint8_t* data, size_t size, BitVector& out, std::string& 
 
 int load_host_index(const std::string& prefix, bool use_klcp, HostIndex& out, std::string& err) {
     const std::string base = prefix + ".fmsi";
-    auto load_bv = [&](const char* ext, BitVector& bv, bool required) -> int {
+    // the parts are independent files: read (and decode) them side by side, report the first failure in file order
+    int rcs[5] = {0, 0, 0, 0, 0};
+    std::string errs[5];
+    auto load_bv_t = [&](int slot, const char* ext, BitVector& bv, bool required) {
         std::vector<uint8_t> raw;
         if (!read_file(base + "." + ext, raw)) {
-            if (!required) return 1;
-            err = "cannot read " + base + "." + ext;
-            return FMSI_HIP_EIO;
+            if (!required) {
+                rcs[slot] = 1;
+                return;
+            }
+            errs[slot] = "cannot read " + base + "." + ext;
+            rcs[slot] = FMSI_HIP_EIO;
+            return;
         }
         Cursor cur{raw.data(), raw.size()};
         if (!cur.bit_vector(bv)) {
-            err = "malformed bit vector " + base + "." + ext;
-            return FMSI_HIP_EIO;
+            errs[slot] = "malformed bit vector " + base + "." + ext;
+            rcs[slot] = FMSI_HIP_EIO;
         }
-        return 0;
     };
-    int rc;
-    if ((rc = load_bv("ac_gt", out.ac_gt, true)) < 0) return rc;
-    if ((rc = load_bv("ac", out.ac, true)) < 0) return rc;
-    if ((rc = load_bv("gt", out.gt, true)) < 0) return rc;
     {
-        std::vector<uint8_t> raw;
-        if (!read_file(base + ".mask", raw)) {
-            err = "cannot read " + base + ".mask";
-            return FMSI_HIP_EIO;
+        std::vector<std::thread> pool;
+        pool.emplace_back([&] { load_bv_t(0, "ac_gt", out.ac_gt, true); });
+        pool.emplace_back([&] { load_bv_t(1, "ac", out.ac, true); });
+        pool.emplace_back([&] { load_bv_t(2, "gt", out.gt, true); });
+        if (use_klcp)   // fms_index.h:513-515: only when the file exists AND -S was given
+            pool.emplace_back([&] { load_bv_t(4, "klcp", out.klcp, false); });
+        {
+            std::vector<uint8_t> raw;
+            if (!read_file(base + ".mask", raw)) {
+                errs[3] = "cannot read " + base + ".mask";
+                rcs[3] = FMSI_HIP_EIO;
+            } else {
+                rcs[3] = std::min(0, decode_rrr63(raw.data(), raw.size(), out.mask, errs[3]));
+            }
         }
-        if ((rc = decode_rrr63(raw.data(), raw.size(), out.mask, err)) < 0) return rc;
+        for (auto& th : pool) th.join();
     }
-    if (use_klcp) {   // fms_index.h:513-515: only when the file exists AND -S was given
-        rc = load_bv("klcp", out.klcp, false);
-        if (rc < 0) return rc;
-    }
+    for (int slot = 0; slot < 5; ++slot)
+        if (rcs[slot] < 0) {
+            err = errs[slot];
+            return rcs[slot];
+        }
     {
         FILE* f = std::fopen((base + ".misc").c_str(), "r");
         if (!f) {
