@@ -643,7 +643,7 @@ __global__ __launch_bounds__(256) void lookup_lane_kernel(PairIndex ix, const ui
                 f = window_kmer(kmers, q + run_delta, k);
             }
         } else if (valid) {
-            f = kmers[q];
+            f = __builtin_nontemporal_load(kmers + q);   // (read once)
         }
         const uint32_t tidx = static_cast<uint32_t>(f >> (2u * R)) & tmask;
         uint32_t i_f = 0, j_f = 0, sf = 0;
@@ -691,7 +691,8 @@ __global__ __launch_bounds__(256) void lookup_lane_kernel(PairIndex ix, const ui
         const bool aligned = (reinterpret_cast<uintptr_t>(dst) & 15u) == 0;
         for (uint32_t off = lane * 16u; off < len; off += 64u * 16u) {
             if (aligned && off + 16u <= len) {
-                *reinterpret_cast<uint4*>(dst + off) = *reinterpret_cast<const uint4*>(res + off);
+                typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+                __builtin_nontemporal_store(*reinterpret_cast<const u32x4*>(res + off), reinterpret_cast<u32x4*>(dst + off));
             } else {
                 for (uint32_t b = off; b < min(len, off + 16u); ++b) dst[b] = res[b];
             }
