@@ -50,7 +50,7 @@ def _worker(rank, world, port, prefix, kmers_text, k, n, out_path):
         return (np.where(fwd != -1, fwd, rc) == 1).astype(np.uint8)   # -O schedule, forward strand first
 
     res = sharded_query(kmers, compute)
-    # ragged gather: 2 ranks, odd count
+    # ragged gather: an item count the world size does not divide
     t = torch.arange(*shard_range(n - 1, rank, world), dtype=torch.int64)
     g = gather_to_root(t, n - 1)
     if rank == 0:
@@ -63,7 +63,9 @@ def _worker(rank, world, port, prefix, kmers_text, k, n, out_path):
 
 
 @pytest.mark.timeout(300)
-def test_two_ranks_gloo_equal_single_process(tmp_path):
+@pytest.mark.parametrize("world", [2, 3, 5])
+def test_ranks_gloo_equal_single_process(tmp_path, world):
+    """World sizes 2, 3 and 5 over 4001 queries: shards of unequal length, rank order = output order."""
     import oracle_py
     from conftest import GOLDEN, index_prefix, mixed_kmers
     oracle_py.build_oracle()
@@ -76,7 +78,7 @@ def test_two_ranks_gloo_equal_single_process(tmp_path):
     fwd, rc = orc.ternaries_bulk(text, n, k, True)
     want = (np.where(fwd != -1, fwd, rc) == 1).astype(np.uint8)
     out = tmp_path / "res.npy"
-    mp.spawn(_worker, args=(2, _free_port(), prefix, text, k, n, str(out)), nprocs=2, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), prefix, text, k, n, str(out)), nprocs=world, join=True)
     got = np.load(out)
     assert np.array_equal(got, want)
     assert 0.4 < got.mean() < 0.6
