@@ -13,7 +13,10 @@ generated and indexed on the device, replicated per GPU):
   --workload stream  (config 4) reads of --read-len bases (half substrings of the superstring, half of those
                      reverse-complemented; half uniform random), `fmsi query -S -O`: fmsi_hip_query_stream (kLCP).
 The seeded, counter-based query stream is sharded across ranks by contiguous ranges -- weak scaling, no collective
-on the data path; the results of the last step are gathered to rank 0 over RCCL after the timed region.
+inside the search.  Results are bit-packed (FMSI_HIP_OUT_BITS: what the reference prints, one symbol per window,
+src/fms_index.h:305-309) and their way to the host is INSIDE the timed region: every step's words are gathered to rank 0
+over RCCL (N > 1) and copied to page-locked host memory on a copy stream, double-buffered against the next step's kernel
+(`--byte-results`: the round-1 form -- bytes left in HBM, gather after the timed region).
 
 Extra objects on the JSON line:
   roofline     -- HBM bound.  `achieved` = algorithmic bytes of one launch / average kernel duration.  The bytes are
@@ -79,6 +82,12 @@ def parse_args():
     ap.add_argument("--abi-gather", action="store_true",
                     help="after the timed region, also gather the results through fmsi_hip_gather (C-ABI, own RCCL communicator) and "
                          "compare with torch.distributed's gather")
+    ap.add_argument("--byte-results", action="store_true",
+                    help="one result byte per window and no device-to-host copy in the timed region (the round-1 form of the benchmark); "
+                         "default: FMSI_HIP_OUT_BITS -- bit-packed results, each step's words copied to page-locked host memory (double "
+                         "buffered) and, for N > 1, gathered to rank 0 over RCCL first, all inside the timed region")
+    ap.add_argument("--no-lf-leg", action="store_true", help="skip the table-less LF-walk legs (roofline.lf_path)")
+    ap.add_argument("--lf-steps", type=int, default=3, help="timed launches per LF-walk leg")
     ap.add_argument("--stream-via", choices=["klcp", "runs"], default="klcp",
                     help="stream workload: klcp = fmsi_hip_query_stream (the kLCP kernel, what -S means in the reference); runs = the same "
                          "windows through fmsi_hip_query_runs (phased kernels + candidate tables; same answers)")
@@ -197,7 +206,18 @@ def main():
         def launch(buf, out, counters_ptr=0, extra=0):
             index.query_kmers_dev(buf.data_ptr(), batch, k, flags | extra, out.data_ptr(), counters_ptr, stream)
 
-    d_out = torch.empty(batch, dtype=torch.uint8, device=dev_t)
+    # results: bit-packed words (default) -- two device buffers, two page-locked host buffers, a copy stream -- or bytes
+    bits = not args.byte_results
+    out_flag = fm.OUT_BITS if bits else 0
+    d_out = torch.empty(batch, dtype=torch.uint8, device=dev_t)                      # byte results (counted launches, checks)
+    n_words = fm.packed_words(batch, 0)
+    d_bits = [torch.zeros(n_words, dtype=torch.int64, device=dev_t) for _ in range(2)] if bits else None
+    root_words = n_words * (world if multi else 1)
+    d_gather = [torch.zeros(root_words, dtype=torch.int64, device=dev_t) for _ in range(2)] if (bits and multi and rank == 0) else None
+    h_bits = [torch.zeros(root_words, dtype=torch.int64).pin_memory() for _ in range(2)] if (bits and rank == 0) else None
+    copy_stream = torch.cuda.Stream(device=dev_t) if bits else None
+    ev_kernel = [torch.cuda.Event() for _ in range(2)]
+    ev_copied = [torch.cuda.Event() for _ in range(2)]
     d_cnt = torch.zeros(fm.N_COUNTERS, dtype=torch.int64, device=dev_t)
     n_buf = max(1, min(args.steps, 4))
     bufs = [torch.empty(in_words, dtype=torch.int64, device=dev_t) for _ in range(n_buf)]
@@ -227,17 +247,55 @@ def main():
 
     for s in range(n_buf):
         make_input(s + 1, bufs[s])
+    compute_stream = torch.cuda.current_stream()
+
+    def step(s):
+        """One pass of the hot path over one resident batch; with packed results also their way to the host: the kernel writes
+        d_bits[b], the copy stream -- behind the kernel's event -- gathers the ranks' words to rank 0 (N > 1) and copies them
+        to page-locked memory while the next step's kernel runs; a buffer is reused when its copy is done."""
+        if not bits:
+            launch(bufs[s % n_buf], d_out)
+            return
+        b = s & 1
+        compute_stream.wait_event(ev_copied[b])
+        launch(bufs[s % n_buf], d_bits[b], extra=out_flag)
+        ev_kernel[b].record(compute_stream)
+        with torch.cuda.stream(copy_stream):
+            copy_stream.wait_event(ev_kernel[b])
+            if multi:
+                dist.gather(d_bits[b], list(d_gather[b].chunk(world)) if rank == 0 else None, dst=0)
+                if rank == 0:
+                    h_bits[b].copy_(d_gather[b], non_blocking=True)
+            else:
+                h_bits[b].copy_(d_bits[b], non_blocking=True)
+            ev_copied[b].record(copy_stream)
+
+    if bits:   # one untimed pass through the copy path (first use of the copy stream, of the gather's communicator, of the pinned pages)
+        for b in range(2):
+            ev_copied[b].record(compute_stream)
+        step(0)
+        step(1)
     index.profile(True)
     index.profile_read(reset=True)
     barrier()   # (the first collective of the run also builds RCCL's communicator: twice, so that the timed one is warm)
     barrier()
     t0 = time.perf_counter()
     for s in range(args.steps):
-        launch(bufs[s % n_buf], d_out)
-    barrier()
+        step(s)
+    barrier()   # (torch.cuda.synchronize() inside: every stream of the device, the copy stream included)
     elapsed = time.perf_counter() - t0
     launches, kernel_ms = index.profile_read(reset=True)
     index.profile(False)
+    # the packed words that reached the host are the byte results of the same batch
+    bits_check = None
+    if bits and rank == 0:
+        last = args.steps - 1
+        launch(bufs[last % n_buf], d_out)
+        torch.cuda.synchronize()
+        got = fm.unpack_bits(h_bits[last & 1][:n_words].numpy().view(np.uint64), batch, 0)
+        bits_check = bool(np.array_equal(got, d_out.cpu().numpy()))
+        if not bits_check:
+            raise RuntimeError("bit-packed results on the host differ from the byte results of the same batch")
 
     el = torch.tensor([elapsed], dtype=torch.float64, device=dev_t)
     if multi:
@@ -246,30 +304,74 @@ def main():
 
     # gather the last step's results to rank 0 (rank order = output order); outside the timed region
     gather_note = None
-    if multi:
+    if multi and bits and rank == 0:   # the gather ran inside the timed region: rank 0's own words must have come through it
+        if not torch.equal(d_gather[(args.steps - 1) & 1][:n_words], d_bits[(args.steps - 1) & 1]):
+            raise RuntimeError("gathered results differ from rank 0's own")
+        gather_note = {"in_timed_region": True, "bytes_per_step": int(root_words * 8), "via": "torch.distributed.gather (RCCL)"}
+    if multi and not bits:
         parts = [torch.empty_like(d_out) for _ in range(world)] if rank == 0 else None
         dist.gather(d_out, parts, dst=0)
         if rank == 0 and not torch.equal(parts[0], d_out):
             raise RuntimeError("gathered results differ from rank 0's own")
     if args.abi_gather:
-        # the same gather through the C-ABI (fmsi_hip_gather over its own RCCL communicator), checked against the above
+        # the same gather through the C-ABI (fmsi_hip_gather over its own RCCL communicator), checked against the above;
+        # a mismatch or a failure ends the run with an error (the flag is an explicit request for this check)
         from fmsi_amd import sharding
-        try:
-            if multi:
-                comm = sharding.comm_from_process_group(local_rank)
+        last_b = (args.steps - 1) & 1
+        src = d_bits[last_b].view(torch.uint8) if bits else d_out
+        comm = sharding.comm_from_process_group(local_rank) if multi else fm.Comm(fm.Comm.unique_id(), 1, 0, local_rank)
+        t_g = time.perf_counter()
+        whole = sharding.gather_to_root_abi(comm, src, src.numel() * world, dst=0)
+        torch.cuda.synchronize()
+        t_g = time.perf_counter() - t_g
+        if rank == 0:
+            if bits:
+                ref = d_gather[last_b].view(torch.uint8) if multi else src
             else:
-                comm = fm.Comm(fm.Comm.unique_id(), 1, 0, local_rank)
-            t_g = time.perf_counter()
-            whole = sharding.gather_to_root_abi(comm, d_out, d_out.numel() * world, dst=0)
+                ref = torch.cat(parts) if multi else d_out
+            if not torch.equal(whole, ref):
+                raise RuntimeError("fmsi_hip_gather: MISMATCH with torch.distributed.gather")
+            gather_note = dict(gather_note or {}, fmsi_hip_gather="matches torch.distributed.gather", bytes=int(whole.numel()),
+                               seconds=round(t_g, 4))
+        comm.close()
+
+    # ---- the table-less LF walk (north_star's form: update_range steps only, src/fms_index.h:98-124) on the same index --------
+    # Timed legs of their own, rank 0 of the 1-GPU run: the two-base-step pair kernel and the lock-step baseline, both with
+    # FMSI_HIP_NO_PREFIX_TABLE, same resident batch, kernel time from the library's HIP events on the launch stream.
+    lf_path = None
+    if not args.no_lf_leg and not stream_mode and world == 1 and not args.no_counters and index.has_pair_layout:
+        lf_path = []
+        lf_out = d_bits[0] if bits else d_out
+        for name, kflag, block_b in (("query_pair_kernel<false,false,false> (two-base steps, 128-B blocks, no table)", fm.KERNEL_PAIR, 128),
+                                     ("query_lockstep_kernel<false> (one lane per k-mer, 64-B blocks, no table)", fm.KERNEL_LOCKSTEP, 64)):
+            base_flags = (flags & ~0xF0) | kflag | fm.NO_PREFIX_TABLE
+            d_cnt.zero_()
+            index.query_kmers_dev(bufs[0].data_ptr(), batch, k, base_flags, d_out.data_ptr(), d_cnt.data_ptr(), stream)
             torch.cuda.synchronize()
-            t_g = time.perf_counter() - t_g
-            if rank == 0:
-                same = torch.equal(whole, torch.cat(parts) if multi else d_out)
-                gather_note = {"fmsi_hip_gather": "matches torch.distributed.gather" if same else "MISMATCH",
-                               "bytes": int(whole.numel()), "seconds": round(t_g, 4)}
-            comm.close()
-        except Exception as e:   # the bench line must still be printed
-            gather_note = {"fmsi_hip_gather": f"failed: {e}"}
+            c = d_cnt.cpu().numpy().astype(np.int64)
+            index.profile(True)
+            index.profile_read(reset=True)
+            torch.cuda.synchronize()
+            t_l = time.perf_counter()
+            for s_ in range(args.lf_steps):
+                index.query_kmers_dev(bufs[s_ % n_buf].data_ptr(), batch, k, base_flags | out_flag, lf_out.data_ptr(), 0, stream)
+            torch.cuda.synchronize()
+            t_l = time.perf_counter() - t_l
+            l_n, l_ms = index.profile_read(reset=True)
+            index.profile(False)
+            k_s = l_ms / max(l_n, 1) / 1e3
+            # the layout's own bytes: one block per boundary read (128 B pair / 64 B single; [1] counts them, explicit mask
+            # probes included), the k-mers in, the packed results out; and SURVEY 8(d)'s canonical 256 B per LF step
+            alg = block_b * int(c[1]) + 8.0 * batch + (batch / 8.0 if bits else batch)
+            canon = 256 * int(c[0]) + 64 * int(c[2]) + 8.0 * batch + batch / 8.0
+            lf_path.append({"kernel": name, "prefix_table": 0, "ms": round(k_s * 1e3, 3), "launches": int(l_n),
+                            "wall_ms_per_step": round(t_l / args.lf_steps * 1e3, 3),
+                            "kmers_per_s": round(batch / k_s, 1), "lf_steps_per_kmer": round(int(c[0]) / batch, 3),
+                            "block_reads_per_kmer": round(int(c[1]) / batch, 3), "block_bytes": block_b,
+                            "algorithmic_bytes": int(alg), "achieved": round(alg / k_s / 1e9, 1), "frac": round(alg / k_s / 1e9 / HBM_PEAK_GBS, 4),
+                            "random_requests_per_s": round(int(c[1]) / k_s / 1e9, 2),
+                            "canonical_bytes": int(canon), "canonical_achieved": round(canon / k_s / 1e9, 1),
+                            "canonical_frac": round(canon / k_s / 1e9 / HBM_PEAK_GBS, 4)})
 
     if rank == 0:
         total_q = batch * world * args.steps
@@ -289,7 +391,8 @@ def main():
             lane_lookups = (not stream_mode or args.stream_via == "runs") and args.kernel == "phased" and entry_b and k - int(index.info.prefix_len) <= 15
             lookup_b = 64
             entry_used_b = entry_b if lane_lookups else 64
-            bytes_launch = block_b * (blocks_read - lookups) + lookup_b * lookups + 8 * klcp_words + in_bytes + 1 * batch
+            out_b = batch / 8.0 if bits else 1.0 * batch   # packed: one bit per window
+            bytes_launch = block_b * (blocks_read - lookups) + lookup_b * lookups + 8 * klcp_words + in_bytes + out_b
             bytes_launch += 32 * verify_reads   # counted as two 32-byte sectors per verification
             # (phased form: the work items of the searches left to the stepping kernel -- 48 bytes for about 3 % of the k-mers -- are not counted)
             canon_bytes = 256 * int(canonical[0]) + 64 * int(canonical[2]) + 8 * int(canonical[5]) + in_bytes + batch // 8
@@ -318,7 +421,8 @@ def main():
                     "useful_frac": round((bytes_launch - (lookup_b - entry_used_b) * lookups) / avg_kernel_s / 1e9 / HBM_PEAK_GBS, 4),
                     "canonical_lf_steps_per_kmer": round(int(canonical[0]) / batch, 3),
                     "canonical_achieved": round(canon_bytes / avg_kernel_s / 1e9, 1),
-                    "canonical_frac": round(canon_bytes / avg_kernel_s / 1e9 / HBM_PEAK_GBS, 4)}
+                    "canonical_frac": round(canon_bytes / avg_kernel_s / 1e9 / HBM_PEAK_GBS, 4),
+                    "lf_path": lf_path}
         info = index.info
         if stream_mode:
             wl = (f"synthetic max-ones masked superstring n={n} (human-genome scale), reads of {args.read_len} bases (50% from the "
@@ -340,6 +444,9 @@ def main():
                        "candidate_entry_bytes": int(info.candidate_entry_bytes),
                        "block_bytes": 128 if (args.kernel in ("pair", "phased") and not stream_mode) or (stream_mode and args.stream_via == "runs") else 64,
                        "parallelism": f"query-sharded x{world}, index replicated", "positive_fraction": round(positives, 4),
+                       "results": ("bit-packed (FMSI_HIP_OUT_BITS), copied to page-locked host memory inside the timed region"
+                                   + (", after the RCCL gather to rank 0" if multi else "")) if bits else "one byte per window, left in HBM",
+                       "results_on_host_match_bytes": bits_check,
                        "index_build_seconds": round(build_s, 2)},
             "roofline": roof,
             "cpu_baseline": None,

@@ -30,6 +30,7 @@ KERNEL_REFILL = 0x20
 KERNEL_PAIR = 0x30
 KERNEL_PHASED = 0x40
 NO_PREFIX_TABLE = 0x100
+OUT_BITS = 0x200
 N_COUNTERS = 8
 
 E_INVAL, E_NODEV, E_HIP, E_NOMEM, E_IO, E_RANGE, E_COMM = -1, -2, -3, -4, -5, -6, -7
@@ -313,10 +314,13 @@ class DeviceIndex:
         """Write the index as the reference's <prefix>.fmsi.* files (fmsi_hip_index_write_files)."""
         _check(lib().fmsi_hip_index_write_files(self._h, os.fsencode(prefix)))
 
+    has_pair_layout = False
+
     def enable_pair_layout(self):
         """Add the 128-B two-base-step layout (fmsi_hip_index_enable_pair_layout); AUTO kernels then use it."""
         _check(lib().fmsi_hip_index_enable_pair_layout(self._h))
         _check(lib().fmsi_hip_index_get_info(self._h, C.byref(self.info)))
+        self.has_pair_layout = True
         return self
 
     def enable_verify(self):
@@ -432,6 +436,8 @@ class DeviceIndex:
     def _alloc_out(n: int, flags: int) -> np.ndarray:
         if flags & ORDERS:
             return np.zeros((n, 2) if flags & STRICT else n, dtype=np.int64)
+        if flags & OUT_BITS:   # u64 words: 1 bit per window, STRICT: one nibble
+            return np.zeros((n + 15) // 16 if flags & STRICT else (n + 63) // 64, dtype=np.uint64)
         return np.zeros(n, dtype=np.uint8)
 
     def close(self):
@@ -483,6 +489,19 @@ def synthetic_text(length: int, seed: int, k: int) -> bytes:
 def decode_strict(out: np.ndarray):
     """Split STRICT presence bytes into (fwd, rc) int8 arrays with values in {-1, 0, 1}."""
     return (out & 3).astype(np.int8) - 1, ((out >> 2) & 3).astype(np.int8) - 1
+
+
+def packed_words(n: int, flags: int) -> int:
+    """u64 words of an OUT_BITS result buffer over n windows."""
+    return (n + 15) // 16 if flags & STRICT else (n + 63) // 64
+
+
+def unpack_bits(words: np.ndarray, n: int, flags: int) -> np.ndarray:
+    """OUT_BITS result words -> the one-byte-per-window form of the same call without the flag."""
+    raw = np.ascontiguousarray(words, dtype=np.uint64).view(np.uint8)
+    if flags & STRICT:
+        return np.stack([raw & 0xF, raw >> 4], axis=1).reshape(-1)[:n].astype(np.uint8)
+    return np.unpackbits(raw, bitorder="little")[:n]
 
 
 def run_cli(args, stdin: bytes | None = None):

@@ -453,7 +453,7 @@ int check_device(int device) {
         set_last_error("no usable HIP device (libfmsi_hip has no CPU fallback)");
         return FMSI_HIP_ENODEV;
     }
-    FMSI_HIP_TRY(hipSetDevice(device));
+    FMSI_HIP_ON_DEVICE(device);
     return 0;
 }
 
@@ -583,7 +583,7 @@ int fmsi_hip_synthetic_queries(fmsi_hip_index* idx, int k, uint64_t seed, uint64
         return FMSI_HIP_EINVAL;
     }
     if (n == 0) return 0;
-    FMSI_HIP_TRY(hipSetDevice(idx->device));
+    FMSI_HIP_ON_DEVICE(idx->device);
     hipLaunchKernelGGL(synth_queries_kernel, dim3(grid_for(n)), dim3(256), 0, static_cast<hipStream_t>(stream),
                        static_cast<const uint64_t*>(idx->d_text2), idx->text_len, k, seed, first, n, d_kmers);
     FMSI_HIP_TRY(hipGetLastError());
@@ -597,7 +597,7 @@ int fmsi_hip_synthetic_reads(fmsi_hip_index* idx, uint64_t read_len, uint64_t se
         return FMSI_HIP_EINVAL;
     }
     if (n_reads == 0) return 0;
-    FMSI_HIP_TRY(hipSetDevice(idx->device));
+    FMSI_HIP_ON_DEVICE(idx->device);
     const uint64_t n_words = (n_reads * read_len) / 32 + 2;
     hipLaunchKernelGGL(synth_reads_kernel, dim3(grid_for(n_words)), dim3(256), 0, static_cast<hipStream_t>(stream),
                        static_cast<const uint64_t*>(idx->d_text2), idx->text_len, read_len, seed, first_read, n_reads, subst_per_million,
@@ -608,7 +608,7 @@ int fmsi_hip_synthetic_reads(fmsi_hip_index* idx, uint64_t read_len, uint64_t se
 
 int fmsi_hip_index_download_text(const fmsi_hip_index* idx, uint64_t* words) {
     if (!idx || !words || !idx->d_text2) return FMSI_HIP_EINVAL;
-    FMSI_HIP_TRY(hipSetDevice(idx->device));
+    FMSI_HIP_ON_DEVICE(idx->device);
     FMSI_HIP_TRY(hipMemcpy(words, idx->d_text2, ((idx->text_len >> 5) + 2) * 8, hipMemcpyDeviceToHost));
     return 0;
 }

@@ -111,7 +111,7 @@ int fmsi_hip_comm_create(const uint8_t* id, int world, int rank, int device, fms
     }
     int rc = load_rccl();
     if (rc) return rc;
-    FMSI_HIP_TRY(hipSetDevice(device));
+    FMSI_HIP_ON_DEVICE(device);
     ncclUniqueId u;
     std::memcpy(&u, id, sizeof(u));
     ncclComm_t comm = nullptr;
@@ -128,7 +128,7 @@ int fmsi_hip_comm_create(const uint8_t* id, int world, int rank, int device, fms
 void fmsi_hip_comm_destroy(fmsi_hip_comm* comm) {
     if (!comm) return;
     if (comm->comm && g_rccl.handle) {
-        (void)hipSetDevice(comm->device);
+        ::fmsi::DeviceGuard device_guard_(comm->device);
         g_rccl.CommDestroy(comm->comm);
     }
     delete comm;
@@ -148,7 +148,7 @@ int fmsi_hip_gather(fmsi_hip_comm* comm, const void* d_send, uint64_t send_bytes
         fmsi::set_last_error("fmsi_hip_gather: send_bytes differs from this rank's entry of bytes_per_rank");
         return FMSI_HIP_EINVAL;
     }
-    FMSI_HIP_TRY(hipSetDevice(comm->device));
+    FMSI_HIP_ON_DEVICE(comm->device);
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (comm->rank != root) {
         if (send_bytes) FMSI_RCCL_TRY(g_rccl.Send(d_send, send_bytes, ncclUint8, root, comm->comm, s));

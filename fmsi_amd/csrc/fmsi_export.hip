@@ -142,7 +142,7 @@ extern "C" int fmsi_hip_index_export(const fmsi_hip_index* idx, char* out, uint6
         return FMSI_HIP_EINVAL;
     }
     if (text_len == 0) return 0;
-    FMSI_HIP_TRY(hipSetDevice(idx->device));
+    FMSI_HIP_ON_DEVICE(idx->device);
     char* d_out = nullptr;
     if (hipMalloc(reinterpret_cast<void**>(&d_out), text_len) != hipSuccess) {
         set_last_error("hipMalloc failed for the export buffers");

@@ -349,6 +349,39 @@ __global__ __launch_bounds__(256) void expand_runs_kernel(const uint64_t* __rest
     }
 }
 
+// FMSI_HIP_OUT_BITS for the kernels that write result bytes: n bytes -> one bit per window (bit w & 63 of u64 word w >> 6), STRICT:
+// one nibble (nibble w & 15 of word w >> 4).  One thread per output word; a streaming pass of n bytes in, n / 8 (n / 2) out.
+template <bool STRICT>
+__global__ __launch_bounds__(256) void pack_results_kernel(const uint8_t* __restrict__ bytes, uint64_t n, unsigned long long* __restrict__ out) {
+    constexpr uint32_t per_word = STRICT ? 16u : 64u;
+    const uint64_t words = (n + per_word - 1) / per_word;
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
+    const bool aligned = (reinterpret_cast<uintptr_t>(bytes) & 15u) == 0;
+    for (uint64_t w = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; w < words; w += stride) {
+        const uint64_t first = w * per_word;
+        unsigned long long v = 0;
+        if (aligned && first + per_word <= n) {
+            const uint4* src = reinterpret_cast<const uint4*>(bytes + first);
+            if (STRICT) {
+                const uint4 x = src[0];
+                auto nib = [](uint32_t d) -> unsigned long long { return (d & 0xFu) | ((d >> 4) & 0xF0u) | ((d >> 8) & 0xF00u) | ((d >> 12) & 0xF000u); };
+                v = nib(x.x) | (nib(x.y) << 16) | (nib(x.z) << 32) | (nib(x.w) << 48);
+            } else {
+#pragma unroll
+                for (uint32_t q = 0; q < 4u; ++q) {
+                    const uint4 x = src[q];
+                    auto bits4 = [](uint32_t d) -> unsigned long long { return (((d & 0x01010101u) * 0x10204080u) >> 28) & 0xFu; };
+                    v |= (bits4(x.x) | (bits4(x.y) << 4) | (bits4(x.z) << 8) | (bits4(x.w) << 12)) << (16u * q);
+                }
+            }
+        } else {
+            for (uint32_t b = 0; b < per_word && first + b < n; ++b)
+                v |= static_cast<unsigned long long>(STRICT ? (bytes[first + b] & 0xFu) : (bytes[first + b] & 1u)) << ((STRICT ? 4u : 1u) * b);
+        }
+        out[w] = v;
+    }
+}
+
 // one level of the prefix table: entry idx of level L = LF step with base (idx & 3) on entry idx >> 2 of level L-1
 __global__ __launch_bounds__(256) void ptable_level_kernel(DevIndex ix, const uint2* __restrict__ prev, uint2* __restrict__ cur,
                                                            uint64_t count) {
@@ -487,6 +520,19 @@ int build_prefix_table(fmsi_hip_index* idx, int t) {
     return 0;
 }
 
+int launch_pack_results(const uint8_t* d_bytes, uint64_t n, bool strict, void* d_out, hipStream_t s) {
+    if (reinterpret_cast<uintptr_t>(d_out) & 7u) {
+        set_last_error("FMSI_HIP_OUT_BITS needs an 8-byte aligned output buffer");
+        return FMSI_HIP_EINVAL;
+    }
+    const uint64_t words = (n + (strict ? 15 : 63)) / (strict ? 16 : 64);
+    const uint32_t blocks = static_cast<uint32_t>(std::min<uint64_t>((words + 255) / 256, 1u << 16));
+    if (strict) hipLaunchKernelGGL((pack_results_kernel<true>), dim3(blocks), dim3(256), 0, s, d_bytes, n, static_cast<unsigned long long*>(d_out));
+    else hipLaunchKernelGGL((pack_results_kernel<false>), dim3(blocks), dim3(256), 0, s, d_bytes, n, static_cast<unsigned long long*>(d_out));
+    FMSI_HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 }  // namespace fmsi
 
 using namespace fmsi;
@@ -516,9 +562,23 @@ int launch_query(fmsi_hip_index* idx, const uint64_t* d_kmers, uint64_t n_window
     long long* o64 = static_cast<long long*>(d_out);
     const uint32_t kernel = flags & FMSI_HIP_KERNEL_MASK;
     const bool use_table = idx->d_ptable && !(flags & FMSI_HIP_NO_PREFIX_TABLE) && k >= idx->prefix_len;
+    int rc;
+    // FMSI_HIP_OUT_BITS: the one-lane lookup kernel and its stepping kernel pack their results themselves; every other
+    // kernel writes its bytes to a scratch buffer that one streaming pass packs (inside the profiled region)
+    const bool phased = (kernel == FMSI_HIP_KERNEL_PHASED || kernel == FMSI_HIP_KERNEL_AUTO) && idx->d_pblocks && use_table;
+    const bool want_bits = (flags & FMSI_HIP_OUT_BITS) && !(flags & FMSI_HIP_ORDERS);
+    const bool pack_after = want_bits && !(phased && phased_packs_bits(idx, k, flags));
+    if (!want_bits || pack_after) flags &= ~FMSI_HIP_OUT_BITS;
+    if (want_bits && (reinterpret_cast<uintptr_t>(d_out) & 7u)) {
+        set_last_error("FMSI_HIP_OUT_BITS needs an 8-byte aligned output buffer");
+        return FMSI_HIP_EINVAL;
+    }
+    if (pack_after) {
+        if ((rc = ensure_cap(&idx->d_bytes, &idx->d_bytes_cap, n_windows))) return rc;
+        o8 = static_cast<uint8_t*>(idx->d_bytes);
+    }
     size_t slot;
-    int rc = prof_begin(idx, s, &slot);
-    if (rc) return rc;
+    if ((rc = prof_begin(idx, s, &slot))) return rc;
     if (kernel == FMSI_HIP_KERNEL_LOCKSTEP) {
         const uint64_t blocks64 = (n_windows + 255) / 256;
         if (blocks64 > 0x7FFFFFFFull) {
@@ -530,7 +590,7 @@ int launch_query(fmsi_hip_index* idx, const uint64_t* d_kmers, uint64_t n_window
             hipLaunchKernelGGL((query_lockstep_kernel<true>), grid, block, 0, s, idx->dev, d_kmers, n_windows, k, flags, o8, o64, d_counters);
         else
             hipLaunchKernelGGL((query_lockstep_kernel<false>), grid, block, 0, s, idx->dev, d_kmers, n_windows, k, flags, o8, o64, d_counters);
-    } else if ((kernel == FMSI_HIP_KERNEL_PHASED || kernel == FMSI_HIP_KERNEL_AUTO) && idx->d_pblocks && use_table) {
+    } else if (phased) {
         if ((rc = launch_phased_query(idx, d_kmers, n_windows, k, flags, o8, o64, d_counters, s))) return rc;
     } else if (kernel == FMSI_HIP_KERNEL_PAIR || kernel == FMSI_HIP_KERNEL_PHASED || (kernel == FMSI_HIP_KERNEL_AUTO && idx->d_pblocks)) {
         // (PHASED without a usable table is the one-kernel form)
@@ -547,13 +607,22 @@ int launch_query(fmsi_hip_index* idx, const uint64_t* d_kmers, uint64_t n_window
         else launch_refill<false, false>(idx, d_kmers, n_windows, k, flags, o8, o64, d_counters, s);
     }
     FMSI_HIP_TRY(hipGetLastError());
+    if (pack_after && (rc = launch_pack_results(o8, n_windows, flags & FMSI_HIP_STRICT, d_out, s))) return rc;
     return prof_end(idx, s, slot);
 }
 
-size_t out_elem_bytes(uint32_t flags) {
-    if (flags & FMSI_HIP_ORDERS) return (flags & FMSI_HIP_STRICT) ? 16 : 8;
-    return 1;
+}  // namespace
+
+namespace fmsi {
+// bytes of the result buffer of a query call over n_windows windows
+size_t out_buffer_bytes(uint64_t n_windows, uint32_t flags) {
+    if (flags & FMSI_HIP_ORDERS) return n_windows * ((flags & FMSI_HIP_STRICT) ? 16 : 8);
+    if (flags & FMSI_HIP_OUT_BITS) return ((flags & FMSI_HIP_STRICT) ? (n_windows + 15) / 16 : (n_windows + 63) / 64) * 8;
+    return n_windows;
 }
+}  // namespace fmsi
+
+namespace {
 
 int check_query_args(const fmsi_hip_index* idx, const void* in, const void* out, int k, int k_max) {
     if (!idx || !in || !out) {
@@ -570,9 +639,9 @@ int check_query_args(const fmsi_hip_index* idx, const void* in, const void* out,
 // Common path of the query entry points.  input_kind 0: `in` = packed k-mers; 1: `in` = packed sequence (+ window starts)
 int run_query(fmsi_hip_index* idx, int input_kind, const uint64_t* in, size_t in_bytes, const uint64_t* wstart, uint64_t n_windows,
               int k, uint32_t flags, void* out, uint64_t* counters, void* stream) {
-    FMSI_HIP_TRY(hipSetDevice(idx->device));
+    FMSI_HIP_ON_DEVICE(idx->device);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const size_t out_bytes = n_windows * out_elem_bytes(flags);
+    const size_t out_bytes = out_buffer_bytes(n_windows, flags);
     const uint64_t* d_in = in;
     const uint64_t* d_ws = wstart;
     void* d_out = out;
@@ -599,10 +668,13 @@ int run_query(fmsi_hip_index* idx, int input_kind, const uint64_t* in, size_t in
     if (input_kind == 1 && k > 32) {
         // the k-mer does not fit a register pair: walk the window off the packed sequence (fmsi_longk.hip)
         if (n_windows == 0) return 0;
+        PackAfter pack;
+        if ((rc = pack.begin(idx, flags, n_windows, d_out))) return rc;
         size_t slot;
         if ((rc = prof_begin(idx, s, &slot))) return rc;
-        launch_longk_query(idx, d_in, d_ws, n_windows, k, flags, static_cast<uint8_t*>(d_out), static_cast<long long*>(d_out), d_cnt, s);
+        launch_longk_query(idx, d_in, d_ws, n_windows, k, flags, pack.bytes, static_cast<long long*>(d_out), d_cnt, s);
         FMSI_HIP_TRY(hipGetLastError());
+        if ((rc = pack.end(n_windows, flags, d_out, s))) return rc;
         if ((rc = prof_end(idx, s, slot))) return rc;
         if (!dev_ptrs) {
             if (out_bytes) FMSI_HIP_TRY(hipMemcpyAsync(out, idx->d_out, out_bytes, hipMemcpyDeviceToHost, s));
@@ -658,7 +730,7 @@ int fmsi_hip_index_create(const fmsi_index_view* view, int device, fmsi_hip_inde
         set_last_error("no usable HIP device (libfmsi_hip has no CPU fallback)");
         return FMSI_HIP_ENODEV;
     }
-    FMSI_HIP_TRY(hipSetDevice(device));
+    FMSI_HIP_ON_DEVICE(device);
     HostLayout L;
     int rc = build_layout(*view, L);
     if (rc) return rc;
@@ -714,10 +786,15 @@ int fmsi_hip_index_create(const fmsi_index_view* view, int device, fmsi_hip_inde
 
 void fmsi_hip_index_destroy(fmsi_hip_index* idx) {
     if (!idx) return;
-    (void)hipSetDevice(idx->device);
+    ::fmsi::DeviceGuard device_guard_(idx->device);
     for (void* p : {idx->d_blocks, idx->d_mrank, idx->d_ptable, idx->d_klcp, idx->d_text2, idx->d_stable, idx->d_vtable, idx->d_in, idx->d_aux, idx->d_out,
-                    idx->d_kmers, idx->d_tasks, idx->d_pblocks, idx->d_sbt, idx->d_c2, static_cast<void*>(idx->d_counters)})
+                    idx->d_kmers, idx->d_tasks, idx->d_bytes, idx->d_pblocks, idx->d_sbt, idx->d_c2, static_cast<void*>(idx->d_counters)})
         if (p) (void)hipFree(p);
+    for (auto& m : idx->meta_ring) {
+        if (m.in_flight) (void)hipEventSynchronize(m.done);
+        if (m.host) (void)hipHostFree(m.host);
+        if (m.done) (void)hipEventDestroy(m.done);
+    }
     for (auto& e : idx->events) {
         (void)hipEventDestroy(e.first);
         (void)hipEventDestroy(e.second);
@@ -747,7 +824,7 @@ int fmsi_hip_index_get_info(const fmsi_hip_index* idx, fmsi_hip_index_info* info
 
 int fmsi_hip_index_download_layout(const fmsi_hip_index* idx, uint32_t* blocks, uint32_t* mrank) {
     if (!idx || !blocks || !mrank) return FMSI_HIP_EINVAL;
-    FMSI_HIP_TRY(hipSetDevice(idx->device));
+    FMSI_HIP_ON_DEVICE(idx->device);
     FMSI_HIP_TRY(hipMemcpy(blocks, idx->d_blocks, idx->n_blocks * kBlockBytes, hipMemcpyDeviceToHost));
     FMSI_HIP_TRY(hipMemcpy(mrank, idx->d_mrank, (idx->n_blocks + 1) * 4, hipMemcpyDeviceToHost));
     return 0;
@@ -755,7 +832,7 @@ int fmsi_hip_index_download_layout(const fmsi_hip_index* idx, uint32_t* blocks, 
 
 int fmsi_hip_index_write_files(const fmsi_hip_index* idx, const char* prefix) {
     if (!idx || !prefix) return FMSI_HIP_EINVAL;
-    FMSI_HIP_TRY(hipSetDevice(idx->device));
+    FMSI_HIP_ON_DEVICE(idx->device);
     std::vector<uint32_t> blocks(idx->n_blocks * kBlockDwords);
     FMSI_HIP_TRY(hipMemcpy(blocks.data(), idx->d_blocks, blocks.size() * 4, hipMemcpyDeviceToHost));
     HostVectors hv;
@@ -791,7 +868,7 @@ int fmsi_hip_index_download_klcp(const fmsi_hip_index* idx, uint64_t* words) {
         set_last_error("the handle holds no kLCP array");
         return FMSI_HIP_EINVAL;
     }
-    FMSI_HIP_TRY(hipSetDevice(idx->device));
+    FMSI_HIP_ON_DEVICE(idx->device);
     FMSI_HIP_TRY(hipMemcpy(words, idx->d_klcp, ((idx->n + 63) / 64) * 8, hipMemcpyDeviceToHost));
     return 0;
 }
@@ -814,8 +891,15 @@ int fmsi_hip_query_runs(fmsi_hip_index* idx, const uint64_t* packed_seq, uint64_
         set_last_error("null argument");
         return FMSI_HIP_EINVAL;
     }
-    // [0, n_runs): run starts, [n_runs, 2 n_runs + 1): exclusive prefix sums of the run lengths
-    std::vector<uint64_t> meta(2 * n_runs + 1);
+    FMSI_HIP_ON_DEVICE(idx->device);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    // [0, n_runs): run starts, [n_runs, 2 n_runs + 1): exclusive prefix sums of the run lengths -- in a page-locked slot
+    // of the handle's ring, so that nothing has to wait for the copy (the call stays asynchronous on `stream`)
+    void* meta_host = nullptr;
+    unsigned meta_slot = 0;
+    if ((rc = meta_stage(idx, (2 * n_runs + 1) * 8, &meta_host, &meta_slot))) return rc;
+    uint64_t* meta = static_cast<uint64_t*>(meta_host);
+    const size_t meta_words = 2 * n_runs + 1;
     uint64_t total = 0;
     for (uint64_t r = 0; r < n_runs; ++r) {
         if (run_windows[r] == 0 || run_start[r] + run_windows[r] + static_cast<uint64_t>(k) - 1 > seq_bases) {
@@ -831,9 +915,7 @@ int fmsi_hip_query_runs(fmsi_hip_index* idx, const uint64_t* packed_seq, uint64_
         set_last_error("n_windows does not equal the sum of run_windows");
         return FMSI_HIP_EINVAL;
     }
-    FMSI_HIP_TRY(hipSetDevice(idx->device));
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    const size_t out_bytes = n_windows * out_elem_bytes(flags);
+    const size_t out_bytes = out_buffer_bytes(n_windows, flags);
     const size_t seq_bytes = (seq_bases / 32 + 2) * 8;
     const bool dev_ptrs = flags & FMSI_HIP_DEVICE_PTRS;
     const uint64_t* d_seq = packed_seq;
@@ -854,11 +936,16 @@ int fmsi_hip_query_runs(fmsi_hip_index* idx, const uint64_t* packed_seq, uint64_
     if (k <= 32 && (kernel == FMSI_HIP_KERNEL_PHASED || kernel == FMSI_HIP_KERNEL_AUTO) && idx->d_pblocks && idx->d_ptable &&
         !(flags & FMSI_HIP_NO_PREFIX_TABLE) && k >= idx->prefix_len && n_windows <= (1ull << 38)) {
         // the phased kernels cut the windows themselves: no pass that writes 8 bytes per window and reads them back
+        PackAfter pack;   // (the one-lane lookup kernel packs FMSI_HIP_OUT_BITS output itself)
+        uint32_t kflags = flags;
+        if (!phased_packs_bits(idx, k, flags) && (rc = pack.begin(idx, kflags, n_windows, d_out))) return rc;
         size_t slot;
         if ((rc = prof_begin(idx, s, &slot))) return rc;
-        if ((rc = launch_phased_query(idx, d_seq, n_windows, k, flags, static_cast<uint8_t*>(d_out), static_cast<long long*>(d_out), d_cnt, s,
-                                      meta.data(), n_runs)))
+        if ((rc = launch_phased_query(idx, d_seq, n_windows, k, kflags, pack.on ? pack.bytes : static_cast<uint8_t*>(d_out),
+                                      static_cast<long long*>(d_out), d_cnt, s, meta, n_runs)))
             return rc;
+        if ((rc = meta_commit(idx, meta_slot, s))) return rc;
+        if ((rc = pack.end(n_windows, flags, d_out, s))) return rc;
         if ((rc = prof_end(idx, s, slot))) return rc;
         if (!dev_ptrs) {
             if (out_bytes) FMSI_HIP_TRY(hipMemcpyAsync(out, idx->d_out, out_bytes, hipMemcpyDeviceToHost, s));
@@ -866,9 +953,9 @@ int fmsi_hip_query_runs(fmsi_hip_index* idx, const uint64_t* packed_seq, uint64_
         }
         return 0;
     }
-    if ((rc = ensure_cap(&idx->d_tasks, &idx->d_tasks_cap, meta.size() * 8))) return rc;
-    FMSI_HIP_TRY(hipMemcpyAsync(idx->d_tasks, meta.data(), meta.size() * 8, hipMemcpyHostToDevice, s));
-    FMSI_HIP_TRY(hipStreamSynchronize(s));   // `meta` is a local vector
+    if ((rc = ensure_cap(&idx->d_tasks, &idx->d_tasks_cap, meta_words * 8))) return rc;
+    FMSI_HIP_TRY(hipMemcpyAsync(idx->d_tasks, meta, meta_words * 8, hipMemcpyHostToDevice, s));
+    if ((rc = meta_commit(idx, meta_slot, s))) return rc;
     const uint64_t* d_rs = static_cast<const uint64_t*>(idx->d_tasks);
     const uint64_t* d_ro = d_rs + n_runs;
     const uint32_t blocks = static_cast<uint32_t>(std::min<uint64_t>((n_windows + 255) / 256, 256 * 16));
@@ -877,11 +964,15 @@ int fmsi_hip_query_runs(fmsi_hip_index* idx, const uint64_t* packed_seq, uint64_
         hipLaunchKernelGGL((expand_runs_kernel<false>), dim3(blocks), dim3(256), 0, s, d_seq, d_rs, d_ro, n_runs, n_windows, k,
                            static_cast<uint64_t*>(idx->d_aux));
         FMSI_HIP_TRY(hipGetLastError());
+        PackAfter pack;
+        uint32_t kflags = flags;
+        if ((rc = pack.begin(idx, kflags, n_windows, d_out))) return rc;
         size_t slot;
         if ((rc = prof_begin(idx, s, &slot))) return rc;
-        launch_longk_query(idx, d_seq, static_cast<const uint64_t*>(idx->d_aux), n_windows, k, flags, static_cast<uint8_t*>(d_out),
+        launch_longk_query(idx, d_seq, static_cast<const uint64_t*>(idx->d_aux), n_windows, k, kflags, pack.bytes,
                            static_cast<long long*>(d_out), d_cnt, s);
         FMSI_HIP_TRY(hipGetLastError());
+        if ((rc = pack.end(n_windows, flags, d_out, s))) return rc;
         if ((rc = prof_end(idx, s, slot))) return rc;
     } else {
         if ((rc = ensure_cap(&idx->d_kmers, &idx->d_kmers_cap, n_windows * 8))) return rc;
@@ -913,7 +1004,7 @@ int fmsi_hip_query_windows(fmsi_hip_index* idx, const uint64_t* packed_seq, uint
 
 int fmsi_hip_sync(fmsi_hip_index* idx, void* stream) {
     if (!idx) return FMSI_HIP_EINVAL;
-    FMSI_HIP_TRY(hipSetDevice(idx->device));
+    FMSI_HIP_ON_DEVICE(idx->device);
     FMSI_HIP_TRY(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
     return 0;
 }
@@ -940,7 +1031,7 @@ int fmsi_hip_profile_enable(fmsi_hip_index* idx, int on) {
 
 int fmsi_hip_profile_read(fmsi_hip_index* idx, uint64_t* n_launches, double* total_ms, int reset) {
     if (!idx) return FMSI_HIP_EINVAL;
-    FMSI_HIP_TRY(hipSetDevice(idx->device));
+    FMSI_HIP_ON_DEVICE(idx->device);
     for (size_t e = 0; e < idx->events_used; ++e) {
         FMSI_HIP_TRY(hipEventSynchronize(idx->events[e].second));
         float ms = 0;

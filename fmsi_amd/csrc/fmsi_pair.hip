@@ -415,6 +415,37 @@ __device__ __forceinline__ uint4 load16_once(const uint4* p) {
     return make_uint4(t.x, t.y, t.z, t.w);
 }
 
+// FMSI_HIP_OUT_BITS: a chunk's result bytes (LDS, `len` of them, the chunk starting at window `start`, a multiple of 128) leave
+// bit-packed -- window w is bit w & 63 of u64 word w >> 6 (its byte's bit 0), STRICT: nibble w & 15 of word w >> 4 (the byte's low
+// four bits: (fwd + 1) | (rc + 1) << 2).  One 8-byte store per 64 (16) windows instead of 64 (16) bytes.
+__device__ __forceinline__ void flush_packed(const uint8_t* res, uint32_t len, bool strict, uint8_t* out, uint64_t start, uint32_t lane) {
+    unsigned long long* dst = reinterpret_cast<unsigned long long*>(out);
+    if (!strict) {
+        const uint32_t words = (len + 63u) >> 6;
+        for (uint32_t w = lane; w < words; w += 64u) {
+            const uint64_t* src = reinterpret_cast<const uint64_t*>(res + 64u * w);
+            unsigned long long v = 0;
+#pragma unroll
+            for (uint32_t b = 0; b < 8u; ++b) v |= (((src[b] & 0x0101010101010101ull) * 0x0102040810204080ull) >> 56) << (8u * b);
+            const uint32_t valid = len - 64u * w;
+            if (valid < 64u) v &= (1ull << valid) - 1ull;
+            __builtin_nontemporal_store(v, dst + (start >> 6) + w);
+        }
+    } else {
+        const uint32_t words = (len + 15u) >> 4;
+        for (uint32_t w = lane; w < words; w += 64u) {
+            const uint4 x = *reinterpret_cast<const uint4*>(res + 16u * w);
+            auto nib = [](uint32_t d) -> unsigned long long {
+                return (d & 0xFu) | ((d >> 4) & 0xF0u) | ((d >> 8) & 0xF00u) | ((d >> 12) & 0xF000u);
+            };
+            unsigned long long v = nib(x.x) | (nib(x.y) << 16) | (nib(x.z) << 32) | (nib(x.w) << 48);
+            const uint32_t valid = len - 16u * w;
+            if (valid < 16u) v &= (1ull << (4u * valid)) - 1ull;
+            __builtin_nontemporal_store(v, dst + (start >> 4) + w);
+        }
+    }
+}
+
 // ---- phase 1 with candidate tables: ONE LANE PER K-MER ----------------------------------------------------------------
 // With the 16-byte candidate entries a k-mer needs 16 bytes of the table, and a lane that issues ONE 16-byte load per
 // lookup costs the memory path one request and one translation per line whether or not a neighbour shares the line
@@ -463,6 +494,11 @@ __global__ __launch_bounds__(256) void lookup_lane_kernel(PairIndex ix, const ui
     uint64_t* qf = s_qf[wib];
     uint32_t* qi = s_qi[wib];
     uint8_t* res = s_res[wib];
+    // FMSI_HIP_OUT_BITS: the chunk's results leave bit-packed (1 bit per window, STRICT: 4).  The result bytes of the k-mers
+    // that go on to the stepping kernel must then read as zero -- it ORs its answers into the packed words
+    const bool out_bits = (flags & FMSI_HIP_OUT_BITS) != 0u;
+    if (out_bits)
+        for (uint32_t off = lane * 16u; off < kMaxChunk; off += 64u * 16u) *reinterpret_cast<uint4*>(res + off) = make_uint4(0, 0, 0, 0);
     uint32_t n_lookups = 0, n_final = 0, n_vreads = 0;
     const uint64_t wave = (static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
     const uint64_t start = wave * chunk;
@@ -686,7 +722,9 @@ __global__ __launch_bounds__(256) void lookup_lane_kernel(PairIndex ix, const ui
     if (qtail != qhead) slow_round(qtail - qhead);
     __syncthreads();   // (every wave of the workgroup comes here)
     if (threadIdx.x == 0 && group_start < n_windows) list_count[blockIdx.x] = s_items;
-    if (len) {   // the chunk's result bytes leave in 16-byte pieces; those of the work items are the stepping kernel's to overlay
+    if (len && out_bits) {
+        flush_packed(res, len, strict != 0u, out, start, lane);
+    } else if (len) {   // the chunk's result bytes leave in 16-byte pieces; those of the work items are the stepping kernel's to overlay
         uint8_t* dst = out + start;
         const bool aligned = (reinterpret_cast<uintptr_t>(dst) & 15u) == 0;
         for (uint32_t off = lane * 16u; off < len; off += 64u * 16u) {
@@ -868,8 +906,18 @@ __global__ __launch_bounds__(256) void query_pair_kernel(PairIndex ix, const uin
                 }
             } else {
                 const uint8_t byte = strict ? static_cast<uint8_t>((rf + 1) | ((rr + 1) << 2)) : static_cast<uint8_t>((was_second ? rr : rf) == 1);
-                if (LIST && !overlay) out[start + q] = byte;
-                else obuf[q] = byte;
+                if (LIST && !overlay) {
+                    const uint64_t w = start + q;
+                    if (!(flags & FMSI_HIP_OUT_BITS)) {
+                        out[w] = byte;
+                    } else if (byte) {   // packed output: the lookup kernel wrote this window's bits as zero (flush_packed)
+                        uint32_t* o32 = reinterpret_cast<uint32_t*>(out);
+                        if (strict) atomicOr(o32 + (w >> 3), static_cast<uint32_t>(byte) << (4u * static_cast<uint32_t>(w & 7u)));
+                        else atomicOr(o32 + (w >> 5), 1u << static_cast<uint32_t>(w & 31u));
+                    }
+                } else {
+                    obuf[q] = byte;
+                }
             }
         }
         st = PS_IDLE;
@@ -1174,6 +1222,16 @@ PairIndex make_pair_index(const fmsi_hip_index* idx) {
     return p;
 }
 
+// the phased launch that writes FMSI_HIP_OUT_BITS output itself: the one-lane lookup kernel + the stepping kernel's ORs
+bool lane_lookup_applies(const fmsi_hip_index* idx, int k, uint32_t flags) {
+    static const bool force_pairs = std::getenv("FMSI_HIP_LOOKUP_PAIRS") != nullptr;   // A/B switch for measurements
+    const int rest = k - idx->prefix_len;
+    // candidate tables in play (the condition pair_lookup_kernel calls `verify`) whose words are the bases themselves, k - t <= 15:
+    // with text positions every candidate is a read of its own, which the one-lane kernel defers, and the lane pairs are the
+    // faster form -- measured at n = 4.7 M, t = 12: 26.3 vs 24.6 G k-mers/s
+    return idx->d_vtable && idx->dev.ptable_packed && !(flags & FMSI_HIP_ORDERS) && rest >= 1 && rest <= 15 && (!force_pairs || idx->vwide);
+}
+
 template <bool COUNT, bool RUNS>
 int launch_phased_t(fmsi_hip_index* idx, const uint64_t* d_kmers, uint64_t n, int k, uint32_t flags, uint8_t* o8, long long* o64,
                     unsigned long long* d_counters, hipStream_t s, const uint64_t* h_runs, uint64_t n_runs) {
@@ -1195,17 +1253,11 @@ int launch_phased_t(fmsi_hip_index* idx, const uint64_t* d_kmers, uint64_t n, in
     auto* d_count = reinterpret_cast<uint32_t*>(static_cast<char*>(idx->d_tasks) + list_bytes);
     auto* d_runs = reinterpret_cast<uint64_t*>(static_cast<char*>(idx->d_tasks) + list_bytes + count_bytes);
     if (RUNS) {
-        FMSI_HIP_TRY(hipMemcpyAsync(d_runs, h_runs, (2 * n_runs + 1) * 8, hipMemcpyHostToDevice, s));
-        FMSI_HIP_TRY(hipStreamSynchronize(s));   // the caller's table may be a local
+        FMSI_HIP_TRY(hipMemcpyAsync(d_runs, h_runs, (2 * n_runs + 1) * 8, hipMemcpyHostToDevice, s));   // (h_runs: a slot of the handle's page-locked ring)
     }
     const PairIndex pix = make_pair_index(idx);
-    // candidate tables in play (the condition pair_lookup_kernel calls `verify`): one lane per k-mer
-    const int rest = k - static_cast<int>(pix.ptable_len);
-    static const bool force_pairs = std::getenv("FMSI_HIP_LOOKUP_PAIRS") != nullptr;   // A/B switch for measurements
-    // (... whose words are the bases themselves, k - t <= 15: with text positions every candidate is a read of its own, which
-    // the one-lane kernel defers, and the lane pairs are the faster form -- measured at n = 4.7 M, t = 12: 26.3 vs 24.6 G k-mers/s)
-    const bool lane_lookup = pix.vtable && pix.ptable_packed && !(flags & FMSI_HIP_ORDERS) && k == pix.verify_k && rest >= 1 && rest <= 15 &&
-                             chunk <= 4096 && (!force_pairs || pix.vwide);
+    // candidate tables in play: one lane per k-mer
+    const bool lane_lookup = k == pix.verify_k && lane_lookup_applies(idx, k, flags);
     if (lane_lookup && pix.vwide)
         hipLaunchKernelGGL((lookup_lane_kernel<COUNT, RUNS, true>), dim3(blocks), dim3(256), 0, s, pix, d_kmers, n, k, flags, static_cast<uint32_t>(chunk), o8,
                            d_list, d_count, d_counters, d_runs, d_runs + n_runs, n_runs);
@@ -1249,6 +1301,10 @@ void launch_pair_t(fmsi_hip_index* idx, const uint64_t* d_kmers, uint64_t n, int
 
 }  // namespace
 
+bool phased_packs_bits(const fmsi_hip_index* idx, int k, uint32_t flags) {
+    return idx->d_pblocks && idx->d_ptable && k == idx->k && lane_lookup_applies(idx, k, flags);
+}
+
 int launch_phased_query(fmsi_hip_index* idx, const uint64_t* d_kmers, uint64_t n, int k, uint32_t flags, uint8_t* o8, long long* o64,
                         unsigned long long* d_counters, hipStream_t s, const uint64_t* h_runs, uint64_t n_runs) {
     if (h_runs)
@@ -1276,7 +1332,7 @@ using namespace fmsi;
 extern "C" int fmsi_hip_index_enable_pair_layout(fmsi_hip_index* idx) {
     if (!idx) return FMSI_HIP_EINVAL;
     if (idx->d_pblocks) return 0;
-    FMSI_HIP_TRY(hipSetDevice(idx->device));
+    FMSI_HIP_ON_DEVICE(idx->device);
     const uint64_t n_blocks = idx->n_blocks;
     const uint64_t n_super = ((n_blocks - 1) >> kSuperBlocksLog2) + 1;
     void *pb = nullptr, *counts = nullptr, *scanned = nullptr, *sbt = nullptr, *c2 = nullptr, *spec = nullptr, *temp = nullptr;
@@ -1470,7 +1526,7 @@ extern "C" int fmsi_hip_index_enable_verify(fmsi_hip_index* idx) {
         set_last_error("text verification needs a packed prefix table with t < k <= 32");
         return FMSI_HIP_EINVAL;
     }
-    FMSI_HIP_TRY(hipSetDevice(idx->device));
+    FMSI_HIP_ON_DEVICE(idx->device);
     const uint64_t n = idx->n, len = n - 1, count = 1ull << (2 * T);
     char* d_chars = nullptr;
     uint32_t *d_sa = nullptr, *d_stable = nullptr;

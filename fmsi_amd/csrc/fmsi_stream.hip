@@ -619,13 +619,19 @@ extern "C" int fmsi_hip_query_stream(fmsi_hip_index* idx, const uint64_t* packed
         set_last_error("streaming queries need 1 <= k <= 64");
         return FMSI_HIP_ERANGE;
     }
-    FMSI_HIP_TRY(hipSetDevice(idx->device));
+    FMSI_HIP_ON_DEVICE(idx->device);
     hipStream_t s = static_cast<hipStream_t>(stream);
     // run_start / run_windows are HOST arrays in every mode (one entry per run); per run the device gets its first base,
     // first task and first result index, and cuts the tasks itself (stream_prep_kernel)
-    std::vector<uint64_t> meta(3 * n_runs + 2);   // [0, R): run_start   [R, 2R]: task_off   [2R + 1, 3R + 1]: out_off
-    uint64_t* h_task_off = meta.data() + n_runs;
-    uint64_t* h_out_off = meta.data() + 2 * n_runs + 1;
+    // (in a page-locked slot of the handle's ring: the call stays asynchronous on `stream`)
+    void* meta_host = nullptr;
+    unsigned meta_slot = 0;
+    int rc;
+    if ((rc = meta_stage(idx, (3 * n_runs + 2) * 8, &meta_host, &meta_slot))) return rc;
+    uint64_t* meta = static_cast<uint64_t*>(meta_host);   // [0, R): run_start   [R, 2R]: task_off   [2R + 1, 3R + 1]: out_off
+    const size_t meta_words = 3 * n_runs + 2;
+    uint64_t* h_task_off = meta + n_runs;
+    uint64_t* h_out_off = meta + 2 * n_runs + 1;
     uint64_t n_tasks = 0, out_pos = 0;
     for (uint64_t r = 0; r < n_runs; ++r) {
         const uint64_t w = run_windows[r];
@@ -646,9 +652,8 @@ extern "C" int fmsi_hip_query_stream(fmsi_hip_index* idx, const uint64_t* packed
         return FMSI_HIP_EINVAL;
     }
     const bool dev_ptrs = flags & FMSI_HIP_DEVICE_PTRS;
-    const size_t out_bytes = n_windows * ((flags & FMSI_HIP_ORDERS) ? ((flags & FMSI_HIP_STRICT) ? 16 : 8) : 1);
+    const size_t out_bytes = out_buffer_bytes(n_windows, flags);
     const size_t seq_bytes = (seq_bases / 32 + 2) * 8;
-    int rc;
     const uint64_t* d_seq = packed_seq;
     void* d_out = out;
     unsigned long long* d_cnt = reinterpret_cast<unsigned long long*>(counters);
@@ -664,19 +669,24 @@ extern "C" int fmsi_hip_query_stream(fmsi_hip_index* idx, const uint64_t* packed
         }
     }
     // run metadata, then the task records and the result slots, in one staging buffer
-    const size_t meta_bytes = (meta.size() * 8 + 63) / 64 * 64;
+    const size_t meta_bytes = (meta_words * 8 + 63) / 64 * 64;
     if ((rc = ensure_cap(&idx->d_tasks, &idx->d_tasks_cap, meta_bytes + 2 * n_tasks * sizeof(TaskRec)))) return rc;
     auto* d_meta = static_cast<uint64_t*>(idx->d_tasks);
     auto* d_rec = reinterpret_cast<TaskRec*>(static_cast<char*>(idx->d_tasks) + meta_bytes);
     auto* d_slots = reinterpret_cast<uint4*>(d_rec + n_tasks);   // one 64-byte line of result bytes per task
-    FMSI_HIP_TRY(hipMemcpyAsync(d_meta, meta.data(), meta.size() * 8, hipMemcpyHostToDevice, s));
-    FMSI_HIP_TRY(hipStreamSynchronize(s));   // `meta` is a local vector: the copy must finish before it dies
+    FMSI_HIP_TRY(hipMemcpyAsync(d_meta, meta, meta_words * 8, hipMemcpyHostToDevice, s));
+    if ((rc = meta_commit(idx, meta_slot, s))) return rc;
+    // FMSI_HIP_OUT_BITS: the compaction writes the bytes to the handle's scratch buffer and one more pass packs them
+    PackAfter pack;
+    const uint32_t caller_flags = flags;
+    if ((rc = pack.begin(idx, flags, n_windows, d_out))) return rc;
+    // the profiling events bracket everything the call runs on the device: prep, the query kernel and the compaction
+    size_t slot;
+    if ((rc = prof_begin(idx, s, &slot))) return rc;
     hipLaunchKernelGGL(stream_prep_kernel, dim3(static_cast<uint32_t>((n_tasks + 255) / 256)), dim3(256), 0, s, d_seq, d_meta, d_meta + n_runs,
                        d_meta + 2 * n_runs + 1, n_runs, n_tasks, seq_bases / 32 + 2, d_rec);
     FMSI_HIP_TRY(hipGetLastError());
     const bool use_table = idx->d_ptable && !(flags & FMSI_HIP_NO_PREFIX_TABLE) && k >= idx->prefix_len;
-    size_t slot;
-    if ((rc = prof_begin(idx, s, &slot))) return rc;
     long long* o64 = static_cast<long long*>(d_out);
     if (k > 32) {
         if (use_table) {
@@ -694,13 +704,14 @@ extern "C" int fmsi_hip_query_stream(fmsi_hip_index* idx, const uint64_t* packed
         else launch_stream<false, false, false>(idx, d_rec, n_tasks, k, flags, d_slots, o64, d_cnt, s);
     }
     FMSI_HIP_TRY(hipGetLastError());
-    if ((rc = prof_end(idx, s, slot))) return rc;
     if (!(flags & FMSI_HIP_ORDERS)) {
         const uint64_t threads = n_tasks * 64;
         hipLaunchKernelGGL(stream_compact_kernel, dim3(static_cast<uint32_t>((threads + 255) / 256)), dim3(256), 0, s,
-                           reinterpret_cast<const uint8_t*>(d_slots), d_rec, n_tasks, static_cast<uint8_t*>(d_out));
+                           reinterpret_cast<const uint8_t*>(d_slots), d_rec, n_tasks, pack.bytes);
         FMSI_HIP_TRY(hipGetLastError());
     }
+    if ((rc = pack.end(n_windows, caller_flags, d_out, s))) return rc;
+    if ((rc = prof_end(idx, s, slot))) return rc;
     if (!dev_ptrs) {
         FMSI_HIP_TRY(hipMemcpyAsync(out, idx->d_out, out_bytes, hipMemcpyDeviceToHost, s));
         if (counters) FMSI_HIP_TRY(hipMemcpyAsync(counters, idx->d_counters, FMSI_HIP_N_COUNTERS * 8, hipMemcpyDeviceToHost, s));

@@ -3,6 +3,7 @@
 #include "common.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <cstring>
 #include <thread>
@@ -115,7 +116,9 @@ inline uint64_t decode_block(unsigned cls, uint64_t nr, const Binomials& B) {
 inline void or_bits(uint64_t* words, uint64_t pos, uint64_t v) {
     unsigned off = pos & 63;
     words[pos >> 6] |= v << off;
-    if (off) words[(pos >> 6) + 1] |= v >> (64 - off);
+    // (the spill word is touched only when bits really spill: the last block of a decoding thread's range ends exactly
+    // at a word boundary, and the next word belongs to the neighbouring thread)
+    if (off && (v >> (64 - off))) words[(pos >> 6) + 1] |= v >> (64 - off);
 }
 
 }  // namespace
@@ -144,15 +147,24 @@ int decode_rrr63(const uint8_t* data, size_t size, BitVector& out, std::string& 
     out.bits = n;
     out.words.assign(static_cast<size_t>((n + 63) >> 6) + 3, 0);
 
+    std::atomic<bool> corrupt{false};   // an offset pointer or class width that runs past the offsets' bit-vector
     auto decode_range = [&](uint64_t s0, uint64_t s1) {
         for (uint64_t s = s0; s < s1; ++s) {
             uint64_t pos = read_bits(btnrp.data(), s * btnrp_w, btnrp_w);
+            if (pos > btnr.bits) {
+                corrupt = true;
+                return;
+            }
             const bool inv = invert.get(s);
             const uint64_t b_end = std::min<uint64_t>((s + 1) * kRrrSuper, n_blocks);
             for (uint64_t b = s * kRrrSuper; b < b_end; ++b) {
                 unsigned stored = static_cast<unsigned>(read_bits(bt.data(), b * 6, 6));
                 unsigned cls = inv ? kRrrBlock - stored : stored;   // rrr_vector.hpp:262-263
                 unsigned width = B.space[stored];
+                if (width > btnr.bits - pos) {
+                    corrupt = true;
+                    return;
+                }
                 uint64_t nr = read_bits(btnr.words.data(), pos, width);
                 pos += width;
                 uint64_t first = b * kRrrBlock;
@@ -176,6 +188,10 @@ int decode_rrr63(const uint8_t* data, size_t size, BitVector& out, std::string& 
             if (a < b) pool.emplace_back(decode_range, a, b);
         }
         for (auto& th : pool) th.join();
+    }
+    if (corrupt) {
+        err = "rrr_vector<63> image: block offsets run past the end of the offset vector";
+        return FMSI_HIP_EIO;
     }
     return 0;
 }

@@ -4,6 +4,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdint>
 #include <string>
 #include <utility>
@@ -34,6 +35,39 @@ struct DevIndex {
             return FMSI_HIP_EHIP;                                                                          \
         }                                                                                                  \
     } while (0)
+
+// Library calls run on the handle's device and leave the calling thread's current device as they found it (a
+// multi-GPU single-process caller -- torch, or the CLI's --devices threads -- is not silently moved to another GPU).
+struct DeviceGuard {
+    int prev = -1, target = -1;
+    hipError_t err = hipSuccess;
+    explicit DeviceGuard(int device) : target(device) {
+        if (hipGetDevice(&prev) != hipSuccess) {
+            (void)hipGetLastError();
+            prev = -1;
+        }
+        if (prev != device) err = hipSetDevice(device);
+    }
+    ~DeviceGuard() {
+        if (prev >= 0 && prev != target) (void)hipSetDevice(prev);
+    }
+    DeviceGuard(const DeviceGuard&) = delete;
+    DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
+#define FMSI_HIP_ON_DEVICE(device)                  \
+    ::fmsi::DeviceGuard device_guard_(device);      \
+    FMSI_HIP_TRY(device_guard_.err)
+
+// Page-locked staging for the small host tables a query call sends along (run starts / offsets): a ring of slots, each
+// guarded by an event recorded behind the copy that reads it, so that the call stays asynchronous on the caller's stream
+// (no hipStreamSynchronize to keep a local vector alive) and a slot is reused only when its copy is done.
+struct MetaSlot {
+    void* host = nullptr;
+    size_t cap = 0;
+    hipEvent_t done = nullptr;
+    bool in_flight = false;
+};
+constexpr unsigned kMetaSlots = 4;
 
 }  // namespace fmsi
 
@@ -66,7 +100,10 @@ struct fmsi_hip_index {
     void* d_out = nullptr; size_t d_out_cap = 0;
     void* d_kmers = nullptr; size_t d_kmers_cap = 0;   // windows -> packed k-mers
     void* d_tasks = nullptr; size_t d_tasks_cap = 0;   // streaming task descriptors + records
+    void* d_bytes = nullptr; size_t d_bytes_cap = 0;   // FMSI_HIP_OUT_BITS: result bytes of the kernels that do not pack themselves
     unsigned long long* d_counters = nullptr;
+    fmsi::MetaSlot meta_ring[fmsi::kMetaSlots];
+    unsigned meta_next = 0;
     // profiling
     bool profiling = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
@@ -94,6 +131,12 @@ void launch_longk_query(fmsi_hip_index* idx, const uint64_t* d_seq, const uint64
 int launch_phased_query(fmsi_hip_index* idx, const uint64_t* d_kmers, uint64_t n, int k, uint32_t flags, uint8_t* o8, long long* o64,
                         unsigned long long* d_counters, hipStream_t s, const uint64_t* h_runs = nullptr, uint64_t n_runs = 0);
 
+// FMSI_HIP_OUT_BITS: does launch_phased_query write the packed output itself for this (handle, k, flags)?  (otherwise the
+// caller has the kernels write bytes into a scratch buffer and packs them with launch_pack_results)
+bool phased_packs_bits(const fmsi_hip_index* idx, int k, uint32_t flags);
+// n result bytes (device) -> packed words at d_out (device, 8-byte aligned): 1 bit per window, `strict`: 4 (fmsi_hip.hip)
+int launch_pack_results(const uint8_t* d_bytes, uint64_t n, bool strict, void* d_out, hipStream_t s);
+
 // the LF walk of `fmsi export` (fmsi_export.hip): letters with the mask's case into d_chars[0 .. n-2] (device), and
 // optionally sa[row] = text position of the row's suffix for every row (device, n entries)
 int export_walk(const fmsi_hip_index* idx, char* d_chars, uint32_t* d_sa);
@@ -109,6 +152,62 @@ inline int ensure_cap(void** p, size_t* cap, size_t need) {
     *cap = want;
     return 0;
 }
+
+// a page-locked buffer of `bytes` for this call's host-side table; meta_commit() after the copy that reads it was enqueued
+inline int meta_stage(fmsi_hip_index* idx, size_t bytes, void** host, unsigned* slot_out) {
+    const unsigned slot = idx->meta_next++ % kMetaSlots;
+    MetaSlot& m = idx->meta_ring[slot];
+    if (m.in_flight) {
+        FMSI_HIP_TRY(hipEventSynchronize(m.done));
+        m.in_flight = false;
+    }
+    if (!m.done) FMSI_HIP_TRY(hipEventCreateWithFlags(&m.done, hipEventDisableTiming));
+    if (m.cap < bytes) {
+        if (m.host) (void)hipHostFree(m.host);
+        m.host = nullptr;
+        m.cap = 0;
+        const size_t want = std::max<size_t>(bytes + bytes / 2, size_t(1) << 16);
+        FMSI_HIP_TRY(hipHostMalloc(&m.host, want, hipHostMallocDefault));
+        m.cap = want;
+    }
+    *host = m.host;
+    *slot_out = slot;
+    return 0;
+}
+inline int meta_commit(fmsi_hip_index* idx, unsigned slot, hipStream_t s) {
+    MetaSlot& m = idx->meta_ring[slot];
+    FMSI_HIP_TRY(hipEventRecord(m.done, s));
+    m.in_flight = true;
+    return 0;
+}
+
+// bytes of the result buffer of a query call over n_windows windows (fmsi_hip.hip)
+size_t out_buffer_bytes(uint64_t n_windows, uint32_t flags);
+
+// FMSI_HIP_OUT_BITS around kernels that write one result byte per window: begin() points them at the handle's scratch bytes
+// and takes the flag out of `flags`, end() packs the bytes into the caller's buffer
+struct PackAfter {
+    bool on = false;
+    uint8_t* bytes = nullptr;
+    int begin(fmsi_hip_index* idx, uint32_t& flags, uint64_t n_windows, void* d_out) {
+        const bool want = (flags & FMSI_HIP_OUT_BITS) && !(flags & FMSI_HIP_ORDERS);
+        flags &= ~FMSI_HIP_OUT_BITS;
+        bytes = static_cast<uint8_t*>(d_out);
+        if (!want) return 0;
+        if (reinterpret_cast<uintptr_t>(d_out) & 7u) {
+            set_last_error("FMSI_HIP_OUT_BITS needs an 8-byte aligned output buffer");
+            return FMSI_HIP_EINVAL;
+        }
+        int rc = ensure_cap(&idx->d_bytes, &idx->d_bytes_cap, n_windows);
+        if (rc) return rc;
+        on = true;
+        bytes = static_cast<uint8_t*>(idx->d_bytes);
+        return 0;
+    }
+    int end(uint64_t n_windows, uint32_t flags, void* d_out, hipStream_t s) const {
+        return on ? launch_pack_results(bytes, n_windows, (flags & FMSI_HIP_STRICT) != 0u, d_out, s) : 0;
+    }
+};
 
 // HIP events around a kernel launch on the launch stream (fmsi_hip_profile_*)
 inline int prof_begin(fmsi_hip_index* idx, hipStream_t s, size_t* slot) {

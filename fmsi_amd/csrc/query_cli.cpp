@@ -1114,8 +1114,11 @@ extern "C" int fmsi_cli_query(int argc, char** argv, int output_orders_i) {
     } catch (const std::exception& e) {
         std::cerr << "ERROR: " << e.what() << std::endl;
         exit_code = 1;
-        raw_q.abort();
     }
+    // whatever ended the loop -- end of input, a device error, a writer that failed (ENOSPC, EPIPE) -- the reader must not
+    // stay blocked in raw_q.push() with batches nobody will take: after a normal end the queue is closed and empty and
+    // this is a no-op, otherwise it wakes the reader so that the join below returns
+    raw_q.abort();
     out_q.close();
     reader_thread.join();
     writer_thread.join();

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define FMSI_HIP_ABI_VERSION 2   /* 2: fmsi_hip_index_info.candidate_entry_bytes, fmsi_hip_comm_*, fmsi_hip_gather */
+#define FMSI_HIP_ABI_VERSION 3   /* 2: fmsi_hip_index_info.candidate_entry_bytes, fmsi_hip_comm_*, fmsi_hip_gather; 3: FMSI_HIP_OUT_BITS */
 
 /* error codes */
 #define FMSI_HIP_OK 0
@@ -69,6 +69,12 @@ extern "C" {
 #define FMSI_HIP_KERNEL_MASK 0xF0u
 /* do not use the private prefix table even if the handle has one (canonical-step accounting runs) */
 #define FMSI_HIP_NO_PREFIX_TABLE 0x100u
+
+/* bit-packed results (non-ORDERS calls): `out` is an 8-byte aligned array of u64 words, LSB first like the reference's
+ * sdsl bit-vectors -- window w is bit (w & 63) of word w >> 6 (what the reference prints as '0' / '1', src/fms_index.h:305-309);
+ * with STRICT, nibble (w & 15) of word w >> 4 holding the STRICT byte below.  ceil(n / 64) resp. ceil(n / 16) words; the unused
+ * high bits of the last word are zero.  One eighth (half) of the bytes over PCIe and over xGMI (fmsi_hip_gather). */
+#define FMSI_HIP_OUT_BITS 0x200u
 
 /* ---- index creation flags --------------------------------------------------------------------- */
 /* build a 4^t-entry prefix table that jumps the first t LF steps (private optimisation: the final SA

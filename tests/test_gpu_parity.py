@@ -577,3 +577,22 @@ def test_block_parallel_reader_equals_the_ordinary_one(fm, oracle_built, tmp_pat
     rc, ref, err = oracle_py.run_cli(checker, [a for a in args if a not in ("--batch", "4096")])
     assert rc == 0 and got == ref
     assert got.count(b"\n") > (100 if fastq_at != 0 else 50)
+
+
+def test_cli_exits_when_stdout_fails(fm, tmp_path):
+    """A writer that fails (ENOSPC: stdout = /dev/full) must end the process with exit status 1 -- not leave the reader thread
+    blocked on a full queue and the CLI hanging in join().  Many small batches, so that input is still pending when it happens."""
+    import subprocess
+    ms = "".join(l.strip() for l in open(GOLDEN / "ref_data" / "GCF_test2_ones.fna.ms.k31") if not l.startswith(">")).upper()
+    q = tmp_path / "many.fa"
+    with open(q, "w") as f:
+        for r in range(4000):
+            p = (r * 37) % (len(ms) - 400)
+            f.write(f">r{r}\n{ms[p:p + 400]}\n")
+    with open("/dev/full", "wb") as full:
+        res = subprocess.run([str(fm.CLI_PATH), "query", "-q", str(q), "--batch", "1024", index_prefix("sars_k31")], stdout=full,
+                             stderr=subprocess.PIPE, timeout=120)
+    assert res.returncode == 1 and b"write to stdout failed" in res.stderr
+    # and the same input to a healthy stdout still works
+    rc, out, _ = fm.run_cli(["query", "-q", str(q), "--batch", "1024", index_prefix("sars_k31")])
+    assert rc == 0 and out.count(b"\n") == 4000

@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol(product_built):
     assert len(names) >= 18
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/fmsi_hip.h but not exported"
-    assert lib.fmsi_hip_abi_version() == 2
+    assert lib.fmsi_hip_abi_version() == 3
 
 
 def test_no_oracle_in_product():
@@ -274,6 +274,57 @@ def test_host_code_under_sanitizers(tmp_path):
         assert "400 records" in res.stdout and ("fastq=1" in res.stdout) == (tag == "mixed")
         for part in ("ac_gt", "ac", "gt", "mask", "misc") + (("klcp",) if klcp else ()):
             assert (GOLDEN / "idx" / f"{name}.fmsi.{part}").read_bytes() == Path(f"{out}.fmsi.{part}").read_bytes(), (name, part)
+
+
+def test_threaded_rrr_decode_under_tsan_and_corrupt_mask(oracle_built, tmp_path):
+    """The threaded part of the RRR-63 decoder (>= 64 superblock pairs: the golden indexes are too small to reach it) under
+    ThreadSanitizer -- neighbouring threads must not touch each other's boundary word -- and equal to the oracle's mask; a
+    .mask file whose offset pointers / class widths run past the offset vector is an error (FMSI_HIP_EIO), not an
+    out-of-bounds read (AddressSanitizer build)."""
+    from pathlib import Path
+
+    src = REPO / "fmsi_amd" / "csrc"
+    ms = synthetic_ms(600_000, 31, 11, mask="mixed")
+    orc = oracle_py.Oracle.construct(ms, 31, use_klcp=False)
+    prefix = tmp_path / "big"
+    orc.dump(str(prefix))
+    fasta = tmp_path / "q.fa"
+    fasta.write_text(">r\nACGTACGTACGTACGTACGTACGTACGTACGTACG\n")
+    srcs = [str(REPO / "tests" / "native" / "host_sanitize.cpp"), str(src / "host_index.cpp"), str(src / "index_writer.cpp"),
+            str(src / "layout.cpp"), str(src / "fastx.cpp")]
+    exes = {}
+    for tag, san in (("tsan", "-fsanitize=thread"), ("asan", "-fsanitize=address,undefined")):
+        exes[tag] = tmp_path / f"host_{tag}"
+        res = subprocess.run(["g++", "-std=c++17", "-O1", "-g", san, "-fno-omit-frame-pointer", f"-I{REPO / 'include'}", *srcs, "-o", str(exes[tag]),
+                              "-lz", "-lpthread"], capture_output=True, text=True)
+        assert res.returncode == 0, res.stderr[-3000:]
+    out = tmp_path / "w_big"
+    res = subprocess.run([str(exes["tsan"]), str(prefix), "0", str(out), str(fasta)], capture_output=True, text=True)
+    assert res.returncode == 0 and "ThreadSanitizer" not in res.stderr, (res.stdout + res.stderr)[-3000:]
+    for part in ("ac_gt", "ac", "gt", "mask", "misc"):   # decoded (threads) and re-encoded: the oracle's bytes
+        assert Path(f"{prefix}.fmsi.{part}").read_bytes() == Path(f"{out}.fmsi.{part}").read_bytes(), part
+    # corrupt images: (a) the first superblock's offset pointer far past the offsets, (b) the offsets' bit-vector cut short
+    good = Path(f"{prefix}.fmsi.mask").read_bytes()
+    import struct
+    n, bt_bits = struct.unpack_from("<QQ", good, 0)
+    off_btnr = 8 + 9 + ((bt_bits + 63) // 64) * 8                     # n | int_vector bt | bit_vector btnr ...
+    btnr_bits = struct.unpack_from("<Q", good, off_btnr)[0]
+    off_btnrp = off_btnr + 8 + ((btnr_bits + 63) // 64) * 8
+    cases = {}
+    b = bytearray(good)
+    b[off_btnrp + 9: off_btnrp + 17] = b"\xff" * 8                     # every pointer in the first word: all ones
+    cases["pointer"] = bytes(b)
+    short_words = max(1, ((btnr_bits + 63) // 64) // 2)
+    b = bytearray(good[:off_btnr]) + struct.pack("<Q", short_words * 64) + good[off_btnr + 8: off_btnr + 8 + short_words * 8] + \
+        good[off_btnrp:]
+    cases["short"] = bytes(b)
+    for tag, image in cases.items():
+        bad = tmp_path / f"bad_{tag}"
+        for part in ("ac_gt", "ac", "gt", "misc"):
+            Path(f"{bad}.fmsi.{part}").write_bytes(Path(f"{prefix}.fmsi.{part}").read_bytes())
+        Path(f"{bad}.fmsi.mask").write_bytes(image)
+        res = subprocess.run([str(exes["asan"]), str(bad), "0", str(tmp_path / "w_bad"), str(fasta)], capture_output=True, text=True)
+        assert res.returncode == 1 and "load failed" in res.stderr and "Sanitizer" not in res.stderr, (tag, (res.stdout + res.stderr)[-2000:])
 
 
 def test_layout_of_many_chunks_equals_numpy(product_built):
