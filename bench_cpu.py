@@ -47,8 +47,8 @@ def _cores():
     return cores, quota
 
 
-def _export_index(index, k, with_klcp):
-    """GPU-built index -> oracle structure -> (reference-format files ->) the real reference if it is available."""
+def oracle_from_index(index, k, with_klcp):
+    """GPU-built index (its downloaded layout planes) -> the oracle's in-memory index (C restatement)."""
     import oracle_py
     blocks, _ = index.download_layout()
     rows = int(index.info.n)
@@ -66,8 +66,14 @@ def _export_index(index, k, with_klcp):
     if with_klcp:
         kl = index.download_klcp()
         L.orc_index_set_klcp(h, kl.ctypes.data, rows)
-    orc = oracle_py.Oracle(L, h)
     del planes
+    return oracle_py.Oracle(L, h)
+
+
+def _export_index(index, k, with_klcp):
+    """GPU-built index -> oracle structure -> (reference-format files ->) the real reference if it is available."""
+    import oracle_py
+    orc = oracle_from_index(index, k, with_klcp)
     if not oracle_py.ref_available():
         return orc, "port", None
     tmp = tempfile.TemporaryDirectory(dir="/dev/shm" if os.path.isdir("/dev/shm") else None)

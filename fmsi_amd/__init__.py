@@ -65,6 +65,13 @@ class IndexInfo(C.Structure):
     ]
 
 
+class SyntheticSpec(C.Structure):
+    _fields_ = [
+        ("len", C.c_uint64), ("seed", C.c_uint64), ("k", C.c_int32), ("with_klcp", C.c_int32), ("prefix_len", C.c_int32),
+        ("repeat_permille", C.c_uint32), ("families", C.c_uint32), ("divergence_permille", C.c_uint32), ("mask_permille", C.c_uint32),
+    ]
+
+
 def build(verbose: bool = False) -> None:
     """Compile libfmsi_hip.so and the fmsi CLI for gfx950 (hipcc cross-compiles without a GPU)."""
     cmd = ["make", "-C", str(_PKG / "csrc")]
@@ -112,6 +119,9 @@ def lib() -> C.CDLL:
     L.fmsi_hip_host_free.restype = None
     L.fmsi_hip_index_build_synthetic.argtypes = [u64, u64, i32, i32, i32, i32, C.POINTER(vp)]
     L.fmsi_hip_index_build_synthetic_repeats.argtypes = [u64, u64, i32, i32, i32, i32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(vp)]
+    L.fmsi_hip_index_build_synthetic_spec.argtypes = [C.POINTER(SyntheticSpec), i32, C.POINTER(vp)]
+    L.fmsi_hip_synthetic_mask_bit.argtypes = [u64, u64, C.c_uint32]
+    L.fmsi_hip_synthetic_mask_bit.restype = C.c_uint32
     L.fmsi_hip_synthetic_text_word_repeats.argtypes = [u64, u64, C.c_uint32, C.c_uint32, C.c_uint32]
     L.fmsi_hip_synthetic_text_word_repeats.restype = u64
     L.fmsi_hip_synthetic_text_word.argtypes = [u64, u64]
@@ -286,13 +296,14 @@ class DeviceIndex:
 
     @classmethod
     def build_synthetic(cls, length: int, seed: int, k: int, with_klcp: bool = False, device: int = 0, prefix_len: int = 0,
-                        repeats=(0, 0, 0)):
-        """Synthetic max-ones superstring generated and indexed in HBM (see include/fmsi_hip.h).
+                        repeats=(0, 0, 0), mask_permille: int = 1000):
+        """Synthetic superstring generated and indexed in HBM (see include/fmsi_hip.h).
         repeats = (repeat_permille, families, divergence_permille): share of 2048-base segments that are diverged copies of
-        one of `families` consensus segments (fmsi_hip_index_build_synthetic_repeats)."""
+        one of `families` consensus segments; mask_permille < 1000: a mixed mask (fmsi_hip_index_build_synthetic_spec)."""
         h = C.c_void_p()
         rp, fam, div = (int(x) for x in repeats)
-        _check(lib().fmsi_hip_index_build_synthetic_repeats(length, seed, k, int(with_klcp), device, prefix_len, rp, fam, div, C.byref(h)))
+        spec = SyntheticSpec(length, seed, k, int(with_klcp), prefix_len, rp, fam, div, int(mask_permille))
+        _check(lib().fmsi_hip_index_build_synthetic_spec(C.byref(spec), device, C.byref(h)))
         return cls(None, device, _handle=h)
 
     def download_layout(self):
@@ -476,13 +487,25 @@ def synthetic_text_words(length: int, seed: int) -> np.ndarray:
     return words
 
 
-def synthetic_text(length: int, seed: int, k: int) -> bytes:
-    """The synthetic masked superstring as text (positions 0..length-k upper case)."""
+def synthetic_mask(length: int, seed: int, k: int, mask_permille: int = 1000) -> np.ndarray:
+    """Host (numpy) restatement of the builder's synthetic mask (fmsi_hip_synthetic_mask_bit): bool per position."""
+    p = np.arange(length, dtype=np.uint64)
+    on = p + np.uint64(k) <= np.uint64(length)
+    if mask_permille < 1000:
+        with np.errstate(over="ignore"):
+            h = _splitmix64(np.uint64(seed) ^ np.uint64(0x3A5C0FF5E7) ^ (p * np.uint64(0xC2B2AE3D27D4EB4F)))
+        on &= (h % np.uint64(1000)) < np.uint64(mask_permille)
+    return on
+
+
+def synthetic_text(length: int, seed: int, k: int, mask_permille: int = 1000) -> bytes:
+    """The synthetic masked superstring as text (ON positions upper case; max-ones: positions 0..length-k)."""
     words = synthetic_text_words(length, seed)
     codes = ((words[:, None] >> (2 * np.arange(32, dtype=np.uint64))) & np.uint64(3)).reshape(-1)[:length].astype(np.uint8)
-    up = np.frombuffer(b"ACGT", dtype=np.uint8)[codes]
-    lo = np.frombuffer(b"acgt", dtype=np.uint8)[codes]
-    out = np.where(np.arange(length) + k <= length, up, lo)
+    del words
+    on = synthetic_mask(length, seed, k, mask_permille)
+    out = np.frombuffer(b"acgt", dtype=np.uint8)[codes]
+    out = out - (on.astype(np.uint8) << 5)   # upper case where ON
     return out.tobytes()
 
 

@@ -453,8 +453,24 @@ int check_device(int device) {
         set_last_error("no usable HIP device (libfmsi_hip has no CPU fallback)");
         return FMSI_HIP_ENODEV;
     }
-    FMSI_HIP_ON_DEVICE(device);
     return 0;
+}
+
+// synthetic mask: position p < len - k + 1 is ON with probability mask_permille / 1000 (a hash of the seed and p), the last
+// k - 1 positions are OFF (no k-mer starts there).  One thread per 64-position word.
+__host__ __device__ inline uint32_t synth_mask_bit(uint64_t seed, uint64_t p, uint32_t mask_permille) {
+    if (mask_permille >= 1000u) return 1u;
+    return (splitmix64(seed ^ 0x3A5C0FF5E7ull ^ (p * 0xC2B2AE3D27D4EB4Full)) % 1000ull) < mask_permille ? 1u : 0u;
+}
+__global__ void synth_mask_kernel(uint64_t* __restrict__ mask, uint64_t m_words, uint64_t len, int k, uint64_t seed, uint32_t mask_permille) {
+    const uint64_t w = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (w >= m_words) return;
+    uint64_t v = 0;
+    for (uint32_t b = 0; b < 64u; ++b) {
+        const uint64_t p = w * 64u + b;
+        if (p + static_cast<uint64_t>(k) <= len && synth_mask_bit(seed, p, mask_permille)) v |= 1ull << b;
+    }
+    mask[w] = v;
 }
 
 // synthetic queries: see fmsi_hip_synthetic_queries in the header
@@ -528,6 +544,7 @@ int fmsi_hip_index_build(const char* ms, uint64_t len, int k, int with_klcp, int
     }
     int rc = check_device(device);
     if (rc) return rc;
+    FMSI_HIP_ON_DEVICE(device);
     const uint64_t n_words = (len >> 5) + 2, m_words = (len >> 6) + 2;
     std::vector<uint64_t> h_text(n_words, 0), h_mask(m_words, 0);
     for (uint64_t p = 0; p < len; ++p) {
@@ -561,16 +578,45 @@ int fmsi_hip_index_build_synthetic_repeats(uint64_t len, uint64_t seed, int k, i
         set_last_error("bad argument (on-device kLCP construction needs k <= 64)");
         return FMSI_HIP_EINVAL;
     }
+    fmsi_hip_synthetic_spec spec;
+    spec.len = len;
+    spec.seed = seed;
+    spec.k = k;
+    spec.with_klcp = with_klcp;
+    spec.prefix_len = prefix_len;
+    spec.repeat_permille = repeat_permille;
+    spec.families = families;
+    spec.divergence_permille = divergence_permille;
+    spec.mask_permille = 1000;
+    return fmsi_hip_index_build_synthetic_spec(&spec, device, out);
+}
+
+int fmsi_hip_index_build_synthetic_spec(const fmsi_hip_synthetic_spec* spec, int device, fmsi_hip_index** out) {
+    if (!spec || !out || spec->k < 1 || spec->len < static_cast<uint64_t>(spec->k) || (spec->with_klcp && spec->k > 64) ||
+        spec->repeat_permille > 1000 || spec->divergence_permille > 1000 || spec->mask_permille > 1000) {
+        set_last_error("bad argument (on-device kLCP construction needs k <= 64)");
+        return FMSI_HIP_EINVAL;
+    }
     int rc = check_device(device);
     if (rc) return rc;
-    const uint64_t n_words = (len >> 5) + 2;
-    DevBuf text2;
+    FMSI_HIP_ON_DEVICE(device);
+    const uint64_t len = spec->len, n_words = (len >> 5) + 2, m_words = (len >> 6) + 2;
+    DevBuf text2, mask_text;
     if ((rc = text2.alloc(n_words * 8))) return rc;
-    hipLaunchKernelGGL(synth_text_kernel, dim3(grid_for(n_words)), dim3(256), 0, 0, text2.as<uint64_t>(), n_words, len, seed, repeat_permille,
-                       families, divergence_permille);
+    hipLaunchKernelGGL(synth_text_kernel, dim3(grid_for(n_words)), dim3(256), 0, 0, text2.as<uint64_t>(), n_words, len, spec->seed,
+                       spec->repeat_permille, spec->families, spec->divergence_permille);
     FMSI_HIP_TRY(hipGetLastError());
-    return build_from_device_text(text2, len, nullptr, k, with_klcp, device, prefix_len, out);
+    if (spec->mask_permille < 1000) {   // a mixed mask: an explicit mask bit-vector, as for a superstring given as text
+        if ((rc = mask_text.alloc(m_words * 8))) return rc;
+        hipLaunchKernelGGL(synth_mask_kernel, dim3(grid_for(m_words)), dim3(256), 0, 0, mask_text.as<uint64_t>(), m_words, len, spec->k, spec->seed,
+                           spec->mask_permille);
+        FMSI_HIP_TRY(hipGetLastError());
+    }
+    return build_from_device_text(text2, len, spec->mask_permille < 1000 ? &mask_text : nullptr, spec->k, spec->with_klcp, device,
+                                  spec->prefix_len, out);
 }
+
+uint32_t fmsi_hip_synthetic_mask_bit(uint64_t seed, uint64_t p, uint32_t mask_permille) { return synth_mask_bit(seed, p, mask_permille); }
 
 uint64_t fmsi_hip_synthetic_text_word(uint64_t seed, uint64_t w) { return synth_word(seed, w); }
 uint64_t fmsi_hip_synthetic_text_word_repeats(uint64_t seed, uint64_t w, uint32_t repeat_permille, uint32_t families, uint32_t divergence_permille) {

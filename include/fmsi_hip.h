@@ -146,6 +146,18 @@ uint64_t fmsi_hip_synthetic_text_word(uint64_t seed, uint64_t w);
 int fmsi_hip_index_build_synthetic_repeats(uint64_t len, uint64_t seed, int k, int with_klcp, int device, int prefix_len,
                                            uint32_t repeat_permille, uint32_t families, uint32_t divergence_permille, fmsi_hip_index** out);
 uint64_t fmsi_hip_synthetic_text_word_repeats(uint64_t seed, uint64_t w, uint32_t repeat_permille, uint32_t families, uint32_t divergence_permille);
+/* The general form: the text as above, and a MASK that need not be max-ones -- position p <= len - k is ON with probability
+ * mask_permille / 1000 (fmsi_hip_synthetic_mask_bit(seed, p, mask_permille); 1000 = every k-mer ON), the last k - 1 positions
+ * OFF.  With a mixed mask `-O` answers depend on which occurrence comes first in the suffix array and the default (OR) mode
+ * on all of them (src/fms_index.h:126-144): what the at-scale parity tests exercise. */
+typedef struct {
+    uint64_t len, seed;
+    int32_t k, with_klcp, prefix_len;
+    uint32_t repeat_permille, families, divergence_permille;
+    uint32_t mask_permille;
+} fmsi_hip_synthetic_spec;
+int fmsi_hip_index_build_synthetic_spec(const fmsi_hip_synthetic_spec* spec, int device, fmsi_hip_index** out);
+uint32_t fmsi_hip_synthetic_mask_bit(uint64_t seed, uint64_t p, uint32_t mask_permille);
 /* Fills d_kmers[0..n) (DEVICE pointer) with queries first..first+n-1 of the seeded stream: with probability 1/2 a
  * k-mer of the superstring (half of those reverse-complemented), else a uniform random k-mer. */
 int fmsi_hip_synthetic_queries(fmsi_hip_index* idx, int k, uint64_t seed, uint64_t first, uint64_t n, uint64_t* d_kmers, void* stream);

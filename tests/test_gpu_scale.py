@@ -1,0 +1,158 @@
+"""At-scale GPU parity (run with `-m gpu` on an MI355X): BASELINE.json's configurations at their full sizes, mixed masks and the
+default (OR) mode at >= 10^8 rows, and an index that is byte-identical to one the REAL reference built at 10^8 rows.
+
+What checks what:
+  * kernels against each other: lookups + candidates (phased), lookups + two-base steps (pair), lock-step single steps without
+    any table -- three independent algorithms, strand by strand (STRICT), both modes;
+  * against the CPU side on a bounded sample of the same seeded queries: the GPU-built index is handed to the oracle (C
+    restatement, both strands' ternaries: src/fms_index.h:117-144 per strand) and, when oracle/_ref travelled, to the real
+    reference's own query_kmers() loop (printed bits, OR mode: the reference's default, whose output does not depend on the
+    strand predictor);
+  * against the real reference's index files: md5s recorded in the build container (tests/golden/make_scale_md5.py).
+"""
+import hashlib
+import json
+import sys
+
+import numpy as np
+import pytest
+
+import oracle_py
+from conftest import GOLDEN, REPO
+
+pytestmark = pytest.mark.gpu
+
+sys.path.insert(0, str(REPO))
+
+
+@pytest.fixture(scope="module")
+def fm(product_built):
+    if product_built.device_count() < 1:
+        pytest.fail("no HIP device visible: the gpu tests must run on an MI355X")
+    return product_built
+
+
+def kmers_text(kmers: np.ndarray, k: int) -> bytes:
+    codes = ((kmers[:, None] >> (2 * np.arange(k, dtype=np.uint64))) & np.uint64(3)).astype(np.uint8)
+    return np.frombuffer(b"ACGT", dtype=np.uint8)[codes].tobytes()
+
+
+def device_answers(fm, dev, d_kmers, nq, k, flags):
+    import torch
+    d_out = torch.empty(nq, dtype=torch.uint8, device="cuda")
+    dev.query_kmers_dev(d_kmers.data_ptr(), nq, k, flags, d_out.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    return d_out.cpu().numpy()
+
+
+def cross_check(fm, dev, k, nq, sample, seed=42, or_reference=True):
+    """nq seeded queries (half drawn from the superstring): kernels agree strand by strand in both modes; the first `sample`
+    of them equal the oracle's ternaries on the exported index and (OR mode) the real reference's printed bits."""
+    import torch
+    import bench_cpu
+    s = torch.cuda.current_stream().cuda_stream
+    d_kmers = torch.empty(nq, dtype=torch.int64, device="cuda")
+    dev.synthetic_queries_dev(k, seed, 0, nq, d_kmers.data_ptr(), s)
+    torch.cuda.synchronize()
+    text = kmers_text(d_kmers[:sample].cpu().numpy().view(np.uint64), k)
+    orc = bench_cpu.oracle_from_index(dev, k, with_klcp=False)
+    strict = {}
+    for mode_name, mode in (("or", fm.MODE_OR), ("all", fm.MODE_ALL)):
+        outs = {name: device_answers(fm, dev, d_kmers, nq, k, mode | fm.STRICT | kern)
+                for name, kern in (("phased", fm.KERNEL_PHASED), ("pair", fm.KERNEL_PAIR | fm.NO_PREFIX_TABLE),
+                                   ("lockstep", fm.KERNEL_LOCKSTEP | fm.NO_PREFIX_TABLE))}
+        assert np.array_equal(outs["phased"], outs["pair"]), mode_name
+        assert np.array_equal(outs["phased"], outs["lockstep"]), mode_name
+        f, r = fm.decode_strict(outs["phased"])
+        of, orr = orc.ternaries_bulk(text, sample, k, mode_name == "all")
+        assert np.array_equal(f[:sample], of) and np.array_equal(r[:sample], orr), mode_name
+        # the cheaper schedule (forward first, reverse complement when needed) and its bit-packed form
+        fast = device_answers(fm, dev, d_kmers, nq, k, mode | fm.KERNEL_PHASED)
+        want = (np.where(f != -1, f, r) == 1) if mode_name == "all" else ((f == 1) | (r == 1))
+        assert np.array_equal(fast.astype(bool), want), mode_name
+        d_bits = torch.zeros(fm.packed_words(nq, 0), dtype=torch.int64, device="cuda")
+        dev.query_kmers_dev(d_kmers.data_ptr(), nq, k, mode | fm.KERNEL_PHASED | fm.OUT_BITS, d_bits.data_ptr(), stream=s)
+        torch.cuda.synchronize()
+        assert np.array_equal(fm.unpack_bits(d_bits.cpu().numpy().view(np.uint64), nq, 0), fast)
+        strict[mode_name] = (f, r)
+    if or_reference and oracle_py.ref_available():
+        import tempfile
+        with tempfile.TemporaryDirectory(dir="/dev/shm") as d:
+            orc.dump(f"{d}/x")
+            ref = oracle_py.Reference.load(f"{d}/x")
+            _, bits = ref.time_isolated_kmers(text, sample, k, oracle_py.MODE_OR)
+            f, r = strict["or"]
+            assert np.array_equal(bits.astype(bool), ((f == 1) | (r == 1))[:sample])
+            ref.close()
+    orc.close()
+    return strict
+
+
+def test_config3_pangenome_scale(fm):
+    """BASELINE.json config 3: E. coli pangenome scale, n = 1.4 x 10^9 rows, k = 31, the production tables (t = 16, 32-byte
+    candidate entries)."""
+    n, k = 1_400_000_000, 31
+    dev = fm.DeviceIndex.build_synthetic(n, 12345, k, prefix_len=16).enable_pair_layout().enable_verify()
+    assert int(dev.info.candidate_entry_bytes) == 32
+    strict = cross_check(fm, dev, k, nq=1 << 22, sample=150_000)
+    f, r = strict["all"]
+    present = (f == 1) | (r == 1)
+    assert 0.49 < present.mean() < 0.51 and ((f == 0) | (r == 0)).sum() == 0    # max-ones: an occurrence is always ON
+
+
+def test_config2_ecoli_full_size(fm):
+    """BASELINE.json config 2 at its full size: n = 4.7 x 10^6 rows, 2^20 queries against the oracle, with the tables bench.py
+    uses at this size (t = 16 + candidates: 172 GB for a 4.7 Mbp genome) and with tables that fit the rule 4^t <= 4n (t = 12)."""
+    n, k = 4_700_000, 31
+    for t in (16, 12):
+        dev = fm.DeviceIndex.build_synthetic(n, 12345, k, prefix_len=t).enable_pair_layout().enable_verify()
+        cross_check(fm, dev, k, nq=1 << 20, sample=1 << 20, or_reference=(t == 16))
+        dev.close()
+
+
+def test_mixed_mask_at_1e8_rows(fm):
+    """A non-max-ones mask at 1.2 x 10^8 rows (60 % of the positions ON) with repeat families, so that intervals of several rows
+    with differing mask bits occur: OR mode scans the interval (src/fms_index.h:133-142), `-O` takes its first row."""
+    n, k = 120_000_000, 31
+    dev = fm.DeviceIndex.build_synthetic(n, 777, k, prefix_len=14, repeats=(200, 50, 10), mask_permille=600).enable_pair_layout().enable_verify()
+    strict = cross_check(fm, dev, k, nq=1 << 22, sample=300_000)
+    fo, ro = strict["or"]
+    fa, ra = strict["all"]
+    assert ((fo == 0) | (ro == 0)).mean() > 0.1 and ((fo == 1) | (ro == 1)).mean() > 0.2     # both answers occur among the present
+    assert (fo != fa).sum() + (ro != ra).sum() > 1000                                          # and the modes really differ
+    assert ((fo == -1) == (fa == -1)).all() and ((ro == -1) == (ra == -1)).all()               # absence does not depend on the mode
+    assert ((fa == 1) <= (fo == 1)).all()                                                      # first row ON => some row ON
+
+
+def test_index_equals_the_reference_built_one_at_1e8(fm, tmp_path):
+    """The real reference built this index (10^8 rows, mixed mask) in the build container; its files' md5s are committed.  The
+    on-device builder + the product's writer reproduce the files byte for byte, and the files -- loaded through
+    fmsi_host_index_load like any reference-made index -- answer like the handle they were written from."""
+    gold = json.loads((GOLDEN / "idx" / "md5_scale.json").read_text())
+    spec = gold["spec"]
+    n, k = spec["len"], spec["k"]
+    dev = fm.DeviceIndex.build_synthetic(n, spec["seed"], k, with_klcp=True, mask_permille=spec["mask_permille"])
+    prefix = str(tmp_path / "scale")
+    dev.write_files(prefix)
+    for part, want in gold["md5"].items():
+        data = open(f"{prefix}.fmsi.{part}", "rb").read()
+        assert len(data) == gold["bytes"][part] and hashlib.md5(data).hexdigest() == want, part
+    import torch
+    loaded = fm.DeviceIndex.from_files(prefix, use_klcp=True, prefix_len=13).enable_pair_layout().enable_verify()
+    nq = 1 << 21
+    d_kmers = torch.empty(nq, dtype=torch.int64, device="cuda")
+    dev.synthetic_queries_dev(k, 5, 0, nq, d_kmers.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    for mode in (fm.MODE_OR, fm.MODE_ALL):
+        a = device_answers(fm, loaded, d_kmers, nq, k, mode | fm.STRICT | fm.KERNEL_PHASED)
+        b = device_answers(fm, dev, d_kmers, nq, k, mode | fm.STRICT | fm.KERNEL_LOCKSTEP)
+        assert np.array_equal(a, b)
+    # -S on the loaded files: streaming == isolated windows
+    L, n_reads = 2000, 256
+    d_reads = torch.empty((n_reads * L) // 32 + 2, dtype=torch.int64, device="cuda")
+    dev.synthetic_reads_dev(L, 3, 0, n_reads, d_reads.data_ptr(), 2000, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    packed = d_reads.cpu().numpy().view(np.uint64)
+    starts = np.arange(n_reads, dtype=np.uint64) * np.uint64(L)
+    wins = np.full(n_reads, L - k + 1, dtype=np.uint32)
+    assert np.array_equal(loaded.query_stream(packed, n_reads * L, starts, wins, k, fm.MODE_OR | fm.STRICT),
+                          loaded.query_runs(packed, n_reads * L, starts, wins, k, fm.MODE_OR | fm.STRICT))
