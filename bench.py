@@ -63,6 +63,10 @@ def parse_args():
                     help="private prefix table length t (0 = none; default: 16; without candidate tables less while 4^t > 4n)")
     ap.add_argument("--kernel", choices=["phased", "pair", "refill", "lockstep"], default="phased",
                     help="phased = pair layout, table lookups in their own kernel (default); pair = the same in one kernel")
+    ap.add_argument("--accel", choices=["dict", "tables"], default="dict",
+                    help="private accelerator of the phased workload: dict = the k-mer dictionary (fmsi_hip_index_enable_dict: one 128-byte "
+                         "bucket read per k-mer, ~12 bytes of HBM per distinct k-mer); tables = prefix table + candidate tables (177 GB at t = 16)")
+    ap.add_argument("--dict-sparse", action="store_true", help="dictionary at half the load (twice the HBM, no second-level reads)")
     ap.add_argument("--mode", choices=["all", "or"], default="all")
     ap.add_argument("--read-len", type=int, default=10000, help="stream workload: bases per read")
     ap.add_argument("--subst-ppm", type=int, default=0, help="stream workload: substitutions per million bases of positive reads")
@@ -109,7 +113,7 @@ def pmc_traffic(args, n, batch, k):
         if (c.get("workload", "kmers"), c.get("n"), c.get("batch"), c.get("k"), c.get("prefix_len"), c.get("mode")) == \
                 (args.workload, n, batch, k, args.prefix_len, args.mode) and c.get("subst_ppm", 0) == args.subst_ppm and \
                 args.repeat_permille == 0 and \
-                ("stream" if (args.workload == "stream" and args.stream_via == "klcp") else
+                ("dict" if getattr(args, "use_dict", False) else "stream" if (args.workload == "stream" and args.stream_via == "klcp") else
                  ("pair" if (args.kernel == "phased" or args.workload == "stream") else args.kernel)) in t.get("kernel", "") and \
                 c.get("stream_via", "klcp") == (args.stream_via if args.workload == "stream" else "klcp"):
             best = t
@@ -146,6 +150,12 @@ def main():
 
     n = int(args.n)
     k = args.k
+    # the dictionary answers presence queries of the phased workload and of `--stream-via runs`; the kLCP kernel and the A/B kernels
+    # (--kernel pair | refill | lockstep) run without it
+    use_dict = args.accel == "dict" and k <= 32 and ((not stream_mode and args.kernel == "phased") or (stream_mode and args.stream_via == "runs"))
+    args.use_dict = use_dict
+    if use_dict and args.prefix_len < 0:
+        args.prefix_len = 0   # no prefix table: the dictionary is the accelerator, the LF-walk legs run table-less anyway
     if args.prefix_len < 0:
         # Measured: the largest table, t = 16, is the fastest, and with the candidate tables (k - t <= 15: one
         # line settles a k-mer) that holds for ANY index size -- E. coli scale: 44 G k-mers/s with the 172 GB of t = 16 tables
@@ -161,11 +171,18 @@ def main():
                                            repeats=(args.repeat_permille, args.repeat_families, args.repeat_divergence_permille))
     build_s = time.time() - t0
     flags = fm.MODE_ALL if args.mode == "all" else fm.MODE_OR
-    if stream_mode and args.stream_via == "runs":
+    accel_s = 0.0
+    if use_dict:
+        t0 = time.time()
+        index.enable_pair_layout()   # (the table-less LF-walk leg and the canonical-step count use it)
+        index.enable_dict(sparse=args.dict_sparse)
+        accel_s = time.time() - t0
+        build_s += accel_s
+    if stream_mode and args.stream_via == "runs" and not use_dict:
         index.enable_pair_layout()
         if 0 < args.prefix_len < k and not args.no_verify:
             index.enable_verify()
-    if not stream_mode:
+    if not stream_mode and not use_dict:
         if args.kernel in ("pair", "phased"):
             t0 = time.time()
             index.enable_pair_layout()
@@ -176,6 +193,8 @@ def main():
                     print(f"warning: text verification is off ({e})", file=sys.stderr)
             build_s += time.time() - t0
         flags |= {"phased": fm.KERNEL_PHASED, "pair": fm.KERNEL_PAIR, "refill": fm.KERNEL_REFILL, "lockstep": fm.KERNEL_LOCKSTEP}[args.kernel]
+    if use_dict:
+        flags |= fm.KERNEL_DICT
     stream = torch.cuda.current_stream().cuda_stream
 
     # ---- one step's input, resident in HBM ----------------------------------------------------------------
@@ -391,6 +410,8 @@ def main():
             lane_lookups = (not stream_mode or args.stream_via == "runs") and args.kernel == "phased" and entry_b and k - int(index.info.prefix_len) <= 15
             lookup_b = 64
             entry_used_b = entry_b if lane_lookups else 64
+            if use_dict:   # a lookup is one 128-byte bucket (sixteen 8-byte slots, eight lanes x 16 bytes in one instruction)
+                lookup_b, entry_used_b, lane_lookups = 128, 128, False
             out_b = batch / 8.0 if bits else 1.0 * batch   # packed: one bit per window
             bytes_launch = block_b * (blocks_read - lookups) + lookup_b * lookups + 8 * klcp_words + in_bytes + out_b
             bytes_launch += 32 * verify_reads   # counted as two 32-byte sectors per verification
@@ -399,7 +420,7 @@ def main():
             ach = bytes_launch / avg_kernel_s / 1e9
             roof = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(args, n, batch, k),
-                    "kernel": ("query_stream_kernel" if stream_mode and args.stream_via == "klcp" else
+                    "kernel": "dict_lookup_kernel" if use_dict else ("query_stream_kernel" if stream_mode and args.stream_via == "klcp" else
                                ("lookup_lane_kernel" if lane_lookups else "pair_lookup_kernel") + " + query_pair_kernel"
                                if args.kernel == "phased" or stream_mode else f"query_{args.kernel}_kernel"),
                     "avg_kernel_ms": round(avg_kernel_s * 1e3, 4), "launches": launches,
@@ -439,7 +460,13 @@ def main():
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed_max / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
             "config": {"workload": wl, "index_rows": int(info.n), "k": k, "queries_per_step_per_gpu": batch, "mode": args.mode,
-                       "kernel": ("phased-runs" if args.stream_via == "runs" else "stream") if stream_mode else args.kernel,
+                       "kernel": ("dictionary-runs" if stream_mode else "dictionary") if use_dict else
+                                 (("phased-runs" if args.stream_via == "runs" else "stream") if stream_mode else args.kernel),
+                       "accelerator": ({"kind": "k-mer dictionary", "bytes": int(info.dict_bytes), "levels": int(info.dict_levels),
+                                        "log2_buckets": int(info.dict_log2_buckets), "keys_per_level": [int(x) for x in info.dict_keys][:int(info.dict_levels)],
+                                        "build_seconds": round(accel_s, 2)} if use_dict else
+                                       {"kind": "prefix table + candidate tables", "prefix_table_len": int(info.prefix_len),
+                                        "candidate_entry_bytes": int(info.candidate_entry_bytes)}),
                        "prefix_table_len": int(info.prefix_len), "index_bytes_hbm": int(info.device_bytes),
                        "candidate_entry_bytes": int(info.candidate_entry_bytes),
                        "block_bytes": 128 if (args.kernel in ("pair", "phased") and not stream_mode) or (stream_mode and args.stream_via == "runs") else 64,

@@ -29,6 +29,8 @@ KERNEL_LOCKSTEP = 0x10
 KERNEL_REFILL = 0x20
 KERNEL_PAIR = 0x30
 KERNEL_PHASED = 0x40
+KERNEL_DICT = 0x50
+DICT_SPARSE = 0x1
 NO_PREFIX_TABLE = 0x100
 OUT_BITS = 0x200
 N_COUNTERS = 8
@@ -61,7 +63,8 @@ class IndexInfo(C.Structure):
         ("n", C.c_uint64), ("k", C.c_int32), ("has_klcp", C.c_int32), ("device", C.c_int32),
         ("prefix_len", C.c_int32), ("block_bytes", C.c_uint64), ("block_symbols", C.c_uint64),
         ("n_blocks", C.c_uint64), ("device_bytes", C.c_uint64), ("counts", C.c_uint64 * 4), ("dollar_position", C.c_uint64),
-        ("candidate_entry_bytes", C.c_uint64),
+        ("candidate_entry_bytes", C.c_uint64), ("dict_bytes", C.c_uint64), ("dict_keys", C.c_uint64 * 4), ("dict_ambiguous", C.c_uint64),
+        ("dict_levels", C.c_uint32), ("dict_log2_buckets", C.c_uint32),
     ]
 
 
@@ -131,6 +134,7 @@ def lib() -> C.CDLL:
     L.fmsi_hip_index_download_klcp.argtypes = [vp, vp]
     L.fmsi_hip_index_enable_pair_layout.argtypes = [vp]
     L.fmsi_hip_index_enable_verify.argtypes = [vp]
+    L.fmsi_hip_index_enable_dict.argtypes = [vp, u32]
     L.fmsi_hip_synthetic_reads.argtypes = [vp, u64, u64, u64, u64, u32, vp, vp]
     L.fmsi_hip_query_kmers.argtypes = [vp, vp, u64, i32, u32, vp, vp, vp]
     L.fmsi_hip_query_windows.argtypes = [vp, vp, u64, vp, u64, i32, u32, vp, vp, vp]
@@ -337,6 +341,12 @@ class DeviceIndex:
     def enable_verify(self):
         """Add text verification for one-row table intervals (fmsi_hip_index_enable_verify); used by the phased kernels."""
         _check(lib().fmsi_hip_index_enable_verify(self._h))
+        _check(lib().fmsi_hip_index_get_info(self._h, C.byref(self.info)))
+        return self
+
+    def enable_dict(self, sparse: bool = False):
+        """Add the k-mer dictionary (fmsi_hip_index_enable_dict): presence queries with the index's k become one bucket read."""
+        _check(lib().fmsi_hip_index_enable_dict(self._h, DICT_SPARSE if sparse else 0))
         _check(lib().fmsi_hip_index_get_info(self._h, C.byref(self.info)))
         return self
 

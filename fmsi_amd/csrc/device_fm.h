@@ -128,4 +128,36 @@ __device__ __forceinline__ uint32_t lanes_below(uint64_t mask) {
     return __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(mask >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(mask), 0u));
 }
 
+
+// FMSI_HIP_OUT_BITS: a chunk's result bytes (LDS, `len` of them, the chunk starting at window `start`, a multiple of 128) leave
+// bit-packed -- window w is bit w & 63 of u64 word w >> 6 (its byte's bit 0), STRICT: nibble w & 15 of word w >> 4 (the byte's low
+// four bits: (fwd + 1) | (rc + 1) << 2).  One 8-byte store per 64 (16) windows instead of 64 (16) bytes.
+__device__ __forceinline__ void flush_packed_results(const uint8_t* res, uint32_t len, bool strict, uint8_t* out, uint64_t start, uint32_t lane) {
+    unsigned long long* dst = reinterpret_cast<unsigned long long*>(out);
+    if (!strict) {
+        const uint32_t words = (len + 63u) >> 6;
+        for (uint32_t w = lane; w < words; w += 64u) {
+            const uint64_t* src = reinterpret_cast<const uint64_t*>(res + 64u * w);
+            unsigned long long v = 0;
+#pragma unroll
+            for (uint32_t b = 0; b < 8u; ++b) v |= (((src[b] & 0x0101010101010101ull) * 0x0102040810204080ull) >> 56) << (8u * b);
+            const uint32_t valid = len - 64u * w;
+            if (valid < 64u) v &= (1ull << valid) - 1ull;
+            __builtin_nontemporal_store(v, dst + (start >> 6) + w);
+        }
+    } else {
+        const uint32_t words = (len + 15u) >> 4;
+        for (uint32_t w = lane; w < words; w += 64u) {
+            const uint4 x = *reinterpret_cast<const uint4*>(res + 16u * w);
+            auto nib = [](uint32_t d) -> unsigned long long {
+                return (d & 0xFu) | ((d >> 4) & 0xF0u) | ((d >> 8) & 0xF00u) | ((d >> 12) & 0xF000u);
+            };
+            unsigned long long v = nib(x.x) | (nib(x.y) << 16) | (nib(x.z) << 32) | (nib(x.w) << 48);
+            const uint32_t valid = len - 16u * w;
+            if (valid < 16u) v &= (1ull << (4u * valid)) - 1ull;
+            __builtin_nontemporal_store(v, dst + (start >> 4) + w);
+        }
+    }
+}
+
 }  // namespace fmsi

@@ -1,0 +1,660 @@
+// The k-mer dictionary: one 128-byte random read per query k-mer, whatever the text looks like.
+//
+// Why.  With the prefix table + candidate tables (fmsi_pair.hip) a k-mer costs one table line as long as the table key -- its
+// last t bases -- has few occurrences; a real genome's repeats break that (17 G k-mers/s instead of 43 G on a
+// text with 2 %-diverged repeat families), the tables take 137 GB at t = 16 for ANY index, and `-S` batches with substitutions
+// fall back to steps.  What decides a query is the full k-mer, so this private accelerator is keyed by it: every distinct
+// canonical k-mer of the superstring -- c = min(q, rc(q)) -- is stored with the answers get_range_with_pattern() +
+// infer_presence() (src/fms_index.h:117-144) give for c and for rc(c): absent / present with `-O` and default-mode bits, 2 bits
+// per strand.  A query is then: canonical form, hash, ONE bucket read, compare -- both strands settled, in both modes, for present
+// and absent k-mers alike; a k-mer that is not in the dictionary occurs on neither strand.  The answers in the slots are computed
+// from the index itself (below), so results are the reference's by construction; tests/ pin dictionary == LF walk == oracle.
+//
+// Layout.  Level 0: 2^b buckets of 128 bytes = 16 slots of 8 bytes, b the smallest with <= 10.5 keys per bucket on average
+// (human scale: 2^28 buckets = 34 GB for 2.8 G k-mers; the footprint follows n, an E. coli index takes 64 MB).  h = mix64(c) is a
+// bijection on 64 bits; bucket = h >> (64 - b), and a slot holds the other 64 - b bits ("quotient", <= 60 bits) << 4 | answer
+// nibble, so a match is exact -- no fingerprints, no false positives.  Answer nibble = code(c) | code(rc(c)) << 2 with code 0
+// absent, 1 present (all occurrences OFF), 2 some occurrence ON but not the first row of the interval, 3 first row ON; it is never 0
+// for a stored key (the k-mer occurs on one strand at least), so an all-zero slot is empty.  A bucket that would hold more than
+// 16 keys keeps 15 and a marker in its last slot; its other keys go to level 1 (its own hash and size, <= 3 keys per bucket), and
+// so on -- 1.1 % of the keys and 3.8 % of the buckets at the densest level-0 load, so 1.04 reads per k-mer at worst.
+//
+// The memory path serves ~45-48 G random 128-byte requests per second when EIGHT lanes fetch 16 bytes each of one line in one
+// instruction (tools/gather_bench entry, coop 8: profiles/r01k_gather_entry.txt), the same rate as for 64-byte or 16-byte
+// requests: the bucket size is free, and 128 bytes keep the overflow rare at 12 bytes of HBM per k-mer.  So a wave looks 64
+// k-mers up per round with eight load instructions of eight buckets each; lane l owns k-mer l, lanes 8j .. 8j+7 serve k-mer
+// 8g + j in round g.
+#include <hip/hip_runtime.h>
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
+#include <rocprim/iterator/counting_iterator.hpp>
+#include <rocprim/iterator/transform_iterator.hpp>
+
+#include <algorithm>
+#include <cstdlib>
+#include <string>
+#include <vector>
+
+#include "../../include/fmsi_hip.h"
+#include "common.h"
+#include "device_fm.h"
+#include "index_priv.h"
+
+namespace fmsi {
+
+namespace {
+
+constexpr uint32_t kDictSlots = 16;
+constexpr uint32_t kMarkerLo = 0xFFFFFFF0u, kMarkerHi = 0xFFFFFFFFu;   // slot 15 of an overflowed bucket (answer nibble 0: never a key)
+constexpr uint64_t kLevelSalt[kDictMaxLevels] = {0ull, 0x9E3779B97F4A7C15ull, 0xD1B54A32D192ED03ull, 0xA24BAED4963EE407ull};
+
+// murmur3's 64-bit finalizer: a bijection on u64 (each step is invertible)
+__host__ __device__ inline uint64_t dict_mix(uint64_t x) {
+    x ^= x >> 33;
+    x *= 0xFF51AFD7ED558CCDull;
+    x ^= x >> 33;
+    x *= 0xC4CEB9FE1A85EC53ull;
+    x ^= x >> 33;
+    return x;
+}
+__host__ __device__ inline uint64_t dict_unmix(uint64_t x) {
+    x ^= x >> 33;
+    x *= 0x9CB4B2F8129337DBull;   // inverse of 0xC4CEB9FE1A85EC53 mod 2^64
+    x ^= x >> 33;
+    x *= 0x4F74430C22A54005ull;   // inverse of 0xFF51AFD7ED558CCD mod 2^64
+    x ^= x >> 33;
+    return x;
+}
+static_assert(0xFF51AFD7ED558CCDull * 0x4F74430C22A54005ull == 1ull && 0xC4CEB9FE1A85EC53ull * 0x9CB4B2F8129337DBull == 1ull, "hash inverses");
+
+__device__ __forceinline__ uint4 load16_nt(const uint4* p) {
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    const u32x4 t = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
+    return make_uint4(t.x, t.y, t.z, t.w);
+}
+
+// ---- the lookup kernel --------------------------------------------------------------------------------------------------
+// A wave owns a contiguous chunk of windows (<= 4096, a multiple of 128), as the other query kernels do; result bytes collect in
+// LDS and leave as 16 bytes per lane -- or bit-packed (FMSI_HIP_OUT_BITS).  RUNS: `kmers` is a 2-bit packed sequence and the
+// windows are cut here (fmsi_hip_query_runs; see pair_lookup_kernel).
+template <bool COUNT, bool RUNS>
+__global__ __launch_bounds__(256) void dict_lookup_kernel(DictIndex dx, const uint64_t* __restrict__ kmers, uint64_t n_windows, int k, uint32_t flags,
+                                                          uint32_t chunk, uint8_t* __restrict__ out, unsigned long long* __restrict__ counters,
+                                                          const uint64_t* __restrict__ run_start, const uint64_t* __restrict__ run_off, uint64_t n_runs) {
+    constexpr uint32_t kMaxChunk = 4096u, kQueue = 128u;
+    __shared__ uint64_t s_qh[4][kQueue];     // k-mers whose level-0 bucket had overflowed: their hash ...
+    __shared__ uint32_t s_qi[4][kQueue];     // ... and index in the chunk | orientation flags
+    __shared__ uint32_t s_tmp[4][64];        // probe results on their way from the serving lanes to the owning lane
+    __shared__ __attribute__((aligned(16))) uint8_t s_res[4][kMaxChunk];
+    const uint32_t strict = flags & FMSI_HIP_STRICT;
+    const uint32_t mode_all = flags & FMSI_HIP_MODE_ALL;
+    const bool out_bits = (flags & FMSI_HIP_OUT_BITS) != 0u;
+    const uint32_t lane = threadIdx.x & 63u, wib = threadIdx.x >> 6;
+    const uint32_t grp = lane >> 3, sub8 = lane & 7u;
+    uint64_t* qh = s_qh[wib];
+    uint32_t* qi = s_qi[wib];
+    uint32_t* tmp = s_tmp[wib];
+    uint8_t* res = s_res[wib];
+    const uint64_t wave = (static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t start = wave * chunk;
+    const uint32_t len = start < n_windows ? static_cast<uint32_t>(min(static_cast<uint64_t>(chunk), n_windows - start)) : 0u;
+    uint32_t qhead = 0, qtail = 0;   // wave-uniform: the queue holds [qhead, qtail), positions mod kQueue
+    uint32_t n_reads = 0, n_final = 0;
+    uint64_t run = 0, run_last = 0, run_end = 0, run_delta = 0;
+    auto find_run = [&](uint64_t lo, uint64_t hi, uint64_t q) -> uint64_t {   // run_off[lo] <= q < run_off[hi]
+        while (hi - lo > 1) {
+            const uint64_t mid = (lo + hi) >> 1;
+            if (run_off[mid] <= q) lo = mid;
+            else hi = mid;
+        }
+        return lo;
+    };
+    if (RUNS && len) {
+        run = find_run(0, n_runs, start);
+        run_last = find_run(run, n_runs, start + len - 1u);
+        run_end = run_off[run + 1];
+        run_delta = run_start[run] - run_off[run];
+    }
+
+    // 64 hashes, one per lane (`active` lanes only), against level `lv`: eight rounds of eight buckets.  Returns at the OWNING lane
+    // the answer nibble of its k-mer (0: not in this bucket) | 16 when the bucket had overflowed (the key may be a level further)
+    auto probe = [&](uint32_t lv, uint64_t h, bool active) -> uint32_t {
+        const DictLevel L = dx.lv[lv];
+        const uint32_t bidx = static_cast<uint32_t>(h >> L.shift);
+        const uint64_t key = (h << (64u - L.shift)) >> (60u - L.shift);   // quotient << 4 (shift <= 60)
+        const uint32_t klo = static_cast<uint32_t>(key) | (active ? 1u : 0u), khi = static_cast<uint32_t>(key >> 32);
+        uint4 piece[8];
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {   // all loads first: eight lines per instruction, 64 in flight per wave
+            const int src = 8 * g + static_cast<int>(grp);
+            const uint32_t b = static_cast<uint32_t>(__shfl(static_cast<int>(bidx), src, 64));
+            const uint32_t a = static_cast<uint32_t>(__shfl(static_cast<int>(klo), src, 64)) & 1u;
+            piece[g] = make_uint4(0, 0, 0, 0);
+            if (a) piece[g] = load16_nt(L.buckets + (static_cast<size_t>(b) << 3) + sub8);
+        }
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            const int src = 8 * g + static_cast<int>(grp);
+            const uint32_t wl = static_cast<uint32_t>(__shfl(static_cast<int>(klo), src, 64)) & ~15u;
+            const uint32_t wh = static_cast<uint32_t>(__shfl(static_cast<int>(khi), src, 64));
+            const uint4 p = piece[g];
+            uint32_t v = 0;
+            if (((p.x ^ wl) & ~15u) == 0u && p.y == wh) v = p.x & 15u;     // (an empty or marker slot has nibble 0)
+            if (((p.z ^ wl) & ~15u) == 0u && p.w == wh) v |= p.z & 15u;
+            if (sub8 == 7u && p.z == kMarkerLo && p.w == kMarkerHi) v |= 16u;
+            v |= static_cast<uint32_t>(__shfl_xor(static_cast<int>(v), 1, 64));
+            v |= static_cast<uint32_t>(__shfl_xor(static_cast<int>(v), 2, 64));
+            v |= static_cast<uint32_t>(__shfl_xor(static_cast<int>(v), 4, 64));
+            if (sub8 == 0u) tmp[src] = v;
+        }
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t mine = tmp[lane];
+        __builtin_amdgcn_wave_barrier();
+        return mine;
+    };
+    // answer nibble (0 = the k-mer is on neither strand) -> this window's result byte
+    auto encode = [&](uint32_t ans, bool swapped, bool pal) -> uint8_t {
+        const uint32_t cc = ans & 3u, cr = pal ? cc : (ans >> 2);           // codes of the canonical k-mer and of its reverse complement
+        const uint32_t cf = swapped ? cr : cc, cb = swapped ? cc : cr;      // ... of the query as given and of its reverse complement
+        const int rf = cf == 0u ? -1 : static_cast<int>(mode_all ? cf == 3u : cf >= 2u);
+        const int rr = cb == 0u ? -1 : static_cast<int>(mode_all ? cb == 3u : cb >= 2u);
+        if (strict) return static_cast<uint8_t>(static_cast<uint32_t>(rf + 1) | (static_cast<uint32_t>(rr + 1) << 2));
+        // forward strand first, the reverse complement when it does not decide (src/fms_index.h:283-299)
+        return static_cast<uint8_t>(mode_all ? (rf != -1 ? rf : rr) == 1 : (rf == 1 || rr == 1));
+    };
+    // the queue's first `items` entries through the further levels
+    auto slow_round = [&](uint32_t items) {
+        bool active = lane < items;
+        const uint32_t pos = (qhead + lane) & (kQueue - 1u);
+        uint64_t h = active ? qh[pos] : 0ull;
+        const uint32_t info = active ? qi[pos] : 0u;
+        uint32_t ans = 0;
+        for (uint32_t lv = 1; lv < dx.levels && __any(active); ++lv) {
+            h = dict_mix(h + kLevelSalt[lv]);
+            const uint32_t v = probe(lv, h, active);
+            if (active) {
+                n_reads++;
+                if ((v & 15u) || !(v & 16u)) {
+                    ans = v & 15u;
+                    active = false;
+                }
+            }
+        }
+        if (lane < items) {
+            n_final++;
+            res[info & 0xFFFFu] = encode(ans, (info >> 16) & 1u, (info >> 17) & 1u);
+        }
+        qhead += items;
+    };
+
+    for (uint32_t base = 0; base < len; base += 64u) {
+        const uint32_t ql = base + lane;
+        const bool valid = ql < len;
+        const uint64_t q = start + ql;
+        uint64_t f = 0ull;
+        if (RUNS) {
+            if (valid) {
+                if (q >= run_end) {
+                    run = find_run(run + 1, run_last + 1, q);
+                    run_end = run_off[run + 1];
+                    run_delta = run_start[run] - run_off[run];
+                }
+                f = window_kmer(kmers, q + run_delta, k);
+            }
+        } else if (valid) {
+            f = __builtin_nontemporal_load(kmers + q);   // (read once)
+        }
+        const uint64_t rc = revcomp_2bit(f, k);
+        const bool swapped = rc < f, pal = rc == f;
+        const uint64_t h = dict_mix(swapped ? rc : f);
+        const uint32_t v = probe(0u, h, valid);
+        bool slow = false;
+        if (valid) {
+            n_reads++;
+            if ((v & 15u) || !(v & 16u)) {
+                n_final++;
+                res[ql] = encode(v & 15u, swapped, pal);
+            } else {
+                slow = true;
+            }
+        }
+        const uint64_t m = __ballot(slow);
+        if (m) {
+            if (slow) {
+                const uint32_t pos = (qtail + lanes_below(m)) & (kQueue - 1u);
+                qh[pos] = h;
+                qi[pos] = ql | (swapped ? 0x10000u : 0u) | (pal ? 0x20000u : 0u);
+            }
+            qtail += static_cast<uint32_t>(__popcll(m));
+            while (qtail - qhead >= 64u) slow_round(64u);
+        }
+    }
+    if (qtail != qhead) slow_round(qtail - qhead);
+    if (len && out_bits) {
+        flush_packed_results(res, len, strict != 0u, out, start, lane);
+    } else if (len) {
+        uint8_t* dst = out + start;
+        const bool aligned = (reinterpret_cast<uintptr_t>(dst) & 15u) == 0;
+        for (uint32_t off = lane * 16u; off < len; off += 64u * 16u) {
+            if (aligned && off + 16u <= len) {
+                typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+                __builtin_nontemporal_store(*reinterpret_cast<const u32x4*>(res + off), reinterpret_cast<u32x4*>(dst + off));
+            } else {
+                for (uint32_t b = off; b < min(len, off + 16u); ++b) dst[b] = res[b];
+            }
+        }
+    }
+    if (COUNT) {
+        uint32_t v[3] = {n_reads, n_final, n_final};   // bucket reads; windows answered; searches (one settles both strands)
+        const int slot[3] = {4, 6, 3};
+#pragma unroll
+        for (int qq = 0; qq < 3; ++qq) {
+            uint32_t x = v[qq];
+            for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+            if (lane == 0 && x) {
+                atomicAdd(&counters[slot[qq]], static_cast<unsigned long long>(x));
+                if (qq == 0) atomicAdd(&counters[1], static_cast<unsigned long long>(x));   // [1] counts the bucket reads with the blocks
+            }
+        }
+    }
+}
+
+// ---- construction ---------------------------------------------------------------------------------------------------------
+struct DevMem {
+    void* p = nullptr;
+    ~DevMem() { reset(); }
+    void reset() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+    }
+    int alloc(size_t bytes, const char* what) {
+        reset();
+        if (hipMalloc(&p, bytes ? bytes : 8) != hipSuccess) {
+            (void)hipGetLastError();
+            set_last_error(std::string("hipMalloc failed for the k-mer dictionary (") + what + ", " + std::to_string(bytes >> 20) + " MiB)");
+            return FMSI_HIP_ENOMEM;
+        }
+        return 0;
+    }
+    template <class T>
+    T* as() const { return static_cast<T*>(p); }
+    void* release() {
+        void* q = p;
+        p = nullptr;
+        return q;
+    }
+};
+
+uint32_t grid_of(uint64_t items) { return static_cast<uint32_t>(std::min<uint64_t>((items + 255) / 256, 0x7FFFFFFFull)); }
+
+// the walk's letters (case = mask) -> 2-bit text words and mask words; one thread per 64 positions
+__global__ __launch_bounds__(256) void dict_planes_kernel(const char* __restrict__ chars, uint64_t len, uint64_t n_words64, uint64_t* __restrict__ text2,
+                                                          uint64_t* __restrict__ maskw) {
+    const uint64_t w = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (w >= n_words64) return;
+    uint64_t t0 = 0, t1 = 0, m = 0;
+    for (uint32_t b = 0; b < 64u; ++b) {
+        const uint64_t p = w * 64u + b;
+        if (p >= len) break;
+        const uint32_t ch = static_cast<uint8_t>(chars[p]);
+        const uint32_t lc = ch | 0x20u;
+        const uint64_t c = lc == 'a' ? 0u : (lc == 'c' ? 1u : (lc == 'g' ? 2u : 3u));
+        if (b < 32u) t0 |= c << (2u * b);
+        else t1 |= c << (2u * (b - 32u));
+        if (ch >= 'A' && ch <= 'Z') m |= 1ull << b;   // is_upper = mask 1, src/kmers.h:71-73
+    }
+    text2[2 * w] = t0;
+    text2[2 * w + 1] = t1;
+    maskw[w] = m;
+}
+
+// text window p -> (hash of its canonical k-mer, mask bit | orientation << 1)
+__global__ __launch_bounds__(256) void dict_keys_kernel(const uint64_t* __restrict__ text2, const uint64_t* __restrict__ maskw, uint64_t n_windows, int k,
+                                                        uint64_t* __restrict__ keys, uint8_t* __restrict__ vals) {
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
+    for (uint64_t p = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; p < n_windows; p += stride) {
+        const uint64_t f = window_kmer(text2, p, k), rc = revcomp_2bit(f, k);
+        const bool swapped = rc < f;
+        keys[p] = dict_mix(swapped ? rc : f);
+        vals[p] = static_cast<uint8_t>(((maskw[p >> 6] >> (p & 63u)) & 1ull) | (swapped ? 2u : 0u));
+    }
+}
+
+struct HeadFlag {
+    const uint64_t* keys;
+    __host__ __device__ uint32_t operator()(uint64_t i) const { return (i == 0 || keys[i] != keys[i - 1]) ? 1u : 0u; }
+};
+
+// One thread per occurrence; the first of each run of equal hashes folds the run into the key's answer nibble.  Per orientation
+// (0: the occurrence reads the canonical k-mer, 1: its reverse complement): code 0 absent, 1 all occurrences OFF, 3 all ON; when ON
+// and OFF occurrences mix, the default mode's answer is 1 and `-O`'s is the mask bit of the interval's FIRST row, which only the
+// suffix order knows -- such keys get code 2 for now and go to the list the index itself resolves (dict_patch_kernel).
+__global__ __launch_bounds__(256) void dict_fold_kernel(const uint64_t* __restrict__ keys, const uint8_t* __restrict__ vals, const uint32_t* __restrict__ uidx,
+                                                        uint64_t n, uint64_t* __restrict__ ukeys, uint8_t* __restrict__ ucodes,
+                                                        uint64_t* __restrict__ amb_kmers, uint32_t* __restrict__ amb_where, uint32_t amb_cap,
+                                                        uint32_t* __restrict__ amb_count) {
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
+    for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const uint64_t key = keys[i];
+        if (i != 0 && keys[i - 1] == key) continue;
+        uint32_t on[2] = {0, 0}, off[2] = {0, 0};
+        for (uint64_t j = i; j < n && keys[j] == key; ++j) {
+            const uint32_t v = vals[j];
+            if (v & 1u) on[v >> 1] = 1u;
+            else off[v >> 1] = 1u;
+        }
+        uint32_t code = 0, amb = 0;
+#pragma unroll
+        for (int o = 0; o < 2; ++o) {
+            const uint32_t c = on[o] ? (off[o] ? 2u : 3u) : (off[o] ? 1u : 0u);
+            code |= c << (2 * o);
+            if (on[o] && off[o]) amb |= 1u << o;
+        }
+        const uint32_t u = uidx[i];
+        ukeys[u] = key;
+        ucodes[u] = static_cast<uint8_t>(code);
+        if (amb) {
+            const uint32_t at = atomicAdd(amb_count, 1u);
+            if (at < amb_cap) {
+                amb_kmers[at] = dict_unmix(key);   // the canonical k-mer: its forward strand is orientation 0
+                amb_where[2 * at] = u;
+                amb_where[2 * at + 1] = amb;
+            }
+        }
+    }
+}
+
+// `-O` answers of the listed keys from the index's own search (STRICT bytes of query mode ALL: (fwd + 1) | (rc + 1) << 2)
+__global__ __launch_bounds__(256) void dict_patch_kernel(const uint8_t* __restrict__ strict_bytes, const uint32_t* __restrict__ amb_where, uint32_t count,
+                                                         uint8_t* __restrict__ ucodes) {
+    const uint32_t a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= count) return;
+    const uint32_t u = amb_where[2 * a], amb = amb_where[2 * a + 1], byte = strict_bytes[a];
+    uint32_t code = ucodes[u];
+    if (amb & 1u) code = (code & ~3u) | (2u + ((byte & 3u) == 2u ? 1u : 0u));
+    if (amb & 2u) code = (code & ~12u) | ((2u + (((byte >> 2) & 3u) == 2u ? 1u : 0u)) << 2);
+    ucodes[u] = static_cast<uint8_t>(code);
+}
+
+// sorted distinct hashes -> first / last index of every non-empty bucket
+__global__ __launch_bounds__(256) void dict_bounds_kernel(const uint64_t* __restrict__ ukeys, uint64_t count, uint32_t shift, uint32_t* __restrict__ first,
+                                                          uint32_t* __restrict__ last) {
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
+    for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < count; i += stride) {
+        const uint64_t b = ukeys[i] >> shift;
+        if (i == 0 || (ukeys[i - 1] >> shift) != b) first[b] = static_cast<uint32_t>(i);
+        if (i + 1 == count || (ukeys[i + 1] >> shift) != b) last[b] = static_cast<uint32_t>(i);
+    }
+}
+
+// ... -> slots; the keys a bucket cannot hold go to the next level's list
+__global__ __launch_bounds__(256) void dict_fill_kernel(const uint64_t* __restrict__ ukeys, const uint8_t* __restrict__ ucodes, uint64_t count, uint32_t shift,
+                                                        const uint32_t* __restrict__ first, const uint32_t* __restrict__ last, uint64_t* __restrict__ slots,
+                                                        uint64_t* __restrict__ spill_keys, uint8_t* __restrict__ spill_codes, uint32_t spill_cap,
+                                                        uint32_t* __restrict__ spill_count) {
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
+    for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < count; i += stride) {
+        const uint64_t key = ukeys[i], b = key >> shift;
+        const uint32_t r = static_cast<uint32_t>(i) - first[b], held = last[b] - first[b] + 1u;
+        const bool over = held > kDictSlots;
+        if (!over || r < kDictSlots - 1u) {
+            slots[b * kDictSlots + r] = (((key << (64u - shift)) >> (60u - shift)) & ~15ull) | ucodes[i];
+        } else {
+            if (r == kDictSlots - 1u) slots[b * kDictSlots + r] = (static_cast<uint64_t>(kMarkerHi) << 32) | kMarkerLo;
+            const uint32_t at = atomicAdd(spill_count, 1u);
+            if (at < spill_cap) {
+                spill_keys[at] = key;
+                spill_codes[at] = ucodes[i];
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void dict_rehash_kernel(uint64_t* __restrict__ keys, uint64_t count, uint64_t salt) {
+    const uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i < count) keys[i] = dict_mix(keys[i] + salt);
+}
+
+uint32_t level_bits(uint64_t count, double per_bucket) {
+    uint32_t b = 4;
+    while (b < 32u && static_cast<double>(count) / static_cast<double>(1ull << b) > per_bucket) ++b;
+    return b;
+}
+
+#define DICT_TRY(expr)                                                                                    \
+    do {                                                                                                  \
+        hipError_t e_ = (expr);                                                                           \
+        if (e_ != hipSuccess) {                                                                           \
+            set_last_error(std::string("k-mer dictionary: ") + #expr + ": " + hipGetErrorString(e_));    \
+            return FMSI_HIP_EHIP;                                                                         \
+        }                                                                                                 \
+    } while (0)
+
+// sorted distinct hashes + codes of one level -> its buckets; what does not fit comes back in spill_* (count in *n_spill)
+int fill_level(const uint64_t* d_ukeys, const uint8_t* d_ucodes, uint64_t count, uint32_t bits, DevMem& buckets, DevMem& spill_keys, DevMem& spill_codes,
+               uint32_t* n_spill) {
+    const uint32_t shift = 64u - bits;
+    const uint64_t n_buckets = 1ull << bits;
+    int rc;
+    DevMem first, last, d_spill;
+    if ((rc = buckets.alloc(n_buckets * 128, "buckets")) || (rc = first.alloc(n_buckets * 4, "bucket bounds")) || (rc = last.alloc(n_buckets * 4, "bucket bounds")) ||
+        (rc = d_spill.alloc(4, "counter")))
+        return rc;
+    const uint32_t cap = static_cast<uint32_t>(std::min<uint64_t>(count / 8 + 4096, 0xFFFFFFFFull));
+    if ((rc = spill_keys.alloc(static_cast<size_t>(cap) * 8, "overflow keys")) || (rc = spill_codes.alloc(cap, "overflow keys"))) return rc;
+    DICT_TRY(hipMemset(buckets.p, 0, n_buckets * 128));
+    DICT_TRY(hipMemset(d_spill.p, 0, 4));
+    if (count) {
+        hipLaunchKernelGGL(dict_bounds_kernel, dim3(grid_of(count)), dim3(256), 0, 0, d_ukeys, count, shift, first.as<uint32_t>(), last.as<uint32_t>());
+        hipLaunchKernelGGL(dict_fill_kernel, dim3(grid_of(count)), dim3(256), 0, 0, d_ukeys, d_ucodes, count, shift, first.as<uint32_t>(), last.as<uint32_t>(),
+                           buckets.as<uint64_t>(), spill_keys.as<uint64_t>(), spill_codes.as<uint8_t>(), cap, d_spill.as<uint32_t>());
+        DICT_TRY(hipGetLastError());
+    }
+    DICT_TRY(hipMemcpy(n_spill, d_spill.p, 4, hipMemcpyDeviceToHost));
+    if (*n_spill > cap) {
+        set_last_error("k-mer dictionary: a level's overflow exceeds its list (degenerate hash distribution)");
+        return FMSI_HIP_ERANGE;
+    }
+    return 0;
+}
+
+template <bool COUNT, bool RUNS>
+void launch_dict_t(const fmsi_hip_index* idx, const uint64_t* d_in, uint64_t n, int k, uint32_t flags, uint8_t* o8, unsigned long long* d_counters, hipStream_t s,
+                   const uint64_t* d_runs, uint64_t n_runs) {
+    uint64_t chunk = n / (256ull * 4 * 2);
+    chunk = std::min<uint64_t>(std::max<uint64_t>(chunk, 128), 4096) & ~127ull;
+    const uint64_t waves = (n + chunk - 1) / chunk;
+    hipLaunchKernelGGL((dict_lookup_kernel<COUNT, RUNS>), dim3(static_cast<uint32_t>((waves + 3) / 4)), dim3(256), 0, s, idx->dict, d_in, n, k, flags,
+                       static_cast<uint32_t>(chunk), o8, d_counters, d_runs, d_runs + n_runs, n_runs);
+}
+
+}  // namespace
+
+bool dict_applies(const fmsi_hip_index* idx, int k, uint32_t flags) {
+    const uint32_t kernel = flags & FMSI_HIP_KERNEL_MASK;
+    return idx->dict.levels != 0 && k == idx->k && !(flags & (FMSI_HIP_ORDERS | FMSI_HIP_NO_PREFIX_TABLE)) &&
+           (kernel == FMSI_HIP_KERNEL_AUTO || kernel == FMSI_HIP_KERNEL_DICT);
+}
+
+int launch_dict_query(fmsi_hip_index* idx, const uint64_t* d_in, uint64_t n, int k, uint32_t flags, uint8_t* o8, unsigned long long* d_counters, hipStream_t s,
+                      const uint64_t* h_runs, uint64_t n_runs) {
+    const uint64_t* d_runs = nullptr;
+    if (h_runs) {   // the run table: n_runs starts, n_runs + 1 offsets (a slot of the handle's page-locked ring)
+        int rc = ensure_cap(&idx->d_tasks, &idx->d_tasks_cap, (2 * n_runs + 1) * 8);
+        if (rc) return rc;
+        FMSI_HIP_TRY(hipMemcpyAsync(idx->d_tasks, h_runs, (2 * n_runs + 1) * 8, hipMemcpyHostToDevice, s));
+        d_runs = static_cast<const uint64_t*>(idx->d_tasks);
+    }
+    if (h_runs) {
+        if (d_counters) launch_dict_t<true, true>(idx, d_in, n, k, flags, o8, d_counters, s, d_runs, n_runs);
+        else launch_dict_t<false, true>(idx, d_in, n, k, flags, o8, d_counters, s, d_runs, n_runs);
+    } else {
+        if (d_counters) launch_dict_t<true, false>(idx, d_in, n, k, flags, o8, d_counters, s, nullptr, 0);
+        else launch_dict_t<false, false>(idx, d_in, n, k, flags, o8, d_counters, s, nullptr, 0);
+    }
+    FMSI_HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+}  // namespace fmsi
+
+using namespace fmsi;
+
+extern "C" int fmsi_hip_index_enable_dict(fmsi_hip_index* idx, uint32_t flags) {
+    if (!idx) return FMSI_HIP_EINVAL;
+    if (idx->dict.levels) return 0;
+    const int k = idx->k;
+    const uint64_t n = idx->n, len = n - 1;
+    if (k < 1 || k > 32 || len < static_cast<uint64_t>(k)) {
+        set_last_error("the k-mer dictionary needs 1 <= k <= 32 and a superstring of at least k bases");
+        return FMSI_HIP_EINVAL;
+    }
+    FMSI_HIP_ON_DEVICE(idx->device);
+    const uint64_t windows = len - static_cast<uint64_t>(k) + 1;
+    int rc;
+    // 1. the superstring with its mask, from the index itself (the LF walk of `fmsi export`): any handle can add the dictionary
+    DevMem text2, maskw;
+    {
+        DevMem chars;
+        if ((rc = chars.alloc(len + 1, "text"))) return rc;
+        if ((rc = export_walk(idx, chars.as<char>(), nullptr))) return rc;
+        const uint64_t n64 = (len >> 6) + 2;
+        if ((rc = text2.alloc(n64 * 16, "text")) || (rc = maskw.alloc(n64 * 8, "mask"))) return rc;
+        hipLaunchKernelGGL(dict_planes_kernel, dim3(grid_of(n64)), dim3(256), 0, 0, chars.as<char>(), len, n64, text2.as<uint64_t>(), maskw.as<uint64_t>());
+        DICT_TRY(hipGetLastError());
+        DICT_TRY(hipDeviceSynchronize());
+    }
+    // 2. one (hash, mask bit | orientation) pair per window of the superstring, sorted by hash
+    DevMem ukeys, ucodes;
+    uint64_t n_unique = 0;
+    {
+        DevMem keys_a, keys_b, vals_a, vals_b, temp, uidx;
+        if ((rc = keys_a.alloc(windows * 8, "sort keys")) || (rc = keys_b.alloc(windows * 8, "sort keys")) || (rc = vals_a.alloc(windows, "sort values")) ||
+            (rc = vals_b.alloc(windows, "sort values")))
+            return rc;
+        hipLaunchKernelGGL(dict_keys_kernel, dim3(grid_of(windows)), dim3(256), 0, 0, text2.as<uint64_t>(), maskw.as<uint64_t>(), windows, k, keys_a.as<uint64_t>(),
+                           vals_a.as<uint8_t>());
+        DICT_TRY(hipGetLastError());
+        rocprim::double_buffer<uint64_t> dk(keys_a.as<uint64_t>(), keys_b.as<uint64_t>());
+        rocprim::double_buffer<uint8_t> dv(vals_a.as<uint8_t>(), vals_b.as<uint8_t>());
+        size_t tb = 0;
+        DICT_TRY(rocprim::radix_sort_pairs(nullptr, tb, dk, dv, static_cast<size_t>(windows), 0, 64, 0));
+        if ((rc = temp.alloc(tb, "sort scratch"))) return rc;
+        DICT_TRY(rocprim::radix_sort_pairs(temp.p, tb, dk, dv, static_cast<size_t>(windows), 0, 64, 0));
+        text2.reset();
+        maskw.reset();
+        // 3. distinct hashes: index of every occurrence's key among them
+        const uint64_t* sk = dk.current();
+        const uint8_t* sv = dv.current();
+        if ((rc = uidx.alloc((windows + 1) * 4, "key indices"))) return rc;
+        auto heads = rocprim::make_transform_iterator(rocprim::make_counting_iterator<uint64_t>(0), HeadFlag{sk});
+        size_t sb = 0;
+        DICT_TRY(rocprim::exclusive_scan(nullptr, sb, heads, uidx.as<uint32_t>(), 0u, static_cast<size_t>(windows), rocprim::plus<uint32_t>()));
+        if (sb > tb && (rc = temp.alloc(sb, "scan scratch"))) return rc;
+        DICT_TRY(rocprim::exclusive_scan(temp.p, sb, heads, uidx.as<uint32_t>(), 0u, static_cast<size_t>(windows), rocprim::plus<uint32_t>()));
+        uint32_t last_idx = 0;   // distinct keys before the last occurrence's position; + 1 when that occurrence starts a key of its own
+        uint64_t tail[2] = {0, 1};
+        DICT_TRY(hipMemcpy(&last_idx, uidx.as<uint32_t>() + (windows - 1), 4, hipMemcpyDeviceToHost));
+        if (windows >= 2) DICT_TRY(hipMemcpy(tail, sk + (windows - 2), 16, hipMemcpyDeviceToHost));
+        n_unique = static_cast<uint64_t>(last_idx) + (tail[0] != tail[1] ? 1u : 0u);
+        // 4. fold the occurrences into answer codes; keys whose `-O` answer depends on the suffix order are listed
+        DevMem amb_kmers, amb_where, amb_count;
+        const uint32_t amb_cap = static_cast<uint32_t>(std::min<uint64_t>(n_unique, 0x7FFFFFFFull));
+        if ((rc = ukeys.alloc(n_unique * 8, "distinct keys")) || (rc = ucodes.alloc(n_unique, "answer codes")) || (rc = amb_count.alloc(4, "counter"))) return rc;
+        DICT_TRY(hipMemset(amb_count.p, 0, 4));
+        // (the list is sized by a first counting pass: mixed masks on repeats only -- usually empty)
+        for (int pass = 0; pass < 2; ++pass) {
+            uint32_t cap = 0;
+            if (pass == 1) {
+                DICT_TRY(hipMemcpy(&cap, amb_count.p, 4, hipMemcpyDeviceToHost));
+                if (cap == 0) break;
+                cap = std::min(cap, amb_cap);
+                if ((rc = amb_kmers.alloc(static_cast<size_t>(cap) * 8, "ambiguous keys")) || (rc = amb_where.alloc(static_cast<size_t>(cap) * 8, "ambiguous keys"))) return rc;
+                DICT_TRY(hipMemset(amb_count.p, 0, 4));
+            }
+            hipLaunchKernelGGL(dict_fold_kernel, dim3(grid_of(windows)), dim3(256), 0, 0, sk, sv, uidx.as<uint32_t>(), windows, ukeys.as<uint64_t>(), ucodes.as<uint8_t>(),
+                               amb_kmers.as<uint64_t>(), amb_where.as<uint32_t>(), cap, amb_count.as<uint32_t>());
+            DICT_TRY(hipGetLastError());
+            DICT_TRY(hipDeviceSynchronize());
+        }
+        uint32_t n_amb = 0;
+        DICT_TRY(hipMemcpy(&n_amb, amb_count.p, 4, hipMemcpyDeviceToHost));
+        // the sort's buffers are no longer needed
+        keys_a.reset();
+        keys_b.reset();
+        vals_a.reset();
+        vals_b.reset();
+        uidx.reset();
+        temp.reset();
+        if (n_amb) {
+            // the index answers for them: first row of the interval, src/fms_index.h:129-131 (the dictionary is not installed yet,
+            // so this is the ordinary search)
+            DevMem bytes;
+            if ((rc = bytes.alloc(n_amb, "ambiguous keys"))) return rc;
+            if ((rc = fmsi_hip_query_kmers(idx, amb_kmers.as<uint64_t>(), n_amb, k, FMSI_HIP_MODE_ALL | FMSI_HIP_STRICT | FMSI_HIP_DEVICE_PTRS, bytes.p, nullptr, nullptr)))
+                return rc;
+            hipLaunchKernelGGL(dict_patch_kernel, dim3((n_amb + 255) / 256), dim3(256), 0, 0, bytes.as<uint8_t>(), amb_where.as<uint32_t>(), n_amb, ucodes.as<uint8_t>());
+            DICT_TRY(hipGetLastError());
+            DICT_TRY(hipDeviceSynchronize());
+        }
+        idx->dict_ambiguous = n_amb;
+    }
+    // 5. the levels: level 0 at <= 10.5 keys per bucket (FMSI_HIP_DICT_SPARSE: half that), the overflow levels at <= 3
+    DictIndex dx{};
+    dx.k = k;
+    void* owned[kDictMaxLevels] = {nullptr, nullptr, nullptr, nullptr};
+    uint64_t bytes_total = 0;
+    auto fail = [&](int code) {
+        for (void* p : owned)
+            if (p) (void)hipFree(p);
+        return code;
+    };
+    DevMem cur_keys, cur_codes;
+    cur_keys.p = ukeys.release();
+    cur_codes.p = ucodes.release();
+    uint64_t count = n_unique;
+    for (uint32_t lv = 0; lv < kDictMaxLevels; ++lv) {
+        const uint32_t bits = level_bits(count, lv == 0 ? ((flags & FMSI_HIP_DICT_SPARSE) ? 5.25 : 10.5) : 3.0);
+        DevMem buckets, spill_keys, spill_codes;
+        uint32_t n_spill = 0;
+        if ((rc = fill_level(cur_keys.as<uint64_t>(), cur_codes.as<uint8_t>(), count, bits, buckets, spill_keys, spill_codes, &n_spill))) return fail(rc);
+        dx.lv[lv].shift = 64u - bits;
+        dx.lv[lv].buckets = static_cast<const uint4*>(buckets.p);
+        owned[lv] = buckets.release();
+        bytes_total += (1ull << bits) * 128;
+        dx.levels = lv + 1;
+        idx->dict_keys[lv] = count;
+        if (n_spill == 0) break;
+        if (lv + 1 == kDictMaxLevels) {
+            set_last_error("k-mer dictionary: keys left over after the last level");
+            return fail(FMSI_HIP_ERANGE);
+        }
+        // the next level: its own hash of the spilled hashes, sorted
+        DevMem sk2, sc2, temp;
+        if ((rc = sk2.alloc(static_cast<size_t>(n_spill) * 8, "overflow keys")) || (rc = sc2.alloc(n_spill, "overflow keys"))) return fail(rc);
+        hipLaunchKernelGGL(dict_rehash_kernel, dim3((n_spill + 255) / 256), dim3(256), 0, 0, spill_keys.as<uint64_t>(), static_cast<uint64_t>(n_spill), kLevelSalt[lv + 1]);
+        rocprim::double_buffer<uint64_t> dk(spill_keys.as<uint64_t>(), sk2.as<uint64_t>());
+        rocprim::double_buffer<uint8_t> dv(spill_codes.as<uint8_t>(), sc2.as<uint8_t>());
+        size_t tb = 0;
+        if (rocprim::radix_sort_pairs(nullptr, tb, dk, dv, static_cast<size_t>(n_spill), 0, 64, 0) != hipSuccess || (rc = temp.alloc(tb, "sort scratch")) ||
+            rocprim::radix_sort_pairs(temp.p, tb, dk, dv, static_cast<size_t>(n_spill), 0, 64, 0) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
+            if (!rc) set_last_error("k-mer dictionary: sorting an overflow level failed");
+            return fail(rc ? rc : FMSI_HIP_EHIP);
+        }
+        const bool in_first = dk.current() == spill_keys.as<uint64_t>();
+        cur_keys.reset();
+        cur_codes.reset();
+        cur_keys.p = in_first ? spill_keys.release() : sk2.release();
+        cur_codes.p = (dv.current() == spill_codes.as<uint8_t>()) ? spill_codes.release() : sc2.release();
+        count = n_spill;
+    }
+    if (hipDeviceSynchronize() != hipSuccess) {
+        set_last_error("k-mer dictionary: device work failed");
+        return fail(FMSI_HIP_EHIP);
+    }
+    idx->dict = dx;
+    for (uint32_t lv = 0; lv < kDictMaxLevels; ++lv) idx->d_dict[lv] = owned[lv];
+    idx->dict_bytes = bytes_total;
+    idx->device_bytes += bytes_total;
+    return 0;
+}

@@ -560,14 +560,19 @@ int launch_query(fmsi_hip_index* idx, const uint64_t* d_kmers, uint64_t n_window
     }
     uint8_t* o8 = static_cast<uint8_t*>(d_out);
     long long* o64 = static_cast<long long*>(d_out);
-    const uint32_t kernel = flags & FMSI_HIP_KERNEL_MASK;
+    uint32_t kernel = flags & FMSI_HIP_KERNEL_MASK;
     const bool use_table = idx->d_ptable && !(flags & FMSI_HIP_NO_PREFIX_TABLE) && k >= idx->prefix_len;
     int rc;
     // FMSI_HIP_OUT_BITS: the one-lane lookup kernel and its stepping kernel pack their results themselves; every other
     // kernel writes its bytes to a scratch buffer that one streaming pass packs (inside the profiled region)
-    const bool phased = (kernel == FMSI_HIP_KERNEL_PHASED || kernel == FMSI_HIP_KERNEL_AUTO) && idx->d_pblocks && use_table;
+    const bool dict = dict_applies(idx, k, flags);
+    if (kernel == FMSI_HIP_KERNEL_DICT && !dict) {   // (no dictionary for this call: AUTO)
+        flags &= ~FMSI_HIP_KERNEL_MASK;
+        kernel = FMSI_HIP_KERNEL_AUTO;
+    }
+    const bool phased = !dict && (kernel == FMSI_HIP_KERNEL_PHASED || kernel == FMSI_HIP_KERNEL_AUTO) && idx->d_pblocks && use_table;
     const bool want_bits = (flags & FMSI_HIP_OUT_BITS) && !(flags & FMSI_HIP_ORDERS);
-    const bool pack_after = want_bits && !(phased && phased_packs_bits(idx, k, flags));
+    const bool pack_after = want_bits && !dict && !(phased && phased_packs_bits(idx, k, flags));
     if (!want_bits || pack_after) flags &= ~FMSI_HIP_OUT_BITS;
     if (want_bits && (reinterpret_cast<uintptr_t>(d_out) & 7u)) {
         set_last_error("FMSI_HIP_OUT_BITS needs an 8-byte aligned output buffer");
@@ -579,7 +584,9 @@ int launch_query(fmsi_hip_index* idx, const uint64_t* d_kmers, uint64_t n_window
     }
     size_t slot;
     if ((rc = prof_begin(idx, s, &slot))) return rc;
-    if (kernel == FMSI_HIP_KERNEL_LOCKSTEP) {
+    if (dict) {
+        if ((rc = launch_dict_query(idx, d_kmers, n_windows, k, flags, o8, d_counters, s))) return rc;
+    } else if (kernel == FMSI_HIP_KERNEL_LOCKSTEP) {
         const uint64_t blocks64 = (n_windows + 255) / 256;
         if (blocks64 > 0x7FFFFFFFull) {
             set_last_error("too many windows for one lockstep launch");
@@ -788,7 +795,7 @@ void fmsi_hip_index_destroy(fmsi_hip_index* idx) {
     if (!idx) return;
     ::fmsi::DeviceGuard device_guard_(idx->device);
     for (void* p : {idx->d_blocks, idx->d_mrank, idx->d_ptable, idx->d_klcp, idx->d_text2, idx->d_stable, idx->d_vtable, idx->d_in, idx->d_aux, idx->d_out,
-                    idx->d_kmers, idx->d_tasks, idx->d_bytes, idx->d_pblocks, idx->d_sbt, idx->d_c2, static_cast<void*>(idx->d_counters)})
+                    idx->d_kmers, idx->d_tasks, idx->d_bytes, idx->d_dict[0], idx->d_dict[1], idx->d_dict[2], idx->d_dict[3], idx->d_pblocks, idx->d_sbt, idx->d_c2, static_cast<void*>(idx->d_counters)})
         if (p) (void)hipFree(p);
     for (auto& m : idx->meta_ring) {
         if (m.in_flight) (void)hipEventSynchronize(m.done);
@@ -819,6 +826,11 @@ int fmsi_hip_index_get_info(const fmsi_hip_index* idx, fmsi_hip_index_info* info
     info->counts[3] = idx->dev.C3;
     info->dollar_position = idx->dev.dollar;
     info->candidate_entry_bytes = idx->d_vtable ? (idx->vwide ? 32u : 16u) : 0u;
+    info->dict_bytes = idx->dict_bytes;
+    for (uint32_t lv = 0; lv < kDictMaxLevels; ++lv) info->dict_keys[lv] = idx->dict_keys[lv];
+    info->dict_ambiguous = idx->dict_ambiguous;
+    info->dict_levels = idx->dict.levels;
+    info->dict_log2_buckets = idx->dict.levels ? 64u - idx->dict.lv[0].shift : 0u;
     return 0;
 }
 
@@ -932,7 +944,24 @@ int fmsi_hip_query_runs(fmsi_hip_index* idx, const uint64_t* packed_seq, uint64_
             d_cnt = idx->d_counters;
         }
     }
-    const uint32_t kernel = flags & FMSI_HIP_KERNEL_MASK;
+    uint32_t kernel = flags & FMSI_HIP_KERNEL_MASK;
+    if (dict_applies(idx, k, flags) && n_windows <= (1ull << 38)) {
+        // the dictionary's lookup kernel cuts the windows itself, too
+        size_t slot;
+        if ((rc = prof_begin(idx, s, &slot))) return rc;
+        if ((rc = launch_dict_query(idx, d_seq, n_windows, k, flags, static_cast<uint8_t*>(d_out), d_cnt, s, meta, n_runs))) return rc;
+        if ((rc = meta_commit(idx, meta_slot, s))) return rc;
+        if ((rc = prof_end(idx, s, slot))) return rc;
+        if (!dev_ptrs) {
+            if (out_bytes) FMSI_HIP_TRY(hipMemcpyAsync(out, idx->d_out, out_bytes, hipMemcpyDeviceToHost, s));
+            if (counters) FMSI_HIP_TRY(hipMemcpyAsync(counters, idx->d_counters, FMSI_HIP_N_COUNTERS * 8, hipMemcpyDeviceToHost, s));
+        }
+        return 0;
+    }
+    if (kernel == FMSI_HIP_KERNEL_DICT) {
+        flags &= ~FMSI_HIP_KERNEL_MASK;
+        kernel = FMSI_HIP_KERNEL_AUTO;
+    }
     if (k <= 32 && (kernel == FMSI_HIP_KERNEL_PHASED || kernel == FMSI_HIP_KERNEL_AUTO) && idx->d_pblocks && idx->d_ptable &&
         !(flags & FMSI_HIP_NO_PREFIX_TABLE) && k >= idx->prefix_len && n_windows <= (1ull << 38)) {
         // the phased kernels cut the windows themselves: no pass that writes 8 bytes per window and reads them back

@@ -27,6 +27,18 @@ struct DevIndex {
     uint32_t ptable_packed;   // entry format: 0 = (i, j); 1 = (i, tagged word) with next-base signatures, see decode_table_entry
 };
 
+// the k-mer dictionary (fmsi_dict.hip): up to four levels of 128-byte buckets, passed by value to the lookup kernel
+constexpr uint32_t kDictMaxLevels = 4;
+struct DictLevel {
+    const uint4* buckets;   // 2^(64 - shift) buckets x 8 x 16 bytes
+    uint32_t shift, pad;    // bucket = hash >> shift
+};
+struct DictIndex {
+    DictLevel lv[kDictMaxLevels];
+    uint32_t levels;        // 0 = no dictionary
+    int k;
+};
+
 #define FMSI_HIP_TRY(expr)                                                                                 \
     do {                                                                                                   \
         hipError_t e_ = (expr);                                                                            \
@@ -93,6 +105,10 @@ struct fmsi_hip_index {
     void* d_vtable = nullptr;    // text verification: the lookup kernel's 16-byte copy of the table entries with candidates 0 and 1
     void* d_stable = nullptr;    // ... and candidate 2 per entry
     bool vwide = false;          // d_vtable holds 32-byte entries (up to seven candidates in a double-stranded entry)
+    // optional k-mer dictionary (fmsi_dict.hip; fmsi_hip_index_enable_dict)
+    fmsi::DictIndex dict{};
+    void* d_dict[fmsi::kDictMaxLevels] = {nullptr, nullptr, nullptr, nullptr};
+    uint64_t dict_bytes = 0, dict_keys[fmsi::kDictMaxLevels] = {0, 0, 0, 0}, dict_ambiguous = 0;
     uint64_t text_len = 0;
     // staging for host-pointer calls
     void* d_in = nullptr; size_t d_in_cap = 0;
@@ -130,6 +146,12 @@ void launch_longk_query(fmsi_hip_index* idx, const uint64_t* d_seq, const uint64
 // the run lengths; the lookup kernel cuts the windows itself
 int launch_phased_query(fmsi_hip_index* idx, const uint64_t* d_kmers, uint64_t n, int k, uint32_t flags, uint8_t* o8, long long* o64,
                         unsigned long long* d_counters, hipStream_t s, const uint64_t* h_runs = nullptr, uint64_t n_runs = 0);
+
+// the k-mer dictionary answers this call (presence modes, the index's k, no NO_PREFIX_TABLE) -- and its launch; h_runs as for
+// launch_phased_query.  The lookup kernel packs FMSI_HIP_OUT_BITS output itself.
+bool dict_applies(const fmsi_hip_index* idx, int k, uint32_t flags);
+int launch_dict_query(fmsi_hip_index* idx, const uint64_t* d_in, uint64_t n, int k, uint32_t flags, uint8_t* o8, unsigned long long* d_counters, hipStream_t s,
+                      const uint64_t* h_runs = nullptr, uint64_t n_runs = 0);
 
 // FMSI_HIP_OUT_BITS: does launch_phased_query write the packed output itself for this (handle, k, flags)?  (otherwise the
 // caller has the kernels write bytes into a scratch buffer and packs them with launch_pack_results)

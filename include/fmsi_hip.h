@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define FMSI_HIP_ABI_VERSION 3   /* 2: fmsi_hip_index_info.candidate_entry_bytes, fmsi_hip_comm_*, fmsi_hip_gather; 3: FMSI_HIP_OUT_BITS */
+#define FMSI_HIP_ABI_VERSION 3   /* 2: fmsi_hip_index_info.candidate_entry_bytes, fmsi_hip_comm_*, fmsi_hip_gather; 3: FMSI_HIP_OUT_BITS, fmsi_hip_index_enable_dict + fmsi_hip_index_info.dict_*, fmsi_hip_index_build_synthetic_spec */
 
 /* error codes */
 #define FMSI_HIP_OK 0
@@ -66,8 +66,11 @@ extern "C" {
 #define FMSI_HIP_KERNEL_PHASED 0x40u     /* pair layout + prefix table: the table lookups run in a kernel of their own and only the
                                             searches they leave alive go to the stepping kernel; AUTO picks it when both exist;
                                             without a usable table it is KERNEL_PAIR */
+#define FMSI_HIP_KERNEL_DICT 0x50u       /* the k-mer dictionary (fmsi_hip_index_enable_dict): one bucket read per k-mer; AUTO picks it when the handle
+                                            has one and the call is a presence query with the index's k; without it this is AUTO */
 #define FMSI_HIP_KERNEL_MASK 0xF0u
-/* do not use the private prefix table even if the handle has one (canonical-step accounting runs) */
+/* do not use the private accelerators -- prefix table, candidate tables, k-mer dictionary -- even if the handle has them: the LF walk
+ * itself (canonical-step accounting runs, the table-less legs of the benchmark) */
 #define FMSI_HIP_NO_PREFIX_TABLE 0x100u
 
 /* bit-packed results (non-ORDERS calls): `out` is an 8-byte aligned array of u64 words, LSB first like the reference's
@@ -113,6 +116,10 @@ typedef struct {
     uint64_t counts[4];         /* C array of the index ({1, #A+1, #A+#C+1, #A+#C+#G+1}, src/fms_index.h:451) */
     uint64_t dollar_position;
     uint64_t candidate_entry_bytes; /* 0 = no candidate tables (fmsi_hip_index_enable_verify), else 16 or 32 bytes per table entry */
+    uint64_t dict_bytes;        /* 0 = no k-mer dictionary (fmsi_hip_index_enable_dict), else its HBM footprint */
+    uint64_t dict_keys[4];      /* distinct canonical k-mers handed to each of its levels (level 0: all of them; further: the overflow) */
+    uint64_t dict_ambiguous;    /* keys whose `-O` answer was taken from the index's own search (occurrences with differing mask bits) */
+    uint32_t dict_levels, dict_log2_buckets;   /* levels in use; log2 of level 0's bucket count */
 } fmsi_hip_index_info;
 
 /* counters written by query calls when `counters` != NULL (8 x u64, accumulated, caller zeroes):
@@ -201,6 +208,16 @@ int fmsi_cli_index(int argc, char** argv);
  * Environment: FMSI_HIP_NARROW_CANDIDATES forces the 16-byte entries, FMSI_HIP_LOOKUP_PAIRS additionally the lane-pair
  * lookup kernel (A/B measurements). */
 int fmsi_hip_index_enable_verify(fmsi_hip_index* idx);
+
+/* Adds the k-mer dictionary to a handle (private optimisation, results unchanged): every distinct canonical k-mer of the
+ * superstring with the answers get_range_with_pattern() + infer_presence() (src/fms_index.h:117-144) give for it and for its reverse
+ * complement, in buckets of 128 bytes addressed by a hash of the k-mer -- a presence query (either mode, STRICT or not, isolated
+ * k-mers, windows, runs) is then ONE random 128-byte read whatever the text's repeats and whether or not the k-mer is present.
+ * About 12 bytes of HBM per distinct k-mer (FMSI_HIP_DICT_SPARSE: twice that, no second-level reads), for the index's k only; the
+ * superstring and its mask come from the LF walk of fmsi_hip_index_export, answers that depend on the suffix order from the index's
+ * own search, so any handle can add it.  ORDERS queries and other k take the other kernels.  Idempotent. */
+#define FMSI_HIP_DICT_SPARSE 0x1u
+int fmsi_hip_index_enable_dict(fmsi_hip_index* idx, uint32_t flags);
 
 /* Replaces export_ms() (src/fms_index.h:462-473): the masked superstring of the index (upper case = mask 1), written
  * to out[0 .. *out_len) without a terminator.  The reference's single LF chain of |MS| steps is cut into about a million

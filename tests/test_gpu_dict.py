@@ -1,0 +1,157 @@
+"""The k-mer dictionary (fmsi_hip_index_enable_dict, fmsi_dict.hip) against the oracle: a private accelerator must give, strand by
+strand and in both modes, exactly what get_range_with_pattern() + infer_presence() give (src/fms_index.h:117-144).  Covered: every
+golden index with k <= 32 (mixed masks: answers that depend on the suffix order come from the index's own search), exhaustive
+k-mer sets incl. palindromes (even k), the overflow levels, runs / windows / bit-packed output, handles built on the device and
+handles loaded from the reference's files, other k and ORDERS falling back to the other kernels.
+"""
+import itertools
+import random
+
+import numpy as np
+import pytest
+
+import oracle_py
+from conftest import DATASETS, GOLDEN, index_prefix, mixed_kmers, revcomp, synthetic_ms
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def fm(product_built):
+    if product_built.device_count() < 1:
+        pytest.fail("no HIP device visible: the gpu tests must run on an MI355X")
+    return product_built
+
+
+def check_against_oracle(fm, dev, orc, kmers, k):
+    raw = "".join(kmers).encode()
+    packed = fm.pack_kmers(kmers, k)
+    n = len(kmers)
+    for mode_all in (False, True):
+        flag = fm.MODE_ALL if mode_all else fm.MODE_OR
+        fwd, rc = orc.ternaries_bulk(raw, n, k, mode_all)
+        got = dev.query_kmers(packed, k, flag | fm.STRICT | fm.KERNEL_DICT)
+        gf, gr = fm.decode_strict(got)
+        assert np.array_equal(gf, fwd) and np.array_equal(gr, rc), ("strict", mode_all)
+        assert np.array_equal(dev.query_kmers(packed, k, flag | fm.STRICT), got)                      # AUTO picks the dictionary
+        want_fast = (np.where(fwd != -1, fwd, rc) == 1) if mode_all else ((fwd == 1) | (rc == 1))
+        fast = dev.query_kmers(packed, k, flag | fm.KERNEL_DICT)
+        assert np.array_equal(fast.astype(bool), want_fast), ("fast", mode_all)
+        for extra, ref in ((0, fast), (fm.STRICT, got)):
+            words = dev.query_kmers(packed, k, flag | fm.KERNEL_DICT | extra | fm.OUT_BITS)
+            assert np.array_equal(fm.unpack_bits(words, n, extra), ref), ("bits", mode_all, extra)
+        # the LF walk on the same handle (no accelerators) agrees
+        assert np.array_equal(dev.query_kmers(packed, k, flag | fm.STRICT | fm.NO_PREFIX_TABLE), got)
+
+
+@pytest.mark.parametrize("name", [n for n in DATASETS if DATASETS[n][0] <= 32])
+def test_dictionary_equals_oracle_on_the_golden_indexes(fm, oracle_built, name):
+    k = DATASETS[name][0]
+    orc = oracle_py.Oracle.load(index_prefix(name))
+    dev = fm.DeviceIndex.from_files(index_prefix(name)).enable_dict()
+    assert dev.info.dict_bytes > 0 and dev.info.dict_levels >= 1
+    ms_file = {"integration_a": "ref_data/integration_a.fa", "integration_b": "ref_data/integration_b.fa",
+               "sars_k13": "ref_data/GCF_009858895.2_ASM985889v3_genomic.fna.ms.k13",
+               "sars_k31": "ref_data/GCF_test2_ones.fna.ms.k31", "mixed_k11": "mixed.fa"}[name]
+    ms = "".join(l.strip() for l in open(GOLDEN / ms_file) if not l.startswith(">"))
+    kmers = mixed_kmers(ms, k, 5000, seed=31)
+    if k <= 6:
+        kmers = ["".join(p) for p in itertools.product("ACGT", repeat=k)]
+    check_against_oracle(fm, dev, orc, kmers, k)
+    # every k-mer of the superstring, both orientations (all of them are keys)
+    up = ms.upper()
+    wins = [up[i:i + k] for i in range(0, len(up) - k + 1, max(1, (len(up) - k + 1) // 4000))]
+    check_against_oracle(fm, dev, orc, wins + [revcomp(w) for w in wins], k)
+    # the dictionary also sits next to the other accelerators
+    both = fm.DeviceIndex.from_files(index_prefix(name), prefix_len=min(k - 1, 6)).enable_pair_layout().enable_verify().enable_dict()
+    check_against_oracle(fm, both, orc, kmers[:2000], k)
+
+
+@pytest.mark.parametrize("k,mask", [(6, "mixed"), (8, "mixed"), (12, "ones"), (32, "mixed"), (1, "mixed"), (2, "mixed")])
+def test_even_k_palindromes_and_repeats(fm, oracle_built, k, mask):
+    """Even k has palindromic k-mers (q == rc(q): one strand, one answer); a short random text over a small k makes every key
+    occur many times on both strands with ON and OFF occurrences mixed (`-O` = the first row of the interval: the index's own
+    search resolves those); k = 32 uses all 64 bits of the key."""
+    rng = random.Random(k)
+    n = 3000 if k <= 12 else 60_000
+    ms = synthetic_ms(n, k, seed=100 + k, mask=mask)
+    if k >= 12:   # plant reverse complements and exact repeats
+        ms = ms[:1000] + revcomp(ms[200:700]).upper() + ms[1000:2000] + ms[300:900] + ms[2000:]
+        ms = ms[: len(ms) - (k - 1)] + ms[len(ms) - (k - 1):].lower()
+    orc = oracle_py.Oracle.construct(ms, k, use_klcp=False)
+    dev = fm.DeviceIndex.build(ms.encode(), k).enable_dict()
+    if k <= 8:
+        kmers = ["".join(p) for p in itertools.product("ACGT", repeat=k)]
+        if mask == "mixed" and k >= 6:
+            assert dev.info.dict_ambiguous > 0      # the suffix-order path was exercised
+    else:
+        kmers = mixed_kmers(ms, k, 6000, seed=k)
+        pal = []
+        for _ in range(300):                          # palindromes: half + its reverse complement
+            h = "".join(rng.choice("ACGT") for _ in range(k // 2))
+            pal.append(h + revcomp(h))
+        kmers += pal
+        up = ms.upper()
+        kmers += [up[i:i + k] for i in range(0, len(up) - k + 1, 7)][:4000]
+    check_against_oracle(fm, dev, orc, kmers, k)
+
+
+def test_overflow_levels_runs_and_other_k(fm, oracle_built):
+    """1.2 M distinct k-mers at 9.2 keys per bucket: some 2000 buckets overflow into level 1.  Runs of windows through the
+    dictionary; a query with another k, and ORDERS, take the other kernels and still agree with the oracle."""
+    k = 31
+    ms = synthetic_ms(1_200_000, k, seed=12345, mask="mixed")
+    orc = oracle_py.Oracle.construct(ms, k, use_klcp=False)
+    dev = fm.DeviceIndex.build(ms.encode(), k).enable_dict()
+    info = dev.info
+    assert info.dict_levels >= 2 and info.dict_keys[1] > 100 and info.dict_keys[0] > 1_190_000
+    assert info.dict_bytes >= (1 << info.dict_log2_buckets) * 128
+    sparse = fm.DeviceIndex.build(ms.encode(), k).enable_dict(sparse=True)
+    assert sparse.info.dict_log2_buckets == info.dict_log2_buckets + 1 and sparse.info.dict_keys[1] < info.dict_keys[1]
+    kmers = mixed_kmers(ms, k, 60_000, seed=8)
+    up = ms.upper()
+    kmers += [up[i:i + k] for i in range(0, len(up) - k + 1, 17)]       # 70 k keys: the spilled ones among them
+    check_against_oracle(fm, dev, orc, kmers, k)
+    check_against_oracle(fm, sparse, orc, kmers[:20_000], k)
+    # runs of windows (reads): both orientations and random stretches, ragged run lengths
+    rng = random.Random(4)
+    seq = up[5000:9000] + "".join(rng.choice("ACGT") for _ in range(600)) + revcomp(up[20000:23000]) + up[100:1100]
+    words = fm.pack_sequence(seq.encode())
+    run_start, run_windows, pos = [], [], 0
+    while pos + k + 2 < len(seq):
+        w = min(rng.choice([1, 5, 64, 130, 1000]), len(seq) - pos - k + 1)
+        run_start.append(pos)
+        run_windows.append(w)
+        pos += w + rng.choice([0, 1, 29])
+    wk = [seq[s + i: s + i + k] for s, w in zip(run_start, run_windows) for i in range(w)]
+    for mode_all in (False, True):
+        flag = fm.MODE_ALL if mode_all else fm.MODE_OR
+        fwd, rc = orc.ternaries_bulk("".join(wk).encode(), len(wk), k, mode_all)
+        got = dev.query_runs(words, len(seq), run_start, run_windows, k, flag | fm.STRICT)
+        gf, gr = fm.decode_strict(got)
+        assert np.array_equal(gf, fwd) and np.array_equal(gr, rc)
+        bits = fm.unpack_bits(dev.query_runs(words, len(seq), run_start, run_windows, k, flag | fm.STRICT | fm.OUT_BITS), len(wk), fm.STRICT)
+        assert np.array_equal(bits, got)
+        starts = np.array([s + i for s, w in zip(run_start, run_windows) for i in range(w)], dtype=np.uint64)
+        assert np.array_equal(dev.query_windows(words, len(seq), k, flag | fm.STRICT, window_start=starts), got)
+    # another k: not the dictionary's business
+    k2 = 21
+    km2 = [s[:k2] for s in kmers[:3000]]
+    f2, r2 = orc.ternaries_bulk("".join(km2).encode(), len(km2), k2, False)
+    g2f, g2r = fm.decode_strict(dev.query_kmers(fm.pack_kmers(km2, k2), k2, fm.MODE_OR | fm.STRICT | fm.KERNEL_DICT))
+    assert np.array_equal(g2f, f2) and np.array_equal(g2r, r2)
+    # lookup (orders)
+    _, _, of, orr = orc.ternaries_bulk("".join(kmers[:3000]).encode(), 3000, k, False, orders=True)
+    got = dev.query_kmers(fm.pack_kmers(kmers[:3000], k), k, fm.ORDERS | fm.STRICT)
+    assert np.array_equal(got[:, 0], of) and np.array_equal(got[:, 1], orr)
+
+
+def test_dictionary_counters(fm):
+    """One bucket read per k-mer (+ the second level's for the few in overflowed buckets), no LF steps."""
+    k = 31
+    ms = synthetic_ms(300_000, k, seed=3)
+    dev = fm.DeviceIndex.build(ms.encode(), k).enable_dict()
+    kmers = mixed_kmers(ms, k, 50_000, seed=1)
+    _, cn = dev.query_kmers(fm.pack_kmers(kmers, k), k, fm.MODE_ALL, counters=True)
+    assert int(cn[0]) == 0 and int(cn[6]) == len(kmers)
+    assert len(kmers) <= int(cn[4]) <= int(1.1 * len(kmers)) and int(cn[1]) == int(cn[4])
