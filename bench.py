@@ -174,7 +174,8 @@ def main():
     accel_s = 0.0
     if use_dict:
         t0 = time.time()
-        index.enable_pair_layout()   # (the table-less LF-walk leg and the canonical-step count use it)
+        if not stream_mode:
+            index.enable_pair_layout()   # (the table-less LF-walk leg and the canonical-step count use it)
         index.enable_dict(sparse=args.dict_sparse)
         accel_s = time.time() - t0
         build_s += accel_s

@@ -31,6 +31,8 @@
 #include <rocprim/iterator/transform_iterator.hpp>
 
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <string>
 #include <vector>
@@ -500,9 +502,25 @@ int launch_dict_query(fmsi_hip_index* idx, const uint64_t* d_in, uint64_t n, int
 
 using namespace fmsi;
 
+namespace {
+// FMSI_HIP_VERBOSE: phase times of the construction on stderr
+struct PhaseClock {
+    bool on = std::getenv("FMSI_HIP_VERBOSE") != nullptr;
+    std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+    void mark(const char* what) {
+        if (!on) return;
+        (void)hipDeviceSynchronize();
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[fmsi dict] %-28s %8.3f s\n", what, std::chrono::duration<double>(now - t).count());
+        t = now;
+    }
+};
+}  // namespace
+
 extern "C" int fmsi_hip_index_enable_dict(fmsi_hip_index* idx, uint32_t flags) {
     if (!idx) return FMSI_HIP_EINVAL;
     if (idx->dict.levels) return 0;
+    PhaseClock clock;
     const int k = idx->k;
     const uint64_t n = idx->n, len = n - 1;
     if (k < 1 || k > 32 || len < static_cast<uint64_t>(k)) {
@@ -518,11 +536,13 @@ extern "C" int fmsi_hip_index_enable_dict(fmsi_hip_index* idx, uint32_t flags) {
         DevMem chars;
         if ((rc = chars.alloc(len + 1, "text"))) return rc;
         if ((rc = export_walk(idx, chars.as<char>(), nullptr))) return rc;
+        clock.mark("LF walk (text + mask)");
         const uint64_t n64 = (len >> 6) + 2;
         if ((rc = text2.alloc(n64 * 16, "text")) || (rc = maskw.alloc(n64 * 8, "mask"))) return rc;
         hipLaunchKernelGGL(dict_planes_kernel, dim3(grid_of(n64)), dim3(256), 0, 0, chars.as<char>(), len, n64, text2.as<uint64_t>(), maskw.as<uint64_t>());
         DICT_TRY(hipGetLastError());
         DICT_TRY(hipDeviceSynchronize());
+        clock.mark("2-bit text + mask words");
     }
     // 2. one (hash, mask bit | orientation) pair per window of the superstring, sorted by hash
     DevMem ukeys, ucodes;
@@ -535,12 +555,14 @@ extern "C" int fmsi_hip_index_enable_dict(fmsi_hip_index* idx, uint32_t flags) {
         hipLaunchKernelGGL(dict_keys_kernel, dim3(grid_of(windows)), dim3(256), 0, 0, text2.as<uint64_t>(), maskw.as<uint64_t>(), windows, k, keys_a.as<uint64_t>(),
                            vals_a.as<uint8_t>());
         DICT_TRY(hipGetLastError());
+        clock.mark("hashes of the text's k-mers");
         rocprim::double_buffer<uint64_t> dk(keys_a.as<uint64_t>(), keys_b.as<uint64_t>());
         rocprim::double_buffer<uint8_t> dv(vals_a.as<uint8_t>(), vals_b.as<uint8_t>());
         size_t tb = 0;
         DICT_TRY(rocprim::radix_sort_pairs(nullptr, tb, dk, dv, static_cast<size_t>(windows), 0, 64, 0));
         if ((rc = temp.alloc(tb, "sort scratch"))) return rc;
         DICT_TRY(rocprim::radix_sort_pairs(temp.p, tb, dk, dv, static_cast<size_t>(windows), 0, 64, 0));
+        clock.mark("radix sort");
         text2.reset();
         maskw.reset();
         // 3. distinct hashes: index of every occurrence's key among them
@@ -557,6 +579,7 @@ extern "C" int fmsi_hip_index_enable_dict(fmsi_hip_index* idx, uint32_t flags) {
         DICT_TRY(hipMemcpy(&last_idx, uidx.as<uint32_t>() + (windows - 1), 4, hipMemcpyDeviceToHost));
         if (windows >= 2) DICT_TRY(hipMemcpy(tail, sk + (windows - 2), 16, hipMemcpyDeviceToHost));
         n_unique = static_cast<uint64_t>(last_idx) + (tail[0] != tail[1] ? 1u : 0u);
+        clock.mark("distinct keys (scan)");
         // 4. fold the occurrences into answer codes; keys whose `-O` answer depends on the suffix order are listed
         DevMem amb_kmers, amb_where, amb_count;
         const uint32_t amb_cap = static_cast<uint32_t>(std::min<uint64_t>(n_unique, 0x7FFFFFFFull));
@@ -579,6 +602,7 @@ extern "C" int fmsi_hip_index_enable_dict(fmsi_hip_index* idx, uint32_t flags) {
         }
         uint32_t n_amb = 0;
         DICT_TRY(hipMemcpy(&n_amb, amb_count.p, 4, hipMemcpyDeviceToHost));
+        clock.mark("answer codes (fold)");
         // the sort's buffers are no longer needed
         keys_a.reset();
         keys_b.reset();
@@ -598,6 +622,7 @@ extern "C" int fmsi_hip_index_enable_dict(fmsi_hip_index* idx, uint32_t flags) {
             DICT_TRY(hipDeviceSynchronize());
         }
         idx->dict_ambiguous = n_amb;
+        clock.mark("suffix-order answers");
     }
     // 5. the levels: level 0 at <= 10.5 keys per bucket (FMSI_HIP_DICT_SPARSE: half that), the overflow levels at <= 3
     DictIndex dx{};
@@ -652,6 +677,7 @@ extern "C" int fmsi_hip_index_enable_dict(fmsi_hip_index* idx, uint32_t flags) {
         set_last_error("k-mer dictionary: device work failed");
         return fail(FMSI_HIP_EHIP);
     }
+    clock.mark("levels (fill)");
     idx->dict = dx;
     for (uint32_t lv = 0; lv < kDictMaxLevels; ++lv) idx->d_dict[lv] = owned[lv];
     idx->dict_bytes = bytes_total;

@@ -78,7 +78,8 @@ struct Options {
     int device = 0;
     uint64_t batch_windows = 1ull << 26;   // bases of query sequence per batch (>= windows)
     unsigned threads = 0;                  // 0 = all CPUs this process may use, at most 16
-    bool full_tables = false;              // --tables full: the 16-deep prefix table and the candidate tables (what bench.py measures)
+    bool full_tables = false;              // --tables full: the k-mer dictionary (what bench.py measures); lookup: the 16-deep prefix table
+    bool candidate_tables = false;         // --tables candidates: the 16-deep prefix table + candidate tables instead (A/B runs)
     bool tables_given = false;             // (--tables on the command line: no choice by the size of the query file)
 };
 
@@ -102,10 +103,11 @@ int usage_query(bool lookup) {
     std::cerr << "  --batch INT  - bases of query sequence per device batch [default: 67108864]" << std::endl;
     std::cerr << "  --threads INT - host threads for packing and formatting [default: available CPUs, at most 16]" << std::endl;
     std::cerr << "  --stats      - print timings to stderr" << std::endl;
-    std::cerr << "  --tables auto|full - device-side accelerators (results unaffected).  auto [default]: a prefix table of up to 14" << std::endl;
-    std::cerr << "                 bases, which keeps the device about level with this program's reader and loads seconds faster" << std::endl;
-    std::cerr << "                 (query files of 30 GB and more get `full`); full: 16 bases plus the candidate tables (up to" << std::endl;
-    std::cerr << "                 180 GB of HBM), the fastest device path" << std::endl;
+    std::cerr << "  --tables auto|full|candidates - device-side accelerators (results unaffected).  auto [default]: a prefix table of up" << std::endl;
+    std::cerr << "                 to 14 bases, which keeps the device about level with this program's reader and loads fastest (query" << std::endl;
+    std::cerr << "                 files of 30 GB and more get `full`); full: the k-mer dictionary -- one 128-byte read per k-mer, about" << std::endl;
+    std::cerr << "                 12 bytes of HBM per distinct k-mer, the fastest device path (also for -S); candidates: the 16-base" << std::endl;
+    std::cerr << "                 prefix table with candidate tables (up to 180 GB of HBM)" << std::endl;
     std::cerr << std::endl;
     return 1;
 }
@@ -843,6 +845,7 @@ extern "C" int fmsi_cli_query(int argc, char** argv, int output_orders_i) {
         case 1005: opt.threads = static_cast<unsigned>(std::max(1, atoi(optarg))); break;
         case 1006:
             if (std::string(optarg) == "full") opt.full_tables = opt.tables_given = true;
+            else if (std::string(optarg) == "candidates") opt.full_tables = opt.candidate_tables = opt.tables_given = true;
             else if (std::string(optarg) != "auto") return usage_query(output_orders);
             break;
         default: return usage_query(output_orders);
@@ -899,7 +902,11 @@ extern "C" int fmsi_cli_query(int argc, char** argv, int output_orders_i) {
             static_cast<uint64_t>(st.st_size) * (gz ? 4u : 1u) >= 30000000000ull)
             opt.full_tables = true;
     }
-    int t = std::min(k, opt.full_tables ? 16 : 14);
+    // `full`: presence queries (also -S ones: their answers do not depend on the kLCP array) are answered by the k-mer
+    // dictionary, which needs no prefix table (a small one serves the few searches of its construction); lookup keeps the
+    // 16-deep table
+    const bool want_dict = opt.full_tables && !opt.candidate_tables && !output_orders && k <= 32 && host->ix.n() > static_cast<uint64_t>(k);
+    int t = std::min(k, want_dict ? 12 : (opt.full_tables ? 16 : 14));
     while (t > 0 && (1ull << (2 * t)) > 4 * host->ix.n()) --t;
     // ... and, for presence queries, text verification of the intervals that leave the table with one to three rows.
     // The accelerators are large (34 GB + 52 GB at human scale): when HBM is short -- the GPU shared with other work --
@@ -912,13 +919,18 @@ extern "C" int fmsi_cli_query(int argc, char** argv, int output_orders_i) {
         std::cerr << "WARNING: not enough device memory for a prefix table of depth " << t << ", trying " << std::max(t - 2, 0) << std::endl;
     }
     t = std::max(t, 0);
-    if (rc_create != 0 || (!opt.has_klcp && fmsi_hip_index_enable_pair_layout(dev) != 0)) {
+    bool have_dict = false;
+    if (rc_create == 0 && want_dict) {
+        have_dict = fmsi_hip_index_enable_dict(dev, 0) == 0;
+        if (!have_dict) std::cerr << "WARNING: the k-mer dictionary is off (" << fmsi_hip_last_error() << "); results are unaffected" << std::endl;
+    }
+    if (rc_create != 0 || (!opt.has_klcp && !have_dict && fmsi_hip_index_enable_pair_layout(dev) != 0)) {
         std::cerr << "ERROR: cannot create the device index: " << fmsi_hip_last_error() << std::endl;
         if (dev) fmsi_hip_index_destroy(dev);
         fmsi_host_index_free(host);
         return 1;
     }
-    const bool want_verify = opt.full_tables && !opt.has_klcp && !output_orders && t > 0 && t < k && k <= 32;
+    const bool want_verify = opt.candidate_tables && !opt.has_klcp && !output_orders && t > 0 && t < k && k <= 32;
     if (want_verify && fmsi_hip_index_enable_verify(dev) != 0)
         std::cerr << "WARNING: text verification is off (" << fmsi_hip_last_error() << "); results are unaffected" << std::endl;
     auto t_loaded = clock::now();
@@ -1091,7 +1103,7 @@ extern "C" int fmsi_cli_query(int argc, char** argv, int output_orders_i) {
             else P->bytes.resize(nw);
             if (nw) {
                 void* dst = output_orders ? static_cast<void*>(P->orders.data()) : static_cast<void*>(P->bytes.data());
-                if (opt.has_klcp)   // -S: kLCP streaming kernel (query_kmers_streaming, src/fms_index.h:181-254)
+                if (opt.has_klcp && !have_dict)   // -S: kLCP streaming kernel (query_kmers_streaming, src/fms_index.h:181-254)
                     check(fmsi_hip_query_stream(dev, P->packed.data(), P->bases, P->run_start.data(), P->run_windows.data(),
                                                 P->run_start.size(), nw, k, flags, dst, nullptr, nullptr),
                           "fmsi_hip_query_stream");

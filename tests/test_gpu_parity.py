@@ -148,12 +148,15 @@ def test_cli_equals_reference_golden(fm, name, kind, mode):
     assert out == golden_out(name, kind, mode)
 
 
-@pytest.mark.parametrize("name,kind,mode", [c for c in CASES if c[2] in ("or", "all")])
-def test_cli_with_full_tables_equals_reference_golden(fm, name, kind, mode):
-    """--tables full (16-deep prefix table + candidate tables, the configuration bench.py measures) changes the device
-    path of the presence modes and not a byte of the output; an unknown value is a usage error."""
+@pytest.mark.parametrize("name,kind,mode,tables", [(*c, t) for c in CASES for t in ("full", "candidates")
+                                                   if c[2] in ("or", "all") or (t == "full" and c[2] in ("or_S", "all_S"))])
+def test_cli_with_full_tables_equals_reference_golden(fm, name, kind, mode, tables):
+    """--tables full (the k-mer dictionary, the configuration bench.py measures; with it `-S` presence queries take the dictionary
+    too) and --tables candidates (16-deep prefix table + candidate tables) change the device path of the presence modes and not
+    a byte of the output -- incl. the exact replay of the strand predictor from the dictionary's both-strand answers; an unknown
+    value is a usage error."""
     k = CLI_DATASETS[name][0]
-    rc, out, err = fm.run_cli([*MODES[mode][0], "--tables", "full", "-k", str(k), "-q", str(query_file(name, kind)), index_prefix(name)])
+    rc, out, err = fm.run_cli([*MODES[mode][0], "--tables", tables, "-k", str(k), "-q", str(query_file(name, kind)), index_prefix(name)])
     assert rc == 0, err.decode()
     assert out == golden_out(name, kind, mode)
     rc, out, err = fm.run_cli([*MODES[mode][0], "--tables", "huge", "-k", str(k), "-q", str(query_file(name, kind)), index_prefix(name)])

@@ -45,7 +45,7 @@ def device_answers(fm, dev, d_kmers, nq, k, flags):
     return d_out.cpu().numpy()
 
 
-def cross_check(fm, dev, k, nq, sample, seed=42, or_reference=True):
+def cross_check(fm, dev, k, nq, sample, seed=42, or_reference=True, with_dict=True):
     """nq seeded queries (half drawn from the superstring): kernels agree strand by strand in both modes; the first `sample`
     of them equal the oracle's ternaries on the exported index and (OR mode) the real reference's printed bits."""
     import torch
@@ -75,6 +75,11 @@ def cross_check(fm, dev, k, nq, sample, seed=42, or_reference=True):
         torch.cuda.synchronize()
         assert np.array_equal(fm.unpack_bits(d_bits.cpu().numpy().view(np.uint64), nq, 0), fast)
         strict[mode_name] = (f, r)
+    if with_dict:   # the k-mer dictionary, added to the same handle: the same answers from one bucket read per k-mer
+        dev.enable_dict()
+        for mode_name, mode in (("or", fm.MODE_OR), ("all", fm.MODE_ALL)):
+            f, r = fm.decode_strict(device_answers(fm, dev, d_kmers, nq, k, mode | fm.STRICT | fm.KERNEL_DICT))
+            assert np.array_equal(f, strict[mode_name][0]) and np.array_equal(r, strict[mode_name][1]), ("dictionary", mode_name)
     if or_reference and oracle_py.ref_available():
         import tempfile
         with tempfile.TemporaryDirectory(dir="/dev/shm") as d:
@@ -122,6 +127,34 @@ def test_mixed_mask_at_1e8_rows(fm):
     assert (fo != fa).sum() + (ro != ra).sum() > 1000                                          # and the modes really differ
     assert ((fo == -1) == (fa == -1)).all() and ((ro == -1) == (ra == -1)).all()               # absence does not depend on the mode
     assert ((fa == 1) <= (fo == 1)).all()                                                      # first row ON => some row ON
+    assert dev.info.dict_ambiguous > 1000      # keys whose `-O` answer the dictionary took from the index's own search
+
+
+def test_dictionary_at_human_scale(fm):
+    """BASELINE.json's headline size (n = 2.8 x 10^9 rows) in bench.py's default configuration: pair layout + k-mer dictionary
+    (36.5 GB), no tables.  Dictionary == two-base LF walk == lock-step LF walk, strand by strand, both modes, on 4 M seeded k-mers;
+    a sample against the oracle on the exported index; reads through the run entry point == their isolated windows."""
+    import torch
+    n, k = 2_800_000_000, 31
+    dev = fm.DeviceIndex.build_synthetic(n, 12345, k).enable_pair_layout()
+    strict = cross_check(fm, dev, k, nq=1 << 22, sample=100_000, or_reference=False)
+    info = dev.info
+    assert info.dict_levels == 2 and info.dict_log2_buckets == 28 and info.dict_keys[0] > 2_799_000_000 and info.dict_bytes < 40e9
+    f, r = strict["all"]
+    assert 0.49 < ((f == 1) | (r == 1)).mean() < 0.51
+    L, n_reads = 3000, 512
+    s = torch.cuda.current_stream().cuda_stream
+    d_reads = torch.empty((n_reads * L) // 32 + 2, dtype=torch.int64, device="cuda")
+    dev.synthetic_reads_dev(L, 7, 0, n_reads, d_reads.data_ptr(), 10000, s)    # 1 % substitutions in the reads drawn from the text
+    torch.cuda.synchronize()
+    packed = d_reads.cpu().numpy().view(np.uint64)
+    starts = np.arange(n_reads, dtype=np.uint64) * np.uint64(L)
+    wins = np.full(n_reads, L - k + 1, dtype=np.uint32)
+    a = dev.query_runs(packed, n_reads * L, starts, wins, k, fm.MODE_ALL | fm.STRICT)                                  # dictionary
+    b = dev.query_runs(packed, n_reads * L, starts, wins, k, fm.MODE_ALL | fm.STRICT | fm.NO_PREFIX_TABLE)            # LF walk
+    assert np.array_equal(a, b)
+    present = (((a & 3) == 2) | (((a >> 2) & 3) == 2)).reshape(n_reads, -1).mean(axis=1)
+    assert 0.3 < (present > 0.5).mean() < 0.7 and ((present > 0.02) & (present < 0.5)).sum() == 0    # reads from the text keep ~73 % of their windows
 
 
 def test_index_equals_the_reference_built_one_at_1e8(fm, tmp_path):

@@ -104,8 +104,8 @@ def test_reference_cli_against_brute_force(name, fname, k, n_reads, length, extr
     check_cli(lambda args, stdin: oracle_py.run_cli(oracle_py.REF_CLI, args, stdin), name, fname, k, n_reads, length, extra)
 
 
-# (--tables full changes the device path of the non-streaming presence queries only)
-PRODUCT_RUNS = [(*r, t) for r in RUNS for t in ([], ["--tables", "full"]) if not (t and "-S" in r[5])]
+# (--tables full: the k-mer dictionary answers the presence queries, -S ones included; candidates: the non-streaming ones only)
+PRODUCT_RUNS = [(*r, t) for r in RUNS for t in ([], ["--tables", "full"], ["--tables", "candidates"]) if not (t and t[1] == "candidates" and "-S" in r[5])]
 
 
 @pytest.mark.gpu
