@@ -92,10 +92,14 @@ def parse_args():
                          "buffered) and, for N > 1, gathered to rank 0 over RCCL first, all inside the timed region")
     ap.add_argument("--no-lf-leg", action="store_true", help="skip the table-less LF-walk legs (roofline.lf_path)")
     ap.add_argument("--lf-steps", type=int, default=3, help="timed launches per LF-walk leg")
-    ap.add_argument("--stream-via", choices=["klcp", "runs"], default="klcp",
+    ap.add_argument("--stream-via", choices=["auto", "klcp", "runs"], default="auto",
                     help="stream workload: klcp = fmsi_hip_query_stream (the kLCP kernel, what -S means in the reference); runs = the same "
-                         "windows through fmsi_hip_query_runs (phased kernels + candidate tables; same answers)")
-    return ap.parse_args()
+                         "windows through fmsi_hip_query_runs (the dictionary, or phased kernels + candidate tables; same answers -- the "
+                         "presence answers of -S do not depend on the kLCP array); auto = runs with --accel dict, else klcp")
+    args = ap.parse_args()
+    if args.stream_via == "auto":
+        args.stream_via = "runs" if args.accel == "dict" else "klcp"
+    return args
 
 
 def pmc_traffic(args, n, batch, k):

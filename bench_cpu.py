@@ -122,7 +122,8 @@ def run(args, index, n, k):
     sample = args.cpu_sample
     if sample < 0:   # ~10 s of single-thread work: ~9 us per k-mer at human scale, ~1.5 us when the index is cache resident
         sample = 1_000_000 if n >= 2e8 else 3_000_000
-    per_worker = max(20_000, sample // 8)
+    # the all-cores leg: the workers together answer the rest of 10^7 k-mers (human scale: ~7 s per worker at 16 workers)
+    per_worker = max(20_000, sample // 8, (10_000_000 - sample) // max(cores, 1) if args.cpu_sample < 0 else 0)
     total = sample + cores * per_worker
 
     d = torch.empty(total, dtype=torch.int64, device="cuda")
@@ -162,7 +163,8 @@ def run(args, index, n, k):
                   f"(-g -O2), query loop only",
         "seconds": round(sec1, 3), "matches_gpu": agree,
         "socket_value": cores * per_worker / max(secs), "socket_cores": cores,
-        "socket_sample": f"{cores} forked workers x {per_worker} further k-mers each, shared read-only index, slowest worker {max(secs):.2f} s",
+        "socket_sample": f"{cores} forked workers x {per_worker} further k-mers each, shared read-only index, slowest worker {max(secs):.2f} s; "
+                         f"socket_cores is what this container may use (cgroup CPU quota {quota} of {os.cpu_count()} logical CPUs), not a whole socket",
         "index_export_seconds": round(prep_s, 1), "cpu_model": _cpu_model(), "logical_cpus": os.cpu_count(), "cgroup_cpu_quota": quota,
     }
 
@@ -191,8 +193,9 @@ def run_stream(args, index, n, k):
     index.synthetic_reads_dev(L, args.query_seed, 0, total_reads, d.data_ptr(), args.subst_ppm, s)
     run_start = np.arange(total_reads, dtype=np.uint64) * np.uint64(L)
     run_windows = np.full(total_reads, wins, dtype=np.uint32)
-    index.query_stream_dev(d.data_ptr(), total_reads * L, run_start, run_windows, k, fm.MODE_ALL if args.mode == "all" else fm.MODE_OR,
-                           d_out.data_ptr(), stream=s)
+    # (the device path bench.py is timing: the kLCP kernel, or the run entry point -- dictionary / candidate tables)
+    gpu_fn = index.query_runs_dev if getattr(args, "stream_via", "klcp") == "runs" else index.query_stream_dev
+    gpu_fn(d.data_ptr(), total_reads * L, run_start, run_windows, k, fm.MODE_ALL if args.mode == "all" else fm.MODE_OR, d_out.data_ptr(), stream=s)
     torch.cuda.synchronize()
     packed = d.cpu().numpy().view(np.uint64)
     codes = ((packed[:, None] >> (2 * np.arange(32, dtype=np.uint64))) & np.uint64(3)).astype(np.uint8).reshape(-1)[:total_reads * L]

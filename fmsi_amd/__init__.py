@@ -64,7 +64,7 @@ class IndexInfo(C.Structure):
         ("prefix_len", C.c_int32), ("block_bytes", C.c_uint64), ("block_symbols", C.c_uint64),
         ("n_blocks", C.c_uint64), ("device_bytes", C.c_uint64), ("counts", C.c_uint64 * 4), ("dollar_position", C.c_uint64),
         ("candidate_entry_bytes", C.c_uint64), ("dict_bytes", C.c_uint64), ("dict_keys", C.c_uint64 * 4), ("dict_ambiguous", C.c_uint64),
-        ("dict_levels", C.c_uint32), ("dict_log2_buckets", C.c_uint32),
+        ("dict_levels", C.c_uint32), ("dict_log2_buckets", C.c_uint32), ("rows64", C.c_uint64),
     ]
 
 

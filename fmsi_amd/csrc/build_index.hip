@@ -26,6 +26,7 @@
 #include "../../include/fmsi_hip.h"
 #include "common.h"
 #include "index_priv.h"
+#include "trace.h"
 
 namespace fmsi {
 namespace {
@@ -270,6 +271,7 @@ uint32_t grid_for(uint64_t items, uint32_t threads = 256) { return static_cast<u
 // Shared tail of both entry points: text2 (device, zero padded, + mask_text or all-ones) -> device index.
 int build_from_device_text(DevBuf& text2, uint64_t len, DevBuf* mask_text, int k, int with_klcp, int device, int prefix_len,
                            fmsi_hip_index** out) {
+    TraceRange trace_range("fmsi: build index on device");
     const uint64_t n = len + 1;
     if (len == 0 || n >= (1ull << 32) - kBlockRows) {
         set_last_error("superstring length must be in [1, 2^32 - 130)");
@@ -439,6 +441,11 @@ int build_from_device_text(DevBuf& text2, uint64_t len, DevBuf* mask_text, int k
     idx->dev.C1 = totals.a;                                     // the '$' slot is stored (and counted) as an 'A'
     idx->dev.C2 = totals.a + totals.c;
     idx->dev.C3 = totals.a + totals.c + totals.g;
+    idx->counts64[0] = idx->dev.C0;
+    idx->counts64[1] = idx->dev.C1;
+    idx->counts64[2] = idx->dev.C2;
+    idx->counts64[3] = idx->dev.C3;
+    idx->dollar64 = dollar_row;
     if (prefix_len > 0 && (rc = build_prefix_table(idx, prefix_len))) {
         fmsi_hip_index_destroy(idx);
         return rc;

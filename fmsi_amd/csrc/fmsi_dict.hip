@@ -41,6 +41,7 @@
 #include "common.h"
 #include "device_fm.h"
 #include "index_priv.h"
+#include "trace.h"
 
 namespace fmsi {
 
@@ -519,8 +520,10 @@ struct PhaseClock {
 
 extern "C" int fmsi_hip_index_enable_dict(fmsi_hip_index* idx, uint32_t flags) {
     if (!idx) return FMSI_HIP_EINVAL;
+    FMSI_HIP_NARROW_ONLY(idx, "the k-mer dictionary");
     if (idx->dict.levels) return 0;
     PhaseClock clock;
+    TraceRange trace_range("fmsi: build k-mer dictionary");
     const int k = idx->k;
     const uint64_t n = idx->n, len = n - 1;
     if (k < 1 || k > 32 || len < static_cast<uint64_t>(k)) {

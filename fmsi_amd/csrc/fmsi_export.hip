@@ -16,6 +16,7 @@
 #include "common.h"
 #include "device_fm.h"
 #include "index_priv.h"
+#include "trace.h"
 
 namespace fmsi {
 namespace {
@@ -83,6 +84,7 @@ namespace fmsi {
 int export_walk(const fmsi_hip_index* idx, char* d_chars, uint32_t* d_sa) {
     const uint64_t n = idx->n, text_len = n - 1;
     if (text_len == 0) return 0;
+    TraceRange trace_range("fmsi: LF walk (export)");
     // about a million chains, at least 64 rows apart
     uint64_t stride64 = 64;
     while ((n + stride64 - 1) / stride64 > (1ull << 20)) stride64 *= 2;
@@ -135,6 +137,7 @@ extern "C" int fmsi_hip_index_export(const fmsi_hip_index* idx, char* out, uint6
         set_last_error("null argument");
         return FMSI_HIP_EINVAL;
     }
+    FMSI_HIP_NARROW_ONLY(idx, "export");
     const uint64_t text_len = idx->n - 1;
     *out_len = text_len;
     if (out_capacity < text_len) {

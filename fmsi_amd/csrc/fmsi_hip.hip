@@ -23,6 +23,7 @@
 #include "common.h"
 #include "device_fm.h"
 #include "index_priv.h"
+#include "trace.h"
 #include "index_writer.h"
 #include "layout.h"
 
@@ -443,6 +444,7 @@ __global__ __launch_bounds__(256) void ptable_pack_kernel(DevIndex ix, uint2* __
 
 int build_prefix_table(fmsi_hip_index* idx, int t) {
     if (t <= 0) return 0;
+    TraceRange trace_range("fmsi: build prefix table");
     if (t > 16) {
         set_last_error("prefix_len must be <= 16");
         return FMSI_HIP_EINVAL;
@@ -557,6 +559,17 @@ int launch_query(fmsi_hip_index* idx, const uint64_t* d_kmers, uint64_t n_window
     if (n_windows > (1ull << 38)) {
         set_last_error("too many windows for one launch");
         return FMSI_HIP_ERANGE;
+    }
+    if (idx->wide) {   // 64-bit rows: one kernel, whatever the selection flags say
+        PackAfter pack;
+        uint32_t kflags = flags;
+        int rcw = pack.begin(idx, kflags, n_windows, d_out);
+        if (rcw) return rcw;
+        size_t slotw;
+        if ((rcw = prof_begin(idx, s, &slotw))) return rcw;
+        if ((rcw = launch_wide_query(idx, d_kmers, n_windows, k, kflags, pack.bytes, static_cast<long long*>(d_out), d_counters, s))) return rcw;
+        if ((rcw = pack.end(n_windows, flags, d_out, s))) return rcw;
+        return prof_end(idx, s, slotw);
     }
     uint8_t* o8 = static_cast<uint8_t*>(d_out);
     long long* o64 = static_cast<long long*>(d_out);
@@ -673,6 +686,7 @@ int run_query(fmsi_hip_index* idx, int input_kind, const uint64_t* in, size_t in
     }
     const uint64_t* d_kmers = d_in;
     if (input_kind == 1 && k > 32) {
+        FMSI_HIP_NARROW_ONLY(idx, "a query with k > 32");
         // the k-mer does not fit a register pair: walk the window off the packed sequence (fmsi_longk.hip)
         if (n_windows == 0) return 0;
         PackAfter pack;
@@ -728,10 +742,9 @@ int fmsi_hip_index_create(const fmsi_index_view* view, int device, fmsi_hip_inde
         set_last_error("empty index");
         return FMSI_HIP_EINVAL;
     }
-    if (view->mask_bits >= (1ull << 32) - kBlockRows) {
-        set_last_error("index has >= 2^32 rows; the 64-bit row variant is not built");
-        return FMSI_HIP_ERANGE;
-    }
+    // 2^32 rows and more (or FMSI_HIP_FORCE_ROWS64, for tests): the 64-bit row variant -- same blocks, plain search only (fmsi_wide.hip)
+    const bool forced_wide = std::getenv("FMSI_HIP_FORCE_ROWS64") != nullptr;
+    const bool wide = forced_wide || view->mask_bits >= (1ull << 32) - kBlockRows;
     int ndev = fmsi_hip_device_count();
     if (ndev <= 0 || device < 0 || device >= ndev) {
         set_last_error("no usable HIP device (libfmsi_hip has no CPU fallback)");
@@ -762,6 +775,34 @@ int fmsi_hip_index_create(const fmsi_index_view* view, int device, fmsi_hip_inde
         return fail(FMSI_HIP_EHIP);
     }
     idx->device_bytes = blocks_bytes + mrank_bytes;
+    for (int c = 0; c < 4; ++c) idx->counts64[c] = view->counts[c];
+    idx->dollar64 = view->dollar_position;
+    if (wide) {
+        // superblocks of 2^31 rows; a forced small index gets superblocks of 8 blocks so that the table matters
+        const uint32_t sb_log2 = forced_wide && view->mask_bits < (1ull << 32) ? 3u : 24u;
+        std::vector<uint64_t> super;
+        wide_super_table(L.blocks.data(), L.mrank.data(), L.n_blocks, sb_log2, super);
+        if (hipMalloc(&idx->d_super, super.size() * 8) != hipSuccess ||
+            hipMemcpy(idx->d_super, super.data(), super.size() * 8, hipMemcpyHostToDevice) != hipSuccess) {
+            set_last_error("uploading the superblock table failed");
+            return fail(FMSI_HIP_EHIP);
+        }
+        idx->device_bytes += super.size() * 8;
+        idx->wide = true;
+        idx->devw.blocks = static_cast<const uint4*>(idx->d_blocks);
+        idx->devw.mrank = static_cast<const uint32_t*>(idx->d_mrank);
+        idx->devw.super = static_cast<const uint64_t*>(idx->d_super);
+        idx->devw.sb_log2 = sb_log2;
+        idx->devw.n = idx->n;
+        idx->devw.dollar = view->dollar_position;
+        idx->devw.C0 = view->counts[0];
+        idx->devw.C1 = view->counts[1];
+        idx->devw.C2 = view->counts[2];
+        idx->devw.C3 = view->counts[3];
+        // (no kLCP streaming, no prefix table for such a handle: view->klcp and view->prefix_len are not used)
+        *out = idx;
+        return 0;
+    }
     idx->dev.blocks = static_cast<const uint4*>(idx->d_blocks);
     idx->dev.mrank = static_cast<const uint32_t*>(idx->d_mrank);
     idx->dev.ptable = nullptr;
@@ -794,7 +835,7 @@ int fmsi_hip_index_create(const fmsi_index_view* view, int device, fmsi_hip_inde
 void fmsi_hip_index_destroy(fmsi_hip_index* idx) {
     if (!idx) return;
     ::fmsi::DeviceGuard device_guard_(idx->device);
-    for (void* p : {idx->d_blocks, idx->d_mrank, idx->d_ptable, idx->d_klcp, idx->d_text2, idx->d_stable, idx->d_vtable, idx->d_in, idx->d_aux, idx->d_out,
+    for (void* p : {idx->d_super, idx->d_blocks, idx->d_mrank, idx->d_ptable, idx->d_klcp, idx->d_text2, idx->d_stable, idx->d_vtable, idx->d_in, idx->d_aux, idx->d_out,
                     idx->d_kmers, idx->d_tasks, idx->d_bytes, idx->d_dict[0], idx->d_dict[1], idx->d_dict[2], idx->d_dict[3], idx->d_pblocks, idx->d_sbt, idx->d_c2, static_cast<void*>(idx->d_counters)})
         if (p) (void)hipFree(p);
     for (auto& m : idx->meta_ring) {
@@ -820,11 +861,9 @@ int fmsi_hip_index_get_info(const fmsi_hip_index* idx, fmsi_hip_index_info* info
     info->block_symbols = kBlockRows;
     info->n_blocks = idx->n_blocks;
     info->device_bytes = idx->device_bytes;
-    info->counts[0] = idx->dev.C0;
-    info->counts[1] = idx->dev.C1;
-    info->counts[2] = idx->dev.C2;
-    info->counts[3] = idx->dev.C3;
-    info->dollar_position = idx->dev.dollar;
+    for (int c = 0; c < 4; ++c) info->counts[c] = idx->counts64[c];
+    info->dollar_position = idx->dollar64;
+    info->rows64 = idx->wide ? 1u : 0u;
     info->candidate_entry_bytes = idx->d_vtable ? (idx->vwide ? 32u : 16u) : 0u;
     info->dict_bytes = idx->dict_bytes;
     for (uint32_t lv = 0; lv < kDictMaxLevels; ++lv) info->dict_keys[lv] = idx->dict_keys[lv];
@@ -866,8 +905,8 @@ int fmsi_hip_index_write_files(const fmsi_hip_index* idx, const char* prefix) {
         v.klcp = klcp.data();
         v.klcp_bits = idx->n;
     }
-    v.counts[0] = idx->dev.C0; v.counts[1] = idx->dev.C1; v.counts[2] = idx->dev.C2; v.counts[3] = idx->dev.C3;
-    v.dollar_position = idx->dev.dollar;
+    for (int c = 0; c < 4; ++c) v.counts[c] = idx->counts64[c];
+    v.dollar_position = idx->dollar64;
     v.k = idx->k;
     std::string err;
     int rc = write_index_files(prefix, v, err);
@@ -962,7 +1001,7 @@ int fmsi_hip_query_runs(fmsi_hip_index* idx, const uint64_t* packed_seq, uint64_
         flags &= ~FMSI_HIP_KERNEL_MASK;
         kernel = FMSI_HIP_KERNEL_AUTO;
     }
-    if (k <= 32 && (kernel == FMSI_HIP_KERNEL_PHASED || kernel == FMSI_HIP_KERNEL_AUTO) && idx->d_pblocks && idx->d_ptable &&
+    if (!idx->wide && k <= 32 && (kernel == FMSI_HIP_KERNEL_PHASED || kernel == FMSI_HIP_KERNEL_AUTO) && idx->d_pblocks && idx->d_ptable &&
         !(flags & FMSI_HIP_NO_PREFIX_TABLE) && k >= idx->prefix_len && n_windows <= (1ull << 38)) {
         // the phased kernels cut the windows themselves: no pass that writes 8 bytes per window and reads them back
         PackAfter pack;   // (the one-lane lookup kernel packs FMSI_HIP_OUT_BITS output itself)
@@ -989,6 +1028,7 @@ int fmsi_hip_query_runs(fmsi_hip_index* idx, const uint64_t* packed_seq, uint64_
     const uint64_t* d_ro = d_rs + n_runs;
     const uint32_t blocks = static_cast<uint32_t>(std::min<uint64_t>((n_windows + 255) / 256, 256 * 16));
     if (k > 32) {
+        FMSI_HIP_NARROW_ONLY(idx, "a query with k > 32");
         if ((rc = ensure_cap(&idx->d_aux, &idx->d_aux_cap, n_windows * 8))) return rc;
         hipLaunchKernelGGL((expand_runs_kernel<false>), dim3(blocks), dim3(256), 0, s, d_seq, d_rs, d_ro, n_runs, n_windows, k,
                            static_cast<uint64_t*>(idx->d_aux));

@@ -41,6 +41,7 @@
 #include "common.h"
 #include "device_fm.h"
 #include "index_priv.h"
+#include "trace.h"
 
 namespace fmsi {
 
@@ -1300,7 +1301,9 @@ using namespace fmsi;
 
 extern "C" int fmsi_hip_index_enable_pair_layout(fmsi_hip_index* idx) {
     if (!idx) return FMSI_HIP_EINVAL;
+    FMSI_HIP_NARROW_ONLY(idx, "this accelerator");
     if (idx->d_pblocks) return 0;
+    TraceRange trace_range("fmsi: build pair layout");
     FMSI_HIP_ON_DEVICE(idx->device);
     const uint64_t n_blocks = idx->n_blocks;
     const uint64_t n_super = ((n_blocks - 1) >> kSuperBlocksLog2) + 1;
@@ -1489,7 +1492,9 @@ __global__ __launch_bounds__(256) void verify_fill_kernel(const uint2* __restric
 
 extern "C" int fmsi_hip_index_enable_verify(fmsi_hip_index* idx) {
     if (!idx) return FMSI_HIP_EINVAL;
+    FMSI_HIP_NARROW_ONLY(idx, "this accelerator");
     if (idx->d_vtable) return 0;
+    TraceRange trace_range("fmsi: build candidate tables");
     const int T = idx->prefix_len, R = idx->k - T;
     if (!idx->d_ptable || !idx->dev.ptable_packed || idx->k > 32 || R < 1) {
         set_last_error("text verification needs a packed prefix table with t < k <= 32");

@@ -607,6 +607,7 @@ extern "C" int fmsi_hip_query_stream(fmsi_hip_index* idx, const uint64_t* packed
         set_last_error("null argument");
         return FMSI_HIP_EINVAL;
     }
+    FMSI_HIP_NARROW_ONLY(idx, "kLCP streaming");
     if (!idx->d_klcp) {
         set_last_error("streaming queries need an index created with its kLCP array");
         return FMSI_HIP_EINVAL;

@@ -1,0 +1,162 @@
+// 64-bit rows: indexes of 2^32 rows and more (the reference's intervals are size_t, src/fms_index.h:98-103).
+//
+// Every configuration of BASELINE.json has n < 2^32, and the fast kernels (fmsi_hip.hip, fmsi_pair.hip, fmsi_stream.hip,
+// fmsi_dict.hip) keep rows, counts and table entries in 32 bits.  A larger index -- a pangenome superstring beyond 4.29 G bases --
+// loads into the SAME 64-byte blocks: their u32 cumulative counts simply wrap, and a small table of absolute u64 counts at every
+// superblock start (2^24 blocks = 2^31 rows) restores them: count = super + (u32)(block count - (u32)super), exact as long as a
+// superblock spans < 2^32 rows.  The search below is the lock-step form of query_lockstep_kernel with u64 rows -- update_range()
+// (src/fms_index.h:98-103), get_range_with_pattern() (:117-124), infer_presence() (:126-144), kmer_order_if_present()
+// (:146-156) -- for isolated k-mers and, through the library's window / run expansion, for windows and runs; presence modes,
+// STRICT, ORDERS and FMSI_HIP_OUT_BITS as everywhere.  Not built for such handles: prefix table, pair layout, candidate tables,
+// dictionary, kLCP streaming, k > 32, export and the on-device builder (FMSI_HIP_ERANGE says so).
+// FMSI_HIP_FORCE_ROWS64 (environment, at fmsi_hip_index_create) sends any index through this path with superblocks of 8 blocks,
+// which is how tests/test_gpu_wide.py holds it against the oracle.
+#include <hip/hip_runtime.h>
+
+#include <cstdlib>
+#include <string>
+#include <vector>
+
+#include "../../include/fmsi_hip.h"
+#include "common.h"
+#include "device_fm.h"
+#include "index_priv.h"
+
+namespace fmsi {
+
+namespace {
+
+__device__ __forceinline__ uint64_t abs_count(const DevIndexW& ix, uint64_t block, uint32_t slot, uint32_t wrapped) {
+    const uint64_t s = ix.super[(block >> ix.sb_log2) * 8u + slot];
+    return s + static_cast<uint32_t>(wrapped - static_cast<uint32_t>(s));
+}
+
+// one LF step on a non-empty [i, j): update_range, src/fms_index.h:98-103 (the upper boundary through the block of row j - 1)
+__device__ __forceinline__ void lf_step_w(const DevIndexW& ix, uint32_t c, uint64_t& i, uint64_t& j, uint32_t& blocks_read) {
+    const uint64_t bi = i >> kBlockRowsLog2, bj = (j - 1u) >> kBlockRowsLog2;
+    const uint4* pi = ix.blocks + (bi << 2);
+    const uint4* pj = ix.blocks + (bj << 2);
+    const uint4 ci = pi[0], hi = pi[1], li = pi[2];
+    const uint4 cj = pj[0], hj = pj[1], lj = pj[2];
+    blocks_read += 1u + (bj != bi);
+    const uint4 z = make_uint4(0, 0, 0, 0);
+    const uint32_t in_i = rank_in_block(z, hi, li, c, static_cast<uint32_t>(i & (kBlockRows - 1u)));
+    const uint32_t in_j = rank_in_block(z, hj, lj, c, static_cast<uint32_t>(j - (bj << kBlockRowsLog2)));
+    uint64_t ri = abs_count(ix, bi, c, sel4(c, opaque(ci.x), opaque(ci.y), opaque(ci.z), opaque(ci.w))) + in_i;
+    uint64_t rj = abs_count(ix, bj, c, sel4(c, opaque(cj.x), opaque(cj.y), opaque(cj.z), opaque(cj.w))) + in_j;
+    if (c == 0u) {   // the '$' slot is stored as an 'A' and subtracted here (src/fms_index.h:81)
+        ri -= (i > ix.dollar);
+        rj -= (j > ix.dollar);
+    }
+    const uint64_t base = c == 0u ? ix.C0 : (c == 1u ? ix.C1 : (c == 2u ? ix.C2 : ix.C3));
+    i = base + ri;
+    j = base + rj;
+}
+
+__device__ __forceinline__ uint64_t mask_rank_w(const DevIndexW& ix, uint64_t b, uint32_t p) {
+    const uint4 m = ix.blocks[(b << 2) + 3];
+    return abs_count(ix, b, 4u, ix.mrank[b]) + popc_prefix128(m, p);
+}
+
+struct WideCounters {
+    uint32_t lf_steps = 0, blocks = 0, probes = 0, searches = 0;
+};
+
+__device__ __forceinline__ int search_strand_w(const DevIndexW& ix, uint64_t cur, int k, uint32_t mode_all, uint32_t want_orders, long long& order,
+                                               WideCounters& cn) {
+    uint64_t i = 0, j = ix.n;
+    cn.searches++;
+    for (int t = k - 1; t >= 0 && i != j; --t) {
+        lf_step_w(ix, static_cast<uint32_t>(cur >> (2 * t)) & 3u, i, j, cn.blocks);
+        cn.lf_steps++;
+    }
+    order = -1;
+    if (i == j) return -1;
+    cn.probes++;
+    cn.blocks++;
+    if (mode_all && !want_orders) {
+        const uint32_t* w = reinterpret_cast<const uint32_t*>(ix.blocks) + ((i >> kBlockRowsLog2) << 4) + 12u;
+        return static_cast<int>((w[(i & (kBlockRows - 1u)) >> 5] >> (i & 31u)) & 1u);
+    }
+    const uint64_t bi = i >> kBlockRowsLog2, bj = (j - 1u) >> kBlockRowsLog2;
+    const uint64_t ri = mask_rank_w(ix, bi, static_cast<uint32_t>(i & (kBlockRows - 1u)));
+    const uint64_t rj = mask_rank_w(ix, bj, static_cast<uint32_t>(j - (bj << kBlockRowsLog2)));
+    const int any = rj > ri;
+    if (want_orders && any) order = static_cast<long long>(ri);
+    return any;
+}
+
+template <bool COUNT>
+__global__ __launch_bounds__(256) void query_wide_kernel(DevIndexW ix, const uint64_t* __restrict__ kmers, uint64_t n_windows, int k, uint32_t flags,
+                                                         uint8_t* __restrict__ out, long long* __restrict__ out_orders,
+                                                         unsigned long long* __restrict__ counters) {
+    const uint64_t q = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    const bool valid = q < n_windows;
+    const uint32_t mode_all = flags & FMSI_HIP_MODE_ALL, strict = flags & FMSI_HIP_STRICT, orders = flags & FMSI_HIP_ORDERS;
+    WideCounters cn;
+    if (valid) {
+        const uint64_t f = kmers[q];
+        long long ord_f = -1, ord_r = -1;
+        const int res_f = search_strand_w(ix, f, k, mode_all, orders, ord_f, cn);
+        int res_r = -1;
+        // second strand: src/fms_index.h:283-299 with the forward strand first
+        const bool second = strict ? true : (orders ? ord_f < 0 : (mode_all ? res_f == -1 : res_f != 1));
+        if (second) res_r = search_strand_w(ix, revcomp_2bit(f, k), k, mode_all, orders, ord_r, cn);
+        if (orders) {
+            if (strict) {
+                out_orders[2 * q] = ord_f;
+                out_orders[2 * q + 1] = ord_r;
+            } else {
+                out_orders[q] = second ? ord_r : ord_f;
+            }
+        } else if (strict) {
+            out[q] = static_cast<uint8_t>((res_f + 1) | ((res_r + 1) << 2));
+        } else {
+            out[q] = static_cast<uint8_t>((second ? res_r : res_f) == 1);
+        }
+    }
+    if (COUNT) {
+        uint32_t v[5] = {cn.lf_steps, cn.blocks, cn.probes, cn.searches, valid ? 1u : 0u};
+        const int slot[5] = {0, 1, 2, 3, 6};
+#pragma unroll
+        for (int s = 0; s < 5; ++s) {
+            uint32_t x = v[s];
+            for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+            if ((threadIdx.x & 63) == 0 && x) atomicAdd(&counters[slot[s]], static_cast<unsigned long long>(x));
+        }
+    }
+}
+
+}  // namespace
+
+// absolute counts at every superblock start from the wrapped u32 counts of the host layout: per block the count of a symbol is
+// (next block's cumulative - this block's) mod 2^32 <= 128
+void wide_super_table(const uint32_t* blocks, const uint32_t* mrank, uint64_t n_blocks, uint32_t sb_log2, std::vector<uint64_t>& super) {
+    const uint64_t n_super = ((n_blocks - 1) >> sb_log2) + 1;
+    super.assign(n_super * 8, 0);
+    uint64_t run[5] = {0, 0, 0, 0, 0};
+    for (uint64_t b = 0; b < n_blocks; ++b) {
+        if ((b & ((1ull << sb_log2) - 1)) == 0)
+            for (int s = 0; s < 5; ++s) super[(b >> sb_log2) * 8 + s] = run[s];
+        if (b + 1 < n_blocks) {
+            for (int s = 0; s < 4; ++s) run[s] += static_cast<uint32_t>(blocks[(b + 1) * kBlockDwords + s] - blocks[b * kBlockDwords + s]);
+            run[4] += static_cast<uint32_t>(mrank[b + 1] - mrank[b]);
+        }
+    }
+}
+
+int launch_wide_query(fmsi_hip_index* idx, const uint64_t* d_kmers, uint64_t n, int k, uint32_t flags, uint8_t* o8, long long* o64,
+                      unsigned long long* d_counters, hipStream_t s) {
+    const uint64_t blocks64 = (n + 255) / 256;
+    if (blocks64 > 0x7FFFFFFFull) {
+        set_last_error("too many windows for one launch");
+        return FMSI_HIP_ERANGE;
+    }
+    const dim3 grid(static_cast<uint32_t>(blocks64)), block(256);
+    if (d_counters) hipLaunchKernelGGL((query_wide_kernel<true>), grid, block, 0, s, idx->devw, d_kmers, n, k, flags, o8, o64, d_counters);
+    else hipLaunchKernelGGL((query_wide_kernel<false>), grid, block, 0, s, idx->devw, d_kmers, n, k, flags, o8, o64, d_counters);
+    FMSI_HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+}  // namespace fmsi

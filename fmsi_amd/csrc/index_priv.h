@@ -27,6 +27,15 @@ struct DevIndex {
     uint32_t ptable_packed;   // entry format: 0 = (i, j); 1 = (i, tagged word) with next-base signatures, see decode_table_entry
 };
 
+// the same blocks for an index of 2^32 rows and more (fmsi_wide.hip): u64 rows, absolute counts per superblock
+struct DevIndexW {
+    const uint4* blocks;
+    const uint32_t* mrank;     // wrapped u32 cumulative mask popcounts
+    const uint64_t* super;     // per superblock of 2^sb_log2 blocks: absolute #A #C #G #T #mask before it (+ 3 words of padding)
+    uint32_t sb_log2, pad;
+    uint64_t n, dollar, C0, C1, C2, C3;
+};
+
 // the k-mer dictionary (fmsi_dict.hip): up to four levels of 128-byte buckets, passed by value to the lookup kernel
 constexpr uint32_t kDictMaxLevels = 4;
 struct DictLevel {
@@ -92,6 +101,11 @@ struct fmsi_hip_index {
     int prefix_len = 0;
     uint64_t n_blocks = 0;
     uint64_t device_bytes = 0;
+    // 64-bit rows (fmsi_wide.hip): n >= 2^32 - 128, or forced for tests; only the blocks, mrank and the superblock table exist
+    bool wide = false;
+    fmsi::DevIndexW devw{};
+    void* d_super = nullptr;
+    uint64_t counts64[4] = {0, 0, 0, 0}, dollar64 = 0;   // C array and dollar position in full width (any handle)
     void* d_blocks = nullptr;
     void* d_mrank = nullptr;
     void* d_ptable = nullptr;
@@ -146,6 +160,19 @@ void launch_longk_query(fmsi_hip_index* idx, const uint64_t* d_seq, const uint64
 // the run lengths; the lookup kernel cuts the windows itself
 int launch_phased_query(fmsi_hip_index* idx, const uint64_t* d_kmers, uint64_t n, int k, uint32_t flags, uint8_t* o8, long long* o64,
                         unsigned long long* d_counters, hipStream_t s, const uint64_t* h_runs = nullptr, uint64_t n_runs = 0);
+
+// 64-bit rows (fmsi_wide.hip)
+void wide_super_table(const uint32_t* blocks, const uint32_t* mrank, uint64_t n_blocks, uint32_t sb_log2, std::vector<uint64_t>& super);
+int launch_wide_query(fmsi_hip_index* idx, const uint64_t* d_kmers, uint64_t n, int k, uint32_t flags, uint8_t* o8, long long* o64,
+                      unsigned long long* d_counters, hipStream_t s);
+// what a handle with 64-bit rows does not have
+#define FMSI_HIP_NARROW_ONLY(idx, what)                                                                                          \
+    do {                                                                                                                         \
+        if ((idx)->wide) {                                                                                                       \
+            ::fmsi::set_last_error(std::string(what) + " is not built for indexes of 2^32 rows or more (64-bit rows: plain search only)"); \
+            return FMSI_HIP_ERANGE;                                                                                              \
+        }                                                                                                                        \
+    } while (0)
 
 // the k-mer dictionary answers this call (presence modes, the index's k, no NO_PREFIX_TABLE) -- and its launch; h_runs as for
 // launch_phased_query.  The lookup kernel packs FMSI_HIP_OUT_BITS output itself.

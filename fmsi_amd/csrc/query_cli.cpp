@@ -42,6 +42,7 @@
 #include "../../include/fmsi_hip.h"
 #include "common.h"
 #include "fastx.h"
+#include "trace.h"
 #include "host_index.h"
 
 namespace fmsi {
@@ -866,7 +867,10 @@ extern "C" int fmsi_cli_query(int argc, char** argv, int output_orders_i) {
     using clock = std::chrono::steady_clock;
     auto t_start = clock::now();
     fmsi_host_index* host = nullptr;
-    if (fmsi_host_index_load(opt.index_prefix.c_str(), opt.has_klcp, &host) != 0 || host->ix.n() == 0) {
+    trace_push("fmsi: load index files");
+    const int rc_load = fmsi_host_index_load(opt.index_prefix.c_str(), opt.has_klcp, &host);
+    trace_pop();
+    if (rc_load != 0 || host->ix.n() == 0) {
         std::cerr << "ERROR: index not correctly loaded. Ensure that you correctly call `fmsi index` before." << std::endl;
         return usage_query(output_orders);
     }
@@ -912,6 +916,7 @@ extern "C" int fmsi_cli_query(int argc, char** argv, int output_orders_i) {
     // The accelerators are large (34 GB + 52 GB at human scale): when HBM is short -- the GPU shared with other work --
     // the table shrinks and the verification is left out; only a failure of the index proper is an error.
     int rc_create = FMSI_HIP_ENOMEM;
+    auto accel_range = std::make_unique<TraceRange>("fmsi: device index + accelerators");
     for (; t >= 0; t -= 2) {
         view.prefix_len = std::max(t, 0);
         rc_create = fmsi_hip_index_create(&view, opt.device, &dev);
@@ -919,20 +924,31 @@ extern "C" int fmsi_cli_query(int argc, char** argv, int output_orders_i) {
         std::cerr << "WARNING: not enough device memory for a prefix table of depth " << t << ", trying " << std::max(t - 2, 0) << std::endl;
     }
     t = std::max(t, 0);
-    bool have_dict = false;
-    if (rc_create == 0 && want_dict) {
+    bool have_dict = false, rows64 = false;
+    if (rc_create == 0) {
+        fmsi_hip_index_info info;
+        rows64 = fmsi_hip_index_get_info(dev, &info) == 0 && info.rows64 != 0;
+        if (rows64 && (opt.has_klcp || k > 32)) {   // 2^32 rows and more: the plain search only (include/fmsi_hip.h)
+            std::cerr << "ERROR: -S and k > 32 are not available on the GPU path for indexes of 2^32 rows or more." << std::endl;
+            fmsi_hip_index_destroy(dev);
+            fmsi_host_index_free(host);
+            return 1;
+        }
+    }
+    if (rc_create == 0 && want_dict && !rows64) {
         have_dict = fmsi_hip_index_enable_dict(dev, 0) == 0;
         if (!have_dict) std::cerr << "WARNING: the k-mer dictionary is off (" << fmsi_hip_last_error() << "); results are unaffected" << std::endl;
     }
-    if (rc_create != 0 || (!opt.has_klcp && !have_dict && fmsi_hip_index_enable_pair_layout(dev) != 0)) {
+    if (rc_create != 0 || (!opt.has_klcp && !have_dict && !rows64 && fmsi_hip_index_enable_pair_layout(dev) != 0)) {
         std::cerr << "ERROR: cannot create the device index: " << fmsi_hip_last_error() << std::endl;
         if (dev) fmsi_hip_index_destroy(dev);
         fmsi_host_index_free(host);
         return 1;
     }
-    const bool want_verify = opt.candidate_tables && !opt.has_klcp && !output_orders && t > 0 && t < k && k <= 32;
+    const bool want_verify = !rows64 && opt.candidate_tables && !opt.has_klcp && !output_orders && t > 0 && t < k && k <= 32;
     if (want_verify && fmsi_hip_index_enable_verify(dev) != 0)
         std::cerr << "WARNING: text verification is off (" << fmsi_hip_last_error() << "); results are unaffected" << std::endl;
+    accel_range.reset();
     auto t_loaded = clock::now();
 
     // OR-mode presence output does not depend on the strand order, so the cheaper schedule is exact;
@@ -1068,9 +1084,12 @@ extern "C" int fmsi_cli_query(int argc, char** argv, int output_orders_i) {
             std::vector<std::string> parts;
             while (out_q.pop(P)) {
                 auto t0 = clock::now();
+                trace_push("fmsi: format");
                 if (output_orders) format_orders(*P, team, parts);
                 else format_bits(*P, team, buf);
+                trace_pop();
                 auto t1 = clock::now();
+                TraceRange write_range("fmsi: write");
                 if (output_orders) {
                     for (const std::string& s : parts)
                         if (!s.empty() && std::fwrite(s.data(), 1, s.size(), stdout) != s.size()) throw std::runtime_error("write to stdout failed");
@@ -1096,12 +1115,15 @@ extern "C" int fmsi_cli_query(int argc, char** argv, int output_orders_i) {
             P->raw = std::move(*raw);
             raw.reset();
             auto t0 = clock::now();
+            trace_push("fmsi: pack batch");
             prepare_batch(*P, k, team);
+            trace_pop();
             auto t1 = clock::now();
             const uint64_t nw = P->windows;
             if (output_orders) P->orders.resize(nw * (strict ? 2 : 1));
             else P->bytes.resize(nw);
             if (nw) {
+                TraceRange device_range("fmsi: device (copy in, kernels, copy out)");
                 void* dst = output_orders ? static_cast<void*>(P->orders.data()) : static_cast<void*>(P->bytes.data());
                 if (opt.has_klcp && !have_dict)   // -S: kLCP streaming kernel (query_kmers_streaming, src/fms_index.h:181-254)
                     check(fmsi_hip_query_stream(dev, P->packed.data(), P->bases, P->run_start.data(), P->run_windows.data(),
@@ -1115,7 +1137,10 @@ extern "C" int fmsi_cli_query(int argc, char** argv, int output_orders_i) {
             }
             auto t2 = clock::now();
             PinVec<uint64_t>().swap(P->packed);
-            if (strict) replay_batch(*P, predictor, opt.mode, output_orders, opt.has_klcp, k, team);
+            if (strict) {
+                TraceRange replay_range("fmsi: predictor replay");
+                replay_batch(*P, predictor, opt.mode, output_orders, opt.has_klcp, k, team);
+            }
             auto t3 = clock::now();
             prep_s += std::chrono::duration<double>(t1 - t0).count();
             gpu_s += std::chrono::duration<double>(t2 - t1).count();

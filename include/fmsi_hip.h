@@ -35,7 +35,7 @@ extern "C" {
 #define FMSI_HIP_EHIP (-3)     /* a HIP runtime call failed */
 #define FMSI_HIP_ENOMEM (-4)
 #define FMSI_HIP_EIO (-5)      /* index files missing / malformed */
-#define FMSI_HIP_ERANGE (-6)   /* index too large for this build (rows >= 2^32) or k unsupported */
+#define FMSI_HIP_ERANGE (-6)   /* not built for this size: an accelerator / streaming / export on an index of >= 2^32 rows, or k unsupported */
 #define FMSI_HIP_ECOMM (-7)    /* RCCL failure */
 
 /* ---- query flags ------------------------------------------------------------------------------ */
@@ -120,6 +120,8 @@ typedef struct {
     uint64_t dict_keys[4];      /* distinct canonical k-mers handed to each of its levels (level 0: all of them; further: the overflow) */
     uint64_t dict_ambiguous;    /* keys whose `-O` answer was taken from the index's own search (occurrences with differing mask bits) */
     uint32_t dict_levels, dict_log2_buckets;   /* levels in use; log2 of level 0's bucket count */
+    uint64_t rows64;            /* 1: the handle keeps 64-bit rows (n >= 2^32 - 128; src/fms_index.h:98-103 uses size_t): plain search only --
+                                   no prefix table, pair layout, candidate tables, dictionary, kLCP streaming, k > 32, export (FMSI_HIP_ERANGE) */
 } fmsi_hip_index_info;
 
 /* counters written by query calls when `counters` != NULL (8 x u64, accumulated, caller zeroes):

@@ -25,7 +25,7 @@ def main(out_dir: str) -> None:
             with open(f, newline="") as fh:
                 for r in csv.DictReader(fh):
                     name = r["Kernel_Name"]
-                    if "query_" not in name and "pair_lookup" not in name and "lookup_lane" not in name:
+                    if "query_" not in name and "pair_lookup" not in name and "lookup_lane" not in name and "dict_lookup" not in name:
                         continue
                     per_dispatch[(name, r["Counter_Name"])][r["Dispatch_Id"]] += float(r["Counter_Value"])
         for (name, counter), d in per_dispatch.items():
@@ -53,6 +53,41 @@ def main(out_dir: str) -> None:
         except (OSError, IndexError, ValueError):
             continue
         roof = b["roofline"]
+        if wl == "kmers" and roof["kernel"].startswith("dict_lookup"):
+            # the k-mer dictionary: every read of the kernel is a 128-byte request (a bucket by eight lanes, 64 k-mers by a wave), which
+            # gfx950 tallies at 64 B in FETCH_SIZE (MI355X_MICROARCH.md, HBM; tools/gather_bench calibration: 0.50x): fetched = 2 x raw
+            raw = avg(fetch_pass, "dict_lookup_kernel", "FETCH_SIZE")
+            if raw is None:
+                continue
+            batch = b["config"]["queries_per_step_per_gpu"]
+            wr = avg("pmc_write", "dict_lookup_kernel", "WRITE_SIZE")
+            t = {"kernel": "dict_lookup_kernel",
+                 "config": {"workload": wl, "n": b["config"]["index_rows"] - 1, "batch": batch, "k": b["config"]["k"],
+                            "prefix_len": b["config"]["prefix_table_len"], "mode": b["config"]["mode"]},
+                 "fetch_size_raw_bytes_per_launch": raw * 1024.0, "fetch_bytes_per_launch": 2.0 * raw * 1024.0,
+                 "write_bytes_per_launch": (wr or 0.0) * 1024.0,
+                 "algorithmic_bytes_per_launch": roof["algorithmic_bytes_per_launch"],
+                 "tcc_hit_per_launch": avg("pmc_write", "dict_lookup_kernel", "TCC_HIT_sum"),
+                 "tcc_miss_per_launch": avg("pmc_write", "dict_lookup_kernel", "TCC_MISS_sum"),
+                 "correction": "2 x raw FETCH_SIZE (gfx950 tallies a 128-B request at 64 B; every read of this kernel is one)"}
+            t["hbm_bytes_per_launch"] = t["fetch_bytes_per_launch"] + t["write_bytes_per_launch"]
+            # the table-less LF-walk legs of the same run: the pair kernel reads 128-B blocks (2 x raw), the lock-step kernel 64-B
+            # blocks (raw / 1.015); both re-read the top of the search tree from the caches, so traffic < algorithmic bytes
+            legs = []
+            for leg in (roof.get("lf_path") or []):
+                sub = "query_pair_kernel<false, false, false>" if "pair" in leg["kernel"] else "query_lockstep_kernel<false>"
+                lraw = avg(fetch_pass, sub, "FETCH_SIZE")
+                if lraw is None:
+                    continue
+                corrected = 2.0 * lraw * 1024.0 if "pair" in leg["kernel"] else lraw * 1024.0 / 1.015
+                legs.append({"kernel": sub, "fetch_size_raw_bytes_per_launch": lraw * 1024.0, "fetch_bytes_per_launch": corrected,
+                             "algorithmic_bytes_per_launch": leg["algorithmic_bytes"], "kernel_ms": leg["ms"],
+                             "hbm_gb_per_s": corrected / (leg["ms"] * 1e-3) / 1e9})
+            t["lf_path"] = legs
+            with open(os.path.join(out_dir, f"traffic_{wl}.json"), "w") as fh:
+                json.dump(t, fh, indent=1)
+                fh.write("\n")
+            continue
         raw = avg(fetch_pass, kernel_sub, "FETCH_SIZE")
         if raw is None:
             continue
