@@ -67,6 +67,9 @@ def parse_args():
                     help="private accelerator of the phased workload: dict = the k-mer dictionary (fmsi_hip_index_enable_dict: one 128-byte "
                          "bucket read per k-mer, ~12 bytes of HBM per distinct k-mer); tables = prefix table + candidate tables (177 GB at t = 16)")
     ap.add_argument("--dict-sparse", action="store_true", help="dictionary at half the load (twice the HBM, no second-level reads)")
+    ap.add_argument("--hbm-budget", type=float, default=0.0,
+                    help="GB of HBM the index and its accelerators may take (0 = no limit): picks the fastest configuration that fits -- "
+                         "sparse dictionary, dictionary, or the LF walk behind the deepest prefix table that fits (DESIGN.md 4, footprint table)")
     ap.add_argument("--mode", choices=["all", "or"], default="all")
     ap.add_argument("--read-len", type=int, default=10000, help="stream workload: bases per read")
     ap.add_argument("--subst-ppm", type=int, default=0, help="stream workload: substitutions per million bases of positive reads")
@@ -157,6 +160,24 @@ def main():
     # the dictionary answers presence queries of the phased workload and of `--stream-via runs`; the kLCP kernel and the A/B kernels
     # (--kernel pair | refill | lockstep) run without it
     use_dict = args.accel == "dict" and k <= 32 and ((not stream_mode and args.kernel == "phased") or (stream_mode and args.stream_via == "runs"))
+    if args.hbm_budget > 0 and use_dict:
+        # footprints: 4 bits per row (single-step blocks) + 8 bits per row (pair layout) + 2 bits per base (text) + the accelerator;
+        # the dictionary: 128 bytes x 2^b buckets, b the smallest with <= 10.5 (sparse: 5.25) distinct k-mers per bucket, + ~3 % overflow
+        base_gb = (n * 0.5 + n * 1.0 + n * 0.25) / 1e9
+        b = 4
+        while n / float(1 << b) > 10.5:
+            b += 1
+        dense_gb, sparse_gb = (1 << b) * 128 * 1.03 / 1e9, (1 << (b + 1)) * 128 * 1.01 / 1e9
+        if args.hbm_budget >= base_gb + sparse_gb:
+            args.dict_sparse = True
+        elif args.hbm_budget < base_gb + dense_gb:   # no room for the dictionary: steps behind a prefix table of 8 x 4^t bytes
+            use_dict = False
+            args.no_verify = True
+            t_fit = 0
+            while t_fit < min(k, 16) and base_gb + 8 * 4 ** (t_fit + 1) / 1e9 <= args.hbm_budget:
+                t_fit += 1
+            if args.prefix_len < 0:
+                args.prefix_len = t_fit
     args.use_dict = use_dict
     if use_dict and args.prefix_len < 0:
         args.prefix_len = 0   # no prefix table: the dictionary is the accelerator, the LF-walk legs run table-less anyway
@@ -306,6 +327,7 @@ def main():
     t0 = time.perf_counter()
     for s in range(args.steps):
         step(s)
+    enqueue_s = time.perf_counter() - t0   # (host time to enqueue the steps: the launches are asynchronous)
     barrier()   # (torch.cuda.synchronize() inside: every stream of the device, the copy stream included)
     elapsed = time.perf_counter() - t0
     launches, kernel_ms = index.profile_read(reset=True)
@@ -478,7 +500,7 @@ def main():
                        "parallelism": f"query-sharded x{world}, index replicated", "positive_fraction": round(positives, 4),
                        "results": ("bit-packed (FMSI_HIP_OUT_BITS), copied to page-locked host memory inside the timed region"
                                    + (", after the RCCL gather to rank 0" if multi else "")) if bits else "one byte per window, left in HBM",
-                       "results_on_host_match_bytes": bits_check,
+                       "results_on_host_match_bytes": bits_check, "host_enqueue_ms_per_step": round(enqueue_s / args.steps * 1e3, 3),
                        "index_build_seconds": round(build_s, 2)},
             "roofline": roof,
             "cpu_baseline": None,

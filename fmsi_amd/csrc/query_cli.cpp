@@ -77,6 +77,7 @@ struct Options {
     bool fast = false;        // --fast: skip the second strand when the first decides (exact for OR; for -O under its precondition)
     bool stats = false;       // --stats: timings on stderr
     int device = 0;
+    std::vector<int> devices;              // --devices a,b,...: one replicated handle per device, batches dealt out among them
     uint64_t batch_windows = 1ull << 26;   // bases of query sequence per batch (>= windows)
     unsigned threads = 0;                  // 0 = all CPUs this process may use, at most 16
     bool full_tables = false;              // --tables full: the k-mer dictionary (what bench.py measures); lookup: the 16-deep prefix table
@@ -99,6 +100,7 @@ int usage_query(bool lookup) {
     }
     std::cerr << "Options (MI355X path):" << std::endl;
     std::cerr << "  --device INT - HIP device to use [default: 0]" << std::endl;
+    std::cerr << "  --devices LIST - several devices (e.g. 0,1,2,3): the index is replicated, batches are dealt out, output order is kept" << std::endl;
     std::cerr << "  --fast       - search the reverse strand only when the forward strand does not decide;" << std::endl;
     std::cerr << "                 identical output for the default mode, and for -O on max-ones masks" << std::endl;
     std::cerr << "  --batch INT  - bases of query sequence per device batch [default: 67108864]" << std::endl;
@@ -168,6 +170,16 @@ public:
         not_full_.notify_one();
         return true;
     }
+    bool pop_seq(T& v, uint64_t& seq) {   // pop() + the item's number in pop order (several consumers, one order)
+        std::unique_lock<std::mutex> lk(m_);
+        not_empty_.wait(lk, [&] { return !q_.empty() || closed_; });
+        if (q_.empty()) return false;
+        v = std::move(q_.front());
+        q_.pop_front();
+        seq = popped_++;
+        not_full_.notify_one();
+        return true;
+    }
     void close() {       // producer: no more items; consumer: stop the producer
         std::lock_guard<std::mutex> lk(m_);
         closed_ = true;
@@ -187,6 +199,7 @@ private:
     std::condition_variable not_full_, not_empty_;
     std::deque<T> q_;
     size_t cap_;
+    uint64_t popped_ = 0;
     bool closed_ = false;
 };
 
@@ -818,7 +831,8 @@ extern "C" int fmsi_cli_query(int argc, char** argv, int output_orders_i) {
     static const option long_opts[] = {{"device", required_argument, nullptr, 1000}, {"fast", no_argument, nullptr, 1001},
                                        {"batch", required_argument, nullptr, 1002},  {"stats", no_argument, nullptr, 1003},
                                        {"strict", no_argument, nullptr, 1004},       {"threads", required_argument, nullptr, 1005},
-                                       {"tables", required_argument, nullptr, 1006}, {nullptr, 0, nullptr, 0}};
+                                       {"tables", required_argument, nullptr, 1006}, {"devices", required_argument, nullptr, 1007},
+                                       {nullptr, 0, nullptr, 0}};
     optind = 1;
     int c;
     while ((c = getopt_long(argc, argv, "f:hq:k:OS", long_opts, nullptr)) >= 0) {
@@ -849,6 +863,19 @@ extern "C" int fmsi_cli_query(int argc, char** argv, int output_orders_i) {
             else if (std::string(optarg) == "candidates") opt.full_tables = opt.candidate_tables = opt.tables_given = true;
             else if (std::string(optarg) != "auto") return usage_query(output_orders);
             break;
+        case 1007: {
+            opt.devices.clear();
+            std::string list = optarg;
+            size_t pos = 0;
+            while (pos <= list.size()) {
+                const size_t comma = std::min(list.find(',', pos), list.size());
+                const std::string item = list.substr(pos, comma - pos);
+                if (item.empty() || item.find_first_not_of("0123456789") != std::string::npos) return usage_query(output_orders);
+                opt.devices.push_back(atoi(item.c_str()));
+                pos = comma + 1;
+            }
+            break;
+        }
         default: return usage_query(output_orders);
         }
     }
@@ -866,118 +893,24 @@ extern "C" int fmsi_cli_query(int argc, char** argv, int output_orders_i) {
 
     using clock = std::chrono::steady_clock;
     auto t_start = clock::now();
-    fmsi_host_index* host = nullptr;
-    trace_push("fmsi: load index files");
-    const int rc_load = fmsi_host_index_load(opt.index_prefix.c_str(), opt.has_klcp, &host);
-    trace_pop();
-    if (rc_load != 0 || host->ix.n() == 0) {
-        std::cerr << "ERROR: index not correctly loaded. Ensure that you correctly call `fmsi index` before." << std::endl;
-        return usage_query(output_orders);
-    }
-    if (opt.has_klcp != (host->ix.klcp.bits > 0)) {
-        std::cerr << "ERROR: kLCP array was not constructed for the given index. Either construct it again without the `-s` flag or use `query -s` which slows down streaming queries." << std::endl;
-        fmsi_host_index_free(host);
-        return usage_query(output_orders);
-    }
-    int k = opt.k;
-    if (k != 0 && k != host->ix.k) {
-        std::cerr << "ERROR: Mismatch. Provided k (" << k << ") does not match the k of the index (" << host->ix.k << ")." << std::endl;
-        fmsi_host_index_free(host);
-        return usage_query(output_orders);
-    }
-    if (k == 0) k = host->ix.k;
-
-    fmsi_hip_index* dev = nullptr;
-    fmsi_index_view view;
-    fmsi_host_index_view(host, &view);
-    // private accelerators (results unchanged): a prefix table of up to 16 steps (4^t entries of 8 bytes with next-base
-    // signatures; smaller while the table would have more than 4n entries) and, for non-streaming queries,
-    // the two-base-step pair layout
-    // How much of them: end to end this program moves 2-3 G windows/s (reader, copies, formatting), and with a
-    // 14-deep table the device stage -- kernels at about 5 G k-mers/s at human scale plus the copies -- is level with that.
-    // The 16-deep table and the candidate tables (40 G k-mers/s on resident batches: bench.py) take seconds more to
-    // load -- 190 GB of fresh HBM -- and buy little here: measured at human scale (profiles/r01m_e2e_cli_human_scale.json)
-    // 2.8 G windows/s after a 1.2 s load against 3.0 G windows/s after a 6.4 s load.  So they are built when asked for
-    // (--tables full) or when the query file is so large (30 GB; uncompressed bytes ~ windows) that the difference adds up.
-    if (!opt.tables_given && opt.query_fn != "-") {
-        struct stat st;
-        const bool gz = opt.query_fn.size() > 3 && opt.query_fn.compare(opt.query_fn.size() - 3, 3, ".gz") == 0;
-        if (stat(opt.query_fn.c_str(), &st) == 0 && S_ISREG(st.st_mode) &&
-            static_cast<uint64_t>(st.st_size) * (gz ? 4u : 1u) >= 30000000000ull)
-            opt.full_tables = true;
-    }
-    // `full`: presence queries (also -S ones: their answers do not depend on the kLCP array) are answered by the k-mer
-    // dictionary, which needs no prefix table (a small one serves the few searches of its construction); lookup keeps the
-    // 16-deep table
-    const bool want_dict = opt.full_tables && !opt.candidate_tables && !output_orders && k <= 32 && host->ix.n() > static_cast<uint64_t>(k);
-    int t = std::min(k, want_dict ? 12 : (opt.full_tables ? 16 : 14));
-    while (t > 0 && (1ull << (2 * t)) > 4 * host->ix.n()) --t;
-    // ... and, for presence queries, text verification of the intervals that leave the table with one to three rows.
-    // The accelerators are large (34 GB + 52 GB at human scale): when HBM is short -- the GPU shared with other work --
-    // the table shrinks and the verification is left out; only a failure of the index proper is an error.
-    int rc_create = FMSI_HIP_ENOMEM;
-    auto accel_range = std::make_unique<TraceRange>("fmsi: device index + accelerators");
-    for (; t >= 0; t -= 2) {
-        view.prefix_len = std::max(t, 0);
-        rc_create = fmsi_hip_index_create(&view, opt.device, &dev);
-        if (rc_create != FMSI_HIP_ENOMEM || t == 0) break;
-        std::cerr << "WARNING: not enough device memory for a prefix table of depth " << t << ", trying " << std::max(t - 2, 0) << std::endl;
-    }
-    t = std::max(t, 0);
-    bool have_dict = false, rows64 = false;
-    if (rc_create == 0) {
-        fmsi_hip_index_info info;
-        rows64 = fmsi_hip_index_get_info(dev, &info) == 0 && info.rows64 != 0;
-        if (rows64 && (opt.has_klcp || k > 32)) {   // 2^32 rows and more: the plain search only (include/fmsi_hip.h)
-            std::cerr << "ERROR: -S and k > 32 are not available on the GPU path for indexes of 2^32 rows or more." << std::endl;
-            fmsi_hip_index_destroy(dev);
-            fmsi_host_index_free(host);
-            return 1;
-        }
-    }
-    if (rc_create == 0 && want_dict && !rows64) {
-        have_dict = fmsi_hip_index_enable_dict(dev, 0) == 0;
-        if (!have_dict) std::cerr << "WARNING: the k-mer dictionary is off (" << fmsi_hip_last_error() << "); results are unaffected" << std::endl;
-    }
-    if (rc_create != 0 || (!opt.has_klcp && !have_dict && !rows64 && fmsi_hip_index_enable_pair_layout(dev) != 0)) {
-        std::cerr << "ERROR: cannot create the device index: " << fmsi_hip_last_error() << std::endl;
-        if (dev) fmsi_hip_index_destroy(dev);
-        fmsi_host_index_free(host);
-        return 1;
-    }
-    const bool want_verify = !rows64 && opt.candidate_tables && !opt.has_klcp && !output_orders && t > 0 && t < k && k <= 32;
-    if (want_verify && fmsi_hip_index_enable_verify(dev) != 0)
-        std::cerr << "WARNING: text verification is off (" << fmsi_hip_last_error() << "); results are unaffected" << std::endl;
-    accel_range.reset();
-    auto t_loaded = clock::now();
-
-    // OR-mode presence output does not depend on the strand order, so the cheaper schedule is exact;
-    // everything else replays the predictor from both strands unless --fast.
-    const bool need_both = opt.has_klcp || output_orders || opt.mode == Mode::All;
-    const bool strict = need_both && !opt.fast;
-    uint32_t flags = (opt.mode == Mode::All ? FMSI_HIP_MODE_ALL : FMSI_HIP_MODE_OR);
-    if (strict) flags |= FMSI_HIP_STRICT;
-    if (output_orders) flags |= FMSI_HIP_ORDERS;
-
-    int exit_code = 0;
-    double gpu_s = 0, prep_s = 0, replay_s = 0, format_s = 0, write_s = 0, read_s = 0;
-    uint64_t total_windows = 0;
+    if (opt.devices.empty()) opt.devices.push_back(opt.device);
     const unsigned team = opt.threads ? opt.threads : std::min(16u, available_cpus());
-    std::unique_ptr<FastxReader> reader;
-    try {
-        reader = std::make_unique<FastxReader>(opt.query_fn);   // throws std::invalid_argument like OpenFile(), src/parser.h:22
-    } catch (const std::invalid_argument&) {
-        fmsi_hip_index_destroy(dev);
-        fmsi_host_index_free(host);
-        throw;   // uncaught in the reference too: abort, exit status 134
-    }
+
+    // ---- the reader starts first: it needs the query file only, so parsing the first batches overlaps the index load ----------
+    // (only when the file is there: a missing query file must fail where the reference's OpenFile() does -- after the index
+    // checks, uncaught, src/parser.h:22 -- so that case keeps the old order)
+    double gpu_s = 0, prep_s = 0, replay_s = 0, format_s = 0, write_s = 0, read_s = 0;
     BoundedQueue<std::unique_ptr<RawBatch>> raw_q(2);
     BoundedQueue<std::unique_ptr<Prepared>> out_q(2);
     std::exception_ptr reader_err, writer_err;
-
+    std::unique_ptr<FastxReader> reader;
     MappedFile mapped;
-    const bool parallel_read = map_plain_fasta(opt.query_fn, mapped);
-    std::thread reader_thread([&] {
+    bool parallel_read = false;
+    std::thread reader_thread;
+    auto start_reader = [&] {
+        reader = std::make_unique<FastxReader>(opt.query_fn);   // throws std::invalid_argument like OpenFile(), src/parser.h:22
+        parallel_read = map_plain_fasta(opt.query_fn, mapped);
+        reader_thread = std::thread([&] {
         try {
             auto b = std::make_unique<RawBatch>();
             auto t0 = clock::now();
@@ -1076,6 +1009,156 @@ extern "C" int fmsi_cli_query(int argc, char** argv, int output_orders_i) {
         }
         raw_q.close();
     });
+    };
+    auto stop_reader = [&] {   // every way out below: the reader must not stay blocked on a full queue
+        raw_q.abort();
+        if (reader_thread.joinable()) reader_thread.join();
+    };
+    {
+        struct stat st;
+        if (opt.query_fn == "-" || stat(opt.query_fn.c_str(), &st) == 0) start_reader();
+    }
+
+    fmsi_host_index* host = nullptr;
+    trace_push("fmsi: load index files");
+    const int rc_load = fmsi_host_index_load(opt.index_prefix.c_str(), opt.has_klcp, &host);
+    trace_pop();
+    if (rc_load != 0 || host->ix.n() == 0) {
+        std::cerr << "ERROR: index not correctly loaded. Ensure that you correctly call `fmsi index` before." << std::endl;
+        stop_reader();
+        return usage_query(output_orders);
+    }
+    if (opt.has_klcp != (host->ix.klcp.bits > 0)) {
+        std::cerr << "ERROR: kLCP array was not constructed for the given index. Either construct it again without the `-s` flag or use `query -s` which slows down streaming queries." << std::endl;
+        fmsi_host_index_free(host);
+        stop_reader();
+        return usage_query(output_orders);
+    }
+    int k = opt.k;
+    if (k != 0 && k != host->ix.k) {
+        std::cerr << "ERROR: Mismatch. Provided k (" << k << ") does not match the k of the index (" << host->ix.k << ")." << std::endl;
+        fmsi_host_index_free(host);
+        stop_reader();
+        return usage_query(output_orders);
+    }
+    if (k == 0) k = host->ix.k;
+
+    fmsi_index_view view;
+    fmsi_host_index_view(host, &view);
+    // private accelerators (results unchanged).  How much of them: end to end this program moves 2-3 G windows/s (reader, copies,
+    // formatting), and with a 14-deep prefix table the device stage -- kernels at about 5 G k-mers/s at human scale
+    // plus the copies -- is level with that.  The k-mer dictionary (45 G k-mers/s on resident batches: bench.py) takes seconds
+    // more to build, so it is built when asked for (--tables full) or when the query file is so large (30 GB; uncompressed
+    // bytes ~ windows) that the difference adds up.
+    if (!opt.tables_given && opt.query_fn != "-") {
+        struct stat st;
+        const bool gz = opt.query_fn.size() > 3 && opt.query_fn.compare(opt.query_fn.size() - 3, 3, ".gz") == 0;
+        if (stat(opt.query_fn.c_str(), &st) == 0 && S_ISREG(st.st_mode) &&
+            static_cast<uint64_t>(st.st_size) * (gz ? 4u : 1u) >= 30000000000ull)
+            opt.full_tables = true;
+    }
+    // `full`: presence queries (also -S ones: their answers do not depend on the kLCP array) are answered by the k-mer
+    // dictionary, which needs no prefix table (a small one serves the few searches of its construction); lookup keeps the
+    // 16-deep table
+    const bool want_dict = opt.full_tables && !opt.candidate_tables && !output_orders && k <= 32 && host->ix.n() > static_cast<uint64_t>(k);
+    int t = std::min(k, want_dict ? 12 : (opt.full_tables ? 16 : 14));
+    while (t > 0 && (1ull << (2 * t)) > 4 * host->ix.n()) --t;
+
+    // ---- one replicated handle per device (the index is read-only, the batches are independent) ---------------
+    struct DeviceCtx {
+        int device = 0;
+        fmsi_hip_index* dev = nullptr;
+        bool have_dict = false;
+        std::string error;
+    };
+    std::vector<DeviceCtx> ctx(opt.devices.size());
+    for (size_t d = 0; d < ctx.size(); ++d) ctx[d].device = opt.devices[d];
+    bool rows64 = false;
+    auto destroy_all = [&] {
+        for (DeviceCtx& c : ctx)
+            if (c.dev) fmsi_hip_index_destroy(c.dev);
+    };
+    // The accelerators are large: when HBM is short -- the GPU shared with other work -- the table shrinks (first device decides,
+    // the others follow) and the optional ones are left out; only a failure of the index proper is an error.
+    auto setup = [&](DeviceCtx& c, bool first) -> bool {
+        fmsi_index_view v = view;
+        int rc_create = FMSI_HIP_ENOMEM;
+        for (;;) {
+            v.prefix_len = std::max(t, 0);
+            rc_create = fmsi_hip_index_create(&v, c.device, &c.dev);
+            if (rc_create != FMSI_HIP_ENOMEM || t <= 0 || !first) break;
+            std::cerr << "WARNING: not enough device memory for a prefix table of depth " << t << ", trying " << std::max(t - 2, 0) << std::endl;
+            t = std::max(t - 2, 0);
+        }
+        if (rc_create != 0) {
+            c.error = fmsi_hip_last_error();
+            return false;
+        }
+        fmsi_hip_index_info info;
+        const bool wide = fmsi_hip_index_get_info(c.dev, &info) == 0 && info.rows64 != 0;
+        if (first) rows64 = wide;
+        if (wide && (opt.has_klcp || k > 32)) {   // 2^32 rows and more: the plain search only (include/fmsi_hip.h)
+            c.error = "-S and k > 32 are not available on the GPU path for indexes of 2^32 rows or more.";
+            return false;
+        }
+        if (want_dict && !wide) {
+            c.have_dict = fmsi_hip_index_enable_dict(c.dev, 0) == 0;
+            if (!c.have_dict)
+                std::cerr << "WARNING: the k-mer dictionary is off on device " << c.device << " (" << fmsi_hip_last_error() << "); results are unaffected" << std::endl;
+        }
+        if (!opt.has_klcp && !c.have_dict && !wide && fmsi_hip_index_enable_pair_layout(c.dev) != 0) {
+            c.error = fmsi_hip_last_error();
+            return false;
+        }
+        const bool want_verify = !wide && opt.candidate_tables && !opt.has_klcp && !output_orders && t > 0 && t < k && k <= 32;
+        if (want_verify && fmsi_hip_index_enable_verify(c.dev) != 0)
+            std::cerr << "WARNING: text verification is off (" << fmsi_hip_last_error() << "); results are unaffected" << std::endl;
+        return true;
+    };
+    {
+        TraceRange accel_range("fmsi: device index + accelerators");
+        bool ok = setup(ctx[0], true);
+        if (ok && ctx.size() > 1) {   // the other devices side by side
+            std::vector<std::thread> pool;
+            std::vector<char> oks(ctx.size(), 1);
+            for (size_t d = 1; d < ctx.size(); ++d) pool.emplace_back([&, d] { oks[d] = setup(ctx[d], false) ? 1 : 0; });
+            for (std::thread& th : pool) th.join();
+            ok = std::find(oks.begin(), oks.end(), 0) == oks.end();
+        }
+        if (!ok) {
+            for (const DeviceCtx& c : ctx)
+                if (!c.error.empty()) {
+                    if (c.error.rfind("-S and k > 32", 0) == 0) std::cerr << "ERROR: " << c.error << std::endl;
+                    else std::cerr << "ERROR: cannot create the device index: " << c.error << std::endl;
+                    break;
+                }
+            destroy_all();
+            fmsi_host_index_free(host);
+            stop_reader();
+            return 1;
+        }
+    }
+    auto t_loaded = clock::now();
+
+    // OR-mode presence output does not depend on the strand order, so the cheaper schedule is exact;
+    // everything else replays the predictor from both strands unless --fast.
+    const bool need_both = opt.has_klcp || output_orders || opt.mode == Mode::All;
+    const bool strict = need_both && !opt.fast;
+    uint32_t flags = (opt.mode == Mode::All ? FMSI_HIP_MODE_ALL : FMSI_HIP_MODE_OR);
+    if (strict) flags |= FMSI_HIP_STRICT;
+    if (output_orders) flags |= FMSI_HIP_ORDERS;
+
+    int exit_code = 0;
+    uint64_t total_windows = 0;
+    if (!reader_thread.joinable()) {
+        try {
+            start_reader();
+        } catch (const std::invalid_argument&) {
+            destroy_all();
+            fmsi_host_index_free(host);
+            throw;   // uncaught in the reference too: abort, exit status 134
+        }
+    }
 
     std::thread writer_thread([&] {
         try {
@@ -1107,59 +1190,115 @@ extern "C" int fmsi_cli_query(int argc, char** argv, int output_orders_i) {
         }
     });
 
+    // ---- device workers: one per handle.  A worker takes the next raw batch (its number = its place in the output), packs it,
+    // runs it on its device and files it under that number; this thread takes the batches in order for the sequential part -- the
+    // replay of the strand predictor -- and hands them to the writer.  With one device this still overlaps a batch's packing and
+    // device time with the previous batch's replay.
+    std::mutex done_m;
+    std::condition_variable done_cv;
+    std::map<uint64_t, std::unique_ptr<Prepared>> done;   // finished batches waiting for their turn
+    uint64_t next_seq = 0;                                // the batch this thread hands on next
+    unsigned workers_left = static_cast<unsigned>(ctx.size());
+    bool stop = false;
+    std::exception_ptr worker_err;
+    std::mutex stats_m;
+    const unsigned worker_team = std::max(1u, team / static_cast<unsigned>(ctx.size()));
+    std::vector<std::thread> workers;
+    for (DeviceCtx& c : ctx)
+        workers.emplace_back([&, cp = &c] {
+            try {
+                std::unique_ptr<RawBatch> raw;
+                uint64_t seq = 0;
+                while (raw_q.pop_seq(raw, seq)) {
+                    auto P = std::make_unique<Prepared>();
+                    P->raw = std::move(*raw);
+                    raw.reset();
+                    auto t0 = clock::now();
+                    trace_push("fmsi: pack batch");
+                    prepare_batch(*P, k, worker_team);
+                    trace_pop();
+                    auto t1 = clock::now();
+                    const uint64_t nw = P->windows;
+                    if (output_orders) P->orders.resize(nw * (strict ? 2 : 1));
+                    else P->bytes.resize(nw);
+                    if (nw) {
+                        TraceRange device_range("fmsi: device (copy in, kernels, copy out)");
+                        void* dst = output_orders ? static_cast<void*>(P->orders.data()) : static_cast<void*>(P->bytes.data());
+                        if (opt.has_klcp && !cp->have_dict)   // -S: kLCP streaming kernel (query_kmers_streaming, src/fms_index.h:181-254)
+                            check(fmsi_hip_query_stream(cp->dev, P->packed.data(), P->bases, P->run_start.data(), P->run_windows.data(),
+                                                        P->run_start.size(), nw, k, flags, dst, nullptr, nullptr),
+                                  "fmsi_hip_query_stream");
+                        else
+                            check(fmsi_hip_query_runs(cp->dev, P->packed.data(), P->bases, P->run_start.data(), P->run_windows.data(),
+                                                      P->run_start.size(), nw, k, flags, dst, nullptr, nullptr),
+                                  "fmsi_hip_query_runs");
+                        check(fmsi_hip_sync(cp->dev, nullptr), "fmsi_hip_sync");
+                    }
+                    auto t2 = clock::now();
+                    PinVec<uint64_t>().swap(P->packed);
+                    {
+                        std::lock_guard<std::mutex> lk(stats_m);
+                        prep_s += std::chrono::duration<double>(t1 - t0).count();
+                        gpu_s += std::chrono::duration<double>(t2 - t1).count();
+                    }
+                    std::unique_lock<std::mutex> lk(done_m);
+                    // (a worker runs at most one batch ahead of the hand-over: the map holds no more batches than there are workers)
+                    done_cv.wait(lk, [&] { return stop || seq < next_seq + 2 * ctx.size(); });
+                    if (stop) break;
+                    done[seq] = std::move(P);
+                    done_cv.notify_all();
+                }
+            } catch (...) {
+                std::lock_guard<std::mutex> lk(done_m);
+                if (!worker_err) worker_err = std::current_exception();
+                stop = true;
+            }
+            std::lock_guard<std::mutex> lk(done_m);
+            --workers_left;
+            done_cv.notify_all();
+        });
+
     try {
         StrandPredictor predictor;
-        std::unique_ptr<RawBatch> raw;
-        while (raw_q.pop(raw)) {
-            auto P = std::make_unique<Prepared>();
-            P->raw = std::move(*raw);
-            raw.reset();
-            auto t0 = clock::now();
-            trace_push("fmsi: pack batch");
-            prepare_batch(*P, k, team);
-            trace_pop();
-            auto t1 = clock::now();
-            const uint64_t nw = P->windows;
-            if (output_orders) P->orders.resize(nw * (strict ? 2 : 1));
-            else P->bytes.resize(nw);
-            if (nw) {
-                TraceRange device_range("fmsi: device (copy in, kernels, copy out)");
-                void* dst = output_orders ? static_cast<void*>(P->orders.data()) : static_cast<void*>(P->bytes.data());
-                if (opt.has_klcp && !have_dict)   // -S: kLCP streaming kernel (query_kmers_streaming, src/fms_index.h:181-254)
-                    check(fmsi_hip_query_stream(dev, P->packed.data(), P->bases, P->run_start.data(), P->run_windows.data(),
-                                                P->run_start.size(), nw, k, flags, dst, nullptr, nullptr),
-                          "fmsi_hip_query_stream");
-                else
-                    check(fmsi_hip_query_runs(dev, P->packed.data(), P->bases, P->run_start.data(), P->run_windows.data(),
-                                              P->run_start.size(), nw, k, flags, dst, nullptr, nullptr),
-                          "fmsi_hip_query_runs");
-                check(fmsi_hip_sync(dev, nullptr), "fmsi_hip_sync");
+        for (;;) {
+            std::unique_ptr<Prepared> P;
+            {
+                std::unique_lock<std::mutex> lk(done_m);
+                done_cv.wait(lk, [&] { return stop || done.count(next_seq) || workers_left == 0; });
+                if (stop) break;
+                auto it = done.find(next_seq);
+                if (it == done.end()) break;   // all workers are gone and the next batch never came: end of input
+                P = std::move(it->second);
+                done.erase(it);
+                ++next_seq;
+                done_cv.notify_all();
             }
             auto t2 = clock::now();
-            PinVec<uint64_t>().swap(P->packed);
             if (strict) {
                 TraceRange replay_range("fmsi: predictor replay");
                 replay_batch(*P, predictor, opt.mode, output_orders, opt.has_klcp, k, team);
             }
-            auto t3 = clock::now();
-            prep_s += std::chrono::duration<double>(t1 - t0).count();
-            gpu_s += std::chrono::duration<double>(t2 - t1).count();
-            replay_s += std::chrono::duration<double>(t3 - t2).count();
-            total_windows += nw;
+            replay_s += std::chrono::duration<double>(clock::now() - t2).count();
+            total_windows += P->windows;
             if (!out_q.push(std::move(P))) break;   // the writer failed
         }
     } catch (const std::exception& e) {
         std::cerr << "ERROR: " << e.what() << std::endl;
         exit_code = 1;
     }
-    // whatever ended the loop -- end of input, a device error, a writer that failed (ENOSPC, EPIPE) -- the reader must not
-    // stay blocked in raw_q.push() with batches nobody will take: after a normal end the queue is closed and empty and
-    // this is a no-op, otherwise it wakes the reader so that the join below returns
+    // whatever ended the loop -- end of input, a device error, a writer that failed (ENOSPC, EPIPE) -- nobody may stay blocked:
+    // the reader in raw_q.push(), a worker in raw_q.pop_seq() or waiting for its turn to file a batch
+    {
+        std::lock_guard<std::mutex> lk(done_m);
+        stop = true;
+        done_cv.notify_all();
+    }
     raw_q.abort();
     out_q.close();
+    for (std::thread& th : workers) th.join();
     reader_thread.join();
     writer_thread.join();
-    for (const std::exception_ptr& ep : {reader_err, writer_err}) {
+    for (const std::exception_ptr& ep : {reader_err, writer_err, worker_err}) {
         if (!ep) continue;
         try {
             std::rethrow_exception(ep);
@@ -1174,11 +1313,11 @@ extern "C" int fmsi_cli_query(int argc, char** argv, int output_orders_i) {
         fprintf(stderr,
                 "{\"windows\": %llu, \"total_seconds\": %.6f, \"load_seconds\": %.6f, \"device_seconds\": %.6f, \"read_seconds\": %.6f, "
                 "\"prepare_seconds\": %.6f, \"replay_seconds\": %.6f, \"format_seconds\": %.6f, \"write_seconds\": %.6f, \"threads\": %u, "
-                "\"strict\": %s}\n",
+                "\"devices\": %zu, \"strict\": %s}\n",
                 static_cast<unsigned long long>(total_windows), total, load, gpu_s, read_s, prep_s, replay_s, format_s, write_s, team,
-                strict ? "true" : "false");
+                ctx.size(), strict ? "true" : "false");
     }
-    fmsi_hip_index_destroy(dev);
+    destroy_all();
     fmsi_host_index_free(host);
     return exit_code;
 }

@@ -599,3 +599,29 @@ def test_cli_exits_when_stdout_fails(fm, tmp_path):
     # and the same input to a healthy stdout still works
     rc, out, _ = fm.run_cli(["query", "-q", str(q), "--batch", "1024", index_prefix("sars_k31")])
     assert rc == 0 and out.count(b"\n") == 4000
+
+
+@pytest.mark.parametrize("mode", ["or", "all", "all_S", "lookup"])
+def test_cli_with_several_device_handles(fm, tmp_path, mode):
+    """--devices a,b,...: one replicated handle per device, batches dealt out to worker threads, output in input order and the
+    strand predictor replayed across the batches as if there were one device.  The GPU box has one GPU, so the list names it twice
+    (two handles, two workers -- the same code path); many small batches, so that batches really finish out of order."""
+    name, k = "mixed_k11", 11      # non-max-ones mask: -O output depends on the predictor's state across batches
+    ms = "".join(l.strip() for l in open(GOLDEN / "mixed.fa") if not l.startswith(">"))
+    rng = random.Random(3)
+    q = tmp_path / "q.fa"
+    q.write_bytes(b"".join(messy_fasta(ms, rng) for _ in range(12)))
+    args = [*MODES[mode][0], "-k", str(k), "-q", str(q)]
+    rc1, out1, err1 = fm.run_cli([*args, "--batch", "2048", index_prefix(name)])
+    assert rc1 == 0, err1.decode()
+    for devices in ("0,0", "0,0,0"):
+        rc, out, err = fm.run_cli([*args, "--batch", "2048", "--devices", devices, "--stats", index_prefix(name)])
+        assert rc == 0, err.decode()
+        assert out == out1
+        assert f'"devices": {len(devices.split(","))}'.encode() in err
+    # and the reference itself says the same (the oracle's record loop over the same file)
+    orc = oracle_py.Oracle.load(index_prefix(name), use_klcp=MODES[mode][2])
+    want, _ = orc.query_file(str(q), k, has_klcp=MODES[mode][2], mode=MODES[mode][3], orders=MODES[mode][1], cap=len(out1) + 4096)
+    assert out1.decode() == want
+    rc, out, err = fm.run_cli([*args, "--devices", "0,x", index_prefix(name)])
+    assert rc == 1 and out == b""
