@@ -83,7 +83,10 @@ __device__ __forceinline__ uint4 load16_nt(const uint4* p) {
 template <bool COUNT, bool RUNS>
 __global__ __launch_bounds__(256) void dict_lookup_kernel(DictIndex dx, const uint64_t* __restrict__ kmers, uint64_t n_windows, int k, uint32_t flags,
                                                           uint32_t chunk, uint8_t* __restrict__ out, unsigned long long* __restrict__ counters,
-                                                          const uint64_t* __restrict__ run_start, const uint64_t* __restrict__ run_off, uint64_t n_runs) {
+                                                          const uint64_t* __restrict__ run_start, const uint64_t* __restrict__ run_off, uint64_t n_runs,
+                                                          uint64_t u_start0, uint64_t u_stride, uint64_t u_wpr) {
+    // (RUNS with u_wpr != 0: uniform runs -- run r is the u_wpr windows from base u_start0 + r * u_stride, reads of one length laid out
+    // back to back -- and there is no run table to fetch or to search)
     constexpr uint32_t kMaxChunk = 4096u, kQueue = 128u;
     __shared__ uint64_t s_qh[4][kQueue];     // k-mers whose level-0 bucket had overflowed: their hash ...
     __shared__ uint32_t s_qi[4][kQueue];     // ... and index in the chunk | orientation flags
@@ -112,11 +115,23 @@ __global__ __launch_bounds__(256) void dict_lookup_kernel(DictIndex dx, const ui
         }
         return lo;
     };
+    auto enter_run = [&](uint64_t r) {   // run_end = first window behind run r, run_delta = its first base - its first window
+        run = r;
+        if (u_wpr) {
+            run_end = (r + 1u) * u_wpr;
+            run_delta = u_start0 + r * (u_stride - u_wpr);
+        } else {
+            run_end = run_off[r + 1];
+            run_delta = run_start[r] - run_off[r];
+        }
+    };
     if (RUNS && len) {
-        run = find_run(0, n_runs, start);
-        run_last = find_run(run, n_runs, start + len - 1u);
-        run_end = run_off[run + 1];
-        run_delta = run_start[run] - run_off[run];
+        if (u_wpr) {
+            enter_run(start / u_wpr);
+        } else {
+            run_last = find_run(0, n_runs, start + len - 1u);
+            enter_run(find_run(0, run_last + 1, start));
+        }
     }
 
     // 64 hashes, one per lane (`active` lanes only), against level `lv`: eight rounds of eight buckets.  Returns at the OWNING lane
@@ -197,11 +212,7 @@ __global__ __launch_bounds__(256) void dict_lookup_kernel(DictIndex dx, const ui
         uint64_t f = 0ull;
         if (RUNS) {
             if (valid) {
-                if (q >= run_end) {
-                    run = find_run(run + 1, run_last + 1, q);
-                    run_end = run_off[run + 1];
-                    run_delta = run_start[run] - run_off[run];
-                }
+                if (q >= run_end) enter_run(u_wpr ? q / u_wpr : find_run(run + 1, run_last + 1, q));
                 f = window_kmer(kmers, q + run_delta, k);
             }
         } else if (valid) {
@@ -463,12 +474,13 @@ int fill_level(const uint64_t* d_ukeys, const uint8_t* d_ucodes, uint64_t count,
 
 template <bool COUNT, bool RUNS>
 void launch_dict_t(const fmsi_hip_index* idx, const uint64_t* d_in, uint64_t n, int k, uint32_t flags, uint8_t* o8, unsigned long long* d_counters, hipStream_t s,
-                   const uint64_t* d_runs, uint64_t n_runs) {
+                   const uint64_t* d_runs, uint64_t n_runs, const uint64_t* uniform) {
     uint64_t chunk = n / (256ull * 4 * 2);
     chunk = std::min<uint64_t>(std::max<uint64_t>(chunk, 128), 4096) & ~127ull;
     const uint64_t waves = (n + chunk - 1) / chunk;
     hipLaunchKernelGGL((dict_lookup_kernel<COUNT, RUNS>), dim3(static_cast<uint32_t>((waves + 3) / 4)), dim3(256), 0, s, idx->dict, d_in, n, k, flags,
-                       static_cast<uint32_t>(chunk), o8, d_counters, d_runs, d_runs + n_runs, n_runs);
+                       static_cast<uint32_t>(chunk), o8, d_counters, d_runs, d_runs + n_runs, n_runs, uniform ? uniform[0] : 0ull, uniform ? uniform[1] : 0ull,
+                       uniform ? uniform[2] : 0ull);
 }
 
 }  // namespace
@@ -482,18 +494,31 @@ bool dict_applies(const fmsi_hip_index* idx, int k, uint32_t flags) {
 int launch_dict_query(fmsi_hip_index* idx, const uint64_t* d_in, uint64_t n, int k, uint32_t flags, uint8_t* o8, unsigned long long* d_counters, hipStream_t s,
                       const uint64_t* h_runs, uint64_t n_runs) {
     const uint64_t* d_runs = nullptr;
-    if (h_runs) {   // the run table: n_runs starts, n_runs + 1 offsets (a slot of the handle's page-locked ring)
+    // uniform runs (reads of one length, back to back or at one stride): three numbers instead of a table on the device
+    uint64_t uniform[3] = {0, 0, 0};
+    bool is_uniform = false;
+    if (h_runs && n_runs >= 1) {
+        const uint64_t wpr = h_runs[n_runs + 1] - h_runs[n_runs], stride = n_runs > 1 ? h_runs[1] - h_runs[0] : wpr;
+        is_uniform = wpr > 0 && stride >= wpr;
+        for (uint64_t r = 1; r < n_runs && is_uniform; ++r)
+            is_uniform = h_runs[n_runs + r + 1] - h_runs[n_runs + r] == wpr && h_runs[r] - h_runs[r - 1] == stride;
+        uniform[0] = h_runs[0];
+        uniform[1] = stride;
+        uniform[2] = wpr;
+    }
+    if (h_runs && !is_uniform) {   // the run table: n_runs starts, n_runs + 1 offsets (a slot of the handle's page-locked ring)
         int rc = ensure_cap(&idx->d_tasks, &idx->d_tasks_cap, (2 * n_runs + 1) * 8);
         if (rc) return rc;
         FMSI_HIP_TRY(hipMemcpyAsync(idx->d_tasks, h_runs, (2 * n_runs + 1) * 8, hipMemcpyHostToDevice, s));
         d_runs = static_cast<const uint64_t*>(idx->d_tasks);
     }
+    const uint64_t* u = is_uniform ? uniform : nullptr;
     if (h_runs) {
-        if (d_counters) launch_dict_t<true, true>(idx, d_in, n, k, flags, o8, d_counters, s, d_runs, n_runs);
-        else launch_dict_t<false, true>(idx, d_in, n, k, flags, o8, d_counters, s, d_runs, n_runs);
+        if (d_counters) launch_dict_t<true, true>(idx, d_in, n, k, flags, o8, d_counters, s, d_runs, n_runs, u);
+        else launch_dict_t<false, true>(idx, d_in, n, k, flags, o8, d_counters, s, d_runs, n_runs, u);
     } else {
-        if (d_counters) launch_dict_t<true, false>(idx, d_in, n, k, flags, o8, d_counters, s, nullptr, 0);
-        else launch_dict_t<false, false>(idx, d_in, n, k, flags, o8, d_counters, s, nullptr, 0);
+        if (d_counters) launch_dict_t<true, false>(idx, d_in, n, k, flags, o8, d_counters, s, nullptr, 0, nullptr);
+        else launch_dict_t<false, false>(idx, d_in, n, k, flags, o8, d_counters, s, nullptr, 0, nullptr);
     }
     FMSI_HIP_TRY(hipGetLastError());
     return 0;
