@@ -492,30 +492,18 @@ bool dict_applies(const fmsi_hip_index* idx, int k, uint32_t flags) {
 }
 
 int launch_dict_query(fmsi_hip_index* idx, const uint64_t* d_in, uint64_t n, int k, uint32_t flags, uint8_t* o8, unsigned long long* d_counters, hipStream_t s,
-                      const uint64_t* h_runs, uint64_t n_runs) {
+                      const uint64_t* h_runs, uint64_t n_runs, const uint64_t* uniform_runs) {
     const uint64_t* d_runs = nullptr;
-    // uniform runs (reads of one length, back to back or at one stride): three numbers instead of a table on the device
-    uint64_t uniform[3] = {0, 0, 0};
-    bool is_uniform = false;
-    if (h_runs && n_runs >= 1) {
-        const uint64_t wpr = h_runs[n_runs + 1] - h_runs[n_runs], stride = n_runs > 1 ? h_runs[1] - h_runs[0] : wpr;
-        is_uniform = wpr > 0 && stride >= wpr;
-        for (uint64_t r = 1; r < n_runs && is_uniform; ++r)
-            is_uniform = h_runs[n_runs + r + 1] - h_runs[n_runs + r] == wpr && h_runs[r] - h_runs[r - 1] == stride;
-        uniform[0] = h_runs[0];
-        uniform[1] = stride;
-        uniform[2] = wpr;
-    }
-    if (h_runs && !is_uniform) {   // the run table: n_runs starts, n_runs + 1 offsets (a slot of the handle's page-locked ring)
+    const bool runs = h_runs != nullptr || uniform_runs != nullptr;
+    if (h_runs && !uniform_runs) {   // the run table: n_runs starts, n_runs + 1 offsets (a slot of the handle's page-locked ring)
         int rc = ensure_cap(&idx->d_tasks, &idx->d_tasks_cap, (2 * n_runs + 1) * 8);
         if (rc) return rc;
         FMSI_HIP_TRY(hipMemcpyAsync(idx->d_tasks, h_runs, (2 * n_runs + 1) * 8, hipMemcpyHostToDevice, s));
         d_runs = static_cast<const uint64_t*>(idx->d_tasks);
     }
-    const uint64_t* u = is_uniform ? uniform : nullptr;
-    if (h_runs) {
-        if (d_counters) launch_dict_t<true, true>(idx, d_in, n, k, flags, o8, d_counters, s, d_runs, n_runs, u);
-        else launch_dict_t<false, true>(idx, d_in, n, k, flags, o8, d_counters, s, d_runs, n_runs, u);
+    if (runs) {
+        if (d_counters) launch_dict_t<true, true>(idx, d_in, n, k, flags, o8, d_counters, s, d_runs, n_runs, uniform_runs);
+        else launch_dict_t<false, true>(idx, d_in, n, k, flags, o8, d_counters, s, d_runs, n_runs, uniform_runs);
     } else {
         if (d_counters) launch_dict_t<true, false>(idx, d_in, n, k, flags, o8, d_counters, s, nullptr, 0, nullptr);
         else launch_dict_t<false, false>(idx, d_in, n, k, flags, o8, d_counters, s, nullptr, 0, nullptr);

@@ -944,27 +944,41 @@ int fmsi_hip_query_runs(fmsi_hip_index* idx, const uint64_t* packed_seq, uint64_
     }
     FMSI_HIP_ON_DEVICE(idx->device);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    // [0, n_runs): run starts, [n_runs, 2 n_runs + 1): exclusive prefix sums of the run lengths -- in a page-locked slot
-    // of the handle's ring, so that nothing has to wait for the copy (the call stays asynchronous on `stream`)
-    void* meta_host = nullptr;
-    unsigned meta_slot = 0;
-    if ((rc = meta_stage(idx, (2 * n_runs + 1) * 8, &meta_host, &meta_slot))) return rc;
-    uint64_t* meta = static_cast<uint64_t*>(meta_host);
-    const size_t meta_words = 2 * n_runs + 1;
+    // the runs are checked first; UNIFORM runs -- equal lengths at one stride: reads of one length laid out back to back -- need no
+    // table on the device (three numbers instead), which the dictionary's kernel takes as such
     uint64_t total = 0;
+    const uint64_t wpr = run_windows[0], stride = n_runs > 1 ? run_start[1] - run_start[0] : wpr;
+    bool uniform = n_runs == 1 || (run_start[1] > run_start[0] && stride >= wpr);
     for (uint64_t r = 0; r < n_runs; ++r) {
         if (run_windows[r] == 0 || run_start[r] + run_windows[r] + static_cast<uint64_t>(k) - 1 > seq_bases) {
             set_last_error("an empty run, or a run of windows that extends past the end of the sequence");
             return FMSI_HIP_EINVAL;
         }
-        meta[r] = run_start[r];
-        meta[n_runs + r] = total;
+        if (uniform && (run_windows[r] != wpr || (r > 0 && run_start[r] - run_start[r - 1] != stride))) uniform = false;
         total += run_windows[r];
     }
-    meta[2 * n_runs] = total;
     if (total != n_windows) {
         set_last_error("n_windows does not equal the sum of run_windows");
         return FMSI_HIP_EINVAL;
+    }
+    const uint64_t uniform_runs[3] = {run_start[0], stride, wpr};
+    const bool table_free = uniform && dict_applies(idx, k, flags) && n_windows <= (1ull << 38);
+    // otherwise: [0, n_runs): run starts, [n_runs, 2 n_runs + 1): exclusive prefix sums of the run lengths -- in a page-locked slot
+    // of the handle's ring, so that nothing has to wait for the copy (the call stays asynchronous on `stream`)
+    void* meta_host = nullptr;
+    unsigned meta_slot = 0;
+    uint64_t* meta = nullptr;
+    const size_t meta_words = 2 * n_runs + 1;
+    if (!table_free) {
+        if ((rc = meta_stage(idx, meta_words * 8, &meta_host, &meta_slot))) return rc;
+        meta = static_cast<uint64_t*>(meta_host);
+        uint64_t off = 0;
+        for (uint64_t r = 0; r < n_runs; ++r) {
+            meta[r] = run_start[r];
+            meta[n_runs + r] = off;
+            off += run_windows[r];
+        }
+        meta[2 * n_runs] = off;
     }
     const size_t out_bytes = out_buffer_bytes(n_windows, flags);
     const size_t seq_bytes = (seq_bases / 32 + 2) * 8;
@@ -988,8 +1002,9 @@ int fmsi_hip_query_runs(fmsi_hip_index* idx, const uint64_t* packed_seq, uint64_
         // the dictionary's lookup kernel cuts the windows itself, too
         size_t slot;
         if ((rc = prof_begin(idx, s, &slot))) return rc;
-        if ((rc = launch_dict_query(idx, d_seq, n_windows, k, flags, static_cast<uint8_t*>(d_out), d_cnt, s, meta, n_runs))) return rc;
-        if ((rc = meta_commit(idx, meta_slot, s))) return rc;
+        if ((rc = launch_dict_query(idx, d_seq, n_windows, k, flags, static_cast<uint8_t*>(d_out), d_cnt, s, meta, n_runs, table_free ? uniform_runs : nullptr)))
+            return rc;
+        if (!table_free && (rc = meta_commit(idx, meta_slot, s))) return rc;
         if ((rc = prof_end(idx, s, slot))) return rc;
         if (!dev_ptrs) {
             if (out_bytes) FMSI_HIP_TRY(hipMemcpyAsync(out, idx->d_out, out_bytes, hipMemcpyDeviceToHost, s));

@@ -177,8 +177,9 @@ int launch_wide_query(fmsi_hip_index* idx, const uint64_t* d_kmers, uint64_t n, 
 // the k-mer dictionary answers this call (presence modes, the index's k, no NO_PREFIX_TABLE) -- and its launch; h_runs as for
 // launch_phased_query.  The lookup kernel packs FMSI_HIP_OUT_BITS output itself.
 bool dict_applies(const fmsi_hip_index* idx, int k, uint32_t flags);
+// (uniform_runs != nullptr: {first base, stride, windows per run} of uniform runs -- no table, h_runs is not read)
 int launch_dict_query(fmsi_hip_index* idx, const uint64_t* d_in, uint64_t n, int k, uint32_t flags, uint8_t* o8, unsigned long long* d_counters, hipStream_t s,
-                      const uint64_t* h_runs = nullptr, uint64_t n_runs = 0);
+                      const uint64_t* h_runs = nullptr, uint64_t n_runs = 0, const uint64_t* uniform_runs = nullptr);
 
 // FMSI_HIP_OUT_BITS: does launch_phased_query write the packed output itself for this (handle, k, flags)?  (otherwise the
 // caller has the kernels write bytes into a scratch buffer and packs them with launch_pack_results)
