@@ -476,11 +476,13 @@ def main():
                     "lf_path": lf_path}
         info = index.info
         if stream_mode:
-            wl = (f"synthetic max-ones masked superstring n={n} (human-genome scale), reads of {args.read_len} bases (50% from the "
+            scale = "human-genome scale" if n >= 2e9 else ("pangenome scale" if n >= 5e8 else ("E. coli scale" if n <= 1e7 else "synthetic scale"))
+            wl = (f"synthetic max-ones masked superstring n={n} ({scale}), reads of {args.read_len} bases (50% from the "
                   f"superstring, half of those reverse-complemented, {args.subst_ppm} substitutions per million), every {k}-mer window, "
                   f"fmsi query -S -O semantics (kLCP streaming)")
         else:
-            wl = (f"synthetic max-ones masked superstring n={n} (human-genome scale), isolated random {k}-mers 50% present, "
+            scale = "human-genome scale" if n >= 2e9 else ("pangenome scale" if n >= 5e8 else ("E. coli scale" if n <= 1e7 else "synthetic scale"))
+            wl = (f"synthetic max-ones masked superstring n={n} ({scale}), isolated random {k}-mers 50% present, "
                   f"fmsi query -O semantics")
         if args.repeat_permille:
             wl += (f"; {args.repeat_permille / 10:.0f}% of the superstring's 2048-base segments are copies of {args.repeat_families} repeat "
