@@ -30,9 +30,12 @@ MODES = {
     "all_S": ["query", "-S", "-O"],
     "all_S_fast": ["query", "-S", "-O", "--fast"],
     "lookup": ["lookup"],
-    # the same with every device-side accelerator (--tables full: 16-deep table + candidate tables), for comparison
+    # the same with the k-mer dictionary (--tables full), for comparison; and two handles on the one device (--devices 0,0)
     "or_full": ["query", "--tables", "full"],
     "all_full": ["query", "-O", "--tables", "full"],
+    "all_S_full": ["query", "-S", "-O", "--tables", "full"],
+    "or_2dev": ["query", "--devices", "0,0"],
+    "all_2dev": ["query", "-O", "--devices", "0,0"],
 }
 
 
@@ -129,7 +132,7 @@ def main() -> None:
             entry["windows_per_s_after_load"] = round(w / max(1e-9, entry["total_seconds"] - entry["load_seconds"]))
         entry["output_bytes"] = outp.stat().st_size
         # reference on the sample: identical bytes?
-        ref_args = [x for x in args if x not in ("--fast", "--tables", "full")]
+        ref_args = [x for x in args if x not in ("--fast", "--tables", "full", "--devices", "0,0")]
         if ref_cli.exists() and a.ref_reads:
             t0 = time.time()
             r = subprocess.run([str(ref_cli), *ref_args, "-k", str(a.k), "-q", str(sample), prefix], capture_output=True)
