@@ -94,6 +94,10 @@ def parse_args():
                          "default: FMSI_HIP_OUT_BITS -- bit-packed results, each step's words copied to page-locked host memory (double "
                          "buffered) and, for N > 1, gathered to rank 0 over RCCL first, all inside the timed region")
     ap.add_argument("--no-lf-leg", action="store_true", help="skip the table-less LF-walk legs (roofline.lf_path)")
+    ap.add_argument("--no-pmc", action="store_true",
+                    help="do not measure roofline.traffic in this run (two child runs of this script under rocprofv3 --pmc, FETCH_SIZE and "
+                         "WRITE_SIZE in separate passes); the figure then comes from the committed profiles/*traffic*.json, if one matches")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)   # the child's mode: build, three launches, nothing printed
     ap.add_argument("--lf-steps", type=int, default=3, help="timed launches per LF-walk leg")
     ap.add_argument("--stream-via", choices=["auto", "klcp", "runs"], default="auto",
                     help="stream workload: klcp = fmsi_hip_query_stream (the kLCP kernel, what -S means in the reference); runs = the same "
@@ -125,6 +129,49 @@ def pmc_traffic(args, n, batch, k):
                 c.get("stream_via", "klcp") == (args.stream_via if args.workload == "stream" else "klcp"):
             best = t
     return None if best is None else best["hbm_bytes_per_launch"]
+
+
+def measure_traffic(args, n, batch, k):
+    """HBM bytes per launch of the dictionary's lookup kernel, measured NOW: this script is run twice more as a child under
+    `rocprofv3 --pmc` -- FETCH_SIZE and WRITE_SIZE cannot share a pass (MI355X_MICROARCH.md, PMC slots) and counters are collected in
+    runs of their own -- with the same index, queries and flags (three launches), and the per-dispatch averages of
+    dict_lookup_kernel<false, ...> are corrected as that guide prescribes: gfx950 tallies a 128-byte request at 64 B in FETCH_SIZE and
+    every read of this kernel is one (buckets by eight lanes x 16 B, k-mers as 512-B wave reads), so fetched = 2 x raw; WRITE_SIZE is
+    exact.  Returns (bytes per launch, description) or (None, reason)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    prof = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if prof is None:
+        return None, "rocprofv3 not found"
+    child = [sys.executable, str(REPO / "bench.py"), "--pmc-child", "--steps", "3", "--n", repr(float(n)), "--batch", repr(float(batch)), "--k", str(k),
+             "--seed", str(args.seed), "--query-seed", str(args.query_seed), "--mode", args.mode, "--accel", "dict", "--workload", args.workload,
+             "--read-len", str(args.read_len), "--subst-ppm", str(args.subst_ppm)] + (["--dict-sparse"] if args.dict_sparse else []) + \
+            (["--repeat-permille", str(args.repeat_permille), "--repeat-families", str(args.repeat_families),
+              "--repeat-divergence-permille", str(args.repeat_divergence_permille)] if args.repeat_permille else [])
+    got = {}
+    env = dict(os.environ, TMPDIR="/tmp")
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        with tempfile.TemporaryDirectory(dir="/tmp") as d:
+            try:
+                res = subprocess.run([prof, "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "run", "--"] + child, cwd="/tmp", env=env,
+                                     stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=300)
+            except (OSError, subprocess.TimeoutExpired) as e:
+                return None, f"rocprofv3 --pmc {counter}: {e!r}"
+            per = {}
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                with open(f, newline="") as fh:
+                    for r in csv.DictReader(fh):
+                        if "dict_lookup_kernel<false" in r["Kernel_Name"] and r["Counter_Name"] == counter:
+                            per[r["Dispatch_Id"]] = per.get(r["Dispatch_Id"], 0.0) + float(r["Counter_Value"])
+            if res.returncode != 0 or not per:
+                return None, f"rocprofv3 --pmc {counter}: rc {res.returncode}, {len(per)} dispatches ({res.stderr.decode(errors='replace')[-200:]})"
+            got[counter] = sum(per.values()) / len(per) * 1024.0   # the counters are in KiB
+    return 2.0 * got["FETCH_SIZE"] + got["WRITE_SIZE"], (
+        f"measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (a child run each, 3 launches of dict_lookup_kernel<false,...>), "
+        f"2 x raw FETCH_SIZE {got['FETCH_SIZE'] / 1e9:.3f} GB (gfx950 tallies a 128-B request at 64 B) + WRITE_SIZE {got['WRITE_SIZE'] / 1e9:.3f} GB")
 
 
 def main():
@@ -272,6 +319,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if args.pmc_child:   # under rocprofv3 --pmc: the timed kernel's launches and nothing else
+        make_input(0, bufs[0])
+        for _ in range(args.steps):
+            launch(bufs[0], d_bits[0] if bits else d_out, extra=out_flag)
+        torch.cuda.synchronize()
+        os.close(json_fd)
+        return
     # ---- warmup, plus counted launches that supply the algorithmic byte counts ----------------------------
     make_input(0, bufs[0])
     for _ in range(max(args.warmup, 1)):
@@ -448,8 +502,16 @@ def main():
             # (phased form: the work items of the searches left to the stepping kernel -- 48 bytes for about 3 % of the k-mers -- are not counted)
             canon_bytes = 256 * int(canonical[0]) + 64 * int(canonical[2]) + 8 * int(canonical[5]) + in_bytes + batch // 8
             ach = bytes_launch / avg_kernel_s / 1e9
+            traffic, traffic_source = None, None
+            if use_dict and world == 1 and not args.no_pmc and not os.environ.get("FMSI_BENCH_NO_PMC"):
+                traffic, traffic_source = measure_traffic(args, n, batch, k)
+            if traffic is None:
+                traffic_source = ("profiles/*traffic*.json (rocprofv3 PMC passes of the same configuration, committed)" +
+                                  (f"; not measured in this run: {traffic_source}" if traffic_source else ""))
+                traffic = pmc_traffic(args, n, batch, k)
             roof = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(args, n, batch, k),
+                    "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source if traffic is not None else None,
+                    "traffic_over_algorithmic": round(traffic / bytes_launch, 4) if traffic else None,
                     "kernel": "dict_lookup_kernel" if use_dict else ("query_stream_kernel" if stream_mode and args.stream_via == "klcp" else
                                ("lookup_lane_kernel" if lane_lookups else "pair_lookup_kernel") + " + query_pair_kernel"
                                if args.kernel == "phased" or stream_mode else f"query_{args.kernel}_kernel"),

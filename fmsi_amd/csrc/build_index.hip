@@ -248,10 +248,10 @@ __global__ void scatter_counts_kernel(const U4* __restrict__ scanned, uint32_t* 
 struct DevBuf {
     void* p = nullptr;
     ~DevBuf() {
-        if (p) (void)hipFree(p);
+        if (p) (void)dev_free(p);
     }
     int alloc(size_t bytes) {
-        if (hipMalloc(&p, bytes ? bytes : 8) != hipSuccess) {
+        if (dev_malloc(&p, bytes ? bytes : 8) != hipSuccess) {
             set_last_error("hipMalloc failed in the index builder (" + std::to_string(bytes) + " bytes)");
             return FMSI_HIP_ENOMEM;
         }
@@ -336,9 +336,9 @@ int build_from_device_text(DevBuf& text2, uint64_t len, DevBuf* mask_text, int k
         // neighbour keeps serving as scratch for nothing -- drop both
         FMSI_HIP_TRY(hipDeviceSynchronize());
         const bool pos_in_a = sorted_pos == pos_a.as<uint32_t>();
-        (void)hipFree(keys_a.release());
-        (void)hipFree(keys_b.release());
-        (void)hipFree(pos_in_a ? pos_b.release() : pos_a.release());
+        (void)dev_free(keys_a.release());
+        (void)dev_free(keys_b.release());
+        (void)dev_free(pos_in_a ? pos_b.release() : pos_a.release());
         for (uint64_t depth = kKeyBases; n_tied; depth *= 2) {
             DevBuf k_a, k_b, i_a, i_b, new_pos, sort_tmp, n_rows, n_pos, n_grp;
             if ((rc = k_a.alloc(n_tied * 8)) || (rc = k_b.alloc(n_tied * 8)) || (rc = i_a.alloc(n_tied * 4)) || (rc = i_b.alloc(n_tied * 4)) ||
@@ -368,7 +368,7 @@ int build_from_device_text(DevBuf& text2, uint64_t len, DevBuf* mask_text, int k
             }
         }
     }
-    (void)hipFree(temp.release());
+    (void)dev_free(temp.release());
     DevBuf blocks, counts, counts_scanned, mcounts, mrank, klcp, dollar, scan_temp;
     const size_t blocks_bytes = n_blocks * kBlockBytes;
     if ((rc = blocks.alloc(blocks_bytes)) || (rc = counts.alloc((n_blocks + 1) * sizeof(U4))) ||
@@ -425,7 +425,7 @@ int build_from_device_text(DevBuf& text2, uint64_t len, DevBuf* mask_text, int k
         idx->has_klcp = 1;
         idx->device_bytes += klcp_words * 8;
     }
-    if (hipMalloc(reinterpret_cast<void**>(&idx->d_counters), FMSI_HIP_N_COUNTERS * 8) != hipSuccess) {
+    if (dev_malloc(reinterpret_cast<void**>(&idx->d_counters), FMSI_HIP_N_COUNTERS * 8) != hipSuccess) {
         fmsi_hip_index_destroy(idx);
         set_last_error("hipMalloc failed");
         return FMSI_HIP_ENOMEM;

@@ -278,12 +278,12 @@ struct DevMem {
     void* p = nullptr;
     ~DevMem() { reset(); }
     void reset() {
-        if (p) (void)hipFree(p);
+        if (p) (void)dev_free(p);
         p = nullptr;
     }
     int alloc(size_t bytes, const char* what) {
         reset();
-        if (hipMalloc(&p, bytes ? bytes : 8) != hipSuccess) {
+        if (dev_malloc(&p, bytes ? bytes : 8) != hipSuccess) {
             (void)hipGetLastError();
             set_last_error(std::string("hipMalloc failed for the k-mer dictionary (") + what + ", " + std::to_string(bytes >> 20) + " MiB)");
             return FMSI_HIP_ENOMEM;
@@ -647,7 +647,7 @@ extern "C" int fmsi_hip_index_enable_dict(fmsi_hip_index* idx, uint32_t flags) {
     uint64_t bytes_total = 0;
     auto fail = [&](int code) {
         for (void* p : owned)
-            if (p) (void)hipFree(p);
+            if (p) (void)dev_free(p);
         return code;
     };
     DevMem cur_keys, cur_codes;

@@ -94,15 +94,15 @@ int export_walk(const fmsi_hip_index* idx, char* d_chars, uint32_t* d_sa) {
     uint64_t* d_last = nullptr;
     auto cleanup = [&]() {
         for (void* p : {static_cast<void*>(d_len), static_cast<void*>(d_landing), static_cast<void*>(d_last)})
-            if (p) (void)hipFree(p);
+            if (p) (void)dev_free(p);
     };
     auto fail = [&](int code, const std::string& msg) {
         cleanup();
         set_last_error(msg);
         return code;
     };
-    if (hipMalloc(reinterpret_cast<void**>(&d_len), n_chains * 4) != hipSuccess || hipMalloc(reinterpret_cast<void**>(&d_landing), n_chains * 4) != hipSuccess ||
-        hipMalloc(reinterpret_cast<void**>(&d_last), n_chains * 8) != hipSuccess)
+    if (dev_malloc(reinterpret_cast<void**>(&d_len), n_chains * 4) != hipSuccess || dev_malloc(reinterpret_cast<void**>(&d_landing), n_chains * 4) != hipSuccess ||
+        dev_malloc(reinterpret_cast<void**>(&d_last), n_chains * 8) != hipSuccess)
         return fail(FMSI_HIP_ENOMEM, "hipMalloc failed for the export buffers");
     const dim3 grid(static_cast<uint32_t>((n_chains + 255) / 256)), block(256);
     hipLaunchKernelGGL(export_measure_kernel, grid, block, 0, 0, idx->dev, stride, n_chains, d_len, d_landing);
@@ -147,7 +147,7 @@ extern "C" int fmsi_hip_index_export(const fmsi_hip_index* idx, char* out, uint6
     if (text_len == 0) return 0;
     FMSI_HIP_ON_DEVICE(idx->device);
     char* d_out = nullptr;
-    if (hipMalloc(reinterpret_cast<void**>(&d_out), text_len) != hipSuccess) {
+    if (dev_malloc(reinterpret_cast<void**>(&d_out), text_len) != hipSuccess) {
         set_last_error("hipMalloc failed for the export buffers");
         return FMSI_HIP_ENOMEM;
     }
@@ -156,6 +156,6 @@ extern "C" int fmsi_hip_index_export(const fmsi_hip_index* idx, char* out, uint6
         set_last_error("export: copying the text back failed");
         rc = FMSI_HIP_EHIP;
     }
-    (void)hipFree(d_out);
+    (void)dev_free(d_out);
     return rc;
 }

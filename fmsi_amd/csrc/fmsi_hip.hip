@@ -452,14 +452,14 @@ int build_prefix_table(fmsi_hip_index* idx, int t) {
     const uint64_t final_count = 1ull << (2 * t);
     uint2 *a = nullptr, *b = nullptr;
     // +64 B so that reading the whole line of the last entry stays inside the allocation
-    if (hipMalloc(reinterpret_cast<void**>(&a), final_count * sizeof(uint2) + 64) != hipSuccess) {
+    if (dev_malloc(reinterpret_cast<void**>(&a), final_count * sizeof(uint2) + 64) != hipSuccess) {
         (void)hipGetLastError();
         set_last_error("hipMalloc failed for the prefix table (" + std::to_string(final_count * sizeof(uint2) >> 20) + " MiB)");
         return FMSI_HIP_ENOMEM;
     }
     if (t > 1) {
-        if (hipMalloc(reinterpret_cast<void**>(&b), (final_count / 4) * sizeof(uint2) + 64) != hipSuccess) {
-            (void)hipFree(a);
+        if (dev_malloc(reinterpret_cast<void**>(&b), (final_count / 4) * sizeof(uint2) + 64) != hipSuccess) {
+            (void)dev_free(a);
             set_last_error("hipMalloc failed for the prefix table");
             return FMSI_HIP_ENOMEM;
         }
@@ -473,8 +473,8 @@ int build_prefix_table(fmsi_hip_index* idx, int t) {
         const uint32_t blocks = static_cast<uint32_t>(std::min<uint64_t>((count + 255) / 256, 1u << 22));
         hipLaunchKernelGGL(ptable_level_kernel, dim3(blocks), dim3(256), 0, 0, idx->dev, prev, bufs[cur], count);
         if (hipGetLastError() != hipSuccess) {
-            (void)hipFree(a);
-            if (b) (void)hipFree(b);
+            (void)dev_free(a);
+            if (b) (void)dev_free(b);
             set_last_error("prefix table build: kernel launch failed");
             return FMSI_HIP_EHIP;
         }
@@ -482,9 +482,9 @@ int build_prefix_table(fmsi_hip_index* idx, int t) {
         cur ^= 1;
     }
     hipError_t e = hipDeviceSynchronize();
-    if (b) (void)hipFree(b);
+    if (b) (void)dev_free(b);
     if (e != hipSuccess) {
-        (void)hipFree(a);
+        (void)dev_free(a);
         set_last_error(std::string("prefix table build: ") + hipGetErrorString(e));
         return FMSI_HIP_EHIP;
     }
@@ -493,14 +493,14 @@ int build_prefix_table(fmsi_hip_index* idx, int t) {
         uint32_t* d_max = nullptr;
         uint32_t h_max = 0;
         const uint32_t blocks = static_cast<uint32_t>(std::min<uint64_t>((final_count + 255) / 256, 1u << 20));
-        if (hipMalloc(reinterpret_cast<void**>(&d_max), 4) != hipSuccess || hipMemset(d_max, 0, 4) != hipSuccess) {
-            (void)hipFree(a);
+        if (dev_malloc(reinterpret_cast<void**>(&d_max), 4) != hipSuccess || hipMemset(d_max, 0, 4) != hipSuccess) {
+            (void)dev_free(a);
             set_last_error("hipMalloc failed");
             return FMSI_HIP_ENOMEM;
         }
         hipLaunchKernelGGL(ptable_maxlen_kernel, dim3(blocks), dim3(256), 0, 0, a, final_count, d_max);
         hipError_t e2 = hipMemcpy(&h_max, d_max, 4, hipMemcpyDeviceToHost);
-        (void)hipFree(d_max);
+        (void)dev_free(d_max);
         idx->dev.ptable_packed = 0;
         if (e2 == hipSuccess && h_max < (1u << 30)) {
             hipLaunchKernelGGL(ptable_pack_kernel, dim3(blocks), dim3(256), 0, 0, idx->dev, a, final_count);
@@ -509,7 +509,7 @@ int build_prefix_table(fmsi_hip_index* idx, int t) {
             idx->dev.ptable_packed = 1;
         }
         if (e2 != hipSuccess) {
-            (void)hipFree(a);
+            (void)dev_free(a);
             set_last_error(std::string("prefix table packing: ") + hipGetErrorString(e2));
             return FMSI_HIP_EHIP;
         }
@@ -764,8 +764,8 @@ int fmsi_hip_index_create(const fmsi_index_view* view, int device, fmsi_hip_inde
         fmsi_hip_index_destroy(idx);
         return code;
     };
-    if (hipMalloc(&idx->d_blocks, blocks_bytes) != hipSuccess || hipMalloc(&idx->d_mrank, mrank_bytes) != hipSuccess ||
-        hipMalloc(reinterpret_cast<void**>(&idx->d_counters), FMSI_HIP_N_COUNTERS * 8) != hipSuccess) {
+    if (dev_malloc(&idx->d_blocks, blocks_bytes) != hipSuccess || dev_malloc(&idx->d_mrank, mrank_bytes) != hipSuccess ||
+        dev_malloc(reinterpret_cast<void**>(&idx->d_counters), FMSI_HIP_N_COUNTERS * 8) != hipSuccess) {
         set_last_error("hipMalloc failed for the device layout");
         return fail(FMSI_HIP_ENOMEM);
     }
@@ -782,7 +782,7 @@ int fmsi_hip_index_create(const fmsi_index_view* view, int device, fmsi_hip_inde
         const uint32_t sb_log2 = forced_wide && view->mask_bits < (1ull << 32) ? 3u : 24u;
         std::vector<uint64_t> super;
         wide_super_table(L.blocks.data(), L.mrank.data(), L.n_blocks, sb_log2, super);
-        if (hipMalloc(&idx->d_super, super.size() * 8) != hipSuccess ||
+        if (dev_malloc(&idx->d_super, super.size() * 8) != hipSuccess ||
             hipMemcpy(idx->d_super, super.data(), super.size() * 8, hipMemcpyHostToDevice) != hipSuccess) {
             set_last_error("uploading the superblock table failed");
             return fail(FMSI_HIP_EHIP);
@@ -816,7 +816,7 @@ int fmsi_hip_index_create(const fmsi_index_view* view, int device, fmsi_hip_inde
     idx->dev.C3 = static_cast<uint32_t>(view->counts[3]);
     if (view->klcp && view->klcp_bits) {
         const size_t kb = ((view->klcp_bits + 63) / 64 + 1) * 8;
-        if (hipMalloc(&idx->d_klcp, kb) != hipSuccess ||
+        if (dev_malloc(&idx->d_klcp, kb) != hipSuccess ||
             hipMemcpy(idx->d_klcp, view->klcp, ((view->klcp_bits + 63) / 64) * 8, hipMemcpyHostToDevice) != hipSuccess) {
             set_last_error("uploading the kLCP array failed");
             return fail(FMSI_HIP_EHIP);
@@ -832,12 +832,20 @@ int fmsi_hip_index_create(const fmsi_index_view* view, int device, fmsi_hip_inde
     return 0;
 }
 
+int fmsi_hip_trim_scratch(int device) {
+    int ndev = fmsi_hip_device_count();
+    if (device < 0 || device >= ndev) return FMSI_HIP_ENODEV;
+    FMSI_HIP_ON_DEVICE(device);
+    (void)dev_trim();
+    return 0;
+}
+
 void fmsi_hip_index_destroy(fmsi_hip_index* idx) {
     if (!idx) return;
     ::fmsi::DeviceGuard device_guard_(idx->device);
     for (void* p : {idx->d_super, idx->d_blocks, idx->d_mrank, idx->d_ptable, idx->d_klcp, idx->d_text2, idx->d_stable, idx->d_vtable, idx->d_in, idx->d_aux, idx->d_out,
                     idx->d_kmers, idx->d_tasks, idx->d_bytes, idx->d_dict[0], idx->d_dict[1], idx->d_dict[2], idx->d_dict[3], idx->d_pblocks, idx->d_sbt, idx->d_c2, static_cast<void*>(idx->d_counters)})
-        if (p) (void)hipFree(p);
+        if (p) (void)dev_free(p);
     for (auto& m : idx->meta_ring) {
         if (m.in_flight) (void)hipEventSynchronize(m.done);
         if (m.host) (void)hipHostFree(m.host);
@@ -848,6 +856,7 @@ void fmsi_hip_index_destroy(fmsi_hip_index* idx) {
         (void)hipEventDestroy(e.second);
     }
     delete idx;
+    (void)dev_trim();   // (what this handle's construction left in the block cache goes back to the driver with it)
 }
 
 int fmsi_hip_index_get_info(const fmsi_hip_index* idx, fmsi_hip_index_info* info) {

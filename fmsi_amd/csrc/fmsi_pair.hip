@@ -1310,19 +1310,19 @@ extern "C" int fmsi_hip_index_enable_pair_layout(fmsi_hip_index* idx) {
     void *pb = nullptr, *counts = nullptr, *scanned = nullptr, *sbt = nullptr, *c2 = nullptr, *spec = nullptr, *temp = nullptr;
     auto cleanup = [&]() {
         for (void* p : {counts, scanned, spec, temp})
-            if (p) (void)hipFree(p);
+            if (p) (void)dev_free(p);
     };
     auto fail = [&](int code, const char* msg) {
         cleanup();
         for (void* p : {pb, sbt, c2})
-            if (p) (void)hipFree(p);
+            if (p) (void)dev_free(p);
         set_last_error(msg);
         return code;
     };
     const size_t pb_bytes = n_blocks * kPairBlockDwords * 4;
-    if (hipMalloc(&pb, pb_bytes) != hipSuccess || hipMalloc(&counts, (n_blocks + 1) * sizeof(U16)) != hipSuccess ||
-        hipMalloc(&scanned, (n_blocks + 1) * sizeof(U16)) != hipSuccess || hipMalloc(&sbt, n_super * 64 + 64) != hipSuccess ||
-        hipMalloc(&c2, 64) != hipSuccess || hipMalloc(&spec, 8) != hipSuccess)
+    if (dev_malloc(&pb, pb_bytes) != hipSuccess || dev_malloc(&counts, (n_blocks + 1) * sizeof(U16)) != hipSuccess ||
+        dev_malloc(&scanned, (n_blocks + 1) * sizeof(U16)) != hipSuccess || dev_malloc(&sbt, n_super * 64 + 64) != hipSuccess ||
+        dev_malloc(&c2, 64) != hipSuccess || dev_malloc(&spec, 8) != hipSuccess)
         return fail(FMSI_HIP_ENOMEM, "hipMalloc failed for the pair layout");
     if (hipMemset(pb, 0, pb_bytes) != hipSuccess || hipMemset(counts, 0, (n_blocks + 1) * sizeof(U16)) != hipSuccess ||
         hipMemset(spec, 0xFF, 8) != hipSuccess || hipMemset(sbt, 0, n_super * 64 + 64) != hipSuccess)
@@ -1336,7 +1336,7 @@ extern "C" int fmsi_hip_index_enable_pair_layout(fmsi_hip_index* idx) {
     if (e1 == hipSuccess)
         e1 = rocprim::exclusive_scan(nullptr, tb, static_cast<U16*>(counts), static_cast<U16*>(scanned), zero, static_cast<size_t>(n_blocks + 1),
                                      U16Plus());
-    if (e1 == hipSuccess) e1 = hipMalloc(&temp, tb);
+    if (e1 == hipSuccess) e1 = dev_malloc(&temp, tb);
     if (e1 == hipSuccess)
         e1 = rocprim::exclusive_scan(temp, tb, static_cast<U16*>(counts), static_cast<U16*>(scanned), zero, static_cast<size_t>(n_blocks + 1),
                                      U16Plus());
@@ -1509,7 +1509,7 @@ extern "C" int fmsi_hip_index_enable_verify(fmsi_hip_index* idx) {
     auto fail = [&](int code, const char* msg) {
         for (void* p : {static_cast<void*>(d_chars), static_cast<void*>(d_sa), static_cast<void*>(d_stable), static_cast<void*>(d_text2),
                         static_cast<void*>(d_vtable)})
-            if (p) (void)hipFree(p);
+            if (p) (void)dev_free(p);
         if (msg) set_last_error(msg);
         return code;
     };
@@ -1519,26 +1519,26 @@ extern "C" int fmsi_hip_index_enable_verify(fmsi_hip_index* idx) {
     if (wide) {
         size_t free_b = 0, total_b = 0;
         const uint64_t need = count * 32 + (len + 1) + n * 4 + ((len >> 5) + 2) * 8 + (16ull << 30);
-        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < need) wide = false;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b + dev_cached_bytes() < need) wide = false;   // (cached blocks are given back on demand)
     }
     const uint64_t entry_bytes = wide ? 32 : 16;
-    if (hipMalloc(reinterpret_cast<void**>(&d_chars), len + 1) != hipSuccess || hipMalloc(reinterpret_cast<void**>(&d_sa), n * 4) != hipSuccess ||
-        (!wide && hipMalloc(reinterpret_cast<void**>(&d_stable), count * 4) != hipSuccess) ||
-        hipMalloc(reinterpret_cast<void**>(&d_vtable), count * entry_bytes + 64) != hipSuccess)
+    if (dev_malloc(reinterpret_cast<void**>(&d_chars), len + 1) != hipSuccess || dev_malloc(reinterpret_cast<void**>(&d_sa), n * 4) != hipSuccess ||
+        (!wide && dev_malloc(reinterpret_cast<void**>(&d_stable), count * 4) != hipSuccess) ||
+        dev_malloc(reinterpret_cast<void**>(&d_vtable), count * entry_bytes + 64) != hipSuccess)
         return fail(FMSI_HIP_ENOMEM, "hipMalloc failed for the text verification tables");
     int rc = export_walk(idx, d_chars, d_sa);
     if (rc) return fail(rc, nullptr);
     const uint64_t n_words = (len >> 5) + 2;
     if (!idx->d_text2) {
-        if (hipMalloc(reinterpret_cast<void**>(&d_text2), n_words * 8) != hipSuccess) return fail(FMSI_HIP_ENOMEM, "hipMalloc failed for the text");
+        if (dev_malloc(reinterpret_cast<void**>(&d_text2), n_words * 8) != hipSuccess) return fail(FMSI_HIP_ENOMEM, "hipMalloc failed for the text");
         hipLaunchKernelGGL(chars_to_text2_kernel, dim3(static_cast<uint32_t>((n_words + 255) / 256)), dim3(256), 0, 0, d_chars, len, n_words, d_text2);
     }
     const uint32_t blocks = static_cast<uint32_t>(std::min<uint64_t>((count + 255) / 256, 1u << 20));
     hipLaunchKernelGGL(verify_fill_kernel, dim3(blocks), dim3(256), 0, 0, static_cast<const uint2*>(idx->d_ptable), count, d_sa, d_chars, len,
                        static_cast<uint32_t>(T), static_cast<uint32_t>(R), R <= 15 ? 1u : 0u, wide ? 1u : 0u, d_vtable, d_stable);
     if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess) return fail(FMSI_HIP_EHIP, "text verification: device work failed");
-    (void)hipFree(d_chars);
-    (void)hipFree(d_sa);
+    (void)dev_free(d_chars);
+    (void)dev_free(d_sa);
     if (d_text2) {
         idx->d_text2 = d_text2;
         idx->text_len = len;

@@ -12,6 +12,7 @@
 
 #include "../../include/fmsi_hip.h"
 #include "common.h"
+#include "devpool.h"
 
 namespace fmsi {
 
@@ -194,11 +195,11 @@ int export_walk(const fmsi_hip_index* idx, char* d_chars, uint32_t* d_sa);
 // grow-only device staging buffer
 inline int ensure_cap(void** p, size_t* cap, size_t need) {
     if (need <= *cap) return 0;
-    if (*p) (void)hipFree(*p);
+    if (*p) (void)dev_free(*p);
     *p = nullptr;
     *cap = 0;
     const size_t want = need > (size_t(1) << 20) ? need : (size_t(1) << 20);
-    FMSI_HIP_TRY(hipMalloc(p, want));
+    FMSI_HIP_TRY(dev_malloc(p, want));
     *cap = want;
     return 0;
 }

@@ -266,6 +266,10 @@ int fmsi_hip_query_stream(fmsi_hip_index* idx, const uint64_t* packed_seq, uint6
                           uint64_t n_windows, int k, uint32_t flags, void* out, uint64_t* counters, void* stream);
 
 int fmsi_hip_sync(fmsi_hip_index* idx, void* stream);
+/* The library keeps large freed device blocks (temporaries of the builders) for reuse -- freeing and re-allocating them is what an index
+ * load mostly waits for on this platform -- and returns them to the driver when an allocation of its own fails or a handle
+ * is destroyed.  A host that needs the HBM for itself in between calls this. */
+int fmsi_hip_trim_scratch(int device);
 /* Page-locked host memory for the caller's batch buffers (hipHostMalloc / hipHostFree).  Any host memory works with the
  * query calls; from page-locked memory the copies to and from the device run at the link's rate instead of through the
  * driver's staging (the CLI's device stage: 0.4-0.6 s -> see DESIGN.md 8 per 10^9 windows).  NULL when it cannot be had. */

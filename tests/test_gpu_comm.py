@@ -80,7 +80,7 @@ def test_bench_multi_rank_path_with_one_rank(fm):
 
     repo = Path(__file__).resolve().parent.parent
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
-           "--master-port", "29547", str(repo / "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--index-bases", "3e6", "--batch", "262144",   # (not --n: torch.distributed.run's own parser trips over it)
+           "--master-port", "29547", str(repo / "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--index-bases", "3e6", "--batch", "262144", "--no-pmc",   # (not --n: torch.distributed.run's own parser trips over it)
            "--force-dist", "--abi-gather", "--cpu-sample", "0", "--prefix-len", "10"]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=str(repo))
