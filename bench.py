@@ -32,8 +32,11 @@ Extra objects on the JSON line:
                   `canonical_achieved` applies SURVEY 8(d)'s reference-layout formula (256 B per LF step the REFERENCE
                   algorithm executes for the same queries + 64 B per mask probe + in/out) to the same time; it can
                   exceed the HBM peak because the fused layout and the prefix table touch far fewer bytes.
-                  `traffic` = HBM bytes per launch from the rocprofv3 PMC passes committed under profiles/ (only when
-                  the profiled configuration is the one being run).
+                  `traffic` = HBM bytes per launch of the timed kernel, MEASURED IN THIS RUN when rocprofv3 is there (default
+                  dictionary path, N = 1): two child runs of this script under `rocprofv3 --pmc` (FETCH_SIZE / WRITE_SIZE, separate
+                  passes, corrected as MI355X_MICROARCH.md prescribes; `traffic_source` says how) -- else from the passes committed
+                  under profiles/ when their configuration is the one being run.  `lf_path` = the table-less LF walk on the same
+                  index in timed legs of its own (two-base steps; lock-step), the path north_star names.
   cpu_baseline -- the real reference (oracle/_ref, kind "reference") or the C restatement (kind "port") timed on
                   this box's host cores on a bounded sample of the same queries against the same index (bench_cpu.py).
 """
@@ -151,6 +154,8 @@ def measure_traffic(args, n, batch, k):
              "--read-len", str(args.read_len), "--subst-ppm", str(args.subst_ppm)] + (["--dict-sparse"] if args.dict_sparse else []) + \
             (["--repeat-permille", str(args.repeat_permille), "--repeat-families", str(args.repeat_families),
               "--repeat-divergence-permille", str(args.repeat_divergence_permille)] if args.repeat_permille else [])
+    import fmsi_amd as fm
+    fm.trim_scratch(int(os.environ.get("LOCAL_RANK", "0")))   # the child builds the same index beside this process: give it the room
     got = {}
     env = dict(os.environ, TMPDIR="/tmp")
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
@@ -167,7 +172,7 @@ def measure_traffic(args, n, batch, k):
                         if "dict_lookup_kernel<false" in r["Kernel_Name"] and r["Counter_Name"] == counter:
                             per[r["Dispatch_Id"]] = per.get(r["Dispatch_Id"], 0.0) + float(r["Counter_Value"])
             if res.returncode != 0 or not per:
-                return None, f"rocprofv3 --pmc {counter}: rc {res.returncode}, {len(per)} dispatches ({res.stderr.decode(errors='replace')[-200:]})"
+                return None, f"rocprofv3 --pmc {counter}: rc {res.returncode}, {len(per)} dispatches ({' '.join(l for l in res.stderr.decode(errors='replace').splitlines() if not l[:1] in 'WIE' or 'rror' in l)[-600:]})"
             got[counter] = sum(per.values()) / len(per) * 1024.0   # the counters are in KiB
     return 2.0 * got["FETCH_SIZE"] + got["WRITE_SIZE"], (
         f"measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (a child run each, 3 launches of dict_lookup_kernel<false,...>), "

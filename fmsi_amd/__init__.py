@@ -135,6 +135,7 @@ def lib() -> C.CDLL:
     L.fmsi_hip_index_enable_pair_layout.argtypes = [vp]
     L.fmsi_hip_index_enable_verify.argtypes = [vp]
     L.fmsi_hip_index_enable_dict.argtypes = [vp, u32]
+    L.fmsi_hip_trim_scratch.argtypes = [i32]
     L.fmsi_hip_synthetic_reads.argtypes = [vp, u64, u64, u64, u64, u32, vp, vp]
     L.fmsi_hip_query_kmers.argtypes = [vp, vp, u64, i32, u32, vp, vp, vp]
     L.fmsi_hip_query_windows.argtypes = [vp, vp, u64, vp, u64, i32, u32, vp, vp, vp]
@@ -522,6 +523,11 @@ def synthetic_text(length: int, seed: int, k: int, mask_permille: int = 1000) ->
 def decode_strict(out: np.ndarray):
     """Split STRICT presence bytes into (fwd, rc) int8 arrays with values in {-1, 0, 1}."""
     return (out & 3).astype(np.int8) - 1, ((out >> 2) & 3).astype(np.int8) - 1
+
+
+def trim_scratch(device: int = 0) -> None:
+    """Return the library's cached device blocks (temporaries of the builders) to the driver (fmsi_hip_trim_scratch)."""
+    _check(lib().fmsi_hip_trim_scratch(device))
 
 
 def packed_words(n: int, flags: int) -> int:
