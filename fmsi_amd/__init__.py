@@ -135,6 +135,7 @@ def lib() -> C.CDLL:
     L.fmsi_hip_index_enable_pair_layout.argtypes = [vp]
     L.fmsi_hip_index_enable_verify.argtypes = [vp]
     L.fmsi_hip_index_enable_dict.argtypes = [vp, u32]
+    L.fmsi_hip_index_load.argtypes = [C.c_char_p, i32, i32, i32, C.POINTER(vp)]
     L.fmsi_hip_trim_scratch.argtypes = [i32]
     L.fmsi_hip_synthetic_reads.argtypes = [vp, u64, u64, u64, u64, u32, vp, vp]
     L.fmsi_hip_query_kmers.argtypes = [vp, vp, u64, i32, u32, vp, vp, vp]
@@ -373,6 +374,13 @@ class DeviceIndex:
         host = HostIndex(prefix, use_klcp)
         host.view.prefix_len = prefix_len
         return cls(host.view, device, keepalive=host)
+
+    @classmethod
+    def load(cls, prefix: str, use_klcp: bool = False, device: int = 0, prefix_len: int = 0):
+        """load_index() straight into HBM (fmsi_hip_index_load): RRR decode and block layout on the device."""
+        h = C.c_void_p()
+        _check(lib().fmsi_hip_index_load(os.fsencode(prefix), int(use_klcp), device, prefix_len, C.byref(h)))
+        return cls(None, device, _handle=h)
 
     # -- host-pointer calls (library stages through its own device buffers) --
     def query_kmers(self, kmers: np.ndarray, k: int, flags: int = MODE_OR, counters: bool = False):

@@ -18,13 +18,21 @@
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
 
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
 
 #include "../../include/fmsi_hip.h"
 #include "common.h"
+#include "host_index.h"
 #include "index_priv.h"
 #include "trace.h"
 
@@ -667,3 +675,391 @@ int fmsi_hip_index_download_text(const fmsi_hip_index* idx, uint64_t* words) {
 }
 
 }  // extern "C"
+
+// ---- load_index() straight into HBM (fmsi_hip_index_load) ---------------------------------------------------------------------------
+// The host path (fmsi_host_index_load + fmsi_hip_index_create) decodes the RRR-63 mask and interleaves the planes with 16 host
+// threads, then uploads the 64-byte blocks: 0.7-0.9 s at human scale, most of the CLI's whole-process time on a 1 GB query file.
+// Here the files' payload goes to the device as it is (1.1 GB instead of 1.4 GB) and three kernels do the rest:
+//   rrr_decode_kernel   a wave per 64 RRR blocks (two superblocks): lane l sums the offset widths of the blocks before it in its
+//                       superblock (shuffle scan) from the superblock's sampled pointer, unranks its 63 bits by the combinatorial
+//                       number system (rrr_helper.hpp:304-320; the binomials sit in LDS), and the wave emits 63 whole words
+//   word popcounts + rocPRIM scan: where a 64-row word's G/T bits start in `gt`
+//   layout_words_kernel a wave per 64-row word, a lane per row: its second-level bit comes from `gt` or `ac` at the lane's rank among
+//                       the word's G/T (A/C) rows -- the pdep of the host builder as one ballot --, planes and per-block counts as
+//                       emit_rows_kernel writes them; the same scans and scatter finish the blocks
+// The result is dword for dword what fmsi_hip_index_create builds (tests/test_gpu_builder.py::test_device_load_equals_host_load).
+namespace fmsi {
+namespace {
+
+struct Mapped {
+    const uint8_t* data = nullptr;
+    size_t size = 0;
+    ~Mapped() {
+        if (data) munmap(const_cast<uint8_t*>(data), size);
+    }
+    bool open_file(const std::string& path) {
+        const int fd = ::open(path.c_str(), O_RDONLY);
+        if (fd < 0) return false;
+        struct stat st;
+        bool ok = fstat(fd, &st) == 0 && st.st_size > 0;
+        if (ok) {
+            void* p = mmap(nullptr, static_cast<size_t>(st.st_size), PROT_READ, MAP_PRIVATE | MAP_POPULATE, fd, 0);
+            ok = p != MAP_FAILED;
+            if (ok) {
+                data = static_cast<const uint8_t*>(p);
+                size = static_cast<size_t>(st.st_size);
+            }
+        }
+        ::close(fd);
+        return ok;
+    }
+};
+
+struct Span {   // a run of u64 words inside a mapped file
+    const uint8_t* p = nullptr;
+    uint64_t bits = 0, words = 0;
+    uint8_t width = 0;
+};
+struct FileCursor {
+    const uint8_t* p;
+    size_t left;
+    bool u64(uint64_t& v) {
+        if (left < 8) return false;
+        std::memcpy(&v, p, 8);
+        p += 8;
+        left -= 8;
+        return true;
+    }
+    bool bit_vector(Span& s) {   // int_vector<1>: u64 bit count + words
+        if (!u64(s.bits)) return false;
+        s.words = (s.bits + 63) >> 6;
+        if (left < s.words * 8) return false;
+        s.p = p;
+        p += s.words * 8;
+        left -= s.words * 8;
+        return true;
+    }
+    bool int_vector(Span& s) {   // int_vector<0>: u64 bit count + u8 width + words
+        if (!u64(s.bits) || left < 1) return false;
+        s.width = *p;
+        ++p;
+        --left;
+        s.words = (s.bits + 63) >> 6;
+        if (left < s.words * 8) return false;
+        s.p = p;
+        p += s.words * 8;
+        left -= s.words * 8;
+        return true;
+    }
+};
+
+__device__ __forceinline__ uint64_t dev_read_bits(const uint64_t* __restrict__ words, uint64_t pos, uint32_t len) {
+    if (len == 0) return 0;
+    const uint64_t* w = words + (pos >> 6);
+    const uint32_t off = static_cast<uint32_t>(pos & 63u);
+    uint64_t v = w[0] >> off;
+    if (off + len > 64u) v |= w[1] << (64u - off);
+    return len >= 64u ? v : (v & ((1ull << len) - 1ull));
+}
+
+__global__ __launch_bounds__(256) void rrr_decode_kernel(const uint64_t* __restrict__ bt, const uint64_t* __restrict__ btnr, uint64_t btnr_bits,
+                                                         const uint64_t* __restrict__ btnrp, uint32_t btnrp_w, const uint64_t* __restrict__ invert,
+                                                         const uint64_t* __restrict__ binom, const uint8_t* __restrict__ space_tab, uint64_t n,
+                                                         uint64_t n_blocks, uint64_t n_super, uint64_t* __restrict__ mask_words, uint64_t n_words,
+                                                         uint32_t* __restrict__ corrupt) {
+    __shared__ uint64_t s_c[64 * 64];
+    __shared__ uint8_t s_space[64];
+    for (uint32_t i = threadIdx.x; i < 64u * 64u; i += blockDim.x) s_c[i] = binom[i];
+    if (threadIdx.x < 64u) s_space[threadIdx.x] = space_tab[threadIdx.x];
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t wave = (static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;   // 64 blocks = 2 superblocks = 63 words
+    const uint64_t b = wave * 64u + lane, s = b >> 5;
+    uint64_t v = 0;
+    uint32_t width = 0, cls = 0;
+    const bool have = b < n_blocks;
+    if (have) {
+        const uint32_t stored = static_cast<uint32_t>(dev_read_bits(bt, b * 6u, 6u));
+        const bool inv = (invert[s >> 6] >> (s & 63u)) & 1ull;
+        cls = inv ? 63u - stored : stored;   // rrr_vector.hpp:262-263
+        width = s_space[stored];
+    }
+    // offset of this block's number: the superblock's sampled pointer + the widths of the blocks before it in the superblock
+    uint32_t incl = width;
+#pragma unroll
+    for (int d = 1; d < 32; d <<= 1) {
+        const uint32_t up = static_cast<uint32_t>(__shfl_up(static_cast<int>(incl), d, 32));
+        if ((lane & 31u) >= static_cast<uint32_t>(d)) incl += up;
+    }
+    if (have && b * 63u < n) {   // (the dummy block of n % 63 == 0 holds nothing)
+        const uint64_t base = s < n_super ? dev_read_bits(btnrp, s * btnrp_w, btnrp_w) : 0ull;
+        const uint64_t pos = base + (incl - width);
+        if (pos + width > btnr_bits) {
+            *corrupt = 1u;
+        } else if (cls == 63u) {
+            v = (1ull << 63) - 1ull;
+        } else if (cls != 0u) {
+            uint64_t nr = dev_read_bits(btnr, pos, width);
+            uint32_t left = cls;
+            for (uint32_t p = 0, remaining = 63u; p < 63u && left > 0u; ++p, --remaining) {   // rrr_helper.hpp:304-320, positions from the LSB
+                const uint64_t skip = s_c[(remaining - 1u) * 64u + left];
+                if (nr >= skip) {
+                    v |= 1ull << p;
+                    nr -= skip;
+                    --left;
+                }
+            }
+        }
+        const uint64_t first = b * 63u;
+        if (first + 63u > n) v &= (1ull << (n - first)) - 1ull;
+    }
+    // 64 x 63 bits -> 63 words: word w of the wave = block w from its bit w on, then the first w + 1 bits of block w + 1
+    const uint64_t nxt = static_cast<uint64_t>(__shfl_down(static_cast<long long>(v), 1, 64));
+    const uint64_t out_w = wave * 63u + lane;
+    if (lane < 63u && out_w < n_words) mask_words[out_w] = (v >> lane) | (nxt << (63u - lane));
+}
+
+__global__ __launch_bounds__(256) void word_popcount_kernel(const uint64_t* __restrict__ words, uint64_t n_words, uint64_t n_bits, uint32_t* __restrict__ pc) {
+    const uint64_t w = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (w >= n_words) return;
+    uint64_t x = words[w];
+    if (w == n_words - 1 && (n_bits & 63u)) x &= (1ull << (n_bits & 63u)) - 1ull;
+    pc[w] = static_cast<uint32_t>(__popcll(x));
+}
+
+// a wave per 64-row word (256 threads = 4 words = 2 blocks, as emit_rows_kernel)
+__global__ __launch_bounds__(256) void layout_words_kernel(const uint64_t* __restrict__ ac_gt, const uint64_t* __restrict__ ac, const uint64_t* __restrict__ gt,
+                                                           const uint64_t* __restrict__ mask, const uint32_t* __restrict__ gt_off, uint64_t n,
+                                                           uint64_t n_words, uint32_t* __restrict__ blocks, U4* __restrict__ block_counts,
+                                                           uint32_t* __restrict__ mask_counts) {
+    __shared__ uint32_t s_cnt[4][5];
+    const uint32_t lane = threadIdx.x & 63u, wave_in_block = threadIdx.x >> 6;
+    const uint64_t w = static_cast<uint64_t>(blockIdx.x) * 4u + wave_in_block;
+    const uint64_t row = w * 64u + lane;
+    const bool valid = w < n_words && row < n;
+    uint64_t g = 0, m = 0, gpos = 0;
+    if (w < n_words) {
+        g = ac_gt[w];
+        m = mask[w];
+        gpos = gt_off[w];
+    }
+    const uint64_t vv = __ballot(valid);
+    g &= vv;
+    m &= vv;
+    const uint64_t below = (1ull << lane) - 1ull;
+    uint32_t lo_bit = 0;
+    if (valid) {
+        if ((g >> lane) & 1ull) {
+            const uint64_t p = gpos + static_cast<uint32_t>(__popcll(g & below));
+            lo_bit = static_cast<uint32_t>(gt[p >> 6] >> (p & 63u)) & 1u;
+        } else {
+            const uint64_t p = (w * 64u - gpos) + static_cast<uint32_t>(__popcll(~g & vv & below));
+            lo_bit = static_cast<uint32_t>(ac[p >> 6] >> (p & 63u)) & 1u;
+        }
+    }
+    const uint64_t lo = __ballot(valid && lo_bit);
+    if (lane == 0) {
+        if (vv) {
+            uint32_t* blk = blocks + (w >> 1) * kBlockDwords;
+            const uint32_t half = static_cast<uint32_t>(w & 1) * 2;
+            blk[4 + half] = static_cast<uint32_t>(g);
+            blk[5 + half] = static_cast<uint32_t>(g >> 32);
+            blk[8 + half] = static_cast<uint32_t>(lo);
+            blk[9 + half] = static_cast<uint32_t>(lo >> 32);
+            blk[12 + half] = static_cast<uint32_t>(m);
+            blk[13 + half] = static_cast<uint32_t>(m >> 32);
+        }
+        s_cnt[wave_in_block][0] = __popcll(vv & ~g & ~lo);
+        s_cnt[wave_in_block][1] = __popcll(vv & ~g & lo);
+        s_cnt[wave_in_block][2] = __popcll(g & ~lo);
+        s_cnt[wave_in_block][3] = __popcll(g & lo);
+        s_cnt[wave_in_block][4] = __popcll(m);
+    }
+    __syncthreads();
+    if (threadIdx.x < 2) {
+        const uint64_t b = static_cast<uint64_t>(blockIdx.x) * 2 + threadIdx.x;
+        const uint32_t w0 = threadIdx.x * 2, w1 = w0 + 1;
+        block_counts[b] = U4{s_cnt[w0][0] + s_cnt[w1][0], s_cnt[w0][1] + s_cnt[w1][1], s_cnt[w0][2] + s_cnt[w1][2], s_cnt[w0][3] + s_cnt[w1][3]};
+        mask_counts[b] = s_cnt[w0][4] + s_cnt[w1][4];
+    }
+}
+
+int load_fail(int code, const std::string& msg) {
+    set_last_error(msg);
+    return code;
+}
+
+}  // namespace
+}  // namespace fmsi
+
+extern "C" int fmsi_hip_index_load(const char* prefix_c, int use_klcp, int device, int prefix_len, fmsi_hip_index** out) {
+    if (!prefix_c || !out) return load_fail(FMSI_HIP_EINVAL, "null argument");
+    TraceRange trace_range("fmsi: load index files into HBM");
+    const std::string base = std::string(prefix_c) + ".fmsi";
+    // ---- the files: headers parsed on the host, payloads stay where the page cache has them ----------------------------------
+    Mapped f_acgt, f_ac, f_gt, f_mask, f_klcp;
+    if (!f_acgt.open_file(base + ".ac_gt")) return load_fail(FMSI_HIP_EIO, "cannot read " + base + ".ac_gt");
+    if (!f_ac.open_file(base + ".ac")) return load_fail(FMSI_HIP_EIO, "cannot read " + base + ".ac");
+    if (!f_gt.open_file(base + ".gt")) return load_fail(FMSI_HIP_EIO, "cannot read " + base + ".gt");
+    if (!f_mask.open_file(base + ".mask")) return load_fail(FMSI_HIP_EIO, "cannot read " + base + ".mask");
+    const bool with_klcp = use_klcp && f_klcp.open_file(base + ".klcp");   // fms_index.h:513-515: only when the file exists AND -S was given
+    Span acgt, ac, gt, klcp, bt, btnr, btnrp, rank_samples, invert;
+    {
+        FileCursor c{f_acgt.data, f_acgt.size};
+        if (!c.bit_vector(acgt)) return load_fail(FMSI_HIP_EIO, "malformed bit vector " + base + ".ac_gt");
+        c = FileCursor{f_ac.data, f_ac.size};
+        if (!c.bit_vector(ac)) return load_fail(FMSI_HIP_EIO, "malformed bit vector " + base + ".ac");
+        c = FileCursor{f_gt.data, f_gt.size};
+        if (!c.bit_vector(gt)) return load_fail(FMSI_HIP_EIO, "malformed bit vector " + base + ".gt");
+        if (with_klcp) {
+            c = FileCursor{f_klcp.data, f_klcp.size};
+            if (!c.bit_vector(klcp)) return load_fail(FMSI_HIP_EIO, "malformed bit vector " + base + ".klcp");
+        }
+    }
+    uint64_t n = 0;
+    {
+        FileCursor c{f_mask.data, f_mask.size};
+        if (!c.u64(n) || !c.int_vector(bt) || !c.bit_vector(btnr) || !c.int_vector(btnrp) || !c.int_vector(rank_samples) || !c.bit_vector(invert))
+            return load_fail(FMSI_HIP_EIO, "truncated rrr_vector<63> image");
+    }
+    const uint64_t n_rrr_blocks = (n + 63) / 63, n_super = (n_rrr_blocks + 31) / 32;   // incl. the dummy block when n % 63 == 0 (rrr_vector.hpp:148)
+    if (bt.width != 6 || bt.bits != n_rrr_blocks * 6 || btnrp.width == 0 || btnrp.width > 64 || btnrp.bits != n_super * btnrp.width || invert.bits != n_super ||
+        rank_samples.width == 0)
+        return load_fail(FMSI_HIP_EIO, "rrr_vector<63> image has inconsistent geometry");
+    unsigned long long dollar = 0, counts[4] = {0, 0, 0, 0};
+    int k = 0;
+    {
+        FILE* f = std::fopen((base + ".misc").c_str(), "r");
+        if (!f) return load_fail(FMSI_HIP_EIO, "cannot read " + base + ".misc");
+        const int got = std::fscanf(f, "%llu %llu %llu %llu %llu %d", &dollar, &counts[0], &counts[1], &counts[2], &counts[3], &k);
+        std::fclose(f);
+        if (got != 6) return load_fail(FMSI_HIP_EIO, "malformed " + base + ".misc");
+    }
+    if (n == 0 || acgt.bits != n || ac.bits + gt.bits != n) return load_fail(FMSI_HIP_EIO, "index parts disagree on the number of rows");
+    if (n >= (1ull << 32) - kBlockRows || std::getenv("FMSI_HIP_FORCE_ROWS64")) {
+        // 64-bit rows go through the host path (fmsi_wide.hip's superblock table is built there)
+        fmsi_host_index* host = nullptr;
+        int rc = fmsi_host_index_load(prefix_c, use_klcp, &host);
+        if (rc) return rc;
+        fmsi_index_view view;
+        fmsi_host_index_view(host, &view);
+        view.prefix_len = prefix_len;
+        rc = fmsi_hip_index_create(&view, device, out);
+        fmsi_host_index_free(host);
+        return rc;
+    }
+    int rc = check_device(device);
+    if (rc) return rc;
+    FMSI_HIP_ON_DEVICE(device);
+
+    // ---- payloads to the device (two zero words of padding behind each) -----------------------------------------------------
+    const uint64_t n_words = (n + 63) >> 6, n_blocks = ((n + kBlockRows - 1) >> kBlockRowsLog2) + 1;
+    DevBuf d_acgt, d_ac, d_gt, d_bt, d_btnr, d_btnrp, d_invert, d_binom, d_space, d_mask, d_gtoff, d_pc, d_corrupt, d_klcp;
+    auto upload = [&](DevBuf& b, const Span& s) -> int {
+        int r = b.alloc((s.words + 2) * 8);
+        if (r) return r;
+        FMSI_HIP_TRY(hipMemsetAsync(static_cast<char*>(b.p) + s.words * 8, 0, 16, 0));
+        if (s.words) FMSI_HIP_TRY(hipMemcpyAsync(b.p, s.p, s.words * 8, hipMemcpyHostToDevice, 0));
+        return 0;
+    };
+    if ((rc = upload(d_bt, bt)) || (rc = upload(d_btnr, btnr)) || (rc = upload(d_btnrp, btnrp)) || (rc = upload(d_invert, invert)) || (rc = upload(d_acgt, acgt)) ||
+        (rc = upload(d_ac, ac)) || (rc = upload(d_gt, gt)))
+        return rc;
+    if (with_klcp && (rc = upload(d_klcp, klcp))) return rc;
+    std::vector<uint64_t> h_binom(64 * 64);
+    uint8_t h_space[64];
+    rrr_tables(h_binom.data(), h_space);
+    if ((rc = d_binom.alloc(64 * 64 * 8)) || (rc = d_space.alloc(64)) || (rc = d_mask.alloc((n_words + 64) * 8)) || (rc = d_gtoff.alloc((n_words + 1) * 4)) ||
+        (rc = d_pc.alloc((n_words + 1) * 4)) || (rc = d_corrupt.alloc(4)))
+        return rc;
+    FMSI_HIP_TRY(hipMemcpyAsync(d_binom.p, h_binom.data(), 64 * 64 * 8, hipMemcpyHostToDevice, 0));
+    FMSI_HIP_TRY(hipMemcpyAsync(d_space.p, h_space, 64, hipMemcpyHostToDevice, 0));
+    FMSI_HIP_TRY(hipMemsetAsync(d_corrupt.p, 0, 4, 0));
+    FMSI_HIP_TRY(hipMemsetAsync(d_pc.p, 0, (n_words + 1) * 4, 0));
+
+    // ---- mask: RRR-63 -> plain words ---------------------------------------------------------------------------------------------
+    {
+        const uint64_t waves = (n_rrr_blocks + 63) / 64;
+        hipLaunchKernelGGL(rrr_decode_kernel, dim3(grid_for(waves * 64)), dim3(256), 0, 0, d_bt.as<uint64_t>(), d_btnr.as<uint64_t>(), btnr.bits,
+                           d_btnrp.as<uint64_t>(), static_cast<uint32_t>(btnrp.width), d_invert.as<uint64_t>(), d_binom.as<uint64_t>(), d_space.as<uint8_t>(), n,
+                           n_rrr_blocks, n_super, d_mask.as<uint64_t>(), n_words, d_corrupt.as<uint32_t>());
+        FMSI_HIP_TRY(hipGetLastError());
+    }
+    // ---- where every word's G/T bits start in `gt` --------------------------------------------------------------------------------
+    hipLaunchKernelGGL(word_popcount_kernel, dim3(grid_for(n_words)), dim3(256), 0, 0, d_acgt.as<uint64_t>(), n_words, n, d_pc.as<uint32_t>());
+    FMSI_HIP_TRY(hipGetLastError());
+    DevBuf scan_temp;
+    {
+        size_t tb = 0;
+        FMSI_HIP_TRY(rocprim::exclusive_scan(nullptr, tb, d_pc.as<uint32_t>(), d_gtoff.as<uint32_t>(), 0u, static_cast<size_t>(n_words + 1), rocprim::plus<uint32_t>()));
+        if ((rc = scan_temp.alloc(tb))) return rc;
+        FMSI_HIP_TRY(rocprim::exclusive_scan(scan_temp.p, tb, d_pc.as<uint32_t>(), d_gtoff.as<uint32_t>(), 0u, static_cast<size_t>(n_words + 1), rocprim::plus<uint32_t>()));
+    }
+    // ---- the blocks -----------------------------------------------------------------------------------------------------------------
+    DevBuf blocks, cnts, cnts_scanned, mcounts, mrank;
+    const size_t blocks_bytes = n_blocks * kBlockBytes;
+    if ((rc = blocks.alloc(blocks_bytes)) || (rc = cnts.alloc((n_blocks + 1) * sizeof(U4))) || (rc = cnts_scanned.alloc((n_blocks + 1) * sizeof(U4))) ||
+        (rc = mcounts.alloc((n_blocks + 1) * 4)) || (rc = mrank.alloc((n_blocks + 2) * 4)))
+        return rc;
+    FMSI_HIP_TRY(hipMemsetAsync(blocks.p, 0, blocks_bytes, 0));
+    FMSI_HIP_TRY(hipMemsetAsync(cnts.p, 0, (n_blocks + 1) * sizeof(U4), 0));
+    FMSI_HIP_TRY(hipMemsetAsync(mcounts.p, 0, (n_blocks + 1) * 4, 0));
+    hipLaunchKernelGGL(layout_words_kernel, dim3(static_cast<uint32_t>((n_words + 3) / 4)), dim3(256), 0, 0, d_acgt.as<uint64_t>(), d_ac.as<uint64_t>(), d_gt.as<uint64_t>(),
+                       d_mask.as<uint64_t>(), d_gtoff.as<uint32_t>(), n, n_words, blocks.as<uint32_t>(), cnts.as<U4>(), mcounts.as<uint32_t>());
+    FMSI_HIP_TRY(hipGetLastError());
+    {
+        size_t t1 = 0, t2 = 0;
+        FMSI_HIP_TRY(rocprim::exclusive_scan(nullptr, t1, cnts.as<U4>(), cnts_scanned.as<U4>(), U4{0, 0, 0, 0}, static_cast<size_t>(n_blocks + 1), U4Plus()));
+        FMSI_HIP_TRY(rocprim::exclusive_scan(nullptr, t2, mcounts.as<uint32_t>(), mrank.as<uint32_t>(), 0u, static_cast<size_t>(n_blocks + 1), rocprim::plus<uint32_t>()));
+        DevBuf t;
+        if ((rc = t.alloc(std::max(t1, t2)))) return rc;
+        FMSI_HIP_TRY(rocprim::exclusive_scan(t.p, t1, cnts.as<U4>(), cnts_scanned.as<U4>(), U4{0, 0, 0, 0}, static_cast<size_t>(n_blocks + 1), U4Plus()));
+        FMSI_HIP_TRY(rocprim::exclusive_scan(t.p, t2, mcounts.as<uint32_t>(), mrank.as<uint32_t>(), 0u, static_cast<size_t>(n_blocks + 1), rocprim::plus<uint32_t>()));
+        hipLaunchKernelGGL(scatter_counts_kernel, dim3(grid_for(n_blocks)), dim3(256), 0, 0, cnts_scanned.as<U4>(), blocks.as<uint32_t>(), n_blocks);
+        FMSI_HIP_TRY(hipGetLastError());
+        U4 totals;
+        uint32_t corrupt = 0, gt_total = 0;
+        FMSI_HIP_TRY(hipMemcpy(&totals, cnts_scanned.as<U4>() + n_blocks, sizeof(U4), hipMemcpyDeviceToHost));
+        FMSI_HIP_TRY(hipMemcpy(&corrupt, d_corrupt.p, 4, hipMemcpyDeviceToHost));
+        FMSI_HIP_TRY(hipMemcpy(&gt_total, d_gtoff.as<uint32_t>() + n_words, 4, hipMemcpyDeviceToHost));
+        FMSI_HIP_TRY(hipDeviceSynchronize());
+        if (corrupt) return load_fail(FMSI_HIP_EIO, "rrr_vector<63> image: block offsets run past the end of the offset vector");
+        if (gt_total != gt.bits) return load_fail(FMSI_HIP_EINVAL, "index view: popcount(ac_gt) != |gt|");
+    }
+    auto* idx = new fmsi_hip_index();
+    idx->device = device;
+    idx->n = n;
+    idx->k = k;
+    idx->n_blocks = n_blocks;
+    idx->d_blocks = blocks.release();
+    idx->d_mrank = mrank.release();
+    idx->device_bytes = blocks_bytes + (n_blocks + 2) * 4;
+    if (with_klcp) {
+        idx->d_klcp = d_klcp.release();
+        idx->has_klcp = 1;
+        idx->device_bytes += (klcp.words + 2) * 8;
+    }
+    if (dev_malloc(reinterpret_cast<void**>(&idx->d_counters), FMSI_HIP_N_COUNTERS * 8) != hipSuccess) {
+        fmsi_hip_index_destroy(idx);
+        return load_fail(FMSI_HIP_ENOMEM, "hipMalloc failed");
+    }
+    idx->dev.blocks = static_cast<const uint4*>(idx->d_blocks);
+    idx->dev.mrank = static_cast<const uint32_t*>(idx->d_mrank);
+    idx->dev.ptable = nullptr;
+    idx->dev.ptable_len = 0;
+    idx->dev.ptable_packed = 0;
+    idx->dev.n = static_cast<uint32_t>(n);
+    idx->dev.dollar = static_cast<uint32_t>(dollar);
+    idx->dev.C0 = static_cast<uint32_t>(counts[0]);
+    idx->dev.C1 = static_cast<uint32_t>(counts[1]);
+    idx->dev.C2 = static_cast<uint32_t>(counts[2]);
+    idx->dev.C3 = static_cast<uint32_t>(counts[3]);
+    for (int c = 0; c < 4; ++c) idx->counts64[c] = counts[c];
+    idx->dollar64 = dollar;
+    if (prefix_len > 0 && (rc = build_prefix_table(idx, prefix_len))) {
+        fmsi_hip_index_destroy(idx);
+        return rc;
+    }
+    *out = idx;
+    return 0;
+}

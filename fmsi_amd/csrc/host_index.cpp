@@ -123,6 +123,13 @@ inline void or_bits(uint64_t* words, uint64_t pos, uint64_t v) {
 
 }  // namespace
 
+void rrr_tables(uint64_t* c, uint8_t* space) {
+    const Binomials& B = binomials();
+    for (int n = 0; n < 64; ++n)
+        for (int k = 0; k < 64; ++k) c[n * 64 + k] = B.c[n][k];
+    std::memcpy(space, B.space, 64);
+}
+
 int decode_rrr63(const uint8_t* data, size_t size, BitVector& out, std::string& err) {
     const Binomials& B = binomials();
     Cursor cur{data, size};
@@ -193,6 +200,34 @@ int decode_rrr63(const uint8_t* data, size_t size, BitVector& out, std::string& 
         err = "rrr_vector<63> image: block offsets run past the end of the offset vector";
         return FMSI_HIP_EIO;
     }
+    return 0;
+}
+
+int peek_host_index(const std::string& prefix, uint64_t& n, int& k, bool& klcp_file) {
+    const std::string base = prefix + ".fmsi";
+    FILE* f = std::fopen((base + ".mask").c_str(), "rb");
+    if (!f) return FMSI_HIP_EIO;
+    uint64_t rows = 0;
+    const bool ok = std::fread(&rows, 8, 1, f) == 1;
+    std::fclose(f);
+    if (!ok) return FMSI_HIP_EIO;
+    f = std::fopen((base + ".misc").c_str(), "r");
+    if (!f) return FMSI_HIP_EIO;
+    unsigned long long d, c[4];
+    int kk = 0;
+    const int got = std::fscanf(f, "%llu %llu %llu %llu %llu %d", &d, &c[0], &c[1], &c[2], &c[3], &kk);
+    std::fclose(f);
+    if (got != 6) return FMSI_HIP_EIO;
+    for (const char* part : {".ac_gt", ".ac", ".gt"}) {
+        f = std::fopen((base + part).c_str(), "rb");
+        if (!f) return FMSI_HIP_EIO;
+        std::fclose(f);
+    }
+    f = std::fopen((base + ".klcp").c_str(), "rb");
+    klcp_file = f != nullptr;
+    if (f) std::fclose(f);
+    n = rows;
+    k = kk;
     return 0;
 }
 
@@ -294,6 +329,20 @@ int fmsi_host_index_load(const char* prefix, int use_klcp, fmsi_host_index** out
 }
 
 void fmsi_host_index_free(fmsi_host_index* h) { delete h; }
+
+int fmsi_host_index_peek(const char* prefix, uint64_t* n, int32_t* k, int32_t* has_klcp_file) {
+    if (!prefix || !n || !k || !has_klcp_file) return FMSI_HIP_EINVAL;
+    int kk = 0;
+    bool kl = false;
+    const int rc = fmsi::peek_host_index(prefix, *n, kk, kl);
+    if (rc) {
+        fmsi::set_last_error(std::string("cannot read the index files of ") + prefix);
+        return rc;
+    }
+    *k = kk;
+    *has_klcp_file = kl ? 1 : 0;
+    return 0;
+}
 
 int fmsi_host_index_view(const fmsi_host_index* h, fmsi_index_view* v) {
     if (!h || !v) return FMSI_HIP_EINVAL;

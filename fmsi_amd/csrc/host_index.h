@@ -29,9 +29,16 @@ struct HostIndex {
 // Returns 0 or a negative FMSI_HIP_E* code; on failure `err` holds the message.
 int load_host_index(const std::string& prefix, bool use_klcp, HostIndex& out, std::string& err);
 
+// rows, k and whether a .klcp file exists, from the files' headers alone (the CLI's checks before the device load)
+int peek_host_index(const std::string& prefix, uint64_t& n, int& k, bool& klcp_file);
+
 // rrr_vector<63> file image -> plain bits (reference src/sdsl-lite/include/sdsl/rrr_vector.hpp:145-238, 350-373;
 // rrr_helper.hpp:304-320).  Exposed for tests.
 int decode_rrr63(const uint8_t* data, size_t size, BitVector& out, std::string& err);
+
+// The RRR-63 decoder's tables for the on-device decoder (build_index.hip): c[n * 64 + k] = C(n, k) for n, k < 64 and the offset
+// widths per class.
+void rrr_tables(uint64_t* c /* 64 x 64 */, uint8_t* space /* 64 */);
 
 }  // namespace fmsi
 

@@ -1019,32 +1019,29 @@ extern "C" int fmsi_cli_query(int argc, char** argv, int output_orders_i) {
         if (opt.query_fn == "-" || stat(opt.query_fn.c_str(), &st) == 0) start_reader();
     }
 
-    fmsi_host_index* host = nullptr;
-    trace_push("fmsi: load index files");
-    const int rc_load = fmsi_host_index_load(opt.index_prefix.c_str(), opt.has_klcp, &host);
-    trace_pop();
-    if (rc_load != 0 || host->ix.n() == 0) {
+    // the index: its scalars from the files' headers now (the checks of ms_query, src/main.cpp:302-320), its payload straight into
+    // HBM below (fmsi_hip_index_load: RRR decode and block layout on the device)
+    uint64_t index_rows = 0;
+    int32_t index_k = 0, klcp_file = 0;
+    const int rc_load = fmsi_host_index_peek(opt.index_prefix.c_str(), &index_rows, &index_k, &klcp_file);
+    if (rc_load != 0 || index_rows == 0) {
         std::cerr << "ERROR: index not correctly loaded. Ensure that you correctly call `fmsi index` before." << std::endl;
         stop_reader();
         return usage_query(output_orders);
     }
-    if (opt.has_klcp != (host->ix.klcp.bits > 0)) {
+    if (opt.has_klcp && !klcp_file) {
         std::cerr << "ERROR: kLCP array was not constructed for the given index. Either construct it again without the `-s` flag or use `query -s` which slows down streaming queries." << std::endl;
-        fmsi_host_index_free(host);
         stop_reader();
         return usage_query(output_orders);
     }
     int k = opt.k;
-    if (k != 0 && k != host->ix.k) {
-        std::cerr << "ERROR: Mismatch. Provided k (" << k << ") does not match the k of the index (" << host->ix.k << ")." << std::endl;
-        fmsi_host_index_free(host);
+    if (k != 0 && k != index_k) {
+        std::cerr << "ERROR: Mismatch. Provided k (" << k << ") does not match the k of the index (" << index_k << ")." << std::endl;
         stop_reader();
         return usage_query(output_orders);
     }
-    if (k == 0) k = host->ix.k;
+    if (k == 0) k = index_k;
 
-    fmsi_index_view view;
-    fmsi_host_index_view(host, &view);
     // private accelerators (results unchanged).  How much of them: end to end this program moves 2-3 G windows/s (reader, copies,
     // formatting), and with a 14-deep prefix table the device stage -- kernels at about 5 G k-mers/s at human scale
     // plus the copies -- is level with that.  The k-mer dictionary (45 G k-mers/s on resident batches: bench.py) takes seconds
@@ -1060,9 +1057,9 @@ extern "C" int fmsi_cli_query(int argc, char** argv, int output_orders_i) {
     // `full`: presence queries (also -S ones: their answers do not depend on the kLCP array) are answered by the k-mer
     // dictionary, which needs no prefix table (a small one serves the few searches of its construction); lookup keeps the
     // 16-deep table
-    const bool want_dict = opt.full_tables && !opt.candidate_tables && !output_orders && k <= 32 && host->ix.n() > static_cast<uint64_t>(k);
+    const bool want_dict = opt.full_tables && !opt.candidate_tables && !output_orders && k <= 32 && index_rows > static_cast<uint64_t>(k);
     int t = std::min(k, want_dict ? 12 : (opt.full_tables ? 16 : 14));
-    while (t > 0 && (1ull << (2 * t)) > 4 * host->ix.n()) --t;
+    while (t > 0 && (1ull << (2 * t)) > 4 * index_rows) --t;
 
     // ---- one replicated handle per device (the index is read-only, the batches are independent) ---------------
     struct DeviceCtx {
@@ -1081,17 +1078,15 @@ extern "C" int fmsi_cli_query(int argc, char** argv, int output_orders_i) {
     // The accelerators are large: when HBM is short -- the GPU shared with other work -- the table shrinks (first device decides,
     // the others follow) and the optional ones are left out; only a failure of the index proper is an error.
     auto setup = [&](DeviceCtx& c, bool first) -> bool {
-        fmsi_index_view v = view;
         int rc_create = FMSI_HIP_ENOMEM;
         for (;;) {
-            v.prefix_len = std::max(t, 0);
-            rc_create = fmsi_hip_index_create(&v, c.device, &c.dev);
+            rc_create = fmsi_hip_index_load(opt.index_prefix.c_str(), opt.has_klcp, c.device, std::max(t, 0), &c.dev);
             if (rc_create != FMSI_HIP_ENOMEM || t <= 0 || !first) break;
             std::cerr << "WARNING: not enough device memory for a prefix table of depth " << t << ", trying " << std::max(t - 2, 0) << std::endl;
             t = std::max(t - 2, 0);
         }
         if (rc_create != 0) {
-            c.error = fmsi_hip_last_error();
+            c.error = rc_create == FMSI_HIP_EIO ? "index files" : fmsi_hip_last_error();
             return false;
         }
         fmsi_hip_index_info info;
@@ -1128,12 +1123,17 @@ extern "C" int fmsi_cli_query(int argc, char** argv, int output_orders_i) {
         if (!ok) {
             for (const DeviceCtx& c : ctx)
                 if (!c.error.empty()) {
+                    if (c.error == "index files") {   // malformed payload: what load_index() failing means to ms_query
+                        std::cerr << "ERROR: index not correctly loaded. Ensure that you correctly call `fmsi index` before." << std::endl;
+                        destroy_all();
+                        stop_reader();
+                        return usage_query(output_orders);
+                    }
                     if (c.error.rfind("-S and k > 32", 0) == 0) std::cerr << "ERROR: " << c.error << std::endl;
                     else std::cerr << "ERROR: cannot create the device index: " << c.error << std::endl;
                     break;
                 }
             destroy_all();
-            fmsi_host_index_free(host);
             stop_reader();
             return 1;
         }
@@ -1155,7 +1155,6 @@ extern "C" int fmsi_cli_query(int argc, char** argv, int output_orders_i) {
             start_reader();
         } catch (const std::invalid_argument&) {
             destroy_all();
-            fmsi_host_index_free(host);
             throw;   // uncaught in the reference too: abort, exit status 134
         }
     }
@@ -1318,6 +1317,5 @@ extern "C" int fmsi_cli_query(int argc, char** argv, int output_orders_i) {
                 ctx.size(), strict ? "true" : "false");
     }
     destroy_all();
-    fmsi_host_index_free(host);
     return exit_code;
 }

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define FMSI_HIP_ABI_VERSION 3   /* 2: fmsi_hip_index_info.candidate_entry_bytes, fmsi_hip_comm_*, fmsi_hip_gather; 3: FMSI_HIP_OUT_BITS, fmsi_hip_index_enable_dict + fmsi_hip_index_info.dict_*, fmsi_hip_index_build_synthetic_spec */
+#define FMSI_HIP_ABI_VERSION 3   /* 2: fmsi_hip_index_info.candidate_entry_bytes, fmsi_hip_comm_*, fmsi_hip_gather; 3: FMSI_HIP_OUT_BITS, fmsi_hip_index_load, fmsi_hip_trim_scratch, fmsi_hip_index_enable_dict + fmsi_hip_index_info.dict_*, fmsi_hip_index_build_synthetic_spec */
 
 /* error codes */
 #define FMSI_HIP_OK 0
@@ -136,6 +136,12 @@ int fmsi_hip_device_count(void);
 int fmsi_hip_index_create(const fmsi_index_view* view, int device, fmsi_hip_index** out);
 void fmsi_hip_index_destroy(fmsi_hip_index* idx);
 int fmsi_hip_index_get_info(const fmsi_hip_index* idx, fmsi_hip_index_info* info);
+
+/* load_index() (src/fms_index.h:502-526) straight into HBM: the files' payloads are uploaded as they are and the device decodes the
+ * rrr_vector<63> mask and interleaves the blocks itself -- the same handle as fmsi_host_index_load + fmsi_hip_index_create give, dword
+ * for dword, without the host-side decode and layout pass (what the CLI's load time mostly was).  use_klcp: take <prefix>.fmsi.klcp if
+ * it exists.  Malformed / missing files: FMSI_HIP_EIO.  Indexes of 2^32 rows and more take the host path internally. */
+int fmsi_hip_index_load(const char* prefix, int use_klcp, int device, int prefix_len, fmsi_hip_index** out);
 
 /* On-device construction -- counterpart of construct<T>() (src/fms_index.h:397-460) producing the device layout
  * directly: 2-bit text -> GPU suffix sort -> BWT / SA-transformed mask / kLCP -> interleaved blocks.
@@ -308,6 +314,8 @@ int fmsi_hip_gather(fmsi_hip_comm* comm, const void* d_send, uint64_t send_bytes
 int fmsi_host_index_load(const char* prefix, int use_klcp, fmsi_host_index** out);
 void fmsi_host_index_free(fmsi_host_index* h);
 int fmsi_host_index_view(const fmsi_host_index* h, fmsi_index_view* view);
+/* rows, k and whether <prefix>.fmsi.klcp exists, from the files' headers alone (what a caller checks before fmsi_hip_index_load) */
+int fmsi_host_index_peek(const char* prefix, uint64_t* n, int32_t* k, int32_t* has_klcp_file);
 
 /* The interleaved device layout built on the host (what fmsi_hip_index_create uploads): n_blocks blocks of
  * 16 dwords (64 B) covering 128 rows each -- dw0-3 cumulative #A,#C,#G,#T before the block, dw4-7 hi plane

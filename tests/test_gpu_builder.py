@@ -227,3 +227,55 @@ def test_synthetic_repeat_families_equal_oracle(fm, oracle_built, tmp_path):
         gf, gr = fm.decode_strict(got)
         assert np.array_equal(gf, fwd) and np.array_equal(gr, rc)
     assert int(cn[0]) > 0.02 * nq          # LF steps were needed: the candidate entries did not hold every key
+
+
+@pytest.mark.parametrize("name", ["integration_a", "integration_b", "sars_k13", "sars_k31", "mixed_k11", "repeats_k40", "repeats_k64"])
+def test_device_load_equals_host_load(fm, name):
+    """fmsi_hip_index_load (RRR-63 decode + block interleaving on the device, from the files' raw payloads) gives dword for dword
+    the layout fmsi_host_index_load + fmsi_hip_index_create build on the host -- blocks, mask ranks, kLCP, scalars -- on every
+    golden index (incl. inverted RRR superblocks in mixed_k11 and n % 63 == 0 cases) and answers the same."""
+    from conftest import index_prefix
+    prefix = index_prefix(name) if name in ("integration_a", "integration_b", "sars_k13", "sars_k31", "mixed_k11") else str(GOLDEN / "idx" / name)
+    a = fm.DeviceIndex.from_files(prefix, use_klcp=True, prefix_len=4)
+    b = fm.DeviceIndex.load(prefix, use_klcp=True, prefix_len=4)
+    ba, ma = a.download_layout()
+    bb, mb = b.download_layout()
+    assert np.array_equal(ba, bb) and np.array_equal(ma, mb)
+    ia, ib = a.info, b.info
+    assert (ia.n, ia.k, ia.has_klcp, ia.prefix_len, list(ia.counts), ia.dollar_position) == (ib.n, ib.k, ib.has_klcp, ib.prefix_len, list(ib.counts), ib.dollar_position)
+    assert np.array_equal(a.download_klcp()[: (ia.n + 63) // 64], b.download_klcp()[: (ia.n + 63) // 64])
+    nok = fm.DeviceIndex.load(prefix, use_klcp=False)
+    assert nok.info.has_klcp == 0
+    with pytest.raises(fm.FmsiError) as e:
+        fm.DeviceIndex.load(prefix + "_missing")
+    assert e.value.code == fm.E_IO
+
+
+def test_device_load_at_scale_and_corrupt_files(fm, oracle_built, tmp_path):
+    """1.2 M rows with a mixed mask (many superblocks, threaded host decode vs the device's), every row count n % 63 / n % 64 /
+    n % 128 boundary in a sweep of small sizes, and corrupt .mask images are FMSI_HIP_EIO on this path too."""
+    import struct
+    from conftest import synthetic_ms
+    for n, seed in [(1_200_000, 1)] + [(m, m) for m in (62, 63, 64, 125, 126, 127, 128, 129, 189, 190, 4031, 4032, 4033, 8063, 8064, 8065)]:
+        k = 5 if n < 1000 else 31
+        ms = synthetic_ms(n, k, seed=seed, mask="mixed")
+        prefix = str(tmp_path / f"i{n}")
+        oracle_py.Oracle.construct(ms, k, use_klcp=True).dump(prefix)
+        a = fm.DeviceIndex.from_files(prefix, use_klcp=True)
+        b = fm.DeviceIndex.load(prefix, use_klcp=True)
+        ba, ma = a.download_layout()
+        bb, mb = b.download_layout()
+        assert np.array_equal(ba, bb) and np.array_equal(ma, mb), n
+        assert np.array_equal(a.download_klcp()[: (n + 64) // 64], b.download_klcp()[: (n + 64) // 64]), n
+    good = open(prefix + ".fmsi.mask", "rb").read()
+    n_, bt_bits = struct.unpack_from("<QQ", good, 0)
+    off_btnr = 8 + 9 + ((bt_bits + 63) // 64) * 8
+    btnr_bits = struct.unpack_from("<Q", good, off_btnr)[0]
+    off_btnrp = off_btnr + 8 + ((btnr_bits + 63) // 64) * 8
+    bad = bytearray(good)
+    bad[off_btnrp + 9: off_btnrp + 17] = b"\xff" * 8
+    for image in (bytes(bad), good[: len(good) // 2]):
+        open(prefix + ".fmsi.mask", "wb").write(image)
+        with pytest.raises(fm.FmsiError) as e:
+            fm.DeviceIndex.load(prefix)
+        assert e.value.code == fm.E_IO
