@@ -1159,77 +1159,52 @@ extern "C" int fmsi_cli_query(int argc, char** argv, int output_orders_i) {
         }
     }
 
-    // formatting and writing are stages of their own: the formatter turns a batch into the bytes of its lines (team threads), the
-    // writer hands them to stdout
-    struct Formatted {
-        std::vector<char> buf;
-        std::vector<std::string> parts;
-    };
-    BoundedQueue<std::unique_ptr<Formatted>> write_q(2);
-    std::exception_ptr format_err;
-    std::thread format_thread([&] {
-        try {
-            std::unique_ptr<Prepared> P;
-            while (out_q.pop(P)) {
-                auto F = std::make_unique<Formatted>();
-                auto t0 = clock::now();
-                trace_push("fmsi: format");
-                if (output_orders) format_orders(*P, team, F->parts);
-                else format_bits(*P, team, F->buf);
-                trace_pop();
-                format_s += std::chrono::duration<double>(clock::now() - t0).count();
-                P.reset();
-                if (!write_q.push(std::move(F))) break;   // the writer failed
-            }
-        } catch (...) {
-            format_err = std::current_exception();
-        }
-        out_q.abort();     // (no-op after a normal end: closed and empty)
-        write_q.close();
-    });
     std::thread writer_thread([&] {
         try {
-            std::unique_ptr<Formatted> F;
-            while (write_q.pop(F)) {
+            std::unique_ptr<Prepared> P;
+            std::vector<char> buf;
+            std::vector<std::string> parts;
+            while (out_q.pop(P)) {
+                auto t0 = clock::now();
+                trace_push("fmsi: format");
+                if (output_orders) format_orders(*P, team, parts);
+                else format_bits(*P, team, buf);
+                trace_pop();
                 auto t1 = clock::now();
                 TraceRange write_range("fmsi: write");
                 if (output_orders) {
-                    for (const std::string& s : F->parts)
+                    for (const std::string& s : parts)
                         if (!s.empty() && std::fwrite(s.data(), 1, s.size(), stdout) != s.size()) throw std::runtime_error("write to stdout failed");
-                } else if (!F->buf.empty() && std::fwrite(F->buf.data(), 1, F->buf.size(), stdout) != F->buf.size()) {
+                } else if (!buf.empty() && std::fwrite(buf.data(), 1, buf.size(), stdout) != buf.size()) {
                     throw std::runtime_error("write to stdout failed");
                 }
+                format_s += std::chrono::duration<double>(t1 - t0).count();
                 write_s += std::chrono::duration<double>(clock::now() - t1).count();
-                F.reset();
+                P.reset();
             }
             std::fflush(stdout);
         } catch (...) {
             writer_err = std::current_exception();
-            write_q.abort();
             out_q.abort();
         }
     });
 
-    // ---- packing threads and device workers.  A packing thread takes the next raw batch (its number = its place in the output) and
-    // packs it; the device workers -- one per handle -- take the packed batches in order, each runs its batch on its device and
-    // files it under its number; this thread takes the finished batches in order for the sequential part -- the replay of the
-    // strand predictor -- and hands them on.  Packing, device time, replay, formatting and writing of consecutive batches overlap.
+    // ---- device workers: one per handle.  A worker takes the next raw batch (its number = its place in the output), packs it,
+    // runs it on its device and files it under that number; this thread takes the batches in order for the sequential part -- the
+    // replay of the strand predictor -- and hands them to the writer.  With one device this still overlaps a batch's packing and
+    // device time with the previous batch's replay.
     std::mutex done_m;
     std::condition_variable done_cv;
-    std::map<uint64_t, std::unique_ptr<Prepared>> packed_ready;   // packed batches waiting for a device
-    std::map<uint64_t, std::unique_ptr<Prepared>> done;           // finished batches waiting for their turn
-    uint64_t next_dev_seq = 0;                                    // the batch the next free device worker takes
-    uint64_t next_seq = 0;                                        // the batch this thread hands on next
-    const unsigned n_pack = std::max(2u, static_cast<unsigned>(ctx.size()));
-    unsigned packers_left = n_pack, workers_left = static_cast<unsigned>(ctx.size());
+    std::map<uint64_t, std::unique_ptr<Prepared>> done;   // finished batches waiting for their turn
+    uint64_t next_seq = 0;                                // the batch this thread hands on next
+    unsigned workers_left = static_cast<unsigned>(ctx.size());
     bool stop = false;
     std::exception_ptr worker_err;
     std::mutex stats_m;
-    const unsigned pack_team = std::max(1u, team / n_pack);
-    const uint64_t ahead = 2 * ctx.size() + 2;                    // batches that may be packed / finished beyond the next hand-over
+    const unsigned worker_team = std::max(1u, team / static_cast<unsigned>(ctx.size()));
     std::vector<std::thread> workers;
-    for (unsigned p = 0; p < n_pack; ++p)
-        workers.emplace_back([&] {
+    for (DeviceCtx& c : ctx)
+        workers.emplace_back([&, cp = &c] {
             try {
                 std::unique_ptr<RawBatch> raw;
                 uint64_t seq = 0;
@@ -1239,44 +1214,8 @@ extern "C" int fmsi_cli_query(int argc, char** argv, int output_orders_i) {
                     raw.reset();
                     auto t0 = clock::now();
                     trace_push("fmsi: pack batch");
-                    prepare_batch(*P, k, pack_team);
+                    prepare_batch(*P, k, worker_team);
                     trace_pop();
-                    const double dt = std::chrono::duration<double>(clock::now() - t0).count();
-                    {
-                        std::lock_guard<std::mutex> lk(stats_m);
-                        prep_s += dt;
-                    }
-                    std::unique_lock<std::mutex> lk(done_m);
-                    done_cv.wait(lk, [&] { return stop || seq < next_seq + ahead; });
-                    if (stop) break;
-                    packed_ready[seq] = std::move(P);
-                    done_cv.notify_all();
-                }
-            } catch (...) {
-                std::lock_guard<std::mutex> lk(done_m);
-                if (!worker_err) worker_err = std::current_exception();
-                stop = true;
-            }
-            std::lock_guard<std::mutex> lk(done_m);
-            --packers_left;
-            done_cv.notify_all();
-        });
-    for (DeviceCtx& c : ctx)
-        workers.emplace_back([&, cp = &c] {
-            try {
-                for (;;) {
-                    std::unique_ptr<Prepared> P;
-                    uint64_t seq = 0;
-                    {
-                        std::unique_lock<std::mutex> lk(done_m);
-                        done_cv.wait(lk, [&] { return stop || packed_ready.count(next_dev_seq) || packers_left == 0; });
-                        if (stop) break;
-                        auto it = packed_ready.find(next_dev_seq);
-                        if (it == packed_ready.end()) break;   // the packers are gone and the next batch never came: end of input
-                        seq = next_dev_seq++;
-                        P = std::move(it->second);
-                        packed_ready.erase(it);
-                    }
                     auto t1 = clock::now();
                     const uint64_t nw = P->windows;
                     if (output_orders) P->orders.resize(nw * (strict ? 2 : 1));
@@ -1294,13 +1233,17 @@ extern "C" int fmsi_cli_query(int argc, char** argv, int output_orders_i) {
                                   "fmsi_hip_query_runs");
                         check(fmsi_hip_sync(cp->dev, nullptr), "fmsi_hip_sync");
                     }
+                    auto t2 = clock::now();
                     PinVec<uint64_t>().swap(P->packed);
-                    const double dt = std::chrono::duration<double>(clock::now() - t1).count();
                     {
                         std::lock_guard<std::mutex> lk(stats_m);
-                        gpu_s += dt;
+                        prep_s += std::chrono::duration<double>(t1 - t0).count();
+                        gpu_s += std::chrono::duration<double>(t2 - t1).count();
                     }
-                    std::lock_guard<std::mutex> lk(done_m);
+                    std::unique_lock<std::mutex> lk(done_m);
+                    // (a worker runs at most one batch ahead of the hand-over: the map holds no more batches than there are workers)
+                    done_cv.wait(lk, [&] { return stop || seq < next_seq + 2 * ctx.size(); });
+                    if (stop) break;
                     done[seq] = std::move(P);
                     done_cv.notify_all();
                 }
@@ -1353,9 +1296,8 @@ extern "C" int fmsi_cli_query(int argc, char** argv, int output_orders_i) {
     out_q.close();
     for (std::thread& th : workers) th.join();
     reader_thread.join();
-    format_thread.join();
     writer_thread.join();
-    for (const std::exception_ptr& ep : {reader_err, format_err, writer_err, worker_err}) {
+    for (const std::exception_ptr& ep : {reader_err, writer_err, worker_err}) {
         if (!ep) continue;
         try {
             std::rethrow_exception(ep);
