@@ -58,7 +58,10 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", choices=["kmers", "stream"], default="kmers")
+    ap.add_argument("--workload", choices=["kmers", "stream", "e2e"], default="kmers",
+                    help="e2e: the whole `fmsi query` process (tools/e2e_bench.py: index files and a FASTA of --reads reads of --read-len bases in "
+                         "/dev/shm, the CLI with --stats, a sample against the real reference) -- SURVEY 8(d)(ii); N = 1 only")
+    ap.add_argument("--reads", type=int, default=100000, help="e2e workload: reads in the query file")
     ap.add_argument("--n", "--index-bases", dest="n", type=float, default=2.8e9, help="superstring length in bases (human scale: 2.8e9)")
     ap.add_argument("--batch", type=float, default=float(1 << 27), help="query windows per step and GPU")
     ap.add_argument("--k", type=int, default=31)
@@ -179,8 +182,40 @@ def measure_traffic(args, n, batch, k):
         f"2 x raw FETCH_SIZE {got['FETCH_SIZE'] / 1e9:.3f} GB (gfx950 tallies a 128-B request at 64 B) + WRITE_SIZE {got['WRITE_SIZE'] / 1e9:.3f} GB")
 
 
+def run_e2e(args):
+    """--workload e2e: one JSON line for the whole-process rate of the drop-in CLI (default mode), the other modes in `config`."""
+    import subprocess
+    cmd = [sys.executable, str(REPO / "tools" / "e2e_bench.py"), "--n", str(int(args.n)), "--reads", str(args.reads), "--read-len", str(args.read_len),
+           "--k", str(args.k), "--modes", "or,all,all_S,or_full", "--ref-reads", "20"]
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    report = None
+    for l in res.stdout.splitlines():
+        if l.startswith("{"):
+            report = json.loads(l)
+    if res.returncode != 0 or report is None:
+        sys.stderr.write(res.stderr[-2000:])
+        raise RuntimeError("tools/e2e_bench.py failed")
+    m = report["modes"]["or"]
+    modes = {name: {"wall_seconds": e["wall_seconds"], "process_seconds": e.get("total_seconds"), "load_seconds": e.get("load_seconds"),
+                    "windows_per_s_whole_process": e.get("windows_per_s_wall"), "windows_per_s_after_load": e.get("windows_per_s_after_load"),
+                    "identical_to_reference_on_sample": e.get("sample_identical_to_reference"), "reference_windows_per_s": e.get("reference_windows_per_s")}
+             for name, e in report["modes"].items()}
+    line = {"metric": "k-mer membership queries/sec (k=31), whole `fmsi query` process", "value": m["windows_per_s_wall"], "unit": "k-mers/s", "n_gpus": 1,
+            "steps": 1, "warmup": 0, "ms_per_step": m["wall_seconds"] * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32",
+            "data": "synthetic",
+            "config": {"workload": f"whole process: fmsi query -q <{report['fasta_bytes'] / 1e9:.2f} GB FASTA, {args.reads} reads of {args.read_len} bases> on a synthetic "
+                                   f"index of {int(args.n)} rows written in the reference's format ({report['index_bytes'] / 1e9:.2f} GB of files in /dev/shm), "
+                                   f"output to a file; wall time of the process incl. index load, parse, device, print",
+                       "windows": m["windows"], "modes": modes},
+            "roofline": None, "cpu_baseline": {"value": m.get("reference_windows_per_s"), "unit": "k-mers/s", "cores": 1, "kind": "reference",
+                                               "sample": "the reference CLI (oracle/_ref/fmsi_ref) on the first 20 reads of the same file, same index files"}}
+    print(json.dumps(line))
+
+
 def main():
     args = parse_args()
+    if args.workload == "e2e":
+        return run_e2e(args)
     # stdout carries the ONE JSON line and nothing else: libraries that print to the C stdout (RCCL's version banner at
     # communicator creation, flushed at exit) are sent to stderr for the whole run
     sys.stdout.flush()

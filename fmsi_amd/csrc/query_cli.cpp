@@ -1067,6 +1067,7 @@ extern "C" int fmsi_cli_query(int argc, char** argv, int output_orders_i) {
         fmsi_hip_index* dev = nullptr;
         bool have_dict = false;
         std::string error;
+        std::unique_ptr<std::mutex> busy = std::make_unique<std::mutex>();   // calls on one handle are not re-entrant: its two workers take turns
     };
     std::vector<DeviceCtx> ctx(opt.devices.size());
     for (size_t d = 0; d < ctx.size(); ++d) ctx[d].device = opt.devices[d];
@@ -1197,14 +1198,16 @@ extern "C" int fmsi_cli_query(int argc, char** argv, int output_orders_i) {
     std::condition_variable done_cv;
     std::map<uint64_t, std::unique_ptr<Prepared>> done;   // finished batches waiting for their turn
     uint64_t next_seq = 0;                                // the batch this thread hands on next
-    unsigned workers_left = static_cast<unsigned>(ctx.size());
+    // two workers per handle: while one has the device, the other packs the next batch
+    constexpr unsigned kWorkersPerDevice = 2;
+    unsigned workers_left = static_cast<unsigned>(ctx.size()) * kWorkersPerDevice;
     bool stop = false;
     std::exception_ptr worker_err;
     std::mutex stats_m;
     const unsigned worker_team = std::max(1u, team / static_cast<unsigned>(ctx.size()));
     std::vector<std::thread> workers;
-    for (DeviceCtx& c : ctx)
-        workers.emplace_back([&, cp = &c] {
+    for (unsigned wi = 0; wi < ctx.size() * kWorkersPerDevice; ++wi)
+        workers.emplace_back([&, cp = &ctx[wi / kWorkersPerDevice]] {
             try {
                 std::unique_ptr<RawBatch> raw;
                 uint64_t seq = 0;
@@ -1216,11 +1219,13 @@ extern "C" int fmsi_cli_query(int argc, char** argv, int output_orders_i) {
                     trace_push("fmsi: pack batch");
                     prepare_batch(*P, k, worker_team);
                     trace_pop();
-                    auto t1 = clock::now();
+                    auto t1 = clock::now(), td = t1;
                     const uint64_t nw = P->windows;
                     if (output_orders) P->orders.resize(nw * (strict ? 2 : 1));
                     else P->bytes.resize(nw);
                     if (nw) {
+                        std::lock_guard<std::mutex> device_turn(*cp->busy);
+                        td = clock::now();   // (device time: from the moment the handle is this worker's)
                         TraceRange device_range("fmsi: device (copy in, kernels, copy out)");
                         void* dst = output_orders ? static_cast<void*>(P->orders.data()) : static_cast<void*>(P->bytes.data());
                         if (opt.has_klcp && !cp->have_dict)   // -S: kLCP streaming kernel (query_kmers_streaming, src/fms_index.h:181-254)
@@ -1238,11 +1243,11 @@ extern "C" int fmsi_cli_query(int argc, char** argv, int output_orders_i) {
                     {
                         std::lock_guard<std::mutex> lk(stats_m);
                         prep_s += std::chrono::duration<double>(t1 - t0).count();
-                        gpu_s += std::chrono::duration<double>(t2 - t1).count();
+                        gpu_s += std::chrono::duration<double>(t2 - td).count();
                     }
                     std::unique_lock<std::mutex> lk(done_m);
                     // (a worker runs at most one batch ahead of the hand-over: the map holds no more batches than there are workers)
-                    done_cv.wait(lk, [&] { return stop || seq < next_seq + 2 * ctx.size(); });
+                    done_cv.wait(lk, [&] { return stop || seq < next_seq + 2 * kWorkersPerDevice * ctx.size(); });
                     if (stop) break;
                     done[seq] = std::move(P);
                     done_cv.notify_all();
