@@ -85,7 +85,10 @@ bool FastxReader::next() {
     int c;
     if (last_char_ == 0) {   // jump to the next header line
         while ((c = getc_()) >= 0 && c != '>' && c != '@') {}
-        if (c < 0) return false;
+        if (c < 0) {
+            clean_end_ = true;
+            return false;
+        }
         last_char_ = c;
     }
     name.clear();
@@ -113,7 +116,10 @@ bool FastxReader::next_append(std::string& text, size_t* name_off, size_t* name_
     int c;
     if (last_char_ == 0) {
         while ((c = getc_()) >= 0 && c != '>' && c != '@') {}
-        if (c < 0) return false;
+        if (c < 0) {
+            clean_end_ = true;
+            return false;
+        }
         last_char_ = c;
     }
     *name_off = text.size();

@@ -22,6 +22,9 @@ public:
     // start is not necessarily a record start and the file must not be cut at such lines.
     FastxReader(const unsigned char* data, size_t len);
     bool saw_fastq() const { return fastq_seen_; }
+    // after next() / next_append() returned false: did the input end between two records (true), or inside one -- a truncated or
+    // malformed record, which ends the stream (false)?  The block-parallel reader cuts FASTQ files only where every part ends clean.
+    bool clean_end() const { return clean_end_; }
     ~FastxReader();
     FastxReader(const FastxReader&) = delete;
     FastxReader& operator=(const FastxReader&) = delete;
@@ -51,6 +54,7 @@ private:
     size_t begin_ = 0, end_ = 0;
     bool eof_ = false;
     bool fastq_seen_ = false;
+    bool clean_end_ = false;
     int last_char_ = 0;
     std::string qual_;
 };

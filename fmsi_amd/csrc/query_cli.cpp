@@ -303,8 +303,9 @@ struct MappedFile {
         if (data) munmap(const_cast<unsigned char*>(data), size);
     }
 };
-// the query file as a mapping, if it is a regular, uncompressed file that starts with a FASTA header and is worth it
-bool map_plain_fasta(const std::string& path, MappedFile& m) {
+// the query file as a mapping, if it is a regular, uncompressed file that starts with a FASTA or FASTQ header and is worth it
+bool map_plain_fasta(const std::string& path, MappedFile& m, bool* fastq) {
+    *fastq = false;
     if (path == "-" || std::getenv("FMSI_HIP_SERIAL_READER")) return false;
     const int fd = open(path.c_str(), O_RDONLY);
     if (fd < 0) return false;
@@ -320,14 +321,36 @@ bool map_plain_fasta(const std::string& path, MappedFile& m) {
             m.data = static_cast<const unsigned char*>(p);
             m.size = static_cast<size_t>(st.st_size);
             (void)madvise(p, m.size, MADV_SEQUENTIAL);
-            if (m.data[0] != '>') ok = false;   // (a gzip stream starts with 0x1f 0x8b, a FASTQ file with '@')
+            if (m.data[0] == '@') *fastq = true;
+            else if (m.data[0] != '>') ok = false;   // (a gzip stream starts with 0x1f 0x8b)
         }
     }
     close(fd);
     return ok;
 }
+// FASTQ: first position >= from of a line that starts with '@' and whose next-but-one line starts with '+' -- in a file of 4-line
+// records that is a header and nothing else (a quality line may start with '@', but then the line after next is a sequence).
+// A wrong guess in an unusual file (multi-line quality) is harmless: the part before it then does not end between two records, its
+// reader says so (clean_end), and the ordinary reader takes over from there.
+size_t next_fastq_start(const unsigned char* d, size_t from, size_t end) {
+    auto next_line = [&](size_t p) -> size_t {
+        const void* nl = p < end ? std::memchr(d + p, '\n', end - p) : nullptr;
+        return nl ? static_cast<size_t>(static_cast<const unsigned char*>(nl) - d) + 1 : end;
+    };
+    size_t p = from;
+    if (p > 0 && p < end && d[p - 1] != '\n') p = next_line(p);
+    while (p < end) {
+        if (d[p] == '@') {
+            const size_t l2 = next_line(next_line(p));
+            if (l2 < end && d[l2] == '+') return p;
+        }
+        p = next_line(p);
+    }
+    return end;
+}
 // first position >= from (and < end) of a '>' that starts a line; `end` if there is none
-size_t next_record_start(const unsigned char* d, size_t from, size_t end) {
+size_t next_record_start(const unsigned char* d, size_t from, size_t end, bool fastq = false) {
+    if (fastq) return next_fastq_start(d, from, end);
     while (from < end) {
         const void* g = std::memchr(d + from, '>', end - from);
         if (!g) return end;
@@ -338,7 +361,7 @@ size_t next_record_start(const unsigned char* d, size_t from, size_t end) {
     return end;
 }
 // all records of d[lo, hi) (lo at a record start) through the ordinary reader; offsets relative to `text`
-bool parse_range(const unsigned char* d, size_t lo, size_t hi, std::string& text, std::vector<RecRef>& recs, uint64_t& seq_bytes) {
+bool parse_range(const unsigned char* d, size_t lo, size_t hi, std::string& text, std::vector<RecRef>& recs, uint64_t& seq_bytes, bool fastq = false) {
     FastxReader r(d + lo, hi - lo);
     text.reserve(hi - lo);
     for (;;) {
@@ -356,7 +379,9 @@ bool parse_range(const unsigned char* d, size_t lo, size_t hi, std::string& text
         recs.push_back(rr);
         seq_bytes += seq_len;
     }
-    return !r.saw_fastq();
+    // FASTA file: clean = no '+' line was met (then '>' lines are record starts).  FASTQ file: clean = the part ended between two
+    // records -- then the next part starts where the sequential parse would start a record, too.
+    return fastq ? r.clean_end() : !r.saw_fastq();
 }
 struct Prepared {
     RawBatch raw;
@@ -905,11 +930,11 @@ extern "C" int fmsi_cli_query(int argc, char** argv, int output_orders_i) {
     std::exception_ptr reader_err, writer_err;
     std::unique_ptr<FastxReader> reader;
     MappedFile mapped;
-    bool parallel_read = false;
+    bool parallel_read = false, parallel_fastq = false;
     std::thread reader_thread;
     auto start_reader = [&] {
         reader = std::make_unique<FastxReader>(opt.query_fn);   // throws std::invalid_argument like OpenFile(), src/parser.h:22
-        parallel_read = map_plain_fasta(opt.query_fn, mapped);
+        parallel_read = map_plain_fasta(opt.query_fn, mapped, &parallel_fastq);
         reader_thread = std::thread([&] {
         try {
             auto b = std::make_unique<RawBatch>();
@@ -923,11 +948,12 @@ extern "C" int fmsi_cli_query(int argc, char** argv, int output_orders_i) {
                 while (pos < mapped.size && !serial) {
                     // a range of about a batch, ending at a record start (or the end of the file)
                     size_t end = mapped.size;
-                    if (mapped.size - pos > opt.batch_windows + (opt.batch_windows >> 3))
-                        end = next_record_start(d, pos + opt.batch_windows, mapped.size);
+                    const uint64_t range_bytes = (parallel_fastq ? 2 : 1) * opt.batch_windows;   // (a FASTQ file is half qualities)
+                    if (mapped.size - pos > range_bytes + (range_bytes >> 3))
+                        end = next_record_start(d, pos + range_bytes, mapped.size, parallel_fastq);
                     std::vector<size_t> cuts{pos};
                     for (unsigned w = 1; w < workers; ++w) {
-                        const size_t c = next_record_start(d, pos + (end - pos) / workers * w, end);
+                        const size_t c = next_record_start(d, pos + (end - pos) / workers * w, end, parallel_fastq);
                         if (c > cuts.back() && c < end) cuts.push_back(c);
                     }
                     cuts.push_back(end);
@@ -941,7 +967,7 @@ extern "C" int fmsi_cli_query(int argc, char** argv, int output_orders_i) {
                     std::vector<std::thread> pool;
                     for (size_t w = 0; w < parts; ++w)
                         pool.emplace_back([&, w] {
-                            clean[w] = parse_range(d, cuts[w], cuts[w + 1], texts[w], recs[w], seq_bytes[w]) ? 1 : 0;
+                            clean[w] = parse_range(d, cuts[w], cuts[w + 1], texts[w], recs[w], seq_bytes[w], parallel_fastq) ? 1 : 0;
                             const size_t shift = cuts[w] - pos;
                             std::memcpy(nb->ext.get() + shift, texts[w].data(), texts[w].size());
                             for (RecRef& r : recs[w]) {

@@ -564,7 +564,8 @@ def test_block_parallel_reader_equals_the_ordinary_one(fm, oracle_built, tmp_pat
     ms = "".join(l.strip() for l in open(GOLDEN / "ref_data" / "GCF_009858895.2_ASM985889v3_genomic.fna.ms.k13") if not l.startswith(">"))
     data = messy_fasta(ms, random.Random(31 + (fastq_at or 7)), fastq_at)
     if fastq_at == 0:
-        data = data[data.index(b"@"):]        # a file that starts as FASTQ never takes the parallel path
+        data = data[data.index(b"@"):]        # a file that starts as FASTQ: cut at '@' lines whose next-but-one line starts with '+'
+                                              # (these records have '>' and '@' at the start of quality lines: parts that do not end clean)
     q = tmp_path / "messy.fa"
     q.write_bytes(data)
     args = [*MODES[mode][0], "-k", str(k), "--batch", "4096", "-q", str(q), index_prefix(name)]
@@ -580,6 +581,62 @@ def test_block_parallel_reader_equals_the_ordinary_one(fm, oracle_built, tmp_pat
     rc, ref, err = oracle_py.run_cli(checker, [a for a in args if a not in ("--batch", "4096")])
     assert rc == 0 and got == ref
     assert got.count(b"\n") > (100 if fastq_at != 0 else 50)
+
+
+@pytest.mark.parametrize("shape", ["four_line", "four_line_crlf", "wrapped_adversarial", "truncated_tail", "short_quality_inside", "no_final_newline"])
+def test_block_parallel_fastq_reader(fm, oracle_built, tmp_path, monkeypatch, shape):
+    """FASTQ files through the block-parallel reader: 4-line records are cut at header lines ('@' line whose next-but-one line starts
+    with '+'; quality lines that start with '@' or '+' do not fool it), every part is read by the ordinary reader (the reference's
+    kseq rules) and must end between two records -- where it does not (wrapped records with adversarial quality lines, a truncated
+    or corrupt record) the ordinary reader takes over at that range, so the output is the sequential parse's in every case."""
+    name, k = "sars_k13", 13
+    ms = "".join(l.strip() for l in open(GOLDEN / "ref_data" / "GCF_009858895.2_ASM985889v3_genomic.fna.ms.k13") if not l.startswith(">")).upper()
+    rng = random.Random(hash(shape) & 0xFFFF)
+    nl = b"\r\n" if shape == "four_line_crlf" else b"\n"
+    out = bytearray()
+    for r in range(1500):
+        L = rng.choice([13, 14, 40, 75, 151, 300])
+        p = rng.randrange(0, len(ms) - L)
+        seq = ms[p:p + L] if rng.random() < 0.6 else "".join(rng.choice("ACGTN") for _ in range(L))
+        qual = "".join(rng.choice("@+>IIIIFFF#5") for _ in range(L))
+        if r % 7 == 0:
+            qual = "@" + qual[1:]
+        if r % 11 == 0:
+            qual = "+" + qual[1:]
+        if shape == "short_quality_inside" and r == 700:
+            qual = qual[: L // 2]
+        if shape == "wrapped_adversarial":
+            w = 30
+            sl = [seq[i:i + w] for i in range(0, L, w)]
+            ql = [qual[i:i + w] for i in range(0, L, w)]
+            if len(ql) >= 3 and r % 3 == 0:     # a quality line starting with '@' whose next-but-one line starts with '+': a false header
+                ql[0] = "@" + ql[0][1:]
+                ql[2] = "+" + ql[2][1:]
+            out += f"@r{r} c".encode() + nl + nl.join(x.encode() for x in sl) + nl + b"+" + nl + nl.join(x.encode() for x in ql) + nl
+        else:
+            out += f"@r{r} comment".encode() + nl + seq.encode() + nl + (b"+" if r % 2 else f"+r{r}".encode()) + nl + qual.encode() + nl
+    data = bytes(out)
+    if shape == "truncated_tail":
+        data = data[: len(data) - 40]
+    if shape == "no_final_newline":
+        data = data.rstrip(b"\n")
+    q = tmp_path / "q.fq"
+    q.write_bytes(data)
+    for mode in ("or", "all_S"):
+        args = [*MODES[mode][0], "-k", str(k), "--batch", "4096", "-q", str(q), index_prefix(name)]
+        monkeypatch.setenv("FMSI_HIP_SERIAL_READER", "1")
+        rc, want, err = fm.run_cli(args)
+        assert rc == 0, err.decode()
+        monkeypatch.delenv("FMSI_HIP_SERIAL_READER")
+        monkeypatch.setenv("FMSI_HIP_READER_MIN_BYTES", "1")
+        rc, got, err = fm.run_cli(args)
+        assert rc == 0, err.decode()
+        monkeypatch.delenv("FMSI_HIP_READER_MIN_BYTES")
+        assert got == want
+        checker = oracle_py.REF_CLI if oracle_py.ref_available() else oracle_py.ORACLE_CLI
+        rc, ref, err = oracle_py.run_cli(checker, [a for a in args if a not in ("--batch", "4096")])
+        assert rc == 0 and got == ref
+        assert got.count(b"\n") > (600 if shape == "short_quality_inside" else 1400)
 
 
 def test_cli_exits_when_stdout_fails(fm, tmp_path):
