@@ -931,6 +931,7 @@ extern "C" int fmsi_cli_query(int argc, char** argv, int output_orders_i) {
     std::unique_ptr<FastxReader> reader;
     MappedFile mapped;
     bool parallel_read = false, parallel_fastq = false;
+    uint64_t parallel_read_bytes = 0;   // (--stats: how far the block-parallel reader got before it had to hand over, if it did)
     std::thread reader_thread;
     auto start_reader = [&] {
         reader = std::make_unique<FastxReader>(opt.query_fn);   // throws std::invalid_argument like OpenFile(), src/parser.h:22
@@ -989,6 +990,7 @@ extern "C" int fmsi_cli_query(int argc, char** argv, int output_orders_i) {
                         nb->seq_bytes += seq_bytes[w];
                     }
                     pos = end;
+                    parallel_read_bytes = pos;
                     if (nb->recs.empty()) continue;
                     // (the stages behind count records in 32 bits per batch like the ordinary reader's batches: at most 2^23)
                     if (nb->recs.size() > (1u << 23)) {
@@ -1343,9 +1345,9 @@ extern "C" int fmsi_cli_query(int argc, char** argv, int output_orders_i) {
         fprintf(stderr,
                 "{\"windows\": %llu, \"total_seconds\": %.6f, \"load_seconds\": %.6f, \"device_seconds\": %.6f, \"read_seconds\": %.6f, "
                 "\"prepare_seconds\": %.6f, \"replay_seconds\": %.6f, \"format_seconds\": %.6f, \"write_seconds\": %.6f, \"threads\": %u, "
-                "\"devices\": %zu, \"strict\": %s}\n",
+                "\"devices\": %zu, \"strict\": %s, \"block_parallel_read_bytes\": %llu}\n",
                 static_cast<unsigned long long>(total_windows), total, load, gpu_s, read_s, prep_s, replay_s, format_s, write_s, team,
-                ctx.size(), strict ? "true" : "false");
+                ctx.size(), strict ? "true" : "false", static_cast<unsigned long long>(parallel_read_bytes));
     }
     destroy_all();
     return exit_code;

@@ -629,10 +629,18 @@ def test_block_parallel_fastq_reader(fm, oracle_built, tmp_path, monkeypatch, sh
         assert rc == 0, err.decode()
         monkeypatch.delenv("FMSI_HIP_SERIAL_READER")
         monkeypatch.setenv("FMSI_HIP_READER_MIN_BYTES", "1")
-        rc, got, err = fm.run_cli(args)
+        rc, got, err = fm.run_cli([*args[:-1], "--stats", args[-1]])
         assert rc == 0, err.decode()
         monkeypatch.delenv("FMSI_HIP_READER_MIN_BYTES")
         assert got == want
+        import json as _json
+        par = _json.loads([l for l in err.decode().splitlines() if l.startswith("{")][-1])["block_parallel_read_bytes"]
+        if shape in ("four_line", "four_line_crlf", "no_final_newline"):
+            assert par == len(data)                     # the whole file went through the parallel parts
+        elif shape == "wrapped_adversarial":
+            assert par < len(data) // 4                 # a false header early on: the ordinary reader took over
+        else:
+            assert 0 < par < len(data)                  # up to the range with the broken record
         checker = oracle_py.REF_CLI if oracle_py.ref_available() else oracle_py.ORACLE_CLI
         rc, ref, err = oracle_py.run_cli(checker, [a for a in args if a not in ("--batch", "4096")])
         assert rc == 0 and got == ref
