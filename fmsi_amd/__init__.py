@@ -31,6 +31,7 @@ KERNEL_PAIR = 0x30
 KERNEL_PHASED = 0x40
 KERNEL_DICT = 0x50
 DICT_SPARSE = 0x1
+DICT_CHAIN = 0x2
 NO_PREFIX_TABLE = 0x100
 OUT_BITS = 0x200
 N_COUNTERS = 8
@@ -64,7 +65,7 @@ class IndexInfo(C.Structure):
         ("prefix_len", C.c_int32), ("block_bytes", C.c_uint64), ("block_symbols", C.c_uint64),
         ("n_blocks", C.c_uint64), ("device_bytes", C.c_uint64), ("counts", C.c_uint64 * 4), ("dollar_position", C.c_uint64),
         ("candidate_entry_bytes", C.c_uint64), ("dict_bytes", C.c_uint64), ("dict_keys", C.c_uint64 * 4), ("dict_ambiguous", C.c_uint64),
-        ("dict_levels", C.c_uint32), ("dict_log2_buckets", C.c_uint32), ("rows64", C.c_uint64),
+        ("dict_levels", C.c_uint32), ("dict_log2_buckets", C.c_uint32), ("dict_chain_bytes", C.c_uint64), ("rows64", C.c_uint64),
     ]
 
 
@@ -346,9 +347,10 @@ class DeviceIndex:
         _check(lib().fmsi_hip_index_get_info(self._h, C.byref(self.info)))
         return self
 
-    def enable_dict(self, sparse: bool = False):
-        """Add the k-mer dictionary (fmsi_hip_index_enable_dict): presence queries with the index's k become one bucket read."""
-        _check(lib().fmsi_hip_index_enable_dict(self._h, DICT_SPARSE if sparse else 0))
+    def enable_dict(self, sparse: bool = False, chain: bool = False):
+        """Add the k-mer dictionary (fmsi_hip_index_enable_dict): presence queries with the index's k become one bucket read;
+        chain: also the extras of chained lookups for reads (query_runs over reads of one length)."""
+        _check(lib().fmsi_hip_index_enable_dict(self._h, (DICT_SPARSE if sparse else 0) | (DICT_CHAIN if chain else 0)))
         _check(lib().fmsi_hip_index_get_info(self._h, C.byref(self.info)))
         return self
 

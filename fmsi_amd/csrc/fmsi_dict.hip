@@ -76,6 +76,59 @@ __device__ __forceinline__ uint4 load16_nt(const uint4* p) {
     return make_uint4(t.x, t.y, t.z, t.w);
 }
 
+constexpr uint32_t kFlagSelf = 0x40000000u;   // kernel-internal (never part of the ABI's flags): the construction's pass over the text's own k-mers
+
+// 64 hashes, one per lane (`active` lanes only), against one level: eight rounds of eight buckets.  Returns at the OWNING lane the
+// answer nibble of its k-mer (0: not in this bucket) | 16 when the bucket had overflowed (the key may be a level further) | the slot
+// it sits in << 8.  `tmp`: 64 words of LDS of this wave.
+__device__ __forceinline__ uint32_t dict_probe(const DictLevel L, uint64_t h, bool active, uint32_t lane, uint32_t* tmp) {
+    const uint32_t grp = lane >> 3, sub8 = lane & 7u;
+    const uint32_t bidx = static_cast<uint32_t>(h >> L.shift);
+    const uint64_t key = (h << (64u - L.shift)) >> (60u - L.shift);   // quotient << 4 (shift <= 60)
+    const uint32_t klo = static_cast<uint32_t>(key) | (active ? 1u : 0u), khi = static_cast<uint32_t>(key >> 32);
+    uint4 piece[8];
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {   // all loads first: eight lines per instruction, 64 in flight per wave
+        const int src = 8 * g + static_cast<int>(grp);
+        const uint32_t b = static_cast<uint32_t>(__shfl(static_cast<int>(bidx), src, 64));
+        const uint32_t a = static_cast<uint32_t>(__shfl(static_cast<int>(klo), src, 64)) & 1u;
+        piece[g] = make_uint4(0, 0, 0, 0);
+        if (a) piece[g] = load16_nt(L.buckets + (static_cast<size_t>(b) << 3) + sub8);
+    }
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+        const int src = 8 * g + static_cast<int>(grp);
+        const uint32_t wl = static_cast<uint32_t>(__shfl(static_cast<int>(klo), src, 64)) & ~15u;
+        const uint32_t wh = static_cast<uint32_t>(__shfl(static_cast<int>(khi), src, 64));
+        const uint4 p = piece[g];
+        uint32_t v = 0;
+        if (((p.x ^ wl) & ~15u) == 0u && p.y == wh && (p.x & 15u)) v = (p.x & 15u) | ((2u * sub8) << 8);     // (an empty or marker slot has nibble 0)
+        if (((p.z ^ wl) & ~15u) == 0u && p.w == wh && (p.z & 15u)) v = (p.z & 15u) | ((2u * sub8 + 1u) << 8);
+        if (sub8 == 7u && p.z == kMarkerLo && p.w == kMarkerHi) v |= 16u;
+        v |= static_cast<uint32_t>(__shfl_xor(static_cast<int>(v), 1, 64));
+        v |= static_cast<uint32_t>(__shfl_xor(static_cast<int>(v), 2, 64));
+        v |= static_cast<uint32_t>(__shfl_xor(static_cast<int>(v), 4, 64));
+        if (sub8 == 0u) tmp[src] = v;
+    }
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t mine = tmp[lane];
+    __builtin_amdgcn_wave_barrier();
+    return mine;
+}
+
+// answer nibble (0 = the k-mer is on neither strand) -> a window's result byte
+__device__ __forceinline__ uint8_t dict_encode(uint32_t ans, bool swapped, bool pal, uint32_t flags) {
+    if (flags & kFlagSelf) return static_cast<uint8_t>(ans);                // (construction: the nibble itself, per text position)
+    const uint32_t mode_all = flags & FMSI_HIP_MODE_ALL;
+    const uint32_t cc = ans & 3u, cr = pal ? cc : (ans >> 2);           // codes of the canonical k-mer and of its reverse complement
+    const uint32_t cf = swapped ? cr : cc, cb = swapped ? cc : cr;      // ... of the query as given and of its reverse complement
+    const int rf = cf == 0u ? -1 : static_cast<int>(mode_all ? cf == 3u : cf >= 2u);
+    const int rr = cb == 0u ? -1 : static_cast<int>(mode_all ? cb == 3u : cb >= 2u);
+    if (flags & FMSI_HIP_STRICT) return static_cast<uint8_t>(static_cast<uint32_t>(rf + 1) | (static_cast<uint32_t>(rr + 1) << 2));
+    // forward strand first, the reverse complement when it does not decide (src/fms_index.h:283-299)
+    return static_cast<uint8_t>(mode_all ? (rf != -1 ? rf : rr) == 1 : (rf == 1 || rr == 1));
+}
+
 // ---- the lookup kernel --------------------------------------------------------------------------------------------------
 // A wave owns a contiguous chunk of windows (<= 4096, a multiple of 128), as the other query kernels do; result bytes collect in
 // LDS and leave as 16 bytes per lane -- or bit-packed (FMSI_HIP_OUT_BITS).  RUNS: `kmers` is a 2-bit packed sequence and the
@@ -84,7 +137,7 @@ template <bool COUNT, bool RUNS>
 __global__ __launch_bounds__(256) void dict_lookup_kernel(DictIndex dx, const uint64_t* __restrict__ kmers, uint64_t n_windows, int k, uint32_t flags,
                                                           uint32_t chunk, uint8_t* __restrict__ out, unsigned long long* __restrict__ counters,
                                                           const uint64_t* __restrict__ run_start, const uint64_t* __restrict__ run_off, uint64_t n_runs,
-                                                          uint64_t u_start0, uint64_t u_stride, uint64_t u_wpr) {
+                                                          uint64_t u_start0, uint64_t u_stride, uint64_t u_wpr, uint32_t* __restrict__ slot_pos) {
     // (RUNS with u_wpr != 0: uniform runs -- run r is the u_wpr windows from base u_start0 + r * u_stride, reads of one length laid out
     // back to back -- and there is no run table to fetch or to search)
     constexpr uint32_t kMaxChunk = 4096u, kQueue = 128u;
@@ -93,10 +146,8 @@ __global__ __launch_bounds__(256) void dict_lookup_kernel(DictIndex dx, const ui
     __shared__ uint32_t s_tmp[4][64];        // probe results on their way from the serving lanes to the owning lane
     __shared__ __attribute__((aligned(16))) uint8_t s_res[4][kMaxChunk];
     const uint32_t strict = flags & FMSI_HIP_STRICT;
-    const uint32_t mode_all = flags & FMSI_HIP_MODE_ALL;
     const bool out_bits = (flags & FMSI_HIP_OUT_BITS) != 0u;
     const uint32_t lane = threadIdx.x & 63u, wib = threadIdx.x >> 6;
-    const uint32_t grp = lane >> 3, sub8 = lane & 7u;
     uint64_t* qh = s_qh[wib];
     uint32_t* qi = s_qi[wib];
     uint32_t* tmp = s_tmp[wib];
@@ -134,51 +185,11 @@ __global__ __launch_bounds__(256) void dict_lookup_kernel(DictIndex dx, const ui
         }
     }
 
-    // 64 hashes, one per lane (`active` lanes only), against level `lv`: eight rounds of eight buckets.  Returns at the OWNING lane
-    // the answer nibble of its k-mer (0: not in this bucket) | 16 when the bucket had overflowed (the key may be a level further)
-    auto probe = [&](uint32_t lv, uint64_t h, bool active) -> uint32_t {
-        const DictLevel L = dx.lv[lv];
-        const uint32_t bidx = static_cast<uint32_t>(h >> L.shift);
-        const uint64_t key = (h << (64u - L.shift)) >> (60u - L.shift);   // quotient << 4 (shift <= 60)
-        const uint32_t klo = static_cast<uint32_t>(key) | (active ? 1u : 0u), khi = static_cast<uint32_t>(key >> 32);
-        uint4 piece[8];
-#pragma unroll
-        for (int g = 0; g < 8; ++g) {   // all loads first: eight lines per instruction, 64 in flight per wave
-            const int src = 8 * g + static_cast<int>(grp);
-            const uint32_t b = static_cast<uint32_t>(__shfl(static_cast<int>(bidx), src, 64));
-            const uint32_t a = static_cast<uint32_t>(__shfl(static_cast<int>(klo), src, 64)) & 1u;
-            piece[g] = make_uint4(0, 0, 0, 0);
-            if (a) piece[g] = load16_nt(L.buckets + (static_cast<size_t>(b) << 3) + sub8);
-        }
-#pragma unroll
-        for (int g = 0; g < 8; ++g) {
-            const int src = 8 * g + static_cast<int>(grp);
-            const uint32_t wl = static_cast<uint32_t>(__shfl(static_cast<int>(klo), src, 64)) & ~15u;
-            const uint32_t wh = static_cast<uint32_t>(__shfl(static_cast<int>(khi), src, 64));
-            const uint4 p = piece[g];
-            uint32_t v = 0;
-            if (((p.x ^ wl) & ~15u) == 0u && p.y == wh) v = p.x & 15u;     // (an empty or marker slot has nibble 0)
-            if (((p.z ^ wl) & ~15u) == 0u && p.w == wh) v |= p.z & 15u;
-            if (sub8 == 7u && p.z == kMarkerLo && p.w == kMarkerHi) v |= 16u;
-            v |= static_cast<uint32_t>(__shfl_xor(static_cast<int>(v), 1, 64));
-            v |= static_cast<uint32_t>(__shfl_xor(static_cast<int>(v), 2, 64));
-            v |= static_cast<uint32_t>(__shfl_xor(static_cast<int>(v), 4, 64));
-            if (sub8 == 0u) tmp[src] = v;
-        }
-        __builtin_amdgcn_wave_barrier();
-        const uint32_t mine = tmp[lane];
-        __builtin_amdgcn_wave_barrier();
-        return mine;
-    };
-    // answer nibble (0 = the k-mer is on neither strand) -> this window's result byte
-    auto encode = [&](uint32_t ans, bool swapped, bool pal) -> uint8_t {
-        const uint32_t cc = ans & 3u, cr = pal ? cc : (ans >> 2);           // codes of the canonical k-mer and of its reverse complement
-        const uint32_t cf = swapped ? cr : cc, cb = swapped ? cc : cr;      // ... of the query as given and of its reverse complement
-        const int rf = cf == 0u ? -1 : static_cast<int>(mode_all ? cf == 3u : cf >= 2u);
-        const int rr = cb == 0u ? -1 : static_cast<int>(mode_all ? cb == 3u : cb >= 2u);
-        if (strict) return static_cast<uint8_t>(static_cast<uint32_t>(rf + 1) | (static_cast<uint32_t>(rr + 1) << 2));
-        // forward strand first, the reverse complement when it does not decide (src/fms_index.h:283-299)
-        return static_cast<uint8_t>(mode_all ? (rf != -1 ? rf : rr) == 1 : (rf == 1 || rr == 1));
+    auto probe = [&](uint32_t lv, uint64_t h, bool active) -> uint32_t { return dict_probe(dx.lv[lv], h, active, lane, tmp); };
+    auto encode = [&](uint32_t ans, bool swapped, bool pal) -> uint8_t { return dict_encode(ans, swapped, pal, flags); };
+    // construction's pass over the text (kFlagSelf): the slot of window q's k-mer learns q as its text position
+    auto note_position = [&](uint32_t lv, uint64_t h, uint32_t v, uint64_t q) {
+        if (slot_pos && (v & 15u)) slot_pos[dx.lv[lv].slot_base + ((h >> dx.lv[lv].shift) << 4) + ((v >> 8) & 15u)] = static_cast<uint32_t>(q);
     };
     // the queue's first `items` entries through the further levels
     auto slow_round = [&](uint32_t items) {
@@ -194,6 +205,7 @@ __global__ __launch_bounds__(256) void dict_lookup_kernel(DictIndex dx, const ui
                 n_reads++;
                 if ((v & 15u) || !(v & 16u)) {
                     ans = v & 15u;
+                    note_position(lv, h, v, start + (info & 0xFFFFu));
                     active = false;
                 }
             }
@@ -227,6 +239,7 @@ __global__ __launch_bounds__(256) void dict_lookup_kernel(DictIndex dx, const ui
             n_reads++;
             if ((v & 15u) || !(v & 16u)) {
                 n_final++;
+                note_position(0u, h, v, q);
                 res[ql] = encode(v & 15u, swapped, pal);
             } else {
                 slow = true;
@@ -268,6 +281,222 @@ __global__ __launch_bounds__(256) void dict_lookup_kernel(DictIndex dx, const ui
             if (lane == 0 && x) {
                 atomicAdd(&counters[slot[qq]], static_cast<unsigned long long>(x));
                 if (qq == 0) atomicAdd(&counters[1], static_cast<unsigned long long>(x));   // [1] counts the bucket reads with the blocks
+            }
+        }
+    }
+}
+
+
+// ---- chained lookups of reads ---------------------------------------------------------------------------------------------------
+// Consecutive windows of a read share k - 1 bases, and when the read comes from the superstring they sit at consecutive text
+// positions -- yet dict_lookup_kernel pays a bucket read for each.  With the construction's extras (FMSI_HIP_DICT_CHAIN: the 2-bit
+// text, the answer nibble of the k-mer at every text position, and per dictionary slot the position of one occurrence) a lane takes
+// 32 consecutive windows: it looks the first one up; if it is there it reads the occurrence's position, checks which way the read
+// runs along the text (the window equals the text's k-mer there, or its reverse complement), and from then on a window costs one
+// base compared with the text and one nibble of the per-position answers -- both cached in registers for the whole task (the answer
+// of a window is a function of its k-mer, and the k-mer is known to be the text's by induction from the exact match of the first).
+// A window that leaves the text (a substitution, the read's end, a read that never was in it) goes to the wave's queue of ordinary
+// lookups, done 64 at a time like everywhere else; so a random read costs what it cost, and a read from the text 6 requests per 32
+// windows instead of 32.  Uniform runs only (reads of one length; fmsi_hip_query_runs falls back to dict_lookup_kernel otherwise).
+// The wave's chunk = 64 tasks = 2048 windows of the OUTPUT order, so results leave exactly as from the other kernels.
+template <bool COUNT>
+__global__ __launch_bounds__(256) void dict_chain_kernel(DictIndex dx, const uint64_t* __restrict__ seq, uint64_t n_windows, int k, uint32_t flags,
+                                                         uint8_t* __restrict__ out, unsigned long long* __restrict__ counters, uint64_t u_start0,
+                                                         uint64_t u_stride, uint64_t u_wpr) {
+    constexpr uint32_t kTask = 32u, kChunk = 64u * kTask, kQueue = 128u;
+    __shared__ uint64_t s_qh[4][kQueue];
+    __shared__ uint32_t s_qi[4][kQueue];
+    __shared__ uint32_t s_tmp[4][64];
+    __shared__ __attribute__((aligned(16))) uint8_t s_res[4][kChunk];
+    const uint32_t strict = flags & FMSI_HIP_STRICT;
+    const bool out_bits = (flags & FMSI_HIP_OUT_BITS) != 0u;
+    const uint32_t lane = threadIdx.x & 63u, wib = threadIdx.x >> 6;
+    uint64_t* qh = s_qh[wib];
+    uint32_t* qi = s_qi[wib];
+    uint32_t* tmp = s_tmp[wib];
+    uint8_t* res = s_res[wib];
+    const uint64_t wave = (static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t start = wave * kChunk;
+    const uint32_t len = start < n_windows ? static_cast<uint32_t>(min(static_cast<uint64_t>(kChunk), n_windows - start)) : 0u;
+    uint32_t qhead = 0, qtail = 0;
+    uint32_t n_reads = 0, n_final = 0, n_side = 0;
+    const uint64_t kmask = k == 32 ? ~0ull : ((1ull << (2 * k)) - 1ull);
+    // the queue's first `items` entries: ordinary lookups from level 0 on
+    auto lookup_round = [&](uint32_t items) {
+        bool active = lane < items;
+        const uint32_t pos = (qhead + lane) & (kQueue - 1u);
+        uint64_t h = active ? qh[pos] : 0ull;
+        const uint32_t info = active ? qi[pos] : 0u;
+        uint32_t ans = 0;
+        for (uint32_t lv = 0; lv < dx.levels && __any(active); ++lv) {
+            if (lv) h = dict_mix(h + kLevelSalt[lv]);
+            const uint32_t v = dict_probe(dx.lv[lv], h, active, lane, tmp);
+            if (active) {
+                n_reads++;
+                if ((v & 15u) || !(v & 16u)) {
+                    ans = v & 15u;
+                    active = false;
+                }
+            }
+        }
+        if (lane < items) {
+            n_final++;
+            res[info & 0xFFFFu] = dict_encode(ans, (info >> 16) & 1u, (info >> 17) & 1u, flags);
+        }
+        qhead += items;
+    };
+    auto push_lookup = [&](bool want, uint64_t f, uint64_t rc, uint32_t ql) {   // (every lane of the wave comes here)
+        const uint64_t m = __ballot(want);
+        if (!m) return;
+        if (want) {
+            const bool swapped = rc < f;
+            const uint32_t pos = (qtail + lanes_below(m)) & (kQueue - 1u);
+            qh[pos] = dict_mix(swapped ? rc : f);
+            qi[pos] = ql | (swapped ? 0x10000u : 0u) | (rc == f ? 0x20000u : 0u);
+        }
+        qtail += static_cast<uint32_t>(__popcll(m));
+        while (qtail - qhead >= 64u) lookup_round(64u);
+    };
+    // base i (0..95) of three consecutive 32-base words
+    auto base3 = [](uint64_t w0, uint64_t w1, uint64_t w2, uint32_t i) -> uint32_t {
+        const uint64_t w = i < 32u ? w0 : (i < 64u ? w1 : w2);
+        return static_cast<uint32_t>(w >> (2u * (i & 31u))) & 3u;
+    };
+
+    // ---- my task: windows [t0, t0 + mine) of the chunk; the first n1 of them lie in the run of the first
+    const uint32_t t0 = lane * kTask;
+    const uint32_t mine = t0 < len ? min(kTask, len - t0) : 0u;
+    const uint64_t q0 = start + t0;
+    uint64_t f = 0, rc = 0, sw0 = 0, sw1 = 0, sw2 = 0, b0 = 0;
+    uint32_t n1 = 0;
+    if (mine) {
+        const uint64_t r = q0 / u_wpr;
+        n1 = static_cast<uint32_t>(min(static_cast<uint64_t>(mine), (r + 1u) * u_wpr - q0));
+        b0 = u_start0 + r * u_stride + (q0 - r * u_wpr);
+        const uint64_t* sp = seq + (b0 >> 5);           // bases b0 .. b0 + k + 30 lie in these three words
+        sw0 = sp[0];
+        sw1 = sp[1];
+        sw2 = (static_cast<uint32_t>(b0 & 31u) + static_cast<uint32_t>(k) + 30u >= 64u) ? sp[2] : 0ull;
+        const uint32_t sh = static_cast<uint32_t>(b0 & 31u) * 2u;
+        f = sw0 >> sh;
+        if (sh) f |= sw1 << (64u - sh);
+        f &= kmask;
+        rc = revcomp_2bit(f, k);
+    }
+    // ---- window 0 of every task: a dense lookup; those that are there become anchors
+    bool anchored = false;
+    int dir = 0;
+    uint64_t p = 0;                 // text position of the CURRENT window's k-mer (dir +1: it starts there; -1: its reverse complement does)
+    uint64_t tw0 = 0, tw1 = 0, tbase = 0, aw0 = 0, aw1 = 0, aw2 = 0, abase = 0;
+    {
+        const bool swapped = rc < f, pal = rc == f;
+        const uint64_t h = dict_mix(swapped ? rc : f);
+        const uint32_t v = dict_probe(dx.lv[0], h, mine != 0u, lane, tmp);
+        // (a first window whose bucket had overflowed and does not hold it takes the ordinary route: the 1 % of the keys that live in
+        // the further levels are not anchors)
+        const bool undecided = mine && !(v & 15u) && (v & 16u);
+        if (mine && !undecided) {
+            n_reads++;
+            n_final++;
+            res[t0] = dict_encode(v & 15u, swapped, pal, flags);
+            if ((v & 15u) && n1 > 1u) {   // where in the text, and which way the read runs along it
+                p = dx.slot_pos[dx.lv[0].slot_base + ((h >> dx.lv[0].shift) << 4) + ((v >> 8) & 15u)];
+                const uint64_t tk = window_kmer(dx.text2, p, k);
+                dir = tk == f ? 1 : (tk == rc ? -1 : 0);
+                n_side += 3u;
+                if (dir > 0) {   // text bases p + k .. p + k + 30, answers of positions p + 1 .. p + 31
+                    tbase = (p + static_cast<uint64_t>(k)) >> 5;
+                    abase = (p + 1u) >> 4;
+                } else if (dir < 0) {   // text bases p - 31 .. p - 1, answers of the same positions
+                    const uint64_t lo = p >= 31u ? p - 31u : 0ull;
+                    tbase = lo >> 5;
+                    abase = lo >> 4;
+                }
+                if (dir) {
+                    anchored = true;
+                    tw0 = dx.text2[tbase];
+                    tw1 = dx.text2[tbase + 1];
+                    aw0 = dx.posans[abase];
+                    aw1 = dx.posans[abase + 1];
+                    aw2 = dx.posans[abase + 2];
+                    n_side += 3u;
+                }
+            }
+        }
+        push_lookup(undecided, f, rc, t0);
+    }
+    // ---- windows 1 .. 31 of every task, the wave in lock-step over the window number
+    for (uint32_t j = 1; j < kTask; ++j) {
+        bool want = false;
+        if (j < mine) {
+            if (j < n1) {
+                const uint32_t nb = base3(sw0, sw1, sw2, static_cast<uint32_t>(b0 & 31u) + static_cast<uint32_t>(k) - 1u + j);
+                f = (f >> 2) | (static_cast<uint64_t>(nb) << (2 * (k - 1)));
+                rc = ((rc << 2) | (3u - nb)) & kmask;
+                if (anchored) {
+                    bool ok;
+                    uint64_t tp;   // the text position whose k-mer this window must equal (or mirror)
+                    if (dir > 0) {
+                        tp = p + j;
+                        ok = tp + static_cast<uint64_t>(k) <= dx.text_len;
+                        if (ok) {
+                            const uint64_t at = tp + static_cast<uint64_t>(k) - 1u - (tbase << 5);   // the window's last base in the text
+                            ok = (static_cast<uint32_t>((at < 32u ? tw0 : tw1) >> (2u * (at & 31u))) & 3u) == nb;
+                        }
+                    } else {
+                        ok = p >= j;
+                        tp = p - j;
+                        if (ok) {
+                            const uint64_t at = tp - (tbase << 5);                                  // the mirrored window's first base
+                            ok = (static_cast<uint32_t>((at < 32u ? tw0 : tw1) >> (2u * (at & 31u))) & 3u) == 3u - nb;
+                        }
+                    }
+                    if (ok) {
+                        const uint64_t at = tp - (abase << 4);
+                        const uint64_t aw = at < 16u ? aw0 : (at < 32u ? aw1 : aw2);
+                        n_final++;
+                        res[t0 + j] = dict_encode(static_cast<uint32_t>(aw >> (4u * (at & 15u))) & 15u, rc < f, rc == f, flags);
+                    } else {
+                        anchored = false;
+                        want = true;
+                    }
+                } else {
+                    want = true;
+                }
+            } else {   // (the task runs over the end of its read: the windows behind it are another read's)
+                const uint64_t q = q0 + j, r = q / u_wpr;
+                f = window_kmer(seq, u_start0 + r * u_stride + (q - r * u_wpr), k);
+                rc = revcomp_2bit(f, k);
+                want = true;
+            }
+        }
+        push_lookup(want, f, rc, t0 + j);
+    }
+    if (qtail != qhead) lookup_round(qtail - qhead);
+    if (len && out_bits) {
+        flush_packed_results(res, len, strict != 0u, out, start, lane);
+    } else if (len) {
+        uint8_t* dst = out + start;
+        const bool aligned = (reinterpret_cast<uintptr_t>(dst) & 15u) == 0;
+        for (uint32_t off = lane * 16u; off < len; off += 64u * 16u) {
+            if (aligned && off + 16u <= len) {
+                typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+                __builtin_nontemporal_store(*reinterpret_cast<const u32x4*>(res + off), reinterpret_cast<u32x4*>(dst + off));
+            } else {
+                for (uint32_t b = off; b < min(len, off + 16u); ++b) dst[b] = res[b];
+            }
+        }
+    }
+    if (COUNT) {
+        uint32_t v[4] = {n_reads, n_final, n_final, n_side};   // bucket reads; windows answered; searches; position / text / answer reads
+        const int slot[4] = {4, 6, 3, 7};
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) {
+            uint32_t x = v[qq];
+            for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+            if (lane == 0 && x) {
+                atomicAdd(&counters[slot[qq]], static_cast<unsigned long long>(x));
+                if (qq == 0 || qq == 3) atomicAdd(&counters[1], static_cast<unsigned long long>(x));   // [1]: every read the kernel makes
             }
         }
     }
@@ -474,13 +703,13 @@ int fill_level(const uint64_t* d_ukeys, const uint8_t* d_ucodes, uint64_t count,
 
 template <bool COUNT, bool RUNS>
 void launch_dict_t(const fmsi_hip_index* idx, const uint64_t* d_in, uint64_t n, int k, uint32_t flags, uint8_t* o8, unsigned long long* d_counters, hipStream_t s,
-                   const uint64_t* d_runs, uint64_t n_runs, const uint64_t* uniform) {
+                   const uint64_t* d_runs, uint64_t n_runs, const uint64_t* uniform, uint32_t* slot_pos = nullptr) {
     uint64_t chunk = n / (256ull * 4 * 2);
     chunk = std::min<uint64_t>(std::max<uint64_t>(chunk, 128), 4096) & ~127ull;
     const uint64_t waves = (n + chunk - 1) / chunk;
     hipLaunchKernelGGL((dict_lookup_kernel<COUNT, RUNS>), dim3(static_cast<uint32_t>((waves + 3) / 4)), dim3(256), 0, s, idx->dict, d_in, n, k, flags,
                        static_cast<uint32_t>(chunk), o8, d_counters, d_runs, d_runs + n_runs, n_runs, uniform ? uniform[0] : 0ull, uniform ? uniform[1] : 0ull,
-                       uniform ? uniform[2] : 0ull);
+                       uniform ? uniform[2] : 0ull, slot_pos);
 }
 
 }  // namespace
@@ -508,6 +737,21 @@ int launch_dict_query(fmsi_hip_index* idx, const uint64_t* d_in, uint64_t n, int
         if (d_counters) launch_dict_t<true, false>(idx, d_in, n, k, flags, o8, d_counters, s, nullptr, 0, nullptr);
         else launch_dict_t<false, false>(idx, d_in, n, k, flags, o8, d_counters, s, nullptr, 0, nullptr);
     }
+    FMSI_HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+bool dict_chain_applies(const fmsi_hip_index* idx, int k, uint32_t flags) {
+    static const bool off = std::getenv("FMSI_HIP_NO_CHAIN") != nullptr;   // A/B switch for measurements
+    return !off && idx->dict.slot_pos != nullptr && dict_applies(idx, k, flags);
+}
+
+int launch_dict_chain(fmsi_hip_index* idx, const uint64_t* d_seq, uint64_t n, int k, uint32_t flags, uint8_t* o8, unsigned long long* d_counters, hipStream_t s,
+                      const uint64_t* u) {
+    const uint64_t waves = (n + 2047) / 2048;
+    const dim3 grid(static_cast<uint32_t>((waves + 3) / 4)), block(256);
+    if (d_counters) hipLaunchKernelGGL((dict_chain_kernel<true>), grid, block, 0, s, idx->dict, d_seq, n, k, flags, o8, d_counters, u[0], u[1], u[2]);
+    else hipLaunchKernelGGL((dict_chain_kernel<false>), grid, block, 0, s, idx->dict, d_seq, n, k, flags, o8, d_counters, u[0], u[1], u[2]);
     FMSI_HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -579,7 +823,7 @@ extern "C" int fmsi_hip_index_enable_dict(fmsi_hip_index* idx, uint32_t flags) {
         if ((rc = temp.alloc(tb, "sort scratch"))) return rc;
         DICT_TRY(rocprim::radix_sort_pairs(temp.p, tb, dk, dv, static_cast<size_t>(windows), 0, 64, 0));
         clock.mark("radix sort");
-        text2.reset();
+        if (!(flags & FMSI_HIP_DICT_CHAIN)) text2.reset();   // (the chained form keeps the text)
         maskw.reset();
         // 3. distinct hashes: index of every occurrence's key among them
         const uint64_t* sk = dk.current();
@@ -650,6 +894,7 @@ extern "C" int fmsi_hip_index_enable_dict(fmsi_hip_index* idx, uint32_t flags) {
             if (p) (void)dev_free(p);
         return code;
     };
+    uint64_t total_slots = 0;
     DevMem cur_keys, cur_codes;
     cur_keys.p = ukeys.release();
     cur_codes.p = ucodes.release();
@@ -660,6 +905,8 @@ extern "C" int fmsi_hip_index_enable_dict(fmsi_hip_index* idx, uint32_t flags) {
         uint32_t n_spill = 0;
         if ((rc = fill_level(cur_keys.as<uint64_t>(), cur_codes.as<uint8_t>(), count, bits, buckets, spill_keys, spill_codes, &n_spill))) return fail(rc);
         dx.lv[lv].shift = 64u - bits;
+        dx.lv[lv].slot_base = total_slots;
+        total_slots += (1ull << bits) * kDictSlots;
         dx.lv[lv].buckets = static_cast<const uint4*>(buckets.p);
         owned[lv] = buckets.release();
         bytes_total += (1ull << bits) * 128;
@@ -698,5 +945,36 @@ extern "C" int fmsi_hip_index_enable_dict(fmsi_hip_index* idx, uint32_t flags) {
     for (uint32_t lv = 0; lv < kDictMaxLevels; ++lv) idx->d_dict[lv] = owned[lv];
     idx->dict_bytes = bytes_total;
     idx->device_bytes += bytes_total;
+    if (flags & FMSI_HIP_DICT_CHAIN) {
+        // The chained form's extras, by a pass of the lookup kernel over the text's own windows: the answer nibble of every text
+        // position (the kernel's STRICT | OUT_BITS packing of the raw nibbles) and, per slot, the position of an occurrence.
+        DevMem posans, slot_pos;
+        const uint64_t pa_words = (windows + 15) / 16 + 4;
+        if ((rc = posans.alloc(pa_words * 8, "answers per text position")) || (rc = slot_pos.alloc(total_slots * 4, "positions per slot"))) return rc;
+        DICT_TRY(hipMemset(posans.p, 0, pa_words * 8));
+        DICT_TRY(hipMemset(slot_pos.p, 0xFF, total_slots * 4));
+        const uint64_t whole_text[3] = {0, windows, windows};   // one run: every window of the superstring
+        launch_dict_t<false, true>(idx, text2.as<uint64_t>(), windows, k, FMSI_HIP_STRICT | FMSI_HIP_OUT_BITS | kFlagSelf, posans.as<uint8_t>(), nullptr, 0, nullptr, 0,
+                                   whole_text, slot_pos.as<uint32_t>());
+        DICT_TRY(hipGetLastError());
+        DICT_TRY(hipDeviceSynchronize());
+        uint64_t extra = pa_words * 8 + total_slots * 4;
+        if (!idx->d_text2) {   // (a handle built on the device already holds the same text)
+            idx->d_text2 = text2.release();
+            idx->text_len = len;
+            idx->dict_owns_text = true;
+            extra += ((len >> 6) + 2) * 16;
+        }
+        idx->d_posans = posans.release();
+        idx->d_slot_pos = slot_pos.release();
+        idx->dict.text2 = static_cast<const uint64_t*>(idx->d_text2);
+        idx->dict.posans = static_cast<const uint64_t*>(idx->d_posans);
+        idx->dict.slot_pos = static_cast<const uint32_t*>(idx->d_slot_pos);
+        idx->dict.text_len = len;
+        idx->dict_chain_bytes = extra;
+        idx->dict_bytes += extra;
+        idx->device_bytes += extra;
+        clock.mark("chain data (self pass)");
+    }
     return 0;
 }

@@ -844,7 +844,7 @@ void fmsi_hip_index_destroy(fmsi_hip_index* idx) {
     if (!idx) return;
     ::fmsi::DeviceGuard device_guard_(idx->device);
     for (void* p : {idx->d_super, idx->d_blocks, idx->d_mrank, idx->d_ptable, idx->d_klcp, idx->d_text2, idx->d_stable, idx->d_vtable, idx->d_in, idx->d_aux, idx->d_out,
-                    idx->d_kmers, idx->d_tasks, idx->d_bytes, idx->d_dict[0], idx->d_dict[1], idx->d_dict[2], idx->d_dict[3], idx->d_pblocks, idx->d_sbt, idx->d_c2, static_cast<void*>(idx->d_counters)})
+                    idx->d_kmers, idx->d_tasks, idx->d_bytes, idx->d_dict[0], idx->d_dict[1], idx->d_dict[2], idx->d_dict[3], idx->d_posans, idx->d_slot_pos, idx->d_pblocks, idx->d_sbt, idx->d_c2, static_cast<void*>(idx->d_counters)})
         if (p) (void)dev_free(p);
     for (auto& m : idx->meta_ring) {
         if (m.in_flight) (void)hipEventSynchronize(m.done);
@@ -879,6 +879,7 @@ int fmsi_hip_index_get_info(const fmsi_hip_index* idx, fmsi_hip_index_info* info
     info->dict_ambiguous = idx->dict_ambiguous;
     info->dict_levels = idx->dict.levels;
     info->dict_log2_buckets = idx->dict.levels ? 64u - idx->dict.lv[0].shift : 0u;
+    info->dict_chain_bytes = idx->dict_chain_bytes;
     return 0;
 }
 
@@ -1011,8 +1012,12 @@ int fmsi_hip_query_runs(fmsi_hip_index* idx, const uint64_t* packed_seq, uint64_
         // the dictionary's lookup kernel cuts the windows itself, too
         size_t slot;
         if ((rc = prof_begin(idx, s, &slot))) return rc;
-        if ((rc = launch_dict_query(idx, d_seq, n_windows, k, flags, static_cast<uint8_t*>(d_out), d_cnt, s, meta, n_runs, table_free ? uniform_runs : nullptr)))
+        if (table_free && dict_chain_applies(idx, k, flags)) {   // reads of one length and the chain data: 32 windows per lane along the text
+            if ((rc = launch_dict_chain(idx, d_seq, n_windows, k, flags, static_cast<uint8_t*>(d_out), d_cnt, s, uniform_runs))) return rc;
+        } else if ((rc = launch_dict_query(idx, d_seq, n_windows, k, flags, static_cast<uint8_t*>(d_out), d_cnt, s, meta, n_runs,
+                                           table_free ? uniform_runs : nullptr))) {
             return rc;
+        }
         if (!table_free && (rc = meta_commit(idx, meta_slot, s))) return rc;
         if ((rc = prof_end(idx, s, slot))) return rc;
         if (!dev_ptrs) {

@@ -42,11 +42,18 @@ constexpr uint32_t kDictMaxLevels = 4;
 struct DictLevel {
     const uint4* buckets;   // 2^(64 - shift) buckets x 8 x 16 bytes
     uint32_t shift, pad;    // bucket = hash >> shift
+    uint64_t slot_base;     // index of this level's first slot in the per-slot side arrays (chained lookups)
 };
 struct DictIndex {
     DictLevel lv[kDictMaxLevels];
     uint32_t levels;        // 0 = no dictionary
     int k;
+    // chained lookups of reads (FMSI_HIP_DICT_CHAIN; null without): the 2-bit superstring, the answer nibble of the k-mer at every text
+    // position (16 per u64 word) and, per dictionary slot, the text position of one occurrence of its k-mer
+    const uint64_t* text2;
+    const uint64_t* posans;
+    const uint32_t* slot_pos;
+    uint64_t text_len;
 };
 
 #define FMSI_HIP_TRY(expr)                                                                                 \
@@ -124,6 +131,10 @@ struct fmsi_hip_index {
     fmsi::DictIndex dict{};
     void* d_dict[fmsi::kDictMaxLevels] = {nullptr, nullptr, nullptr, nullptr};
     uint64_t dict_bytes = 0, dict_keys[fmsi::kDictMaxLevels] = {0, 0, 0, 0}, dict_ambiguous = 0;
+    void* d_posans = nullptr;     // chained lookups: answer nibble per text position
+    void* d_slot_pos = nullptr;   // ... and a text position per dictionary slot
+    bool dict_owns_text = false;  // d_text2 was made by the dictionary's construction
+    uint64_t dict_chain_bytes = 0;
     uint64_t text_len = 0;
     // staging for host-pointer calls
     void* d_in = nullptr; size_t d_in_cap = 0;
@@ -181,6 +192,11 @@ bool dict_applies(const fmsi_hip_index* idx, int k, uint32_t flags);
 // (uniform_runs != nullptr: {first base, stride, windows per run} of uniform runs -- no table, h_runs is not read)
 int launch_dict_query(fmsi_hip_index* idx, const uint64_t* d_in, uint64_t n, int k, uint32_t flags, uint8_t* o8, unsigned long long* d_counters, hipStream_t s,
                       const uint64_t* h_runs = nullptr, uint64_t n_runs = 0, const uint64_t* uniform_runs = nullptr);
+// uniform runs of a packed read batch through the chained form (needs the dictionary's chain data): a lane takes 32 consecutive
+// windows, looks the first one up and follows the superstring from its occurrence
+bool dict_chain_applies(const fmsi_hip_index* idx, int k, uint32_t flags);
+int launch_dict_chain(fmsi_hip_index* idx, const uint64_t* d_seq, uint64_t n, int k, uint32_t flags, uint8_t* o8, unsigned long long* d_counters, hipStream_t s,
+                      const uint64_t* uniform_runs);
 
 // FMSI_HIP_OUT_BITS: does launch_phased_query write the packed output itself for this (handle, k, flags)?  (otherwise the
 // caller has the kernels write bytes into a scratch buffer and packs them with launch_pack_results)

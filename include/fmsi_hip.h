@@ -120,6 +120,7 @@ typedef struct {
     uint64_t dict_keys[4];      /* distinct canonical k-mers handed to each of its levels (level 0: all of them; further: the overflow) */
     uint64_t dict_ambiguous;    /* keys whose `-O` answer was taken from the index's own search (occurrences with differing mask bits) */
     uint32_t dict_levels, dict_log2_buckets;   /* levels in use; log2 of level 0's bucket count */
+    uint64_t dict_chain_bytes;  /* 0, or the bytes of the chained lookups' extras (FMSI_HIP_DICT_CHAIN; included in dict_bytes) */
     uint64_t rows64;            /* 1: the handle keeps 64-bit rows (n >= 2^32 - 128; src/fms_index.h:98-103 uses size_t): plain search only --
                                    no prefix table, pair layout, candidate tables, dictionary, kLCP streaming, k > 32, export (FMSI_HIP_ERANGE) */
 } fmsi_hip_index_info;
@@ -225,6 +226,11 @@ int fmsi_hip_index_enable_verify(fmsi_hip_index* idx);
  * superstring and its mask come from the LF walk of fmsi_hip_index_export, answers that depend on the suffix order from the index's
  * own search, so any handle can add it.  ORDERS queries and other k take the other kernels.  Idempotent. */
 #define FMSI_HIP_DICT_SPARSE 0x1u
+/* ... and the extras of CHAINED lookups (+ about 6.5 bytes per k-mer: a text position per slot, an answer nibble per text position, the
+ * 2-bit text): fmsi_hip_query_runs over reads of one length then gives a lane 32 consecutive windows -- it looks the first one up and
+ * follows the superstring from its occurrence, a base compare and a nibble per further window; windows that leave the text take the
+ * ordinary lookups.  Same answers; several times fewer memory requests on reads that come from the indexed sequences. */
+#define FMSI_HIP_DICT_CHAIN 0x2u
 int fmsi_hip_index_enable_dict(fmsi_hip_index* idx, uint32_t flags);
 
 /* Replaces export_ms() (src/fms_index.h:462-473): the masked superstring of the index (upper case = mask 1), written

@@ -155,3 +155,67 @@ def test_dictionary_counters(fm):
     _, cn = dev.query_kmers(fm.pack_kmers(kmers, k), k, fm.MODE_ALL, counters=True)
     assert int(cn[0]) == 0 and int(cn[6]) == len(kmers)
     assert len(kmers) <= int(cn[4]) <= int(1.1 * len(kmers)) and int(cn[1]) == int(cn[4])
+
+
+@pytest.mark.parametrize("read_len,k,mask", [(150, 31, "mixed"), (62, 31, "mixed"), (45, 31, "ones"), (31, 31, "mixed"), (500, 13, "mixed"), (96, 32, "mixed"), (40, 8, "mixed")])
+def test_chained_lookups_of_reads(fm, oracle_built, read_len, k, mask):
+    """FMSI_HIP_DICT_CHAIN: reads of one length through fmsi_hip_query_runs take dict_chain_kernel -- a lane follows the superstring
+    from the occurrence of its task's first window.  Reads from the text in both orientations, with substitutions (the chain breaks and
+    the rest of the task takes ordinary lookups), random reads, reads that run to the text's two ends, tasks that straddle reads
+    (windows per read not a multiple of 32, and reads of fewer than 32 windows), small k (every k-mer occurs many times, on both
+    strands, with mixed mask bits): strand by strand what the oracle says, in both modes, as bytes and bit-packed, and equal to the
+    unchained dictionary."""
+    rng = random.Random(read_len * 100 + k)
+    n = 40_000 if k > 12 else 3_000
+    ms = synthetic_ms(n, k, seed=read_len + k, mask=mask)
+    orc = oracle_py.Oracle.construct(ms, k, use_klcp=False)
+    dev = fm.DeviceIndex.build(ms.encode(), k).enable_dict(chain=True)
+    plain = fm.DeviceIndex.build(ms.encode(), k).enable_dict()
+    assert dev.info.dict_chain_bytes > 0 and plain.info.dict_chain_bytes == 0
+    up = ms.upper()
+    reads = []
+    for r in range(700):
+        kind = r % 7
+        if kind in (0, 1, 2):
+            p = rng.randrange(0, len(up) - read_len + 1)
+            s = up[p:p + read_len]
+        elif kind == 3:
+            s = up[:read_len] if r % 2 else up[len(up) - read_len:]                   # the text's two ends
+        elif kind == 4:
+            s = "".join(rng.choice("ACGT") for _ in range(read_len))
+        else:
+            p = rng.randrange(0, len(up) - read_len + 1)
+            s = list(up[p:p + read_len])
+            for _ in range(1 + read_len // 60):
+                s[rng.randrange(read_len)] = rng.choice("ACGT")                        # substitutions
+            s = "".join(s)
+        if kind in (1, 5) or (kind == 3 and r % 4 == 3):
+            s = revcomp(s)
+        reads.append(s)
+    seq = "".join(reads)
+    words = fm.pack_sequence(seq.encode())
+    w = read_len - k + 1
+    starts = np.arange(len(reads), dtype=np.uint64) * np.uint64(read_len)
+    wins = np.full(len(reads), w, dtype=np.uint32)
+    kmers = [r[i:i + k] for r in reads for i in range(w)]
+    for mode_all in (False, True):
+        flag = fm.MODE_ALL if mode_all else fm.MODE_OR
+        fwd, rc = orc.ternaries_bulk("".join(kmers).encode(), len(kmers), k, mode_all)
+        got, cn = dev.query_runs(words, len(seq), starts, wins, k, flag | fm.STRICT, counters=True)
+        gf, gr = fm.decode_strict(got)
+        assert np.array_equal(gf, fwd) and np.array_equal(gr, rc), mode_all
+        assert np.array_equal(plain.query_runs(words, len(seq), starts, wins, k, flag | fm.STRICT), got)
+        bits = dev.query_runs(words, len(seq), starts, wins, k, flag | fm.OUT_BITS)
+        want_fast = (np.where(fwd != -1, fwd, rc) == 1) if mode_all else ((fwd == 1) | (rc == 1))
+        assert np.array_equal(fm.unpack_bits(bits, len(kmers), 0).astype(bool), want_fast)
+        assert int(cn[6]) == len(kmers)
+        if w >= 64 and k > 12:
+            assert int(cn[4]) < 0.6 * len(kmers)          # fewer bucket reads than windows: the chains really ran
+    # ragged runs are not chained and still right
+    starts2 = starts[:50].copy()
+    wins2 = wins[:50].copy()
+    wins2[::3] = max(1, w // 2)
+    km2 = [reads[r][i:i + k] for r in range(50) for i in range(int(wins2[r]))]
+    f2, r2 = orc.ternaries_bulk("".join(km2).encode(), len(km2), k, True)
+    g2f, g2r = fm.decode_strict(dev.query_runs(words, len(seq), starts2, wins2, k, fm.MODE_ALL | fm.STRICT))
+    assert np.array_equal(g2f, f2) and np.array_equal(g2r, r2)
