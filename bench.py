@@ -73,6 +73,9 @@ def parse_args():
                     help="private accelerator of the phased workload: dict = the k-mer dictionary (fmsi_hip_index_enable_dict: one 128-byte "
                          "bucket read per k-mer, ~12 bytes of HBM per distinct k-mer); tables = prefix table + candidate tables (177 GB at t = 16)")
     ap.add_argument("--dict-sparse", action="store_true", help="dictionary at half the load (twice the HBM, no second-level reads)")
+    ap.add_argument("--dict-chain", action="store_true",
+                    help="stream workload: the dictionary with the extras of chained lookups (FMSI_HIP_DICT_CHAIN, + about 6.5 B per k-mer): a lane "
+                         "follows the superstring from the occurrence of its 32-window task's first window")
     ap.add_argument("--hbm-budget", type=float, default=0.0,
                     help="GB of HBM the index and its accelerators may take (0 = no limit): picks the fastest configuration that fits -- "
                          "sparse dictionary, dictionary, or the LF walk behind the deepest prefix table that fits (DESIGN.md 4, footprint table)")
@@ -288,7 +291,7 @@ def main():
         t0 = time.time()
         if not stream_mode:
             index.enable_pair_layout()   # (the table-less LF-walk leg and the canonical-step count use it)
-        index.enable_dict(sparse=args.dict_sparse)
+        index.enable_dict(sparse=args.dict_sparse, chain=bool(args.dict_chain and stream_mode))
         accel_s = time.time() - t0
         build_s += accel_s
     if stream_mode and args.stream_via == "runs" and not use_dict:
@@ -552,7 +555,7 @@ def main():
             roof = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source if traffic is not None else None,
                     "traffic_over_algorithmic": round(traffic / bytes_launch, 4) if traffic else None,
-                    "kernel": "dict_lookup_kernel" if use_dict else ("query_stream_kernel" if stream_mode and args.stream_via == "klcp" else
+                    "kernel": ("dict_chain_kernel" if (args.dict_chain and stream_mode) else "dict_lookup_kernel") if use_dict else ("query_stream_kernel" if stream_mode and args.stream_via == "klcp" else
                                ("lookup_lane_kernel" if lane_lookups else "pair_lookup_kernel") + " + query_pair_kernel"
                                if args.kernel == "phased" or stream_mode else f"query_{args.kernel}_kernel"),
                     "avg_kernel_ms": round(avg_kernel_s * 1e3, 4), "launches": launches,
@@ -594,10 +597,11 @@ def main():
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed_max / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
             "config": {"workload": wl, "index_rows": int(info.n), "k": k, "queries_per_step_per_gpu": batch, "mode": args.mode,
-                       "kernel": ("dictionary-runs" if stream_mode else "dictionary") if use_dict else
+                       "kernel": (("dictionary-chained-runs" if args.dict_chain else "dictionary-runs") if stream_mode else "dictionary") if use_dict else
                                  (("phased-runs" if args.stream_via == "runs" else "stream") if stream_mode else args.kernel),
                        "accelerator": ({"kind": "k-mer dictionary", "bytes": int(info.dict_bytes), "levels": int(info.dict_levels),
                                         "log2_buckets": int(info.dict_log2_buckets), "keys_per_level": [int(x) for x in info.dict_keys][:int(info.dict_levels)],
+                                        "chain_bytes": int(info.dict_chain_bytes),
                                         "build_seconds": round(accel_s, 2)} if use_dict else
                                        {"kind": "prefix table + candidate tables", "prefix_table_len": int(info.prefix_len),
                                         "candidate_entry_bytes": int(info.candidate_entry_bytes)}),
