@@ -322,13 +322,15 @@ __global__ __launch_bounds__(256) void dict_chain_kernel(DictIndex dx, const uin
     uint32_t n_reads = 0, n_final = 0, n_side = 0;
     const uint64_t kmask = k == 32 ? ~0ull : ((1ull << (2 * k)) - 1ull);
     // the queue's first `items` entries: ordinary lookups from level 0 on
-    auto lookup_round = [&](uint32_t items) {
+    auto lookup_round = [&](uint32_t items) __attribute__((always_inline)) {
         bool active = lane < items;
         const uint32_t pos = (qhead + lane) & (kQueue - 1u);
         uint64_t h = active ? qh[pos] : 0ull;
         const uint32_t info = active ? qi[pos] : 0u;
         uint32_t ans = 0;
-        for (uint32_t lv = 0; lv < dx.levels && __any(active); ++lv) {
+#pragma unroll   // (constant level numbers: the levels' descriptors stay in scalar registers instead of a scratch copy of `dx`)
+        for (uint32_t lv = 0; lv < kDictMaxLevels; ++lv) {
+            if (lv >= dx.levels || !__any(active)) break;
             if (lv) h = dict_mix(h + kLevelSalt[lv]);
             const uint32_t v = dict_probe(dx.lv[lv], h, active, lane, tmp);
             if (active) {
@@ -345,7 +347,7 @@ __global__ __launch_bounds__(256) void dict_chain_kernel(DictIndex dx, const uin
         }
         qhead += items;
     };
-    auto push_lookup = [&](bool want, uint64_t f, uint64_t rc, uint32_t ql) {   // (every lane of the wave comes here)
+    auto push_lookup = [&](bool want, uint64_t f, uint64_t rc, uint32_t ql) __attribute__((always_inline)) {   // (every lane of the wave comes here)
         const uint64_t m = __ballot(want);
         if (!m) return;
         if (want) {
@@ -358,7 +360,7 @@ __global__ __launch_bounds__(256) void dict_chain_kernel(DictIndex dx, const uin
         while (qtail - qhead >= 64u) lookup_round(64u);
     };
     // base i (0..95) of three consecutive 32-base words
-    auto base3 = [](uint64_t w0, uint64_t w1, uint64_t w2, uint32_t i) -> uint32_t {
+    auto base3 = [](uint64_t w0, uint64_t w1, uint64_t w2, uint32_t i) __attribute__((always_inline)) -> uint32_t {
         const uint64_t w = i < 32u ? w0 : (i < 64u ? w1 : w2);
         return static_cast<uint32_t>(w >> (2u * (i & 31u))) & 3u;
     };
