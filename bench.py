@@ -73,9 +73,10 @@ def parse_args():
                     help="private accelerator of the phased workload: dict = the k-mer dictionary (fmsi_hip_index_enable_dict: one 128-byte "
                          "bucket read per k-mer, ~12 bytes of HBM per distinct k-mer); tables = prefix table + candidate tables (177 GB at t = 16)")
     ap.add_argument("--dict-sparse", action="store_true", help="dictionary at half the load (twice the HBM, no second-level reads)")
-    ap.add_argument("--dict-chain", action="store_true",
-                    help="stream workload: the dictionary with the extras of chained lookups (FMSI_HIP_DICT_CHAIN, + about 6.5 B per k-mer): a lane "
-                         "follows the superstring from the occurrence of its 32-window task's first window")
+    ap.add_argument("--no-dict-chain", dest="dict_chain", action="store_false",
+                    help="stream workload: the dictionary without the extras of chained lookups (FMSI_HIP_DICT_CHAIN, + about 7 B per k-mer: 58.7 "
+                         "instead of 39.0 GB at human scale), i.e. one bucket read per window; default: chained -- a lane follows the superstring "
+                         "from the occurrence of its 32-window task's first window")
     ap.add_argument("--hbm-budget", type=float, default=0.0,
                     help="GB of HBM the index and its accelerators may take (0 = no limit): picks the fastest configuration that fits -- "
                          "sparse dictionary, dictionary, or the LF walk behind the deepest prefix table that fits (DESIGN.md 4, footprint table)")

@@ -45,7 +45,7 @@ def device_answers(fm, dev, d_kmers, nq, k, flags):
     return d_out.cpu().numpy()
 
 
-def cross_check(fm, dev, k, nq, sample, seed=42, or_reference=True, with_dict=True):
+def cross_check(fm, dev, k, nq, sample, seed=42, or_reference=True, with_dict=True, chain=False):
     """nq seeded queries (half drawn from the superstring): kernels agree strand by strand in both modes; the first `sample`
     of them equal the oracle's ternaries on the exported index and (OR mode) the real reference's printed bits."""
     import torch
@@ -76,7 +76,7 @@ def cross_check(fm, dev, k, nq, sample, seed=42, or_reference=True, with_dict=Tr
         assert np.array_equal(fm.unpack_bits(d_bits.cpu().numpy().view(np.uint64), nq, 0), fast)
         strict[mode_name] = (f, r)
     if with_dict:   # the k-mer dictionary, added to the same handle: the same answers from one bucket read per k-mer
-        dev.enable_dict()
+        dev.enable_dict(chain=chain)
         for mode_name, mode in (("or", fm.MODE_OR), ("all", fm.MODE_ALL)):
             f, r = fm.decode_strict(device_answers(fm, dev, d_kmers, nq, k, mode | fm.STRICT | fm.KERNEL_DICT))
             assert np.array_equal(f, strict[mode_name][0]) and np.array_equal(r, strict[mode_name][1]), ("dictionary", mode_name)
@@ -137,9 +137,10 @@ def test_dictionary_at_human_scale(fm):
     import torch
     n, k = 2_800_000_000, 31
     dev = fm.DeviceIndex.build_synthetic(n, 12345, k).enable_pair_layout()
-    strict = cross_check(fm, dev, k, nq=1 << 22, sample=100_000, or_reference=False)
+    strict = cross_check(fm, dev, k, nq=1 << 22, sample=100_000, or_reference=False, chain=True)
     info = dev.info
-    assert info.dict_levels == 2 and info.dict_log2_buckets == 28 and info.dict_keys[0] > 2_799_000_000 and info.dict_bytes < 40e9
+    assert info.dict_levels == 2 and info.dict_log2_buckets == 28 and info.dict_keys[0] > 2_799_000_000
+    assert info.dict_bytes - info.dict_chain_bytes < 40e9 and 15e9 < info.dict_chain_bytes < 25e9
     f, r = strict["all"]
     assert 0.49 < ((f == 1) | (r == 1)).mean() < 0.51
     L, n_reads = 3000, 512
@@ -150,9 +151,10 @@ def test_dictionary_at_human_scale(fm):
     packed = d_reads.cpu().numpy().view(np.uint64)
     starts = np.arange(n_reads, dtype=np.uint64) * np.uint64(L)
     wins = np.full(n_reads, L - k + 1, dtype=np.uint32)
-    a = dev.query_runs(packed, n_reads * L, starts, wins, k, fm.MODE_ALL | fm.STRICT)                                  # dictionary
+    a, cn = dev.query_runs(packed, n_reads * L, starts, wins, k, fm.MODE_ALL | fm.STRICT, counters=True)               # dictionary, chained
     b = dev.query_runs(packed, n_reads * L, starts, wins, k, fm.MODE_ALL | fm.STRICT | fm.NO_PREFIX_TABLE)            # LF walk
     assert np.array_equal(a, b)
+    assert int(cn[4]) < 0.8 * a.size                       # (fewer bucket reads than windows: the chains ran)
     present = (((a & 3) == 2) | (((a >> 2) & 3) == 2)).reshape(n_reads, -1).mean(axis=1)
     assert 0.3 < (present > 0.5).mean() < 0.7 and ((present > 0.02) & (present < 0.5)).sum() == 0    # reads from the text keep ~73 % of their windows
 

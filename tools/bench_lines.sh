@@ -12,6 +12,8 @@ for l in sys.stdin:
 run --steps 10 --abi-gather
 run --no-pmc --workload stream --steps 10
 run --no-pmc --workload stream --subst-ppm 10000 --steps 10 --cpu-sample 0
+run --no-pmc --workload stream --no-dict-chain --steps 10 --cpu-sample 0
+run --no-pmc --workload stream --no-dict-chain --subst-ppm 10000 --steps 10 --cpu-sample 0
 run --no-pmc --workload stream --stream-via klcp --steps 10 --cpu-sample 0
 run --no-pmc --workload stream --stream-via klcp --subst-ppm 10000 --steps 10 --cpu-sample 0
 run --no-pmc --repeat-permille 300 --steps 10 --cpu-sample 0 --no-lf-leg
