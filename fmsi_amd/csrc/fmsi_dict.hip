@@ -807,10 +807,69 @@ struct PhaseClock {
 };
 }  // namespace
 
+namespace {
+// The chained form's extras, by a pass of the lookup kernel over the text's own windows: the answer nibble of every text position
+// (the kernel's STRICT | OUT_BITS packing of the raw nibbles) and, per slot, the position of an occurrence.  `text2`: the 2-bit text
+// the construction made (taken over when the handle has none of its own).
+int add_chain_extras(fmsi_hip_index* idx, DevMem& text2, uint64_t total_slots) {
+    const int k = idx->k;
+    const uint64_t len = idx->n - 1, windows = len - static_cast<uint64_t>(k) + 1;
+    int rc;
+    DevMem posans, slot_pos;
+    const uint64_t pa_words = (windows + 15) / 16 + 4;
+    if ((rc = posans.alloc(pa_words * 8, "answers per text position")) || (rc = slot_pos.alloc(total_slots * 4, "positions per slot"))) return rc;
+    DICT_TRY(hipMemset(posans.p, 0, pa_words * 8));
+    DICT_TRY(hipMemset(slot_pos.p, 0xFF, total_slots * 4));
+    const uint64_t* d_text = idx->d_text2 ? static_cast<const uint64_t*>(idx->d_text2) : text2.as<uint64_t>();
+    const uint64_t whole_text[3] = {0, windows, windows};   // one run: every window of the superstring
+    launch_dict_t<false, true>(idx, d_text, windows, k, FMSI_HIP_STRICT | FMSI_HIP_OUT_BITS | kFlagSelf, posans.as<uint8_t>(), nullptr, 0, nullptr, 0, whole_text,
+                               slot_pos.as<uint32_t>());
+    DICT_TRY(hipGetLastError());
+    DICT_TRY(hipDeviceSynchronize());
+    uint64_t extra = pa_words * 8 + total_slots * 4;
+    if (!idx->d_text2) {   // (a handle built on the device already holds the same text)
+        idx->d_text2 = text2.release();
+        idx->text_len = len;
+        idx->dict_owns_text = true;
+        extra += ((len >> 6) + 2) * 16;
+    }
+    idx->d_posans = posans.release();
+    idx->d_slot_pos = slot_pos.release();
+    idx->dict.text2 = static_cast<const uint64_t*>(idx->d_text2);
+    idx->dict.posans = static_cast<const uint64_t*>(idx->d_posans);
+    idx->dict.slot_pos = static_cast<const uint32_t*>(idx->d_slot_pos);
+    idx->dict.text_len = len;
+    idx->dict_chain_bytes = extra;
+    idx->dict_bytes += extra;
+    idx->device_bytes += extra;
+    return 0;
+}
+}  // namespace
+
 extern "C" int fmsi_hip_index_enable_dict(fmsi_hip_index* idx, uint32_t flags) {
     if (!idx) return FMSI_HIP_EINVAL;
     FMSI_HIP_NARROW_ONLY(idx, "the k-mer dictionary");
-    if (idx->dict.levels) return 0;
+    if (idx->dict.levels) {
+        if (!(flags & FMSI_HIP_DICT_CHAIN) || idx->dict.slot_pos) return 0;
+        // the dictionary is there, the chained lookups' extras are asked for now: the text (again from the LF walk when the handle keeps
+        // none) and the pass over it
+        FMSI_HIP_ON_DEVICE(idx->device);
+        DevMem text2;
+        if (!idx->d_text2) {
+            const uint64_t len = idx->n - 1, n64 = (len >> 6) + 2;
+            DevMem chars, maskw;
+            int rc;
+            if ((rc = chars.alloc(len + 1, "text")) || (rc = export_walk(idx, chars.as<char>(), nullptr)) || (rc = text2.alloc(n64 * 16, "text")) ||
+                (rc = maskw.alloc(n64 * 8, "mask")))
+                return rc;
+            hipLaunchKernelGGL(dict_planes_kernel, dim3(grid_of(n64)), dim3(256), 0, 0, chars.as<char>(), len, n64, text2.as<uint64_t>(), maskw.as<uint64_t>());
+            DICT_TRY(hipGetLastError());
+            DICT_TRY(hipDeviceSynchronize());
+        }
+        uint64_t total_slots = 0;
+        for (uint32_t lv = 0; lv < idx->dict.levels; ++lv) total_slots = idx->dict.lv[lv].slot_base + (16ull << (64u - idx->dict.lv[lv].shift));
+        return add_chain_extras(idx, text2, total_slots);
+    }
     PhaseClock clock;
     TraceRange trace_range("fmsi: build k-mer dictionary");
     const int k = idx->k;
@@ -978,34 +1037,7 @@ extern "C" int fmsi_hip_index_enable_dict(fmsi_hip_index* idx, uint32_t flags) {
     idx->dict_bytes = bytes_total;
     idx->device_bytes += bytes_total;
     if (flags & FMSI_HIP_DICT_CHAIN) {
-        // The chained form's extras, by a pass of the lookup kernel over the text's own windows: the answer nibble of every text
-        // position (the kernel's STRICT | OUT_BITS packing of the raw nibbles) and, per slot, the position of an occurrence.
-        DevMem posans, slot_pos;
-        const uint64_t pa_words = (windows + 15) / 16 + 4;
-        if ((rc = posans.alloc(pa_words * 8, "answers per text position")) || (rc = slot_pos.alloc(total_slots * 4, "positions per slot"))) return rc;
-        DICT_TRY(hipMemset(posans.p, 0, pa_words * 8));
-        DICT_TRY(hipMemset(slot_pos.p, 0xFF, total_slots * 4));
-        const uint64_t whole_text[3] = {0, windows, windows};   // one run: every window of the superstring
-        launch_dict_t<false, true>(idx, text2.as<uint64_t>(), windows, k, FMSI_HIP_STRICT | FMSI_HIP_OUT_BITS | kFlagSelf, posans.as<uint8_t>(), nullptr, 0, nullptr, 0,
-                                   whole_text, slot_pos.as<uint32_t>());
-        DICT_TRY(hipGetLastError());
-        DICT_TRY(hipDeviceSynchronize());
-        uint64_t extra = pa_words * 8 + total_slots * 4;
-        if (!idx->d_text2) {   // (a handle built on the device already holds the same text)
-            idx->d_text2 = text2.release();
-            idx->text_len = len;
-            idx->dict_owns_text = true;
-            extra += ((len >> 6) + 2) * 16;
-        }
-        idx->d_posans = posans.release();
-        idx->d_slot_pos = slot_pos.release();
-        idx->dict.text2 = static_cast<const uint64_t*>(idx->d_text2);
-        idx->dict.posans = static_cast<const uint64_t*>(idx->d_posans);
-        idx->dict.slot_pos = static_cast<const uint32_t*>(idx->d_slot_pos);
-        idx->dict.text_len = len;
-        idx->dict_chain_bytes = extra;
-        idx->dict_bytes += extra;
-        idx->device_bytes += extra;
+        if ((rc = add_chain_extras(idx, text2, total_slots))) return rc;
         clock.mark("chain data (self pass)");
     }
     return 0;

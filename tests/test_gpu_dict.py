@@ -211,6 +211,10 @@ def test_chained_lookups_of_reads(fm, oracle_built, read_len, k, mask):
         assert int(cn[6]) == len(kmers)
         if w >= 64 and k > 12:
             assert int(cn[4]) < 0.6 * len(kmers)          # fewer bucket reads than windows: the chains really ran
+    # the extras can be added to a dictionary that is already there (a handle from files keeps no text: the LF walk supplies it again)
+    plain.enable_dict(chain=True)
+    assert plain.info.dict_chain_bytes > 0
+    assert np.array_equal(plain.query_runs(words, len(seq), starts, wins, k, fm.MODE_ALL | fm.STRICT), dev.query_runs(words, len(seq), starts, wins, k, fm.MODE_ALL | fm.STRICT))
     # ragged runs are not chained and still right
     starts2 = starts[:50].copy()
     wins2 = wins[:50].copy()

@@ -364,3 +364,49 @@ def test_layout_of_many_chunks_equals_numpy(product_built):
     assert np.array_equal(blocks[:, 12:16], plane(maskbits))
     mcum = np.concatenate([[0], np.cumsum(pad(maskbits).reshape(nb, 128).sum(axis=1))])
     assert np.array_equal(mrank.astype(np.int64), mcum)
+
+
+def test_packed_result_helpers_and_synthetic_generators(product_built):
+    """The host-side mirrors the GPU tests and bench.py lean on, without a GPU: FMSI_HIP_OUT_BITS unpacking (bit w & 63 of word w >> 6;
+    STRICT: nibble w & 15 of word w >> 4), and the numpy restatements of the synthetic superstring and mask against the library's own
+    host functions (fmsi_hip_synthetic_text_word / _mask_bit), which is what lets tests/golden/make_scale_md5.py hand the REAL reference
+    the very text the device builder indexes."""
+    fm = product_built
+    w = np.array([0b1011, 1 << 63], dtype=np.uint64)
+    got = fm.unpack_bits(w, 70, 0)
+    assert got[:4].tolist() == [1, 1, 0, 1] and got[63] == 0 and got.size == 70 and got[4:63].sum() == 0
+    assert fm.unpack_bits(np.array([0xA5], dtype=np.uint64), 3, fm.STRICT).tolist() == [5, 10, 0]
+    assert (fm.packed_words(64, 0), fm.packed_words(65, 0), fm.packed_words(16, fm.STRICT), fm.packed_words(17, fm.STRICT)) == (1, 2, 1, 2)
+    L = fm.lib()
+    words = fm.synthetic_text_words(1000, 77)
+    for i in (0, 1, 7, 30):
+        assert int(words[i]) == L.fmsi_hip_synthetic_text_word(77, i)
+    assert int(words[31]) == L.fmsi_hip_synthetic_text_word(77, 31) & ((1 << (2 * (1000 - 31 * 32))) - 1)    # the last word is cut at the length
+    mask = fm.synthetic_mask(3000, 5, 31, 600)
+    assert all(int(mask[p]) == (L.fmsi_hip_synthetic_mask_bit(5, p, 600) if p + 31 <= 3000 else 0) for p in range(3000))
+    text = fm.synthetic_text(3000, 5, 31, 600)
+    assert all(chr(text[p]).isupper() == bool(mask[p]) for p in range(3000)) and text[-30:].islower()
+    assert fm.synthetic_text(200, 5, 31)[:170].isupper()
+
+
+def test_bench_defaults():
+    """bench.py's contract defaults (driver: `python bench.py` = N = 1, K = 10, W = 2) and the round-2 defaults: the k-mer dictionary,
+    bit-packed results with the copy inside the timed region, the LF-walk legs, chained lookups for the stream workload."""
+    import importlib.util
+    import sys
+    spec = importlib.util.spec_from_file_location("bench_mod", REPO / "bench.py")
+    m = importlib.util.module_from_spec(spec)
+    argv = sys.argv
+    try:
+        sys.argv = ["bench.py"]
+        spec.loader.exec_module(m)
+        a = m.parse_args()
+        assert (a.gpus, a.steps, a.warmup, a.workload, a.accel, a.byte_results, a.no_lf_leg, a.k) == (1, 10, 2, "kmers", "dict", False, False, 31)
+        assert int(a.n) == 2_800_000_000 and int(a.batch) == 1 << 27
+        sys.argv = ["bench.py", "--workload", "stream"]
+        a = m.parse_args()
+        assert a.stream_via == "runs" and a.dict_chain
+        sys.argv = ["bench.py", "--workload", "stream", "--accel", "tables"]
+        assert m.parse_args().stream_via == "klcp"
+    finally:
+        sys.argv = argv
