@@ -2,6 +2,10 @@
 // provided (`index`, `query`, `lookup`, `export`; reference dispatcher: src/main.cpp:668-699); everything else of the
 // reference's CLI (index construction, set operations, export, ...) is out of scope of this build and
 // says so instead of silently doing something different.
+#include <unistd.h>
+
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <iostream>
 #include <string>
@@ -27,8 +31,16 @@ static int usage() {
 int main(int argc, char* argv[]) {
     if (argc < 2) return usage();
     const std::string op = argv[1];
-    if (op == "query") return fmsi_cli_query(argc - 1, argv + 1, 0);
-    if (op == "lookup") return fmsi_cli_query(argc - 1, argv + 1, 1);
+    if (op == "query" || op == "lookup") {
+        // The process ends with the command: what it wrote is flushed, and the teardown of the device context, of gigabytes of HBM and
+        // of the page-locked batch buffers is left to the operating system (0.1-0.2 s of a 0.9 s run at human scale).
+        setenv("FMSI_HIP_CLI_NO_TEARDOWN", "1", 0);
+        const int rc = fmsi_cli_query(argc - 1, argv + 1, op == "lookup" ? 1 : 0);
+        std::cout.flush();
+        std::cerr.flush();
+        std::fflush(nullptr);
+        _exit(rc);
+    }
     if (op == "index") return fmsi_cli_index(argc - 1, argv + 1);
     if (op == "export") return fmsi_cli_export(argc - 1, argv + 1);
     if (op == "-v") {

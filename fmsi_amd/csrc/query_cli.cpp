@@ -1349,6 +1349,6 @@ extern "C" int fmsi_cli_query(int argc, char** argv, int output_orders_i) {
                 static_cast<unsigned long long>(total_windows), total, load, gpu_s, read_s, prep_s, replay_s, format_s, write_s, team,
                 ctx.size(), strict ? "true" : "false", static_cast<unsigned long long>(parallel_read_bytes));
     }
-    destroy_all();
+    if (!std::getenv("FMSI_HIP_CLI_NO_TEARDOWN")) destroy_all();   // (the `fmsi` binary exits right behind this call: main.cpp)
     return exit_code;
 }
