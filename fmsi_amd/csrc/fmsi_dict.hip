@@ -600,33 +600,40 @@ struct HeadFlag {
     __host__ __device__ uint32_t operator()(uint64_t i) const { return (i == 0 || keys[i] != keys[i - 1]) ? 1u : 0u; }
 };
 
-// One thread per occurrence; the first of each run of equal hashes folds the run into the key's answer nibble.  Per orientation
-// (0: the occurrence reads the canonical k-mer, 1: its reverse complement): code 0 absent, 1 all occurrences OFF, 3 all ON; when ON
-// and OFF occurrences mix, the default mode's answer is 1 and `-O`'s is the mask bit of the interval's FIRST row, which only the
-// suffix order knows -- such keys get code 2 for now and go to the list the index itself resolves (dict_patch_kernel).
-__global__ __launch_bounds__(256) void dict_fold_kernel(const uint64_t* __restrict__ keys, const uint8_t* __restrict__ vals, const uint32_t* __restrict__ uidx,
-                                                        uint64_t n, uint64_t* __restrict__ ukeys, uint8_t* __restrict__ ucodes,
-                                                        uint64_t* __restrict__ amb_kmers, uint32_t* __restrict__ amb_where, uint32_t amb_cap,
-                                                        uint32_t* __restrict__ amb_count) {
+// One thread per occurrence of the sorted (hash, mask bit | orientation) pairs.  A key with ONE occurrence (nearly all of them) gets its
+// code at once.  The occurrences of a repeated key OR their (orientation, ON / OFF) bit into the key's flag byte -- atomics on the
+// containing dword, so a key with a million occurrences (poly-A) costs a million atomics, not a million iterations of one thread --
+// and dict_codes_kernel turns the flags into codes: per orientation (0: the occurrence reads the canonical k-mer, 1: its reverse
+// complement) code 0 absent, 1 all occurrences OFF, 3 all ON; when ON and OFF occurrences mix, the default mode's answer is 1 and
+// `-O`'s is the mask bit of the interval's FIRST row, which only the suffix order knows -- such keys get code 2 for now and go to the
+// list the index itself resolves (dict_patch_kernel).
+__global__ __launch_bounds__(256) void dict_flags_kernel(const uint64_t* __restrict__ keys, const uint8_t* __restrict__ vals, const uint32_t* __restrict__ uidx,
+                                                         uint64_t n, uint64_t* __restrict__ ukeys, uint8_t* __restrict__ ucodes, uint32_t* __restrict__ kflags32) {
     const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
     for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) {
         const uint64_t key = keys[i];
-        if (i != 0 && keys[i - 1] == key) continue;
-        uint32_t on[2] = {0, 0}, off[2] = {0, 0};
-        for (uint64_t j = i; j < n && keys[j] == key; ++j) {
-            const uint32_t v = vals[j];
-            if (v & 1u) on[v >> 1] = 1u;
-            else off[v >> 1] = 1u;
-        }
+        const bool head = i == 0 || keys[i - 1] != key, last = i + 1 == n || keys[i + 1] != key;
+        const uint32_t u = uidx[i] - (head ? 0u : 1u), v = vals[i];   // (uidx counts the heads before i)
+        if (head) ukeys[u] = key;
+        if (head && last) ucodes[u] = static_cast<uint8_t>(((v & 1u) ? 3u : 1u) << (2u * (v >> 1)));
+        else atomicOr(kflags32 + (u >> 2), (1u << ((v >> 1) * 2u + (v & 1u))) << (8u * (u & 3u)));
+    }
+}
+__global__ __launch_bounds__(256) void dict_codes_kernel(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ uidx, uint64_t n,
+                                                         const uint8_t* __restrict__ kflags, uint8_t* __restrict__ ucodes, uint64_t* __restrict__ amb_kmers,
+                                                         uint32_t* __restrict__ amb_where, uint32_t amb_cap, uint32_t* __restrict__ amb_count) {
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
+    for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const uint64_t key = keys[i];
+        if ((i != 0 && keys[i - 1] == key) || i + 1 == n || keys[i + 1] != key) continue;   // heads of repeated keys only
+        const uint32_t u = uidx[i], fl = kflags[u];
         uint32_t code = 0, amb = 0;
 #pragma unroll
         for (int o = 0; o < 2; ++o) {
-            const uint32_t c = on[o] ? (off[o] ? 2u : 3u) : (off[o] ? 1u : 0u);
-            code |= c << (2 * o);
-            if (on[o] && off[o]) amb |= 1u << o;
+            const uint32_t off = (fl >> (2 * o)) & 1u, on = (fl >> (2 * o + 1)) & 1u;
+            code |= (on ? (off ? 2u : 3u) : (off ? 1u : 0u)) << (2 * o);
+            if (on && off) amb |= 1u << o;
         }
-        const uint32_t u = uidx[i];
-        ukeys[u] = key;
         ucodes[u] = static_cast<uint8_t>(code);
         if (amb) {
             const uint32_t at = atomicAdd(amb_count, 1u);
@@ -936,6 +943,12 @@ extern "C" int fmsi_hip_index_enable_dict(fmsi_hip_index* idx, uint32_t flags) {
         const uint32_t amb_cap = static_cast<uint32_t>(std::min<uint64_t>(n_unique, 0x7FFFFFFFull));
         if ((rc = ukeys.alloc(n_unique * 8, "distinct keys")) || (rc = ucodes.alloc(n_unique, "answer codes")) || (rc = amb_count.alloc(4, "counter"))) return rc;
         DICT_TRY(hipMemset(amb_count.p, 0, 4));
+        DevMem kflags;
+        if ((rc = kflags.alloc(n_unique + 8, "key flags"))) return rc;
+        DICT_TRY(hipMemset(kflags.p, 0, n_unique + 8));
+        hipLaunchKernelGGL(dict_flags_kernel, dim3(grid_of(windows)), dim3(256), 0, 0, sk, sv, uidx.as<uint32_t>(), windows, ukeys.as<uint64_t>(), ucodes.as<uint8_t>(),
+                           kflags.as<uint32_t>());
+        DICT_TRY(hipGetLastError());
         // (the list is sized by a first counting pass: mixed masks on repeats only -- usually empty)
         for (int pass = 0; pass < 2; ++pass) {
             uint32_t cap = 0;
@@ -946,7 +959,7 @@ extern "C" int fmsi_hip_index_enable_dict(fmsi_hip_index* idx, uint32_t flags) {
                 if ((rc = amb_kmers.alloc(static_cast<size_t>(cap) * 8, "ambiguous keys")) || (rc = amb_where.alloc(static_cast<size_t>(cap) * 8, "ambiguous keys"))) return rc;
                 DICT_TRY(hipMemset(amb_count.p, 0, 4));
             }
-            hipLaunchKernelGGL(dict_fold_kernel, dim3(grid_of(windows)), dim3(256), 0, 0, sk, sv, uidx.as<uint32_t>(), windows, ukeys.as<uint64_t>(), ucodes.as<uint8_t>(),
+            hipLaunchKernelGGL(dict_codes_kernel, dim3(grid_of(windows)), dim3(256), 0, 0, sk, uidx.as<uint32_t>(), windows, kflags.as<uint8_t>(), ucodes.as<uint8_t>(),
                                amb_kmers.as<uint64_t>(), amb_where.as<uint32_t>(), cap, amb_count.as<uint32_t>());
             DICT_TRY(hipGetLastError());
             DICT_TRY(hipDeviceSynchronize());

@@ -223,3 +223,30 @@ def test_chained_lookups_of_reads(fm, oracle_built, read_len, k, mask):
     f2, r2 = orc.ternaries_bulk("".join(km2).encode(), len(km2), k, True)
     g2f, g2r = fm.decode_strict(dev.query_runs(words, len(seq), starts2, wins2, k, fm.MODE_ALL | fm.STRICT))
     assert np.array_equal(g2f, f2) and np.array_equal(g2r, r2)
+
+
+@pytest.mark.parametrize("shape", ["poly_a", "period_4", "tandem_unit", "two_keys"])
+def test_dictionary_on_degenerate_texts(fm, oracle_built, shape):
+    """Texts whose k-mers are a handful of keys with 10^5 occurrences each (the construction folds occurrences with atomics, never
+    with a thread that walks them), mixed masks on top so that nearly every key is ambiguous for `-O` and the index's own search
+    decides; chained lookups on the same."""
+    k = 21
+    rng = random.Random(7)
+    unit = {"poly_a": "A", "period_4": "ACGT", "tandem_unit": "".join(rng.choice("ACGT") for _ in range(997)), "two_keys": "AT"}[shape]
+    n = 200_000
+    up = (unit * (n // len(unit) + 1))[:n]
+    ms = "".join(c if rng.random() < 0.5 else c.lower() for c in up[: n - k + 1]) + up[n - k + 1:].lower()
+    orc = oracle_py.Oracle.construct(ms, k, use_klcp=False)
+    dev = fm.DeviceIndex.build(ms.encode(), k).enable_dict(chain=True)
+    assert dev.info.dict_keys[0] <= 2 * len(unit) + 2 * k and dev.info.dict_ambiguous >= 1
+    kmers = [up[i:i + k] for i in range(0, 3000)] + [revcomp(up[i:i + k]) for i in range(0, 3000, 3)] + mixed_kmers(ms, k, 3000, seed=2)
+    check_against_oracle(fm, dev, orc, kmers, k)
+    L = 300
+    reads = [up[p:p + L] for p in range(0, 30_000, 997)] + [revcomp(up[p:p + L]) for p in range(5, 30_000, 1499)]
+    seq = "".join(reads)
+    w = L - k + 1
+    wk = [r[i:i + k] for r in reads for i in range(w)]
+    fwd, rc = orc.ternaries_bulk("".join(wk).encode(), len(wk), k, True)
+    gf, gr = fm.decode_strict(dev.query_runs(fm.pack_sequence(seq.encode()), len(seq), np.arange(len(reads), dtype=np.uint64) * np.uint64(L),
+                                             np.full(len(reads), w, dtype=np.uint32), k, fm.MODE_ALL | fm.STRICT))
+    assert np.array_equal(gf, fwd) and np.array_equal(gr, rc)
