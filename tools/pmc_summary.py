@@ -25,7 +25,7 @@ def main(out_dir: str) -> None:
             with open(f, newline="") as fh:
                 for r in csv.DictReader(fh):
                     name = r["Kernel_Name"]
-                    if "query_" not in name and "pair_lookup" not in name and "lookup_lane" not in name and "dict_lookup" not in name:
+                    if "query_" not in name and "pair_lookup" not in name and "lookup_lane" not in name and "dict_lookup" not in name and "dict_chain" not in name:
                         continue
                     per_dispatch[(name, r["Counter_Name"])][r["Dispatch_Id"]] += float(r["Counter_Value"])
         for (name, counter), d in per_dispatch.items():
@@ -84,6 +84,22 @@ def main(out_dir: str) -> None:
                              "algorithmic_bytes_per_launch": leg["algorithmic_bytes"], "kernel_ms": leg["ms"],
                              "hbm_gb_per_s": corrected / (leg["ms"] * 1e-3) / 1e9})
             t["lf_path"] = legs
+            with open(os.path.join(out_dir, f"traffic_{wl}.json"), "w") as fh:
+                json.dump(t, fh, indent=1)
+                fh.write("\n")
+            continue
+        if wl == "stream" and roof["kernel"].startswith("dict_"):
+            # the stream workload through the dictionary (chained or not): bucket reads are 128-byte requests (2 x raw); the chained
+            # kernel's side reads (4..16 bytes each) are a few per cent of its traffic and are left at the counter's tally
+            sub = "dict_chain_kernel" if "chain" in roof["kernel"] else "dict_lookup_kernel"
+            raw = avg(fetch_pass, sub, "FETCH_SIZE")
+            if raw is None:
+                continue
+            t = {"kernel": sub, "config": {"workload": wl, "n": b["config"]["index_rows"] - 1, "batch": b["config"]["queries_per_step_per_gpu"],
+                                            "k": b["config"]["k"], "prefix_len": b["config"]["prefix_table_len"], "mode": b["config"]["mode"], "stream_via": "runs"},
+                 "fetch_size_raw_bytes_per_launch": raw * 1024.0, "fetch_bytes_per_launch": 2.0 * raw * 1024.0, "hbm_bytes_per_launch": 2.0 * raw * 1024.0,
+                 "algorithmic_bytes_per_launch": roof["algorithmic_bytes_per_launch"],
+                 "correction": "2 x raw FETCH_SIZE (128-byte bucket requests tallied at 64 B); result words not included"}
             with open(os.path.join(out_dir, f"traffic_{wl}.json"), "w") as fh:
                 json.dump(t, fh, indent=1)
                 fh.write("\n")
