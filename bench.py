@@ -163,6 +163,13 @@ def measure_traffic(args, n, batch, k):
               "--repeat-divergence-permille", str(args.repeat_divergence_permille)] if args.repeat_permille else [])
     import fmsi_amd as fm
     fm.trim_scratch(int(os.environ.get("LOCAL_RANK", "0")))   # the child builds the same index beside this process: give it the room
+    # the timed kernel's name as rocprofv3 prints it (the construction of a chained dictionary also runs dict_lookup_kernel<false, true>
+    # once, over the text: not that one)
+    if args.workload == "stream":
+        kernel_tag = "dict_chain_kernel<false>" if args.dict_chain else "dict_lookup_kernel<false, true>"
+        child += [] if args.dict_chain else ["--no-dict-chain"]
+    else:
+        kernel_tag = "dict_lookup_kernel<false, false>"
     got = {}
     env = dict(os.environ, TMPDIR="/tmp")
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
@@ -176,13 +183,13 @@ def measure_traffic(args, n, batch, k):
             for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
                 with open(f, newline="") as fh:
                     for r in csv.DictReader(fh):
-                        if "dict_lookup_kernel<false" in r["Kernel_Name"] and r["Counter_Name"] == counter:
+                        if kernel_tag in r["Kernel_Name"] and r["Counter_Name"] == counter:
                             per[r["Dispatch_Id"]] = per.get(r["Dispatch_Id"], 0.0) + float(r["Counter_Value"])
             if res.returncode != 0 or not per:
                 return None, f"rocprofv3 --pmc {counter}: rc {res.returncode}, {len(per)} dispatches ({' '.join(l for l in res.stderr.decode(errors='replace').splitlines() if not l[:1] in 'WIE' or 'rror' in l)[-600:]})"
             got[counter] = sum(per.values()) / len(per) * 1024.0   # the counters are in KiB
     return 2.0 * got["FETCH_SIZE"] + got["WRITE_SIZE"], (
-        f"measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (a child run each, 3 launches of dict_lookup_kernel<false,...>), "
+        f"measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (a child run each, 3 launches of {kernel_tag}), "
         f"2 x raw FETCH_SIZE {got['FETCH_SIZE'] / 1e9:.3f} GB (gfx950 tallies a 128-B request at 64 B) + WRITE_SIZE {got['WRITE_SIZE'] / 1e9:.3f} GB")
 
 
