@@ -1,5 +1,6 @@
 #include "fastx.h"
 
+#include <algorithm>
 #include <cctype>
 #include <cstdio>
 #include <cstring>
@@ -142,6 +143,102 @@ bool FastxReader::next_append(std::string& text, size_t* name_off, size_t* name_
     while (until_(true, &qual_, nullptr, nullptr) && qual_.size() < *seq_len) {}
     last_char_ = 0;
     return qual_.size() == *seq_len;
+}
+
+char* FastxViewParser::Arena::take(size_t n) {
+    if (blocks.empty() || cap - used < n) {
+        cap = std::max<size_t>(n, size_t(1) << 22);
+        blocks.emplace_back(new char[cap]);
+        used = 0;
+    }
+    char* p = blocks.back().get() + used;
+    used += n;
+    return p;
+}
+
+bool FastxViewParser::next(Arena& arena, const char** name, size_t* name_len, const char** seq, size_t* seq_len) {
+    // FastxReader::next_append() step by step, on positions instead of copies
+    const unsigned char* d = d_;
+    auto line_end = [&](size_t from) -> size_t {   // position of the next '\n' at or behind `from`, or the end
+        const void* nl = from < end_ ? std::memchr(d + from, '\n', end_ - from) : nullptr;
+        return nl ? static_cast<size_t>(static_cast<const unsigned char*>(nl) - d) : end_;
+    };
+    if (last_char_ == 0) {   // jump to the next '>' or '@', wherever it is (src/kseq.h:186-189)
+        while (p_ < end_ && d[p_] != '>' && d[p_] != '@') ++p_;
+        if (p_ >= end_) {
+            clean_end_ = true;
+            return false;
+        }
+        last_char_ = d[p_++];
+    }
+    if (p_ >= end_) return false;   // a header character at the very end: no name
+    size_t q = p_;
+    while (q < end_ && !std::isspace(d[q])) ++q;
+    *name = reinterpret_cast<const char*>(d + p_);
+    *name_len = q - p_;
+    const int delim = q < end_ ? d[q] : 0;
+    p_ = q < end_ ? q + 1 : end_;
+    if (delim != '\n' && p_ < end_) p_ = std::min(end_, line_end(p_) + 1);   // comment
+    lines_.clear();
+    size_t total = 0;
+    int c = -1;
+    while (p_ < end_) {
+        c = d[p_++];
+        if (c == '>' || c == '+' || c == '@') break;
+        if (c == '\n') {
+            c = -1;
+            continue;
+        }
+        const bool last_byte = p_ >= end_;   // (the reader's line read finds nothing then and returns before the CR rule)
+        size_t from = p_ - 1, to = line_end(p_);
+        p_ = std::min(end_, to + 1);
+        total += to - from;
+        if (!last_byte && total > 1 && d[to - 1] == '\r') {   // the trailing-CR rule looks at the sequence so far (src/kseq.h:146)
+            --to;
+            --total;
+        }
+        lines_.emplace_back(from, to);
+        c = -1;
+    }
+    if (lines_.size() <= 1) {
+        *seq = lines_.empty() ? reinterpret_cast<const char*>(d + p_) : reinterpret_cast<const char*>(d + lines_[0].first);
+    } else {
+        char* dst = arena.take(total);
+        *seq = dst;
+        for (const auto& [from, to] : lines_) {
+            std::memcpy(dst, d + from, to - from);
+            dst += to - from;
+        }
+    }
+    *seq_len = total;
+    if (c == '>' || c == '@') last_char_ = c;
+    if (c != '+') return true;   // FASTA
+    fastq_seen_ = true;
+    {   // rest of the '+' line; none: no quality string
+        const size_t nl = line_end(p_);
+        if (nl >= end_) {
+            p_ = end_;
+            return false;
+        }
+        p_ = nl + 1;
+    }
+    // quality lines until they are as long as the sequence (at least one line is read); the CR rule looks at the whole string read
+    // so far, so its lines are kept as ranges
+    size_t qual = 0;
+    lines_.clear();
+    while (p_ < end_) {
+        const size_t to = line_end(p_);
+        if (to > p_) lines_.emplace_back(p_, to);
+        qual += to - p_;
+        p_ = std::min(end_, to + 1);
+        if (qual > 1 && d[lines_.back().second - 1] == '\r') {
+            --qual;
+            if (--lines_.back().second == lines_.back().first) lines_.pop_back();
+        }
+        if (qual >= total) break;
+    }
+    last_char_ = 0;
+    return qual == total;
 }
 
 }  // namespace fmsi

@@ -5,7 +5,9 @@
 #pragma once
 
 #include <cstdint>
+#include <memory>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include <zlib.h>
@@ -57,6 +59,31 @@ private:
     bool clean_end_ = false;
     int last_char_ = 0;
     std::string qual_;
+};
+
+// The same rules over bytes in memory WITHOUT copying them: a record's name and -- when its sequence sits on one line, the common
+// shape of read files -- its sequence are views into the caller's bytes; only a multi-line sequence is joined into `arena` (whose
+// blocks never move: views into it stay valid while the arena lives).  Record by record this yields exactly what FastxReader over the
+// same bytes yields (tests/native/fastx_view_fuzz.cpp holds the two against each other), including saw_fastq() and clean_end().
+class FastxViewParser {
+public:
+    struct Arena {
+        std::vector<std::unique_ptr<char[]>> blocks;
+        size_t used = 0, cap = 0;
+        char* take(size_t n);   // n contiguous bytes
+    };
+    FastxViewParser(const unsigned char* data, size_t len) : d_(data), end_(len) {}
+    // false at the end of the input (or a truncated / malformed FASTQ record, which ends the stream as in the reference)
+    bool next(Arena& arena, const char** name, size_t* name_len, const char** seq, size_t* seq_len);
+    bool saw_fastq() const { return fastq_seen_; }
+    bool clean_end() const { return clean_end_; }
+
+private:
+    const unsigned char* d_;
+    size_t p_ = 0, end_;
+    bool fastq_seen_ = false, clean_end_ = false;
+    int last_char_ = 0;
+    std::vector<std::pair<size_t, size_t>> lines_;   // the current record's sequence lines [from, to)
 };
 
 }  // namespace fmsi

@@ -17,6 +17,7 @@
 #include <fcntl.h>
 
 #include <sched.h>
+#include <emmintrin.h>   // SSE2: part of x86-64
 
 #include <algorithm>
 #include <charconv>
@@ -210,8 +211,10 @@ struct Op {
     uint64_t count;
     bool is_run;
 };
-struct RecRef {
-    uint64_t name_off, seq_off, seq_len;
+struct RecRef {   // views: into the mapped query file, the batch's arena (multi-line sequences) or the batch's text (ordinary reader)
+    const char* name;
+    const char* seq;
+    uint64_t seq_len;
     uint32_t name_len;
 };
 // Page-locked memory for what crosses the link every batch (packed bases in, result bytes / orders out): blocks come from
@@ -282,17 +285,16 @@ struct PinnedAlloc {
 template <class T> using PinVec = std::vector<T, PinnedAlloc<T>>;
 
 struct RawBatch {
-    std::string text;            // names and sequences, as read ...
-    std::unique_ptr<char[]> ext; // ... or here (block-parallel reader: the workers' parts at the offsets of their file ranges)
+    std::string text;                                 // ordinary reader: names and sequences, as read
+    std::vector<FastxViewParser::Arena> arenas;       // block-parallel reader: one per part, holding only what is not a view of the file
     std::vector<RecRef> recs;
     uint64_t seq_bytes = 0;
-    const char* base() const { return ext ? ext.get() : text.data(); }
 };
 
 // ---- block-parallel reader ---------------------------------------------------------------------------------------
 // A plain (not gzipped) FASTA file is mapped and cut at lines that start with '>' into ranges of about a batch; a range
-// is cut again the same way into one part per worker, and every worker runs the ordinary reader (fastx.cpp, the
-// reference's kseq rules) over its part.  That is the sequential parse exactly, as long as no '+' separator line occurs:
+// is cut again the same way into one part per worker, and every worker runs the reader's rules (fastx.cpp, the
+// reference's kseq rules) over its part WITHOUT copying: names and single-line sequences stay views of the mapping.  That is the sequential parse exactly, as long as no '+' separator line occurs:
 // a line-start '>' is then always a record start (src/kseq.h:183-226: only a FASTQ quality string can hold one that is
 // not).  A worker that meets a '+' line says so, and the range is parsed again by ONE reader that then goes on to the
 // end of the file -- ranges before it held no '+' line, so its start is a record start of the sequential parse too.
@@ -360,21 +362,15 @@ size_t next_record_start(const unsigned char* d, size_t from, size_t end, bool f
     }
     return end;
 }
-// all records of d[lo, hi) (lo at a record start) through the ordinary reader; offsets relative to `text`
-bool parse_range(const unsigned char* d, size_t lo, size_t hi, std::string& text, std::vector<RecRef>& recs, uint64_t& seq_bytes, bool fastq = false) {
-    FastxReader r(d + lo, hi - lo);
-    text.reserve(hi - lo);
+// all records of d[lo, hi) (lo at a record start) as views (FastxViewParser: the ordinary reader's rules)
+bool parse_range(const unsigned char* d, size_t lo, size_t hi, FastxViewParser::Arena& arena, std::vector<RecRef>& recs, uint64_t& seq_bytes,
+                 bool fastq = false) {
+    FastxViewParser r(d + lo, hi - lo);
     for (;;) {
         RecRef rr;
-        const size_t before = text.size();
-        size_t name_off, name_len, seq_off, seq_len;
-        if (!r.next_append(text, &name_off, &name_len, &seq_off, &seq_len)) {
-            text.resize(before);
-            break;
-        }
-        rr.name_off = name_off;
+        size_t name_len, seq_len;
+        if (!r.next(arena, &rr.name, &name_len, &rr.seq, &seq_len)) break;
         rr.name_len = static_cast<uint32_t>(name_len);
-        rr.seq_off = seq_off;
         rr.seq_len = seq_len;
         recs.push_back(rr);
         seq_bytes += seq_len;
@@ -393,7 +389,9 @@ struct Prepared {
     std::vector<uint32_t> run_windows;
     PinVec<uint64_t> packed;
     uint64_t bases = 0, windows = 0;
-    PinVec<uint8_t> bytes;                // device results, then (after the replay) the final 0/1 per window
+    PinVec<uint8_t> bytes;                // device results, then (after the replay) the final 0/1 per window ...
+    PinVec<uint64_t> bits;                // ... or, when nothing is replayed, one BIT per window straight from the device (FMSI_HIP_OUT_BITS)
+    bool packed_bits = false;
     PinVec<int64_t> orders;               // lookup: device results, then the final order per window
 };
 
@@ -411,45 +409,81 @@ const CodeTable kCode;
 
 // 2-bit packing of `len` VALID bases into zeroed words: base i in bits [2(i%32), +1] of dst[i/32].
 // For valid characters the code is ((c >> 1) & 3) ^ ((c >> 2) & 1): A/a 0, C/c 1, G/g 2, T/t 3.
-__attribute__((target("bmi2"))) void pack_run(const char* s, uint64_t len, uint64_t* dst) {
+inline uint64_t codes_of8(const char* s) {   // 8 characters -> their codes in the low 2 bits of 8 bytes
+    uint64_t v;
+    std::memcpy(&v, s, 8);
+    return ((v >> 1) & 0x0303030303030303ull) ^ ((v >> 2) & 0x0101010101010101ull);
+}
+inline void pack_tail(const char* s, uint64_t from, uint64_t len, uint64_t* dst) {
+    if (from >= len) return;
+    uint64_t w = 0;
+    for (uint64_t j = from; j < len; ++j) w |= static_cast<uint64_t>(kCode.t[static_cast<unsigned char>(s[j])] & 3u) << (2 * (j - from));
+    dst[from >> 5] = w;
+}
+__attribute__((target("bmi2"))) void pack_run_bmi2(const char* s, uint64_t len, uint64_t* dst) {
+    uint64_t i = 0;
+    for (; i + 32 <= len; i += 32) {
+        uint64_t w = 0;
+        for (int q = 0; q < 4; ++q) w |= __builtin_ia32_pext_di(codes_of8(s + i + 8 * q), 0x0303030303030303ull) << (16 * q);
+        dst[i >> 5] = w;
+    }
+    pack_tail(s, i, len, dst);
+}
+void pack_run_plain(const char* s, uint64_t len, uint64_t* dst) {   // the same without PEXT: three shift-or rounds per 8 bases
     uint64_t i = 0;
     for (; i + 32 <= len; i += 32) {
         uint64_t w = 0;
         for (int q = 0; q < 4; ++q) {
-            uint64_t v;
-            std::memcpy(&v, s + i + 8 * q, 8);
-            const uint64_t x = ((v >> 1) & 0x0303030303030303ull) ^ ((v >> 2) & 0x0101010101010101ull);
-            w |= __builtin_ia32_pext_di(x, 0x0303030303030303ull) << (16 * q);
+            uint64_t x = codes_of8(s + i + 8 * q);
+            x = (x | (x >> 6)) & 0x000F000F000F000Full;
+            x = (x | (x >> 12)) & 0x000000FF000000FFull;
+            x = (x | (x >> 24)) & 0xFFFFull;
+            w |= x << (16 * q);
         }
         dst[i >> 5] = w;
     }
-    if (i < len) {
-        uint64_t w = 0;
-        for (uint64_t j = i; j < len; ++j) w |= static_cast<uint64_t>(kCode.t[static_cast<unsigned char>(s[j])] & 3u) << (2 * (j - i));
-        dst[i >> 5] = w;
+    pack_tail(s, i, len, dst);
+}
+inline void pack_run(const char* s, uint64_t len, uint64_t* dst) {
+    static const bool bmi2 = __builtin_cpu_supports("bmi2") && !std::getenv("FMSI_HIP_NO_BMI2");
+    if (bmi2) pack_run_bmi2(s, len, dst);
+    else pack_run_plain(s, len, dst);
+}
+
+// next_invalid_character_or_end (src/parser.h:57-64): length of the longest prefix of s[0, n) made of ACGTacgt, 16 characters a step
+inline int64_t valid_prefix(const char* s, int64_t n) {
+    int64_t i = 0;
+    const __m128i fold = _mm_set1_epi8(static_cast<char>(0xDF));   // a-z -> A-Z (and nothing else onto A, C, G, T)
+    const __m128i a = _mm_set1_epi8('A'), c = _mm_set1_epi8('C'), g = _mm_set1_epi8('G'), t = _mm_set1_epi8('T');
+    for (; i + 16 <= n; i += 16) {
+        const __m128i v = _mm_and_si128(_mm_loadu_si128(reinterpret_cast<const __m128i*>(s + i)), fold);
+        const __m128i ok = _mm_or_si128(_mm_or_si128(_mm_cmpeq_epi8(v, a), _mm_cmpeq_epi8(v, c)), _mm_or_si128(_mm_cmpeq_epi8(v, g), _mm_cmpeq_epi8(v, t)));
+        const unsigned bad = ~static_cast<unsigned>(_mm_movemask_epi8(ok)) & 0xFFFFu;
+        if (bad) return i + __builtin_ctz(bad);
     }
+    while (i < n && kCode.t[static_cast<unsigned char>(s[i])] != 4) ++i;
+    return i;
 }
 
 struct TeamPlan {   // what one thread of the team found in its records
     std::vector<Op> ops;
     std::vector<uint32_t> rec_nops;
     std::vector<uint64_t> rec_windows, rec_symbols;
-    std::vector<std::pair<uint64_t, uint64_t>> runs;   // (offset in raw.text, length in bases >= k)
+    std::vector<std::pair<const char*, uint64_t>> runs;   // (first base, length in bases >= k)
     uint64_t windows = 0, words = 0, dev_runs = 0;
 };
 
 constexpr uint64_t kMaxRunWindows = 0x40000000ull;   // run lengths are 32-bit in the C-ABI
 
 // Walk of one record exactly as src/main.cpp:337-371 does it, recording instead of querying.
-inline void plan_record(const char* sequence, int64_t sequence_length, uint64_t text_off, int k, TeamPlan& tp) {
+inline void plan_record(const char* sequence, int64_t sequence_length, int k, TeamPlan& tp) {
     uint32_t nops = 0;
     uint64_t windows_total = 0, symbols = 0;
     while (sequence_length > 0) {
-        int64_t current_length = 0;   // next_invalid_character_or_end, src/parser.h:57-64
-        while (current_length < sequence_length && kCode.t[static_cast<unsigned char>(sequence[current_length])] != 4) ++current_length;
+        int64_t current_length = valid_prefix(sequence, sequence_length);
         if (current_length >= k) {
             const uint64_t windows = static_cast<uint64_t>(current_length - k + 1);
-            tp.runs.emplace_back(text_off, static_cast<uint64_t>(current_length));
+            tp.runs.emplace_back(sequence, static_cast<uint64_t>(current_length));
             tp.words += (static_cast<uint64_t>(current_length) + 31) / 32;
             tp.dev_runs += (windows + kMaxRunWindows - 1) / kMaxRunWindows;
             tp.ops.push_back({windows, true});
@@ -458,13 +492,11 @@ inline void plan_record(const char* sequence, int64_t sequence_length, uint64_t 
             symbols += windows;
             // the reference consumes chunk_length - k + 1 characters per chunk: k - 1 remain
             sequence += windows;
-            text_off += windows;
             sequence_length -= static_cast<int64_t>(windows);
             current_length -= static_cast<int64_t>(windows);
         }
         sequence_length -= current_length + 1;
         sequence += current_length + 1;
-        text_off += static_cast<uint64_t>(current_length + 1);
         if (sequence_length >= 0) {
             const uint64_t fill = static_cast<uint64_t>(std::min<int64_t>(k, current_length + 1));
             tp.ops.push_back({fill, false});
@@ -495,11 +527,10 @@ void prepare_batch(Prepared& P, int k, unsigned team) {
         }
     }
     std::vector<TeamPlan> tp(team);
-    const char* text = P.raw.base();
     parallel_for(team, [&](unsigned t) {
         for (size_t r = cut[t]; r < cut[t + 1]; ++r) {
             const RecRef& rr = P.raw.recs[r];
-            plan_record(text + rr.seq_off, static_cast<int64_t>(rr.seq_len), rr.seq_off, k, tp[t]);
+            plan_record(rr.seq, static_cast<int64_t>(rr.seq_len), k, tp[t]);
         }
     });
     // offsets of every thread's share
@@ -538,8 +569,8 @@ void prepare_batch(Prepared& P, int k, unsigned team) {
             b += P.raw.recs[r].name_len + 2 + tp[t].rec_symbols[r - cut[t]];
         }
         uint64_t word = word_at[t], run = run_at[t];
-        for (const auto& [off, len] : tp[t].runs) {
-            pack_run(text + off, len, P.packed.data() + word);
+        for (const auto& [first, len] : tp[t].runs) {
+            pack_run(first, len, P.packed.data() + word);
             uint64_t windows = len - static_cast<uint64_t>(k) + 1, base = word * 32;
             while (windows) {
                 const uint64_t take = std::min(windows, kMaxRunWindows);
@@ -762,12 +793,48 @@ void replay_batch(Prepared& P, StrandPredictor& predictor, Mode mode, bool order
 }
 
 // ---- formatting ----------------------------------------------------------------------------------
+// `count` result bits from bit `first` of `words` (FMSI_HIP_OUT_BITS layout) -> '0' / '1' characters, 8 a step
+inline uint64_t bits_from(const uint64_t* words, uint64_t at) {   // 64 bits starting at bit `at` (the buffer has a spare word)
+    const unsigned sh = static_cast<unsigned>(at & 63);
+    const uint64_t lo = words[at >> 6] >> sh;
+    return sh ? lo | (words[(at >> 6) + 1] << (64 - sh)) : lo;
+}
+__attribute__((target("bmi2"))) void expand_bits_bmi2(const uint64_t* words, uint64_t first, uint64_t count, char* dst) {
+    uint64_t i = 0;
+    for (; i + 64 <= count; i += 64) {
+        const uint64_t x = bits_from(words, first + i);
+        for (int q = 0; q < 8; ++q) {
+            const uint64_t c = __builtin_ia32_pdep_di(x >> (8 * q), 0x0101010101010101ull) | 0x3030303030303030ull;
+            std::memcpy(dst + i + 8 * q, &c, 8);
+        }
+    }
+    for (; i < count; ++i) dst[i] = static_cast<char>('0' + ((words[(first + i) >> 6] >> ((first + i) & 63)) & 1));
+}
+void expand_bits_plain(const uint64_t* words, uint64_t first, uint64_t count, char* dst) {
+    uint64_t i = 0;
+    for (; i + 64 <= count; i += 64) {
+        const uint64_t x = bits_from(words, first + i);
+        for (int q = 0; q < 8; ++q) {
+            // byte j <- bit j of the q-th byte: spread by a multiply, keep one bit per byte, normalise it to 0 / 1
+            uint64_t c = (((x >> (8 * q)) & 0xFF) * 0x0101010101010101ull) & 0x8040201008040201ull;
+            c = ((c + 0x7F7F7F7F7F7F7F7Full) >> 7) & 0x0101010101010101ull;
+            c |= 0x3030303030303030ull;
+            std::memcpy(dst + i + 8 * q, &c, 8);
+        }
+    }
+    for (; i < count; ++i) dst[i] = static_cast<char>('0' + ((words[(first + i) >> 6] >> ((first + i) & 63)) & 1));
+}
+inline void expand_bits(const uint64_t* words, uint64_t first, uint64_t count, char* dst) {
+    static const bool bmi2 = __builtin_cpu_supports("bmi2") && !std::getenv("FMSI_HIP_NO_BMI2");
+    if (bmi2) expand_bits_bmi2(words, first, count, dst);
+    else expand_bits_plain(words, first, count, dst);
+}
+
 // presence modes: every line has a known length, the team writes straight into one buffer
 void format_bits(const Prepared& P, unsigned team, std::vector<char>& out) {
     const size_t nrec = P.raw.recs.size();
     out.resize(P.rec_out[nrec]);
     team = static_cast<unsigned>(std::max<size_t>(1, std::min<size_t>(team, nrec / 64 + 1)));
-    const char* text = P.raw.base();
     parallel_for(team, [&](unsigned t) {
         // ranges of about equal output size
         const uint64_t lo = P.rec_out[nrec] / team * t, hi = t + 1 == team ? P.rec_out[nrec] : P.rec_out[nrec] / team * (t + 1);
@@ -775,15 +842,19 @@ void format_bits(const Prepared& P, unsigned team, std::vector<char>& out) {
         for (; r < nrec && P.rec_out[r] < hi; ++r) {
             char* dst = out.data() + P.rec_out[r];
             const RecRef& rr = P.raw.recs[r];
-            std::memcpy(dst, text + rr.name_off, rr.name_len);
+            std::memcpy(dst, rr.name, rr.name_len);
             dst += rr.name_len;
             *dst++ = '\t';
             uint64_t w = P.rec_first[r];
             for (uint64_t o = P.rec_ops[r]; o < P.rec_ops[r + 1]; ++o) {
                 const uint64_t c = P.ops[o].count;
                 if (P.ops[o].is_run) {
-                    const uint8_t* src = P.bytes.data() + w;
-                    for (uint64_t i = 0; i < c; ++i) dst[i] = static_cast<char>('0' + (src[i] != 0));
+                    if (P.packed_bits) {
+                        expand_bits(P.bits.data(), w, c, dst);
+                    } else {
+                        const uint8_t* src = P.bytes.data() + w;
+                        for (uint64_t i = 0; i < c; ++i) dst[i] = static_cast<char>('0' + (src[i] != 0));
+                    }
                     w += c;
                 } else {
                     std::memset(dst, '0', c);
@@ -800,7 +871,6 @@ void format_orders(const Prepared& P, unsigned team, std::vector<std::string>& p
     const size_t nrec = P.raw.recs.size();
     team = static_cast<unsigned>(std::max<size_t>(1, std::min<size_t>(team, nrec / 64 + 1)));
     parts.assign(team, std::string());
-    const char* text = P.raw.base();
     const uint64_t total = P.rec_first[nrec] + nrec;   // balance by windows (+1 per record)
     parallel_for(team, [&](unsigned t) {
         std::string& s = parts[t];
@@ -811,7 +881,7 @@ void format_orders(const Prepared& P, unsigned team, std::vector<std::string>& p
             if (key < lo) continue;
             if (key >= hi) break;
             const RecRef& rr = P.raw.recs[r];
-            s.append(text + rr.name_off, rr.name_len);
+            s.append(rr.name, rr.name_len);
             s += '\t';
             bool first = true;
             uint64_t w = P.rec_first[r];
@@ -959,22 +1029,15 @@ extern "C" int fmsi_cli_query(int argc, char** argv, int output_orders_i) {
                     }
                     cuts.push_back(end);
                     const size_t parts = cuts.size() - 1;
-                    std::vector<std::string> texts(parts);
                     std::vector<std::vector<RecRef>> recs(parts);
                     std::vector<uint64_t> seq_bytes(parts, 0);
                     std::vector<char> clean(parts, 1);
                     auto nb = std::make_unique<RawBatch>();
-                    nb->ext.reset(new char[end - pos + 1]);   // a part's names and sequences are shorter than its range
+                    nb->arenas.resize(parts);
                     std::vector<std::thread> pool;
                     for (size_t w = 0; w < parts; ++w)
                         pool.emplace_back([&, w] {
-                            clean[w] = parse_range(d, cuts[w], cuts[w + 1], texts[w], recs[w], seq_bytes[w], parallel_fastq) ? 1 : 0;
-                            const size_t shift = cuts[w] - pos;
-                            std::memcpy(nb->ext.get() + shift, texts[w].data(), texts[w].size());
-                            for (RecRef& r : recs[w]) {
-                                r.name_off += shift;
-                                r.seq_off += shift;
-                            }
+                            clean[w] = parse_range(d, cuts[w], cuts[w + 1], nb->arenas[w], recs[w], seq_bytes[w], parallel_fastq) ? 1 : 0;
                         });
                     for (std::thread& t : pool) t.join();
                     if (std::find(clean.begin(), clean.end(), 0) != clean.end()) {   // a FASTQ record: the ordinary reader from here on
@@ -1009,6 +1072,17 @@ extern "C" int fmsi_cli_query(int argc, char** argv, int output_orders_i) {
                 }
                 reader = std::make_unique<FastxReader>(mapped.data + resume_at, mapped.size - resume_at);
             }
+            // ordinary reader: names and sequences are appended to the batch's text, which moves as it grows -- the records hold
+            // offsets until the batch is complete
+            std::vector<std::pair<size_t, size_t>> offs;   // (name, sequence) offsets of the batch's records
+            auto finish = [&offs](RawBatch& rb) {
+                const char* base = rb.text.data();
+                for (size_t r = 0; r < rb.recs.size(); ++r) {
+                    rb.recs[r].name = base + offs[r].first;
+                    rb.recs[r].seq = base + offs[r].second;
+                }
+                offs.clear();
+            };
             for (;;) {
                 RecRef rr;
                 const size_t before = b->text.size();
@@ -1017,19 +1091,21 @@ extern "C" int fmsi_cli_query(int argc, char** argv, int output_orders_i) {
                     b->text.resize(before);   // a partial record (truncated FASTQ) ends the stream, as in the reference
                     break;
                 }
-                rr.name_off = name_off;
+                rr.name = rr.seq = nullptr;
                 rr.name_len = static_cast<uint32_t>(name_len);
-                rr.seq_off = seq_off;
                 rr.seq_len = seq_len;
                 b->recs.push_back(rr);
+                offs.emplace_back(name_off, seq_off);
                 b->seq_bytes += rr.seq_len;
                 if (b->seq_bytes >= opt.batch_windows || b->recs.size() >= (1u << 23)) {
+                    finish(*b);
                     read_s += std::chrono::duration<double>(clock::now() - t0).count();
                     if (!raw_q.push(std::move(b))) return;
                     b = std::make_unique<RawBatch>();
                     t0 = clock::now();
                 }
             }
+            finish(*b);
             read_s += std::chrono::duration<double>(clock::now() - t0).count();
             if (!b->recs.empty()) raw_q.push(std::move(b));
         } catch (...) {
@@ -1173,9 +1249,9 @@ extern "C" int fmsi_cli_query(int argc, char** argv, int output_orders_i) {
     // everything else replays the predictor from both strands unless --fast.
     const bool need_both = opt.has_klcp || output_orders || opt.mode == Mode::All;
     const bool strict = need_both && !opt.fast;
-    uint32_t flags = (opt.mode == Mode::All ? FMSI_HIP_MODE_ALL : FMSI_HIP_MODE_OR);
-    if (strict) flags |= FMSI_HIP_STRICT;
-    if (output_orders) flags |= FMSI_HIP_ORDERS;
+    uint32_t flags_all = (opt.mode == Mode::All ? FMSI_HIP_MODE_ALL : FMSI_HIP_MODE_OR);
+    if (strict) flags_all |= FMSI_HIP_STRICT;
+    if (output_orders) flags_all |= FMSI_HIP_ORDERS;
 
     int exit_code = 0;
     uint64_t total_windows = 0;
@@ -1188,34 +1264,102 @@ extern "C" int fmsi_cli_query(int argc, char** argv, int output_orders_i) {
         }
     }
 
+    // ---- output: a formatter (the team writes the batch's lines into one buffer) and behind it the sink that hands the buffer to
+    // stdout while the next batch is formatted.  A regular file that is not in append mode is written by several threads at once,
+    // each its slice at its own offset (pwrite); anything else -- a pipe, a terminal, /dev/null -- by plain write().
+    struct Sink {
+        bool positional = false;
+        off_t pos = 0;
+        unsigned threads = 1;
+        void init(unsigned team) {
+            std::fflush(stdout);
+            struct stat st;
+            const int fl = fcntl(STDOUT_FILENO, F_GETFL);
+            if (fstat(STDOUT_FILENO, &st) == 0 && S_ISREG(st.st_mode) && fl >= 0 && !(fl & O_APPEND) && !std::getenv("FMSI_HIP_SERIAL_WRITER")) {
+                pos = lseek(STDOUT_FILENO, 0, SEEK_CUR);
+                positional = pos >= 0;
+            }
+            threads = std::max(1u, std::min(8u, team));
+        }
+        static void write_all(const char* p, size_t n, bool at, off_t off) {
+            while (n) {
+                const ssize_t w = at ? pwrite(STDOUT_FILENO, p, n, off) : write(STDOUT_FILENO, p, n);
+                if (w < 0 && errno == EINTR) continue;
+                if (w <= 0) throw std::runtime_error("write to stdout failed");
+                p += w;
+                n -= static_cast<size_t>(w);
+                off += w;
+            }
+        }
+        void put(const char* p, size_t n) {
+            if (!n) return;
+            if (!positional) {
+                write_all(p, n, false, 0);
+                return;
+            }
+            const unsigned parts = static_cast<unsigned>(std::max<size_t>(1, std::min<size_t>(threads, n >> 22)));
+            const size_t per = (n / parts + 4095) & ~size_t(4095);
+            parallel_for(parts, [&](unsigned t) {
+                const size_t lo = std::min(n, per * t), hi = t + 1 == parts ? n : std::min(n, per * (t + 1));
+                if (hi > lo) write_all(p + lo, hi - lo, true, pos + static_cast<off_t>(lo));
+            });
+            pos += static_cast<off_t>(n);
+        }
+        void finish() {   // leave the shared file offset behind what was written, as sequential writes would
+            if (positional) (void)lseek(STDOUT_FILENO, pos, SEEK_SET);
+        }
+    };
+    struct OutBuf {
+        std::vector<char> bits;             // presence modes: the whole batch
+        std::vector<std::string> parts;     // lookup: one piece per formatting thread
+    };
+    BoundedQueue<std::unique_ptr<OutBuf>> sink_q(1), spare_q(3);
+    std::exception_ptr sink_err;
+    std::thread sink_thread([&] {
+        try {
+            Sink sink;
+            sink.init(team);
+            std::unique_ptr<OutBuf> b;
+            while (sink_q.pop(b)) {
+                auto t1 = clock::now();
+                {
+                    TraceRange write_range("fmsi: write");
+                    if (output_orders)
+                        for (const std::string& s : b->parts) sink.put(s.data(), s.size());
+                    else sink.put(b->bits.data(), b->bits.size());
+                }
+                write_s += std::chrono::duration<double>(clock::now() - t1).count();
+                (void)spare_q.push(std::move(b));
+            }
+            sink.finish();
+        } catch (...) {
+            sink_err = std::current_exception();
+            sink_q.abort();
+            spare_q.abort();
+        }
+    });
     std::thread writer_thread([&] {
         try {
+            for (int i = 0; i < 2; ++i) (void)spare_q.push(std::make_unique<OutBuf>());
             std::unique_ptr<Prepared> P;
-            std::vector<char> buf;
-            std::vector<std::string> parts;
             while (out_q.pop(P)) {
+                std::unique_ptr<OutBuf> b;
+                if (!spare_q.pop(b)) break;   // the sink failed
                 auto t0 = clock::now();
                 trace_push("fmsi: format");
-                if (output_orders) format_orders(*P, team, parts);
-                else format_bits(*P, team, buf);
+                if (output_orders) format_orders(*P, team, b->parts);
+                else format_bits(*P, team, b->bits);
                 trace_pop();
-                auto t1 = clock::now();
-                TraceRange write_range("fmsi: write");
-                if (output_orders) {
-                    for (const std::string& s : parts)
-                        if (!s.empty() && std::fwrite(s.data(), 1, s.size(), stdout) != s.size()) throw std::runtime_error("write to stdout failed");
-                } else if (!buf.empty() && std::fwrite(buf.data(), 1, buf.size(), stdout) != buf.size()) {
-                    throw std::runtime_error("write to stdout failed");
-                }
-                format_s += std::chrono::duration<double>(t1 - t0).count();
-                write_s += std::chrono::duration<double>(clock::now() - t1).count();
+                format_s += std::chrono::duration<double>(clock::now() - t0).count();
                 P.reset();
+                if (!sink_q.push(std::move(b))) break;
             }
-            std::fflush(stdout);
+            sink_q.close();
         } catch (...) {
             writer_err = std::current_exception();
-            out_q.abort();
+            sink_q.abort();
         }
+        out_q.abort();   // (on every way out: the hand-over loop must not block on a writer that is gone)
     });
 
     // ---- device workers: one per handle.  A worker takes the next raw batch (its number = its place in the output), packs it,
@@ -1249,13 +1393,18 @@ extern "C" int fmsi_cli_query(int argc, char** argv, int output_orders_i) {
                     trace_pop();
                     auto t1 = clock::now(), td = t1;
                     const uint64_t nw = P->windows;
+                    // nothing to replay: the device hands over one bit per window, an eighth of the bytes to copy and to read here
+                    P->packed_bits = !output_orders && !strict;
                     if (output_orders) P->orders.resize(nw * (strict ? 2 : 1));
+                    else if (P->packed_bits) P->bits.resize((nw + 63) / 64 + 1);
                     else P->bytes.resize(nw);
                     if (nw) {
                         std::lock_guard<std::mutex> device_turn(*cp->busy);
                         td = clock::now();   // (device time: from the moment the handle is this worker's)
                         TraceRange device_range("fmsi: device (copy in, kernels, copy out)");
-                        void* dst = output_orders ? static_cast<void*>(P->orders.data()) : static_cast<void*>(P->bytes.data());
+                        void* dst = output_orders ? static_cast<void*>(P->orders.data())
+                                                  : (P->packed_bits ? static_cast<void*>(P->bits.data()) : static_cast<void*>(P->bytes.data()));
+                        const uint32_t flags = flags_all | (P->packed_bits ? FMSI_HIP_OUT_BITS : 0u);
                         if (opt.has_klcp && !cp->have_dict)   // -S: kLCP streaming kernel (query_kmers_streaming, src/fms_index.h:181-254)
                             check(fmsi_hip_query_stream(cp->dev, P->packed.data(), P->bases, P->run_start.data(), P->run_windows.data(),
                                                         P->run_start.size(), nw, k, flags, dst, nullptr, nullptr),
@@ -1330,7 +1479,8 @@ extern "C" int fmsi_cli_query(int argc, char** argv, int output_orders_i) {
     for (std::thread& th : workers) th.join();
     reader_thread.join();
     writer_thread.join();
-    for (const std::exception_ptr& ep : {reader_err, writer_err, worker_err}) {
+    sink_thread.join();
+    for (const std::exception_ptr& ep : {reader_err, writer_err, sink_err, worker_err}) {
         if (!ep) continue;
         try {
             std::rethrow_exception(ep);

@@ -276,6 +276,20 @@ def test_host_code_under_sanitizers(tmp_path):
             assert (GOLDEN / "idx" / f"{name}.fmsi.{part}").read_bytes() == Path(f"{out}.fmsi.{part}").read_bytes(), (name, part)
 
 
+def test_view_parser_equals_reader_fuzz(tmp_path):
+    """The CLI's block-parallel reader parses without copying (FastxViewParser: names and single-line sequences are views of the
+    mapped file): record by record it must yield what the ordinary reader (the reference's kseq rules) yields on the same bytes --
+    well-formed and mutated FASTA / FASTQ, CRLF, stray header characters, truncations.  ASan + UBSan build."""
+    exe = tmp_path / "fastx_view_fuzz"
+    res = subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+                          str(REPO / "tests" / "native" / "fastx_view_fuzz.cpp"), str(REPO / "fmsi_amd" / "csrc" / "fastx.cpp"), "-lz", "-o", str(exe)],
+                         capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr[-3000:]
+    res = subprocess.run([str(exe), "150000"], capture_output=True, text=True)
+    assert res.returncode == 0, (res.stdout + res.stderr)[-3000:]
+    assert "on 150000 inputs" in res.stdout
+
+
 def test_threaded_rrr_decode_under_tsan_and_corrupt_mask(oracle_built, tmp_path):
     """The threaded part of the RRR-63 decoder (>= 64 superblock pairs: the golden indexes are too small to reach it) under
     ThreadSanitizer -- neighbouring threads must not touch each other's boundary word -- and equal to the oracle's mask; a

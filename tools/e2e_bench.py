@@ -114,11 +114,17 @@ def main() -> None:
     windows_per_read = max(0, a.read_len - a.k + 1)
 
     for mode in a.modes.split(","):
-        args = MODES[mode]
-        outp = work / f"out_{mode}.txt"
+        # "or+--threads+8": mode `or` with extra arguments; "NAME=value+or": with an environment variable
+        parts = mode.split("+")
+        env = dict(os.environ)
+        while "=" in parts[0] and not parts[0].startswith("-"):
+            key, _, val = parts.pop(0).partition("=")
+            env[key] = val
+        args = MODES[parts[0]] + parts[1:]
+        outp = work / f"out_{parts[0]}.txt"
         t0 = time.time()
         with open(outp, "wb") as so:
-            p = subprocess.run([str(fm.CLI_PATH), *args, "--stats", "-q", str(fasta), prefix], stdout=so, stderr=subprocess.PIPE)
+            p = subprocess.run([str(fm.CLI_PATH), *args, "--stats", "-q", str(fasta), prefix], stdout=so, stderr=subprocess.PIPE, env=env)
         wall = time.time() - t0
         entry = {"rc": p.returncode, "wall_seconds": round(wall, 3)}
         for line in p.stderr.decode().splitlines():
@@ -132,12 +138,12 @@ def main() -> None:
             entry["windows_per_s_after_load"] = round(w / max(1e-9, entry["total_seconds"] - entry["load_seconds"]))
         entry["output_bytes"] = outp.stat().st_size
         # reference on the sample: identical bytes?
-        ref_args = [x for x in args if x not in ("--fast", "--tables", "full", "--devices", "0,0")]
+        ref_args = [x for x in MODES[parts[0]] if x not in ("--fast", "--tables", "full", "--devices", "0,0")]
         if ref_cli.exists() and a.ref_reads:
             t0 = time.time()
             r = subprocess.run([str(ref_cli), *ref_args, "-k", str(a.k), "-q", str(sample), prefix], capture_output=True)
             ref_s = time.time() - t0
-            g = subprocess.run([str(fm.CLI_PATH), *args, "-q", str(sample), prefix], capture_output=True)
+            g = subprocess.run([str(fm.CLI_PATH), *args, "-q", str(sample), prefix], capture_output=True, env=env)
             entry["sample_identical_to_reference"] = bool(r.returncode == 0 and r.stdout == g.stdout)
             entry["reference_windows_per_s"] = round(a.ref_reads * windows_per_read / ref_s)
             with open(outp, "rb") as f:
