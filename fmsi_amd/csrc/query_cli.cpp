@@ -109,7 +109,7 @@ int usage_query(bool lookup) {
     std::cerr << "  --stats      - print timings to stderr" << std::endl;
     std::cerr << "  --tables auto|full|candidates - device-side accelerators (results unaffected).  auto [default]: a prefix table of up" << std::endl;
     std::cerr << "                 to 14 bases, which keeps the device about level with this program's reader and loads fastest (query" << std::endl;
-    std::cerr << "                 files of 30 GB and more get `full`); full: the k-mer dictionary -- one 128-byte read per k-mer, about" << std::endl;
+    std::cerr << "                 files of 16 GB and more get `full`); full: the k-mer dictionary -- one 128-byte read per k-mer, about" << std::endl;
     std::cerr << "                 12 bytes of HBM per distinct k-mer, the fastest device path (also for -S); candidates: the 16-base" << std::endl;
     std::cerr << "                 prefix table with candidate tables (up to 180 GB of HBM)" << std::endl;
     std::cerr << std::endl;
@@ -671,6 +671,82 @@ inline uint64_t run_end(const uint8_t* p, uint64_t from, uint64_t n, uint8_t v) 
     return e;
 }
 
+// One -S chunk of strict result bytes, 16 windows a step.  With F = f + 1 = b & 3 and R = r + 1 = (b >> 2) & 3 (0, 1, 2 for -1, 0, 1):
+// the first strand searched settles a window when it says 1, or 0 under -O (replay_streaming_chunk above); the window prints 1
+// when the settling strand says 1, or -- unsettled -- when the other one does.  sums[swap] = {sum of the first strand's results,
+// sum of the second strand's over the unsettled windows}; returns whether some window prints differently for the two strand orders.
+struct ChunkMasks {
+    __m128i dec0, dec1, one0, one1, F, R4;
+};
+inline ChunkMasks chunk_masks(__m128i v, bool maximized_ones) {
+    ChunkMasks m;
+    m.F = _mm_and_si128(v, _mm_set1_epi8(3));
+    m.R4 = _mm_and_si128(v, _mm_set1_epi8(12));   // 4 (r + 1)
+    const __m128i f_one = _mm_cmpeq_epi8(m.F, _mm_set1_epi8(2)), r_one = _mm_cmpeq_epi8(m.R4, _mm_set1_epi8(8));
+    m.dec0 = f_one;
+    m.dec1 = r_one;
+    if (maximized_ones) {
+        m.dec0 = _mm_or_si128(m.dec0, _mm_cmpeq_epi8(m.F, _mm_set1_epi8(1)));
+        m.dec1 = _mm_or_si128(m.dec1, _mm_cmpeq_epi8(m.R4, _mm_set1_epi8(4)));
+    }
+    m.one0 = _mm_or_si128(f_one, _mm_andnot_si128(m.dec0, r_one));
+    m.one1 = _mm_or_si128(r_one, _mm_andnot_si128(m.dec1, f_one));
+    return m;
+}
+inline bool chunk_sums(const uint8_t* b, uint32_t n, bool maximized_ones, int sums[2][2]) {
+    int fs[2] = {0, 0}, ss[2] = {0, 0};
+    bool matters = false;
+    uint32_t i = 0;
+    if (n >= 16) {
+        const __m128i zero = _mm_setzero_si128(), one = _mm_set1_epi8(1);
+        __m128i sF = zero, sR4 = zero, sR4u = zero, sFu = zero, nu0 = zero, nu1 = zero, diff = zero;   // byte sums (two 64-bit lanes each)
+        for (; i + 16 <= n; i += 16) {
+            const ChunkMasks m = chunk_masks(_mm_loadu_si128(reinterpret_cast<const __m128i*>(b + i)), maximized_ones);
+            sF = _mm_add_epi64(sF, _mm_sad_epu8(m.F, zero));
+            sR4 = _mm_add_epi64(sR4, _mm_sad_epu8(m.R4, zero));
+            sR4u = _mm_add_epi64(sR4u, _mm_sad_epu8(_mm_andnot_si128(m.dec0, m.R4), zero));   // second strand = r where f does not settle
+            sFu = _mm_add_epi64(sFu, _mm_sad_epu8(_mm_andnot_si128(m.dec1, m.F), zero));      // second strand = f where r does not settle
+            nu0 = _mm_add_epi64(nu0, _mm_sad_epu8(_mm_andnot_si128(m.dec0, one), zero));
+            nu1 = _mm_add_epi64(nu1, _mm_sad_epu8(_mm_andnot_si128(m.dec1, one), zero));
+            diff = _mm_or_si128(diff, _mm_xor_si128(m.one0, m.one1));
+        }
+        auto total = [](__m128i x) { return static_cast<int>(_mm_cvtsi128_si32(x) + _mm_cvtsi128_si32(_mm_srli_si128(x, 8))); };
+        const int done = static_cast<int>(i);
+        fs[0] = total(sF) - done;              // sum of f = sum of F - windows
+        fs[1] = total(sR4) / 4 - done;
+        ss[0] = total(sR4u) / 4 - total(nu0);
+        ss[1] = total(sFu) - total(nu1);
+        matters = _mm_movemask_epi8(diff) != 0;
+    }
+    for (; i < n; ++i) {
+        const int f = fwd_of(b[i]), r = rc_of(b[i]);
+        const bool dec0 = f == 1 || (f == 0 && maximized_ones), dec1 = r == 1 || (r == 0 && maximized_ones);
+        fs[0] += f;
+        ss[0] += dec0 ? 0 : r;
+        fs[1] += r;
+        ss[1] += dec1 ? 0 : f;
+        const int v0 = dec0 ? f : std::max(f, r), v1 = dec1 ? r : std::max(r, f);
+        matters |= (v0 == 1) != (v1 == 1);
+    }
+    sums[0][0] = fs[0];
+    sums[0][1] = ss[0];
+    sums[1][0] = fs[1];
+    sums[1][1] = ss[1];
+    return matters;
+}
+// ... and its output bytes when the strand order does not matter: 1 where the window prints '1'
+inline void chunk_output(uint8_t* b, uint32_t n, bool maximized_ones) {
+    uint32_t i = 0;
+    for (; i + 16 <= n; i += 16) {
+        const ChunkMasks m = chunk_masks(_mm_loadu_si128(reinterpret_cast<const __m128i*>(b + i)), maximized_ones);
+        _mm_storeu_si128(reinterpret_cast<__m128i*>(b + i), _mm_and_si128(m.one0, _mm_set1_epi8(1)));
+    }
+    for (; i < n; ++i) {
+        const int f = fwd_of(b[i]), r = rc_of(b[i]);
+        b[i] = static_cast<uint8_t>((f == 1 || (f == 0 && maximized_ones) ? f : std::max(f, r)) == 1);
+    }
+}
+
 // strict results (both strands per window) -> final per-window values, in the order the reference visits them
 void replay_batch(Prepared& P, StrandPredictor& predictor, Mode mode, bool orders, bool streaming, int k, unsigned team) {
     if (!streaming) {
@@ -755,29 +831,11 @@ void replay_batch(Prepared& P, StrandPredictor& predictor, Mode mode, bool order
         for (size_t c = nc / team * t, hi = t + 1 == team ? nc : nc / team * (t + 1); c < hi; ++c) {
             Chunk& ch = chunks[c];
             uint8_t* b = P.bytes.data() + ch.w0;
-            int fs[2] = {0, 0}, ss[2] = {0, 0};
-            bool matters = false;
-            for (uint32_t i = 0; i < ch.n; ++i) {
-                const int f = fwd_of(b[i]), r = rc_of(b[i]);
-                // no swap: first = f; swap: first = r (replay_streaming_chunk above)
-                const bool dec0 = f == 1 || (f == 0 && maximized_ones), dec1 = r == 1 || (r == 0 && maximized_ones);
-                fs[0] += f;
-                ss[0] += dec0 ? 0 : r;
-                fs[1] += r;
-                ss[1] += dec1 ? 0 : f;
-                const int v0 = dec0 ? f : std::max(f, r), v1 = dec1 ? r : std::max(r, f);
-                matters |= (v0 == 1) != (v1 == 1);
-            }
-            ch.sums[0][0] = static_cast<int16_t>(fs[0]);
-            ch.sums[0][1] = static_cast<int16_t>(ss[0]);
-            ch.sums[1][0] = static_cast<int16_t>(fs[1]);
-            ch.sums[1][1] = static_cast<int16_t>(ss[1]);
-            ch.order_matters = matters;
-            if (!matters)
-                for (uint32_t i = 0; i < ch.n; ++i) {
-                    const int f = fwd_of(b[i]), r = rc_of(b[i]);
-                    b[i] = static_cast<uint8_t>((f == 1 || (f == 0 && maximized_ones) ? f : std::max(f, r)) == 1);
-                }
+            int sums[2][2];
+            ch.order_matters = chunk_sums(b, ch.n, maximized_ones, sums);
+            for (int sw = 0; sw < 2; ++sw)
+                for (int j = 0; j < 2; ++j) ch.sums[sw][j] = static_cast<int16_t>(sums[sw][j]);
+            if (!ch.order_matters) chunk_output(b, ch.n, maximized_ones);
         }
     });
     for (Chunk& ch : chunks) {
@@ -831,16 +889,15 @@ inline void expand_bits(const uint64_t* words, uint64_t first, uint64_t count, c
 }
 
 // presence modes: every line has a known length, the team writes straight into one buffer
-void format_bits(const Prepared& P, unsigned team, std::vector<char>& out) {
+void format_bits(const Prepared& P, unsigned team, char* out) {   // out: P.rec_out[records] bytes
     const size_t nrec = P.raw.recs.size();
-    out.resize(P.rec_out[nrec]);
     team = static_cast<unsigned>(std::max<size_t>(1, std::min<size_t>(team, nrec / 64 + 1)));
     parallel_for(team, [&](unsigned t) {
         // ranges of about equal output size
         const uint64_t lo = P.rec_out[nrec] / team * t, hi = t + 1 == team ? P.rec_out[nrec] : P.rec_out[nrec] / team * (t + 1);
         size_t r = static_cast<size_t>(std::lower_bound(P.rec_out.begin(), P.rec_out.begin() + static_cast<std::ptrdiff_t>(nrec), lo) - P.rec_out.begin());
         for (; r < nrec && P.rec_out[r] < hi; ++r) {
-            char* dst = out.data() + P.rec_out[r];
+            char* dst = out + P.rec_out[r];
             const RecRef& rr = P.raw.recs[r];
             std::memcpy(dst, rr.name, rr.name_len);
             dst += rr.name_len;
@@ -1146,16 +1203,16 @@ extern "C" int fmsi_cli_query(int argc, char** argv, int output_orders_i) {
     }
     if (k == 0) k = index_k;
 
-    // private accelerators (results unchanged).  How much of them: end to end this program moves 2-3 G windows/s (reader, copies,
-    // formatting), and with a 14-deep prefix table the device stage -- kernels at about 5 G k-mers/s at human scale
-    // plus the copies -- is level with that.  The k-mer dictionary (45 G k-mers/s on resident batches: bench.py) takes seconds
-    // more to build, so it is built when asked for (--tables full) or when the query file is so large (30 GB; uncompressed
-    // bytes ~ windows) that the difference adds up.
+    // private accelerators (results unchanged).  How much of them: end to end this program moves 3-4 G windows/s at human scale
+    // with a 14-deep prefix table -- the device stage (LF walk at about 5 G k-mers/s) is then the longest, just ahead of write()
+    // -- and 5-7 G windows/s with the k-mer dictionary (45 G k-mers/s on resident batches: bench.py), which takes about half a
+    // second more to build at that scale.  So the dictionary is built when asked for (--tables full) or when the
+    // query file is so large (16 GB; uncompressed bytes ~ windows) that the difference pays for the build several times over.
     if (!opt.tables_given && opt.query_fn != "-") {
         struct stat st;
         const bool gz = opt.query_fn.size() > 3 && opt.query_fn.compare(opt.query_fn.size() - 3, 3, ".gz") == 0;
         if (stat(opt.query_fn.c_str(), &st) == 0 && S_ISREG(st.st_mode) &&
-            static_cast<uint64_t>(st.st_size) * (gz ? 4u : 1u) >= 30000000000ull)
+            static_cast<uint64_t>(st.st_size) * (gz ? 4u : 1u) >= 16000000000ull)
             opt.full_tables = true;
     }
     // `full`: presence queries (also -S ones: their answers do not depend on the kLCP array) are answered by the k-mer
@@ -1265,73 +1322,39 @@ extern "C" int fmsi_cli_query(int argc, char** argv, int output_orders_i) {
     }
 
     // ---- output: a formatter (the team writes the batch's lines into one buffer) and behind it the sink that hands the buffer to
-    // stdout while the next batch is formatted.  A regular file that is not in append mode is written by several threads at once,
-    // each its slice at its own offset (pwrite); anything else -- a pipe, a terminal, /dev/null -- by plain write().
-    struct Sink {
-        bool positional = false;
-        off_t pos = 0;
-        unsigned threads = 1;
-        void init(unsigned team) {
-            std::fflush(stdout);
-            struct stat st;
-            const int fl = fcntl(STDOUT_FILENO, F_GETFL);
-            if (fstat(STDOUT_FILENO, &st) == 0 && S_ISREG(st.st_mode) && fl >= 0 && !(fl & O_APPEND) && !std::getenv("FMSI_HIP_SERIAL_WRITER")) {
-                pos = lseek(STDOUT_FILENO, 0, SEEK_CUR);
-                positional = pos >= 0;
-            }
-            threads = std::max(1u, std::min(8u, team));
-        }
-        static void write_all(const char* p, size_t n, bool at, off_t off) {
-            while (n) {
-                const ssize_t w = at ? pwrite(STDOUT_FILENO, p, n, off) : write(STDOUT_FILENO, p, n);
-                if (w < 0 && errno == EINTR) continue;
-                if (w <= 0) throw std::runtime_error("write to stdout failed");
-                p += w;
-                n -= static_cast<size_t>(w);
-                off += w;
-            }
-        }
-        void put(const char* p, size_t n) {
-            if (!n) return;
-            if (!positional) {
-                write_all(p, n, false, 0);
-                return;
-            }
-            const unsigned parts = static_cast<unsigned>(std::max<size_t>(1, std::min<size_t>(threads, n >> 22)));
-            const size_t per = (n / parts + 4095) & ~size_t(4095);
-            parallel_for(parts, [&](unsigned t) {
-                const size_t lo = std::min(n, per * t), hi = t + 1 == parts ? n : std::min(n, per * (t + 1));
-                if (hi > lo) write_all(p + lo, hi - lo, true, pos + static_cast<off_t>(lo));
-            });
-            pos += static_cast<off_t>(n);
-        }
-        void finish() {   // leave the shared file offset behind what was written, as sequential writes would
-            if (positional) (void)lseek(STDOUT_FILENO, pos, SEEK_SET);
-        }
-    };
+    // stdout with write() while the next batch is formatted.  (Measured and dropped, profiles/README.md r02n: several threads
+    // pwrite()-ing slices of a regular file -- buffered writes to one inode serialise on its lock -- and formatting straight into
+    // a shared mapping of the grown file -- the team's page faults on one address space cost 2-3x the write() they replace.)
     struct OutBuf {
         std::vector<char> bits;             // presence modes: the whole batch
         std::vector<std::string> parts;     // lookup: one piece per formatting thread
+    };
+    auto write_all = [](const char* p, size_t n) {
+        while (n) {
+            const ssize_t w = write(STDOUT_FILENO, p, n);
+            if (w < 0 && errno == EINTR) continue;
+            if (w <= 0) throw std::runtime_error("write to stdout failed");
+            p += w;
+            n -= static_cast<size_t>(w);
+        }
     };
     BoundedQueue<std::unique_ptr<OutBuf>> sink_q(1), spare_q(3);
     std::exception_ptr sink_err;
     std::thread sink_thread([&] {
         try {
-            Sink sink;
-            sink.init(team);
+            std::fflush(stdout);   // (nothing of this program's is in stdio's buffer, but whatever is goes first)
             std::unique_ptr<OutBuf> b;
             while (sink_q.pop(b)) {
                 auto t1 = clock::now();
                 {
                     TraceRange write_range("fmsi: write");
                     if (output_orders)
-                        for (const std::string& s : b->parts) sink.put(s.data(), s.size());
-                    else sink.put(b->bits.data(), b->bits.size());
+                        for (const std::string& s : b->parts) write_all(s.data(), s.size());
+                    else write_all(b->bits.data(), b->bits.size());
                 }
                 write_s += std::chrono::duration<double>(clock::now() - t1).count();
                 (void)spare_q.push(std::move(b));
             }
-            sink.finish();
         } catch (...) {
             sink_err = std::current_exception();
             sink_q.abort();
@@ -1343,12 +1366,17 @@ extern "C" int fmsi_cli_query(int argc, char** argv, int output_orders_i) {
             for (int i = 0; i < 2; ++i) (void)spare_q.push(std::make_unique<OutBuf>());
             std::unique_ptr<Prepared> P;
             while (out_q.pop(P)) {
+                const size_t n = output_orders ? 0 : P->rec_out[P->raw.recs.size()];
                 std::unique_ptr<OutBuf> b;
                 if (!spare_q.pop(b)) break;   // the sink failed
                 auto t0 = clock::now();
                 trace_push("fmsi: format");
-                if (output_orders) format_orders(*P, team, b->parts);
-                else format_bits(*P, team, b->bits);
+                if (output_orders) {
+                    format_orders(*P, team, b->parts);
+                } else {
+                    b->bits.resize(n);
+                    format_bits(*P, team, b->bits.data());
+                }
                 trace_pop();
                 format_s += std::chrono::duration<double>(clock::now() - t0).count();
                 P.reset();

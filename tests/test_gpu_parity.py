@@ -666,6 +666,48 @@ def test_cli_exits_when_stdout_fails(fm, tmp_path):
     assert rc == 0 and out.count(b"\n") == 4000
 
 
+@pytest.mark.parametrize("mode", ["or", "all", "all_S"])
+def test_cli_output_to_a_regular_file(fm, tmp_path, mode):
+    """stdout = a regular file instead of a pipe: the bytes a pipe receives -- behind whatever was in the file before the offset (a
+    shell's `{ echo; fmsi query; } > out`), leaving alone what lies behind the range when the file is already longer (`1<> out`),
+    with the shared offset behind the output afterwards; and appended to a file opened for appending."""
+    import os
+    import subprocess
+    name, k = "mixed_k11", 11
+    ms = "".join(l.strip() for l in open(GOLDEN / "mixed.fa") if not l.startswith(">"))
+    rng = random.Random(11)
+    q = tmp_path / "q.fa"
+    q.write_bytes(b"".join(messy_fasta(ms, rng) for _ in range(8)))
+    args = [str(fm.CLI_PATH), *MODES[mode][0], "-k", str(k), "-q", str(q), "--batch", "4096", index_prefix(name)]
+    want = subprocess.run(args, capture_output=True, timeout=300)
+    assert want.returncode == 0 and len(want.stdout) > 10000, want.stderr.decode()
+    # (1) a fresh write-only file with a header line before the output and a trailer after it, through the one shared offset
+    out = tmp_path / "out1.txt"
+    with open(out, "wb") as f:
+        os.write(f.fileno(), b"header line\n")
+        res = subprocess.run(args, stdout=f, stderr=subprocess.PIPE, timeout=300)
+        assert res.returncode == 0, res.stderr.decode()
+        os.write(f.fileno(), b"trailer\n")
+    assert out.read_bytes() == b"header line\n" + want.stdout + b"trailer\n"
+    # (2) a longer file opened read-write at offset 5: the output overwrites its range, the rest stays
+    out = tmp_path / "out2.txt"
+    filler = b"x" * (len(want.stdout) + 1000)
+    out.write_bytes(filler)
+    fd = os.open(out, os.O_RDWR)
+    os.lseek(fd, 5, os.SEEK_SET)
+    res = subprocess.run(args, stdout=fd, stderr=subprocess.PIPE, timeout=300)
+    assert res.returncode == 0, res.stderr.decode()
+    assert os.lseek(fd, 0, os.SEEK_CUR) == 5 + len(want.stdout)
+    os.close(fd)
+    assert out.read_bytes() == filler[:5] + want.stdout + filler[5 + len(want.stdout):]
+    # (3) append mode
+    out = tmp_path / "out3.txt"
+    out.write_bytes(b"before\n")
+    with open(out, "ab") as f:
+        res = subprocess.run(args, stdout=f, stderr=subprocess.PIPE, timeout=300)
+    assert res.returncode == 0 and out.read_bytes() == b"before\n" + want.stdout
+
+
 @pytest.mark.parametrize("mode", ["or", "all", "all_S", "lookup"])
 def test_cli_with_several_device_handles(fm, tmp_path, mode):
     """--devices a,b,...: one replicated handle per device, batches dealt out to worker threads, output in input order and the

@@ -6,6 +6,7 @@ that the product fails LOUDLY without a GPU instead of falling back to anything.
 import ctypes as C
 import re
 import random
+import os
 import subprocess
 
 import numpy as np
@@ -288,6 +289,22 @@ def test_view_parser_equals_reader_fuzz(tmp_path):
     res = subprocess.run([str(exe), "150000"], capture_output=True, text=True)
     assert res.returncode == 0, (res.stdout + res.stderr)[-3000:]
     assert "on 150000 inputs" in res.stdout
+
+
+def test_cli_host_kernels_equal_their_definitions(tmp_path):
+    """The CLI's word-at-a-time host loops -- SSE2 validity scan, PEXT / plain 2-bit packer, PDEP / plain expansion of result bits
+    into characters, SSE2 sums and output bytes of a -S chunk -- against their character-at-a-time definitions (ASan + UBSan)."""
+    import fmsi_amd
+    fmsi_amd.build()
+    exe = tmp_path / "cli_host_kernels"
+    lib = REPO / "fmsi_amd" / "lib"
+    src = REPO / "fmsi_amd" / "csrc"
+    res = subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", f"-I{REPO / 'include'}",
+                          str(REPO / "tests" / "native" / "cli_host_kernels.cpp"), str(src / "fastx.cpp"), str(src / "trace.cpp"), "-o", str(exe),
+                          f"-L{lib}", "-lfmsi_hip", "-lz", "-lpthread", "-ldl", f"-Wl,-rpath,{lib}"], capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr[-3000:]
+    res = subprocess.run([str(exe)], capture_output=True, text=True, env={**os.environ, "ASAN_OPTIONS": "detect_leaks=0"})
+    assert res.returncode == 0 and "cli host kernels OK" in res.stdout, (res.stdout + res.stderr)[-3000:]
 
 
 def test_threaded_rrr_decode_under_tsan_and_corrupt_mask(oracle_built, tmp_path):
