@@ -895,6 +895,7 @@ int load_fail(int code, const std::string& msg) {
 extern "C" int fmsi_hip_index_load(const char* prefix_c, int use_klcp, int device, int prefix_len, fmsi_hip_index** out) {
     if (!prefix_c || !out) return load_fail(FMSI_HIP_EINVAL, "null argument");
     TraceRange trace_range("fmsi: load index files into HBM");
+    PhaseClock clock{"load"};
     const std::string base = std::string(prefix_c) + ".fmsi";
     // ---- the files: headers parsed on the host, payloads stay where the page cache has them ----------------------------------
     Mapped f_acgt, f_ac, f_gt, f_mask, f_klcp;
@@ -948,9 +949,11 @@ extern "C" int fmsi_hip_index_load(const char* prefix_c, int use_klcp, int devic
         fmsi_host_index_free(host);
         return rc;
     }
+    clock.mark("files mapped, headers");
     int rc = check_device(device);
     if (rc) return rc;
     FMSI_HIP_ON_DEVICE(device);
+    clock.mark("device selected (HIP init)");
 
     // ---- payloads to the device (two zero words of padding behind each) -----------------------------------------------------
     const uint64_t n_words = (n + 63) >> 6, n_blocks = ((n + kBlockRows - 1) >> kBlockRowsLog2) + 1;
@@ -977,6 +980,7 @@ extern "C" int fmsi_hip_index_load(const char* prefix_c, int use_klcp, int devic
     FMSI_HIP_TRY(hipMemsetAsync(d_corrupt.p, 0, 4, 0));
     FMSI_HIP_TRY(hipMemsetAsync(d_pc.p, 0, (n_words + 1) * 4, 0));
 
+    clock.mark("payloads uploaded");
     // ---- mask: RRR-63 -> plain words ---------------------------------------------------------------------------------------------
     {
         const uint64_t waves = (n_rrr_blocks + 63) / 64;
@@ -1026,6 +1030,7 @@ extern "C" int fmsi_hip_index_load(const char* prefix_c, int use_klcp, int devic
         if (corrupt) return load_fail(FMSI_HIP_EIO, "rrr_vector<63> image: block offsets run past the end of the offset vector");
         if (gt_total != gt.bits) return load_fail(FMSI_HIP_EINVAL, "index view: popcount(ac_gt) != |gt|");
     }
+    clock.mark("mask decoded, blocks laid out");
     auto* idx = new fmsi_hip_index();
     idx->device = device;
     idx->n = n;
@@ -1060,6 +1065,7 @@ extern "C" int fmsi_hip_index_load(const char* prefix_c, int use_klcp, int devic
         fmsi_hip_index_destroy(idx);
         return rc;
     }
+    clock.mark("prefix table");
     *out = idx;
     return 0;
 }

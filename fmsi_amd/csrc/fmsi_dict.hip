@@ -800,21 +800,6 @@ int launch_dict_chain(fmsi_hip_index* idx, const uint64_t* d_seq, uint64_t n, in
 using namespace fmsi;
 
 namespace {
-// FMSI_HIP_VERBOSE: phase times of the construction on stderr
-struct PhaseClock {
-    bool on = std::getenv("FMSI_HIP_VERBOSE") != nullptr;
-    std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
-    void mark(const char* what) {
-        if (!on) return;
-        (void)hipDeviceSynchronize();
-        const auto now = std::chrono::steady_clock::now();
-        fprintf(stderr, "[fmsi dict] %-28s %8.3f s\n", what, std::chrono::duration<double>(now - t).count());
-        t = now;
-    }
-};
-}  // namespace
-
-namespace {
 // The chained form's extras, by a pass of the lookup kernel over the text's own windows: the answer nibble of every text position
 // (the kernel's STRICT | OUT_BITS packing of the raw nibbles) and, per slot, the position of an occurrence.  `text2`: the 2-bit text
 // the construction made (taken over when the handle has none of its own).
@@ -877,7 +862,7 @@ extern "C" int fmsi_hip_index_enable_dict(fmsi_hip_index* idx, uint32_t flags) {
         for (uint32_t lv = 0; lv < idx->dict.levels; ++lv) total_slots = idx->dict.lv[lv].slot_base + (16ull << (64u - idx->dict.lv[lv].shift));
         return add_chain_extras(idx, text2, total_slots);
     }
-    PhaseClock clock;
+    PhaseClock clock{"dict"};
     TraceRange trace_range("fmsi: build k-mer dictionary");
     const int k = idx->k;
     const uint64_t n = idx->n, len = n - 1;

@@ -5,7 +5,10 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdint>
+#include <cstdio>
+#include <cstdlib>
 #include <string>
 #include <utility>
 #include <vector>
@@ -295,4 +298,18 @@ inline int prof_end(fmsi_hip_index* idx, hipStream_t s, size_t slot) {
     FMSI_HIP_TRY(hipEventRecord(idx->events[slot].second, s));
     return 0;
 }
+// FMSI_HIP_VERBOSE: phase times of the load / the constructions on stderr (a device synchronisation per mark, only then)
+struct PhaseClock {
+    const char* tag = "";
+    bool on = std::getenv("FMSI_HIP_VERBOSE") != nullptr;
+    std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+    void mark(const char* what) {
+        if (!on) return;
+        (void)hipDeviceSynchronize();
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[fmsi %s] %-28s %8.3f s\n", tag, what, std::chrono::duration<double>(now - t).count());
+        t = now;
+    }
+};
+
 }  // namespace fmsi

@@ -130,6 +130,8 @@ def main() -> None:
         for line in p.stderr.decode().splitlines():
             if line.startswith("{"):
                 entry.update(json.loads(line))
+            elif "FMSI_HIP_VERBOSE" in env:
+                print("   ", line, flush=True)
         if p.returncode != 0:
             entry["stderr"] = p.stderr.decode()[-400:]
         w = entry.get("windows", 0)
