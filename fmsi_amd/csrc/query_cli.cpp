@@ -748,7 +748,7 @@ inline void chunk_output(uint8_t* b, uint32_t n, bool maximized_ones) {
 }
 
 // strict results (both strands per window) -> final per-window values, in the order the reference visits them
-void replay_batch(Prepared& P, StrandPredictor& predictor, Mode mode, bool orders, bool streaming, int k, unsigned team) {
+void replay_batch(Prepared& P, StrandPredictor& predictor, Mode mode, bool orders, bool streaming, int k, unsigned team, bool wide_orders = false) {
     if (!streaming) {
         // One predictor step per window, in output order == result order; fills do not touch the predictor.  The
         // predictor is a small saturating state machine: when a step leaves it unchanged, every following window with
@@ -771,23 +771,29 @@ void replay_batch(Prepared& P, StrandPredictor& predictor, Mode mode, bool order
             }
             return;
         }
+        // lookup.  What a window prints is its first strand's order if that strand has the k-mer, else the second's
+        // (src/fms_index.h:281-287: the first strand's order is looked at as an int -- an order of 2^31 and more counts as absent
+        // there -- the second's sign as it is), and what the predictor is told are those signs.  A first strand that is negative
+        // as an int goes into the predictor with its value (fms_index.h:283-291); any value below -14 saturates the scores alike,
+        // and orders below 2^32 - 128 (every index with 32-bit rows) are such values, so there the four signs stand for the
+        // window; an index of 2^32 rows and more takes every step with the values themselves.
+        // (Measured and dropped, profiles/README.md r02n: signs by the team, predictor over the sign bytes, choice by the team --
+        // three passes over 16 bytes per window cost more than this one: 2.0 against 1.0 s per 10^9 windows at 1.4 G rows, 3.9
+        // against 2.9 s at 2.8 G rows, where every other present k-mer's order is above 2^31 and equal neighbours are rare.)
         int64_t* o = P.orders.data();
+        auto cls = [](int64_t x, int64_t y) {
+            return (static_cast<int>(x) >= 0 ? 1 : 0) | (x >= 0 ? 2 : 0) | (static_cast<int>(y) >= 0 ? 4 : 0) | (y >= 0 ? 8 : 0);
+        };
         while (w < nw) {
             const int64_t f = o[2 * w], r = o[2 * w + 1];
             const StrandPredictor before = predictor;
             o[w++] = replay_single(predictor, mode, true, f, r);
-            if (same_state(before, predictor)) {
-                // the decision looks at the first strand's order truncated to int and at the sign of the second's
-                // (src/fms_index.h:281-287), so that is what "the same input" means here
-                auto cls = [](int64_t x, int64_t y) {
-                    return (static_cast<int>(x) >= 0 ? 1 : 0) | (x >= 0 ? 2 : 0) | (static_cast<int>(y) >= 0 ? 4 : 0) | (y >= 0 ? 8 : 0);
-                };
-                const int c0 = cls(f, r);
-                const bool swap = predictor.predict_swap();
-                while (w < nw && cls(o[2 * w], o[2 * w + 1]) == c0) {
-                    const int64_t first = swap ? o[2 * w + 1] : o[2 * w], second = swap ? o[2 * w] : o[2 * w + 1];
-                    o[w++] = static_cast<int>(first) >= 0 ? first : second;
-                }
+            if (wide_orders || !same_state(before, predictor)) continue;
+            const int c0 = cls(f, r);
+            const bool swap = predictor.predict_swap();
+            while (w < nw && cls(o[2 * w], o[2 * w + 1]) == c0) {
+                const int64_t first = swap ? o[2 * w + 1] : o[2 * w], second = swap ? o[2 * w] : o[2 * w + 1];
+                o[w++] = static_cast<int>(first) >= 0 ? first : second;
             }
         }
         return;
@@ -927,11 +933,13 @@ void format_bits(const Prepared& P, unsigned team, char* out) {   // out: P.rec_
 void format_orders(const Prepared& P, unsigned team, std::vector<std::string>& parts) {
     const size_t nrec = P.raw.recs.size();
     team = static_cast<unsigned>(std::max<size_t>(1, std::min<size_t>(team, nrec / 64 + 1)));
-    parts.assign(team, std::string());
+    parts.resize(team);   // (the strings keep their capacity from batch to batch)
     const uint64_t total = P.rec_first[nrec] + nrec;   // balance by windows (+1 per record)
     parallel_for(team, [&](unsigned t) {
         std::string& s = parts[t];
         const uint64_t lo = total / team * t, hi = t + 1 == team ? total + 1 : total / team * (t + 1);
+        s.clear();
+        if (s.capacity() < (hi - lo) * 8) s.reserve((hi - lo) * 8);   // (about 7 characters per order at human scale; grows if that is short)
         char num[24];
         for (size_t r = 0; r < nrec; ++r) {
             const uint64_t key = P.rec_first[r] + r;
@@ -1485,7 +1493,7 @@ extern "C" int fmsi_cli_query(int argc, char** argv, int output_orders_i) {
             auto t2 = clock::now();
             if (strict) {
                 TraceRange replay_range("fmsi: predictor replay");
-                replay_batch(*P, predictor, opt.mode, output_orders, opt.has_klcp, k, team);
+                replay_batch(*P, predictor, opt.mode, output_orders, opt.has_klcp, k, team, rows64);
             }
             replay_s += std::chrono::duration<double>(clock::now() - t2).count();
             total_windows += P->windows;

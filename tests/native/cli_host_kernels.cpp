@@ -81,6 +81,48 @@ int main() {
         chunk_output(b.data(), n, maximized_ones);
         if (b != out) return fail("chunk_output", it, n);
     }
+    // lookup replay (runs of windows with the same signs skipped behind a step that left the predictor unchanged) against one
+    // replay_single per window: absent strands, orders that fit an int, orders of 2^31 and more (absent to the reference's int)
+    // and -- as indexes of 2^32 rows and more produce them, replayed value by value -- orders whose low 32 bits are anything
+    for (size_t it = 0; it < 60; ++it) {
+        const uint64_t nw = it < 50 ? 1 + rng() % 3000 : 200000 + rng() % 300000;
+        Prepared P;
+        P.windows = nw;
+        P.orders.resize(2 * nw);
+        const int shape = static_cast<int>(it % 5);
+        const bool wide = it % 3 == 0;
+        auto draw = [&](int strand) -> int64_t {
+            const uint64_t x = rng();
+            const int kind = shape == 4 ? static_cast<int>(x % (wide ? 6 : 3)) : (shape == strand ? 1 + static_cast<int>(x % 2) : (x % 40 ? 0 : 1 + static_cast<int>(x % (wide ? 5 : 2))));
+            switch (kind) {
+            case 0: return -1;
+            case 1: return static_cast<int64_t>((x >> 8) % 2000000000u);
+            case 2: return static_cast<int64_t>(0x80000000ull + (x >> 8) % 0x7FFFFF00ull);
+            case 3: return static_cast<int64_t>((1ull << 32) + (x >> 8) % 1000u);
+            case 4: return static_cast<int64_t>((3ull << 32) - 1 - (x >> 8) % 14u);   // (int) in [-14, -1]
+            default: return static_cast<int64_t>((5ull << 32) - 20 - (x >> 8) % 100000u);
+            }
+        };
+        uint64_t i = 0;
+        while (i < nw) {   // runs of similar windows, as reads give them
+            const uint64_t run = 1 + rng() % 200;
+            const int64_t f = draw(0), r = draw(1);
+            for (uint64_t j = 0; j < run && i < nw; ++j, ++i) {
+                P.orders[2 * i] = f < 0 || rng() % 8 ? f : draw(0);
+                P.orders[2 * i + 1] = r < 0 || rng() % 8 ? r : draw(1);
+            }
+        }
+        StrandPredictor a, b;
+        for (int warm = static_cast<int>(rng() % 5); warm > 0; --warm) {
+            const int x = static_cast<int>(rng() % 3) - 1, y = static_cast<int>(rng() % 3) - 1;
+            a.log_result(x, y);
+            b.log_result(x, y);
+        }
+        std::vector<int64_t> want(nw);
+        for (uint64_t w = 0; w < nw; ++w) want[w] = replay_single(a, Mode::Or, true, P.orders[2 * w], P.orders[2 * w + 1]);
+        replay_batch(P, b, Mode::Or, true, false, 31, it % 2 ? 5u : 1u, wide);
+        if (!same_state(a, b) || std::memcmp(want.data(), P.orders.data(), nw * 8) != 0) return fail("lookup replay", it, nw);
+    }
     printf("cli host kernels OK\n");
     return 0;
 }

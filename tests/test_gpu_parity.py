@@ -647,6 +647,60 @@ def test_block_parallel_fastq_reader(fm, oracle_built, tmp_path, monkeypatch, sh
         assert got.count(b"\n") > (600 if shape == "short_quality_inside" else 1400)
 
 
+@pytest.mark.parametrize("name,k", [("mixed_k11", 11), ("sars_k13", 13), ("both_strands", 13)])
+def test_lookup_replay_on_large_batches(fm, oracle_built, tmp_path, name, k):
+    """`fmsi lookup` on batches of a million windows and more: the replay of the strand predictor skips runs of windows with the
+    same signs behind a step that left it unchanged, and must still print the other strand's order where it had swapped the
+    strands -- `both_strands`: a text that holds reverse-complemented copies of its own pieces under a random mask, so that windows
+    whose two strands both have the k-mer come in long runs.  Byte for byte the reference's output, in one batch and in many."""
+    if name == "both_strands":
+        rng = random.Random(77)
+        base = "".join(rng.choice("ACGT") for _ in range(30000))
+        pieces = [base]
+        for _ in range(12):
+            p = rng.randrange(0, len(base) - 3000)
+            pieces.append(revcomp(base[p:p + rng.choice([500, 1500, 3000])]))
+        text = "".join(pieces)
+        ms = "".join(ch if rng.random() < 0.6 else ch.lower() for ch in text)
+        ms = ms[: len(ms) - (k - 1)] + ms[len(ms) - (k - 1):].lower()
+        prefix = str(tmp_path / "both")
+        oracle_py.Oracle.construct(ms, k, use_klcp=False).dump(prefix)
+    else:
+        src = GOLDEN / ("mixed.fa" if name == "mixed_k11" else "ref_data/GCF_009858895.2_ASM985889v3_genomic.fna.ms.k13")
+        ms = "".join(l.strip() for l in open(src) if not l.startswith(">"))
+        prefix = index_prefix(name)
+    rng = random.Random(5)
+    q = tmp_path / "q.fa"
+    with open(q, "w") as f:
+        for r in range(700):
+            L = rng.choice([1500, 2500, 4000])
+            p = rng.randrange(0, len(ms) - L)
+            seq = ms[p:p + L]
+            if r % 3 == 1:
+                seq = revcomp(seq.upper())
+            if r % 5 == 4:
+                seq = "".join(rng.choice("ACGT") for _ in range(L))
+            if r % 7 == 0:
+                seq = seq[:L // 2] + "N" + seq[L // 2:]
+            f.write(f">r{r}\n{seq}\n")
+    args = ["lookup", "-k", str(k), "-q", str(q), prefix]
+    checker = oracle_py.REF_CLI if oracle_py.ref_available() else oracle_py.ORACLE_CLI
+    rc, ref, err = oracle_py.run_cli(checker, args)
+    assert rc == 0, err
+    if name == "both_strands":   # many windows whose two strands both have the k-mer, with different orders
+        both = fm.DeviceIndex.from_files(prefix, device=0)
+        kms = [ms.upper()[p:p + k] for p in range(0, 30000, 3)]
+        o = both.query_kmers(fm.pack_kmers(kms, k), k, fm.ORDERS | fm.STRICT).reshape(-1, 2)
+        assert int(((o[:, 0] >= 0) & (o[:, 1] >= 0) & (o[:, 0] != o[:, 1])).sum()) > 500
+        both.close()
+    rc, got, err = fm.run_cli(args)
+    assert rc == 0, err.decode()
+    assert got == ref
+    rc, got, err = fm.run_cli([*args[:-1], "--batch", "50000", "--threads", "5", args[-1]])
+    assert rc == 0 and got == ref
+    assert sum(len(l.split(b"\t")[1].split(b",")) for l in ref.splitlines()) > 1_500_000
+
+
 def test_cli_exits_when_stdout_fails(fm, tmp_path):
     """A writer that fails (ENOSPC: stdout = /dev/full) must end the process with exit status 1 -- not leave the reader thread
     blocked on a full queue and the CLI hanging in join().  Many small batches, so that input is still pending when it happens."""
