@@ -34,6 +34,7 @@ DICT_SPARSE = 0x1
 DICT_CHAIN = 0x2
 NO_PREFIX_TABLE = 0x100
 OUT_BITS = 0x200
+FN_AND, FN_XOR, FN_RANGE = 1, 2, 3   # demasking functions of query_runs_fn (`-f and|xor|r-s`)
 N_COUNTERS = 8
 
 E_INVAL, E_NODEV, E_HIP, E_NOMEM, E_IO, E_RANGE, E_COMM = -1, -2, -3, -4, -5, -6, -7
@@ -143,6 +144,8 @@ def lib() -> C.CDLL:
     L.fmsi_hip_query_windows.argtypes = [vp, vp, u64, vp, u64, i32, u32, vp, vp, vp]
     L.fmsi_hip_query_stream.argtypes = [vp, vp, u64, vp, vp, u64, u64, i32, u32, vp, vp, vp]
     L.fmsi_hip_query_runs.argtypes = [vp, vp, u64, vp, vp, u64, u64, i32, u32, vp, vp, vp]
+    L.fmsi_hip_query_runs_fn.restype = i32
+    L.fmsi_hip_query_runs_fn.argtypes = [vp, vp, u64, vp, vp, u64, u64, i32, i32, u64, u64, u32, vp, vp, vp]
     L.fmsi_hip_sync.argtypes = [vp, vp]
     L.fmsi_hip_profile_enable.argtypes = [vp, i32]
     L.fmsi_hip_profile_read.argtypes = [vp, C.POINTER(u64), C.POINTER(C.c_double), i32]
@@ -415,6 +418,20 @@ class DeviceIndex:
                    counters: bool = False):
         """Non-streaming queries over runs of consecutive windows (window starts expanded on the device)."""
         return self.query_stream(packed, seq_bases, run_start, run_windows, k, flags, counters, _fn="fmsi_hip_query_runs")
+
+    def query_runs_fn(self, packed: np.ndarray, seq_bases: int, run_start, run_windows, k: int, fn: int, r: int = 0, s: int = 0,
+                      flags: int = 0, counters: bool = False):
+        """`-f and|xor|r-s` over runs of consecutive windows: f(ones, total) of both strands per window (FN_AND / FN_XOR / FN_RANGE)."""
+        packed = np.ascontiguousarray(packed, dtype=np.uint64)
+        run_start = np.ascontiguousarray(run_start, dtype=np.uint64)
+        run_windows = np.ascontiguousarray(run_windows, dtype=np.uint32)
+        n = int(run_windows.sum())
+        out = self._alloc_out(n, flags)
+        cn = np.zeros(N_COUNTERS, dtype=np.uint64) if counters else None
+        _check(lib().fmsi_hip_query_runs_fn(self._h, packed.ctypes.data, seq_bases, run_start.ctypes.data, run_windows.ctypes.data, run_start.size, n, k,
+                                            fn, r, s, flags, out.ctypes.data, cn.ctypes.data if counters else None, None))
+        self.sync()
+        return (out, cn) if counters else out
 
     def query_stream(self, packed: np.ndarray, seq_bases: int, run_start, run_windows, k: int, flags: int = MODE_OR,
                      counters: bool = False, _fn: str = "fmsi_hip_query_stream"):

@@ -1,0 +1,159 @@
+// `fmsi query -f and|xor|r-s`: f-masked superstrings (the reference's query_mode::general, src/fms_index.h:316-327 with
+// single_query_general(), :171-179, and the demasking functions of src/functions.h:8-19).
+//
+// A window's answer is f(ones, total) over BOTH strands' SA intervals: total = the number of occurrences of the k-mer and of its
+// reverse complement in the superstring, ones = how many of them carry an ON mask bit; a self-complementary k-mer is counted once
+// (:319).  The strand predictor is consulted but never told anything in this mode and the two strands are summed, so -- unlike the
+// presence modes -- nothing depends on the order of the windows: no replay, every window independent.
+//
+// The search is the k-agnostic walk of fmsi_longk.hip: a lane walks its window straight off the 2-bit packed sequence, the forward
+// strand right-to-left, the reverse complement left-to-right with complemented bases, starting from the prefix table's interval
+// when the handle has one; the ON bits of an interval [i, j) are two mask ranks (block count + popcount below the row: the
+// mask plane of the interleaved block), where the reference adds up j - i single accesses of its RRR vector.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+
+#include "../../include/fmsi_hip.h"
+#include "common.h"
+#include "device_fm.h"
+#include "index_priv.h"
+
+namespace fmsi {
+namespace {
+
+struct SeqCache {   // one cached word of the packed sequence
+    const uint64_t* seq;
+    uint64_t idx = ~0ull, word = 0;
+    __device__ __forceinline__ uint32_t base(uint64_t p) {
+        const uint64_t w = p >> 5;
+        if (w != idx) {
+            word = seq[w];
+            idx = w;
+        }
+        return static_cast<uint32_t>(word >> (2u * static_cast<uint32_t>(p & 31u))) & 3u;
+    }
+};
+
+struct FnCounters {
+    uint32_t lf_steps = 0, blocks = 0, probes = 0, searches = 0, lookups = 0;
+};
+
+// get_range_with_pattern (src/fms_index.h:117-124) of one strand of the window at base p
+__device__ __forceinline__ void strand_range(const DevIndex& ix, SeqCache& sc, uint64_t p, int k, bool rc, uint32_t& i, uint32_t& j, FnCounters& cn) {
+    cn.searches++;
+    const int T = static_cast<int>(ix.ptable_len);
+    int t = k - 1;
+    i = 0;
+    j = ix.n;
+    if (ix.ptable && T > 0 && k >= T) {
+        // the T bases the search consumes first: the window's last T (forward) or its first T, complemented and reversed
+        const uint64_t w = window_kmer(sc.seq, rc ? p : p + static_cast<uint64_t>(k - T), T);
+        const uint32_t tidx = static_cast<uint32_t>(rc ? revcomp_2bit(w, T) : w);
+        const uint2 e = ix.ptable[tidx];
+        decode_table_entry(e.x, e.y, ix.ptable_packed, false, 0u, i, j);   // (no signature shortcut: the interval itself)
+        cn.lookups++;
+        t = k - T - 1;
+    }
+    for (; t >= 0 && i != j; --t) {
+        const uint32_t c = rc ? 3u - sc.base(p + static_cast<uint64_t>(k - 1 - t)) : sc.base(p + static_cast<uint64_t>(t));
+        lf_step(ix, c, i, j, cn.blocks);
+        cn.lf_steps++;
+    }
+}
+
+// ON bits among the rows [i, j), i < j
+__device__ __forceinline__ uint32_t ones_in(const DevIndex& ix, uint32_t i, uint32_t j, FnCounters& cn) {
+    const uint32_t bi = i >> kBlockRowsLog2, bj = (j - 1u) >> kBlockRowsLog2;
+    cn.probes++;
+    cn.blocks += 1u + (bj != bi);
+    return mask_rank(ix, bj, j - (bj << kBlockRowsLog2)) - mask_rank(ix, bi, i & (kBlockRows - 1u));
+}
+
+// f(ones, total) the way query_kmers_single<general> reaches it: through std::function<bool(int, int)> wrappers, i.e. with both
+// counts truncated to int and widened again (src/functions.h:21, src/main.cpp:251, src/fms_index.h:334)
+__device__ __forceinline__ bool apply_fn(int fn, uint64_t r, uint64_t s, uint64_t ones, uint64_t total) {
+    const uint64_t o = static_cast<uint64_t>(static_cast<int64_t>(static_cast<int32_t>(static_cast<uint32_t>(ones))));
+    const uint64_t t = static_cast<uint64_t>(static_cast<int64_t>(static_cast<int32_t>(static_cast<uint32_t>(total))));
+    if (fn == FMSI_HIP_FN_AND) return t != 0 && o == t;   // f_and, src/functions.h:11
+    if (fn == FMSI_HIP_FN_XOR) return (o & 1u) != 0;      // f_xor, :14
+    return o <= s && o >= r;                              // f_r_to_s, :17-19
+}
+
+template <bool COUNT>
+__global__ __launch_bounds__(256) void query_fn_kernel(DevIndex ix, const uint64_t* __restrict__ seq, const uint64_t* __restrict__ window_start,
+                                                       uint64_t n_windows, int k, int fn, uint64_t fn_r, uint64_t fn_s, uint8_t* __restrict__ out,
+                                                       unsigned long long* __restrict__ counters) {
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
+    FnCounters cn;
+    uint32_t done = 0;
+    SeqCache sc{seq};
+    for (uint64_t q = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; q < n_windows; q += stride) {
+        const uint64_t p = window_start[q];
+        uint32_t fi, fj, ri, rj;
+        strand_range(ix, sc, p, k, false, fi, fj, cn);
+        strand_range(ix, sc, p, k, true, ri, rj, cn);
+        uint64_t ones = 0, total = 0;
+        if (fi != fj) {
+            ones = ones_in(ix, fi, fj, cn);
+            total = fj - fi;
+        }
+        // "Do not count self complementary k-mers twice" (:319): equal strings have equal intervals, and different strings that both
+        // occur have different ones; two empty intervals add nothing either way
+        if (ri != rj && !(ri == fi && rj == fj)) {
+            ones += ones_in(ix, ri, rj, cn);
+            total += rj - ri;
+        }
+        out[q] = apply_fn(fn, fn_r, fn_s, ones, total) ? 1 : 0;
+        ++done;
+    }
+    if (COUNT) {
+        uint32_t v[6] = {cn.lf_steps, cn.blocks, cn.probes, cn.searches, cn.lookups, done};
+        const int slot[6] = {0, 1, 2, 3, 4, 6};
+#pragma unroll
+        for (int s = 0; s < 6; ++s) {
+            uint32_t x = v[s];
+            for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+            if ((threadIdx.x & 63) == 0 && x) atomicAdd(&counters[slot[s]], static_cast<unsigned long long>(x));
+        }
+    }
+}
+
+}  // namespace
+
+void launch_fn_query(fmsi_hip_index* idx, const uint64_t* d_seq, const uint64_t* d_window_start, uint64_t n, int k, bool use_table, uint8_t* o8,
+                     unsigned long long* d_counters, hipStream_t s) {
+    const uint32_t blocks = static_cast<uint32_t>(std::min<uint64_t>((n + 255) / 256, 256ull * 32));
+    DevIndex ix = idx->dev;
+    if (!use_table) ix.ptable = nullptr;
+    if (d_counters)
+        hipLaunchKernelGGL((query_fn_kernel<true>), dim3(blocks), dim3(256), 0, s, ix, d_seq, d_window_start, n, k, idx->fn_kind, idx->fn_r, idx->fn_s, o8,
+                           d_counters);
+    else
+        hipLaunchKernelGGL((query_fn_kernel<false>), dim3(blocks), dim3(256), 0, s, ix, d_seq, d_window_start, n, k, idx->fn_kind, idx->fn_r, idx->fn_s, o8,
+                           d_counters);
+}
+
+}  // namespace fmsi
+
+using namespace fmsi;
+
+extern "C" int fmsi_hip_query_runs_fn(fmsi_hip_index* idx, const uint64_t* packed_seq, uint64_t seq_bases, const uint64_t* run_start,
+                                      const uint32_t* run_windows, uint64_t n_runs, uint64_t n_windows, int k, int fn, uint64_t r, uint64_t s,
+                                      uint32_t flags, void* out, uint64_t* counters, void* stream) {
+    if (!idx) return FMSI_HIP_EINVAL;
+    if (fn != FMSI_HIP_FN_AND && fn != FMSI_HIP_FN_XOR && fn != FMSI_HIP_FN_RANGE) {
+        set_last_error("unknown demasking function");
+        return FMSI_HIP_EINVAL;
+    }
+    if (flags & (FMSI_HIP_STRICT | FMSI_HIP_ORDERS)) {
+        set_last_error("FMSI_HIP_STRICT / FMSI_HIP_ORDERS have no meaning with a demasking function");   // src/main.cpp:297-300
+        return FMSI_HIP_EINVAL;
+    }
+    FMSI_HIP_NARROW_ONLY(idx, "a demasking function (-f)");
+    idx->fn_kind = fn;
+    idx->fn_r = r;
+    idx->fn_s = s;
+    return fmsi_hip_query_runs(idx, packed_seq, seq_bases, run_start, run_windows, n_runs, n_windows, k,
+                               (flags & (FMSI_HIP_DEVICE_PTRS | FMSI_HIP_OUT_BITS | FMSI_HIP_NO_PREFIX_TABLE)) | kModeFn, out, counters, stream);
+}

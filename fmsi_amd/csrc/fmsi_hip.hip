@@ -972,7 +972,9 @@ int fmsi_hip_query_runs(fmsi_hip_index* idx, const uint64_t* packed_seq, uint64_
         return FMSI_HIP_EINVAL;
     }
     const uint64_t uniform_runs[3] = {run_start[0], stride, wpr};
-    const bool table_free = uniform && dict_applies(idx, k, flags) && n_windows <= (1ull << 38);
+    const bool fn_mode = (flags & kModeFn) != 0;   // a demasking function: fmsi_hip_query_runs_fn (fmsi_fn.hip)
+    flags &= ~kModeFn;
+    const bool table_free = !fn_mode && uniform && dict_applies(idx, k, flags) && n_windows <= (1ull << 38);
     // otherwise: [0, n_runs): run starts, [n_runs, 2 n_runs + 1): exclusive prefix sums of the run lengths -- in a page-locked slot
     // of the handle's ring, so that nothing has to wait for the copy (the call stays asynchronous on `stream`)
     void* meta_host = nullptr;
@@ -1008,7 +1010,7 @@ int fmsi_hip_query_runs(fmsi_hip_index* idx, const uint64_t* packed_seq, uint64_
         }
     }
     uint32_t kernel = flags & FMSI_HIP_KERNEL_MASK;
-    if (dict_applies(idx, k, flags) && n_windows <= (1ull << 38)) {
+    if (!fn_mode && dict_applies(idx, k, flags) && n_windows <= (1ull << 38)) {
         // the dictionary's lookup kernel cuts the windows itself, too
         size_t slot;
         if ((rc = prof_begin(idx, s, &slot))) return rc;
@@ -1030,7 +1032,7 @@ int fmsi_hip_query_runs(fmsi_hip_index* idx, const uint64_t* packed_seq, uint64_
         flags &= ~FMSI_HIP_KERNEL_MASK;
         kernel = FMSI_HIP_KERNEL_AUTO;
     }
-    if (!idx->wide && k <= 32 && (kernel == FMSI_HIP_KERNEL_PHASED || kernel == FMSI_HIP_KERNEL_AUTO) && idx->d_pblocks && idx->d_ptable &&
+    if (!fn_mode && !idx->wide && k <= 32 && (kernel == FMSI_HIP_KERNEL_PHASED || kernel == FMSI_HIP_KERNEL_AUTO) && idx->d_pblocks && idx->d_ptable &&
         !(flags & FMSI_HIP_NO_PREFIX_TABLE) && k >= idx->prefix_len && n_windows <= (1ull << 38)) {
         // the phased kernels cut the windows themselves: no pass that writes 8 bytes per window and reads them back
         PackAfter pack;   // (the one-lane lookup kernel packs FMSI_HIP_OUT_BITS output itself)
@@ -1056,7 +1058,22 @@ int fmsi_hip_query_runs(fmsi_hip_index* idx, const uint64_t* packed_seq, uint64_
     const uint64_t* d_rs = static_cast<const uint64_t*>(idx->d_tasks);
     const uint64_t* d_ro = d_rs + n_runs;
     const uint32_t blocks = static_cast<uint32_t>(std::min<uint64_t>((n_windows + 255) / 256, 256 * 16));
-    if (k > 32) {
+    if (fn_mode) {
+        // f(ones, total) per window, both strands: the walk off the packed sequence, any k (fmsi_fn.hip)
+        if ((rc = ensure_cap(&idx->d_aux, &idx->d_aux_cap, n_windows * 8))) return rc;
+        hipLaunchKernelGGL((expand_runs_kernel<false>), dim3(blocks), dim3(256), 0, s, d_seq, d_rs, d_ro, n_runs, n_windows, k,
+                           static_cast<uint64_t*>(idx->d_aux));
+        FMSI_HIP_TRY(hipGetLastError());
+        PackAfter pack;
+        uint32_t kflags = flags;
+        if ((rc = pack.begin(idx, kflags, n_windows, d_out))) return rc;
+        size_t slot;
+        if ((rc = prof_begin(idx, s, &slot))) return rc;
+        launch_fn_query(idx, d_seq, static_cast<const uint64_t*>(idx->d_aux), n_windows, k, !(flags & FMSI_HIP_NO_PREFIX_TABLE), pack.bytes, d_cnt, s);
+        FMSI_HIP_TRY(hipGetLastError());
+        if ((rc = pack.end(n_windows, flags, d_out, s))) return rc;
+        if ((rc = prof_end(idx, s, slot))) return rc;
+    } else if (k > 32) {
         FMSI_HIP_NARROW_ONLY(idx, "a query with k > 32");
         if ((rc = ensure_cap(&idx->d_aux, &idx->d_aux_cap, n_windows * 8))) return rc;
         hipLaunchKernelGGL((expand_runs_kernel<false>), dim3(blocks), dim3(256), 0, s, d_seq, d_rs, d_ro, n_runs, n_windows, k,

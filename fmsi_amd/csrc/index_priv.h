@@ -120,6 +120,8 @@ struct fmsi_hip_index {
     void* d_blocks = nullptr;
     void* d_mrank = nullptr;
     void* d_ptable = nullptr;
+    int fn_kind = 0;             // demasking function of the current fmsi_hip_query_runs_fn call (FMSI_HIP_FN_*) and its bounds
+    uint64_t fn_r = 0, fn_s = 0;
     void* d_klcp = nullptr;      // plain kLCP bit-vector (n bits, u64 words), when present
     // optional pair layout (fmsi_pair.hip): 128-B blocks for two-base LF steps
     void* d_pblocks = nullptr;
@@ -166,6 +168,11 @@ void launch_pair_query(fmsi_hip_index* idx, const uint64_t* d_kmers, uint64_t n,
                        long long* o64, unsigned long long* d_counters, hipStream_t s);
 
 // k > 32: windows searched straight off the packed sequence (fmsi_longk.hip)
+// `-f and|xor|r-s` (fmsi_fn.hip): fmsi_hip_query_runs_fn leaves the function in the handle and goes through fmsi_hip_query_runs with this
+// private flag, which cuts the runs into window starts and launches the kernel below
+constexpr uint32_t kModeFn = 0x80000000u;
+void launch_fn_query(fmsi_hip_index* idx, const uint64_t* d_seq, const uint64_t* d_window_start, uint64_t n, int k, bool use_table, uint8_t* o8,
+                     unsigned long long* d_counters, hipStream_t s);
 void launch_longk_query(fmsi_hip_index* idx, const uint64_t* d_seq, const uint64_t* d_window_start, uint64_t n, int k, uint32_t flags,
                         uint8_t* o8, long long* o64, unsigned long long* d_counters, hipStream_t s);
 

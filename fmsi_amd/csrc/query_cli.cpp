@@ -84,7 +84,35 @@ struct Options {
     bool full_tables = false;              // --tables full: the k-mer dictionary (what bench.py measures); lookup: the 16-deep prefix table
     bool candidate_tables = false;         // --tables candidates: the 16-deep prefix table + candidate tables instead (A/B runs)
     bool tables_given = false;             // (--tables on the command line: no choice by the size of the query file)
+    int fn = 0;                            // -f and|xor|r-s: FMSI_HIP_FN_* (query_mode::general), 0 = the presence modes
+    uint64_t fn_r = 0, fn_s = 0;
 };
+
+// mask_function(name), src/functions.h:23-57: 0 = a general function (o.fn, o.fn_r, o.fn_s set), 1 = "or", 2 = "all", -1 = not recognized.
+// A bound that std::stoi rejects leaves the reference with an uncaught std::out_of_range: the same exception from here.
+int parse_function(const std::string& name, Options& o) {
+    if (name == "or") return 1;
+    if (name == "and") {
+        o.fn = FMSI_HIP_FN_AND;
+        return 0;
+    }
+    if (name == "xor") {
+        o.fn = FMSI_HIP_FN_XOR;
+        return 0;
+    }
+    if (name == "all") return 2;
+    for (size_t i = 1; i + 1 < name.size(); ++i) {
+        if (name[i] != '-') continue;
+        const std::string r_string = name.substr(0, i), s_string = name.substr(i + 1);
+        const auto digits = [](const std::string& x) { return x.find_first_not_of("0123456789") == std::string::npos; };
+        if (!digits(r_string) || !digits(s_string)) break;
+        o.fn = FMSI_HIP_FN_RANGE;
+        o.fn_r = static_cast<uint64_t>(std::stoi(r_string));
+        o.fn_s = static_cast<uint64_t>(std::stoi(s_string));
+        return 0;
+    }
+    return -1;
+}
 
 int usage_query(bool lookup) {
     // text of the reference's usage_query()/usage_lookup() (src/main.cpp:102-130) plus the GPU options
@@ -97,7 +125,13 @@ int usage_query(bool lookup) {
     if (!lookup) {
         std::cerr << "  -O      - FMSI uses properties of max-one masked superstrings to speed up queries" << std::endl;
         std::cerr << "            Use only if a masked superstring with maximum number of ones is indexed." << std::endl;
-        std::cerr << "  -f FUNCTION - Demasking function; the GPU path supports: or [default], all (= -O)" << std::endl;
+        std::cerr << "Parameters (experimental, using f-MS framework):" << std::endl;   // usage_functions(), src/main.cpp:85-100
+        std::cerr << "  -f FUNCTION - Demasking function to determine k-mer presence; recognized functions:" << std::endl;
+        std::cerr << "    or      - represented when at least 1 ON occurrence [default]" << std::endl;
+        std::cerr << "    all     - all occurrence are either ON or OFF (equivalent to -O flag for queries)" << std::endl;
+        std::cerr << "    and     - represented when no OFF occurrence" << std::endl;
+        std::cerr << "    xor     - represented when an odd number of ON occurrences" << std::endl;
+        std::cerr << "    INT-INT - represented when in the bounds" << std::endl;
     }
     std::cerr << "Options (MI355X path):" << std::endl;
     std::cerr << "  --device INT - HIP device to use [default: 0]" << std::endl;
@@ -997,13 +1031,15 @@ extern "C" int fmsi_cli_query(int argc, char** argv, int output_orders_i) {
     int c;
     while ((c = getopt_long(argc, argv, "f:hq:k:OS", long_opts, nullptr)) >= 0) {
         switch (c) {
-        case 'f':
+        case 'f': {   // src/main.cpp:255-263
             f_name = optarg;
-            if (f_name != "or" && f_name != "all") {
-                std::cerr << "ERROR: Function '" << optarg << "' is not available on the GPU path (supported: or, all)." << std::endl;
-                return usage_query(output_orders);
+            opt.fn = 0;
+            if (parse_function(f_name, opt) < 0) {
+                std::cerr << "ERROR: Function '" << optarg << "' not recognized." << std::endl;
+                return usage_query(false);   // (the reference prints the query usage here, also for lookup)
             }
             break;
+        }
         case 'h': usage = true; break;
         case 'q': opt.query_fn = optarg; break;
         case 'k': opt.k = atoi(optarg); break;
@@ -1048,8 +1084,16 @@ extern "C" int fmsi_cli_query(int argc, char** argv, int output_orders_i) {
     }
     if (output_orders && f_name == "all") {
         std::cerr << "WARNING: The current version of FMSI has speed benefits only if output as (minimum) perfect hash function is not used. Additionally, if you desire minimum perfect hash function, please minimize the number of ones in the mask." << std::endl;
+    } else if (f_name != "or" && output_orders) {   // src/main.cpp:297-300
+        std::cerr << "ERROR: FMSI as Minimum Perfect Hash Function is not allowed with f-masked superstrings in the current version." << std::endl;
+        return usage_query(output_orders);
     }
     opt.mode = f_name == "all" ? Mode::All : Mode::Or;
+    // -f and|xor|r-s: query_mode::general (src/fms_index.h:316-327).  f(ones, total) over both strands per window: the strand
+    // predictor is never told anything and -S changes nothing (:336), so no strand is replayed and the kLCP array stays on disk --
+    // though -S still asks for its file, as load_index() does.
+    const bool general = opt.fn != 0;
+    const bool load_klcp = opt.has_klcp && !general;
 
     using clock = std::chrono::steady_clock;
     auto t_start = clock::now();
@@ -1226,7 +1270,7 @@ extern "C" int fmsi_cli_query(int argc, char** argv, int output_orders_i) {
     // `full`: presence queries (also -S ones: their answers do not depend on the kLCP array) are answered by the k-mer
     // dictionary, which needs no prefix table (a small one serves the few searches of its construction); lookup keeps the
     // 16-deep table
-    const bool want_dict = opt.full_tables && !opt.candidate_tables && !output_orders && k <= 32 && index_rows > static_cast<uint64_t>(k);
+    const bool want_dict = !general && opt.full_tables && !opt.candidate_tables && !output_orders && k <= 32 && index_rows > static_cast<uint64_t>(k);
     int t = std::min(k, want_dict ? 12 : (opt.full_tables ? 16 : 14));
     while (t > 0 && (1ull << (2 * t)) > 4 * index_rows) --t;
 
@@ -1250,7 +1294,7 @@ extern "C" int fmsi_cli_query(int argc, char** argv, int output_orders_i) {
     auto setup = [&](DeviceCtx& c, bool first) -> bool {
         int rc_create = FMSI_HIP_ENOMEM;
         for (;;) {
-            rc_create = fmsi_hip_index_load(opt.index_prefix.c_str(), opt.has_klcp, c.device, std::max(t, 0), &c.dev);
+            rc_create = fmsi_hip_index_load(opt.index_prefix.c_str(), load_klcp, c.device, std::max(t, 0), &c.dev);
             if (rc_create != FMSI_HIP_ENOMEM || t <= 0 || !first) break;
             std::cerr << "WARNING: not enough device memory for a prefix table of depth " << t << ", trying " << std::max(t - 2, 0) << std::endl;
             t = std::max(t - 2, 0);
@@ -1262,8 +1306,9 @@ extern "C" int fmsi_cli_query(int argc, char** argv, int output_orders_i) {
         fmsi_hip_index_info info;
         const bool wide = fmsi_hip_index_get_info(c.dev, &info) == 0 && info.rows64 != 0;
         if (first) rows64 = wide;
-        if (wide && (opt.has_klcp || k > 32)) {   // 2^32 rows and more: the plain search only (include/fmsi_hip.h)
+        if (wide && (load_klcp || k > 32 || general)) {   // 2^32 rows and more: the plain search only (include/fmsi_hip.h)
             c.error = "-S and k > 32 are not available on the GPU path for indexes of 2^32 rows or more.";
+            if (general) c.error = "-f with a general function is not available on the GPU path for indexes of 2^32 rows or more.";
             return false;
         }
         if (want_dict && !wide) {
@@ -1271,11 +1316,11 @@ extern "C" int fmsi_cli_query(int argc, char** argv, int output_orders_i) {
             if (!c.have_dict)
                 std::cerr << "WARNING: the k-mer dictionary is off on device " << c.device << " (" << fmsi_hip_last_error() << "); results are unaffected" << std::endl;
         }
-        if (!opt.has_klcp && !c.have_dict && !wide && fmsi_hip_index_enable_pair_layout(c.dev) != 0) {
+        if (!load_klcp && !general && !c.have_dict && !wide && fmsi_hip_index_enable_pair_layout(c.dev) != 0) {
             c.error = fmsi_hip_last_error();
             return false;
         }
-        const bool want_verify = !wide && opt.candidate_tables && !opt.has_klcp && !output_orders && t > 0 && t < k && k <= 32;
+        const bool want_verify = !wide && !general && opt.candidate_tables && !opt.has_klcp && !output_orders && t > 0 && t < k && k <= 32;
         if (want_verify && fmsi_hip_index_enable_verify(c.dev) != 0)
             std::cerr << "WARNING: text verification is off (" << fmsi_hip_last_error() << "); results are unaffected" << std::endl;
         return true;
@@ -1312,7 +1357,7 @@ extern "C" int fmsi_cli_query(int argc, char** argv, int output_orders_i) {
 
     // OR-mode presence output does not depend on the strand order, so the cheaper schedule is exact;
     // everything else replays the predictor from both strands unless --fast.
-    const bool need_both = opt.has_klcp || output_orders || opt.mode == Mode::All;
+    const bool need_both = !general && (opt.has_klcp || output_orders || opt.mode == Mode::All);
     const bool strict = need_both && !opt.fast;
     uint32_t flags_all = (opt.mode == Mode::All ? FMSI_HIP_MODE_ALL : FMSI_HIP_MODE_OR);
     if (strict) flags_all |= FMSI_HIP_STRICT;
@@ -1441,7 +1486,11 @@ extern "C" int fmsi_cli_query(int argc, char** argv, int output_orders_i) {
                         void* dst = output_orders ? static_cast<void*>(P->orders.data())
                                                   : (P->packed_bits ? static_cast<void*>(P->bits.data()) : static_cast<void*>(P->bytes.data()));
                         const uint32_t flags = flags_all | (P->packed_bits ? FMSI_HIP_OUT_BITS : 0u);
-                        if (opt.has_klcp && !cp->have_dict)   // -S: kLCP streaming kernel (query_kmers_streaming, src/fms_index.h:181-254)
+                        if (general)   // -f and|xor|r-s: f(ones, total) of both strands (query_kmers<general>, src/fms_index.h:316-327)
+                            check(fmsi_hip_query_runs_fn(cp->dev, P->packed.data(), P->bases, P->run_start.data(), P->run_windows.data(), P->run_start.size(), nw, k,
+                                                         opt.fn, opt.fn_r, opt.fn_s, FMSI_HIP_OUT_BITS, dst, nullptr, nullptr),
+                                  "fmsi_hip_query_runs_fn");
+                        else if (opt.has_klcp && !cp->have_dict)   // -S: kLCP streaming kernel (query_kmers_streaming, src/fms_index.h:181-254)
                             check(fmsi_hip_query_stream(cp->dev, P->packed.data(), P->bases, P->run_start.data(), P->run_windows.data(),
                                                         P->run_start.size(), nw, k, flags, dst, nullptr, nullptr),
                                   "fmsi_hip_query_stream");
@@ -1493,7 +1542,7 @@ extern "C" int fmsi_cli_query(int argc, char** argv, int output_orders_i) {
             auto t2 = clock::now();
             if (strict) {
                 TraceRange replay_range("fmsi: predictor replay");
-                replay_batch(*P, predictor, opt.mode, output_orders, opt.has_klcp, k, team, rows64);
+                replay_batch(*P, predictor, opt.mode, output_orders, load_klcp, k, team, rows64);
             }
             replay_s += std::chrono::duration<double>(clock::now() - t2).count();
             total_windows += P->windows;

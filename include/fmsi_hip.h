@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define FMSI_HIP_ABI_VERSION 3   /* 2: fmsi_hip_index_info.candidate_entry_bytes, fmsi_hip_comm_*, fmsi_hip_gather; 3: FMSI_HIP_OUT_BITS, fmsi_hip_index_load, fmsi_hip_trim_scratch, fmsi_hip_index_enable_dict + fmsi_hip_index_info.dict_*, fmsi_hip_index_build_synthetic_spec */
+#define FMSI_HIP_ABI_VERSION 4   /* 4: fmsi_hip_query_runs_fn (`-f and|xor|r-s`); 2: fmsi_hip_index_info.candidate_entry_bytes, fmsi_hip_comm_*, fmsi_hip_gather; 3: FMSI_HIP_OUT_BITS, fmsi_hip_index_load, fmsi_hip_trim_scratch, fmsi_hip_index_enable_dict + fmsi_hip_index_info.dict_*, fmsi_hip_index_build_synthetic_spec */
 
 /* error codes */
 #define FMSI_HIP_OK 0
@@ -265,6 +265,24 @@ int fmsi_hip_query_windows(fmsi_hip_index* idx, const uint64_t* packed_seq, uint
 int fmsi_hip_query_runs(fmsi_hip_index* idx, const uint64_t* packed_seq, uint64_t seq_bases,
                         const uint64_t* run_start, const uint32_t* run_windows, uint64_t n_runs, uint64_t n_windows,
                         int k, uint32_t flags, void* out, uint64_t* counters, void* stream);
+
+/* f-masked superstrings, `fmsi query -f and|xor|r-s`: replaces query_kmers<query_mode::general>() (src/fms_index.h:333-342 ->
+ * query_kmers_single<general>, :316-327) with the demasking functions of src/functions.h:8-19.  Per window: total = occurrences of
+ * the k-mer and of its reverse complement in the superstring (single_query_general(), :171-179, of both strands; a self-complementary
+ * k-mer counted once, :319), ones = how many of them have their mask bit ON; the answer is
+ *   FMSI_HIP_FN_AND    total != 0 && ones == total          (f_and)
+ *   FMSI_HIP_FN_XOR    ones odd                             (f_xor)
+ *   FMSI_HIP_FN_RANGE  r <= ones <= s                       (f_r_to_s; r, s as `-f r-s` parses them)
+ * with ones and total passed through int as the reference's std::function<bool(int, int)> wrappers pass them.  Runs, buffers and
+ * result layout as fmsi_hip_query_runs (one byte 0 / 1 per window, or FMSI_HIP_OUT_BITS); of `flags` only FMSI_HIP_DEVICE_PTRS,
+ * FMSI_HIP_OUT_BITS and FMSI_HIP_NO_PREFIX_TABLE are looked at.  The strand predictor plays no part in this mode (it is asked
+ * but never told, and both strands are added up), and `-S` changes nothing (:336).  Any k; not for indexes of 2^32 rows or more. */
+#define FMSI_HIP_FN_AND 1
+#define FMSI_HIP_FN_XOR 2
+#define FMSI_HIP_FN_RANGE 3
+int fmsi_hip_query_runs_fn(fmsi_hip_index* idx, const uint64_t* packed_seq, uint64_t seq_bases,
+                           const uint64_t* run_start, const uint32_t* run_windows, uint64_t n_runs, uint64_t n_windows,
+                           int k, int fn, uint64_t r, uint64_t s, uint32_t flags, void* out, uint64_t* counters, void* stream);
 
 /* Replaces query_kmers_streaming<>() (`-S`, src/fms_index.h:181-254): runs of consecutive windows walked
  * right-to-left with the kLCP extension (src/fms_index.h:106-115).  Run r covers windows starting at bases

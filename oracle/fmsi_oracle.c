@@ -871,6 +871,56 @@ static void query_kmers_streaming(orc_index* ix, const char* sequence, const cha
     free(result);
 }
 
+/* ---- query_mode::general: f-masked superstrings (src/functions.h, src/fms_index.h:171-179, 317-327) ---- */
+int orc_parse_function(const char* name, int* kind, uint64_t* r, uint64_t* s) { /* functions.h:23-57 */
+    if (!strcmp(name, "or")) return 1;
+    if (!strcmp(name, "and")) { *kind = ORC_FN_AND; return 0; }
+    if (!strcmp(name, "xor")) { *kind = ORC_FN_XOR; return 0; }
+    if (!strcmp(name, "all")) return 2;
+    size_t len = strlen(name);
+    for (size_t i = 1; i + 1 < len; ++i) {                       /* :39 */
+        if (name[i] != '-') continue;
+        int valid = 1;
+        for (size_t j = 0; j < i; ++j) if (name[j] < '0' || name[j] > '9') valid = 0;
+        for (size_t j = i + 1; j < len; ++j) if (name[j] < '0' || name[j] > '9') valid = 0;
+        if (!valid) break;                                          /* :50-51 */
+        /* std::stoi: digits only here, so the one failure is a value above INT_MAX */
+        uint64_t rv = 0, sv = 0;
+        for (size_t j = 0; j < i; ++j) { rv = rv * 10 + (uint64_t)(name[j] - '0'); if (rv > 2147483647ull) return -2; }
+        for (size_t j = i + 1; j < len; ++j) { sv = sv * 10 + (uint64_t)(name[j] - '0'); if (sv > 2147483647ull) return -2; }
+        *kind = ORC_FN_RANGE; *r = rv; *s = sv;
+        return 0;
+    }
+    return -1;                                                      /* :59 */
+}
+void orc_set_function(orc_index* ix, int kind, uint64_t r, uint64_t s) { ix->fn_kind = kind; ix->fn_r = r; ix->fn_s = s; }
+int orc_apply_function(int kind, uint64_t r, uint64_t s, uint64_t ones, uint64_t total) {
+    /* the chain of std::function wrappers between ms_query's f and f_and/f_xor/the lambda converts size_t -> int -> size_t */
+    uint64_t o = (uint64_t)(int64_t)(int32_t)(uint32_t)ones, t = (uint64_t)(int64_t)(int32_t)(uint32_t)total;
+    if (kind == ORC_FN_AND) return t && o == t;                     /* functions.h:11 */
+    if (kind == ORC_FN_XOR) return (int)(o % 2);                    /* :14 */
+    return o <= s && o >= r;                                        /* :17-19 */
+}
+static void single_query_general(orc_index* ix, const char* pattern, int k, uint64_t* ones, uint64_t* total) { /* :171-179 */
+    uint64_t sa_start, sa_end;
+    orc_get_range_with_pattern(ix, pattern, k, &sa_start, &sa_end);
+    uint64_t o = 0;
+    for (uint64_t i = sa_start; i < sa_end; ++i) o += (uint64_t)orc_rrr_access(&ix->mask, i);
+    *ones = o;
+    *total = sa_end - sa_start;
+}
+void orc_kmer_general(orc_index* ix, const char* kmer, int k, uint64_t* ones, uint64_t* total) { /* :317-323 */
+    char* rc = reverse_complement(kmer, (uint64_t)k);
+    single_query_general(ix, kmer, k, ones, total);
+    if (strncmp(kmer, rc, (size_t)k) != 0) {                        /* AreStringsEqual, kmers.h */
+        uint64_t o2, t2;
+        single_query_general(ix, rc, k, &o2, &t2);
+        *ones += o2;
+        *total += t2;
+    }
+    free(rc);
+}
+
 static void query_kmers_single(orc_index* ix, const char* sequence, const char* rc_sequence, uint64_t sequence_length,
                                int k, int mode, int output_orders, orc_obuf* of) { /* :263-331, modes orr / all */
     for (uint64_t i = 0; i <= sequence_length - (uint64_t)k; ++i) {
@@ -878,6 +928,18 @@ static void query_kmers_single(orc_index* ix, const char* sequence, const char* 
         const char* rc_kmer = rc_sequence + (sequence_length - (uint64_t)k - i);
         int should_swap = predictor_predict_swap(&ix->predictor);
         if (should_swap) { const char* t = kmer; kmer = rc_kmer; rc_kmer = t; }
+        if (mode == ORC_MODE_GENERAL) {                                                /* :316-327; the predictor is not told */
+            uint64_t ones, total;
+            single_query_general(ix, kmer, k, &ones, &total);
+            if (strncmp(kmer, rc_kmer, (size_t)k) != 0) {
+                uint64_t o2, t2;
+                single_query_general(ix, rc_kmer, k, &o2, &t2);
+                ones += o2;
+                total += t2;
+            }
+            ob_putc(of, orc_apply_function(ix->fn_kind, ix->fn_r, ix->fn_s, ones, total) ? '1' : '0');
+            continue;
+        }
         int forward_predictor_result = 0, backward_predictor_result = 0;
         int64_t got;
         if (output_orders) got = single_query_order(ix, kmer, k);
@@ -907,7 +969,7 @@ static void query_kmers_single(orc_index* ix, const char* sequence, const char* 
 void orc_query_kmers(orc_index* ix, const char* seq, uint64_t len, int k, int has_klcp, int mode,
                      int output_orders, orc_obuf* of) { /* :333-342 */
     char* rc = reverse_complement(seq, len);
-    if (has_klcp) query_kmers_streaming(ix, seq, rc, len, k, mode == ORC_MODE_ALL, output_orders, of);
+    if (has_klcp && mode != ORC_MODE_GENERAL) query_kmers_streaming(ix, seq, rc, len, k, mode == ORC_MODE_ALL, output_orders, of);   /* :336 */
     else query_kmers_single(ix, seq, rc, len, k, mode, output_orders, of);
     free(rc);
 }
@@ -1149,20 +1211,36 @@ static int cli_query(int argc, char** argv, int output_orders) {
     const char* fn = argv[argc - 1];
     argc--;
     const char* query_fn = "-";
-    int k = 0, c, has_klcp = 0, mode = ORC_MODE_OR, timing = 0;
-    while ((c = getopt(argc, argv, "q:k:OST")) >= 0) {
+    int k = 0, c, has_klcp = 0, mode = ORC_MODE_OR, timing = 0, fn_kind = 0;
+    uint64_t fn_r = 0, fn_s = 0;
+    while ((c = getopt(argc, argv, "f:q:k:OST")) >= 0) {
         switch (c) {
+        case 'f': {                                                                    /* main.cpp:255-263 */
+            int p = orc_parse_function(optarg, &fn_kind, &fn_r, &fn_s);
+            if (p == -2) abort();
+            if (p < 0) { fprintf(stderr, "ERROR: Function '%s' not recognized.\n", optarg); return 1; }
+            mode = p == 1 ? ORC_MODE_OR : (p == 2 ? ORC_MODE_ALL : ORC_MODE_GENERAL);
+            break;
+        }
         case 'q': query_fn = optarg; break;
         case 'k': k = atoi(optarg); break;
-        case 'O': mode = ORC_MODE_ALL; break;
+        case 'O':                                                                      /* main.cpp:273-280 */
+            if (mode != ORC_MODE_OR) fprintf(stderr, "WARNING: Parameter -O is ignored when parameter -f is specified.\n");
+            else mode = ORC_MODE_ALL;
+            break;
         case 'S': has_klcp = 1; break;
         case 'T': timing = 1; break;
         default: return 1;
         }
     }
+    if (output_orders && mode == ORC_MODE_GENERAL) {                                   /* main.cpp:297-300 */
+        fprintf(stderr, "ERROR: FMSI as Minimum Perfect Hash Function is not allowed with f-masked superstrings in the current version.\n");
+        return 1;
+    }
     double t0 = now_s();
     orc_index* ix = orc_index_load(fn, has_klcp);
     double load_s = now_s() - t0;
+    if (ix) orc_set_function(ix, fn_kind, fn_r, fn_s);
     if (!ix || orc_index_n(ix) == 0) { fprintf(stderr, "ERROR: index not correctly loaded\n"); return 1; }
     if (has_klcp != orc_index_has_klcp(ix)) { fprintf(stderr, "ERROR: kLCP mismatch\n"); return 1; }
     if (k != 0 && k != ix->k) { fprintf(stderr, "ERROR: k mismatch\n"); return 1; }

@@ -74,9 +74,23 @@ typedef struct {
     uint64_t mask_probes;   /* rrr operator[] calls */
     uint64_t klcp_bits;     /* klcp bit reads */
     uint64_t strand_searches;
+    /* demasking function of query_mode::general (`-f and|xor|r-s`, src/functions.h:8-57); set by orc_set_function */
+    int fn_kind;
+    uint64_t fn_r, fn_s;
 } orc_index;
 
-enum { ORC_MODE_OR = 0, ORC_MODE_ALL = 1 };
+enum { ORC_MODE_OR = 0, ORC_MODE_ALL = 1, ORC_MODE_GENERAL = 2 };
+enum { ORC_FN_AND = 1, ORC_FN_XOR = 2, ORC_FN_RANGE = 3 };
+/* mask_function(name) (src/functions.h:23-57): 0 = a general function (kind, r, s filled in), 1 = "or", 2 = "all" (the two
+ * that map to the fast paths), -1 = not recognized (the reference throws std::invalid_argument), -2 = a bound std::stoi rejects
+ * (the reference dies of the uncaught std::out_of_range) */
+int orc_parse_function(const char* name, int* kind, uint64_t* r, uint64_t* s);
+void orc_set_function(orc_index* ix, int kind, uint64_t r, uint64_t s);
+/* f(ones, total) as query_kmers_single<general> reaches it (src/fms_index.h:317-327): through std::function<bool(int,int)> wrappers,
+ * i.e. both counts truncated to int and widened again */
+int orc_apply_function(int kind, uint64_t r, uint64_t s, uint64_t ones, uint64_t total);
+/* single_query_general of both strands of one k-mer, a self-complementary k-mer counted once (src/fms_index.h:171-179, 317-323) */
+void orc_kmer_general(orc_index* ix, const char* kmer, int k, uint64_t* ones, uint64_t* total);
 
 /* growable output buffer standing in for std::ostream */
 typedef struct {

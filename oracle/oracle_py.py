@@ -208,6 +208,10 @@ def oracle_lib() -> C.CDLL:
         L.orc_kmer_ternaries.restype = None
         L.orc_kmers_ternaries_bulk.argtypes = [vp, C.c_char_p, u64, i32, i32, vp, vp, vp, vp]
         L.orc_kmers_ternaries_bulk.restype = None
+        L.orc_kmer_general.argtypes = [vp, C.c_char_p, i32, C.POINTER(u64), C.POINTER(u64)]
+        L.orc_kmer_general.restype = None
+        L.orc_apply_function.argtypes = [i32, u64, u64, u64, u64]
+        L.orc_apply_function.restype = i32
         _oracle_lib = L
     return _oracle_lib
 
@@ -321,6 +325,16 @@ class Oracle(_Base):
         self.L.orc_kmers_ternaries_bulk(self.h, kmers, n, k, int(maximized_ones), fwd.ctypes.data, rc.ctypes.data,
                                         of.ctypes.data if orders else None, orc.ctypes.data if orders else None)
         return (fwd, rc, of, orc) if orders else (fwd, rc)
+
+
+    def kmer_general(self, kmer: bytes, k: int):
+        """(ones, total) of a k-mer over both strands, a self-complementary k-mer counted once (query_mode::general)."""
+        o, t = C.c_uint64(), C.c_uint64()
+        self.L.orc_kmer_general(self.h, kmer, k, C.byref(o), C.byref(t))
+        return int(o.value), int(t.value)
+
+    def apply_function(self, kind: int, r: int, s: int, ones: int, total: int) -> bool:
+        return bool(self.L.orc_apply_function(kind, r, s, ones, total))
 
 
 class Reference(_Base):

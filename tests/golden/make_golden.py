@@ -75,7 +75,7 @@ def main():
 
     # 1. the reference's own test data
     for f in ["integration_a.fa", "integration_b.fa", "queries.txt", "result_a_complements.txt", "result_a_complements_hash.txt",
-              "result_b_complements.txt", "result_merged_complements.txt"]:
+              "result_b_complements.txt", "result_b_complements_xor.txt", "result_merged_complements.txt"]:
         shutil.copy(REF / "tests" / "testfiles" / f, rd / f)
     for f in ["GCF_009858895.2_ASM985889v3_genomic.fna.ms.k13", "GCF_test2_ones.fna.ms.k31"]:
         shutil.copy(REF / "tests" / "data" / f, rd / f)

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 import oracle_py
-from conftest import CLI_DATASETS, DATASETS, GOLDEN, MODES, golden_out, index_prefix, messy_fasta, mixed_kmers, query_file, revcomp, synthetic_ms
+from conftest import CLI_DATASETS, DATASETS, FN_CASES, GOLDEN, MODES, golden_fn_out, golden_out, index_prefix, messy_fasta, mixed_kmers, query_file, revcomp, synthetic_ms
 
 pytestmark = pytest.mark.gpu
 
@@ -699,6 +699,108 @@ def test_lookup_replay_on_large_batches(fm, oracle_built, tmp_path, name, k):
     rc, got, err = fm.run_cli([*args[:-1], "--batch", "50000", "--threads", "5", args[-1]])
     assert rc == 0 and got == ref
     assert sum(len(l.split(b"\t")[1].split(b",")) for l in ref.splitlines()) > 1_500_000
+
+
+@pytest.mark.parametrize("name,kind,fn", FN_CASES)
+def test_cli_general_functions_equal_reference_golden(fm, name, kind, fn):
+    """`fmsi query -f and|xor|r-s` (f-masked superstrings: query_mode::general, src/fms_index.h:316-327) reproduces the real
+    reference's stdout byte for byte -- k = 3 .. 64, masks of every kind, repeats (totals above 1), the reference's own golden
+    for `-f xor` among them -- also with -S (which changes nothing in this mode), in small batches and on two handles."""
+    k, _ = CLI_DATASETS[name]
+    want = golden_fn_out(name, kind, fn)
+    base = ["query", "-f", fn, "-k", str(k), "-q", str(query_file(name, kind))]
+    rc, out, err = fm.run_cli([*base, index_prefix(name)])
+    assert rc == 0, err.decode()
+    assert out == want
+    if fn in ("xor", "2-3"):
+        for extra in (["-S"], ["--batch", "1500", "--devices", "0,0"], ["--tables", "full"]):
+            rc, out, err = fm.run_cli([*base, *extra, index_prefix(name)])
+            assert rc == 0, err.decode()
+            assert out == want, extra
+
+
+def test_cli_function_names_and_errors(fm):
+    """mask_function() (src/functions.h:23-57) and ms_query's handling of -f (src/main.cpp:255-263, 273-280, 297-300): unknown names,
+    -O after -f, lookup with a function, `or` / `all` as names of the fast paths."""
+    q, prefix = str(query_file("integration_b", "queries")), index_prefix("integration_b")
+    for name in ("nand", "5", "1-", "-1-2", "1-x", "a-3", "1--2", ""):
+        rc, out, err = fm.run_cli(["query", "-f", name, "-q", q, prefix])
+        assert rc == 1 and out == b"" and f"ERROR: Function '{name}' not recognized.".encode() in err and b"Usage:   fmsi query" in err, name
+    rc, out, err = fm.run_cli(["query", "-f", "xor", "-O", "-q", q, prefix])
+    assert rc == 0 and out == golden_fn_out("integration_b", "queries", "xor") and b"WARNING: Parameter -O is ignored when parameter -f is specified." in err
+    rc, out, err = fm.run_cli(["query", "-f", "all", "-q", q, prefix])
+    assert rc == 0 and out == golden_out("integration_b", "queries", "all")
+    rc, out, err = fm.run_cli(["query", "-f", "xor", "-f", "or", "-q", q, prefix])
+    assert rc == 0 and out == golden_out("integration_b", "queries", "or")
+    rc, out, err = fm.run_cli(["query", "-f", "007-9", "-q", q, prefix])
+    rc2, out2, _ = fm.run_cli(["query", "-f", "7-9", "-q", q, prefix])
+    assert rc == 0 and rc2 == 0 and out == out2
+    rc, out, err = fm.run_cli(["lookup", "-f", "xor", "-q", q, prefix])
+    assert rc == 1 and out == b"" and b"not allowed with f-masked superstrings" in err and b"Usage:   fmsi lookup" in err
+    rc, out, err = fm.run_cli(["lookup", "-f", "all", "-q", q, prefix])
+    assert rc == 0 and out == golden_out("integration_b", "queries", "lookup") and b"WARNING: The current version of FMSI has speed benefits" in err
+    # a bound std::stoi rejects kills the reference (uncaught std::out_of_range): the same here
+    rc, out, err = fm.run_cli(["query", "-f", "1-99999999999", "-q", q, prefix])
+    assert rc in (134, -6) and out == b""
+
+
+@pytest.mark.parametrize("k", [4, 12, 31, 32, 33, 40])
+def test_general_function_counts_equal_oracle(fm, oracle_built, tmp_path, k):
+    """fmsi_hip_query_runs_fn against the oracle's single_query_general() of both strands, window by window: a text with repeats
+    (totals up to dozens), reverse-complemented copies (both strands occur) and -- for even k -- self-complementary k-mers, which
+    count once; every function, with and without the prefix table, byte and bit-packed results, k on both sides of 32."""
+    rng = random.Random(100 + k)
+    unit = "".join(rng.choice("ACGT") for _ in range(300))
+    pal = "".join(rng.choice("ACGT") for _ in range(k // 2))
+    pal = pal + revcomp(pal)                                   # self-complementary when k is even
+    pieces = []
+    for i in range(60):
+        c = rng.random()
+        if c < 0.3:
+            pieces.append(unit[rng.randrange(0, 100):][: rng.randrange(k, 200)])
+        elif c < 0.45:
+            pieces.append(revcomp(unit[rng.randrange(0, 100):][: rng.randrange(k, 200)]))
+        elif c < 0.6:
+            pieces.append(pal)
+        else:
+            pieces.append("".join(rng.choice("ACGT") for _ in range(rng.randrange(k, 400))))
+    text = "".join(pieces)
+    ms = "".join(ch if rng.random() < 0.55 else ch.lower() for ch in text)
+    ms = ms[: len(ms) - (k - 1)] + ms[len(ms) - (k - 1):].lower()
+    prefix = str(tmp_path / "fn")
+    orc = oracle_py.Oracle.construct(ms, k, use_klcp=False)
+    orc.dump(prefix)
+    # reads: pieces of the text, of its reverse complement, random ones, the palindrome
+    reads = []
+    for i in range(120):
+        L = rng.randrange(k, 3 * k + 60)
+        p = rng.randrange(0, len(text) - L)
+        r = text[p:p + L] if i % 4 else "".join(rng.choice("ACGT") for _ in range(L))
+        reads.append(revcomp(r) if i % 3 == 1 else r)
+    reads.append(pal + pal)
+    seq = "".join(reads)
+    starts, wins, off = [], [], 0
+    for r in reads:
+        starts.append(off)
+        wins.append(len(r) - k + 1)
+        off += len(r)
+    kmers = [r[i:i + k] for r in reads for i in range(len(r) - k + 1)]
+    counts = [orc.kmer_general(km.encode(), k) for km in kmers]
+    assert max(t for _, t in counts) >= 8 and any(o not in (0, t) for o, t in counts)
+    if k % 2 == 0:
+        assert orc.kmer_general(pal.encode(), k)[1] >= 1
+    packed = fm.pack_sequence(seq.encode())
+    for t in (0, min(k, 6)):
+        dev = fm.DeviceIndex.from_files(prefix, device=0, prefix_len=t)
+        for fn, r, s in ((fm.FN_AND, 0, 0), (fm.FN_XOR, 0, 0), (fm.FN_RANGE, 0, 0), (fm.FN_RANGE, 1, 1), (fm.FN_RANGE, 2, 5), (fm.FN_RANGE, 3, 2)):
+            want = np.array([orc.apply_function(fn, r, s, o, tt) for o, tt in counts], dtype=np.uint8)
+            got, cn = dev.query_runs_fn(packed, len(seq), starts, wins, k, fn, r, s, counters=True)
+            assert np.array_equal(got, want), (t, fn, r, s)
+            assert int(cn[6]) == len(kmers) and int(cn[3]) == 2 * len(kmers) and (int(cn[4]) == 2 * len(kmers) if t else int(cn[4]) == 0)
+            bits = dev.query_runs_fn(packed, len(seq), starts, wins, k, fn, r, s, flags=fm.OUT_BITS)
+            assert np.array_equal(fm.unpack_bits(bits, len(kmers), 0), want)
+        assert 0 < int(want.sum()) or True
+        dev.close()
 
 
 def test_cli_exits_when_stdout_fails(fm, tmp_path):

@@ -13,7 +13,7 @@ import numpy as np
 import pytest
 
 import oracle_py
-from conftest import (CLI_DATASETS, DATASETS, GOLDEN, INDEX_CASES, INDEX_PARTS, MODES, golden_index_part, golden_out, index_prefix, mixed_kmers,
+from conftest import (CLI_DATASETS, DATASETS, FN_CASES, GOLDEN, golden_fn_out, INDEX_CASES, INDEX_PARTS, MODES, golden_index_part, golden_out, index_prefix, mixed_kmers,
                       query_file, synthetic_ms)
 
 
@@ -128,12 +128,40 @@ def test_cli_output_equals_reference(oracle_built, name, kind, mode):
     assert out == golden_out(name, kind, mode)
 
 
+@pytest.mark.parametrize("name,kind,fn", FN_CASES)
+def test_cli_general_functions_equal_reference(oracle_built, name, kind, fn):
+    """`query -f and|xor|r-s` (query_mode::general, src/fms_index.h:316-327): the restatement against the real reference's output."""
+    k, _ = CLI_DATASETS[name]
+    rc, out, err = oracle_py.run_cli(oracle_py.ORACLE_CLI, ["query", "-f", fn, "-k", str(k), "-q", str(query_file(name, kind)), index_prefix(name)])
+    assert rc == 0, err
+    assert out == golden_fn_out(name, kind, fn)
+    if fn == "xor":   # -S changes nothing in this mode (:336), -O is ignored with a warning (src/main.cpp:273-276)
+        rc, out2, err = oracle_py.run_cli(oracle_py.ORACLE_CLI, ["query", "-S", "-f", fn, "-O", "-q", str(query_file(name, kind)), index_prefix(name)])
+        assert rc == 0 and out2 == out and b"WARNING: Parameter -O is ignored" in err
+
+
+def test_function_names_parse_like_the_reference(oracle_built):
+    """mask_function(), src/functions.h:23-57: which names are functions, and what the unknown ones print."""
+    q, prefix = str(query_file("integration_b", "queries")), index_prefix("integration_b")
+    for name in ("nand", "5", "1-", "-1-2", "1-x", "a-3", "1--2", ""):
+        for cli in ([oracle_py.ORACLE_CLI] + ([oracle_py.REF_CLI] if oracle_py.ref_available() else [])):
+            rc, out, err = oracle_py.run_cli(cli, ["query", "-f", name, "-q", q, prefix])
+            assert rc == 1 and out == b"" and f"ERROR: Function '{name}' not recognized.".encode() in err, (cli, name, err)
+    for name, same_as in (("or", []), ("all", ["-O"]), ("0-1000", ["-f", "0-2000"]), ("007-9", ["-f", "7-9"])):
+        rc, out, err = oracle_py.run_cli(oracle_py.ORACLE_CLI, ["query", "-f", name, "-q", q, prefix])
+        rc2, out2, _ = oracle_py.run_cli(oracle_py.ORACLE_CLI, ["query", *same_as, "-q", q, prefix])
+        assert rc == 0 and rc2 == 0 and out == out2, name
+    rc, out, err = oracle_py.run_cli(oracle_py.ORACLE_CLI, ["lookup", "-f", "xor", "-q", q, prefix])
+    assert rc == 1 and b"not allowed with f-masked superstrings" in err
+
+
 def test_reference_goldens_unchanged():
     """The reference's own committed goldens (tests/testfiles/result_*_complements*.txt)."""
     rd = GOLDEN / "ref_data"
     assert golden_out("integration_a", "queries", "or") == (rd / "result_a_complements.txt").read_bytes()
     assert golden_out("integration_a", "queries", "lookup") == (rd / "result_a_complements_hash.txt").read_bytes()
     assert golden_out("integration_b", "queries", "or") == (rd / "result_b_complements.txt").read_bytes()
+    assert golden_fn_out("integration_b", "queries", "xor") == (rd / "result_b_complements_xor.txt").read_bytes()
 
 
 def test_rrr_roundtrip_densities(oracle_built, tmp_path):

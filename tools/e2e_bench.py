@@ -30,6 +30,10 @@ MODES = {
     "all_S": ["query", "-S", "-O"],
     "all_S_fast": ["query", "-S", "-O", "--fast"],
     "lookup": ["lookup"],
+    # f-masked superstrings (query_mode::general): f(ones, total) over both strands, no replay
+    "xor": ["query", "-f", "xor"],
+    "and": ["query", "-f", "and"],
+    "range": ["query", "-f", "1-1"],
     # the same with the k-mer dictionary (--tables full), for comparison; and two handles on the one device (--devices 0,0)
     "or_full": ["query", "--tables", "full"],
     "all_full": ["query", "-O", "--tables", "full"],
