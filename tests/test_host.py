@@ -217,8 +217,10 @@ def test_cli_option_handling(product_built):
     assert rc == 1 and b"Mismatch. Provided k (5) does not match the k of the index (31)" in err
     rc, out, err = run(["query", str(GOLDEN / "idx" / "nope")])
     assert rc == 1 and b"index not correctly loaded" in err
-    rc, out, err = run(["query", "-f", "xor", index_prefix("sars_k31")])
-    assert rc == 1 and b"not available on the GPU path" in err
+    rc, out, err = run(["query", "-f", "nand", index_prefix("sars_k31")])               # src/main.cpp:255-263
+    assert rc == 1 and b"ERROR: Function 'nand' not recognized." in err and b"Usage:   fmsi query" in err
+    rc, out, err = run(["lookup", "-f", "xor", index_prefix("sars_k31")])               # src/main.cpp:297-300
+    assert rc == 1 and b"not allowed with f-masked superstrings" in err
     rc, out, err = run(["-v"])
     assert rc == 0 and out.strip()
     rc, out, err = run(["merge", "x"])
