@@ -145,7 +145,7 @@ def lib() -> C.CDLL:
     L.fmsi_hip_query_stream.argtypes = [vp, vp, u64, vp, vp, u64, u64, i32, u32, vp, vp, vp]
     L.fmsi_hip_query_runs.argtypes = [vp, vp, u64, vp, vp, u64, u64, i32, u32, vp, vp, vp]
     L.fmsi_hip_query_runs_fn.restype = i32
-    L.fmsi_hip_query_runs_fn.argtypes = [vp, vp, u64, vp, vp, u64, u64, i32, i32, u64, u64, u32, vp, vp, vp]
+    L.fmsi_hip_query_runs_fn.argtypes = [vp, vp, vp, u64, vp, vp, u64, u64, i32, i32, u64, u64, u32, vp, vp, vp]
     L.fmsi_hip_sync.argtypes = [vp, vp]
     L.fmsi_hip_profile_enable.argtypes = [vp, i32]
     L.fmsi_hip_profile_read.argtypes = [vp, C.POINTER(u64), C.POINTER(C.c_double), i32]
@@ -211,6 +211,14 @@ def pack_sequence(seq: bytes) -> np.ndarray:
     if bad != len(seq):
         raise ValueError(f"invalid character at {bad}")
     return words
+
+
+def lower_case_bits(seq: bytes) -> np.ndarray:
+    """One bit per character of a sequence, set where it is lower case (bit p & 63 of word p >> 6): query_runs_fn's lower_case."""
+    a = np.frombuffer(seq, dtype=np.uint8)
+    bits = np.zeros((len(seq) // 64 + 1) * 64, dtype=np.uint8)
+    bits[:len(seq)] = (a >= ord("a")) & (a <= ord("z"))
+    return np.packbits(bits, bitorder="little").view(np.uint64)
 
 
 class HostIndex:
@@ -420,15 +428,19 @@ class DeviceIndex:
         return self.query_stream(packed, seq_bases, run_start, run_windows, k, flags, counters, _fn="fmsi_hip_query_runs")
 
     def query_runs_fn(self, packed: np.ndarray, seq_bases: int, run_start, run_windows, k: int, fn: int, r: int = 0, s: int = 0,
-                      flags: int = 0, counters: bool = False):
-        """`-f and|xor|r-s` over runs of consecutive windows: f(ones, total) of both strands per window (FN_AND / FN_XOR / FN_RANGE)."""
+                      flags: int = 0, counters: bool = False, lower_case: np.ndarray | None = None):
+        """`-f and|xor|r-s` over runs of consecutive windows: f(ones, total) of both strands per window (FN_AND / FN_XOR / FN_RANGE).
+        lower_case: one bit per base (lower_case_bits(seq)), which decides whether a self-complementary k-mer counts once or twice."""
         packed = np.ascontiguousarray(packed, dtype=np.uint64)
+        if lower_case is not None:
+            lower_case = np.ascontiguousarray(lower_case, dtype=np.uint64)
+            assert lower_case.size >= seq_bases // 64 + 1
         run_start = np.ascontiguousarray(run_start, dtype=np.uint64)
         run_windows = np.ascontiguousarray(run_windows, dtype=np.uint32)
         n = int(run_windows.sum())
         out = self._alloc_out(n, flags)
         cn = np.zeros(N_COUNTERS, dtype=np.uint64) if counters else None
-        _check(lib().fmsi_hip_query_runs_fn(self._h, packed.ctypes.data, seq_bases, run_start.ctypes.data, run_windows.ctypes.data, run_start.size, n, k,
+        _check(lib().fmsi_hip_query_runs_fn(self._h, packed.ctypes.data, lower_case.ctypes.data if lower_case is not None else None, seq_bases, run_start.ctypes.data, run_windows.ctypes.data, run_start.size, n, k,
                                             fn, r, s, flags, out.ctypes.data, cn.ctypes.data if counters else None, None))
         self.sync()
         return (out, cn) if counters else out

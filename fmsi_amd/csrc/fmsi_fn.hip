@@ -6,6 +6,11 @@
 // (:319).  The strand predictor is consulted but never told anything in this mode and the two strands are summed, so -- unlike the
 // presence modes -- nothing depends on the order of the windows: no replay, every window independent.
 //
+// "Counted once" is the reference's `!AreStringsEqual(kmer, rc_kmer, k)` on the query's CHARACTERS, and its reverse complement keeps
+// the case of every character (src/kmers.h:21-38, 53-68): a self-complementary k-mer typed with asymmetric case -- acGT, whose reverse
+// complement reads ACgt -- is not equal to it as a string and IS counted twice (which flips an xor and doubles the count a range
+// looks at).  The 2-bit sequence has no case, so the caller hands over one bit per base (lower case or not) next to it.
+//
 // The search is the k-agnostic walk of fmsi_longk.hip: a lane walks its window straight off the 2-bit packed sequence, the forward
 // strand right-to-left, the reverse complement left-to-right with complemented bases, starting from the prefix table's interval
 // when the handle has one; the ON bits of an interval [i, j) are two mask ranks (block count + popcount below the row: the
@@ -80,10 +85,19 @@ __device__ __forceinline__ bool apply_fn(int fn, uint64_t r, uint64_t s, uint64_
     return o <= s && o >= r;                              // f_r_to_s, :17-19
 }
 
+// is the case of the window's characters symmetric (character t like character k-1-t)?  lower: bit p = base p is lower case
+__device__ __forceinline__ bool case_symmetric(const uint64_t* __restrict__ lower, uint64_t p, int k) {
+    for (int t = 0; t < k / 2; ++t) {
+        const uint64_t a = p + static_cast<uint64_t>(t), b = p + static_cast<uint64_t>(k - 1 - t);
+        if (((lower[a >> 6] >> (a & 63u)) ^ (lower[b >> 6] >> (b & 63u))) & 1u) return false;
+    }
+    return true;
+}
+
 template <bool COUNT>
-__global__ __launch_bounds__(256) void query_fn_kernel(DevIndex ix, const uint64_t* __restrict__ seq, const uint64_t* __restrict__ window_start,
-                                                       uint64_t n_windows, int k, int fn, uint64_t fn_r, uint64_t fn_s, uint8_t* __restrict__ out,
-                                                       unsigned long long* __restrict__ counters) {
+__global__ __launch_bounds__(256) void query_fn_kernel(DevIndex ix, const uint64_t* __restrict__ seq, const uint64_t* __restrict__ lower,
+                                                       const uint64_t* __restrict__ window_start, uint64_t n_windows, int k, int fn, uint64_t fn_r,
+                                                       uint64_t fn_s, uint8_t* __restrict__ out, unsigned long long* __restrict__ counters) {
     const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
     FnCounters cn;
     uint32_t done = 0;
@@ -98,11 +112,17 @@ __global__ __launch_bounds__(256) void query_fn_kernel(DevIndex ix, const uint64
             ones = ones_in(ix, fi, fj, cn);
             total = fj - fi;
         }
-        // "Do not count self complementary k-mers twice" (:319): equal strings have equal intervals, and different strings that both
-        // occur have different ones; two empty intervals add nothing either way
-        if (ri != rj && !(ri == fi && rj == fj)) {
-            ones += ones_in(ix, ri, rj, cn);
-            total += rj - ri;
+        // "Do not count self complementary k-mers twice" (:319): equal k-mers have equal intervals, and different k-mers that both
+        // occur have different ones; two empty intervals add nothing either way.  Equal k-mers in asymmetric case are different
+        // strings to the reference, though (see the top of this file).
+        if (ri != rj) {
+            if (!(ri == fi && rj == fj)) {
+                ones += ones_in(ix, ri, rj, cn);
+                total += rj - ri;
+            } else if (lower && !case_symmetric(lower, p, k)) {
+                ones += ones;
+                total += total;
+            }
         }
         out[q] = apply_fn(fn, fn_r, fn_s, ones, total) ? 1 : 0;
         ++done;
@@ -127,20 +147,20 @@ void launch_fn_query(fmsi_hip_index* idx, const uint64_t* d_seq, const uint64_t*
     DevIndex ix = idx->dev;
     if (!use_table) ix.ptable = nullptr;
     if (d_counters)
-        hipLaunchKernelGGL((query_fn_kernel<true>), dim3(blocks), dim3(256), 0, s, ix, d_seq, d_window_start, n, k, idx->fn_kind, idx->fn_r, idx->fn_s, o8,
-                           d_counters);
+        hipLaunchKernelGGL((query_fn_kernel<true>), dim3(blocks), dim3(256), 0, s, ix, d_seq, idx->fn_case, d_window_start, n, k, idx->fn_kind, idx->fn_r,
+                           idx->fn_s, o8, d_counters);
     else
-        hipLaunchKernelGGL((query_fn_kernel<false>), dim3(blocks), dim3(256), 0, s, ix, d_seq, d_window_start, n, k, idx->fn_kind, idx->fn_r, idx->fn_s, o8,
-                           d_counters);
+        hipLaunchKernelGGL((query_fn_kernel<false>), dim3(blocks), dim3(256), 0, s, ix, d_seq, idx->fn_case, d_window_start, n, k, idx->fn_kind, idx->fn_r,
+                           idx->fn_s, o8, d_counters);
 }
 
 }  // namespace fmsi
 
 using namespace fmsi;
 
-extern "C" int fmsi_hip_query_runs_fn(fmsi_hip_index* idx, const uint64_t* packed_seq, uint64_t seq_bases, const uint64_t* run_start,
-                                      const uint32_t* run_windows, uint64_t n_runs, uint64_t n_windows, int k, int fn, uint64_t r, uint64_t s,
-                                      uint32_t flags, void* out, uint64_t* counters, void* stream) {
+extern "C" int fmsi_hip_query_runs_fn(fmsi_hip_index* idx, const uint64_t* packed_seq, const uint64_t* lower_case, uint64_t seq_bases,
+                                      const uint64_t* run_start, const uint32_t* run_windows, uint64_t n_runs, uint64_t n_windows, int k, int fn, uint64_t r,
+                                      uint64_t s, uint32_t flags, void* out, uint64_t* counters, void* stream) {
     if (!idx) return FMSI_HIP_EINVAL;
     if (fn != FMSI_HIP_FN_AND && fn != FMSI_HIP_FN_XOR && fn != FMSI_HIP_FN_RANGE) {
         set_last_error("unknown demasking function");
@@ -154,6 +174,19 @@ extern "C" int fmsi_hip_query_runs_fn(fmsi_hip_index* idx, const uint64_t* packe
     idx->fn_kind = fn;
     idx->fn_r = r;
     idx->fn_s = s;
+    idx->fn_case = nullptr;
+    if (lower_case && k % 2 == 0 && n_windows) {   // (no k-mer of odd length is its own reverse complement)
+        if (flags & FMSI_HIP_DEVICE_PTRS) {
+            idx->fn_case = lower_case;
+        } else {
+            FMSI_HIP_ON_DEVICE(idx->device);
+            const size_t bytes = (seq_bases / 64 + 1) * 8;
+            int rc = ensure_cap(&idx->d_case, &idx->d_case_cap, bytes);
+            if (rc) return rc;
+            FMSI_HIP_TRY(hipMemcpyAsync(idx->d_case, lower_case, bytes, hipMemcpyHostToDevice, static_cast<hipStream_t>(stream)));
+            idx->fn_case = static_cast<const uint64_t*>(idx->d_case);
+        }
+    }
     return fmsi_hip_query_runs(idx, packed_seq, seq_bases, run_start, run_windows, n_runs, n_windows, k,
                                (flags & (FMSI_HIP_DEVICE_PTRS | FMSI_HIP_OUT_BITS | FMSI_HIP_NO_PREFIX_TABLE)) | kModeFn, out, counters, stream);
 }

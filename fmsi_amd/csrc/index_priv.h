@@ -148,6 +148,8 @@ struct fmsi_hip_index {
     void* d_kmers = nullptr; size_t d_kmers_cap = 0;   // windows -> packed k-mers
     void* d_tasks = nullptr; size_t d_tasks_cap = 0;   // streaming task descriptors + records
     void* d_bytes = nullptr; size_t d_bytes_cap = 0;   // FMSI_HIP_OUT_BITS: result bytes of the kernels that do not pack themselves
+    void* d_case = nullptr; size_t d_case_cap = 0;     // fmsi_hip_query_runs_fn: the sequence's lower-case bits
+    const uint64_t* fn_case = nullptr;                 // ... as the current call's kernel sees them (device pointer or nullptr)
     unsigned long long* d_counters = nullptr;
     fmsi::MetaSlot meta_ring[fmsi::kMetaSlots];
     unsigned meta_next = 0;

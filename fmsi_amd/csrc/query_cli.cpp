@@ -318,7 +318,10 @@ struct PinnedAlloc {
 };
 template <class T> using PinVec = std::vector<T, PinnedAlloc<T>>;
 
-struct RawBatch {
+struct RawBatch {   // never moved or copied: its records point into its own text (a short std::string lives INSIDE the object)
+    RawBatch() = default;
+    RawBatch(const RawBatch&) = delete;
+    RawBatch& operator=(const RawBatch&) = delete;
     std::string text;                                 // ordinary reader: names and sequences, as read
     std::vector<FastxViewParser::Arena> arenas;       // block-parallel reader: one per part, holding only what is not a view of the file
     std::vector<RecRef> recs;
@@ -414,7 +417,9 @@ bool parse_range(const unsigned char* d, size_t lo, size_t hi, FastxViewParser::
     return fastq ? r.clean_end() : !r.saw_fastq();
 }
 struct Prepared {
-    RawBatch raw;
+    explicit Prepared(std::unique_ptr<RawBatch> r = std::make_unique<RawBatch>()) : raw_owner(std::move(r)), raw(*raw_owner) {}
+    std::unique_ptr<RawBatch> raw_owner;
+    RawBatch& raw;
     std::vector<Op> ops;                  // all records' ops, record r owns [rec_ops[r], rec_ops[r+1])
     std::vector<uint64_t> rec_ops;
     std::vector<uint64_t> rec_first;      // first result (window) index of record r; [recs] = total
@@ -422,6 +427,7 @@ struct Prepared {
     std::vector<uint64_t> run_start;      // device runs: first base (a multiple of 32: runs are word aligned in `packed`)
     std::vector<uint32_t> run_windows;
     PinVec<uint64_t> packed;
+    PinVec<uint64_t> lower;               // -f with an even k: the lower-case bit of every packed base (case_run)
     uint64_t bases = 0, windows = 0;
     PinVec<uint8_t> bytes;                // device results, then (after the replay) the final 0/1 per window ...
     PinVec<uint64_t> bits;                // ... or, when nothing is replayed, one BIT per window straight from the device (FMSI_HIP_OUT_BITS)
@@ -482,6 +488,21 @@ inline void pack_run(const char* s, uint64_t len, uint64_t* dst) {
     static const bool bmi2 = __builtin_cpu_supports("bmi2") && !std::getenv("FMSI_HIP_NO_BMI2");
     if (bmi2) pack_run_bmi2(s, len, dst);
     else pack_run_plain(s, len, dst);
+}
+
+// Lower-case bits of `len` valid bases: bit i % 32 of dst32[i / 32] = character i is lower case (bit 5 of an ASCII letter) -- what
+// fmsi_hip_query_runs_fn wants next to the packed bases (a self-complementary k-mer in asymmetric case counts twice, include/fmsi_hip.h)
+inline void case_run(const char* s, uint64_t len, uint32_t* dst32) {
+    uint64_t i = 0;
+    for (; i + 8 <= len; i += 8) {
+        uint64_t v;
+        std::memcpy(&v, s + i, 8);
+        const uint32_t bits = static_cast<uint32_t>((((v >> 5) & 0x0101010101010101ull) * 0x0102040810204080ull) >> 56);   // byte j's bit -> bit j
+        if ((i & 31) == 0) dst32[i >> 5] = bits;
+        else dst32[i >> 5] |= bits << (i & 31);
+    }
+    if (i < len && (i & 31) == 0) dst32[i >> 5] = 0;
+    for (; i < len; ++i) dst32[i >> 5] |= static_cast<uint32_t>((static_cast<unsigned char>(s[i]) >> 5) & 1u) << (i & 31);
 }
 
 // next_invalid_character_or_end (src/parser.h:57-64): length of the longest prefix of s[0, n) made of ACGTacgt, 16 characters a step
@@ -545,7 +566,7 @@ inline void plan_record(const char* sequence, int64_t sequence_length, int k, Te
 }
 
 // records -> ops, device runs and the packed sequence, on `team` threads
-void prepare_batch(Prepared& P, int k, unsigned team) {
+void prepare_batch(Prepared& P, int k, unsigned team, bool with_case = false) {
     const size_t nrec = P.raw.recs.size();
     team = static_cast<unsigned>(std::max<size_t>(1, std::min<size_t>(team, nrec / 64 + 1)));
     // contiguous record ranges of about equal sequence length
@@ -582,6 +603,7 @@ void prepare_batch(Prepared& P, int k, unsigned team) {
     P.run_start.resize(run_at[team]);
     P.run_windows.resize(run_at[team]);
     P.packed.assign(word_at[team] + 2, 0);
+    if (with_case) P.lower.assign(word_at[team] / 2 + 2, 0);
     P.windows = win_at[team];
     P.bases = word_at[team] * 32;
     // byte offsets of the records' output lines (presence modes): name + '\t' + symbols + '\n'
@@ -605,6 +627,7 @@ void prepare_batch(Prepared& P, int k, unsigned team) {
         uint64_t word = word_at[t], run = run_at[t];
         for (const auto& [first, len] : tp[t].runs) {
             pack_run(first, len, P.packed.data() + word);
+            if (with_case) case_run(first, len, reinterpret_cast<uint32_t*>(P.lower.data()) + word);
             uint64_t windows = len - static_cast<uint64_t>(k) + 1, base = word * 32;
             while (windows) {
                 const uint64_t take = std::min(windows, kMaxRunWindows);
@@ -1465,12 +1488,10 @@ extern "C" int fmsi_cli_query(int argc, char** argv, int output_orders_i) {
                 std::unique_ptr<RawBatch> raw;
                 uint64_t seq = 0;
                 while (raw_q.pop_seq(raw, seq)) {
-                    auto P = std::make_unique<Prepared>();
-                    P->raw = std::move(*raw);
-                    raw.reset();
+                    auto P = std::make_unique<Prepared>(std::move(raw));
                     auto t0 = clock::now();
                     trace_push("fmsi: pack batch");
-                    prepare_batch(*P, k, worker_team);
+                    prepare_batch(*P, k, worker_team, general && k % 2 == 0);
                     trace_pop();
                     auto t1 = clock::now(), td = t1;
                     const uint64_t nw = P->windows;
@@ -1487,7 +1508,7 @@ extern "C" int fmsi_cli_query(int argc, char** argv, int output_orders_i) {
                                                   : (P->packed_bits ? static_cast<void*>(P->bits.data()) : static_cast<void*>(P->bytes.data()));
                         const uint32_t flags = flags_all | (P->packed_bits ? FMSI_HIP_OUT_BITS : 0u);
                         if (general)   // -f and|xor|r-s: f(ones, total) of both strands (query_kmers<general>, src/fms_index.h:316-327)
-                            check(fmsi_hip_query_runs_fn(cp->dev, P->packed.data(), P->bases, P->run_start.data(), P->run_windows.data(), P->run_start.size(), nw, k,
+                            check(fmsi_hip_query_runs_fn(cp->dev, P->packed.data(), P->lower.empty() ? nullptr : P->lower.data(), P->bases, P->run_start.data(), P->run_windows.data(), P->run_start.size(), nw, k,
                                                          opt.fn, opt.fn_r, opt.fn_s, FMSI_HIP_OUT_BITS, dst, nullptr, nullptr),
                                   "fmsi_hip_query_runs_fn");
                         else if (opt.has_klcp && !cp->have_dict)   // -S: kLCP streaming kernel (query_kmers_streaming, src/fms_index.h:181-254)
@@ -1502,6 +1523,7 @@ extern "C" int fmsi_cli_query(int argc, char** argv, int output_orders_i) {
                     }
                     auto t2 = clock::now();
                     PinVec<uint64_t>().swap(P->packed);
+                    PinVec<uint64_t>().swap(P->lower);
                     {
                         std::lock_guard<std::mutex> lk(stats_m);
                         prep_s += std::chrono::duration<double>(t1 - t0).count();

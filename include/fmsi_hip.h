@@ -273,14 +273,18 @@ int fmsi_hip_query_runs(fmsi_hip_index* idx, const uint64_t* packed_seq, uint64_
  *   FMSI_HIP_FN_AND    total != 0 && ones == total          (f_and)
  *   FMSI_HIP_FN_XOR    ones odd                             (f_xor)
  *   FMSI_HIP_FN_RANGE  r <= ones <= s                       (f_r_to_s; r, s as `-f r-s` parses them)
- * with ones and total passed through int as the reference's std::function<bool(int, int)> wrappers pass them.  Runs, buffers and
+ * with ones and total passed through int as the reference's std::function<bool(int, int)> wrappers pass them.
+ * `lower_case`: one bit per base of the sequence (bit p & 63 of word p >> 6, seq_bases / 64 + 1 words; host or device like packed_seq)
+ * that is set where the query character is lower case, or NULL for a sequence in one case.  It matters to self-complementary
+ * k-mers only: the reference recognises them by comparing the query's characters with their case-preserving reverse complement
+ * (AreStringsEqual, src/kmers.h:61-68), so "acGT" is not equal to its reverse complement "ACgt" and is counted TWICE.  Runs, buffers and
  * result layout as fmsi_hip_query_runs (one byte 0 / 1 per window, or FMSI_HIP_OUT_BITS); of `flags` only FMSI_HIP_DEVICE_PTRS,
  * FMSI_HIP_OUT_BITS and FMSI_HIP_NO_PREFIX_TABLE are looked at.  The strand predictor plays no part in this mode (it is asked
  * but never told, and both strands are added up), and `-S` changes nothing (:336).  Any k; not for indexes of 2^32 rows or more. */
 #define FMSI_HIP_FN_AND 1
 #define FMSI_HIP_FN_XOR 2
 #define FMSI_HIP_FN_RANGE 3
-int fmsi_hip_query_runs_fn(fmsi_hip_index* idx, const uint64_t* packed_seq, uint64_t seq_bases,
+int fmsi_hip_query_runs_fn(fmsi_hip_index* idx, const uint64_t* packed_seq, const uint64_t* lower_case, uint64_t seq_bases,
                            const uint64_t* run_start, const uint32_t* run_windows, uint64_t n_runs, uint64_t n_windows,
                            int k, int fn, uint64_t r, uint64_t s, uint32_t flags, void* out, uint64_t* counters, void* stream);
 

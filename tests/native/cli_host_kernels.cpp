@@ -38,6 +38,16 @@ int main() {
             if (b != want) return fail("pack_run_bmi2", it, n);
         }
     }
+    // lower-case bits
+    for (size_t it = 0; it < 5000; ++it) {
+        const size_t n = 1 + rng() % 300, off = rng() % 8;
+        std::string s(off + n, 'A');
+        for (size_t i = 0; i < n; ++i) s[off + i] = "ACGTacgt"[rng() % 8];
+        std::vector<uint32_t> want((n + 31) / 32, 0), got(want.size(), 0);
+        for (size_t i = 0; i < n; ++i) want[i / 32] |= static_cast<uint32_t>(s[off + i] >= 'a') << (i % 32);
+        case_run(s.data() + off, n, got.data());
+        if (got != want) return fail("case_run", it, n);
+    }
     // result bits -> characters
     for (size_t it = 0; it < 5000; ++it) {
         const size_t total = 64 + rng() % 1000;

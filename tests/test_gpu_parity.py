@@ -778,6 +778,12 @@ def test_general_function_counts_equal_oracle(fm, oracle_built, tmp_path, k):
         r = text[p:p + L] if i % 4 else "".join(rng.choice("ACGT") for _ in range(L))
         reads.append(revcomp(r) if i % 3 == 1 else r)
     reads.append(pal + pal)
+    # ... in mixed case: the reference compares CHARACTERS with their case-preserving reverse complement (src/kmers.h:53-68), so a
+    # self-complementary k-mer typed in asymmetric case is counted twice
+    reads = [r if i % 2 else "".join(c.lower() if rng.random() < 0.3 else c for c in r) for i, r in enumerate(reads)]
+    if k % 2 == 0:
+        reads.append(pal[: k // 2].lower() + pal[k // 2:])
+        reads.append(pal.lower())
     seq = "".join(reads)
     starts, wins, off = [], [], 0
     for r in reads:
@@ -790,14 +796,18 @@ def test_general_function_counts_equal_oracle(fm, oracle_built, tmp_path, k):
     if k % 2 == 0:
         assert orc.kmer_general(pal.encode(), k)[1] >= 1
     packed = fm.pack_sequence(seq.encode())
+    lower = fm.lower_case_bits(seq.encode())
+    if k % 2 == 0:   # the asymmetric palindrome counts twice, the symmetric ones once
+        o1, t1 = orc.kmer_general(pal.encode(), k)
+        assert orc.kmer_general((pal[: k // 2].lower() + pal[k // 2:]).encode(), k) == (2 * o1, 2 * t1) and orc.kmer_general(pal.lower().encode(), k) == (o1, t1)
     for t in (0, min(k, 6)):
         dev = fm.DeviceIndex.from_files(prefix, device=0, prefix_len=t)
         for fn, r, s in ((fm.FN_AND, 0, 0), (fm.FN_XOR, 0, 0), (fm.FN_RANGE, 0, 0), (fm.FN_RANGE, 1, 1), (fm.FN_RANGE, 2, 5), (fm.FN_RANGE, 3, 2)):
             want = np.array([orc.apply_function(fn, r, s, o, tt) for o, tt in counts], dtype=np.uint8)
-            got, cn = dev.query_runs_fn(packed, len(seq), starts, wins, k, fn, r, s, counters=True)
+            got, cn = dev.query_runs_fn(packed, len(seq), starts, wins, k, fn, r, s, counters=True, lower_case=lower)
             assert np.array_equal(got, want), (t, fn, r, s)
             assert int(cn[6]) == len(kmers) and int(cn[3]) == 2 * len(kmers) and (int(cn[4]) == 2 * len(kmers) if t else int(cn[4]) == 0)
-            bits = dev.query_runs_fn(packed, len(seq), starts, wins, k, fn, r, s, flags=fm.OUT_BITS)
+            bits = dev.query_runs_fn(packed, len(seq), starts, wins, k, fn, r, s, flags=fm.OUT_BITS, lower_case=lower)
             assert np.array_equal(fm.unpack_bits(bits, len(kmers), 0), want)
         assert 0 < int(want.sum()) or True
         dev.close()
