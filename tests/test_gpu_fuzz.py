@@ -1,7 +1,8 @@
 """Differential runs of the whole CLI against the real reference (oracle/_ref; the oracle's CLI where that is not built): random
 masked superstrings -- any k from 1 to 70, repeats, reverse-complemented copies, poly-A stretches, random masks -- indexed by the
 oracle's restatement of `fmsi index`, random query files of every record shape, every mode (`query`, `-O`, `-S`, `lookup`,
-`-f and|xor|r-s`) under random GPU-side options (batch size, threads, tables, two handles).  stdout must be the reference's, byte for byte.
+`-f and|xor|r-s`) under random GPU-side options (batch size, threads, tables, two handles).  stdout must be the reference's, byte for byte;
+every third superstring also goes through `fmsi index` on the device (same files as the restatement's, which the reference's pin) and `fmsi export`.
 tools/fuzz_cli.py runs the same generator for as long as one likes."""
 import random
 
@@ -49,6 +50,15 @@ def one_case(fm, tmp_path, seed: int, checker):
     prefix = str(tmp_path / f"fz{seed}")
     use_klcp = k <= 64
     oracle_py.Oracle.construct(ms, k, use_klcp=use_klcp).dump(prefix)
+    if seed % 3 == 0:   # `fmsi index` on the device writes the same bytes, and `fmsi export` gives the superstring back
+        fa = tmp_path / f"ms{seed}.fa"
+        fa.write_text(f">ms\n{ms}\n")
+        rc, out, err = fm.run_cli(["index", "-k", str(k), str(fa)])
+        assert rc == 0, (seed, k, err.decode()[-400:])
+        for part in ("ac_gt", "ac", "gt", "mask", "misc") + (("klcp",) if use_klcp else ()):
+            assert (tmp_path / f"ms{seed}.fa.fmsi.{part}").read_bytes() == (tmp_path / f"fz{seed}.fmsi.{part}").read_bytes(), (seed, k, len(ms), part)
+        rc, out, err = fm.run_cli(["export", str(fa)])
+        assert rc == 0 and out.decode() == ">exported masked superstring\n" + ms + "\n", (seed, k, len(ms))
     q = tmp_path / f"fz{seed}.fa"
     src = ms if len(ms) > 800 else ms * (800 // len(ms) + 2)      # (messy_fasta draws reads of up to 700 bases)
     q.write_bytes(messy_fasta(src, rng, fastq_at=rng.choice([None, None, 150, 0])))
