@@ -1,5 +1,10 @@
 #include "fastx.h"
 
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
 #include <algorithm>
 #include <cctype>
 #include <cstdio>
@@ -29,6 +34,80 @@ FastxReader::FastxReader(const std::string& path) : own_(kBufSize) {
 
 FastxReader::~FastxReader() {
     if (fp_) gzclose(fp_);
+}
+
+void FastxReader::skip(uint64_t bytes) {
+    if (fp_ && bytes) (void)gzseek(fp_, static_cast<z_off_t>(bytes), SEEK_SET);   // (forward from 0: zlib inflates and discards)
+    begin_ = end_ = 0;
+}
+
+BgzfFile::~BgzfFile() {
+    if (data_) munmap(const_cast<unsigned char*>(data_), size_);
+}
+
+bool BgzfFile::open(const std::string& path, size_t min_bytes) {
+    const int fd = ::open(path.c_str(), O_RDONLY);
+    if (fd < 0) return false;
+    struct stat st;
+    bool ok = fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && static_cast<size_t>(st.st_size) >= std::max<size_t>(min_bytes, 28);
+    if (ok) {
+        void* p = mmap(nullptr, static_cast<size_t>(st.st_size), PROT_READ, MAP_PRIVATE, fd, 0);
+        ok = p != MAP_FAILED;
+        if (ok) {
+            data_ = static_cast<const unsigned char*>(p);
+            size_ = static_cast<size_t>(st.st_size);
+            (void)madvise(p, size_, MADV_SEQUENTIAL);
+            Member m;
+            if (!member(0, &m)) {
+                munmap(p, size_);
+                data_ = nullptr;
+                size_ = 0;
+                ok = false;
+            }
+        }
+    }
+    ::close(fd);
+    return ok;
+}
+
+bool BgzfFile::member(size_t at, Member* m) const {
+    // RFC 1952 header with FLG.FEXTRA: ID1 ID2 CM FLG MTIME(4) XFL OS XLEN(2) | subfields: SI1 SI2 SLEN(2) data
+    if (at + 18 > size_) return false;
+    const unsigned char* h = data_ + at;
+    if (h[0] != 0x1f || h[1] != 0x8b || h[2] != 8 || h[3] != 4) return false;   // (exactly FEXTRA: what BGZF writers emit)
+    const size_t xlen = h[10] | (static_cast<size_t>(h[11]) << 8);
+    if (at + 12 + xlen + 8 > size_) return false;
+    size_t bsize = 0;
+    for (size_t x = 0; x + 4 <= xlen;) {
+        const unsigned char* sf = h + 12 + x;
+        const size_t slen = sf[2] | (static_cast<size_t>(sf[3]) << 8);
+        if (x + 4 + slen > xlen) return false;
+        if (sf[0] == 'B' && sf[1] == 'C' && slen == 2) bsize = (sf[4] | (static_cast<size_t>(sf[5]) << 8)) + 1;   // total block size
+        x += 4 + slen;
+    }
+    if (bsize < 12 + xlen + 8 || at + bsize > size_) return false;
+    m->data_off = at + 12 + xlen;
+    m->data_len = bsize - (12 + xlen) - 8;
+    const unsigned char* t = data_ + at + bsize - 8;
+    m->crc = t[0] | (static_cast<uint32_t>(t[1]) << 8) | (static_cast<uint32_t>(t[2]) << 16) | (static_cast<uint32_t>(t[3]) << 24);
+    m->isize = t[4] | (static_cast<uint32_t>(t[5]) << 8) | (static_cast<uint32_t>(t[6]) << 16) | (static_cast<uint32_t>(t[7]) << 24);
+    m->next = at + bsize;
+    return true;
+}
+
+bool BgzfFile::inflate(const Member& m, char* dst) const {
+    z_stream zs;
+    std::memset(&zs, 0, sizeof zs);
+    if (inflateInit2(&zs, -15) != Z_OK) return false;   // raw deflate
+    zs.next_in = const_cast<Bytef*>(data_ + m.data_off);
+    zs.avail_in = static_cast<uInt>(m.data_len);
+    char none = 0;   // (an empty member -- BGZF's end-of-file marker -- still wants somewhere to write)
+    zs.next_out = reinterpret_cast<Bytef*>(m.isize ? dst : &none);
+    zs.avail_out = m.isize ? m.isize : 1;
+    const int rc = ::inflate(&zs, Z_FINISH);
+    const bool ok = rc == Z_STREAM_END && zs.total_out == m.isize && zs.avail_in == 0;
+    inflateEnd(&zs);
+    return ok && crc32(crc32(0L, Z_NULL, 0), reinterpret_cast<const Bytef*>(dst), m.isize) == m.crc;
 }
 
 bool FastxReader::fill_() {

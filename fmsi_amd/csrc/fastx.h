@@ -40,6 +40,10 @@ public:
     // record past its old size, which the caller truncates.
     bool next_append(std::string& text, size_t* name_off, size_t* name_len, size_t* seq_off, size_t* seq_len);
 
+    // file mode, before the first record is read: go on from `bytes` into the UNCOMPRESSED stream (what a reader that took the
+    // first part of the stream itself has consumed)
+    void skip(uint64_t bytes);
+
     std::string name;
     std::string seq;
 
@@ -84,6 +88,35 @@ private:
     bool fastq_seen_ = false, clean_end_ = false;
     int last_char_ = 0;
     std::vector<std::pair<size_t, size_t>> lines_;   // the current record's sequence lines [from, to)
+};
+
+// A block-gzip file (BGZF: htslib's bgzip, Illumina's converters -- a series of gzip members of at most 64 KiB each whose header
+// says how long the member is, RFC 1952 extra subfield 'B' 'C'): the members can be found without inflating anything and inflated
+// independently, which is what lets several threads share the decompression.  To zlib -- and so to the reference's reader,
+// src/parser.h:14-27 -- such a file is an ordinary multi-member gzip stream.
+class BgzfFile {
+public:
+    struct Member {
+        size_t data_off, data_len;   // the raw deflate stream
+        uint32_t isize, crc;         // uncompressed length and CRC-32 (the member's trailer)
+        size_t next;                 // offset of the member behind it
+    };
+    BgzfFile() = default;
+    ~BgzfFile();
+    BgzfFile(const BgzfFile&) = delete;
+    BgzfFile& operator=(const BgzfFile&) = delete;
+    // maps the file if it is a regular file of at least min_bytes that starts with a BGZF member
+    bool open(const std::string& path, size_t min_bytes);
+    // the member at compressed offset `at`; false: no (complete) BGZF member there
+    bool member(size_t at, Member* m) const;
+    // inflates one member into dst[0, isize) and checks length and CRC
+    bool inflate(const Member& m, char* dst) const;
+    size_t size() const { return size_; }
+    explicit operator bool() const { return data_ != nullptr; }
+
+private:
+    const unsigned char* data_ = nullptr;
+    size_t size_ = 0;
 };
 
 }  // namespace fmsi

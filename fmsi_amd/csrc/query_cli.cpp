@@ -324,6 +324,7 @@ struct RawBatch {   // never moved or copied: its records point into its own tex
     RawBatch& operator=(const RawBatch&) = delete;
     std::string text;                                 // ordinary reader: names and sequences, as read
     std::vector<FastxViewParser::Arena> arenas;       // block-parallel reader: one per part, holding only what is not a view of the file
+    std::shared_ptr<char[]> inflated;                 // block-gzip reader: the decompressed bytes the views look into
     std::vector<RecRef> recs;
     uint64_t seq_bytes = 0;
 };
@@ -399,6 +400,30 @@ size_t next_record_start(const unsigned char* d, size_t from, size_t end, bool f
     }
     return end;
 }
+// last position <= len where a record starts (by the rules of next_record_start), 0 if there is none behind the first byte:
+// everything in front of it is whole records, what follows is carried over to the next stretch of the stream
+size_t last_record_start(const unsigned char* d, size_t len, bool fastq) {
+    if (!fastq) {
+        for (size_t e = len; e > 0;) {
+            const void* g = memrchr(d, '>', e);
+            if (!g) return 0;
+            const size_t at = static_cast<size_t>(static_cast<const unsigned char*>(g) - d);
+            if (at == 0 || d[at - 1] == '\n') return at;
+            e = at;
+        }
+        return 0;
+    }
+    for (size_t window = size_t(1) << 20;; window <<= 2) {   // a header needs its next two lines in sight: look from a little before the end
+        const size_t from = len > window ? len - window : 0;
+        size_t c = next_fastq_start(d, from, len);
+        if (c < len) {
+            for (size_t n; (n = next_fastq_start(d, c + 1, len)) < len;) c = n;
+            return c;
+        }
+        if (from == 0) return 0;
+    }
+}
+
 // all records of d[lo, hi) (lo at a record start) as views (FastxViewParser: the ordinary reader's rules)
 bool parse_range(const unsigned char* d, size_t lo, size_t hi, FastxViewParser::Arena& arena, std::vector<RecRef>& recs, uint64_t& seq_bytes,
                  bool fastq = false) {
@@ -1132,12 +1157,17 @@ extern "C" int fmsi_cli_query(int argc, char** argv, int output_orders_i) {
     std::exception_ptr reader_err, writer_err;
     std::unique_ptr<FastxReader> reader;
     MappedFile mapped;
+    BgzfFile bgzf;
     bool parallel_read = false, parallel_fastq = false;
     uint64_t parallel_read_bytes = 0;   // (--stats: how far the block-parallel reader got before it had to hand over, if it did)
     std::thread reader_thread;
     auto start_reader = [&] {
         reader = std::make_unique<FastxReader>(opt.query_fn);   // throws std::invalid_argument like OpenFile(), src/parser.h:22
         parallel_read = map_plain_fasta(opt.query_fn, mapped, &parallel_fastq);
+        if (!parallel_read && opt.query_fn != "-" && !std::getenv("FMSI_HIP_SERIAL_READER")) {
+            const char* min_env = std::getenv("FMSI_HIP_READER_MIN_BYTES");
+            (void)bgzf.open(opt.query_fn, min_env ? static_cast<size_t>(std::max(1ll, atoll(min_env))) : (size_t(1) << 20));
+        }
         reader_thread = std::thread([&] {
         try {
             auto b = std::make_unique<RawBatch>();
@@ -1203,6 +1233,105 @@ extern "C" int fmsi_cli_query(int argc, char** argv, int output_orders_i) {
                     return;
                 }
                 reader = std::make_unique<FastxReader>(mapped.data + resume_at, mapped.size - resume_at);
+            }
+            // ---- block-gzip (BGZF) file: the members are found by their headers and inflated side by side into one stretch of the
+            // stream after the other; a stretch ends where its last record starts (the rest is carried into the next one) and is
+            // parsed like a range of a mapped plain file.  Anything unusual -- a member that is not BGZF, a CRC that does not match, a
+            // part that does not end between two records -- hands the stream to the ordinary reader at the last byte given out.
+            if (bgzf) {
+                const unsigned workers = std::max(1u, std::min(8u, team / 2));
+                size_t at = 0;             // compressed offset of the next member
+                uint64_t consumed = 0;     // uncompressed bytes handed on in batches
+                std::string carry;
+                bool eof = false, serial = false, first = true, fastq = false;
+                while (!serial && !(eof && carry.empty())) {
+                    const uint64_t range_bytes = (fastq ? 2 : 1) * opt.batch_windows;
+                    std::vector<BgzfFile::Member> ms;
+                    std::vector<size_t> offs;
+                    size_t bytes = 0;
+                    while (!eof && bytes < range_bytes) {
+                        if (at >= bgzf.size()) {
+                            eof = true;
+                            break;
+                        }
+                        BgzfFile::Member m;
+                        if (!bgzf.member(at, &m)) {
+                            serial = true;
+                            break;
+                        }
+                        offs.push_back(bytes);
+                        ms.push_back(m);
+                        bytes += m.isize;
+                        at = m.next;
+                    }
+                    if (serial) break;
+                    const size_t len = carry.size() + bytes;
+                    std::shared_ptr<char[]> seg(new char[len + 1]);
+                    std::memcpy(seg.get(), carry.data(), carry.size());
+                    // (inflating is by far the longest piece of work on this path: the whole team takes it)
+                    const unsigned inflaters = static_cast<unsigned>(std::max<size_t>(1, std::min<size_t>(team, ms.size())));
+                    std::vector<char> ok(inflaters, 1);
+                    parallel_for(inflaters, [&](unsigned t) {
+                        for (size_t i = t; i < ms.size(); i += inflaters)
+                            if (!bgzf.inflate(ms[i], seg.get() + carry.size() + offs[i])) ok[t] = 0;
+                    });
+                    if (std::find(ok.begin(), ok.end(), 0) != ok.end()) {
+                        serial = true;
+                        break;
+                    }
+                    const unsigned char* d = reinterpret_cast<const unsigned char*>(seg.get());
+                    if (first && len) {
+                        if (d[0] == '@') fastq = true;
+                        else if (d[0] != '>') serial = true;   // (leading junk: the ordinary reader knows what to do with it)
+                        first = false;
+                        if (serial) break;
+                    }
+                    const size_t cut = eof ? len : last_record_start(d, len, fastq);
+                    if (cut == 0 && !eof) {   // one record longer than the stretch: read on
+                        carry.assign(seg.get(), len);
+                        continue;
+                    }
+                    std::vector<size_t> cuts{0};
+                    for (unsigned w = 1; w < workers; ++w) {
+                        const size_t c = next_record_start(d, cut / workers * w, cut, fastq);
+                        if (c > cuts.back() && c < cut) cuts.push_back(c);
+                    }
+                    cuts.push_back(cut);
+                    const size_t parts = cuts.size() - 1;
+                    std::vector<std::vector<RecRef>> recs(parts);
+                    std::vector<uint64_t> seq_bytes(parts, 0);
+                    std::vector<char> clean(parts, 1);
+                    auto nb = std::make_unique<RawBatch>();
+                    nb->arenas.resize(parts);
+                    nb->inflated = seg;
+                    parallel_for(static_cast<unsigned>(parts), [&](unsigned w) {
+                        clean[w] = parse_range(d, cuts[w], cuts[w + 1], nb->arenas[w], recs[w], seq_bytes[w], fastq) ? 1 : 0;
+                    });
+                    size_t total = 0;
+                    for (size_t w = 0; w < parts; ++w) total += recs[w].size();
+                    if (std::find(clean.begin(), clean.end(), 0) != clean.end() || total > (1u << 23)) {
+                        serial = true;
+                        break;
+                    }
+                    nb->recs.reserve(total);
+                    for (size_t w = 0; w < parts; ++w) {
+                        nb->recs.insert(nb->recs.end(), recs[w].begin(), recs[w].end());
+                        nb->seq_bytes += seq_bytes[w];
+                    }
+                    carry.assign(seg.get() + cut, len - cut);
+                    consumed += cut;
+                    parallel_read_bytes = consumed;
+                    if (nb->recs.empty()) continue;
+                    read_s += std::chrono::duration<double>(clock::now() - t0).count();
+                    if (!raw_q.push(std::move(nb))) return;
+                    t0 = clock::now();
+                }
+                if (!serial) {
+                    read_s += std::chrono::duration<double>(clock::now() - t0).count();
+                    raw_q.close();
+                    return;
+                }
+                reader->skip(consumed);
             }
             // ordinary reader: names and sequences are appended to the batch's text, which moves as it grows -- the records hold
             // offsets until the batch is complete

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 import oracle_py
-from conftest import CLI_DATASETS, DATASETS, FN_CASES, GOLDEN, MODES, golden_fn_out, golden_out, index_prefix, messy_fasta, mixed_kmers, query_file, revcomp, synthetic_ms
+from conftest import CLI_DATASETS, DATASETS, FN_CASES, GOLDEN, MODES, bgzf_bytes, golden_fn_out, golden_out, index_prefix, messy_fasta, mixed_kmers, query_file, revcomp, synthetic_ms
 
 pytestmark = pytest.mark.gpu
 
@@ -811,6 +811,81 @@ def test_general_function_counts_equal_oracle(fm, oracle_built, tmp_path, k):
             assert np.array_equal(fm.unpack_bits(bits, len(kmers), 0), want)
         assert 0 < int(want.sum()) or True
         dev.close()
+
+
+@pytest.mark.parametrize("shape", ["fasta_messy", "fastq_4line", "fasta_long_records", "then_plain_gzip", "bad_crc", "not_bgzf_gzip"])
+def test_block_gzip_reader(fm, oracle_built, tmp_path, monkeypatch, shape):
+    """Block-gzip (BGZF) query files: the members are found by their headers, inflated by several threads and parsed in stretches that
+    end where a record starts -- the output must be what the ordinary reader (zlib's gzread, as in the reference) makes of the same
+    file, for records of every shape, records far longer than a stretch, and files that stop being BGZF half way (an ordinary gzip
+    member appended, a member whose CRC does not match): there the ordinary reader takes over at the byte the parallel part reached."""
+    import gzip
+    import json as _json
+    name, k = "sars_k13", 13
+    ms = "".join(l.strip() for l in open(GOLDEN / "ref_data" / "GCF_009858895.2_ASM985889v3_genomic.fna.ms.k13") if not l.startswith(">"))
+    rng = random.Random(hash(shape) & 0xFFFF)
+    if shape == "fastq_4line":
+        up = ms.upper()
+        data = bytearray()
+        for r in range(1500):
+            L = rng.choice([13, 40, 75, 151, 300])
+            p = rng.randrange(0, len(up) - L)
+            qual = "".join(rng.choice("@+>IIIIFFF#5") for _ in range(L))
+            data += f"@r{r} c\n{up[p:p + L]}\n+\n{qual}\n".encode()
+        data = bytes(data)
+    elif shape == "fasta_long_records":
+        up = ms.upper()
+        data = b"".join(f">long{r}\n".encode() + (up[rng.randrange(0, 1000):][:rng.choice([9000, 20000])] + "N" + up[:5000]).encode() + b"\n" for r in range(12))
+    else:
+        data = b">first\nACGTTGCA\n" + messy_fasta(ms, rng)     # (messy_fasta may open with an '@' header: that would make it a FASTQ file)
+    blob = bgzf_bytes(data, block=rng.choice([700, 3000, 0xFF00]))
+    expect_parallel = len(data)
+    if shape == "then_plain_gzip":
+        extra = messy_fasta(ms, random.Random(9))
+        blob = bgzf_bytes(data, block=1500, eof=False) + gzip.compress(extra)
+        data, expect_parallel = data + extra, None
+    elif shape == "bad_crc":
+        blob = bytearray(bgzf_bytes(data, block=1500))
+        at, members = 0, []
+        while at < len(blob):
+            bsize = int.from_bytes(blob[at + 16:at + 18], "little") + 1
+            members.append((at, bsize))
+            at += bsize
+        at, bsize = members[len(members) // 2]
+        good = tmp_path / "good.fa.gz"
+        good.write_bytes(bytes(blob))
+        blob[at + bsize - 8] ^= 0x5A                     # the CRC of a member in the middle
+        blob, expect_parallel = bytes(blob), None
+    elif shape == "not_bgzf_gzip":
+        blob, expect_parallel = gzip.compress(data), 0
+    q = tmp_path / "q.fa.gz"
+    q.write_bytes(blob)
+    for mode in ("or", "all_S", "lookup"):
+        args = [*MODES[mode][0], "-k", str(k), "--batch", "4096", "-q", str(q), index_prefix(name)]
+        monkeypatch.setenv("FMSI_HIP_SERIAL_READER", "1")
+        rc0, want, err0 = fm.run_cli(args)
+        monkeypatch.delenv("FMSI_HIP_SERIAL_READER")
+        monkeypatch.setenv("FMSI_HIP_READER_MIN_BYTES", "1")
+        rc, got, err = fm.run_cli([*args[:-1], "--stats", args[-1]])
+        monkeypatch.delenv("FMSI_HIP_READER_MIN_BYTES")
+        assert rc == rc0 == 0, err.decode()
+        if shape == "bad_crc":
+            # zlib's gzread drops what it had inflated in the call that meets the error, so how much comes out in front of a corrupt
+            # member depends on buffer sizes (the reference's too): whole lines of the intact file's output, up to short of the damage
+            rc, whole, _ = fm.run_cli([*args[:-2], str(good), args[-1]])
+            assert rc == 0 and whole.startswith(got) and (got == b"" or got.endswith(b"\n")) and 0 < len(got) < len(whole) and whole.startswith(want)
+        else:
+            assert got == want
+        par = _json.loads([l for l in err.decode().splitlines() if l.startswith("{")][-1])["block_parallel_read_bytes"]
+        if expect_parallel is not None:
+            assert par == expect_parallel
+        else:
+            assert 0 < par < len(data)
+        if shape != "bad_crc":       # (zlib's error handling on a corrupt stream is the serial reader's business; the reference's is the same zlib)
+            checker = oracle_py.REF_CLI if oracle_py.ref_available() else oracle_py.ORACLE_CLI
+            rc, ref, _ = oracle_py.run_cli(checker, [a for a in args if a not in ("--batch", "4096")])
+            assert rc == 0 and got == ref
+        assert got.count(b"\n") >= 12
 
 
 def test_cli_exits_when_stdout_fails(fm, tmp_path):

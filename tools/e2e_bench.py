@@ -72,6 +72,8 @@ def main() -> None:
     ap.add_argument("--ref-reads", type=int, default=40, help="reads of the sample that also go through the reference CLI")
     ap.add_argument("--dir", default="/dev/shm/fmsi_e2e")
     ap.add_argument("--out", default=None, help="write the JSON report here")
+    ap.add_argument("--compress", choices=["none", "bgzf", "gzip"], default="none",
+                    help="query file as block-gzip (members of 64 KiB, level 1: read by several threads) or as one ordinary gzip member")
     a = ap.parse_args()
 
     import torch
@@ -105,13 +107,39 @@ def main() -> None:
         del d
     report["fasta_bytes"] = fasta.stat().st_size
     report["fasta_seconds"] = round(time.time() - t0, 3)
+    if a.compress != "none":
+        import struct
+        import zlib
+        t0 = time.time()
+        gz = work / "reads.fa.gz"
+        with open(fasta, "rb") as f, open(gz, "wb") as g:
+            if a.compress == "gzip":
+                c = zlib.compressobj(1, zlib.DEFLATED, 31)
+                while chunk := f.read(1 << 24):
+                    g.write(c.compress(chunk))
+                g.write(c.flush())
+            else:
+                while True:
+                    chunk = f.read(0xFF00)
+                    c = zlib.compressobj(1, zlib.DEFLATED, -15)
+                    raw = c.compress(chunk) + c.flush()
+                    g.write(b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00" + struct.pack("<H", 12 + 6 + len(raw) + 8 - 1) + raw +
+                            struct.pack("<II", zlib.crc32(chunk) & 0xFFFFFFFF, len(chunk)))
+                    if not chunk:
+                        break
+        fasta.unlink()
+        fasta = gz
+        report["compressed_bytes"] = gz.stat().st_size
+        report["compress_seconds"] = round(time.time() - t0, 3)
+        report["compress"] = a.compress
     dev.close()
     del dev
     torch.cuda.empty_cache()
 
     # sample for the reference
     sample = work / "sample.fa"
-    with open(fasta, "rb") as f, open(sample, "wb") as g:
+    import gzip as _gzip
+    with (_gzip.open(fasta, "rb") if a.compress != "none" else open(fasta, "rb")) as f, open(sample, "wb") as g:
         for _ in range(2 * a.ref_reads):
             g.write(f.readline())
     ref_cli = REPO / "oracle" / "_ref" / "fmsi_ref"
