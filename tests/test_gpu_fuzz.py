@@ -4,12 +4,13 @@ oracle's restatement of `fmsi index`, random query files of every record shape, 
 `-f and|xor|r-s`) under random GPU-side options (batch size, threads, tables, two handles).  stdout must be the reference's, byte for byte;
 every third superstring also goes through `fmsi index` on the device (same files as the restatement's, which the reference's pin) and `fmsi export`.
 tools/fuzz_cli.py runs the same generator for as long as one likes."""
+import os
 import random
 
 import pytest
 
 import oracle_py
-from conftest import messy_fasta, revcomp
+from conftest import bgzf_bytes, messy_fasta, revcomp
 
 pytestmark = pytest.mark.gpu
 
@@ -61,7 +62,19 @@ def one_case(fm, tmp_path, seed: int, checker):
         assert rc == 0 and out.decode() == ">exported masked superstring\n" + ms + "\n", (seed, k, len(ms))
     q = tmp_path / f"fz{seed}.fa"
     src = ms if len(ms) > 800 else ms * (800 // len(ms) + 2)      # (messy_fasta draws reads of up to 700 bases)
-    q.write_bytes(messy_fasta(src, rng, fastq_at=rng.choice([None, None, 150, 0])))
+    data = messy_fasta(src, rng, fastq_at=rng.choice([None, None, 150, 0]))
+    packing = rng.choice(["plain", "plain", "bgzf", "gzip"])
+    if packing == "bgzf":
+        data = bgzf_bytes(data, block=rng.choice([300, 2000, 0xFF00]))
+    elif packing == "gzip":
+        import gzip
+        data = gzip.compress(data)
+    q.write_bytes(data)
+    # odd seeds: also files this small go through the block-parallel readers (mapped plain files, block-gzip members)
+    if seed % 2:
+        os.environ["FMSI_HIP_READER_MIN_BYTES"] = "1"
+    else:
+        os.environ.pop("FMSI_HIP_READER_MIN_BYTES", None)
     modes = [m for m in MODES if use_klcp or "-S" not in m]
     for mode in rng.sample(modes, 3):
         opts = []
@@ -79,7 +92,8 @@ def one_case(fm, tmp_path, seed: int, checker):
             continue
         rc, got, err = fm.run_cli([*mode, *opts, "-q", str(q), prefix])
         assert rc == 0, (seed, mode, opts, err.decode()[-600:])
-        assert got == want, (seed, k, len(ms), mode, opts)
+        assert got == want, (seed, k, len(ms), mode, opts, packing)
+    os.environ.pop("FMSI_HIP_READER_MIN_BYTES", None)
 
 
 @pytest.mark.parametrize("seed", range(40))
