@@ -309,6 +309,46 @@ def test_cli_host_kernels_equal_their_definitions(tmp_path):
     assert res.returncode == 0 and "cli host kernels OK" in res.stdout, (res.stdout + res.stderr)[-3000:]
 
 
+@pytest.mark.parametrize("sanitizer", ["thread", "address,undefined"])
+def test_cli_host_pipeline_under_sanitizers(tmp_path, sanitizer):
+    """The whole host pipeline of `fmsi query` / `lookup` (readers -- ordinary, block-parallel on a mapped file, block-gzip --, packing
+    teams, two workers per handle, in-order hand-over, predictor replay, formatting, sink) with the device stood in for by
+    tests/native/cli_pipeline_stub.cpp, which answers every window from a hash of its k-mer: built with ThreadSanitizer and with
+    ASan + UBSan, no reports; and since such answers depend on the k-mer alone, the output must not depend on how the input is cut
+    into batches, on the team size, on the number of handles or on how the file is packed."""
+    from conftest import bgzf_bytes, messy_fasta
+    src = REPO / "fmsi_amd" / "csrc"
+    exe = tmp_path / "cli_stub"
+    res = subprocess.run(["g++", "-std=c++17", "-O1", "-g", f"-fsanitize={sanitizer}", "-fno-omit-frame-pointer", f"-I{REPO / 'include'}",
+                          str(REPO / "tests" / "native" / "cli_pipeline_stub.cpp"), *(str(src / f) for f in ("query_cli.cpp", "fastx.cpp", "trace.cpp", "host_index.cpp",
+                                                                                                            "layout.cpp", "index_writer.cpp")),
+                          "-o", str(exe), "-lz", "-lpthread", "-ldl"], capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr[-3000:]
+    ms = "".join(l.strip() for l in open(GOLDEN / "ref_data" / "GCF_009858895.2_ASM985889v3_genomic.fna.ms.k13") if not l.startswith(">"))
+    rng = random.Random(3)
+    fasta = b">first\nACGTTGCA\n" + messy_fasta(ms, rng) + messy_fasta(ms, rng)
+    mixed = messy_fasta(ms, rng, fastq_at=150)
+    files = {}
+    for tag, data in (("fa", fasta), ("fq", mixed)):
+        files[tag] = [tmp_path / f"q_{tag}.txt", tmp_path / f"q_{tag}.txt.gz"]
+        files[tag][0].write_bytes(data)
+        files[tag][1].write_bytes(bgzf_bytes(data, block=900))
+    env = {**os.environ, "FMSI_HIP_READER_MIN_BYTES": "1", "TSAN_OPTIONS": "halt_on_error=1", "ASAN_OPTIONS": "detect_leaks=0"}
+    prefix = str(GOLDEN / "idx" / "sars_k13")
+    for mode in (["query"], ["query", "-O"], ["query", "-S", "-O"], ["lookup"], ["lookup", "-S"], ["query", "-f", "xor"]):
+        for tag, paths in files.items():
+            outs = set()
+            for q in paths:
+                for opts in ([], ["--batch", "2048", "--threads", "3", "--devices", "0,0"], ["--batch", "7000", "--threads", "5"]):
+                    res = subprocess.run([str(exe), *mode, *opts, "-q", str(q), prefix], capture_output=True, env=env)
+                    assert res.returncode == 0, (mode, q.name, opts, res.stderr.decode()[-3000:])
+                    outs.add(res.stdout)
+            res = subprocess.run([str(exe), *mode, "-q", str(paths[0]), prefix], capture_output=True, env={**env, "FMSI_HIP_SERIAL_READER": "1"})
+            assert res.returncode == 0
+            outs.add(res.stdout)
+            assert len(outs) == 1 and len(res.stdout) > 10000, (mode, tag)
+
+
 def test_threaded_rrr_decode_under_tsan_and_corrupt_mask(oracle_built, tmp_path):
     """The threaded part of the RRR-63 decoder (>= 64 superblock pairs: the golden indexes are too small to reach it) under
     ThreadSanitizer -- neighbouring threads must not touch each other's boundary word -- and equal to the oracle's mask; a
