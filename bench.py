@@ -197,7 +197,7 @@ def run_e2e(args):
     """--workload e2e: one JSON line for the whole-process rate of the drop-in CLI (default mode), the other modes in `config`."""
     import subprocess
     cmd = [sys.executable, str(REPO / "tools" / "e2e_bench.py"), "--n", str(int(args.n)), "--reads", str(args.reads), "--read-len", str(args.read_len),
-           "--k", str(args.k), "--modes", "or,all,all_S,or_full", "--ref-reads", "20"]
+           "--k", str(args.k), "--modes", "or,all,all_S,xor,or_full", "--ref-reads", "20"]
     res = subprocess.run(cmd, capture_output=True, text=True)
     report = None
     for l in res.stdout.splitlines():
