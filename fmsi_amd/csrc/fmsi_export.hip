@@ -4,11 +4,15 @@
 // (letter = access(row), case = mask bit of the row it lands on).  The walk is a single path through all rows, so it
 // can be cut anywhere: every S-th row starts a chain that walks until it lands on another start row (or on the '$'
 // row, the end of the path).  Chain lengths are geometric with mean S because consecutive text positions sit at
-// unrelated rows.  Pass 1 measures every chain (length, landing row); the host strings the chains together from row 0
-// (one pointer chase per chain) and hands each its offset in the text; pass 2 walks again and writes the letters.
-// 2 N dependent 64-byte block reads spread over about a million lanes instead of N on one core.
+// unrelated rows.  Pass 1 measures every chain (length, landing row); the chains form one linked list from row 0, and
+// their offsets in the text are a list ranking -- pointer jumping on the device, log2(chains) rounds over two small
+// arrays --; pass 2 walks again and writes the letters.  2 N dependent 64-byte block reads spread over millions of lanes
+// instead of N on one core.  With the ranking on the device the chains can be short (mean 256 steps at human scale,
+// 11 million of them): the longest chain, which every pass has to wait for, is about ln(chains) mean lengths.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -54,6 +58,40 @@ __global__ __launch_bounds__(256) void export_measure_kernel(DevIndex ix, uint32
     landing[c] = row;
 }
 
+// ---- list ranking: offset of every chain along the walk ------------------------------------------------------------------
+constexpr uint32_t kListEnd = 0xFFFFFFFFu;
+// nxt[c] = the chain that follows c on the walk (the one starting at c's landing row), dist[c] = len[c]
+__global__ __launch_bounds__(256) void rank_init_kernel(const uint32_t* __restrict__ len, const uint32_t* __restrict__ landing, uint32_t stride, uint32_t dollar,
+                                                        uint64_t n_chains, uint32_t* __restrict__ nxt, uint64_t* __restrict__ dist) {
+    const uint64_t c = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (c >= n_chains) return;
+    const uint32_t row = landing[c];
+    nxt[c] = row == dollar ? kListEnd : row / stride;
+    dist[c] = len[c];
+}
+// one round of pointer jumping: dist[c] becomes the steps from c's start to the start of nxt[c]'s successor, ... after
+// ceil(log2(chains)) rounds to the end of the walk
+__global__ __launch_bounds__(256) void rank_jump_kernel(const uint32_t* __restrict__ nxt_in, const uint64_t* __restrict__ dist_in, uint64_t n_chains,
+                                                        uint32_t* __restrict__ nxt_out, uint64_t* __restrict__ dist_out) {
+    const uint64_t c = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (c >= n_chains) return;
+    const uint32_t n = nxt_in[c];
+    if (n == kListEnd || n >= n_chains) {
+        nxt_out[c] = kListEnd;
+        dist_out[c] = dist_in[c];
+    } else {
+        nxt_out[c] = nxt_in[n];
+        dist_out[c] = dist_in[c] + dist_in[n];
+    }
+}
+// dist[c] = steps from c's start to the end of the walk  ->  last[c] = text position of the chain's first letter
+__global__ __launch_bounds__(256) void rank_last_kernel(const uint64_t* __restrict__ dist, uint64_t n_chains, uint64_t text_len, uint64_t* __restrict__ last) {
+    const uint64_t c = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (c >= n_chains) return;
+    last[c] = dist[c] - 1u;   // offset = text_len - dist[c]; last = text_len - 1 - offset
+    (void)text_len;
+}
+
 // the chain's i-th letter is text position  last[c] - i  (last[c] = N - 1 - offset of the chain along the walk)
 __global__ __launch_bounds__(256) void export_write_kernel(DevIndex ix, uint32_t stride, uint64_t n_chains, const uint32_t* __restrict__ len,
                                                            const uint64_t* __restrict__ last, char* __restrict__ out,
@@ -85,15 +123,17 @@ int export_walk(const fmsi_hip_index* idx, char* d_chars, uint32_t* d_sa) {
     const uint64_t n = idx->n, text_len = n - 1;
     if (text_len == 0) return 0;
     TraceRange trace_range("fmsi: LF walk (export)");
-    // about a million chains, at least 64 rows apart
-    uint64_t stride64 = 64;
-    while ((n + stride64 - 1) / stride64 > (1ull << 20)) stride64 *= 2;
+    // at most 2^24 chains, 16 rows apart or more (human scale: 256 rows, 11 million chains; FMSI_HIP_EXPORT_STRIDE: another distance, for A/B runs)
+    uint64_t stride64 = 16;
+    if (const char* e = std::getenv("FMSI_HIP_EXPORT_STRIDE")) stride64 = std::max<uint64_t>(1, strtoull(e, nullptr, 10));
+    while ((n + stride64 - 1) / stride64 > (1ull << 24)) stride64 *= 2;
     const uint32_t stride = static_cast<uint32_t>(stride64);
     const uint64_t n_chains = (n + stride64 - 1) / stride64;
-    uint32_t *d_len = nullptr, *d_landing = nullptr;
-    uint64_t* d_last = nullptr;
+    uint32_t *d_len = nullptr, *d_landing = nullptr, *d_nxt[2] = {nullptr, nullptr};
+    uint64_t *d_last = nullptr, *d_dist[2] = {nullptr, nullptr};
     auto cleanup = [&]() {
-        for (void* p : {static_cast<void*>(d_len), static_cast<void*>(d_landing), static_cast<void*>(d_last)})
+        for (void* p : {static_cast<void*>(d_len), static_cast<void*>(d_landing), static_cast<void*>(d_last), static_cast<void*>(d_nxt[0]), static_cast<void*>(d_nxt[1]),
+                        static_cast<void*>(d_dist[0]), static_cast<void*>(d_dist[1])})
             if (p) (void)dev_free(p);
     };
     auto fail = [&](int code, const std::string& msg) {
@@ -102,27 +142,25 @@ int export_walk(const fmsi_hip_index* idx, char* d_chars, uint32_t* d_sa) {
         return code;
     };
     if (dev_malloc(reinterpret_cast<void**>(&d_len), n_chains * 4) != hipSuccess || dev_malloc(reinterpret_cast<void**>(&d_landing), n_chains * 4) != hipSuccess ||
-        dev_malloc(reinterpret_cast<void**>(&d_last), n_chains * 8) != hipSuccess)
+        dev_malloc(reinterpret_cast<void**>(&d_last), n_chains * 8) != hipSuccess || dev_malloc(reinterpret_cast<void**>(&d_nxt[0]), n_chains * 4) != hipSuccess ||
+        dev_malloc(reinterpret_cast<void**>(&d_nxt[1]), n_chains * 4) != hipSuccess || dev_malloc(reinterpret_cast<void**>(&d_dist[0]), n_chains * 8) != hipSuccess ||
+        dev_malloc(reinterpret_cast<void**>(&d_dist[1]), n_chains * 8) != hipSuccess)
         return fail(FMSI_HIP_ENOMEM, "hipMalloc failed for the export buffers");
     const dim3 grid(static_cast<uint32_t>((n_chains + 255) / 256)), block(256);
     hipLaunchKernelGGL(export_measure_kernel, grid, block, 0, 0, idx->dev, stride, n_chains, d_len, d_landing);
-    std::vector<uint32_t> len(n_chains), landing(n_chains);
-    if (hipGetLastError() != hipSuccess || hipMemcpy(len.data(), d_len, n_chains * 4, hipMemcpyDeviceToHost) != hipSuccess ||
-        hipMemcpy(landing.data(), d_landing, n_chains * 4, hipMemcpyDeviceToHost) != hipSuccess)
+    // rank the list of chains: distance of every chain's start from the end of the walk
+    hipLaunchKernelGGL(rank_init_kernel, grid, block, 0, 0, d_len, d_landing, stride, idx->dev.dollar, n_chains, d_nxt[0], d_dist[0]);
+    int cur = 0;
+    for (uint64_t reach = 1; reach < n_chains; reach *= 2, cur ^= 1)
+        hipLaunchKernelGGL(rank_jump_kernel, grid, block, 0, 0, d_nxt[cur], d_dist[cur], n_chains, d_nxt[cur ^ 1], d_dist[cur ^ 1]);
+    hipLaunchKernelGGL(rank_last_kernel, grid, block, 0, 0, d_dist[cur], n_chains, text_len, d_last);
+    // the walk from row 0 (chain 0) must be the whole text, every chain on it: then the distances are a permutation-free cover
+    uint64_t head = 0;
+    uint32_t head_next = 0;
+    if (hipGetLastError() != hipSuccess || hipMemcpy(&head, d_dist[cur], 8, hipMemcpyDeviceToHost) != hipSuccess ||
+        hipMemcpy(&head_next, d_nxt[cur], 4, hipMemcpyDeviceToHost) != hipSuccess)
         return fail(FMSI_HIP_EHIP, "export: measuring the chains failed");
-    // string the chains together from row 0: chain c covers walk steps [offset, offset + len[c])
-    std::vector<uint64_t> last(n_chains, 0);
-    uint64_t offset = 0, c = 0, visited = 0;
-    for (;;) {
-        last[c] = text_len - 1 - offset;
-        offset += len[c];
-        ++visited;
-        const uint32_t row = landing[c];
-        if (row == idx->dev.dollar || visited > n_chains) break;
-        c = row / stride;
-    }
-    if (offset != text_len) return fail(FMSI_HIP_EHIP, "export: the LF walk from row 0 does not cover the text (corrupt index?)");
-    if (hipMemcpy(d_last, last.data(), n_chains * 8, hipMemcpyHostToDevice) != hipSuccess) return fail(FMSI_HIP_EHIP, "export: upload failed");
+    if (head != text_len || head_next != kListEnd) return fail(FMSI_HIP_EHIP, "export: the LF walk from row 0 does not cover the text (corrupt index?)");
     if (d_sa && hipMemset(d_sa + idx->dev.dollar, 0, 4) != hipSuccess) return fail(FMSI_HIP_EHIP, "export: memset failed");
     hipLaunchKernelGGL(export_write_kernel, grid, block, 0, 0, idx->dev, stride, n_chains, d_len, d_last, d_chars, d_sa);
     if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess) return fail(FMSI_HIP_EHIP, "export: writing the text failed");
