@@ -281,8 +281,10 @@ int build_from_device_text(DevBuf& text2, uint64_t len, DevBuf* mask_text, int k
                            fmsi_hip_index** out) {
     TraceRange trace_range("fmsi: build index on device");
     const uint64_t n = len + 1;
-    if (len == 0 || n >= (1ull << 32) - kBlockRows) {
-        set_last_error("superstring length must be in [1, 2^32 - 130)");
+    // (2^32 - 130 is where 32-bit rows end; rocPRIM's radix sort stops a few thousand items earlier -- its launch arithmetic is 32-bit --
+    // so the on-device builder does, too.  An index of that size made elsewhere still loads: the loader sorts nothing.)
+    if (len == 0 || len > kMaxSortItems) {
+        set_last_error("superstring length must be in [1, 2^32 - 8192] for the on-device builder");
         return FMSI_HIP_ERANGE;
     }
     const uint64_t n_blocks = ((n + kBlockRows - 1) >> kBlockRowsLog2) + 1;

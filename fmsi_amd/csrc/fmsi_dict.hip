@@ -872,6 +872,10 @@ extern "C" int fmsi_hip_index_enable_dict(fmsi_hip_index* idx, uint32_t flags) {
     }
     FMSI_HIP_ON_DEVICE(idx->device);
     const uint64_t windows = len - static_cast<uint64_t>(k) + 1;
+    if (windows > kMaxSortItems) {
+        set_last_error("the k-mer dictionary is not built for superstrings of more than 2^32 - 8192 k-mers (the sort's limit)");
+        return FMSI_HIP_ERANGE;
+    }
     int rc;
     // 1. the superstring with its mask, from the index itself (the LF walk of `fmsi export`): any handle can add the dictionary
     DevMem text2, maskw;

@@ -172,6 +172,8 @@ void launch_pair_query(fmsi_hip_index* idx, const uint64_t* d_kmers, uint64_t n,
 // k > 32: windows searched straight off the packed sequence (fmsi_longk.hip)
 // `-f and|xor|r-s` (fmsi_fn.hip): fmsi_hip_query_runs_fn leaves the function in the handle and goes through fmsi_hip_query_runs with this
 // private flag, which cuts the runs into window starts and launches the kernel below
+// most items one rocprim::radix_sort call is given here (measured on ROCm 7.2: 2^32 - 135 items fail with "invalid configuration argument", 2^32 - 4099 sort)
+constexpr uint64_t kMaxSortItems = (1ull << 32) - 8192;
 constexpr uint32_t kModeFn = 0x80000000u;
 void launch_fn_query(fmsi_hip_index* idx, const uint64_t* d_seq, const uint64_t* d_window_start, uint64_t n, int k, bool use_table, uint8_t* o8,
                      unsigned long long* d_counters, hipStream_t s);

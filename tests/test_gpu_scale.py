@@ -159,6 +159,23 @@ def test_dictionary_at_human_scale(fm):
     assert 0.3 < (present > 0.5).mean() < 0.7 and ((present > 0.02) & (present < 0.5)).sum() == 0    # reads from the text keep ~73 % of their windows
 
 
+def test_largest_index_with_32_bit_rows(fm):
+    """A superstring of 2^32 - 8192 bases, the largest the on-device builder takes (rocPRIM's sort ends there, 32-bit rows 8 000 rows later): built on
+    the device, then dictionary == lookups + two-base LF walk == lock-step LF walk strand by strand in both modes on 2^20 seeded k-mers,
+    a sample against the oracle on the downloaded index -- rows, counts, suffix positions and dictionary indices all at the edge of
+    what 32 bits hold."""
+    length, k = (1 << 32) - 8192, 31
+    with pytest.raises(fm.FmsiError, match="2\\^32 - 8192"):
+        fm.DeviceIndex.build_synthetic(length + 1, 4242, k)
+    dev = fm.DeviceIndex.build_synthetic(length, 4242, k, prefix_len=14).enable_pair_layout()
+    assert int(dev.info.n) == length + 1 and not int(dev.info.rows64)
+    strict = cross_check(fm, dev, k, nq=1 << 20, sample=20_000, or_reference=False)
+    f, r = strict["all"]
+    assert 0.49 < ((f == 1) | (r == 1)).mean() < 0.51
+    assert int(dev.info.dict_keys[0]) > 4_290_000_000 and int(dev.info.dict_log2_buckets) == 29
+    dev.close()
+
+
 def test_index_equals_the_reference_built_one_at_1e8(fm, tmp_path):
     """The real reference built this index (10^8 rows, mixed mask) in the build container; its files' md5s are committed.  The
     on-device builder + the product's writer reproduce the files byte for byte, and the files -- loaded through
