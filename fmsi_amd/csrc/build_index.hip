@@ -28,6 +28,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/fmsi_hip.h"
@@ -554,6 +555,32 @@ using namespace fmsi;
 
 extern "C" {
 
+namespace {
+// characters [0, count) of a slice that starts at text position `at` (a multiple of 64) -> 2-bit text words and mask words; one thread
+// per 64 positions; *first_bad = the smallest position holding anything but ACGTacgt
+__global__ __launch_bounds__(256) void pack_chars_kernel(const char* __restrict__ chars, uint64_t count, uint64_t at, uint64_t* __restrict__ text2,
+                                                         uint64_t* __restrict__ maskw, unsigned long long* __restrict__ first_bad) {
+    const uint64_t w = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (w * 64u >= count) return;
+    uint64_t t0 = 0, t1 = 0, m = 0;
+    for (uint32_t b = 0; b < 64u; ++b) {
+        const uint64_t p = w * 64u + b;
+        if (p >= count) break;
+        const uint32_t ch = static_cast<uint8_t>(chars[p]);
+        const uint32_t lc = ch | 0x20u;
+        const uint64_t c = lc == 'a' ? 0u : (lc == 'c' ? 1u : (lc == 'g' ? 2u : 3u));
+        if (c == 3u && lc != 't') atomicMin(first_bad, static_cast<unsigned long long>(at + p));
+        if (b < 32u) t0 |= c << (2u * b);
+        else t1 |= c << (2u * (b - 32u));
+        if (ch >= 'A' && ch <= 'Z') m |= 1ull << b;
+    }
+    const uint64_t gw = (at >> 6) + w;
+    text2[2 * gw] = t0;
+    text2[2 * gw + 1] = t1;
+    maskw[gw] = m;
+}
+}  // namespace
+
 int fmsi_hip_index_build(const char* ms, uint64_t len, int k, int with_klcp, int device, int prefix_len, fmsi_hip_index** out) {
     if (!ms || !out || k < 1 || (with_klcp && k > 64)) {
         set_last_error("bad argument (on-device kLCP construction needs k <= 64)");
@@ -562,26 +589,62 @@ int fmsi_hip_index_build(const char* ms, uint64_t len, int k, int with_klcp, int
     int rc = check_device(device);
     if (rc) return rc;
     FMSI_HIP_ON_DEVICE(device);
+    // the characters go up as they are (in slices, so that a superstring of gigabytes needs no second copy of itself on the device) and a
+    // kernel packs them: 2-bit codes (nucleotideToInt, src/kmers.h:3-20), mask bit = upper case (is_upper, :71-73), and the position of
+    // the first character that is not ACGTacgt, if there is one
     const uint64_t n_words = (len >> 5) + 2, m_words = (len >> 6) + 2;
-    std::vector<uint64_t> h_text(n_words, 0), h_mask(m_words, 0);
-    for (uint64_t p = 0; p < len; ++p) {
-        unsigned c;
-        switch (ms[p]) {   // nucleotideToInt, src/kmers.h:3-20
-        case 'A': case 'a': c = 0; break;
-        case 'C': case 'c': c = 1; break;
-        case 'G': case 'g': c = 2; break;
-        case 'T': case 't': c = 3; break;
-        default:
-            set_last_error("masked superstring contains a non-ACGT character at " + std::to_string(p));
-            return FMSI_HIP_EINVAL;
+    DevBuf text2, mask_text, bad;
+    // (through two page-locked staging buffers filled by a few host threads: the caller's memory may be anything -- the CLI hands over
+    // a mapping of the file, which the driver copies from at a fraction of the link's rate)
+    const uint64_t slice = std::min<uint64_t>((len + 63) / 64 * 64, 1ull << 26);   // a multiple of 64
+    if ((rc = text2.alloc(n_words * 8)) || (rc = mask_text.alloc(m_words * 8)) || (rc = bad.alloc(8))) return rc;
+    FMSI_HIP_TRY(hipMemset(text2.p, 0, n_words * 8));
+    FMSI_HIP_TRY(hipMemset(mask_text.p, 0, m_words * 8));
+    FMSI_HIP_TRY(hipMemset(bad.p, 0xFF, 8));
+    struct Stage {
+        void* host = nullptr;
+        DevBuf dev;
+        hipEvent_t done = nullptr;
+        ~Stage() {
+            if (done) (void)hipEventDestroy(done);
+            if (host) (void)hipHostFree(host);
         }
-        h_text[p >> 5] |= static_cast<uint64_t>(c) << (2 * (p & 31));
-        if (ms[p] >= 'A' && ms[p] <= 'Z') h_mask[p >> 6] |= 1ull << (p & 63);   // is_upper, src/kmers.h:71-73
+    } stage[2];
+    for (Stage& st : stage) {
+        if (hipHostMalloc(&st.host, slice, hipHostMallocDefault) != hipSuccess) st.host = nullptr;   // (then straight from the caller's memory)
+        if ((rc = st.dev.alloc(slice + 64))) return rc;
+        FMSI_HIP_TRY(hipEventCreateWithFlags(&st.done, hipEventDisableTiming));
     }
-    DevBuf text2, mask_text;
-    if ((rc = text2.alloc(n_words * 8)) || (rc = mask_text.alloc(m_words * 8))) return rc;
-    FMSI_HIP_TRY(hipMemcpy(text2.p, h_text.data(), n_words * 8, hipMemcpyHostToDevice));
-    FMSI_HIP_TRY(hipMemcpy(mask_text.p, h_mask.data(), m_words * 8, hipMemcpyHostToDevice));
+    const unsigned copiers = std::max(1u, std::min(8u, std::thread::hardware_concurrency()));
+    unsigned turn = 0;
+    for (uint64_t at = 0; at < len; at += slice, turn ^= 1u) {
+        Stage& st = stage[turn];
+        const uint64_t count = std::min(slice, len - at);
+        FMSI_HIP_TRY(hipEventSynchronize(st.done));   // the kernel that read this buffer two slices ago
+        const char* src = ms + at;
+        if (st.host) {
+            std::vector<std::thread> pool;
+            for (unsigned t = 0; t < copiers; ++t) {
+                const uint64_t lo = count / copiers * t, hi = t + 1 == copiers ? count : count / copiers * (t + 1);
+                pool.emplace_back([&, lo, hi] { std::memcpy(static_cast<char*>(st.host) + lo, ms + at + lo, hi - lo); });
+            }
+            for (std::thread& th : pool) th.join();
+            src = static_cast<const char*>(st.host);
+        }
+        FMSI_HIP_TRY(hipMemcpyAsync(st.dev.p, src, count, hipMemcpyHostToDevice, 0));
+        hipLaunchKernelGGL(pack_chars_kernel, dim3(grid_for((count + 63) / 64)), dim3(256), 0, 0, st.dev.as<char>(), count, at, text2.as<uint64_t>(),
+                           mask_text.as<uint64_t>(), bad.as<unsigned long long>());
+        FMSI_HIP_TRY(hipGetLastError());
+        FMSI_HIP_TRY(hipEventRecord(st.done, 0));
+        if (!st.host) FMSI_HIP_TRY(hipDeviceSynchronize());   // (pageable source: the copy must have read it before the caller goes on)
+    }
+    FMSI_HIP_TRY(hipDeviceSynchronize());
+    unsigned long long first_bad = ~0ull;
+    FMSI_HIP_TRY(hipMemcpy(&first_bad, bad.p, 8, hipMemcpyDeviceToHost));
+    if (first_bad != ~0ull) {
+        set_last_error("masked superstring contains a non-ACGT character at " + std::to_string(first_bad));
+        return FMSI_HIP_EINVAL;
+    }
     return build_from_device_text(text2, len, &mask_text, k, with_klcp, device, prefix_len, out);
 }
 

@@ -3,7 +3,15 @@
 // src/parser.h:31-55), the suffix sort / BWT / SA-transformed mask / kLCP are computed on the device
 // (build_index.hip) and the six files are written in the reference's format (index_writer.cpp): byte-identical
 // to `fmsi index` of the reference (tests/test_gpu_index_cli.py).
+#include <fcntl.h>
 #include <getopt.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 
 #include <cstdlib>
 #include <iostream>
@@ -60,19 +68,78 @@ int run_index(int argc, char** argv) {
         return usage_index();
     }
     std::cerr << "Starting " << fn << std::endl;
-    std::string ms;
+    const bool verbose = std::getenv("FMSI_HIP_VERBOSE") != nullptr;   // phase times on stderr
+    auto t_phase = std::chrono::steady_clock::now();
+    auto phase = [&](const char* what) {
+        const auto now = std::chrono::steady_clock::now();
+        if (verbose) fprintf(stderr, "[fmsi index] %-28s %8.3f s\n", what, std::chrono::duration<double>(now - t_phase).count());
+        t_phase = now;
+    };
+    // The first record's sequence is the masked superstring (read_masked_superstring, src/parser.h:41-55).  A plain file is mapped and
+    // parsed in place -- a sequence on one line, the usual shape, is then a view of the file and never copied on the host --; a gzip
+    // stream (or a file that cannot be mapped) goes through the ordinary reader.
+    std::string ms_owned;
+    const char* ms_data = nullptr;
+    size_t ms_len = 0;
+    bool more = false;
+    struct Mapping {
+        const unsigned char* data = nullptr;
+        size_t size = 0;
+        ~Mapping() {
+            if (data) munmap(const_cast<unsigned char*>(data), size);
+        }
+    } map;
+    fmsi::FastxViewParser::Arena arena;
     {
+        const int fd = open(fn.c_str(), O_RDONLY);
+        struct stat st;
+        if (fd >= 0 && fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && st.st_size >= 2) {
+            void* p = mmap(nullptr, static_cast<size_t>(st.st_size), PROT_READ, MAP_PRIVATE, fd, 0);
+            if (p != MAP_FAILED) {
+                map.data = static_cast<const unsigned char*>(p);
+                map.size = static_cast<size_t>(st.st_size);
+                if (map.data[0] == 0x1f && map.data[1] == 0x8b) {   // gzip
+                    munmap(p, map.size);
+                    map.data = nullptr;
+                }
+            }
+        }
+        if (fd >= 0) close(fd);
+    }
+    if (map.data) {
+        fmsi::FastxViewParser parser(map.data, map.size);
+        const char *name, *seq;
+        size_t name_len;
+        if (!parser.next(arena, &name, &name_len, &seq, &ms_len))
+            throw std::invalid_argument("Error reading the fasta file. The fasta file should contain a single entry - the masked superstring.");
+        ms_data = seq;
+        const char* seq2;
+        size_t len2;
+        more = parser.next(arena, &name, &name_len, &seq2, &len2);
+    } else {
         fmsi::FastxReader reader(fn);   // throws std::invalid_argument like OpenFile(), src/parser.h:22
         if (!reader.next()) throw std::invalid_argument("Error reading the fasta file. The fasta file should contain a single entry - the masked superstring.");
-        ms.swap(reader.seq);
-        if (reader.next()) std::cerr << "Warning: The fasta file contains more than one entry. Only the first entry will be used." << std::endl;
+        ms_owned.swap(reader.seq);
+        ms_data = ms_owned.data();
+        ms_len = ms_owned.size();
+        more = reader.next();
     }
+    if (more) std::cerr << "Warning: The fasta file contains more than one entry. Only the first entry will be used." << std::endl;
+    struct MsView {   // (what the code below knows as `ms`)
+        const char* d;
+        size_t n;
+        bool empty() const { return n == 0; }
+        size_t size() const { return n; }
+        const char* data() const { return d; }
+        char operator[](size_t i) const { return d[i]; }
+    } ms{ms_data, ms_len};
     if (ms.empty()) {
         std::cerr << "ERROR: The file '" << fn
                   << "' is in incorrect format. It is supposed to be a fasta file with a single entry, the masked superstring" << std::endl;
         return usage_index();
     }
     std::cerr << "Read masked superstring of length " << ms.size() << std::endl;
+    phase("superstring read");
     int inferred_k = 1;                                       // infer_k, src/parser.h:31-37
     while (static_cast<size_t>(inferred_k) <= ms.size() && !is_upper(ms[ms.size() - inferred_k])) inferred_k++;
     if (k == 0) {
@@ -94,6 +161,7 @@ int run_index(int argc, char** argv) {
         return 1;
     }
     std::cerr << "Constructed index" << std::endl;
+    phase("index built on the device");
     const int rc = fmsi_hip_index_write_files(dev, fn.c_str());
     fmsi_hip_index_destroy(dev);
     if (rc != 0) {
@@ -101,6 +169,7 @@ int run_index(int argc, char** argv) {
         return 1;
     }
     std::cerr << "Written index" << std::endl;
+    phase("files written");
     return 0;
 }
 }  // namespace

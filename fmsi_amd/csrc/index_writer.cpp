@@ -8,6 +8,8 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
+#include <thread>
+#include <vector>
 
 #include "common.h"
 
@@ -96,55 +98,101 @@ struct Out {
 
 // rrr_vector<63> image of `bits` (n bits), written to `o` -- the constructor of sdsl/rrr_vector.hpp:145-238 followed
 // by serialize() (:350-362)
+// Threads: the encoder's loops go superblock by superblock, and everything a superblock writes -- 32 class fields of 6 bits (3 words), one
+// sample each of the offset pointers and of the ranks, one inversion bit, its blocks' offsets -- sits in words of its own once the
+// superblocks are taken 64 at a time (64 samples of w bits are w words), except the offsets, whose bit positions run through: those go in
+// with atomic ORs.  What a range of superblocks needs from the ones before it (offset bits and ones so far) comes from a first pass that
+// also yields the classes; the widths do not depend on the inversion (space[x] == space[63 - x]).
+inline void put_bits_shared(uint64_t* w, uint64_t pos, uint64_t x, unsigned len) {
+    if (!len) return;
+    x &= low_mask(len);
+    const unsigned off = pos & 63;
+    __atomic_fetch_or(w + (pos >> 6), x << off, __ATOMIC_RELAXED);
+    if (off + len > 64) __atomic_fetch_or(w + (pos >> 6) + 1, x >> (64 - off), __ATOMIC_RELAXED);
+}
+
+template <class F>
+void in_ranges(uint64_t items, uint64_t grain, F&& fn) {   // fn(lo, hi) over [0, items) cut at multiples of `grain`, on up to 16 threads
+    const uint64_t chunks = (items + grain - 1) / grain;
+    const unsigned threads = static_cast<unsigned>(std::max<uint64_t>(1, std::min<uint64_t>({16, std::thread::hardware_concurrency(), chunks / 4 + 1})));
+    if (threads <= 1) {
+        fn(uint64_t(0), items);
+        return;
+    }
+    std::vector<std::thread> pool;
+    for (unsigned t = 0; t < threads; ++t) {
+        const uint64_t lo = std::min(items, chunks * t / threads * grain), hi = t + 1 == threads ? items : std::min(items, chunks * (t + 1) / threads * grain);
+        if (hi > lo) pool.emplace_back([&fn, lo, hi] { fn(lo, hi); });
+    }
+    for (std::thread& th : pool) th.join();
+}
+
 static void write_rrr63(Out& o, const uint64_t* bits, uint64_t n) {
     const Binom& B = binom();
     const uint64_t n_bt = (n + kBs) / kBs;                      // incl. the dummy block when n % 63 == 0
     const uint64_t n_super = (n_bt + kK - 1) / kK;
     std::vector<uint8_t> bt(n_bt, 0);
-    uint64_t sum_rank = 0, btnr_bits = 0;
-    for (uint64_t b = 0; b * kBs < n; ++b) {
-        const uint64_t pos = b * kBs;
-        const unsigned len = static_cast<unsigned>(std::min<uint64_t>(kBs, n - pos));
-        const unsigned x = static_cast<unsigned>(__builtin_popcountll(get_bits(bits, pos, len)));
-        bt[b] = static_cast<uint8_t>(x);
-        sum_rank += x;
-        btnr_bits += B.space[x];                                // space is symmetric in x <-> 63 - x
+    // pass 1: classes; per superblock its ones and its offset bits
+    std::vector<uint32_t> sb_ones(n_super + 1, 0), sb_bits(n_super + 1, 0);
+    in_ranges(n_super, 64, [&](uint64_t s0, uint64_t s1) {
+        for (uint64_t s = s0; s < s1; ++s) {
+            uint32_t ones = 0, width = 0;
+            for (uint64_t b = s * kK; b < std::min<uint64_t>((s + 1) * kK, n_bt) && b * kBs < n; ++b) {
+                const uint64_t pos = b * kBs;
+                const unsigned len = static_cast<unsigned>(std::min<uint64_t>(kBs, n - pos));
+                const unsigned x = static_cast<unsigned>(__builtin_popcountll(get_bits(bits, pos, len)));
+                bt[b] = static_cast<uint8_t>(x);
+                ones += x;
+                width += B.space[x];                            // space is symmetric in x <-> 63 - x
+            }
+            sb_ones[s] = ones;
+            sb_bits[s] = width;
+        }
+    });
+    std::vector<uint64_t> ones_before(n_super + 1, 0), bits_before(n_super + 1, 0);
+    for (uint64_t s = 0; s < n_super; ++s) {
+        ones_before[s + 1] = ones_before[s] + sb_ones[s];
+        bits_before[s + 1] = bits_before[s] + sb_bits[s];
     }
+    const uint64_t sum_rank = ones_before[n_super], btnr_bits = bits_before[n_super];
     const uint64_t btnr_size = std::max<uint64_t>(btnr_bits, 64);
     std::vector<uint64_t> btnr((btnr_size + 63) / 64 + 1, 0);
     const uint8_t btnrp_w = static_cast<uint8_t>(hi_bit(btnr_bits) + 1), rank_w = static_cast<uint8_t>(hi_bit(sum_rank) + 1);
     const uint64_t n_rank = n_super + ((n % (kK * kBs)) > 0 ? 1 : 0);
     std::vector<uint64_t> btnrp((n_super * btnrp_w + 63) / 64 + 1, 0), rank((n_rank * rank_w + 63) / 64 + 1, 0);
     std::vector<uint64_t> invert((n_super + 63) / 64 + 1, 0), bt_packed((n_bt * 6 + 63) / 64 + 1, 0);
-    uint64_t pos_bits = 0, ones = 0;
-    for (uint64_t s = 0; s < n_super; ++s) {
-        const uint64_t b0 = s * kK, b1 = std::min<uint64_t>(b0 + kK, n_bt);
-        if (b0 * kBs < n) {   // a superblock that consists of the dummy block alone gets no samples (rrr_vector.hpp:180-233)
-            put_bits(btnrp, s * btnrp_w, pos_bits, btnrp_w);
-            put_bits(rank, s * rank_w, ones, rank_w);
-        }
-        bool inv = false;
-        if (b0 + kK <= n_bt) {                                  // only complete superblocks may be inverted (:186-199)
-            unsigned heavy = 0;
-            for (uint64_t b = b0; b < b1; ++b) heavy += bt[b] > kBs / 2;
-            inv = heavy > kK / 2;
-        }
-        if (inv) invert[s >> 6] |= 1ull << (s & 63);
-        for (uint64_t b = b0; b < b1; ++b) {
-            const unsigned x = bt[b];                           // true popcount
-            const unsigned stored = inv ? kBs - x : x;
-            put_bits(bt_packed, b * 6, stored, 6);
-            const uint64_t first = b * kBs;
-            if (first >= n) continue;                           // dummy block: class 0, no offset
-            ones += x;
-            const unsigned width = B.space[stored];
-            if (width) {
-                const unsigned len = static_cast<unsigned>(std::min<uint64_t>(kBs, n - first));
-                put_bits(btnr, pos_bits, bin_to_nr(get_bits(bits, first, len), B), width);
+    // pass 2: samples, inversion, class fields, offsets
+    in_ranges(n_super, 64, [&](uint64_t s0, uint64_t s1) {
+        for (uint64_t s = s0; s < s1; ++s) {
+            uint64_t pos_bits = bits_before[s];
+            const uint64_t b0 = s * kK, b1 = std::min<uint64_t>(b0 + kK, n_bt);
+            if (b0 * kBs < n) {   // a superblock that consists of the dummy block alone gets no samples (rrr_vector.hpp:180-233)
+                put_bits(btnrp, s * btnrp_w, pos_bits, btnrp_w);
+                put_bits(rank, s * rank_w, ones_before[s], rank_w);
             }
-            pos_bits += width;
+            bool inv = false;
+            if (b0 + kK <= n_bt) {                                  // only complete superblocks may be inverted (:186-199)
+                unsigned heavy = 0;
+                for (uint64_t b = b0; b < b1; ++b) heavy += bt[b] > kBs / 2;
+                inv = heavy > kK / 2;
+            }
+            if (inv) invert[s >> 6] |= 1ull << (s & 63);
+            for (uint64_t b = b0; b < b1; ++b) {
+                const unsigned x = bt[b];                           // true popcount
+                const unsigned stored = inv ? kBs - x : x;
+                put_bits(bt_packed, b * 6, stored, 6);
+                const uint64_t first = b * kBs;
+                if (first >= n) continue;                           // dummy block: class 0, no offset
+                const unsigned width = B.space[stored];
+                if (width) {
+                    const unsigned len = static_cast<unsigned>(std::min<uint64_t>(kBs, n - first));
+                    put_bits_shared(btnr.data(), pos_bits, bin_to_nr(get_bits(bits, first, len), B), width);
+                }
+                pos_bits += width;
+            }
         }
-    }
+    });
+    const uint64_t ones = sum_rank;
     put_bits(rank, (n_rank - 1) * rank_w, ones, rank_w);        // last element = total number of ones (:236)
     o.u64(n);
     o.int_vector(bt_packed, n_bt * 6, 6);
