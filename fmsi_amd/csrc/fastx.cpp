@@ -92,7 +92,7 @@ bool BgzfFile::member(size_t at, Member* m) const {
     m->crc = t[0] | (static_cast<uint32_t>(t[1]) << 8) | (static_cast<uint32_t>(t[2]) << 16) | (static_cast<uint32_t>(t[3]) << 24);
     m->isize = t[4] | (static_cast<uint32_t>(t[5]) << 8) | (static_cast<uint32_t>(t[6]) << 16) | (static_cast<uint32_t>(t[7]) << 24);
     m->next = at + bsize;
-    return true;
+    return m->isize <= 65536;   // (a BGZF member holds at most 64 KiB; anything else is left to zlib)
 }
 
 bool BgzfFile::inflate(const Member& m, char* dst) const {
