@@ -888,6 +888,40 @@ def test_block_gzip_reader(fm, oracle_built, tmp_path, monkeypatch, shape):
         assert got.count(b"\n") >= 12
 
 
+DEGENERATE_INPUTS = {
+    "empty": b"", "newline": b"\n", "gt_only": b">", "name_only": b">name", "name_nl": b">name\n", "junk": b"hello world\nno header here\n",
+    "junk_then_rec": b"garbage\n>r\nACGTACGTACGTACGTACGT\n", "nul_bytes": b">r\nACGT\x00ACGTACGTACGTACGTAC\n", "only_at": b"@",
+    "fastq_no_qual": b"@r\nACGTACGTACGTACGTACGT\n+\n", "cr_only": b">r\rACGTACGTACGTACGTACGT\r", "tabs": b">r\tc\nACGTACGTACGTACGTACGT\n",
+    "long_name": b">" + b"n" * 100000 + b"\nACGTACGTACGTACGTACGT\n", "high_bytes": b">r\n\xff\xfeACGTACGTACGTACGTACGT\n",
+    "two_gt": b">>r\nACGTACGTACGTACGTACGT\n", "space_name": b"> r\nACGTACGTACGTACGTACGT\n",
+}
+
+
+@pytest.mark.parametrize("case", list(DEGENERATE_INPUTS))
+def test_degenerate_query_files(fm, oracle_built, tmp_path, monkeypatch, case):
+    """Query files that are hardly files: empty, a lone '>', a header without a sequence, no header at all, NUL and high bytes, CR line
+    ends only, a FASTQ record without its quality, a 100-kB name -- plain and block-gzip, through the ordinary and the block-parallel
+    readers, and over stdin: exit status and bytes of the real reference."""
+    import subprocess
+    prefix = index_prefix("sars_k13")
+    checker = oracle_py.REF_CLI if oracle_py.ref_available() else oracle_py.ORACLE_CLI
+    data = DEGENERATE_INPUTS[case]
+    for pack in ("plain", "bgzf"):
+        q = tmp_path / f"q_{pack}"
+        q.write_bytes(data if pack == "plain" else bgzf_bytes(data))
+        for mode in (["query", "-O"], ["lookup", "-S"]):
+            rc0, ref, _ = oracle_py.run_cli(checker, [*mode, "-q", str(q), prefix])
+            for min_bytes in (None, "1"):
+                if min_bytes:
+                    monkeypatch.setenv("FMSI_HIP_READER_MIN_BYTES", min_bytes)
+                rc, got, err = fm.run_cli([*mode, "-q", str(q), prefix])
+                monkeypatch.delenv("FMSI_HIP_READER_MIN_BYTES", raising=False)
+                assert rc == rc0 and got == ref, (pack, mode, min_bytes, err.decode()[-300:])
+    ref = subprocess.run([str(checker), "query", prefix], input=data, capture_output=True)
+    got = subprocess.run([str(fm.CLI_PATH), "query", prefix], input=data, capture_output=True)
+    assert got.returncode == ref.returncode and got.stdout == ref.stdout
+
+
 def test_cli_exits_when_stdout_fails(fm, tmp_path):
     """A writer that fails (ENOSPC: stdout = /dev/full) must end the process with exit status 1 -- not leave the reader thread
     blocked on a full queue and the CLI hanging in join().  Many small batches, so that input is still pending when it happens."""
