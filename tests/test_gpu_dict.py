@@ -250,3 +250,34 @@ def test_dictionary_on_degenerate_texts(fm, oracle_built, shape):
     gf, gr = fm.decode_strict(dev.query_runs(fm.pack_sequence(seq.encode()), len(seq), np.arange(len(reads), dtype=np.uint64) * np.uint64(L),
                                              np.full(len(reads), w, dtype=np.uint32), k, fm.MODE_ALL | fm.STRICT))
     assert np.array_equal(gf, fwd) and np.array_equal(gr, rc)
+
+
+def test_handle_lifecycle_returns_its_memory(fm, tmp_path):
+    """Handles created, given every accelerator, queried and destroyed over and over: after the library's block cache is trimmed the device
+    has its memory back (nothing a handle allocated outlives it), and a destroyed handle's staging buffers do not pile up."""
+    import torch
+    ms = synthetic_text_for_lifecycle()
+    free0 = None
+    for cycle in range(7):
+        if cycle == 1:      # (the first cycle also pays for what the runtime and rocPRIM keep for themselves)
+            fm.trim_scratch(0)
+            torch.cuda.synchronize()
+            free0 = torch.cuda.mem_get_info()[0]
+        dev = fm.DeviceIndex.build(ms.encode(), 21, with_klcp=True, prefix_len=8).enable_pair_layout()
+        dev.enable_verify()
+        dev.enable_dict(chain=bool(cycle % 2))
+        kmers = [ms[i:i + 21].upper() for i in range(0, 4000, 7)]
+        a = dev.query_kmers(fm.pack_kmers(kmers, 21), 21, fm.MODE_ALL | fm.STRICT)
+        b = dev.query_kmers(fm.pack_kmers(kmers, 21), 21, fm.MODE_ALL | fm.STRICT | fm.KERNEL_LOCKSTEP | fm.NO_PREFIX_TABLE)
+        assert np.array_equal(a, b)
+        dev.close()
+    fm.trim_scratch(0)
+    torch.cuda.synchronize()
+    free1 = torch.cuda.mem_get_info()[0]
+    assert free0 - free1 < (64 << 20), (free0, free1)
+
+
+def synthetic_text_for_lifecycle():
+    rng = random.Random(12)
+    s = "".join(rng.choice("ACGT") for _ in range(3_000_000))
+    return s[:-20] + s[-20:].lower()
