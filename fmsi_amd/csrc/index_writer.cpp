@@ -204,22 +204,36 @@ static void write_rrr63(Out& o, const uint64_t* bits, uint64_t n) {
 
 int write_index_files(const std::string& prefix, const fmsi_index_view& v, std::string& err) {
     const std::string base = prefix + ".fmsi";
-    auto bv = [&](const char* ext, const uint64_t* words, uint64_t bits) {
+    // the plain bit-vectors go out side by side while the mask is encoded (each file has its own thread; the encoder has its own)
+    std::string errs[4];
+    bool oks[4] = {true, true, true, true};
+    auto bv_into = [&](int slot, const char* ext, const uint64_t* words, uint64_t bits) {
         Out o(base + "." + ext);
         o.bit_vector(words, bits);
-        if (!o.ok) err = "cannot write " + base + "." + ext;
-        return o.ok;
+        if (!o.ok) errs[slot] = "cannot write " + base + "." + ext;
+        oks[slot] = o.ok;
     };
-    if (!bv("ac_gt", v.ac_gt, v.ac_gt_bits) || !bv("ac", v.ac, v.ac_bits) || !bv("gt", v.gt, v.gt_bits)) return FMSI_HIP_EIO;
+    std::vector<std::thread> writers;
+    writers.emplace_back(bv_into, 0, "ac_gt", v.ac_gt, v.ac_gt_bits);
+    writers.emplace_back(bv_into, 1, "ac", v.ac, v.ac_bits);
+    writers.emplace_back(bv_into, 2, "gt", v.gt, v.gt_bits);
+    if (v.klcp && v.klcp_bits) writers.emplace_back(bv_into, 3, "klcp", v.klcp, v.klcp_bits);   // fms_index.h:490-492
+    bool mask_ok;
     {
         Out o(base + ".mask");
         write_rrr63(o, v.mask, v.mask_bits);
-        if (!o.ok) {
-            err = "cannot write " + base + ".mask";
+        mask_ok = o.ok;
+    }
+    for (std::thread& t : writers) t.join();
+    for (int i = 0; i < 4; ++i)
+        if (!oks[i]) {
+            err = errs[i];
             return FMSI_HIP_EIO;
         }
+    if (!mask_ok) {
+        err = "cannot write " + base + ".mask";
+        return FMSI_HIP_EIO;
     }
-    if (v.klcp && v.klcp_bits && !bv("klcp", v.klcp, v.klcp_bits)) return FMSI_HIP_EIO;   // fms_index.h:490-492
     FILE* f = std::fopen((base + ".misc").c_str(), "w");
     if (!f) {
         err = "cannot write " + base + ".misc";
@@ -253,31 +267,46 @@ void vectors_from_blocks(const uint32_t* blocks, uint64_t n, HostVectors& out) {
     out.ac_gt.assign(words + 2, 0);
     out.mask.assign(words + 2, 0);
     std::vector<uint64_t> lo(words + 2, 0);
-    uint64_t gt_bits = 0;
-    for (uint64_t w = 0; w < words; ++w) {
-        const uint32_t* blk = blocks + (w >> 1) * kBlockDwords;
-        const unsigned half = static_cast<unsigned>(w & 1) * 2;
-        const uint64_t valid = (w == words - 1 && (n & 63)) ? low_mask(static_cast<unsigned>(n & 63)) : ~0ull;
-        out.ac_gt[w] = ((static_cast<uint64_t>(blk[5 + half]) << 32) | blk[4 + half]) & valid;
-        lo[w] = ((static_cast<uint64_t>(blk[9 + half]) << 32) | blk[8 + half]) & valid;
-        out.mask[w] = ((static_cast<uint64_t>(blk[13 + half]) << 32) | blk[12 + half]) & valid;
-        gt_bits += static_cast<uint64_t>(__builtin_popcountll(out.ac_gt[w]));
-    }
+    // ranges of 4096 words on threads: the planes of a word come out of its block; how many G/T (A/C) bits lie before a range is a
+    // prefix sum over the ranges, and the compacted bits go in with atomic ORs (neighbouring ranges share a word of `ac` / `gt`)
+    constexpr uint64_t kGrain = 4096;
+    const uint64_t chunks = (words + kGrain - 1) / kGrain;
+    std::vector<uint64_t> chunk_gt(chunks + 1, 0);
+    in_ranges(words, kGrain, [&](uint64_t w0, uint64_t w1) {
+        for (uint64_t c = w0 / kGrain; c * kGrain < w1; ++c) {
+            uint64_t gt = 0;
+            for (uint64_t w = c * kGrain; w < std::min(w1, (c + 1) * kGrain); ++w) {
+                const uint32_t* blk = blocks + (w >> 1) * kBlockDwords;
+                const unsigned half = static_cast<unsigned>(w & 1) * 2;
+                const uint64_t valid = (w == words - 1 && (n & 63)) ? low_mask(static_cast<unsigned>(n & 63)) : ~0ull;
+                out.ac_gt[w] = ((static_cast<uint64_t>(blk[5 + half]) << 32) | blk[4 + half]) & valid;
+                lo[w] = ((static_cast<uint64_t>(blk[9 + half]) << 32) | blk[8 + half]) & valid;
+                out.mask[w] = ((static_cast<uint64_t>(blk[13 + half]) << 32) | blk[12 + half]) & valid;
+                gt += static_cast<uint64_t>(__builtin_popcountll(out.ac_gt[w]));
+            }
+            chunk_gt[c + 1] = gt;
+        }
+    });
+    for (uint64_t c = 0; c < chunks; ++c) chunk_gt[c + 1] += chunk_gt[c];
+    const uint64_t gt_bits = chunk_gt[chunks];
     out.gt_bits = gt_bits;
     out.ac_bits = n - gt_bits;
     out.ac.assign((out.ac_bits + 63) / 64 + 2, 0);
     out.gt.assign((out.gt_bits + 63) / 64 + 2, 0);
     const bool hw = __builtin_cpu_supports("bmi2");
-    uint64_t ap = 0, gp = 0;
-    for (uint64_t w = 0; w < words; ++w) {
-        const uint64_t valid = (w == words - 1 && (n & 63)) ? low_mask(static_cast<unsigned>(n & 63)) : ~0ull;
-        const uint64_t g = out.ac_gt[w], ng = ~g & valid;
-        const unsigned cg = static_cast<unsigned>(__builtin_popcountll(g)), ca = static_cast<unsigned>(__builtin_popcountll(ng));
-        put_bits(out.gt, gp, hw ? extract_hw(lo[w], g) : extract_sw(lo[w], g), cg);
-        put_bits(out.ac, ap, hw ? extract_hw(lo[w], ng) : extract_sw(lo[w], ng), ca);
-        gp += cg;
-        ap += ca;
-    }
+    in_ranges(words, kGrain, [&](uint64_t w0, uint64_t w1) {
+        uint64_t gp = chunk_gt[w0 / kGrain];
+        uint64_t ap = std::min(w0 * 64, n) - gp;   // valid rows before the range that are not G/T
+        for (uint64_t w = w0; w < w1; ++w) {
+            const uint64_t valid = (w == words - 1 && (n & 63)) ? low_mask(static_cast<unsigned>(n & 63)) : ~0ull;
+            const uint64_t g = out.ac_gt[w], ng = ~g & valid;
+            const unsigned cg = static_cast<unsigned>(__builtin_popcountll(g)), ca = static_cast<unsigned>(__builtin_popcountll(ng));
+            put_bits_shared(out.gt.data(), gp, hw ? extract_hw(lo[w], g) : extract_sw(lo[w], g), cg);
+            put_bits_shared(out.ac.data(), ap, hw ? extract_hw(lo[w], ng) : extract_sw(lo[w], ng), ca);
+            gp += cg;
+            ap += ca;
+        }
+    });
 }
 
 }  // namespace fmsi

@@ -14,6 +14,8 @@
 
 #include "../../include/fmsi_hip.h"
 #include "../../fmsi_amd/csrc/fastx.h"
+#include "../../fmsi_amd/csrc/index_writer.h"
+#include "../../fmsi_amd/csrc/layout.h"
 
 namespace fmsi { const char* last_error(); }
 // (fmsi_hip_last_error lives in the HIP translation unit of the library; the host-only build supplies it)
@@ -31,6 +33,29 @@ int main(int argc, char** argv) {
     if (fmsi_host_index_write(argv[3], &v) != 0) {
         std::cerr << "write failed: " << fmsi_hip_last_error() << "\n";
         return 1;
+    }
+    // the device layout of the same vectors (layout.cpp: what the host path uploads) and back again (vectors_from_blocks: what the
+    // writer makes of a downloaded handle, on threads): the same bits
+    {
+        fmsi::HostLayout L;
+        if (fmsi::build_layout(v, L) != 0) {
+            std::cerr << "layout failed: " << fmsi_hip_last_error() << "\n";
+            return 1;
+        }
+        fmsi::HostVectors hv;
+        fmsi::vectors_from_blocks(L.blocks.data(), v.ac_gt_bits, hv);
+        auto same = [](const uint64_t* a, const std::vector<uint64_t>& b, uint64_t bits) {
+            for (uint64_t w = 0; w < (bits + 63) / 64; ++w) {
+                const uint64_t m = (w == bits / 64 && (bits & 63)) ? ((1ull << (bits & 63)) - 1) : ~0ull;
+                if ((a[w] & m) != (b[w] & m)) return false;
+            }
+            return true;
+        };
+        if (hv.n != v.ac_gt_bits || hv.ac_bits != v.ac_bits || hv.gt_bits != v.gt_bits || !same(v.ac_gt, hv.ac_gt, v.ac_gt_bits) || !same(v.ac, hv.ac, v.ac_bits) ||
+            !same(v.gt, hv.gt, v.gt_bits) || !same(v.mask, hv.mask, v.mask_bits)) {
+            std::cerr << "layout -> vectors round trip differs\n";
+            return 1;
+        }
     }
     fmsi_host_index_free(h);
     // a missing index is an error, not a crash

@@ -357,7 +357,7 @@ def test_threaded_rrr_decode_under_tsan_and_corrupt_mask(oracle_built, tmp_path)
     from pathlib import Path
 
     src = REPO / "fmsi_amd" / "csrc"
-    ms = synthetic_ms(600_000, 31, 11, mask="mixed")
+    ms = synthetic_ms(1_300_000, 31, 11, mask="mixed")     # (enough words for several threads in every threaded loop)
     orc = oracle_py.Oracle.construct(ms, 31, use_klcp=False)
     prefix = tmp_path / "big"
     orc.dump(str(prefix))
