@@ -894,16 +894,19 @@ int fmsi_hip_index_download_layout(const fmsi_hip_index* idx, uint32_t* blocks, 
 int fmsi_hip_index_write_files(const fmsi_hip_index* idx, const char* prefix) {
     if (!idx || !prefix) return FMSI_HIP_EINVAL;
     FMSI_HIP_ON_DEVICE(idx->device);
-    std::vector<uint32_t> blocks(idx->n_blocks * kBlockDwords);
+    // (no clearing pass over buffers the copies fill: 1.4 GB of blocks at human scale)
+    std::vector<uint32_t, NoInitAlloc<uint32_t>> blocks(idx->n_blocks * kBlockDwords);
     FMSI_HIP_TRY(hipMemcpy(blocks.data(), idx->d_blocks, blocks.size() * 4, hipMemcpyDeviceToHost));
     HostVectors hv;
     vectors_from_blocks(blocks.data(), idx->n, hv);
     blocks.clear();
     blocks.shrink_to_fit();
-    std::vector<uint64_t> klcp;
+    std::vector<uint64_t, NoInitAlloc<uint64_t>> klcp;
     if (idx->d_klcp) {
-        klcp.assign((idx->n + 63) / 64 + 2, 0);
-        FMSI_HIP_TRY(hipMemcpy(klcp.data(), idx->d_klcp, ((idx->n + 63) / 64) * 8, hipMemcpyDeviceToHost));
+        const uint64_t kw = (idx->n + 63) / 64;
+        klcp.resize(kw + 2);
+        klcp[kw] = klcp[kw + 1] = 0;
+        FMSI_HIP_TRY(hipMemcpy(klcp.data(), idx->d_klcp, kw * 8, hipMemcpyDeviceToHost));
     }
     fmsi_index_view v;
     std::memset(&v, 0, sizeof v);
