@@ -15,6 +15,7 @@
 
 #include <cstdlib>
 #include <iostream>
+#include <memory>
 #include <stdexcept>
 #include <string>
 
@@ -216,30 +217,40 @@ int run_export(int argc, char** argv) {
         usage_export();
         return 0;
     }
-    fmsi_host_index* host = nullptr;
-    if (fmsi_host_index_load(fn.c_str(), 0, &host) != 0 || host->ix.n() == 0) {
+    // the index goes straight into HBM (fmsi_hip_index_load: RRR decode and block layout on the device), the walk runs there
+    // (fmsi_export.hip), and the text comes back into a buffer nobody clears first
+    uint64_t rows = 0;
+    int32_t index_k = 0, klcp_file = 0;
+    if (fmsi_host_index_peek(fn.c_str(), &rows, &index_k, &klcp_file) != 0 || rows == 0) {
         std::cerr << "ERROR: index not correctly loaded. Ensure that you correctly call `fmsi index` before." << std::endl;
         return usage_export();
     }
-    fmsi_index_view view;
-    fmsi_host_index_view(host, &view);
     fmsi_hip_index* dev = nullptr;
-    if (fmsi_hip_index_create(&view, device, &dev) != 0) {
+    const int rc_load = fmsi_hip_index_load(fn.c_str(), 0, device, 0, &dev);
+    if (rc_load == FMSI_HIP_EIO) {
+        std::cerr << "ERROR: index not correctly loaded. Ensure that you correctly call `fmsi index` before." << std::endl;
+        return usage_export();
+    }
+    if (rc_load != 0) {
         std::cerr << "ERROR: cannot create the device index: " << fmsi_hip_last_error() << std::endl;
-        fmsi_host_index_free(host);
         return 1;
     }
-    std::string ms(host->ix.n() - 1, '\0');
+    const uint64_t text_len = rows - 1;
+    std::unique_ptr<char[]> ms(new char[text_len + 1]);
     uint64_t len = 0;
-    const int rc = fmsi_hip_index_export(dev, ms.data(), ms.size(), &len);
+    const int rc = fmsi_hip_index_export(dev, ms.get(), text_len, &len);
     fmsi_hip_index_destroy(dev);
-    fmsi_host_index_free(host);
     if (rc != 0) {
         std::cerr << "ERROR: export failed: " << fmsi_hip_last_error() << std::endl;
         return 1;
     }
-    std::cout << ">exported masked superstring" << std::endl;
-    std::cout << ms << std::endl;
+    ms[len] = '\n';
+    static const char header[] = ">exported masked superstring\n";
+    std::cout.flush();
+    if (std::fwrite(header, 1, sizeof header - 1, stdout) != sizeof header - 1 || std::fwrite(ms.get(), 1, len + 1, stdout) != len + 1 || std::fflush(stdout) != 0) {
+        std::cerr << "ERROR: write to stdout failed" << std::endl;
+        return 1;
+    }
     return 0;
 }
 }  // namespace

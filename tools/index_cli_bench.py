@@ -40,6 +40,7 @@ def main() -> None:
     with open(fa, "wb") as f:
         f.write(b">ms\n" + ms + b"\n")
     del ms
+    time.sleep(3)   # (the driver wipes the device memory this process just released; a process that starts meanwhile waits for it in its first hipMalloc)
     t0 = time.time()
     import os
     p = subprocess.run([str(fm.CLI_PATH), "index", "-k", str(k), str(fa)], capture_output=True, env={**os.environ, "FMSI_HIP_VERBOSE": "1"})
