@@ -1305,6 +1305,7 @@ extern "C" int fmsi_hip_index_enable_pair_layout(fmsi_hip_index* idx) {
     if (idx->d_pblocks) return 0;
     TraceRange trace_range("fmsi: build pair layout");
     FMSI_HIP_ON_DEVICE(idx->device);
+    PhaseClock clock{"pair"};
     const uint64_t n_blocks = idx->n_blocks;
     const uint64_t n_super = ((n_blocks - 1) >> kSuperBlocksLog2) + 1;
     void *pb = nullptr, *counts = nullptr, *scanned = nullptr, *sbt = nullptr, *c2 = nullptr, *spec = nullptr, *temp = nullptr;
@@ -1381,6 +1382,7 @@ extern "C" int fmsi_hip_index_enable_pair_layout(fmsi_hip_index* idx) {
     idx->pair_r1 = r1;
     idx->pair_p1 = p1;
     idx->device_bytes += pb_bytes + n_super * 64 + 64;
+    clock.mark("pair layout");
     return 0;
 }
 
