@@ -45,8 +45,8 @@ int main(int argc, char** argv) {
         }
         const double t_fill = since(t0);
         t0 = hclock::now();
-        std::vector<char> buf;
-        format_bits(*P, 1, buf);
+        std::vector<char> buf(P->rec_out[P->raw.recs.size()]);
+        format_bits(*P, 1, buf.data());
         const double t_fmt = since(t0);
         t0 = hclock::now();
         FILE* f = std::fopen(out_path, "w");
