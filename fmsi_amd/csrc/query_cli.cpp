@@ -1029,8 +1029,9 @@ extern "C" int fmsi_cli_query(int argc, char** argv, int output_orders_i) {
                 uint64_t consumed = 0;     // uncompressed bytes handed on in batches
                 std::string carry;
                 bool eof = false, serial = false, first = true, fastq = false;
+                uint64_t grow = 1;   // a record longer than a stretch: the next stretch is twice as long (so that carrying it along stays linear)
                 while (!serial && !(eof && carry.empty())) {
-                    const uint64_t range_bytes = (fastq ? 2 : 1) * opt.batch_windows;
+                    const uint64_t range_bytes = (fastq ? 2 : 1) * opt.batch_windows * grow;
                     std::vector<BgzfFile::Member> ms;
                     std::vector<size_t> offs;
                     size_t bytes = 0;
@@ -1074,8 +1075,10 @@ extern "C" int fmsi_cli_query(int argc, char** argv, int output_orders_i) {
                     const size_t cut = eof ? len : last_record_start(d, len, fastq);
                     if (cut == 0 && !eof) {   // one record longer than the stretch: read on
                         carry.assign(seg.get(), len);
+                        grow *= 2;
                         continue;
                     }
+                    grow = 1;
                     std::vector<size_t> cuts{0};
                     for (unsigned w = 1; w < workers; ++w) {
                         const size_t c = next_record_start(d, cut / workers * w, cut, fastq);
