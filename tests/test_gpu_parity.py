@@ -813,7 +813,7 @@ def test_general_function_counts_equal_oracle(fm, oracle_built, tmp_path, k):
         dev.close()
 
 
-@pytest.mark.parametrize("shape", ["fasta_messy", "fastq_4line", "fasta_long_records", "then_plain_gzip", "bad_crc", "not_bgzf_gzip"])
+@pytest.mark.parametrize("shape", ["fasta_messy", "fastq_4line", "fasta_long_records", "fasta_one_giant_record", "then_plain_gzip", "bad_crc", "not_bgzf_gzip"])
 def test_block_gzip_reader(fm, oracle_built, tmp_path, monkeypatch, shape):
     """Block-gzip (BGZF) query files: the members are found by their headers, inflated by several threads and parsed in stretches that
     end where a record starts -- the output must be what the ordinary reader (zlib's gzread, as in the reference) makes of the same
@@ -833,6 +833,10 @@ def test_block_gzip_reader(fm, oracle_built, tmp_path, monkeypatch, shape):
             qual = "".join(rng.choice("@+>IIIIFFF#5") for _ in range(L))
             data += f"@r{r} c\n{up[p:p + L]}\n+\n{qual}\n".encode()
         data = bytes(data)
+    elif shape == "fasta_one_giant_record":      # hundreds of stretches long: the stretches double until it fits
+        up = ms.upper()
+        giant = "".join(up[rng.randrange(0, 20000):][:5000] for _ in range(120))
+        data = (f">small0\n{up[100:400]}\n>giant\n{giant[:300000]}N{giant[300000:]}\n>small1\n{up[500:900]}\n").encode()
     elif shape == "fasta_long_records":
         up = ms.upper()
         data = b"".join(f">long{r}\n".encode() + (up[rng.randrange(0, 1000):][:rng.choice([9000, 20000])] + "N" + up[:5000]).encode() + b"\n" for r in range(12))
@@ -885,7 +889,7 @@ def test_block_gzip_reader(fm, oracle_built, tmp_path, monkeypatch, shape):
             checker = oracle_py.REF_CLI if oracle_py.ref_available() else oracle_py.ORACLE_CLI
             rc, ref, _ = oracle_py.run_cli(checker, [a for a in args if a not in ("--batch", "4096")])
             assert rc == 0 and got == ref
-        assert got.count(b"\n") >= 12
+        assert got.count(b"\n") >= (3 if shape == "fasta_one_giant_record" else 12)
 
 
 DEGENERATE_INPUTS = {
