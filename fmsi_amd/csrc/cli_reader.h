@@ -1,0 +1,488 @@
+// The query side's readers of `fmsi query` / `lookup` (query_cli.cpp): batches of raw records for the packing workers.
+//   * a plain file is mapped and parsed in place by several threads (ranges cut at record starts; names and single-line sequences stay
+//     views of the mapping),
+//   * a block-gzip file has its members inflated side by side, stretch after stretch, each parsed the same way,
+//   * anything else -- gzip, stdin, a FASTQ file that cannot be cut safely -- goes through the ordinary reader (fastx.cpp, the
+//     reference's kseq rules), which also takes over wherever the two above have to stop.
+// Every path yields the sequential parse of the reference (src/kseq.h:183-226, src/parser.h:14-27), batch after batch in file order.
+#pragma once
+
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <chrono>
+#include <condition_variable>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <deque>
+#include <exception>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "fastx.h"
+
+namespace fmsi {
+namespace {
+
+template <class F>
+void parallel_for(unsigned team, F&& fn) {   // fn(t) for t in [0, team); t = 0 runs on the caller
+    if (team <= 1) {
+        fn(0u);
+        return;
+    }
+    std::vector<std::thread> th;
+    std::vector<std::exception_ptr> err(team);
+    th.reserve(team - 1);
+    for (unsigned t = 1; t < team; ++t)
+        th.emplace_back([&, t] {
+            try { fn(t); } catch (...) { err[t] = std::current_exception(); }
+        });
+    try { fn(0u); } catch (...) { err[0] = std::current_exception(); }
+    for (auto& x : th) x.join();
+    for (auto& e : err)
+        if (e) std::rethrow_exception(e);
+}
+
+template <class T>
+class BoundedQueue {
+public:
+    explicit BoundedQueue(size_t cap) : cap_(cap) {}
+    bool push(T&& v) {   // false: the consumer has gone away
+        std::unique_lock<std::mutex> lk(m_);
+        not_full_.wait(lk, [&] { return q_.size() < cap_ || closed_; });
+        if (closed_) return false;
+        q_.push_back(std::move(v));
+        not_empty_.notify_one();
+        return true;
+    }
+    bool pop(T& v) {     // false: closed and drained
+        std::unique_lock<std::mutex> lk(m_);
+        not_empty_.wait(lk, [&] { return !q_.empty() || closed_; });
+        if (q_.empty()) return false;
+        v = std::move(q_.front());
+        q_.pop_front();
+        not_full_.notify_one();
+        return true;
+    }
+    bool pop_seq(T& v, uint64_t& seq) {   // pop() + the item's number in pop order (several consumers, one order)
+        std::unique_lock<std::mutex> lk(m_);
+        not_empty_.wait(lk, [&] { return !q_.empty() || closed_; });
+        if (q_.empty()) return false;
+        v = std::move(q_.front());
+        q_.pop_front();
+        seq = popped_++;
+        not_full_.notify_one();
+        return true;
+    }
+    void close() {       // producer: no more items; consumer: stop the producer
+        std::lock_guard<std::mutex> lk(m_);
+        closed_ = true;
+        not_full_.notify_all();
+        not_empty_.notify_all();
+    }
+    void abort() {
+        std::lock_guard<std::mutex> lk(m_);
+        closed_ = true;
+        q_.clear();
+        not_full_.notify_all();
+        not_empty_.notify_all();
+    }
+
+private:
+    std::mutex m_;
+    std::condition_variable not_full_, not_empty_;
+    std::deque<T> q_;
+    size_t cap_;
+    uint64_t popped_ = 0;
+    bool closed_ = false;
+};
+
+struct RecRef {   // views: into the mapped query file, the batch's arena (multi-line sequences) or the batch's text (ordinary reader)
+    const char* name;
+    const char* seq;
+    uint64_t seq_len;
+    uint32_t name_len;
+};
+struct RawBatch {   // never moved or copied: its records point into its own text (a short std::string lives INSIDE the object)
+    RawBatch() = default;
+    RawBatch(const RawBatch&) = delete;
+    RawBatch& operator=(const RawBatch&) = delete;
+    std::string text;                                 // ordinary reader: names and sequences, as read
+    std::vector<FastxViewParser::Arena> arenas;       // block-parallel reader: one per part, holding only what is not a view of the file
+    std::shared_ptr<char[]> inflated;                 // block-gzip reader: the decompressed bytes the views look into
+    std::vector<RecRef> recs;
+    uint64_t seq_bytes = 0;
+};
+
+// ---- block-parallel reader ---------------------------------------------------------------------------------------
+// A plain (not gzipped) FASTA file is mapped and cut at lines that start with '>' into ranges of about a batch; a range
+// is cut again the same way into one part per worker, and every worker runs the reader's rules (fastx.cpp, the
+// reference's kseq rules) over its part WITHOUT copying: names and single-line sequences stay views of the mapping.  That is the sequential parse exactly, as long as no '+' separator line occurs:
+// a line-start '>' is then always a record start (src/kseq.h:183-226: only a FASTQ quality string can hold one that is
+// not).  A worker that meets a '+' line says so, and the range is parsed again by ONE reader that then goes on to the
+// end of the file -- ranges before it held no '+' line, so its start is a record start of the sequential parse too.
+struct MappedFile {
+    const unsigned char* data = nullptr;
+    size_t size = 0;
+    ~MappedFile() {
+        if (data) munmap(const_cast<unsigned char*>(data), size);
+    }
+};
+// the query file as a mapping, if it is a regular, uncompressed file that starts with a FASTA or FASTQ header and is worth it
+bool map_plain_fasta(const std::string& path, MappedFile& m, bool* fastq) {
+    *fastq = false;
+    if (path == "-" || std::getenv("FMSI_HIP_SERIAL_READER")) return false;
+    const int fd = open(path.c_str(), O_RDONLY);
+    if (fd < 0) return false;
+    struct stat st;
+    // (FMSI_HIP_READER_MIN_BYTES: the tests send small files through here)
+    const char* min_env = std::getenv("FMSI_HIP_READER_MIN_BYTES");
+    const long long min_bytes = min_env ? std::max(1ll, atoll(min_env)) : (8ll << 20);
+    bool ok = fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && st.st_size >= min_bytes;
+    if (ok) {
+        void* p = mmap(nullptr, static_cast<size_t>(st.st_size), PROT_READ, MAP_PRIVATE, fd, 0);
+        ok = p != MAP_FAILED;
+        if (ok) {
+            m.data = static_cast<const unsigned char*>(p);
+            m.size = static_cast<size_t>(st.st_size);
+            (void)madvise(p, m.size, MADV_SEQUENTIAL);
+            if (m.data[0] == '@') *fastq = true;
+            else if (m.data[0] != '>') ok = false;   // (a gzip stream starts with 0x1f 0x8b)
+        }
+    }
+    close(fd);
+    return ok;
+}
+// FASTQ: first position >= from of a line that starts with '@' and whose next-but-one line starts with '+' -- in a file of 4-line
+// records that is a header and nothing else (a quality line may start with '@', but then the line after next is a sequence).
+// A wrong guess in an unusual file (multi-line quality) is harmless: the part before it then does not end between two records, its
+// reader says so (clean_end), and the ordinary reader takes over from there.
+size_t next_fastq_start(const unsigned char* d, size_t from, size_t end) {
+    auto next_line = [&](size_t p) -> size_t {
+        const void* nl = p < end ? std::memchr(d + p, '\n', end - p) : nullptr;
+        return nl ? static_cast<size_t>(static_cast<const unsigned char*>(nl) - d) + 1 : end;
+    };
+    size_t p = from;
+    if (p > 0 && p < end && d[p - 1] != '\n') p = next_line(p);
+    while (p < end) {
+        if (d[p] == '@') {
+            const size_t l2 = next_line(next_line(p));
+            if (l2 < end && d[l2] == '+') return p;
+        }
+        p = next_line(p);
+    }
+    return end;
+}
+// first position >= from (and < end) of a '>' that starts a line; `end` if there is none
+size_t next_record_start(const unsigned char* d, size_t from, size_t end, bool fastq = false) {
+    if (fastq) return next_fastq_start(d, from, end);
+    while (from < end) {
+        const void* g = std::memchr(d + from, '>', end - from);
+        if (!g) return end;
+        const size_t at = static_cast<size_t>(static_cast<const unsigned char*>(g) - d);
+        if (at == 0 || d[at - 1] == '\n') return at;
+        from = at + 1;
+    }
+    return end;
+}
+// last position <= len where a record starts (by the rules of next_record_start), 0 if there is none behind the first byte:
+// everything in front of it is whole records, what follows is carried over to the next stretch of the stream
+size_t last_record_start(const unsigned char* d, size_t len, bool fastq) {
+    if (!fastq) {
+        for (size_t e = len; e > 0;) {
+            const void* g = memrchr(d, '>', e);
+            if (!g) return 0;
+            const size_t at = static_cast<size_t>(static_cast<const unsigned char*>(g) - d);
+            if (at == 0 || d[at - 1] == '\n') return at;
+            e = at;
+        }
+        return 0;
+    }
+    for (size_t window = size_t(1) << 20;; window <<= 2) {   // a header needs its next two lines in sight: look from a little before the end
+        const size_t from = len > window ? len - window : 0;
+        size_t c = next_fastq_start(d, from, len);
+        if (c < len) {
+            for (size_t n; (n = next_fastq_start(d, c + 1, len)) < len;) c = n;
+            return c;
+        }
+        if (from == 0) return 0;
+    }
+}
+
+// all records of d[lo, hi) (lo at a record start) as views (FastxViewParser: the ordinary reader's rules)
+bool parse_range(const unsigned char* d, size_t lo, size_t hi, FastxViewParser::Arena& arena, std::vector<RecRef>& recs, uint64_t& seq_bytes,
+                 bool fastq = false) {
+    FastxViewParser r(d + lo, hi - lo);
+    for (;;) {
+        RecRef rr;
+        size_t name_len, seq_len;
+        if (!r.next(arena, &rr.name, &name_len, &rr.seq, &seq_len)) break;
+        rr.name_len = static_cast<uint32_t>(name_len);
+        rr.seq_len = seq_len;
+        recs.push_back(rr);
+        seq_bytes += seq_len;
+    }
+    // FASTA file: clean = no '+' line was met (then '>' lines are record starts).  FASTQ file: clean = the part ended between two
+    // records -- then the next part starts where the sequential parse would start a record, too.
+    return fastq ? r.clean_end() : !r.saw_fastq();
+}
+class QueryReader {
+public:
+    using clock = std::chrono::steady_clock;
+    QueryReader(const std::string& query_fn, uint64_t batch_windows, unsigned team, BoundedQueue<std::unique_ptr<RawBatch>>& raw_q)
+        : opt{query_fn, batch_windows}, team(team), raw_q(raw_q) {}
+    ~QueryReader() {   // (whoever leaves without draining the queue: the thread must not stay blocked on it)
+        raw_q.abort();
+        join();
+    }
+    // opens the file -- throws std::invalid_argument like OpenFile(), src/parser.h:22 -- and starts reading on a thread of its own
+    void start() {
+    reader = std::make_unique<FastxReader>(opt.query_fn);   // throws std::invalid_argument like OpenFile(), src/parser.h:22
+    parallel_read = map_plain_fasta(opt.query_fn, mapped, &parallel_fastq);
+    if (!parallel_read && opt.query_fn != "-" && !std::getenv("FMSI_HIP_SERIAL_READER")) {
+        const char* min_env = std::getenv("FMSI_HIP_READER_MIN_BYTES");
+        (void)bgzf.open(opt.query_fn, min_env ? static_cast<size_t>(std::max(1ll, atoll(min_env))) : (size_t(1) << 20));
+    }
+        reader_thread = std::thread([this] { run(); });
+    }
+    bool started() const { return reader_thread.joinable(); }
+    void join() {
+        if (reader_thread.joinable()) reader_thread.join();
+    }
+    double read_s = 0;                  // time spent reading (not waiting for the queue)
+    uint64_t parallel_read_bytes = 0;   // (--stats: how far the block-parallel readers got before they had to hand over, if they did)
+    std::exception_ptr reader_err;
+
+private:
+    struct {
+        std::string query_fn;
+        uint64_t batch_windows;         // bases of query sequence per batch
+    } opt;
+    unsigned team;
+    BoundedQueue<std::unique_ptr<RawBatch>>& raw_q;
+    std::unique_ptr<FastxReader> reader;
+    MappedFile mapped;
+    BgzfFile bgzf;
+    bool parallel_read = false, parallel_fastq = false;
+    std::thread reader_thread;
+
+    void run() {
+    try {
+        auto b = std::make_unique<RawBatch>();
+        auto t0 = clock::now();
+        size_t resume_at = 0;   // block-parallel reader: where the ordinary reader takes over (a '+' line was met)
+        if (parallel_read) {
+            const unsigned workers = std::max(1u, std::min(8u, team / 2));
+            const unsigned char* d = mapped.data;
+            size_t pos = 0;
+            bool serial = false;
+            while (pos < mapped.size && !serial) {
+                // a range of about a batch, ending at a record start (or the end of the file)
+                size_t end = mapped.size;
+                const uint64_t range_bytes = (parallel_fastq ? 2 : 1) * opt.batch_windows;   // (a FASTQ file is half qualities)
+                if (mapped.size - pos > range_bytes + (range_bytes >> 3))
+                    end = next_record_start(d, pos + range_bytes, mapped.size, parallel_fastq);
+                std::vector<size_t> cuts{pos};
+                for (unsigned w = 1; w < workers; ++w) {
+                    const size_t c = next_record_start(d, pos + (end - pos) / workers * w, end, parallel_fastq);
+                    if (c > cuts.back() && c < end) cuts.push_back(c);
+                }
+                cuts.push_back(end);
+                const size_t parts = cuts.size() - 1;
+                std::vector<std::vector<RecRef>> recs(parts);
+                std::vector<uint64_t> seq_bytes(parts, 0);
+                std::vector<char> clean(parts, 1);
+                auto nb = std::make_unique<RawBatch>();
+                nb->arenas.resize(parts);
+                std::vector<std::thread> pool;
+                for (size_t w = 0; w < parts; ++w)
+                    pool.emplace_back([&, w] {
+                        clean[w] = parse_range(d, cuts[w], cuts[w + 1], nb->arenas[w], recs[w], seq_bytes[w], parallel_fastq) ? 1 : 0;
+                    });
+                for (std::thread& t : pool) t.join();
+                if (std::find(clean.begin(), clean.end(), 0) != clean.end()) {   // a FASTQ record: the ordinary reader from here on
+                    serial = true;
+                    resume_at = pos;
+                    break;
+                }
+                size_t total = 0;
+                for (size_t w = 0; w < parts; ++w) total += recs[w].size();
+                nb->recs.reserve(total);
+                for (size_t w = 0; w < parts; ++w) {
+                    nb->recs.insert(nb->recs.end(), recs[w].begin(), recs[w].end());
+                    nb->seq_bytes += seq_bytes[w];
+                }
+                pos = end;
+                parallel_read_bytes = pos;
+                if (nb->recs.empty()) continue;
+                // (the stages behind count records in 32 bits per batch like the ordinary reader's batches: at most 2^23)
+                if (nb->recs.size() > (1u << 23)) {
+                    serial = true;
+                    resume_at = cuts[0];
+                    break;
+                }
+                read_s += std::chrono::duration<double>(clock::now() - t0).count();
+                if (!raw_q.push(std::move(nb))) return;
+                t0 = clock::now();
+            }
+            if (!serial) {
+                read_s += std::chrono::duration<double>(clock::now() - t0).count();
+                raw_q.close();
+                return;
+            }
+            reader = std::make_unique<FastxReader>(mapped.data + resume_at, mapped.size - resume_at);
+        }
+        // ---- block-gzip (BGZF) file: the members are found by their headers and inflated side by side into one stretch of the
+        // stream after the other; a stretch ends where its last record starts (the rest is carried into the next one) and is
+        // parsed like a range of a mapped plain file.  Anything unusual -- a member that is not BGZF, a CRC that does not match, a
+        // part that does not end between two records -- hands the stream to the ordinary reader at the last byte given out.
+        if (bgzf) {
+            const unsigned workers = std::max(1u, std::min(8u, team / 2));
+            size_t at = 0;             // compressed offset of the next member
+            uint64_t consumed = 0;     // uncompressed bytes handed on in batches
+            std::string carry;
+            bool eof = false, serial = false, first = true, fastq = false;
+            uint64_t grow = 1;   // a record longer than a stretch: the next stretch is twice as long (so that carrying it along stays linear)
+            while (!serial && !(eof && carry.empty())) {
+                const uint64_t range_bytes = (fastq ? 2 : 1) * opt.batch_windows * grow;
+                std::vector<BgzfFile::Member> ms;
+                std::vector<size_t> offs;
+                size_t bytes = 0;
+                while (!eof && bytes < range_bytes) {
+                    if (at >= bgzf.size()) {
+                        eof = true;
+                        break;
+                    }
+                    BgzfFile::Member m;
+                    if (!bgzf.member(at, &m)) {
+                        serial = true;
+                        break;
+                    }
+                    offs.push_back(bytes);
+                    ms.push_back(m);
+                    bytes += m.isize;
+                    at = m.next;
+                }
+                if (serial) break;
+                const size_t len = carry.size() + bytes;
+                std::shared_ptr<char[]> seg(new char[len + 1]);
+                std::memcpy(seg.get(), carry.data(), carry.size());
+                // (inflating is by far the longest piece of work on this path: the whole team takes it)
+                const unsigned inflaters = static_cast<unsigned>(std::max<size_t>(1, std::min<size_t>(team, ms.size())));
+                std::vector<char> ok(inflaters, 1);
+                parallel_for(inflaters, [&](unsigned t) {
+                    for (size_t i = t; i < ms.size(); i += inflaters)
+                        if (!bgzf.inflate(ms[i], seg.get() + carry.size() + offs[i])) ok[t] = 0;
+                });
+                if (std::find(ok.begin(), ok.end(), 0) != ok.end()) {
+                    serial = true;
+                    break;
+                }
+                const unsigned char* d = reinterpret_cast<const unsigned char*>(seg.get());
+                if (first && len) {
+                    if (d[0] == '@') fastq = true;
+                    else if (d[0] != '>') serial = true;   // (leading junk: the ordinary reader knows what to do with it)
+                    first = false;
+                    if (serial) break;
+                }
+                const size_t cut = eof ? len : last_record_start(d, len, fastq);
+                if (cut == 0 && !eof) {   // one record longer than the stretch: read on
+                    carry.assign(seg.get(), len);
+                    grow *= 2;
+                    continue;
+                }
+                grow = 1;
+                std::vector<size_t> cuts{0};
+                for (unsigned w = 1; w < workers; ++w) {
+                    const size_t c = next_record_start(d, cut / workers * w, cut, fastq);
+                    if (c > cuts.back() && c < cut) cuts.push_back(c);
+                }
+                cuts.push_back(cut);
+                const size_t parts = cuts.size() - 1;
+                std::vector<std::vector<RecRef>> recs(parts);
+                std::vector<uint64_t> seq_bytes(parts, 0);
+                std::vector<char> clean(parts, 1);
+                auto nb = std::make_unique<RawBatch>();
+                nb->arenas.resize(parts);
+                nb->inflated = seg;
+                parallel_for(static_cast<unsigned>(parts), [&](unsigned w) {
+                    clean[w] = parse_range(d, cuts[w], cuts[w + 1], nb->arenas[w], recs[w], seq_bytes[w], fastq) ? 1 : 0;
+                });
+                size_t total = 0;
+                for (size_t w = 0; w < parts; ++w) total += recs[w].size();
+                if (std::find(clean.begin(), clean.end(), 0) != clean.end() || total > (1u << 23)) {
+                    serial = true;
+                    break;
+                }
+                nb->recs.reserve(total);
+                for (size_t w = 0; w < parts; ++w) {
+                    nb->recs.insert(nb->recs.end(), recs[w].begin(), recs[w].end());
+                    nb->seq_bytes += seq_bytes[w];
+                }
+                carry.assign(seg.get() + cut, len - cut);
+                consumed += cut;
+                parallel_read_bytes = consumed;
+                if (nb->recs.empty()) continue;
+                read_s += std::chrono::duration<double>(clock::now() - t0).count();
+                if (!raw_q.push(std::move(nb))) return;
+                t0 = clock::now();
+            }
+            if (!serial) {
+                read_s += std::chrono::duration<double>(clock::now() - t0).count();
+                raw_q.close();
+                return;
+            }
+            reader->skip(consumed);
+        }
+        // ordinary reader: names and sequences are appended to the batch's text, which moves as it grows -- the records hold
+        // offsets until the batch is complete
+        std::vector<std::pair<size_t, size_t>> offs;   // (name, sequence) offsets of the batch's records
+        auto finish = [&offs](RawBatch& rb) {
+            const char* base = rb.text.data();
+            for (size_t r = 0; r < rb.recs.size(); ++r) {
+                rb.recs[r].name = base + offs[r].first;
+                rb.recs[r].seq = base + offs[r].second;
+            }
+            offs.clear();
+        };
+        for (;;) {
+            RecRef rr;
+            const size_t before = b->text.size();
+            size_t name_off, name_len, seq_off, seq_len;
+            if (!reader->next_append(b->text, &name_off, &name_len, &seq_off, &seq_len)) {
+                b->text.resize(before);   // a partial record (truncated FASTQ) ends the stream, as in the reference
+                break;
+            }
+            rr.name = rr.seq = nullptr;
+            rr.name_len = static_cast<uint32_t>(name_len);
+            rr.seq_len = seq_len;
+            b->recs.push_back(rr);
+            offs.emplace_back(name_off, seq_off);
+            b->seq_bytes += rr.seq_len;
+            if (b->seq_bytes >= opt.batch_windows || b->recs.size() >= (1u << 23)) {
+                finish(*b);
+                read_s += std::chrono::duration<double>(clock::now() - t0).count();
+                if (!raw_q.push(std::move(b))) return;
+                b = std::make_unique<RawBatch>();
+                t0 = clock::now();
+            }
+        }
+        finish(*b);
+        read_s += std::chrono::duration<double>(clock::now() - t0).count();
+        if (!b->recs.empty()) raw_q.push(std::move(b));
+    } catch (...) {
+        reader_err = std::current_exception();
+    }
+    raw_q.close();
+    }
+};
+
+}  // namespace
+}  // namespace fmsi
