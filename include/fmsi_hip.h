@@ -146,7 +146,9 @@ int fmsi_hip_index_load(const char* prefix, int use_klcp, int device, int prefix
 
 /* On-device construction -- counterpart of construct<T>() (src/fms_index.h:397-460) producing the device layout
  * directly: 2-bit text -> GPU suffix sort -> BWT / SA-transformed mask / kLCP -> interleaved blocks.
- * `ms` is the masked superstring (upper case = mask 1, src/kmers.h:71-73).  with_klcp needs k <= 64 (as the reference, src/main.cpp:223-226). */
+ * `ms` is the masked superstring (upper case = mask 1, src/kmers.h:71-73), host memory of any kind (it goes up in slices through page-locked
+ * staging buffers; a character outside ACGTacgt: FMSI_HIP_EINVAL with its position).  with_klcp needs k <= 64 (as the reference,
+ * src/main.cpp:223-226).  len <= 2^32 - 8192 (FMSI_HIP_ERANGE beyond: the device sort's limit, a little before 32-bit rows end). */
 int fmsi_hip_index_build(const char* ms, uint64_t len, int k, int with_klcp, int device, int prefix_len, fmsi_hip_index** out);
 
 /* Synthetic workloads (no network on the GPU box, so no real genomes): the superstring is
