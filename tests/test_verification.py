@@ -114,3 +114,142 @@ PRODUCT_RUNS = [(*r, t) for r in RUNS for t in ([], ["--tables", "full"], ["--ta
 def test_product_cli_against_brute_force(product_built, name, fname, k, n_reads, length, extra, dirty, tables):
     fm = product_built
     check_cli(lambda args, stdin: fm.run_cli([*args[:-1], *tables, args[-1]], stdin), name, fname, k, n_reads, length, extra, dirty)
+
+
+# ---- `-f and|xor|r-s` (f-masked superstrings, query_mode::general): the same kind of checker -------------------------------------------
+# f(ones, total) with total = occurrences of the k-mer and of its reverse complement in the superstring and ones = those with the
+# mask ON, counted by brute force; a k-mer that reads the same as its reverse complement CHARACTER BY CHARACTER (the reference compares
+# the query's characters, case included, src/kmers.h:53-68) is counted once.
+FN_RUNS = [
+    # index, masked superstring file (under tests/golden), k, function
+    ("mixed_k11", "mixed.fa", 11, "and"), ("mixed_k11", "mixed.fa", 11, "xor"), ("mixed_k11", "mixed.fa", 11, "1-1"), ("mixed_k11", "mixed.fa", 11, "2-9"),
+    ("integration_b", "ref_data/integration_b.fa", 3, "xor"), ("integration_b", "ref_data/integration_b.fa", 3, "and"),
+    ("sars_k13", "ref_data/GCF_009858895.2_ASM985889v3_genomic.fna.ms.k13", 13, "xor"), ("sars_k13", "ref_data/GCF_009858895.2_ASM985889v3_genomic.fna.ms.k13", 13, "0-0"),
+]
+
+
+def occurrence_counts(ms: str, k: int) -> dict:
+    """k-mer -> [ON occurrences, occurrences] over the superstring's own strand."""
+    up = ms.upper()
+    counts = {}
+    for p in range(len(ms) - k + 1):
+        c = counts.setdefault(up[p:p + k], [0, 0])
+        c[0] += ms[p].isupper()
+        c[1] += 1
+    return counts
+
+
+def apply_fn(fn: str, ones: int, total: int) -> bool:
+    if fn == "and":
+        return total > 0 and ones == total
+    if fn == "xor":
+        return ones % 2 == 1
+    r, s = (int(x) for x in fn.split("-"))
+    return r <= ones <= s
+
+
+def brute_force_fn_line(read: str, counts: dict, k: int, fn: str) -> str:
+    comp = str.maketrans("ACGTacgt", "TGCAtgca")
+    out = []
+    for i in range(len(read) - k + 1):
+        w = read[i:i + k]
+        if any(c not in "ACGTacgt" for c in w):
+            out.append("0")
+            continue
+        rc = w[::-1].translate(comp)                        # case-preserving, as ReverseComplementString is
+        ones, total = counts.get(w.upper(), (0, 0))
+        if w != rc:                                           # AreStringsEqual on the characters
+            o2, t2 = counts.get(rc.upper(), (0, 0))
+            ones, total = ones + o2, total + t2
+        out.append("1" if apply_fn(fn, ones, total) else "0")
+    return "".join(out)
+
+
+def check_fn_cli(run, name, fname, k, fn):
+    ms = "".join(l.strip() for l in open(GOLDEN / fname) if not l.startswith(">"))
+    counts = occurrence_counts(ms, k)
+    length = max(4 * k, 40)
+    reads = seeded_reads(ms * (1 + 2 * length // len(ms)), 80, length, seed=7, dirty=True)
+    # (these k are odd: no k-mer is its own reverse complement here -- test_self_complementary_kmers_by_brute_force has an even k)
+    stdin = "".join(f">r{i}\n{r}\n" for i, r in enumerate(reads)).encode()
+    rc, out, err = run(["query", "-f", fn, "-q", "-", "-k", str(k), index_prefix(name)], stdin)
+    assert rc == 0, err.decode()
+    lines = out.decode().split("\n")
+    assert lines[-1] == "" and len(lines) == len(reads) + 1
+    ones = 0
+    for read, line in zip(reads, lines):
+        bits = line.partition("\t")[2]
+        want = brute_force_fn_line(read, counts, k, fn)
+        if "N" in read:
+            assert bits[:len(want)] == want and set(bits[len(want):]) <= {"0"}
+        else:
+            assert bits == want
+        ones += want.count("1")
+    assert ones > 0
+
+
+def test_self_complementary_kmers_by_brute_force(oracle_built, tmp_path):
+    """Even k: a k-mer equal to its own reverse complement counts once -- unless its CASE is asymmetric, then the reference's character
+    comparison does not see the equality and counts it twice.  Oracle CLI and (when built) the real reference against the brute force."""
+    k = 6
+    rng = random.Random(3)
+    pal = "ACGCGT"                                            # its own reverse complement
+    body = "".join(rng.choice("ACGT") for _ in range(300))
+    text = body[:100] + pal + body[100:200] + pal + body[200:] + pal
+    ms = "".join(c if rng.random() < 0.6 else c.lower() for c in text)
+    ms = ms[: len(ms) - (k - 1)] + ms[len(ms) - (k - 1):].lower()
+    prefix = str(tmp_path / "pal")
+    oracle_py.Oracle.construct(ms, k, use_klcp=False).dump(prefix)
+    counts = occurrence_counts(ms, k)
+    assert counts[pal][1] >= 3
+    reads = [pal, pal.lower(), "acgCGT", "ACGcgt", "AcGcGt", "TT" + pal + "GG" + "acGCGt" + "A"]
+    stdin = "".join(f">r{i}\n{r}\n" for i, r in enumerate(reads)).encode()
+    clis = [oracle_py.ORACLE_CLI] + ([oracle_py.REF_CLI] if oracle_py.ref_available() else [])
+    for fn in ("xor", "and", "1-3", "4-100"):
+        want = "".join(f"r{i}\t{brute_force_fn_line(r, counts, k, fn)}\n" for i, r in enumerate(reads))
+        for cli in clis:
+            rc, out, err = oracle_py.run_cli(cli, ["query", "-f", fn, "-q", "-", prefix], stdin)
+            assert rc == 0 and out.decode() == want, (fn, cli)
+    # the rule makes a difference on these reads: symmetric and asymmetric case answer differently for some function
+    assert brute_force_fn_line("acgCGT", counts, k, "1-3") != brute_force_fn_line(pal, counts, k, "1-3") or \
+        brute_force_fn_line("acgCGT", counts, k, "xor") != brute_force_fn_line(pal, counts, k, "xor")
+
+
+@pytest.mark.parametrize("name,fname,k,fn", FN_RUNS)
+def test_oracle_cli_general_functions_against_brute_force(oracle_built, name, fname, k, fn):
+    check_fn_cli(lambda args, stdin: oracle_py.run_cli(oracle_py.ORACLE_CLI, args, stdin), name, fname, k, fn)
+
+
+@pytest.mark.skipif(not oracle_py.ref_available(), reason="oracle/_ref not built")
+@pytest.mark.parametrize("name,fname,k,fn", FN_RUNS[:4])
+def test_reference_cli_general_functions_against_brute_force(name, fname, k, fn):
+    check_fn_cli(lambda args, stdin: oracle_py.run_cli(oracle_py.REF_CLI, args, stdin), name, fname, k, fn)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,fname,k,fn", FN_RUNS)
+def test_product_cli_general_functions_against_brute_force(product_built, name, fname, k, fn):
+    fm = product_built
+    check_fn_cli(lambda args, stdin: fm.run_cli(args, stdin), name, fname, k, fn)
+
+
+@pytest.mark.gpu
+def test_product_self_complementary_kmers_by_brute_force(product_built, oracle_built, tmp_path):
+    fm = product_built
+    k = 6
+    rng = random.Random(3)
+    pal = "ACGCGT"
+    body = "".join(rng.choice("ACGT") for _ in range(300))
+    text = body[:100] + pal + body[100:200] + pal + body[200:] + pal
+    ms = "".join(c if rng.random() < 0.6 else c.lower() for c in text)
+    ms = ms[: len(ms) - (k - 1)] + ms[len(ms) - (k - 1):].lower()
+    prefix = str(tmp_path / "pal")
+    oracle_py.Oracle.construct(ms, k, use_klcp=False).dump(prefix)
+    counts = occurrence_counts(ms, k)
+    reads = [pal, pal.lower(), "acgCGT", "ACGcgt", "AcGcGt", "TT" + pal + "GG" + "acGCGt" + "A"]
+    stdin = "".join(f">r{i}\n{r}\n" for i, r in enumerate(reads)).encode()
+    for fn in ("xor", "and", "1-3", "4-100"):
+        want = "".join(f"r{i}\t{brute_force_fn_line(r, counts, k, fn)}\n" for i, r in enumerate(reads))
+        rc, out, err = fm.run_cli(["query", "-f", fn, "-q", "-", prefix], stdin)
+        assert rc == 0 and out.decode() == want, fn
+
