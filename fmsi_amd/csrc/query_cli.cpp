@@ -6,10 +6,11 @@
 // Output is byte-identical to the reference: per-window results of both strands come back from the
 // device and the sequential strand predictor (src/fms_index.h:18-49) is replayed here.
 //
-// Host pipeline: reader thread (FASTA/FASTQ, gzip) -> batches of raw records -> main thread:
-// planning + 2-bit packing on a team of threads, one device call per batch, predictor replay (sequential by
-// nature) -> writer thread: formatting on a team of threads + one fwrite per batch.  Batches flow through bounded
-// queues, so parsing, device work and printing of consecutive batches overlap and the output order is the input order.
+// Host pipeline, every stage on threads of its own, batches in bounded queues, output order = input order:
+//   readers (cli_reader.h: mapped plain files and block-gzip files parsed in place, the ordinary reader for gzip / stdin)
+//   -> two workers per device handle: planning + 2-bit packing on a team (cli_host_kernels.h), one device call per batch
+//   -> this thread, batches in order: predictor replay (sequential by nature; skipped when nothing depends on it)
+//   -> formatter (a team writes the batch's lines into one buffer) -> sink (write()).
 #include <getopt.h>
 #include <sys/stat.h>
 #include <unistd.h>
