@@ -22,6 +22,8 @@ struct fmsi_hip_index {
 namespace {
 uint64_t kmer_hash(const uint64_t* seq, uint64_t start, int k) {
     uint64_t h = 0x9E3779B97F4A7C15ull;
+    static const bool fast = std::getenv("FMSI_STUB_FAST") != nullptr;   // (timing runs of the host stages: the window's first word only)
+    if (fast) return (seq[start >> 5] >> (start & 31)) * 0x9E3779B97F4A7C15ull >> 7;
     for (int t = 0; t < k; ++t) {
         const uint64_t p = start + static_cast<uint64_t>(t);
         h = (h ^ ((seq[p >> 5] >> (2 * (p & 31))) & 3u)) * 0x100000001B3ull;
