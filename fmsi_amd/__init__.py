@@ -139,6 +139,10 @@ def lib() -> C.CDLL:
     L.fmsi_hip_index_enable_dict.argtypes = [vp, u32]
     L.fmsi_hip_index_load.argtypes = [C.c_char_p, i32, i32, i32, C.POINTER(vp)]
     L.fmsi_hip_trim_scratch.argtypes = [i32]
+    L.fmsi_hip_keep_scratch.argtypes = [i32]
+    L.fmsi_hip_keep_scratch.restype = None
+    L.fmsi_hip_scratch_bytes.argtypes = [i32]
+    L.fmsi_hip_scratch_bytes.restype = u64
     L.fmsi_hip_synthetic_reads.argtypes = [vp, u64, u64, u64, u64, u32, vp, vp]
     L.fmsi_hip_query_kmers.argtypes = [vp, vp, u64, i32, u32, vp, vp, vp]
     L.fmsi_hip_query_windows.argtypes = [vp, vp, u64, vp, u64, i32, u32, vp, vp, vp]
@@ -567,6 +571,31 @@ def decode_strict(out: np.ndarray):
 def trim_scratch(device: int = 0) -> None:
     """Return the library's cached device blocks (temporaries of the builders) to the driver (fmsi_hip_trim_scratch)."""
     _check(lib().fmsi_hip_trim_scratch(device))
+
+
+def scratch_bytes(device: int = 0) -> int:
+    """Bytes of freed device blocks the library keeps for reuse (fmsi_hip_scratch_bytes)."""
+    return int(lib().fmsi_hip_scratch_bytes(device))
+
+
+class builder_chain:
+    """`with builder_chain(device):` -- a chain of builder calls (build / load, enable_pair_layout, enable_dict ...) shares the library's
+    cached device blocks (fmsi_hip_keep_scratch) and returns them to the driver once, when the chain ends."""
+
+    def __init__(self, device: int = 0):
+        self.device = device
+
+    def __enter__(self):
+        lib().fmsi_hip_keep_scratch(1)
+        return self
+
+    def __exit__(self, *exc):
+        lib().fmsi_hip_keep_scratch(0)
+        try:
+            trim_scratch(self.device)
+        except FmsiError:
+            pass
+        return False
 
 
 def packed_words(n: int, flags: int) -> int:

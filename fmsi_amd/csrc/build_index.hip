@@ -582,6 +582,7 @@ __global__ __launch_bounds__(256) void pack_chars_kernel(const char* __restrict_
 }  // namespace
 
 int fmsi_hip_index_build(const char* ms, uint64_t len, int k, int with_klcp, int device, int prefix_len, fmsi_hip_index** out) {
+    ::fmsi::ScratchScope scratch_scope_(device);   // (devpool.h: the outermost builder returns the block cache to the driver)
     if (!ms || !out || k < 1 || (with_klcp && k > 64)) {
         set_last_error("bad argument (on-device kLCP construction needs k <= 64)");
         return FMSI_HIP_EINVAL;
@@ -672,6 +673,7 @@ int fmsi_hip_index_build_synthetic_repeats(uint64_t len, uint64_t seed, int k, i
 }
 
 int fmsi_hip_index_build_synthetic_spec(const fmsi_hip_synthetic_spec* spec, int device, fmsi_hip_index** out) {
+    ::fmsi::ScratchScope scratch_scope_(device);   // (devpool.h: the outermost builder returns the block cache to the driver)
     if (!spec || !out || spec->k < 1 || spec->len < static_cast<uint64_t>(spec->k) || (spec->with_klcp && spec->k > 64) ||
         spec->repeat_permille > 1000 || spec->divergence_permille > 1000 || spec->mask_permille > 1000) {
         set_last_error("bad argument (on-device kLCP construction needs k <= 64)");
@@ -958,6 +960,7 @@ int load_fail(int code, const std::string& msg) {
 }  // namespace fmsi
 
 extern "C" int fmsi_hip_index_load(const char* prefix_c, int use_klcp, int device, int prefix_len, fmsi_hip_index** out) {
+    ::fmsi::ScratchScope scratch_scope_(device);   // (devpool.h: the outermost builder returns the block cache to the driver)
     if (!prefix_c || !out) return load_fail(FMSI_HIP_EINVAL, "null argument");
     TraceRange trace_range("fmsi: load index files into HBM");
     PhaseClock clock{"load"};
@@ -1002,6 +1005,12 @@ extern "C" int fmsi_hip_index_load(const char* prefix_c, int use_klcp, int devic
         if (got != 6) return load_fail(FMSI_HIP_EIO, "malformed " + base + ".misc");
     }
     if (n == 0 || acgt.bits != n || ac.bits + gt.bits != n) return load_fail(FMSI_HIP_EIO, "index parts disagree on the number of rows");
+    // (the reference reads these blindly, fms_index.h:513-524; a kLCP vector of another index, a `$` row or C[] values outside the rows would send
+    // -S queries and LF steps past the arrays)
+    if (with_klcp && klcp.bits != n) return load_fail(FMSI_HIP_EIO, "index parts disagree on the number of rows (" + base + ".klcp)");
+    if (dollar >= n || counts[0] != 1 || counts[0] > counts[1] || counts[1] > counts[2] || counts[2] > counts[3] || counts[3] > n ||
+        counts[2] != ac.bits)   // #A (with the `$` slot) + #C = |ac| (fms_index.h:427-451)
+        return load_fail(FMSI_HIP_EIO, "index not correctly loaded: " + base + ".misc does not belong to these bit-vectors");
     if (n >= (1ull << 32) - kBlockRows || std::getenv("FMSI_HIP_FORCE_ROWS64")) {
         // 64-bit rows go through the host path (fmsi_wide.hip's superblock table is built there)
         fmsi_host_index* host = nullptr;
@@ -1064,6 +1073,13 @@ extern "C" int fmsi_hip_index_load(const char* prefix_c, int use_klcp, int devic
         if ((rc = scan_temp.alloc(tb))) return rc;
         FMSI_HIP_TRY(rocprim::exclusive_scan(scan_temp.p, tb, d_pc.as<uint32_t>(), d_gtoff.as<uint32_t>(), 0u, static_cast<size_t>(n_words + 1), rocprim::plus<uint32_t>()));
     }
+    {   // popcount(ac_gt) must be |gt| (and the rest |ac|) BEFORE layout_words_kernel indexes gt[] / ac[] by ranks in ac_gt: a mismatched
+        // pair of files is an error of the load, not a memory fault on the device
+        uint32_t gt_total = 0;
+        FMSI_HIP_TRY(hipMemcpy(&gt_total, d_gtoff.as<uint32_t>() + n_words, 4, hipMemcpyDeviceToHost));
+        if (gt_total != gt.bits || n - gt_total != ac.bits)
+            return load_fail(FMSI_HIP_EIO, "index not correctly loaded: popcount(ac_gt) != |gt| (" + base + ".ac_gt / .ac / .gt are not one index's)");
+    }
     // ---- the blocks -----------------------------------------------------------------------------------------------------------------
     DevBuf blocks, cnts, cnts_scanned, mcounts, mrank;
     const size_t blocks_bytes = n_blocks * kBlockBytes;
@@ -1087,13 +1103,15 @@ extern "C" int fmsi_hip_index_load(const char* prefix_c, int use_klcp, int devic
         hipLaunchKernelGGL(scatter_counts_kernel, dim3(grid_for(n_blocks)), dim3(256), 0, 0, cnts_scanned.as<U4>(), blocks.as<uint32_t>(), n_blocks);
         FMSI_HIP_TRY(hipGetLastError());
         U4 totals;
-        uint32_t corrupt = 0, gt_total = 0;
+        uint32_t corrupt = 0;
         FMSI_HIP_TRY(hipMemcpy(&totals, cnts_scanned.as<U4>() + n_blocks, sizeof(U4), hipMemcpyDeviceToHost));
         FMSI_HIP_TRY(hipMemcpy(&corrupt, d_corrupt.p, 4, hipMemcpyDeviceToHost));
-        FMSI_HIP_TRY(hipMemcpy(&gt_total, d_gtoff.as<uint32_t>() + n_words, 4, hipMemcpyDeviceToHost));
         FMSI_HIP_TRY(hipDeviceSynchronize());
         if (corrupt) return load_fail(FMSI_HIP_EIO, "rrr_vector<63> image: block offsets run past the end of the offset vector");
-        if (gt_total != gt.bits) return load_fail(FMSI_HIP_EINVAL, "index view: popcount(ac_gt) != |gt|");
+        // the symbol counts of the rows are what C[] says (fms_index.h:451: {1, #A+1, #A+#C+1, #A+#C+#G+1} with the `$` slot stored as 'A')
+        if (static_cast<uint64_t>(totals.a) != counts[1] || static_cast<uint64_t>(totals.a) + totals.c != counts[2] ||
+            static_cast<uint64_t>(totals.a) + totals.c + totals.g != counts[3])
+            return load_fail(FMSI_HIP_EIO, "index not correctly loaded: " + base + ".misc's counts are not those of the bit-vectors");
     }
     clock.mark("mask decoded, blocks laid out");
     auto* idx = new fmsi_hip_index();

@@ -40,10 +40,16 @@ void parallel_for(unsigned team, F&& fn) {   // fn(t) for t in [0, team); t = 0 
     std::vector<std::thread> th;
     std::vector<std::exception_ptr> err(team);
     th.reserve(team - 1);
-    for (unsigned t = 1; t < team; ++t)
-        th.emplace_back([&, t] {
-            try { fn(t); } catch (...) { err[t] = std::current_exception(); }
-        });
+    unsigned started = 1;
+    try {
+        for (; started < team; ++started)
+            th.emplace_back([&, started] {
+                try { fn(started); } catch (...) { err[started] = std::current_exception(); }
+            });
+    } catch (...) {   // a thread that cannot be started: its share and the rest run on the caller
+    }
+    for (unsigned t = started; t < team; ++t)
+        try { fn(t); } catch (...) { err[t] = std::current_exception(); }
     try { fn(0u); } catch (...) { err[0] = std::current_exception(); }
     for (auto& x : th) x.join();
     for (auto& e : err)
@@ -301,12 +307,9 @@ private:
                 std::vector<char> clean(parts, 1);
                 auto nb = std::make_unique<RawBatch>();
                 nb->arenas.resize(parts);
-                std::vector<std::thread> pool;
-                for (size_t w = 0; w < parts; ++w)
-                    pool.emplace_back([&, w] {
-                        clean[w] = parse_range(d, cuts[w], cuts[w + 1], nb->arenas[w], recs[w], seq_bytes[w], parallel_fastq) ? 1 : 0;
-                    });
-                for (std::thread& t : pool) t.join();
+                parallel_for(static_cast<unsigned>(parts), [&](unsigned w) {   // (joins its threads and passes a worker's exception on)
+                    clean[w] = parse_range(d, cuts[w], cuts[w + 1], nb->arenas[w], recs[w], seq_bytes[w], parallel_fastq) ? 1 : 0;
+                });
                 if (std::find(clean.begin(), clean.end(), 0) != clean.end()) {   // a FASTQ record: the ordinary reader from here on
                     serial = true;
                     resume_at = pos;

@@ -1,5 +1,6 @@
 #include "devpool.h"
 
+#include <atomic>
 #include <map>
 #include <mutex>
 #include <unordered_map>
@@ -8,32 +9,52 @@ namespace fmsi {
 namespace {
 
 constexpr size_t kMinCached = size_t(64) << 20;
+constexpr int kMaxDevices = 16;
 
+struct Live {
+    size_t bytes;
+    int device;   // the device the block was allocated on: where it is filed when freed, whatever the thread's current device is then
+};
 struct Pool {
     std::mutex m;
-    std::unordered_map<void*, size_t> live;          // blocks handed out (>= kMinCached only)
-    std::multimap<size_t, void*> cached[16];         // per device: size -> freed block
-    size_t cached_bytes[16] = {};
+    std::unordered_map<void*, Live> live;                    // blocks handed out (>= kMinCached only)
+    std::multimap<size_t, void*> cached[kMaxDevices];        // per device: size -> freed block
+    size_t cached_bytes[kMaxDevices] = {};
 };
 Pool& pool() {
     static Pool* p = new Pool;   // (never destroyed: handles may be freed during process exit)
     return *p;
 }
+std::atomic<int> g_keep{0};
+thread_local int t_scope_depth = 0;
+
 int current_device() {
     int d = 0;
     if (hipGetDevice(&d) != hipSuccess) {
         (void)hipGetLastError();
         return 0;
     }
-    return d < 0 || d >= 16 ? 0 : d;
+    return d < 0 || d >= kMaxDevices ? 0 : d;
+}
+
+// runs fn with `device` current and puts the thread back where it was
+template <class F>
+void on_device(int device, F&& fn) {
+    const int prev = current_device();
+    if (prev != device && hipSetDevice(device) != hipSuccess) (void)hipGetLastError();
+    fn();
+    if (prev != device && hipSetDevice(prev) != hipSuccess) (void)hipGetLastError();
 }
 
 size_t trim_locked(Pool& P, int d) {
     size_t freed = 0;
-    for (auto& e : P.cached[d]) {
-        (void)hipFree(e.second);
-        freed += e.first;
-    }
+    if (P.cached[d].empty()) return 0;
+    on_device(d, [&] {
+        for (auto& e : P.cached[d]) {
+            (void)hipFree(e.second);
+            freed += e.first;
+        }
+    });
     P.cached[d].clear();
     P.cached_bytes[d] = 0;
     return freed;
@@ -42,14 +63,25 @@ size_t trim_locked(Pool& P, int d) {
 }  // namespace
 
 hipError_t dev_malloc(void** p, size_t bytes) {
-    if (bytes < kMinCached) return hipMalloc(p, bytes ? bytes : 8);
     Pool& P = pool();
     const int d = current_device();
+    if (bytes < kMinCached) {
+        hipError_t e = hipMalloc(p, bytes ? bytes : 8);
+        if (e != hipSuccess) {   // the cache may be holding the room a small allocation needs, too
+            std::lock_guard<std::mutex> lk(P.m);
+            if (!P.cached[d].empty()) {
+                (void)hipGetLastError();
+                trim_locked(P, d);
+                e = hipMalloc(p, bytes ? bytes : 8);
+            }
+        }
+        return e;
+    }
     std::lock_guard<std::mutex> lk(P.m);
     auto it = P.cached[d].lower_bound(bytes);
     if (it != P.cached[d].end() && it->first <= bytes + bytes / 4) {   // (best fit, at most a quarter more than asked for)
         *p = it->second;
-        P.live[*p] = it->first;
+        P.live[*p] = Live{it->first, d};
         P.cached_bytes[d] -= it->first;
         P.cached[d].erase(it);
         return hipSuccess;
@@ -60,25 +92,38 @@ hipError_t dev_malloc(void** p, size_t bytes) {
         trim_locked(P, d);
         e = hipMalloc(p, bytes);
     }
-    if (e == hipSuccess) P.live[*p] = bytes;
+    if (e == hipSuccess) P.live[*p] = Live{bytes, d};
     return e;
 }
 
 hipError_t dev_free(void* p) {
     if (!p) return hipSuccess;
     Pool& P = pool();
+    Live l{0, -1};
     {
         std::lock_guard<std::mutex> lk(P.m);
         auto it = P.live.find(p);
         if (it != P.live.end()) {
-            const int d = current_device();
-            P.cached[d].emplace(it->second, p);
-            P.cached_bytes[d] += it->second;
+            l = it->second;
             P.live.erase(it);
-            return hipSuccess;
         }
     }
-    return hipFree(p);
+    if (l.device < 0) return hipFree(p);
+    // hipFree waits for the device before it releases memory; a parked block must offer the same -- the next owner may be another
+    // handle, another stream or a stream-0 builder while a kernel enqueued on the first owner's stream still reads or writes it
+    // (host-pointer query calls are asynchronous, and ensure_cap frees a staging buffer right behind them)
+    hipError_t e = hipSuccess;
+    on_device(l.device, [&] { e = hipDeviceSynchronize(); });
+    if (e != hipSuccess) {   // a device that cannot be waited for: the block is not handed to anybody else
+        (void)hipGetLastError();
+        hipError_t f = hipSuccess;
+        on_device(l.device, [&] { f = hipFree(p); });
+        return f;
+    }
+    std::lock_guard<std::mutex> lk(P.m);
+    P.cached[l.device].emplace(l.bytes, p);
+    P.cached_bytes[l.device] += l.bytes;
+    return hipSuccess;
 }
 
 size_t dev_trim() {
@@ -91,6 +136,18 @@ size_t dev_cached_bytes() {
     Pool& P = pool();
     std::lock_guard<std::mutex> lk(P.m);
     return P.cached_bytes[current_device()];
+}
+
+void dev_keep_scratch(bool on) { g_keep.store(on ? 1 : 0); }
+bool dev_keeps_scratch() { return g_keep.load() != 0; }
+
+ScratchScope::ScratchScope(int device) : device_(device) { ++t_scope_depth; }
+ScratchScope::~ScratchScope() {
+    if (--t_scope_depth > 0 || g_keep.load()) return;   // (a builder inside a builder: the outermost one settles)
+    if (device_ < 0 || device_ >= kMaxDevices) return;
+    Pool& P = pool();
+    std::lock_guard<std::mutex> lk(P.m);
+    trim_locked(P, device_);
 }
 
 }  // namespace fmsi

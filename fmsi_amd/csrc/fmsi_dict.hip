@@ -836,9 +836,21 @@ int add_chain_extras(fmsi_hip_index* idx, DevMem& text2, uint64_t total_slots) {
     idx->device_bytes += extra;
     return 0;
 }
+// The extras are an accelerator of an accelerator: when they cannot be had (no room for posans / slot_pos) the handle keeps the plain
+// dictionary -- installed, consistent, used by every later presence query -- and the call SUCCEEDS; fmsi_hip_index_info.dict_chain_bytes
+// stays 0 and fmsi_hip_last_error() says why.  (An error here used to leave caller and library in disagreement about the handle.)
+int chain_extras_or_warn(fmsi_hip_index* idx, DevMem& text2, uint64_t total_slots) {
+    const int rc = add_chain_extras(idx, text2, total_slots);
+    if (rc) {
+        (void)hipGetLastError();
+        set_last_error(std::string("k-mer dictionary: chained lookups are off (") + fmsi_hip_last_error() + "); the plain dictionary is in use");
+    }
+    return 0;
+}
 }  // namespace
 
 extern "C" int fmsi_hip_index_enable_dict(fmsi_hip_index* idx, uint32_t flags) {
+    ::fmsi::ScratchScope scratch_scope_(idx ? idx->device : -1);   // (devpool.h: the outermost builder returns the block cache to the driver)
     if (!idx) return FMSI_HIP_EINVAL;
     FMSI_HIP_NARROW_ONLY(idx, "the k-mer dictionary");
     if (idx->dict.levels) {
@@ -860,7 +872,7 @@ extern "C" int fmsi_hip_index_enable_dict(fmsi_hip_index* idx, uint32_t flags) {
         }
         uint64_t total_slots = 0;
         for (uint32_t lv = 0; lv < idx->dict.levels; ++lv) total_slots = idx->dict.lv[lv].slot_base + (16ull << (64u - idx->dict.lv[lv].shift));
-        return add_chain_extras(idx, text2, total_slots);
+        return chain_extras_or_warn(idx, text2, total_slots);
     }
     PhaseClock clock{"dict"};
     TraceRange trace_range("fmsi: build k-mer dictionary");
@@ -1039,7 +1051,7 @@ extern "C" int fmsi_hip_index_enable_dict(fmsi_hip_index* idx, uint32_t flags) {
     idx->dict_bytes = bytes_total;
     idx->device_bytes += bytes_total;
     if (flags & FMSI_HIP_DICT_CHAIN) {
-        if ((rc = add_chain_extras(idx, text2, total_slots))) return rc;
+        (void)chain_extras_or_warn(idx, text2, total_slots);
         clock.mark("chain data (self pass)");
     }
     return 0;

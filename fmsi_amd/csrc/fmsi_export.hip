@@ -173,6 +173,7 @@ int export_walk(const fmsi_hip_index* idx, char* d_chars, uint32_t* d_sa) {
 }  // namespace fmsi
 
 extern "C" int fmsi_hip_index_export(const fmsi_hip_index* idx, char* out, uint64_t out_capacity, uint64_t* out_len) {
+    ::fmsi::ScratchScope scratch_scope_(idx ? idx->device : -1);   // (devpool.h: the outermost builder returns the block cache to the driver)
     if (!idx || !out || !out_len) {
         set_last_error("null argument");
         return FMSI_HIP_EINVAL;

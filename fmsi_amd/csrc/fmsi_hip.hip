@@ -734,6 +734,7 @@ int fmsi_hip_device_count(void) {
 }
 
 int fmsi_hip_index_create(const fmsi_index_view* view, int device, fmsi_hip_index** out) {
+    ::fmsi::ScratchScope scratch_scope_(device);   // (devpool.h: the outermost builder returns the block cache to the driver)
     if (!view || !out || !view->ac_gt || !view->ac || !view->gt || !view->mask) {
         set_last_error("null argument");
         return FMSI_HIP_EINVAL;
@@ -840,6 +841,13 @@ int fmsi_hip_trim_scratch(int device) {
     return 0;
 }
 
+void fmsi_hip_keep_scratch(int on) { dev_keep_scratch(on != 0); }
+uint64_t fmsi_hip_scratch_bytes(int device) {
+    if (device < 0 || device >= fmsi_hip_device_count()) return 0;
+    ::fmsi::DeviceGuard device_guard_(device);
+    return dev_cached_bytes();
+}
+
 void fmsi_hip_index_destroy(fmsi_hip_index* idx) {
     if (!idx) return;
     ::fmsi::DeviceGuard device_guard_(idx->device);
@@ -892,6 +900,7 @@ int fmsi_hip_index_download_layout(const fmsi_hip_index* idx, uint32_t* blocks, 
 }
 
 int fmsi_hip_index_write_files(const fmsi_hip_index* idx, const char* prefix) {
+    ::fmsi::ScratchScope scratch_scope_(idx ? idx->device : -1);   // (devpool.h: the outermost builder returns the block cache to the driver)
     if (!idx || !prefix) return FMSI_HIP_EINVAL;
     FMSI_HIP_ON_DEVICE(idx->device);
     // (no clearing pass over buffers the copies fill: 1.4 GB of blocks at human scale)

@@ -1300,6 +1300,7 @@ void launch_pair_query(fmsi_hip_index* idx, const uint64_t* d_kmers, uint64_t n,
 using namespace fmsi;
 
 extern "C" int fmsi_hip_index_enable_pair_layout(fmsi_hip_index* idx) {
+    ::fmsi::ScratchScope scratch_scope_(idx ? idx->device : -1);   // (devpool.h: the outermost builder returns the block cache to the driver)
     if (!idx) return FMSI_HIP_EINVAL;
     FMSI_HIP_NARROW_ONLY(idx, "this accelerator");
     if (idx->d_pblocks) return 0;
@@ -1493,6 +1494,7 @@ __global__ __launch_bounds__(256) void verify_fill_kernel(const uint2* __restric
 }  // namespace fmsi
 
 extern "C" int fmsi_hip_index_enable_verify(fmsi_hip_index* idx) {
+    ::fmsi::ScratchScope scratch_scope_(idx ? idx->device : -1);   // (devpool.h: the outermost builder returns the block cache to the driver)
     if (!idx) return FMSI_HIP_EINVAL;
     FMSI_HIP_NARROW_ONLY(idx, "this accelerator");
     if (idx->d_vtable) return 0;

@@ -178,6 +178,11 @@ int run_index(int argc, char** argv) {
 // No exception crosses the C boundary: the reference lets std::invalid_argument from its parser terminate the
 // process (src/parser.h:22-29); here the message is printed and the exit code is 1.
 extern "C" int fmsi_cli_index(int argc, char** argv) {
+    // the command is a chain of builder calls in a process of its own: they share the library's block cache (include/fmsi_hip.h)
+    struct KeepScratch {
+        KeepScratch() { fmsi_hip_keep_scratch(1); }
+        ~KeepScratch() { fmsi_hip_keep_scratch(0); }
+    } keep_scratch_;
     try {
         return run_index(argc, argv);
     } catch (const std::exception& e) {
@@ -256,6 +261,11 @@ int run_export(int argc, char** argv) {
 }  // namespace
 
 extern "C" int fmsi_cli_export(int argc, char** argv) {
+    // the command is a chain of builder calls in a process of its own: they share the library's block cache (include/fmsi_hip.h)
+    struct KeepScratch {
+        KeepScratch() { fmsi_hip_keep_scratch(1); }
+        ~KeepScratch() { fmsi_hip_keep_scratch(0); }
+    } keep_scratch_;
     try {
         return run_export(argc, argv);
     } catch (const std::exception& e) {

@@ -8,6 +8,8 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
+#include <exception>
+#include <string>
 #include <thread>
 #include <vector>
 
@@ -208,21 +210,38 @@ int write_index_files(const std::string& prefix, const fmsi_index_view& v, std::
     std::string errs[4];
     bool oks[4] = {true, true, true, true};
     auto bv_into = [&](int slot, const char* ext, const uint64_t* words, uint64_t bits) {
-        Out o(base + "." + ext);
-        o.bit_vector(words, bits);
-        if (!o.ok) errs[slot] = "cannot write " + base + "." + ext;
-        oks[slot] = o.ok;
+        try {
+            Out o(base + "." + ext);
+            o.bit_vector(words, bits);
+            oks[slot] = o.ok;
+        } catch (...) {   // (out of memory in a writer thread: an error of this call, not std::terminate)
+            oks[slot] = false;
+        }
+        if (!oks[slot]) errs[slot] = "cannot write " + base + "." + ext;
     };
     std::vector<std::thread> writers;
-    writers.emplace_back(bv_into, 0, "ac_gt", v.ac_gt, v.ac_gt_bits);
-    writers.emplace_back(bv_into, 1, "ac", v.ac, v.ac_bits);
-    writers.emplace_back(bv_into, 2, "gt", v.gt, v.gt_bits);
-    if (v.klcp && v.klcp_bits) writers.emplace_back(bv_into, 3, "klcp", v.klcp, v.klcp_bits);   // fms_index.h:490-492
-    bool mask_ok;
-    {
+    struct JoinAll {   // whatever leaves this function -- the encoder may throw std::bad_alloc -- no thread is destroyed while joinable
+        std::vector<std::thread>& t;
+        ~JoinAll() {
+            for (std::thread& x : t)
+                if (x.joinable()) x.join();
+        }
+    } join_all{writers};
+    bool mask_ok = false;
+    try {
+        writers.reserve(4);
+        writers.emplace_back(bv_into, 0, "ac_gt", v.ac_gt, v.ac_gt_bits);
+        writers.emplace_back(bv_into, 1, "ac", v.ac, v.ac_bits);
+        writers.emplace_back(bv_into, 2, "gt", v.gt, v.gt_bits);
+        if (v.klcp && v.klcp_bits) writers.emplace_back(bv_into, 3, "klcp", v.klcp, v.klcp_bits);   // fms_index.h:490-492
         Out o(base + ".mask");
         write_rrr63(o, v.mask, v.mask_bits);
         mask_ok = o.ok;
+    } catch (const std::exception& e) {
+        for (std::thread& t : writers)
+            if (t.joinable()) t.join();
+        err = std::string("cannot write the index files: ") + e.what();
+        return FMSI_HIP_ENOMEM;
     }
     for (std::thread& t : writers) t.join();
     for (int i = 0; i < 4; ++i)

@@ -41,6 +41,17 @@ int build_layout(const fmsi_index_view& v, HostLayout& L) {
         set_last_error("index view: ac_gt/ac/gt/mask sizes are inconsistent");
         return FMSI_HIP_EINVAL;
     }
+    // the scalars of .misc and the optional kLCP vector must belong to these rows (the reference reads them blindly, fms_index.h:513-524):
+    // LF steps add C[c] to a rank and -S scans klcp[] by row, so anything outside [0, n] would index past the arrays on the device
+    if (v.dollar_position >= n || v.counts[0] != 1 || v.counts[0] > v.counts[1] || v.counts[1] > v.counts[2] || v.counts[2] > v.counts[3] ||
+        v.counts[3] > n || v.counts[2] != v.ac_bits) {
+        set_last_error("index view: dollar_position / counts[] do not belong to these bit-vectors");
+        return FMSI_HIP_EINVAL;
+    }
+    if (v.klcp && v.klcp_bits && v.klcp_bits != n) {
+        set_last_error("index view: the kLCP vector has another number of rows");
+        return FMSI_HIP_EINVAL;
+    }
     const uint64_t n_words = (n + 63) >> 6;
     const uint64_t n_blocks = ((n + kBlockRows - 1) >> kBlockRowsLog2) + 1;
     L.n_blocks = n_blocks;

@@ -39,6 +39,13 @@ int main(int argc, char* argv[]) {
         std::cout.flush();
         std::cerr.flush();
         std::fflush(nullptr);
+        // ... unless something in the process writes its output when the process is finalised: rocprofv3 / rocprofiler-sdk and rocTX
+        // (trace.h's ranges), sanitizers, gcov.  Then the ordinary exit runs the atexit handlers and library destructors.
+        for (const char* v : {"ROCP_TOOL_LIBRARIES", "ROCPROFILER_REGISTER_FORCE_LOAD", "HSA_TOOLS_LIB", "LD_PRELOAD", "ASAN_OPTIONS", "TSAN_OPTIONS",
+                              "UBSAN_OPTIONS", "GCOV_PREFIX", "FMSI_HIP_CLI_FULL_EXIT"}) {
+            const char* e = std::getenv(v);
+            if (e && *e) std::exit(rc);
+        }
         _exit(rc);
     }
     if (op == "index") return fmsi_cli_index(argc - 1, argv + 1);

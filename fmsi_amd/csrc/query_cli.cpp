@@ -645,6 +645,11 @@ void check(int rc, const char* what) {
 using namespace fmsi;
 
 extern "C" int fmsi_cli_query(int argc, char** argv, int output_orders_i) {
+    // the command is a chain of builder calls in a process of its own: they share the library's block cache (include/fmsi_hip.h)
+    struct KeepScratch {
+        KeepScratch() { fmsi_hip_keep_scratch(1); }
+        ~KeepScratch() { fmsi_hip_keep_scratch(0); }
+    } keep_scratch_;
     const bool output_orders = output_orders_i != 0;
     Options opt;
     opt.output_orders = output_orders;

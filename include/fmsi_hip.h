@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define FMSI_HIP_ABI_VERSION 4   /* 4: fmsi_hip_query_runs_fn (`-f and|xor|r-s`); 2: fmsi_hip_index_info.candidate_entry_bytes, fmsi_hip_comm_*, fmsi_hip_gather; 3: FMSI_HIP_OUT_BITS, fmsi_hip_index_load, fmsi_hip_trim_scratch, fmsi_hip_index_enable_dict + fmsi_hip_index_info.dict_*, fmsi_hip_index_build_synthetic_spec */
+#define FMSI_HIP_ABI_VERSION 5   /* 5: fmsi_hip_keep_scratch; 4: fmsi_hip_query_runs_fn (`-f and|xor|r-s`); 2: fmsi_hip_index_info.candidate_entry_bytes, fmsi_hip_comm_*, fmsi_hip_gather; 3: FMSI_HIP_OUT_BITS, fmsi_hip_index_load, fmsi_hip_trim_scratch, fmsi_hip_index_enable_dict + fmsi_hip_index_info.dict_*, fmsi_hip_index_build_synthetic_spec */
 
 /* error codes */
 #define FMSI_HIP_OK 0
@@ -306,6 +306,14 @@ int fmsi_hip_sync(fmsi_hip_index* idx, void* stream);
  * load mostly waits for on this platform -- and returns them to the driver when an allocation of its own fails or a handle
  * is destroyed.  A host that needs the HBM for itself in between calls this. */
 int fmsi_hip_trim_scratch(int device);
+/* By default every builder call (index build / load, pair layout, candidate tables, dictionary, export, file writer) returns that cache to
+ * the driver when it ends, so that nothing the handle's info does not count stays on the device.  A host that runs a CHAIN of builders
+ * turns that off for the chain -- they then hand each other their temporaries instead of waiting for the allocator -- and trims once:
+ *   fmsi_hip_keep_scratch(1); load / build; enable_pair_layout; enable_dict; fmsi_hip_keep_scratch(0); fmsi_hip_trim_scratch(device);
+ * Process-wide. */
+void fmsi_hip_keep_scratch(int on);
+/* bytes of freed blocks the library currently keeps for reuse on `device` (not part of any handle's device_bytes) */
+uint64_t fmsi_hip_scratch_bytes(int device);
 /* Page-locked host memory for the caller's batch buffers (hipHostMalloc / hipHostFree).  Any host memory works with the
  * query calls; from page-locked memory the copies to and from the device run at the link's rate instead of through the
  * driver's staging (the CLI's device stage: 0.4-0.6 s -> see DESIGN.md 8 per 10^9 windows).  NULL when it cannot be had. */

@@ -81,6 +81,8 @@ int fmsi_hip_index_enable_dict(fmsi_hip_index*, uint32_t) { return 0; }
 int fmsi_hip_index_enable_pair_layout(fmsi_hip_index*) { return 0; }
 int fmsi_hip_index_enable_verify(fmsi_hip_index*) { return 0; }
 int fmsi_hip_sync(fmsi_hip_index*, void*) { return 0; }
+void fmsi_hip_keep_scratch(int) {}
+int fmsi_hip_trim_scratch(int) { return 0; }
 int fmsi_hip_query_runs(fmsi_hip_index*, const uint64_t* seq, uint64_t, const uint64_t* run_start, const uint32_t* run_windows, uint64_t n_runs,
                         uint64_t n_windows, int k, uint32_t flags, void* out, uint64_t*, void*) {
     return run_all(seq, run_start, run_windows, n_runs, n_windows, k, flags, 0, out);

@@ -279,3 +279,84 @@ def test_device_load_at_scale_and_corrupt_files(fm, oracle_built, tmp_path):
         with pytest.raises(fm.FmsiError) as e:
             fm.DeviceIndex.load(prefix)
         assert e.value.code == fm.E_IO
+
+
+def test_device_load_rejects_parts_of_different_indexes(fm, oracle_built, tmp_path):
+    """Header-consistent but MISMATCHED index parts -- .ac / .gt of another index of the same length, a .klcp of another length, a .misc
+    whose `$` row or C[] lie outside the rows or belong to another text -- are FMSI_HIP_EIO ("index not correctly loaded") on the
+    device-load path, decided BEFORE any kernel indexes gt[] / ac[] by ranks taken from ac_gt (the layout kernel used to run first and
+    read past the device allocations), and the process goes on to load and query a good index afterwards."""
+    import shutil
+    from conftest import synthetic_ms
+    n, k = 300_000, 21
+    pa, pb, pc = (str(tmp_path / t) for t in "abc")
+    oracle_py.Oracle.construct(synthetic_ms(n, k, seed=11, mask="mixed"), k, use_klcp=True).dump(pa)
+    # another text of the same length with a skewed composition: popcount(ac_gt) differs by thousands
+    rng = np.random.default_rng(3)
+    skew = "".join(np.frombuffer(b"ACGT", dtype=np.uint8)[rng.choice(4, size=n, p=[0.4, 0.3, 0.2, 0.1])].tobytes().decode())
+    skew = skew[: n - (k - 1)] + skew[n - (k - 1):].lower()
+    oracle_py.Oracle.construct(skew, k, use_klcp=True).dump(pb)
+    oracle_py.Oracle.construct(synthetic_ms(n // 2, k, seed=12, mask="mixed"), k, use_klcp=True).dump(pc)
+    parts = ("ac_gt", "ac", "gt", "mask", "klcp", "misc")
+
+    def mixed(tag, **take):
+        dst = str(tmp_path / tag)
+        for part in parts:
+            shutil.copy(f"{take.get(part, pa)}.fmsi.{part}", f"{dst}.fmsi.{part}")
+        return dst
+
+    cases = {
+        "gt_ac_of_b": mixed("m1", ac=pb, gt=pb),          # |ac| + |gt| = n still holds
+        "acgt_of_b": mixed("m2", ac_gt=pb),
+        "klcp_of_c": mixed("m3", klcp=pc),
+        "misc_of_b": mixed("m4", misc=pb),
+    }
+    d = mixed("m5")
+    lines = open(d + ".fmsi.misc").read().split()
+    open(d + ".fmsi.misc", "w").write("\n".join([str(n + 5)] + lines[1:]) + "\n")   # `$` row outside the rows
+    cases["dollar_outside"] = d
+    d = mixed("m6")
+    open(d + ".fmsi.misc", "w").write("\n".join([lines[0], lines[1], lines[3], lines[2], lines[4], lines[5]]) + "\n")   # C[] not monotone
+    cases["counts_not_monotone"] = d
+    for tag, prefix in cases.items():
+        with pytest.raises(fm.FmsiError) as e:
+            fm.DeviceIndex.load(prefix, use_klcp=True)
+        assert e.value.code == fm.E_IO, tag
+        with pytest.raises(fm.FmsiError):   # the host path refuses them too (build_layout's checks)
+            fm.DeviceIndex.from_files(prefix, use_klcp=True)
+    good = fm.DeviceIndex.load(pa, use_klcp=True, prefix_len=6)
+    ms = synthetic_ms(n, k, seed=11, mask="mixed").upper()
+    kmers = [ms[p:p + k] for p in range(0, 4000, 7)]
+    got = good.query_kmers(fm.pack_kmers(kmers, k), k, fm.MODE_OR)
+    orc = oracle_py.Oracle.load(pa)
+    wf, wr = orc.ternaries_bulk("".join(kmers).encode(), len(kmers), k, False)
+    assert np.array_equal(got, (np.maximum(wf, wr) == 1).astype(np.uint8))
+
+
+def test_block_cache_rules(fm):
+    """devpool.h: by default a builder returns the cache of large freed blocks to the driver when it ends (nothing the handle's info does
+    not count stays on the device); inside builder_chain the blocks stay for the next builder and go back when the chain ends."""
+    n, k = 300_000_000, 31   # (temporaries of 0.3-2.4 GB: well above the cache's 64 MB threshold)
+    assert fm.scratch_bytes(0) == 0
+    dev = fm.DeviceIndex.build_synthetic(n, 5, k)
+    assert fm.scratch_bytes(0) == 0
+    dev.enable_pair_layout()
+    assert fm.scratch_bytes(0) == 0
+    del dev
+    with fm.builder_chain(0):
+        dev = fm.DeviceIndex.build_synthetic(n, 5, k)
+        kept = fm.scratch_bytes(0)
+        assert kept > (1 << 30)
+        dev.enable_pair_layout().enable_dict()
+        assert fm.scratch_bytes(0) > 0
+    assert fm.scratch_bytes(0) == 0
+    import torch
+    d_k = torch.empty(1 << 20, dtype=torch.int64, device="cuda")
+    d_o = torch.empty(1 << 20, dtype=torch.uint8, device="cuda")
+    s = torch.cuda.current_stream().cuda_stream
+    dev.synthetic_queries_dev(k, 42, 0, 1 << 20, d_k.data_ptr(), s)
+    dev.query_kmers_dev(d_k.data_ptr(), 1 << 20, k, fm.MODE_ALL | fm.KERNEL_DICT, d_o.data_ptr(), stream=s)
+    a = d_o.cpu().numpy().copy()
+    dev.query_kmers_dev(d_k.data_ptr(), 1 << 20, k, fm.MODE_ALL | fm.KERNEL_PAIR | fm.NO_PREFIX_TABLE, d_o.data_ptr(), stream=s)
+    torch.cuda.synchronize()
+    assert np.array_equal(a, d_o.cpu().numpy()) and 0.45 < a.mean() < 0.55

@@ -25,11 +25,14 @@ pytestmark = pytest.mark.gpu
 sys.path.insert(0, str(REPO))
 
 
-@pytest.fixture(scope="module")
+@pytest.fixture
 def fm(product_built):
     if product_built.device_count() < 1:
         pytest.fail("no HIP device visible: the gpu tests must run on an MI355X")
-    return product_built
+    # every test here runs a chain of builders over tens of GB of temporaries: they share the library's block cache (devpool.h) and
+    # return it once, when the test ends
+    with product_built.builder_chain(0):
+        yield product_built
 
 
 def kmers_text(kmers: np.ndarray, k: int) -> bytes:

@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol(product_built):
     assert len(names) >= 18
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/fmsi_hip.h but not exported"
-    assert lib.fmsi_hip_abi_version() == 4
+    assert lib.fmsi_hip_abi_version() == 5
 
 
 def test_no_oracle_in_product():
@@ -425,7 +425,9 @@ def test_layout_of_many_chunks_equals_numpy(product_built):
         b = np.concatenate([bits, np.zeros(pad + 64, dtype=np.uint8)])
         return np.packbits(b.reshape(-1, 8), axis=1, bitorder="little").reshape(-1).view(np.uint64).copy(), len(bits)
 
-    view, keep = fm.view_from_arrays(words(hi), words(ac), words(gt), words(maskbits), [1, 2, 3, 4], 0, 31)
+    # (C[] as construct() writes it, fms_index.h:451, the `$` slot counted among the A rows: build_layout checks it against |ac|)
+    cnt = [1, int((sym == 0).sum()), int((sym <= 1).sum()), int((sym <= 2).sum())]
+    view, keep = fm.view_from_arrays(words(hi), words(ac), words(gt), words(maskbits), cnt, 0, 31)
     nb = int(fm.lib().fmsi_host_layout_blocks(C.byref(view)))
     blocks = np.zeros((nb, 16), dtype=np.uint32)
     mrank = np.zeros(nb + 1, dtype=np.uint32)
