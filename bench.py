@@ -6,43 +6,40 @@ torch.distributed.run with one rank per GPU.  One "step" = one pass of the hot p
 synthetic queries that is already resident in HBM; W untimed steps, then exactly K timed steps bracketed by
 barrier + synchronize, MAX over ranks, one JSON line from rank 0.
 
-Workloads (BASELINE.json configs; all on a synthetic max-ones masked superstring of --n bases that is
-generated and indexed on the device, replicated per GPU):
-  --workload kmers   (default; configs 2/3/5) isolated random 31-mers, half of them present (half of those as the
-                     reverse complement), `fmsi query -O` semantics: fmsi_hip_query_kmers, forward strand first.
-  --workload stream  (config 4) reads of --read-len bases (half substrings of the superstring, half of those
-                     reverse-complemented; half uniform random), `fmsi query -S -O`: fmsi_hip_query_stream (kLCP).
-The seeded, counter-based query stream is sharded across ranks by contiguous ranges -- weak scaling, no collective
-inside the search.  Results are bit-packed (FMSI_HIP_OUT_BITS: what the reference prints, one symbol per window,
-src/fms_index.h:305-309) and their way to the host is INSIDE the timed region: every step's words are gathered to rank 0
-over RCCL (N > 1) and copied to page-locked host memory on a copy stream, double-buffered against the next step's kernel
-(`--byte-results`: the round-1 form -- bytes left in HBM, gather after the timed region).
+The line's `value` (headline; BASELINE.json configs 3/5's workload at N GPUs): a synthetic max-ones masked superstring of 2.8 x 10^9
+bases, generated and indexed on the device and replicated per GPU; 2^27 isolated random 31-mers per step and GPU, half of them present
+(half of those as the reverse complement), `fmsi query -O` semantics, answered by the handle's k-mer dictionary -- a hash table of the
+answers the index gives, ONE 128-byte read and NO LF step per k-mer; the LF walk itself is timed in `roofline.lf_path`.
+The seeded, counter-based query stream is sharded across ranks by contiguous ranges -- weak scaling, no collective inside the search.
+Results are bit-packed (FMSI_HIP_OUT_BITS: what the reference prints, one symbol per window, src/fms_index.h:305-309) and their way to the
+host is INSIDE the timed region: every step's words are gathered to rank 0's HBM over RCCL (N > 1) and copied to page-locked host memory on
+a copy stream, double-buffered against the next step's kernel (`--host-copy per-rank`, default: every rank copies its own words over its
+own PCIe link; `root`: rank 0 copies all N ranks' words).
 
 Extra objects on the JSON line:
-  roofline     -- HBM bound.  `achieved` = algorithmic bytes of one launch / average kernel duration.  The bytes are
-                  what this layout must touch, counted by the kernels themselves: 64 B per table line, 128 B per
-                  pair-layout block (64 B per single-step block), 32 B per candidate / text read, 8 B per kLCP word
-                  when streaming, + query bytes in + 1 B result out per window; the duration comes from HIP events
-                  recorded on the launch stream inside the library, around the launch's kernels (the default `phased`
-                  form is two: lookup + stepping).  `random_requests_per_s` is the figure the path is really bound by
-                  (DESIGN.md 3, 5): random requests, not bytes -- `request_roofline` prices it against the chip's measured
-                  ceiling of 48 G random line requests/s (tools/gather_bench entry, profiles/r01k_gather_entry.txt).  A table
-                  line counts 64 B (the smallest HBM access) although the entry used is 16 or 32 bytes: `useful_*` counts
-                  the entry's bytes instead.
-                  `canonical_achieved` applies SURVEY 8(d)'s reference-layout formula (256 B per LF step the REFERENCE
-                  algorithm executes for the same queries + 64 B per mask probe + in/out) to the same time; it can
-                  exceed the HBM peak because the fused layout and the prefix table touch far fewer bytes.
-                  `traffic` = HBM bytes per launch of the timed kernel, MEASURED IN THIS RUN when rocprofv3 is there (default
-                  dictionary path, N = 1): two child runs of this script under `rocprofv3 --pmc` (FETCH_SIZE / WRITE_SIZE, separate
-                  passes, corrected as MI355X_MICROARCH.md prescribes; `traffic_source` says how) -- else from the passes committed
-                  under profiles/ when their configuration is the one being run.  `lf_path` = the table-less LF walk on the same
-                  index in timed legs of its own (two-base steps; lock-step), the path north_star names.
-  cpu_baseline -- the real reference (oracle/_ref, kind "reference") or the C restatement (kind "port") timed on
-                  this box's host cores on a bounded sample of the same queries against the same index (bench_cpu.py).
+  roofline     -- HBM bound, for the headline's kernel.  `achieved` = algorithmic bytes of one launch / average kernel duration (HIP events
+                  recorded on the launch stream inside the library).  `traffic` = HBM bytes per launch MEASURED IN THIS RUN: this script is
+                  run twice more as a child under `rocprofv3 --pmc` (FETCH_SIZE and WRITE_SIZE in passes of their own, corrected as
+                  MI355X_MICROARCH.md prescribes; `traffic_source` says how).  `lf_path` = the table-less LF walk on the same index in
+                  timed legs of its own -- two-base steps (query_pair_kernel) and one lane per k-mer in lock-step (query_lockstep_kernel),
+                  the path north_star names -- each with `algorithmic_incl_cache` (block reads x block bytes / time: includes the top of
+                  the search tree, which the caches serve) and `hbm_frac` (PMC bytes of the same child runs / time / 8 TB/s).
+  cpu_baseline -- the real reference (oracle/_ref, kind "reference") or the C restatement (kind "port") timed on this box's host cores
+                  on a bounded sample of the same queries against the same index (bench_cpu.py).
+  configs      -- (N = 1, default workload) one entry per further BASELINE configuration, each measured in a child process of this
+                  script on a freshly built index, with kernel time, algorithmic bytes, PMC traffic (in-run child passes) and a sample
+                  checked against the real reference:
+                    c2  E. coli scale (n = 4.7 x 10^6), 10^8 isolated 31-mers per step: cache resident, L2-level GB/s, frac null
+                    c3  pangenome scale (n = 1.4 x 10^9), 2^27 per step x 8 steps >= 10^9 queries
+                    c4  human scale, reads of 10 kb with `-S -O` answers, three ways -- chained dictionary lookups, plain dictionary
+                        lookups, the kLCP kernel (what -S means in the reference) -- each without and with 1 % substitutions
+                    e2e the whole `fmsi query` process (index load + parse + device + print), default / -O / -S -O
+                  `--no-config-legs` skips them; `--legs c2,c4` picks.
 """
 import argparse
 import json
 import os
+import re
 import sys
 import time
 from pathlib import Path
@@ -51,9 +48,11 @@ REPO = Path(__file__).resolve().parent
 sys.path.insert(0, str(REPO))
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak (MI355X_MICROARCH.md); ~6.3 TB/s is the measured streaming ceiling
+REQUEST_PEAK_G = 48.0   # random line requests/s the chip serves (tools/gather_bench entry, profiles/r01k_gather_entry.txt)
+MARKER_KERNELS = ("synth_queries_kernel", "synth_reads_kernel")   # every variant of a PMC child run starts by drawing its input
 
 
-def parse_args():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -71,7 +70,7 @@ def parse_args():
                     help="phased = pair layout, table lookups in their own kernel (default); pair = the same in one kernel")
     ap.add_argument("--accel", choices=["dict", "tables"], default="dict",
                     help="private accelerator of the phased workload: dict = the k-mer dictionary (fmsi_hip_index_enable_dict: one 128-byte "
-                         "bucket read per k-mer, ~12 bytes of HBM per distinct k-mer); tables = prefix table + candidate tables (177 GB at t = 16)")
+                         "bucket read per k-mer, ~13 bytes of HBM per distinct k-mer); tables = prefix table + candidate tables (177 GB at t = 16)")
     ap.add_argument("--dict-sparse", action="store_true", help="dictionary at half the load (twice the HBM, no second-level reads)")
     ap.add_argument("--no-dict-chain", dest="dict_chain", action="store_false",
                     help="stream workload: the dictionary without the extras of chained lookups (FMSI_HIP_DICT_CHAIN, + about 7 B per k-mer: 58.7 "
@@ -103,160 +102,77 @@ def parse_args():
                     help="one result byte per window and no device-to-host copy in the timed region (the round-1 form of the benchmark); "
                          "default: FMSI_HIP_OUT_BITS -- bit-packed results, each step's words copied to page-locked host memory (double "
                          "buffered) and, for N > 1, gathered to rank 0 over RCCL first, all inside the timed region")
+    ap.add_argument("--host-copy", choices=["per-rank", "root"], default="per-rank",
+                    help="N > 1, packed results: per-rank = every rank copies ITS OWN step's words to its page-locked host buffer over its own "
+                         "PCIe link while the RCCL gather brings all ranks' words to rank 0's HBM (both inside the timed region); root = rank 0 "
+                         "copies all N ranks' words after the gather (one PCIe link carries N x 16.8 MB per step).  The other form is timed in a "
+                         "short region of its own afterwards and reported in config.gather")
+    ap.add_argument("--stagger-build", type=float, default=0.0, help="N > 1: rank r starts its index build r x this many seconds late")
     ap.add_argument("--no-lf-leg", action="store_true", help="skip the table-less LF-walk legs (roofline.lf_path)")
     ap.add_argument("--no-pmc", action="store_true",
-                    help="do not measure roofline.traffic in this run (two child runs of this script under rocprofv3 --pmc, FETCH_SIZE and "
-                         "WRITE_SIZE in separate passes); the figure then comes from the committed profiles/*traffic*.json, if one matches")
-    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)   # the child's mode: build, three launches, nothing printed
+                    help="do not measure roofline.traffic in this run (child runs of this script under rocprofv3 --pmc, FETCH_SIZE and "
+                         "WRITE_SIZE in separate passes)")
+    ap.add_argument("--no-config-legs", action="store_true", help="skip the `configs` legs (BASELINE configs 2, 3, 4 and the whole process)")
+    ap.add_argument("--legs", default="c2,c3,c4,e2e", help="which `configs` legs to run")
+    ap.add_argument("--leg", default=None, help=argparse.SUPPRESS)          # child mode: one leg, a JSON list on stdout
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)   # child mode under rocprofv3: the plan's launches, nothing printed
+    ap.add_argument("--pmc-plan", default=None, help=argparse.SUPPRESS)
+    ap.add_argument("--leg-handle", default=None, help=argparse.SUPPRESS)   # (a PMC child of a leg: which leg's handle it rebuilds)
     ap.add_argument("--lf-steps", type=int, default=3, help="timed launches per LF-walk leg")
     ap.add_argument("--stream-via", choices=["auto", "klcp", "runs"], default="auto",
                     help="stream workload: klcp = fmsi_hip_query_stream (the kLCP kernel, what -S means in the reference); runs = the same "
                          "windows through fmsi_hip_query_runs (the dictionary, or phased kernels + candidate tables; same answers -- the "
                          "presence answers of -S do not depend on the kLCP array); auto = runs with --accel dict, else klcp")
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
     if args.stream_via == "auto":
         args.stream_via = "runs" if args.accel == "dict" else "klcp"
     return args
 
 
-def pmc_traffic(args, n, batch, k):
-    """HBM bytes per launch of the timed kernel from the rocprofv3 PMC passes committed under profiles/
-    (FETCH_SIZE and WRITE_SIZE in separate passes, calibrated on random 64-B reads: profiles/README.md).
-    bench.py cannot collect PMC counters itself; the figure is attached only when the run's configuration is
-    the one that was profiled, otherwise null."""
-    best = None
-    for p in sorted((REPO / "profiles").glob("r*_traffic*.json")):
-        try:
-            t = json.loads(p.read_text())
-        except (OSError, ValueError):
-            continue
-        c = t.get("config", {})
-        if (c.get("workload", "kmers"), c.get("n"), c.get("batch"), c.get("k"), c.get("prefix_len"), c.get("mode")) == \
-                (args.workload, n, batch, k, args.prefix_len, args.mode) and c.get("subst_ppm", 0) == args.subst_ppm and \
-                args.repeat_permille == 0 and \
-                ("dict" if getattr(args, "use_dict", False) else "stream" if (args.workload == "stream" and args.stream_via == "klcp") else
-                 ("pair" if (args.kernel == "phased" or args.workload == "stream") else args.kernel)) in t.get("kernel", "") and \
-                c.get("stream_via", "klcp") == (args.stream_via if args.workload == "stream" else "klcp"):
-            best = t
-    return None if best is None else best["hbm_bytes_per_launch"]
+# ======================================================================================================================================
+# process / device context
+# ======================================================================================================================================
+class Ctx:
+    pass
 
 
-def measure_traffic(args, n, batch, k):
-    """HBM bytes per launch of the dictionary's lookup kernel, measured NOW: this script is run twice more as a child under
-    `rocprofv3 --pmc` -- FETCH_SIZE and WRITE_SIZE cannot share a pass (MI355X_MICROARCH.md, PMC slots) and counters are collected in
-    runs of their own -- with the same index, queries and flags (three launches), and the per-dispatch averages of
-    dict_lookup_kernel<false, ...> are corrected as that guide prescribes: gfx950 tallies a 128-byte request at 64 B in FETCH_SIZE and
-    every read of this kernel is one (buckets by eight lanes x 16 B, k-mers as 512-B wave reads), so fetched = 2 x raw; WRITE_SIZE is
-    exact.  Returns (bytes per launch, description) or (None, reason)."""
-    import csv
-    import glob
-    import shutil
-    import subprocess
-    import tempfile
-    prof = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
-    if prof is None:
-        return None, "rocprofv3 not found"
-    child = [sys.executable, str(REPO / "bench.py"), "--pmc-child", "--steps", "3", "--n", repr(float(n)), "--batch", repr(float(batch)), "--k", str(k),
-             "--seed", str(args.seed), "--query-seed", str(args.query_seed), "--mode", args.mode, "--accel", "dict", "--workload", args.workload,
-             "--read-len", str(args.read_len), "--subst-ppm", str(args.subst_ppm)] + (["--dict-sparse"] if args.dict_sparse else []) + \
-            (["--repeat-permille", str(args.repeat_permille), "--repeat-families", str(args.repeat_families),
-              "--repeat-divergence-permille", str(args.repeat_divergence_permille)] if args.repeat_permille else [])
-    import fmsi_amd as fm
-    fm.trim_scratch(int(os.environ.get("LOCAL_RANK", "0")))   # the child builds the same index beside this process: give it the room
-    # the timed kernel's name as rocprofv3 prints it (the construction of a chained dictionary also runs dict_lookup_kernel<false, true>
-    # once, over the text: not that one)
-    if args.workload == "stream":
-        kernel_tag = "dict_chain_kernel<false>" if args.dict_chain else "dict_lookup_kernel<false, true>"
-        child += [] if args.dict_chain else ["--no-dict-chain"]
-    else:
-        kernel_tag = "dict_lookup_kernel<false, false>"
-    got = {}
-    env = dict(os.environ, TMPDIR="/tmp")
-    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
-        with tempfile.TemporaryDirectory(dir="/tmp") as d:
-            try:
-                res = subprocess.run([prof, "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "run", "--"] + child, cwd="/tmp", env=env,
-                                     stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=300)
-            except (OSError, subprocess.TimeoutExpired) as e:
-                return None, f"rocprofv3 --pmc {counter}: {e!r}"
-            per = {}
-            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
-                with open(f, newline="") as fh:
-                    for r in csv.DictReader(fh):
-                        if kernel_tag in r["Kernel_Name"] and r["Counter_Name"] == counter:
-                            per[r["Dispatch_Id"]] = per.get(r["Dispatch_Id"], 0.0) + float(r["Counter_Value"])
-            if res.returncode != 0 or not per:
-                return None, f"rocprofv3 --pmc {counter}: rc {res.returncode}, {len(per)} dispatches ({' '.join(l for l in res.stderr.decode(errors='replace').splitlines() if not l[:1] in 'WIE' or 'rror' in l)[-600:]})"
-            got[counter] = sum(per.values()) / len(per) * 1024.0   # the counters are in KiB
-    return 2.0 * got["FETCH_SIZE"] + got["WRITE_SIZE"], (
-        f"measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (a child run each, 3 launches of {kernel_tag}), "
-        f"2 x raw FETCH_SIZE {got['FETCH_SIZE'] / 1e9:.3f} GB (gfx950 tallies a 128-B request at 64 B) + WRITE_SIZE {got['WRITE_SIZE'] / 1e9:.3f} GB")
-
-
-def run_e2e(args):
-    """--workload e2e: one JSON line for the whole-process rate of the drop-in CLI (default mode), the other modes in `config`."""
-    import subprocess
-    cmd = [sys.executable, str(REPO / "tools" / "e2e_bench.py"), "--n", str(int(args.n)), "--reads", str(args.reads), "--read-len", str(args.read_len),
-           "--k", str(args.k), "--modes", "or,all,all_S,xor,or_full", "--ref-reads", "20"]
-    res = subprocess.run(cmd, capture_output=True, text=True)
-    report = None
-    for l in res.stdout.splitlines():
-        if l.startswith("{"):
-            report = json.loads(l)
-    if res.returncode != 0 or report is None:
-        sys.stderr.write(res.stderr[-2000:])
-        raise RuntimeError("tools/e2e_bench.py failed")
-    m = report["modes"]["or"]
-    modes = {name: {"wall_seconds": e["wall_seconds"], "process_seconds": e.get("total_seconds"), "load_seconds": e.get("load_seconds"),
-                    "windows_per_s_whole_process": e.get("windows_per_s_wall"), "windows_per_s_after_load": e.get("windows_per_s_after_load"),
-                    "identical_to_reference_on_sample": e.get("sample_identical_to_reference"), "reference_windows_per_s": e.get("reference_windows_per_s")}
-             for name, e in report["modes"].items()}
-    line = {"metric": "k-mer membership queries/sec (k=31), whole `fmsi query` process", "value": m["windows_per_s_wall"], "unit": "k-mers/s", "n_gpus": 1,
-            "steps": 1, "warmup": 0, "ms_per_step": m["wall_seconds"] * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32",
-            "data": "synthetic",
-            "config": {"workload": f"whole process: fmsi query -q <{report['fasta_bytes'] / 1e9:.2f} GB FASTA, {args.reads} reads of {args.read_len} bases> on a synthetic "
-                                   f"index of {int(args.n)} rows written in the reference's format ({report['index_bytes'] / 1e9:.2f} GB of files in /dev/shm), "
-                                   f"output to a file; wall time of the process incl. index load, parse, device, print",
-                       "windows": m["windows"], "modes": modes},
-            "roofline": None, "cpu_baseline": {"value": m.get("reference_windows_per_s"), "unit": "k-mers/s", "cores": 1, "kind": "reference",
-                                               "sample": "the reference CLI (oracle/_ref/fmsi_ref) on the first 20 reads of the same file, same index files"}}
-    print(json.dumps(line))
-
-
-def main():
-    args = parse_args()
-    if args.workload == "e2e":
-        return run_e2e(args)
-    # stdout carries the ONE JSON line and nothing else: libraries that print to the C stdout (RCCL's version banner at
-    # communicator creation, flushed at exit) are sent to stderr for the whole run
-    sys.stdout.flush()
-    json_fd = os.dup(1)
-    os.dup2(2, 1)
+def open_ctx(args):
     import numpy as np
     import torch
     import torch.distributed as dist
     import fmsi_amd as fm
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    multi = world > 1 or args.force_dist   # the multi-rank code path
-    if multi:
+    c = Ctx()
+    c.np, c.torch, c.dist, c.fm = np, torch, dist, fm
+    c.world = int(os.environ.get("WORLD_SIZE", "1"))
+    c.rank = int(os.environ.get("RANK", "0"))
+    c.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    c.multi = c.world > 1 or args.force_dist   # the multi-rank code path
+    if c.multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-    if args.gpus != world and rank == 0 and world > 1:
-        print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
-    torch.cuda.set_device(local_rank)
-    dev_t = torch.device("cuda", local_rank)
-    stream_mode = args.workload == "stream"
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", c.local_rank))
+    if args.gpus != c.world and c.rank == 0 and c.world > 1:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE {c.world}", file=sys.stderr)
+    torch.cuda.set_device(c.local_rank)
+    c.dev_t = torch.device("cuda", c.local_rank)
+    c.stream = torch.cuda.current_stream().cuda_stream
+    return c
 
-    n = int(args.n)
-    k = args.k
-    # the dictionary answers presence queries of the phased workload and of `--stream-via runs`; the kLCP kernel and the A/B kernels
-    # (--kernel pair | refill | lockstep) run without it
+
+def barrier(c):
+    if c.multi:
+        c.dist.barrier()
+    c.torch.cuda.synchronize()
+
+
+# ======================================================================================================================================
+# the handle: index + accelerators for what the run measures
+# ======================================================================================================================================
+def resolve_accelerators(args, n, k, stream_mode):
+    """Which private accelerator answers the timed queries (sets args.use_dict, args.prefix_len): the dictionary answers presence queries of
+    the phased workload and of `--stream-via runs`; the kLCP kernel and the A/B kernels (--kernel pair | refill | lockstep) run without."""
     use_dict = args.accel == "dict" and k <= 32 and ((not stream_mode and args.kernel == "phased") or (stream_mode and args.stream_via == "runs"))
     if args.hbm_budget > 0 and use_dict:
         # footprints: 4 bits per row (single-step blocks) + 8 bits per row (pair layout) + 2 bits per base (text) + the accelerator;
@@ -281,188 +197,656 @@ def main():
         args.prefix_len = 0   # no prefix table: the dictionary is the accelerator, the LF-walk legs run table-less anyway
     if args.prefix_len < 0:
         # Measured: the largest table, t = 16, is the fastest, and with the candidate tables (k - t <= 15: one
-        # line settles a k-mer) that holds for ANY index size -- E. coli scale: 44 G k-mers/s with the 172 GB of t = 16 tables
-        # against 26 G/s with cache-resident t = 12 ones.  The kLCP kernel and the table-less kernels keep the rule "no more
+        # line settles a k-mer) that holds for ANY index size.  The kLCP kernel and the table-less kernels keep the rule "no more
         # entries than 4 x rows".
         args.prefix_len = min(k, 16)
         candidates = args.kernel == "phased" and not args.no_verify and (args.workload == "kmers" or args.stream_via == "runs") and \
             1 <= k - args.prefix_len <= 15
         while not candidates and args.prefix_len > 0 and 4 ** args.prefix_len > 4 * n:
             args.prefix_len -= 1
+
+
+def build_handle(c, args, n, k, stream_mode, with_klcp=None, want_pair=None, chain=None):
+    """Synthetic superstring -> index -> accelerators, as one chain of builders (they share the library's block cache).
+    Returns (index, seconds for everything, seconds for the accelerators)."""
+    fm = c.fm
+    if c.multi and args.stagger_build > 0:
+        time.sleep(args.stagger_build * c.rank)
+    with_klcp = stream_mode if with_klcp is None else with_klcp
+    chain = bool(args.dict_chain and stream_mode) if chain is None else chain
     t0 = time.time()
-    index = fm.DeviceIndex.build_synthetic(n, args.seed, k, with_klcp=stream_mode, device=local_rank, prefix_len=args.prefix_len,
-                                           repeats=(args.repeat_permille, args.repeat_families, args.repeat_divergence_permille))
-    build_s = time.time() - t0
-    flags = fm.MODE_ALL if args.mode == "all" else fm.MODE_OR
     accel_s = 0.0
-    if use_dict:
-        t0 = time.time()
-        if not stream_mode:
-            index.enable_pair_layout()   # (the table-less LF-walk leg and the canonical-step count use it)
-        index.enable_dict(sparse=args.dict_sparse, chain=bool(args.dict_chain and stream_mode))
-        accel_s = time.time() - t0
-        build_s += accel_s
-    if stream_mode and args.stream_via == "runs" and not use_dict:
-        index.enable_pair_layout()
-        if 0 < args.prefix_len < k and not args.no_verify:
-            index.enable_verify()
-    if not stream_mode and not use_dict:
-        if args.kernel in ("pair", "phased"):
-            t0 = time.time()
+    with fm.builder_chain(c.local_rank):
+        index = fm.DeviceIndex.build_synthetic(n, args.seed, k, with_klcp=with_klcp, device=c.local_rank, prefix_len=args.prefix_len,
+                                               repeats=(args.repeat_permille, args.repeat_families, args.repeat_divergence_permille))
+        if args.use_dict:
+            t1 = time.time()
+            if (not stream_mode) if want_pair is None else want_pair:
+                index.enable_pair_layout()   # (the table-less LF-walk leg and the canonical-step count use it)
+            index.enable_dict(sparse=args.dict_sparse, chain=chain)
+            accel_s = time.time() - t1
+        elif stream_mode and args.stream_via == "runs":
+            index.enable_pair_layout()
+            if 0 < args.prefix_len < k and not args.no_verify:
+                index.enable_verify()
+        elif not stream_mode and args.kernel in ("pair", "phased"):
             index.enable_pair_layout()
             if args.kernel == "phased" and 0 < args.prefix_len < k and not args.no_verify:
                 try:
                     index.enable_verify()
                 except fm.FmsiError as e:   # an accelerator: without it the run is slower, not wrong
                     print(f"warning: text verification is off ({e})", file=sys.stderr)
-            build_s += time.time() - t0
-        flags |= {"phased": fm.KERNEL_PHASED, "pair": fm.KERNEL_PAIR, "refill": fm.KERNEL_REFILL, "lockstep": fm.KERNEL_LOCKSTEP}[args.kernel]
-    if use_dict:
-        flags |= fm.KERNEL_DICT
-    stream = torch.cuda.current_stream().cuda_stream
+    c.torch.cuda.synchronize()
+    return index, time.time() - t0, accel_s
 
-    # ---- one step's input, resident in HBM ----------------------------------------------------------------
-    if stream_mode:
-        L = args.read_len
-        n_reads = max(1, int(args.batch) // (L - k + 1))
-        batch = n_reads * (L - k + 1)                       # windows per step and GPU
-        run_start = np.arange(n_reads, dtype=np.uint64) * np.uint64(L)
-        run_windows = np.full(n_reads, L - k + 1, dtype=np.uint32)
-        in_words = n_reads * L // 32 + 2
-        in_bytes = n_reads * L / 4.0
 
-        def make_input(step, buf):
-            index.synthetic_reads_dev(L, args.query_seed, (step * world + rank) * n_reads, n_reads, buf.data_ptr(), args.subst_ppm, stream)
+# ======================================================================================================================================
+# a "path": one way of answering one kind of batch on one handle
+# ======================================================================================================================================
+class QueryPath:
+    """What one timed variant launches.  via:
+         dict        isolated k-mers, fmsi_hip_query_kmers, the k-mer dictionary (headline)
+         legacy      isolated k-mers, the kernel --kernel / --accel tables select
+         lf_pair     isolated k-mers, two-base LF steps without any table     lf_lockstep  one lane per k-mer, lock-step, no table
+         runs_chain  reads, fmsi_hip_query_runs, chained dictionary lookups   runs_plain   the same, one bucket read per window
+         runs_tables reads, fmsi_hip_query_runs, candidate tables             klcp         reads, fmsi_hip_query_stream (kLCP kernel)"""
 
-        def launch(buf, out, counters_ptr=0, extra=0):
-            fn = index.query_runs_dev if args.stream_via == "runs" else index.query_stream_dev
-            fn(buf.data_ptr(), n_reads * L, run_start, run_windows, k, flags | extra, out.data_ptr(), counters_ptr, stream)
-    else:
-        batch = int(args.batch)
-        in_words = batch
-        in_bytes = 8.0 * batch
+    def __init__(self, c, args, index, via, k, batch, read_len=10000, subst_ppm=0):
+        fm, np = c.fm, c.np
+        self.c, self.args, self.index, self.via, self.k, self.subst_ppm = c, args, index, via, k, subst_ppm
+        self.stream_mode = via in ("runs_chain", "runs_plain", "runs_tables", "klcp")
+        mode = fm.MODE_ALL if args.mode == "all" else fm.MODE_OR
+        self.block_b = 64 if via in ("klcp", "lf_lockstep") or (via == "legacy" and args.kernel in ("refill", "lockstep")) else 128
+        self.is_dict = via in ("dict", "runs_chain", "runs_plain")
+        if self.stream_mode:
+            L = self.read_len = read_len
+            self.n_reads = max(1, int(batch) // (L - k + 1))
+            self.batch = self.n_reads * (L - k + 1)                       # windows per step and GPU
+            self.run_start = np.arange(self.n_reads, dtype=np.uint64) * np.uint64(L)
+            self.run_windows = np.full(self.n_reads, L - k + 1, dtype=np.uint32)
+            self.in_words = self.n_reads * L // 32 + 2
+            self.in_bytes = self.n_reads * L / 4.0
+            self.flags = mode | {"runs_chain": fm.KERNEL_DICT, "runs_plain": fm.KERNEL_DICT | fm.NO_DICT_CHAIN, "runs_tables": 0, "klcp": 0}[via]
+            self.kernel = {"runs_chain": "dict_chain_kernel", "runs_plain": "dict_lookup_kernel", "runs_tables": "lookup_lane_kernel + query_pair_kernel",
+                           "klcp": "query_stream_kernel"}[via]
+            self.pmc_kernel = {"runs_chain": "dict_chain_kernel<false>", "runs_plain": "dict_lookup_kernel<false, true>", "runs_tables": "lookup_lane_kernel<false",
+                               "klcp": "query_stream_kernel<false"}[via]
+        else:
+            self.batch = int(batch)
+            self.in_words = self.batch
+            self.in_bytes = 8.0 * self.batch
+            if via == "dict":
+                self.flags, self.kernel, self.pmc_kernel = mode | fm.KERNEL_DICT, "dict_lookup_kernel", "dict_lookup_kernel<false, false>"
+            elif via == "lf_pair":
+                self.flags, self.kernel, self.pmc_kernel = mode | fm.KERNEL_PAIR | fm.NO_PREFIX_TABLE, "query_pair_kernel", "query_pair_kernel<false, false, false>"
+            elif via == "lf_lockstep":
+                self.flags, self.kernel, self.pmc_kernel = mode | fm.KERNEL_LOCKSTEP | fm.NO_PREFIX_TABLE, "query_lockstep_kernel", "query_lockstep_kernel<false>"
+            else:
+                self.flags = mode | {"phased": fm.KERNEL_PHASED, "pair": fm.KERNEL_PAIR, "refill": fm.KERNEL_REFILL, "lockstep": fm.KERNEL_LOCKSTEP}[args.kernel]
+                entry_b = int(index.info.candidate_entry_bytes)
+                lane = args.kernel == "phased" and entry_b and k - int(index.info.prefix_len) <= 15
+                self.kernel = (("lookup_lane_kernel" if lane else "pair_lookup_kernel") + " + query_pair_kernel") if args.kernel == "phased" else f"query_{args.kernel}_kernel"
+                self.pmc_kernel = "query_pair_kernel<false" if args.kernel in ("phased", "pair") else f"query_{args.kernel}_kernel<false"
 
-        def make_input(step, buf):
-            # rank r owns the contiguous range [r*batch, (r+1)*batch) of every step's global batch (weak scaling)
-            index.synthetic_queries_dev(k, args.query_seed, (step * world + rank) * batch, batch, buf.data_ptr(), stream)
+    def make_input(self, step, buf):
+        """rank r owns the contiguous range [r*batch, (r+1)*batch) of every step's global batch (weak scaling)"""
+        c, a = self.c, self.args
+        if self.stream_mode:
+            self.index.synthetic_reads_dev(self.read_len, a.query_seed, (step * c.world + c.rank) * self.n_reads, self.n_reads, buf.data_ptr(), self.subst_ppm, c.stream)
+        else:
+            self.index.synthetic_queries_dev(self.k, a.query_seed, (step * c.world + c.rank) * self.batch, self.batch, buf.data_ptr(), c.stream)
 
-        def launch(buf, out, counters_ptr=0, extra=0):
-            index.query_kmers_dev(buf.data_ptr(), batch, k, flags | extra, out.data_ptr(), counters_ptr, stream)
+    def launch(self, buf, out, counters_ptr=0, extra=0):
+        c = self.c
+        if self.stream_mode:
+            fn = self.index.query_stream_dev if self.via == "klcp" else self.index.query_runs_dev
+            fn(buf.data_ptr(), self.n_reads * self.read_len, self.run_start, self.run_windows, self.k, self.flags | extra, out.data_ptr(), counters_ptr, c.stream)
+        else:
+            self.index.query_kmers_dev(buf.data_ptr(), self.batch, self.k, self.flags | extra, out.data_ptr(), counters_ptr, c.stream)
 
-    # results: bit-packed words (default) -- two device buffers, two page-locked host buffers, a copy stream -- or bytes
-    bits = not args.byte_results
+    def describe(self):
+        return {"via": self.via, "workload": "stream" if self.stream_mode else "kmers", "subst_ppm": self.subst_ppm}
+
+
+def timed_region(c, args, path, steps, warmup, bits=True, host_copy="per-rank", want_counters=True, want_canonical=False, alt_region=False):
+    """W untimed + exactly K timed steps of `path` on resident batches, bracketed by barrier + synchronize; with packed results the
+    words' way to the host is inside the region (module docstring).  Returns a dict of raw measurements."""
+    torch, np, fm, dist = c.torch, c.np, c.fm, c.dist
+    index, batch = path.index, path.batch
+    multi, world, rank = c.multi, c.world, c.rank
     out_flag = fm.OUT_BITS if bits else 0
-    d_out = torch.empty(batch, dtype=torch.uint8, device=dev_t)                      # byte results (counted launches, checks)
+    d_out = torch.empty(batch, dtype=torch.uint8, device=c.dev_t)                      # byte results (counted launches, checks)
     n_words = fm.packed_words(batch, 0)
-    d_bits = [torch.zeros(n_words, dtype=torch.int64, device=dev_t) for _ in range(2)] if bits else None
+    d_bits = [torch.zeros(n_words, dtype=torch.int64, device=c.dev_t) for _ in range(2)] if bits else None
     root_words = n_words * (world if multi else 1)
-    d_gather = [torch.zeros(root_words, dtype=torch.int64, device=dev_t) for _ in range(2)] if (bits and multi and rank == 0) else None
-    h_bits = [torch.zeros(root_words, dtype=torch.int64).pin_memory() for _ in range(2)] if (bits and rank == 0) else None
-    copy_stream = torch.cuda.Stream(device=dev_t) if bits else None
+    d_gather = [torch.zeros(root_words, dtype=torch.int64, device=c.dev_t) for _ in range(2)] if (bits and multi and rank == 0) else None
+    # page-locked host buffers: rank 0 can take every rank's words (root funnel), every other rank its own (per-rank copies)
+    h_bits = [torch.zeros(root_words if rank == 0 else n_words, dtype=torch.int64).pin_memory() for _ in range(2)] if bits else None
+    copy_stream = torch.cuda.Stream(device=c.dev_t) if bits else None    # the gather (N > 1) and, without one, the copy to the host
+    d2h_stream = torch.cuda.Stream(device=c.dev_t) if (bits and multi) else None   # per-rank copies run beside the gather
     ev_kernel = [torch.cuda.Event() for _ in range(2)]
     ev_copied = [torch.cuda.Event() for _ in range(2)]
-    d_cnt = torch.zeros(fm.N_COUNTERS, dtype=torch.int64, device=dev_t)
-    n_buf = max(1, min(args.steps, 4))
-    bufs = [torch.empty(in_words, dtype=torch.int64, device=dev_t) for _ in range(n_buf)]
+    ev_d2h = [torch.cuda.Event() for _ in range(2)]
+    d_cnt = torch.zeros(fm.N_COUNTERS, dtype=torch.int64, device=c.dev_t)
+    n_buf = max(1, min(steps, 4))
+    bufs = [torch.empty(path.in_words, dtype=torch.int64, device=c.dev_t) for _ in range(n_buf)]
 
-    def barrier():
-        if multi:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    if args.pmc_child:   # under rocprofv3 --pmc: the timed kernel's launches and nothing else
-        make_input(0, bufs[0])
-        for _ in range(args.steps):
-            launch(bufs[0], d_bits[0] if bits else d_out, extra=out_flag)
-        torch.cuda.synchronize()
-        os.close(json_fd)
-        return
     # ---- warmup, plus counted launches that supply the algorithmic byte counts ----------------------------
-    make_input(0, bufs[0])
-    for _ in range(max(args.warmup, 1)):
-        launch(bufs[0], d_out)
+    path.make_input(0, bufs[0])
+    for _ in range(max(warmup, 1)):
+        path.launch(bufs[0], d_out)
     counters = canonical = None
-    if not args.no_counters:
+    if want_counters:
         d_cnt.zero_()
-        launch(bufs[0], d_out, d_cnt.data_ptr())
+        path.launch(bufs[0], d_out, d_cnt.data_ptr())
         torch.cuda.synchronize()
         counters = d_cnt.cpu().numpy().astype(np.int64)
-        # what the reference algorithm executes for the same queries: no prefix table (and, for the stream workload,
-        # its own chunking is longer than a 64-window task, so this is an upper bound on its steps)
-        d_cnt.zero_()
-        launch(bufs[0], d_out, d_cnt.data_ptr(), fm.NO_PREFIX_TABLE)
-        torch.cuda.synchronize()
-        canonical = d_cnt.cpu().numpy().astype(np.int64)
+        if want_canonical:
+            # what the reference algorithm executes for the same queries: no prefix table (and, for the stream workload,
+            # its own chunking is longer than a 64-window task, so this is an upper bound on its steps)
+            d_cnt.zero_()
+            path.launch(bufs[0], d_out, d_cnt.data_ptr(), fm.NO_PREFIX_TABLE)
+            torch.cuda.synchronize()
+            canonical = d_cnt.cpu().numpy().astype(np.int64)
     positives = float(d_out.to(torch.float32).mean().item())
-
     for s in range(n_buf):
-        make_input(s + 1, bufs[s])
+        path.make_input(s + 1, bufs[s])
     compute_stream = torch.cuda.current_stream()
+    ev_times = []   # per timed step: gather start / end on the copy stream, D2H start / end on the stream that copies
 
-    def step(s):
+    def step(s, mode, record=False):
         """One pass of the hot path over one resident batch; with packed results also their way to the host: the kernel writes
-        d_bits[b], the copy stream -- behind the kernel's event -- gathers the ranks' words to rank 0 (N > 1) and copies them
+        d_bits[b], the copy stream -- behind the kernel's event -- gathers the ranks' words to rank 0's HBM (N > 1) and copies them
         to page-locked memory while the next step's kernel runs; a buffer is reused when its copy is done."""
         if not bits:
-            launch(bufs[s % n_buf], d_out)
+            path.launch(bufs[s % n_buf], d_out)
             return
         b = s & 1
         compute_stream.wait_event(ev_copied[b])
-        launch(bufs[s % n_buf], d_bits[b], extra=out_flag)
+        path.launch(bufs[s % n_buf], d_bits[b], extra=out_flag)
         ev_kernel[b].record(compute_stream)
+        e = [torch.cuda.Event(enable_timing=True) for _ in range(4)] if record else None   # gather start / end, D2H start / end
+        if multi and mode == "per-rank":   # own words over the own PCIe link, beside the gather (the path's collective) on the copy stream
+            with torch.cuda.stream(d2h_stream):
+                d2h_stream.wait_event(ev_kernel[b])
+                if record:
+                    e[2].record(d2h_stream)
+                h_bits[b][:n_words].copy_(d_bits[b], non_blocking=True)
+                if record:
+                    e[3].record(d2h_stream)
+                ev_d2h[b].record(d2h_stream)
+            d2h_stream.query()
         with torch.cuda.stream(copy_stream):
             copy_stream.wait_event(ev_kernel[b])
+            if record:
+                e[0].record(copy_stream)
             if multi:
                 dist.gather(d_bits[b], list(d_gather[b].chunk(world)) if rank == 0 else None, dst=0)
-                if rank == 0:
-                    h_bits[b].copy_(d_gather[b], non_blocking=True)
+            if record:
+                e[1].record(copy_stream)
+            if multi and mode == "per-rank":
+                copy_stream.wait_event(ev_d2h[b])
             else:
-                h_bits[b].copy_(d_bits[b], non_blocking=True)
+                if record:
+                    e[2].record(copy_stream)
+                if not multi:
+                    h_bits[b][:n_words].copy_(d_bits[b], non_blocking=True)
+                elif rank == 0:   # root funnel: all N ranks' words over rank 0's PCIe link
+                    h_bits[b].copy_(d_gather[b], non_blocking=True)
+                if record:
+                    e[3].record(copy_stream)
+            if record:
+                ev_times.append(e)
             ev_copied[b].record(copy_stream)
         # (hipStreamQuery: hands the copy to the hardware now -- the runtime batches enqueued commands, and a host thread that next
         # blocks inside a library call would leave the copy unsubmitted until it wakes; measured: 0.5 ms per step in the stream workload)
         copy_stream.query()
 
-    if bits:   # one untimed pass through the copy path (first use of the copy stream, of the gather's communicator, of the pinned pages)
-        for b in range(2):
-            ev_copied[b].record(compute_stream)
-        step(0)
-        step(1)
-    index.profile(True)
-    index.profile_read(reset=True)
-    barrier()   # (the first collective of the run also builds RCCL's communicator: twice, so that the timed one is warm)
-    barrier()
-    t0 = time.perf_counter()
-    for s in range(args.steps):
-        step(s)
-    enqueue_s = time.perf_counter() - t0   # (host time to enqueue the steps: the launches are asynchronous)
-    barrier()   # (torch.cuda.synchronize() inside: every stream of the device, the copy stream included)
-    elapsed = time.perf_counter() - t0
-    launches, kernel_ms = index.profile_read(reset=True)
-    index.profile(False)
+    def region(k_steps, mode, record):
+        if bits:   # one untimed pass through the copy path (first use of the copy stream, of the gather's communicator, of the pinned pages)
+            for b in range(2):
+                ev_copied[b].record(compute_stream)
+            step(0, mode)
+            step(1, mode)
+        index.profile(True)
+        index.profile_read(reset=True)
+        barrier(c)   # (the first collective of the run also builds RCCL's communicator: twice, so that the timed one is warm)
+        barrier(c)
+        t0 = time.perf_counter()
+        for s in range(k_steps):
+            step(s, mode, record)
+        enqueue_s = time.perf_counter() - t0   # (host time to enqueue the steps: the launches are asynchronous)
+        barrier(c)   # (torch.cuda.synchronize() inside: every stream of the device, the copy stream included)
+        elapsed = time.perf_counter() - t0
+        launches, kernel_ms = index.profile_read(reset=True)
+        index.profile(False)
+        el = torch.tensor([elapsed], dtype=torch.float64, device=c.dev_t)
+        if multi:
+            dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        return float(el.item()), enqueue_s, launches, kernel_ms
+
+    elapsed_max, enqueue_s, launches, kernel_ms = region(steps, host_copy, True)
+    m = {"batch": batch, "steps": steps, "elapsed_max": elapsed_max, "enqueue_s": enqueue_s, "launches": launches, "kernel_ms": kernel_ms,
+         "counters": counters, "canonical": canonical, "positives": positives, "bits": bits, "n_words": n_words, "root_words": root_words,
+         "bits_check": None, "gather": None}
     # the packed words that reached the host are the byte results of the same batch
-    bits_check = None
-    if bits and rank == 0:
-        last = args.steps - 1
-        launch(bufs[last % n_buf], d_out)
+    if bits:
+        last = steps - 1
+        path.launch(bufs[last % n_buf], d_out)
         torch.cuda.synchronize()
-        got = fm.unpack_bits(h_bits[last & 1][:n_words].numpy().view(np.uint64), batch, 0)
-        bits_check = bool(np.array_equal(got, d_out.cpu().numpy()))
-        if not bits_check:
-            raise RuntimeError("bit-packed results on the host differ from the byte results of the same batch")
+        own_ok = multi and host_copy == "root" and rank != 0   # (root funnel: only rank 0 holds host copies)
+        if not own_ok:
+            got = fm.unpack_bits(h_bits[last & 1][:n_words].numpy().view(np.uint64), batch, 0)
+            m["bits_check"] = bool(np.array_equal(got, d_out.cpu().numpy()))
+            if not m["bits_check"]:
+                raise RuntimeError("bit-packed results on the host differ from the byte results of the same batch")
+    if multi and bits:
+        ones = torch.ones(1, dtype=torch.int64, device=c.dev_t)
+        dist.all_reduce(ones)
+        ms_g = sum(e[0].elapsed_time(e[1]) for e in ev_times) / max(len(ev_times), 1)
+        ms_c = sum(e[2].elapsed_time(e[3]) for e in ev_times) / max(len(ev_times), 1)
+        g = {"in_timed_region": True, "ranks_seen": int(ones.item()), "world": world, "via": "torch.distributed.gather (RCCL) to rank 0's HBM",
+             "host_copy": host_copy, "bytes_gathered_per_step": int(root_words * 8), "bytes_to_host_per_step_rank0": int((n_words if host_copy == "per-rank" else root_words) * 8),
+             "gather_ms_per_step_rank0": round(ms_g, 4), "d2h_ms_per_step_rank0": round(ms_c, 4)}
+        if rank == 0:   # the gather ran inside the timed region: rank 0's own words must have come through it
+            if not torch.equal(d_gather[(steps - 1) & 1][:n_words], d_bits[(steps - 1) & 1]):
+                raise RuntimeError("gathered results differ from rank 0's own")
+        if alt_region:   # the other host-copy form, timed the same way over a short region of its own
+            other = "root" if host_copy == "per-rank" else "per-rank"
+            k2 = max(2, min(steps, 10))
+            el2, _, _, _ = region(k2, other, False)
+            g["alt"] = {"host_copy": other, "steps": k2, "ms_per_step": round(el2 / k2 * 1e3, 4), "value": batch * world * k2 / el2}
+        m["gather"] = g
+    m["_keep"] = (d_out, d_bits, d_gather, h_bits, bufs, d_cnt)   # (the caller's further checks use them)
+    return m
 
-    el = torch.tensor([elapsed], dtype=torch.float64, device=dev_t)
+
+def roofline_of(path, m, info):
+    """The HBM roofline object of one measured path (without PMC traffic): the layout's own algorithmic bytes over the kernel's time."""
+    batch, counters = m["batch"], m["counters"]
+    avg_kernel_s = m["kernel_ms"] / max(m["launches"], 1) / 1e3
+    if counters is None:
+        return {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None, "kernel": path.kernel,
+                "avg_kernel_ms": round(avg_kernel_s * 1e3, 4), "launches": m["launches"]}
+    blocks_read, lookups, klcp_words = int(counters[1]), int(counters[4]), int(counters[5])
+    verify_reads = int(counters[7])   # text verification / chained side reads: counted as 32-byte sectors
+    # blocks_read already contains the table lines / bucket reads (one per lookup)
+    entry_b = int(info.candidate_entry_bytes)
+    lookup_b, entry_used_b = 64, 64
+    if path.is_dict:      # a lookup is one 128-byte bucket (sixteen 8-byte slots, eight lanes x 16 bytes in one instruction)
+        lookup_b = entry_used_b = 128
+    elif "lookup_lane" in path.kernel and entry_b:
+        entry_used_b = entry_b   # a table lookup is one 64-byte HBM access whatever the entry's size; useful_* counts the entry's bytes
+    out_b = batch / 8.0 if m["bits"] else 1.0 * batch   # packed: one bit per window
+    bytes_launch = path.block_b * (blocks_read - lookups) + lookup_b * lookups + 8 * klcp_words + path.in_bytes + out_b + 32 * verify_reads
+    ach = bytes_launch / avg_kernel_s / 1e9
+    requests = blocks_read + klcp_words + verify_reads
+    roof = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+            "traffic": None, "traffic_source": None, "traffic_over_algorithmic": None,
+            "kernel": path.kernel, "avg_kernel_ms": round(avg_kernel_s * 1e3, 4), "launches": m["launches"],
+            "algorithmic_bytes_per_launch": int(bytes_launch), "bytes_per_kmer": round(bytes_launch / batch, 1),
+            "lf_steps_per_kmer": round(int(counters[0]) / batch, 3), "blocks_per_kmer": round(blocks_read / batch, 3),
+            "table_lookups_per_kmer": round(lookups / batch, 3), "klcp_words_per_kmer": round(klcp_words / batch, 3),
+            "side_reads_per_kmer": round(verify_reads / batch, 3),
+            "random_requests_per_s": round(requests / avg_kernel_s / 1e9, 2),
+            # the ceiling the lookups run against (DESIGN.md 3): random line requests per second, measured with tools/gather_bench on the
+            # same footprint (an index that fits the caches -- E. coli scale -- is not bound by it: null)
+            "request_roofline": None if int(info.device_bytes) < (2 << 30) else
+                                {"achieved": round(requests / avg_kernel_s / 1e9, 2), "peak": REQUEST_PEAK_G, "unit": "G random requests/s",
+                                 "frac": round(requests / avg_kernel_s / 1e9 / REQUEST_PEAK_G, 4)},
+            "table_entry_bytes": entry_used_b,
+            "useful_bytes_per_kmer": round((bytes_launch - (lookup_b - entry_used_b) * lookups) / batch, 1)}
+    if m["canonical"] is not None:   # SURVEY 8(d)'s reference-layout accounting: 256 B per LF step the reference would execute + 64 B per probe
+        canonical = m["canonical"]
+        canon_bytes = 256 * int(canonical[0]) + 64 * int(canonical[2]) + 8 * int(canonical[5]) + path.in_bytes + batch // 8
+        roof["canonical_lf_steps_per_kmer"] = round(int(canonical[0]) / batch, 3)
+        roof["canonical_bytes_per_launch"] = int(canon_bytes)
+    return roof
+
+
+# ======================================================================================================================================
+# PMC traffic: child runs of this script under rocprofv3 --pmc
+# ======================================================================================================================================
+def fetch_factor(kernel_name):
+    """FETCH_SIZE correction per kernel (MI355X_MICROARCH.md, HBM: gfx950 tallies a 128-byte request at 64 B -- 0.50x -- as it does wide
+    coalesced streaming reads; random 64-byte reads are tallied at 1.015x: tools/gather_bench calibration, profiles/README.md r01)."""
+    if any(t in kernel_name for t in ("query_lockstep_kernel", "query_refill_kernel", "query_fn_kernel", "query_longk_kernel")):
+        return 1.0 / 1.015
+    if "query_stream_kernel" in kernel_name:   # 64-byte blocks and table lines, 8-byte kLCP words
+        return 1.0 / 1.015
+    return 2.0
+
+
+def pmc_child(c, args, index, plan):
+    """Under rocprofv3 --pmc: per variant of the plan its input (the marker dispatch) and three launches, nothing else."""
+    torch, fm = c.torch, c.fm
+    for v in plan:
+        path = QueryPath(c, args, index, v["via"], args.k, v.get("batch", args.batch), args.read_len, v.get("subst_ppm", 0))
+        buf = torch.empty(path.in_words, dtype=torch.int64, device=c.dev_t)
+        out = torch.zeros(max(fm.packed_words(path.batch, 0), 1), dtype=torch.int64, device=c.dev_t)
+        torch.cuda.synchronize()
+        path.make_input(1, buf)
+        for _ in range(3):
+            path.launch(buf, out, extra=fm.OUT_BITS)
+        torch.cuda.synchronize()
+        del buf, out
+
+
+def measure_traffic(args, plan, child_args):
+    """HBM bytes per launch of every variant of `plan`, measured NOW: this script runs twice more as a child under `rocprofv3 --pmc` --
+    FETCH_SIZE and WRITE_SIZE cannot share a pass (MI355X_MICROARCH.md, PMC slots) and counters are collected in runs of their own -- with
+    the same index and flags; a variant's dispatches are those between its marker (the generator kernel that draws its input) and the
+    next one.  Returns ({variant name: {...}}, None) or (None, reason)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    prof = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if prof is None:
+        return None, "rocprofv3 not found"
+    child = [sys.executable, str(REPO / "bench.py"), "--pmc-child", "--pmc-plan", json.dumps(plan)] + child_args
+    per_variant = [dict(name=v["name"], kernels={}) for v in plan]
+    env = dict(os.environ, TMPDIR="/tmp")
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        with tempfile.TemporaryDirectory(dir="/tmp") as d:
+            try:
+                res = subprocess.run([prof, "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "run", "--"] + child, cwd="/tmp", env=env,
+                                     stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=420)
+            except (OSError, subprocess.TimeoutExpired) as e:
+                return None, f"rocprofv3 --pmc {counter}: {e!r}"
+            rows = {}
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                with open(f, newline="") as fh:
+                    for r in csv.DictReader(fh):
+                        if r["Counter_Name"] != counter:
+                            continue
+                        key = int(r["Dispatch_Id"])
+                        name, val = rows.get(key, (r["Kernel_Name"], 0.0))
+                        rows[key] = (name, val + float(r["Counter_Value"]))
+            group = -1
+            seen = 0
+            for key in sorted(rows):
+                name, val = rows[key]
+                if any(mk in name for mk in MARKER_KERNELS):
+                    group += 1
+                    continue
+                if 0 <= group < len(plan) and "fmsi::" in name:   # (the library's kernels; not torch's fill of the next variant's buffer)
+                    kk = per_variant[group]["kernels"].setdefault(name, {"FETCH_SIZE": 0.0, "WRITE_SIZE": 0.0, "dispatches": 0})
+                    kk[counter] += val * 1024.0   # the counters are in KiB
+                    if counter == "FETCH_SIZE":
+                        kk["dispatches"] += 1
+                    seen += 1
+            if res.returncode != 0 or group + 1 != len(plan) or not seen:
+                return None, (f"rocprofv3 --pmc {counter}: rc {res.returncode}, {group + 1} of {len(plan)} variants seen "
+                              f"({' '.join(l for l in res.stderr.decode(errors='replace').splitlines() if not l[:1] in 'WIE' or 'rror' in l)[-600:]})")
+    out = {}
+    for pv in per_variant:
+        fetched = written = raw = 0.0
+        by_kernel = {}
+        for name, kk in pv["kernels"].items():
+            f = fetch_factor(name)
+            fetched += f * kk["FETCH_SIZE"] / 3.0
+            raw += kk["FETCH_SIZE"] / 3.0
+            written += kk["WRITE_SIZE"] / 3.0
+            mk = re.search(r"(\w+_kernel(?:<[^(]*>)?)", name)
+            short = mk.group(1) if mk else name[:70]
+            by_kernel[short] = {"fetch_raw": round(kk["FETCH_SIZE"] / 3.0), "fetch_factor": round(f, 4), "write": round(kk["WRITE_SIZE"] / 3.0), "dispatches_per_launch": kk["dispatches"] / 3.0}
+        out[pv["name"]] = {"traffic": fetched + written, "fetch_raw": raw, "fetch": fetched, "write": written, "by_kernel": by_kernel,
+                           "source": (f"measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (a child run each, 3 launches per variant); raw FETCH_SIZE "
+                                      f"{raw / 1e9:.3f} GB -> {fetched / 1e9:.3f} GB (x2 where the kernel reads 128-B requests or wide coalesced streams, which gfx950 "
+                                      f"tallies at half; /1.015 for random 64-B block reads) + WRITE_SIZE {written / 1e9:.3f} GB")}
+    return out, None
+
+
+def base_child_args(args, n, batch):
+    a = ["--n", repr(float(n)), "--batch", repr(float(batch)), "--k", str(args.k), "--seed", str(args.seed), "--query-seed", str(args.query_seed),
+         "--mode", args.mode, "--read-len", str(args.read_len), "--prefix-len", str(args.prefix_len)]
+    if args.dict_sparse:
+        a.append("--dict-sparse")
+    if args.repeat_permille:
+        a += ["--repeat-permille", str(args.repeat_permille), "--repeat-families", str(args.repeat_families),
+              "--repeat-divergence-permille", str(args.repeat_divergence_permille)]
+    return a
+
+
+# ======================================================================================================================================
+# the whole process (SURVEY 8(d)(ii))
+# ======================================================================================================================================
+def e2e_report(args, modes="or,all,all_S"):
+    import subprocess
+    cmd = [sys.executable, str(REPO / "tools" / "e2e_bench.py"), "--n", str(int(args.n)), "--reads", str(args.reads), "--read-len", str(args.read_len),
+           "--k", str(args.k), "--modes", modes, "--ref-reads", "20"]
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    report = None
+    for l in res.stdout.splitlines():
+        if l.startswith("{"):
+            report = json.loads(l)
+    if res.returncode != 0 or report is None:
+        sys.stderr.write(res.stderr[-2000:])
+        raise RuntimeError("tools/e2e_bench.py failed")
+    modes_out = {name: {"wall_seconds": e["wall_seconds"], "process_seconds": e.get("total_seconds"), "load_seconds": e.get("load_seconds"),
+                        "windows_per_s_whole_process": e.get("windows_per_s_wall"), "windows_per_s_after_load": e.get("windows_per_s_after_load"),
+                        "stages": {s: e.get(s) for s in ("read_seconds", "prepare_seconds", "device_seconds", "replay_seconds", "format_seconds", "write_seconds") if e.get(s) is not None},
+                        "dictionary": e.get("dictionary"),
+                        "identical_to_reference_on_sample": e.get("sample_identical_to_reference"), "reference_windows_per_s": e.get("reference_windows_per_s")}
+                 for name, e in report["modes"].items()}
+    return report, modes_out
+
+
+def run_e2e(args):
+    """--workload e2e: one JSON line for the whole-process rate of the drop-in CLI (default mode), the other modes in `config`."""
+    report, modes = e2e_report(args, "or,all,all_S,xor,or_full")
+    m = report["modes"]["or"]
+    line = {"metric": "k-mer membership queries/sec (k=31), whole `fmsi query` process", "value": m["windows_per_s_wall"], "unit": "k-mers/s", "n_gpus": 1,
+            "steps": 1, "warmup": 0, "ms_per_step": m["wall_seconds"] * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32",
+            "data": "synthetic",
+            "config": {"workload": f"whole process: fmsi query -q <{report['fasta_bytes'] / 1e9:.2f} GB FASTA, {args.reads} reads of {args.read_len} bases> on a synthetic "
+                                   f"index of {int(args.n)} rows written in the reference's format ({report['index_bytes'] / 1e9:.2f} GB of files in /dev/shm), "
+                                   f"output to a file; wall time of the process incl. index load, parse, device, print",
+                       "windows": m["windows"], "modes": modes},
+            "roofline": None, "cpu_baseline": {"value": m.get("reference_windows_per_s"), "unit": "k-mers/s", "cores": 1, "kind": "reference",
+                                               "sample": "the reference CLI (oracle/_ref/fmsi_ref) on the first 20 reads of the same file, same index files"}}
+    print(json.dumps(line))
+
+
+# ======================================================================================================================================
+# the `configs` legs (children of the default run)
+# ======================================================================================================================================
+LEG_SPECS = {
+    # name: (n, workload, batch per step, steps, variants [(variant name, via, subst_ppm)])
+    "c2": (4.7e6, "kmers", 1e8, 5, [("c2", "dict", 0)]),
+    "c3": (1.4e9, "kmers", float(1 << 27), 8, [("c3", "dict", 0)]),
+    "c4": (2.8e9, "stream", float(1 << 27), 8, [("c4_dict_chain", "runs_chain", 0), ("c4_dict_chain_subst1pct", "runs_chain", 10000),
+                                                 ("c4_dict_plain", "runs_plain", 0), ("c4_dict_plain_subst1pct", "runs_plain", 10000),
+                                                 ("c4_klcp", "klcp", 0), ("c4_klcp_subst1pct", "klcp", 10000)]),
+}
+LEG_TEXT = {
+    "c2": "BASELINE config 2: E. coli single-genome scale (synthetic max-ones masked superstring n=4700000), k=31, 10^8 isolated random 31-mers per step "
+          "(50% present), fmsi query -O semantics, k-mer dictionary; the handle (a few tens of MB) is cache resident: `l2_level_gbs` is the algorithmic "
+          "rate, `frac` (of HBM) is not meaningful and null",
+    "c3": "BASELINE config 3: E. coli pangenome scale (n=1400000000, ~1.4 G distinct 31-mers), k=31, 2^27 isolated random 31-mers per step x 8 steps "
+          "(>= 10^9 queries, 50% present), fmsi query -O semantics, k-mer dictionary",
+    "c4": "BASELINE config 4: human-genome scale (n=2800000000), k=31, reads of 10000 bases (50% from the superstring, half of those reverse-complemented), "
+          "every 31-mer window, fmsi query -S -O answers",
+}
+VIA_TEXT = {"runs_chain": "fmsi_hip_query_runs, chained dictionary lookups (58.7 GB handle): a lane follows the superstring from its task's first window",
+            "runs_plain": "fmsi_hip_query_runs, one dictionary bucket read per window (FMSI_HIP_NO_DICT_CHAIN)",
+            "klcp": "fmsi_hip_query_stream: the kLCP kernel (extend_range_with_klcp + one LF step per positive window, src/fms_index.h:106-115,181-254)",
+            "dict": "fmsi_hip_query_kmers, k-mer dictionary"}
+
+
+def run_leg(args):
+    """Child mode (--leg NAME): builds the leg's handle once, times every variant on it, checks a sample of each against the real
+    reference, frees the handle, measures the variants' HBM traffic (PMC grandchildren) and prints ONE JSON list."""
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+    name = args.leg
+    n, workload, batch, steps, variants = LEG_SPECS[name]
+    n = int(n)
+    args.n, args.batch, args.workload = float(n), batch, workload
+    stream_mode = workload == "stream"
+    args.stream_via = "runs"
+    if stream_mode:
+        args.prefix_len = 16   # (the kLCP kernel's fresh searches start from its 16-deep prefix table, as in the earlier rounds' runs; the dictionary paths do not use it)
+    c = open_ctx(args)
+    k = args.k
+    resolve_accelerators(args, n, k, stream_mode)
+    index, build_s, accel_s = build_handle(c, args, n, k, stream_mode, with_klcp=stream_mode, want_pair=False, chain=stream_mode)
+    info = index.info
+    legs = []
+    paths = []
+    for vname, via, subst in variants:
+        path = QueryPath(c, args, index, via, k, batch, args.read_len, subst)
+        m = timed_region(c, args, path, steps, args.warmup, bits=True)
+        roof = roofline_of(path, m, info)
+        m.pop("_keep")
+        value = m["batch"] * steps / m["elapsed_max"]
+        resident = int(info.device_bytes) < (1 << 28)   # fits the Infinity Cache: HBM % is not meaningful (SURVEY 8(d))
+        legs.append({"name": vname, "config": LEG_TEXT[name] + ("; " + VIA_TEXT[via] if stream_mode else "") + (f"; {subst // 10000}% substitutions in the reads drawn from the superstring" if subst else ""),
+                     "value": value, "unit": "k-mers/s", "steps": steps, "queries_per_step": m["batch"], "ms": round(m["elapsed_max"] / steps * 1e3, 4),
+                     "kernel": roof["kernel"], "avg_kernel_ms": roof["avg_kernel_ms"], "algorithmic_bytes": roof.get("algorithmic_bytes_per_launch"),
+                     "achieved_gbs": None if resident else roof["achieved"], "l2_level_gbs": roof["achieved"] if resident else None,
+                     "frac": None if resident else roof["frac"], "traffic": None, "traffic_over_algorithmic": None, "traffic_source": None,
+                     "requests_per_kmer": round(roof.get("blocks_per_kmer", 0) + roof.get("klcp_words_per_kmer", 0) + roof.get("side_reads_per_kmer", 0), 3),
+                     "lf_steps_per_kmer": roof.get("lf_steps_per_kmer"), "random_requests_per_s": roof.get("random_requests_per_s"),
+                     "positive_fraction": round(m["positives"], 4), "results_on_host_match_bytes": m["bits_check"],
+                     "index_rows": int(info.n), "handle_bytes_hbm": int(info.device_bytes), "dict_bytes": int(info.dict_bytes), "dict_chain_bytes": int(info.dict_chain_bytes),
+                     "index_build_seconds": round(build_s, 2), "matches_reference": None, "reference": None})
+        paths.append(path)
+        del m
+    # ---- a sample of every variant against the real reference (bench_cpu.py: the only user of oracle/) ----
+    try:
+        import bench_cpu
+        checks = bench_cpu.check_legs(c, args, index, paths, [v[0] for v in variants])
+        for leg in legs:
+            ch = checks.get(leg["name"])
+            if ch:
+                leg["matches_reference"], leg["reference"] = ch["matches"], ch["what"]
+    except Exception as e:   # a check that could not run is reported as such, never as a match
+        for leg in legs:
+            leg["reference"] = f"not checked: {e!r}"
+    del paths
+    index.close()
+    del index
+    c.torch.cuda.empty_cache()
+    c.fm.trim_scratch(c.local_rank)
+    if not args.no_pmc and not os.environ.get("FMSI_BENCH_NO_PMC"):
+        plan = [{"name": vn, "via": via, "subst_ppm": s, "batch": batch} for vn, via, s in variants]
+        extra = ["--workload", workload, "--stream-via", "runs", "--leg-handle", name] + base_child_args(args, n, batch)
+        got, why = measure_traffic(args, plan, extra)
+        for leg in legs:
+            if got and leg["name"] in got:
+                t = got[leg["name"]]
+                leg["traffic"] = t["traffic"]
+                leg["traffic_over_algorithmic"] = round(t["traffic"] / leg["algorithmic_bytes"], 4) if leg["algorithmic_bytes"] else None
+                leg["traffic_source"] = t["source"]
+                leg["traffic_by_kernel"] = t["by_kernel"]
+                if leg["frac"] is not None:
+                    leg["hbm_frac"] = round(t["traffic"] / (leg["avg_kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+            else:
+                leg["traffic_source"] = f"not measured: {why}"
+    os.write(json_fd, (json.dumps(legs) + "\n").encode())
+    os.close(json_fd)
+
+
+def run_config_legs(args):
+    """The parent's side: one child process per leg (a fresh handle each; the parent has released its own)."""
+    import subprocess
+    out = []
+    for name in [x for x in args.legs.split(",") if x]:
+        t0 = time.time()
+        if name == "e2e":
+            try:
+                report, modes = e2e_report(args)
+                for mode_name, cli in (("or", "fmsi query"), ("all", "fmsi query -O"), ("all_S", "fmsi query -S -O")):
+                    e = modes.get(mode_name)
+                    if not e:
+                        continue
+                    out.append({"name": f"e2e_{mode_name}", "config": f"whole process `{cli} -q <{report['fasta_bytes'] / 1e9:.2f} GB FASTA: {args.reads} reads of {args.read_len} bases> "
+                                                                      f"<index of {int(args.n)} rows, {report['index_bytes'] / 1e9:.2f} GB of .fmsi.* files in /dev/shm>`, output to a file, default options; "
+                                                                      f"wall time of the process incl. index load, parse, device, print (SURVEY 8(d)(ii), src/main.cpp:238-375)",
+                                "value": e["windows_per_s_whole_process"], "unit": "k-mers/s", "ms": round(e["wall_seconds"] * 1e3, 1), "windows": report["modes"][mode_name].get("windows"),
+                                "load_seconds": e["load_seconds"], "windows_per_s_after_load": e["windows_per_s_after_load"], "stages": e["stages"], "dictionary": e["dictionary"],
+                                "kernel": None, "avg_kernel_ms": None, "algorithmic_bytes": None, "frac": None, "traffic": None,
+                                "matches_reference": e["identical_to_reference_on_sample"],
+                                "reference": f"the reference CLI on the first 20 reads of the same file, same index files: {e['reference_windows_per_s']} windows/s on one core; byte-identical output"})
+            except Exception as e:
+                out.append({"name": "e2e", "error": repr(e)})
+            out[-1]["leg_seconds"] = round(time.time() - t0, 1)
+            continue
+        if name not in LEG_SPECS:
+            out.append({"name": name, "error": "unknown leg"})
+            continue
+        cmd = [sys.executable, str(REPO / "bench.py"), "--leg", name, "--warmup", str(args.warmup), "--seed", str(args.seed), "--query-seed", str(args.query_seed),
+               "--mode", args.mode, "--k", str(args.k)] + (["--no-pmc"] if args.no_pmc else [])
+        try:
+            res = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+            got = None
+            for l in res.stdout.splitlines():
+                if l.startswith("["):
+                    got = json.loads(l)
+            if res.returncode != 0 or got is None:
+                raise RuntimeError(f"rc {res.returncode}: {res.stderr[-800:]}")
+            for g in got:
+                g["leg_seconds"] = round(time.time() - t0, 1)
+            out += got
+        except Exception as e:
+            out.append({"name": name, "error": repr(e)[:1200]})
+    return out
+
+
+# ======================================================================================================================================
+def main():
+    args = parse_args()
+    if args.workload == "e2e":
+        return run_e2e(args)
+    if args.leg:
+        return run_leg(args)
+    # stdout carries the ONE JSON line and nothing else: libraries that print to the C stdout (RCCL's version banner at
+    # communicator creation, flushed at exit) are sent to stderr for the whole run
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+    c = open_ctx(args)
+    np, torch, dist, fm = c.np, c.torch, c.dist, c.fm
+    world, rank, multi = c.world, c.rank, c.multi
+    stream_mode = args.workload == "stream"
+    n, k = int(args.n), args.k
+    resolve_accelerators(args, n, k, stream_mode)
+    use_dict = args.use_dict
+
+    if args.pmc_child:   # under rocprofv3 --pmc: the plan's launches and nothing else (the handle is built as the measured run built it)
+        plan = json.loads(args.pmc_plan)
+        index, _, _ = build_handle(c, args, n, k, stream_mode, with_klcp=any(v["via"] == "klcp" for v in plan),
+                                   want_pair=any(v["via"].startswith("lf_") for v in plan), chain=any(v["via"] == "runs_chain" for v in plan))
+        pmc_child(c, args, index, plan)
+        os.close(json_fd)
+        return
+
+    index, build_s, accel_s = build_handle(c, args, n, k, stream_mode)
+    # per-rank build time: with N ranks building at once (each on its own GPU) the slowest is what the run waits for
+    build_all = [build_s]
     if multi:
-        dist.all_reduce(el, op=dist.ReduceOp.MAX)
-    elapsed_max = float(el.item())
+        t = torch.tensor([build_s], dtype=torch.float64, device=c.dev_t)
+        parts = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(parts, t)
+        build_all = [float(p.item()) for p in parts]
+    if stream_mode:
+        via = ("runs_chain" if args.dict_chain else "runs_plain") if use_dict else ("runs_tables" if args.stream_via == "runs" else "klcp")
+    else:
+        via = "dict" if use_dict else "legacy"
+    path = QueryPath(c, args, index, via, k, args.batch, args.read_len, args.subst_ppm)
+    batch = path.batch
+    bits = not args.byte_results
+    m = timed_region(c, args, path, args.steps, args.warmup, bits=bits, host_copy=args.host_copy, want_counters=not args.no_counters,
+                     want_canonical=not args.no_counters, alt_region=world > 1)
+    d_out, d_bits, d_gather, h_bits, bufs, d_cnt = m.pop("_keep")
+    elapsed_max = m["elapsed_max"]
+    gather_note = m["gather"]
 
-    # gather the last step's results to rank 0 (rank order = output order); outside the timed region
-    gather_note = None
-    if multi and bits and rank == 0:   # the gather ran inside the timed region: rank 0's own words must have come through it
-        if not torch.equal(d_gather[(args.steps - 1) & 1][:n_words], d_bits[(args.steps - 1) & 1]):
-            raise RuntimeError("gathered results differ from rank 0's own")
-        gather_note = {"in_timed_region": True, "bytes_per_step": int(root_words * 8), "via": "torch.distributed.gather (RCCL)"}
-    if multi and not bits:
+    if multi and not bits:   # byte results: gathered after the timed region (the round-1 form)
         parts = [torch.empty_like(d_out) for _ in range(world)] if rank == 0 else None
         dist.gather(d_out, parts, dst=0)
         if rank == 0 and not torch.equal(parts[0], d_out):
@@ -473,7 +857,7 @@ def main():
         from fmsi_amd import sharding
         last_b = (args.steps - 1) & 1
         src = d_bits[last_b].view(torch.uint8) if bits else d_out
-        comm = sharding.comm_from_process_group(local_rank) if multi else fm.Comm(fm.Comm.unique_id(), 1, 0, local_rank)
+        comm = sharding.comm_from_process_group(c.local_rank) if multi else fm.Comm(fm.Comm.unique_id(), 1, 0, c.local_rank)
         t_g = time.perf_counter()
         whole = sharding.gather_to_root_abi(comm, src, src.numel() * world, dst=0)
         torch.cuda.synchronize()
@@ -485,30 +869,30 @@ def main():
                 ref = torch.cat(parts) if multi else d_out
             if not torch.equal(whole, ref):
                 raise RuntimeError("fmsi_hip_gather: MISMATCH with torch.distributed.gather")
-            gather_note = dict(gather_note or {}, fmsi_hip_gather="matches torch.distributed.gather", bytes=int(whole.numel()),
-                               seconds=round(t_g, 4))
+            gather_note = dict(gather_note or {}, fmsi_hip_gather="matches torch.distributed.gather", bytes=int(whole.numel()), seconds=round(t_g, 4))
         comm.close()
 
     # ---- the table-less LF walk (north_star's form: update_range steps only, src/fms_index.h:98-124) on the same index --------
     # Timed legs of their own, rank 0 of the 1-GPU run: the two-base-step pair kernel and the lock-step baseline, both with
-    # FMSI_HIP_NO_PREFIX_TABLE, same resident batch, kernel time from the library's HIP events on the launch stream.
+    # FMSI_HIP_NO_PREFIX_TABLE, same resident batches, kernel time from the library's HIP events on the launch stream.
     lf_path = None
     if not args.no_lf_leg and not stream_mode and world == 1 and not args.no_counters and index.has_pair_layout:
         lf_path = []
         lf_out = d_bits[0] if bits else d_out
-        for name, kflag, block_b in (("query_pair_kernel<false,false,false> (two-base steps, 128-B blocks, no table)", fm.KERNEL_PAIR, 128),
-                                     ("query_lockstep_kernel<false> (one lane per k-mer, 64-B blocks, no table)", fm.KERNEL_LOCKSTEP, 64)):
-            base_flags = (flags & ~0xF0) | kflag | fm.NO_PREFIX_TABLE
+        out_flag = fm.OUT_BITS if bits else 0
+        for lf_via, label in (("lf_pair", "query_pair_kernel<false,false,false> (two-base steps, 128-B blocks, no table)"),
+                              ("lf_lockstep", "query_lockstep_kernel<false> (one lane per k-mer walked in lock-step, 64-B blocks, no table)")):
+            p = QueryPath(c, args, index, lf_via, k, batch)
             d_cnt.zero_()
-            index.query_kmers_dev(bufs[0].data_ptr(), batch, k, base_flags, d_out.data_ptr(), d_cnt.data_ptr(), stream)
+            p.launch(bufs[0], d_out, d_cnt.data_ptr())
             torch.cuda.synchronize()
-            c = d_cnt.cpu().numpy().astype(np.int64)
+            cn = d_cnt.cpu().numpy().astype(np.int64)
             index.profile(True)
             index.profile_read(reset=True)
             torch.cuda.synchronize()
             t_l = time.perf_counter()
             for s_ in range(args.lf_steps):
-                index.query_kmers_dev(bufs[s_ % n_buf].data_ptr(), batch, k, base_flags | out_flag, lf_out.data_ptr(), 0, stream)
+                p.launch(bufs[s_ % len(bufs)], lf_out, 0, out_flag)
             torch.cuda.synchronize()
             t_l = time.perf_counter() - t_l
             l_n, l_ms = index.profile_read(reset=True)
@@ -516,123 +900,114 @@ def main():
             k_s = l_ms / max(l_n, 1) / 1e3
             # the layout's own bytes: one block per boundary read (128 B pair / 64 B single; [1] counts them, explicit mask
             # probes included), the k-mers in, the packed results out; and SURVEY 8(d)'s canonical 256 B per LF step
-            alg = block_b * int(c[1]) + 8.0 * batch + (batch / 8.0 if bits else batch)
-            canon = 256 * int(c[0]) + 64 * int(c[2]) + 8.0 * batch + batch / 8.0
-            lf_path.append({"kernel": name, "prefix_table": 0, "ms": round(k_s * 1e3, 3), "launches": int(l_n),
+            alg = p.block_b * int(cn[1]) + 8.0 * batch + (batch / 8.0 if bits else batch)
+            canon = 256 * int(cn[0]) + 64 * int(cn[2]) + 8.0 * batch + batch / 8.0
+            lf_path.append({"kernel": label, "via": lf_via, "prefix_table": 0, "ms": round(k_s * 1e3, 3), "launches": int(l_n),
                             "wall_ms_per_step": round(t_l / args.lf_steps * 1e3, 3),
-                            "kmers_per_s": round(batch / k_s, 1), "lf_steps_per_kmer": round(int(c[0]) / batch, 3),
-                            "block_reads_per_kmer": round(int(c[1]) / batch, 3), "block_bytes": block_b,
-                            "algorithmic_bytes": int(alg), "achieved": round(alg / k_s / 1e9, 1), "frac": round(alg / k_s / 1e9 / HBM_PEAK_GBS, 4),
-                            "random_requests_per_s": round(int(c[1]) / k_s / 1e9, 2),
-                            "canonical_bytes": int(canon), "canonical_achieved": round(canon / k_s / 1e9, 1),
-                            "canonical_frac": round(canon / k_s / 1e9 / HBM_PEAK_GBS, 4)})
+                            "kmers_per_s": round(batch / k_s, 1), "lf_steps_per_kmer": round(int(cn[0]) / batch, 3),
+                            "block_reads_per_kmer": round(int(cn[1]) / batch, 3), "block_bytes": p.block_b,
+                            "algorithmic_bytes": int(alg),
+                            # block reads x block bytes over the kernel's time: INCLUDES the reads the caches serve (the first four to five
+                            # steps of every search touch 4^9 distinct blocks and fewer) -- not an HBM figure, may exceed the HBM peak
+                            "algorithmic_incl_cache": {"gbs": round(alg / k_s / 1e9, 1), "over_hbm_peak": round(alg / k_s / 1e9 / HBM_PEAK_GBS, 4)},
+                            "random_requests_per_s": round(int(cn[1]) / k_s / 1e9, 2),
+                            "canonical_bytes": int(canon), "canonical_gbs": round(canon / k_s / 1e9, 1),
+                            "hbm_traffic": None, "hbm_gbs": None, "hbm_frac": None})
 
-    if rank == 0:
-        total_q = batch * world * args.steps
-        value = total_q / elapsed_max
-        avg_kernel_s = kernel_ms / max(launches, 1) / 1e3
-        roof = None
-        if counters is not None:
-            blocks_read, lookups, klcp_words = int(counters[1]), int(counters[4]), int(counters[5])
-            verify_reads = int(counters[7])   # text verification: 4-byte position + 8..16 bytes of text, two requests per verified search
-            # blocks_read already contains the prefix-table lines (one 64-B line per lookup); the pair layout reads 128-B blocks
-            pair_blocks = (args.kernel in ("pair", "phased") and not stream_mode) or (stream_mode and args.stream_via == "runs")
-            block_b = 128 if pair_blocks else 64
-            # a table lookup is one 64-byte HBM access whatever the entry's size (8, 16 or 32 bytes): the memory delivers
-            # nothing smaller (PMC, profiles/r01m_traffic_kmers.json: 60 B fetched per lookup of a 32-byte entry), so the line is
-            # what is counted; useful_* below counts the entry's own bytes instead
-            entry_b = int(index.info.candidate_entry_bytes)
-            lane_lookups = (not stream_mode or args.stream_via == "runs") and args.kernel == "phased" and entry_b and k - int(index.info.prefix_len) <= 15
-            lookup_b = 64
-            entry_used_b = entry_b if lane_lookups else 64
-            if use_dict:   # a lookup is one 128-byte bucket (sixteen 8-byte slots, eight lanes x 16 bytes in one instruction)
-                lookup_b, entry_used_b, lane_lookups = 128, 128, False
-            out_b = batch / 8.0 if bits else 1.0 * batch   # packed: one bit per window
-            bytes_launch = block_b * (blocks_read - lookups) + lookup_b * lookups + 8 * klcp_words + in_bytes + out_b
-            bytes_launch += 32 * verify_reads   # counted as two 32-byte sectors per verification
-            # (phased form: the work items of the searches left to the stepping kernel -- 48 bytes for about 3 % of the k-mers -- are not counted)
-            canon_bytes = 256 * int(canonical[0]) + 64 * int(canonical[2]) + 8 * int(canonical[5]) + in_bytes + batch // 8
-            ach = bytes_launch / avg_kernel_s / 1e9
-            traffic, traffic_source = None, None
-            if use_dict and world == 1 and not args.no_pmc and not os.environ.get("FMSI_BENCH_NO_PMC"):
-                traffic, traffic_source = measure_traffic(args, n, batch, k)
-            if traffic is None:
-                traffic_source = ("profiles/*traffic*.json (rocprofv3 PMC passes of the same configuration, committed)" +
-                                  (f"; not measured in this run: {traffic_source}" if traffic_source else ""))
-                traffic = pmc_traffic(args, n, batch, k)
-            roof = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source if traffic is not None else None,
-                    "traffic_over_algorithmic": round(traffic / bytes_launch, 4) if traffic else None,
-                    "kernel": ("dict_chain_kernel" if (args.dict_chain and stream_mode) else "dict_lookup_kernel") if use_dict else ("query_stream_kernel" if stream_mode and args.stream_via == "klcp" else
-                               ("lookup_lane_kernel" if lane_lookups else "pair_lookup_kernel") + " + query_pair_kernel"
-                               if args.kernel == "phased" or stream_mode else f"query_{args.kernel}_kernel"),
-                    "avg_kernel_ms": round(avg_kernel_s * 1e3, 4), "launches": launches,
-                    "algorithmic_bytes_per_launch": int(bytes_launch),
-                    "bytes_per_kmer": round(bytes_launch / batch, 1),
-                    "lf_steps_per_kmer": round(int(counters[0]) / batch, 3),
-                    "blocks_per_kmer": round(blocks_read / batch, 3), "table_lookups_per_kmer": round(lookups / batch, 3),
-                    "klcp_words_per_kmer": round(klcp_words / batch, 3), "verify_reads_per_kmer": round(verify_reads / batch, 3),
-                    "random_requests_per_s": round((blocks_read + klcp_words + verify_reads) / avg_kernel_s / 1e9, 2),
-                    # the ceiling this path runs against: random line requests per second, measured with
-                    # tools/gather_bench on the same footprint (profiles/r01k_gather_entry.txt: 48 G/s for 16..64-byte reads on 69-137 GB)
-                    # (an index that fits the caches -- E. coli scale -- is not bound by it: null)
-                    "request_roofline": None if int(index.info.device_bytes) < (2 << 30) else
-                                        {"achieved": round((blocks_read + klcp_words + verify_reads) / avg_kernel_s / 1e9, 2), "peak": 48.0,
-                                         "unit": "G random requests/s",
-                                         "frac": round((blocks_read + klcp_words + verify_reads) / avg_kernel_s / 1e9 / 48.0, 4)},
-                    "table_entry_bytes": entry_used_b,
-                    "useful_bytes_per_kmer": round((bytes_launch - (lookup_b - entry_used_b) * lookups) / batch, 1),
-                    "useful_frac": round((bytes_launch - (lookup_b - entry_used_b) * lookups) / avg_kernel_s / 1e9 / HBM_PEAK_GBS, 4),
-                    "canonical_lf_steps_per_kmer": round(int(canonical[0]) / batch, 3),
-                    "canonical_achieved": round(canon_bytes / avg_kernel_s / 1e9, 1),
-                    "canonical_frac": round(canon_bytes / avg_kernel_s / 1e9 / HBM_PEAK_GBS, 4),
-                    "lf_path": lf_path}
-        info = index.info
-        if stream_mode:
-            scale = "human-genome scale" if n >= 2e9 else ("pangenome scale" if n >= 5e8 else ("E. coli scale" if n <= 1e7 else "synthetic scale"))
-            wl = (f"synthetic max-ones masked superstring n={n} ({scale}), reads of {args.read_len} bases (50% from the "
-                  f"superstring, half of those reverse-complemented, {args.subst_ppm} substitutions per million), every {k}-mer window, "
-                  f"fmsi query -S -O semantics (kLCP streaming)")
+    if rank != 0:
+        os.close(json_fd)
+        if multi:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    total_q = batch * world * args.steps
+    value = total_q / elapsed_max
+    info = index.info
+    roof = roofline_of(path, m, info) if m["counters"] is not None else None
+    cpu_baseline = None
+    if args.cpu_sample != 0 and world == 1:   # reported baseline: rank 0 of the 1-GPU run only
+        try:
+            import bench_cpu   # the only part of the benchmark that touches oracle/
+            cpu_baseline = bench_cpu.run_stream(args, index, n, k) if stream_mode else bench_cpu.run(args, index, n, k)
+        except Exception as e:   # the baseline is a reported figure, never a reason to lose the GPU line
+            cpu_baseline = {"error": repr(e)}
+    info_d = {"n": int(info.n), "device_bytes": int(info.device_bytes), "dict_bytes": int(info.dict_bytes), "dict_levels": int(info.dict_levels),
+              "dict_log2_buckets": int(info.dict_log2_buckets), "dict_keys": [int(x) for x in info.dict_keys][:int(info.dict_levels)],
+              "dict_chain_bytes": int(info.dict_chain_bytes), "prefix_len": int(info.prefix_len), "candidate_entry_bytes": int(info.candidate_entry_bytes)}
+    # ---- everything below runs in child processes: the handle goes first ----
+    del path, d_out, d_bits, d_gather, h_bits, bufs, d_cnt
+    index.close()
+    del index
+    torch.cuda.empty_cache()
+    fm.trim_scratch(c.local_rank)
+
+    if roof is not None and world == 1 and not args.no_pmc and not os.environ.get("FMSI_BENCH_NO_PMC") and via in ("dict", "runs_chain", "runs_plain", "klcp"):
+        plan = [{"name": "headline", "via": via, "subst_ppm": args.subst_ppm, "batch": batch}]
+        for leg in (lf_path or []):
+            plan.append({"name": leg["via"], "via": leg["via"], "batch": batch})
+        extra = ["--workload", args.workload, "--stream-via", args.stream_via, "--subst-ppm", str(args.subst_ppm)] + ([] if args.dict_chain else ["--no-dict-chain"]) + \
+            base_child_args(args, n, args.batch)
+        got, why = measure_traffic(args, plan, extra)
+        if got:
+            t = got["headline"]
+            roof["traffic"], roof["traffic_source"], roof["traffic_by_kernel"] = t["traffic"], t["source"], t["by_kernel"]
+            roof["traffic_over_algorithmic"] = round(t["traffic"] / roof["algorithmic_bytes_per_launch"], 4)
+            roof["hbm_frac"] = round(t["traffic"] / (roof["avg_kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+            for leg in (lf_path or []):
+                tt = got.get(leg["via"])
+                if tt:
+                    leg["hbm_traffic"] = tt["traffic"]
+                    leg["hbm_gbs"] = round(tt["traffic"] / (leg["ms"] * 1e-3) / 1e9, 1)
+                    leg["hbm_frac"] = round(tt["traffic"] / (leg["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+                    leg["traffic_by_kernel"] = tt["by_kernel"]
         else:
-            scale = "human-genome scale" if n >= 2e9 else ("pangenome scale" if n >= 5e8 else ("E. coli scale" if n <= 1e7 else "synthetic scale"))
-            wl = (f"synthetic max-ones masked superstring n={n} ({scale}), isolated random {k}-mers 50% present, "
-                  f"fmsi query -O semantics")
-        if args.repeat_permille:
-            wl += (f"; {args.repeat_permille / 10:.0f}% of the superstring's 2048-base segments are copies of {args.repeat_families} repeat "
-                   f"families at {args.repeat_divergence_permille / 10:.0f}% divergence")
-        line = {
-            "metric": "k-mer membership queries/sec (k=31)", "value": value, "unit": "k-mers/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed_max / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
-            "config": {"workload": wl, "index_rows": int(info.n), "k": k, "queries_per_step_per_gpu": batch, "mode": args.mode,
-                       "kernel": (("dictionary-chained-runs" if args.dict_chain else "dictionary-runs") if stream_mode else "dictionary") if use_dict else
-                                 (("phased-runs" if args.stream_via == "runs" else "stream") if stream_mode else args.kernel),
-                       "accelerator": ({"kind": "k-mer dictionary", "bytes": int(info.dict_bytes), "levels": int(info.dict_levels),
-                                        "log2_buckets": int(info.dict_log2_buckets), "keys_per_level": [int(x) for x in info.dict_keys][:int(info.dict_levels)],
-                                        "chain_bytes": int(info.dict_chain_bytes),
-                                        "build_seconds": round(accel_s, 2)} if use_dict else
-                                       {"kind": "prefix table + candidate tables", "prefix_table_len": int(info.prefix_len),
-                                        "candidate_entry_bytes": int(info.candidate_entry_bytes)}),
-                       "prefix_table_len": int(info.prefix_len), "index_bytes_hbm": int(info.device_bytes),
-                       "candidate_entry_bytes": int(info.candidate_entry_bytes),
-                       "block_bytes": 128 if (args.kernel in ("pair", "phased") and not stream_mode) or (stream_mode and args.stream_via == "runs") else 64,
-                       "parallelism": f"query-sharded x{world}, index replicated", "positive_fraction": round(positives, 4),
-                       "results": ("bit-packed (FMSI_HIP_OUT_BITS), copied to page-locked host memory inside the timed region"
-                                   + (", after the RCCL gather to rank 0" if multi else "")) if bits else "one byte per window, left in HBM",
-                       "results_on_host_match_bytes": bits_check, "host_enqueue_ms_per_step": round(enqueue_s / args.steps * 1e3, 3),
-                       "index_build_seconds": round(build_s, 2)},
-            "roofline": roof,
-            "cpu_baseline": None,
-        }
-        if gather_note is not None:
-            line["config"]["gather"] = gather_note
-        if args.cpu_sample != 0 and world == 1:   # reported baseline: rank 0 of the 1-GPU run only
-            try:
-                import bench_cpu   # the only part of the benchmark that touches oracle/
-                line["cpu_baseline"] = bench_cpu.run_stream(args, index, n, k) if stream_mode else bench_cpu.run(args, index, n, k)
-            except Exception as e:   # the baseline is a reported figure, never a reason to lose the GPU line
-                line["cpu_baseline"] = {"error": repr(e)}
-        os.write(json_fd, (json.dumps(line) + "\n").encode())
+            roof["traffic_source"] = f"not measured in this run: {why}"
+    if roof is not None:
+        roof["lf_path"] = lf_path
+
+    scale = "human-genome scale" if n >= 2e9 else ("pangenome scale" if n >= 5e8 else ("E. coli scale" if n <= 1e7 else "synthetic scale"))
+    if stream_mode:
+        wl = (f"synthetic max-ones masked superstring n={n} ({scale}), reads of {args.read_len} bases (50% from the "
+              f"superstring, half of those reverse-complemented, {args.subst_ppm} substitutions per million), every {k}-mer window, "
+              f"fmsi query -S -O semantics")
+    else:
+        wl = (f"synthetic max-ones masked superstring n={n} ({scale}), isolated random {k}-mers 50% present, fmsi query -O semantics")
+    if use_dict:
+        wl += "; answered by the handle's k-mer dictionary (a hash table of the index's answers: one 128-byte read and no LF step per k-mer; the LF walk is roofline.lf_path)"
+    if args.repeat_permille:
+        wl += (f"; {args.repeat_permille / 10:.0f}% of the superstring's 2048-base segments are copies of {args.repeat_families} repeat "
+               f"families at {args.repeat_divergence_permille / 10:.0f}% divergence")
+    line = {
+        "metric": "k-mer membership queries/sec (k=31)", "value": value, "unit": "k-mers/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed_max / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+        "config": {"workload": wl, "index_rows": info_d["n"], "k": k, "queries_per_step_per_gpu": batch, "mode": args.mode,
+                   "kernel": {"dict": "dictionary", "runs_chain": "dictionary-chained-runs", "runs_plain": "dictionary-runs", "runs_tables": "phased-runs",
+                              "klcp": "stream"}.get(via, args.kernel),
+                   "accelerator": ({"kind": "k-mer dictionary", "bytes": info_d["dict_bytes"], "levels": info_d["dict_levels"],
+                                    "log2_buckets": info_d["dict_log2_buckets"], "keys_per_level": info_d["dict_keys"],
+                                    "chain_bytes": info_d["dict_chain_bytes"], "build_seconds": round(accel_s, 2),
+                                    "lf_steps_per_query": 0} if use_dict else
+                                   {"kind": "prefix table + candidate tables", "prefix_table_len": info_d["prefix_len"],
+                                    "candidate_entry_bytes": info_d["candidate_entry_bytes"]}),
+                   "prefix_table_len": info_d["prefix_len"], "index_bytes_hbm": info_d["device_bytes"],
+                   "candidate_entry_bytes": info_d["candidate_entry_bytes"],
+                   "parallelism": f"query-sharded x{world}, index replicated", "positive_fraction": round(m["positives"], 4),
+                   "results": ("bit-packed (FMSI_HIP_OUT_BITS), copied to page-locked host memory inside the timed region"
+                               + (f", {args.host_copy} copies beside the RCCL gather to rank 0's HBM" if multi else "")) if bits else "one byte per window, left in HBM",
+                   "results_on_host_match_bytes": m["bits_check"], "host_enqueue_ms_per_step": round(m["enqueue_s"] / args.steps * 1e3, 3),
+                   "index_build_seconds": round(max(build_all), 2), "index_build_seconds_per_rank": [round(x, 2) for x in build_all]},
+        "roofline": roof,
+        "cpu_baseline": cpu_baseline,
+    }
+    if gather_note is not None:
+        line["config"]["gather"] = gather_note
+    if world == 1 and not multi and not stream_mode and use_dict and not args.no_config_legs and not args.repeat_permille:
+        t0 = time.time()
+        line["configs"] = run_config_legs(args)
+        line["config"]["config_legs_seconds"] = round(time.time() - t0, 1)
+    os.write(json_fd, (json.dumps(line) + "\n").encode())
     os.close(json_fd)
     if multi:
         dist.barrier()

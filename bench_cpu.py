@@ -238,3 +238,80 @@ def run_stream(args, index, n, k):
         "socket_sample": f"{cores} forked workers x {per_worker} further reads each, slowest worker {max(secs):.2f} s",
         "index_export_seconds": round(prep_s, 1), "cpu_model": _cpu_model(), "logical_cpus": os.cpu_count(), "cgroup_cpu_quota": quota,
     }
+
+
+def check_legs(c, args, index, paths, names):
+    """The `configs` legs of bench.py: a bounded sample of every variant's queries against the real reference (oracle/_ref; the oracle's
+    restatement when it did not travel) on the SAME index -- written here by the product's own writer (fmsi_hip_index_write_files: byte
+    identical to the reference's files on the goldens and on a 10^8-row index the reference built; 1 s at human scale where the oracle's
+    single-threaded RRR encoder takes 18 s) and loaded by the reference's load_index().  Isolated k-mers: query_kmers() per k-mer;
+    reads: the reference's record loop with -S (has_klcp) over a FASTA of the first reads of the variant's seeded stream.  The GPU side
+    answers the same sample through the variant's own path (same entry point, same flags).  Returns {name: {"matches", "what"}}."""
+    import torch
+    import fmsi_amd as fm
+    import oracle_py
+    from bench import QueryPath
+
+    k = args.k
+    mode = oracle_py.MODE_ALL if args.mode == "all" else oracle_py.MODE_OR
+    n_rows = int(index.info.n)
+    has_klcp = bool(index.info.has_klcp)
+    tmp = tempfile.TemporaryDirectory(dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    prefix = os.path.join(tmp.name, "leg")
+    t0 = time.time()
+    index.write_files(prefix)
+    write_s = time.time() - t0
+    t0 = time.time()
+    if oracle_py.ref_available():
+        ref, kind = oracle_py.Reference.load(prefix, use_klcp=has_klcp), "the real reference (oracle/_ref)"
+    else:
+        ref, kind = oracle_py.Oracle.load(prefix, use_klcp=has_klcp), "the oracle's C restatement (oracle/_ref did not travel)"
+    load_s = time.time() - t0
+    out = {}
+    stream_expected = {}   # subst_ppm -> (bits per read, seconds, reads)
+    for path, name in zip(paths, names):
+        if not path.stream_mode:
+            sample = 1_000_000 if n_rows < 2e8 else 200_000
+            p = QueryPath(c, args, index, path.via, k, sample)
+            d = torch.empty(sample, dtype=torch.int64, device=c.dev_t)
+            d_out = torch.empty(sample, dtype=torch.uint8, device=c.dev_t)
+            p.make_input(0, d)
+            p.launch(d, d_out)
+            torch.cuda.synchronize()
+            text = _kmers_to_text(d.cpu().numpy().view(np.uint64), k)
+            sec, bits = ref.time_isolated_kmers(text, sample, k, mode)
+            out[name] = {"matches": bool(np.array_equal(bits, d_out.cpu().numpy())),
+                         "what": f"{kind}: query_kmers() on the first {sample} k-mers of the leg's seeded stream, {sample / sec:.0f} k-mers/s on one core, against the "
+                                 f"same {n_rows}-row index (files by fmsi_hip_index_write_files {write_s:.1f} s, load_index {load_s:.1f} s)"}
+            continue
+        L = path.read_len
+        wins = L - k + 1
+        reads = 30
+        p = QueryPath(c, args, index, path.via, k, reads * wins, L, path.subst_ppm)
+        d = torch.empty(p.in_words, dtype=torch.int64, device=c.dev_t)
+        d_out = torch.empty(p.batch, dtype=torch.uint8, device=c.dev_t)
+        p.make_input(0, d)
+        p.launch(d, d_out)
+        torch.cuda.synchronize()
+        gpu_bits = d_out.cpu().numpy().reshape(p.n_reads, wins)
+        if path.subst_ppm not in stream_expected:
+            packed = d.cpu().numpy().view(np.uint64)
+            codes = ((packed[:, None] >> (2 * np.arange(32, dtype=np.uint64))) & np.uint64(3)).astype(np.uint8).reshape(-1)[:p.n_reads * L]
+            bases = np.frombuffer(b"ACGT", dtype=np.uint8)[codes].reshape(p.n_reads, L)
+            fa = os.path.join(tmp.name, f"s{path.subst_ppm}.fa")
+            with open(fa, "wb") as f:
+                for r in range(p.n_reads):
+                    f.write(b">r%d\n" % r)
+                    f.write(bases[r].tobytes())
+                    f.write(b"\n")
+            text, sec = ref.query_file(fa, k, has_klcp=has_klcp, mode=mode, cap=p.n_reads * (wins + 32) + 4096)
+            want = np.array([np.frombuffer(line.split("\t")[1].encode(), dtype=np.uint8) - ord("0") for line in text.splitlines()])
+            stream_expected[path.subst_ppm] = (want, sec, p.n_reads)
+        want, sec, nr = stream_expected[path.subst_ppm]
+        out[name] = {"matches": bool(want.shape == gpu_bits.shape and np.array_equal(want, gpu_bits)),
+                     "what": f"{kind}: its record loop with -S -O (query_kmers<all>(..., has_klcp=true)) over the first {nr} reads ({nr * wins} windows) of the leg's "
+                             f"seeded read stream, {nr * wins / sec:.0f} windows/s on one core, against the same {n_rows}-row index incl. its kLCP array "
+                             f"(files by fmsi_hip_index_write_files {write_s:.1f} s, load_index {load_s:.1f} s)"}
+    ref.close()
+    tmp.cleanup()
+    return out

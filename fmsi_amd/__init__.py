@@ -34,6 +34,7 @@ DICT_SPARSE = 0x1
 DICT_CHAIN = 0x2
 NO_PREFIX_TABLE = 0x100
 OUT_BITS = 0x200
+NO_DICT_CHAIN = 0x400
 FN_AND, FN_XOR, FN_RANGE = 1, 2, 3   # demasking functions of query_runs_fn (`-f and|xor|r-s`)
 N_COUNTERS = 8
 

@@ -782,7 +782,7 @@ int launch_dict_query(fmsi_hip_index* idx, const uint64_t* d_in, uint64_t n, int
 
 bool dict_chain_applies(const fmsi_hip_index* idx, int k, uint32_t flags) {
     static const bool off = std::getenv("FMSI_HIP_NO_CHAIN") != nullptr;   // A/B switch for measurements
-    return !off && idx->dict.slot_pos != nullptr && dict_applies(idx, k, flags);
+    return !off && !(flags & FMSI_HIP_NO_DICT_CHAIN) && idx->dict.slot_pos != nullptr && dict_applies(idx, k, flags);
 }
 
 int launch_dict_chain(fmsi_hip_index* idx, const uint64_t* d_seq, uint64_t n, int k, uint32_t flags, uint8_t* o8, unsigned long long* d_counters, hipStream_t s,

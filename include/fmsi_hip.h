@@ -78,6 +78,9 @@ extern "C" {
  * with STRICT, nibble (w & 15) of word w >> 4 holding the STRICT byte below.  ceil(n / 64) resp. ceil(n / 16) words; the unused
  * high bits of the last word are zero.  One eighth (half) of the bytes over PCIe and over xGMI (fmsi_hip_gather). */
 #define FMSI_HIP_OUT_BITS 0x200u
+/* fmsi_hip_query_runs on a handle whose dictionary has the chained lookups' extras: take the plain lookups (one bucket read per window)
+ * for this call -- A/B runs of the two forms on one handle */
+#define FMSI_HIP_NO_DICT_CHAIN 0x400u
 
 /* ---- index creation flags --------------------------------------------------------------------- */
 /* build a 4^t-entry prefix table that jumps the first t LF steps (private optimisation: the final SA
