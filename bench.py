@@ -256,7 +256,9 @@ class QueryPath:
         self.c, self.args, self.index, self.via, self.k, self.subst_ppm = c, args, index, via, k, subst_ppm
         self.stream_mode = via in ("runs_chain", "runs_plain", "runs_tables", "klcp")
         mode = fm.MODE_ALL if args.mode == "all" else fm.MODE_OR
-        self.block_b = 64 if via in ("klcp", "lf_lockstep") or (via == "legacy" and args.kernel in ("refill", "lockstep")) else 128
+        # (the kLCP kernel reads 128-byte S-blocks since round 3; FMSI_HIP_STREAM_V1 brings the 64-byte-block kernel back)
+        self.block_b = 64 if via == "lf_lockstep" or (via == "klcp" and os.environ.get("FMSI_HIP_STREAM_V1")) or \
+            (via == "legacy" and args.kernel in ("refill", "lockstep")) else 128
         self.is_dict = via in ("dict", "runs_chain", "runs_plain")
         if self.stream_mode:
             L = self.read_len = read_len
@@ -268,9 +270,9 @@ class QueryPath:
             self.in_bytes = self.n_reads * L / 4.0
             self.flags = mode | {"runs_chain": fm.KERNEL_DICT, "runs_plain": fm.KERNEL_DICT | fm.NO_DICT_CHAIN, "runs_tables": 0, "klcp": 0}[via]
             self.kernel = {"runs_chain": "dict_chain_kernel", "runs_plain": "dict_lookup_kernel", "runs_tables": "lookup_lane_kernel + query_pair_kernel",
-                           "klcp": "query_stream_kernel"}[via]
+                           "klcp": "query_stream_kernel" if os.environ.get("FMSI_HIP_STREAM_V1") else "query_stream2_kernel"}[via]
             self.pmc_kernel = {"runs_chain": "dict_chain_kernel<false>", "runs_plain": "dict_lookup_kernel<false, true>", "runs_tables": "lookup_lane_kernel<false",
-                               "klcp": "query_stream_kernel<false"}[via]
+                               "klcp": "query_stream2_kernel<false"}[via]
         else:
             self.batch = int(batch)
             self.in_words = self.batch
@@ -509,12 +511,14 @@ def roofline_of(path, m, info):
 # ======================================================================================================================================
 def fetch_factor(kernel_name):
     """FETCH_SIZE correction per kernel (MI355X_MICROARCH.md, HBM: gfx950 tallies a 128-byte request at 64 B -- 0.50x -- as it does wide
-    coalesced streaming reads; random 64-byte reads are tallied at 1.015x: tools/gather_bench calibration, profiles/README.md r01)."""
-    if any(t in kernel_name for t in ("query_lockstep_kernel", "query_refill_kernel", "query_fn_kernel", "query_longk_kernel")):
-        return 1.0 / 1.015
-    if "query_stream_kernel" in kernel_name:   # 64-byte blocks and table lines, 8-byte kLCP words
-        return 1.0 / 1.015
-    return 2.0
+    coalesced streaming reads; random 64-byte reads are tallied at 1.015x: tools/gather_bench calibration, profiles/README.md r01).
+    Returns (factor, 128-byte lines counted at half): kernels that MIX 128-byte block reads with small reads (the streaming kernel: S-blocks
+    beside 8-byte table entries and task records) get raw + 64 B x their 128-byte line reads per launch instead of a factor."""
+    if any(t in kernel_name for t in ("query_lockstep_kernel", "query_refill_kernel", "query_fn_kernel", "query_longk_kernel", "query_stream_kernel")):
+        return 1.0 / 1.015, False
+    if "query_stream2_kernel" in kernel_name:
+        return 1.0, True
+    return 2.0, False
 
 
 def pmc_child(c, args, index, plan):
@@ -546,7 +550,7 @@ def measure_traffic(args, plan, child_args):
     if prof is None:
         return None, "rocprofv3 not found"
     child = [sys.executable, str(REPO / "bench.py"), "--pmc-child", "--pmc-plan", json.dumps(plan)] + child_args
-    per_variant = [dict(name=v["name"], kernels={}) for v in plan]
+    per_variant = [dict(name=v["name"], kernels={}, lines128=v.get("lines128")) for v in plan]
     env = dict(os.environ, TMPDIR="/tmp")
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
         with tempfile.TemporaryDirectory(dir="/tmp") as d:
@@ -585,7 +589,9 @@ def measure_traffic(args, plan, child_args):
         fetched = written = raw = 0.0
         by_kernel = {}
         for name, kk in pv["kernels"].items():
-            f = fetch_factor(name)
+            f, add_lines = fetch_factor(name)
+            if add_lines:
+                fetched += 64.0 * float(pv.get("lines128") or 0)
             fetched += f * kk["FETCH_SIZE"] / 3.0
             raw += kk["FETCH_SIZE"] / 3.0
             written += kk["WRITE_SIZE"] / 3.0
@@ -595,7 +601,8 @@ def measure_traffic(args, plan, child_args):
         out[pv["name"]] = {"traffic": fetched + written, "fetch_raw": raw, "fetch": fetched, "write": written, "by_kernel": by_kernel,
                            "source": (f"measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (a child run each, 3 launches per variant); raw FETCH_SIZE "
                                       f"{raw / 1e9:.3f} GB -> {fetched / 1e9:.3f} GB (x2 where the kernel reads 128-B requests or wide coalesced streams, which gfx950 "
-                                      f"tallies at half; /1.015 for random 64-B block reads) + WRITE_SIZE {written / 1e9:.3f} GB")}
+                                      f"tallies at half; /1.015 for random 64-B block reads; raw + 64 B per 128-B block read where a kernel mixes them with small reads) "
+                                      f"+ WRITE_SIZE {written / 1e9:.3f} GB")}
     return out, None
 
 
@@ -713,7 +720,8 @@ def run_leg(args):
                      "lf_steps_per_kmer": roof.get("lf_steps_per_kmer"), "random_requests_per_s": roof.get("random_requests_per_s"),
                      "positive_fraction": round(m["positives"], 4), "results_on_host_match_bytes": m["bits_check"],
                      "index_rows": int(info.n), "handle_bytes_hbm": int(info.device_bytes), "dict_bytes": int(info.dict_bytes), "dict_chain_bytes": int(info.dict_chain_bytes),
-                     "index_build_seconds": round(build_s, 2), "matches_reference": None, "reference": None})
+                     "index_build_seconds": round(build_s, 2), "matches_reference": None, "reference": None,
+                     "_lines128": int(m["counters"][1]) - int(m["counters"][4]) if path.block_b == 128 and not path.is_dict else 0})
         paths.append(path)
         del m
     # ---- a sample of every variant against the real reference (bench_cpu.py: the only user of oracle/) ----
@@ -733,7 +741,7 @@ def run_leg(args):
     c.torch.cuda.empty_cache()
     c.fm.trim_scratch(c.local_rank)
     if not args.no_pmc and not os.environ.get("FMSI_BENCH_NO_PMC"):
-        plan = [{"name": vn, "via": via, "subst_ppm": s, "batch": batch} for vn, via, s in variants]
+        plan = [{"name": vn, "via": via, "subst_ppm": s, "batch": batch, "lines128": leg["_lines128"]} for (vn, via, s), leg in zip(variants, legs)]
         extra = ["--workload", workload, "--stream-via", "runs", "--leg-handle", name] + base_child_args(args, n, batch)
         got, why = measure_traffic(args, plan, extra)
         for leg in legs:
@@ -747,6 +755,8 @@ def run_leg(args):
                     leg["hbm_frac"] = round(t["traffic"] / (leg["avg_kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
             else:
                 leg["traffic_source"] = f"not measured: {why}"
+    for leg in legs:
+        leg.pop("_lines128", None)
     os.write(json_fd, (json.dumps(legs) + "\n").encode())
     os.close(json_fd)
 
@@ -943,7 +953,8 @@ def main():
     fm.trim_scratch(c.local_rank)
 
     if roof is not None and world == 1 and not args.no_pmc and not os.environ.get("FMSI_BENCH_NO_PMC") and via in ("dict", "runs_chain", "runs_plain", "klcp"):
-        plan = [{"name": "headline", "via": via, "subst_ppm": args.subst_ppm, "batch": batch}]
+        plan = [{"name": "headline", "via": via, "subst_ppm": args.subst_ppm, "batch": batch,
+                 "lines128": int(m["counters"][1]) - int(m["counters"][4]) if via == "klcp" else 0}]
         for leg in (lf_path or []):
             plan.append({"name": leg["via"], "via": leg["via"], "batch": batch})
         extra = ["--workload", args.workload, "--stream-via", args.stream_via, "--subst-ppm", str(args.subst_ppm)] + ([] if args.dict_chain else ["--no-dict-chain"]) + \

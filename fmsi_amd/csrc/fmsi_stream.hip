@@ -582,6 +582,525 @@ __global__ __launch_bounds__(256) void query_stream_kernel(DevIndex ix, const ui
     }
 }
 
+// ======================================================================================================================
+// Round 3: the streaming kernel for k <= 32 presence queries over a layout of its own ("S-blocks").
+//
+// What bound the kernel above (SQ counters + tools/gather_bench): a streamed window cost its lane FOUR 16-byte loads
+// of its own 64-byte block plus one or two 8-byte kLCP words -- the memory path charges per load instruction and distinct line, so
+// that is 5-6 units per window where one would do -- and some 950 VALU instructions per wave round went into a six-state machine
+// that kept its result bytes in LDS.  Here:
+//   * one S-block = 128 bytes = 192 rows carrying EVERYTHING a streamed window needs -- cumulative symbol counts, counts after 64 and
+//     128 rows (a rank is one 64-bit popcount, not four masked 32-bit ones), the hi / lo / mask planes AND the kLCP plane of its rows
+//     (plus the kLCP bit of the row before the block and the cumulative mask rank) -- so a positive window is ONE 128-byte request;
+//   * the lines are fetched cooperatively: eight lanes load 16 bytes each of one lane's line in ONE instruction (eight instructions
+//     serve the wave's 64 lines), pass them through LDS (144-byte pitch: conflict-free b128 reads) and the owner reads the few words
+//     it needs -- one unit per line, as in the dictionary's kernel;
+//   * the rare second line of an interval that straddles two blocks is read by its lane directly (six small loads);
+//   * prefix-table entries are 8-byte loads of the owning lane (one instruction, one unit per entry);
+//   * a task's results live in registers (two bit planes per strand) and leave as one 64-byte line per task.
+// Control flow -- tasks of <= 64 windows, pass 0 on one strand, pass 1 over the undecided windows of the other, the reverse-complement
+// probe of the task's last window -- is the kernel's above, and so are the answers (tests/test_gpu_stream.py: stream2 == stream == runs).
+// ORDERS (`lookup -S`) and 33 <= k <= 64 stay with the kernel above.
+constexpr uint32_t kSRows = 192;
+constexpr uint32_t kSDwords = 32;
+constexpr uint32_t kSPitch = 9;   // uint4 per staged line in LDS: 144 bytes
+
+// S-blocks from the single-step blocks + the plain kLCP words; one thread per S-block
+__global__ __launch_bounds__(256) void sblock_build_kernel(const uint32_t* __restrict__ blocks, const uint32_t* __restrict__ mrank, uint64_t n_blocks,
+                                                           const uint32_t* __restrict__ klcp32, uint64_t klcp_dwords, uint64_t n_sblocks,
+                                                           uint32_t* __restrict__ out) {
+    const uint64_t b = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (b >= n_sblocks) return;
+    uint32_t hi[6], lo[6], mk[6], kl[6];
+#pragma unroll
+    for (uint32_t d = 0; d < 6; ++d) {
+        const uint64_t g = 6 * b + d;             // dword of the planes (32 rows each)
+        const uint64_t sb = g >> 2;
+        const uint32_t w = static_cast<uint32_t>(g & 3u);
+        const bool in = sb < n_blocks;
+        hi[d] = in ? blocks[sb * kBlockDwords + 4 + w] : 0u;
+        lo[d] = in ? blocks[sb * kBlockDwords + 8 + w] : 0u;
+        mk[d] = in ? blocks[sb * kBlockDwords + 12 + w] : 0u;
+        kl[d] = g < klcp_dwords ? klcp32[g] : 0u;
+    }
+    // counts before row 192 b: through source block (192 b) >> 7 at offset 0 or 64
+    const uint64_t row = b * kSRows;
+    const uint64_t sb0 = row >> kBlockRowsLog2;
+    const uint32_t off = static_cast<uint32_t>(row & (kBlockRows - 1u));
+    uint32_t cnt[4] = {0, 0, 0, 0}, mr = 0;
+    if (sb0 < n_blocks) {
+        const uint32_t* src = blocks + sb0 * kBlockDwords;
+        mr = mrank[sb0];
+        for (uint32_t c = 0; c < 4; ++c) cnt[c] = src[c];
+        if (off) {   // off == 64: the first two plane dwords of the source block come before this S-block
+            for (uint32_t w = 0; w < 2; ++w) {
+                const uint32_t h = src[4 + w], l = src[8 + w];
+                cnt[0] += __popc(~h & ~l);
+                cnt[1] += __popc(~h & l);
+                cnt[2] += __popc(h & ~l);
+                cnt[3] += __popc(h & l);
+                mr += __popc(src[12 + w]);
+            }
+        }
+    }
+    uint32_t sub[2] = {0, 0}, msub = 0;
+    {
+        uint32_t a[4] = {0, 0, 0, 0}, m = 0;
+        for (uint32_t d = 0; d < 4; ++d) {
+            a[0] += __popc(~hi[d] & ~lo[d]);
+            a[1] += __popc(~hi[d] & lo[d]);
+            a[2] += __popc(hi[d] & ~lo[d]);
+            a[3] += __popc(hi[d] & lo[d]);
+            m += __popc(mk[d]);
+            if (d == 1) {
+                sub[0] = a[0] | (a[1] << 8) | (a[2] << 16) | (a[3] << 24);
+                msub = m;
+            }
+        }
+        sub[1] = a[0] | (a[1] << 8) | (a[2] << 16) | (a[3] << 24);
+        msub |= m << 8;
+    }
+    uint32_t prev_klcp = 0;
+    if (row > 0) {
+        const uint64_t g = (row - 1) >> 5;
+        prev_klcp = g < klcp_dwords ? (klcp32[g] >> ((row - 1) & 31u)) & 1u : 0u;
+    }
+    uint32_t* o = out + b * kSDwords;
+    o[0] = cnt[0]; o[1] = cnt[1]; o[2] = cnt[2]; o[3] = cnt[3];
+    o[4] = sub[0]; o[5] = sub[1]; o[6] = mr; o[7] = msub | (prev_klcp << 31);
+#pragma unroll
+    for (uint32_t d = 0; d < 6; ++d) {
+        o[8 + d] = hi[d];
+        o[14 + d] = lo[d];
+        o[20 + d] = mk[d];
+        o[26 + d] = kl[d];
+    }
+}
+
+// what a lane takes out of one S-block for the boundaries it ranks: by pointer into LDS (line A) or from registers (line B)
+struct SPiece {
+    uint32_t cnt, sub;        // cumulative count of c before the block; count of c in the block's first 64 q rows
+    uint64_t hw, lw;          // hi / lo words of rows 64 q .. 64 q + 63
+    uint32_t mrank, msub;     // the same for the mask
+    uint64_t mw;
+};
+__device__ __forceinline__ uint64_t below64(uint32_t r) { return r >= 64u ? ~0ull : ((1ull << r) - 1ull); }
+__device__ __forceinline__ uint32_t s_quarter(uint32_t p) { return p >= 128u ? 2u : (p >> 6); }   // p in [0, 192]
+__device__ __forceinline__ uint32_t spiece_rank(const SPiece& x, uint32_t c, uint32_t p, uint32_t q) {
+    const uint64_t xh = (c & 2u) ? 0ull : ~0ull, xl = (c & 1u) ? 0ull : ~0ull;
+    return x.cnt + x.sub + static_cast<uint32_t>(__popcll((x.hw ^ xh) & (x.lw ^ xl) & below64(p - 64u * q)));
+}
+__device__ __forceinline__ uint32_t spiece_mask_rank(const SPiece& x, uint32_t p, uint32_t q) {
+    return x.mrank + x.msub + static_cast<uint32_t>(__popcll(x.mw & below64(p - 64u * q)));
+}
+// from the staged line (dword pointer into LDS)
+__device__ __forceinline__ SPiece spiece_lds(const uint32_t* L, uint32_t c, uint32_t q) {
+    SPiece x;
+    x.cnt = L[c];
+    x.sub = q ? (L[3u + q] >> (8u * c)) & 0xFFu : 0u;
+    x.hw = *reinterpret_cast<const uint64_t*>(L + 8u + 2u * q);
+    x.lw = *reinterpret_cast<const uint64_t*>(L + 14u + 2u * q);
+    x.mrank = L[6];
+    x.msub = q ? (L[7] >> (8u * (q - 1u))) & 0xFFu : 0u;
+    x.mw = *reinterpret_cast<const uint64_t*>(L + 20u + 2u * q);
+    return x;
+}
+// straight from memory (the second line of a straddling interval: few lanes, small loads)
+__device__ __forceinline__ SPiece spiece_global(const uint32_t* __restrict__ B, uint32_t c, uint32_t q) {
+    SPiece x;
+    const uint4 h0 = *reinterpret_cast<const uint4*>(B), h1 = *reinterpret_cast<const uint4*>(B + 4);
+    x.cnt = sel4(c, h0.x, h0.y, h0.z, h0.w);
+    const uint32_t sw = q == 2u ? h1.y : h1.x;
+    x.sub = q ? (sw >> (8u * c)) & 0xFFu : 0u;
+    x.hw = *reinterpret_cast<const uint64_t*>(B + 8u + 2u * q);
+    x.lw = *reinterpret_cast<const uint64_t*>(B + 14u + 2u * q);
+    x.mrank = h1.z;
+    x.msub = q ? (h1.w >> (8u * (q - 1u))) & 0xFFu : 0u;
+    x.mw = *reinterpret_cast<const uint64_t*>(B + 20u + 2u * q);
+    return x;
+}
+
+// expands the 16 bits [16 d, 16 d + 16) of four bit planes to 16 result bytes (plane p contributes bit p of each byte)
+__device__ __forceinline__ uint32_t spread4(uint32_t nib) { return ((nib & 0xFu) * 0x00204081u) & 0x01010101u; }
+__device__ __forceinline__ uint4 result_bytes16(uint64_t p0, uint64_t p1, uint64_t p2, uint64_t p3, uint32_t d) {
+    const uint32_t a = static_cast<uint32_t>(p0 >> (16u * d)) & 0xFFFFu, b = static_cast<uint32_t>(p1 >> (16u * d)) & 0xFFFFu;
+    const uint32_t c = static_cast<uint32_t>(p2 >> (16u * d)) & 0xFFFFu, e = static_cast<uint32_t>(p3 >> (16u * d)) & 0xFFFFu;
+    uint4 r;
+    r.x = spread4(a) | (spread4(b) << 1) | (spread4(c) << 2) | (spread4(e) << 3);
+    r.y = spread4(a >> 4) | (spread4(b >> 4) << 1) | (spread4(c >> 4) << 2) | (spread4(e >> 4) << 3);
+    r.z = spread4(a >> 8) | (spread4(b >> 8) << 1) | (spread4(c >> 8) << 2) | (spread4(e >> 8) << 3);
+    r.w = spread4(a >> 12) | (spread4(b >> 12) << 1) | (spread4(c >> 12) << 2) | (spread4(e >> 12) << 3);
+    return r;
+}
+
+template <bool COUNT, bool PTABLE>
+__global__ __launch_bounds__(256, 4) void query_stream2_kernel(DevIndex ix, const uint4* __restrict__ sblocks, const uint64_t* __restrict__ klcp,
+                                                            const TaskRec* __restrict__ tasks, uint64_t n_tasks, int k, uint32_t flags, uint32_t chunk,
+                                                            uint4* __restrict__ slots, unsigned long long* __restrict__ counters) {
+    __shared__ uint4 s_line[4][64 * kSPitch];
+    const uint32_t ln = threadIdx.x & 63u;
+    uint4* my_wave_lines = s_line[threadIdx.x >> 6];
+    const uint32_t* L = reinterpret_cast<const uint32_t*>(my_wave_lines + ln * kSPitch);   // this lane's staged line
+    const uint32_t mode_all = flags & FMSI_HIP_MODE_ALL;
+    const uint32_t strict = flags & FMSI_HIP_STRICT;
+    const uint64_t wave = (static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
+    uint64_t next = wave * chunk;
+    const uint64_t end = min(n_tasks, next + static_cast<uint64_t>(chunk));
+    const int T = PTABLE ? static_cast<int>(ix.ptable_len) : 0;
+    const uint64_t kmask = k == 32 ? ~0ull : ((1ull << (2 * k)) - 1ull);
+
+    uint64_t s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+    uint32_t n = 0;
+    uint64_t kmer = 0;
+    uint64_t rf_lo = 0, rf_hi = 0;   // pass-0 result + 1 of window w in bit w of the two planes (0 = empty interval)
+    uint64_t rr_lo = 0, rr_hi = 0;   // pass-1 result + 1 (0: not visited or empty)
+    uint64_t todo = 0;
+    uint32_t i = 0, j = 0, st = SS_IDLE, pass = 0, widx = 0;
+    bool cur_rc = false, probing = false;
+    uint32_t special = 0;
+    uint64_t task_id = 0;
+    uint32_t scan_i = 0, scan_j = 0;
+    int t = 0;
+    StreamCounters cn;
+
+    auto kmer_base = [&](int tt) -> uint32_t { return static_cast<uint32_t>(kmer >> (2 * tt)) & 3u; };
+    auto load_kmer = [&]() {
+        const uint64_t f = task_kmer(s0, s1, s2, s3, widx, k);
+        kmer = !cur_rc ? f : revcomp_2bit(f, k);
+    };
+    auto fresh = [&]() {
+        if (COUNT) cn.searches++;
+        if (PTABLE) {
+            st = SS_LOOKUP;
+        } else {
+            i = 0;
+            j = ix.n;
+            t = k - 1;
+            st = SS_LF;
+        }
+    };
+    auto end_task = [&]() {
+        uint64_t p0, p1, p2, p3;
+        if (strict) {   // byte = (f + 1) | (r + 1) << 2
+            p0 = rf_lo; p1 = rf_hi; p2 = rr_lo; p3 = rr_hi;
+        } else {
+            const uint64_t f1 = rf_hi & ~rf_lo, r1 = rr_hi & ~rr_lo;
+            p0 = mode_all ? (((rf_lo | rf_hi) & f1) | (~(rf_lo | rf_hi) & r1)) : (f1 | r1);   // ALL: (f != -1 ? f : r) == 1; OR: f == 1 || r == 1
+            p1 = p2 = p3 = 0;
+        }
+        uint4* dst = slots + (task_id << 2);
+        dst[0] = result_bytes16(p0, p1, p2, p3, 0);
+        dst[1] = result_bytes16(p0, p1, p2, p3, 1);
+        dst[2] = result_bytes16(p0, p1, p2, p3, 2);
+        dst[3] = result_bytes16(p0, p1, p2, p3, 3);
+        st = SS_IDLE;
+    };
+    auto begin_pass1 = [&]() {
+        pass = 1;
+        cur_rc = !cur_rc;
+        const uint64_t all = n == 64 ? ~0ull : ((1ull << n) - 1ull);
+        if (strict) todo = all;
+        else if (!mode_all) todo = all & ~(rf_hi & ~rf_lo);   // OR: only a pass-0 result of 1 decides
+        else todo = all & ~(rf_lo | rf_hi);                   // ALL: any non-empty pass-0 interval decides
+        if (!todo) {
+            end_task();
+            return;
+        }
+        if (cur_rc) {
+            widx = static_cast<uint32_t>(__ffsll(static_cast<unsigned long long>(todo))) - 1u;
+            todo &= todo - 1;
+        } else {
+            widx = 63u - static_cast<uint32_t>(__clzll(static_cast<long long>(todo)));
+            todo &= ~(1ull << widx);
+        }
+        load_kmer();
+        fresh();
+    };
+    auto window_done = [&](int res) {
+        if (!strict && pass == 0 && n > 1u) {
+            if (probing) {
+                probing = false;
+                if (res != -1) {
+                    special = 2;
+                    return;
+                }
+                cur_rc = false;
+                load_kmer();
+                res = -1;
+            } else if (!cur_rc && res == -1 && widx == n - 1u) {
+                probing = true;
+                special = 1;
+                return;
+            }
+        }
+        const uint64_t bit = 1ull << widx;
+        const uint32_t v = static_cast<uint32_t>(res + 1);
+        if (pass == 0) {
+            if (v & 1u) rf_lo |= bit;
+            if (v & 2u) rf_hi |= bit;
+        } else {
+            if (v & 1u) rr_lo |= bit;
+            if (v & 2u) rr_hi |= bit;
+        }
+    };
+    auto shift_fwd = [&](uint32_t w) { kmer = ((kmer << 2) | task_base(s0, s1, s2, s3, w)) & kmask; };
+    auto shift_rc = [&](uint32_t w) { kmer = ((kmer << 2) | (3u - task_base(s0, s1, s2, s3, w + static_cast<uint32_t>(k)))) & kmask; };
+    auto advance = [&](bool have) -> bool {
+        if (special) {
+            const uint32_t sp = special;
+            special = 0;
+            cur_rc = true;
+            if (sp == 2) widx = 0;
+            load_kmer();
+            fresh();
+            return false;
+        }
+        if (pass == 0) {
+            if (!cur_rc) {
+                if (widx == 0) {
+                    begin_pass1();
+                    return false;
+                }
+                --widx;
+                shift_fwd(widx);
+            } else {
+                if (widx + 1u == n) {
+                    begin_pass1();
+                    return false;
+                }
+                shift_rc(widx);
+                ++widx;
+            }
+            if (have) return true;
+            fresh();
+            return false;
+        }
+        if (!todo) {
+            end_task();
+            return false;
+        }
+        uint32_t nw;
+        bool adjacent;
+        if (cur_rc) {
+            nw = static_cast<uint32_t>(__ffsll(static_cast<unsigned long long>(todo))) - 1u;
+            todo &= todo - 1;
+            adjacent = nw == widx + 1u;
+            if (adjacent) shift_rc(widx);
+        } else {
+            nw = 63u - static_cast<uint32_t>(__clzll(static_cast<long long>(todo)));
+            todo &= ~(1ull << nw);
+            adjacent = nw + 1u == widx;
+            if (adjacent) shift_fwd(nw);
+        }
+        widx = nw;
+        if (adjacent) {
+            if (have) return true;
+        } else {
+            load_kmer();
+        }
+        fresh();
+        return false;
+    };
+
+    for (;;) {
+        {   // idle lanes draw the wave's next tasks (ballot + prefix rank, no atomics); a task's record is three 16-byte loads per 64 windows
+            const bool want = st == SS_IDLE;
+            const uint64_t m = __ballot(want);
+            if (m) {
+                const uint64_t cand = next + lanes_below(m);
+                if (want && cand < end) {
+                    const uint4* p = reinterpret_cast<const uint4*>(tasks + cand);
+                    const uint4 r0 = p[0], r1 = p[1], r2 = p[2];
+                    s0 = (static_cast<uint64_t>(r0.y) << 32) | r0.x;
+                    s1 = (static_cast<uint64_t>(r0.w) << 32) | r0.z;
+                    s2 = (static_cast<uint64_t>(r1.y) << 32) | r1.x;
+                    s3 = (static_cast<uint64_t>(r1.w) << 32) | r1.z;
+                    n = r2.z;
+                    task_id = cand;
+                    pass = 0;
+                    cur_rc = false;
+                    probing = false;
+                    special = 0;
+                    rf_lo = rf_hi = rr_lo = rr_hi = 0;
+                    widx = n - 1u;
+                    load_kmer();
+                    fresh();
+                }
+                next += static_cast<uint64_t>(__popcll(m));
+            }
+        }
+        if (!__any(st != SS_IDLE)) break;
+        // ---- this round's reads ----
+        const bool lk = PTABLE && st == SS_LOOKUP;
+        const bool need_line = st == SS_LF || st == SS_HAVE || st == SS_EXTLF;
+        uint32_t bi = 0, bj = 0;
+        if (need_line) {
+            bi = i / kSRows;
+            bj = (j - 1u) / kSRows;
+        }
+        const bool two = need_line && bj != bi;
+        uint2 ent = make_uint2(0, 0);
+        if (lk) {
+            const uint32_t tidx = static_cast<uint32_t>(kmer >> (2 * (k - T))) & static_cast<uint32_t>((1ull << (2 * T)) - 1ull);
+            ent = ix.ptable[tidx];
+        }
+        uint64_t kwi = 0, kwj = 0;
+        if (st == SS_EXTSCAN) {   // a running extension scan (rare): the plain kLCP words at the frontier
+            if (scan_i) kwi = klcp[(i - 1u) >> 6];
+            if (scan_j) kwj = klcp[(j - 1u) >> 6];
+            if (COUNT) cn.klcp_words += scan_i + scan_j;
+        }
+        const uint64_t line_mask = __ballot(need_line);
+        if (line_mask) {   // eight lanes per line, eight lines per instruction
+            const uint32_t piece = ln & 7u, grp = ln >> 3;
+            uint4 v[8];
+#pragma unroll
+            for (uint32_t g = 0; g < 8; ++g) {
+                const uint32_t owner = 8u * g + grp;
+                const uint32_t bo = static_cast<uint32_t>(__shfl(static_cast<int>(bi), static_cast<int>(owner), 64));
+                v[g] = make_uint4(0, 0, 0, 0);
+                if ((line_mask >> owner) & 1ull) v[g] = sblocks[(static_cast<size_t>(bo) << 3) + piece];
+            }
+#pragma unroll
+            for (uint32_t g = 0; g < 8; ++g) my_wave_lines[(8u * g + grp) * kSPitch + piece] = v[g];
+        }
+        if (COUNT) cn.blocks += (need_line ? 1u : 0u) + (two ? 1u : 0u) + (lk ? 1u : 0u);   // ([1] counts table lines too, [4] says how many)
+        __builtin_amdgcn_wave_barrier();
+
+        // ---- arithmetic ----
+        bool do_lf = false;
+        uint32_t c = 0;
+        if (st == SS_LOOKUP) {
+            if (COUNT) cn.lookups++;
+            t = k - 1 - T;
+            uint32_t q4 = 0;
+            if (t >= 3) q4 = kmer_base(t - 3) | (kmer_base(t - 2) << 2) | (kmer_base(t - 1) << 4) | (kmer_base(t) << 6);
+            decode_table_entry(ent.x, ent.y, ix.ptable_packed, t >= 3, q4, i, j);
+            if (i == j) {
+                window_done(-1);
+                advance(false);
+            } else {
+                st = t < 0 ? SS_HAVE : SS_LF;
+            }
+        } else if (st == SS_LF) {
+            do_lf = true;
+            c = kmer_base(t);
+        } else if (st == SS_EXTLF) {
+            do_lf = true;
+            c = kmer_base(0);
+        } else if (st == SS_HAVE) {
+            // the current window's result off the mask plane (infer_presence, fms_index.h:126-144), the kLCP bits of rows i - 1 and
+            // j - 1 off the same line(s)
+            if (COUNT) cn.probes++;
+            const uint32_t pi_off = i - bi * kSRows, pj_off = j - bj * kSRows;   // 0..191, 1..192
+            const uint32_t* B = reinterpret_cast<const uint32_t*>(sblocks) + static_cast<size_t>(bj) * kSDwords;
+            int res;
+            if (mode_all) {
+                res = static_cast<int>((L[20u + (pi_off >> 5)] >> (pi_off & 31u)) & 1u);
+            } else if (j - i == 1u) {
+                res = static_cast<int>((L[20u + (pi_off >> 5)] >> (pi_off & 31u)) & 1u);
+            } else {
+                const uint32_t qi = s_quarter(pi_off), qj = s_quarter(pj_off);
+                const uint32_t lo_r = spiece_mask_rank(spiece_lds(L, 0, qi), pi_off, qi);
+                const uint32_t hi_r = two ? spiece_mask_rank(spiece_global(B, 0, qj), pj_off, qj) : spiece_mask_rank(spiece_lds(L, 0, qj), pj_off, qj);
+                res = hi_r > lo_r;
+            }
+            // klcp[i - 1]: the bit before the block when i is its first row; klcp[j - 1]: row j - 1 is row pj_off - 1 of block bj
+            const uint32_t ki = i == 0u ? 0u : (pi_off == 0u ? (L[7] >> 31) : (L[26u + ((pi_off - 1u) >> 5)] >> ((pi_off - 1u) & 31u)) & 1u);
+            const uint32_t kjw = two ? B[26u + ((pj_off - 1u) >> 5)] : L[26u + ((pj_off - 1u) >> 5)];
+            const uint32_t kj = (kjw >> ((pj_off - 1u) & 31u)) & 1u;
+            window_done(res);
+            if (advance(true)) {
+                if (!(ki | kj)) {
+                    do_lf = true;   // common case: the (k-1)-mer's interval is the k-mer's; the line is here
+                    c = kmer_base(0);
+                } else {
+                    // extend_range_with_klcp (fms_index.h:106-115) over the plain kLCP words, as a scan of its own
+                    scan_i = ki;
+                    scan_j = kj;
+                    st = SS_EXTSCAN;
+                }
+            }
+        } else if (st == SS_EXTSCAN) {
+            if (scan_j) {   // j grows while klcp[j - 1]
+                const uint32_t pj = (j - 1u) & 63u;
+                const uint64_t up = kwj >> pj;
+                const uint32_t run = static_cast<uint32_t>(__ffsll(static_cast<unsigned long long>(~up))) - 1u;
+                const uint32_t lim = 64u - pj;
+                const uint32_t r = (~up == 0ull || run > lim) ? lim : run;
+                j += r;
+                scan_j = (r == lim && j < ix.n) ? 1u : 0u;
+            }
+            if (scan_i) {   // i shrinks while klcp[i - 1]
+                const uint32_t pi_ = (i - 1u) & 63u;
+                const uint64_t dn = kwi << (63u - pi_);
+                const uint32_t run = static_cast<uint32_t>(__clzll(static_cast<long long>(~dn)));
+                const uint32_t lim = pi_ + 1u;
+                const uint32_t r = (~dn == 0ull || run > lim) ? lim : run;
+                i -= r;
+                scan_i = (r == lim && i > 0u) ? 1u : 0u;
+            }
+            if (!(scan_i | scan_j)) st = SS_EXTLF;
+        }
+        if (do_lf) {
+            const uint32_t pi_off = i - bi * kSRows, pj_off = j - bj * kSRows;
+            const uint32_t qi = s_quarter(pi_off), qj = s_quarter(pj_off);
+            uint32_t ri = spiece_rank(spiece_lds(L, c, qi), c, pi_off, qi);
+            uint32_t rj;
+            if (two) {
+                const uint32_t* B = reinterpret_cast<const uint32_t*>(sblocks) + static_cast<size_t>(bj) * kSDwords;
+                rj = spiece_rank(spiece_global(B, c, qj), c, pj_off, qj);
+            } else {
+                rj = spiece_rank(spiece_lds(L, c, qj), c, pj_off, qj);
+            }
+            if (c == 0u) {
+                ri -= (i > ix.dollar);
+                rj -= (j > ix.dollar);
+            }
+            const uint32_t base = sel4(c, ix.C0, ix.C1, ix.C2, ix.C3);
+            i = base + ri;
+            j = base + rj;
+            if (COUNT) cn.lf_steps++;
+            if (st == SS_LF) {
+                --t;
+                if (i == j) {
+                    window_done(-1);
+                    advance(false);
+                } else if (t < 0) {
+                    st = SS_HAVE;
+                }
+            } else {
+                if (i == j) {
+                    window_done(-1);
+                    advance(false);
+                } else {
+                    st = SS_HAVE;
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();   // (the next round's staging must not overtake this round's reads of the lines)
+    }
+    if (COUNT) {
+        uint32_t v[6] = {cn.lf_steps, cn.blocks, cn.probes, cn.searches, cn.lookups, cn.klcp_words};
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+            uint32_t x = v[q];
+            for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+            if ((threadIdx.x & 63) == 0 && x) atomicAdd(&counters[q], static_cast<unsigned long long>(x));
+        }
+    }
+}
+
+template <bool COUNT, bool PTABLE>
+void launch_stream2(fmsi_hip_index* idx, const TaskRec* recs, uint64_t n_tasks, int k, uint32_t flags, uint4* slots, unsigned long long* d_counters, hipStream_t s) {
+    uint64_t chunk = n_tasks / (256ull * 32 * 8);
+    chunk = std::min<uint64_t>(std::max<uint64_t>(chunk, 64), 1024);
+    const uint64_t waves = (n_tasks + chunk - 1) / chunk;
+    const uint32_t blocks = static_cast<uint32_t>((waves + 3) / 4);
+    hipLaunchKernelGGL((query_stream2_kernel<COUNT, PTABLE>), dim3(blocks), dim3(256), 0, s, idx->dev, static_cast<const uint4*>(idx->d_sblocks),
+                       static_cast<const uint64_t*>(idx->d_klcp), recs, n_tasks, k, flags, static_cast<uint32_t>(chunk), slots, d_counters);
+}
+
 template <bool COUNT, bool PTABLE, bool WIDE>
 void launch_stream(fmsi_hip_index* idx, const TaskRec* recs, uint64_t n_tasks, int k, uint32_t flags, uint4* o8, long long* o64,
                    unsigned long long* d_counters, hipStream_t s) {
@@ -598,6 +1117,38 @@ void launch_stream(fmsi_hip_index* idx, const TaskRec* recs, uint64_t n_tasks, i
 }  // namespace fmsi
 
 using namespace fmsi;
+
+// The streaming layout of a handle with a kLCP array (idempotent; fmsi_hip_query_stream builds it on first use): 128 bytes per 192 rows.
+extern "C" int fmsi_hip_index_enable_stream_layout(fmsi_hip_index* idx) {
+    if (!idx) return FMSI_HIP_EINVAL;
+    FMSI_HIP_NARROW_ONLY(idx, "kLCP streaming");
+    if (!idx->d_klcp) {
+        set_last_error("the streaming layout needs an index created with its kLCP array");
+        return FMSI_HIP_EINVAL;
+    }
+    if (idx->d_sblocks) return 0;
+    ::fmsi::ScratchScope scratch_scope_(idx->device);
+    FMSI_HIP_ON_DEVICE(idx->device);
+    const uint64_t n_s = (idx->n + kSRows - 1) / kSRows + 1;
+    void* p = nullptr;
+    if (dev_malloc(&p, n_s * kSDwords * 4) != hipSuccess) {
+        (void)hipGetLastError();
+        set_last_error("hipMalloc failed for the streaming layout");
+        return FMSI_HIP_ENOMEM;
+    }
+    hipLaunchKernelGGL(sblock_build_kernel, dim3(static_cast<uint32_t>((n_s + 255) / 256)), dim3(256), 0, 0, static_cast<const uint32_t*>(idx->d_blocks),
+                       static_cast<const uint32_t*>(idx->d_mrank), idx->n_blocks, static_cast<const uint32_t*>(idx->d_klcp), ((idx->n + 63) / 64) * 2, n_s,
+                       static_cast<uint32_t*>(p));
+    if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
+        (void)dev_free(p);
+        set_last_error("building the streaming layout failed");
+        return FMSI_HIP_EHIP;
+    }
+    idx->d_sblocks = p;
+    idx->n_sblocks = n_s;
+    idx->device_bytes += n_s * kSDwords * 4;
+    return 0;
+}
 
 extern "C" int fmsi_hip_query_stream(fmsi_hip_index* idx, const uint64_t* packed_seq, uint64_t seq_bases, const uint64_t* run_start,
                                      const uint32_t* run_windows, uint64_t n_runs, uint64_t n_windows, int k, uint32_t flags,
@@ -622,6 +1173,14 @@ extern "C" int fmsi_hip_query_stream(fmsi_hip_index* idx, const uint64_t* packed
     }
     FMSI_HIP_ON_DEVICE(idx->device);
     hipStream_t s = static_cast<hipStream_t>(stream);
+    // k <= 32 presence queries: the S-block kernel (its layout is built on the handle's first such call; FMSI_HIP_STREAM_V1: the first
+    // kernel, for A/B runs)
+    static const bool force_v1 = std::getenv("FMSI_HIP_STREAM_V1") != nullptr;
+    const bool v2 = k <= 32 && !(flags & FMSI_HIP_ORDERS) && !force_v1 && (flags & FMSI_HIP_KERNEL_MASK) != FMSI_HIP_KERNEL_REFILL;
+    if (v2 && !idx->d_sblocks) {
+        const int rc_s = fmsi_hip_index_enable_stream_layout(idx);
+        if (rc_s) return rc_s;
+    }
     // run_start / run_windows are HOST arrays in every mode (one entry per run); per run the device gets its first base,
     // first task and first result index, and cuts the tasks itself (stream_prep_kernel)
     // (in a page-locked slot of the handle's ring: the call stays asynchronous on `stream`)
@@ -689,7 +1248,15 @@ extern "C" int fmsi_hip_query_stream(fmsi_hip_index* idx, const uint64_t* packed
     FMSI_HIP_TRY(hipGetLastError());
     const bool use_table = idx->d_ptable && !(flags & FMSI_HIP_NO_PREFIX_TABLE) && k >= idx->prefix_len;
     long long* o64 = static_cast<long long*>(d_out);
-    if (k > 32) {
+    if (v2) {
+        if (use_table) {
+            if (d_cnt) launch_stream2<true, true>(idx, d_rec, n_tasks, k, flags, d_slots, d_cnt, s);
+            else launch_stream2<false, true>(idx, d_rec, n_tasks, k, flags, d_slots, d_cnt, s);
+        } else {
+            if (d_cnt) launch_stream2<true, false>(idx, d_rec, n_tasks, k, flags, d_slots, d_cnt, s);
+            else launch_stream2<false, false>(idx, d_rec, n_tasks, k, flags, d_slots, d_cnt, s);
+        }
+    } else if (k > 32) {
         if (use_table) {
             if (d_cnt) launch_stream<true, true, true>(idx, d_rec, n_tasks, k, flags, d_slots, o64, d_cnt, s);
             else launch_stream<false, true, true>(idx, d_rec, n_tasks, k, flags, d_slots, o64, d_cnt, s);

@@ -123,6 +123,8 @@ struct fmsi_hip_index {
     int fn_kind = 0;             // demasking function of the current fmsi_hip_query_runs_fn call (FMSI_HIP_FN_*) and its bounds
     uint64_t fn_r = 0, fn_s = 0;
     void* d_klcp = nullptr;      // plain kLCP bit-vector (n bits, u64 words), when present
+    void* d_sblocks = nullptr;   // streaming layout (fmsi_stream.hip): 128-byte blocks of 192 rows with the kLCP plane, built on first use
+    uint64_t n_sblocks = 0;
     // optional pair layout (fmsi_pair.hip): 128-B blocks for two-base LF steps
     void* d_pblocks = nullptr;
     void* d_sbt = nullptr;

@@ -60,7 +60,8 @@ extern "C" {
 /* kernel selection (diagnostics / A-B runs); default = FMSI_HIP_KERNEL_AUTO */
 #define FMSI_HIP_KERNEL_AUTO 0x00u
 #define FMSI_HIP_KERNEL_LOCKSTEP 0x10u   /* one lane per k-mer, wave walks the k LF steps in lock-step */
-#define FMSI_HIP_KERNEL_REFILL 0x20u     /* persistent lanes: a lane that finishes pulls the next k-mer (ballot/mbcnt) */
+#define FMSI_HIP_KERNEL_REFILL 0x20u     /* persistent lanes: a lane that finishes pulls the next k-mer (ballot/mbcnt); with fmsi_hip_query_stream:
+                                            the first streaming kernel (64-byte blocks + separate kLCP words) instead of the S-block one */
 #define FMSI_HIP_KERNEL_PAIR 0x30u       /* persistent lanes + two-base LF steps over the 128-B pair layout (needs
                                             fmsi_hip_index_enable_pair_layout); AUTO picks it when the layout exists */
 #define FMSI_HIP_KERNEL_PHASED 0x40u     /* pair layout + prefix table: the table lookups run in a kernel of their own and only the
@@ -303,6 +304,12 @@ int fmsi_hip_query_runs_fn(fmsi_hip_index* idx, const uint64_t* packed_seq, cons
 int fmsi_hip_query_stream(fmsi_hip_index* idx, const uint64_t* packed_seq, uint64_t seq_bases,
                           const uint64_t* run_start, const uint32_t* run_windows, uint64_t n_runs,
                           uint64_t n_windows, int k, uint32_t flags, void* out, uint64_t* counters, void* stream);
+
+/* The layout fmsi_hip_query_stream's kernel for k <= 32 presence queries reads -- 128-byte blocks of 192 rows that carry the kLCP bits of
+ * their rows beside the wavelet-tree and mask planes, so that a streamed window is one memory request (4/3 byte per row of HBM) -- is
+ * built from the handle's blocks and kLCP array on the first such call; a host that wants the cost at load time calls this.  Idempotent;
+ * needs a handle with a kLCP array. */
+int fmsi_hip_index_enable_stream_layout(fmsi_hip_index* idx);
 
 int fmsi_hip_sync(fmsi_hip_index* idx, void* stream);
 /* The library keeps large freed device blocks (temporaries of the builders) for reuse -- freeing and re-allocating them is what an index

@@ -49,6 +49,12 @@ def run_case(fm, orc, dev, reads, k, check_orders=True):
         assert np.array_equal(fast.astype(bool), stream_expected_fast(fwd, rc, wins, mode_all))
         # same answers without the prefix table and (forward strand first everywhere) from the non-streaming kernel
         assert np.array_equal(dev.query_stream(words, len(seq), starts, wins, k, flag | fm.NO_PREFIX_TABLE), fast)
+        # ... and from the first streaming kernel (64-byte blocks + separate kLCP words; what ORDERS and k > 32 still run)
+        assert np.array_equal(dev.query_stream(words, len(seq), starts, wins, k, flag | fm.KERNEL_REFILL), fast)
+        v1f, v1r = fm.decode_strict(dev.query_stream(words, len(seq), starts, wins, k, flag | fm.STRICT | fm.KERNEL_REFILL | fm.NO_PREFIX_TABLE))
+        assert np.array_equal(v1f, fwd) and np.array_equal(v1r, rc)
+        packed = dev.query_stream(words, len(seq), starts, wins, k, flag | fm.OUT_BITS)
+        assert np.array_equal(fm.unpack_bits(packed, n, 0), fast)
         assert np.array_equal(dev.query_kmers(fm.pack_kmers(kmers, k), k, flag).astype(bool), expected_fast(fwd, rc, mode_all))
     if check_orders:
         fwd, rc, of, orr = orc.ternaries_bulk(raw, n, k, False, orders=True)
@@ -133,3 +139,33 @@ def test_stream_counters_positive_read(fm, oracle_built):
     assert 6400 <= int(cn[0]) <= 6400 + 100 * (k + 1)
     out2, cn2 = dev.query_windows(words, len(read), k, fm.MODE_ALL, counters=True)
     assert np.array_equal(out, out2) and int(cn2[0]) == 6400 * k
+
+
+@pytest.mark.parametrize("k", [5, 12])
+def test_stream_layout_boundaries(fm, oracle_built, tmp_path, k):
+    """The streaming layout's blocks hold 192 rows: row counts around its multiples (and around the 64- and 128-row marks inside a block),
+    mixed masks, repeats (intervals of many rows that straddle blocks, kLCP runs across them), reads in both orientations with
+    substitutions -- against the oracle strand by strand, in both modes, with and without the prefix table."""
+    rng = random.Random(100 + k)
+    for n in (63, 64, 65, 127, 128, 129, 190, 191, 192, 193, 255, 256, 383, 384, 385, 575, 576, 577, 767, 768, 769, 1151, 1152, 1153, 4000):
+        body = "".join(rng.choice("ACGT") for _ in range(max(8, n // 3)))
+        ms = (body * 4)[:n] if n > 40 else body[:n]
+        ms = "".join(rng.choice("ACGT") if rng.random() < 0.05 else ch for ch in ms)
+        ms = "".join(ch if rng.random() < 0.6 else ch.lower() for ch in ms)
+        ms = ms[: len(ms) - (k - 1)] + ms[len(ms) - (k - 1):].lower()
+        orc = oracle_py.Oracle.construct(ms, k, use_klcp=True)
+        prefix = str(tmp_path / f"b{n}")
+        orc.dump(prefix)
+        dev = fm.DeviceIndex.load(prefix, use_klcp=True, prefix_len=3)
+        up = ms.upper()
+        reads = [up, revcomp(up)]
+        for _ in range(6):
+            L = rng.randrange(k, min(len(up), 150) + 1)
+            p = rng.randrange(0, len(up) - L + 1)
+            r = up[p:p + L]
+            if rng.random() < 0.5:
+                r = revcomp(r)
+            if rng.random() < 0.5:
+                r = "".join(rng.choice("ACGT") if rng.random() < 0.03 else ch for ch in r)
+            reads.append(r)
+        run_case(fm, orc, dev, reads, k, check_orders=False)
