@@ -33,19 +33,22 @@ int main(int argc, char* argv[]) {
     const std::string op = argv[1];
     if (op == "query" || op == "lookup") {
         // The process ends with the command: what it wrote is flushed, and the teardown of the device context, of gigabytes of HBM and
-        // of the page-locked batch buffers is left to the operating system (0.1-0.2 s of a 0.9 s run at human scale).
-        setenv("FMSI_HIP_CLI_NO_TEARDOWN", "1", 0);
+        // of the page-locked batch buffers is left to the operating system (0.1-0.2 s of a 0.9 s run at human scale) -- unless something
+        // in the process writes its output when the process is finalised: rocprofv3 / rocprofiler-sdk and rocTX (trace.h's ranges),
+        // sanitizers, gcov.  Then the command tears down what it built (and waits for a dictionary still being built beside the queries)
+        // and the ordinary exit runs the atexit handlers and library destructors.
+        bool full_exit = false;
+        for (const char* v : {"ROCP_TOOL_LIBRARIES", "ROCPROFILER_REGISTER_FORCE_LOAD", "HSA_TOOLS_LIB", "LD_PRELOAD", "ASAN_OPTIONS", "TSAN_OPTIONS",
+                              "UBSAN_OPTIONS", "GCOV_PREFIX", "FMSI_HIP_CLI_FULL_EXIT"}) {
+            const char* e = std::getenv(v);
+            if (e && *e) full_exit = true;
+        }
+        if (!full_exit) setenv("FMSI_HIP_CLI_NO_TEARDOWN", "1", 0);
         const int rc = fmsi_cli_query(argc - 1, argv + 1, op == "lookup" ? 1 : 0);
         std::cout.flush();
         std::cerr.flush();
         std::fflush(nullptr);
-        // ... unless something in the process writes its output when the process is finalised: rocprofv3 / rocprofiler-sdk and rocTX
-        // (trace.h's ranges), sanitizers, gcov.  Then the ordinary exit runs the atexit handlers and library destructors.
-        for (const char* v : {"ROCP_TOOL_LIBRARIES", "ROCPROFILER_REGISTER_FORCE_LOAD", "HSA_TOOLS_LIB", "LD_PRELOAD", "ASAN_OPTIONS", "TSAN_OPTIONS",
-                              "UBSAN_OPTIONS", "GCOV_PREFIX", "FMSI_HIP_CLI_FULL_EXIT"}) {
-            const char* e = std::getenv(v);
-            if (e && *e) std::exit(rc);
-        }
+        if (full_exit && !std::getenv("FMSI_HIP_CLI_NO_TEARDOWN")) std::exit(rc);
         _exit(rc);
     }
     if (op == "index") return fmsi_cli_index(argc - 1, argv + 1);

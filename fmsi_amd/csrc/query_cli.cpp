@@ -20,6 +20,7 @@
 #include <sched.h>
 
 #include <algorithm>
+#include <atomic>
 #include <charconv>
 #include <chrono>
 #include <cmath>
@@ -86,6 +87,7 @@ struct Options {
     bool full_tables = false;              // --tables full: the k-mer dictionary (what bench.py measures); lookup: the 16-deep prefix table
     bool candidate_tables = false;         // --tables candidates: the 16-deep prefix table + candidate tables instead (A/B runs)
     bool tables_given = false;             // (--tables on the command line: no choice by the size of the query file)
+    bool background_dict = false;          // --tables background, or a large query file: the dictionary is built beside the first batches
     int fn = 0;                            // -f and|xor|r-s: FMSI_HIP_FN_* (query_mode::general), 0 = the presence modes
     uint64_t fn_r = 0, fn_s = 0;
 };
@@ -143,11 +145,13 @@ int usage_query(bool lookup) {
     std::cerr << "  --batch INT  - bases of query sequence per device batch [default: 67108864]" << std::endl;
     std::cerr << "  --threads INT - host threads for packing and formatting [default: available CPUs, at most 16]" << std::endl;
     std::cerr << "  --stats      - print timings to stderr" << std::endl;
-    std::cerr << "  --tables auto|full|candidates - device-side accelerators (results unaffected).  auto [default]: a prefix table of up" << std::endl;
-    std::cerr << "                 to 14 bases, which keeps the device about level with this program's reader and loads fastest (query" << std::endl;
-    std::cerr << "                 files of 16 GB and more get `full`); full: the k-mer dictionary -- one 128-byte read per k-mer, about" << std::endl;
-    std::cerr << "                 12 bytes of HBM per distinct k-mer, the fastest device path (also for -S); candidates: the 16-base" << std::endl;
-    std::cerr << "                 prefix table with candidate tables (up to 180 GB of HBM)" << std::endl;
+    std::cerr << "  --tables auto|background|full|candidates - device-side accelerators (results unaffected).  auto [default]: a prefix" << std::endl;
+    std::cerr << "                 table of up to 14 bases, which keeps the device about level with this program's reader and loads fastest" << std::endl;
+    std::cerr << "                 (query files of 8 GB and more get `background`); background: the same, and the k-mer dictionary is built" << std::endl;
+    std::cerr << "                 beside the first batches, which the LF walk answers -- every batch after it stands goes to the dictionary;" << std::endl;
+    std::cerr << "                 full: the dictionary before the first batch -- one 128-byte read per k-mer, about 13 bytes of HBM per" << std::endl;
+    std::cerr << "                 distinct k-mer, the fastest device path (also for -S); candidates: the 16-base prefix table with" << std::endl;
+    std::cerr << "                 candidate tables (up to 180 GB of HBM)" << std::endl;
     std::cerr << std::endl;
     return 1;
 }
@@ -694,6 +698,7 @@ extern "C" int fmsi_cli_query(int argc, char** argv, int output_orders_i) {
         case 1005: opt.threads = static_cast<unsigned>(std::max(1, atoi(optarg))); break;
         case 1006:
             if (std::string(optarg) == "full") opt.full_tables = opt.tables_given = true;
+            else if (std::string(optarg) == "background") opt.background_dict = opt.tables_given = true;
             else if (std::string(optarg) == "candidates") opt.full_tables = opt.candidate_tables = opt.tables_given = true;
             else if (std::string(optarg) != "auto") return usage_query(output_orders);
             break;
@@ -784,17 +789,24 @@ extern "C" int fmsi_cli_query(int argc, char** argv, int output_orders_i) {
     // -- and 5-7 G windows/s with the k-mer dictionary (45 G k-mers/s on resident batches: bench.py), which takes about half a
     // second more to build at that scale.  So the dictionary is built when asked for (--tables full) or when the
     // query file is so large (16 GB; uncompressed bytes ~ windows) that the difference pays for the build several times over.
+    // Round 3: that dictionary is built BESIDE the queries -- a second handle in a thread of its own, the first batches answered by the LF
+    // walk (or the kLCP kernel), every batch from the moment the dictionary stands by the dictionary: same bytes (the dictionary holds the
+    // index's own answers), no half second of load.  It pays from some 8 GB of queries on (the build is half a second of device time the
+    // batches queue behind, and the host's write() of one byte per window caps the program at about 5 G windows/s either way: DESIGN.md 8),
+    // so that is where `--tables auto` starts it; `--tables background` always does, `--tables full` builds it before the first batch.
     if (!opt.tables_given && opt.query_fn != "-") {
         struct stat st;
         const bool gz = opt.query_fn.size() > 3 && opt.query_fn.compare(opt.query_fn.size() - 3, 3, ".gz") == 0;
         if (stat(opt.query_fn.c_str(), &st) == 0 && S_ISREG(st.st_mode) &&
-            static_cast<uint64_t>(st.st_size) * (gz ? 4u : 1u) >= 16000000000ull)
-            opt.full_tables = true;
+            static_cast<uint64_t>(st.st_size) * (gz ? 4u : 1u) >= 8000000000ull)
+            opt.background_dict = true;
     }
     // `full`: presence queries (also -S ones: their answers do not depend on the kLCP array) are answered by the k-mer
     // dictionary, which needs no prefix table (a small one serves the few searches of its construction); lookup keeps the
     // 16-deep table
-    const bool want_dict = !general && opt.full_tables && !opt.candidate_tables && !output_orders && k <= 32 && index_rows > static_cast<uint64_t>(k);
+    const bool dict_possible = !general && !opt.candidate_tables && !output_orders && k <= 32 && index_rows > static_cast<uint64_t>(k);
+    const bool want_dict = dict_possible && opt.full_tables;
+    const bool want_bg_dict = dict_possible && !opt.full_tables && opt.background_dict;
     int t = std::min(k, want_dict ? 12 : (opt.full_tables ? 16 : 14));
     while (t > 0 && (1ull << (2 * t)) > 4 * index_rows) --t;
 
@@ -803,15 +815,40 @@ extern "C" int fmsi_cli_query(int argc, char** argv, int output_orders_i) {
         int device = 0;
         fmsi_hip_index* dev = nullptr;
         bool have_dict = false;
+        // the dictionary built beside the queries (--tables background / large inputs): a second handle, published when it stands
+        fmsi_hip_index* dict_dev = nullptr;
+        std::atomic<bool> dict_ready{false};
+        std::thread dict_builder;
+        uint64_t dict_batches = 0;
         std::string error;
         std::unique_ptr<std::mutex> busy = std::make_unique<std::mutex>();   // calls on one handle are not re-entrant: its two workers take turns
     };
-    std::vector<DeviceCtx> ctx(opt.devices.size());
+    // (on the heap, and left there when the binary skips the teardown: a dictionary builder that is still running then must not find
+    // its context gone)
+    auto* ctx_heap = new std::vector<DeviceCtx>(opt.devices.size());
+    std::vector<DeviceCtx>& ctx = *ctx_heap;
+    struct CtxOwner {
+        std::vector<DeviceCtx>* p;
+        bool keep = false;
+        ~CtxOwner() {
+            if (keep) return;
+            for (DeviceCtx& c : *p)
+                if (c.dict_builder.joinable()) c.dict_builder.join();
+            delete p;
+        }
+    } ctx_owner{ctx_heap};
     for (size_t d = 0; d < ctx.size(); ++d) ctx[d].device = opt.devices[d];
     bool rows64 = false;
-    auto destroy_all = [&] {
+    auto join_builders = [&] {
         for (DeviceCtx& c : ctx)
+            if (c.dict_builder.joinable()) c.dict_builder.join();
+    };
+    auto destroy_all = [&] {
+        join_builders();
+        for (DeviceCtx& c : ctx) {
+            if (c.dict_dev) fmsi_hip_index_destroy(c.dict_dev);
             if (c.dev) fmsi_hip_index_destroy(c.dev);
+        }
     };
     // The accelerators are large: when HBM is short -- the GPU shared with other work -- the table shrinks (first device decides,
     // the others follow) and the optional ones are left out; only a failure of the index proper is an error.
@@ -878,6 +915,20 @@ extern "C" int fmsi_cli_query(int argc, char** argv, int output_orders_i) {
         }
     }
     auto t_loaded = clock::now();
+    if (want_bg_dict && !rows64)
+        for (DeviceCtx& c : ctx)
+            c.dict_builder = std::thread([&c, prefix = opt.index_prefix] {
+                TraceRange range("fmsi: k-mer dictionary beside the queries");
+                fmsi_hip_index* h = nullptr;
+                // (a failure -- no room on the device -- leaves the run on the path it started on; results are the same)
+                if (fmsi_hip_index_load(prefix.c_str(), 0, c.device, 0, &h) != 0) return;
+                if (fmsi_hip_index_enable_dict(h, 0) != 0) {
+                    fmsi_hip_index_destroy(h);
+                    return;
+                }
+                c.dict_dev = h;
+                c.dict_ready.store(true, std::memory_order_release);
+            });
 
     // OR-mode presence output does not depend on the strand order, so the cheaper schedule is exact;
     // everything else replays the predictor from both strands unless --fast.
@@ -1008,19 +1059,23 @@ extern "C" int fmsi_cli_query(int argc, char** argv, int output_orders_i) {
                         void* dst = output_orders ? static_cast<void*>(P->orders.data())
                                                   : (P->packed_bits ? static_cast<void*>(P->bits.data()) : static_cast<void*>(P->bytes.data()));
                         const uint32_t flags = flags_all | (P->packed_bits ? FMSI_HIP_OUT_BITS : 0u);
+                        // the handle this batch goes to: the dictionary's, once it stands (same answers, so the switch may fall anywhere)
+                        const bool bg_dict = !cp->have_dict && cp->dict_ready.load(std::memory_order_acquire);
+                        fmsi_hip_index* const handle = bg_dict ? cp->dict_dev : cp->dev;
+                        if (bg_dict) ++cp->dict_batches;
                         if (general)   // -f and|xor|r-s: f(ones, total) of both strands (query_kmers<general>, src/fms_index.h:316-327)
                             check(fmsi_hip_query_runs_fn(cp->dev, P->packed.data(), P->lower.empty() ? nullptr : P->lower.data(), P->bases, P->run_start.data(), P->run_windows.data(), P->run_start.size(), nw, k,
                                                          opt.fn, opt.fn_r, opt.fn_s, FMSI_HIP_OUT_BITS, dst, nullptr, nullptr),
                                   "fmsi_hip_query_runs_fn");
-                        else if (opt.has_klcp && !cp->have_dict)   // -S: kLCP streaming kernel (query_kmers_streaming, src/fms_index.h:181-254)
-                            check(fmsi_hip_query_stream(cp->dev, P->packed.data(), P->bases, P->run_start.data(), P->run_windows.data(),
+                        else if (opt.has_klcp && !cp->have_dict && !bg_dict)   // -S: kLCP streaming kernel (query_kmers_streaming, src/fms_index.h:181-254)
+                            check(fmsi_hip_query_stream(handle, P->packed.data(), P->bases, P->run_start.data(), P->run_windows.data(),
                                                         P->run_start.size(), nw, k, flags, dst, nullptr, nullptr),
                                   "fmsi_hip_query_stream");
                         else
-                            check(fmsi_hip_query_runs(cp->dev, P->packed.data(), P->bases, P->run_start.data(), P->run_windows.data(),
+                            check(fmsi_hip_query_runs(handle, P->packed.data(), P->bases, P->run_start.data(), P->run_windows.data(),
                                                       P->run_start.size(), nw, k, flags, dst, nullptr, nullptr),
                                   "fmsi_hip_query_runs");
-                        check(fmsi_hip_sync(cp->dev, nullptr), "fmsi_hip_sync");
+                        check(fmsi_hip_sync(handle, nullptr), "fmsi_hip_sync");
                     }
                     auto t2 = clock::now();
                     PinVec<uint64_t>().swap(P->packed);
@@ -1103,10 +1158,21 @@ extern "C" int fmsi_cli_query(int argc, char** argv, int output_orders_i) {
         fprintf(stderr,
                 "{\"windows\": %llu, \"total_seconds\": %.6f, \"load_seconds\": %.6f, \"device_seconds\": %.6f, \"read_seconds\": %.6f, "
                 "\"prepare_seconds\": %.6f, \"replay_seconds\": %.6f, \"format_seconds\": %.6f, \"write_seconds\": %.6f, \"threads\": %u, "
-                "\"devices\": %zu, \"strict\": %s, \"block_parallel_read_bytes\": %llu}\n",
+                "\"devices\": %zu, \"strict\": %s, \"block_parallel_read_bytes\": %llu, \"dictionary\": \"%s\", \"dictionary_batches\": %llu}\n",
                 static_cast<unsigned long long>(total_windows), total, load, gpu_s, query_reader.read_s, prep_s, replay_s, format_s, write_s, team,
-                ctx.size(), strict ? "true" : "false", static_cast<unsigned long long>(query_reader.parallel_read_bytes));
+                ctx.size(), strict ? "true" : "false", static_cast<unsigned long long>(query_reader.parallel_read_bytes),
+                ctx[0].have_dict ? "before the first batch" : (want_bg_dict && !rows64 ? "beside the queries" : "none"),
+                static_cast<unsigned long long>(ctx[0].dict_batches));
     }
-    if (!std::getenv("FMSI_HIP_CLI_NO_TEARDOWN")) destroy_all();   // (the `fmsi` binary exits right behind this call: main.cpp)
+    // (the `fmsi` binary exits right behind this call, main.cpp: it neither tears the device down nor waits for a dictionary that is still
+    // being built when the input has ended)
+    if (!std::getenv("FMSI_HIP_CLI_NO_TEARDOWN")) destroy_all();
+    else {
+        for (DeviceCtx& c : ctx)
+            if (c.dict_builder.joinable()) {
+                c.dict_builder.detach();
+                ctx_owner.keep = true;
+            }
+    }
     return exit_code;
 }

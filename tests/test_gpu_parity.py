@@ -148,8 +148,8 @@ def test_cli_equals_reference_golden(fm, name, kind, mode):
     assert out == golden_out(name, kind, mode)
 
 
-@pytest.mark.parametrize("name,kind,mode,tables", [(*c, t) for c in CASES for t in ("full", "candidates")
-                                                   if c[2] in ("or", "all") or (t == "full" and c[2] in ("or_S", "all_S"))])
+@pytest.mark.parametrize("name,kind,mode,tables", [(*c, t) for c in CASES for t in ("full", "candidates", "background")
+                                                   if c[2] in ("or", "all") or (t in ("full", "background") and c[2] in ("or_S", "all_S"))])
 def test_cli_with_full_tables_equals_reference_golden(fm, name, kind, mode, tables):
     """--tables full (the k-mer dictionary, the configuration bench.py measures; with it `-S` presence queries take the dictionary
     too) and --tables candidates (16-deep prefix table + candidate tables) change the device path of the presence modes and not
@@ -1011,3 +1011,33 @@ def test_cli_with_several_device_handles(fm, tmp_path, mode):
     assert out1.decode() == want
     rc, out, err = fm.run_cli([*args, "--devices", "0,x", index_prefix(name)])
     assert rc == 1 and out == b""
+
+
+@pytest.mark.parametrize("mode", ["or", "all", "or_S", "all_S"])
+def test_cli_background_dictionary_switch_over(fm, tmp_path, mode):
+    """--tables background (what `--tables auto` does from 8 GB of queries on): the first batches are answered by the LF walk / the kLCP
+    kernel while a second handle builds the k-mer dictionary in a thread of its own; every batch from the moment it stands goes to the
+    dictionary.  The bytes do not depend on where the switch falls -- many small batches, two handles, a non-max-ones mask whose -O output
+    depends on the predictor's state across batches -- and equal the one-path runs and the oracle's record loop; --stats says how many
+    batches the dictionary answered."""
+    import json as _json
+    name, k = "mixed_k11", 11
+    ms = "".join(l.strip() for l in open(GOLDEN / "mixed.fa") if not l.startswith(">"))
+    rng = random.Random(17)
+    q = tmp_path / "q.fa"
+    q.write_bytes(b"".join(messy_fasta(ms, rng) for _ in range(60)))
+    args = [*MODES[mode][0], "-k", str(k), "-q", str(q)]
+    rc0, out0, err0 = fm.run_cli([*args, "--batch", "2048", index_prefix(name)])
+    assert rc0 == 0, err0.decode()
+    switched = 0
+    for extra in (["--tables", "background"], ["--tables", "background", "--devices", "0,0"], ["--tables", "background", "--threads", "3"]):
+        rc, out, err = fm.run_cli([*args, "--batch", "2048", "--stats", *extra, index_prefix(name)])
+        assert rc == 0, err.decode()
+        assert out == out0, extra
+        stats = _json.loads([l for l in err.decode().splitlines() if l.startswith("{")][-1])
+        assert stats["dictionary"] == "beside the queries"
+        switched += stats["dictionary_batches"]
+    assert switched > 0   # (a 12-kb index: the dictionary stands within the first batches of at least one of the runs)
+    orc = oracle_py.Oracle.load(index_prefix(name), use_klcp=MODES[mode][2])
+    want, _ = orc.query_file(str(q), k, has_klcp=MODES[mode][2], mode=MODES[mode][3], orders=MODES[mode][1], cap=len(out0) + 4096)
+    assert out0.decode() == want

@@ -38,6 +38,8 @@ MODES = {
     "or_full": ["query", "--tables", "full"],
     "all_full": ["query", "-O", "--tables", "full"],
     "all_S_full": ["query", "-S", "-O", "--tables", "full"],
+    "or_bg": ["query", "--tables", "background"],
+    "all_S_bg": ["query", "-S", "-O", "--tables", "background"],
     "or_2dev": ["query", "--devices", "0,0"],
     "all_2dev": ["query", "-O", "--devices", "0,0"],
 }
@@ -172,7 +174,7 @@ def main() -> None:
             entry["windows_per_s_after_load"] = round(w / max(1e-9, entry["total_seconds"] - entry["load_seconds"]))
         entry["output_bytes"] = outp.stat().st_size
         # reference on the sample: identical bytes?
-        ref_args = [x for x in MODES[parts[0]] if x not in ("--fast", "--tables", "full", "--devices", "0,0")]
+        ref_args = [x for x in MODES[parts[0]] if x not in ("--fast", "--tables", "full", "background", "--devices", "0,0")]
         if ref_cli.exists() and a.ref_reads:
             t0 = time.time()
             r = subprocess.run([str(ref_cli), *ref_args, "-k", str(a.k), "-q", str(sample), prefix], capture_output=True)
