@@ -113,7 +113,7 @@ def parse_args(argv=None):
                     help="do not measure roofline.traffic in this run (child runs of this script under rocprofv3 --pmc, FETCH_SIZE and "
                          "WRITE_SIZE in separate passes)")
     ap.add_argument("--no-config-legs", action="store_true", help="skip the `configs` legs (BASELINE configs 2, 3, 4 and the whole process)")
-    ap.add_argument("--legs", default="c2,c3,c4,e2e", help="which `configs` legs to run")
+    ap.add_argument("--legs", default="c2,c3,c4,c4sk,e2e", help="which `configs` legs to run")
     ap.add_argument("--leg", default=None, help=argparse.SUPPRESS)          # child mode: one leg, a JSON list on stdout
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)   # child mode under rocprofv3: the plan's launches, nothing printed
     ap.add_argument("--pmc-plan", default=None, help=argparse.SUPPRESS)
@@ -206,7 +206,7 @@ def resolve_accelerators(args, n, k, stream_mode):
             args.prefix_len -= 1
 
 
-def build_handle(c, args, n, k, stream_mode, with_klcp=None, want_pair=None, chain=None):
+def build_handle(c, args, n, k, stream_mode, with_klcp=None, want_pair=None, chain=None, superkmer_only=False):
     """Synthetic superstring -> index -> accelerators, as one chain of builders (they share the library's block cache).
     Returns (index, seconds for everything, seconds for the accelerators)."""
     fm = c.fm
@@ -223,7 +223,7 @@ def build_handle(c, args, n, k, stream_mode, with_klcp=None, want_pair=None, cha
             t1 = time.time()
             if (not stream_mode) if want_pair is None else want_pair:
                 index.enable_pair_layout()   # (the table-less LF-walk leg and the canonical-step count use it)
-            index.enable_dict(sparse=args.dict_sparse, chain=chain)
+            index.enable_dict(sparse=args.dict_sparse, chain=chain, superkmer_only=superkmer_only)
             accel_s = time.time() - t1
         elif stream_mode and args.stream_via == "runs":
             index.enable_pair_layout()
@@ -254,12 +254,12 @@ class QueryPath:
     def __init__(self, c, args, index, via, k, batch, read_len=10000, subst_ppm=0):
         fm, np = c.fm, c.np
         self.c, self.args, self.index, self.via, self.k, self.subst_ppm = c, args, index, via, k, subst_ppm
-        self.stream_mode = via in ("runs_chain", "runs_plain", "runs_tables", "klcp")
+        self.stream_mode = via in ("runs_chain", "runs_plain", "runs_tables", "runs_sk", "klcp")
         mode = fm.MODE_ALL if args.mode == "all" else fm.MODE_OR
         # (the kLCP kernel reads 128-byte S-blocks since round 3; FMSI_HIP_STREAM_V1 brings the 64-byte-block kernel back)
         self.block_b = 64 if via == "lf_lockstep" or (via == "klcp" and os.environ.get("FMSI_HIP_STREAM_V1")) or \
             (via == "legacy" and args.kernel in ("refill", "lockstep")) else 128
-        self.is_dict = via in ("dict", "runs_chain", "runs_plain")
+        self.is_dict = via in ("dict", "runs_chain", "runs_plain", "runs_sk")
         if self.stream_mode:
             L = self.read_len = read_len
             self.n_reads = max(1, int(batch) // (L - k + 1))
@@ -268,10 +268,11 @@ class QueryPath:
             self.run_windows = np.full(self.n_reads, L - k + 1, dtype=np.uint32)
             self.in_words = self.n_reads * L // 32 + 2
             self.in_bytes = self.n_reads * L / 4.0
-            self.flags = mode | {"runs_chain": fm.KERNEL_DICT, "runs_plain": fm.KERNEL_DICT | fm.NO_DICT_CHAIN, "runs_tables": 0, "klcp": 0}[via]
-            self.kernel = {"runs_chain": "dict_chain_kernel", "runs_plain": "dict_lookup_kernel", "runs_tables": "lookup_lane_kernel + query_pair_kernel",
+            self.flags = mode | {"runs_chain": fm.KERNEL_DICT | fm.NO_SUPERKMER, "runs_plain": fm.KERNEL_DICT | fm.NO_DICT_CHAIN | fm.NO_SUPERKMER, "runs_tables": 0,
+                                 "runs_sk": fm.KERNEL_DICT, "klcp": 0}[via]
+            self.kernel = {"runs_chain": "dict_chain_kernel", "runs_plain": "dict_lookup_kernel", "runs_tables": "lookup_lane_kernel + query_pair_kernel", "runs_sk": "sk_runs_kernel",
                            "klcp": "query_stream_kernel" if os.environ.get("FMSI_HIP_STREAM_V1") else "query_stream2_kernel"}[via]
-            self.pmc_kernel = {"runs_chain": "dict_chain_kernel<false>", "runs_plain": "dict_lookup_kernel<false, true>", "runs_tables": "lookup_lane_kernel<false",
+            self.pmc_kernel = {"runs_chain": "dict_chain_kernel<false>", "runs_plain": "dict_lookup_kernel<false, true>", "runs_tables": "lookup_lane_kernel<false", "runs_sk": "sk_runs_kernel<false>",
                                "klcp": "query_stream2_kernel<false"}[via]
         else:
             self.batch = int(batch)
@@ -667,6 +668,9 @@ LEG_SPECS = {
     "c4": (2.8e9, "stream", float(1 << 27), 8, [("c4_dict_chain", "runs_chain", 0), ("c4_dict_chain_subst1pct", "runs_chain", 10000),
                                                  ("c4_dict_plain", "runs_plain", 0), ("c4_dict_plain_subst1pct", "runs_plain", 10000),
                                                  ("c4_klcp", "klcp", 0), ("c4_klcp_subst1pct", "klcp", 10000)]),
+    # the same reads through the super-k-mer dictionary ALONE (FMSI_HIP_DICT_SUPERKMER_ONLY: the k-mer dictionary is released after the
+    # construction -- the handle is the index's blocks + the records + the small aux dictionary)
+    "c4sk": (2.8e9, "stream", float(1 << 27), 8, [("c4_superkmer", "runs_sk", 0), ("c4_superkmer_subst1pct", "runs_sk", 10000)]),
 }
 LEG_TEXT = {
     "c2": "BASELINE config 2: E. coli single-genome scale (synthetic max-ones masked superstring n=4700000), k=31, 10^8 isolated random 31-mers per step "
@@ -677,9 +681,11 @@ LEG_TEXT = {
     "c4": "BASELINE config 4: human-genome scale (n=2800000000), k=31, reads of 10000 bases (50% from the superstring, half of those reverse-complemented), "
           "every 31-mer window, fmsi query -S -O answers",
 }
+LEG_TEXT["c4sk"] = LEG_TEXT["c4"]
 VIA_TEXT = {"runs_chain": "fmsi_hip_query_runs, chained dictionary lookups (58.7 GB handle): a lane follows the superstring from its task's first window",
             "runs_plain": "fmsi_hip_query_runs, one dictionary bucket read per window (FMSI_HIP_NO_DICT_CHAIN)",
             "klcp": "fmsi_hip_query_stream: the kLCP kernel (extend_range_with_klcp + one LF step per positive window, src/fms_index.h:106-115,181-254)",
+            "runs_sk": "fmsi_hip_query_runs, super-k-mer dictionary alone (records filed by minimizer: a bucket read when a lane's minimizer changes; the handle holds no k-mer dictionary)",
             "dict": "fmsi_hip_query_kmers, k-mer dictionary"}
 
 
@@ -695,12 +701,14 @@ def run_leg(args):
     args.n, args.batch, args.workload = float(n), batch, workload
     stream_mode = workload == "stream"
     args.stream_via = "runs"
-    if stream_mode:
+    sk_only = name == "c4sk"
+    if stream_mode and not sk_only:
         args.prefix_len = 16   # (the kLCP kernel's fresh searches start from its 16-deep prefix table, as in the earlier rounds' runs; the dictionary paths do not use it)
     c = open_ctx(args)
     k = args.k
     resolve_accelerators(args, n, k, stream_mode)
-    index, build_s, accel_s = build_handle(c, args, n, k, stream_mode, with_klcp=stream_mode, want_pair=False, chain=stream_mode)
+    index, build_s, accel_s = build_handle(c, args, n, k, stream_mode, with_klcp=stream_mode and not sk_only, want_pair=False, chain=stream_mode and not sk_only,
+                                           superkmer_only=sk_only)
     info = index.info
     legs = []
     paths = []
@@ -720,6 +728,9 @@ def run_leg(args):
                      "lf_steps_per_kmer": roof.get("lf_steps_per_kmer"), "random_requests_per_s": roof.get("random_requests_per_s"),
                      "positive_fraction": round(m["positives"], 4), "results_on_host_match_bytes": m["bits_check"],
                      "index_rows": int(info.n), "handle_bytes_hbm": int(info.device_bytes), "dict_bytes": int(info.dict_bytes), "dict_chain_bytes": int(info.dict_chain_bytes),
+                     "superkmer": None if not int(info.sk_bytes) else {"bytes": int(info.sk_bytes), "records": int(info.sk_records), "log2_buckets": int(info.sk_log2_buckets),
+                                                                        "minimizer_len": int(info.sk_minimizer_len), "heavy_minimizers": int(info.sk_heavy_minimizers),
+                                                                        "overflowed_buckets": int(info.sk_overflowed_buckets), "aux_dictionary_keys": int(info.sk_aux_keys)},
                      "index_build_seconds": round(build_s, 2), "matches_reference": None, "reference": None,
                      "_lines128": int(m["counters"][1]) - int(m["counters"][4]) if path.block_b == 128 and not path.is_dict else 0})
         paths.append(path)
@@ -830,7 +841,8 @@ def main():
     if args.pmc_child:   # under rocprofv3 --pmc: the plan's launches and nothing else (the handle is built as the measured run built it)
         plan = json.loads(args.pmc_plan)
         index, _, _ = build_handle(c, args, n, k, stream_mode, with_klcp=any(v["via"] == "klcp" for v in plan),
-                                   want_pair=any(v["via"].startswith("lf_") for v in plan), chain=any(v["via"] == "runs_chain" for v in plan))
+                                   want_pair=any(v["via"].startswith("lf_") for v in plan), chain=any(v["via"] == "runs_chain" for v in plan),
+                                   superkmer_only=all(v["via"] == "runs_sk" for v in plan))
         pmc_child(c, args, index, plan)
         os.close(json_fd)
         return

@@ -309,8 +309,9 @@ def check_legs(c, args, index, paths, names):
             stream_expected[path.subst_ppm] = (want, sec, p.n_reads)
         want, sec, nr = stream_expected[path.subst_ppm]
         out[name] = {"matches": bool(want.shape == gpu_bits.shape and np.array_equal(want, gpu_bits)),
-                     "what": f"{kind}: its record loop with -S -O (query_kmers<all>(..., has_klcp=true)) over the first {nr} reads ({nr * wins} windows) of the leg's "
-                             f"seeded read stream, {nr * wins / sec:.0f} windows/s on one core, against the same {n_rows}-row index incl. its kLCP array "
+                     "what": f"{kind}: its record loop with {'-S -O (query_kmers<all>(..., has_klcp=true))' if has_klcp else '-O (this handle has no kLCP array; the presence answers are the same)'} "
+                             f"over the first {nr} reads ({nr * wins} windows) of the leg's "
+                             f"seeded read stream, {nr * wins / sec:.0f} windows/s on one core, against the same {n_rows}-row index "
                              f"(files by fmsi_hip_index_write_files {write_s:.1f} s, load_index {load_s:.1f} s)"}
     ref.close()
     tmp.cleanup()

@@ -32,9 +32,12 @@ KERNEL_PHASED = 0x40
 KERNEL_DICT = 0x50
 DICT_SPARSE = 0x1
 DICT_CHAIN = 0x2
+DICT_SUPERKMER = 0x4
+DICT_SUPERKMER_ONLY = 0x8
 NO_PREFIX_TABLE = 0x100
 OUT_BITS = 0x200
 NO_DICT_CHAIN = 0x400
+NO_SUPERKMER = 0x800
 FN_AND, FN_XOR, FN_RANGE = 1, 2, 3   # demasking functions of query_runs_fn (`-f and|xor|r-s`)
 N_COUNTERS = 8
 
@@ -68,6 +71,8 @@ class IndexInfo(C.Structure):
         ("n_blocks", C.c_uint64), ("device_bytes", C.c_uint64), ("counts", C.c_uint64 * 4), ("dollar_position", C.c_uint64),
         ("candidate_entry_bytes", C.c_uint64), ("dict_bytes", C.c_uint64), ("dict_keys", C.c_uint64 * 4), ("dict_ambiguous", C.c_uint64),
         ("dict_levels", C.c_uint32), ("dict_log2_buckets", C.c_uint32), ("dict_chain_bytes", C.c_uint64), ("rows64", C.c_uint64),
+        ("sk_bytes", C.c_uint64), ("sk_records", C.c_uint64), ("sk_heavy_minimizers", C.c_uint64), ("sk_overflowed_buckets", C.c_uint64),
+        ("sk_aux_keys", C.c_uint64), ("sk_log2_buckets", C.c_uint32), ("sk_minimizer_len", C.c_uint32),
     ]
 
 
@@ -363,10 +368,11 @@ class DeviceIndex:
         _check(lib().fmsi_hip_index_get_info(self._h, C.byref(self.info)))
         return self
 
-    def enable_dict(self, sparse: bool = False, chain: bool = False):
+    def enable_dict(self, sparse: bool = False, chain: bool = False, superkmer: bool = False, superkmer_only: bool = False):
         """Add the k-mer dictionary (fmsi_hip_index_enable_dict): presence queries with the index's k become one bucket read;
         chain: also the extras of chained lookups for reads (query_runs over reads of one length)."""
-        _check(lib().fmsi_hip_index_enable_dict(self._h, (DICT_SPARSE if sparse else 0) | (DICT_CHAIN if chain else 0)))
+        _check(lib().fmsi_hip_index_enable_dict(self._h, (DICT_SPARSE if sparse else 0) | (DICT_CHAIN if chain else 0) | (DICT_SUPERKMER if superkmer else 0) |
+                                                (DICT_SUPERKMER_ONLY if superkmer_only else 0)))
         _check(lib().fmsi_hip_index_get_info(self._h, C.byref(self.info)))
         return self
 

@@ -27,6 +27,7 @@
 #include <hip/hip_runtime.h>
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
+#include <rocprim/device/device_select.hpp>
 #include <rocprim/iterator/counting_iterator.hpp>
 #include <rocprim/iterator/transform_iterator.hpp>
 
@@ -803,6 +804,69 @@ namespace {
 // The chained form's extras, by a pass of the lookup kernel over the text's own windows: the answer nibble of every text position
 // (the kernel's STRICT | OUT_BITS packing of the raw nibbles) and, per slot, the position of an occurrence.  `text2`: the 2-bit text
 // the construction made (taken over when the handle has none of its own).
+#include "skdict.inc"
+
+// sorted distinct hashes + codes -> the levels of a dictionary (level 0 at <= load0 keys per bucket, the overflow levels at <= 3); the
+// level buffers are handed over in owned[] (freed here on failure), the key arrays are consumed
+int build_dict_levels(DevMem& ukeys, DevMem& ucodes, uint64_t n_unique, double load0, DictIndex& dx, void* owned[kDictMaxLevels], uint64_t& bytes_total,
+                      uint64_t* keys_per_level, uint64_t& total_slots) {
+    int rc;
+    auto fail = [&](int code) {
+        for (uint32_t lv = 0; lv < kDictMaxLevels; ++lv) {
+            if (owned[lv]) (void)dev_free(owned[lv]);
+            owned[lv] = nullptr;
+        }
+        return code;
+    };
+    total_slots = 0;
+    DevMem cur_keys, cur_codes;
+    cur_keys.p = ukeys.release();
+    cur_codes.p = ucodes.release();
+    uint64_t count = n_unique;
+    for (uint32_t lv = 0; lv < kDictMaxLevels; ++lv) {
+        const uint32_t bits = level_bits(count, lv == 0 ? load0 : 3.0);
+        DevMem buckets, spill_keys, spill_codes;
+        uint32_t n_spill = 0;
+        if ((rc = fill_level(cur_keys.as<uint64_t>(), cur_codes.as<uint8_t>(), count, bits, buckets, spill_keys, spill_codes, &n_spill))) return fail(rc);
+        dx.lv[lv].shift = 64u - bits;
+        dx.lv[lv].slot_base = total_slots;
+        total_slots += (1ull << bits) * kDictSlots;
+        dx.lv[lv].buckets = static_cast<const uint4*>(buckets.p);
+        owned[lv] = buckets.release();
+        bytes_total += (1ull << bits) * 128;
+        dx.levels = lv + 1;
+        if (keys_per_level) keys_per_level[lv] = count;
+        if (n_spill == 0) break;
+        if (lv + 1 == kDictMaxLevels) {
+            set_last_error("k-mer dictionary: keys left over after the last level");
+            return fail(FMSI_HIP_ERANGE);
+        }
+        // the next level: its own hash of the spilled hashes, sorted
+        DevMem sk2, sc2, temp;
+        if ((rc = sk2.alloc(static_cast<size_t>(n_spill) * 8, "overflow keys")) || (rc = sc2.alloc(n_spill, "overflow keys"))) return fail(rc);
+        hipLaunchKernelGGL(dict_rehash_kernel, dim3((n_spill + 255) / 256), dim3(256), 0, 0, spill_keys.as<uint64_t>(), static_cast<uint64_t>(n_spill), kLevelSalt[lv + 1]);
+        rocprim::double_buffer<uint64_t> dk(spill_keys.as<uint64_t>(), sk2.as<uint64_t>());
+        rocprim::double_buffer<uint8_t> dv(spill_codes.as<uint8_t>(), sc2.as<uint8_t>());
+        size_t tb = 0;
+        if (rocprim::radix_sort_pairs(nullptr, tb, dk, dv, static_cast<size_t>(n_spill), 0, 64, 0) != hipSuccess || (rc = temp.alloc(tb, "sort scratch")) ||
+            rocprim::radix_sort_pairs(temp.p, tb, dk, dv, static_cast<size_t>(n_spill), 0, 64, 0) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
+            if (!rc) set_last_error("k-mer dictionary: sorting an overflow level failed");
+            return fail(rc ? rc : FMSI_HIP_EHIP);
+        }
+        const bool in_first = dk.current() == spill_keys.as<uint64_t>();
+        cur_keys.reset();
+        cur_codes.reset();
+        cur_keys.p = in_first ? spill_keys.release() : sk2.release();
+        cur_codes.p = (dv.current() == spill_codes.as<uint8_t>()) ? spill_codes.release() : sc2.release();
+        count = n_spill;
+    }
+    if (hipDeviceSynchronize() != hipSuccess) {
+        set_last_error("k-mer dictionary: device work failed");
+        return fail(FMSI_HIP_EHIP);
+    }
+    return 0;
+}
+
 int add_chain_extras(fmsi_hip_index* idx, DevMem& text2, uint64_t total_slots) {
     const int k = idx->k;
     const uint64_t len = idx->n - 1, windows = len - static_cast<uint64_t>(k) + 1;
@@ -849,8 +913,7 @@ int chain_extras_or_warn(fmsi_hip_index* idx, DevMem& text2, uint64_t total_slot
 }
 }  // namespace
 
-extern "C" int fmsi_hip_index_enable_dict(fmsi_hip_index* idx, uint32_t flags) {
-    ::fmsi::ScratchScope scratch_scope_(idx ? idx->device : -1);   // (devpool.h: the outermost builder returns the block cache to the driver)
+static int enable_dict_impl(fmsi_hip_index* idx, uint32_t flags) {
     if (!idx) return FMSI_HIP_EINVAL;
     FMSI_HIP_NARROW_ONLY(idx, "the k-mer dictionary");
     if (idx->dict.levels) {
@@ -993,58 +1056,8 @@ extern "C" int fmsi_hip_index_enable_dict(fmsi_hip_index* idx, uint32_t flags) {
     DictIndex dx{};
     dx.k = k;
     void* owned[kDictMaxLevels] = {nullptr, nullptr, nullptr, nullptr};
-    uint64_t bytes_total = 0;
-    auto fail = [&](int code) {
-        for (void* p : owned)
-            if (p) (void)dev_free(p);
-        return code;
-    };
-    uint64_t total_slots = 0;
-    DevMem cur_keys, cur_codes;
-    cur_keys.p = ukeys.release();
-    cur_codes.p = ucodes.release();
-    uint64_t count = n_unique;
-    for (uint32_t lv = 0; lv < kDictMaxLevels; ++lv) {
-        const uint32_t bits = level_bits(count, lv == 0 ? ((flags & FMSI_HIP_DICT_SPARSE) ? 5.25 : 10.5) : 3.0);
-        DevMem buckets, spill_keys, spill_codes;
-        uint32_t n_spill = 0;
-        if ((rc = fill_level(cur_keys.as<uint64_t>(), cur_codes.as<uint8_t>(), count, bits, buckets, spill_keys, spill_codes, &n_spill))) return fail(rc);
-        dx.lv[lv].shift = 64u - bits;
-        dx.lv[lv].slot_base = total_slots;
-        total_slots += (1ull << bits) * kDictSlots;
-        dx.lv[lv].buckets = static_cast<const uint4*>(buckets.p);
-        owned[lv] = buckets.release();
-        bytes_total += (1ull << bits) * 128;
-        dx.levels = lv + 1;
-        idx->dict_keys[lv] = count;
-        if (n_spill == 0) break;
-        if (lv + 1 == kDictMaxLevels) {
-            set_last_error("k-mer dictionary: keys left over after the last level");
-            return fail(FMSI_HIP_ERANGE);
-        }
-        // the next level: its own hash of the spilled hashes, sorted
-        DevMem sk2, sc2, temp;
-        if ((rc = sk2.alloc(static_cast<size_t>(n_spill) * 8, "overflow keys")) || (rc = sc2.alloc(n_spill, "overflow keys"))) return fail(rc);
-        hipLaunchKernelGGL(dict_rehash_kernel, dim3((n_spill + 255) / 256), dim3(256), 0, 0, spill_keys.as<uint64_t>(), static_cast<uint64_t>(n_spill), kLevelSalt[lv + 1]);
-        rocprim::double_buffer<uint64_t> dk(spill_keys.as<uint64_t>(), sk2.as<uint64_t>());
-        rocprim::double_buffer<uint8_t> dv(spill_codes.as<uint8_t>(), sc2.as<uint8_t>());
-        size_t tb = 0;
-        if (rocprim::radix_sort_pairs(nullptr, tb, dk, dv, static_cast<size_t>(n_spill), 0, 64, 0) != hipSuccess || (rc = temp.alloc(tb, "sort scratch")) ||
-            rocprim::radix_sort_pairs(temp.p, tb, dk, dv, static_cast<size_t>(n_spill), 0, 64, 0) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
-            if (!rc) set_last_error("k-mer dictionary: sorting an overflow level failed");
-            return fail(rc ? rc : FMSI_HIP_EHIP);
-        }
-        const bool in_first = dk.current() == spill_keys.as<uint64_t>();
-        cur_keys.reset();
-        cur_codes.reset();
-        cur_keys.p = in_first ? spill_keys.release() : sk2.release();
-        cur_codes.p = (dv.current() == spill_codes.as<uint8_t>()) ? spill_codes.release() : sc2.release();
-        count = n_spill;
-    }
-    if (hipDeviceSynchronize() != hipSuccess) {
-        set_last_error("k-mer dictionary: device work failed");
-        return fail(FMSI_HIP_EHIP);
-    }
+    uint64_t bytes_total = 0, total_slots = 0;
+    if ((rc = build_dict_levels(ukeys, ucodes, n_unique, (flags & FMSI_HIP_DICT_SPARSE) ? 5.25 : 10.5, dx, owned, bytes_total, idx->dict_keys, total_slots))) return rc;
     clock.mark("levels (fill)");
     idx->dict = dx;
     for (uint32_t lv = 0; lv < kDictMaxLevels; ++lv) idx->d_dict[lv] = owned[lv];
@@ -1056,3 +1069,280 @@ extern "C" int fmsi_hip_index_enable_dict(fmsi_hip_index* idx, uint32_t flags) {
     }
     return 0;
 }
+
+
+// ---- the super-k-mer dictionary: construction (skdict.inc has the kernels) -------------------------------------------------------------
+namespace {
+#define SK_TRY(expr)                                                                                            \
+    do {                                                                                                        \
+        hipError_t e_ = (expr);                                                                                 \
+        if (e_ != hipSuccess) {                                                                                 \
+            set_last_error(std::string("super-k-mer dictionary: ") + #expr + ": " + hipGetErrorString(e_));    \
+            return FMSI_HIP_EHIP;                                                                               \
+        }                                                                                                       \
+    } while (0)
+
+struct U32ToU64 {
+    const uint32_t* p;
+    __host__ __device__ uint64_t operator()(uint64_t i) const { return p[i]; }
+};
+
+// needs the k-mer dictionary with its chained-lookup extras (the 2-bit text and the answer nibble of every text position)
+int build_skdict(fmsi_hip_index* idx) {
+    PhaseClock clock{"skdict"};
+    TraceRange trace_range("fmsi: build super-k-mer dictionary");
+    const int k = idx->k;
+    if (k < 23 || k > 32) {
+        set_last_error("the super-k-mer dictionary is built for 23 <= k <= 32 (minimizers of 21 or 23 bases)");
+        return FMSI_HIP_ERANGE;
+    }
+    const int m = k <= 31 ? 21 : 23;   // odd (an m-mer is never its own reverse complement), k - m <= 10
+    const uint32_t mbits = 2u * static_cast<uint32_t>(m);
+    const uint64_t len = idx->n - 1, windows = len - static_cast<uint64_t>(k) + 1;
+    const uint64_t* text2 = idx->dict.text2;
+    const uint64_t* posans = idx->dict.posans;
+    if (!text2 || !posans) {
+        set_last_error("the super-k-mer dictionary needs the k-mer dictionary's chained-lookup extras");
+        return FMSI_HIP_EINVAL;
+    }
+    int rc;
+    // 1. every window's minimizer occurrence(s); records per window; their places
+    DevMem tl, tr, cnt, off;
+    if ((rc = tl.alloc(windows * 4, "minimizer positions")) || (rc = tr.alloc(windows * 4, "minimizer positions")) || (rc = cnt.alloc(windows * 4, "record counts")) ||
+        (rc = off.alloc((windows + 1) * 8, "record offsets")))
+        return rc;
+    hipLaunchKernelGGL(sk_minimizer_kernel, dim3(grid_of(windows)), dim3(256), 0, 0, text2, windows, k, m, tl.as<uint32_t>(), tr.as<uint32_t>());
+    hipLaunchKernelGGL(sk_count_kernel, dim3(grid_of(windows)), dim3(256), 0, 0, tl.as<uint32_t>(), tr.as<uint32_t>(), windows, cnt.as<uint32_t>());
+    SK_TRY(hipGetLastError());
+    uint64_t n_rec = 0;
+    {
+        auto in = rocprim::make_transform_iterator(rocprim::make_counting_iterator<uint64_t>(0), U32ToU64{cnt.as<uint32_t>()});
+        size_t tb = 0;
+        DevMem temp;
+        SK_TRY(rocprim::exclusive_scan(nullptr, tb, in, off.as<uint64_t>(), 0ull, static_cast<size_t>(windows), rocprim::plus<uint64_t>()));
+        if ((rc = temp.alloc(tb, "scan scratch"))) return rc;
+        SK_TRY(rocprim::exclusive_scan(temp.p, tb, in, off.as<uint64_t>(), 0ull, static_cast<size_t>(windows), rocprim::plus<uint64_t>()));
+        uint64_t last_off = 0;
+        uint32_t last_cnt = 0;
+        SK_TRY(hipMemcpy(&last_off, off.as<uint64_t>() + (windows - 1), 8, hipMemcpyDeviceToHost));
+        SK_TRY(hipMemcpy(&last_cnt, cnt.as<uint32_t>() + (windows - 1), 4, hipMemcpyDeviceToHost));
+        n_rec = last_off + last_cnt;
+    }
+    cnt.reset();
+    clock.mark("minimizers of the text's windows");
+    if (n_rec > (3ull << 29) || n_rec >= kMaxSortItems) {   // (a low-complexity text: every window a record of its own)
+        set_last_error("the super-k-mer dictionary is not built for this text (" + std::to_string(n_rec) + " super-k-mer records before deduplication)");
+        return FMSI_HIP_ERANGE;
+    }
+    // 2. the records, sorted by (minimizer, neighbourhood); duplicates (repeats) collapse
+    DevMem keys_a, keys_b, vals_a, vals_b;
+    if ((rc = keys_a.alloc(n_rec * 16, "records")) || (rc = keys_b.alloc(n_rec * 16, "records")) || (rc = vals_a.alloc(n_rec * 8, "records")) ||
+        (rc = vals_b.alloc(n_rec * 8, "records")))
+        return rc;
+    hipLaunchKernelGGL(sk_emit_kernel, dim3(grid_of(windows)), dim3(256), 0, 0, text2, posans, tl.as<uint32_t>(), tr.as<uint32_t>(), off.as<uint64_t>(), windows, k, m,
+                       keys_a.as<__uint128_t>(), vals_a.as<uint64_t>());
+    SK_TRY(hipGetLastError());
+    SK_TRY(hipDeviceSynchronize());
+    tl.reset();
+    tr.reset();
+    off.reset();
+    clock.mark("records");
+    uint64_t n_uniq = 0;
+    DevMem ukeys, uvals;
+    {
+        rocprim::double_buffer<__uint128_t> dk(keys_a.as<__uint128_t>(), keys_b.as<__uint128_t>());
+        rocprim::double_buffer<uint64_t> dv(vals_a.as<uint64_t>(), vals_b.as<uint64_t>());
+        size_t tb = 0;
+        DevMem temp;
+        SK_TRY(rocprim::radix_sort_pairs(nullptr, tb, dk, dv, static_cast<size_t>(n_rec), 0, mbits + 48, 0));
+        if ((rc = temp.alloc(tb, "sort scratch"))) return rc;
+        SK_TRY(rocprim::radix_sort_pairs(temp.p, tb, dk, dv, static_cast<size_t>(n_rec), 0, mbits + 48, 0));
+        clock.mark("radix sort");
+        const __uint128_t* sk_ = dk.current();
+        const uint64_t* sv = dv.current();
+        DevMem flag, d_n;
+        if ((rc = flag.alloc(n_rec, "flags")) || (rc = d_n.alloc(8, "counter"))) return rc;
+        hipLaunchKernelGGL(sk_unique_flags_kernel, dim3(grid_of(n_rec)), dim3(256), 0, 0, sk_, n_rec, flag.as<uint8_t>());
+        SK_TRY(hipGetLastError());
+        __uint128_t* other_k = sk_ == keys_a.as<__uint128_t>() ? keys_b.as<__uint128_t>() : keys_a.as<__uint128_t>();
+        uint64_t* other_v = sv == vals_a.as<uint64_t>() ? vals_b.as<uint64_t>() : vals_a.as<uint64_t>();
+        size_t t1 = 0, t2 = 0;
+        SK_TRY(rocprim::select(nullptr, t1, sk_, flag.as<uint8_t>(), other_k, d_n.as<size_t>(), static_cast<size_t>(n_rec)));
+        SK_TRY(rocprim::select(nullptr, t2, sv, flag.as<uint8_t>(), other_v, d_n.as<size_t>(), static_cast<size_t>(n_rec)));
+        if ((rc = temp.alloc(std::max(t1, t2), "select scratch"))) return rc;
+        SK_TRY(rocprim::select(temp.p, t1, sk_, flag.as<uint8_t>(), other_k, d_n.as<size_t>(), static_cast<size_t>(n_rec)));
+        SK_TRY(rocprim::select(temp.p, t2, sv, flag.as<uint8_t>(), other_v, d_n.as<size_t>(), static_cast<size_t>(n_rec)));
+        size_t got = 0;
+        SK_TRY(hipMemcpy(&got, d_n.p, sizeof(size_t), hipMemcpyDeviceToHost));
+        n_uniq = got;
+        // keep the compacted copies, free the sorted ones
+        if (other_k == keys_a.as<__uint128_t>()) { ukeys.p = keys_a.release(); keys_b.reset(); } else { ukeys.p = keys_b.release(); keys_a.reset(); }
+        if (other_v == vals_a.as<uint64_t>()) { uvals.p = vals_a.release(); vals_b.reset(); } else { uvals.p = vals_b.release(); vals_a.reset(); }
+    }
+    clock.mark("distinct records");
+    // 3. the buckets: about 3.5 records each
+    uint32_t bits = 6;
+    while (bits < 31u && bits + 6u < mbits && static_cast<double>(n_uniq) / static_cast<double>(1ull << bits) > 3.5) ++bits;
+    const uint64_t n_buckets = 1ull << bits;
+    const uint32_t shift = mbits - bits;
+    DevMem buckets, first, last, stats;
+    if ((rc = buckets.alloc(n_buckets * 128, "buckets")) || (rc = first.alloc(n_buckets * 4, "bucket bounds")) || (rc = last.alloc(n_buckets * 4, "bucket bounds")) ||
+        (rc = stats.alloc(32, "counters")))
+        return rc;
+    SK_TRY(hipMemset(buckets.p, 0, n_buckets * 128));
+    SK_TRY(hipMemset(first.p, 0xFF, n_buckets * 4));
+    SK_TRY(hipMemset(stats.p, 0, 32));
+    if (n_uniq) {
+        hipLaunchKernelGGL(sk_bounds_kernel, dim3(grid_of(n_uniq)), dim3(256), 0, 0, ukeys.as<__uint128_t>(), n_uniq, shift, first.as<uint32_t>(), last.as<uint32_t>());
+        hipLaunchKernelGGL(sk_fill_kernel, dim3(grid_of(n_buckets)), dim3(256), 0, 0, ukeys.as<__uint128_t>(), uvals.as<uint64_t>(), first.as<uint32_t>(), last.as<uint32_t>(),
+                           n_buckets, shift, buckets.as<uint64_t>(), stats.as<unsigned long long>());
+        SK_TRY(hipGetLastError());
+    }
+    unsigned long long h_stats[4] = {0, 0, 0, 0};
+    SK_TRY(hipMemcpy(h_stats, stats.p, 32, hipMemcpyDeviceToHost));
+    ukeys.reset();
+    uvals.reset();
+    first.reset();
+    last.reset();
+    clock.mark("buckets");
+    SkIndex sk{};
+    sk.buckets = static_cast<const uint4*>(buckets.p);
+    sk.bits = bits;
+    sk.k = k;
+    sk.m = m;
+    // 4. the text through the structure itself: what the records do not hold goes to the aux dictionary; every record's nibble is checked
+    DevMem aux_keys, aux_codes, aux_cnt;
+    if ((rc = aux_cnt.alloc(16, "counter"))) return rc;
+    uint64_t n_aux = 0;
+    const uint64_t waves = (windows + 64ull * kSkTask - 1) / (64ull * kSkTask);
+    for (int pass = 0; pass < 2; ++pass) {
+        uint64_t cap = 0;
+        if (pass == 1) {
+            if (n_aux == 0) break;
+            cap = n_aux;
+            if ((rc = aux_keys.alloc(cap * 8, "aux keys")) || (rc = aux_codes.alloc(cap, "aux codes"))) return rc;
+        }
+        SK_TRY(hipMemset(aux_cnt.p, 0, 16));
+        hipLaunchKernelGGL((sk_runs_kernel<false>), dim3(static_cast<uint32_t>((waves + 3) / 4)), dim3(256), 0, 0, sk, DictIndex{}, text2, windows,
+                           static_cast<uint32_t>(kFlagSelf), nullptr, nullptr, 0ull, windows, windows, posans, aux_keys.as<uint64_t>(), aux_codes.as<uint8_t>(),
+                           aux_cnt.as<unsigned long long>(), cap);
+        SK_TRY(hipGetLastError());
+        unsigned long long got[2] = {0, 0};
+        SK_TRY(hipMemcpy(got, aux_cnt.p, 16, hipMemcpyDeviceToHost));
+        if (got[1] != 0) {
+            set_last_error("super-k-mer dictionary: " + std::to_string(got[1]) + " of the text's own windows came back with another answer (construction bug)");
+            return FMSI_HIP_EHIP;
+        }
+        n_aux = got[0];
+    }
+    clock.mark("text through the records (aux list)");
+    DictIndex aux{};
+    aux.k = k;
+    void* owned[kDictMaxLevels] = {nullptr, nullptr, nullptr, nullptr};
+    uint64_t aux_bytes = 0, aux_unique = 0;
+    if (n_aux) {
+        if (n_aux >= kMaxSortItems) {
+            set_last_error("super-k-mer dictionary: too many k-mers outside the records");
+            return FMSI_HIP_ERANGE;
+        }
+        DevMem k2, c2, temp, uk, uc, flag, d_n;
+        if ((rc = k2.alloc(n_aux * 8, "aux keys")) || (rc = c2.alloc(n_aux, "aux codes"))) return rc;
+        rocprim::double_buffer<uint64_t> dk(aux_keys.as<uint64_t>(), k2.as<uint64_t>());
+        rocprim::double_buffer<uint8_t> dv(aux_codes.as<uint8_t>(), c2.as<uint8_t>());
+        size_t tb = 0;
+        SK_TRY(rocprim::radix_sort_pairs(nullptr, tb, dk, dv, static_cast<size_t>(n_aux), 0, 64, 0));
+        if ((rc = temp.alloc(tb, "sort scratch"))) return rc;
+        SK_TRY(rocprim::radix_sort_pairs(temp.p, tb, dk, dv, static_cast<size_t>(n_aux), 0, 64, 0));
+        if ((rc = uk.alloc(n_aux * 8, "aux keys")) || (rc = uc.alloc(n_aux, "aux codes")) || (rc = d_n.alloc(8, "counter"))) return rc;
+        auto heads = rocprim::make_transform_iterator(rocprim::make_counting_iterator<uint64_t>(0), HeadFlag{dk.current()});
+        size_t t1 = 0, t2 = 0;
+        SK_TRY(rocprim::select(nullptr, t1, dk.current(), heads, uk.as<uint64_t>(), d_n.as<size_t>(), static_cast<size_t>(n_aux)));
+        SK_TRY(rocprim::select(nullptr, t2, dv.current(), heads, uc.as<uint8_t>(), d_n.as<size_t>(), static_cast<size_t>(n_aux)));
+        if ((rc = temp.alloc(std::max(t1, t2), "select scratch"))) return rc;
+        SK_TRY(rocprim::select(temp.p, t1, dk.current(), heads, uk.as<uint64_t>(), d_n.as<size_t>(), static_cast<size_t>(n_aux)));
+        SK_TRY(rocprim::select(temp.p, t2, dv.current(), heads, uc.as<uint8_t>(), d_n.as<size_t>(), static_cast<size_t>(n_aux)));
+        size_t got = 0;
+        SK_TRY(hipMemcpy(&got, d_n.p, sizeof(size_t), hipMemcpyDeviceToHost));
+        aux_unique = got;
+        aux_keys.reset();
+        aux_codes.reset();
+        k2.reset();
+        c2.reset();
+        uint64_t slots = 0;
+        if ((rc = build_dict_levels(uk, uc, aux_unique, 10.5, aux, owned, aux_bytes, nullptr, slots))) return rc;
+    }
+    clock.mark("aux dictionary");
+    idx->sk = sk;
+    idx->d_sk = buckets.release();
+    idx->sk_aux = aux;
+    for (uint32_t lv = 0; lv < kDictMaxLevels; ++lv) idx->d_sk_aux[lv] = owned[lv];
+    idx->sk_bytes = n_buckets * 128 + aux_bytes;
+    idx->sk_records = h_stats[2];
+    idx->sk_heavy = h_stats[0];
+    idx->sk_overflowed = h_stats[1];
+    idx->sk_aux_keys = aux_unique;
+    idx->device_bytes += idx->sk_bytes;
+    return 0;
+}
+
+// the k-mer dictionary and the chained lookups' extras go (FMSI_HIP_DICT_SUPERKMER_ONLY): presence queries over runs take the super-k-mer
+// dictionary, everything else the index's own search
+void drop_kmer_dict(fmsi_hip_index* idx) {
+    for (uint32_t lv = 0; lv < kDictMaxLevels; ++lv) {
+        if (idx->d_dict[lv]) (void)dev_free(idx->d_dict[lv]);
+        idx->d_dict[lv] = nullptr;
+    }
+    if (idx->d_posans) (void)dev_free(idx->d_posans);
+    if (idx->d_slot_pos) (void)dev_free(idx->d_slot_pos);
+    idx->d_posans = idx->d_slot_pos = nullptr;
+    if (idx->dict_owns_text && idx->d_text2) {
+        (void)dev_free(idx->d_text2);
+        idx->d_text2 = nullptr;
+        idx->dict_owns_text = false;
+    }
+    idx->device_bytes -= idx->dict_bytes;
+    idx->dict_bytes = idx->dict_chain_bytes = 0;
+    idx->dict = DictIndex{};
+}
+}  // namespace
+
+extern "C" int fmsi_hip_index_enable_dict(fmsi_hip_index* idx, uint32_t flags) {
+    ::fmsi::ScratchScope scratch_scope_(idx ? idx->device : -1);   // (devpool.h: the outermost builder returns the block cache to the driver)
+    if (!idx) return FMSI_HIP_EINVAL;
+    const bool want_sk = (flags & (FMSI_HIP_DICT_SUPERKMER | FMSI_HIP_DICT_SUPERKMER_ONLY)) != 0u;
+    if (!want_sk) return enable_dict_impl(idx, flags & (FMSI_HIP_DICT_SPARSE | FMSI_HIP_DICT_CHAIN));
+    FMSI_HIP_NARROW_ONLY(idx, "the super-k-mer dictionary");
+    if (idx->sk.bits) return 0;
+    int rc = enable_dict_impl(idx, (flags & FMSI_HIP_DICT_SPARSE) | FMSI_HIP_DICT_CHAIN);   // (its per-position answers are what the records are made of)
+    if (rc) return rc;
+    if (!idx->dict.posans) {
+        set_last_error(std::string("the super-k-mer dictionary needs the chained lookups' extras: ") + fmsi_hip_last_error());
+        return FMSI_HIP_ENOMEM;
+    }
+    FMSI_HIP_ON_DEVICE(idx->device);
+    if ((rc = build_skdict(idx))) return rc;
+    if (flags & FMSI_HIP_DICT_SUPERKMER_ONLY) drop_kmer_dict(idx);
+    return 0;
+}
+
+namespace fmsi {
+bool skdict_applies(const fmsi_hip_index* idx, int k, uint32_t flags) {
+    const uint32_t kernel = flags & FMSI_HIP_KERNEL_MASK;
+    return idx->sk.bits != 0 && k == idx->k && !(flags & (FMSI_HIP_ORDERS | FMSI_HIP_NO_PREFIX_TABLE | FMSI_HIP_NO_SUPERKMER)) &&
+           (kernel == FMSI_HIP_KERNEL_AUTO || kernel == FMSI_HIP_KERNEL_DICT);
+}
+
+int launch_skdict(fmsi_hip_index* idx, const uint64_t* d_seq, uint64_t n, int k, uint32_t flags, uint8_t* o8, unsigned long long* d_counters, hipStream_t s,
+                  const uint64_t* u) {
+    (void)k;
+    const uint64_t waves = (n + 64ull * kSkTask - 1) / (64ull * kSkTask);
+    const dim3 grid(static_cast<uint32_t>((waves + 3) / 4)), block(256);
+    if (d_counters)
+        hipLaunchKernelGGL((sk_runs_kernel<true>), grid, block, 0, s, idx->sk, idx->sk_aux, d_seq, n, flags, o8, d_counters, u[0], u[1], u[2], nullptr, nullptr, nullptr, nullptr, 0ull);
+    else
+        hipLaunchKernelGGL((sk_runs_kernel<false>), grid, block, 0, s, idx->sk, idx->sk_aux, d_seq, n, flags, o8, d_counters, u[0], u[1], u[2], nullptr, nullptr, nullptr, nullptr, 0ull);
+    FMSI_HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+}  // namespace fmsi

@@ -851,6 +851,8 @@ uint64_t fmsi_hip_scratch_bytes(int device) {
 void fmsi_hip_index_destroy(fmsi_hip_index* idx) {
     if (!idx) return;
     ::fmsi::DeviceGuard device_guard_(idx->device);
+    for (void* p : {idx->d_sk, idx->d_sk_aux[0], idx->d_sk_aux[1], idx->d_sk_aux[2], idx->d_sk_aux[3]})
+        if (p) (void)dev_free(p);
     for (void* p : {idx->d_super, idx->d_blocks, idx->d_mrank, idx->d_ptable, idx->d_klcp, idx->d_sblocks, idx->d_text2, idx->d_stable, idx->d_vtable, idx->d_in, idx->d_aux, idx->d_out,
                     idx->d_kmers, idx->d_tasks, idx->d_bytes, idx->d_case, idx->d_dict[0], idx->d_dict[1], idx->d_dict[2], idx->d_dict[3], idx->d_posans, idx->d_slot_pos, idx->d_pblocks, idx->d_sbt, idx->d_c2, static_cast<void*>(idx->d_counters)})
         if (p) (void)dev_free(p);
@@ -888,6 +890,13 @@ int fmsi_hip_index_get_info(const fmsi_hip_index* idx, fmsi_hip_index_info* info
     info->dict_levels = idx->dict.levels;
     info->dict_log2_buckets = idx->dict.levels ? 64u - idx->dict.lv[0].shift : 0u;
     info->dict_chain_bytes = idx->dict_chain_bytes;
+    info->sk_bytes = idx->sk_bytes;
+    info->sk_records = idx->sk_records;
+    info->sk_heavy_minimizers = idx->sk_heavy;
+    info->sk_overflowed_buckets = idx->sk_overflowed;
+    info->sk_aux_keys = idx->sk_aux_keys;
+    info->sk_log2_buckets = idx->sk.bits;
+    info->sk_minimizer_len = idx->sk.bits ? static_cast<uint32_t>(idx->sk.m) : 0u;
     return 0;
 }
 
@@ -986,7 +995,8 @@ int fmsi_hip_query_runs(fmsi_hip_index* idx, const uint64_t* packed_seq, uint64_
     const uint64_t uniform_runs[3] = {run_start[0], stride, wpr};
     const bool fn_mode = (flags & kModeFn) != 0;   // a demasking function: fmsi_hip_query_runs_fn (fmsi_fn.hip)
     flags &= ~kModeFn;
-    const bool table_free = !fn_mode && uniform && dict_applies(idx, k, flags) && n_windows <= (1ull << 38);
+    const bool via_sk = !fn_mode && uniform && skdict_applies(idx, k, flags) && n_windows <= (1ull << 38);
+    const bool table_free = via_sk || (!fn_mode && uniform && dict_applies(idx, k, flags) && n_windows <= (1ull << 38));
     // otherwise: [0, n_runs): run starts, [n_runs, 2 n_runs + 1): exclusive prefix sums of the run lengths -- in a page-locked slot
     // of the handle's ring, so that nothing has to wait for the copy (the call stays asynchronous on `stream`)
     void* meta_host = nullptr;
@@ -1022,6 +1032,17 @@ int fmsi_hip_query_runs(fmsi_hip_index* idx, const uint64_t* packed_seq, uint64_
         }
     }
     uint32_t kernel = flags & FMSI_HIP_KERNEL_MASK;
+    if (via_sk) {   // reads of one length through the super-k-mer dictionary: a bucket read per minimizer
+        size_t slot;
+        if ((rc = prof_begin(idx, s, &slot))) return rc;
+        if ((rc = launch_skdict(idx, d_seq, n_windows, k, flags, static_cast<uint8_t*>(d_out), d_cnt, s, uniform_runs))) return rc;
+        if ((rc = prof_end(idx, s, slot))) return rc;
+        if (!dev_ptrs) {
+            if (out_bytes) FMSI_HIP_TRY(hipMemcpyAsync(out, idx->d_out, out_bytes, hipMemcpyDeviceToHost, s));
+            if (counters) FMSI_HIP_TRY(hipMemcpyAsync(counters, idx->d_counters, FMSI_HIP_N_COUNTERS * 8, hipMemcpyDeviceToHost, s));
+        }
+        return 0;
+    }
     if (!fn_mode && dict_applies(idx, k, flags) && n_windows <= (1ull << 38)) {
         // the dictionary's lookup kernel cuts the windows itself, too
         size_t slot;

@@ -59,6 +59,14 @@ struct DictIndex {
     uint64_t text_len;
 };
 
+// the super-k-mer dictionary (skdict.inc): one level of 128-byte buckets of eight 16-byte records, passed by value to its kernel
+struct SkIndex {
+    const uint4* buckets;   // 2^bits buckets
+    uint32_t bits;          // 0: none
+    int k, m;
+    uint32_t pad;
+};
+
 #define FMSI_HIP_TRY(expr)                                                                                 \
     do {                                                                                                   \
         hipError_t e_ = (expr);                                                                            \
@@ -138,6 +146,12 @@ struct fmsi_hip_index {
     fmsi::DictIndex dict{};
     void* d_dict[fmsi::kDictMaxLevels] = {nullptr, nullptr, nullptr, nullptr};
     uint64_t dict_bytes = 0, dict_keys[fmsi::kDictMaxLevels] = {0, 0, 0, 0}, dict_ambiguous = 0;
+    // optional super-k-mer dictionary (skdict.inc; FMSI_HIP_DICT_SUPERKMER) with its aux k-mer dictionary of what it does not hold
+    fmsi::SkIndex sk{};
+    void* d_sk = nullptr;
+    fmsi::DictIndex sk_aux{};
+    void* d_sk_aux[fmsi::kDictMaxLevels] = {nullptr, nullptr, nullptr, nullptr};
+    uint64_t sk_bytes = 0, sk_records = 0, sk_heavy = 0, sk_overflowed = 0, sk_aux_keys = 0;
     void* d_posans = nullptr;     // chained lookups: answer nibble per text position
     void* d_slot_pos = nullptr;   // ... and a text position per dictionary slot
     bool dict_owns_text = false;  // d_text2 was made by the dictionary's construction
@@ -211,6 +225,10 @@ int launch_dict_query(fmsi_hip_index* idx, const uint64_t* d_in, uint64_t n, int
 // uniform runs of a packed read batch through the chained form (needs the dictionary's chain data): a lane takes 32 consecutive
 // windows, looks the first one up and follows the superstring from its occurrence
 bool dict_chain_applies(const fmsi_hip_index* idx, int k, uint32_t flags);
+// uniform runs through the super-k-mer dictionary (a bucket read per minimizer, not per window)
+bool skdict_applies(const fmsi_hip_index* idx, int k, uint32_t flags);
+int launch_skdict(fmsi_hip_index* idx, const uint64_t* d_seq, uint64_t n, int k, uint32_t flags, uint8_t* o8, unsigned long long* d_counters, hipStream_t s,
+                  const uint64_t* uniform_runs);
 int launch_dict_chain(fmsi_hip_index* idx, const uint64_t* d_seq, uint64_t n, int k, uint32_t flags, uint8_t* o8, unsigned long long* d_counters, hipStream_t s,
                       const uint64_t* uniform_runs);
 

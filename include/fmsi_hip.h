@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define FMSI_HIP_ABI_VERSION 5   /* 5: fmsi_hip_keep_scratch; 4: fmsi_hip_query_runs_fn (`-f and|xor|r-s`); 2: fmsi_hip_index_info.candidate_entry_bytes, fmsi_hip_comm_*, fmsi_hip_gather; 3: FMSI_HIP_OUT_BITS, fmsi_hip_index_load, fmsi_hip_trim_scratch, fmsi_hip_index_enable_dict + fmsi_hip_index_info.dict_*, fmsi_hip_index_build_synthetic_spec */
+#define FMSI_HIP_ABI_VERSION 6   /* 6: FMSI_HIP_DICT_SUPERKMER + fmsi_hip_index_info.sk_*, fmsi_hip_index_enable_stream_layout, FMSI_HIP_NO_DICT_CHAIN; 5: fmsi_hip_keep_scratch; 4: fmsi_hip_query_runs_fn (`-f and|xor|r-s`); 2: fmsi_hip_index_info.candidate_entry_bytes, fmsi_hip_comm_*, fmsi_hip_gather; 3: FMSI_HIP_OUT_BITS, fmsi_hip_index_load, fmsi_hip_trim_scratch, fmsi_hip_index_enable_dict + fmsi_hip_index_info.dict_*, fmsi_hip_index_build_synthetic_spec */
 
 /* error codes */
 #define FMSI_HIP_OK 0
@@ -82,6 +82,8 @@ extern "C" {
 /* fmsi_hip_query_runs on a handle whose dictionary has the chained lookups' extras: take the plain lookups (one bucket read per window)
  * for this call -- A/B runs of the two forms on one handle */
 #define FMSI_HIP_NO_DICT_CHAIN 0x400u
+/* ... and not the super-k-mer dictionary either */
+#define FMSI_HIP_NO_SUPERKMER 0x800u
 
 /* ---- index creation flags --------------------------------------------------------------------- */
 /* build a 4^t-entry prefix table that jumps the first t LF steps (private optimisation: the final SA
@@ -127,6 +129,9 @@ typedef struct {
     uint64_t dict_chain_bytes;  /* 0, or the bytes of the chained lookups' extras (FMSI_HIP_DICT_CHAIN; included in dict_bytes) */
     uint64_t rows64;            /* 1: the handle keeps 64-bit rows (n >= 2^32 - 128; src/fms_index.h:98-103 uses size_t): plain search only --
                                    no prefix table, pair layout, candidate tables, dictionary, kLCP streaming, k > 32, export (FMSI_HIP_ERANGE) */
+    uint64_t sk_bytes;          /* 0 = no super-k-mer dictionary (FMSI_HIP_DICT_SUPERKMER), else its HBM footprint incl. the aux dictionary */
+    uint64_t sk_records, sk_heavy_minimizers, sk_overflowed_buckets, sk_aux_keys;
+    uint32_t sk_log2_buckets, sk_minimizer_len;
 } fmsi_hip_index_info;
 
 /* counters written by query calls when `counters` != NULL (8 x u64, accumulated, caller zeroes):
@@ -237,6 +242,15 @@ int fmsi_hip_index_enable_verify(fmsi_hip_index* idx);
  * follows the superstring from its occurrence, a base compare and a nibble per further window; windows that leave the text take the
  * ordinary lookups.  Same answers; several times fewer memory requests on reads that come from the indexed sequences. */
 #define FMSI_HIP_DICT_CHAIN 0x2u
+/* ... and the SUPER-K-MER dictionary (23 <= k <= 32): the text's k-mers filed by their minimizer (21 or 23 bases, both strands), one 16-byte
+ * record per super-k-mer -- the bases around one occurrence of a minimizer and an answer nibble for each of the up to 11 k-mers that share
+ * it -- in buckets of 128 bytes addressed by the minimizer.  fmsi_hip_query_runs over reads of one length then fetches a bucket when a
+ * lane's minimizer CHANGES, about every sixth window, whether the read is in the text or not; about 5 bytes of HBM per k-mer.  What the
+ * scheme does not hold (minimizers with more than four distinct neighbourhoods, overflowing buckets) lives in a small k-mer dictionary
+ * beside it.  Same answers.  _ONLY: the k-mer dictionary that the construction goes through is released afterwards (isolated k-mers and
+ * runs of differing lengths then take the index's own search). */
+#define FMSI_HIP_DICT_SUPERKMER 0x4u
+#define FMSI_HIP_DICT_SUPERKMER_ONLY 0x8u
 int fmsi_hip_index_enable_dict(fmsi_hip_index* idx, uint32_t flags);
 
 /* Replaces export_ms() (src/fms_index.h:462-473): the masked superstring of the index (upper case = mask 1), written

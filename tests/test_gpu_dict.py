@@ -281,3 +281,111 @@ def synthetic_text_for_lifecycle():
     rng = random.Random(12)
     s = "".join(rng.choice("ACGT") for _ in range(3_000_000))
     return s[:-20] + s[-20:].lower()
+
+
+def _sk_reads(rng, up, read_len, n_reads):
+    reads = []
+    for r in range(n_reads):
+        kind = r % 7
+        if kind in (0, 1, 2):
+            p = rng.randrange(0, len(up) - read_len + 1)
+            s = up[p:p + read_len]
+        elif kind == 3:
+            s = up[:read_len] if r % 2 else up[len(up) - read_len:]                   # the text's two ends
+        elif kind == 4:
+            s = "".join(rng.choice("ACGT") for _ in range(read_len))
+        else:
+            p = rng.randrange(0, len(up) - read_len + 1)
+            s = list(up[p:p + read_len])
+            for _ in range(1 + read_len // 60):
+                s[rng.randrange(read_len)] = rng.choice("ACGT")                        # substitutions
+            s = "".join(s)
+        if kind in (1, 5) or (kind == 3 and r % 4 == 3):
+            s = revcomp(s)
+        reads.append(s)
+    return reads
+
+
+@pytest.mark.parametrize("read_len,k,mask,shape", [(150, 31, "ones", "random"), (100, 31, "mixed", "repeats"), (40, 27, "mixed", "random"),
+                                                  (250, 32, "mixed", "repeats"), (64, 23, "ones", "lowcomplexity"), (33, 31, "mixed", "random")])
+def test_super_kmer_dictionary(fm, oracle_built, read_len, k, mask, shape):
+    """FMSI_HIP_DICT_SUPERKMER: reads of one length through fmsi_hip_query_runs take sk_runs_kernel -- a bucket read when a lane's
+    minimizer changes, the window compared base by base with the records of its minimizer.  Texts with repeats (minimizers with many
+    neighbourhoods: heavy records, the aux dictionary), low-complexity stretches (ties between equal m-mers and between an m-mer and its
+    reverse complement: the leftmost / rightmost records), reads in both orientations, with substitutions, random reads, the text's two
+    ends, tasks that straddle reads and reads shorter than a task, even k (self-complementary k-mers), mixed masks: strand by strand what
+    the oracle says, in both modes, as bytes and bit-packed, equal to the k-mer dictionary -- also when the k-mer dictionary is gone."""
+    rng = random.Random(read_len * 1000 + k)
+    n = 40_000
+    if shape == "random":
+        ms = synthetic_ms(n, k, seed=read_len + k, mask=mask)
+    else:
+        body = synthetic_ms(n // 2, k, seed=read_len + k + 1, mask=mask)
+        pieces = [body]
+        unit = body[1000:1400]
+        for c in range(30):      # a repeat family: copies with a few substitutions each
+            cp = list(unit)
+            for _ in range(4):
+                cp[rng.randrange(len(cp))] = rng.choice("ACGTacgt")
+            pieces.append("".join(cp))
+            pieces.append(body[rng.randrange(0, len(body) - 300):][:300])
+        if shape == "lowcomplexity":
+            pieces += ["A" * 300, "AT" * 200, "ACG" * 150, "aaaaaaaaaaaaaaaaaaaaaaaaaaaaaaTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTT" * 3, revcomp(unit) * 2]
+        pieces.append(revcomp(body[3000:3500]))
+        ms = "".join(pieces)
+        ms = ms[: len(ms) - (k - 1)] + ms[len(ms) - (k - 1):].lower()
+    orc = oracle_py.Oracle.construct(ms, k, use_klcp=False)
+    dev = fm.DeviceIndex.build(ms.encode(), k).enable_dict(superkmer=True)
+    only = fm.DeviceIndex.build(ms.encode(), k).enable_dict(superkmer_only=True)
+    plain = fm.DeviceIndex.build(ms.encode(), k).enable_dict()
+    assert dev.info.sk_bytes > 0 and dev.info.dict_bytes > 0 and only.info.sk_bytes > 0 and only.info.dict_bytes == 0 and plain.info.sk_bytes == 0
+    assert dev.info.sk_minimizer_len == (21 if k <= 31 else 23)
+    if shape != "random":
+        assert dev.info.sk_aux_keys > 0      # the repeat family's minimizers are heavy
+    up = ms.upper()
+    reads = _sk_reads(rng, up, read_len, 700)
+    seq = "".join(reads)
+    words = fm.pack_sequence(seq.encode())
+    w = read_len - k + 1
+    starts = np.arange(len(reads), dtype=np.uint64) * np.uint64(read_len)
+    wins = np.full(len(reads), w, dtype=np.uint32)
+    kmers = [r[i:i + k] for r in reads for i in range(w)]
+    for mode_all in (False, True):
+        flag = fm.MODE_ALL if mode_all else fm.MODE_OR
+        fwd, rc = orc.ternaries_bulk("".join(kmers).encode(), len(kmers), k, mode_all)
+        got, cn = dev.query_runs(words, len(seq), starts, wins, k, flag | fm.STRICT, counters=True)
+        gf, gr = fm.decode_strict(got)
+        assert np.array_equal(gf, fwd), (mode_all, np.nonzero(gf != fwd)[0][:10])
+        assert np.array_equal(gr, rc), (mode_all, np.nonzero(gr != rc)[0][:10])
+        assert np.array_equal(only.query_runs(words, len(seq), starts, wins, k, flag | fm.STRICT), got)
+        assert np.array_equal(plain.query_runs(words, len(seq), starts, wins, k, flag | fm.STRICT), got)
+        assert np.array_equal(dev.query_runs(words, len(seq), starts, wins, k, flag | fm.STRICT | fm.NO_SUPERKMER), got)
+        bits = only.query_runs(words, len(seq), starts, wins, k, flag | fm.OUT_BITS)
+        want_fast = (np.where(fwd != -1, fwd, rc) == 1) if mode_all else ((fwd == 1) | (rc == 1))
+        assert np.array_equal(fm.unpack_bits(bits, len(kmers), 0).astype(bool), want_fast)
+        assert int(cn[6]) == len(kmers)
+        if w >= 64 and shape == "random":
+            assert int(cn[4]) < 0.4 * len(kmers)          # far fewer bucket reads than windows
+    # isolated k-mers and ragged runs do not take the records -- with the k-mer dictionary gone they take the index's own search
+    km = kmers[:3000]
+    f1, r1 = orc.ternaries_bulk("".join(km).encode(), len(km), k, True)
+    g1f, g1r = fm.decode_strict(only.query_kmers(fm.pack_kmers(km, k), k, fm.MODE_ALL | fm.STRICT))
+    assert np.array_equal(g1f, f1) and np.array_equal(g1r, r1)
+    starts2 = starts[:50].copy()
+    wins2 = wins[:50].copy()
+    wins2[::3] = max(1, w // 2)
+    km2 = [reads[r][i:i + k] for r in range(50) for i in range(int(wins2[r]))]
+    f2, r2 = orc.ternaries_bulk("".join(km2).encode(), len(km2), k, True)
+    for h in (dev, only):
+        g2f, g2r = fm.decode_strict(h.query_runs(words, len(seq), starts2, wins2, k, fm.MODE_ALL | fm.STRICT))
+        assert np.array_equal(g2f, f2) and np.array_equal(g2r, r2)
+
+
+def test_super_kmer_dictionary_needs_its_k(fm):
+    """k outside 23..32: FMSI_HIP_ERANGE, and the handle keeps the k-mer dictionary the construction went through."""
+    k = 15
+    ms = synthetic_ms(5000, k, seed=3, mask="ones")
+    dev = fm.DeviceIndex.build(ms.encode(), k)
+    with pytest.raises(fm.FmsiError) as e:
+        dev.enable_dict(superkmer=True)
+    assert e.value.code == fm.E_RANGE
