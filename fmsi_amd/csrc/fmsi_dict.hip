@@ -1225,7 +1225,7 @@ int build_skdict(fmsi_hip_index* idx) {
         SK_TRY(hipMemset(aux_cnt.p, 0, 16));
         hipLaunchKernelGGL((sk_runs_kernel<false>), dim3(static_cast<uint32_t>((waves + 1) / 2)), dim3(128), 0, 0, sk, DictIndex{}, text2, windows,
                            static_cast<uint32_t>(kFlagSelf), nullptr, nullptr, 0ull, windows, windows, posans, aux_keys.as<uint64_t>(), aux_codes.as<uint8_t>(),
-                           aux_cnt.as<unsigned long long>(), cap);
+                           aux_cnt.as<unsigned long long>(), cap, nullptr, nullptr, 0ull);
         SK_TRY(hipGetLastError());
         unsigned long long got[2] = {0, 0};
         SK_TRY(hipMemcpy(got, aux_cnt.p, 16, hipMemcpyDeviceToHost));
@@ -1333,14 +1333,26 @@ bool skdict_applies(const fmsi_hip_index* idx, int k, uint32_t flags) {
 }
 
 int launch_skdict(fmsi_hip_index* idx, const uint64_t* d_seq, uint64_t n, int k, uint32_t flags, uint8_t* o8, unsigned long long* d_counters, hipStream_t s,
-                  const uint64_t* u) {
+                  const uint64_t* u, const uint64_t* h_runs, uint64_t n_runs) {
     (void)k;
+    const uint64_t* d_runs = nullptr;
+    uint64_t uu[3] = {0, 0, 0};
+    if (u) {
+        uu[0] = u[0]; uu[1] = u[1]; uu[2] = u[2];
+    } else {   // the run table: n_runs starts, n_runs + 1 offsets (a slot of the handle's page-locked ring)
+        int rc = ensure_cap(&idx->d_tasks, &idx->d_tasks_cap, (2 * n_runs + 1) * 8);
+        if (rc) return rc;
+        FMSI_HIP_TRY(hipMemcpyAsync(idx->d_tasks, h_runs, (2 * n_runs + 1) * 8, hipMemcpyHostToDevice, s));
+        d_runs = static_cast<const uint64_t*>(idx->d_tasks);
+    }
     const uint64_t waves = (n + 2047) / 2048;
     const dim3 grid(static_cast<uint32_t>((waves + 1) / 2)), block(128);
     if (d_counters)
-        hipLaunchKernelGGL((sk_runs_kernel<true>), grid, block, 0, s, idx->sk, idx->sk_aux, d_seq, n, flags, o8, d_counters, u[0], u[1], u[2], nullptr, nullptr, nullptr, nullptr, 0ull);
+        hipLaunchKernelGGL((sk_runs_kernel<true>), grid, block, 0, s, idx->sk, idx->sk_aux, d_seq, n, flags, o8, d_counters, uu[0], uu[1], uu[2], nullptr, nullptr, nullptr, nullptr, 0ull,
+                           d_runs, d_runs ? d_runs + n_runs : nullptr, n_runs);
     else
-        hipLaunchKernelGGL((sk_runs_kernel<false>), grid, block, 0, s, idx->sk, idx->sk_aux, d_seq, n, flags, o8, d_counters, u[0], u[1], u[2], nullptr, nullptr, nullptr, nullptr, 0ull);
+        hipLaunchKernelGGL((sk_runs_kernel<false>), grid, block, 0, s, idx->sk, idx->sk_aux, d_seq, n, flags, o8, d_counters, uu[0], uu[1], uu[2], nullptr, nullptr, nullptr, nullptr, 0ull,
+                           d_runs, d_runs ? d_runs + n_runs : nullptr, n_runs);
     FMSI_HIP_TRY(hipGetLastError());
     return 0;
 }

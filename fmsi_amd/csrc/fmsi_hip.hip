@@ -995,8 +995,8 @@ int fmsi_hip_query_runs(fmsi_hip_index* idx, const uint64_t* packed_seq, uint64_
     const uint64_t uniform_runs[3] = {run_start[0], stride, wpr};
     const bool fn_mode = (flags & kModeFn) != 0;   // a demasking function: fmsi_hip_query_runs_fn (fmsi_fn.hip)
     flags &= ~kModeFn;
-    const bool via_sk = !fn_mode && uniform && skdict_applies(idx, k, flags) && n_windows <= (1ull << 38);
-    const bool table_free = via_sk || (!fn_mode && uniform && dict_applies(idx, k, flags) && n_windows <= (1ull << 38));
+    const bool via_sk = !fn_mode && skdict_applies(idx, k, flags) && n_windows <= (1ull << 38);   // (reads of any lengths)
+    const bool table_free = uniform && (via_sk || (!fn_mode && dict_applies(idx, k, flags) && n_windows <= (1ull << 38)));
     // otherwise: [0, n_runs): run starts, [n_runs, 2 n_runs + 1): exclusive prefix sums of the run lengths -- in a page-locked slot
     // of the handle's ring, so that nothing has to wait for the copy (the call stays asynchronous on `stream`)
     void* meta_host = nullptr;
@@ -1035,7 +1035,8 @@ int fmsi_hip_query_runs(fmsi_hip_index* idx, const uint64_t* packed_seq, uint64_
     if (via_sk) {   // reads of one length through the super-k-mer dictionary: a bucket read per minimizer
         size_t slot;
         if ((rc = prof_begin(idx, s, &slot))) return rc;
-        if ((rc = launch_skdict(idx, d_seq, n_windows, k, flags, static_cast<uint8_t*>(d_out), d_cnt, s, uniform_runs))) return rc;
+        if ((rc = launch_skdict(idx, d_seq, n_windows, k, flags, static_cast<uint8_t*>(d_out), d_cnt, s, table_free ? uniform_runs : nullptr, meta, n_runs))) return rc;
+        if (!table_free && (rc = meta_commit(idx, meta_slot, s))) return rc;
         if ((rc = prof_end(idx, s, slot))) return rc;
         if (!dev_ptrs) {
             if (out_bytes) FMSI_HIP_TRY(hipMemcpyAsync(out, idx->d_out, out_bytes, hipMemcpyDeviceToHost, s));

@@ -366,7 +366,8 @@ def test_super_kmer_dictionary(fm, oracle_built, read_len, k, mask, shape):
         assert int(cn[6]) == len(kmers)
         if w >= 64 and shape == "random":
             assert int(cn[4]) < 0.4 * len(kmers)          # far fewer bucket reads than windows
-    # isolated k-mers and ragged runs do not take the records -- with the k-mer dictionary gone they take the index's own search
+    # isolated k-mers do not take the records -- with the k-mer dictionary gone they take the index's own search; runs of differing
+    # lengths do (the run table instead of three numbers)
     km = kmers[:3000]
     f1, r1 = orc.ternaries_bulk("".join(km).encode(), len(km), k, True)
     g1f, g1r = fm.decode_strict(only.query_kmers(fm.pack_kmers(km, k), k, fm.MODE_ALL | fm.STRICT))
@@ -377,8 +378,10 @@ def test_super_kmer_dictionary(fm, oracle_built, read_len, k, mask, shape):
     km2 = [reads[r][i:i + k] for r in range(50) for i in range(int(wins2[r]))]
     f2, r2 = orc.ternaries_bulk("".join(km2).encode(), len(km2), k, True)
     for h in (dev, only):
-        g2f, g2r = fm.decode_strict(h.query_runs(words, len(seq), starts2, wins2, k, fm.MODE_ALL | fm.STRICT))
+        g2, cn2 = h.query_runs(words, len(seq), starts2, wins2, k, fm.MODE_ALL | fm.STRICT, counters=True)
+        g2f, g2r = fm.decode_strict(g2)
         assert np.array_equal(g2f, f2) and np.array_equal(g2r, r2)
+        assert int(cn2[0]) == 0 and int(cn2[6]) == len(km2)     # no LF step: the records answered
 
 
 def test_super_kmer_dictionary_needs_its_k(fm):

@@ -140,7 +140,7 @@ def test_dictionary_at_human_scale(fm):
     import torch
     n, k = 2_800_000_000, 31
     dev = fm.DeviceIndex.build_synthetic(n, 12345, k).enable_pair_layout()
-    strict = cross_check(fm, dev, k, nq=1 << 22, sample=100_000, or_reference=False, chain=True)
+    strict = cross_check(fm, dev, k, nq=1 << 22, sample=100_000, or_reference=True, chain=True)   # (the sample also through the real reference's query_kmers())
     info = dev.info
     assert info.dict_levels == 2 and info.dict_log2_buckets == 28 and info.dict_keys[0] > 2_799_000_000
     assert info.dict_bytes - info.dict_chain_bytes < 40e9 and 15e9 < info.dict_chain_bytes < 25e9
@@ -160,6 +160,125 @@ def test_dictionary_at_human_scale(fm):
     assert int(cn[4]) < 0.8 * a.size                       # (fewer bucket reads than windows: the chains ran)
     present = (((a & 3) == 2) | (((a >> 2) & 3) == 2)).reshape(n_reads, -1).mean(axis=1)
     assert 0.3 < (present > 0.5).mean() < 0.7 and ((present > 0.02) & (present < 0.5)).sum() == 0    # reads from the text keep ~73 % of their windows
+
+
+def _reads_agree(fm, dev, k, L, n_reads, subst_ppm, flags_a, flags_b, seed=7):
+    """n_reads seeded reads of L bases (half from the text, with substitutions) through fmsi_hip_query_runs under two flag sets: same bytes."""
+    import torch
+    s = torch.cuda.current_stream().cuda_stream
+    d_reads = torch.empty((n_reads * L) // 32 + 2, dtype=torch.int64, device="cuda")
+    dev.synthetic_reads_dev(L, seed, 0, n_reads, d_reads.data_ptr(), subst_ppm, s)
+    torch.cuda.synchronize()
+    packed = d_reads.cpu().numpy().view(np.uint64)
+    starts = np.arange(n_reads, dtype=np.uint64) * np.uint64(L)
+    wins = np.full(n_reads, L - k + 1, dtype=np.uint32)
+    a, cn = dev.query_runs(packed, n_reads * L, starts, wins, k, flags_a, counters=True)
+    b = dev.query_runs(packed, n_reads * L, starts, wins, k, flags_b)
+    assert np.array_equal(a, b)
+    return a, cn
+
+
+def test_mixed_mask_at_human_scale(fm):
+    """The headline size with a NON-max-ones mask (60 % of the positions ON) and repeat families (a fifth of the 2048-base segments are
+    copies of 50 consensus segments at 1 % divergence: thousands of occurrences per k-mer with differing mask bits): OR mode scans the
+    interval (src/fms_index.h:133-142), `-O` takes its first row, STRICT both strands.  Dictionary == two-base LF walk == lock-step LF
+    walk on 4 M seeded k-mers in both modes, the oracle's ternaries and the real reference's printed bits on a sample of the exported
+    index; then the super-k-mer dictionary (the families' minimizers are heavy: the aux dictionary) against the LF walk on reads."""
+    n, k = 2_800_000_000, 31
+    dev = fm.DeviceIndex.build_synthetic(n, 777, k, repeats=(200, 50, 10), mask_permille=600).enable_pair_layout()
+    strict = cross_check(fm, dev, k, nq=1 << 22, sample=100_000, or_reference=True)
+    fo, ro = strict["or"]
+    fa, ra = strict["all"]
+    assert ((fo == 0) | (ro == 0)).mean() > 0.1 and ((fo == 1) | (ro == 1)).mean() > 0.2     # both answers occur among the present
+    assert (fo != fa).sum() + (ro != ra).sum() > 1000                                          # and the modes really differ
+    assert ((fo == -1) == (fa == -1)).all() and ((ro == -1) == (ra == -1)).all()               # absence does not depend on the mode
+    assert ((fa == 1) <= (fo == 1)).all()                                                      # first row ON => some row ON
+    assert dev.info.dict_ambiguous > 100_000     # keys whose `-O` answer the dictionary took from the index's own search
+    dev.enable_dict(superkmer=True)
+    info = dev.info
+    assert info.sk_bytes > 0 and info.sk_heavy_minimizers > 1000 and info.sk_aux_keys > 100_000
+    for mode in (fm.MODE_OR, fm.MODE_ALL):
+        a, cn = _reads_agree(fm, dev, k, 3000, 512, 10000, mode | fm.STRICT, mode | fm.STRICT | fm.NO_PREFIX_TABLE)       # records (+ aux) == LF walk
+        assert int(cn[0]) == 0 and int(cn[4]) < 0.6 * a.size
+        _reads_agree(fm, dev, k, 3000, 512, 10000, mode | fm.STRICT | fm.NO_SUPERKMER, mode | fm.STRICT)                   # == k-mer dictionary
+
+
+def test_adversarial_text_at_1e9_rows(fm):
+    """A text of 10^9 bases that is NOT i.i.d.: megabase homopolymers, tandem repeats of 2..6-base units, a family of 10^5 copies of one
+    300-base consensus at 1 % divergence, on a random background with a 60 % mask -- through the on-device builder (prefix doubling over
+    millions of tied rows), the k-mer dictionary (keys with 10^6 occurrences and mixed mask bits: the index's own search decides), the
+    OR mode's interval scan over intervals of 10^6 rows, and the super-k-mer dictionary (ties in every window of the low-complexity
+    stretches).  All kernels agree strand by strand in both modes on seeded queries AND on k-mers cut from the adversarial stretches and
+    their borders; a sample of both against the oracle and the real reference."""
+    import torch
+    n, k = 1_000_000_000, 31
+    rng = np.random.default_rng(2024)
+    codes = rng.integers(0, 4, size=n, dtype=np.uint8)
+    lut = np.frombuffer(b"ACGT", dtype=np.uint8)
+    regions = []
+
+    def put(at, block):
+        codes[at:at + block.size] = block
+        regions.append((at, block.size))
+
+    put(50_000_000, np.zeros(1_500_000, dtype=np.uint8))                        # poly-A, 1.5 Mb
+    put(150_000_000, np.full(1_000_000, 3, dtype=np.uint8))                     # poly-T (its reverse complement: the two strands meet)
+    put(250_000_000, np.full(700_000, 1, dtype=np.uint8))                       # poly-C
+    at = 300_000_000
+    for unit in ([0, 3], [0, 1, 2], [0, 1, 2, 3], [2, 2, 0, 1, 3], [0, 0, 1, 3, 2, 2]):   # AT, ACG, ACGT (= its own reverse complement), ...
+        put(at, np.tile(np.array(unit, dtype=np.uint8), 500_000 // len(unit)))
+        at += 7_000_000
+    consensus = rng.integers(0, 4, size=300, dtype=np.uint8)
+    fam = np.tile(consensus, 100_000)
+    hits = rng.random(fam.size) < 0.01
+    fam[hits] = rng.integers(0, 4, size=int(hits.sum()), dtype=np.uint8)
+    put(600_000_000, fam)                                                        # 10^5 copies back to back (30 Mb)
+    for c in range(2000):                                                        # ... and 2000 more scattered over the text
+        cp = consensus.copy()
+        cp[rng.integers(0, 300, size=3)] = rng.integers(0, 4, size=3, dtype=np.uint8)
+        codes[700_000_000 + c * 100_000: 700_000_000 + c * 100_000 + 300] = cp
+    on = rng.random(n) < 0.6
+    on[n - (k - 1):] = False
+    ms = lut[codes] + np.where(on, 0, 32).astype(np.uint8)                       # lower case = OFF
+    del on
+    dev = fm.DeviceIndex.build(ms.tobytes(), k).enable_pair_layout()
+    del ms
+    assert int(dev.info.n) == n + 1
+    strict = cross_check(fm, dev, k, nq=1 << 21, sample=50_000, or_reference=True)
+    assert dev.info.dict_ambiguous > 1000
+    # k-mers cut from the adversarial stretches, their borders and the family (both orientations, a few substitutions)
+    picks = []
+    for at, size in regions:
+        for d in (-40, -31, -30, -16, -1, 0, 1, 15, 100, size // 2, size - 32, size - 31, size - 16, size - 1, size):
+            picks.append(at + d)
+        picks += [int(x) for x in rng.integers(at, at + max(1, size - k), size=300)]
+    picks += [700_000_000 + c * 100_000 + int(o) for c in range(0, 2000, 7) for o in (0, 100, 269)]
+    picks = np.array([p for p in picks if 0 <= p <= n - k], dtype=np.int64)
+    win = codes[picks[:, None] + np.arange(k)[None, :]].astype(np.uint64)
+    flip = rng.random(picks.size) < 0.5
+    win[flip] = 3 - win[flip][:, ::-1]
+    sub = rng.random(picks.size) < 0.2
+    win[sub, rng.integers(0, k, size=int(sub.sum()))] = rng.integers(0, 4, size=int(sub.sum()))
+    kmers = (win << (2 * np.arange(k, dtype=np.uint64))[None, :]).sum(axis=1).astype(np.uint64)
+    del codes
+    text = kmers_text(kmers, k)
+    import bench_cpu
+    orc = bench_cpu.oracle_from_index(dev, k, with_klcp=False)
+    for mode_name, mode in (("or", fm.MODE_OR), ("all", fm.MODE_ALL)):
+        of, orr = orc.ternaries_bulk(text, kmers.size, k, mode_name == "all")
+        for kern in (fm.KERNEL_DICT, fm.KERNEL_PAIR | fm.NO_PREFIX_TABLE, fm.KERNEL_LOCKSTEP | fm.NO_PREFIX_TABLE):
+            f, r = fm.decode_strict(dev.query_kmers(kmers, k, mode | fm.STRICT | kern))
+            assert np.array_equal(f, of) and np.array_equal(r, orr), (mode_name, kern)
+        assert (of == 1).sum() > 100 and (of == 0).sum() > 0 and (of == -1).sum() > 100   # (present ON, present OFF, absent all occur)
+    orc.close()
+    # the super-k-mer dictionary on such a text: either it is built (and agrees with the LF walk on reads), or it says why not
+    try:
+        dev.enable_dict(superkmer=True)
+    except fm.FmsiError as e:
+        assert e.code == fm.E_RANGE
+    else:
+        for mode in (fm.MODE_OR, fm.MODE_ALL):
+            _reads_agree(fm, dev, k, 2000, 512, 10000, mode | fm.STRICT, mode | fm.STRICT | fm.NO_PREFIX_TABLE)
 
 
 def test_largest_index_with_32_bit_rows(fm):
