@@ -277,6 +277,8 @@ struct DevBuf {
 
 uint32_t grid_for(uint64_t items, uint32_t threads = 256) { return static_cast<uint32_t>((items + threads - 1) / threads); }
 
+int build_wide_from_device_text(DevBuf& text2, uint64_t len, DevBuf* mask_text, int k, int with_klcp, int device, fmsi_hip_index** out);
+
 // Shared tail of both entry points: text2 (device, zero padded, + mask_text or all-ones) -> device index.
 int build_from_device_text(DevBuf& text2, uint64_t len, DevBuf* mask_text, int k, int with_klcp, int device, int prefix_len,
                            fmsi_hip_index** out) {
@@ -284,10 +286,11 @@ int build_from_device_text(DevBuf& text2, uint64_t len, DevBuf* mask_text, int k
     const uint64_t n = len + 1;
     // (2^32 - 130 is where 32-bit rows end; rocPRIM's radix sort stops a few thousand items earlier -- its launch arithmetic is 32-bit --
     // so the on-device builder does, too.  An index of that size made elsewhere still loads: the loader sorts nothing.)
-    if (len == 0 || len > kMaxSortItems) {
-        set_last_error("superstring length must be in [1, 2^32 - 8192] for the on-device builder");
+    if (len == 0) {
+        set_last_error("empty superstring");
         return FMSI_HIP_ERANGE;
     }
+    if (len > kMaxSortItems || std::getenv("FMSI_HIP_FORCE_WIDE_BUILD")) return build_wide_from_device_text(text2, len, mask_text, k, with_klcp, device, out);
     const uint64_t n_blocks = ((n + kBlockRows - 1) >> kBlockRowsLog2) + 1;
     int rc;
     DevBuf keys_a, keys_b, pos_a, pos_b, temp;
@@ -461,6 +464,330 @@ int build_from_device_text(DevBuf& text2, uint64_t len, DevBuf* mask_text, int k
         fmsi_hip_index_destroy(idx);
         return rc;
     }
+    *out = idx;
+    return 0;
+}
+
+// ---- indexes of 2^32 rows and more (fmsi_wide.hip's handles) built on the device -------------------------------------------------------
+// rocPRIM's radix sort takes fewer than 2^32 items and the builder above keeps suffix positions in 32 bits; beyond that the suffixes are
+// dealt into 16 buckets by their first two bases (a histogram pass and a scatter pass with wave-aggregated cursors), every bucket -- a
+// sixteenth of the text or so -- is sorted by its 29-base keys with 64-bit positions as values, and the buckets in order are the suffix
+// array by 29 bases.  Suffixes that still tie (a handful in a text without long repeats: n^2 / 4^29 pairs) are ordered by comparing
+// their next 29-base keys directly, group by group; a text with tied groups of more than kWideTieCap suffixes is not for this builder
+// (FMSI_HIP_ERANGE: prefix doubling with 64-bit ranks is what it would take).  Rows, blocks and counts as above -- the u32 cumulative
+// counts simply wrap -- plus the table of absolute counts per superblock that query_wide_kernel reads.  No kLCP array, no tables.
+constexpr uint32_t kWideTieCap = 64;
+
+__device__ __forceinline__ uint64_t wide_key(const uint64_t* __restrict__ text2, uint64_t len, uint64_t p) {
+    const uint64_t rem = len - p < kKeyBases ? len - p : kKeyBases;
+    return (to_lex_key(bases_at(text2, p)) & ~63ull) | rem;   // text2 is zero past `len`
+}
+
+__global__ __launch_bounds__(256) void wide_hist_kernel(const uint64_t* __restrict__ text2, uint64_t len, unsigned long long* __restrict__ hist /* 16 buckets + 4 bases */) {
+    __shared__ unsigned long long s_h[20];
+    if (threadIdx.x < 20) s_h[threadIdx.x] = 0;
+    __syncthreads();
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
+    uint32_t loc[20];
+#pragma unroll
+    for (int i = 0; i < 20; ++i) loc[i] = 0;
+    for (uint64_t p = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; p < len; p += stride) {
+        const uint32_t b = static_cast<uint32_t>(wide_key(text2, len, p) >> 60);
+        const uint32_t c = static_cast<uint32_t>(text2[p >> 5] >> (2 * (p & 31))) & 3u;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) loc[i] += (b == static_cast<uint32_t>(i));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) loc[16 + i] += (c == static_cast<uint32_t>(i));
+    }
+#pragma unroll
+    for (int i = 0; i < 20; ++i)
+        if (loc[i]) atomicAdd(&s_h[i], static_cast<unsigned long long>(loc[i]));
+    __syncthreads();
+    if (threadIdx.x < 20 && s_h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], s_h[threadIdx.x]);
+}
+
+// (a launch holds fewer than 2^32 threads: the kernels over all positions / rows are launched in pieces of 2^30, `first` says where a piece starts)
+__global__ __launch_bounds__(256) void wide_scatter_kernel(const uint64_t* __restrict__ text2, uint64_t len, unsigned long long* __restrict__ cursor,
+                                                           uint64_t* __restrict__ keys, uint64_t* __restrict__ pos, uint64_t first_item) {
+    const uint64_t p = first_item + static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    const bool valid = p < len;
+    uint64_t key = 0;
+    uint32_t b = 16;
+    if (valid) {
+        key = wide_key(text2, len, p);
+        b = static_cast<uint32_t>(key >> 60);
+    }
+    uint64_t todo = __ballot(valid);
+    const uint32_t lane = threadIdx.x & 63u;
+    while (todo) {   // one cursor bump per bucket present in the wave
+        const uint32_t first = static_cast<uint32_t>(__ffsll(static_cast<unsigned long long>(todo))) - 1u;
+        const uint32_t b0 = static_cast<uint32_t>(__shfl(static_cast<int>(b), static_cast<int>(first), 64));
+        const uint64_t m = __ballot(valid && b == b0);
+        unsigned long long base = 0;
+        if (lane == first) base = atomicAdd(&cursor[b0], static_cast<unsigned long long>(__popcll(m)));
+        base = static_cast<unsigned long long>(__shfl(static_cast<long long>(base), static_cast<int>(first), 64));
+        if (valid && b == b0) {
+            const uint64_t at = base + __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), 0u));
+            keys[at] = key;
+            pos[at] = p;
+        }
+        todo &= ~m;
+    }
+}
+
+// is suffix p before suffix q, both known to agree on their first `from` bases?  (key by key, the way the sort orders them)
+__device__ __forceinline__ bool wide_suffix_less(const uint64_t* __restrict__ text2, uint64_t len, uint64_t p, uint64_t q, uint64_t from) {
+    for (uint64_t off = from;; off += kKeyBases) {
+        if (p + off >= len || q + off >= len) return p > q;   // the shorter suffix (the later position) first
+        const uint64_t a = wide_key(text2, len, p + off), b = wide_key(text2, len, q + off);
+        if (a != b) return a < b;
+    }
+}
+
+// one thread per head of a group of equal keys: the group's positions in suffix order (insertion sort; groups are tiny)
+__global__ __launch_bounds__(256) void wide_ties_kernel(const uint64_t* __restrict__ keys, uint64_t* __restrict__ sa, uint64_t count, const uint64_t* __restrict__ text2,
+                                                        uint64_t len, unsigned long long* __restrict__ stats /* tied suffixes, groups over the cap */, uint64_t first_item) {
+    const uint64_t i = first_item + static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const uint64_t key = keys[i];
+    if ((i > 0 && keys[i - 1] == key) || i + 1 >= count || keys[i + 1] != key) return;
+    uint64_t g = 2;
+    while (i + g < count && keys[i + g] == key && g <= kWideTieCap) ++g;
+    atomicAdd(&stats[0], static_cast<unsigned long long>(g));
+    if (g > kWideTieCap) {
+        atomicAdd(&stats[1], 1ull);
+        return;
+    }
+    for (uint64_t a = 1; a < g; ++a) {
+        const uint64_t v = sa[i + a];
+        uint64_t b = a;
+        while (b > 0 && wide_suffix_less(text2, len, v, sa[i + b - 1], kKeyBases)) {
+            sa[i + b] = sa[i + b - 1];
+            --b;
+        }
+        sa[i + b] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void emit_rows_wide_kernel(const uint64_t* __restrict__ text2, const uint64_t* __restrict__ mask_text,
+                                                             const uint64_t* __restrict__ sa_sorted, uint64_t len, int k, int all_ones_mask,
+                                                             uint32_t* __restrict__ blocks, U4* __restrict__ block_counts,
+                                                             uint32_t* __restrict__ mask_counts, unsigned long long* __restrict__ dollar_row, uint64_t first_row) {
+    __shared__ uint32_t s_cnt[4][5];
+    const uint64_t n = len + 1;
+    const uint64_t row = first_row + static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    const uint32_t wave_in_block = threadIdx.x >> 6;
+    uint32_t sym = 0, mbit = 0;
+    const bool valid = row < n;
+    if (valid) {
+        const uint64_t s = row == 0 ? len : sa_sorted[row - 1];
+        if (s == 0) *dollar_row = row;                                                          // fms_index.h:414-415
+        else sym = static_cast<uint32_t>(text2[(s - 1) >> 5] >> (2 * ((s - 1) & 31))) & 3u;   // :417
+        if (s != len) {                                                                         // :419-421
+            if (all_ones_mask) mbit = s + static_cast<uint64_t>(k) <= len;
+            else mbit = static_cast<uint32_t>(mask_text[s >> 6] >> (s & 63)) & 1u;
+        }
+    }
+    const uint64_t hi = __ballot(valid && (sym & 2u));
+    const uint64_t lo = __ballot(valid && (sym & 1u));
+    const uint64_t mm = __ballot(valid && mbit);
+    const uint64_t vv = __ballot(valid);
+    if ((threadIdx.x & 63) == 0) {
+        const uint64_t w = row >> 6;
+        if (vv) {
+            uint32_t* blk = blocks + (w >> 1) * kBlockDwords;
+            const uint32_t half = static_cast<uint32_t>(w & 1) * 2;
+            blk[4 + half] = static_cast<uint32_t>(hi);
+            blk[5 + half] = static_cast<uint32_t>(hi >> 32);
+            blk[8 + half] = static_cast<uint32_t>(lo);
+            blk[9 + half] = static_cast<uint32_t>(lo >> 32);
+            blk[12 + half] = static_cast<uint32_t>(mm);
+            blk[13 + half] = static_cast<uint32_t>(mm >> 32);
+        }
+        s_cnt[wave_in_block][0] = __popcll(vv & ~hi & ~lo);
+        s_cnt[wave_in_block][1] = __popcll(vv & ~hi & lo);
+        s_cnt[wave_in_block][2] = __popcll(hi & ~lo);
+        s_cnt[wave_in_block][3] = __popcll(hi & lo);
+        s_cnt[wave_in_block][4] = __popcll(mm);
+    }
+    __syncthreads();
+    if (threadIdx.x < 2) {
+        const uint64_t b = (first_row >> kBlockRowsLog2) + static_cast<uint64_t>(blockIdx.x) * 2 + threadIdx.x;
+        const uint32_t w0 = threadIdx.x * 2, w1 = w0 + 1;
+        block_counts[b] = U4{s_cnt[w0][0] + s_cnt[w1][0], s_cnt[w0][1] + s_cnt[w1][1], s_cnt[w0][2] + s_cnt[w1][2],
+                             s_cnt[w0][3] + s_cnt[w1][3]};
+        mask_counts[b] = s_cnt[w0][4] + s_cnt[w1][4];
+    }
+}
+
+int build_wide_from_device_text(DevBuf& text2, uint64_t len, DevBuf* mask_text, int k, int with_klcp, int device, fmsi_hip_index** out) {
+    TraceRange trace_range("fmsi: build index on device (64-bit rows)");
+    PhaseClock clock{"wide build"};
+    if (with_klcp) {
+        set_last_error("the on-device builder makes no kLCP array for a superstring of more than 2^32 - 8192 bases (64-bit rows: plain search only)");
+        return FMSI_HIP_ERANGE;
+    }
+    if (len > (1ull << 34)) {
+        set_last_error("superstring too long for the on-device builder (2^34 bases)");
+        return FMSI_HIP_ERANGE;
+    }
+    const uint64_t n = len + 1;
+    const uint64_t n_blocks = ((n + kBlockRows - 1) >> kBlockRowsLog2) + 1;
+    int rc;
+    // ---- the suffixes into 16 buckets by their first two bases
+    DevBuf hist, cursor, k0, p0, k1, p1;
+    if ((rc = hist.alloc(20 * 8)) || (rc = cursor.alloc(16 * 8)) || (rc = k0.alloc(len * 8)) || (rc = p0.alloc(len * 8)) || (rc = k1.alloc(len * 8)) ||
+        (rc = p1.alloc(len * 8)))
+        return rc;
+    FMSI_HIP_TRY(hipMemset(hist.p, 0, 20 * 8));
+    hipLaunchKernelGGL(wide_hist_kernel, dim3(256 * 32), dim3(256), 0, 0, text2.as<uint64_t>(), len, hist.as<unsigned long long>());
+    FMSI_HIP_TRY(hipGetLastError());
+    unsigned long long h_hist[20], h_off[17];
+    FMSI_HIP_TRY(hipMemcpy(h_hist, hist.p, 20 * 8, hipMemcpyDeviceToHost));
+    h_off[0] = 0;
+    for (int b = 0; b < 16; ++b) {
+        h_off[b + 1] = h_off[b] + h_hist[b];
+        if (h_hist[b] > kMaxSortItems) {
+            set_last_error("a first-two-bases bucket of the suffixes holds 2^32 items or more: not for this builder");
+            return FMSI_HIP_ERANGE;
+        }
+    }
+    if (h_off[16] != len) {
+        set_last_error("wide builder: the bucket histogram does not add up");
+        return FMSI_HIP_EHIP;
+    }
+    FMSI_HIP_TRY(hipMemcpy(cursor.p, h_off, 16 * 8, hipMemcpyHostToDevice));
+    constexpr uint64_t kPiece = 1ull << 30;
+    for (uint64_t at = 0; at < len; at += kPiece) {
+        const uint64_t cnt = std::min(kPiece, len - at);
+        hipLaunchKernelGGL(wide_scatter_kernel, dim3(static_cast<uint32_t>((cnt + 255) / 256)), dim3(256), 0, 0, text2.as<uint64_t>(), len, cursor.as<unsigned long long>(),
+                           k0.as<uint64_t>(), p0.as<uint64_t>(), at);
+    }
+    FMSI_HIP_TRY(hipGetLastError());
+    clock.mark("suffixes dealt into 16 buckets");
+    // ---- every bucket sorted by its 29-base keys
+    {
+        size_t tb_max = 0;
+        for (int b = 0; b < 16; ++b) {
+            size_t tb = 0;
+            if (h_hist[b]) FMSI_HIP_TRY(rocprim::radix_sort_pairs(nullptr, tb, k0.as<uint64_t>(), k1.as<uint64_t>(), p0.as<uint64_t>(), p1.as<uint64_t>(), static_cast<size_t>(h_hist[b]), 0, 60, 0));
+            tb_max = std::max(tb_max, tb);
+        }
+        DevBuf temp;
+        if ((rc = temp.alloc(tb_max))) return rc;
+        for (int b = 0; b < 16; ++b) {
+            if (!h_hist[b]) continue;
+            size_t tb = tb_max;
+            FMSI_HIP_TRY(rocprim::radix_sort_pairs(temp.p, tb, k0.as<uint64_t>() + h_off[b], k1.as<uint64_t>() + h_off[b], p0.as<uint64_t>() + h_off[b],
+                                                   p1.as<uint64_t>() + h_off[b], static_cast<size_t>(h_hist[b]), 0, 60, 0));
+        }
+        FMSI_HIP_TRY(hipDeviceSynchronize());
+    }
+    (void)dev_free(k0.release());
+    (void)dev_free(p0.release());
+    clock.mark("buckets sorted");
+    // ---- ties
+    {
+        DevBuf stats;
+        if ((rc = stats.alloc(16))) return rc;
+        FMSI_HIP_TRY(hipMemset(stats.p, 0, 16));
+        for (uint64_t at = 0; at < len; at += kPiece) {
+            const uint64_t cnt = std::min(kPiece, len - at);
+            hipLaunchKernelGGL(wide_ties_kernel, dim3(static_cast<uint32_t>((cnt + 255) / 256)), dim3(256), 0, 0, k1.as<uint64_t>(), p1.as<uint64_t>(), len, text2.as<uint64_t>(), len,
+                               stats.as<unsigned long long>(), at);
+        }
+        FMSI_HIP_TRY(hipGetLastError());
+        unsigned long long h_stats[2] = {0, 0};
+        FMSI_HIP_TRY(hipMemcpy(h_stats, stats.p, 16, hipMemcpyDeviceToHost));
+        if (h_stats[1]) {
+            set_last_error("the on-device builder for 2^32 rows and more orders tied suffixes group by group: " + std::to_string(h_stats[1]) +
+                           " groups of more than 64 suffixes that agree on 29 bases (a repetitive text) are beyond it");
+            return FMSI_HIP_ERANGE;
+        }
+    }
+    (void)dev_free(k1.release());
+    clock.mark("ties");
+    // ---- rows -> blocks
+    DevBuf blocks, counts, counts_scanned, mcounts, mrank, dollar, scan_temp;
+    const size_t blocks_bytes = n_blocks * kBlockBytes;
+    if ((rc = blocks.alloc(blocks_bytes)) || (rc = counts.alloc((n_blocks + 1) * sizeof(U4))) || (rc = counts_scanned.alloc((n_blocks + 1) * sizeof(U4))) ||
+        (rc = mcounts.alloc((n_blocks + 1) * 4)) || (rc = mrank.alloc((n_blocks + 2) * 4)) || (rc = dollar.alloc(8)))
+        return rc;
+    FMSI_HIP_TRY(hipMemset(blocks.p, 0, blocks_bytes));
+    FMSI_HIP_TRY(hipMemset(counts.p, 0, (n_blocks + 1) * sizeof(U4)));
+    FMSI_HIP_TRY(hipMemset(mcounts.p, 0, (n_blocks + 1) * 4));
+    for (uint64_t at = 0; at < n; at += kPiece) {   // (kPiece is a multiple of 256 rows = two blocks)
+        const uint64_t cnt = std::min(kPiece, n - at);
+        hipLaunchKernelGGL(emit_rows_wide_kernel, dim3(static_cast<uint32_t>((cnt + 255) / 256)), dim3(256), 0, 0, text2.as<uint64_t>(),
+                           mask_text ? mask_text->as<uint64_t>() : nullptr, p1.as<uint64_t>(), len, k, mask_text ? 0 : 1, blocks.as<uint32_t>(), counts.as<U4>(),
+                           mcounts.as<uint32_t>(), dollar.as<unsigned long long>(), at);
+    }
+    FMSI_HIP_TRY(hipGetLastError());
+    size_t st1 = 0, st2 = 0;
+    FMSI_HIP_TRY(rocprim::exclusive_scan(nullptr, st1, counts.as<U4>(), counts_scanned.as<U4>(), U4{0, 0, 0, 0}, static_cast<size_t>(n_blocks + 1), U4Plus()));
+    FMSI_HIP_TRY(rocprim::exclusive_scan(nullptr, st2, mcounts.as<uint32_t>(), mrank.as<uint32_t>(), 0u, static_cast<size_t>(n_blocks + 1), rocprim::plus<uint32_t>()));
+    if ((rc = scan_temp.alloc(std::max(st1, st2)))) return rc;
+    FMSI_HIP_TRY(rocprim::exclusive_scan(scan_temp.p, st1, counts.as<U4>(), counts_scanned.as<U4>(), U4{0, 0, 0, 0}, static_cast<size_t>(n_blocks + 1), U4Plus()));
+    FMSI_HIP_TRY(rocprim::exclusive_scan(scan_temp.p, st2, mcounts.as<uint32_t>(), mrank.as<uint32_t>(), 0u, static_cast<size_t>(n_blocks + 1), rocprim::plus<uint32_t>()));
+    hipLaunchKernelGGL(scatter_counts_kernel, dim3(grid_for(n_blocks)), dim3(256), 0, 0, counts_scanned.as<U4>(), blocks.as<uint32_t>(), n_blocks);
+    FMSI_HIP_TRY(hipGetLastError());
+    unsigned long long dollar_row = 0;
+    FMSI_HIP_TRY(hipMemcpy(&dollar_row, dollar.p, 8, hipMemcpyDeviceToHost));
+    FMSI_HIP_TRY(hipDeviceSynchronize());
+    (void)dev_free(p1.release());
+    clock.mark("rows -> blocks");
+    // ---- the table of absolute counts per superblock (on the host, from the wrapped counts: fmsi_wide.hip)
+    std::vector<uint64_t> super;
+    {
+        std::vector<uint32_t> h_cnt(n_blocks * 4), h_mrank(n_blocks + 1);
+        FMSI_HIP_TRY(hipMemcpy2D(h_cnt.data(), 16, blocks.p, kBlockBytes, 16, n_blocks, hipMemcpyDeviceToHost));   // dw 0..3 of every block
+        FMSI_HIP_TRY(hipMemcpy(h_mrank.data(), mrank.p, (n_blocks + 1) * 4, hipMemcpyDeviceToHost));
+        const uint32_t sb_log2 = 24;
+        const uint64_t n_super = ((n_blocks - 1) >> sb_log2) + 1;
+        super.assign(n_super * 8, 0);
+        uint64_t run[5] = {0, 0, 0, 0, 0};
+        for (uint64_t b = 0; b < n_blocks; ++b) {
+            if ((b & ((1ull << sb_log2) - 1)) == 0)
+                for (int s5 = 0; s5 < 5; ++s5) super[(b >> sb_log2) * 8 + s5] = run[s5];
+            if (b + 1 < n_blocks) {
+                for (int c4 = 0; c4 < 4; ++c4) run[c4] += static_cast<uint32_t>(h_cnt[(b + 1) * 4 + c4] - h_cnt[b * 4 + c4]);
+                run[4] += static_cast<uint32_t>(h_mrank[b + 1] - h_mrank[b]);
+            }
+        }
+    }
+    auto* idx = new fmsi_hip_index();
+    idx->device = device;
+    idx->n = n;
+    idx->k = k;
+    idx->n_blocks = n_blocks;
+    idx->d_blocks = blocks.release();
+    idx->d_mrank = mrank.release();
+    idx->d_text2 = text2.release();
+    idx->text_len = len;
+    idx->device_bytes = blocks_bytes + (n_blocks + 2) * 4 + ((len >> 5) + 2) * 8 + super.size() * 8;
+    idx->wide = true;
+    if (dev_malloc(&idx->d_super, super.size() * 8) != hipSuccess || hipMemcpy(idx->d_super, super.data(), super.size() * 8, hipMemcpyHostToDevice) != hipSuccess ||
+        dev_malloc(reinterpret_cast<void**>(&idx->d_counters), FMSI_HIP_N_COUNTERS * 8) != hipSuccess) {
+        fmsi_hip_index_destroy(idx);
+        set_last_error("hipMalloc failed");
+        return FMSI_HIP_ENOMEM;
+    }
+    idx->counts64[0] = 1;                                  // counts = {1, #A+1, ...}, fms_index.h:451 (the `$` slot counts as an 'A' row)
+    idx->counts64[1] = h_hist[16] + 1;
+    idx->counts64[2] = idx->counts64[1] + h_hist[17];
+    idx->counts64[3] = idx->counts64[2] + h_hist[18];
+    idx->dollar64 = dollar_row;
+    idx->devw.blocks = static_cast<const uint4*>(idx->d_blocks);
+    idx->devw.mrank = static_cast<const uint32_t*>(idx->d_mrank);
+    idx->devw.super = static_cast<const uint64_t*>(idx->d_super);
+    idx->devw.sb_log2 = 24;
+    idx->devw.n = n;
+    idx->devw.dollar = dollar_row;
+    idx->devw.C0 = idx->counts64[0];
+    idx->devw.C1 = idx->counts64[1];
+    idx->devw.C2 = idx->counts64[2];
+    idx->devw.C3 = idx->counts64[3];
+    clock.mark("superblock table, handle");
     *out = idx;
     return 0;
 }

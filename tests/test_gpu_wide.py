@@ -96,3 +96,87 @@ def test_cli_with_wide_rows(fm, name, kind, mode):
     assert out == golden_out(name, kind, mode)
     rc, out, err = fm.run_cli([*MODES["or_S"][0], "-k", str(k), "-q", str(query_file(name, kind)), index_prefix(name)])
     assert rc == 1 and b"2^32 rows" in err
+
+
+@pytest.mark.parametrize("shape", ["random", "mixed_mask", "small_repeats"])
+def test_wide_builder_equals_the_narrow_one(product_built, oracle_built, monkeypatch, shape):
+    """The on-device builder for superstrings of 2^32 bases and more (suffixes dealt into 16 buckets by their first two bases, a rocPRIM
+    sort per bucket with 64-bit positions, tied suffixes ordered group by group) forced onto small texts (FMSI_HIP_FORCE_WIDE_BUILD): dword
+    for dword the blocks and mask ranks of the 32-bit builder, the same scalars, and -- through query_wide_kernel and its superblock
+    table -- the oracle's answers."""
+    fm = product_built
+    k = 31
+    rng = np.random.default_rng(5)
+    if shape == "small_repeats":
+        base = synthetic_ms(60_000, k, seed=9, mask="mixed")
+        ms = base + base[1000:1400] * 20 + base[5000:5100].upper() * 8 + base[:30_000]     # tied groups of up to a few dozen suffixes
+        ms = ms[: len(ms) - (k - 1)] + ms[len(ms) - (k - 1):].lower()
+    else:
+        ms = synthetic_ms(300_000, k, seed=3, mask="mixed" if shape == "mixed_mask" else "ones")
+    narrow = fm.DeviceIndex.build(ms.encode(), k)
+    monkeypatch.setenv("FMSI_HIP_FORCE_WIDE_BUILD", "1")
+    wide = fm.DeviceIndex.build(ms.encode(), k)
+    monkeypatch.delenv("FMSI_HIP_FORCE_WIDE_BUILD")
+    assert wide.info.rows64 == 1 and narrow.info.rows64 == 0
+    bn, mn = narrow.download_layout()
+    bw, mw = wide.download_layout()
+    assert np.array_equal(bn, bw) and np.array_equal(mn, mw)
+    assert (list(wide.info.counts), wide.info.dollar_position, wide.info.n) == (list(narrow.info.counts), narrow.info.dollar_position, narrow.info.n)
+    orc = oracle_py.Oracle.construct(ms, k, use_klcp=False)
+    check(fm, wide, orc, mixed_kmers(ms, k, 20_000, seed=int(rng.integers(1, 1000))), k)
+    with pytest.raises(fm.FmsiError) as e:     # kLCP arrays are not made for such handles
+        monkeypatch.setenv("FMSI_HIP_FORCE_WIDE_BUILD", "1")
+        fm.DeviceIndex.build(ms.encode(), k, with_klcp=True)
+    assert e.value.code == fm.E_RANGE
+
+
+def test_wide_builder_refuses_repetitive_texts(product_built, monkeypatch):
+    fm = product_built
+    monkeypatch.setenv("FMSI_HIP_FORCE_WIDE_BUILD", "1")
+    ms = ("ACGTTGCA" * 4000) + "acgttgcaacgttgcaacgttgcaacgttg"
+    with pytest.raises(fm.FmsiError) as e:
+        fm.DeviceIndex.build(ms.encode(), 31)
+    assert e.value.code == fm.E_RANGE and "groups" in str(e.value)
+
+
+def test_index_of_more_than_2_to_32_rows(product_built, oracle_built):
+    """A REAL index with 64-bit rows: 4.5 x 10^9 bases generated and indexed on the device (2.25 GB of blocks, three superblocks of 2^31
+    rows), queried by query_wide_kernel: strand by strand in both modes against the oracle on the downloaded planes (2^15 k-mers), present
+    k-mers present and absent ones absent on 2^20 seeded queries, windows through the run entry point, ORDERS against the oracle."""
+    import torch
+    import bench_cpu
+    fm = product_built
+    n, k = 4_500_000_000, 31
+    with fm.builder_chain(0):
+        dev = fm.DeviceIndex.build_synthetic(n, 99, k)
+    info = dev.info
+    assert info.rows64 == 1 and info.n == n + 1 and info.n > (1 << 32)
+    nq = 1 << 20
+    s = torch.cuda.current_stream().cuda_stream
+    d_k = torch.empty(nq, dtype=torch.int64, device="cuda")
+    d_o = torch.empty(nq, dtype=torch.uint8, device="cuda")
+    dev.synthetic_queries_dev(k, 42, 0, nq, d_k.data_ptr(), s)
+    outs = {}
+    for name, mode in (("or", fm.MODE_OR), ("all", fm.MODE_ALL)):
+        dev.query_kmers_dev(d_k.data_ptr(), nq, k, mode | fm.STRICT, d_o.data_ptr(), stream=s)
+        torch.cuda.synchronize()
+        outs[name] = d_o.cpu().numpy().copy()
+    f, r = fm.decode_strict(outs["all"])
+    present = (f == 1) | (r == 1)
+    assert 0.49 < present.mean() < 0.51 and ((f == 0) | (r == 0)).sum() == 0     # max-ones: half the stream is drawn from the text, and ON
+    assert np.array_equal(outs["or"], outs["all"])                                 # (max-ones: the modes agree)
+    sample = 1 << 15
+    kmers = d_k[:sample].cpu().numpy().view(np.uint64)
+    codes = ((kmers[:, None] >> (2 * np.arange(k, dtype=np.uint64))) & np.uint64(3)).astype(np.uint8)
+    text = np.frombuffer(b"ACGT", dtype=np.uint8)[codes].tobytes()
+    orc = bench_cpu.oracle_from_index(dev, k, with_klcp=False)
+    assert orc.n == n + 1
+    for name, mode_all in (("or", False), ("all", True)):
+        of, orr = orc.ternaries_bulk(text, sample, k, mode_all)
+        gf, gr = fm.decode_strict(outs[name][:sample])
+        assert np.array_equal(gf, of) and np.array_equal(gr, orr), name
+    _, _, oo_f, oo_r = orc.ternaries_bulk(text, sample, k, False, orders=True)
+    got = dev.query_kmers(kmers, k, fm.ORDERS | fm.STRICT)
+    assert np.array_equal(got[:, 0], oo_f) and np.array_equal(got[:, 1], oo_r)
+    assert int(oo_f.max()) > (1 << 32) or int(oo_r.max()) > (1 << 32)              # ranks beyond 32 bits really occur
+    orc.close()
