@@ -115,6 +115,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-config-legs", action="store_true", help="skip the `configs` legs (BASELINE configs 2, 3, 4 and the whole process)")
     ap.add_argument("--legs", default="c2,c3,c4,c4sk,e2e", help="which `configs` legs to run")
     ap.add_argument("--leg", default=None, help=argparse.SUPPRESS)          # child mode: one leg, a JSON list on stdout
+    ap.add_argument("--variants", default=None, help="with --leg: only these variants of the leg (comma-separated names), e.g. for a rocprofv3 run of one")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)   # child mode under rocprofv3: the plan's launches, nothing printed
     ap.add_argument("--pmc-plan", default=None, help=argparse.SUPPRESS)
     ap.add_argument("--leg-handle", default=None, help=argparse.SUPPRESS)   # (a PMC child of a leg: which leg's handle it rebuilds)
@@ -157,7 +158,12 @@ def open_ctx(args):
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE {c.world}", file=sys.stderr)
     torch.cuda.set_device(c.local_rank)
     c.dev_t = torch.device("cuda", c.local_rank)
-    c.stream = torch.cuda.current_stream().cuda_stream
+    # The queries run on a stream of their own, not on the legacy default stream: whatever a library puts on stream 0 -- RCCL's gather
+    # does (measured: with the kernels on the default stream every step's gather waited for the NEXT step's kernel, and kernel, gather
+    # and copy ran one after the other: 3.30 instead of 2.95 ms per step) -- orders itself against EVERY blocking stream's work.
+    c.compute_stream = torch.cuda.Stream(device=c.dev_t)
+    torch.cuda.set_stream(c.compute_stream)
+    c.stream = c.compute_stream.cuda_stream
     return c
 
 
@@ -697,6 +703,8 @@ def run_leg(args):
     os.dup2(2, 1)
     name = args.leg
     n, workload, batch, steps, variants = LEG_SPECS[name]
+    if args.variants:
+        variants = [v for v in variants if v[0] in args.variants.split(",")]
     n = int(n)
     args.n, args.batch, args.workload = float(n), batch, workload
     stream_mode = workload == "stream"
@@ -868,6 +876,7 @@ def main():
     elapsed_max = m["elapsed_max"]
     gather_note = m["gather"]
 
+    torch.cuda.synchronize()
     if multi and not bits:   # byte results: gathered after the timed region (the round-1 form)
         parts = [torch.empty_like(d_out) for _ in range(world)] if rank == 0 else None
         dist.gather(d_out, parts, dst=0)

@@ -8,9 +8,11 @@
 // (src/fms_index.h:98-103), get_range_with_pattern() (:117-124), infer_presence() (:126-144), kmer_order_if_present()
 // (:146-156) -- for isolated k-mers and, through the library's window / run expansion, for windows and runs; presence modes,
 // STRICT, ORDERS and FMSI_HIP_OUT_BITS as everywhere.  Not built for such handles: prefix table, pair layout, candidate tables,
-// dictionary, kLCP streaming, k > 32, export and the on-device builder (FMSI_HIP_ERANGE says so).
+// dictionary, kLCP streaming, k > 32 and export (FMSI_HIP_ERANGE says so).  Such handles come from index files (the host path) or from
+// the on-device builder for 64-bit rows (build_index.hip, build_wide_from_device_text: a 4.5 x 10^9-base index is built and queried
+// against the oracle in tests/test_gpu_wide.py).
 // FMSI_HIP_FORCE_ROWS64 (environment, at fmsi_hip_index_create) sends any index through this path with superblocks of 8 blocks,
-// which is how tests/test_gpu_wide.py holds it against the oracle.
+// which is how tests/test_gpu_wide.py holds it against the oracle on the golden indexes.
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>

@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""Condenses tools/profile_round3.sh's rocprofv3 outputs: one CSV row per (run, query kernel) with calls and average duration, next to
+the avg_kernel_ms the bench line / leg reported for the same variant (HIP events inside the library)."""
+import csv
+import glob
+import json
+import os
+import re
+import sys
+
+QUERY = ("dict_lookup_kernel", "dict_chain_kernel", "sk_runs_kernel", "query_stream2_kernel", "query_stream_kernel", "stream_prep_kernel", "stream_compact_kernel",
+         "pack_results_kernel", "query_pair_kernel", "query_lockstep_kernel")
+
+
+def main(out):
+    rows = []
+    bench = {}
+    try:
+        line = json.loads([l for l in open(os.path.join(out, "bench_default.json")) if l.startswith("{")][-1])
+        bench["headline"] = line["roofline"]["avg_kernel_ms"]
+        for leg in line["roofline"].get("lf_path") or []:
+            bench[leg["via"]] = leg["ms"]
+        for c in line.get("configs", []):
+            if c.get("avg_kernel_ms"):
+                bench[c["name"]] = c["avg_kernel_ms"]
+    except (OSError, IndexError, ValueError, KeyError):
+        pass
+    for d in sorted(glob.glob(os.path.join(out, "trace_*"))):
+        if not os.path.isdir(d):
+            continue
+        run = os.path.basename(d)[len("trace_"):]
+        leg_ms = None
+        try:
+            got = json.loads([l for l in open(d + ".json") if l.startswith("[")][-1])
+            leg_ms = got[0].get("avg_kernel_ms")
+        except (OSError, IndexError, ValueError):
+            pass
+        for f in glob.glob(os.path.join(d, "**", "*kernel_stats.csv"), recursive=True):
+            with open(f, newline="") as fh:
+                for r in csv.DictReader(fh):
+                    name = r["Name"]
+                    if not any(q in name for q in QUERY) or "<true" in name:
+                        continue
+                    m = re.search(r"(\w+_kernel(?:<[^(]*>)?)", name)
+                    rows.append({"run": run, "kernel": m.group(1) if m else name[:60], "calls": int(r["Calls"]), "avg_ms": round(float(r["AverageNs"]) / 1e6, 4),
+                                 "total_ms": round(float(r["TotalDurationNs"]) / 1e6, 3), "under_rocprof_hip_events_avg_kernel_ms": leg_ms,
+                                 "bench_line_avg_kernel_ms": bench.get(run)})
+    with open(os.path.join(out, "kernel_stats_summary.csv"), "w", newline="") as fh:
+        w = csv.DictWriter(fh, fieldnames=["run", "kernel", "calls", "avg_ms", "total_ms", "under_rocprof_hip_events_avg_kernel_ms", "bench_line_avg_kernel_ms"])
+        w.writeheader()
+        for r in rows:
+            w.writerow(r)
+    for r in rows:
+        print(r)
+
+
+if __name__ == "__main__":
+    main(sys.argv[1])
