@@ -579,13 +579,16 @@ int launch_query(fmsi_hip_index* idx, const uint64_t* d_kmers, uint64_t n_window
     // FMSI_HIP_OUT_BITS: the one-lane lookup kernel and its stepping kernel pack their results themselves; every other
     // kernel writes its bytes to a scratch buffer that one streaming pass packs (inside the profiled region)
     const bool dict = dict_applies(idx, k, flags);
+    // a handle that keeps the super-k-mer dictionary ALONE answers isolated k-mers from it, too: the 8-byte k-mers are a packed sequence of
+    // one-window reads at a stride of 32 bases (every window finds its own minimizer: a bucket read per k-mer, no LF step)
+    const bool sk_iso = !dict && skdict_applies(idx, k, flags);
     if (kernel == FMSI_HIP_KERNEL_DICT && !dict) {   // (no dictionary for this call: AUTO)
         flags &= ~FMSI_HIP_KERNEL_MASK;
         kernel = FMSI_HIP_KERNEL_AUTO;
     }
-    const bool phased = !dict && (kernel == FMSI_HIP_KERNEL_PHASED || kernel == FMSI_HIP_KERNEL_AUTO) && idx->d_pblocks && use_table;
+    const bool phased = !dict && !sk_iso && (kernel == FMSI_HIP_KERNEL_PHASED || kernel == FMSI_HIP_KERNEL_AUTO) && idx->d_pblocks && use_table;
     const bool want_bits = (flags & FMSI_HIP_OUT_BITS) && !(flags & FMSI_HIP_ORDERS);
-    const bool pack_after = want_bits && !dict && !(phased && phased_packs_bits(idx, k, flags));
+    const bool pack_after = want_bits && !dict && !sk_iso && !(phased && phased_packs_bits(idx, k, flags));
     if (!want_bits || pack_after) flags &= ~FMSI_HIP_OUT_BITS;
     if (want_bits && (reinterpret_cast<uintptr_t>(d_out) & 7u)) {
         set_last_error("FMSI_HIP_OUT_BITS needs an 8-byte aligned output buffer");
@@ -599,6 +602,9 @@ int launch_query(fmsi_hip_index* idx, const uint64_t* d_kmers, uint64_t n_window
     if ((rc = prof_begin(idx, s, &slot))) return rc;
     if (dict) {
         if ((rc = launch_dict_query(idx, d_kmers, n_windows, k, flags, o8, d_counters, s))) return rc;
+    } else if (sk_iso) {
+        const uint64_t one_window_reads[3] = {0, 32, 1};
+        if ((rc = launch_skdict(idx, d_kmers, n_windows, k, flags, o8, d_counters, s, one_window_reads))) return rc;
     } else if (kernel == FMSI_HIP_KERNEL_LOCKSTEP) {
         const uint64_t blocks64 = (n_windows + 255) / 256;
         if (blocks64 > 0x7FFFFFFFull) {

@@ -366,12 +366,16 @@ def test_super_kmer_dictionary(fm, oracle_built, read_len, k, mask, shape):
         assert int(cn[6]) == len(kmers)
         if w >= 64 and shape == "random":
             assert int(cn[4]) < 0.4 * len(kmers)          # far fewer bucket reads than windows
-    # isolated k-mers do not take the records -- with the k-mer dictionary gone they take the index's own search; runs of differing
-    # lengths do (the run table instead of three numbers)
+    # isolated k-mers (when the k-mer dictionary is gone) and runs of differing lengths (the run table instead of three numbers)
     km = kmers[:3000]
     f1, r1 = orc.ternaries_bulk("".join(km).encode(), len(km), k, True)
-    g1f, g1r = fm.decode_strict(only.query_kmers(fm.pack_kmers(km, k), k, fm.MODE_ALL | fm.STRICT))
+    g1, cn1 = only.query_kmers(fm.pack_kmers(km, k), k, fm.MODE_ALL | fm.STRICT, counters=True)
+    g1f, g1r = fm.decode_strict(g1)
     assert np.array_equal(g1f, f1) and np.array_equal(g1r, r1)
+    assert int(cn1[0]) == 0 and int(cn1[6]) == len(km)     # (the records answer isolated k-mers, too: one-window reads, no LF step)
+    assert np.array_equal(fm.unpack_bits(only.query_kmers(fm.pack_kmers(km, k), k, fm.MODE_ALL | fm.OUT_BITS), len(km), 0).astype(bool), np.where(f1 != -1, f1, r1) == 1)
+    g1n = only.query_kmers(fm.pack_kmers(km, k), k, fm.MODE_ALL | fm.STRICT | fm.NO_SUPERKMER)             # ... unless told not to: the index's own search
+    assert np.array_equal(g1n, g1)
     starts2 = starts[:50].copy()
     wins2 = wins[:50].copy()
     wins2[::3] = max(1, w // 2)
