@@ -42,20 +42,34 @@ static_assert(sizeof(TaskRec) == 64, "TaskRec layout");
 
 // Runs -> tasks of <= 64 windows.  Per run the host supplies only its first base, first task and first result index
 // (24 bytes per run; a 10-kb read is 156 tasks); task t belongs to the run r with task_off[r] <= t < task_off[r + 1].
+// (u_wpr != 0: UNIFORM runs -- run r is the u_wpr windows from base u_start0 + r * u_stride, reads of one length back to back -- and there is
+// no table to fetch, to stage on the host or to search)
 __global__ __launch_bounds__(256) void stream_prep_kernel(const uint64_t* __restrict__ seq, const uint64_t* __restrict__ run_start,
                                                           const uint64_t* __restrict__ task_off, const uint64_t* __restrict__ out_off,
-                                                          uint64_t n_runs, uint64_t n_tasks, uint64_t seq_words, TaskRec* __restrict__ rec) {
+                                                          uint64_t n_runs, uint64_t n_tasks, uint64_t seq_words, TaskRec* __restrict__ rec,
+                                                          uint64_t u_start0, uint64_t u_stride, uint64_t u_wpr) {
     const uint64_t t = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     if (t >= n_tasks) return;
-    uint64_t lo = 0, hi = n_runs;   // invariant: task_off[lo] <= t < task_off[hi]
-    while (hi - lo > 1) {
-        const uint64_t mid = (lo + hi) >> 1;
-        if (task_off[mid] <= t) lo = mid;
-        else hi = mid;
+    uint64_t j, run_windows, first_base, first_out;
+    if (u_wpr) {
+        const uint64_t tpr = (u_wpr + kTaskWindows - 1) / kTaskWindows, r = t / tpr;
+        j = t - r * tpr;
+        run_windows = u_wpr;
+        first_base = u_start0 + r * u_stride;
+        first_out = r * u_wpr;
+    } else {
+        uint64_t lo = 0, hi = n_runs;   // invariant: task_off[lo] <= t < task_off[hi]
+        while (hi - lo > 1) {
+            const uint64_t mid = (lo + hi) >> 1;
+            if (task_off[mid] <= t) lo = mid;
+            else hi = mid;
+        }
+        j = t - task_off[lo];
+        run_windows = out_off[lo + 1] - out_off[lo];
+        first_base = run_start[lo];
+        first_out = out_off[lo];
     }
-    const uint64_t j = t - task_off[lo];
-    const uint64_t run_windows = out_off[lo + 1] - out_off[lo];
-    const uint64_t base = run_start[lo] + j * kTaskWindows;
+    const uint64_t base = first_base + j * kTaskWindows;
     const uint64_t w = base >> 5;
     const uint32_t sh = static_cast<uint32_t>(base & 31u) * 2u;
     TaskRec r;
@@ -65,7 +79,7 @@ __global__ __launch_bounds__(256) void stream_prep_kernel(const uint64_t* __rest
         if (sh && w + q + 1 < seq_words) v |= seq[w + q + 1] << (64u - sh);
         r.s[q] = v;
     }
-    r.out = out_off[lo] + j * kTaskWindows;
+    r.out = first_out + j * kTaskWindows;
     r.n = static_cast<uint32_t>(min(static_cast<uint64_t>(kTaskWindows), run_windows - j * kTaskWindows));
     r.pad = 0;
     r.pad2[0] = r.pad2[1] = 0;
@@ -1184,14 +1198,22 @@ extern "C" int fmsi_hip_query_stream(fmsi_hip_index* idx, const uint64_t* packed
     // run_start / run_windows are HOST arrays in every mode (one entry per run); per run the device gets its first base,
     // first task and first result index, and cuts the tasks itself (stream_prep_kernel)
     // (in a page-locked slot of the handle's ring: the call stays asynchronous on `stream`)
+    // UNIFORM runs (equal lengths at one stride: reads of one length laid out back to back) need no table at all: three numbers
+    const uint64_t wpr = run_windows[0], stride = n_runs > 1 ? run_start[1] - run_start[0] : wpr;
+    bool uniform = n_runs == 1 || (run_start[1] > run_start[0] && stride >= wpr);
+    for (uint64_t r = 0; r < n_runs && uniform; ++r)
+        if (run_windows[r] != wpr || (r > 0 && run_start[r] - run_start[r - 1] != stride)) uniform = false;
     void* meta_host = nullptr;
     unsigned meta_slot = 0;
     int rc;
-    if ((rc = meta_stage(idx, (3 * n_runs + 2) * 8, &meta_host, &meta_slot))) return rc;
-    uint64_t* meta = static_cast<uint64_t*>(meta_host);   // [0, R): run_start   [R, 2R]: task_off   [2R + 1, 3R + 1]: out_off
-    const size_t meta_words = 3 * n_runs + 2;
-    uint64_t* h_task_off = meta + n_runs;
-    uint64_t* h_out_off = meta + 2 * n_runs + 1;
+    uint64_t* meta = nullptr;   // [0, R): run_start   [R, 2R]: task_off   [2R + 1, 3R + 1]: out_off
+    const size_t meta_words = uniform ? 0 : 3 * n_runs + 2;
+    if (!uniform) {
+        if ((rc = meta_stage(idx, (3 * n_runs + 2) * 8, &meta_host, &meta_slot))) return rc;
+        meta = static_cast<uint64_t*>(meta_host);
+    }
+    uint64_t* h_task_off = meta ? meta + n_runs : nullptr;
+    uint64_t* h_out_off = meta ? meta + 2 * n_runs + 1 : nullptr;
     uint64_t n_tasks = 0, out_pos = 0;
     for (uint64_t r = 0; r < n_runs; ++r) {
         const uint64_t w = run_windows[r];
@@ -1199,14 +1221,18 @@ extern "C" int fmsi_hip_query_stream(fmsi_hip_index* idx, const uint64_t* packed
             set_last_error("an empty run, or a run of windows that extends past the end of the sequence");
             return FMSI_HIP_EINVAL;
         }
-        meta[r] = run_start[r];
-        h_task_off[r] = n_tasks;
-        h_out_off[r] = out_pos;
+        if (meta) {
+            meta[r] = run_start[r];
+            h_task_off[r] = n_tasks;
+            h_out_off[r] = out_pos;
+        }
         n_tasks += (w + kTaskWindows - 1) / kTaskWindows;
         out_pos += w;
     }
-    h_task_off[n_runs] = n_tasks;
-    h_out_off[n_runs] = out_pos;
+    if (meta) {
+        h_task_off[n_runs] = n_tasks;
+        h_out_off[n_runs] = out_pos;
+    }
     if (out_pos != n_windows) {
         set_last_error("n_windows does not equal the sum of run_windows");
         return FMSI_HIP_EINVAL;
@@ -1234,8 +1260,10 @@ extern "C" int fmsi_hip_query_stream(fmsi_hip_index* idx, const uint64_t* packed
     auto* d_meta = static_cast<uint64_t*>(idx->d_tasks);
     auto* d_rec = reinterpret_cast<TaskRec*>(static_cast<char*>(idx->d_tasks) + meta_bytes);
     auto* d_slots = reinterpret_cast<uint4*>(d_rec + n_tasks);   // one 64-byte line of result bytes per task
-    FMSI_HIP_TRY(hipMemcpyAsync(d_meta, meta, meta_words * 8, hipMemcpyHostToDevice, s));
-    if ((rc = meta_commit(idx, meta_slot, s))) return rc;
+    if (meta) {
+        FMSI_HIP_TRY(hipMemcpyAsync(d_meta, meta, meta_words * 8, hipMemcpyHostToDevice, s));
+        if ((rc = meta_commit(idx, meta_slot, s))) return rc;
+    }
     // FMSI_HIP_OUT_BITS: the compaction writes the bytes to the handle's scratch buffer and one more pass packs them
     PackAfter pack;
     const uint32_t caller_flags = flags;
@@ -1244,7 +1272,7 @@ extern "C" int fmsi_hip_query_stream(fmsi_hip_index* idx, const uint64_t* packed
     size_t slot;
     if ((rc = prof_begin(idx, s, &slot))) return rc;
     hipLaunchKernelGGL(stream_prep_kernel, dim3(static_cast<uint32_t>((n_tasks + 255) / 256)), dim3(256), 0, s, d_seq, d_meta, d_meta + n_runs,
-                       d_meta + 2 * n_runs + 1, n_runs, n_tasks, seq_bases / 32 + 2, d_rec);
+                       d_meta + 2 * n_runs + 1, n_runs, n_tasks, seq_bases / 32 + 2, d_rec, uniform ? run_start[0] : 0ull, uniform ? stride : 0ull, uniform ? wpr : 0ull);
     FMSI_HIP_TRY(hipGetLastError());
     const bool use_table = idx->d_ptable && !(flags & FMSI_HIP_NO_PREFIX_TABLE) && k >= idx->prefix_len;
     long long* o64 = static_cast<long long*>(d_out);

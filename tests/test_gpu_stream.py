@@ -97,6 +97,42 @@ def test_stream_equals_oracle(fm, oracle_built, name):
     run_case(fm, orc, dev, reads, k)
 
 
+@pytest.mark.parametrize("length", [31, 95, 96, 400])
+def test_stream_runs_of_one_length(fm, oracle_built, length):
+    """Reads of ONE length back to back (and one read alone): the library takes these without a run table (three numbers in the
+    kernel's arguments) -- answers must be those of the same reads handed over with a table (reads of two lengths)."""
+    name = "sars_k31"
+    k = DATASETS[name][0]
+    orc = oracle_py.Oracle.load(index_prefix(name))
+    dev = fm.DeviceIndex.from_files(index_prefix(name), use_klcp=True, prefix_len=5)
+    ms = ms_of(name).upper()
+    rng = random.Random(length)
+    reads = []
+    for i in range(70):
+        p = rng.randrange(0, len(ms) - length)
+        r = ms[p:p + length]
+        if i % 3 == 1:
+            r = revcomp(r)
+        if i % 4 == 2:
+            r = "".join(rng.choice("ACGT") if rng.random() < 0.03 else ch for ch in r)
+        reads.append(r)
+    run_case(fm, orc, dev, reads, k, check_orders=length == 95)
+    run_case(fm, orc, dev, reads[:1], k, check_orders=False)
+    # equal runs at a stride with gaps (windows over the junctions left out), against the same call with one run made ragged
+    seq = "".join(reads)
+    words = fm.pack_sequence(seq.encode())
+    wpr = length - k + 1
+    starts = [i * length for i in range(len(reads))]
+    a = dev.query_stream(words, len(seq), starts, [wpr] * len(reads), k, fm.MODE_ALL)
+    if wpr > 1:
+        b = dev.query_stream(words, len(seq), starts, [wpr] * (len(reads) - 1) + [wpr - 1], k, fm.MODE_ALL)
+        assert np.array_equal(a[:-1], b)
+    # runs that overlap: each run is answered as a read of its own
+    half = dev.query_stream(words, len(seq), [0, length // 2 + 1], [wpr, wpr], k, fm.MODE_ALL)
+    one = dev.query_stream(words, len(seq), [length // 2 + 1], [wpr], k, fm.MODE_ALL)
+    assert np.array_equal(half[wpr:], one) and np.array_equal(half[:wpr], a[:wpr])
+
+
 def test_stream_on_repetitive_index(fm, oracle_built, tmp_path):
     """Long runs of set kLCP bits (many rows sharing a (k-1)-mer): the extension crosses 64-bit words and blocks."""
     k = 9
