@@ -1214,7 +1214,7 @@ int build_skdict(fmsi_hip_index* idx) {
     DevMem aux_keys, aux_codes, aux_cnt;
     if ((rc = aux_cnt.alloc(16, "counter"))) return rc;
     uint64_t n_aux = 0;
-    const uint64_t waves = (windows + 2047) / 2048;
+    const uint64_t waves = (windows + kSkChunk - 1) / kSkChunk;
     for (int pass = 0; pass < 2; ++pass) {
         uint64_t cap = 0;
         if (pass == 1) {
@@ -1223,7 +1223,7 @@ int build_skdict(fmsi_hip_index* idx) {
             if ((rc = aux_keys.alloc(cap * 8, "aux keys")) || (rc = aux_codes.alloc(cap, "aux codes"))) return rc;
         }
         SK_TRY(hipMemset(aux_cnt.p, 0, 16));
-        hipLaunchKernelGGL((sk_runs_kernel<false>), dim3(static_cast<uint32_t>((waves + 1) / 2)), dim3(128), 0, 0, sk, DictIndex{}, text2, windows,
+        hipLaunchKernelGGL((sk_runs_kernel<false, true>), dim3(static_cast<uint32_t>((waves + 1) / 2)), dim3(128), 0, 0, sk, DictIndex{}, text2, windows,
                            static_cast<uint32_t>(kFlagSelf), nullptr, nullptr, 0ull, windows, windows, posans, aux_keys.as<uint64_t>(), aux_codes.as<uint8_t>(),
                            aux_cnt.as<unsigned long long>(), cap, nullptr, nullptr, 0ull);
         SK_TRY(hipGetLastError());
@@ -1345,13 +1345,13 @@ int launch_skdict(fmsi_hip_index* idx, const uint64_t* d_seq, uint64_t n, int k,
         FMSI_HIP_TRY(hipMemcpyAsync(idx->d_tasks, h_runs, (2 * n_runs + 1) * 8, hipMemcpyHostToDevice, s));
         d_runs = static_cast<const uint64_t*>(idx->d_tasks);
     }
-    const uint64_t waves = (n + 2047) / 2048;
+    const uint64_t waves = (n + kSkChunk - 1) / kSkChunk;
     const dim3 grid(static_cast<uint32_t>((waves + 1) / 2)), block(128);
     if (d_counters)
-        hipLaunchKernelGGL((sk_runs_kernel<true>), grid, block, 0, s, idx->sk, idx->sk_aux, d_seq, n, flags, o8, d_counters, uu[0], uu[1], uu[2], nullptr, nullptr, nullptr, nullptr, 0ull,
+        hipLaunchKernelGGL((sk_runs_kernel<true, false>), grid, block, 0, s, idx->sk, idx->sk_aux, d_seq, n, flags, o8, d_counters, uu[0], uu[1], uu[2], nullptr, nullptr, nullptr, nullptr, 0ull,
                            d_runs, d_runs ? d_runs + n_runs : nullptr, n_runs);
     else
-        hipLaunchKernelGGL((sk_runs_kernel<false>), grid, block, 0, s, idx->sk, idx->sk_aux, d_seq, n, flags, o8, d_counters, uu[0], uu[1], uu[2], nullptr, nullptr, nullptr, nullptr, 0ull,
+        hipLaunchKernelGGL((sk_runs_kernel<false, false>), grid, block, 0, s, idx->sk, idx->sk_aux, d_seq, n, flags, o8, d_counters, uu[0], uu[1], uu[2], nullptr, nullptr, nullptr, nullptr, 0ull,
                            d_runs, d_runs ? d_runs + n_runs : nullptr, n_runs);
     FMSI_HIP_TRY(hipGetLastError());
     return 0;
