@@ -1225,7 +1225,7 @@ int build_skdict(fmsi_hip_index* idx) {
         SK_TRY(hipMemset(aux_cnt.p, 0, 16));
         hipLaunchKernelGGL((sk_runs_kernel<false, true>), dim3(static_cast<uint32_t>((waves + 1) / 2)), dim3(128), 0, 0, sk, DictIndex{}, text2, windows,
                            static_cast<uint32_t>(kFlagSelf), nullptr, nullptr, 0ull, windows, windows, posans, aux_keys.as<uint64_t>(), aux_codes.as<uint8_t>(),
-                           aux_cnt.as<unsigned long long>(), cap, nullptr, nullptr, 0ull);
+                           aux_cnt.as<unsigned long long>(), cap, nullptr, nullptr, 0ull, (windows + static_cast<uint64_t>(k) - 2ull) >> 5);
         SK_TRY(hipGetLastError());
         unsigned long long got[2] = {0, 0};
         SK_TRY(hipMemcpy(got, aux_cnt.p, 16, hipMemcpyDeviceToHost));
@@ -1332,8 +1332,8 @@ bool skdict_applies(const fmsi_hip_index* idx, int k, uint32_t flags) {
            (kernel == FMSI_HIP_KERNEL_AUTO || kernel == FMSI_HIP_KERNEL_DICT);
 }
 
-int launch_skdict(fmsi_hip_index* idx, const uint64_t* d_seq, uint64_t n, int k, uint32_t flags, uint8_t* o8, unsigned long long* d_counters, hipStream_t s,
-                  const uint64_t* u, const uint64_t* h_runs, uint64_t n_runs) {
+int launch_skdict(fmsi_hip_index* idx, const uint64_t* d_seq, uint64_t seq_words, uint64_t n, int k, uint32_t flags, uint8_t* o8, unsigned long long* d_counters,
+                  hipStream_t s, const uint64_t* u, const uint64_t* h_runs, uint64_t n_runs) {
     (void)k;
     const uint64_t* d_runs = nullptr;
     uint64_t uu[3] = {0, 0, 0};
@@ -1349,10 +1349,10 @@ int launch_skdict(fmsi_hip_index* idx, const uint64_t* d_seq, uint64_t n, int k,
     const dim3 grid(static_cast<uint32_t>((waves + 1) / 2)), block(128);
     if (d_counters)
         hipLaunchKernelGGL((sk_runs_kernel<true, false>), grid, block, 0, s, idx->sk, idx->sk_aux, d_seq, n, flags, o8, d_counters, uu[0], uu[1], uu[2], nullptr, nullptr, nullptr, nullptr, 0ull,
-                           d_runs, d_runs ? d_runs + n_runs : nullptr, n_runs);
+                           d_runs, d_runs ? d_runs + n_runs : nullptr, n_runs, seq_words ? seq_words - 1 : 0);
     else
         hipLaunchKernelGGL((sk_runs_kernel<false, false>), grid, block, 0, s, idx->sk, idx->sk_aux, d_seq, n, flags, o8, d_counters, uu[0], uu[1], uu[2], nullptr, nullptr, nullptr, nullptr, 0ull,
-                           d_runs, d_runs ? d_runs + n_runs : nullptr, n_runs);
+                           d_runs, d_runs ? d_runs + n_runs : nullptr, n_runs, seq_words ? seq_words - 1 : 0);
     FMSI_HIP_TRY(hipGetLastError());
     return 0;
 }

@@ -604,7 +604,7 @@ int launch_query(fmsi_hip_index* idx, const uint64_t* d_kmers, uint64_t n_window
         if ((rc = launch_dict_query(idx, d_kmers, n_windows, k, flags, o8, d_counters, s))) return rc;
     } else if (sk_iso) {
         const uint64_t one_window_reads[3] = {0, 32, 1};
-        if ((rc = launch_skdict(idx, d_kmers, n_windows, k, flags, o8, d_counters, s, one_window_reads))) return rc;
+        if ((rc = launch_skdict(idx, d_kmers, n_windows, n_windows, k, flags, o8, d_counters, s, one_window_reads))) return rc;
     } else if (kernel == FMSI_HIP_KERNEL_LOCKSTEP) {
         const uint64_t blocks64 = (n_windows + 255) / 256;
         if (blocks64 > 0x7FFFFFFFull) {
@@ -1041,7 +1041,7 @@ int fmsi_hip_query_runs(fmsi_hip_index* idx, const uint64_t* packed_seq, uint64_
     if (via_sk) {   // reads of one length through the super-k-mer dictionary: a bucket read per minimizer
         size_t slot;
         if ((rc = prof_begin(idx, s, &slot))) return rc;
-        if ((rc = launch_skdict(idx, d_seq, n_windows, k, flags, static_cast<uint8_t*>(d_out), d_cnt, s, table_free ? uniform_runs : nullptr, meta, n_runs))) return rc;
+        if ((rc = launch_skdict(idx, d_seq, (seq_bases + 31) / 32, n_windows, k, flags, static_cast<uint8_t*>(d_out), d_cnt, s, table_free ? uniform_runs : nullptr, meta, n_runs))) return rc;
         if (!table_free && (rc = meta_commit(idx, meta_slot, s))) return rc;
         if ((rc = prof_end(idx, s, slot))) return rc;
         if (!dev_ptrs) {

@@ -227,9 +227,10 @@ int launch_dict_query(fmsi_hip_index* idx, const uint64_t* d_in, uint64_t n, int
 bool dict_chain_applies(const fmsi_hip_index* idx, int k, uint32_t flags);
 // uniform runs through the super-k-mer dictionary (a bucket read per minimizer, not per window)
 bool skdict_applies(const fmsi_hip_index* idx, int k, uint32_t flags);
-// (uniform_runs, or the host-side run table of launch_dict_query: n_runs starts, then n_runs + 1 offsets)
-int launch_skdict(fmsi_hip_index* idx, const uint64_t* d_seq, uint64_t n, int k, uint32_t flags, uint8_t* o8, unsigned long long* d_counters, hipStream_t s,
-                  const uint64_t* uniform_runs, const uint64_t* h_runs = nullptr, uint64_t n_runs = 0);
+// (uniform_runs, or the host-side run table of launch_dict_query: n_runs starts, then n_runs + 1 offsets; seq_words: the words of d_seq that
+// hold bases -- the kernel reads no further)
+int launch_skdict(fmsi_hip_index* idx, const uint64_t* d_seq, uint64_t seq_words, uint64_t n, int k, uint32_t flags, uint8_t* o8, unsigned long long* d_counters,
+                  hipStream_t s, const uint64_t* uniform_runs, const uint64_t* h_runs = nullptr, uint64_t n_runs = 0);
 int launch_dict_chain(fmsi_hip_index* idx, const uint64_t* d_seq, uint64_t n, int k, uint32_t flags, uint8_t* o8, unsigned long long* d_counters, hipStream_t s,
                       const uint64_t* uniform_runs);
 
