@@ -77,6 +77,7 @@ __device__ __forceinline__ uint4 load16_nt(const uint4* p) {
     return make_uint4(t.x, t.y, t.z, t.w);
 }
 
+constexpr uint32_t kFlagSelfRight = 0x20000000u;   // ... its second pass (skdict.inc: ties to the rightmost minimal m-mer)
 constexpr uint32_t kFlagSelf = 0x40000000u;   // kernel-internal (never part of the ABI's flags): the construction's pass over the text's own k-mers
 
 // 64 hashes, one per lane (`active` lanes only), against one level: eight rounds of eight buckets.  Returns at the OWNING lane the
@@ -1223,10 +1224,16 @@ int build_skdict(fmsi_hip_index* idx) {
             if ((rc = aux_keys.alloc(cap * 8, "aux keys")) || (rc = aux_codes.alloc(cap, "aux codes"))) return rc;
         }
         SK_TRY(hipMemset(aux_cnt.p, 0, 16));
-        hipLaunchKernelGGL((sk_runs_kernel<false, true>), dim3(static_cast<uint32_t>((waves + 1) / 2)), dim3(128), 0, 0, sk, DictIndex{}, text2, windows,
-                           static_cast<uint32_t>(kFlagSelf), nullptr, nullptr, 0ull, windows, windows, posans, aux_keys.as<uint64_t>(), aux_codes.as<uint8_t>(),
-                           aux_cnt.as<unsigned long long>(), cap, nullptr, nullptr, 0ull, (windows + static_cast<uint64_t>(k) - 2ull) >> 5);
-        SK_TRY(hipGetLastError());
+        // twice: a window whose smallest score sits at several m-mers (a repeated m-mer, or two m-mers the 19-bit score does not tell apart) is
+        // looked up under the LEFTMOST of them when it is asked as the text has it and under the RIGHTMOST when the other strand is asked --
+        // two different minimizers, two different buckets, and either may be heavy or overflowed on its own.  (The lists may repeat k-mers:
+        // they are sorted and made unique below.)
+        for (uint32_t side : {0u, kFlagSelfRight}) {
+            hipLaunchKernelGGL((sk_runs_kernel<false, true, false>), dim3(static_cast<uint32_t>((waves + 1) / 2)), dim3(128), 0, 0, sk, DictIndex{}, text2, windows,
+                               static_cast<uint32_t>(kFlagSelf | side), nullptr, nullptr, 0ull, windows, windows, posans, aux_keys.as<uint64_t>(),
+                               aux_codes.as<uint8_t>(), aux_cnt.as<unsigned long long>(), cap, nullptr, nullptr, 0ull, (windows + static_cast<uint64_t>(k) - 2ull) >> 5);
+            SK_TRY(hipGetLastError());
+        }
         unsigned long long got[2] = {0, 0};
         SK_TRY(hipMemcpy(got, aux_cnt.p, 16, hipMemcpyDeviceToHost));
         if (got[1] != 0) {
@@ -1347,12 +1354,18 @@ int launch_skdict(fmsi_hip_index* idx, const uint64_t* d_seq, uint64_t seq_words
     }
     const uint64_t waves = (n + kSkChunk - 1) / kSkChunk;
     const dim3 grid(static_cast<uint32_t>((waves + 1) / 2)), block(128);
-    if (d_counters)
-        hipLaunchKernelGGL((sk_runs_kernel<true, false>), grid, block, 0, s, idx->sk, idx->sk_aux, d_seq, n, flags, o8, d_counters, uu[0], uu[1], uu[2], nullptr, nullptr, nullptr, nullptr, 0ull,
-                           d_runs, d_runs ? d_runs + n_runs : nullptr, n_runs, seq_words ? seq_words - 1 : 0);
-    else
-        hipLaunchKernelGGL((sk_runs_kernel<false, false>), grid, block, 0, s, idx->sk, idx->sk_aux, d_seq, n, flags, o8, d_counters, uu[0], uu[1], uu[2], nullptr, nullptr, nullptr, nullptr, 0ull,
-                           d_runs, d_runs ? d_runs + n_runs : nullptr, n_runs, seq_words ? seq_words - 1 : 0);
+    auto go = [&](auto kernel) {
+        hipLaunchKernelGGL(kernel, grid, block, 0, s, idx->sk, idx->sk_aux, d_seq, n, flags, o8, d_counters, uu[0], uu[1], uu[2], nullptr, nullptr, nullptr, nullptr, 0ull, d_runs,
+                           d_runs ? d_runs + n_runs : nullptr, n_runs, seq_words ? seq_words - 1 : 0);
+    };
+    const bool strict = (flags & FMSI_HIP_STRICT) != 0u;
+    if (d_counters) {
+        if (strict) go(sk_runs_kernel<true, false, true>);
+        else go(sk_runs_kernel<true, false, false>);
+    } else {
+        if (strict) go(sk_runs_kernel<false, false, true>);
+        else go(sk_runs_kernel<false, false, false>);
+    }
     FMSI_HIP_TRY(hipGetLastError());
     return 0;
 }

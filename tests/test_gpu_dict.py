@@ -388,6 +388,31 @@ def test_super_kmer_dictionary(fm, oracle_built, read_len, k, mask, shape):
         assert int(cn2[0]) == 0 and int(cn2[6]) == len(km2)     # no LF step: the records answered
 
 
+def test_super_kmer_dictionary_score_ties(fm):
+    """Two DIFFERENT m-mers of a window can share the smallest (19-bit) score: the window is then filed under the leftmost AND the rightmost
+    of them, and a query of the other strand takes the one the text's own orientation does not -- whose records may be heavy or pushed out
+    of an overflowed bucket on their own.  The construction therefore runs the text through the records twice (ties to the left, ties to
+    the right).  3 x 10^7 windows of seeded 10-kb reads (a few hundred such ties; half the reads reverse-complemented): the super-k-mer
+    dictionary, alone and beside the k-mer dictionary, == the k-mer dictionary, as bytes, STRICT and bit-packed."""
+    import torch
+    n, k, L, n_reads = 50_000_000, 31, 10_000, 3000
+    dev = fm.DeviceIndex.build_synthetic(n, 1234, k).enable_dict(superkmer=True)
+    only = fm.DeviceIndex.build_synthetic(n, 1234, k).enable_dict(superkmer_only=True)
+    s = torch.cuda.current_stream().cuda_stream
+    d_reads = torch.empty((n_reads * L) // 32 + 2, dtype=torch.int64, device="cuda")
+    dev.synthetic_reads_dev(L, 7, 0, n_reads, d_reads.data_ptr(), 10000, s)
+    torch.cuda.synchronize()
+    packed = d_reads.cpu().numpy().view(np.uint64)
+    starts = np.arange(n_reads, dtype=np.uint64) * np.uint64(L)
+    wins = np.full(n_reads, L - k + 1, dtype=np.uint32)
+    for flags in (fm.MODE_OR, fm.MODE_ALL | fm.STRICT, fm.MODE_ALL | fm.OUT_BITS):
+        want = dev.query_runs(packed, n_reads * L, starts, wins, k, flags | fm.NO_SUPERKMER)
+        got, cn = dev.query_runs(packed, n_reads * L, starts, wins, k, flags, counters=True)
+        assert int(cn[0]) == 0 and int(cn[4]) < 0.3 * int(wins.sum())      # (the records answered: a bucket read per ~6 windows)
+        assert np.array_equal(got, want), np.nonzero(got != want)[0][:10]
+        assert np.array_equal(only.query_runs(packed, n_reads * L, starts, wins, k, flags), want)
+
+
 def test_super_kmer_dictionary_needs_its_k(fm):
     """k outside 23..32: FMSI_HIP_ERANGE, and the handle keeps the k-mer dictionary the construction went through."""
     k = 15
