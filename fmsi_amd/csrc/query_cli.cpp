@@ -85,6 +85,7 @@ struct Options {
     uint64_t batch_windows = 1ull << 26;   // bases of query sequence per batch (>= windows)
     unsigned threads = 0;                  // 0 = all CPUs this process may use, at most 16
     bool full_tables = false;              // --tables full: the k-mer dictionary (what bench.py measures); lookup: the 16-deep prefix table
+    bool compact_tables = false;           // --tables compact: the super-k-mer dictionary alone (records filed by minimizer; a third of the dictionary's HBM)
     bool candidate_tables = false;         // --tables candidates: the 16-deep prefix table + candidate tables instead (A/B runs)
     bool tables_given = false;             // (--tables on the command line: no choice by the size of the query file)
     bool background_dict = false;          // --tables background, or a large query file: the dictionary is built beside the first batches
@@ -145,12 +146,14 @@ int usage_query(bool lookup) {
     std::cerr << "  --batch INT  - bases of query sequence per device batch [default: 67108864]" << std::endl;
     std::cerr << "  --threads INT - host threads for packing and formatting [default: available CPUs, at most 16]" << std::endl;
     std::cerr << "  --stats      - print timings to stderr" << std::endl;
-    std::cerr << "  --tables auto|background|full|candidates - device-side accelerators (results unaffected).  auto [default]: a prefix" << std::endl;
+    std::cerr << "  --tables auto|background|full|compact|candidates - device-side accelerators (results unaffected).  auto [default]: a prefix" << std::endl;
     std::cerr << "                 table of up to 14 bases, which keeps the device about level with this program's reader and loads fastest" << std::endl;
     std::cerr << "                 (query files of 8 GB and more get `background`); background: the same, and the k-mer dictionary is built" << std::endl;
     std::cerr << "                 beside the first batches, which the LF walk answers -- every batch after it stands goes to the dictionary;" << std::endl;
     std::cerr << "                 full: the dictionary before the first batch -- one 128-byte read per k-mer, about 13 bytes of HBM per" << std::endl;
-    std::cerr << "                 distinct k-mer, the fastest device path (also for -S); candidates: the 16-base prefix table with" << std::endl;
+    std::cerr << "                 distinct k-mer, the fastest device path for isolated k-mers (also for -S); compact: the super-k-mer" << std::endl;
+    std::cerr << "                 dictionary instead (23 <= k <= 32) -- records filed by minimizer, one read per ~6 windows of a sequence," << std::endl;
+    std::cerr << "                 about 6 bytes of HBM per distinct k-mer, the fastest path for reads; candidates: the 16-base prefix table with" << std::endl;
     std::cerr << "                 candidate tables (up to 180 GB of HBM)" << std::endl;
     std::cerr << std::endl;
     return 1;
@@ -698,6 +701,7 @@ extern "C" int fmsi_cli_query(int argc, char** argv, int output_orders_i) {
         case 1005: opt.threads = static_cast<unsigned>(std::max(1, atoi(optarg))); break;
         case 1006:
             if (std::string(optarg) == "full") opt.full_tables = opt.tables_given = true;
+            else if (std::string(optarg) == "compact") opt.full_tables = opt.compact_tables = opt.tables_given = true;
             else if (std::string(optarg) == "background") opt.background_dict = opt.tables_given = true;
             else if (std::string(optarg) == "candidates") opt.full_tables = opt.candidate_tables = opt.tables_given = true;
             else if (std::string(optarg) != "auto") return usage_query(output_orders);
@@ -873,7 +877,9 @@ extern "C" int fmsi_cli_query(int argc, char** argv, int output_orders_i) {
             return false;
         }
         if (want_dict && !wide) {
-            c.have_dict = fmsi_hip_index_enable_dict(c.dev, 0) == 0;
+            // (compact: 23 <= k <= 32 -- the minimizers are 21 / 23 bases; other k take the k-mer dictionary)
+            const uint32_t form = opt.compact_tables && k >= 23 ? FMSI_HIP_DICT_SUPERKMER_ONLY : 0u;
+            c.have_dict = fmsi_hip_index_enable_dict(c.dev, form) == 0;
             if (!c.have_dict)
                 std::cerr << "WARNING: the k-mer dictionary is off on device " << c.device << " (" << fmsi_hip_last_error() << "); results are unaffected" << std::endl;
         }

@@ -83,7 +83,7 @@ def one_case(fm, tmp_path, seed: int, checker):
         if rng.random() < 0.3:
             opts += ["--threads", str(rng.choice([1, 3, 7]))]
         if rng.random() < 0.4:
-            opts += ["--tables", rng.choice(["full", "candidates", "auto", "background", "background"])]   # (background: the switch to the dictionary falls on any batch)
+            opts += ["--tables", rng.choice(["full", "compact", "candidates", "auto", "background", "background"])]   # (background: the switch to the dictionary falls on any batch)
         if rng.random() < 0.25:
             opts += ["--devices", "0,0"]
         rc, want, err = oracle_py.run_cli(checker, [*mode, "-q", str(q), prefix])

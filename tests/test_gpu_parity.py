@@ -148,11 +148,11 @@ def test_cli_equals_reference_golden(fm, name, kind, mode):
     assert out == golden_out(name, kind, mode)
 
 
-@pytest.mark.parametrize("name,kind,mode,tables", [(*c, t) for c in CASES for t in ("full", "candidates", "background")
-                                                   if c[2] in ("or", "all") or (t in ("full", "background") and c[2] in ("or_S", "all_S"))])
+@pytest.mark.parametrize("name,kind,mode,tables", [(*c, t) for c in CASES for t in ("full", "compact", "candidates", "background")
+                                                   if c[2] in ("or", "all") or (t in ("full", "compact", "background") and c[2] in ("or_S", "all_S"))])
 def test_cli_with_full_tables_equals_reference_golden(fm, name, kind, mode, tables):
     """--tables full (the k-mer dictionary, the configuration bench.py measures; with it `-S` presence queries take the dictionary
-    too) and --tables candidates (16-deep prefix table + candidate tables) change the device path of the presence modes and not
+    too), --tables compact (the super-k-mer dictionary alone where 23 <= k <= 32, the k-mer dictionary elsewhere) and --tables candidates (16-deep prefix table + candidate tables) change the device path of the presence modes and not
     a byte of the output -- incl. the exact replay of the strand predictor from the dictionary's both-strand answers; an unknown
     value is a usage error."""
     k = CLI_DATASETS[name][0]

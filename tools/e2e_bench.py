@@ -38,6 +38,8 @@ MODES = {
     "or_full": ["query", "--tables", "full"],
     "all_full": ["query", "-O", "--tables", "full"],
     "all_S_full": ["query", "-S", "-O", "--tables", "full"],
+    "or_compact": ["query", "--tables", "compact"],       # the super-k-mer dictionary alone
+    "all_S_compact": ["query", "-S", "-O", "--tables", "compact"],
     "or_bg": ["query", "--tables", "background"],
     "all_S_bg": ["query", "-S", "-O", "--tables", "background"],
     "or_2dev": ["query", "--devices", "0,0"],
