@@ -8,7 +8,7 @@
 // (src/fms_index.h:98-103), get_range_with_pattern() (:117-124), infer_presence() (:126-144), kmer_order_if_present()
 // (:146-156) -- for isolated k-mers and, through the library's window / run expansion, for windows and runs; presence modes,
 // STRICT, ORDERS and FMSI_HIP_OUT_BITS as everywhere.  Not built for such handles: prefix table, pair layout, candidate tables,
-// dictionary, kLCP streaming, k > 32 and export (FMSI_HIP_ERANGE says so).  Such handles come from index files (the host path) or from
+// dictionary, kLCP streaming and k > 32 (FMSI_HIP_ERANGE says so); export walks 64-bit rows (fmsi_export.hip, device_fm_wide.h).  Such handles come from index files (the host path) or from
 // the on-device builder for 64-bit rows (build_index.hip, build_wide_from_device_text: a 4.5 x 10^9-base index is built and queried
 // against the oracle in tests/test_gpu_wide.py).
 // FMSI_HIP_FORCE_ROWS64 (environment, at fmsi_hip_index_create) sends any index through this path with superblocks of 8 blocks,
@@ -23,42 +23,11 @@
 #include "common.h"
 #include "device_fm.h"
 #include "index_priv.h"
+#include "device_fm_wide.h"
 
 namespace fmsi {
 
 namespace {
-
-__device__ __forceinline__ uint64_t abs_count(const DevIndexW& ix, uint64_t block, uint32_t slot, uint32_t wrapped) {
-    const uint64_t s = ix.super[(block >> ix.sb_log2) * 8u + slot];
-    return s + static_cast<uint32_t>(wrapped - static_cast<uint32_t>(s));
-}
-
-// one LF step on a non-empty [i, j): update_range, src/fms_index.h:98-103 (the upper boundary through the block of row j - 1)
-__device__ __forceinline__ void lf_step_w(const DevIndexW& ix, uint32_t c, uint64_t& i, uint64_t& j, uint32_t& blocks_read) {
-    const uint64_t bi = i >> kBlockRowsLog2, bj = (j - 1u) >> kBlockRowsLog2;
-    const uint4* pi = ix.blocks + (bi << 2);
-    const uint4* pj = ix.blocks + (bj << 2);
-    const uint4 ci = pi[0], hi = pi[1], li = pi[2];
-    const uint4 cj = pj[0], hj = pj[1], lj = pj[2];
-    blocks_read += 1u + (bj != bi);
-    const uint4 z = make_uint4(0, 0, 0, 0);
-    const uint32_t in_i = rank_in_block(z, hi, li, c, static_cast<uint32_t>(i & (kBlockRows - 1u)));
-    const uint32_t in_j = rank_in_block(z, hj, lj, c, static_cast<uint32_t>(j - (bj << kBlockRowsLog2)));
-    uint64_t ri = abs_count(ix, bi, c, sel4(c, opaque(ci.x), opaque(ci.y), opaque(ci.z), opaque(ci.w))) + in_i;
-    uint64_t rj = abs_count(ix, bj, c, sel4(c, opaque(cj.x), opaque(cj.y), opaque(cj.z), opaque(cj.w))) + in_j;
-    if (c == 0u) {   // the '$' slot is stored as an 'A' and subtracted here (src/fms_index.h:81)
-        ri -= (i > ix.dollar);
-        rj -= (j > ix.dollar);
-    }
-    const uint64_t base = c == 0u ? ix.C0 : (c == 1u ? ix.C1 : (c == 2u ? ix.C2 : ix.C3));
-    i = base + ri;
-    j = base + rj;
-}
-
-__device__ __forceinline__ uint64_t mask_rank_w(const DevIndexW& ix, uint64_t b, uint32_t p) {
-    const uint4 m = ix.blocks[(b << 2) + 3];
-    return abs_count(ix, b, 4u, ix.mrank[b]) + popc_prefix128(m, p);
-}
 
 struct WideCounters {
     uint32_t lf_steps = 0, blocks = 0, probes = 0, searches = 0;

@@ -3,6 +3,8 @@ loads into the same blocks with a table of absolute counts per superblock.  No s
 FMSI_HIP_FORCE_ROWS64 sends the golden indexes -- and a 1.2 M-row one, 1170 superblocks of 8 blocks -- through that
 instantiation: every mode against the oracle, the CLI against the reference's golden output, and the entry points that do not
 exist for such handles refuse with FMSI_HIP_ERANGE instead of answering wrongly."""
+import os
+
 import numpy as np
 import pytest
 
@@ -55,10 +57,11 @@ def test_wide_rows_equal_oracle_on_the_golden_indexes(fm, oracle_built, name):
     check(fm, dev, orc, kmers, k)
     info = dev.info
     assert info.prefix_len == 0 and info.has_klcp == 0
-    for call in (dev.enable_pair_layout, dev.enable_dict, dev.enable_verify, dev.export):
+    for call in (dev.enable_pair_layout, dev.enable_dict, dev.enable_verify):
         with pytest.raises(fm.FmsiError) as e:
             call()
         assert e.value.code == fm.E_RANGE
+    assert dev.export() == ms.encode()        # export_ms() over 64-bit rows: the superstring the index was made of, mask as case
     # windows and runs go through the same kernel
     up = ms.upper()[:3000]
     if len(up) > k + 10:
@@ -85,6 +88,7 @@ def test_wide_rows_across_many_superblocks(fm, oracle_built, tmp_path):
     dev.write_files(str(tmp_path / "w2"))
     for part in ("ac_gt", "ac", "gt", "mask", "misc"):
         assert open(f"{tmp_path}/w.fmsi.{part}", "rb").read() == open(f"{tmp_path}/w2.fmsi.{part}", "rb").read()
+    assert dev.export() == ms.encode()        # (the walk crosses superblocks at every other step)
 
 
 @pytest.mark.parametrize("name,kind,mode", [(n, kind, mode) for n, (k, kinds) in CLI_DATASETS.items() if k <= 32 for kind in kinds[:1]
@@ -96,6 +100,13 @@ def test_cli_with_wide_rows(fm, name, kind, mode):
     assert out == golden_out(name, kind, mode)
     rc, out, err = fm.run_cli([*MODES["or_S"][0], "-k", str(k), "-q", str(query_file(name, kind)), index_prefix(name)])
     assert rc == 1 and b"2^32 rows" in err
+    if mode == "or":     # `fmsi export` walks 64-bit rows, too: the same FASTA as with 32-bit rows (tests/test_gpu_export.py holds that one against the reference)
+        rc, out, err = fm.run_cli(["export", index_prefix(name)])
+        assert rc == 0, err.decode()
+        os.environ.pop("FMSI_HIP_FORCE_ROWS64")
+        rc2, out2, err2 = fm.run_cli(["export", index_prefix(name)])
+        os.environ["FMSI_HIP_FORCE_ROWS64"] = "1"
+        assert rc2 == 0 and out == out2 and out.startswith(b">exported masked superstring\n")
 
 
 @pytest.mark.parametrize("shape", ["random", "mixed_mask", "small_repeats"])
@@ -180,3 +191,21 @@ def test_index_of_more_than_2_to_32_rows(product_built, oracle_built):
     assert np.array_equal(got[:, 0], oo_f) and np.array_equal(got[:, 1], oo_r)
     assert int(oo_f.max()) > (1 << 32) or int(oo_r.max()) > (1 << 32)              # ranks beyond 32 bits really occur
     orc.close()
+    # `fmsi export` of such an index: the LF walk over 64-bit rows gives back the text the generator made -- all of it (max-ones: upper case
+    # but for the last k - 1 positions), compared word by word with fmsi_hip_synthetic_text_word
+    got = np.frombuffer(dev.export(), dtype=np.uint8)
+    assert got.size == n
+    lower = (got & 32) != 0
+    assert not lower[: n - (k - 1)].any() and lower[n - (k - 1):].all()
+    code = np.zeros(256, dtype=np.uint8)
+    code[ord("C")] = code[ord("c")] = 1
+    code[ord("G")] = code[ord("g")] = 2
+    code[ord("T")] = code[ord("t")] = 3
+    lib = fm.lib()
+    rng = np.random.default_rng(5)
+    words = np.unique(np.concatenate([np.arange(0, 4096), (1 << 27) + np.arange(-2048, 2048), rng.integers(0, n // 32 - 1, size=200_000), [n // 32 - 1]]))
+    # (sampled words incl. those around the text's 2^32nd base = word 2^27)
+    pos = words[:, None] * 32 + np.arange(32)
+    have = (code[got[pos]].astype(np.uint64) << (2 * np.arange(32, dtype=np.uint64))).sum(axis=1, dtype=np.uint64)
+    want = np.array([lib.fmsi_hip_synthetic_text_word(99, int(w)) for w in words], dtype=np.uint64)
+    assert np.array_equal(have, want), words[np.nonzero(have != want)[0][:5]]
