@@ -169,9 +169,11 @@ struct U4Plus {
 // rows whose suffix is shorter than k-1 get 0).  One thread per row, one 64-bit ballot per wave.  Kept apart from
 // emit_rows_kernel: fused into it, the compare gave run-to-run differing bits on gfx950 for rows >= 2^16
 // (tests/test_gpu_builder.py::test_klcp_equals_oracle pins this kernel).
-__global__ __launch_bounds__(256) void klcp_kernel(const uint64_t* __restrict__ text2, const uint32_t* __restrict__ sa_sorted,
-                                                   uint64_t len, int k, uint64_t* __restrict__ klcp) {
-    const uint64_t row = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+// (POS: 32- or 64-bit suffix positions; first_row: launches hold fewer than 2^32 threads, the builder for 64-bit rows comes in pieces)
+template <class POS>
+__global__ __launch_bounds__(256) void klcp_kernel(const uint64_t* __restrict__ text2, const POS* __restrict__ sa_sorted,
+                                                   uint64_t len, int k, uint64_t* __restrict__ klcp, uint64_t first_row) {
+    const uint64_t row = first_row + static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     bool kbit = false;
     if (row < len) {
         const uint64_t s = row == 0 ? len : sa_sorted[row - 1];
@@ -401,7 +403,7 @@ int build_from_device_text(DevBuf& text2, uint64_t len, DevBuf* mask_text, int k
                        counts.as<U4>(), mcounts.as<uint32_t>(), dollar.as<uint32_t>());
     FMSI_HIP_TRY(hipGetLastError());
     if (with_klcp) {
-        hipLaunchKernelGGL(klcp_kernel, dim3(emit_grid), dim3(256), 0, 0, text2.as<uint64_t>(), sorted_pos, len, k, klcp.as<uint64_t>());
+        hipLaunchKernelGGL((klcp_kernel<uint32_t>), dim3(emit_grid), dim3(256), 0, 0, text2.as<uint64_t>(), sorted_pos, len, k, klcp.as<uint64_t>(), 0ull);
         FMSI_HIP_TRY(hipGetLastError());
     }
     // exclusive prefix sums over blocks (+1 element: totals)
@@ -623,10 +625,6 @@ __global__ __launch_bounds__(256) void emit_rows_wide_kernel(const uint64_t* __r
 int build_wide_from_device_text(DevBuf& text2, uint64_t len, DevBuf* mask_text, int k, int with_klcp, int device, fmsi_hip_index** out) {
     TraceRange trace_range("fmsi: build index on device (64-bit rows)");
     PhaseClock clock{"wide build"};
-    if (with_klcp) {
-        set_last_error("the on-device builder makes no kLCP array for a superstring of more than 2^32 - 8192 bases (64-bit rows: plain search only)");
-        return FMSI_HIP_ERANGE;
-    }
     if (len > (1ull << 34)) {
         set_last_error("superstring too long for the on-device builder (2^34 bases)");
         return FMSI_HIP_ERANGE;
@@ -708,11 +706,21 @@ int build_wide_from_device_text(DevBuf& text2, uint64_t len, DevBuf* mask_text, 
     (void)dev_free(k1.release());
     clock.mark("ties");
     // ---- rows -> blocks
-    DevBuf blocks, counts, counts_scanned, mcounts, mrank, dollar, scan_temp;
+    DevBuf blocks, counts, counts_scanned, mcounts, mrank, dollar, scan_temp, klcp;
     const size_t blocks_bytes = n_blocks * kBlockBytes;
+    const uint64_t klcp_words = (n + 63) / 64 + 1;
     if ((rc = blocks.alloc(blocks_bytes)) || (rc = counts.alloc((n_blocks + 1) * sizeof(U4))) || (rc = counts_scanned.alloc((n_blocks + 1) * sizeof(U4))) ||
-        (rc = mcounts.alloc((n_blocks + 1) * 4)) || (rc = mrank.alloc((n_blocks + 2) * 4)) || (rc = dollar.alloc(8)))
+        (rc = mcounts.alloc((n_blocks + 1) * 4)) || (rc = mrank.alloc((n_blocks + 2) * 4)) || (rc = dollar.alloc(8)) || (with_klcp && (rc = klcp.alloc(klcp_words * 8))))
         return rc;
+    if (with_klcp) {   // the kLCP array (what `fmsi index` writes as .klcp; this handle's own search does not read it)
+        FMSI_HIP_TRY(hipMemset(klcp.p, 0, klcp_words * 8));
+        for (uint64_t at = 0; at < n; at += kPiece) {
+            const uint64_t cnt = std::min(kPiece, n - at);
+            hipLaunchKernelGGL((klcp_kernel<uint64_t>), dim3(static_cast<uint32_t>((cnt + 255) / 256)), dim3(256), 0, 0, text2.as<uint64_t>(), p1.as<uint64_t>(), len, k,
+                               klcp.as<uint64_t>(), at);
+        }
+        FMSI_HIP_TRY(hipGetLastError());
+    }
     FMSI_HIP_TRY(hipMemset(blocks.p, 0, blocks_bytes));
     FMSI_HIP_TRY(hipMemset(counts.p, 0, (n_blocks + 1) * sizeof(U4)));
     FMSI_HIP_TRY(hipMemset(mcounts.p, 0, (n_blocks + 1) * 4));
@@ -766,6 +774,11 @@ int build_wide_from_device_text(DevBuf& text2, uint64_t len, DevBuf* mask_text, 
     idx->text_len = len;
     idx->device_bytes = blocks_bytes + (n_blocks + 2) * 4 + ((len >> 5) + 2) * 8 + super.size() * 8;
     idx->wide = true;
+    if (with_klcp) {
+        idx->d_klcp = klcp.release();
+        idx->has_klcp = 1;
+        idx->device_bytes += klcp_words * 8;
+    }
     if (dev_malloc(&idx->d_super, super.size() * 8) != hipSuccess || hipMemcpy(idx->d_super, super.data(), super.size() * 8, hipMemcpyHostToDevice) != hipSuccess ||
         dev_malloc(reinterpret_cast<void**>(&idx->d_counters), FMSI_HIP_N_COUNTERS * 8) != hipSuccess) {
         fmsi_hip_index_destroy(idx);

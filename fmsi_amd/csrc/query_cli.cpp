@@ -871,8 +871,10 @@ extern "C" int fmsi_cli_query(int argc, char** argv, int output_orders_i) {
         fmsi_hip_index_info info;
         const bool wide = fmsi_hip_index_get_info(c.dev, &info) == 0 && info.rows64 != 0;
         if (first) rows64 = wide;
-        if (wide && (load_klcp || k > 32 || general)) {   // 2^32 rows and more: the plain search only (include/fmsi_hip.h)
-            c.error = "-S and k > 32 are not available on the GPU path for indexes of 2^32 rows or more.";
+        // 2^32 rows and more: the plain search only (include/fmsi_hip.h).  -S needs nothing else -- the kLCP array is a short cut of the
+        // reference's, the answers are the plain search's (and the record loop's strand bookkeeping is replayed on the host as always)
+        if (wide && (k > 32 || general)) {
+            c.error = "k > 32 is not available on the GPU path for indexes of 2^32 rows or more.";
             if (general) c.error = "-f with a general function is not available on the GPU path for indexes of 2^32 rows or more.";
             return false;
         }
@@ -1073,7 +1075,7 @@ extern "C" int fmsi_cli_query(int argc, char** argv, int output_orders_i) {
                             check(fmsi_hip_query_runs_fn(cp->dev, P->packed.data(), P->lower.empty() ? nullptr : P->lower.data(), P->bases, P->run_start.data(), P->run_windows.data(), P->run_start.size(), nw, k,
                                                          opt.fn, opt.fn_r, opt.fn_s, FMSI_HIP_OUT_BITS, dst, nullptr, nullptr),
                                   "fmsi_hip_query_runs_fn");
-                        else if (opt.has_klcp && !cp->have_dict && !bg_dict)   // -S: kLCP streaming kernel (query_kmers_streaming, src/fms_index.h:181-254)
+                        else if (opt.has_klcp && !cp->have_dict && !bg_dict && !rows64)   // -S: kLCP streaming kernel (query_kmers_streaming, src/fms_index.h:181-254)
                             check(fmsi_hip_query_stream(handle, P->packed.data(), P->bases, P->run_start.data(), P->run_windows.data(),
                                                         P->run_start.size(), nw, k, flags, dst, nullptr, nullptr),
                                   "fmsi_hip_query_stream");

@@ -128,7 +128,8 @@ typedef struct {
     uint32_t dict_levels, dict_log2_buckets;   /* levels in use; log2 of level 0's bucket count */
     uint64_t dict_chain_bytes;  /* 0, or the bytes of the chained lookups' extras (FMSI_HIP_DICT_CHAIN; included in dict_bytes) */
     uint64_t rows64;            /* 1: the handle keeps 64-bit rows (n >= 2^32 - 128; src/fms_index.h:98-103 uses size_t): plain search only --
-                                   no prefix table, pair layout, candidate tables, dictionary, kLCP streaming, k > 32 (FMSI_HIP_ERANGE); export works;
+                                   no prefix table, pair layout, candidate tables, dictionary, kLCP streaming, k > 32 (FMSI_HIP_ERANGE); export works, and the
+                                   CLI serves -S by the plain search (same answers);
                                    loaded from files or built on the device (fmsi_hip_index_build*, len > 2^32 - 8192) */
     uint64_t sk_bytes;          /* 0 = no super-k-mer dictionary (FMSI_HIP_DICT_SUPERKMER), else its HBM footprint incl. the aux dictionary */
     uint64_t sk_records, sk_heavy_minimizers, sk_overflowed_buckets, sk_aux_keys;
@@ -161,7 +162,7 @@ int fmsi_hip_index_load(const char* prefix, int use_klcp, int device, int prefix
  * src/main.cpp:223-226).  len > 2^32 - 8192 (where the device sort of the 32-bit builder ends, a little before 32-bit rows do): the builder
  * for 64-bit rows -- suffixes dealt into 16 buckets by their first two bases, a sort per bucket with 64-bit positions, tied suffixes ordered
  * group by group (a text with groups of more than 64 suffixes that agree on 29 bases: FMSI_HIP_ERANGE) -- and a handle with rows64 = 1;
- * no kLCP array for such a handle (with_klcp: FMSI_HIP_ERANGE). */
+ * with_klcp gives it the kLCP array, too (what `fmsi index` writes as .klcp; the handle's own search does not read it). */
 int fmsi_hip_index_build(const char* ms, uint64_t len, int k, int with_klcp, int device, int prefix_len, fmsi_hip_index** out);
 
 /* Synthetic workloads (no network on the GPU box, so no real genomes): the superstring is

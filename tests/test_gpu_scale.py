@@ -287,8 +287,6 @@ def test_largest_index_with_32_bit_rows(fm):
     a sample against the oracle on the downloaded index -- rows, counts, suffix positions and dictionary indices all at the edge of
     what 32 bits hold."""
     length, k = (1 << 32) - 8192, 31
-    with pytest.raises(fm.FmsiError, match="no kLCP array"):     # one base more goes to the builder for 64-bit rows (tests/test_gpu_wide.py), which makes none
-        fm.DeviceIndex.build_synthetic(length + 1, 4242, k, with_klcp=True)
     dev = fm.DeviceIndex.build_synthetic(length, 4242, k, prefix_len=14).enable_pair_layout()
     assert int(dev.info.n) == length + 1 and not int(dev.info.rows64)
     strict = cross_check(fm, dev, k, nq=1 << 20, sample=20_000, or_reference=False)

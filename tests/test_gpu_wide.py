@@ -98,8 +98,13 @@ def test_cli_with_wide_rows(fm, name, kind, mode):
     rc, out, err = fm.run_cli([*MODES[mode][0], "-k", str(k), "-q", str(query_file(name, kind)), index_prefix(name)])
     assert rc == 0, err.decode()
     assert out == golden_out(name, kind, mode)
-    rc, out, err = fm.run_cli([*MODES["or_S"][0], "-k", str(k), "-q", str(query_file(name, kind)), index_prefix(name)])
-    assert rc == 1 and b"2^32 rows" in err
+    # -S on such an index: the kLCP array is the reference's short cut, not another answer -- the plain search over 64-bit rows serves it
+    # (and the record loop's strand bookkeeping is replayed as for any -S run): the reference's -S output
+    s_mode = {"or": "or_S", "all": "all_S", "lookup": "lookup_S"}.get(mode)
+    if s_mode in MODES:
+        rc, out, err = fm.run_cli([*MODES[s_mode][0], "-k", str(k), "-q", str(query_file(name, kind)), index_prefix(name)])
+        assert rc == 0, err.decode()
+        assert out == golden_out(name, kind, s_mode)
     if mode == "or":     # `fmsi export` walks 64-bit rows, too: the same FASTA as with 32-bit rows (tests/test_gpu_export.py holds that one against the reference)
         rc, out, err = fm.run_cli(["export", index_prefix(name)])
         assert rc == 0, err.decode()
@@ -135,10 +140,12 @@ def test_wide_builder_equals_the_narrow_one(product_built, oracle_built, monkeyp
     assert (list(wide.info.counts), wide.info.dollar_position, wide.info.n) == (list(narrow.info.counts), narrow.info.dollar_position, narrow.info.n)
     orc = oracle_py.Oracle.construct(ms, k, use_klcp=False)
     check(fm, wide, orc, mixed_kmers(ms, k, 20_000, seed=int(rng.integers(1, 1000))), k)
-    with pytest.raises(fm.FmsiError) as e:     # kLCP arrays are not made for such handles
-        monkeypatch.setenv("FMSI_HIP_FORCE_WIDE_BUILD", "1")
-        fm.DeviceIndex.build(ms.encode(), k, with_klcp=True)
-    assert e.value.code == fm.E_RANGE
+    # the kLCP array (what `fmsi index` writes as .klcp): bit for bit the 32-bit builder's
+    kn = fm.DeviceIndex.build(ms.encode(), k, with_klcp=True).download_klcp()
+    monkeypatch.setenv("FMSI_HIP_FORCE_WIDE_BUILD", "1")
+    kw = fm.DeviceIndex.build(ms.encode(), k, with_klcp=True)
+    assert kw.info.rows64 == 1 and kw.info.has_klcp == 1
+    assert np.array_equal(kw.download_klcp(), kn)
 
 
 def test_wide_builder_refuses_repetitive_texts(product_built, monkeypatch):
@@ -209,3 +216,64 @@ def test_index_of_more_than_2_to_32_rows(product_built, oracle_built):
     have = (code[got[pos]].astype(np.uint64) << (2 * np.arange(32, dtype=np.uint64))).sum(axis=1, dtype=np.uint64)
     want = np.array([lib.fmsi_hip_synthetic_text_word(99, int(w)) for w in words], dtype=np.uint64)
     assert np.array_equal(have, want), words[np.nonzero(have != want)[0][:5]]
+
+
+def test_cli_index_query_export_beyond_2_to_32_bases(product_built):
+    """The three commands as a user of the reference would chain them, on a masked superstring of 4.32 x 10^9 bases (> 2^32): `fmsi index`
+    (FASTA -> the on-device builder for 64-bit rows -> the reference's files), `fmsi query` on those files (k-mers cut from the text answer
+    their mask bit, random ones 0; with -S, too) and `fmsi export` (the walk over 64-bit rows): the exported FASTA is the input superstring, byte for byte."""
+    import shutil
+    import subprocess
+    fm = product_built
+    n, k = 4_320_000_000, 31
+    d = "/dev/shm/fmsi_wide_cli"
+    shutil.rmtree(d, ignore_errors=True)
+    os.makedirs(d)
+    try:
+        fa, out_fa, q_fa = f"{d}/ms.fa", f"{d}/exported.fa", f"{d}/q.fa"
+        rng = np.random.default_rng(77)
+        lut = np.frombuffer(b"ACGT", dtype=np.uint8)
+        picks = []          # (k-mer, its mask bit) cut from the text while it is written
+        step = 1 << 28
+        with open(fa, "wb") as f:
+            f.write(b">ms\n")
+            for at in range(0, n, step):
+                m = min(step, n - at)
+                chunk = lut[rng.integers(0, 4, size=m, dtype=np.uint8)]
+                off = rng.integers(0, 10, size=m, dtype=np.uint8) >= 7          # 30 % of the k-mers OFF (lower case)
+                if at + m > n - (k - 1):
+                    off[max(0, n - (k - 1) - at):] = True                          # the last k - 1 positions carry no k-mer
+                chunk = chunk | (off.astype(np.uint8) << 5)
+                for p in rng.integers(0, m - k, size=120):
+                    picks.append((bytes(chunk[p:p + k]).upper(), not bool(off[p])))
+                chunk.tofile(f)
+            f.write(b"\n")
+        rc, _, err = fm.run_cli(["index", "-k", str(k), fa])      # (as the reference's default: with the kLCP array)
+        assert rc == 0, err.decode()[-2000:]
+        assert os.path.getsize(fa + ".fmsi.klcp") > n // 8
+        with open(q_fa, "wb") as f:
+            for i, (kmer, _) in enumerate(picks):
+                f.write(b">p%d\n%s\n" % (i, kmer))
+            for i in range(500):
+                f.write(b">r%d\n%s\n" % (i, bytes(lut[rng.integers(0, 4, size=k, dtype=np.uint8)])))
+        rc, out, err = fm.run_cli(["query", "-k", str(k), "-q", q_fa, fa])
+        assert rc == 0, err.decode()[-2000:]
+        answers = [l.split(b"\t")[-1] for l in out.split(b"\n") if l]      # (one line per record: name, tab, one digit per window)
+        assert len(answers) == len(picks) + 500
+        assert [a == b"1" for a in answers[:len(picks)]] == [on for _, on in picks]     # (random text: a k-mer occurs once, on one strand)
+        assert all(a == b"0" for a in answers[len(picks):])
+        rc, out_s, err = fm.run_cli(["query", "-S", "-k", str(k), "-q", q_fa, fa])      # -S on 64-bit rows: the plain search, the same answers
+        assert rc == 0 and out_s == out, err.decode()[-2000:]
+        with open(out_fa, "wb") as f:
+            res = subprocess.run([str(fm.CLI_PATH), "export", fa], stdout=f, stderr=subprocess.PIPE)
+        assert res.returncode == 0, res.stderr.decode()[-2000:]
+        head = b">exported masked superstring\n"
+        assert os.path.getsize(out_fa) == len(head) + n + 1
+        a = np.memmap(fa, dtype=np.uint8, mode="r", offset=4)
+        b = np.memmap(out_fa, dtype=np.uint8, mode="r", offset=len(head))
+        assert open(out_fa, "rb").read(len(head)) == head
+        for at in range(0, n + 1, step):
+            assert np.array_equal(a[at:at + step], b[at:at + step]), at
+        del a, b
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
