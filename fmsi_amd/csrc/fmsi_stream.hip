@@ -1172,7 +1172,9 @@ extern "C" int fmsi_hip_query_stream(fmsi_hip_index* idx, const uint64_t* packed
         set_last_error("null argument");
         return FMSI_HIP_EINVAL;
     }
-    FMSI_HIP_NARROW_ONLY(idx, "kLCP streaming");
+    // 64-bit rows: no kLCP kernel -- and no need for one to ANSWER: the extension is the reference's short cut to the interval a fresh
+    // search finds (src/fms_index.h:106-115), so the plain search over the same runs gives these results, in this order
+    if (idx->wide) return fmsi_hip_query_runs(idx, packed_seq, seq_bases, run_start, run_windows, n_runs, n_windows, k, flags, out, counters, stream);
     if (!idx->d_klcp) {
         set_last_error("streaming queries need an index created with its kLCP array");
         return FMSI_HIP_EINVAL;
