@@ -97,6 +97,59 @@ __global__ __launch_bounds__(256) void stream_compact_kernel(const uint8_t* __re
     if (w < rec[t].n) out[o + w] = slots[(t << 6) + w];
 }
 
+// The same for UNIFORM runs (reads of one length): a run's tasks are neighbours, so its wpr result bytes are ONE contiguous piece of the
+// slots -- slots[r * tpr * 64 ...) -- that goes to out[r * wpr ...): a copy per run, 16 bytes per thread (aligned loads, stores at
+// whatever alignment the run's first window has), instead of a thread per byte and a look at the task's record.
+__global__ __launch_bounds__(256) void stream_compact_uniform_kernel(const uint8_t* __restrict__ slots, uint32_t wpr, uint32_t tpr, uint64_t n_pieces,
+                                                                     uint8_t* __restrict__ out) {
+    const uint64_t g = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (g >= n_pieces) return;
+    const uint32_t ppr = tpr * 4u;   // 16-byte pieces per run
+    const uint64_t r = g / ppr;
+    const uint32_t at = static_cast<uint32_t>(g - r * ppr) * 16u;   // first byte of the piece in its run
+    if (at >= wpr) return;
+    const uint4 v = *reinterpret_cast<const uint4*>(slots + (r * tpr << 6) + at);
+    uint8_t* dst = out + r * wpr + at;
+    if (at + 16u <= wpr) {
+        __builtin_memcpy(dst, &v, 16);
+    } else {
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+        for (uint32_t b = 0; b < wpr - at; ++b) dst[b] = static_cast<uint8_t>(w[b >> 2] >> (8u * (b & 3u)));
+    }
+}
+// ... and with FMSI_HIP_OUT_BITS (one bit per window, no STRICT): a thread per 64-bit word of the output gathers its 64 result bytes -- four
+// 16-byte loads at the run's alignment; byte by byte where the word spans two runs -- and packs their low bits: no pass of bytes in between
+__global__ __launch_bounds__(256) void stream_compact_uniform_bits_kernel(const uint8_t* __restrict__ slots, uint32_t wpr, uint32_t tpr, uint64_t n_windows,
+                                                                          unsigned long long* __restrict__ out) {
+    const uint64_t g = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    const uint64_t q0 = g << 6;
+    if (q0 >= n_windows) return;
+    uint64_t r = q0 / wpr;
+    uint32_t w = static_cast<uint32_t>(q0 - r * wpr);
+    unsigned long long word = 0;
+    if (w + 64u <= wpr && q0 + 64u <= n_windows) {
+        const uint8_t* src = slots + (r * tpr << 6) + w;
+#pragma unroll
+        for (uint32_t d = 0; d < 4; ++d) {
+            uint4 v;
+            __builtin_memcpy(&v, src + 16u * d, 16);
+            const uint64_t lo = (static_cast<uint64_t>(v.y) << 32) | v.x, hi = (static_cast<uint64_t>(v.w) << 32) | v.z;
+            const uint64_t bl = ((lo & 0x0101010101010101ull) * 0x0102040810204080ull) >> 56, bh = ((hi & 0x0101010101010101ull) * 0x0102040810204080ull) >> 56;
+            word |= (bl | (bh << 8)) << (16u * d);
+        }
+    } else {
+        const uint32_t cnt = static_cast<uint32_t>(min(static_cast<uint64_t>(64u), n_windows - q0));
+        for (uint32_t b = 0; b < cnt; ++b) {
+            word |= static_cast<unsigned long long>(slots[(r * tpr << 6) + w] & 1u) << b;
+            if (++w == wpr) {
+                w = 0;
+                ++r;
+            }
+        }
+    }
+    out[g] = word;
+}
+
 enum : uint32_t { SS_IDLE = 0, SS_LOOKUP = 1, SS_LF = 2, SS_HAVE = 3, SS_EXTSCAN = 4, SS_EXTLF = 5 };
 
 struct StreamCounters {
@@ -1302,13 +1355,26 @@ extern "C" int fmsi_hip_query_stream(fmsi_hip_index* idx, const uint64_t* packed
         else launch_stream<false, false, false>(idx, d_rec, n_tasks, k, flags, d_slots, o64, d_cnt, s);
     }
     FMSI_HIP_TRY(hipGetLastError());
-    if (!(flags & FMSI_HIP_ORDERS)) {
+    const uint32_t tpr = uniform ? static_cast<uint32_t>((wpr + kTaskWindows - 1) / kTaskWindows) : 0u;
+    const bool run_wise = uniform && !(flags & FMSI_HIP_ORDERS) && wpr < (1ull << 31);   // (reads of one length: a copy per run)
+    const bool bits_here = run_wise && pack.on && !(caller_flags & FMSI_HIP_STRICT);       // ... straight to the packed words
+    if (bits_here) {
+        const uint64_t words = (n_windows + 63) / 64;
+        hipLaunchKernelGGL(stream_compact_uniform_bits_kernel, dim3(static_cast<uint32_t>((words + 255) / 256)), dim3(256), 0, s,
+                           reinterpret_cast<const uint8_t*>(d_slots), static_cast<uint32_t>(wpr), tpr, n_windows, static_cast<unsigned long long*>(d_out));
+        FMSI_HIP_TRY(hipGetLastError());
+    } else if (run_wise) {
+        const uint64_t pieces = n_tasks * 4;
+        hipLaunchKernelGGL(stream_compact_uniform_kernel, dim3(static_cast<uint32_t>((pieces + 255) / 256)), dim3(256), 0, s,
+                           reinterpret_cast<const uint8_t*>(d_slots), static_cast<uint32_t>(wpr), tpr, pieces, pack.bytes);
+        FMSI_HIP_TRY(hipGetLastError());
+    } else if (!(flags & FMSI_HIP_ORDERS)) {
         const uint64_t threads = n_tasks * 64;
         hipLaunchKernelGGL(stream_compact_kernel, dim3(static_cast<uint32_t>((threads + 255) / 256)), dim3(256), 0, s,
                            reinterpret_cast<const uint8_t*>(d_slots), d_rec, n_tasks, pack.bytes);
         FMSI_HIP_TRY(hipGetLastError());
     }
-    if ((rc = pack.end(n_windows, caller_flags, d_out, s))) return rc;
+    if (!bits_here && (rc = pack.end(n_windows, caller_flags, d_out, s))) return rc;
     if ((rc = prof_end(idx, s, slot))) return rc;
     if (!dev_ptrs) {
         FMSI_HIP_TRY(hipMemcpyAsync(out, idx->d_out, out_bytes, hipMemcpyDeviceToHost, s));
