@@ -800,10 +800,17 @@ __device__ __forceinline__ uint4 result_bytes16(uint64_t p0, uint64_t p1, uint64
     return r;
 }
 
-template <bool COUNT, bool PTABLE>
+// UNI: reads of one length -- run r is the u.wpr windows from base u.start0 + r * u.stride -- are cut into tasks HERE (a division and five
+// 8-byte loads when a lane draws a task) instead of by a preparation pass that writes a 64-byte record per task for this kernel to read.
+struct UniformRuns {
+    const uint64_t* seq;
+    uint64_t seq_words, start0, stride;
+    uint32_t wpr, tpr;
+};
+template <bool COUNT, bool PTABLE, bool UNI>
 __global__ __launch_bounds__(256, 4) void query_stream2_kernel(DevIndex ix, const uint4* __restrict__ sblocks, const uint64_t* __restrict__ klcp,
                                                             const TaskRec* __restrict__ tasks, uint64_t n_tasks, int k, uint32_t flags, uint32_t chunk,
-                                                            uint4* __restrict__ slots, unsigned long long* __restrict__ counters) {
+                                                            uint4* __restrict__ slots, unsigned long long* __restrict__ counters, UniformRuns u) {
     __shared__ uint4 s_line[4][64 * kSPitch];
     const uint32_t ln = threadIdx.x & 63u;
     uint4* my_wave_lines = s_line[threadIdx.x >> 6];
@@ -976,13 +983,28 @@ __global__ __launch_bounds__(256, 4) void query_stream2_kernel(DevIndex ix, cons
             if (m) {
                 const uint64_t cand = next + lanes_below(m);
                 if (want && cand < end) {
-                    const uint4* p = reinterpret_cast<const uint4*>(tasks + cand);
-                    const uint4 r0 = p[0], r1 = p[1], r2 = p[2];
-                    s0 = (static_cast<uint64_t>(r0.y) << 32) | r0.x;
-                    s1 = (static_cast<uint64_t>(r0.w) << 32) | r0.z;
-                    s2 = (static_cast<uint64_t>(r1.y) << 32) | r1.x;
-                    s3 = (static_cast<uint64_t>(r1.w) << 32) | r1.z;
-                    n = r2.z;
+                    if (UNI) {   // (n_tasks < 2^32: the host checks)
+                        const uint32_t r = static_cast<uint32_t>(cand) / u.tpr, j = static_cast<uint32_t>(cand) - r * u.tpr;
+                        const uint64_t base = u.start0 + static_cast<uint64_t>(r) * u.stride + 64ull * j;
+                        const uint64_t w0 = base >> 5;
+                        const uint32_t sh = static_cast<uint32_t>(base & 31u) * 2u;
+                        uint64_t v[5];
+#pragma unroll
+                        for (uint32_t q = 0; q < 5; ++q) v[q] = w0 + q < u.seq_words ? u.seq[w0 + q] : 0ull;   // (never past the caller's buffer)
+                        s0 = v[0] >> sh; s1 = v[1] >> sh; s2 = v[2] >> sh; s3 = v[3] >> sh;
+                        if (sh) {
+                            s0 |= v[1] << (64u - sh); s1 |= v[2] << (64u - sh); s2 |= v[3] << (64u - sh); s3 |= v[4] << (64u - sh);
+                        }
+                        n = min(64u, u.wpr - 64u * j);
+                    } else {
+                        const uint4* p = reinterpret_cast<const uint4*>(tasks + cand);
+                        const uint4 r0 = p[0], r1 = p[1], r2 = p[2];
+                        s0 = (static_cast<uint64_t>(r0.y) << 32) | r0.x;
+                        s1 = (static_cast<uint64_t>(r0.w) << 32) | r0.z;
+                        s2 = (static_cast<uint64_t>(r1.y) << 32) | r1.x;
+                        s3 = (static_cast<uint64_t>(r1.w) << 32) | r1.z;
+                        n = r2.z;
+                    }
                     task_id = cand;
                     pass = 0;
                     cur_rc = false;
@@ -1159,13 +1181,18 @@ __global__ __launch_bounds__(256, 4) void query_stream2_kernel(DevIndex ix, cons
 }
 
 template <bool COUNT, bool PTABLE>
-void launch_stream2(fmsi_hip_index* idx, const TaskRec* recs, uint64_t n_tasks, int k, uint32_t flags, uint4* slots, unsigned long long* d_counters, hipStream_t s) {
+void launch_stream2(fmsi_hip_index* idx, const TaskRec* recs, uint64_t n_tasks, int k, uint32_t flags, uint4* slots, unsigned long long* d_counters, hipStream_t s,
+                    const UniformRuns* uni) {
     uint64_t chunk = n_tasks / (256ull * 32 * 8);
     chunk = std::min<uint64_t>(std::max<uint64_t>(chunk, 64), 1024);
     const uint64_t waves = (n_tasks + chunk - 1) / chunk;
     const uint32_t blocks = static_cast<uint32_t>((waves + 3) / 4);
-    hipLaunchKernelGGL((query_stream2_kernel<COUNT, PTABLE>), dim3(blocks), dim3(256), 0, s, idx->dev, static_cast<const uint4*>(idx->d_sblocks),
-                       static_cast<const uint64_t*>(idx->d_klcp), recs, n_tasks, k, flags, static_cast<uint32_t>(chunk), slots, d_counters);
+    if (uni)
+        hipLaunchKernelGGL((query_stream2_kernel<COUNT, PTABLE, true>), dim3(blocks), dim3(256), 0, s, idx->dev, static_cast<const uint4*>(idx->d_sblocks),
+                           static_cast<const uint64_t*>(idx->d_klcp), recs, n_tasks, k, flags, static_cast<uint32_t>(chunk), slots, d_counters, *uni);
+    else
+        hipLaunchKernelGGL((query_stream2_kernel<COUNT, PTABLE, false>), dim3(blocks), dim3(256), 0, s, idx->dev, static_cast<const uint4*>(idx->d_sblocks),
+                           static_cast<const uint64_t*>(idx->d_klcp), recs, n_tasks, k, flags, static_cast<uint32_t>(chunk), slots, d_counters, UniformRuns{});
 }
 
 template <bool COUNT, bool PTABLE, bool WIDE>
@@ -1326,18 +1353,30 @@ extern "C" int fmsi_hip_query_stream(fmsi_hip_index* idx, const uint64_t* packed
     // the profiling events bracket everything the call runs on the device: prep, the query kernel and the compaction
     size_t slot;
     if ((rc = prof_begin(idx, s, &slot))) return rc;
-    hipLaunchKernelGGL(stream_prep_kernel, dim3(static_cast<uint32_t>((n_tasks + 255) / 256)), dim3(256), 0, s, d_seq, d_meta, d_meta + n_runs,
-                       d_meta + 2 * n_runs + 1, n_runs, n_tasks, seq_bases / 32 + 2, d_rec, uniform ? run_start[0] : 0ull, uniform ? stride : 0ull, uniform ? wpr : 0ull);
-    FMSI_HIP_TRY(hipGetLastError());
+    // (reads of one length through the S-block kernel: it cuts its tasks itself)
+    const bool cut_in_kernel = v2 && uniform && n_tasks < (1ull << 32) && wpr < (1ull << 31);
+    UniformRuns uni{};
+    if (cut_in_kernel) {
+        uni.seq = d_seq;
+        uni.seq_words = seq_bases / 32 + 2;
+        uni.start0 = run_start[0];
+        uni.stride = stride;
+        uni.wpr = static_cast<uint32_t>(wpr);
+        uni.tpr = static_cast<uint32_t>((wpr + kTaskWindows - 1) / kTaskWindows);
+    } else {
+        hipLaunchKernelGGL(stream_prep_kernel, dim3(static_cast<uint32_t>((n_tasks + 255) / 256)), dim3(256), 0, s, d_seq, d_meta, d_meta + n_runs,
+                           d_meta + 2 * n_runs + 1, n_runs, n_tasks, seq_bases / 32 + 2, d_rec, uniform ? run_start[0] : 0ull, uniform ? stride : 0ull, uniform ? wpr : 0ull);
+        FMSI_HIP_TRY(hipGetLastError());
+    }
     const bool use_table = idx->d_ptable && !(flags & FMSI_HIP_NO_PREFIX_TABLE) && k >= idx->prefix_len;
     long long* o64 = static_cast<long long*>(d_out);
     if (v2) {
         if (use_table) {
-            if (d_cnt) launch_stream2<true, true>(idx, d_rec, n_tasks, k, flags, d_slots, d_cnt, s);
-            else launch_stream2<false, true>(idx, d_rec, n_tasks, k, flags, d_slots, d_cnt, s);
+            if (d_cnt) launch_stream2<true, true>(idx, d_rec, n_tasks, k, flags, d_slots, d_cnt, s, cut_in_kernel ? &uni : nullptr);
+            else launch_stream2<false, true>(idx, d_rec, n_tasks, k, flags, d_slots, d_cnt, s, cut_in_kernel ? &uni : nullptr);
         } else {
-            if (d_cnt) launch_stream2<true, false>(idx, d_rec, n_tasks, k, flags, d_slots, d_cnt, s);
-            else launch_stream2<false, false>(idx, d_rec, n_tasks, k, flags, d_slots, d_cnt, s);
+            if (d_cnt) launch_stream2<true, false>(idx, d_rec, n_tasks, k, flags, d_slots, d_cnt, s, cut_in_kernel ? &uni : nullptr);
+            else launch_stream2<false, false>(idx, d_rec, n_tasks, k, flags, d_slots, d_cnt, s, cut_in_kernel ? &uni : nullptr);
         }
     } else if (k > 32) {
         if (use_table) {
