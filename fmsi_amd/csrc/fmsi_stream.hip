@@ -86,15 +86,24 @@ __global__ __launch_bounds__(256) void stream_prep_kernel(const uint64_t* __rest
     rec[t] = r;
 }
 
-// slots[task] (one aligned 64-byte line of result bytes per task) -> the caller's contiguous result array
+// slots[task] (one aligned 64-byte line of result bytes per task) -> the caller's contiguous result array: four threads per task, 16 bytes
+// each (an aligned load, a store at whatever alignment the task's first window has; the tail of a run's last task byte by byte)
 __global__ __launch_bounds__(256) void stream_compact_kernel(const uint8_t* __restrict__ slots, const TaskRec* __restrict__ rec,
                                                              uint64_t n_tasks, uint8_t* __restrict__ out) {
     const uint64_t g = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-    const uint64_t t = g >> 6;
-    const uint32_t w = static_cast<uint32_t>(g & 63u);
+    const uint64_t t = g >> 2;
+    const uint32_t at = static_cast<uint32_t>(g & 3u) * 16u;
     if (t >= n_tasks) return;
-    const uint64_t o = rec[t].out;
-    if (w < rec[t].n) out[o + w] = slots[(t << 6) + w];
+    const uint32_t n = rec[t].n;
+    if (at >= n) return;
+    const uint4 v = *reinterpret_cast<const uint4*>(slots + (t << 6) + at);
+    uint8_t* dst = out + rec[t].out + at;
+    if (at + 16u <= n) {
+        __builtin_memcpy(dst, &v, 16);
+    } else {
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+        for (uint32_t b = 0; b < n - at; ++b) dst[b] = static_cast<uint8_t>(w[b >> 2] >> (8u * (b & 3u)));
+    }
 }
 
 // The same for UNIFORM runs (reads of one length): a run's tasks are neighbours, so its wpr result bytes are ONE contiguous piece of the
@@ -1408,7 +1417,7 @@ extern "C" int fmsi_hip_query_stream(fmsi_hip_index* idx, const uint64_t* packed
                            reinterpret_cast<const uint8_t*>(d_slots), static_cast<uint32_t>(wpr), tpr, pieces, pack.bytes);
         FMSI_HIP_TRY(hipGetLastError());
     } else if (!(flags & FMSI_HIP_ORDERS)) {
-        const uint64_t threads = n_tasks * 64;
+        const uint64_t threads = n_tasks * 4;
         hipLaunchKernelGGL(stream_compact_kernel, dim3(static_cast<uint32_t>((threads + 255) / 256)), dim3(256), 0, s,
                            reinterpret_cast<const uint8_t*>(d_slots), d_rec, n_tasks, pack.bytes);
         FMSI_HIP_TRY(hipGetLastError());
