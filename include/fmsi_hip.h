@@ -275,7 +275,7 @@ int fmsi_hip_query_kmers(fmsi_hip_index* idx, const uint64_t* kmers, uint64_t n_
                          void* out, uint64_t* counters, void* stream);
 
 /* Same, for windows of a 2-bit packed sequence (base p in bits [2(p%32), 2(p%32)+1] of word p/32; the
- * buffer must be readable for one word past the last base).  Window w is the k-mer starting at base
+ * buffer holds seq_bases / 32 + 2 words: the library copies / reads that many, i.e. up to two words past the last base's).  Window w is the k-mer starting at base
  * window_start[w]; window_start == NULL means windows 0 .. n_windows-1 start at bases 0 .. n_windows-1. */
 int fmsi_hip_query_windows(fmsi_hip_index* idx, const uint64_t* packed_seq, uint64_t seq_bases,
                            const uint64_t* window_start, uint64_t n_windows, int k, uint32_t flags,
