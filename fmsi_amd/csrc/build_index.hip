@@ -279,7 +279,7 @@ struct DevBuf {
 
 uint32_t grid_for(uint64_t items, uint32_t threads = 256) { return static_cast<uint32_t>((items + threads - 1) / threads); }
 
-int build_wide_from_device_text(DevBuf& text2, uint64_t len, DevBuf* mask_text, int k, int with_klcp, int device, fmsi_hip_index** out);
+int build_wide_from_device_text(DevBuf& text2, uint64_t len, DevBuf* mask_text, int k, int with_klcp, int device, int prefix_len, fmsi_hip_index** out);
 
 // Shared tail of both entry points: text2 (device, zero padded, + mask_text or all-ones) -> device index.
 int build_from_device_text(DevBuf& text2, uint64_t len, DevBuf* mask_text, int k, int with_klcp, int device, int prefix_len,
@@ -292,7 +292,7 @@ int build_from_device_text(DevBuf& text2, uint64_t len, DevBuf* mask_text, int k
         set_last_error("empty superstring");
         return FMSI_HIP_ERANGE;
     }
-    if (len > kMaxSortItems || std::getenv("FMSI_HIP_FORCE_WIDE_BUILD")) return build_wide_from_device_text(text2, len, mask_text, k, with_klcp, device, out);
+    if (len > kMaxSortItems || std::getenv("FMSI_HIP_FORCE_WIDE_BUILD")) return build_wide_from_device_text(text2, len, mask_text, k, with_klcp, device, prefix_len, out);
     const uint64_t n_blocks = ((n + kBlockRows - 1) >> kBlockRowsLog2) + 1;
     int rc;
     DevBuf keys_a, keys_b, pos_a, pos_b, temp;
@@ -622,7 +622,7 @@ __global__ __launch_bounds__(256) void emit_rows_wide_kernel(const uint64_t* __r
     }
 }
 
-int build_wide_from_device_text(DevBuf& text2, uint64_t len, DevBuf* mask_text, int k, int with_klcp, int device, fmsi_hip_index** out) {
+int build_wide_from_device_text(DevBuf& text2, uint64_t len, DevBuf* mask_text, int k, int with_klcp, int device, int prefix_len, fmsi_hip_index** out) {
     TraceRange trace_range("fmsi: build index on device (64-bit rows)");
     PhaseClock clock{"wide build"};
     if (len > (1ull << 34)) {
@@ -800,7 +800,14 @@ int build_wide_from_device_text(DevBuf& text2, uint64_t len, DevBuf* mask_text, 
     idx->devw.C1 = idx->counts64[1];
     idx->devw.C2 = idx->counts64[2];
     idx->devw.C3 = idx->counts64[3];
+    idx->devw.ptable = nullptr;
+    idx->devw.ptable_len = 0;
     clock.mark("superblock table, handle");
+    if (prefix_len > 0 && (rc = build_prefix_table_wide(idx, prefix_len))) {
+        fmsi_hip_index_destroy(idx);
+        return rc;
+    }
+    clock.mark("prefix table");
     *out = idx;
     return 0;
 }

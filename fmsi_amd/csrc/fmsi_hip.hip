@@ -806,7 +806,10 @@ int fmsi_hip_index_create(const fmsi_index_view* view, int device, fmsi_hip_inde
         idx->devw.C1 = view->counts[1];
         idx->devw.C2 = view->counts[2];
         idx->devw.C3 = view->counts[3];
-        // (no kLCP streaming, no prefix table for such a handle: view->klcp and view->prefix_len are not used)
+        idx->devw.ptable = nullptr;
+        idx->devw.ptable_len = 0;
+        // (no kLCP kernel for such a handle: view->klcp is not used; the prefix table has 16-byte entries and is at most 14 deep)
+        if (view->prefix_len > 0 && (rc = build_prefix_table_wide(idx, view->prefix_len))) return fail(rc);
         *out = idx;
         return 0;
     }

@@ -36,8 +36,9 @@ struct DevIndexW {
     const uint4* blocks;
     const uint32_t* mrank;     // wrapped u32 cumulative mask popcounts
     const uint64_t* super;     // per superblock of 2^sb_log2 blocks: absolute #A #C #G #T #mask before it (+ 3 words of padding)
-    uint32_t sb_log2, pad;
+    uint32_t sb_log2, ptable_len;   // ptable_len: 0 = no prefix table
     uint64_t n, dollar, C0, C1, C2, C3;
+    const ulonglong2* ptable;       // 4^ptable_len intervals [i, j) of the patterns' last ptable_len bases (fmsi_wide.hip)
 };
 
 // the k-mer dictionary (fmsi_dict.hip): up to four levels of 128-byte buckets, passed by value to the lookup kernel
@@ -207,6 +208,7 @@ int launch_phased_query(fmsi_hip_index* idx, const uint64_t* d_kmers, uint64_t n
 void wide_super_table(const uint32_t* blocks, const uint32_t* mrank, uint64_t n_blocks, uint32_t sb_log2, std::vector<uint64_t>& super);
 int launch_wide_query(fmsi_hip_index* idx, const uint64_t* d_kmers, uint64_t n, int k, uint32_t flags, uint8_t* o8, long long* o64,
                       unsigned long long* d_counters, hipStream_t s);
+int build_prefix_table_wide(fmsi_hip_index* idx, int t);   // (at most 14 deep: 16-byte entries)
 // what a handle with 64-bit rows does not have
 #define FMSI_HIP_NARROW_ONLY(idx, what)                                                                                          \
     do {                                                                                                                         \

@@ -29,9 +29,14 @@ def check(fm, dev, orc, kmers, k):
     for mode_all in (False, True):
         flag = fm.MODE_ALL if mode_all else fm.MODE_OR
         fwd, rc = orc.ternaries_bulk(raw, len(kmers), k, mode_all)
-        got = dev.query_kmers(packed, k, flag | fm.STRICT)
+        got, cn = dev.query_kmers(packed, k, flag | fm.STRICT, counters=True)
         gf, gr = fm.decode_strict(got)
         assert np.array_equal(gf, fwd) and np.array_equal(gr, rc)
+        # the same from the search without the handle's prefix table (16-byte [i, j) entries for 64-bit rows) -- which saves steps when it is there
+        plain, cn0 = dev.query_kmers(packed, k, flag | fm.STRICT | fm.NO_PREFIX_TABLE, counters=True)
+        assert np.array_equal(plain, got) and int(cn0[4]) == 0
+        if dev.info.prefix_len and k >= dev.info.prefix_len:
+            assert int(cn[4]) == int(cn[3]) and int(cn[0]) < int(cn0[0])      # a lookup per strand search, fewer LF steps
         fast = dev.query_kmers(packed, k, flag | fm.KERNEL_PHASED)      # (kernel selection flags do not matter here)
         assert np.array_equal(fast.astype(bool), (np.where(fwd != -1, fwd, rc) == 1) if mode_all else ((fwd == 1) | (rc == 1)))
         assert np.array_equal(fm.unpack_bits(dev.query_kmers(packed, k, flag | fm.STRICT | fm.OUT_BITS), len(kmers), fm.STRICT), got)
@@ -45,7 +50,7 @@ def check(fm, dev, orc, kmers, k):
 def test_wide_rows_equal_oracle_on_the_golden_indexes(fm, oracle_built, name):
     k = DATASETS[name][0]
     orc = oracle_py.Oracle.load(index_prefix(name))
-    dev = fm.DeviceIndex.from_files(index_prefix(name), use_klcp=True, prefix_len=6)     # (table and kLCP are not taken)
+    dev = fm.DeviceIndex.from_files(index_prefix(name), use_klcp=True, prefix_len=6)     # (the kLCP array is not taken; the table is, as deep as the index is large)
     ms_file = {"integration_a": "ref_data/integration_a.fa", "integration_b": "ref_data/integration_b.fa",
                "sars_k13": "ref_data/GCF_009858895.2_ASM985889v3_genomic.fna.ms.k13",
                "sars_k31": "ref_data/GCF_test2_ones.fna.ms.k31", "mixed_k11": "mixed.fa"}[name]
@@ -56,7 +61,7 @@ def test_wide_rows_equal_oracle_on_the_golden_indexes(fm, oracle_built, name):
         kmers = ["".join(p) for p in itertools.product("ACGT", repeat=k)]
     check(fm, dev, orc, kmers, k)
     info = dev.info
-    assert info.prefix_len == 0 and info.has_klcp == 0
+    assert 1 <= info.prefix_len <= 6 and info.has_klcp == 0
     for call in (dev.enable_pair_layout, dev.enable_dict, dev.enable_verify):
         with pytest.raises(fm.FmsiError) as e:
             call()
@@ -83,7 +88,8 @@ def test_wide_rows_across_many_superblocks(fm, oracle_built, tmp_path):
     ms = synthetic_ms(1_200_000, k, seed=4242, mask="mixed")
     orc = oracle_py.Oracle.construct(ms, k, use_klcp=False)
     orc.dump(str(tmp_path / "w"))
-    dev = fm.DeviceIndex.from_files(str(tmp_path / "w"))
+    dev = fm.DeviceIndex.from_files(str(tmp_path / "w"), prefix_len=9)
+    assert dev.info.prefix_len == 9
     check(fm, dev, orc, mixed_kmers(ms, k, 100_000, seed=6), k)
     # and the written files are the loaded ones (the writer works from the same blocks)
     dev.write_files(str(tmp_path / "w2"))
@@ -167,9 +173,9 @@ def test_index_of_more_than_2_to_32_rows(product_built, oracle_built):
     fm = product_built
     n, k = 4_500_000_000, 31
     with fm.builder_chain(0):
-        dev = fm.DeviceIndex.build_synthetic(n, 99, k)
+        dev = fm.DeviceIndex.build_synthetic(n, 99, k, prefix_len=14)
     info = dev.info
-    assert info.rows64 == 1 and info.n == n + 1 and info.n > (1 << 32)
+    assert info.rows64 == 1 and info.n == n + 1 and info.n > (1 << 32) and info.prefix_len == 14
     nq = 1 << 20
     s = torch.cuda.current_stream().cuda_stream
     d_k = torch.empty(nq, dtype=torch.int64, device="cuda")
@@ -184,6 +190,9 @@ def test_index_of_more_than_2_to_32_rows(product_built, oracle_built):
     present = (f == 1) | (r == 1)
     assert 0.49 < present.mean() < 0.51 and ((f == 0) | (r == 0)).sum() == 0     # max-ones: half the stream is drawn from the text, and ON
     assert np.array_equal(outs["or"], outs["all"])                                 # (max-ones: the modes agree)
+    dev.query_kmers_dev(d_k.data_ptr(), nq, k, fm.MODE_ALL | fm.STRICT | fm.NO_PREFIX_TABLE, d_o.data_ptr(), stream=s)
+    torch.cuda.synchronize()
+    assert np.array_equal(d_o.cpu().numpy(), outs["all"])                          # the 14-deep table (4.3 GB of 16-byte entries) changes no answer
     sample = 1 << 15
     kmers = d_k[:sample].cpu().numpy().view(np.uint64)
     codes = ((kmers[:, None] >> (2 * np.arange(k, dtype=np.uint64))) & np.uint64(3)).astype(np.uint8)
