@@ -40,4 +40,46 @@ __device__ __forceinline__ uint64_t mask_rank_w(const DevIndexW& ix, uint64_t b,
     return abs_count(ix, b, 4u, ix.mrank[b]) + popc_prefix128(m, p);
 }
 
+
+// ---- one set of names for the kernels that are templates over the handle's view (32-bit rows: DevIndex, 64-bit rows: DevIndexW) ----
+template <class IX> struct RowOf;
+template <> struct RowOf<DevIndex> { typedef uint32_t type; };
+template <> struct RowOf<DevIndexW> { typedef uint64_t type; };
+
+__device__ __forceinline__ void view_lf_step(const DevIndex& ix, uint32_t c, uint32_t& i, uint32_t& j, uint32_t& blocks) { lf_step(ix, c, i, j, blocks); }
+__device__ __forceinline__ void view_lf_step(const DevIndexW& ix, uint32_t c, uint64_t& i, uint64_t& j, uint32_t& blocks) { lf_step_w(ix, c, i, j, blocks); }
+// the mask bit of a row; the ON bits among the rows below `row` (row may be n)
+__device__ __forceinline__ uint32_t view_mask_bit(const DevIndex& ix, uint32_t row) { return mask_bit(ix, row); }
+__device__ __forceinline__ uint32_t view_mask_bit(const DevIndexW& ix, uint64_t row) {
+    const uint32_t* m = reinterpret_cast<const uint32_t*>(ix.blocks) + ((row >> kBlockRowsLog2) << 4) + 12u;
+    return (m[(static_cast<uint32_t>(row) & (kBlockRows - 1u)) >> 5] >> (row & 31u)) & 1u;
+}
+// ON bits among the rows [i, j), i < j (two mask ranks: the upper one through the block of row j - 1)
+__device__ __forceinline__ uint64_t view_ones_in(const DevIndex& ix, uint32_t i, uint32_t j, uint32_t& blocks, uint64_t* rank_i = nullptr) {
+    const uint32_t bi = i >> kBlockRowsLog2, bj = (j - 1u) >> kBlockRowsLog2;
+    blocks += 1u + (bj != bi);
+    const uint32_t ri = mask_rank(ix, bi, i & (kBlockRows - 1u));
+    if (rank_i) *rank_i = ri;
+    return mask_rank(ix, bj, j - (bj << kBlockRowsLog2)) - ri;
+}
+__device__ __forceinline__ uint64_t view_ones_in(const DevIndexW& ix, uint64_t i, uint64_t j, uint32_t& blocks, uint64_t* rank_i = nullptr) {
+    const uint64_t bi = i >> kBlockRowsLog2, bj = (j - 1u) >> kBlockRowsLog2;
+    blocks += 1u + (bj != bi);
+    const uint64_t ri = mask_rank_w(ix, bi, static_cast<uint32_t>(i & (kBlockRows - 1u)));
+    if (rank_i) *rank_i = ri;
+    return mask_rank_w(ix, bj, static_cast<uint32_t>(j - (bj << kBlockRowsLog2))) - ri;
+}
+// the interval of a pattern's last T bases from the handle's prefix table (tidx: those bases, the first of them in the low bits)
+__device__ __forceinline__ bool view_has_table(const DevIndex& ix, int k) { return ix.ptable && ix.ptable_len > 0 && k >= static_cast<int>(ix.ptable_len); }
+__device__ __forceinline__ bool view_has_table(const DevIndexW& ix, int k) { return ix.ptable && ix.ptable_len > 0 && k >= static_cast<int>(ix.ptable_len); }
+__device__ __forceinline__ void view_table_entry(const DevIndex& ix, uint64_t tidx, uint32_t& i, uint32_t& j) {
+    const uint2 e = ix.ptable[static_cast<uint32_t>(tidx)];
+    decode_table_entry(e.x, e.y, ix.ptable_packed, false, 0u, i, j);   // (no signature shortcut: the interval itself)
+}
+__device__ __forceinline__ void view_table_entry(const DevIndexW& ix, uint64_t tidx, uint64_t& i, uint64_t& j) {
+    const ulonglong2 e = ix.ptable[tidx];
+    i = e.x;
+    j = e.y;
+}
+
 }  // namespace fmsi

@@ -30,10 +30,6 @@
 namespace fmsi {
 namespace {
 
-template <class IX> struct RowOf;
-template <> struct RowOf<DevIndex> { typedef uint32_t type; };
-template <> struct RowOf<DevIndexW> { typedef uint64_t type; };
-
 template <class ROW>
 struct StepOut {
     uint32_t letter, mask_at_next;

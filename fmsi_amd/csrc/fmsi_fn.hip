@@ -15,6 +15,7 @@
 // strand right-to-left, the reverse complement left-to-right with complemented bases, starting from the prefix table's interval
 // when the handle has one; the ON bits of an interval [i, j) are two mask ranks (block count + popcount below the row: the
 // mask plane of the interleaved block), where the reference adds up j - i single accesses of its RRR vector.
+// The kernel is a template over the handle's view: 32-bit rows, or 64-bit rows (indexes of 2^32 rows and more, device_fm_wide.h).
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -22,6 +23,7 @@
 #include "../../include/fmsi_hip.h"
 #include "common.h"
 #include "device_fm.h"
+#include "device_fm_wide.h"
 #include "index_priv.h"
 
 namespace fmsi {
@@ -45,34 +47,33 @@ struct FnCounters {
 };
 
 // get_range_with_pattern (src/fms_index.h:117-124) of one strand of the window at base p
-__device__ __forceinline__ void strand_range(const DevIndex& ix, SeqCache& sc, uint64_t p, int k, bool rc, uint32_t& i, uint32_t& j, FnCounters& cn) {
+template <class IX>
+__device__ __forceinline__ void strand_range(const IX& ix, SeqCache& sc, uint64_t p, int k, bool rc, typename RowOf<IX>::type& i, typename RowOf<IX>::type& j,
+                                             FnCounters& cn) {
     cn.searches++;
     const int T = static_cast<int>(ix.ptable_len);
     int t = k - 1;
     i = 0;
     j = ix.n;
-    if (ix.ptable && T > 0 && k >= T) {
+    if (view_has_table(ix, k)) {
         // the T bases the search consumes first: the window's last T (forward) or its first T, complemented and reversed
         const uint64_t w = window_kmer(sc.seq, rc ? p : p + static_cast<uint64_t>(k - T), T);
-        const uint32_t tidx = static_cast<uint32_t>(rc ? revcomp_2bit(w, T) : w);
-        const uint2 e = ix.ptable[tidx];
-        decode_table_entry(e.x, e.y, ix.ptable_packed, false, 0u, i, j);   // (no signature shortcut: the interval itself)
+        view_table_entry(ix, rc ? revcomp_2bit(w, T) : w, i, j);
         cn.lookups++;
         t = k - T - 1;
     }
     for (; t >= 0 && i != j; --t) {
         const uint32_t c = rc ? 3u - sc.base(p + static_cast<uint64_t>(k - 1 - t)) : sc.base(p + static_cast<uint64_t>(t));
-        lf_step(ix, c, i, j, cn.blocks);
+        view_lf_step(ix, c, i, j, cn.blocks);
         cn.lf_steps++;
     }
 }
 
 // ON bits among the rows [i, j), i < j
-__device__ __forceinline__ uint32_t ones_in(const DevIndex& ix, uint32_t i, uint32_t j, FnCounters& cn) {
-    const uint32_t bi = i >> kBlockRowsLog2, bj = (j - 1u) >> kBlockRowsLog2;
+template <class IX, class ROW>
+__device__ __forceinline__ uint64_t ones_in(const IX& ix, ROW i, ROW j, FnCounters& cn) {
     cn.probes++;
-    cn.blocks += 1u + (bj != bi);
-    return mask_rank(ix, bj, j - (bj << kBlockRowsLog2)) - mask_rank(ix, bi, i & (kBlockRows - 1u));
+    return view_ones_in(ix, i, j, cn.blocks);
 }
 
 // f(ones, total) the way query_kmers_single<general> reaches it: through std::function<bool(int, int)> wrappers, i.e. with both
@@ -94,8 +95,8 @@ __device__ __forceinline__ bool case_symmetric(const uint64_t* __restrict__ lowe
     return true;
 }
 
-template <bool COUNT>
-__global__ __launch_bounds__(256) void query_fn_kernel(DevIndex ix, const uint64_t* __restrict__ seq, const uint64_t* __restrict__ lower,
+template <bool COUNT, class IX>
+__global__ __launch_bounds__(256) void query_fn_kernel(IX ix, const uint64_t* __restrict__ seq, const uint64_t* __restrict__ lower,
                                                        const uint64_t* __restrict__ window_start, uint64_t n_windows, int k, int fn, uint64_t fn_r,
                                                        uint64_t fn_s, uint8_t* __restrict__ out, unsigned long long* __restrict__ counters) {
     const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
@@ -104,7 +105,7 @@ __global__ __launch_bounds__(256) void query_fn_kernel(DevIndex ix, const uint64
     SeqCache sc{seq};
     for (uint64_t q = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; q < n_windows; q += stride) {
         const uint64_t p = window_start[q];
-        uint32_t fi, fj, ri, rj;
+        typename RowOf<IX>::type fi, fj, ri, rj;
         strand_range(ix, sc, p, k, false, fi, fj, cn);
         strand_range(ix, sc, p, k, true, ri, rj, cn);
         uint64_t ones = 0, total = 0;
@@ -144,14 +145,18 @@ __global__ __launch_bounds__(256) void query_fn_kernel(DevIndex ix, const uint64
 void launch_fn_query(fmsi_hip_index* idx, const uint64_t* d_seq, const uint64_t* d_window_start, uint64_t n, int k, bool use_table, uint8_t* o8,
                      unsigned long long* d_counters, hipStream_t s) {
     const uint32_t blocks = static_cast<uint32_t>(std::min<uint64_t>((n + 255) / 256, 256ull * 32));
-    DevIndex ix = idx->dev;
-    if (!use_table) ix.ptable = nullptr;
-    if (d_counters)
-        hipLaunchKernelGGL((query_fn_kernel<true>), dim3(blocks), dim3(256), 0, s, ix, d_seq, idx->fn_case, d_window_start, n, k, idx->fn_kind, idx->fn_r,
-                           idx->fn_s, o8, d_counters);
-    else
-        hipLaunchKernelGGL((query_fn_kernel<false>), dim3(blocks), dim3(256), 0, s, ix, d_seq, idx->fn_case, d_window_start, n, k, idx->fn_kind, idx->fn_r,
-                           idx->fn_s, o8, d_counters);
+    auto go = [&](auto view) {
+        if (!use_table) view.ptable = nullptr;
+        typedef decltype(view) IX;
+        if (d_counters)
+            hipLaunchKernelGGL((query_fn_kernel<true, IX>), dim3(blocks), dim3(256), 0, s, view, d_seq, idx->fn_case, d_window_start, n, k, idx->fn_kind, idx->fn_r,
+                               idx->fn_s, o8, d_counters);
+        else
+            hipLaunchKernelGGL((query_fn_kernel<false, IX>), dim3(blocks), dim3(256), 0, s, view, d_seq, idx->fn_case, d_window_start, n, k, idx->fn_kind, idx->fn_r,
+                               idx->fn_s, o8, d_counters);
+    };
+    if (idx->wide) go(idx->devw);
+    else go(idx->dev);
 }
 
 }  // namespace fmsi
@@ -170,7 +175,6 @@ extern "C" int fmsi_hip_query_runs_fn(fmsi_hip_index* idx, const uint64_t* packe
         set_last_error("FMSI_HIP_STRICT / FMSI_HIP_ORDERS have no meaning with a demasking function");   // src/main.cpp:297-300
         return FMSI_HIP_EINVAL;
     }
-    FMSI_HIP_NARROW_ONLY(idx, "a demasking function (-f)");
     idx->fn_kind = fn;
     idx->fn_r = r;
     idx->fn_s = s;

@@ -692,7 +692,6 @@ int run_query(fmsi_hip_index* idx, int input_kind, const uint64_t* in, size_t in
     }
     const uint64_t* d_kmers = d_in;
     if (input_kind == 1 && k > 32) {
-        FMSI_HIP_NARROW_ONLY(idx, "a query with k > 32");
         // the k-mer does not fit a register pair: walk the window off the packed sequence (fmsi_longk.hip)
         if (n_windows == 0) return 0;
         PackAfter pack;
@@ -1117,7 +1116,6 @@ int fmsi_hip_query_runs(fmsi_hip_index* idx, const uint64_t* packed_seq, uint64_
         if ((rc = pack.end(n_windows, flags, d_out, s))) return rc;
         if ((rc = prof_end(idx, s, slot))) return rc;
     } else if (k > 32) {
-        FMSI_HIP_NARROW_ONLY(idx, "a query with k > 32");
         if ((rc = ensure_cap(&idx->d_aux, &idx->d_aux_cap, n_windows * 8))) return rc;
         hipLaunchKernelGGL((expand_runs_kernel<false>), dim3(blocks), dim3(256), 0, s, d_seq, d_rs, d_ro, n_runs, n_windows, k,
                            static_cast<uint64_t*>(idx->d_aux));

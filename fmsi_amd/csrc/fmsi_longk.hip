@@ -6,11 +6,13 @@
 // the sequence (32 bases) is cached per lane, so the sequence costs one (coalesced, neighbouring lanes share it) read
 // per 32 LF steps; every LF step is the same 64-B block read(s) as everywhere else (device_fm.h: lf_step).
 // Lock-step waves: neighbouring lanes hold neighbouring windows of a read, whose searches end at about the same depth.
+// The kernel is a template over the handle's view: 32-bit rows, or 64-bit rows (indexes of 2^32 rows and more, device_fm_wide.h).
 #include <hip/hip_runtime.h>
 
 #include "../../include/fmsi_hip.h"
 #include "common.h"
 #include "device_fm.h"
+#include "device_fm_wide.h"
 #include "index_priv.h"
 
 namespace fmsi {
@@ -34,30 +36,31 @@ struct SeqWord {   // one cached word of the packed sequence
 };
 
 // get_range_with_pattern (src/fms_index.h:117-124) + infer_presence (:126-144) / kmer_order_if_present (:146-156)
-__device__ __forceinline__ int search_window_strand(const DevIndex& ix, SeqWord& sw, uint64_t p, int k, bool rc, uint32_t mode_all,
+template <class IX>
+__device__ __forceinline__ int search_window_strand(const IX& ix, SeqWord& sw, uint64_t p, int k, bool rc, uint32_t mode_all,
                                                     uint32_t want_orders, long long& order, WideCounters& cn) {
-    uint32_t i = 0, j = ix.n;
+    typename RowOf<IX>::type i = 0, j = ix.n;
     cn.searches++;
     for (int t = k - 1; t >= 0 && i != j; --t) {
         const uint32_t c = rc ? 3u - sw.base(p + static_cast<uint64_t>(k - 1 - t)) : sw.base(p + static_cast<uint64_t>(t));
-        lf_step(ix, c, i, j, cn.blocks);
+        view_lf_step(ix, c, i, j, cn.blocks);
         cn.lf_steps++;
     }
     order = -1;
     if (i == j) return -1;
     cn.probes++;
-    cn.blocks++;
-    if (mode_all && !want_orders) return static_cast<int>(mask_bit(ix, i));
-    const uint32_t bi = i >> kBlockRowsLog2, bj = (j - 1u) >> kBlockRowsLog2;
-    const uint32_t ri = mask_rank(ix, bi, i & (kBlockRows - 1u));
-    const uint32_t rj = mask_rank(ix, bj, j - (bj << kBlockRowsLog2));
-    const int any = rj > ri;
+    if (mode_all && !want_orders) {
+        cn.blocks++;
+        return static_cast<int>(view_mask_bit(ix, i));
+    }
+    uint64_t ri = 0;
+    const int any = view_ones_in(ix, i, j, cn.blocks, &ri) != 0;
     if (want_orders && any) order = static_cast<long long>(ri);
     return any;
 }
 
-template <bool COUNT>
-__global__ __launch_bounds__(256) void query_longk_kernel(DevIndex ix, const uint64_t* __restrict__ seq,
+template <bool COUNT, class IX>
+__global__ __launch_bounds__(256) void query_longk_kernel(IX ix, const uint64_t* __restrict__ seq,
                                                           const uint64_t* __restrict__ window_start, uint64_t n_windows, int k,
                                                           uint32_t flags, uint8_t* __restrict__ out, long long* __restrict__ out_orders,
                                                           unsigned long long* __restrict__ counters) {
@@ -107,12 +110,16 @@ __global__ __launch_bounds__(256) void query_longk_kernel(DevIndex ix, const uin
 void launch_longk_query(fmsi_hip_index* idx, const uint64_t* d_seq, const uint64_t* d_window_start, uint64_t n, int k, uint32_t flags,
                         uint8_t* o8, long long* o64, unsigned long long* d_counters, hipStream_t s) {
     const uint32_t blocks = static_cast<uint32_t>(std::min<uint64_t>((n + 255) / 256, 256ull * 32));
-    if (d_counters)
-        hipLaunchKernelGGL((query_longk_kernel<true>), dim3(blocks), dim3(256), 0, s, idx->dev, d_seq, d_window_start, n, k, flags, o8, o64,
-                           d_counters);
-    else
-        hipLaunchKernelGGL((query_longk_kernel<false>), dim3(blocks), dim3(256), 0, s, idx->dev, d_seq, d_window_start, n, k, flags, o8, o64,
-                           d_counters);
+    if (idx->wide) {
+        if (d_counters)
+            hipLaunchKernelGGL((query_longk_kernel<true, DevIndexW>), dim3(blocks), dim3(256), 0, s, idx->devw, d_seq, d_window_start, n, k, flags, o8, o64, d_counters);
+        else
+            hipLaunchKernelGGL((query_longk_kernel<false, DevIndexW>), dim3(blocks), dim3(256), 0, s, idx->devw, d_seq, d_window_start, n, k, flags, o8, o64, d_counters);
+    } else if (d_counters) {
+        hipLaunchKernelGGL((query_longk_kernel<true, DevIndex>), dim3(blocks), dim3(256), 0, s, idx->dev, d_seq, d_window_start, n, k, flags, o8, o64, d_counters);
+    } else {
+        hipLaunchKernelGGL((query_longk_kernel<false, DevIndex>), dim3(blocks), dim3(256), 0, s, idx->dev, d_seq, d_window_start, n, k, flags, o8, o64, d_counters);
+    }
 }
 
 }  // namespace fmsi

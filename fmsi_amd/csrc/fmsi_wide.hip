@@ -8,8 +8,9 @@
 // (src/fms_index.h:98-103), get_range_with_pattern() (:117-124), infer_presence() (:126-144), kmer_order_if_present()
 // (:146-156) -- for isolated k-mers and, through the library's window / run expansion, for windows and runs; presence modes,
 // STRICT, ORDERS and FMSI_HIP_OUT_BITS as everywhere.  A prefix table of plain 16-byte [i, j) entries, at most 14 deep, gives the search its
-// first bases in one read (2.6 x on a 4.5 x 10^9-row index).  Not built for such handles: pair layout, candidate tables,
-// dictionary, kLCP streaming and k > 32 (FMSI_HIP_ERANGE says so); export walks 64-bit rows (fmsi_export.hip, device_fm_wide.h), and the
+// first bases in one read (2.6 x on a 4.5 x 10^9-row index).  k > 32 and the demasking functions (-f) take the k-agnostic walks of
+// fmsi_longk.hip / fmsi_fn.hip, which are templates over the row width.  Not built for such handles: pair layout, candidate tables,
+// dictionaries and the kLCP kernel (FMSI_HIP_ERANGE says so); export walks 64-bit rows (fmsi_export.hip, device_fm_wide.h), and the
 // CLI answers -S through this search (the kLCP array is the reference's short cut: the answers are the same).  Such handles come from index files (the host path) or from
 // the on-device builder for 64-bit rows (build_index.hip, build_wide_from_device_text: a 4.5 x 10^9-base index is built and queried
 // against the oracle in tests/test_gpu_wide.py).

@@ -871,13 +871,9 @@ extern "C" int fmsi_cli_query(int argc, char** argv, int output_orders_i) {
         fmsi_hip_index_info info;
         const bool wide = fmsi_hip_index_get_info(c.dev, &info) == 0 && info.rows64 != 0;
         if (first) rows64 = wide;
-        // 2^32 rows and more: the plain search only (include/fmsi_hip.h).  -S needs nothing else -- the kLCP array is a short cut of the
+        // 2^32 rows and more: the plain search (from a prefix table of its own) -- also for k > 32 and -f, whose kernels are templates over
+        // the row width -- and no other accelerator (include/fmsi_hip.h).  -S needs nothing else: the kLCP array is a short cut of the
         // reference's, the answers are the plain search's (and the record loop's strand bookkeeping is replayed on the host as always)
-        if (wide && (k > 32 || general)) {
-            c.error = "k > 32 is not available on the GPU path for indexes of 2^32 rows or more.";
-            if (general) c.error = "-f with a general function is not available on the GPU path for indexes of 2^32 rows or more.";
-            return false;
-        }
         if (want_dict && !wide) {
             // (compact: 23 <= k <= 32 -- the minimizers are 21 / 23 bases; other k take the k-mer dictionary)
             const uint32_t form = opt.compact_tables && k >= 23 ? FMSI_HIP_DICT_SUPERKMER_ONLY : 0u;

@@ -35,7 +35,7 @@ extern "C" {
 #define FMSI_HIP_EHIP (-3)     /* a HIP runtime call failed */
 #define FMSI_HIP_ENOMEM (-4)
 #define FMSI_HIP_EIO (-5)      /* index files missing / malformed */
-#define FMSI_HIP_ERANGE (-6)   /* not built for this size: an accelerator / streaming on an index of >= 2^32 rows, or k unsupported */
+#define FMSI_HIP_ERANGE (-6)   /* not built for this size: an accelerator on an index of >= 2^32 rows, or k unsupported */
 #define FMSI_HIP_ECOMM (-7)    /* RCCL failure */
 
 /* ---- query flags ------------------------------------------------------------------------------ */
@@ -128,7 +128,8 @@ typedef struct {
     uint32_t dict_levels, dict_log2_buckets;   /* levels in use; log2 of level 0's bucket count */
     uint64_t dict_chain_bytes;  /* 0, or the bytes of the chained lookups' extras (FMSI_HIP_DICT_CHAIN; included in dict_bytes) */
     uint64_t rows64;            /* 1: the handle keeps 64-bit rows (n >= 2^32 - 128; src/fms_index.h:98-103 uses size_t): plain search only --
-                                   a prefix table of 16-byte entries (at most 14 deep), but no pair layout, candidate tables, dictionary, k > 32 (FMSI_HIP_ERANGE); export works, and
+                                   a prefix table of 16-byte entries (at most 14 deep), any k and the demasking functions, but no pair layout, candidate tables or dictionary
+                                   (FMSI_HIP_ERANGE); export works, and
                                    fmsi_hip_query_stream is served by the plain search (no kLCP kernel; the same answers);
                                    loaded from files or built on the device (fmsi_hip_index_build*, len > 2^32 - 8192) */
     uint64_t sk_bytes;          /* 0 = no super-k-mer dictionary (FMSI_HIP_DICT_SUPERKMER), else its HBM footprint incl. the aux dictionary */

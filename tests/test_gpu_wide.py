@@ -9,7 +9,8 @@ import numpy as np
 import pytest
 
 import oracle_py
-from conftest import CLI_DATASETS, DATASETS, GOLDEN, MODES, golden_out, index_prefix, mixed_kmers, query_file, synthetic_ms
+from conftest import (CLI_DATASETS, DATASETS, FN_CASES, GOLDEN, MODES, golden_fn_out, golden_out, index_prefix, mixed_kmers, query_file,
+                      synthetic_ms)
 
 pytestmark = pytest.mark.gpu
 
@@ -98,9 +99,10 @@ def test_wide_rows_across_many_superblocks(fm, oracle_built, tmp_path):
     assert dev.export() == ms.encode()        # (the walk crosses superblocks at every other step)
 
 
-@pytest.mark.parametrize("name,kind,mode", [(n, kind, mode) for n, (k, kinds) in CLI_DATASETS.items() if k <= 32 for kind in kinds[:1]
+@pytest.mark.parametrize("name,kind,mode", [(n, kind, mode) for n, (k, kinds) in CLI_DATASETS.items() for kind in kinds[:1]
                                             for mode in ("or", "all", "lookup")])
 def test_cli_with_wide_rows(fm, name, kind, mode):
+    """(k <= 32: query_wide_kernel; k = 40, 64: the k-agnostic walk of fmsi_longk.hip, a template over the row width)"""
     k = CLI_DATASETS[name][0]
     rc, out, err = fm.run_cli([*MODES[mode][0], "-k", str(k), "-q", str(query_file(name, kind)), index_prefix(name)])
     assert rc == 0, err.decode()
@@ -287,3 +289,14 @@ def test_cli_index_query_export_beyond_2_to_32_bases(product_built):
         del a, b
     finally:
         shutil.rmtree(d, ignore_errors=True)
+
+
+@pytest.mark.parametrize("name,kind,fn", [c for c in FN_CASES if c[2] in ("and", "xor", "1-1", "2-3")])
+def test_cli_demasking_functions_with_wide_rows(fm, name, kind, fn):
+    """`fmsi query -f and|xor|r-s` over 64-bit rows (the kernel of fmsi_fn.hip is a template over the row width, too): the reference's
+    golden output, k <= 32 and k = 40, 64 alike."""
+    k = CLI_DATASETS[name][0]
+    rc, out, err = fm.run_cli(["query", "-f", fn, "-k", str(k), "-q", str(query_file(name, kind)), index_prefix(name)])
+    assert rc == 0, err.decode()
+    assert out == golden_fn_out(name, kind, fn)
+
