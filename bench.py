@@ -827,6 +827,123 @@ def run_config_legs(args):
 
 
 # ======================================================================================================================================
+# ---- the line the driver parses ---------------------------------------------------------------------------------------------
+# The driver keeps the last 8 KB of stdout (its stderr trailer included) and parses the LAST line: that line is a compact summary of
+# at most COMPACT_LIMIT bytes -- numbers and short names only.  The full record (every leg's counters, sources and prose) is written
+# one line earlier on stdout and to bench_details.json beside this file (and under gpurun_out/ when that exists).
+COMPACT_LIMIT = 3900
+
+
+def _r(x, nd=4):
+    return round(x, nd) if isinstance(x, float) else x
+
+
+def _short_kernel(name):
+    """'query_pair_kernel<false,false,false> (two-base ...)' -> 'query_pair_kernel<false,false,false>'"""
+    return None if name is None else str(name).split(" (")[0]
+
+
+def compact_line(line):
+    cfg, roof, cpu = line.get("config") or {}, line.get("roofline"), line.get("cpu_baseline")
+    out = {k: line[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                                "vs_baseline", "dtype", "data") if k in line}
+    out["value"], out["ms_per_step"] = _r(out["value"], 1), _r(out["ms_per_step"], 5)
+    acc = cfg.get("accelerator") or {}
+    c2 = {"workload": cfg.get("workload_short") or str(cfg.get("workload", ""))[:96], "index_rows": cfg.get("index_rows"), "k": cfg.get("k"),
+          "queries_per_step_per_gpu": cfg.get("queries_per_step_per_gpu"), "mode": cfg.get("mode"), "kernel": cfg.get("kernel"),
+          "accelerator": acc.get("kind"), "accelerator_bytes": acc.get("bytes"), "index_bytes_hbm": cfg.get("index_bytes_hbm"),
+          "parallelism": cfg.get("parallelism"), "positive_fraction": cfg.get("positive_fraction"),
+          "results_on_host_match_bytes": cfg.get("results_on_host_match_bytes"), "index_build_seconds": cfg.get("index_build_seconds")}
+    g = cfg.get("gather")
+    if g:
+        c2["gather"] = {k: g[k] for k in ("in_timed_region", "ranks_seen", "world", "host_copy", "bytes_gathered_per_step", "gather_ms_per_step_rank0",
+                                            "d2h_ms_per_step_rank0", "fmsi_hip_gather") if k in g}
+        if "alt" in g:
+            c2["gather"]["alt"] = {k: _r(g["alt"][k], 1) for k in ("host_copy", "ms_per_step", "value") if k in g["alt"]}
+    out["config"] = c2
+    if roof:
+        r2 = {k: roof.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "hbm_frac", "traffic_over_algorithmic", "kernel",
+                                       "avg_kernel_ms", "launches", "algorithmic_bytes_per_launch", "bytes_per_kmer", "blocks_per_kmer")}
+        rr = roof.get("request_roofline")
+        if rr:
+            r2["requests_gps"], r2["requests_frac"] = rr.get("achieved"), rr.get("frac")
+        if roof.get("lf_path"):
+            r2["lf_path"] = [{"kernel": _short_kernel(l.get("kernel")), "ms": l.get("ms"), "kmers_per_s": l.get("kmers_per_s"),
+                              "lf_steps_per_kmer": l.get("lf_steps_per_kmer"), "hbm_frac": l.get("hbm_frac"),
+                              "hbm_lines_per_kmer": l.get("hbm_lines_per_kmer"), "hbm_glines_per_s": l.get("hbm_glines_per_s")} for l in roof["lf_path"]]
+            r2["lf_path"] = [{k: v for k, v in l.items() if v is not None} for l in r2["lf_path"]]
+        if isinstance(r2.get("traffic"), float):
+            r2["traffic"] = int(r2["traffic"])
+        for l in r2.get("lf_path") or []:
+            l["kmers_per_s"] = int(l["kmers_per_s"])
+        out["roofline"] = r2
+    else:
+        out["roofline"] = None
+    if cpu:
+        if "error" in cpu:
+            out["cpu_baseline"] = {"error": str(cpu["error"])[:120]}
+        else:
+            c3 = {k: _r(cpu.get(k), 1) for k in ("value", "unit", "cores", "kind", "matches_gpu", "socket_value", "socket_cores", "tuned_value", "cpu_model")}
+            c3["sample"] = cpu.get("sample_short") or str(cpu.get("sample", ""))[:80]
+            out["cpu_baseline"] = c3
+    else:
+        out["cpu_baseline"] = None
+    if line.get("configs"):
+        legs = []
+        for l in line["configs"]:
+            if not isinstance(l, dict):
+                continue
+            if "error" in l and "value" not in l:
+                legs.append({"name": l.get("name"), "error": str(l["error"])[:60]})
+                continue
+            leg = {"name": l.get("name"), "value": None if l.get("value") is None else int(float("%.5g" % l["value"])), "ms": l.get("ms"),
+                   "kernel": _short_kernel(l.get("kernel")),
+                   "kernel_ms": l.get("avg_kernel_ms"), "frac": l.get("frac"), "hbm_frac": l.get("hbm_frac"),
+                   "hbm_gb": None if not l.get("handle_bytes_hbm") else round(l["handle_bytes_hbm"] / 1e9, 1),
+                   "after_load": None if not l.get("windows_per_s_after_load") else int(float("%.4g" % l["windows_per_s_after_load"])),
+                   "load_s": None if l.get("load_seconds") is None else round(l["load_seconds"], 3), "dictionary": l.get("dictionary"),
+                   "matches_reference": l.get("matches_reference")}
+            legs.append({k: v for k, v in leg.items() if v is not None or k in ("name", "value", "matches_reference")})
+        out["configs"] = legs
+    out["details"] = "previous stdout line"
+
+    def size(o):
+        return len(json.dumps(o, separators=(",", ":")))
+    # never above the limit: shed the least important fields first
+    for drop in (("configs", "kernel_ms"), ("configs", "hbm_gb"), ("roofline", "bytes_per_kmer"), ("roofline", "blocks_per_kmer"), ("config", "gather", "alt"),
+                 ("configs", "kernel"), ("cpu_baseline", "cpu_model"), ("configs", "ms")):
+        if size(out) <= COMPACT_LIMIT:
+            break
+        tgt = out.get(drop[0])
+        if isinstance(tgt, list):
+            for t in tgt:
+                t.pop(drop[1], None)
+        elif isinstance(tgt, dict):
+            for key in drop[1:-1]:
+                tgt = tgt.get(key) or {}
+            tgt.pop(drop[-1], None)
+    while size(out) > COMPACT_LIMIT and out.get("configs"):
+        out["configs"].pop()
+    return json.dumps(out, separators=(",", ":"))
+
+
+def emit(fd, line):
+    """stdout: the full record, then -- last -- the compact line the driver parses."""
+    full = json.dumps(line)
+    here = os.path.dirname(os.path.abspath(__file__))
+    for d in (here, os.path.join(here, "gpurun_out")):
+        try:
+            if os.path.isdir(d):
+                with open(os.path.join(d, "bench_details.json"), "w") as f:
+                    f.write(full + "\n")
+        except OSError:
+            pass
+    small = compact_line(line)
+    assert len(small) <= COMPACT_LIMIT and "\n" not in small
+    os.write(fd, (full + "\n").encode())
+    os.write(fd, (small + "\n").encode())
+
+
 def main():
     args = parse_args()
     if args.workload == "e2e":
@@ -1039,7 +1156,7 @@ def main():
         t0 = time.time()
         line["configs"] = run_config_legs(args)
         line["config"]["config_legs_seconds"] = round(time.time() - t0, 1)
-    os.write(json_fd, (json.dumps(line) + "\n").encode())
+    emit(json_fd, line)
     os.close(json_fd)
     if multi:
         dist.barrier()

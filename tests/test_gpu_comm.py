@@ -71,7 +71,7 @@ def test_gather_of_sharded_query_results(fm, oracle_built, tmp_path):
 def test_bench_multi_rank_path_with_one_rank(fm):
     """bench.py's multi-rank code path -- process group over RCCL with a device id, barriers, MAX over ranks, the gather of
     the results through torch.distributed and through fmsi_hip_gather -- launched the way the driver launches it, with the
-    one rank a 1-GPU box allows (--force-dist), on a small index: exactly one JSON line on stdout, the two gathers agree."""
+    one rank a 1-GPU box allows (--force-dist), on a small index: the full record and -- last -- the compact line on stdout, the two gathers agree."""
     import json
     import os
     import subprocess
@@ -86,8 +86,11 @@ def test_bench_multi_rank_path_with_one_rank(fm):
     res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=str(repo))
     assert res.returncode == 0, res.stderr[-2000:]
     lines = [l for l in res.stdout.splitlines() if l.strip()]
-    assert len(lines) == 1, res.stdout[-2000:]
+    assert len(lines) == 2, res.stdout[-2000:]     # the full record, then the compact line the driver parses
+    small = json.loads(lines[1])
+    assert len(lines[1]) < 4096 and small["config"]["gather"]["ranks_seen"] == 1 and small["roofline"]["bound"] == "hbm"
     line = json.loads(lines[0])
+    assert small["value"] == round(line["value"], 1) and small["n_gpus"] == 1 and small["steps"] == 3
     assert line["n_gpus"] == 1 and line["steps"] == 3 and line["value"] > 0 and line["scaling"] == "weak"
     g = line["config"]["gather"]
     assert g["fmsi_hip_gather"] == "matches torch.distributed.gather"

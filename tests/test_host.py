@@ -491,3 +491,43 @@ def test_bench_defaults():
         assert m.parse_args().stream_via == "klcp"
     finally:
         sys.argv = argv
+
+
+def test_bench_compact_line_fits_the_drivers_tail():
+    """The driver keeps the last 8 KB of bench.py's stdout and parses the LAST line (round 3's 28-KB line was cut: `parsed: null`).
+    bench.compact_line() of round 3's full record -- 13 legs -- and of the same record with twice the legs must stay below 4 KB, be valid
+    JSON and carry the contract's keys, `roofline` (with the LF-walk legs) and `cpu_baseline`."""
+    import importlib.util
+    import json
+    import sys
+    spec = importlib.util.spec_from_file_location("bench_mod2", REPO / "bench.py")
+    m = importlib.util.module_from_spec(spec)
+    argv = sys.argv
+    try:
+        sys.argv = ["bench.py"]
+        spec.loader.exec_module(m)
+    finally:
+        sys.argv = argv
+    full = json.loads((REPO / "profiles" / "r03u_bench_default.json").read_text().splitlines()[0])
+    for grow in (1, 2):
+        rec = dict(full, configs=full["configs"] * grow)
+        s = m.compact_line(rec)
+        assert len(s) <= m.COMPACT_LIMIT < 4096 and "\n" not in s
+        d = json.loads(s)
+        for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+                    "roofline", "cpu_baseline", "configs"):
+            assert key in d, key
+        assert d["config"]["workload"] and "model" not in d["config"]
+        r = d["roofline"]
+        assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and r["traffic"] > 0
+        assert [l["kernel"] for l in r["lf_path"]] == ["query_pair_kernel<false,false,false>", "query_lockstep_kernel<false>"]
+        c = d["cpu_baseline"]
+        assert c["kind"] == "reference" and c["cores"] == 1 and c["value"] > 0 and c["unit"] == "k-mers/s" and c["sample"]
+        assert d["configs"][0]["name"] == "c2" and d["configs"][0]["matches_reference"] is True
+        if grow == 1:
+            assert len(d["configs"]) == len(full["configs"])
+    # a record without legs, counters or baseline (N > 1 ranks print this form)
+    bare = {k: v for k, v in full.items() if k != "configs"}
+    bare["roofline"], bare["cpu_baseline"] = None, None
+    d = json.loads(m.compact_line(bare))
+    assert d["roofline"] is None and d["cpu_baseline"] is None and "configs" not in d
