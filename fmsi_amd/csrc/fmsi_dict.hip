@@ -1182,7 +1182,9 @@ int build_skdict(fmsi_hip_index* idx) {
     }
     clock.mark("distinct records");
     // 3. the buckets: about 3.5 records each
-    uint32_t bits = 6;
+    // (a record keeps 36 bits of the hashed minimizer beside the bucket number -- 16 in word A, 20 in word B: at least mbits - 36 of its
+    // bits must select the bucket, however few records there are; k = 32 on a text of a few kb used to start below that)
+    uint32_t bits = mbits > 42u ? mbits - 36u : 6u;
     while (bits < 31u && bits + 6u < mbits && static_cast<double>(n_uniq) / static_cast<double>(1ull << bits) > 3.5) ++bits;
     const uint64_t n_buckets = 1ull << bits;
     const uint32_t shift = mbits - bits;

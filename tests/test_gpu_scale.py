@@ -178,14 +178,114 @@ def _reads_agree(fm, dev, k, L, n_reads, subst_ppm, flags_a, flags_b, seed=7):
     return a, cn
 
 
-def test_mixed_mask_at_human_scale(fm):
+@pytest.fixture(scope="module")
+def human_mixed(product_built):
+    """ONE handle for the at-scale tests that want the hard text: n = 2.8 x 10^9 rows, 60 % of the positions ON, a fifth of the 2048-base
+    segments copies of 50 consensus segments at 1 % divergence, with the kLCP array and the pair layout (building it takes longer than
+    either test's queries; the dictionaries a test adds stay on it)."""
+    fm = product_built
+    n, k = 2_800_000_000, 31
+    with fm.builder_chain(0):
+        dev = fm.DeviceIndex.build_synthetic(n, 777, k, with_klcp=True, repeats=(200, 50, 10), mask_permille=600).enable_pair_layout()
+    yield dev
+    dev.close()
+    fm.trim_scratch(0)
+
+
+def _seeded_reads(dev, L, n_reads, subst_ppm, seed):
+    import torch
+    s = torch.cuda.current_stream().cuda_stream
+    d_reads = torch.empty((n_reads * L) // 32 + 2, dtype=torch.int64, device="cuda")
+    dev.synthetic_reads_dev(L, seed, 0, n_reads, d_reads.data_ptr(), subst_ppm, s)
+    torch.cuda.synchronize()
+    return d_reads.cpu().numpy().view(np.uint64)
+
+
+def test_stream_kernel_at_human_scale(fm, human_mixed):
+    """The S-block kLCP kernel (query_stream2_kernel, what `fmsi query -S` runs; src/fms_index.h:106-115,181-254) held against CHECKERS at
+    the headline size, on the configuration bench.py times: n = 2.8 x 10^9 rows (mixed mask + repeat families: kLCP runs of thousands of
+    rows, intervals with differing mask bits), 512 reads of 3000 bases, half from the text, 1 % substitutions.
+      * every window, both modes: STRICT ternaries == the table-less LF walk (fmsi_hip_query_runs | NO_PREFIX_TABLE: fresh searches);
+      * the fast schedule (first strand decides if it can), as bytes and bit-packed (OUT_BITS), == what the ternaries imply;
+      * uniform runs (three numbers in the kernel's arguments) and ragged runs (the run table, tasks that end inside reads);
+      * the first 34 reads (10^5 windows): == the ORACLE's ternaries (C restatement on the downloaded index incl. kLCP) and == the REAL
+        reference's `-S` record loop (query_kmers<or>(..., has_klcp=true)) on the index written in its own file format;
+      * ORDERS (`lookup -S`: the round-2 kernel) == the oracle's orders on the sample, == the LF walk on all windows."""
+    import os
+    import tempfile
+    import bench_cpu
+    from conftest import stream_expected_fast, stream_expected_orders
+    dev, k, L, n_reads = human_mixed, 31, 3000, 512
+    assert int(dev.info.has_klcp) == 1
+    packed = _seeded_reads(dev, L, n_reads, 10000, seed=11)
+    w = L - k + 1
+    starts = np.arange(n_reads, dtype=np.uint64) * np.uint64(L)
+    wins = np.full(n_reads, w, dtype=np.uint32)
+    wins_r = wins.copy()                     # ragged: every third read cut short, one read of a single window, one of 65 (a task + 1)
+    wins_r[::3] = w // 2 + 7
+    wins_r[5], wins_r[8] = 1, 65
+    sample_reads = 34
+    # ---- the checker's side: oracle on the downloaded index; the real reference on the files the product writes ----
+    orc = bench_cpu.oracle_from_index(dev, k, with_klcp=True)
+    codes = ((packed[:, None] >> (2 * np.arange(32, dtype=np.uint64))) & np.uint64(3)).astype(np.uint8).reshape(-1)[:n_reads * L]
+    bases = np.frombuffer(b"ACGT", dtype=np.uint8)[codes].reshape(n_reads, L)
+    idx = np.arange(w)[:, None] + np.arange(k)[None, :]
+    sample_text = b"".join(bases[r][idx].tobytes() for r in range(sample_reads))
+    n_sample = sample_reads * w
+    strict = {}
+    for mode_all in (False, True):
+        flag = fm.MODE_ALL if mode_all else fm.MODE_OR
+        for rw, tag in ((wins, "uniform"), (wins_r, "ragged")):
+            walk = dev.query_runs(packed, n_reads * L, starts, rw, k, flag | fm.STRICT | fm.NO_PREFIX_TABLE)
+            got, cn = dev.query_stream(packed, n_reads * L, starts, rw, k, flag | fm.STRICT, counters=True)
+            assert np.array_equal(got, walk), (mode_all, tag, np.nonzero(got != walk)[0][:10])
+            f, r = fm.decode_strict(got)
+            # a streamed window costs about one LF step where the read follows the text: far fewer steps than fresh searches of k bases
+            assert int(cn[6]) == int(rw.sum()) and int(cn[0]) < 8 * int(rw.sum())
+            fast = dev.query_stream(packed, n_reads * L, starts, rw, k, flag)
+            assert np.array_equal(fast.astype(bool), stream_expected_fast(f, r, rw, mode_all)), (mode_all, tag)
+            bits = dev.query_stream(packed, n_reads * L, starts, rw, k, flag | fm.OUT_BITS)
+            assert np.array_equal(fm.unpack_bits(bits, int(rw.sum()), 0), fast), (mode_all, tag)
+            if tag == "uniform":
+                strict[mode_all] = (f, r)
+                of, orr = orc.ternaries_bulk(sample_text, n_sample, k, mode_all)
+                assert np.array_equal(f[:n_sample], of) and np.array_equal(r[:n_sample], orr), mode_all
+    fo, ro = strict[False]
+    fa, ra = strict[True]
+    assert ((fo == 1) | (ro == 1)).mean() > 0.15 and ((fo == 0) | (ro == 0)).mean() > 0.05 and ((fo == -1) & (ro == -1)).mean() > 0.4
+    assert (fo != fa).sum() + (ro != ra).sum() > 100          # the modes differ on this mask (intervals with mixed bits)
+    # ---- lookup -S (ORDERS): the round-2 kernel ----
+    _, _, of, orr = orc.ternaries_bulk(sample_text, n_sample, k, False, orders=True)
+    got = dev.query_stream(packed, n_reads * L, starts, wins, k, fm.ORDERS | fm.STRICT)
+    assert np.array_equal(got[:n_sample, 0], of) and np.array_equal(got[:n_sample, 1], orr)
+    walk = dev.query_runs(packed, n_reads * L, starts, wins, k, fm.ORDERS | fm.STRICT | fm.NO_PREFIX_TABLE)
+    assert np.array_equal(got, walk)
+    got1 = dev.query_stream(packed, n_reads * L, starts, wins, k, fm.ORDERS)
+    assert np.array_equal(got1, stream_expected_orders(fo, ro, got[:, 0], got[:, 1], wins))
+    orc.close()
+    # ---- the real reference's own -S loop on the sample ----
+    if oracle_py.ref_available():
+        with tempfile.TemporaryDirectory(dir="/dev/shm") as d:
+            dev.write_files(f"{d}/x")
+            ref = oracle_py.Reference.load(f"{d}/x", use_klcp=True)
+            fa_path = os.path.join(d, "s.fa")
+            with open(fa_path, "wb") as fh:
+                for r_ in range(sample_reads):
+                    fh.write(b">r%d\n" % r_ + bases[r_].tobytes() + b"\n")
+            text, _ = ref.query_file(fa_path, k, has_klcp=True, mode=oracle_py.MODE_OR, cap=sample_reads * (w + 32) + 4096)
+            want = np.concatenate([np.frombuffer(line.split("\t")[1].encode(), dtype=np.uint8) - ord("0") for line in text.splitlines()])
+            assert np.array_equal(want.astype(bool), ((fo == 1) | (ro == 1))[:n_sample])
+            ref.close()
+
+
+def test_mixed_mask_at_human_scale(fm, human_mixed):
     """The headline size with a NON-max-ones mask (60 % of the positions ON) and repeat families (a fifth of the 2048-base segments are
     copies of 50 consensus segments at 1 % divergence: thousands of occurrences per k-mer with differing mask bits): OR mode scans the
     interval (src/fms_index.h:133-142), `-O` takes its first row, STRICT both strands.  Dictionary == two-base LF walk == lock-step LF
     walk on 4 M seeded k-mers in both modes, the oracle's ternaries and the real reference's printed bits on a sample of the exported
     index; then the super-k-mer dictionary (the families' minimizers are heavy: the aux dictionary) against the LF walk on reads."""
-    n, k = 2_800_000_000, 31
-    dev = fm.DeviceIndex.build_synthetic(n, 777, k, repeats=(200, 50, 10), mask_permille=600).enable_pair_layout()
+    k = 31
+    dev = human_mixed
     strict = cross_check(fm, dev, k, nq=1 << 22, sample=100_000, or_reference=True)
     fo, ro = strict["or"]
     fa, ra = strict["all"]
