@@ -30,6 +30,7 @@ KERNEL_REFILL = 0x20
 KERNEL_PAIR = 0x30
 KERNEL_PHASED = 0x40
 KERNEL_DICT = 0x50
+KERNEL_SORTED = 0x60
 DICT_SPARSE = 0x1
 DICT_CHAIN = 0x2
 DICT_SUPERKMER = 0x4

@@ -586,6 +586,11 @@ int launch_query(fmsi_hip_index* idx, const uint64_t* d_kmers, uint64_t n_window
         flags &= ~FMSI_HIP_KERNEL_MASK;
         kernel = FMSI_HIP_KERNEL_AUTO;
     }
+    const bool sorted = !dict && !sk_iso && sorted_walk_applies(idx, k, flags);
+    if (kernel == FMSI_HIP_KERNEL_SORTED && !sorted) {   // (lookup, k > 32, no pair layout: AUTO)
+        flags &= ~FMSI_HIP_KERNEL_MASK;
+        kernel = FMSI_HIP_KERNEL_AUTO;
+    }
     const bool phased = !dict && !sk_iso && (kernel == FMSI_HIP_KERNEL_PHASED || kernel == FMSI_HIP_KERNEL_AUTO) && idx->d_pblocks && use_table;
     const bool want_bits = (flags & FMSI_HIP_OUT_BITS) && !(flags & FMSI_HIP_ORDERS);
     const bool pack_after = want_bits && !dict && !sk_iso && !(phased && phased_packs_bits(idx, k, flags));
@@ -605,6 +610,8 @@ int launch_query(fmsi_hip_index* idx, const uint64_t* d_kmers, uint64_t n_window
     } else if (sk_iso) {
         const uint64_t one_window_reads[3] = {0, 32, 1};
         if ((rc = launch_skdict(idx, d_kmers, n_windows, n_windows, k, flags, o8, d_counters, s, one_window_reads))) return rc;
+    } else if (sorted) {
+        if ((rc = launch_sorted_query(idx, d_kmers, n_windows, k, flags, o8, d_counters, s))) return rc;
     } else if (kernel == FMSI_HIP_KERNEL_LOCKSTEP) {
         const uint64_t blocks64 = (n_windows + 255) / 256;
         if (blocks64 > 0x7FFFFFFFull) {
@@ -862,7 +869,7 @@ void fmsi_hip_index_destroy(fmsi_hip_index* idx) {
     for (void* p : {idx->d_sk, idx->d_sk_aux[0], idx->d_sk_aux[1], idx->d_sk_aux[2], idx->d_sk_aux[3]})
         if (p) (void)dev_free(p);
     for (void* p : {idx->d_super, idx->d_blocks, idx->d_mrank, idx->d_ptable, idx->d_klcp, idx->d_sblocks, idx->d_text2, idx->d_stable, idx->d_vtable, idx->d_in, idx->d_aux, idx->d_out,
-                    idx->d_kmers, idx->d_tasks, idx->d_bytes, idx->d_case, idx->d_dict[0], idx->d_dict[1], idx->d_dict[2], idx->d_dict[3], idx->d_posans, idx->d_slot_pos, idx->d_pblocks, idx->d_sbt, idx->d_c2, static_cast<void*>(idx->d_counters)})
+                    idx->d_kmers, idx->d_tasks, idx->d_bytes, idx->d_case, idx->d_sorted, idx->d_dict[0], idx->d_dict[1], idx->d_dict[2], idx->d_dict[3], idx->d_posans, idx->d_slot_pos, idx->d_pblocks, idx->d_sbt, idx->d_c2, static_cast<void*>(idx->d_counters)})
         if (p) (void)dev_free(p);
     for (auto& m : idx->meta_ring) {
         if (m.in_flight) (void)hipEventSynchronize(m.done);

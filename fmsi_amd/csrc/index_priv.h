@@ -166,6 +166,7 @@ struct fmsi_hip_index {
     void* d_tasks = nullptr; size_t d_tasks_cap = 0;   // streaming task descriptors + records
     void* d_bytes = nullptr; size_t d_bytes_cap = 0;   // FMSI_HIP_OUT_BITS: result bytes of the kernels that do not pack themselves
     void* d_case = nullptr; size_t d_case_cap = 0;     // fmsi_hip_query_runs_fn: the sequence's lower-case bits
+    void* d_sorted = nullptr; size_t d_sorted_cap = 0; // FMSI_HIP_KERNEL_SORTED: items, sort buffers, hand-over slots, ternaries
     const uint64_t* fn_case = nullptr;                 // ... as the current call's kernel sees them (device pointer or nullptr)
     unsigned long long* d_counters = nullptr;
     fmsi::MetaSlot meta_ring[fmsi::kMetaSlots];
@@ -217,6 +218,10 @@ int build_prefix_table_wide(fmsi_hip_index* idx, int t);   // (at most 14 deep: 
             return FMSI_HIP_ERANGE;                                                                                              \
         }                                                                                                                        \
     } while (0)
+
+// FMSI_HIP_KERNEL_SORTED (fmsi_sorted.hip): the batch's strand searches sorted and walked in lock-step over the pair layout
+bool sorted_walk_applies(const fmsi_hip_index* idx, int k, uint32_t flags);
+int launch_sorted_query(fmsi_hip_index* idx, const uint64_t* d_kmers, uint64_t n, int k, uint32_t flags, uint8_t* o8, unsigned long long* d_counters, hipStream_t s);
 
 // the k-mer dictionary answers this call (presence modes, the index's k, no NO_PREFIX_TABLE) -- and its launch; h_runs as for
 // launch_phased_query.  The lookup kernel packs FMSI_HIP_OUT_BITS output itself.

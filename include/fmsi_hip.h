@@ -69,6 +69,9 @@ extern "C" {
                                             without a usable table it is KERNEL_PAIR */
 #define FMSI_HIP_KERNEL_DICT 0x50u       /* the k-mer dictionary (fmsi_hip_index_enable_dict): one bucket read per k-mer; AUTO picks it when the handle
                                             has one and the call is a presence query with the index's k; without it this is AUTO */
+#define FMSI_HIP_KERNEL_SORTED 0x60u     /* the table-less LF walk for a batch (fmsi_sorted.hip): both strands' searches sorted by the bases the
+                                            backward search consumes first, one lane per search in lock-step, two-base steps (needs the pair
+                                            layout; presence modes, k <= 32 -- otherwise the call takes what AUTO takes); reads no table */
 #define FMSI_HIP_KERNEL_MASK 0xF0u
 /* do not use the private accelerators -- prefix table, candidate tables, k-mer dictionary -- even if the handle has them: the LF walk
  * itself (canonical-step accounting runs, the table-less legs of the benchmark) */

@@ -388,6 +388,33 @@ def test_super_kmer_dictionary(fm, oracle_built, read_len, k, mask, shape):
         assert int(cn2[0]) == 0 and int(cn2[6]) == len(km2)     # no LF step: the records answered
 
 
+@pytest.mark.parametrize("n,k", [(3000, 32), (1200, 32), (3000, 31), (400, 24)])
+def test_super_kmer_dictionary_on_a_tiny_text(fm, oracle_built, n, k):
+    """Few records: the bucket count's floor.  A record keeps 36 bits of its hashed minimizer beside the bucket number, so at least
+    mbits - 36 bits must pick the bucket however small the text is (k = 32: m = 23, 46 bits -> >= 2^10 buckets; the construction used to
+    start at 2^6 for texts below ~10 kb, dropped the top bits of the remainder and failed its own self-check)."""
+    ms = synthetic_ms(n, k, seed=n + k, mask="mixed")
+    orc = oracle_py.Oracle.construct(ms, k, use_klcp=False)
+    only = fm.DeviceIndex.build(ms.encode(), k).enable_dict(superkmer_only=True)
+    assert only.info.sk_bytes > 0 and only.info.dict_bytes == 0
+    rng = random.Random(n)
+    up = ms.upper()
+    reads = _sk_reads(rng, up, min(150, n // 3), 60)
+    read_len = len(reads[0])
+    seq = "".join(reads)
+    words = fm.pack_sequence(seq.encode())
+    w = read_len - k + 1
+    starts = np.arange(len(reads), dtype=np.uint64) * np.uint64(read_len)
+    wins = np.full(len(reads), w, dtype=np.uint32)
+    kmers = [r[i:i + k] for r in reads for i in range(w)]
+    for mode_all in (False, True):
+        fwd, rc = orc.ternaries_bulk("".join(kmers).encode(), len(kmers), k, mode_all)
+        got, cn = only.query_runs(words, len(seq), starts, wins, k, (fm.MODE_ALL if mode_all else fm.MODE_OR) | fm.STRICT, counters=True)
+        gf, gr = fm.decode_strict(got)
+        assert np.array_equal(gf, fwd) and np.array_equal(gr, rc), mode_all
+        assert int(cn[0]) == 0
+
+
 def test_super_kmer_dictionary_score_ties(fm):
     """Two DIFFERENT m-mers of a window can share the smallest (19-bit) score: the window is then filed under the leftmost AND the rightmost
     of them, and a query of the other strand takes the one the text's own orientation does not -- whose records may be heavy or pushed out

@@ -46,7 +46,7 @@ def test_packed_equals_bytes_every_kernel(fm, oracle_built, n_kmers):
     tab = fm.DeviceIndex.from_files(index_prefix(name), prefix_len=6).enable_pair_layout()
     cand = fm.DeviceIndex.from_files(index_prefix(name), prefix_len=6).enable_pair_layout().enable_verify()    # one-lane lookups pack in-kernel
     variants = [(plain, fm.KERNEL_LOCKSTEP), (plain, fm.KERNEL_REFILL), (tab, fm.KERNEL_PAIR), (tab, fm.KERNEL_PHASED), (cand, fm.KERNEL_PHASED),
-                (cand, 0), (cand, fm.NO_PREFIX_TABLE | fm.KERNEL_PAIR)]
+                (cand, 0), (cand, fm.NO_PREFIX_TABLE | fm.KERNEL_PAIR), (tab, fm.KERNEL_SORTED)]
     for mode_all in (False, True):
         flag = fm.MODE_ALL if mode_all else fm.MODE_OR
         fwd, rc = orc.ternaries_bulk("".join(kmers).encode(), n_kmers, k, mode_all)

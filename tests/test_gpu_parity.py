@@ -49,6 +49,8 @@ def test_both_strands_equal_oracle(fm, oracle_built, name):
     dev_pe = fm.DeviceIndex.from_files(index_prefix(name), prefix_len=min(k, 6)).enable_pair_layout()
     dev_po = fm.DeviceIndex.from_files(index_prefix(name), prefix_len=max(1, min(k, 6) - 1)).enable_pair_layout()
     variants += [(dev_p, fm.KERNEL_PAIR), (dev_pe, fm.KERNEL_PAIR), (dev_po, fm.KERNEL_PAIR), (dev_pe, fm.KERNEL_REFILL)]
+    # the batch-sorted lock-step walk (fmsi_sorted.hip): no table read, whatever the handle has
+    variants += [(dev_p, fm.KERNEL_SORTED), (dev_pe, fm.KERNEL_SORTED)]
     # phased form (table lookups in a kernel of their own; what AUTO picks with a pair layout and a table)
     variants += [(dev_pe, fm.KERNEL_PHASED), (dev_po, fm.KERNEL_PHASED), (dev_po, 0)]
     # ... with text verification of one-row table intervals (needs t < k)

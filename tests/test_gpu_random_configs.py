@@ -55,7 +55,7 @@ def test_random_config(fm, oracle_built, seed):
     orc = oracle_py.Oracle.construct(ms, k, use_klcp=True)
     dev = fm.DeviceIndex.build(ms.encode(), k, with_klcp=True, prefix_len=t)
     dev_p = fm.DeviceIndex.build(ms.encode(), k, with_klcp=True, prefix_len=t).enable_pair_layout()
-    variants = [(dev, fm.KERNEL_LOCKSTEP), (dev, fm.KERNEL_REFILL), (dev_p, fm.KERNEL_PAIR), (dev_p, fm.KERNEL_PHASED), (dev_p, 0)]
+    variants = [(dev, fm.KERNEL_LOCKSTEP), (dev, fm.KERNEL_REFILL), (dev_p, fm.KERNEL_PAIR), (dev_p, fm.KERNEL_PHASED), (dev_p, 0), (dev_p, fm.KERNEL_SORTED)]
     if 0 < t < k:
         dev_v = fm.DeviceIndex.build(ms.encode(), k, with_klcp=True, prefix_len=t).enable_pair_layout().enable_verify()
         variants += [(dev_v, fm.KERNEL_PHASED), (dev_v, 0), (dev_v, fm.KERNEL_REFILL)]

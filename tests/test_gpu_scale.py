@@ -63,9 +63,10 @@ def cross_check(fm, dev, k, nq, sample, seed=42, or_reference=True, with_dict=Tr
     for mode_name, mode in (("or", fm.MODE_OR), ("all", fm.MODE_ALL)):
         outs = {name: device_answers(fm, dev, d_kmers, nq, k, mode | fm.STRICT | kern)
                 for name, kern in (("phased", fm.KERNEL_PHASED), ("pair", fm.KERNEL_PAIR | fm.NO_PREFIX_TABLE),
-                                   ("lockstep", fm.KERNEL_LOCKSTEP | fm.NO_PREFIX_TABLE))}
+                                   ("lockstep", fm.KERNEL_LOCKSTEP | fm.NO_PREFIX_TABLE), ("sorted", fm.KERNEL_SORTED))}
         assert np.array_equal(outs["phased"], outs["pair"]), mode_name
         assert np.array_equal(outs["phased"], outs["lockstep"]), mode_name
+        assert np.array_equal(outs["phased"], outs["sorted"]), mode_name
         f, r = fm.decode_strict(outs["phased"])
         of, orr = orc.ternaries_bulk(text, sample, k, mode_name == "all")
         assert np.array_equal(f[:sample], of) and np.array_equal(r[:sample], orr), mode_name
@@ -366,7 +367,7 @@ def test_adversarial_text_at_1e9_rows(fm):
     orc = bench_cpu.oracle_from_index(dev, k, with_klcp=False)
     for mode_name, mode in (("or", fm.MODE_OR), ("all", fm.MODE_ALL)):
         of, orr = orc.ternaries_bulk(text, kmers.size, k, mode_name == "all")
-        for kern in (fm.KERNEL_DICT, fm.KERNEL_PAIR | fm.NO_PREFIX_TABLE, fm.KERNEL_LOCKSTEP | fm.NO_PREFIX_TABLE):
+        for kern in (fm.KERNEL_DICT, fm.KERNEL_PAIR | fm.NO_PREFIX_TABLE, fm.KERNEL_LOCKSTEP | fm.NO_PREFIX_TABLE, fm.KERNEL_SORTED):
             f, r = fm.decode_strict(dev.query_kmers(kmers, k, mode | fm.STRICT | kern))
             assert np.array_equal(f, of) and np.array_equal(r, orr), (mode_name, kern)
         assert (of == 1).sum() > 100 and (of == 0).sum() > 0 and (of == -1).sum() > 100   # (present ON, present OFF, absent all occur)
