@@ -113,7 +113,7 @@ def parse_args(argv=None):
                     help="do not measure roofline.traffic in this run (child runs of this script under rocprofv3 --pmc, FETCH_SIZE and "
                          "WRITE_SIZE in separate passes)")
     ap.add_argument("--no-config-legs", action="store_true", help="skip the `configs` legs (BASELINE configs 2, 3, 4 and the whole process)")
-    ap.add_argument("--legs", default="c2,c3,c4,c4sk,e2e", help="which `configs` legs to run")
+    ap.add_argument("--legs", default="c2,c3,c3sk,c4,c4sk,c5sk,e2e", help="which `configs` legs to run")
     ap.add_argument("--leg", default=None, help=argparse.SUPPRESS)          # child mode: one leg, a JSON list on stdout
     ap.add_argument("--variants", default=None, help="with --leg: only these variants of the leg (comma-separated names), e.g. for a rocprofv3 run of one")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)   # child mode under rocprofv3: the plan's launches, nothing printed
@@ -265,7 +265,7 @@ class QueryPath:
         # (the kLCP kernel reads 128-byte S-blocks since round 3; FMSI_HIP_STREAM_V1 brings the 64-byte-block kernel back)
         self.block_b = 64 if via == "lf_lockstep" or (via == "klcp" and os.environ.get("FMSI_HIP_STREAM_V1")) or \
             (via == "legacy" and args.kernel in ("refill", "lockstep")) else 128
-        self.is_dict = via in ("dict", "runs_chain", "runs_plain", "runs_sk")
+        self.is_dict = via in ("dict", "dict_sk", "runs_chain", "runs_plain", "runs_sk")
         if self.stream_mode:
             L = self.read_len = read_len
             self.n_reads = max(1, int(batch) // (L - k + 1))
@@ -286,10 +286,14 @@ class QueryPath:
             self.in_bytes = 8.0 * self.batch
             if via == "dict":
                 self.flags, self.kernel, self.pmc_kernel = mode | fm.KERNEL_DICT, "dict_lookup_kernel", "dict_lookup_kernel<false, false>"
+            elif via == "dict_sk":   # a handle that keeps the super-k-mer dictionary alone: every k-mer a one-window read (fmsi_hip.hip, sk_iso)
+                self.flags, self.kernel, self.pmc_kernel = mode | fm.KERNEL_DICT, "sk_runs_kernel", "sk_runs_kernel<false"
             elif via == "lf_pair":
                 self.flags, self.kernel, self.pmc_kernel = mode | fm.KERNEL_PAIR | fm.NO_PREFIX_TABLE, "query_pair_kernel", "query_pair_kernel<false, false, false>"
             elif via == "lf_lockstep":
                 self.flags, self.kernel, self.pmc_kernel = mode | fm.KERNEL_LOCKSTEP | fm.NO_PREFIX_TABLE, "query_lockstep_kernel", "query_lockstep_kernel<false>"
+            elif via == "lf_sorted":
+                self.flags, self.kernel, self.pmc_kernel = mode | fm.KERNEL_SORTED | fm.NO_PREFIX_TABLE, "sorted_walk_kernel", "sorted_walk_kernel<false>"
             else:
                 self.flags = mode | {"phased": fm.KERNEL_PHASED, "pair": fm.KERNEL_PAIR, "refill": fm.KERNEL_REFILL, "lockstep": fm.KERNEL_LOCKSTEP}[args.kernel]
                 entry_b = int(index.info.candidate_entry_bytes)
@@ -582,7 +586,7 @@ def measure_traffic(args, plan, child_args):
                 if any(mk in name for mk in MARKER_KERNELS):
                     group += 1
                     continue
-                if 0 <= group < len(plan) and "fmsi::" in name:   # (the library's kernels; not torch's fill of the next variant's buffer)
+                if 0 <= group < len(plan) and ("fmsi::" in name or "rocprim::" in name):   # (the library's kernels and the sorts it calls; not torch's fill of the next variant's buffer)
                     kk = per_variant[group]["kernels"].setdefault(name, {"FETCH_SIZE": 0.0, "WRITE_SIZE": 0.0, "dispatches": 0})
                     kk[counter] += val * 1024.0   # the counters are in KiB
                     if counter == "FETCH_SIZE":
@@ -677,6 +681,9 @@ LEG_SPECS = {
     # the same reads through the super-k-mer dictionary ALONE (FMSI_HIP_DICT_SUPERKMER_ONLY: the k-mer dictionary is released after the
     # construction -- the handle is the index's blocks + the records + the small aux dictionary)
     "c4sk": (2.8e9, "stream", float(1 << 27), 8, [("c4_superkmer", "runs_sk", 0), ("c4_superkmer_subst1pct", "runs_sk", 10000)]),
+    # configs 3 and 5 (isolated 31-mers) on the compact structure alone: what a handle of <= 20 GB answers them at
+    "c3sk": (1.4e9, "kmers", float(1 << 27), 8, [("c3_superkmer", "dict_sk", 0)]),
+    "c5sk": (2.8e9, "kmers", float(1 << 27), 8, [("c5_superkmer", "dict_sk", 0)]),
 }
 LEG_TEXT = {
     "c2": "BASELINE config 2: E. coli single-genome scale (synthetic max-ones masked superstring n=4700000), k=31, 10^8 isolated random 31-mers per step "
@@ -688,6 +695,10 @@ LEG_TEXT = {
           "every 31-mer window, fmsi query -S -O answers",
 }
 LEG_TEXT["c4sk"] = LEG_TEXT["c4"]
+LEG_TEXT["c3sk"] = LEG_TEXT["c3"].replace("k-mer dictionary", "super-k-mer dictionary ALONE (the handle holds no k-mer dictionary: every k-mer is a one-window read, its minimizer's bucket "
+                                          "one 128-byte read, heavy / overflowed ones the small aux dictionary)")
+LEG_TEXT["c5sk"] = ("BASELINE config 5's per-GPU work (and the headline's): human-genome scale (n=2800000000), k=31, 2^27 isolated random 31-mers per step x 8 steps (50% present), "
+                    "fmsi query -O semantics, super-k-mer dictionary ALONE (no k-mer dictionary in the handle)")
 VIA_TEXT = {"runs_chain": "fmsi_hip_query_runs, chained dictionary lookups (58.7 GB handle): a lane follows the superstring from its task's first window",
             "runs_plain": "fmsi_hip_query_runs, one dictionary bucket read per window (FMSI_HIP_NO_DICT_CHAIN)",
             "klcp": "fmsi_hip_query_stream: the kLCP kernel (extend_range_with_klcp + one LF step per positive window, src/fms_index.h:106-115,181-254)",
@@ -709,7 +720,7 @@ def run_leg(args):
     args.n, args.batch, args.workload = float(n), batch, workload
     stream_mode = workload == "stream"
     args.stream_via = "runs"
-    sk_only = name == "c4sk"
+    sk_only = name.endswith("sk")
     if stream_mode and not sk_only:
         args.prefix_len = 16   # (the kLCP kernel's fresh searches start from its 16-deep prefix table, as in the earlier rounds' runs; the dictionary paths do not use it)
     c = open_ctx(args)
@@ -831,7 +842,7 @@ def run_config_legs(args):
 # The driver keeps the last 8 KB of stdout (its stderr trailer included) and parses the LAST line: that line is a compact summary of
 # at most COMPACT_LIMIT bytes -- numbers and short names only.  The full record (every leg's counters, sources and prose) is written
 # one line earlier on stdout and to bench_details.json beside this file (and under gpurun_out/ when that exists).
-COMPACT_LIMIT = 3900
+COMPACT_LIMIT = 4000
 
 
 def _r(x, nd=4):
@@ -905,13 +916,12 @@ def compact_line(line):
                    "matches_reference": l.get("matches_reference")}
             legs.append({k: v for k, v in leg.items() if v is not None or k in ("name", "value", "matches_reference")})
         out["configs"] = legs
-    out["details"] = "previous stdout line"
 
     def size(o):
         return len(json.dumps(o, separators=(",", ":")))
     # never above the limit: shed the least important fields first
-    for drop in (("configs", "kernel_ms"), ("configs", "hbm_gb"), ("roofline", "bytes_per_kmer"), ("roofline", "blocks_per_kmer"), ("config", "gather", "alt"),
-                 ("configs", "kernel"), ("cpu_baseline", "cpu_model"), ("configs", "ms")):
+    for drop in (("configs", "kernel"), ("roofline", "bytes_per_kmer"), ("roofline", "blocks_per_kmer"), ("config", "gather", "alt"), ("cpu_baseline", "cpu_model"),
+                 ("cpu_baseline", "tuned_value"), ("configs", "kernel_ms"), ("configs", "frac"), ("configs", "hbm_gb"), ("configs", "ms")):
         if size(out) <= COMPACT_LIMIT:
             break
         tgt = out.get(drop[0])
@@ -967,7 +977,7 @@ def main():
         plan = json.loads(args.pmc_plan)
         index, _, _ = build_handle(c, args, n, k, stream_mode, with_klcp=any(v["via"] == "klcp" for v in plan),
                                    want_pair=any(v["via"].startswith("lf_") for v in plan), chain=any(v["via"] == "runs_chain" for v in plan),
-                                   superkmer_only=all(v["via"] == "runs_sk" for v in plan))
+                                   superkmer_only=all(v["via"] in ("runs_sk", "dict_sk") for v in plan))
         pmc_child(c, args, index, plan)
         os.close(json_fd)
         return
@@ -1028,7 +1038,9 @@ def main():
         lf_path = []
         lf_out = d_bits[0] if bits else d_out
         out_flag = fm.OUT_BITS if bits else 0
-        for lf_via, label in (("lf_pair", "query_pair_kernel<false,false,false> (two-base steps, 128-B blocks, no table)"),
+        for lf_via, label in (("lf_sorted", "sorted_walk_kernel<false> (the batch's strand searches sorted by their first bases, one lane per search in lock-step, two-base "
+                                            "steps, no index-side table; items + radix sort + per-batch top of the search tree + walk + combine, all inside the timed launches)"),
+                              ("lf_pair", "query_pair_kernel<false,false,false> (two-base steps, 128-B blocks, no table)"),
                               ("lf_lockstep", "query_lockstep_kernel<false> (one lane per k-mer walked in lock-step, 64-B blocks, no table)")):
             p = QueryPath(c, args, index, lf_via, k, batch)
             d_cnt.zero_()
@@ -1109,6 +1121,9 @@ def main():
                     leg["hbm_traffic"] = tt["traffic"]
                     leg["hbm_gbs"] = round(tt["traffic"] / (leg["ms"] * 1e-3) / 1e9, 1)
                     leg["hbm_frac"] = round(tt["traffic"] / (leg["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+                    # requests that reached the memory side, in the kernel's own line size, per k-mer and per second (the ceiling is ~48 G/s: DESIGN.md 3)
+                    leg["hbm_lines_per_kmer"] = round(tt["traffic"] / leg["block_bytes"] / batch, 2)
+                    leg["hbm_glines_per_s"] = round(tt["traffic"] / leg["block_bytes"] / (leg["ms"] * 1e-3) / 1e9, 2)
                     leg["traffic_by_kernel"] = tt["by_kernel"]
         else:
             roof["traffic_source"] = f"not measured in this run: {why}"

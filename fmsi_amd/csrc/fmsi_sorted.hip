@@ -70,43 +70,68 @@ __global__ __launch_bounds__(256) void sw_items_kernel(const uint64_t* __restric
 }
 
 // ---- (3) the walk ----------------------------------------------------------------------------------------------------------------------
+// what a launch of the walk takes its searches from and where it leaves them
+enum : uint32_t {
+    kSrcItems = 0,     // the sorted items, from the root interval [0, n) or -- top != nullptr -- from the top table's entry of their first top_bases bases
+    kSrcHandover = 1,  // the survivors an earlier launch left in the hand-over slots (kJoin waves' slots per wave)
+    kSrcTable = 2,     // lane e = entry e of a top-of-tree level: the out_bases-mer e, from the root or from its parent entry in `top`
+};
+enum : uint32_t {
+    kSinkResults = 0,  // walks to the k-mer's end: ternaries
+    kSinkHandover = 1, // stops when stop_left bases are left: survivors to the hand-over slots
+    kSinkTable = 2,    // stops at the level's depth: the interval (or (0, 0)) to top_out[e]
+};
 struct WalkArgs {
-    const uint64_t* keys;     // first launch: the sorted items
+    const uint64_t* keys;     // kSrcItems: the sorted items
     const uint32_t* vals;
-    uint64_t n_items;
-    // hand-over between the two launches: wave w of the first launch leaves its survivors in slots [64 w, 64 w + count[w])
+    uint64_t n_items;         // items, or entries of the level being made
+    // hand-over between launches: wave w leaves its survivors in slots [64 w, 64 w + count[w])
     uint64_t* h_key;          // the bases still to go, left-aligned
     uint2* h_ij;
     uint32_t* h_val;
     uint32_t* h_count;
-    uint64_t n_waves_a;       // waves of the first launch
+    uint64_t n_waves_a;       // waves of the launch that filled the slots
     uint8_t* tern;            // result + 1 per item (0 = absent: pre-zeroed)
+    // the top of the search tree, made once per batch (transient: scratch memory of this call): entry e of a level of D bases = the
+    // interval of the D-mer e (first-consumed base most significant), (0, 0) when it is empty
+    const uint2* top;
+    uint2* top_out;
+    uint32_t top_bases, out_bases;
     uint32_t left0;           // bases to go when this launch starts
-    uint32_t stop_left;       // hand over when this many bases are left (0: walk to the end)
-    uint32_t second;          // 1: this is the second launch (items come from the hand-over slots)
+    uint32_t stop_left;       // stop when this many bases are left (0: walk to the end)
+    uint32_t src, sink;
     uint32_t mode_all;
 };
 
-__device__ __forceinline__ uint64_t below64s(int s) { return s >= 64 ? ~0ull : (s <= 0 ? 0ull : ((1ull << s) - 1ull)); }
-
-// rows of a staged pair block that match pair p (single: symbol c1 = p >> 2 only): halves 0 (rows 0-63) and 1 (rows 64-127)
-__device__ __forceinline__ void block_match(const uint4* L4, uint32_t p, bool single, uint64_t& m_lo, uint64_t& m_hi) {
+// ---- rank arithmetic on a staged pair block, in 32-bit words (the kernel is bound by vector instructions: DESIGN.md 5) ----------------
+struct Match {
+    uint32_t m0, m1, m2, m3;   // rows 0-31, 32-63, 64-95, 96-127 of the block that match the step's pattern
+};
+// rows of the staged block that match pair p = c2 | c1 << 2 (SINGLE: symbol c1 = p >> 2 alone)
+template <bool SINGLE>
+__device__ __forceinline__ Match block_match(const uint4* L4, uint32_t p) {
     const uint32_t x1h = (p & 8u) ? 0u : 0xFFFFFFFFu, x1l = (p & 4u) ? 0u : 0xFFFFFFFFu;
-    const uint32_t x2h = (p & 2u) ? 0u : 0xFFFFFFFFu, x2l = (p & 1u) ? 0u : 0xFFFFFFFFu;
-    const uint32_t all = single ? 0xFFFFFFFFu : 0u;
-    const uint4 a0 = L4[0], a1 = L4[1], b0 = L4[4], b1 = L4[5];
-    const uint32_t m0 = (a0.x ^ x1h) & (a0.z ^ x1l) & ((a1.x ^ x2h) | all) & ((a1.z ^ x2l) | all);
-    const uint32_t m1 = (a0.y ^ x1h) & (a0.w ^ x1l) & ((a1.y ^ x2h) | all) & ((a1.w ^ x2l) | all);
-    const uint32_t m2 = (b0.x ^ x1h) & (b0.z ^ x1l) & ((b1.x ^ x2h) | all) & ((b1.z ^ x2l) | all);
-    const uint32_t m3 = (b0.y ^ x1h) & (b0.w ^ x1l) & ((b1.y ^ x2h) | all) & ((b1.w ^ x2l) | all);
-    m_lo = (static_cast<uint64_t>(m1) << 32) | m0;
-    m_hi = (static_cast<uint64_t>(m3) << 32) | m2;
+    const uint4 a0 = L4[0], b0 = L4[4];   // {c1hi 0-31, c1hi 32-63, c1lo 0-31, c1lo 32-63} of rows 0-63 / 64-127
+    Match m;
+    m.m0 = (a0.x ^ x1h) & (a0.z ^ x1l);
+    m.m1 = (a0.y ^ x1h) & (a0.w ^ x1l);
+    m.m2 = (b0.x ^ x1h) & (b0.z ^ x1l);
+    m.m3 = (b0.y ^ x1h) & (b0.w ^ x1l);
+    if (!SINGLE) {
+        const uint32_t x2h = (p & 2u) ? 0u : 0xFFFFFFFFu, x2l = (p & 1u) ? 0u : 0xFFFFFFFFu;
+        const uint4 a1 = L4[1], b1 = L4[5];   // the same for c2
+        m.m0 &= (a1.x ^ x2h) & (a1.z ^ x2l);
+        m.m1 &= (a1.y ^ x2h) & (a1.w ^ x2l);
+        m.m2 &= (b1.x ^ x2h) & (b1.z ^ x2l);
+        m.m3 &= (b1.y ^ x2h) & (b1.w ^ x2l);
+    }
+    return m;
 }
-// cumulative count of pair p before the block (24 bits, relative to its superblock); single: of the four pairs with c1 = p >> 2
-__device__ __forceinline__ uint32_t block_count(const uint32_t* L, uint32_t p, bool single) {
-    const uint32_t h = p >> 3;                      // the half that keeps the counts of c1 in {2h, 2h+1}
-    const uint32_t* H = L + 16u * h;
-    if (single) {
+// cumulative count of pair p before the block (24 bits, relative to its superblock); SINGLE: of the four pairs with c1 = p >> 2
+template <bool SINGLE>
+__device__ __forceinline__ uint32_t block_count(const uint32_t* L, uint32_t p) {
+    const uint32_t* H = L + 16u * (p >> 3);         // the half that keeps the counts of c1 in {2h, 2h+1}
+    if (SINGLE) {
         const uint32_t g = (p >> 2) & 1u;
         const uint32_t l0 = H[10u + 2u * g], l1 = H[11u + 2u * g], hb = H[14u + g];
         return (l0 & 0xFFFFu) + (l0 >> 16) + (l1 & 0xFFFFu) + (l1 >> 16) +
@@ -116,15 +141,189 @@ __device__ __forceinline__ uint32_t block_count(const uint32_t* L, uint32_t p, b
     const uint32_t lw = H[10u + (m >> 1)], hw = H[14u + (m >> 2)];
     return ((lw >> (16u * (m & 1u))) & 0xFFFFu) | (((hw >> (8u * (m & 3u))) & 0xFFu) << 16);
 }
-__device__ __forceinline__ uint32_t rows_below(uint64_t m_lo, uint64_t m_hi, int o) {
-    return static_cast<uint32_t>(__popcll(m_lo & below64s(o)) + __popcll(m_hi & below64s(o - 64)));
+// matching rows among the block's first o rows, o in [0, 128]: whole words through the running sums, one masked popcount
+struct MatchSums {
+    uint32_t p1, p2, p3, p4;
+};
+__device__ __forceinline__ MatchSums match_sums(const Match& m) {
+    MatchSums s;
+    s.p1 = __popc(m.m0);
+    s.p2 = s.p1 + __popc(m.m1);
+    s.p3 = s.p2 + __popc(m.m2);
+    s.p4 = s.p3 + __popc(m.m3);
+    return s;
+}
+__device__ __forceinline__ uint32_t rows_below(const Match& m, const MatchSums& s, uint32_t o) {
+    const uint32_t wq = o >> 5, r = o & 31u;
+    uint32_t word = wq > 0u ? m.m1 : m.m0, full = wq > 0u ? s.p1 : 0u;
+    word = wq > 1u ? m.m2 : word;
+    full = wq > 1u ? s.p2 : full;
+    word = wq > 2u ? m.m3 : word;
+    full = wq > 2u ? s.p3 : full;
+    full = wq > 3u ? s.p4 : full;                   // (o == 128: r == 0, the masked word counts nothing)
+    return full + __popc(word & ((1u << r) - 1u));
+}
+// the last step's rows: bits [lo, hi) of a 128-row block as four words
+__device__ __forceinline__ Match row_range(int lo, int hi) {
+    Match r;
+    r.m0 = prefix32(hi) & ~prefix32(lo);
+    r.m1 = prefix32(hi - 32) & ~prefix32(lo - 32);
+    r.m2 = prefix32(hi - 64) & ~prefix32(lo - 64);
+    r.m3 = prefix32(hi - 96) & ~prefix32(lo - 96);
+    return r;
 }
 // a row that is stored as 'A' but stands for no symbol (suffix starts 0 and 1) is not a row of any interval
-__device__ __forceinline__ void drop_row128(uint32_t row, uint32_t blk, uint64_t& m_lo, uint64_t& m_hi) {
+__device__ __forceinline__ void drop_row128(uint32_t row, uint32_t blk, Match& m) {
     if ((row >> kBlockRowsLog2) == blk) {
-        const uint32_t b = row & 127u;
-        if (b < 64u) m_lo &= ~(1ull << b);
-        else m_hi &= ~(1ull << (b - 64u));
+        const uint32_t b = row & 127u, bit = ~(1u << (b & 31u));
+        if (b < 32u) m.m0 &= bit;
+        else if (b < 64u) m.m1 &= bit;
+        else if (b < 96u) m.m2 &= bit;
+        else m.m3 &= bit;
+    }
+}
+// first selected row's bit of the pre-mapped mask plane (2 | bit), or 0 when no row is selected
+__device__ __forceinline__ uint32_t first_row_bit(const Match& sel, const Match& K) {
+    if (sel.m0) return 2u | ((K.m0 >> (__ffs(static_cast<int>(sel.m0)) - 1)) & 1u);
+    if (sel.m1) return 2u | ((K.m1 >> (__ffs(static_cast<int>(sel.m1)) - 1)) & 1u);
+    if (sel.m2) return 2u | ((K.m2 >> (__ffs(static_cast<int>(sel.m2)) - 1)) & 1u);
+    if (sel.m3) return 2u | ((K.m3 >> (__ffs(static_cast<int>(sel.m3)) - 1)) & 1u);
+    return 0u;
+}
+
+// what a lane carries from round to round
+struct Search {
+    uint64_t key;     // the bases still to go, left-aligned
+    uint32_t i, j;    // the interval (i == j == 0 for a lane without a search)
+    bool alive;
+    int res;          // the ternary once the last step has folded it
+};
+
+// One lock-step round: a pair step (SINGLE: the one single-base step of an odd k) for every live lane of the wave.  LAST: the k-mer's
+// last step, which also answers the search when the block(s) at hand cover the interval.
+template <bool SINGLE, bool LAST, bool COUNT>
+__device__ __forceinline__ void walk_round(const PairIndex& ix, const uint32_t* s_c2, uint4* lines, const uint4* L4, uint32_t ln, uint32_t mode_all, Search& q,
+                                           uint32_t& n_steps, uint32_t& n_blocks) {
+    const uint32_t* L = reinterpret_cast<const uint32_t*>(L4);
+    const char* pbase = reinterpret_cast<const char*>(ix.pb);
+    const uint32_t piece16 = (ln & 7u) * 16u, grp = ln >> 3, piece = ln & 7u;
+    const uint32_t p = SINGLE ? (static_cast<uint32_t>(q.key >> 62) << 2) : static_cast<uint32_t>(q.key >> 60);
+    const uint32_t bi = q.i >> kBlockRowsLog2, bj = (q.j - 1u) >> kBlockRowsLog2;
+    const bool two = q.alive && bj != bi;
+    const bool any_two = __any(two);
+    // byte offsets of the lines (a lane without a search, or without a second line, asks for a line that is at hand anyway: no predicates)
+    const uint32_t off_a = q.alive ? (bi << 7) : 0u;
+    const uint32_t off_b = two ? (bj << 7) : off_a;
+    // superblock counts and C2 (small tables: cache resident)
+    uint32_t sbi, sbj, cbase;
+    if (SINGLE) {
+        const uint4 si = *reinterpret_cast<const uint4*>(ix.sbt + ((q.i >> kSuperLog2) << 4) + (p & 12u));
+        const uint4 sj = *reinterpret_cast<const uint4*>(ix.sbt + (((q.j - 1u) >> kSuperLog2) << 4) + (p & 12u));
+        sbi = si.x + si.y + si.z + si.w;
+        sbj = sj.x + sj.y + sj.z + sj.w;
+        cbase = sel4(p >> 2, ix.C0, ix.C1, ix.C2_, ix.C3);
+    } else {
+        sbi = ix.sbt[((q.i >> kSuperLog2) << 4) + p];
+        sbj = any_two ? ix.sbt[(((q.j - 1u) >> kSuperLog2) << 4) + p] : sbi;
+        cbase = s_c2[p];
+    }
+    // ---- the lines: eight lanes per line, eight lines per instruction ----
+    uint4 va[8];
+#pragma unroll
+    for (uint32_t g = 0; g < 8; ++g) {
+        const uint32_t o = static_cast<uint32_t>(__shfl(static_cast<int>(off_a), static_cast<int>(8u * g + grp), 64));
+        va[g] = *reinterpret_cast<const uint4*>(pbase + static_cast<uint64_t>(o + piece16));
+    }
+#pragma unroll
+    for (uint32_t g = 0; g < 8; ++g) lines[(8u * g + grp) * kLinePitch + piece] = va[g];
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t oi = q.i & (kBlockRows - 1u), oj = q.j - (bj << kBlockRowsLog2);   // 0..127, 1..128
+    const Match ma = block_match<SINGLE>(L4, p);
+    const MatchSums sa = match_sums(ma);
+    const uint32_t cnt_a = block_count<SINGLE>(L, p);
+    uint32_t ri = cnt_a + rows_below(ma, sa, oi);
+    uint32_t rj;
+    Match mb = ma;
+    Match ka{0, 0, 0, 0}, kb{0, 0, 0, 0};   // the pre-mapped mask planes of the two blocks (last step only)
+    if (LAST) {
+        ka.m0 = L[8]; ka.m1 = L[9]; ka.m2 = L[24]; ka.m3 = L[25];
+    }
+    if (any_two) {   // (the second lines in a pass of their own: rare once the walk is below the top of the tree, and no registers held for it)
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (uint32_t g = 0; g < 8; ++g) {
+            const uint32_t o = static_cast<uint32_t>(__shfl(static_cast<int>(off_b), static_cast<int>(8u * g + grp), 64));
+            va[g] = *reinterpret_cast<const uint4*>(pbase + static_cast<uint64_t>(o + piece16));
+        }
+#pragma unroll
+        for (uint32_t g = 0; g < 8; ++g) lines[(8u * g + grp) * kLinePitch + piece] = va[g];
+        __builtin_amdgcn_wave_barrier();
+        mb = block_match<SINGLE>(L4, p);
+        rj = block_count<SINGLE>(L, p) + rows_below(mb, match_sums(mb), oj);
+        if (LAST) {
+            kb.m0 = L[8]; kb.m1 = L[9]; kb.m2 = L[24]; kb.m3 = L[25];
+        }
+    } else {
+        rj = cnt_a + rows_below(ma, sa, oj);
+    }
+    __builtin_amdgcn_wave_barrier();   // (the next round's staging must not overtake this round's reads)
+    if (COUNT && q.alive) {
+        n_steps += SINGLE ? 1u : 2u;
+        n_blocks += two ? 2u : 1u;
+    }
+    // the last step also answers the search when the block(s) at hand cover the interval: the rows of [i, j) that match the pair ARE the
+    // new interval, in order, and the mask plane holds mask[LF2(row)] (src/fms_index.h:126-144)
+    int folded = -2;
+    if (LAST && q.alive && bj - bi <= 1u) {
+        Match ra = row_range(static_cast<int>(oi), two ? 128 : static_cast<int>(oj));
+        ra.m0 &= ma.m0; ra.m1 &= ma.m1; ra.m2 &= ma.m2; ra.m3 &= ma.m3;
+        Match rb = row_range(0, two ? static_cast<int>(oj) : 0);
+        rb.m0 &= mb.m0; rb.m1 &= mb.m1; rb.m2 &= mb.m2; rb.m3 &= mb.m3;
+        drop_row128(ix.r0, bi, ra);
+        drop_row128(ix.r1, bi, ra);
+        drop_row128(ix.r0, bj, rb);
+        drop_row128(ix.r1, bj, rb);
+        if (mode_all) {   // the mask bit of the interval's first row
+            uint32_t h = first_row_bit(ra, ka);
+            if (!h) h = first_row_bit(rb, kb);
+            if (h) folded = static_cast<int>(h & 1u);
+        } else if (ra.m0 | ra.m1 | ra.m2 | ra.m3 | rb.m0 | rb.m1 | rb.m2 | rb.m3) {   // any ON row in the interval
+            folded = ((ra.m0 & ka.m0) | (ra.m1 & ka.m1) | (ra.m2 & ka.m2) | (ra.m3 & ka.m3) | (rb.m0 & kb.m0) | (rb.m1 & kb.m1) | (rb.m2 & kb.m2) |
+                      (rb.m3 & kb.m3))
+                         ? 1
+                         : 0;
+        }
+    }
+    ri += sbi;
+    rj += sbj;
+    if (SINGLE) {
+        if (p == 0u) {   // the '$' slot is stored as c1 = 'A' (src/fms_index.h:81)
+            ri -= (q.i > ix.r0);
+            rj -= (q.j > ix.r0);
+        }
+        q.key <<= 2;
+    } else {
+        if (p == 0u) {   // '$' slot stored as (A, A)
+            ri -= (q.i > ix.r0);
+            rj -= (q.j > ix.r0);
+        }
+        if (p == ix.p1) {   // the row of suffix 1 has no c2: stored as (A, T[0])
+            ri -= (q.i > ix.r1);
+            rj -= (q.j > ix.r1);
+        }
+        q.key <<= 4;
+    }
+    if (q.alive) {
+        q.i = cbase + ri;
+        q.j = cbase + rj;
+        if (q.i == q.j) {
+            q.alive = false;          // absent: the ternary array's zero fill says so
+            q.i = q.j = 0;
+        } else if (LAST && folded >= 0) {
+            q.res = folded;
+            q.alive = false;
+            q.i = q.j = 0;
+        }
     }
 }
 
@@ -137,15 +336,12 @@ __global__ __launch_bounds__(256) void sorted_walk_kernel(PairIndex ix, WalkArgs
     const uint32_t ln = threadIdx.x & 63u;
     uint4* lines = s_line[threadIdx.x >> 6];
     const uint4* L4 = lines + ln * kLinePitch;
-    const uint32_t* L = reinterpret_cast<const uint32_t*>(L4);
-    const uint4* pb4 = reinterpret_cast<const uint4*>(ix.pb);
     const uint64_t wave = (static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
-    const uint32_t piece = ln & 7u, grp = ln >> 3;
     uint32_t n_steps = 0, n_blocks = 0, n_probes = 0, n_items = 0;
 
-    // the second launch takes the survivors of kJoin waves of the first, 64 at a time
+    // a launch over the hand-over slots takes the survivors of kJoin waves of the launch before, 64 at a time
     uint32_t c0 = 0, c1n = 0, total = 0;
-    if (a.second) {
+    if (a.src == kSrcHandover) {
         const uint64_t w0 = wave * kJoin;
         if (w0 >= a.n_waves_a) return;
         c0 = a.h_count[w0];
@@ -158,205 +354,87 @@ __global__ __launch_bounds__(256) void sorted_walk_kernel(PairIndex ix, WalkArgs
     }
 
     for (uint32_t at = 0; at < total; at += 64u) {
-        // ---- this pass's items ----
-        uint64_t key = 0;
-        uint32_t i = 0, j = 0, val = 0;
-        bool alive = false;
+        // ---- this pass's searches ----
+        Search q;
+        q.key = 0;
+        q.i = q.j = 0;
+        q.alive = false;
+        q.res = -1;
+        uint32_t val = 0;
         const uint32_t me = at + ln;
         if (me < total) {
-            alive = true;
-            if (a.second) {
+            if (a.src == kSrcHandover) {
                 const uint32_t r = me < c0 ? 0u : (me < c0 + c1n ? 1u : 2u);
                 const uint64_t slot = (wave * kJoin + r) * 64u + (me - (r == 0u ? 0u : (r == 1u ? c0 : c0 + c1n)));
-                key = a.h_key[slot];
+                q.key = a.h_key[slot];
                 const uint2 ij = a.h_ij[slot];
-                i = ij.x;
-                j = ij.y;
+                q.i = ij.x;
+                q.j = ij.y;
                 val = a.h_val[slot];
             } else {
                 const uint64_t it = wave * 64u + me;
-                key = a.keys[it];
-                val = a.vals[it];
-                i = 0;
-                j = ix.n;
+                if (a.src == kSrcTable) {
+                    q.key = it << (64u - 2u * a.out_bases);
+                    val = static_cast<uint32_t>(it);
+                } else {
+                    q.key = a.keys[it];
+                    val = a.vals[it];
+                }
+                q.i = 0;
+                q.j = ix.n;
+                if (a.top) {   // the first top_bases bases were walked once for the whole batch
+                    const uint2 ij = a.top[q.key >> (64u - 2u * a.top_bases)];
+                    q.i = ij.x;
+                    q.j = ij.y;
+                    q.key <<= 2u * a.top_bases;
+                }
             }
-            if (COUNT && !a.second) n_items++;
+            q.alive = q.i != q.j;
+            if (COUNT && a.src == kSrcItems) n_items++;
         }
-        int res = -1;          // the item's ternary once it is known
-        bool answered = false;
         uint32_t left = a.left0;
-        while (left > a.stop_left) {
-            if (!__any(alive)) break;
-            const bool single = (left & 1u) != 0u;   // an odd number of bases to go: one single-base step first
-            const uint32_t c1 = static_cast<uint32_t>(key >> 62);
-            const uint32_t c2 = single ? 0u : (static_cast<uint32_t>(key >> 60) & 3u);
-            const uint32_t p = c2 | (c1 << 2);
-            const uint32_t bi = i >> kBlockRowsLog2, bj = (j - 1u) >> kBlockRowsLog2;
-            const bool two = alive && bj != bi;
-            const uint64_t line_mask = __ballot(alive);
-            const uint64_t two_mask = __ballot(two);
-            // superblock counts and C2 (small tables: cache resident)
-            uint32_t sbi = 0, sbj = 0, cbase = 0;
-            if (alive) {
-                if (single) {
-                    const uint4 si = *reinterpret_cast<const uint4*>(ix.sbt + ((static_cast<size_t>(i >> kSuperLog2)) << 4) + (p & 12u));
-                    sbi = si.x + si.y + si.z + si.w;
-                    sbj = sbi;
-                    if (two) {
-                        const uint4 sj = *reinterpret_cast<const uint4*>(ix.sbt + ((static_cast<size_t>((j - 1u) >> kSuperLog2)) << 4) + (p & 12u));
-                        sbj = sj.x + sj.y + sj.z + sj.w;
-                    }
-                    cbase = sel4(c1, ix.C0, ix.C1, ix.C2_, ix.C3);
-                } else {
-                    sbi = ix.sbt[((static_cast<size_t>(i >> kSuperLog2)) << 4) + p];
-                    sbj = two ? ix.sbt[((static_cast<size_t>((j - 1u) >> kSuperLog2)) << 4) + p] : sbi;
-                    cbase = s_c2[p];
-                }
-            }
-            // ---- the lines: eight lanes per line, eight lines per instruction ----
-            uint4 va[8], vb[8];
-#pragma unroll
-            for (uint32_t g = 0; g < 8; ++g) {
-                const uint32_t owner = 8u * g + grp;
-                const uint32_t bo = static_cast<uint32_t>(__shfl(static_cast<int>(bi), static_cast<int>(owner), 64));
-                va[g] = make_uint4(0, 0, 0, 0);
-                if ((line_mask >> owner) & 1ull) va[g] = pb4[(static_cast<size_t>(bo) << 3) + piece];
-            }
-            if (two_mask) {
-#pragma unroll
-                for (uint32_t g = 0; g < 8; ++g) {
-                    const uint32_t owner = 8u * g + grp;
-                    const uint32_t bo = static_cast<uint32_t>(__shfl(static_cast<int>(bj), static_cast<int>(owner), 64));
-                    vb[g] = make_uint4(0, 0, 0, 0);
-                    if ((two_mask >> owner) & 1ull) vb[g] = pb4[(static_cast<size_t>(bo) << 3) + piece];
-                }
-            }
-#pragma unroll
-            for (uint32_t g = 0; g < 8; ++g) lines[(8u * g + grp) * kLinePitch + piece] = va[g];
-            __builtin_amdgcn_wave_barrier();
-            const int oi = static_cast<int>(i & (kBlockRows - 1u)), oj = static_cast<int>(j - (bj << kBlockRowsLog2));   // 0..127, 1..128
-            uint64_t ma_lo = 0, ma_hi = 0, mb_lo = 0, mb_hi = 0;
-            uint64_t ka_lo = 0, ka_hi = 0, kb_lo = 0, kb_hi = 0;   // pre-mapped mask planes (last step only)
-            const bool last = !single && left == 2u;
-            uint32_t ri = 0, rj = 0;
-            if (alive) {
-                block_match(L4, p, single, ma_lo, ma_hi);
-                const uint32_t cnt = block_count(L, p, single);
-                const uint32_t below_i = rows_below(ma_lo, ma_hi, oi);
-                ri = cnt + below_i;
-                if (!two) rj = cnt + rows_below(ma_lo, ma_hi, oj);
-                if (last) {
-                    ka_lo = *reinterpret_cast<const uint64_t*>(L + 8);
-                    ka_hi = *reinterpret_cast<const uint64_t*>(L + 24);
-                }
-            }
-            if (two_mask) {
-                __builtin_amdgcn_wave_barrier();
-#pragma unroll
-                for (uint32_t g = 0; g < 8; ++g) lines[(8u * g + grp) * kLinePitch + piece] = vb[g];
-                __builtin_amdgcn_wave_barrier();
-                if (two) {
-                    block_match(L4, p, single, mb_lo, mb_hi);
-                    rj = block_count(L, p, single) + rows_below(mb_lo, mb_hi, oj);
-                    if (last) {
-                        kb_lo = *reinterpret_cast<const uint64_t*>(L + 8);
-                        kb_hi = *reinterpret_cast<const uint64_t*>(L + 24);
-                    }
-                }
-            }
-            __builtin_amdgcn_wave_barrier();   // (the next round's staging must not overtake this round's reads)
-            if (alive) {
-                if (COUNT) {
-                    n_steps += single ? 1u : 2u;
-                    n_blocks += two ? 2u : 1u;
-                }
-                // the last step also answers the search when the block(s) at hand cover the interval: the rows of [i, j) that match
-                // the pair ARE the new interval, in order, and the mask plane holds mask[LF2(row)] (src/fms_index.h:126-144)
-                int folded = -2;
-                if (last && bj - bi <= 1u) {
-                    uint64_t sa_lo = ma_lo & ~below64s(oi), sa_hi = ma_hi & ~below64s(oi - 64), sb_lo = 0, sb_hi = 0;
-                    if (two) {
-                        sb_lo = mb_lo & below64s(oj);
-                        sb_hi = mb_hi & below64s(oj - 64);
-                    } else {
-                        sa_lo &= below64s(oj);
-                        sa_hi &= below64s(oj - 64);
-                    }
-                    drop_row128(ix.r0, bi, sa_lo, sa_hi);
-                    drop_row128(ix.r1, bi, sa_lo, sa_hi);
-                    drop_row128(ix.r0, bj, sb_lo, sb_hi);
-                    drop_row128(ix.r1, bj, sb_lo, sb_hi);
-                    if (a.mode_all) {   // the mask bit of the interval's first row
-                        if (sa_lo) folded = static_cast<int>((ka_lo >> (__ffsll(static_cast<unsigned long long>(sa_lo)) - 1)) & 1ull);
-                        else if (sa_hi) folded = static_cast<int>((ka_hi >> (__ffsll(static_cast<unsigned long long>(sa_hi)) - 1)) & 1ull);
-                        else if (sb_lo) folded = static_cast<int>((kb_lo >> (__ffsll(static_cast<unsigned long long>(sb_lo)) - 1)) & 1ull);
-                        else if (sb_hi) folded = static_cast<int>((kb_hi >> (__ffsll(static_cast<unsigned long long>(sb_hi)) - 1)) & 1ull);
-                    } else if (sa_lo | sa_hi | sb_lo | sb_hi) {   // any ON row in the interval
-                        folded = ((sa_lo & ka_lo) | (sa_hi & ka_hi) | (sb_lo & kb_lo) | (sb_hi & kb_hi)) ? 1 : 0;
-                    }
-                }
-                ri += sbi;
-                rj += sbj;
-                if (single) {
-                    if (c1 == 0u) {   // the '$' slot is stored as c1 = 'A' (src/fms_index.h:81)
-                        ri -= (i > ix.r0);
-                        rj -= (j > ix.r0);
-                    }
-                    key <<= 2;
-                } else {
-                    if (p == 0u) {    // '$' slot stored as (A, A)
-                        ri -= (i > ix.r0);
-                        rj -= (j > ix.r0);
-                    }
-                    if (p == ix.p1) {   // the row of suffix 1 has no c2: stored as (A, T[0])
-                        ri -= (i > ix.r1);
-                        rj -= (j > ix.r1);
-                    }
-                    key <<= 4;
-                }
-                i = cbase + ri;
-                j = cbase + rj;
-                if (i == j) {
-                    alive = false;          // absent: the array's zero fill says so
-                    answered = true;
-                } else if (folded >= 0) {
-                    res = folded;
-                    alive = false;
-                    answered = true;
-                }
-            }
-            left -= single ? 1u : 2u;
+        if ((left & 1u) && left > a.stop_left && __any(q.alive)) {   // an odd number of bases to go: one single-base step first
+            walk_round<true, false, COUNT>(ix, s_c2, lines, L4, ln, a.mode_all, q, n_steps, n_blocks);
+            left -= 1u;
+        }
+        const uint32_t fold_at = a.sink == kSinkResults ? 2u : 0u;      // the k-mer's last pair step folds the answer
+        while (left > a.stop_left + fold_at && __any(q.alive)) {
+            walk_round<false, false, COUNT>(ix, s_c2, lines, L4, ln, a.mode_all, q, n_steps, n_blocks);
+            left -= 2u;
+        }
+        if (fold_at && left == 2u && __any(q.alive)) {
+            walk_round<false, true, COUNT>(ix, s_c2, lines, L4, ln, a.mode_all, q, n_steps, n_blocks);
+            left = 0;
         }
         // ---- what is left of this pass ----
-        if (a.stop_left) {
-            // hand the survivors over: dense in this wave's slots (none when the wave's last search died before the cut)
-            const uint64_t m = __ballot(alive);
-            if (alive) {
+        if (a.sink == kSinkHandover) {
+            // the survivors: dense in this wave's slots (none when the wave's last search died before the cut)
+            const uint64_t m = __ballot(q.alive);
+            if (q.alive) {
                 const uint64_t slot = wave * 64u + lanes_below(m);
-                a.h_key[slot] = key;
-                a.h_ij[slot] = make_uint2(i, j);
+                a.h_key[slot] = q.key;
+                a.h_ij[slot] = make_uint2(q.i, q.j);
                 a.h_val[slot] = val;
             }
             if (ln == 0u) a.h_count[wave] = static_cast<uint32_t>(__popcll(m));
-        } else {
-            if (alive) {
-                // a non-empty interval that the last step could not answer (more than two blocks, or k == 1): the single-step layout's
-                // mask plane / rank directory (infer_presence, src/fms_index.h:126-144)
-                const uint32_t bi = i >> kBlockRowsLog2, o = i & (kBlockRows - 1u);
-                const uint4 mi = ix.sblocks[(static_cast<size_t>(bi) << 2) + 3u];
-                if (a.mode_all) {
-                    const uint32_t mw = sel4(o >> 5, opaque(mi.x), opaque(mi.y), opaque(mi.z), opaque(mi.w));
-                    res = static_cast<int>((mw >> (o & 31u)) & 1u);
-                } else {
-                    const uint32_t bj = (j - 1u) >> kBlockRowsLog2, oj = j - (bj << kBlockRowsLog2);
-                    const uint4 mj = ix.sblocks[(static_cast<size_t>(bj) << 2) + 3u];
-                    res = (ix.mrank[bj] + popc_prefix128(mj, oj)) > (ix.mrank[bi] + popc_prefix128(mi, o));
-                }
-                answered = true;
+        } else if (a.sink == kSinkTable) {
+            if (me < total) a.top_out[val] = make_uint2(q.i, q.j);   // ((0, 0) when the entry's interval is empty)
+        } else if (q.alive) {
+            // a non-empty interval that the last step could not answer (more than two blocks, or k == 1): the single-step layout's
+            // mask plane / rank directory (infer_presence, src/fms_index.h:126-144)
+            const uint32_t bi = q.i >> kBlockRowsLog2, o = q.i & (kBlockRows - 1u);
+            const uint4 mi = ix.sblocks[(static_cast<size_t>(bi) << 2) + 3u];
+            if (a.mode_all) {
+                const uint32_t mw = sel4(o >> 5, opaque(mi.x), opaque(mi.y), opaque(mi.z), opaque(mi.w));
+                q.res = static_cast<int>((mw >> (o & 31u)) & 1u);
+            } else {
+                const uint32_t bj = (q.j - 1u) >> kBlockRowsLog2, oj = q.j - (bj << kBlockRowsLog2);
+                const uint4 mj = ix.sblocks[(static_cast<size_t>(bj) << 2) + 3u];
+                q.res = (ix.mrank[bj] + popc_prefix128(mj, oj)) > (ix.mrank[bi] + popc_prefix128(mi, o));
             }
         }
-        if (answered && res >= 0) {
-            a.tern[val] = static_cast<uint8_t>(res + 1);
+        if (q.res >= 0) {
+            a.tern[val] = static_cast<uint8_t>(q.res + 1);
             if (COUNT) n_probes++;
         }
     }
@@ -364,10 +442,10 @@ __global__ __launch_bounds__(256) void sorted_walk_kernel(PairIndex ix, WalkArgs
         uint32_t v[4] = {n_steps, n_blocks, n_probes, n_items};
         const int slot[4] = {0, 1, 2, 3};
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            uint32_t x = v[q];
+        for (int qq = 0; qq < 4; ++qq) {
+            uint32_t x = v[qq];
             for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
-            if (ln == 0 && x) atomicAdd(&counters[slot[q]], static_cast<unsigned long long>(x));
+            if (ln == 0 && x) atomicAdd(&counters[slot[qq]], static_cast<unsigned long long>(x));
         }
     }
 }
@@ -388,16 +466,40 @@ __global__ __launch_bounds__(256) void sw_combine_kernel(const uint16_t* __restr
     if (COUNT && (q & 63u) == 0u) atomicAdd(&counters[6], static_cast<unsigned long long>(min(static_cast<uint64_t>(64), n - q)));
 }
 
+// depths of the batch's transient top-of-tree levels (0 = none): D2 = the deepest level with at least one search per entry on average
+// (at most 13 bases: 4^13 intervals are 537 MB), D1 four bases above it; both of k's parity, so that the walk's one single-base step --
+// taken first when k is odd -- falls into the first level and everything below it is pair steps
+void top_depths(uint64_t items, int k, uint32_t& d1, uint32_t& d2) {
+    d1 = d2 = 0;
+    static const bool off = std::getenv("FMSI_HIP_SORTED_NO_TOP") != nullptr;   // (measurements)
+    if (off) return;
+    uint32_t d = 0;
+    while (d + 2 <= 14 && (1ull << (2 * (d + 2))) <= items) d += 2;
+    if ((static_cast<uint32_t>(k) & 1u) && d > 0) d -= 1;       // odd k: odd depths
+    d = std::min(d, 13u - ((static_cast<uint32_t>(k) & 1u) ? 0u : 1u));
+    if (d < 3 || static_cast<uint32_t>(k) < d + 4) return;
+    d2 = d;
+    if (d >= 7) d1 = d - 4;
+}
+
 template <bool COUNT>
 int launch_sorted_t(fmsi_hip_index* idx, const uint64_t* d_kmers, uint64_t n, int k, uint32_t flags, uint8_t* o8, unsigned long long* d_counters, hipStream_t s) {
     const uint64_t items = 2 * n;
     const uint64_t waves_a = (items + 63) / 64;
+    uint32_t d1 = 0, d2 = 0;
+    top_depths(items, k, d1, d2);
     // scratch: two key / value buffers (the sort's double buffers; the hand-over reuses the spare ones), (i, j) per hand-over slot, the
-    // ternaries, the sort's own temporary storage
-    const int sort_bases = std::min(k, 16);
+    // ternaries, the top-of-tree levels, the sort's own temporary storage
+    // sorted by their first 12 bases: three radix passes.  What the order has to deliver is (a) neighbouring lanes under one entry of the
+    // deepest top level (13 bases at most) and (b) the lines of the first step below it shared inside a wave; 16 bases (a fourth pass,
+    // +2.0 ms per 2^28 items) bought 0.3 ms of walk at human scale, 8 bases lost 0.8 ms (profiles/r04f_*)
+    static const char* sort_env = std::getenv("FMSI_HIP_SORTED_BASES");   // (measurements)
+    const int sort_bases = std::min(k, sort_env ? std::max(1, std::atoi(sort_env)) : 12);
     const unsigned begin_bit = 64u - 2u * static_cast<unsigned>(sort_bases), end_bit = 64u;
     auto round_up = [](size_t x) { return (x + 255) & ~size_t(255); };
-    const size_t key_b = round_up(items * 8), val_b = round_up(items * 4), ij_b = round_up(waves_a * 64 * 8), tern_b = round_up(items), cnt_b = round_up(waves_a * 4);
+    const size_t key_b = round_up(waves_a * 64 * 8), val_b = round_up(waves_a * 64 * 4), ij_b = round_up(waves_a * 64 * 8), tern_b = round_up(items),
+                 cnt_b = round_up(waves_a * 4);
+    const size_t top1_b = d1 ? round_up((size_t(1) << (2 * d1)) * 8) : 0, top2_b = d2 ? round_up((size_t(1) << (2 * d2)) * 8) : 0;
     size_t temp_b = 0;
     {
         rocprim::double_buffer<uint64_t> dk(nullptr, nullptr);
@@ -405,27 +507,25 @@ int launch_sorted_t(fmsi_hip_index* idx, const uint64_t* d_kmers, uint64_t n, in
         SW_TRY(rocprim::radix_sort_pairs<SortConfig>(nullptr, temp_b, dk, dv, static_cast<size_t>(items), begin_bit, end_bit, s));
     }
     temp_b = round_up(temp_b);
-    const size_t need = 2 * round_up(waves_a * 64 * 8) + 2 * round_up(waves_a * 64 * 4) + ij_b + tern_b + cnt_b + temp_b;
-    (void)key_b;
-    (void)val_b;
+    const size_t need = 2 * key_b + 2 * val_b + ij_b + tern_b + cnt_b + top1_b + top2_b + temp_b;
     int rc = ensure_cap(&idx->d_sorted, &idx->d_sorted_cap, need);
     if (rc) return rc;
     char* base = static_cast<char*>(idx->d_sorted);
-    uint64_t* keys0 = reinterpret_cast<uint64_t*>(base);
-    base += round_up(waves_a * 64 * 8);
-    uint64_t* keys1 = reinterpret_cast<uint64_t*>(base);
-    base += round_up(waves_a * 64 * 8);
-    uint32_t* vals0 = reinterpret_cast<uint32_t*>(base);
-    base += round_up(waves_a * 64 * 4);
-    uint32_t* vals1 = reinterpret_cast<uint32_t*>(base);
-    base += round_up(waves_a * 64 * 4);
-    uint2* ij = reinterpret_cast<uint2*>(base);
-    base += ij_b;
-    uint8_t* tern = reinterpret_cast<uint8_t*>(base);
-    base += tern_b;
-    uint32_t* h_count = reinterpret_cast<uint32_t*>(base);
-    base += cnt_b;
-    void* temp = base;
+    auto carve = [&](size_t bytes) {
+        char* p = base;
+        base += bytes;
+        return p;
+    };
+    uint64_t* keys0 = reinterpret_cast<uint64_t*>(carve(key_b));
+    uint64_t* keys1 = reinterpret_cast<uint64_t*>(carve(key_b));
+    uint32_t* vals0 = reinterpret_cast<uint32_t*>(carve(val_b));
+    uint32_t* vals1 = reinterpret_cast<uint32_t*>(carve(val_b));
+    uint2* ij = reinterpret_cast<uint2*>(carve(ij_b));
+    uint8_t* tern = reinterpret_cast<uint8_t*>(carve(tern_b));
+    uint32_t* h_count = reinterpret_cast<uint32_t*>(carve(cnt_b));
+    uint2* top1 = reinterpret_cast<uint2*>(carve(top1_b));
+    uint2* top2 = reinterpret_cast<uint2*>(carve(top2_b));
+    void* temp = carve(temp_b);
 
     hipLaunchKernelGGL(sw_items_kernel, dim3(static_cast<uint32_t>((n + 255) / 256)), dim3(256), 0, s, d_kmers, n, k, reinterpret_cast<ulonglong2*>(keys0),
                        reinterpret_cast<uint2*>(vals0));
@@ -437,38 +537,66 @@ int launch_sorted_t(fmsi_hip_index* idx, const uint64_t* d_kmers, uint64_t n, in
     if (!no_sort) SW_TRY(rocprim::radix_sort_pairs<SortConfig>(temp, temp_b, dk, dv, static_cast<size_t>(items), begin_bit, end_bit, s));
 
     const PairIndex pix = make_pair_index(idx);
-    // where to cut: the absent searches have died out a couple of bases past log4(rows)
-    uint32_t bases_a = static_cast<uint32_t>(std::ceil(std::log(static_cast<double>(std::max<uint64_t>(idx->n, 4))) / std::log(4.0))) + 2u;
-    static const char* cut_env = std::getenv("FMSI_HIP_SORTED_CUT");   // (measurements: bases walked by the first launch; 0 = one launch)
-    if (cut_env) bases_a = static_cast<uint32_t>(std::atoi(cut_env));
-    uint32_t stop_left = 0;
-    if (bases_a != 0 && static_cast<uint32_t>(k) > bases_a + 3u) {
-        stop_left = static_cast<uint32_t>(k) - bases_a;
-        stop_left &= ~1u;                // pair steps from there on
-    }
+    auto launch = [&](const WalkArgs& w, uint64_t waves) {
+        hipLaunchKernelGGL((sorted_walk_kernel<COUNT>), dim3(static_cast<uint32_t>((waves + 3) / 4)), dim3(256), 0, s, pix, w, d_counters);
+    };
     WalkArgs a{};
-    a.keys = dk.current();
-    a.vals = dv.current();
-    a.n_items = items;
     a.h_key = dk.alternate();
     a.h_ij = ij;
     a.h_val = dv.alternate();
     a.h_count = h_count;
-    a.n_waves_a = waves_a;
     a.tern = tern;
-    a.left0 = static_cast<uint32_t>(k);
-    a.stop_left = stop_left;
-    a.second = 0;
     a.mode_all = (flags & FMSI_HIP_MODE_ALL) ? 1u : 0u;
-    hipLaunchKernelGGL((sorted_walk_kernel<COUNT>), dim3(static_cast<uint32_t>((waves_a + 3) / 4)), dim3(256), 0, s, pix, a, d_counters);
+    // ---- the top of the search tree, once for the batch ----
+    const uint2* top = nullptr;
+    uint32_t top_bases = 0;
+    for (int lv = 0; lv < 2; ++lv) {
+        const uint32_t d = lv == 0 ? d1 : d2;
+        if (!d) continue;
+        WalkArgs t = a;
+        t.src = kSrcTable;
+        t.sink = kSinkTable;
+        t.n_items = 1ull << (2 * d);
+        t.top = top;
+        t.top_bases = top_bases;
+        t.top_out = lv == 0 ? top1 : top2;
+        t.out_bases = d;
+        t.left0 = d - top_bases;
+        t.stop_left = 0;
+        launch(t, (t.n_items + 63) / 64);
+        SW_TRY(hipGetLastError());
+        top = t.top_out;
+        top_bases = d;
+    }
+    // ---- the items: to where the absent searches have died out (a few bases past log4(rows)), the survivors to the end ----
+    uint32_t bases_a = static_cast<uint32_t>(std::ceil(std::log(static_cast<double>(std::max<uint64_t>(idx->n, 4))) / std::log(4.0))) + 3u;
+    static const char* cut_env = std::getenv("FMSI_HIP_SORTED_CUT");   // (measurements: bases walked before the cut; 0 = no cut)
+    if (cut_env) bases_a = static_cast<uint32_t>(std::atoi(cut_env));
+    uint32_t stop_left = 0;
+    if (bases_a != 0 && static_cast<uint32_t>(k) > bases_a + 3u && bases_a > top_bases) {
+        stop_left = static_cast<uint32_t>(k) - bases_a;
+        stop_left &= ~1u;                // pair steps from there on
+    }
+    a.keys = dk.current();
+    a.vals = dv.current();
+    a.n_items = items;
+    a.n_waves_a = waves_a;
+    a.top = top;
+    a.top_bases = top_bases;
+    a.left0 = static_cast<uint32_t>(k) - top_bases;
+    a.stop_left = stop_left;
+    a.src = kSrcItems;
+    a.sink = stop_left ? kSinkHandover : kSinkResults;
+    launch(a, waves_a);
     SW_TRY(hipGetLastError());
     if (stop_left) {
         WalkArgs b = a;
+        b.top = nullptr;
         b.left0 = stop_left;
         b.stop_left = 0;
-        b.second = 1;
-        const uint64_t waves_b = (waves_a + kJoin - 1) / kJoin;
-        hipLaunchKernelGGL((sorted_walk_kernel<COUNT>), dim3(static_cast<uint32_t>((waves_b + 3) / 4)), dim3(256), 0, s, pix, b, d_counters);
+        b.src = kSrcHandover;
+        b.sink = kSinkResults;
+        launch(b, (waves_a + kJoin - 1) / kJoin);
         SW_TRY(hipGetLastError());
     }
     hipLaunchKernelGGL((sw_combine_kernel<COUNT>), dim3(static_cast<uint32_t>((n + 255) / 256)), dim3(256), 0, s, reinterpret_cast<const uint16_t*>(tern), n, flags, o8,

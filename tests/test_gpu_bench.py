@@ -38,7 +38,9 @@ def test_default_bench_line_is_parseable_by_the_driver(fm):
     r = d["roofline"]
     assert r and r["bound"] == "hbm" and r["peak"] == 8000.0 and 0 < r["frac"] < 1 and r["kernel"] and r["avg_kernel_ms"] <= d["ms_per_step"]
     assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["avg_kernel_ms"] * 1e-3) / 1e9) / r["achieved"] < 0.01
-    assert len(r["lf_path"]) == 2 and all(l["kmers_per_s"] > 1e8 for l in r["lf_path"])
+    assert [l["kernel"].split("<")[0] for l in r["lf_path"]] == ["sorted_walk_kernel", "query_pair_kernel", "query_lockstep_kernel"]
+    assert all(l["kmers_per_s"] > 1e9 and l["hbm_lines_per_kmer"] > 0 for l in r["lf_path"])
+    assert r["lf_path"][0]["kmers_per_s"] > r["lf_path"][1]["kmers_per_s"] > r["lf_path"][2]["kmers_per_s"]
     c = d["cpu_baseline"]
     assert c and c["value"] > 0 and c["cores"] == 1 and c["kind"] == "reference" and c["matches_gpu"] is True and c["sample"]
     names = [l["name"] for l in d["configs"]]
