@@ -208,7 +208,8 @@ __device__ __forceinline__ void walk_round(const PairIndex& ix, const uint32_t* 
     const char* pbase = reinterpret_cast<const char*>(ix.pb);
     const uint32_t piece16 = (ln & 7u) * 16u, grp = ln >> 3, piece = ln & 7u;
     const uint32_t p = SINGLE ? (static_cast<uint32_t>(q.key >> 62) << 2) : static_cast<uint32_t>(q.key >> 60);
-    const uint32_t bi = q.i >> kBlockRowsLog2, bj = (q.j - 1u) >> kBlockRowsLog2;
+    const uint32_t jm1 = q.alive ? q.j - 1u : 0u;   // (a lane without a search computes on row 0: every address it forms is valid)
+    const uint32_t bi = q.i >> kBlockRowsLog2, bj = jm1 >> kBlockRowsLog2;
     const bool two = q.alive && bj != bi;
     const bool any_two = __any(two);
     // byte offsets of the lines (a lane without a search, or without a second line, asks for a line that is at hand anyway: no predicates)
@@ -218,13 +219,13 @@ __device__ __forceinline__ void walk_round(const PairIndex& ix, const uint32_t* 
     uint32_t sbi, sbj, cbase;
     if (SINGLE) {
         const uint4 si = *reinterpret_cast<const uint4*>(ix.sbt + ((q.i >> kSuperLog2) << 4) + (p & 12u));
-        const uint4 sj = *reinterpret_cast<const uint4*>(ix.sbt + (((q.j - 1u) >> kSuperLog2) << 4) + (p & 12u));
+        const uint4 sj = *reinterpret_cast<const uint4*>(ix.sbt + ((jm1 >> kSuperLog2) << 4) + (p & 12u));
         sbi = si.x + si.y + si.z + si.w;
         sbj = sj.x + sj.y + sj.z + sj.w;
         cbase = sel4(p >> 2, ix.C0, ix.C1, ix.C2_, ix.C3);
     } else {
         sbi = ix.sbt[((q.i >> kSuperLog2) << 4) + p];
-        sbj = any_two ? ix.sbt[(((q.j - 1u) >> kSuperLog2) << 4) + p] : sbi;
+        sbj = any_two ? ix.sbt[((jm1 >> kSuperLog2) << 4) + p] : sbi;
         cbase = s_c2[p];
     }
     // ---- the lines: eight lanes per line, eight lines per instruction ----
