@@ -113,7 +113,7 @@ def parse_args(argv=None):
                     help="do not measure roofline.traffic in this run (child runs of this script under rocprofv3 --pmc, FETCH_SIZE and "
                          "WRITE_SIZE in separate passes)")
     ap.add_argument("--no-config-legs", action="store_true", help="skip the `configs` legs (BASELINE configs 2, 3, 4 and the whole process)")
-    ap.add_argument("--legs", default="c2,c3,c3sk,c4,c4sk,c5sk,e2e", help="which `configs` legs to run")
+    ap.add_argument("--legs", default="c2,c3,c3sk,c4,c4sk,e2e", help="which `configs` legs to run")
     ap.add_argument("--leg", default=None, help=argparse.SUPPRESS)          # child mode: one leg, a JSON list on stdout
     ap.add_argument("--variants", default=None, help="with --leg: only these variants of the leg (comma-separated names), e.g. for a rocprofv3 run of one")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)   # child mode under rocprofv3: the plan's launches, nothing printed
@@ -680,10 +680,10 @@ LEG_SPECS = {
                                                  ("c4_klcp", "klcp", 0), ("c4_klcp_subst1pct", "klcp", 10000)]),
     # the same reads through the super-k-mer dictionary ALONE (FMSI_HIP_DICT_SUPERKMER_ONLY: the k-mer dictionary is released after the
     # construction -- the handle is the index's blocks + the records + the small aux dictionary)
-    "c4sk": (2.8e9, "stream", float(1 << 27), 8, [("c4_superkmer", "runs_sk", 0), ("c4_superkmer_subst1pct", "runs_sk", 10000)]),
-    # configs 3 and 5 (isolated 31-mers) on the compact structure alone: what a handle of <= 20 GB answers them at
+    # ... and, on the same handle, config 5's per-GPU work (= the headline's): isolated 31-mers on the compact structure alone
+    "c4sk": (2.8e9, "stream", float(1 << 27), 8, [("c4_superkmer", "runs_sk", 0), ("c4_superkmer_subst1pct", "runs_sk", 10000), ("c5_superkmer", "dict_sk", 0)]),
+    # config 3 (isolated 31-mers, pangenome scale) on the compact structure alone
     "c3sk": (1.4e9, "kmers", float(1 << 27), 8, [("c3_superkmer", "dict_sk", 0)]),
-    "c5sk": (2.8e9, "kmers", float(1 << 27), 8, [("c5_superkmer", "dict_sk", 0)]),
 }
 LEG_TEXT = {
     "c2": "BASELINE config 2: E. coli single-genome scale (synthetic max-ones masked superstring n=4700000), k=31, 10^8 isolated random 31-mers per step "
@@ -697,7 +697,7 @@ LEG_TEXT = {
 LEG_TEXT["c4sk"] = LEG_TEXT["c4"]
 LEG_TEXT["c3sk"] = LEG_TEXT["c3"].replace("k-mer dictionary", "super-k-mer dictionary ALONE (the handle holds no k-mer dictionary: every k-mer is a one-window read, its minimizer's bucket "
                                           "one 128-byte read, heavy / overflowed ones the small aux dictionary)")
-LEG_TEXT["c5sk"] = ("BASELINE config 5's per-GPU work (and the headline's): human-genome scale (n=2800000000), k=31, 2^27 isolated random 31-mers per step x 8 steps (50% present), "
+LEG_TEXT["c5_superkmer"] = ("BASELINE config 5's per-GPU work (and the headline's): human-genome scale (n=2800000000), k=31, 2^27 isolated random 31-mers per step x 8 steps (50% present), "
                     "fmsi query -O semantics, super-k-mer dictionary ALONE (no k-mer dictionary in the handle)")
 VIA_TEXT = {"runs_chain": "fmsi_hip_query_runs, chained dictionary lookups (58.7 GB handle): a lane follows the superstring from its task's first window",
             "runs_plain": "fmsi_hip_query_runs, one dictionary bucket read per window (FMSI_HIP_NO_DICT_CHAIN)",
@@ -722,7 +722,7 @@ def run_leg(args):
     args.stream_via = "runs"
     sk_only = name.endswith("sk")
     if stream_mode and not sk_only:
-        args.prefix_len = 16   # (the kLCP kernel's fresh searches start from its 16-deep prefix table, as in the earlier rounds' runs; the dictionary paths do not use it)
+        args.prefix_len = 15   # (the kLCP kernel's fresh searches start from a 15-deep prefix table in its double-stranded form, 17 GB -- rounds 1-3: 16 deep, 8-byte entries, 34 GB; the dictionary paths do not use it)
     c = open_ctx(args)
     k = args.k
     resolve_accelerators(args, n, k, stream_mode)
@@ -738,7 +738,8 @@ def run_leg(args):
         m.pop("_keep")
         value = m["batch"] * steps / m["elapsed_max"]
         resident = int(info.device_bytes) < (1 << 28)   # fits the Infinity Cache: HBM % is not meaningful
-        legs.append({"name": vname, "config": LEG_TEXT[name] + ("; " + VIA_TEXT[via] if stream_mode else "") + (f"; {subst // 10000}% substitutions in the reads drawn from the superstring" if subst else ""),
+        legs.append({"name": vname, "config": LEG_TEXT.get(vname) or (LEG_TEXT[name] + ("; " + VIA_TEXT[via] if path.stream_mode else "") +
+                                                                      (f"; {subst // 10000}% substitutions in the reads drawn from the superstring" if subst else "")),
                      "value": value, "unit": "k-mers/s", "steps": steps, "queries_per_step": m["batch"], "ms": round(m["elapsed_max"] / steps * 1e3, 4),
                      "kernel": roof["kernel"], "avg_kernel_ms": roof["avg_kernel_ms"], "algorithmic_bytes": roof.get("algorithmic_bytes_per_launch"),
                      "achieved_gbs": None if resident else roof["achieved"], "l2_level_gbs": roof["achieved"] if resident else None,

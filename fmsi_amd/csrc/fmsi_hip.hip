@@ -868,7 +868,7 @@ void fmsi_hip_index_destroy(fmsi_hip_index* idx) {
     ::fmsi::DeviceGuard device_guard_(idx->device);
     for (void* p : {idx->d_sk, idx->d_sk_aux[0], idx->d_sk_aux[1], idx->d_sk_aux[2], idx->d_sk_aux[3]})
         if (p) (void)dev_free(p);
-    for (void* p : {idx->d_super, idx->d_blocks, idx->d_mrank, idx->d_ptable, idx->d_klcp, idx->d_sblocks, idx->d_text2, idx->d_stable, idx->d_vtable, idx->d_in, idx->d_aux, idx->d_out,
+    for (void* p : {idx->d_super, idx->d_blocks, idx->d_mrank, idx->d_ptable, idx->d_klcp, idx->d_sblocks, idx->d_dtable, idx->d_text2, idx->d_stable, idx->d_vtable, idx->d_in, idx->d_aux, idx->d_out,
                     idx->d_kmers, idx->d_tasks, idx->d_bytes, idx->d_case, idx->d_sorted, idx->d_dict[0], idx->d_dict[1], idx->d_dict[2], idx->d_dict[3], idx->d_posans, idx->d_slot_pos, idx->d_pblocks, idx->d_sbt, idx->d_c2, static_cast<void*>(idx->d_counters)})
         if (p) (void)dev_free(p);
     for (auto& m : idx->meta_ring) {

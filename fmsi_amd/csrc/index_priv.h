@@ -134,6 +134,7 @@ struct fmsi_hip_index {
     void* d_klcp = nullptr;      // plain kLCP bit-vector (n bits, u64 words), when present
     void* d_sblocks = nullptr;   // streaming layout (fmsi_stream.hip): 128-byte blocks of 192 rows with the kLCP plane, built on first use
     uint64_t n_sblocks = 0;
+    void* d_dtable = nullptr;    // ... and its double-stranded prefix table: 16-byte entries (the key's entry, its reverse complement's), 4^prefix_len of them
     // optional pair layout (fmsi_pair.hip): 128-B blocks for two-base LF steps
     void* d_pblocks = nullptr;
     void* d_sbt = nullptr;

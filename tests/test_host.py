@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol(product_built):
     assert len(names) >= 18
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/fmsi_hip.h but not exported"
-    assert lib.fmsi_hip_abi_version() == 6
+    assert lib.fmsi_hip_abi_version() == 7
 
 
 def test_no_oracle_in_product():
