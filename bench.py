@@ -722,7 +722,7 @@ def run_leg(args):
     args.stream_via = "runs"
     sk_only = name.endswith("sk")
     if stream_mode and not sk_only:
-        args.prefix_len = 15   # (the kLCP kernel's fresh searches start from a 15-deep prefix table in its double-stranded form, 17 GB -- rounds 1-3: 16 deep, 8-byte entries, 34 GB; the dictionary paths do not use it)
+        args.prefix_len = 16   # (the kLCP kernel's fresh searches start from its 16-deep prefix table, as in the earlier rounds' runs; the dictionary paths do not use it)
     c = open_ctx(args)
     k = args.k
     resolve_accelerators(args, n, k, stream_mode)

@@ -397,7 +397,7 @@ __global__ __launch_bounds__(256) void ptable_level_kernel(DevIndex ix, const ui
     }
 }
 
-// longest interval of the final level (decides whether the packed entry format fits: lengths < 2^30)
+// longest interval of the final level (decides whether the packed entry format fits: lengths < 2^26)
 __global__ __launch_bounds__(256) void ptable_maxlen_kernel(const uint2* __restrict__ tab, uint64_t count, uint32_t* __restrict__ max_len) {
     const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
     uint32_t m = 0;
@@ -407,6 +407,25 @@ __global__ __launch_bounds__(256) void ptable_maxlen_kernel(const uint2* __restr
     }
     for (int off = 32; off > 0; off >>= 1) m = max(m, static_cast<uint32_t>(__shfl_down(static_cast<int>(m), off, 64)));
     if ((threadIdx.x & 63) == 0 && m) atomicMax(max_len, m);
+}
+
+// Five bits about the entry of every key's reverse complement into the key's own entry (decode_table_entry, "hints"): in place -- a
+// thread writes bits 31, 29..26 of its own entry and reads the other bits of another, which nobody changes.
+__global__ __launch_bounds__(256) void ptable_hint_kernel(uint2* __restrict__ tab, int t, uint64_t count) {
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
+    for (uint64_t idx = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; idx < count; idx += stride) {
+        const uint32_t yo = tab[revcomp_2bit(idx, t)].y;
+        uint32_t hint;
+        if ((yo >> 30) & 1u) {   // 1..3 rows: the bases that precede them (the first symbol of each signature)
+            const uint32_t rows = (yo >> 24) & 3u;
+            hint = 1u << (26u + ((yo >> 6) & 3u));
+            if (rows > 1u) hint |= 1u << (26u + ((yo >> 14) & 3u));
+            if (rows > 2u) hint |= 1u << (26u + ((yo >> 22) & 3u));
+        } else {
+            hint = (yo & 0x03FFFFFFu) ? (15u << 26) : (1u << 31);   // many rows: any base may precede one of them; none: the t-mer does not occur
+        }
+        tab[idx].y = (tab[idx].y & ~kTableHintMask) | hint;
+    }
 }
 
 // (i, j) -> packed entries (decode_table_entry): intervals of 1..3 rows get the signatures of their rows
@@ -502,11 +521,18 @@ int build_prefix_table(fmsi_hip_index* idx, int t) {
         hipError_t e2 = hipMemcpy(&h_max, d_max, 4, hipMemcpyDeviceToHost);
         (void)dev_free(d_max);
         idx->dev.ptable_packed = 0;
-        if (e2 == hipSuccess && h_max < (1u << 30)) {
+        if (e2 == hipSuccess && h_max < (1u << 26)) {
             hipLaunchKernelGGL(ptable_pack_kernel, dim3(blocks), dim3(256), 0, 0, idx->dev, a, final_count);
             e2 = hipGetLastError();
             if (e2 == hipSuccess) e2 = hipDeviceSynchronize();
             idx->dev.ptable_packed = 1;
+            // a handle that can stream (kLCP array): the entries' hints about the other strand (fmsi_stream.hip)
+            if (e2 == hipSuccess && idx->d_klcp) {
+                hipLaunchKernelGGL(ptable_hint_kernel, dim3(blocks), dim3(256), 0, 0, a, t, final_count);
+                e2 = hipGetLastError();
+                if (e2 == hipSuccess) e2 = hipDeviceSynchronize();
+                idx->dev.ptable_packed = 2;
+            }
         }
         if (e2 != hipSuccess) {
             (void)dev_free(a);
@@ -868,7 +894,7 @@ void fmsi_hip_index_destroy(fmsi_hip_index* idx) {
     ::fmsi::DeviceGuard device_guard_(idx->device);
     for (void* p : {idx->d_sk, idx->d_sk_aux[0], idx->d_sk_aux[1], idx->d_sk_aux[2], idx->d_sk_aux[3]})
         if (p) (void)dev_free(p);
-    for (void* p : {idx->d_super, idx->d_blocks, idx->d_mrank, idx->d_ptable, idx->d_klcp, idx->d_sblocks, idx->d_dtable, idx->d_text2, idx->d_stable, idx->d_vtable, idx->d_in, idx->d_aux, idx->d_out,
+    for (void* p : {idx->d_super, idx->d_blocks, idx->d_mrank, idx->d_ptable, idx->d_klcp, idx->d_sblocks, idx->d_text2, idx->d_stable, idx->d_vtable, idx->d_in, idx->d_aux, idx->d_out,
                     idx->d_kmers, idx->d_tasks, idx->d_bytes, idx->d_case, idx->d_sorted, idx->d_dict[0], idx->d_dict[1], idx->d_dict[2], idx->d_dict[3], idx->d_posans, idx->d_slot_pos, idx->d_pblocks, idx->d_sbt, idx->d_c2, static_cast<void*>(idx->d_counters)})
         if (p) (void)dev_free(p);
     for (auto& m : idx->meta_ring) {

@@ -1404,14 +1404,16 @@ __global__ __launch_bounds__(256) void verify_fill_kernel(const uint2* __restric
         const uint32_t ch = static_cast<uint8_t>(c) | 0x20u;
         return ch == 'a' ? 0u : (ch == 'c' ? 1u : (ch == 'g' ? 2u : 3u));
     };
-    auto rows_of = [](uint2 e) -> uint32_t { return (e.y >> 30) == 1u ? ((e.y >> 24) & 3u) : e.y; };   // 8-byte format: tag 0 = length
+    auto rows_of = [](uint2 e) -> uint32_t { return (e.y >> 30) == 1u ? ((e.y >> 24) & 3u) : e.y; };   // 8-byte format: tag 0 = length (hint bits cleared below)
     for (uint64_t idx = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; idx < count; idx += stride) {
         uint2 e = tab[idx];
+        e.y &= ~kTableHintMask;   // (the prefix table's hints about the other strand are the streaming kernel's: bits 26-28 are mask bits here)
         uint32_t cand[7] = {0, 0, 0, 0, 0, 0, 0};
         const uint32_t nf = rows_of(e);
         bool done = false;
         if (bases_mode && nf <= max_total) {
-            const uint2 er = tab[revcomp_2bit(idx, static_cast<int>(T))];
+            uint2 er = tab[revcomp_2bit(idx, static_cast<int>(T))];
+            er.y &= ~kTableHintMask;
             const uint32_t nr = rows_of(er);
             if (nf + nr <= max_total) {
                 // narrow: nf in bits 24-25, nr in bits 22-23, mask bits from bit 26; wide: nf bits 0-2, nr bits 3-5, mask bits from bit 8

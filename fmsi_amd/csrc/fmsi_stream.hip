@@ -819,8 +819,7 @@ struct UniformRuns {
 template <bool COUNT, bool PTABLE, bool UNI>
 __global__ __launch_bounds__(256, 4) void query_stream2_kernel(DevIndex ix, const uint4* __restrict__ sblocks, const uint64_t* __restrict__ klcp,
                                                             const TaskRec* __restrict__ tasks, uint64_t n_tasks, int k, uint32_t flags, uint32_t chunk,
-                                                            uint4* __restrict__ slots, unsigned long long* __restrict__ counters, UniformRuns u,
-                                                            const uint4* __restrict__ dtable) {
+                                                            uint4* __restrict__ slots, unsigned long long* __restrict__ counters, UniformRuns u) {
     __shared__ uint4 s_line[4][64 * kSPitch];
     const uint32_t ln = threadIdx.x & 63u;
     uint4* my_wave_lines = s_line[threadIdx.x >> 6];
@@ -839,7 +838,7 @@ __global__ __launch_bounds__(256, 4) void query_stream2_kernel(DevIndex ix, cons
     uint64_t rf_lo = 0, rf_hi = 0;   // pass-0 result + 1 of window w in bit w of the two planes (0 = empty interval)
     uint64_t rr_lo = 0, rr_hi = 0;   // pass-1 result + 1 (0: not visited or empty)
     uint64_t todo = 0;
-    uint64_t other_dead = 0;          // double-stranded table: windows whose search on the strand pass 0 does NOT walk is known to be empty
+    uint64_t other_dead = 0;          // windows whose search on the strand pass 0 does NOT walk is known to be empty (the table entries' hints)
     uint32_t i = 0, j = 0, st = SS_IDLE, pass = 0, widx = 0;
     bool cur_rc = false, probing = false;
     uint32_t special = 0;
@@ -1042,16 +1041,10 @@ __global__ __launch_bounds__(256, 4) void query_stream2_kernel(DevIndex ix, cons
             bj = (j - 1u) / kSRows;
         }
         const bool two = need_line && bj != bi;
-        uint2 ent = make_uint2(0, 0), ent_other = make_uint2(0, 0);
+        uint2 ent = make_uint2(0, 0);
         if (lk) {
             const uint32_t tidx = static_cast<uint32_t>(kmer >> (2 * (k - T))) & static_cast<uint32_t>((1ull << (2 * T)) - 1ull);
-            if (dtable) {   // (one 16-byte load: this strand's entry and the entry of the key's reverse complement)
-                const uint4 e4 = dtable[tidx];
-                ent = make_uint2(e4.x, e4.y);
-                ent_other = make_uint2(e4.z, e4.w);
-            } else {
-                ent = ix.ptable[tidx];
-            }
+            ent = ix.ptable[tidx];
         }
         uint64_t kwi = 0, kwj = 0;
         if (st == SS_EXTSCAN) {   // a running extension scan (rare): the plain kLCP words at the frontier
@@ -1085,21 +1078,23 @@ __global__ __launch_bounds__(256, 4) void query_stream2_kernel(DevIndex ix, cons
             uint32_t q4 = 0;
             if (t >= 3) q4 = kmer_base(t - 3) | (kmer_base(t - 2) << 2) | (kmer_base(t - 1) << 4) | (kmer_base(t) << 6);
             decode_table_entry(ent.x, ent.y, ix.ptable_packed, t >= 3, q4, i, j);
-            if (dtable && pass == 0 && !probing) {
-                // The key's reverse complement is the table key of the OTHER strand's search of another window of this read: the last T
-                // bases of window w (forward strand) are the first T bases of window w + (k - T), whose reverse-complement search starts
-                // with their reverse complement -- and the other way round.  If that entry (with its next-base signatures) says "empty",
-                // pass 1 need not look the window up: an absent read costs one table request per window instead of two.
+            if (ix.ptable_packed == 2u && pass == 0 && !probing) {
+                // The entry also carries five bits about the entry of its key's REVERSE COMPLEMENT (ptable_hint_kernel) -- which is the table
+                // key of the OTHER strand's search of another window of this read: the last T bases of window w (forward strand) are the
+                // first T bases of window w + (k - T), whose reverse-complement search starts with their reverse complement, and the other
+                // way round.  "No such T-mer", or "none of its rows is preceded by the base that search consumes next": pass 1 need not
+                // look that window up -- an absent read costs about one table request per window instead of two.
                 const uint32_t d = static_cast<uint32_t>(k - T);
                 const uint32_t w2 = cur_rc ? widx - d : widx + d;      // (cur_rc, widx < d: wraps above n)
                 if (w2 < n) {
-                    const uint64_t f2 = task_kmer(s0, s1, s2, s3, w2, k);
-                    const uint64_t k2 = cur_rc ? f2 : revcomp_2bit(f2, k);     // the k-mer the other strand's search of window w2 walks
-                    uint32_t q4o = 0;
-                    if (t >= 3) q4o = static_cast<uint32_t>(k2 >> (2 * (t - 3))) & 0xFFu;
-                    uint32_t i2, j2;
-                    decode_table_entry(ent_other.x, ent_other.y, ix.ptable_packed, t >= 3, q4o, i2, j2);
-                    if (i2 == j2) other_dead |= 1ull << w2;
+                    bool dead = (ent.y >> 31) != 0u;
+                    if (t >= 0) {
+                        // the base the other strand's search of window w2 consumes after its T table bases: base t of the k-mer it walks
+                        // (the forward k-mer, or -- base t of a reverse complement -- the complement of the forward k-mer's base k - 1 - t = T)
+                        const uint32_t c_next = cur_rc ? task_base(s0, s1, s2, s3, w2 + static_cast<uint32_t>(t)) : 3u - task_base(s0, s1, s2, s3, w2 + static_cast<uint32_t>(T));
+                        dead = dead || !((ent.y >> (26u + c_next)) & 1u);
+                    }
+                    if (dead) other_dead |= 1ull << w2;
                 }
             }
             if (i == j) {
@@ -1217,16 +1212,6 @@ __global__ __launch_bounds__(256, 4) void query_stream2_kernel(DevIndex ix, cons
     }
 }
 
-// The double-stranded table of the S-block kernel: entry X = the prefix table's entry of the t-mer X and that of its reverse complement,
-// 16 bytes, so that ONE request serves a forward-strand lookup of one window and the reverse-complement lookup of the window k - t
-// further on (query_stream2_kernel, SS_LOOKUP).
-__global__ __launch_bounds__(256) void dtable_build_kernel(const uint2* __restrict__ pt, int t, uint64_t count, uint4* __restrict__ out) {
-    const uint64_t x = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-    if (x >= count) return;
-    const uint2 a = pt[x], b = pt[revcomp_2bit(x, t)];
-    out[x] = make_uint4(a.x, a.y, b.x, b.y);
-}
-
 template <bool COUNT, bool PTABLE>
 void launch_stream2(fmsi_hip_index* idx, const TaskRec* recs, uint64_t n_tasks, int k, uint32_t flags, uint4* slots, unsigned long long* d_counters, hipStream_t s,
                     const UniformRuns* uni) {
@@ -1234,14 +1219,12 @@ void launch_stream2(fmsi_hip_index* idx, const TaskRec* recs, uint64_t n_tasks, 
     chunk = std::min<uint64_t>(std::max<uint64_t>(chunk, 64), 1024);
     const uint64_t waves = (n_tasks + chunk - 1) / chunk;
     const uint32_t blocks = static_cast<uint32_t>((waves + 3) / 4);
-    static const bool no_dtable = std::getenv("FMSI_HIP_STREAM_NO_DTABLE") != nullptr;   // (A/B runs: the 8-byte entries of the prefix table)
-    const uint4* dtable = PTABLE && !no_dtable ? static_cast<const uint4*>(idx->d_dtable) : nullptr;
     if (uni)
         hipLaunchKernelGGL((query_stream2_kernel<COUNT, PTABLE, true>), dim3(blocks), dim3(256), 0, s, idx->dev, static_cast<const uint4*>(idx->d_sblocks),
-                           static_cast<const uint64_t*>(idx->d_klcp), recs, n_tasks, k, flags, static_cast<uint32_t>(chunk), slots, d_counters, *uni, dtable);
+                           static_cast<const uint64_t*>(idx->d_klcp), recs, n_tasks, k, flags, static_cast<uint32_t>(chunk), slots, d_counters, *uni);
     else
         hipLaunchKernelGGL((query_stream2_kernel<COUNT, PTABLE, false>), dim3(blocks), dim3(256), 0, s, idx->dev, static_cast<const uint4*>(idx->d_sblocks),
-                           static_cast<const uint64_t*>(idx->d_klcp), recs, n_tasks, k, flags, static_cast<uint32_t>(chunk), slots, d_counters, UniformRuns{}, dtable);
+                           static_cast<const uint64_t*>(idx->d_klcp), recs, n_tasks, k, flags, static_cast<uint32_t>(chunk), slots, d_counters, UniformRuns{});
 }
 
 template <bool COUNT, bool PTABLE, bool WIDE>
@@ -1293,37 +1276,6 @@ extern "C" int fmsi_hip_index_enable_stream_layout(fmsi_hip_index* idx) {
     return 0;
 }
 
-// The double-stranded table (idempotent; built on the handle's first table-backed S-block call): 16 bytes x 4^t, from a prefix table of
-// t <= 15 bases (t = 16 would be 69 GB).  A handle that cannot afford it keeps looking its 8-byte entries up.
-extern "C" int fmsi_hip_index_enable_stream_table(fmsi_hip_index* idx) {
-    if (!idx) return FMSI_HIP_EINVAL;
-    FMSI_HIP_NARROW_ONLY(idx, "kLCP streaming");
-    if (idx->d_dtable) return 0;
-    if (!idx->d_ptable || idx->prefix_len < 1 || idx->prefix_len > 15) {
-        set_last_error("the double-stranded table needs a prefix table of 1 <= t <= 15 bases");
-        return FMSI_HIP_EINVAL;
-    }
-    ::fmsi::ScratchScope scratch_scope_(idx->device);
-    FMSI_HIP_ON_DEVICE(idx->device);
-    const uint64_t count = 1ull << (2 * idx->prefix_len);
-    void* p = nullptr;
-    if (dev_malloc(&p, count * 16 + 64) != hipSuccess) {
-        (void)hipGetLastError();
-        set_last_error("hipMalloc failed for the double-stranded table");
-        return FMSI_HIP_ENOMEM;
-    }
-    hipLaunchKernelGGL(dtable_build_kernel, dim3(static_cast<uint32_t>((count + 255) / 256)), dim3(256), 0, 0, static_cast<const uint2*>(idx->d_ptable), idx->prefix_len, count,
-                       static_cast<uint4*>(p));
-    if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
-        (void)dev_free(p);
-        set_last_error("building the double-stranded table failed");
-        return FMSI_HIP_EHIP;
-    }
-    idx->d_dtable = p;
-    idx->device_bytes += count * 16 + 64;
-    return 0;
-}
-
 extern "C" int fmsi_hip_query_stream(fmsi_hip_index* idx, const uint64_t* packed_seq, uint64_t seq_bases, const uint64_t* run_start,
                                      const uint32_t* run_windows, uint64_t n_runs, uint64_t n_windows, int k, uint32_t flags,
                                      void* out, uint64_t* counters, void* stream) {
@@ -1356,11 +1308,6 @@ extern "C" int fmsi_hip_query_stream(fmsi_hip_index* idx, const uint64_t* packed
     if (v2 && !idx->d_sblocks) {
         const int rc_s = fmsi_hip_index_enable_stream_layout(idx);
         if (rc_s) return rc_s;
-    }
-    if (v2 && !idx->d_dtable && idx->d_ptable && idx->dev.ptable_packed && idx->prefix_len <= 15 && k - idx->prefix_len >= 4 && !(flags & FMSI_HIP_NO_PREFIX_TABLE)) {
-        static const bool no_dtable = std::getenv("FMSI_HIP_STREAM_NO_DTABLE") != nullptr;
-        // (an accelerator: a handle without the room for it keeps the 8-byte lookups)
-        if (!no_dtable && fmsi_hip_index_enable_stream_table(idx) != 0) (void)hipGetLastError();
     }
     // run_start / run_windows are HOST arrays in every mode (one entry per run); per run the device gets its first base,
     // first task and first result index, and cuts the tasks itself (stream_prep_kernel)

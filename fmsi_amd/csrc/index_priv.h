@@ -28,7 +28,8 @@ struct DevIndex {
     uint32_t dollar;          // dollar_position
     uint32_t C0, C1, C2, C3;  // counts[] (src/fms_index.h:451)
     uint32_t ptable_len;      // t
-    uint32_t ptable_packed;   // entry format: 0 = (i, j); 1 = (i, tagged word) with next-base signatures, see decode_table_entry
+    uint32_t ptable_packed;   // entry format: 0 = (i, j); 1 = (i, tagged word) with next-base signatures, see decode_table_entry; 2 = the same
+                              // plus five bits about the entry of the key's reverse complement (ptable_hint_kernel)
 };
 
 // the same blocks for an index of 2^32 rows and more (fmsi_wide.hip): u64 rows, absolute counts per superblock
@@ -134,7 +135,6 @@ struct fmsi_hip_index {
     void* d_klcp = nullptr;      // plain kLCP bit-vector (n bits, u64 words), when present
     void* d_sblocks = nullptr;   // streaming layout (fmsi_stream.hip): 128-byte blocks of 192 rows with the kLCP plane, built on first use
     uint64_t n_sblocks = 0;
-    void* d_dtable = nullptr;    // ... and its double-stranded prefix table: 16-byte entries (the key's entry, its reverse complement's), 4^prefix_len of them
     // optional pair layout (fmsi_pair.hip): 128-B blocks for two-base LF steps
     void* d_pblocks = nullptr;
     void* d_sbt = nullptr;

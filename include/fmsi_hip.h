@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define FMSI_HIP_ABI_VERSION 7   /* 7: FMSI_HIP_KERNEL_SORTED, fmsi_hip_index_enable_stream_table; 6: FMSI_HIP_DICT_SUPERKMER + fmsi_hip_index_info.sk_*, fmsi_hip_index_enable_stream_layout, FMSI_HIP_NO_DICT_CHAIN; 5: fmsi_hip_keep_scratch; 4: fmsi_hip_query_runs_fn (`-f and|xor|r-s`); 2: fmsi_hip_index_info.candidate_entry_bytes, fmsi_hip_comm_*, fmsi_hip_gather; 3: FMSI_HIP_OUT_BITS, fmsi_hip_index_load, fmsi_hip_trim_scratch, fmsi_hip_index_enable_dict + fmsi_hip_index_info.dict_*, fmsi_hip_index_build_synthetic_spec */
+#define FMSI_HIP_ABI_VERSION 7   /* 7: FMSI_HIP_KERNEL_SORTED; 6: FMSI_HIP_DICT_SUPERKMER + fmsi_hip_index_info.sk_*, fmsi_hip_index_enable_stream_layout, FMSI_HIP_NO_DICT_CHAIN; 5: fmsi_hip_keep_scratch; 4: fmsi_hip_query_runs_fn (`-f and|xor|r-s`); 2: fmsi_hip_index_info.candidate_entry_bytes, fmsi_hip_comm_*, fmsi_hip_gather; 3: FMSI_HIP_OUT_BITS, fmsi_hip_index_load, fmsi_hip_trim_scratch, fmsi_hip_index_enable_dict + fmsi_hip_index_info.dict_*, fmsi_hip_index_build_synthetic_spec */
 
 /* error codes */
 #define FMSI_HIP_OK 0
@@ -333,13 +333,6 @@ int fmsi_hip_query_stream(fmsi_hip_index* idx, const uint64_t* packed_seq, uint6
  * built from the handle's blocks and kLCP array on the first such call; a host that wants the cost at load time calls this.  Idempotent;
  * needs a handle with a kLCP array. */
 int fmsi_hip_index_enable_stream_layout(fmsi_hip_index* idx);
-/* ... and, when the handle has a prefix table of t <= 15 bases with k - t >= 4, that kernel looks its keys up in a DOUBLE-STRANDED copy of it:
- * 16-byte entries holding the key's entry and the entry of the key's reverse complement (16 bytes x 4^t of HBM).  The last t bases of a
- * window are the first t bases of the window k - t further on, so the one request that starts a forward-strand search also tells whether the
- * reverse-complement search of that other window can find anything (src/fms_index.h:181-254 restarts both per absent window): a read that is
- * not in the index costs one table request per window instead of two.  Private accelerator, results unchanged; built on the first such call
- * (a handle without the room for it keeps the 8-byte lookups); idempotent. */
-int fmsi_hip_index_enable_stream_table(fmsi_hip_index* idx);
 
 int fmsi_hip_sync(fmsi_hip_index* idx, void* stream);
 /* The library keeps large freed device blocks (temporaries of the builders) for reuse -- freeing and re-allocating them is what an index
