@@ -1217,6 +1217,8 @@ void launch_stream2(fmsi_hip_index* idx, const TaskRec* recs, uint64_t n_tasks, 
                     const UniformRuns* uni) {
     uint64_t chunk = n_tasks / (256ull * 32 * 8);
     chunk = std::min<uint64_t>(std::max<uint64_t>(chunk, 64), 1024);
+    static const char* chunk_env = std::getenv("FMSI_HIP_STREAM_CHUNK");   // (measurements: tasks per wave)
+    if (chunk_env) chunk = std::max(1, std::atoi(chunk_env));
     const uint64_t waves = (n_tasks + chunk - 1) / chunk;
     const uint32_t blocks = static_cast<uint32_t>((waves + 3) / 4);
     if (uni)
@@ -1304,10 +1306,15 @@ extern "C" int fmsi_hip_query_stream(fmsi_hip_index* idx, const uint64_t* packed
     // k <= 32 presence queries: the S-block kernel (its layout is built on the handle's first such call; FMSI_HIP_STREAM_V1: the first
     // kernel, for A/B runs)
     static const bool force_v1 = std::getenv("FMSI_HIP_STREAM_V1") != nullptr;
-    const bool v2 = k <= 32 && !(flags & FMSI_HIP_ORDERS) && !force_v1 && (flags & FMSI_HIP_KERNEL_MASK) != FMSI_HIP_KERNEL_REFILL;
+    bool v2 = k <= 32 && !(flags & FMSI_HIP_ORDERS) && !force_v1 && (flags & FMSI_HIP_KERNEL_MASK) != FMSI_HIP_KERNEL_REFILL;
     if (v2 && !idx->d_sblocks) {
-        const int rc_s = fmsi_hip_index_enable_stream_layout(idx);
-        if (rc_s) return rc_s;
+        // built here on the handle's first such call (a kernel on the null stream and a device synchronisation: this ONE call is not
+        // asynchronous on `stream`; fmsi_hip_index_enable_stream_layout at load time avoids that).  A handle without the room for the
+        // layout (2/3 byte per row) keeps streaming through the first kernel -- the same answers, slower
+        if (fmsi_hip_index_enable_stream_layout(idx) != 0) {
+            (void)hipGetLastError();
+            v2 = false;
+        }
     }
     // run_start / run_windows are HOST arrays in every mode (one entry per run); per run the device gets its first base,
     // first task and first result index, and cuts the tasks itself (stream_prep_kernel)
