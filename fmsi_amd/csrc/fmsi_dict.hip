@@ -1341,6 +1341,185 @@ bool skdict_applies(const fmsi_hip_index* idx, int k, uint32_t flags) {
            (kernel == FMSI_HIP_KERNEL_AUTO || kernel == FMSI_HIP_KERNEL_DICT);
 }
 
+// ---- isolated k-mers on the super-k-mer dictionary (round 4) ---------------------------------------------------------------------
+// fmsi_hip_query_kmers on a handle that keeps the records ALONE used to send every k-mer through sk_runs_kernel as a one-window read;
+// that kernel is built around what consecutive windows share, and an isolated k-mer shares nothing.  Here a lane owns a k-mer from the
+// 8-byte load to the result byte, in the shape of dict_lookup_kernel: a wave takes 64 k-mers per round; each lane finds its k-mer's
+// minimizer (the k - m + 1 m-mers of the k-mer and of its reverse complement side by side: one score each, the smallest key -- score, then
+// position -- wins, exactly sk_runs_kernel's order), turns the k-mer into the minimizer's orientation, hashes the canonical m-mer to bucket +
+// remainder; the 64 buckets arrive eight lanes x 16 bytes at a time and EACH OF THE EIGHT LANES matches the one record it holds against
+// the owner's remainder and flank string (sk_match: all bases); three xor-shuffles fold the answer nibble / heavy / overflow flags to the
+// owner.  A k-mer of a heavy minimizer or of an overflowed bucket that no record holds queues up for the aux dictionary's ordinary
+// lookups, 64 at a time.  Results collect in LDS and leave as 16 bytes per lane or bit-packed.
+template <bool COUNT>
+__global__ __launch_bounds__(256) void sk_kmers_kernel(SkIndex sk, DictIndex aux, const uint64_t* __restrict__ kmers, uint64_t n_windows, uint32_t flags, uint32_t chunk,
+                                                       uint8_t* __restrict__ out, unsigned long long* __restrict__ counters) {
+    constexpr uint32_t kMaxChunk = 4096u, kQueue = 128u;
+    __shared__ uint64_t s_qh[4][kQueue];     // k-mers waiting for the aux dictionary: canonical k-mer's hash ...
+    __shared__ uint32_t s_qi[4][kQueue];     // ... and index in the chunk | (rc < f) << 16 | (rc == f) << 17
+    __shared__ uint32_t s_tmp[4][64];
+    __shared__ __attribute__((aligned(16))) uint8_t s_res[4][kMaxChunk];
+    const int k = sk.k, m = sk.m;
+    const uint32_t strict = flags & FMSI_HIP_STRICT;
+    const bool out_bits = (flags & FMSI_HIP_OUT_BITS) != 0u;
+    const uint32_t lane = threadIdx.x & 63u, wib = threadIdx.x >> 6;
+    uint64_t* qh = s_qh[wib];
+    uint32_t* qi = s_qi[wib];
+    uint32_t* tmp = s_tmp[wib];
+    uint8_t* res = s_res[wib];
+    const uint64_t wave = (static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t start = wave * chunk;
+    const uint32_t len = start < n_windows ? static_cast<uint32_t>(min(static_cast<uint64_t>(chunk), n_windows - start)) : 0u;
+    const uint32_t nflank = static_cast<uint32_t>(k - m), mbits = 2u * static_cast<uint32_t>(m), rshift = mbits - sk.bits;
+    const uint64_t mmask = (1ull << mbits) - 1ull;
+    const uint32_t grp = lane >> 3, piece = lane & 7u;
+    uint32_t qhead = 0, qtail = 0;
+    uint32_t n_reads = 0, n_final = 0, n_aux = 0;
+
+    auto aux_round = [&](uint32_t items) {
+        bool active = lane < items;
+        const uint32_t pos = (qhead + lane) & (kQueue - 1u);
+        uint64_t h = active ? qh[pos] : 0ull;
+        const uint32_t info = active ? qi[pos] : 0u;
+        uint32_t ans = 0;
+        for (uint32_t lv = 0; lv < aux.levels && __any(active); ++lv) {
+            if (lv) h = dict_mix(h + kLevelSalt[lv]);
+            const uint32_t v = dict_probe(aux.lv[lv], h, active, lane, tmp);
+            if (active) {
+                n_aux++;
+                if ((v & 15u) || !(v & 16u)) {
+                    ans = v & 15u;
+                    active = false;
+                }
+            }
+        }
+        if (lane < items) {
+            n_final++;
+            res[info & 0xFFFFu] = dict_encode(ans, (info >> 16) & 1u, (info >> 17) & 1u, flags);
+        }
+        qhead += items;
+    };
+
+    for (uint32_t base = 0; base < len; base += 64u) {
+        const uint32_t ql = base + lane;
+        const bool valid = ql < len;
+        const uint64_t f = valid ? __builtin_nontemporal_load(kmers + start + ql) : 0ull;
+        const uint64_t rc = revcomp_2bit(f, k);
+        const bool swapped = rc < f, pal = rc == f;
+        // ---- the minimizer: m-mer p of f is x, its reverse complement is m-mer (k - m - p) of rc
+        uint32_t best = ~0u;
+#pragma unroll 1
+        for (uint32_t p = 0; p <= nflank; ++p) {
+            const uint64_t x = (f >> (2u * p)) & mmask, y = (rc >> (2u * (nflank - p))) & mmask;
+            const bool flip = y < x;
+            const uint32_t key = (sk_score(flip ? y : x, mbits) << 5) | (p << 1) | (flip ? 1u : 0u);   // leftmost of equal scores: the smaller p
+            best = min(best, key);
+        }
+        const uint32_t p = (best >> 1) & 15u;
+        const bool flip = (best & 1u) != 0u;
+        const uint64_t g = flip ? rc : f;                       // the k-mer in its minimizer's orientation
+        const uint32_t pc = flip ? nflank - p : p;              // ... and the minimizer's offset in it
+        const uint64_t xc = (g >> (2u * pc)) & mmask;           // canonical as it stands there
+        const uint64_t G = sk_mix(sk_mix(xc, mbits, kSkScoreSalt), mbits, kSkBucketSalt);
+        const uint32_t bidx = valid ? static_cast<uint32_t>(G >> rshift) : 0u;
+        const uint64_t rem = G & ((1ull << rshift) - 1ull);
+        const uint32_t rem_a = static_cast<uint32_t>(rem >> 20), rem_b = static_cast<uint32_t>(rem) & 0xFFFFFu;
+        const uint32_t wf = sk_flanks(g, k, m, pc);
+        // ---- the buckets: eight lanes per bucket, eight buckets per instruction (a lane without a k-mer asks for bucket 0)
+        uint4 v[8];
+#pragma unroll
+        for (uint32_t gq = 0; gq < 8; ++gq) {
+            const uint32_t bo = static_cast<uint32_t>(__shfl(static_cast<int>(bidx), static_cast<int>(8u * gq + grp), 64));
+            v[gq] = load16_nt(sk.buckets + (static_cast<size_t>(bo) << 3) + piece);
+        }
+#pragma unroll
+        for (uint32_t gq = 0; gq < 8; ++gq) {   // lane l holds record (l & 7) of owner 8 gq + (l >> 3)
+            const int owner = static_cast<int>(8u * gq + grp);
+            const uint32_t oa = static_cast<uint32_t>(__shfl(static_cast<int>(rem_a), owner, 64));
+            const uint32_t ob = static_cast<uint32_t>(__shfl(static_cast<int>(rem_b), owner, 64));
+            const uint32_t owf = static_cast<uint32_t>(__shfl(static_cast<int>(wf), owner, 64));
+            const uint32_t opc = static_cast<uint32_t>(__shfl(static_cast<int>(pc), owner, 64));
+            const uint4 r = v[gq];
+            uint32_t got = 0;   // answer nibble | heavy << 4 | overflow << 5
+            const bool mine = (r.z & 15u) != 0u && (r.y >> 16) == oa && (r.w >> 12) == ob;
+            if (mine) {
+                if (((r.y >> 8) & 15u) == 15u) got = 16u;
+                else got = sk_match((static_cast<uint64_t>(r.y) << 32) | r.x, (static_cast<uint64_t>(r.w) << 32) | r.z, owf, opc, nflank);
+            }
+            if ((r.x & r.y) == ~0u && (r.z | r.w) == 0u) got |= 32u;
+            got |= static_cast<uint32_t>(__shfl_xor(static_cast<int>(got), 1, 64));
+            got |= static_cast<uint32_t>(__shfl_xor(static_cast<int>(got), 2, 64));
+            got |= static_cast<uint32_t>(__shfl_xor(static_cast<int>(got), 4, 64));
+            if (piece == 0u) tmp[owner] = got;
+        }
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t mine = tmp[lane];
+        __builtin_amdgcn_wave_barrier();
+        bool slow = false;
+        if (valid) {
+            n_reads++;
+            const uint32_t ans = mine & 15u;
+            // a heavy minimizer's k-mers live in the aux dictionary; so may a k-mer that an overflowed bucket does not hold
+            if ((mine & 16u) || (!ans && (mine & 32u))) {
+                slow = true;
+            } else {
+                n_final++;
+                res[ql] = dict_encode(ans, swapped, pal, flags);
+            }
+        }
+        const uint64_t mk = __ballot(slow);
+        if (mk) {
+            if (slow) {
+                const uint32_t pos = (qtail + lanes_below(mk)) & (kQueue - 1u);
+                qh[pos] = dict_mix(swapped ? rc : f);
+                qi[pos] = ql | (swapped ? 0x10000u : 0u) | (pal ? 0x20000u : 0u);
+            }
+            qtail += static_cast<uint32_t>(__popcll(mk));
+            while (qtail - qhead >= 64u) aux_round(64u);
+        }
+    }
+    if (qtail != qhead) aux_round(qtail - qhead);
+    if (len && out_bits) {
+        flush_packed_results(res, len, strict != 0u, out, start, lane);
+    } else if (len) {
+        uint8_t* dst = out + start;
+        const bool aligned = (reinterpret_cast<uintptr_t>(dst) & 15u) == 0;
+        for (uint32_t off = lane * 16u; off < len; off += 64u * 16u) {
+            if (aligned && off + 16u <= len) {
+                typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+                __builtin_nontemporal_store(*reinterpret_cast<const u32x4*>(res + off), reinterpret_cast<u32x4*>(dst + off));
+            } else {
+                for (uint32_t b = off; b < min(len, off + 16u); ++b) dst[b] = res[b];
+            }
+        }
+    }
+    if (COUNT) {
+        uint32_t vv[3] = {n_reads + n_aux, n_final, n_final};   // bucket reads (records + aux); windows answered; searches (one settles both strands)
+        const int slot[3] = {4, 6, 3};
+#pragma unroll
+        for (int qq = 0; qq < 3; ++qq) {
+            uint32_t x = vv[qq];
+            for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+            if (lane == 0 && x) {
+                atomicAdd(&counters[slot[qq]], static_cast<unsigned long long>(x));
+                if (qq == 0) atomicAdd(&counters[1], static_cast<unsigned long long>(x));
+            }
+        }
+    }
+}
+
+// isolated k-mers (8 bytes each) through the records: fmsi_hip_query_kmers on a handle without the k-mer dictionary
+int launch_skdict_kmers(fmsi_hip_index* idx, const uint64_t* d_kmers, uint64_t n, uint32_t flags, uint8_t* o8, unsigned long long* d_counters, hipStream_t s) {
+    uint64_t chunk = n / (256ull * 8 * 8);
+    chunk = std::min<uint64_t>(std::max<uint64_t>(chunk, 128), 4096) & ~127ull;
+    const uint64_t waves = (n + chunk - 1) / chunk;
+    const dim3 grid(static_cast<uint32_t>((waves + 3) / 4)), block(256);
+    if (d_counters) hipLaunchKernelGGL((sk_kmers_kernel<true>), grid, block, 0, s, idx->sk, idx->sk_aux, d_kmers, n, flags, static_cast<uint32_t>(chunk), o8, d_counters);
+    else hipLaunchKernelGGL((sk_kmers_kernel<false>), grid, block, 0, s, idx->sk, idx->sk_aux, d_kmers, n, flags, static_cast<uint32_t>(chunk), o8, d_counters);
+    FMSI_HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 int launch_skdict(fmsi_hip_index* idx, const uint64_t* d_seq, uint64_t seq_words, uint64_t n, int k, uint32_t flags, uint8_t* o8, unsigned long long* d_counters,
                   hipStream_t s, const uint64_t* u, const uint64_t* h_runs, uint64_t n_runs) {
     (void)k;

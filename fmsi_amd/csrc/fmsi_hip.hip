@@ -634,8 +634,11 @@ int launch_query(fmsi_hip_index* idx, const uint64_t* d_kmers, uint64_t n_window
     if (dict) {
         if ((rc = launch_dict_query(idx, d_kmers, n_windows, k, flags, o8, d_counters, s))) return rc;
     } else if (sk_iso) {
+        static const bool as_reads = std::getenv("FMSI_HIP_SK_ONE_WINDOW_READS") != nullptr;   // (A/B runs: round 3's form, sk_runs_kernel on one-window reads)
         const uint64_t one_window_reads[3] = {0, 32, 1};
-        if ((rc = launch_skdict(idx, d_kmers, n_windows, n_windows, k, flags, o8, d_counters, s, one_window_reads))) return rc;
+        if (as_reads) rc = launch_skdict(idx, d_kmers, n_windows, n_windows, k, flags, o8, d_counters, s, one_window_reads);
+        else rc = launch_skdict_kmers(idx, d_kmers, n_windows, flags, o8, d_counters, s);
+        if (rc) return rc;
     } else if (sorted) {
         if ((rc = launch_sorted_query(idx, d_kmers, n_windows, k, flags, o8, d_counters, s))) return rc;
     } else if (kernel == FMSI_HIP_KERNEL_LOCKSTEP) {

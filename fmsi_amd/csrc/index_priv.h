@@ -239,6 +239,8 @@ bool skdict_applies(const fmsi_hip_index* idx, int k, uint32_t flags);
 // hold bases -- the kernel reads no further)
 int launch_skdict(fmsi_hip_index* idx, const uint64_t* d_seq, uint64_t seq_words, uint64_t n, int k, uint32_t flags, uint8_t* o8, unsigned long long* d_counters,
                   hipStream_t s, const uint64_t* uniform_runs, const uint64_t* h_runs = nullptr, uint64_t n_runs = 0);
+// ... and isolated k-mers (8 bytes each) through the records: a lane per k-mer, one bucket read each (sk_kmers_kernel)
+int launch_skdict_kmers(fmsi_hip_index* idx, const uint64_t* d_kmers, uint64_t n, uint32_t flags, uint8_t* o8, unsigned long long* d_counters, hipStream_t s);
 int launch_dict_chain(fmsi_hip_index* idx, const uint64_t* d_seq, uint64_t n, int k, uint32_t flags, uint8_t* o8, unsigned long long* d_counters, hipStream_t s,
                       const uint64_t* uniform_runs);
 
