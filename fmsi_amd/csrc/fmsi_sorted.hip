@@ -614,7 +614,8 @@ bool sorted_walk_applies(const fmsi_hip_index* idx, int k, uint32_t flags) {
 
 int launch_sorted_query(fmsi_hip_index* idx, const uint64_t* d_kmers, uint64_t n, int k, uint32_t flags, uint8_t* o8, unsigned long long* d_counters, hipStream_t s) {
     // sub-batches: item values are 32 bits (2 q + strand) and one radix sort takes < 2^32 items
-    constexpr uint64_t kSub = 1ull << 28;
+    static const char* sub_env = std::getenv("FMSI_HIP_SORTED_SUB");   // (tests: k-mers per sub-batch)
+    const uint64_t kSub = sub_env ? std::max<uint64_t>(1, std::strtoull(sub_env, nullptr, 10)) : (1ull << 28);
     for (uint64_t at = 0; at < n; at += kSub) {
         const uint64_t m = std::min(kSub, n - at);
         const int rc = d_counters ? launch_sorted_t<true>(idx, d_kmers + at, m, k, flags, o8 + at, d_counters, s)

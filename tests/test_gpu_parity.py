@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 import oracle_py
-from conftest import CLI_DATASETS, DATASETS, FN_CASES, GOLDEN, MODES, bgzf_bytes, golden_fn_out, golden_out, index_prefix, messy_fasta, mixed_kmers, query_file, revcomp, synthetic_ms
+from conftest import CLI_DATASETS, DATASETS, FN_CASES, GOLDEN, MODES, REPO, bgzf_bytes, golden_fn_out, golden_out, index_prefix, messy_fasta, mixed_kmers, query_file, revcomp, synthetic_ms
 
 pytestmark = pytest.mark.gpu
 
@@ -1043,3 +1043,39 @@ def test_cli_background_dictionary_switch_over(fm, tmp_path, mode):
     orc = oracle_py.Oracle.load(index_prefix(name), use_klcp=MODES[mode][2])
     want, _ = orc.query_file(str(q), k, has_klcp=MODES[mode][2], mode=MODES[mode][3], orders=MODES[mode][1], cap=len(out0) + 4096)
     assert out0.decode() == want
+
+
+def test_sorted_walk_in_sub_batches(fm, oracle_built, monkeypatch):
+    """FMSI_HIP_KERNEL_SORTED cuts a call into sub-batches (item values are 32 bits, one radix sort takes < 2^32 items: 2^28 k-mers each);
+    forced down to 1000 and to 7 k-mers per sub-batch here: the same bytes as one batch, as the oracle, bytes and bit-packed, odd and even
+    k, with the cut between the two launches at every depth the environment can ask for."""
+    import subprocess
+    import sys
+    code = """
+import sys, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r); sys.path.insert(0, %r)
+import fmsi_amd as fm, oracle_py
+from conftest import synthetic_ms, mixed_kmers
+for k, n in ((31, 20000), (32, 5000), (12, 3000)):
+    ms = synthetic_ms(n, k, seed=k, mask="mixed")
+    orc = oracle_py.Oracle.construct(ms, k, use_klcp=False)
+    dev = fm.DeviceIndex.build(ms.encode(), k).enable_pair_layout()
+    kmers = mixed_kmers(ms, k, 4001, seed=3)
+    packed = fm.pack_kmers(kmers, k)
+    for mode_all in (False, True):
+        flag = fm.MODE_ALL if mode_all else fm.MODE_OR
+        fwd, rc = orc.ternaries_bulk("".join(kmers).encode(), len(kmers), k, mode_all)
+        gf, gr = fm.decode_strict(dev.query_kmers(packed, k, flag | fm.STRICT | fm.KERNEL_SORTED))
+        assert np.array_equal(gf, fwd) and np.array_equal(gr, rc), (k, mode_all)
+        fast = dev.query_kmers(packed, k, flag | fm.KERNEL_SORTED)
+        want = (np.where(fwd != -1, fwd, rc) == 1) if mode_all else ((fwd == 1) | (rc == 1))
+        assert np.array_equal(fast.astype(bool), want)
+        bits = dev.query_kmers(packed, k, flag | fm.KERNEL_SORTED | fm.OUT_BITS)
+        assert np.array_equal(fm.unpack_bits(bits, len(kmers), 0), fast)
+print("ok")
+""" % (str(REPO), str(REPO / "oracle"), str(REPO / "tests"))
+    import os
+    for env in ({"FMSI_HIP_SORTED_SUB": "1000"}, {"FMSI_HIP_SORTED_SUB": "7"}, {"FMSI_HIP_SORTED_CUT": "0"}, {"FMSI_HIP_SORTED_CUT": "5"}, {"FMSI_HIP_SORTED_CUT": "24"},
+                {"FMSI_HIP_SORTED_NO_TOP": "1"}, {"FMSI_HIP_SORTED_BASES": "3"}):
+        res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=dict(os.environ, **env))
+        assert res.returncode == 0 and res.stdout.strip().endswith("ok"), (env, res.stderr[-1500:])
