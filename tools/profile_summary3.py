@@ -9,7 +9,8 @@ import re
 import sys
 
 QUERY = ("dict_lookup_kernel", "dict_chain_kernel", "sk_runs_kernel", "query_stream2_kernel", "query_stream_kernel", "stream_prep_kernel", "stream_compact_kernel",
-         "pack_results_kernel", "query_pair_kernel", "query_lockstep_kernel")
+         "pack_results_kernel", "query_pair_kernel", "query_lockstep_kernel", "sk_kmers_kernel", "sorted_walk_kernel", "sw_items_kernel", "sw_combine_kernel",
+         "onesweep_iteration_kernel")
 
 
 def main(out):
