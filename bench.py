@@ -68,9 +68,11 @@ def parse_args(argv=None):
                     help="private prefix table length t (0 = none; default: 16; without candidate tables less while 4^t > 4n)")
     ap.add_argument("--kernel", choices=["phased", "pair", "refill", "lockstep"], default="phased",
                     help="phased = pair layout, table lookups in their own kernel (default); pair = the same in one kernel")
-    ap.add_argument("--accel", choices=["dict", "tables"], default="dict",
-                    help="private accelerator of the phased workload: dict = the k-mer dictionary (fmsi_hip_index_enable_dict: one 128-byte "
-                         "bucket read per k-mer, ~13 bytes of HBM per distinct k-mer); tables = prefix table + candidate tables (177 GB at t = 16)")
+    ap.add_argument("--accel", choices=["compact", "dict", "tables"], default="compact",
+                    help="private accelerator of the phased workload: compact = the super-k-mer dictionary ALONE (FMSI_HIP_DICT_SUPERKMER_ONLY: 16-byte "
+                         "records filed by minimizer, one 128-byte bucket read per isolated k-mer, ~7 bytes of HBM per distinct k-mer; 23 <= k <= 32, "
+                         "else dict); dict = the k-mer dictionary (fmsi_hip_index_enable_dict: one 128-byte bucket read per k-mer, ~13 bytes of HBM "
+                         "per distinct k-mer); tables = prefix table + candidate tables (177 GB at t = 16)")
     ap.add_argument("--dict-sparse", action="store_true", help="dictionary at half the load (twice the HBM, no second-level reads)")
     ap.add_argument("--no-dict-chain", dest="dict_chain", action="store_false",
                     help="stream workload: the dictionary without the extras of chained lookups (FMSI_HIP_DICT_CHAIN, + about 7 B per k-mer: 58.7 "
@@ -113,7 +115,7 @@ def parse_args(argv=None):
                     help="do not measure roofline.traffic in this run (child runs of this script under rocprofv3 --pmc, FETCH_SIZE and "
                          "WRITE_SIZE in separate passes)")
     ap.add_argument("--no-config-legs", action="store_true", help="skip the `configs` legs (BASELINE configs 2, 3, 4 and the whole process)")
-    ap.add_argument("--legs", default="c2,c3,c3sk,c4,c4sk,e2e", help="which `configs` legs to run")
+    ap.add_argument("--legs", default="c2,c3,c3sk,c4,c4sk,c5dict,e2e", help="which `configs` legs to run")
     ap.add_argument("--leg", default=None, help=argparse.SUPPRESS)          # child mode: one leg, a JSON list on stdout
     ap.add_argument("--variants", default=None, help="with --leg: only these variants of the leg (comma-separated names), e.g. for a rocprofv3 run of one")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)   # child mode under rocprofv3: the plan's launches, nothing printed
@@ -126,7 +128,7 @@ def parse_args(argv=None):
                          "presence answers of -S do not depend on the kLCP array); auto = runs with --accel dict, else klcp")
     args = ap.parse_args(argv)
     if args.stream_via == "auto":
-        args.stream_via = "runs" if args.accel == "dict" else "klcp"
+        args.stream_via = "runs" if args.accel in ("dict", "compact") else "klcp"
     return args
 
 
@@ -179,7 +181,11 @@ def barrier(c):
 def resolve_accelerators(args, n, k, stream_mode):
     """Which private accelerator answers the timed queries (sets args.use_dict, args.prefix_len): the dictionary answers presence queries of
     the phased workload and of `--stream-via runs`; the kLCP kernel and the A/B kernels (--kernel pair | refill | lockstep) run without."""
-    use_dict = args.accel == "dict" and k <= 32 and ((not stream_mode and args.kernel == "phased") or (stream_mode and args.stream_via == "runs"))
+    use_dict = args.accel in ("dict", "compact") and k <= 32 and ((not stream_mode and args.kernel == "phased") or (stream_mode and args.stream_via == "runs"))
+    # the compact structure answers isolated k-mers (the headline) at the k-mer dictionary's rate and half its HBM; reads of the stream
+    # workload keep the k-mer dictionary with chained lookups unless --accel compact is given explicitly with --no-dict-chain
+    args.compact = use_dict and args.accel == "compact" and 23 <= k <= 32 and not args.dict_sparse and not args.hbm_budget and \
+        (not stream_mode or not args.dict_chain)
     if args.hbm_budget > 0 and use_dict:
         # footprints: 4 bits per row (single-step blocks) + 8 bits per row (pair layout) + 2 bits per base (text) + the accelerator;
         # the dictionary: 128 bytes x 2^b buckets, b the smallest with <= 10.5 (sparse: 5.25) distinct k-mers per bucket, + ~3 % overflow
@@ -229,7 +235,14 @@ def build_handle(c, args, n, k, stream_mode, with_klcp=None, want_pair=None, cha
             t1 = time.time()
             if (not stream_mode) if want_pair is None else want_pair:
                 index.enable_pair_layout()   # (the table-less LF-walk leg and the canonical-step count use it)
-            index.enable_dict(sparse=args.dict_sparse, chain=chain, superkmer_only=superkmer_only)
+            try:
+                index.enable_dict(sparse=args.dict_sparse, chain=chain and not (superkmer_only or args.compact), superkmer_only=superkmer_only or args.compact)
+            except fm.FmsiError as e:
+                if not args.compact or e.code != fm.E_RANGE:
+                    raise
+                # (a text whose minimizers are too heavy for the records: the k-mer dictionary the construction went through stays)
+                print(f"warning: no super-k-mer dictionary for this text ({e}); the k-mer dictionary answers", file=sys.stderr)
+                args.compact = False
             accel_s = time.time() - t1
         elif stream_mode and args.stream_via == "runs":
             index.enable_pair_layout()
@@ -619,7 +632,7 @@ def measure_traffic(args, plan, child_args):
 
 def base_child_args(args, n, batch):
     a = ["--n", repr(float(n)), "--batch", repr(float(batch)), "--k", str(args.k), "--seed", str(args.seed), "--query-seed", str(args.query_seed),
-         "--mode", args.mode, "--read-len", str(args.read_len), "--prefix-len", str(args.prefix_len)]
+         "--mode", args.mode, "--read-len", str(args.read_len), "--prefix-len", str(args.prefix_len), "--accel", args.accel]
     if args.dict_sparse:
         a.append("--dict-sparse")
     if args.repeat_permille:
@@ -682,6 +695,8 @@ LEG_SPECS = {
     # construction -- the handle is the index's blocks + the records + the small aux dictionary)
     # ... and, on the same handle, config 5's per-GPU work (= the headline's): isolated 31-mers on the compact structure alone
     "c4sk": (2.8e9, "stream", float(1 << 27), 8, [("c4_superkmer", "runs_sk", 0), ("c4_superkmer_subst1pct", "runs_sk", 10000), ("c5_superkmer", "dict_sk", 0)]),
+    # config 5's per-GPU work on the k-mer dictionary (rounds 2-3's headline; round 4's headline is the compact structure): n = 2.8e9, isolated 31-mers
+    "c5dict": (2.8e9, "kmers", float(1 << 27), 8, [("c5_kmer_dictionary", "dict", 0)]),
     # config 3 (isolated 31-mers, pangenome scale) on the compact structure alone
     "c3sk": (1.4e9, "kmers", float(1 << 27), 8, [("c3_superkmer", "dict_sk", 0)]),
 }
@@ -697,6 +712,8 @@ LEG_TEXT = {
 LEG_TEXT["c4sk"] = LEG_TEXT["c4"]
 LEG_TEXT["c3sk"] = LEG_TEXT["c3"].replace("k-mer dictionary", "super-k-mer dictionary ALONE (the handle holds no k-mer dictionary: every k-mer is a one-window read, its minimizer's bucket "
                                           "one 128-byte read, heavy / overflowed ones the small aux dictionary)")
+LEG_TEXT["c5dict"] = ("BASELINE config 5's per-GPU work on the K-MER dictionary (a hash table of the index's answers, 13 B per k-mer: what rounds 2-3 quoted as the headline): "
+                      "human-genome scale (n=2800000000), k=31, 2^27 isolated random 31-mers per step x 8 steps (50% present), fmsi query -O semantics")
 LEG_TEXT["c5_superkmer"] = ("BASELINE config 5's per-GPU work (and the headline's): human-genome scale (n=2800000000), k=31, 2^27 isolated random 31-mers per step x 8 steps (50% present), "
                     "fmsi query -O semantics, super-k-mer dictionary ALONE (no k-mer dictionary in the handle)")
 VIA_TEXT = {"runs_chain": "fmsi_hip_query_runs, chained dictionary lookups (58.7 GB handle): a lane follows the superstring from its task's first window",
@@ -721,6 +738,7 @@ def run_leg(args):
     stream_mode = workload == "stream"
     args.stream_via = "runs"
     sk_only = name.endswith("sk")
+    args.accel = "dict"   # (the legs say themselves which structure their handle keeps: sk_only)
     if stream_mode and not sk_only:
         args.prefix_len = 16   # (the kLCP kernel's fresh searches start from its 16-deep prefix table, as in the earlier rounds' runs; the dictionary paths do not use it)
     c = open_ctx(args)
@@ -978,7 +996,7 @@ def main():
         plan = json.loads(args.pmc_plan)
         index, _, _ = build_handle(c, args, n, k, stream_mode, with_klcp=any(v["via"] == "klcp" for v in plan),
                                    want_pair=any(v["via"].startswith("lf_") for v in plan), chain=any(v["via"] == "runs_chain" for v in plan),
-                                   superkmer_only=all(v["via"] in ("runs_sk", "dict_sk") for v in plan))
+                                   superkmer_only=any(v["via"] in ("runs_sk", "dict_sk") for v in plan))
         pmc_child(c, args, index, plan)
         os.close(json_fd)
         return
@@ -992,9 +1010,9 @@ def main():
         dist.all_gather(parts, t)
         build_all = [float(p.item()) for p in parts]
     if stream_mode:
-        via = ("runs_chain" if args.dict_chain else "runs_plain") if use_dict else ("runs_tables" if args.stream_via == "runs" else "klcp")
+        via = ("runs_sk" if args.compact else ("runs_chain" if args.dict_chain else "runs_plain")) if use_dict else ("runs_tables" if args.stream_via == "runs" else "klcp")
     else:
-        via = "dict" if use_dict else "legacy"
+        via = ("dict_sk" if args.compact else "dict") if use_dict else "legacy"
     path = QueryPath(c, args, index, via, k, args.batch, args.read_len, args.subst_ppm)
     batch = path.batch
     bits = not args.byte_results
@@ -1094,6 +1112,8 @@ def main():
         except Exception as e:   # the baseline is a reported figure, never a reason to lose the GPU line
             cpu_baseline = {"error": repr(e)}
     info_d = {"n": int(info.n), "device_bytes": int(info.device_bytes), "dict_bytes": int(info.dict_bytes), "dict_levels": int(info.dict_levels),
+              "sk_bytes": int(info.sk_bytes), "sk_records": int(info.sk_records), "sk_log2_buckets": int(info.sk_log2_buckets), "sk_minimizer_len": int(info.sk_minimizer_len),
+              "sk_heavy_minimizers": int(info.sk_heavy_minimizers), "sk_overflowed_buckets": int(info.sk_overflowed_buckets), "sk_aux_keys": int(info.sk_aux_keys),
               "dict_log2_buckets": int(info.dict_log2_buckets), "dict_keys": [int(x) for x in info.dict_keys][:int(info.dict_levels)],
               "dict_chain_bytes": int(info.dict_chain_bytes), "prefix_len": int(info.prefix_len), "candidate_entry_bytes": int(info.candidate_entry_bytes)}
     # ---- everything below runs in child processes: the handle goes first ----
@@ -1103,7 +1123,7 @@ def main():
     torch.cuda.empty_cache()
     fm.trim_scratch(c.local_rank)
 
-    if roof is not None and world == 1 and not args.no_pmc and not os.environ.get("FMSI_BENCH_NO_PMC") and via in ("dict", "runs_chain", "runs_plain", "klcp"):
+    if roof is not None and world == 1 and not args.no_pmc and not os.environ.get("FMSI_BENCH_NO_PMC") and via in ("dict", "dict_sk", "runs_sk", "runs_chain", "runs_plain", "klcp"):
         plan = [{"name": "headline", "via": via, "subst_ppm": args.subst_ppm, "batch": batch,
                  "lines128": int(m["counters"][1]) - int(m["counters"][4]) if via == "klcp" else 0}]
         for leg in (lf_path or []):
@@ -1138,7 +1158,10 @@ def main():
               f"fmsi query -S -O semantics")
     else:
         wl = (f"synthetic max-ones masked superstring n={n} ({scale}), isolated random {k}-mers 50% present, fmsi query -O semantics")
-    if use_dict:
+    if use_dict and args.compact:
+        wl += ("; answered by the handle's super-k-mer dictionary ALONE (the index's answers filed by minimizer in 16-byte records: one 128-byte bucket read and no LF "
+               "step per k-mer, no k-mer dictionary in the handle; the LF walk is roofline.lf_path)")
+    elif use_dict:
         wl += "; answered by the handle's k-mer dictionary (a hash table of the index's answers: one 128-byte read and no LF step per k-mer; the LF walk is roofline.lf_path)"
     if args.repeat_permille:
         wl += (f"; {args.repeat_permille / 10:.0f}% of the superstring's 2048-base segments are copies of {args.repeat_families} repeat "
@@ -1148,9 +1171,13 @@ def main():
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed_max / args.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
         "config": {"workload": wl, "index_rows": info_d["n"], "k": k, "queries_per_step_per_gpu": batch, "mode": args.mode,
-                   "kernel": {"dict": "dictionary", "runs_chain": "dictionary-chained-runs", "runs_plain": "dictionary-runs", "runs_tables": "phased-runs",
-                              "klcp": "stream"}.get(via, args.kernel),
-                   "accelerator": ({"kind": "k-mer dictionary", "bytes": info_d["dict_bytes"], "levels": info_d["dict_levels"],
+                   "kernel": {"dict": "dictionary", "dict_sk": "super-k-mer dictionary", "runs_sk": "super-k-mer-runs", "runs_chain": "dictionary-chained-runs",
+                              "runs_plain": "dictionary-runs", "runs_tables": "phased-runs", "klcp": "stream"}.get(via, args.kernel),
+                   "accelerator": ({"kind": "super-k-mer dictionary alone", "bytes": info_d["sk_bytes"], "records": info_d["sk_records"],
+                                    "log2_buckets": info_d["sk_log2_buckets"], "minimizer_len": info_d["sk_minimizer_len"],
+                                    "heavy_minimizers": info_d["sk_heavy_minimizers"], "overflowed_buckets": info_d["sk_overflowed_buckets"],
+                                    "aux_dictionary_keys": info_d["sk_aux_keys"], "build_seconds": round(accel_s, 2), "lf_steps_per_query": 0} if (use_dict and args.compact) else
+                                   {"kind": "k-mer dictionary", "bytes": info_d["dict_bytes"], "levels": info_d["dict_levels"],
                                     "log2_buckets": info_d["dict_log2_buckets"], "keys_per_level": info_d["dict_keys"],
                                     "chain_bytes": info_d["dict_chain_bytes"], "build_seconds": round(accel_s, 2),
                                     "lf_steps_per_query": 0} if use_dict else

@@ -482,7 +482,7 @@ def test_bench_defaults():
         sys.argv = ["bench.py"]
         spec.loader.exec_module(m)
         a = m.parse_args()
-        assert (a.gpus, a.steps, a.warmup, a.workload, a.accel, a.byte_results, a.no_lf_leg, a.k) == (1, 10, 2, "kmers", "dict", False, False, 31)
+        assert (a.gpus, a.steps, a.warmup, a.workload, a.accel, a.byte_results, a.no_lf_leg, a.k) == (1, 10, 2, "kmers", "compact", False, False, 31)
         assert int(a.n) == 2_800_000_000 and int(a.batch) == 1 << 27
         sys.argv = ["bench.py", "--workload", "stream"]
         a = m.parse_args()
