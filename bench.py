@@ -300,7 +300,7 @@ class QueryPath:
             if via == "dict":
                 self.flags, self.kernel, self.pmc_kernel = mode | fm.KERNEL_DICT, "dict_lookup_kernel", "dict_lookup_kernel<false, false>"
             elif via == "dict_sk":   # a handle that keeps the super-k-mer dictionary alone: every k-mer a one-window read (fmsi_hip.hip, sk_iso)
-                self.flags, self.kernel, self.pmc_kernel = mode | fm.KERNEL_DICT, "sk_runs_kernel", "sk_runs_kernel<false"
+                self.flags, self.kernel, self.pmc_kernel = mode | fm.KERNEL_DICT, "sk_kmers_kernel", "sk_kmers_kernel<false>"
             elif via == "lf_pair":
                 self.flags, self.kernel, self.pmc_kernel = mode | fm.KERNEL_PAIR | fm.NO_PREFIX_TABLE, "query_pair_kernel", "query_pair_kernel<false, false, false>"
             elif via == "lf_lockstep":
@@ -693,8 +693,8 @@ LEG_SPECS = {
                                                  ("c4_klcp", "klcp", 0), ("c4_klcp_subst1pct", "klcp", 10000)]),
     # the same reads through the super-k-mer dictionary ALONE (FMSI_HIP_DICT_SUPERKMER_ONLY: the k-mer dictionary is released after the
     # construction -- the handle is the index's blocks + the records + the small aux dictionary)
-    # ... and, on the same handle, config 5's per-GPU work (= the headline's): isolated 31-mers on the compact structure alone
-    "c4sk": (2.8e9, "stream", float(1 << 27), 8, [("c4_superkmer", "runs_sk", 0), ("c4_superkmer_subst1pct", "runs_sk", 10000), ("c5_superkmer", "dict_sk", 0)]),
+    # (isolated 31-mers on the compact structure alone, config 5's per-GPU work, are the headline itself since round 4)
+    "c4sk": (2.8e9, "stream", float(1 << 27), 8, [("c4_superkmer", "runs_sk", 0), ("c4_superkmer_subst1pct", "runs_sk", 10000)]),
     # config 5's per-GPU work on the k-mer dictionary (rounds 2-3's headline; round 4's headline is the compact structure): n = 2.8e9, isolated 31-mers
     "c5dict": (2.8e9, "kmers", float(1 << 27), 8, [("c5_kmer_dictionary", "dict", 0)]),
     # config 3 (isolated 31-mers, pangenome scale) on the compact structure alone
