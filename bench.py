@@ -322,13 +322,17 @@ class QueryPath:
         else:
             self.index.synthetic_queries_dev(self.k, a.query_seed, (step * c.world + c.rank) * self.batch, self.batch, buf.data_ptr(), c.stream)
 
-    def launch(self, buf, out, counters_ptr=0, extra=0):
+    def launch(self, buf, out, counters_ptr=0, extra=0, kernel=None):
+        """kernel: replaces the path's kernel selection bits for this launch (the canonical-step count: the per-k-mer walk)"""
         c = self.c
+        flags = self.flags | extra
+        if kernel is not None:
+            flags = (flags & ~0xF0) | kernel
         if self.stream_mode:
             fn = self.index.query_stream_dev if self.via == "klcp" else self.index.query_runs_dev
-            fn(buf.data_ptr(), self.n_reads * self.read_len, self.run_start, self.run_windows, self.k, self.flags | extra, out.data_ptr(), counters_ptr, c.stream)
+            fn(buf.data_ptr(), self.n_reads * self.read_len, self.run_start, self.run_windows, self.k, flags, out.data_ptr(), counters_ptr, c.stream)
         else:
-            self.index.query_kmers_dev(buf.data_ptr(), self.batch, self.k, self.flags | extra, out.data_ptr(), counters_ptr, c.stream)
+            self.index.query_kmers_dev(buf.data_ptr(), self.batch, self.k, flags, out.data_ptr(), counters_ptr, c.stream)
 
     def describe(self):
         return {"via": self.via, "workload": "stream" if self.stream_mode else "kmers", "subst_ppm": self.subst_ppm}
@@ -371,7 +375,8 @@ def timed_region(c, args, path, steps, warmup, bits=True, host_copy="per-rank", 
             # what the reference algorithm executes for the same queries: no prefix table (and, for the stream workload,
             # its own chunking is longer than a 64-window task, so this is an upper bound on its steps)
             d_cnt.zero_()
-            path.launch(bufs[0], d_out, d_cnt.data_ptr(), fm.NO_PREFIX_TABLE)
+            path.launch(bufs[0], d_out, d_cnt.data_ptr(), fm.NO_PREFIX_TABLE,
+                        kernel=fm.KERNEL_PAIR if (index.has_pair_layout and path.via != "klcp") else None)   # (one search per k-mer and strand: not the batch-sorted walk AUTO would take)
             torch.cuda.synchronize()
             canonical = d_cnt.cpu().numpy().astype(np.int64)
     positives = float(d_out.to(torch.float32).mean().item())

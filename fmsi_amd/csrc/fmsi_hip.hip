@@ -612,7 +612,12 @@ int launch_query(fmsi_hip_index* idx, const uint64_t* d_kmers, uint64_t n_window
         flags &= ~FMSI_HIP_KERNEL_MASK;
         kernel = FMSI_HIP_KERNEL_AUTO;
     }
-    const bool sorted = !dict && !sk_iso && sorted_walk_applies(idx, k, flags);
+    // AUTO on a handle with the pair layout and no usable table: a LARGE batch takes the batch-sorted walk (3.8 G k-mers/s at human scale
+    // where the per-k-mer pair kernel does 2.1 G; its sort and its per-batch top levels do not pay below a few million k-mers); a handle
+    // without the room for its scratch (about 50 bytes per k-mer) keeps the pair kernel
+    const bool sorted_auto = !dict && !sk_iso && kernel == FMSI_HIP_KERNEL_AUTO && !use_table && idx->d_pblocks && n_windows >= (1ull << 22) &&
+                             sorted_walk_applies(idx, k, (flags & ~FMSI_HIP_KERNEL_MASK) | FMSI_HIP_KERNEL_SORTED);
+    const bool sorted = !dict && !sk_iso && (sorted_auto || sorted_walk_applies(idx, k, flags));
     if (kernel == FMSI_HIP_KERNEL_SORTED && !sorted) {   // (lookup, k > 32, no pair layout: AUTO)
         flags &= ~FMSI_HIP_KERNEL_MASK;
         kernel = FMSI_HIP_KERNEL_AUTO;
@@ -640,7 +645,13 @@ int launch_query(fmsi_hip_index* idx, const uint64_t* d_kmers, uint64_t n_window
         else rc = launch_skdict_kmers(idx, d_kmers, n_windows, flags, o8, d_counters, s);
         if (rc) return rc;
     } else if (sorted) {
-        if ((rc = launch_sorted_query(idx, d_kmers, n_windows, k, flags, o8, d_counters, s))) return rc;
+        rc = launch_sorted_query(idx, d_kmers, n_windows, k, flags, o8, d_counters, s);
+        if (rc == FMSI_HIP_ENOMEM && sorted_auto) {   // (nothing was launched: the scratch is claimed first)
+            (void)hipGetLastError();
+            launch_pair_query(idx, d_kmers, n_windows, k, flags, false, o8, o64, d_counters, s);
+            rc = 0;
+        }
+        if (rc) return rc;
     } else if (kernel == FMSI_HIP_KERNEL_LOCKSTEP) {
         const uint64_t blocks64 = (n_windows + 255) / 256;
         if (blocks64 > 0x7FFFFFFFull) {

@@ -509,8 +509,11 @@ int launch_sorted_t(fmsi_hip_index* idx, const uint64_t* d_kmers, uint64_t n, in
     }
     temp_b = round_up(temp_b);
     const size_t need = 2 * key_b + 2 * val_b + ij_b + tern_b + cnt_b + top1_b + top2_b + temp_b;
-    int rc = ensure_cap(&idx->d_sorted, &idx->d_sorted_cap, need);
-    if (rc) return rc;
+    if (ensure_cap(&idx->d_sorted, &idx->d_sorted_cap, need)) {   // (before anything is launched: a caller may fall back to another kernel)
+        (void)hipGetLastError();
+        set_last_error("no device memory for the sorted walk's scratch (" + std::to_string(need >> 20) + " MiB)");
+        return FMSI_HIP_ENOMEM;
+    }
     char* base = static_cast<char*>(idx->d_sorted);
     auto carve = [&](size_t bytes) {
         char* p = base;

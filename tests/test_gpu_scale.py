@@ -378,9 +378,18 @@ def test_adversarial_text_at_1e9_rows(fm):
         dev.enable_dict(superkmer=True)
     except fm.FmsiError as e:
         assert e.code == fm.E_RANGE
+        print(f"adversarial text: no super-k-mer dictionary (FMSI_HIP_ERANGE: {e})")
+        branch = "refused"
     else:
+        info = dev.info
+        print(f"adversarial text: super-k-mer dictionary built ({info.sk_records} records, {info.sk_heavy_minimizers} heavy minimizers, "
+              f"{info.sk_aux_keys} k-mers in the aux dictionary)")
+        branch = "built"
         for mode in (fm.MODE_OR, fm.MODE_ALL):
             _reads_agree(fm, dev, k, 2000, 512, 10000, mode | fm.STRICT, mode | fm.STRICT | fm.NO_PREFIX_TABLE)
+    # which branch this text takes is a property of the construction, not of the box: it is BUILT (the megabase homopolymers and tandem
+    # repeats are a few heavy minimizers whose k-mers go to the aux dictionary) -- a change of that is a change to look at
+    assert branch == "built"
 
 
 def test_largest_index_with_32_bit_rows(fm):
@@ -430,3 +439,26 @@ def test_index_equals_the_reference_built_one_at_1e8(fm, tmp_path):
     wins = np.full(n_reads, L - k + 1, dtype=np.uint32)
     assert np.array_equal(loaded.query_stream(packed, n_reads * L, starts, wins, k, fm.MODE_OR | fm.STRICT),
                           loaded.query_runs(packed, n_reads * L, starts, wins, k, fm.MODE_OR | fm.STRICT))
+
+
+def test_auto_takes_the_sorted_walk_for_large_batches(fm):
+    """FMSI_HIP_KERNEL_AUTO on a handle with the pair layout and no table: a batch of 2^22 k-mers and more goes through the batch-sorted walk
+    (fmsi_sorted.hip) -- recognisable by its counters: the shared top of the search tree is walked once, far fewer LF steps than one search per
+    k-mer and strand executes -- a smaller one through the per-k-mer pair kernel; the answers are the same either way."""
+    import torch
+    n, k = 100_000_000, 31
+    dev = fm.DeviceIndex.build_synthetic(n, 4321, k, mask_permille=700).enable_pair_layout()
+    s = torch.cuda.current_stream().cuda_stream
+    for nq, expect_sorted in ((1 << 22, True), ((1 << 22) - 64, False)):
+        d_kmers = torch.empty(nq, dtype=torch.int64, device="cuda")
+        dev.synthetic_queries_dev(k, 9, 0, nq, d_kmers.data_ptr(), s)
+        outs, steps = {}, {}
+        for name, kern in (("auto", 0), ("pair", fm.KERNEL_PAIR), ("sorted", fm.KERNEL_SORTED)):
+            d_out = torch.empty(nq, dtype=torch.uint8, device="cuda")
+            d_cnt = torch.zeros(fm.N_COUNTERS, dtype=torch.int64, device="cuda")
+            dev.query_kmers_dev(d_kmers.data_ptr(), nq, k, fm.MODE_ALL | fm.STRICT | kern, d_out.data_ptr(), d_cnt.data_ptr(), s)
+            torch.cuda.synchronize()
+            outs[name], steps[name] = d_out.cpu().numpy(), int(d_cnt[0].item())
+        assert np.array_equal(outs["auto"], outs["pair"]) and np.array_equal(outs["sorted"], outs["pair"])
+        assert steps["sorted"] < 0.7 * steps["pair"]
+        assert steps["auto"] == (steps["sorted"] if expect_sorted else steps["pair"]), (nq, steps)
