@@ -115,7 +115,7 @@ def parse_args(argv=None):
                     help="do not measure roofline.traffic in this run (child runs of this script under rocprofv3 --pmc, FETCH_SIZE and "
                          "WRITE_SIZE in separate passes)")
     ap.add_argument("--no-config-legs", action="store_true", help="skip the `configs` legs (BASELINE configs 2, 3, 4 and the whole process)")
-    ap.add_argument("--legs", default="c2,c3,c3sk,c4,c4sk,c5dict,e2e", help="which `configs` legs to run")
+    ap.add_argument("--legs", default="c2,c3,c3sk,c4,c4k,c4sk,c5dict,e2e", help="which `configs` legs to run")
     ap.add_argument("--leg", default=None, help=argparse.SUPPRESS)          # child mode: one leg, a JSON list on stdout
     ap.add_argument("--variants", default=None, help="with --leg: only these variants of the leg (comma-separated names), e.g. for a rocprofv3 run of one")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)   # child mode under rocprofv3: the plan's launches, nothing printed
@@ -694,8 +694,10 @@ LEG_SPECS = {
     "c2": (4.7e6, "kmers", 1e8, 5, [("c2", "dict", 0)]),
     "c3": (1.4e9, "kmers", float(1 << 27), 8, [("c3", "dict", 0)]),
     "c4": (2.8e9, "stream", float(1 << 27), 8, [("c4_dict_chain", "runs_chain", 0), ("c4_dict_chain_subst1pct", "runs_chain", 10000),
-                                                 ("c4_dict_plain", "runs_plain", 0), ("c4_dict_plain_subst1pct", "runs_plain", 10000),
-                                                 ("c4_klcp", "klcp", 0), ("c4_klcp_subst1pct", "klcp", 10000)]),
+                                                 ("c4_dict_plain", "runs_plain", 0), ("c4_dict_plain_subst1pct", "runs_plain", 10000)]),
+    # the kLCP kernel on a handle of its own: blocks, kLCP array, S-blocks and the 16-deep prefix table -- no dictionary (round 3 timed it on the
+    # chained dictionary's 93-GB handle)
+    "c4k": (2.8e9, "stream", float(1 << 27), 8, [("c4_klcp", "klcp", 0), ("c4_klcp_subst1pct", "klcp", 10000)]),
     # the same reads through the super-k-mer dictionary ALONE (FMSI_HIP_DICT_SUPERKMER_ONLY: the k-mer dictionary is released after the
     # construction -- the handle is the index's blocks + the records + the small aux dictionary)
     # (isolated 31-mers on the compact structure alone, config 5's per-GPU work, are the headline itself since round 4)
@@ -715,6 +717,7 @@ LEG_TEXT = {
           "every 31-mer window, fmsi query -S -O answers",
 }
 LEG_TEXT["c4sk"] = LEG_TEXT["c4"]
+LEG_TEXT["c4k"] = LEG_TEXT["c4"]
 LEG_TEXT["c3sk"] = LEG_TEXT["c3"].replace("k-mer dictionary", "super-k-mer dictionary ALONE (the handle holds no k-mer dictionary: every k-mer is a one-window read, its minimizer's bucket "
                                           "one 128-byte read, heavy / overflowed ones the small aux dictionary)")
 LEG_TEXT["c5dict"] = ("BASELINE config 5's per-GPU work on the K-MER dictionary (a hash table of the index's answers, 13 B per k-mer: what rounds 2-3 quoted as the headline): "
@@ -741,15 +744,16 @@ def run_leg(args):
     n = int(n)
     args.n, args.batch, args.workload = float(n), batch, workload
     stream_mode = workload == "stream"
-    args.stream_via = "runs"
     sk_only = name.endswith("sk")
-    args.accel = "dict"   # (the legs say themselves which structure their handle keeps: sk_only)
-    if stream_mode and not sk_only:
-        args.prefix_len = 16   # (the kLCP kernel's fresh searches start from its 16-deep prefix table, as in the earlier rounds' runs; the dictionary paths do not use it)
+    klcp_only = name == "c4k"
+    args.stream_via = "klcp" if klcp_only else "runs"
+    args.accel = "tables" if klcp_only else "dict"   # (the legs say themselves which structures their handle keeps)
+    if klcp_only:
+        args.prefix_len = 16   # (the kLCP kernel's fresh searches start from its 16-deep prefix table, as in the earlier rounds' runs)
     c = open_ctx(args)
     k = args.k
     resolve_accelerators(args, n, k, stream_mode)
-    index, build_s, accel_s = build_handle(c, args, n, k, stream_mode, with_klcp=stream_mode and not sk_only, want_pair=False, chain=stream_mode and not sk_only,
+    index, build_s, accel_s = build_handle(c, args, n, k, stream_mode, with_klcp=klcp_only, want_pair=False, chain=stream_mode and not sk_only and not klcp_only,
                                            superkmer_only=sk_only)
     info = index.info
     legs = []
@@ -796,7 +800,7 @@ def run_leg(args):
     c.fm.trim_scratch(c.local_rank)
     if not args.no_pmc and not os.environ.get("FMSI_BENCH_NO_PMC"):
         plan = [{"name": vn, "via": via, "subst_ppm": s, "batch": batch, "lines128": leg["_lines128"]} for (vn, via, s), leg in zip(variants, legs)]
-        extra = ["--workload", workload, "--stream-via", "runs", "--leg-handle", name] + base_child_args(args, n, batch)
+        extra = ["--workload", workload, "--stream-via", args.stream_via, "--leg-handle", name] + base_child_args(args, n, batch)
         got, why = measure_traffic(args, plan, extra)
         for leg in legs:
             if got and leg["name"] in got:
