@@ -821,8 +821,13 @@ __global__ __launch_bounds__(256, 4) void query_stream2_kernel(DevIndex ix, cons
                                                             const TaskRec* __restrict__ tasks, uint64_t n_tasks, int k, uint32_t flags, uint32_t chunk,
                                                             uint4* __restrict__ slots, unsigned long long* __restrict__ counters, UniformRuns u) {
     __shared__ uint4 s_line[4][64 * kSPitch];
+    // what a lane's pass 0 learns about the FIRST windows of the NEXT task of its read (the hints of its last k - T lookups point past its own
+    // 64 windows): task number and one bit per window, read by the right-hand neighbour -- which holds that task -- when its pass 1 begins
+    __shared__ uint32_t s_hint_task[4][64], s_hint_bits[4][64];
     const uint32_t ln = threadIdx.x & 63u;
     uint4* my_wave_lines = s_line[threadIdx.x >> 6];
+    uint32_t* hint_task = s_hint_task[threadIdx.x >> 6];
+    uint32_t* hint_bits = s_hint_bits[threadIdx.x >> 6];
     const uint32_t* L = reinterpret_cast<const uint32_t*>(my_wave_lines + ln * kSPitch);   // this lane's staged line
     const uint32_t mode_all = flags & FMSI_HIP_MODE_ALL;
     const uint32_t strict = flags & FMSI_HIP_STRICT;
@@ -886,6 +891,8 @@ __global__ __launch_bounds__(256, 4) void query_stream2_kernel(DevIndex ix, cons
         if (strict) todo = all;
         else if (!mode_all) todo = all & ~(rf_hi & ~rf_lo);   // OR: only a pass-0 result of 1 decides
         else todo = all & ~(rf_lo | rf_hi);                   // ALL: any non-empty pass-0 interval decides
+        if (UNI && cur_rc && ln > 0u && hint_task[ln - 1u] + 1u == static_cast<uint32_t>(task_id) && static_cast<uint32_t>(task_id) % u.tpr != 0u)
+            other_dead |= hint_bits[ln - 1u];                 // (the left neighbour walked the task before mine of the same read: its hints about my first windows)
         todo &= ~other_dead;                                  // (their pass-1 result is "empty interval": the planes' zero says so)
         if (!todo) {
             end_task();
@@ -1024,6 +1031,8 @@ __global__ __launch_bounds__(256, 4) void query_stream2_kernel(DevIndex ix, cons
                     special = 0;
                     rf_lo = rf_hi = rr_lo = rr_hi = 0;
                     other_dead = 0;
+                    hint_task[ln] = static_cast<uint32_t>(cand);
+                    hint_bits[ln] = 0u;
                     widx = n - 1u;
                     load_kmer();
                     fresh();
@@ -1095,6 +1104,12 @@ __global__ __launch_bounds__(256, 4) void query_stream2_kernel(DevIndex ix, cons
                         dead = dead || !((ent.y >> (26u + c_next)) & 1u);
                     }
                     if (dead) other_dead |= 1ull << w2;
+                } else if (UNI && !cur_rc && n == 64u && w2 < 64u + d) {
+                    // window w2 - 64 of the NEXT task of this read (if there is one: the reader checks): the same test, the bases are at hand
+                    // (a task's four words hold 128 bases, w2 + T <= 94)
+                    bool dead = (ent.y >> 31) != 0u;
+                    if (t >= 0) dead = dead || !((ent.y >> (26u + 3u - task_base(s0, s1, s2, s3, w2 + static_cast<uint32_t>(T)))) & 1u);
+                    if (dead) hint_bits[ln] |= 1u << (w2 - 64u);
                 }
             }
             if (i == j) {
