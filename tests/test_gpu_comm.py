@@ -104,7 +104,7 @@ def test_one_rank_under_torchrun_is_as_fast_as_the_plain_run(fm):
     """The headline workload (human scale, 2^27 31-mers per step, dictionary) launched the way the driver launches N > 1 -- torch.distributed.run,
     process group over RCCL, gather + per-rank host copy on side streams inside the timed region -- with the one rank this box allows, against the
     plain `python bench.py` run: the multi-rank plumbing must not serialise anything (the first version of this test found that it did: kernel,
-    gather and copy ran one after the other).  Two runs each, alternating; the better of each."""
+    gather and copy ran one after the other).  One run each (two each until round 4: the ratio did not move between them)."""
     import json
     import os
     import subprocess
@@ -118,7 +118,7 @@ def test_one_rank_under_torchrun_is_as_fast_as_the_plain_run(fm):
             str(repo / "bench.py"), *common, "--force-dist"]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     vals = {"plain": [], "dist": []}
-    for rnd in range(2):
+    for rnd in range(1):
         for name, cmd in (("plain", plain), ("dist", dist)):
             res = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=str(repo))
             assert res.returncode == 0, res.stderr[-2000:]
