@@ -475,8 +475,8 @@ int build_from_device_text(DevBuf& text2, uint64_t len, DevBuf* mask_text, int k
 // dealt into 16 buckets by their first two bases (a histogram pass and a scatter pass with wave-aggregated cursors), every bucket -- a
 // sixteenth of the text or so -- is sorted by its 29-base keys with 64-bit positions as values, and the buckets in order are the suffix
 // array by 29 bases.  Suffixes that still tie (a handful in a text without long repeats: n^2 / 4^29 pairs) are ordered by comparing
-// their next 29-base keys directly, group by group; a text with tied groups of more than kWideTieCap suffixes is not for this builder
-// (FMSI_HIP_ERANGE: prefix doubling with 64-bit ranks is what it would take).  Rows, blocks and counts as above -- the u32 cumulative
+// their next 29-base keys directly, group by group; a text with tied groups of more than kWideTieCap suffixes -- a repetitive one, i.e. any
+// real genome of this size -- gets prefix doubling with 64-bit ranks over all tied suffixes (wide_prefix_doubling, round 4).  Rows, blocks and counts as above -- the u32 cumulative
 // counts simply wrap -- plus the table of absolute counts per superblock that query_wide_kernel reads.  No kLCP array, no tables.
 constexpr uint32_t kWideTieCap = 64;
 
@@ -569,6 +569,187 @@ __global__ __launch_bounds__(256) void wide_ties_kernel(const uint64_t* __restri
         }
         sa[i + b] = v;
     }
+}
+
+// ---- prefix doubling with 64-bit rows (round 4): tied groups of any size ---------------------------------------------------------------
+// The narrow builder's scheme (group_heads / rank_and_ties / compact_ties / doubling_keys / apply_order above) with u64 rows, positions and
+// ranks: rank[p] = 1 + first row of the group of suffix p (0: the empty suffix); the rows whose 29-base key equals a neighbour's are kept as
+// (row, position, group) triples and sorted by (group, rank[position + depth]) -- a 128-bit key -- with the depth doubling until every
+// group is one suffix.  The first pass runs over ALL len > 2^32 sorted suffixes: kernels and scans in pieces of 2^30 (a launch and a rocPRIM
+// call take fewer than 2^32 items), carries handed from piece to piece; the rounds run over the tied suffixes only (fewer than 2^32 - 8192,
+// or FMSI_HIP_ERANGE).
+struct U64Max {
+    __host__ __device__ uint64_t operator()(uint64_t a, uint64_t b) const { return a > b ? a : b; }
+};
+// start[i] = its own row when element i starts a group of equal keys, else 0; the first element of a piece takes the carry (the group's
+// first row as the piece before left it) when it continues that piece's last group
+__global__ __launch_bounds__(256) void wide_heads_kernel(const uint64_t* __restrict__ keys, uint64_t count, uint64_t first_item, uint64_t* __restrict__ start) {
+    const uint64_t i = first_item + static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const bool head = i == 0 || keys[i] != keys[i - 1];
+    start[i] = head ? i : ((i == first_item) ? start[i - 1] : 0ull);   // (start[i - 1]: the piece before is scanned by now -- its group's first row)
+}
+// rank of every suffix, and whether its group has more than one member
+__global__ __launch_bounds__(256) void wide_rank_ties_kernel(const uint64_t* __restrict__ grp, const uint64_t* __restrict__ pos, uint64_t count, uint64_t first_item,
+                                                             uint64_t* __restrict__ rank, uint32_t* __restrict__ tied /* this piece's flags, from 0 */) {
+    const uint64_t i = first_item + static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const uint64_t g = grp[i];
+    rank[pos[i]] = g + 1u;
+    tied[i - first_item] = ((i > 0 && grp[i - 1] == g) || (i + 1 < count && grp[i + 1] == g)) ? 1u : 0u;
+}
+__global__ __launch_bounds__(256) void wide_compact_kernel(const uint32_t* __restrict__ tied, const uint32_t* __restrict__ slot, const uint64_t* __restrict__ pos,
+                                                           const uint64_t* __restrict__ grp, uint64_t count, uint64_t first_item, uint64_t out_base,
+                                                           uint64_t* __restrict__ out_rows, uint64_t* __restrict__ out_pos, uint64_t* __restrict__ out_grp) {
+    const uint64_t i = first_item + static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= count || !tied[i - first_item]) return;
+    const uint64_t o = out_base + slot[i - first_item];
+    out_rows[o] = i;
+    out_pos[o] = pos[i];
+    out_grp[o] = grp[i];
+}
+// ---- the rounds over the tied suffixes (count < 2^32)
+__global__ __launch_bounds__(256) void wide_doubling_keys_kernel(const uint64_t* __restrict__ pos, const uint64_t* __restrict__ grp, const uint64_t* __restrict__ rank,
+                                                                 uint64_t count, uint64_t depth, __uint128_t* __restrict__ keys, uint32_t* __restrict__ idx) {
+    const uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    // (a tied suffix is at least `depth` long -- shorter ones were unique by their length field -- so pos + depth <= len: rank[len] = 0)
+    keys[i] = (static_cast<__uint128_t>(grp[i]) << 64) | rank[pos[i] + depth];
+    idx[i] = static_cast<uint32_t>(i);
+}
+__global__ __launch_bounds__(256) void wide_apply_order_kernel(const uint32_t* __restrict__ order, const uint64_t* __restrict__ pos, const uint64_t* __restrict__ rows,
+                                                               uint64_t count, uint64_t* __restrict__ new_pos, uint64_t* __restrict__ sa) {
+    const uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const uint64_t p = pos[order[i]];
+    new_pos[i] = p;
+    sa[rows[i]] = p;
+}
+__global__ __launch_bounds__(256) void wide_round_heads_kernel(const __uint128_t* __restrict__ keys, const uint64_t* __restrict__ rows, uint64_t count,
+                                                               uint64_t* __restrict__ start) {
+    const uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    start[i] = (i == 0 || keys[i] != keys[i - 1]) ? rows[i] : 0ull;
+}
+__global__ __launch_bounds__(256) void wide_round_rank_ties_kernel(const uint64_t* __restrict__ grp, const uint64_t* __restrict__ pos, uint64_t count,
+                                                                   uint64_t* __restrict__ rank, uint32_t* __restrict__ tied) {
+    const uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const uint64_t g = grp[i];
+    rank[pos[i]] = g + 1u;
+    tied[i] = ((i > 0 && grp[i - 1] == g) || (i + 1 < count && grp[i + 1] == g)) ? 1u : 0u;
+}
+__global__ __launch_bounds__(256) void wide_round_compact_kernel(const uint32_t* __restrict__ tied, const uint32_t* __restrict__ slot, const uint64_t* __restrict__ rows,
+                                                                 const uint64_t* __restrict__ pos, const uint64_t* __restrict__ grp, uint64_t count,
+                                                                 uint64_t* __restrict__ out_rows, uint64_t* __restrict__ out_pos, uint64_t* __restrict__ out_grp) {
+    const uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= count || !tied[i]) return;
+    const uint32_t o = slot[i];
+    out_rows[o] = rows[i];
+    out_pos[o] = pos[i];
+    out_grp[o] = grp[i];
+}
+
+// keys: the sorted 29-base keys (consumed: freed here), sa: the positions in that order -- on return the suffix array
+int wide_prefix_doubling(DevBuf& keys, uint64_t* sa, uint64_t len, PhaseClock& clock) {
+    constexpr uint64_t kPiece = 1ull << 30;
+    int rc;
+    DevBuf grp, rank, tied, slot, scan_tmp;
+    if ((rc = grp.alloc(len * 8)) || (rc = rank.alloc((len + 1) * 8)) || (rc = tied.alloc((kPiece + 1) * 4)) || (rc = slot.alloc((kPiece + 1) * 4))) return rc;
+    size_t sb1 = 0, sb2 = 0;
+    FMSI_HIP_TRY(rocprim::inclusive_scan(nullptr, sb1, grp.as<uint64_t>(), grp.as<uint64_t>(), static_cast<size_t>(kPiece), U64Max()));
+    FMSI_HIP_TRY(rocprim::exclusive_scan(nullptr, sb2, tied.as<uint32_t>(), slot.as<uint32_t>(), 0u, static_cast<size_t>(kPiece + 1), rocprim::plus<uint32_t>()));
+    if ((rc = scan_tmp.alloc(std::max(sb1, sb2)))) return rc;
+    // ---- groups of equal keys over all suffixes: first rows by a max-scan, piece by piece
+    for (uint64_t at = 0; at < len; at += kPiece) {
+        const uint64_t cnt = std::min(kPiece, len - at);
+        hipLaunchKernelGGL(wide_heads_kernel, dim3(grid_for(cnt)), dim3(256), 0, 0, keys.as<uint64_t>(), len, at, grp.as<uint64_t>());
+        size_t b1 = sb1;
+        FMSI_HIP_TRY(rocprim::inclusive_scan(scan_tmp.p, b1, grp.as<uint64_t>() + at, grp.as<uint64_t>() + at, static_cast<size_t>(cnt), U64Max()));
+    }
+    FMSI_HIP_TRY(hipDeviceSynchronize());
+    (void)dev_free(keys.release());   // (only their equality was needed)
+    FMSI_HIP_TRY(hipMemset(rank.p, 0, (len + 1) * 8));   // rank[len] = 0: the empty suffix
+    // ---- ranks, and the tied suffixes counted (pass 0) and kept (pass 1)
+    DevBuf t_rows, t_pos, t_grp;
+    uint64_t n_tied = 0;
+    for (int pass = 0; pass < 2; ++pass) {
+        uint64_t base = 0;
+        for (uint64_t at = 0; at < len; at += kPiece) {
+            const uint64_t cnt = std::min(kPiece, len - at);
+            hipLaunchKernelGGL(wide_rank_ties_kernel, dim3(grid_for(cnt)), dim3(256), 0, 0, grp.as<uint64_t>(), sa, len, at, rank.as<uint64_t>(), tied.as<uint32_t>());
+            FMSI_HIP_TRY(hipMemsetAsync(tied.as<uint32_t>() + cnt, 0, 4, 0));
+            size_t b2 = sb2;
+            FMSI_HIP_TRY(rocprim::exclusive_scan(scan_tmp.p, b2, tied.as<uint32_t>(), slot.as<uint32_t>(), 0u, static_cast<size_t>(cnt + 1), rocprim::plus<uint32_t>()));
+            uint32_t t = 0;
+            FMSI_HIP_TRY(hipMemcpy(&t, slot.as<uint32_t>() + cnt, 4, hipMemcpyDeviceToHost));
+            if (pass == 1 && t) {
+                hipLaunchKernelGGL(wide_compact_kernel, dim3(grid_for(cnt)), dim3(256), 0, 0, tied.as<uint32_t>(), slot.as<uint32_t>(), sa, grp.as<uint64_t>(), len, at, base,
+                                   t_rows.as<uint64_t>(), t_pos.as<uint64_t>(), t_grp.as<uint64_t>());
+                FMSI_HIP_TRY(hipGetLastError());
+            }
+            base += t;
+        }
+        if (pass == 0) {
+            n_tied = base;
+            if (n_tied == 0) return 0;
+            if (n_tied > kMaxSortItems) {
+                set_last_error("the on-device builder for 2^32 rows and more: " + std::to_string(n_tied) + " suffixes share their first 29 bases with another -- more than one sort takes");
+                return FMSI_HIP_ERANGE;
+            }
+            if ((rc = t_rows.alloc(n_tied * 8)) || (rc = t_pos.alloc(n_tied * 8)) || (rc = t_grp.alloc(n_tied * 8))) return rc;
+        }
+    }
+    FMSI_HIP_TRY(hipDeviceSynchronize());
+    (void)dev_free(grp.release());
+    clock.mark("ties: ranks + tied suffixes");
+    // ---- the rounds
+    for (uint64_t depth = kKeyBases; n_tied; depth *= 2) {
+        DevBuf k_a, k_b, i_a, i_b, new_pos, sort_tmp, r_grp, r_tied, r_slot, n_rows, n_pos, n_grp, r_scan;
+        if ((rc = k_a.alloc(n_tied * 16)) || (rc = k_b.alloc(n_tied * 16)) || (rc = i_a.alloc(n_tied * 4)) || (rc = i_b.alloc(n_tied * 4)) || (rc = new_pos.alloc(n_tied * 8)) ||
+            (rc = r_grp.alloc(n_tied * 8)) || (rc = r_tied.alloc((n_tied + 1) * 4)) || (rc = r_slot.alloc((n_tied + 1) * 4)))
+            return rc;
+        hipLaunchKernelGGL(wide_doubling_keys_kernel, dim3(grid_for(n_tied)), dim3(256), 0, 0, t_pos.as<uint64_t>(), t_grp.as<uint64_t>(), rank.as<uint64_t>(), n_tied, depth,
+                           k_a.as<__uint128_t>(), i_a.as<uint32_t>());
+        rocprim::double_buffer<__uint128_t> dk2(k_a.as<__uint128_t>(), k_b.as<__uint128_t>());
+        rocprim::double_buffer<uint32_t> dv2(i_a.as<uint32_t>(), i_b.as<uint32_t>());
+        size_t tb = 0;
+        FMSI_HIP_TRY(rocprim::radix_sort_pairs(nullptr, tb, dk2, dv2, static_cast<size_t>(n_tied), 0, 128, 0));
+        if ((rc = sort_tmp.alloc(tb))) return rc;
+        FMSI_HIP_TRY(rocprim::radix_sort_pairs(sort_tmp.p, tb, dk2, dv2, static_cast<size_t>(n_tied), 0, 128, 0));
+        hipLaunchKernelGGL(wide_apply_order_kernel, dim3(grid_for(n_tied)), dim3(256), 0, 0, dv2.current(), t_pos.as<uint64_t>(), t_rows.as<uint64_t>(), n_tied,
+                           new_pos.as<uint64_t>(), sa);
+        // the groups of this round (rows stay in place: t_rows), ranks of the settled ones, what is still tied
+        hipLaunchKernelGGL(wide_round_heads_kernel, dim3(grid_for(n_tied)), dim3(256), 0, 0, dk2.current(), t_rows.as<uint64_t>(), n_tied, r_grp.as<uint64_t>());
+        size_t s1 = 0, s2 = 0;
+        FMSI_HIP_TRY(rocprim::inclusive_scan(nullptr, s1, r_grp.as<uint64_t>(), r_grp.as<uint64_t>(), static_cast<size_t>(n_tied), U64Max()));
+        FMSI_HIP_TRY(rocprim::exclusive_scan(nullptr, s2, r_tied.as<uint32_t>(), r_slot.as<uint32_t>(), 0u, static_cast<size_t>(n_tied + 1), rocprim::plus<uint32_t>()));
+        if ((rc = r_scan.alloc(std::max(s1, s2)))) return rc;
+        FMSI_HIP_TRY(rocprim::inclusive_scan(r_scan.p, s1, r_grp.as<uint64_t>(), r_grp.as<uint64_t>(), static_cast<size_t>(n_tied), U64Max()));
+        hipLaunchKernelGGL(wide_round_rank_ties_kernel, dim3(grid_for(n_tied)), dim3(256), 0, 0, r_grp.as<uint64_t>(), new_pos.as<uint64_t>(), n_tied, rank.as<uint64_t>(),
+                           r_tied.as<uint32_t>());
+        FMSI_HIP_TRY(hipMemsetAsync(r_tied.as<uint32_t>() + n_tied, 0, 4, 0));
+        FMSI_HIP_TRY(rocprim::exclusive_scan(r_scan.p, s2, r_tied.as<uint32_t>(), r_slot.as<uint32_t>(), 0u, static_cast<size_t>(n_tied + 1), rocprim::plus<uint32_t>()));
+        uint32_t still = 0;
+        FMSI_HIP_TRY(hipMemcpy(&still, r_slot.as<uint32_t>() + n_tied, 4, hipMemcpyDeviceToHost));
+        if (still) {
+            if ((rc = n_rows.alloc(static_cast<size_t>(still) * 8)) || (rc = n_pos.alloc(static_cast<size_t>(still) * 8)) || (rc = n_grp.alloc(static_cast<size_t>(still) * 8))) return rc;
+            hipLaunchKernelGGL(wide_round_compact_kernel, dim3(grid_for(n_tied)), dim3(256), 0, 0, r_tied.as<uint32_t>(), r_slot.as<uint32_t>(), t_rows.as<uint64_t>(),
+                               new_pos.as<uint64_t>(), r_grp.as<uint64_t>(), n_tied, n_rows.as<uint64_t>(), n_pos.as<uint64_t>(), n_grp.as<uint64_t>());
+            FMSI_HIP_TRY(hipGetLastError());
+        }
+        FMSI_HIP_TRY(hipDeviceSynchronize());
+        std::swap(t_rows.p, n_rows.p);
+        std::swap(t_pos.p, n_pos.p);
+        std::swap(t_grp.p, n_grp.p);
+        n_tied = still;
+        if (depth > 2 * len) {
+            set_last_error("suffix sort (64-bit rows): prefix doubling did not converge");
+            return FMSI_HIP_EHIP;
+        }
+    }
+    clock.mark("ties: prefix doubling");
+    return 0;
 }
 
 __global__ __launch_bounds__(256) void emit_rows_wide_kernel(const uint64_t* __restrict__ text2, const uint64_t* __restrict__ mask_text,
@@ -697,13 +878,15 @@ int build_wide_from_device_text(DevBuf& text2, uint64_t len, DevBuf* mask_text, 
         FMSI_HIP_TRY(hipGetLastError());
         unsigned long long h_stats[2] = {0, 0};
         FMSI_HIP_TRY(hipMemcpy(h_stats, stats.p, 16, hipMemcpyDeviceToHost));
-        if (h_stats[1]) {
-            set_last_error("the on-device builder for 2^32 rows and more orders tied suffixes group by group: " + std::to_string(h_stats[1]) +
-                           " groups of more than 64 suffixes that agree on 29 bases (a repetitive text) are beyond it");
-            return FMSI_HIP_ERANGE;
+        // groups beyond the insertion sort's cap (a repetitive text: any real genome of this size), or on request: prefix doubling over
+        // ALL tied suffixes (what the group-by-group pass reordered inside its groups does not matter to it)
+        static const bool force_doubling = std::getenv("FMSI_HIP_WIDE_DOUBLING") != nullptr;
+        if (h_stats[1] || force_doubling) {
+            clock.mark("ties (group by group)");
+            if ((rc = wide_prefix_doubling(k1, p1.as<uint64_t>(), len, clock))) return rc;
         }
     }
-    (void)dev_free(k1.release());
+    if (k1.p) (void)dev_free(k1.release());
     clock.mark("ties");
     // ---- rows -> blocks
     DevBuf blocks, counts, counts_scanned, mcounts, mrank, dollar, scan_temp, klcp;

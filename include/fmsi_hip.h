@@ -165,7 +165,8 @@ int fmsi_hip_index_load(const char* prefix, int use_klcp, int device, int prefix
  * staging buffers; a character outside ACGTacgt: FMSI_HIP_EINVAL with its position).  with_klcp needs k <= 64 (as the reference,
  * src/main.cpp:223-226).  len > 2^32 - 8192 (where the device sort of the 32-bit builder ends, a little before 32-bit rows do): the builder
  * for 64-bit rows -- suffixes dealt into 16 buckets by their first two bases, a sort per bucket with 64-bit positions, tied suffixes ordered
- * group by group (a text with groups of more than 64 suffixes that agree on 29 bases: FMSI_HIP_ERANGE) -- and a handle with rows64 = 1;
+ * group by group or, where groups of more than 64 suffixes agree on 29 bases (repetitive texts), by prefix doubling with 64-bit ranks -- and a
+ * handle with rows64 = 1;
  * with_klcp gives it the kLCP array, too (what `fmsi index` writes as .klcp; the handle's own search does not read it). */
 int fmsi_hip_index_build(const char* ms, uint64_t len, int k, int with_klcp, int device, int prefix_len, fmsi_hip_index** out);
 

@@ -4,6 +4,7 @@ FMSI_HIP_FORCE_ROWS64 sends the golden indexes -- and a 1.2 M-row one, 1170 supe
 instantiation: every mode against the oracle, the CLI against the reference's golden output, and the entry points that do not
 exist for such handles refuse with FMSI_HIP_ERANGE instead of answering wrongly."""
 import os
+import random
 
 import numpy as np
 import pytest
@@ -125,7 +126,7 @@ def test_cli_with_wide_rows(fm, name, kind, mode):
         assert rc2 == 0 and out == out2 and out.startswith(b">exported masked superstring\n")
 
 
-@pytest.mark.parametrize("shape", ["random", "mixed_mask", "small_repeats"])
+@pytest.mark.parametrize("shape", ["random", "mixed_mask", "small_repeats", "small_repeats_doubling", "big_repeats", "tandem", "homopolymer"])
 def test_wide_builder_equals_the_narrow_one(product_built, oracle_built, monkeypatch, shape):
     """The on-device builder for superstrings of 2^32 bases and more (suffixes dealt into 16 buckets by their first two bases, a rocPRIM
     sort per bucket with 64-bit positions, tied suffixes ordered group by group) forced onto small texts (FMSI_HIP_FORCE_WIDE_BUILD): dword
@@ -134,9 +135,28 @@ def test_wide_builder_equals_the_narrow_one(product_built, oracle_built, monkeyp
     fm = product_built
     k = 31
     rng = np.random.default_rng(5)
-    if shape == "small_repeats":
+    if shape.startswith("small_repeats"):
         base = synthetic_ms(60_000, k, seed=9, mask="mixed")
         ms = base + base[1000:1400] * 20 + base[5000:5100].upper() * 8 + base[:30_000]     # tied groups of up to a few dozen suffixes
+        ms = ms[: len(ms) - (k - 1)] + ms[len(ms) - (k - 1):].lower()
+        if shape.endswith("doubling"):      # ... through the prefix doubling all the same (FMSI_HIP_WIDE_DOUBLING)
+            monkeypatch.setenv("FMSI_HIP_WIDE_DOUBLING", "1")
+    elif shape == "big_repeats":            # tied groups of hundreds and thousands of suffixes: prefix doubling with 64-bit ranks (round 4)
+        base = synthetic_ms(80_000, k, seed=11, mask="mixed")
+        fam = base[2000:2600]
+        copies = []
+        r2 = random.Random(7)
+        for _ in range(300):
+            c = list(fam)
+            for _ in range(3):
+                c[r2.randrange(len(c))] = r2.choice("ACGTacgt")
+            copies.append("".join(c))
+        ms = base + "".join(copies) + base[10_000:40_000] + fam * 40
+        ms = ms[: len(ms) - (k - 1)] + ms[len(ms) - (k - 1):].lower()
+    elif shape == "tandem":                 # one group of 32 000 suffixes that differ only beyond tens of thousands of bases: many rounds
+        ms = ("ACGTTGCA" * 4000) + "acgttgcaacgttgcaacgttgcaacgttg"
+    elif shape == "homopolymer":
+        ms = synthetic_ms(5000, k, seed=2, mask="ones").upper() + "A" * 50_000 + synthetic_ms(5000, k, seed=4, mask="ones")
         ms = ms[: len(ms) - (k - 1)] + ms[len(ms) - (k - 1):].lower()
     else:
         ms = synthetic_ms(300_000, k, seed=3, mask="mixed" if shape == "mixed_mask" else "ones")
@@ -159,19 +179,26 @@ def test_wide_builder_equals_the_narrow_one(product_built, oracle_built, monkeyp
     assert np.array_equal(kw.download_klcp(), kn)
 
 
-def test_wide_builder_refuses_repetitive_texts(product_built, monkeypatch):
+def test_wide_builder_takes_repetitive_texts(product_built, oracle_built, monkeypatch):
+    """(Until round 4 this text was refused with FMSI_HIP_ERANGE: a group of 32 000 suffixes that agree on 29 bases.)  Prefix doubling with
+    64-bit ranks orders it: the index answers like the oracle's, and `fmsi export`'s walk gives the superstring back."""
     fm = product_built
     monkeypatch.setenv("FMSI_HIP_FORCE_WIDE_BUILD", "1")
     ms = ("ACGTTGCA" * 4000) + "acgttgcaacgttgcaacgttgcaacgttg"
-    with pytest.raises(fm.FmsiError) as e:
-        fm.DeviceIndex.build(ms.encode(), 31)
-    assert e.value.code == fm.E_RANGE and "groups" in str(e.value)
+    dev = fm.DeviceIndex.build(ms.encode(), 31)
+    assert dev.info.rows64 == 1
+    orc = oracle_py.Oracle.construct(ms, 31, use_klcp=False)
+    check(fm, dev, orc, mixed_kmers(ms, 31, 2000, seed=5), 31)
+    assert dev.export().decode() == ms
 
 
-def test_index_of_more_than_2_to_32_rows(product_built, oracle_built):
+@pytest.mark.parametrize("repeats", [(0, 0, 0), (200, 50, 10)], ids=["uniform", "repeat_families"])
+def test_index_of_more_than_2_to_32_rows(product_built, oracle_built, repeats):
     """A REAL index with 64-bit rows: 4.5 x 10^9 bases generated and indexed on the device (2.25 GB of blocks, three superblocks of 2^31
     rows), queried by query_wide_kernel: strand by strand in both modes against the oracle on the downloaded planes (2^15 k-mers), present
-    k-mers present and absent ones absent on 2^20 seeded queries, windows through the run entry point, ORDERS against the oracle."""
+    k-mers present and absent ones absent on 2^20 seeded queries, windows through the run entry point, ORDERS against the oracle.
+    repeat_families (round 4): a fifth of the text's 2048-base segments are copies of 50 consensus segments at 1 % divergence -- tied groups of
+    thousands of suffixes, ~10^9 tied suffixes in all: the builder's prefix doubling with 64-bit ranks (until round 4: FMSI_HIP_ERANGE)."""
     import torch
     import bench_cpu
     fm = product_built
@@ -180,7 +207,7 @@ def test_index_of_more_than_2_to_32_rows(product_built, oracle_built):
     if free_b < 170e9:   # (the builder's temporaries at this size: ~150 GB)
         pytest.skip(f"needs ~170 GB of free HBM for the builder's temporaries, this device has {free_b / 1e9:.0f} GB free")
     with fm.builder_chain(0):
-        dev = fm.DeviceIndex.build_synthetic(n, 99, k, prefix_len=14)
+        dev = fm.DeviceIndex.build_synthetic(n, 99, k, prefix_len=14, repeats=repeats)
     info = dev.info
     assert info.rows64 == 1 and info.n == n + 1 and info.n > (1 << 32) and info.prefix_len == 14
     nq = 1 << 20
@@ -231,7 +258,8 @@ def test_index_of_more_than_2_to_32_rows(product_built, oracle_built):
     # (sampled words incl. those around the text's 2^32nd base = word 2^27)
     pos = words[:, None] * 32 + np.arange(32)
     have = (code[got[pos]].astype(np.uint64) << (2 * np.arange(32, dtype=np.uint64))).sum(axis=1, dtype=np.uint64)
-    want = np.array([lib.fmsi_hip_synthetic_text_word(99, int(w)) for w in words], dtype=np.uint64)
+    want = np.array([lib.fmsi_hip_synthetic_text_word_repeats(99, int(w), *repeats) if repeats[0] else lib.fmsi_hip_synthetic_text_word(99, int(w)) for w in words],
+                    dtype=np.uint64)
     assert np.array_equal(have, want), words[np.nonzero(have != want)[0][:5]]
 
 
