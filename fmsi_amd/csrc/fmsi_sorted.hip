@@ -3,7 +3,8 @@
 //
 // What it replaces in the reference: get_range_with_pattern() + infer_presence() per strand (src/fms_index.h:117-144) under the strand
 // schedule of query_kmers_single<>() (src/fms_index.h:263-331); every interval is the one update_range() (src/fms_index.h:98-103) produces,
-// so the answers are the reference's.  No table of any kind is read: what makes it fast is the ORDER of the searches.
+// so the answers are the reference's.  No table of the index is read: what makes it fast is the ORDER of the searches (and that the top of
+// the search tree, which every search of a large batch shares, is walked once per batch).
 //
 // Why (measured, profiles/r04b_lf_sorted_probe.txt): the walk is bound by random line requests.  The first ~log4(n) steps of
 // every search touch blocks that other searches of the batch touch as well; in the order the k-mers arrive those reads are spread over
@@ -14,13 +15,16 @@
 // persistent-lane pair kernel on the unsorted one (59 vs 65 ms per 2^27 31-mers at n = 2.8 x 10^9); this file adds what the order makes
 // possible on top:
 //   * both strands of every k-mer are search ITEMS of their own (key = the strand's bases left-aligned, value = 2 q + strand), sorted
-//     together by rocPRIM's radix sort on the first 16 bases: the reverse-complement searches share their first steps like the forward
-//     ones (a second strand that the schedule would not have asked for costs a few shared steps and dies; its ternary is simply unused);
+//     together by rocPRIM's radix sort on the first 12 bases (three passes): the reverse-complement searches share their first steps like
+//     the forward ones (a second strand that the schedule would not have asked for costs a few shared steps and dies; its ternary is unused);
+//   * the top of the search tree ONCE per batch: the intervals of all 4^D1, then all 4^D2 first-base strings (D2 <= 13, about one search
+//     per entry; scratch memory of the call, made anew for every batch) by this kernel with a lane per entry -- the items start from
+//     their D2 entry;
 //   * two-base steps over the 128-byte pair blocks, the lines fetched COOPERATIVELY -- eight lanes load 16 bytes each of one lane's line
 //     in one instruction (lanes of a sorted wave that want the same line share the request), staged through LDS at a 144-byte pitch,
 //     the owner reads its planes with conflict-free b128 reads and ranks both boundaries itself (no lane pairs, no shuffles);
-//   * the walk is cut in two launches where the absent k-mers have died out (after ~log4(n) + 2 bases): the survivors of three waves
-//     continue in ONE wave of the second launch, so that the long private tails of the present k-mers run with full lanes;
+//   * the items' walk is cut in two launches where the absent k-mers have died out (after ~log4(n) + 3 bases): the survivors of three
+//     waves continue in ONE wave of the second launch, so that the long private tails of the present k-mers run with most lanes live;
 //   * the last pair step answers infer_presence() from the pre-mapped mask plane of the block(s) at hand (as query_pair_kernel does).
 // Results: one ternary per item, scattered to tern[2 q + strand] (absent = the array's zero fill: three quarters of the items write
 // nothing), folded per k-mer by a last pass into the call's output encoding.
