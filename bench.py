@@ -115,7 +115,7 @@ def parse_args(argv=None):
                     help="do not measure roofline.traffic in this run (child runs of this script under rocprofv3 --pmc, FETCH_SIZE and "
                          "WRITE_SIZE in separate passes)")
     ap.add_argument("--no-config-legs", action="store_true", help="skip the `configs` legs (BASELINE configs 2, 3, 4 and the whole process)")
-    ap.add_argument("--legs", default="c2,c3,c3sk,c4,c4k,c4sk,c5dict,e2e", help="which `configs` legs to run")
+    ap.add_argument("--legs", default="c2,c3,c3sk,c4,c4k,c4k48,c4sk,c5dict,e2e", help="which `configs` legs to run")
     ap.add_argument("--leg", default=None, help=argparse.SUPPRESS)          # child mode: one leg, a JSON list on stdout
     ap.add_argument("--variants", default=None, help="with --leg: only these variants of the leg (comma-separated names), e.g. for a rocprofv3 run of one")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)   # child mode under rocprofv3: the plan's launches, nothing printed
@@ -273,10 +273,12 @@ class QueryPath:
     def __init__(self, c, args, index, via, k, batch, read_len=10000, subst_ppm=0):
         fm, np = c.fm, c.np
         self.c, self.args, self.index, self.via, self.k, self.subst_ppm = c, args, index, via, k, subst_ppm
-        self.stream_mode = via in ("runs_chain", "runs_plain", "runs_tables", "runs_sk", "klcp")
+        self.stream_mode = via in ("runs_chain", "runs_plain", "runs_tables", "runs_sk", "klcp", "klcp_orders", "klcp_orders_fast")
+        # `lookup -S`: 8-byte orders, one per window (--fast) or one per window and strand (the CLI's default: it replays the strand predictor)
+        self.order_words = {"klcp_orders": 2, "klcp_orders_fast": 1}.get(via, 0)
         mode = fm.MODE_ALL if args.mode == "all" else fm.MODE_OR
         # (the kLCP kernel reads 128-byte S-blocks since round 3; FMSI_HIP_STREAM_V1 brings the 64-byte-block kernel back)
-        self.block_b = 64 if via == "lf_lockstep" or (via == "klcp" and os.environ.get("FMSI_HIP_STREAM_V1")) or \
+        self.block_b = 64 if via == "lf_lockstep" or (via.startswith("klcp") and os.environ.get("FMSI_HIP_STREAM_V1")) or \
             (via == "legacy" and args.kernel in ("refill", "lockstep")) else 128
         self.is_dict = via in ("dict", "dict_sk", "runs_chain", "runs_plain", "runs_sk")
         if self.stream_mode:
@@ -288,11 +290,13 @@ class QueryPath:
             self.in_words = self.n_reads * L // 32 + 2
             self.in_bytes = self.n_reads * L / 4.0
             self.flags = mode | {"runs_chain": fm.KERNEL_DICT | fm.NO_SUPERKMER, "runs_plain": fm.KERNEL_DICT | fm.NO_DICT_CHAIN | fm.NO_SUPERKMER, "runs_tables": 0,
-                                 "runs_sk": fm.KERNEL_DICT, "klcp": 0}[via]
+                                 "runs_sk": fm.KERNEL_DICT, "klcp": 0, "klcp_orders": 0, "klcp_orders_fast": 0}[via]
+            if self.order_words:
+                self.flags = fm.ORDERS | (fm.STRICT if self.order_words == 2 else 0)
             self.kernel = {"runs_chain": "dict_chain_kernel", "runs_plain": "dict_lookup_kernel", "runs_tables": "lookup_lane_kernel + query_pair_kernel", "runs_sk": "sk_runs_kernel",
-                           "klcp": "query_stream_kernel" if os.environ.get("FMSI_HIP_STREAM_V1") else "query_stream2_kernel"}[via]
+                           "klcp": "query_stream_kernel" if os.environ.get("FMSI_HIP_STREAM_V1") else "query_stream2_kernel"}[via.split("_orders")[0]]
             self.pmc_kernel = {"runs_chain": "dict_chain_kernel<false>", "runs_plain": "dict_lookup_kernel<false, true>", "runs_tables": "lookup_lane_kernel<false", "runs_sk": "sk_runs_kernel<false>",
-                               "klcp": "query_stream2_kernel<false"}[via]
+                               "klcp": "query_stream2_kernel<false"}[via.split("_orders")[0]]
         else:
             self.batch = int(batch)
             self.in_words = self.batch
@@ -329,7 +333,7 @@ class QueryPath:
         if kernel is not None:
             flags = (flags & ~0xF0) | kernel
         if self.stream_mode:
-            fn = self.index.query_stream_dev if self.via == "klcp" else self.index.query_runs_dev
+            fn = self.index.query_stream_dev if self.via.startswith("klcp") else self.index.query_runs_dev
             fn(buf.data_ptr(), self.n_reads * self.read_len, self.run_start, self.run_windows, self.k, flags, out.data_ptr(), counters_ptr, c.stream)
         else:
             self.index.query_kmers_dev(buf.data_ptr(), self.batch, self.k, flags, out.data_ptr(), counters_ptr, c.stream)
@@ -344,8 +348,12 @@ def timed_region(c, args, path, steps, warmup, bits=True, host_copy="per-rank", 
     torch, np, fm, dist = c.torch, c.np, c.fm, c.dist
     index, batch = path.index, path.batch
     multi, world, rank = c.multi, c.world, c.rank
+    orders = getattr(path, "order_words", 0)
+    if orders:
+        bits = False   # (8-byte orders stay in HBM: their way to the host would be PCIe's rate, not the kernel's)
     out_flag = fm.OUT_BITS if bits else 0
-    d_out = torch.empty(batch, dtype=torch.uint8, device=c.dev_t)                      # byte results (counted launches, checks)
+    d_out = torch.empty(batch * orders, dtype=torch.int64, device=c.dev_t) if orders else \
+        torch.empty(batch, dtype=torch.uint8, device=c.dev_t)                          # byte results (counted launches, checks)
     n_words = fm.packed_words(batch, 0)
     d_bits = [torch.zeros(n_words, dtype=torch.int64, device=c.dev_t) for _ in range(2)] if bits else None
     root_words = n_words * (world if multi else 1)
@@ -379,7 +387,10 @@ def timed_region(c, args, path, steps, warmup, bits=True, host_copy="per-rank", 
                         kernel=fm.KERNEL_PAIR if (index.has_pair_layout and path.via != "klcp") else None)   # (one search per k-mer and strand: not the batch-sorted walk AUTO would take)
             torch.cuda.synchronize()
             canonical = d_cnt.cpu().numpy().astype(np.int64)
-    positives = float(d_out.to(torch.float32).mean().item())
+    if orders:
+        positives = float((d_out.view(batch, orders).max(dim=1).values >= 0).to(torch.float32).mean().item())
+    else:
+        positives = float(d_out.to(torch.float32).mean().item())
     for s in range(n_buf):
         path.make_input(s + 1, bufs[s])
     compute_stream = torch.cuda.current_stream()
@@ -458,7 +469,7 @@ def timed_region(c, args, path, steps, warmup, bits=True, host_copy="per-rank", 
 
     elapsed_max, enqueue_s, launches, kernel_ms = region(steps, host_copy, True)
     m = {"batch": batch, "steps": steps, "elapsed_max": elapsed_max, "enqueue_s": enqueue_s, "launches": launches, "kernel_ms": kernel_ms,
-         "counters": counters, "canonical": canonical, "positives": positives, "bits": bits, "n_words": n_words, "root_words": root_words,
+         "counters": counters, "canonical": canonical, "positives": positives, "bits": bits, "order_words": orders, "n_words": n_words, "root_words": root_words,
          "bits_check": None, "gather": None}
     # the packed words that reached the host are the byte results of the same batch
     if bits:
@@ -509,6 +520,8 @@ def roofline_of(path, m, info):
     elif "lookup_lane" in path.kernel and entry_b:
         entry_used_b = entry_b   # a table lookup is one 64-byte HBM access whatever the entry's size; useful_* counts the entry's bytes
     out_b = batch / 8.0 if m["bits"] else 1.0 * batch   # packed: one bit per window
+    if m.get("order_words"):
+        out_b = 8.0 * m["order_words"] * batch              # the array of orders (filled with -1 on the device, then the orders found)
     bytes_launch = path.block_b * (blocks_read - lookups) + lookup_b * lookups + 8 * klcp_words + path.in_bytes + out_b + 32 * verify_reads
     ach = bytes_launch / avg_kernel_s / 1e9
     requests = blocks_read + klcp_words + verify_reads
@@ -556,11 +569,11 @@ def pmc_child(c, args, index, plan):
     for v in plan:
         path = QueryPath(c, args, index, v["via"], args.k, v.get("batch", args.batch), args.read_len, v.get("subst_ppm", 0))
         buf = torch.empty(path.in_words, dtype=torch.int64, device=c.dev_t)
-        out = torch.zeros(max(fm.packed_words(path.batch, 0), 1), dtype=torch.int64, device=c.dev_t)
+        out = torch.zeros(max(path.batch * path.order_words if getattr(path, "order_words", 0) else fm.packed_words(path.batch, 0), 1), dtype=torch.int64, device=c.dev_t)
         torch.cuda.synchronize()
         path.make_input(1, buf)
         for _ in range(3):
-            path.launch(buf, out, extra=fm.OUT_BITS)
+            path.launch(buf, out, extra=0 if getattr(path, "order_words", 0) else fm.OUT_BITS)
         torch.cuda.synchronize()
         del buf, out
 
@@ -697,7 +710,12 @@ LEG_SPECS = {
                                                  ("c4_dict_plain", "runs_plain", 0), ("c4_dict_plain_subst1pct", "runs_plain", 10000)]),
     # the kLCP kernel on a handle of its own: blocks, kLCP array, S-blocks and the 16-deep prefix table -- no dictionary (round 3 timed it on the
     # chained dictionary's 93-GB handle)
-    "c4k": (2.8e9, "stream", float(1 << 27), 8, [("c4_klcp", "klcp", 0), ("c4_klcp_subst1pct", "klcp", 10000)]),
+    "c4k": (2.8e9, "stream", float(1 << 27), 8, [("c4_klcp", "klcp", 0), ("c4_klcp_subst1pct", "klcp", 10000),
+                                                  # `fmsi lookup -S` (k-mer orders: src/fms_index.h:147-157 inside :181-254) on the same handle: both strands'
+                                                  # orders as the CLI asks for them (it replays the strand predictor), and --fast's one order per window
+                                                  ("c4_klcp_lookup", "klcp_orders", 0), ("c4_klcp_lookup_fast", "klcp_orders_fast", 0)]),
+    # `fmsi query -S -O` with k = 48 (the reference's __uint128_t k-mers, src/main.cpp:223-230): an index of its own, the same read mix
+    "c4k48": (2.8e9, "stream", float(1 << 27), 8, [("c4_klcp_k48", "klcp", 0)]),
     # the same reads through the super-k-mer dictionary ALONE (FMSI_HIP_DICT_SUPERKMER_ONLY: the k-mer dictionary is released after the
     # construction -- the handle is the index's blocks + the records + the small aux dictionary)
     # (isolated 31-mers on the compact structure alone, config 5's per-GPU work, are the headline itself since round 4)
@@ -718,6 +736,8 @@ LEG_TEXT = {
 }
 LEG_TEXT["c4sk"] = LEG_TEXT["c4"]
 LEG_TEXT["c4k"] = LEG_TEXT["c4"]
+LEG_TEXT["c4k48"] = LEG_TEXT["c4"].replace("k=31", "k=48").replace("31-mer", "48-mer")
+LEG_K = {"c4k48": 48}
 LEG_TEXT["c3sk"] = LEG_TEXT["c3"].replace("k-mer dictionary", "super-k-mer dictionary ALONE (the handle holds no k-mer dictionary: every k-mer is a one-window read, its minimizer's bucket "
                                           "one 128-byte read, heavy / overflowed ones the small aux dictionary)")
 LEG_TEXT["c5dict"] = ("BASELINE config 5's per-GPU work on the K-MER dictionary (a hash table of the index's answers, 13 B per k-mer: what rounds 2-3 quoted as the headline): "
@@ -727,6 +747,9 @@ LEG_TEXT["c5_superkmer"] = ("BASELINE config 5's per-GPU work (and the headline'
 VIA_TEXT = {"runs_chain": "fmsi_hip_query_runs, chained dictionary lookups (58.7 GB handle): a lane follows the superstring from its task's first window",
             "runs_plain": "fmsi_hip_query_runs, one dictionary bucket read per window (FMSI_HIP_NO_DICT_CHAIN)",
             "klcp": "fmsi_hip_query_stream: the kLCP kernel (extend_range_with_klcp + one LF step per positive window, src/fms_index.h:106-115,181-254)",
+            "klcp_orders": "fmsi_hip_query_stream with FMSI_HIP_ORDERS | FMSI_HIP_STRICT -- what `fmsi lookup -S` runs: the kLCP kernel's ORD instantiation, an 8-byte order per "
+                           "window AND strand (16 B per window, left in HBM: not bit-packed, no host copy in the region)",
+            "klcp_orders_fast": "fmsi_hip_query_stream with FMSI_HIP_ORDERS -- `fmsi lookup -S --fast`: one 8-byte order per window (left in HBM)",
             "runs_sk": "fmsi_hip_query_runs, super-k-mer dictionary alone (records filed by minimizer: a bucket read when a lane's minimizer changes; the handle holds no k-mer dictionary)",
             "dict": "fmsi_hip_query_kmers, k-mer dictionary"}
 
@@ -745,7 +768,9 @@ def run_leg(args):
     args.n, args.batch, args.workload = float(n), batch, workload
     stream_mode = workload == "stream"
     sk_only = name.endswith("sk")
-    klcp_only = name == "c4k"
+    klcp_only = name in ("c4k", "c4k48")
+    if name in LEG_K:
+        args.k = LEG_K[name]
     args.stream_via = "klcp" if klcp_only else "runs"
     args.accel = "tables" if klcp_only else "dict"   # (the legs say themselves which structures their handle keeps)
     if klcp_only:
@@ -1003,7 +1028,7 @@ def main():
 
     if args.pmc_child:   # under rocprofv3 --pmc: the plan's launches and nothing else (the handle is built as the measured run built it)
         plan = json.loads(args.pmc_plan)
-        index, _, _ = build_handle(c, args, n, k, stream_mode, with_klcp=any(v["via"] == "klcp" for v in plan),
+        index, _, _ = build_handle(c, args, n, k, stream_mode, with_klcp=any(v["via"].startswith("klcp") for v in plan),
                                    want_pair=any(v["via"].startswith("lf_") for v in plan), chain=any(v["via"] == "runs_chain" for v in plan),
                                    superkmer_only=any(v["via"] in ("runs_sk", "dict_sk") for v in plan))
         pmc_child(c, args, index, plan)

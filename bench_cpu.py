@@ -289,21 +289,42 @@ def check_legs(c, args, index, paths, names):
         reads = 30
         p = QueryPath(c, args, index, path.via, k, reads * wins, L, path.subst_ppm)
         d = torch.empty(p.in_words, dtype=torch.int64, device=c.dev_t)
+        def fasta_of_reads():
+            fa_ = os.path.join(tmp.name, f"s{path.subst_ppm}.fa")
+            if not os.path.exists(fa_):
+                packed_ = d.cpu().numpy().view(np.uint64)
+                codes_ = ((packed_[:, None] >> (2 * np.arange(32, dtype=np.uint64))) & np.uint64(3)).astype(np.uint8).reshape(-1)[:p.n_reads * L]
+                bases_ = np.frombuffer(b"ACGT", dtype=np.uint8)[codes_].reshape(p.n_reads, L)
+                with open(fa_, "wb") as f_:
+                    for r_ in range(p.n_reads):
+                        f_.write(b">r%d\n" % r_)
+                        f_.write(bases_[r_].tobytes())
+                        f_.write(b"\n")
+            return fa_
+
+        ow = getattr(p, "order_words", 0)
+        if ow:   # `lookup -S`: the reference's orders (its record loop with output_orders) against the device's -- the first strand that has one
+            d_ord = torch.empty(p.batch * ow, dtype=torch.int64, device=c.dev_t)
+            p.make_input(0, d)
+            p.launch(d, d_ord)
+            torch.cuda.synchronize()
+            got = d_ord.cpu().numpy().reshape(p.batch, ow)
+            got = np.where(got[:, 0] >= 0, got[:, 0], got[:, -1]).reshape(p.n_reads, wins)
+            fa = fasta_of_reads()
+            text, sec = ref.query_file(fa, k, has_klcp=has_klcp, mode=mode, orders=True, cap=p.n_reads * (wins * 11 + 32) + 4096)
+            want = np.array([np.array(line.split("\t")[1].split(","), dtype=np.int64) for line in text.splitlines()])
+            out[name] = {"matches": bool(want.shape == got.shape and np.array_equal(want, got) and (want >= 0).mean() > 0.2),
+                         "what": f"{kind}: its record loop as `lookup -S` (query_kmers_streaming(..., output_orders = true)) over the first {p.n_reads} reads ({p.n_reads * wins} windows) "
+                                 f"of the leg's seeded read stream, {p.n_reads * wins / sec:.0f} windows/s on one core, against the same {n_rows}-row index; the device's order of a window "
+                                 f"= the first strand's that has one (on this text no k-mer occurs on both strands)"}
+            continue
         d_out = torch.empty(p.batch, dtype=torch.uint8, device=c.dev_t)
         p.make_input(0, d)
         p.launch(d, d_out)
         torch.cuda.synchronize()
         gpu_bits = d_out.cpu().numpy().reshape(p.n_reads, wins)
         if path.subst_ppm not in stream_expected:
-            packed = d.cpu().numpy().view(np.uint64)
-            codes = ((packed[:, None] >> (2 * np.arange(32, dtype=np.uint64))) & np.uint64(3)).astype(np.uint8).reshape(-1)[:p.n_reads * L]
-            bases = np.frombuffer(b"ACGT", dtype=np.uint8)[codes].reshape(p.n_reads, L)
-            fa = os.path.join(tmp.name, f"s{path.subst_ppm}.fa")
-            with open(fa, "wb") as f:
-                for r in range(p.n_reads):
-                    f.write(b">r%d\n" % r)
-                    f.write(bases[r].tobytes())
-                    f.write(b"\n")
+            fa = fasta_of_reads()
             text, sec = ref.query_file(fa, k, has_klcp=has_klcp, mode=mode, cap=p.n_reads * (wins + 32) + 4096)
             want = np.array([np.frombuffer(line.split("\t")[1].encode(), dtype=np.uint8) - ord("0") for line in text.splitlines()])
             stream_expected[path.subst_ppm] = (want, sec, p.n_reads)

@@ -816,10 +816,15 @@ struct UniformRuns {
     uint64_t seq_words, start0, stride;
     uint32_t wpr, tpr;
 };
-template <bool COUNT, bool PTABLE, bool UNI>
+// WIDE (33 <= k <= 64): no k-mer register -- the bases of the current window come from the task's 128 bases, as in the first kernel.
+// ORD (`lookup -S`, kmer_order_if_present of fms_index.h:151-157 in the loops of :181-254): a window's strand result is the mask rank of its
+// interval's first row when a row of the interval is masked; the caller's array is filled with -1 BEFORE the kernel (one streaming pass) and
+// the kernel stores the orders it finds (8 bytes each, straight to their place: no result planes for them, no slots, no compaction).
+template <bool COUNT, bool PTABLE, bool UNI, bool WIDE, bool ORD>
 __global__ __launch_bounds__(256, 4) void query_stream2_kernel(DevIndex ix, const uint4* __restrict__ sblocks, const uint64_t* __restrict__ klcp,
                                                             const TaskRec* __restrict__ tasks, uint64_t n_tasks, int k, uint32_t flags, uint32_t chunk,
-                                                            uint4* __restrict__ slots, unsigned long long* __restrict__ counters, UniformRuns u) {
+                                                            uint4* __restrict__ slots, long long* __restrict__ out_orders,
+                                                            unsigned long long* __restrict__ counters, UniformRuns u) {
     __shared__ uint4 s_line[4][64 * kSPitch];
     // what a lane's pass 0 learns about the FIRST windows of the NEXT task of its read (the hints of its last k - T lookups point past its own
     // 64 windows): task number and one bit per window, read by the right-hand neighbour -- which holds that task -- when its pass 1 begins
@@ -829,15 +834,15 @@ __global__ __launch_bounds__(256, 4) void query_stream2_kernel(DevIndex ix, cons
     uint32_t* hint_task = s_hint_task[threadIdx.x >> 6];
     uint32_t* hint_bits = s_hint_bits[threadIdx.x >> 6];
     const uint32_t* L = reinterpret_cast<const uint32_t*>(my_wave_lines + ln * kSPitch);   // this lane's staged line
-    const uint32_t mode_all = flags & FMSI_HIP_MODE_ALL;
+    const uint32_t mode_all = ORD ? 0u : (flags & FMSI_HIP_MODE_ALL);   // (orders: a strand decides a window when it HAS an order -- OR's schedule)
     const uint32_t strict = flags & FMSI_HIP_STRICT;
     const uint64_t wave = (static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
     uint64_t next = wave * chunk;
     const uint64_t end = min(n_tasks, next + static_cast<uint64_t>(chunk));
     const int T = PTABLE ? static_cast<int>(ix.ptable_len) : 0;
-    const uint64_t kmask = k == 32 ? ~0ull : ((1ull << (2 * k)) - 1ull);
+    const uint64_t kmask = (WIDE || k == 32) ? ~0ull : ((1ull << (2 * k)) - 1ull);
 
-    uint64_t s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+    uint64_t s0 = 0, s1 = 0, s2 = 0, s3 = 0, obase = 0;
     uint32_t n = 0;
     uint64_t kmer = 0;
     uint64_t rf_lo = 0, rf_hi = 0;   // pass-0 result + 1 of window w in bit w of the two planes (0 = empty interval)
@@ -852,8 +857,18 @@ __global__ __launch_bounds__(256, 4) void query_stream2_kernel(DevIndex ix, cons
     int t = 0;
     StreamCounters cn;
 
-    auto kmer_base = [&](int tt) -> uint32_t { return static_cast<uint32_t>(kmer >> (2 * tt)) & 3u; };
+    auto kmer_base = [&](int tt) -> uint32_t {   // base tt of the current window's k-mer on the current strand
+        if (WIDE) return !cur_rc ? task_base(s0, s1, s2, s3, widx + static_cast<uint32_t>(tt))
+                                   : 3u - task_base(s0, s1, s2, s3, widx + static_cast<uint32_t>(k - 1 - tt));
+        return static_cast<uint32_t>(kmer >> (2 * tt)) & 3u;
+    };
+    auto kmer_table_index = [&]() -> uint32_t {   // its last T bases
+        if (WIDE) return static_cast<uint32_t>(!cur_rc ? task_kmer(s0, s1, s2, s3, widx + static_cast<uint32_t>(k - T), T)
+                                                         : revcomp_2bit(task_kmer(s0, s1, s2, s3, widx, T), T));
+        return static_cast<uint32_t>(kmer >> (2 * (k - T))) & static_cast<uint32_t>((1ull << (2 * T)) - 1ull);
+    };
     auto load_kmer = [&]() {
+        if (WIDE) return;
         const uint64_t f = task_kmer(s0, s1, s2, s3, widx, k);
         kmer = !cur_rc ? f : revcomp_2bit(f, k);
     };
@@ -869,6 +884,10 @@ __global__ __launch_bounds__(256, 4) void query_stream2_kernel(DevIndex ix, cons
         }
     };
     auto end_task = [&]() {
+        if (ORD) {
+            st = SS_IDLE;
+            return;
+        }
         uint64_t p0, p1, p2, p3;
         if (strict) {   // byte = (f + 1) | (r + 1) << 2
             p0 = rf_lo; p1 = rf_hi; p2 = rr_lo; p3 = rr_hi;
@@ -908,7 +927,7 @@ __global__ __launch_bounds__(256, 4) void query_stream2_kernel(DevIndex ix, cons
         load_kmer();
         fresh();
     };
-    auto window_done = [&](int res) {
+    auto window_done = [&](int res, uint32_t ord = 0u) {
         if (!strict && pass == 0 && n > 1u) {
             if (probing) {
                 probing = false;
@@ -930,13 +949,21 @@ __global__ __launch_bounds__(256, 4) void query_stream2_kernel(DevIndex ix, cons
         if (pass == 0) {
             if (v & 1u) rf_lo |= bit;
             if (v & 2u) rf_hi |= bit;
-        } else {
+        } else if (!ORD) {
             if (v & 1u) rr_lo |= bit;
             if (v & 2u) rr_hi |= bit;
         }
+        if (ORD && res == 1) {   // (every other strand result is the -1 the array holds already)
+            if (strict) out_orders[2ull * (obase + widx) + pass] = static_cast<long long>(ord);
+            else out_orders[obase + widx] = static_cast<long long>(ord);   // (pass 1 visits a window only when pass 0 had no order for it)
+        }
     };
-    auto shift_fwd = [&](uint32_t w) { kmer = ((kmer << 2) | task_base(s0, s1, s2, s3, w)) & kmask; };
-    auto shift_rc = [&](uint32_t w) { kmer = ((kmer << 2) | (3u - task_base(s0, s1, s2, s3, w + static_cast<uint32_t>(k)))) & kmask; };
+    auto shift_fwd = [&](uint32_t w) {
+        if (!WIDE) kmer = ((kmer << 2) | task_base(s0, s1, s2, s3, w)) & kmask;
+    };
+    auto shift_rc = [&](uint32_t w) {
+        if (!WIDE) kmer = ((kmer << 2) | (3u - task_base(s0, s1, s2, s3, w + static_cast<uint32_t>(k)))) & kmask;
+    };
     auto advance = [&](bool have) -> bool {
         if (special) {
             const uint32_t sp = special;
@@ -1015,6 +1042,7 @@ __global__ __launch_bounds__(256, 4) void query_stream2_kernel(DevIndex ix, cons
                             s0 |= v[1] << (64u - sh); s1 |= v[2] << (64u - sh); s2 |= v[3] << (64u - sh); s3 |= v[4] << (64u - sh);
                         }
                         n = min(64u, u.wpr - 64u * j);
+                        if (ORD) obase = static_cast<uint64_t>(r) * u.wpr + 64ull * j;
                     } else {
                         const uint4* p = reinterpret_cast<const uint4*>(tasks + cand);
                         const uint4 r0 = p[0], r1 = p[1], r2 = p[2];
@@ -1023,6 +1051,7 @@ __global__ __launch_bounds__(256, 4) void query_stream2_kernel(DevIndex ix, cons
                         s2 = (static_cast<uint64_t>(r1.y) << 32) | r1.x;
                         s3 = (static_cast<uint64_t>(r1.w) << 32) | r1.z;
                         n = r2.z;
+                        if (ORD) obase = (static_cast<uint64_t>(r2.y) << 32) | r2.x;
                     }
                     task_id = cand;
                     pass = 0;
@@ -1051,10 +1080,7 @@ __global__ __launch_bounds__(256, 4) void query_stream2_kernel(DevIndex ix, cons
         }
         const bool two = need_line && bj != bi;
         uint2 ent = make_uint2(0, 0);
-        if (lk) {
-            const uint32_t tidx = static_cast<uint32_t>(kmer >> (2 * (k - T))) & static_cast<uint32_t>((1ull << (2 * T)) - 1ull);
-            ent = ix.ptable[tidx];
-        }
+        if (lk) ent = ix.ptable[kmer_table_index()];
         uint64_t kwi = 0, kwj = 0;
         if (st == SS_EXTSCAN) {   // a running extension scan (rare): the plain kLCP words at the frontier
             if (scan_i) kwi = klcp[(i - 1u) >> 6];
@@ -1131,21 +1157,23 @@ __global__ __launch_bounds__(256, 4) void query_stream2_kernel(DevIndex ix, cons
             const uint32_t pi_off = i - bi * kSRows, pj_off = j - bj * kSRows;   // 0..191, 1..192
             const uint32_t* B = reinterpret_cast<const uint32_t*>(sblocks) + static_cast<size_t>(bj) * kSDwords;
             int res;
+            uint32_t ord = 0;
             if (mode_all) {
                 res = static_cast<int>((L[20u + (pi_off >> 5)] >> (pi_off & 31u)) & 1u);
-            } else if (j - i == 1u) {
+            } else if (!ORD && j - i == 1u) {
                 res = static_cast<int>((L[20u + (pi_off >> 5)] >> (pi_off & 31u)) & 1u);
             } else {
                 const uint32_t qi = s_quarter(pi_off), qj = s_quarter(pj_off);
                 const uint32_t lo_r = spiece_mask_rank(spiece_lds(L, 0, qi), pi_off, qi);
                 const uint32_t hi_r = two ? spiece_mask_rank(spiece_global(B, 0, qj), pj_off, qj) : spiece_mask_rank(spiece_lds(L, 0, qj), pj_off, qj);
                 res = hi_r > lo_r;
+                ord = lo_r;   // kmer_order (fms_index.h:147-149): the mask rank of the interval's first row
             }
             // klcp[i - 1]: the bit before the block when i is its first row; klcp[j - 1]: row j - 1 is row pj_off - 1 of block bj
             const uint32_t ki = i == 0u ? 0u : (pi_off == 0u ? (L[7] >> 31) : (L[26u + ((pi_off - 1u) >> 5)] >> ((pi_off - 1u) & 31u)) & 1u);
             const uint32_t kjw = two ? B[26u + ((pj_off - 1u) >> 5)] : L[26u + ((pj_off - 1u) >> 5)];
             const uint32_t kj = (kjw >> ((pj_off - 1u) & 31u)) & 1u;
-            window_done(res);
+            window_done(res, ord);
             if (advance(true)) {
                 if (!(ki | kj)) {
                     do_lf = true;   // common case: the (k-1)-mer's interval is the k-mer's; the line is here
@@ -1227,9 +1255,9 @@ __global__ __launch_bounds__(256, 4) void query_stream2_kernel(DevIndex ix, cons
     }
 }
 
-template <bool COUNT, bool PTABLE>
-void launch_stream2(fmsi_hip_index* idx, const TaskRec* recs, uint64_t n_tasks, int k, uint32_t flags, uint4* slots, unsigned long long* d_counters, hipStream_t s,
-                    const UniformRuns* uni) {
+template <bool COUNT, bool PTABLE, bool WIDE, bool ORD>
+void launch_stream2(fmsi_hip_index* idx, const TaskRec* recs, uint64_t n_tasks, int k, uint32_t flags, uint4* slots, long long* o64,
+                    unsigned long long* d_counters, hipStream_t s, const UniformRuns* uni) {
     uint64_t chunk = n_tasks / (256ull * 32 * 8);
     chunk = std::min<uint64_t>(std::max<uint64_t>(chunk, 64), 1024);
     static const char* chunk_env = std::getenv("FMSI_HIP_STREAM_CHUNK");   // (measurements: tasks per wave)
@@ -1237,11 +1265,24 @@ void launch_stream2(fmsi_hip_index* idx, const TaskRec* recs, uint64_t n_tasks, 
     const uint64_t waves = (n_tasks + chunk - 1) / chunk;
     const uint32_t blocks = static_cast<uint32_t>((waves + 3) / 4);
     if (uni)
-        hipLaunchKernelGGL((query_stream2_kernel<COUNT, PTABLE, true>), dim3(blocks), dim3(256), 0, s, idx->dev, static_cast<const uint4*>(idx->d_sblocks),
-                           static_cast<const uint64_t*>(idx->d_klcp), recs, n_tasks, k, flags, static_cast<uint32_t>(chunk), slots, d_counters, *uni);
+        hipLaunchKernelGGL((query_stream2_kernel<COUNT, PTABLE, true, WIDE, ORD>), dim3(blocks), dim3(256), 0, s, idx->dev,
+                           static_cast<const uint4*>(idx->d_sblocks), static_cast<const uint64_t*>(idx->d_klcp), recs, n_tasks, k, flags,
+                           static_cast<uint32_t>(chunk), slots, o64, d_counters, *uni);
     else
-        hipLaunchKernelGGL((query_stream2_kernel<COUNT, PTABLE, false>), dim3(blocks), dim3(256), 0, s, idx->dev, static_cast<const uint4*>(idx->d_sblocks),
-                           static_cast<const uint64_t*>(idx->d_klcp), recs, n_tasks, k, flags, static_cast<uint32_t>(chunk), slots, d_counters, UniformRuns{});
+        hipLaunchKernelGGL((query_stream2_kernel<COUNT, PTABLE, false, WIDE, ORD>), dim3(blocks), dim3(256), 0, s, idx->dev,
+                           static_cast<const uint4*>(idx->d_sblocks), static_cast<const uint64_t*>(idx->d_klcp), recs, n_tasks, k, flags,
+                           static_cast<uint32_t>(chunk), slots, o64, d_counters, UniformRuns{});
+}
+template <bool WIDE, bool ORD>
+void launch_stream2_variant(fmsi_hip_index* idx, bool count, bool table, const TaskRec* recs, uint64_t n_tasks, int k, uint32_t flags, uint4* slots,
+                            long long* o64, unsigned long long* d_counters, hipStream_t s, const UniformRuns* uni) {
+    if (table) {
+        if (count) launch_stream2<true, true, WIDE, ORD>(idx, recs, n_tasks, k, flags, slots, o64, d_counters, s, uni);
+        else launch_stream2<false, true, WIDE, ORD>(idx, recs, n_tasks, k, flags, slots, o64, d_counters, s, uni);
+    } else {
+        if (count) launch_stream2<true, false, WIDE, ORD>(idx, recs, n_tasks, k, flags, slots, o64, d_counters, s, uni);
+        else launch_stream2<false, false, WIDE, ORD>(idx, recs, n_tasks, k, flags, slots, o64, d_counters, s, uni);
+    }
 }
 
 template <bool COUNT, bool PTABLE, bool WIDE>
@@ -1318,10 +1359,10 @@ extern "C" int fmsi_hip_query_stream(fmsi_hip_index* idx, const uint64_t* packed
     }
     FMSI_HIP_ON_DEVICE(idx->device);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    // k <= 32 presence queries: the S-block kernel (its layout is built on the handle's first such call; FMSI_HIP_STREAM_V1: the first
-    // kernel, for A/B runs)
+    // the S-block kernel (its layout is built on the handle's first such call; FMSI_HIP_STREAM_V1 / FMSI_HIP_KERNEL_REFILL: the first kernel,
+    // for A/B runs) -- since round 4 also for ORDERS (`lookup -S`) and 33 <= k <= 64
     static const bool force_v1 = std::getenv("FMSI_HIP_STREAM_V1") != nullptr;
-    bool v2 = k <= 32 && !(flags & FMSI_HIP_ORDERS) && !force_v1 && (flags & FMSI_HIP_KERNEL_MASK) != FMSI_HIP_KERNEL_REFILL;
+    bool v2 = !force_v1 && (flags & FMSI_HIP_KERNEL_MASK) != FMSI_HIP_KERNEL_REFILL;
     if (v2 && !idx->d_sblocks) {
         // built here on the handle's first such call (a kernel on the null stream and a device synchronisation: this ONE call is not
         // asynchronous on `stream`; fmsi_hip_index_enable_stream_layout at load time avoids that).  A handle without the room for the
@@ -1425,12 +1466,16 @@ extern "C" int fmsi_hip_query_stream(fmsi_hip_index* idx, const uint64_t* packed
     const bool use_table = idx->d_ptable && !(flags & FMSI_HIP_NO_PREFIX_TABLE) && k >= idx->prefix_len;
     long long* o64 = static_cast<long long*>(d_out);
     if (v2) {
-        if (use_table) {
-            if (d_cnt) launch_stream2<true, true>(idx, d_rec, n_tasks, k, flags, d_slots, d_cnt, s, cut_in_kernel ? &uni : nullptr);
-            else launch_stream2<false, true>(idx, d_rec, n_tasks, k, flags, d_slots, d_cnt, s, cut_in_kernel ? &uni : nullptr);
+        const UniformRuns* up = cut_in_kernel ? &uni : nullptr;
+        const bool ord = flags & FMSI_HIP_ORDERS;
+        if (ord)   // every strand result without an order is -1: the array is filled first, the kernel stores the orders it finds
+            FMSI_HIP_TRY(hipMemsetAsync(d_out, 0xFF, out_bytes, s));
+        if (k > 32) {
+            if (ord) launch_stream2_variant<true, true>(idx, d_cnt != nullptr, use_table, d_rec, n_tasks, k, flags, d_slots, o64, d_cnt, s, up);
+            else launch_stream2_variant<true, false>(idx, d_cnt != nullptr, use_table, d_rec, n_tasks, k, flags, d_slots, o64, d_cnt, s, up);
         } else {
-            if (d_cnt) launch_stream2<true, false>(idx, d_rec, n_tasks, k, flags, d_slots, d_cnt, s, cut_in_kernel ? &uni : nullptr);
-            else launch_stream2<false, false>(idx, d_rec, n_tasks, k, flags, d_slots, d_cnt, s, cut_in_kernel ? &uni : nullptr);
+            if (ord) launch_stream2_variant<false, true>(idx, d_cnt != nullptr, use_table, d_rec, n_tasks, k, flags, d_slots, o64, d_cnt, s, up);
+            else launch_stream2_variant<false, false>(idx, d_cnt != nullptr, use_table, d_rec, n_tasks, k, flags, d_slots, o64, d_cnt, s, up);
         }
     } else if (k > 32) {
         if (use_table) {

@@ -76,11 +76,17 @@ def check(fm, orc, dev, reads, k, stream):
         want_fast = stream_expected_fast(fwd, rc, wins, mode_all) if stream else expected_fast(fwd, rc, mode_all)
         assert np.array_equal(fast.astype(bool), want_fast)
         assert np.array_equal(run(flag | fm.NO_PREFIX_TABLE), fast)
+        if stream:   # the S-block kernel's WIDE instantiation (round 4) against the first kernel's, and its bit-packed results
+            assert np.array_equal(run(flag | fm.KERNEL_REFILL), fast)
+            assert np.array_equal(run(flag | fm.STRICT | fm.KERNEL_REFILL), run(flag | fm.STRICT))
+            assert np.array_equal(fm.unpack_bits(run(flag | fm.OUT_BITS), n, 0), fast)
         assert 0.05 < fast.mean() < 0.95
     fwd, rc, of, orr = orc.ternaries_bulk(raw, n, k, False, orders=True)
     got = run(fm.ORDERS | fm.STRICT)
     assert np.array_equal(got[:, 0], of) and np.array_equal(got[:, 1], orr)
     assert np.array_equal(run(fm.ORDERS), stream_expected_orders(fwd, rc, of, orr, wins) if stream else np.where(of >= 0, of, orr))
+    if stream:
+        assert np.array_equal(run(fm.ORDERS | fm.STRICT | fm.KERNEL_REFILL), got) and np.array_equal(run(fm.ORDERS | fm.KERNEL_REFILL), run(fm.ORDERS))
     if not stream:   # LF-step accounting of the both-strands schedule equals the oracle's
         orc.counters_reset()
         orc.ternaries_bulk(raw, n, k, True)
@@ -104,6 +110,29 @@ def test_longk_synthetic_equals_oracle(fm, oracle_built, tmp_path, k, stream):
     orc = oracle_py.Oracle.construct(ms, k, use_klcp=k <= 64)
     dev = fm.DeviceIndex.build(ms.encode(), k, with_klcp=k <= 64, prefix_len=7)
     check(fm, orc, dev, make_reads(ms, k, seed=3 * k, n_reads=40), k, stream)
+
+
+@pytest.mark.parametrize("k,length", [(33, 96), (48, 150), (64, 64), (64, 191), (40, 400)])
+def test_longk_stream_runs_of_one_length(fm, oracle_built, k, length):
+    """Reads of ONE length (no run table: the S-block kernel cuts its tasks itself) for 33 <= k <= 64: results and orders against the oracle."""
+    ms = synthetic_ms(60_000, k, seed=100 + k, mask="mixed")
+    orc = oracle_py.Oracle.construct(ms, k, use_klcp=True)
+    dev = fm.DeviceIndex.build(ms.encode(), k, with_klcp=True, prefix_len=6)
+    up = ms.upper()
+    rng = random.Random(k * length)
+    reads = []
+    for i in range(90):
+        if i % 5 == 4:
+            r = "".join(rng.choice("ACGT") for _ in range(length))
+        else:
+            p = rng.randrange(0, len(up) - length)
+            r = up[p:p + length]
+            if i % 3 == 1:
+                r = revcomp(r)
+            if i % 4 == 2:
+                r = "".join(rng.choice("ACGT") if rng.random() < 0.01 else ch for ch in r)
+        reads.append(r)
+    check(fm, orc, dev, reads, k, True)
 
 
 def test_longk_entry_point_limits(fm):

@@ -49,7 +49,7 @@ def run_case(fm, orc, dev, reads, k, check_orders=True):
         assert np.array_equal(fast.astype(bool), stream_expected_fast(fwd, rc, wins, mode_all))
         # same answers without the prefix table and (forward strand first everywhere) from the non-streaming kernel
         assert np.array_equal(dev.query_stream(words, len(seq), starts, wins, k, flag | fm.NO_PREFIX_TABLE), fast)
-        # ... and from the first streaming kernel (64-byte blocks + separate kLCP words; what ORDERS and k > 32 still run)
+        # ... and from the first streaming kernel (64-byte blocks + separate kLCP words)
         assert np.array_equal(dev.query_stream(words, len(seq), starts, wins, k, flag | fm.KERNEL_REFILL), fast)
         v1f, v1r = fm.decode_strict(dev.query_stream(words, len(seq), starts, wins, k, flag | fm.STRICT | fm.KERNEL_REFILL | fm.NO_PREFIX_TABLE))
         assert np.array_equal(v1f, fwd) and np.array_equal(v1r, rc)
@@ -62,6 +62,10 @@ def run_case(fm, orc, dev, reads, k, check_orders=True):
         assert np.array_equal(got[:, 0], of) and np.array_equal(got[:, 1], orr)
         got1 = dev.query_stream(words, len(seq), starts, wins, k, fm.ORDERS)
         assert np.array_equal(got1, stream_expected_orders(fwd, rc, of, orr, wins))
+        # (since round 4 the S-block kernel's ORD instantiation; the first kernel and the table-less start give the same orders)
+        for extra in (fm.KERNEL_REFILL, fm.NO_PREFIX_TABLE):
+            assert np.array_equal(dev.query_stream(words, len(seq), starts, wins, k, fm.ORDERS | fm.STRICT | extra), got)
+            assert np.array_equal(dev.query_stream(words, len(seq), starts, wins, k, fm.ORDERS | extra), got1)
 
 
 def ms_of(name):
@@ -116,7 +120,7 @@ def test_stream_runs_of_one_length(fm, oracle_built, length):
         if i % 4 == 2:
             r = "".join(rng.choice("ACGT") if rng.random() < 0.03 else ch for ch in r)
         reads.append(r)
-    run_case(fm, orc, dev, reads, k, check_orders=length == 95)
+    run_case(fm, orc, dev, reads, k)
     run_case(fm, orc, dev, reads[:1], k, check_orders=False)
     # equal runs at a stride with gaps (windows over the junctions left out), against the same call with one run made ragged
     seq = "".join(reads)
