@@ -159,7 +159,7 @@ __global__ __launch_bounds__(256) void stream_compact_uniform_bits_kernel(const 
     out[g] = word;
 }
 
-enum : uint32_t { SS_IDLE = 0, SS_LOOKUP = 1, SS_LF = 2, SS_HAVE = 3, SS_EXTSCAN = 4, SS_EXTLF = 5 };
+enum : uint32_t { SS_IDLE = 0, SS_LOOKUP = 1, SS_LF = 2, SS_HAVE = 3, SS_EXTSCAN = 4, SS_EXTLF = 5, SS_CERT = 6 };
 
 struct StreamCounters {
     uint32_t lf_steps = 0, blocks = 0, probes = 0, searches = 0, lookups = 0, klcp_words = 0;
@@ -841,6 +841,17 @@ __global__ __launch_bounds__(256, 4) void query_stream2_kernel(DevIndex ix, cons
     const uint64_t end = min(n_tasks, next + static_cast<uint64_t>(chunk));
     const int T = PTABLE ? static_cast<int>(ix.ptable_len) : 0;
     const uint64_t kmask = (WIDE || k == 32) ? ~0ull : ((1ull << (2 * k)) - 1ull);
+    // ABSENCE CERTIFICATES (round 4).  A fresh search that follows a failed window starts with a table lookup of its own: the entry of bases
+    // 4 .. T + 3 of the window's k-mer (on the strand being walked) with the signature test on bases 0 .. 3 -- a (T + 4)-mer at the END the pass
+    // is walking TOWARDS (the forward strand goes through the windows right to left and this is its k-mer's first T + 4 bases; the
+    // reverse-complement strand goes left to right and its k-mer's first bases are the window's last).  If that string does not occur in the
+    // text, no k-mer containing it does: the window AND the cert_d = k - T - 4 windows the pass would visit next are absent on this strand --
+    // one 8-byte request instead of cert_d + 1 searches (each one lookup, or, next to a substitution, up to k - T steps that end at the
+    // same base).  The ordinary lookup's entry -- the k-mer's LAST T bases -- says the same about the windows the pass has just left: that is
+    // why it cannot be used for this.  Exact: get_range_with_pattern (src/fms_index.h:117-124) returns an empty range for a pattern with an
+    // absent substring.  A certificate that fails (the string occurs, or its entry has more than three rows) costs its round.
+    const bool cert_ok = PTABLE && k >= T + 4;
+    const uint32_t cert_d = static_cast<uint32_t>(k - T - 4);
 
     uint64_t s0 = 0, s1 = 0, s2 = 0, s3 = 0, obase = 0;
     uint32_t n = 0;
@@ -872,10 +883,18 @@ __global__ __launch_bounds__(256, 4) void query_stream2_kernel(DevIndex ix, cons
         const uint64_t f = task_kmer(s0, s1, s2, s3, widx, k);
         kmer = !cur_rc ? f : revcomp_2bit(f, k);
     };
-    auto fresh = [&]() {
+    auto cert_string = [&]() -> uint64_t {   // the first T + 4 bases of the current window's k-mer on the current strand (base 0 in bits 0..1)
+        if (WIDE) {
+            const uint64_t z = task_kmer(s0, s1, s2, s3, !cur_rc ? widx : widx + cert_d, T + 4);
+            return !cur_rc ? z : revcomp_2bit(z, T + 4);
+        }
+        return kmer & ((1ull << (2 * (T + 4))) - 1ull);
+    };
+    // after_fail: the window before this one (in the pass' order) had an empty interval -- try a certificate first
+    auto fresh = [&](bool after_fail = false) {
         if (COUNT) cn.searches++;
         if (PTABLE) {
-            st = SS_LOOKUP;
+            st = (after_fail && cert_ok) ? SS_CERT : SS_LOOKUP;
         } else {
             i = 0;
             j = ix.n;
@@ -925,7 +944,7 @@ __global__ __launch_bounds__(256, 4) void query_stream2_kernel(DevIndex ix, cons
             todo &= ~(1ull << widx);
         }
         load_kmer();
-        fresh();
+        fresh(true);   // (pass 1 visits the windows pass 0 left undecided: mostly windows that are in the text on neither strand)
     };
     auto window_done = [&](int res, uint32_t ord = 0u) {
         if (!strict && pass == 0 && n > 1u) {
@@ -992,7 +1011,7 @@ __global__ __launch_bounds__(256, 4) void query_stream2_kernel(DevIndex ix, cons
                 ++widx;
             }
             if (have) return true;
-            fresh();
+            fresh(true);
             return false;
         }
         if (!todo) {
@@ -1018,8 +1037,46 @@ __global__ __launch_bounds__(256, 4) void query_stream2_kernel(DevIndex ix, cons
         } else {
             load_kmer();
         }
-        fresh();
+        fresh(!have);
         return false;
+    };
+    // a certificate said so: the current window and the cert_d windows the pass would visit after it have empty intervals on this strand
+    // (their result planes hold "empty" already) -- on to the first window behind them
+    auto skip_dead = [&]() {
+        if (pass == 0) {
+            if (!cur_rc) {
+                if (widx <= cert_d) {
+                    begin_pass1();
+                    return;
+                }
+                widx -= cert_d + 1u;
+            } else {
+                if (widx + cert_d + 1u >= n) {
+                    begin_pass1();
+                    return;
+                }
+                widx += cert_d + 1u;
+            }
+        } else {
+            if (cur_rc) {   // windows (widx, widx + cert_d]
+                if (cert_d) todo &= ~((((2ull << (cert_d - 1u)) - 1ull) << widx) << 1);
+            } else {        // windows [widx - cert_d, widx)
+                todo &= ~((1ull << widx) - 1ull) | (widx > cert_d ? (1ull << (widx - cert_d)) - 1ull : 0ull);
+            }
+            if (!todo) {
+                end_task();
+                return;
+            }
+            if (cur_rc) {
+                widx = static_cast<uint32_t>(__ffsll(static_cast<unsigned long long>(todo))) - 1u;
+                todo &= todo - 1;
+            } else {
+                widx = 63u - static_cast<uint32_t>(__clzll(static_cast<long long>(todo)));
+                todo &= ~(1ull << widx);
+            }
+        }
+        load_kmer();
+        fresh(true);
     };
 
     for (;;) {
@@ -1071,7 +1128,7 @@ __global__ __launch_bounds__(256, 4) void query_stream2_kernel(DevIndex ix, cons
         }
         if (!__any(st != SS_IDLE)) break;
         // ---- this round's reads ----
-        const bool lk = PTABLE && st == SS_LOOKUP;
+        const bool lk = PTABLE && (st == SS_LOOKUP || st == SS_CERT);
         const bool need_line = st == SS_LF || st == SS_HAVE || st == SS_EXTLF;
         uint32_t bi = 0, bj = 0;
         if (need_line) {
@@ -1080,7 +1137,18 @@ __global__ __launch_bounds__(256, 4) void query_stream2_kernel(DevIndex ix, cons
         }
         const bool two = need_line && bj != bi;
         uint2 ent = make_uint2(0, 0);
-        if (lk) ent = ix.ptable[kmer_table_index()];
+        uint32_t cert_q4 = 0;
+        if (lk) {
+            uint32_t tidx;
+            if (st == SS_CERT) {
+                const uint64_t z = cert_string();
+                cert_q4 = static_cast<uint32_t>(z) & 0xFFu;   // bases 0 .. 3 in the signatures' packing (base 3, the next one a search would consume, on top)
+                tidx = static_cast<uint32_t>(z >> 8);
+            } else {
+                tidx = kmer_table_index();
+            }
+            ent = ix.ptable[tidx];
+        }
         uint64_t kwi = 0, kwj = 0;
         if (st == SS_EXTSCAN) {   // a running extension scan (rare): the plain kLCP words at the frontier
             if (scan_i) kwi = klcp[(i - 1u) >> 6];
@@ -1107,7 +1175,13 @@ __global__ __launch_bounds__(256, 4) void query_stream2_kernel(DevIndex ix, cons
         // ---- arithmetic ----
         bool do_lf = false;
         uint32_t c = 0;
-        if (st == SS_LOOKUP) {
+        if (st == SS_CERT) {
+            if (COUNT) cn.lookups++;
+            uint32_t ci, cj;
+            decode_table_entry(ent.x, ent.y, ix.ptable_packed, true, cert_q4, ci, cj);
+            if (ci == cj) skip_dead();
+            else st = SS_LOOKUP;
+        } else if (st == SS_LOOKUP) {
             if (COUNT) cn.lookups++;
             t = k - 1 - T;
             uint32_t q4 = 0;
