@@ -218,13 +218,14 @@ __global__ __launch_bounds__(256) void query_stream_kernel(DevIndex ix, const ui
     uint32_t i = 0, j = 0, st = SS_IDLE, pass = 0, widx = 0;
     // Strand order of the task.  Pass 0 walks ALL windows on one strand, pass 1 the undecided ones on the other.
     // Default: forward strand first (right-to-left), like the reference without its predictor.  Without STRICT the
-    // answer does not depend on the order, so when the task's last window is absent on the forward strand but present
-    // as reverse complement (one extra search per task) the read is taken to be reverse-complement oriented and the
-    // RC strand goes first (left-to-right) -- otherwise every window of such a read would pay a failed forward search
-    // before the RC pass streams through it.  This is the job the reference gives its strand predictor.
+    // answer does not depend on the order, so when the task's last window is absent on the forward strand the task's FIRST
+    // window is searched as reverse complement (the probe: one extra search per task): if it is there the read is taken to
+    // be reverse-complement oriented and the RC strand goes first (left-to-right, from the probe's interval on) -- otherwise
+    // every window of such a read would pay a failed forward search before the RC pass streams through it.  This is the job
+    // the reference gives its strand predictor.  (Rounds 1-3 probed the LAST window and searched the first one again.)
     bool cur_rc = false;          // strand of the current pass
-    bool probing = false;         // the RC probe of the last window is running
-    uint32_t special = 0;         // set by window_done for advance(): 1 start the probe, 2 probe hit -> RC pass first
+    bool probing = false;         // the RC probe of the first window is running
+    uint32_t special = 0;         // set by window_done for advance(): 1 start the probe
     uint64_t task_id = 0, ntask_id = 0;
     uint32_t scan_i = 0, scan_j = 0;   // EXTSCAN: sides still extending
     int t = 0;
@@ -299,14 +300,13 @@ __global__ __launch_bounds__(256) void query_stream_kernel(DevIndex ix, const ui
         if (!strict && pass == 0 && n > 1u) {
             if (probing) {
                 probing = false;
-                if (res != -1) {          // present as reverse complement: restart the task with the RC strand first
-                    special = 2;
-                    return;
+                if (res == -1) {          // absent there, too: forward strand first after all, from the last window on (its forward result: -1)
+                    cur_rc = false;
+                    widx = n - 1u;
+                    load_kmer();
+                    ord = -1;
                 }
-                cur_rc = false;           // absent on both strands: carry on forward-first with the forward result (-1)
-                load_kmer();
-                res = -1;
-                ord = -1;
+                // (else: the probe was the FIRST window of a pass 0 on the reverse-complement strand -- its result is recorded below, the pass goes on from it)
             } else if (!cur_rc && res == -1 && widx == n - 1u) {
                 probing = true;
                 special = 1;
@@ -344,11 +344,10 @@ __global__ __launch_bounds__(256) void query_stream_kernel(DevIndex ix, const ui
         if (!WIDE) kmer = ((kmer << 2) | (3u - task_base(s0, s1, s2, s3, w + static_cast<uint32_t>(k)))) & kmask;
     };
     auto advance = [&](bool have) -> bool {
-        if (special) {
-            const uint32_t sp = special;
+        if (special) {   // the probe: the task's FIRST window on the reverse-complement strand (where a pass on that strand starts)
             special = 0;
             cur_rc = true;
-            if (sp == 2) widx = 0;          // the probe hit: RC pass over all windows, ascending
+            widx = 0;
             load_kmer();
             fresh();
             return false;
@@ -677,6 +676,7 @@ __global__ __launch_bounds__(256) void query_stream_kernel(DevIndex ix, const ui
 // Control flow -- tasks of <= 64 windows, pass 0 on one strand, pass 1 over the undecided windows of the other, the reverse-complement
 // probe of the task's last window -- is the kernel's above, and so are the answers (tests/test_gpu_stream.py: stream2 == stream == runs).
 // ORDERS (`lookup -S`) and 33 <= k <= 64 stay with the kernel above.
+constexpr uint32_t kStreamNoCert = 1u << 30, kStreamCertPlain = 1u << 31;   // internal bits of the kernel's flags word (FMSI_HIP_STREAM_CERT=0 / 1: measurements)
 constexpr uint32_t kSRows = 192;
 constexpr uint32_t kSDwords = 32;
 constexpr uint32_t kSPitch = 9;   // uint4 per staged line in LDS: 144 bytes
@@ -850,8 +850,16 @@ __global__ __launch_bounds__(256, 4) void query_stream2_kernel(DevIndex ix, cons
     // same base).  The ordinary lookup's entry -- the k-mer's LAST T bases -- says the same about the windows the pass has just left: that is
     // why it cannot be used for this.  Exact: get_range_with_pattern (src/fms_index.h:117-124) returns an empty range for a pattern with an
     // absent substring.  A certificate that fails (the string occurs, or its entry has more than three rows) costs its round.
-    const bool cert_ok = PTABLE && k >= T + 4;
+    // WHERE in the k-mer the certificate's string lies (offset o, 0 .. cert_d; it then settles cert_d + 1 - o windows): when a STREAMED step
+    // dies -- a read that follows the text until a substituted base -- only strings that contain that base are absent, and the windows that
+    // contain it are a run of k (aff_end: its last window in the pass' order).  While more than cert_d windows of the run are left the
+    // string at offset 0 holds the base; for the run's last windows it moves towards the run's far end by the difference and settles
+    // exactly those.  Everywhere else (reads that are not from the text, the strand a read does not follow) any string will do: offset 0.
+    const bool cert_ok = PTABLE && k >= T + 4 && !(flags & kStreamNoCert);
+    const bool cert_plain = (flags & kStreamCertPlain) != 0u;   // (A/B runs: always offset 0)
     const uint32_t cert_d = static_cast<uint32_t>(k - T - 4);
+    constexpr int kAffFar = 1 << 20;
+    int aff_end = 0;
 
     uint64_t s0 = 0, s1 = 0, s2 = 0, s3 = 0, obase = 0;
     uint32_t n = 0;
@@ -883,12 +891,18 @@ __global__ __launch_bounds__(256, 4) void query_stream2_kernel(DevIndex ix, cons
         const uint64_t f = task_kmer(s0, s1, s2, s3, widx, k);
         kmer = !cur_rc ? f : revcomp_2bit(f, k);
     };
-    auto cert_string = [&]() -> uint64_t {   // the first T + 4 bases of the current window's k-mer on the current strand (base 0 in bits 0..1)
+    auto cert_offset = [&]() -> uint32_t {
+        if (cert_plain) return 0u;
+        // windows left in the run of windows that hold the base a streamed step died at, the current one included (<= 0: behind it, or none known)
+        const int r = !cur_rc ? static_cast<int>(widx) - aff_end + 1 : aff_end - static_cast<int>(widx) + 1;
+        return (r <= 0 || r > static_cast<int>(cert_d)) ? 0u : cert_d + 1u - static_cast<uint32_t>(r);
+    };
+    auto cert_string = [&](uint32_t o) -> uint64_t {   // bases o .. o + T + 3 of the current window's k-mer on the current strand (the first in bits 0..1)
         if (WIDE) {
-            const uint64_t z = task_kmer(s0, s1, s2, s3, !cur_rc ? widx : widx + cert_d, T + 4);
+            const uint64_t z = task_kmer(s0, s1, s2, s3, !cur_rc ? widx + o : widx + cert_d - o, T + 4);
             return !cur_rc ? z : revcomp_2bit(z, T + 4);
         }
-        return kmer & ((1ull << (2 * (T + 4))) - 1ull);
+        return (kmer >> (2u * o)) & ((1ull << (2 * (T + 4))) - 1ull);
     };
     // after_fail: the window before this one (in the pass' order) had an empty interval -- try a certificate first
     auto fresh = [&](bool after_fail = false) {
@@ -925,6 +939,7 @@ __global__ __launch_bounds__(256, 4) void query_stream2_kernel(DevIndex ix, cons
     auto begin_pass1 = [&]() {
         pass = 1;
         cur_rc = !cur_rc;
+        aff_end = cur_rc ? -kAffFar : kAffFar;
         const uint64_t all = n == 64 ? ~0ull : ((1ull << n) - 1ull);
         if (strict) todo = all;
         else if (!mode_all) todo = all & ~(rf_hi & ~rf_lo);   // OR: only a pass-0 result of 1 decides
@@ -950,13 +965,13 @@ __global__ __launch_bounds__(256, 4) void query_stream2_kernel(DevIndex ix, cons
         if (!strict && pass == 0 && n > 1u) {
             if (probing) {
                 probing = false;
-                if (res != -1) {
-                    special = 2;
-                    return;
+                if (res == -1) {   // absent there, too: forward strand first after all, from the last window on
+                    other_dead |= 1ull;   // (and pass 1 need not search window 0 on the other strand again)
+                    cur_rc = false;
+                    widx = n - 1u;
+                    load_kmer();
                 }
-                cur_rc = false;
-                load_kmer();
-                res = -1;
+                // (else: the probe was the first window of a pass 0 on the reverse-complement strand: recorded below, the pass streams on from its interval)
             } else if (!cur_rc && res == -1 && widx == n - 1u) {
                 probing = true;
                 special = 1;
@@ -984,12 +999,12 @@ __global__ __launch_bounds__(256, 4) void query_stream2_kernel(DevIndex ix, cons
         if (!WIDE) kmer = ((kmer << 2) | (3u - task_base(s0, s1, s2, s3, w + static_cast<uint32_t>(k)))) & kmask;
     };
     auto advance = [&](bool have) -> bool {
-        if (special) {
-            const uint32_t sp = special;
+        if (special) {   // the probe: the task's FIRST window on the reverse-complement strand (where a pass on that strand starts)
             special = 0;
             cur_rc = true;
-            other_dead = 0;   // (pass 0 changes strands: what was learnt about the other one no longer is pass 1's)
-            if (sp == 2) widx = 0;
+            aff_end = -kAffFar;
+            other_dead = 0;   // (pass 0 may change strands: what was learnt about the other one no longer is pass 1's)
+            widx = 0;
             load_kmer();
             fresh();
             return false;
@@ -1042,26 +1057,27 @@ __global__ __launch_bounds__(256, 4) void query_stream2_kernel(DevIndex ix, cons
     };
     // a certificate said so: the current window and the cert_d windows the pass would visit after it have empty intervals on this strand
     // (their result planes hold "empty" already) -- on to the first window behind them
-    auto skip_dead = [&]() {
+    auto skip_dead = [&](uint32_t o) {
+        const uint32_t cnt = cert_d - o;   // windows settled beside the current one
         if (pass == 0) {
             if (!cur_rc) {
-                if (widx <= cert_d) {
+                if (widx <= cnt) {
                     begin_pass1();
                     return;
                 }
-                widx -= cert_d + 1u;
+                widx -= cnt + 1u;
             } else {
-                if (widx + cert_d + 1u >= n) {
+                if (widx + cnt + 1u >= n) {
                     begin_pass1();
                     return;
                 }
-                widx += cert_d + 1u;
+                widx += cnt + 1u;
             }
         } else {
-            if (cur_rc) {   // windows (widx, widx + cert_d]
-                if (cert_d) todo &= ~((((2ull << (cert_d - 1u)) - 1ull) << widx) << 1);
-            } else {        // windows [widx - cert_d, widx)
-                todo &= ~((1ull << widx) - 1ull) | (widx > cert_d ? (1ull << (widx - cert_d)) - 1ull : 0ull);
+            if (cur_rc) {   // windows (widx, widx + cnt]
+                if (cnt) todo &= ~((((2ull << (cnt - 1u)) - 1ull) << widx) << 1);
+            } else {        // windows [widx - cnt, widx)
+                todo &= ~((1ull << widx) - 1ull) | (widx > cnt ? (1ull << (widx - cnt)) - 1ull : 0ull);
             }
             if (!todo) {
                 end_task();
@@ -1111,6 +1127,7 @@ __global__ __launch_bounds__(256, 4) void query_stream2_kernel(DevIndex ix, cons
                         if (ORD) obase = (static_cast<uint64_t>(r2.y) << 32) | r2.x;
                     }
                     task_id = cand;
+                    aff_end = kAffFar;    // (no run known: pass 0 starts on the forward strand, windows descending)
                     pass = 0;
                     cur_rc = false;
                     probing = false;
@@ -1141,7 +1158,7 @@ __global__ __launch_bounds__(256, 4) void query_stream2_kernel(DevIndex ix, cons
         if (lk) {
             uint32_t tidx;
             if (st == SS_CERT) {
-                const uint64_t z = cert_string();
+                const uint64_t z = cert_string(cert_offset());
                 cert_q4 = static_cast<uint32_t>(z) & 0xFFu;   // bases 0 .. 3 in the signatures' packing (base 3, the next one a search would consume, on top)
                 tidx = static_cast<uint32_t>(z >> 8);
             } else {
@@ -1179,7 +1196,7 @@ __global__ __launch_bounds__(256, 4) void query_stream2_kernel(DevIndex ix, cons
             if (COUNT) cn.lookups++;
             uint32_t ci, cj;
             decode_table_entry(ent.x, ent.y, ix.ptable_packed, true, cert_q4, ci, cj);
-            if (ci == cj) skip_dead();
+            if (ci == cj) skip_dead(cert_offset());
             else st = SS_LOOKUP;
         } else if (st == SS_LOOKUP) {
             if (COUNT) cn.lookups++;
@@ -1300,15 +1317,17 @@ __global__ __launch_bounds__(256, 4) void query_stream2_kernel(DevIndex ix, cons
             j = base + rj;
             if (COUNT) cn.lf_steps++;
             if (st == SS_LF) {
-                --t;
                 if (i == j) {
                     window_done(-1);
                     advance(false);
-                } else if (t < 0) {
+                } else if (--t < 0) {
                     st = SS_HAVE;
                 }
             } else {
                 if (i == j) {
+                    // a streamed step with an empty interval: the window's new base -- its first on the forward strand, its last on the other -- is
+                    // one the text does not have there; the windows that hold it end k - 1 windows on in the pass' order
+                    aff_end = !cur_rc ? static_cast<int>(widx) - (k - 1) : static_cast<int>(widx) + (k - 1);
                     window_done(-1);
                     advance(false);
                 } else {
@@ -1338,6 +1357,10 @@ void launch_stream2(fmsi_hip_index* idx, const TaskRec* recs, uint64_t n_tasks, 
     if (chunk_env) chunk = std::max(1, std::atoi(chunk_env));
     const uint64_t waves = (n_tasks + chunk - 1) / chunk;
     const uint32_t blocks = static_cast<uint32_t>((waves + 3) / 4);
+    static const char* cert_env = std::getenv("FMSI_HIP_STREAM_CERT");   // (measurements: 0 = no certificates, 1 = always at offset 0)
+    flags &= ~(kStreamNoCert | kStreamCertPlain);
+    if (cert_env && cert_env[0] == '0') flags |= kStreamNoCert;
+    if (cert_env && cert_env[0] == '1') flags |= kStreamCertPlain;
     if (uni)
         hipLaunchKernelGGL((query_stream2_kernel<COUNT, PTABLE, true, WIDE, ORD>), dim3(blocks), dim3(256), 0, s, idx->dev,
                            static_cast<const uint4*>(idx->d_sblocks), static_cast<const uint64_t*>(idx->d_klcp), recs, n_tasks, k, flags,
