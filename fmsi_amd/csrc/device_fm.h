@@ -91,9 +91,9 @@ __device__ __forceinline__ uint32_t mask_bit(const DevIndex& ix, uint32_t row) {
 //          get_range_with_pattern() would return an empty range either way (src/fms_index.h:117-124), so it is returned
 //          empty right here and the block reads of those steps never happen.  A row whose preceding text is shorter
 //          than four symbols carries an arbitrary signature (a false match only costs the ordinary steps).
-//   hints (ptable_packed == 2; zero otherwise): five bits about the entry of the key's REVERSE COMPLEMENT, for the kernel that walks both
-//          strands of consecutive windows (fmsi_stream.hip): bit 31 = that t-mer does not occur; bit 26 + c = some row of its interval is
-//          preceded by base c (all four set when the interval has more than three rows).  This function ignores them.
+//   (bits 31, 29..26 of y: zero.  Round 4's first kLCP kernel kept five bits about the entry of the key's reverse complement there -- "that
+//   t-mer does not occur", "which bases precede its rows" -- to spare pass 1 the other strand's lookups; the absence certificates of
+//   fmsi_stream.hip settle those windows a dozen at a time and the bits no longer changed a request count: removed)
 constexpr uint32_t kTableHintMask = 0xBC000000u;   // bits 31, 29..26
 __device__ __forceinline__ void decode_table_entry(uint32_t x, uint32_t y, uint32_t packed, bool have4, uint32_t q4, uint32_t& i, uint32_t& j) {
     i = x;

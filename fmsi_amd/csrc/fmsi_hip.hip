@@ -409,25 +409,6 @@ __global__ __launch_bounds__(256) void ptable_maxlen_kernel(const uint2* __restr
     if ((threadIdx.x & 63) == 0 && m) atomicMax(max_len, m);
 }
 
-// Five bits about the entry of every key's reverse complement into the key's own entry (decode_table_entry, "hints"): in place -- a
-// thread writes bits 31, 29..26 of its own entry and reads the other bits of another, which nobody changes.
-__global__ __launch_bounds__(256) void ptable_hint_kernel(uint2* __restrict__ tab, int t, uint64_t count) {
-    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
-    for (uint64_t idx = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; idx < count; idx += stride) {
-        const uint32_t yo = tab[revcomp_2bit(idx, t)].y;
-        uint32_t hint;
-        if ((yo >> 30) & 1u) {   // 1..3 rows: the bases that precede them (the first symbol of each signature)
-            const uint32_t rows = (yo >> 24) & 3u;
-            hint = 1u << (26u + ((yo >> 6) & 3u));
-            if (rows > 1u) hint |= 1u << (26u + ((yo >> 14) & 3u));
-            if (rows > 2u) hint |= 1u << (26u + ((yo >> 22) & 3u));
-        } else {
-            hint = (yo & 0x03FFFFFFu) ? (15u << 26) : (1u << 31);   // many rows: any base may precede one of them; none: the t-mer does not occur
-        }
-        tab[idx].y = (tab[idx].y & ~kTableHintMask) | hint;
-    }
-}
-
 // (i, j) -> packed entries (decode_table_entry): intervals of 1..3 rows get the signatures of their rows
 __global__ __launch_bounds__(256) void ptable_pack_kernel(DevIndex ix, uint2* __restrict__ tab, uint64_t count) {
     const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
@@ -526,13 +507,6 @@ int build_prefix_table(fmsi_hip_index* idx, int t) {
             e2 = hipGetLastError();
             if (e2 == hipSuccess) e2 = hipDeviceSynchronize();
             idx->dev.ptable_packed = 1;
-            // a handle that can stream (kLCP array): the entries' hints about the other strand (fmsi_stream.hip)
-            if (e2 == hipSuccess && idx->d_klcp) {
-                hipLaunchKernelGGL(ptable_hint_kernel, dim3(blocks), dim3(256), 0, 0, a, t, final_count);
-                e2 = hipGetLastError();
-                if (e2 == hipSuccess) e2 = hipDeviceSynchronize();
-                idx->dev.ptable_packed = 2;
-            }
         }
         if (e2 != hipSuccess) {
             (void)dev_free(a);

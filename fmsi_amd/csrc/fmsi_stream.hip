@@ -826,13 +826,8 @@ __global__ __launch_bounds__(256, 4) void query_stream2_kernel(DevIndex ix, cons
                                                             uint4* __restrict__ slots, long long* __restrict__ out_orders,
                                                             unsigned long long* __restrict__ counters, UniformRuns u) {
     __shared__ uint4 s_line[4][64 * kSPitch];
-    // what a lane's pass 0 learns about the FIRST windows of the NEXT task of its read (the hints of its last k - T lookups point past its own
-    // 64 windows): task number and one bit per window, read by the right-hand neighbour -- which holds that task -- when its pass 1 begins
-    __shared__ uint32_t s_hint_task[4][64], s_hint_bits[4][64];
     const uint32_t ln = threadIdx.x & 63u;
     uint4* my_wave_lines = s_line[threadIdx.x >> 6];
-    uint32_t* hint_task = s_hint_task[threadIdx.x >> 6];
-    uint32_t* hint_bits = s_hint_bits[threadIdx.x >> 6];
     const uint32_t* L = reinterpret_cast<const uint32_t*>(my_wave_lines + ln * kSPitch);   // this lane's staged line
     const uint32_t mode_all = ORD ? 0u : (flags & FMSI_HIP_MODE_ALL);   // (orders: a strand decides a window when it HAS an order -- OR's schedule)
     const uint32_t strict = flags & FMSI_HIP_STRICT;
@@ -867,7 +862,7 @@ __global__ __launch_bounds__(256, 4) void query_stream2_kernel(DevIndex ix, cons
     uint64_t rf_lo = 0, rf_hi = 0;   // pass-0 result + 1 of window w in bit w of the two planes (0 = empty interval)
     uint64_t rr_lo = 0, rr_hi = 0;   // pass-1 result + 1 (0: not visited or empty)
     uint64_t todo = 0;
-    uint64_t other_dead = 0;          // windows whose search on the strand pass 0 does NOT walk is known to be empty (the table entries' hints)
+    bool first_dead = false;          // the probe found window 0 absent on the reverse-complement strand: pass 1 need not search it again
     uint32_t i = 0, j = 0, st = SS_IDLE, pass = 0, widx = 0;
     bool cur_rc = false, probing = false;
     uint32_t special = 0;
@@ -944,9 +939,7 @@ __global__ __launch_bounds__(256, 4) void query_stream2_kernel(DevIndex ix, cons
         if (strict) todo = all;
         else if (!mode_all) todo = all & ~(rf_hi & ~rf_lo);   // OR: only a pass-0 result of 1 decides
         else todo = all & ~(rf_lo | rf_hi);                   // ALL: any non-empty pass-0 interval decides
-        if (UNI && cur_rc && ln > 0u && hint_task[ln - 1u] + 1u == static_cast<uint32_t>(task_id) && static_cast<uint32_t>(task_id) % u.tpr != 0u)
-            other_dead |= hint_bits[ln - 1u];                 // (the left neighbour walked the task before mine of the same read: its hints about my first windows)
-        todo &= ~other_dead;                                  // (their pass-1 result is "empty interval": the planes' zero says so)
+        if (first_dead) todo &= ~1ull;                        // (its pass-1 result is "empty interval": the planes' zero says so)
         if (!todo) {
             end_task();
             return;
@@ -966,7 +959,7 @@ __global__ __launch_bounds__(256, 4) void query_stream2_kernel(DevIndex ix, cons
             if (probing) {
                 probing = false;
                 if (res == -1) {   // absent there, too: forward strand first after all, from the last window on
-                    other_dead |= 1ull;   // (and pass 1 need not search window 0 on the other strand again)
+                    first_dead = true;
                     cur_rc = false;
                     widx = n - 1u;
                     load_kmer();
@@ -1003,7 +996,6 @@ __global__ __launch_bounds__(256, 4) void query_stream2_kernel(DevIndex ix, cons
             special = 0;
             cur_rc = true;
             aff_end = -kAffFar;
-            other_dead = 0;   // (pass 0 may change strands: what was learnt about the other one no longer is pass 1's)
             widx = 0;
             load_kmer();
             fresh();
@@ -1133,9 +1125,7 @@ __global__ __launch_bounds__(256, 4) void query_stream2_kernel(DevIndex ix, cons
                     probing = false;
                     special = 0;
                     rf_lo = rf_hi = rr_lo = rr_hi = 0;
-                    other_dead = 0;
-                    hint_task[ln] = static_cast<uint32_t>(cand);
-                    hint_bits[ln] = 0u;
+                    first_dead = false;
                     widx = n - 1u;
                     load_kmer();
                     fresh();
@@ -1204,31 +1194,6 @@ __global__ __launch_bounds__(256, 4) void query_stream2_kernel(DevIndex ix, cons
             uint32_t q4 = 0;
             if (t >= 3) q4 = kmer_base(t - 3) | (kmer_base(t - 2) << 2) | (kmer_base(t - 1) << 4) | (kmer_base(t) << 6);
             decode_table_entry(ent.x, ent.y, ix.ptable_packed, t >= 3, q4, i, j);
-            if (ix.ptable_packed == 2u && pass == 0 && !probing) {
-                // The entry also carries five bits about the entry of its key's REVERSE COMPLEMENT (ptable_hint_kernel) -- which is the table
-                // key of the OTHER strand's search of another window of this read: the last T bases of window w (forward strand) are the
-                // first T bases of window w + (k - T), whose reverse-complement search starts with their reverse complement, and the other
-                // way round.  "No such T-mer", or "none of its rows is preceded by the base that search consumes next": pass 1 need not
-                // look that window up -- an absent read costs about one table request per window instead of two.
-                const uint32_t d = static_cast<uint32_t>(k - T);
-                const uint32_t w2 = cur_rc ? widx - d : widx + d;      // (cur_rc, widx < d: wraps above n)
-                if (w2 < n) {
-                    bool dead = (ent.y >> 31) != 0u;
-                    if (t >= 0) {
-                        // the base the other strand's search of window w2 consumes after its T table bases: base t of the k-mer it walks
-                        // (the forward k-mer, or -- base t of a reverse complement -- the complement of the forward k-mer's base k - 1 - t = T)
-                        const uint32_t c_next = cur_rc ? task_base(s0, s1, s2, s3, w2 + static_cast<uint32_t>(t)) : 3u - task_base(s0, s1, s2, s3, w2 + static_cast<uint32_t>(T));
-                        dead = dead || !((ent.y >> (26u + c_next)) & 1u);
-                    }
-                    if (dead) other_dead |= 1ull << w2;
-                } else if (UNI && !cur_rc && n == 64u && w2 < 64u + d) {
-                    // window w2 - 64 of the NEXT task of this read (if there is one: the reader checks): the same test, the bases are at hand
-                    // (a task's four words hold 128 bases, w2 + T <= 94)
-                    bool dead = (ent.y >> 31) != 0u;
-                    if (t >= 0) dead = dead || !((ent.y >> (26u + 3u - task_base(s0, s1, s2, s3, w2 + static_cast<uint32_t>(T)))) & 1u);
-                    if (dead) hint_bits[ln] |= 1u << (w2 - 64u);
-                }
-            }
             if (i == j) {
                 window_done(-1);
                 advance(false);

@@ -28,8 +28,7 @@ struct DevIndex {
     uint32_t dollar;          // dollar_position
     uint32_t C0, C1, C2, C3;  // counts[] (src/fms_index.h:451)
     uint32_t ptable_len;      // t
-    uint32_t ptable_packed;   // entry format: 0 = (i, j); 1 = (i, tagged word) with next-base signatures, see decode_table_entry; 2 = the same
-                              // plus five bits about the entry of the key's reverse complement (ptable_hint_kernel)
+    uint32_t ptable_packed;   // entry format: 0 = (i, j); 1 = (i, tagged word) with next-base signatures, see decode_table_entry
 };
 
 // the same blocks for an index of 2^32 rows and more (fmsi_wide.hip): u64 rows, absolute counts per superblock
