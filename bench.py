@@ -974,7 +974,7 @@ def compact_line(line):
         return len(json.dumps(o, separators=(",", ":")))
     # never above the limit: shed the least important fields first
     for drop in (("configs", "kernel"), ("roofline", "bytes_per_kmer"), ("roofline", "blocks_per_kmer"), ("config", "gather", "alt"), ("cpu_baseline", "cpu_model"),
-                 ("cpu_baseline", "tuned_value"), ("configs", "kernel_ms"), ("configs", "frac"), ("configs", "hbm_gb"), ("configs", "ms")):
+                 ("cpu_baseline", "tuned_value"), ("configs", "hbm_gb"), ("configs", "kernel_ms"), ("configs", "ms"), ("configs", "frac")):
         if size(out) <= COMPACT_LIMIT:
             break
         tgt = out.get(drop[0])

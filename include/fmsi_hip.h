@@ -322,14 +322,19 @@ int fmsi_hip_query_runs_fn(fmsi_hip_index* idx, const uint64_t* packed_seq, cons
  * right-to-left with the kLCP extension (src/fms_index.h:106-115).  Run r covers windows starting at bases
  * run_start[r] .. run_start[r] + run_windows[r] - 1; results are written consecutively in run order.
  * Without FMSI_HIP_STRICT the strand order is chosen per task of <= 64 consecutive windows, the way the reference's
- * strand predictor chooses it per chunk: forward strand first, unless the task's last window is absent on the forward
- * strand and present as reverse complement -- then the reverse-complement strand goes first.  As with the reference's
- * predictor this cannot change an OR-mode answer, nor an ALL-mode answer under the max-ones precondition. */
+ * strand predictor chooses it per chunk: forward strand first, unless the task's last window (where a forward pass starts)
+ * is absent on the forward strand and its first window (where a reverse-complement pass starts) is present as reverse
+ * complement -- then the reverse-complement strand goes first.  As with the reference's predictor this cannot change an
+ * OR-mode answer, nor an ALL-mode answer under the max-ones precondition.
+ * FMSI_HIP_ORDERS (`lookup -S`) and 33 <= k <= 64 (the reference's __uint128_t k-mers, src/main.cpp:223-230) are served by the
+ * same kernel.  A fresh search that follows a failed window is preceded by a prefix-table request for a (t + 4)-mer of the
+ * window that its next k - t - 4 neighbours share: a string the text does not hold settles all of them (exact: a pattern with
+ * an absent substring has an empty range, src/fms_index.h:117-124). */
 int fmsi_hip_query_stream(fmsi_hip_index* idx, const uint64_t* packed_seq, uint64_t seq_bases,
                           const uint64_t* run_start, const uint32_t* run_windows, uint64_t n_runs,
                           uint64_t n_windows, int k, uint32_t flags, void* out, uint64_t* counters, void* stream);
 
-/* The layout fmsi_hip_query_stream's kernel for k <= 32 presence queries reads -- 128-byte blocks of 192 rows that carry the kLCP bits of
+/* The layout fmsi_hip_query_stream's kernel reads -- 128-byte blocks of 192 rows that carry the kLCP bits of
  * their rows beside the wavelet-tree and mask planes, so that a streamed window is one memory request (4/3 byte per row of HBM) -- is
  * built from the handle's blocks and kLCP array on the first such call; a host that wants the cost at load time calls this.  Idempotent;
  * needs a handle with a kLCP array. */

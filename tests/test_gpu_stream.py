@@ -155,6 +155,46 @@ def test_stream_on_repetitive_index(fm, oracle_built, tmp_path):
     run_case(fm, orc, dev, reads, k)
 
 
+@pytest.mark.parametrize("k,t", [(7, 4), (8, 4), (9, 4), (10, 4), (12, 6), (31, 9), (32, 8)])
+def test_stream_absence_certificates(fm, oracle_built, tmp_path, k, t):
+    """The certificate lookups of the S-block kernel (a (t + 4)-mer that the text does not hold settles k - t - 3 windows at once): k below
+    t + 4 (none possible), k = t + 4 (a certificate settles its own window only), k just above, table keys with MANY rows (a short table
+    on a repetitive text: entries without signatures cannot certify), reads that leave and rejoin the text at substitutions a few bases
+    apart, at the first and last bases of tasks, reads of random bases, reads shorter than a certificate's reach -- strand by strand
+    against the oracle, both modes, orders, and against the first kernel."""
+    rng = random.Random(1000 * k + t)
+    body = "".join(rng.choice("ACGT") for _ in range(6000))
+    fam = "".join(rng.choice("ACGT") for _ in range(300))
+    ms = body[:2000] + fam + body[2000:4000] + "".join(rng.choice("ACGT") if rng.random() < 0.03 else ch for ch in fam) + body[4000:] + "AC" * 200 + "T" * 150
+    ms = "".join(ch if rng.random() < 0.7 else ch.lower() for ch in ms)
+    ms = ms[: len(ms) - (k - 1)] + ms[len(ms) - (k - 1):].lower()
+    orc = oracle_py.Oracle.construct(ms, k, use_klcp=True)
+    prefix = str(tmp_path / "c")
+    orc.dump(prefix)
+    dev = fm.DeviceIndex.load(prefix, use_klcp=True, prefix_len=t)
+    up = ms.upper()
+    reads = []
+    for L in (k, k + 1, 64 + k - 1, 64 + k, 200, 700):
+        for _ in range(6):
+            p = rng.randrange(0, len(up) - L + 1)
+            r = up[p:p + L]
+            if rng.random() < 0.5:
+                r = revcomp(r)
+            reads.append(r)
+            sub = list(r)
+            for x in sorted({0, L - 1, L // 2, rng.randrange(L), min(L - 1, L // 2 + rng.randrange(1, 6)), rng.randrange(L)}):
+                if rng.random() < 0.7:
+                    sub[x] = rng.choice([c for c in "ACGT" if c != sub[x]])
+            reads.append("".join(sub))
+        reads.append("".join(rng.choice("ACGT") for _ in range(L)))
+    reads.append(up[:900])
+    reads.append(revcomp(up[-900:]))
+    reads.append("ACGT" * 60 + "T" * 100)
+    run_case(fm, orc, dev, reads, k)
+    one = [r[:150 + k - 1].ljust(150 + k - 1, "A") for r in reads if len(r) >= 150]     # reads of one length: tasks cut inside the kernel
+    run_case(fm, orc, dev, one, k)
+
+
 def test_stream_argument_errors(fm):
     dev_no = fm.DeviceIndex.from_files(index_prefix("sars_k31"), use_klcp=False)
     words = fm.pack_sequence(b"ACGT" * 20)

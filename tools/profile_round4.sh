@@ -11,7 +11,7 @@ mkdir -p "$O"
 cd /tmp && export TMPDIR=/tmp
 timeout 600 python3 "$R/bench.py" --steps 20 --warmup 5 > "$O/bench_default.json" 2> "$O/bench_default.err"
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/trace_headline" -o run -- python3 "$R/bench.py" --steps 20 --warmup 5 --no-pmc --no-config-legs --cpu-sample 0 > "$O/trace_headline.log" 2>&1
-for spec in c2:c2 c3:c3 c3sk:c3_superkmer c4:c4_dict_chain c4:c4_dict_plain c4k:c4_klcp c4k:c4_klcp_subst1pct c4sk:c4_superkmer c4sk:c4_superkmer_subst1pct c5dict:c5_kmer_dictionary; do
+for spec in c2:c2 c3:c3 c3sk:c3_superkmer c4:c4_dict_chain c4:c4_dict_plain c4k:c4_klcp c4k:c4_klcp_subst1pct c4k:c4_klcp_lookup c4k:c4_klcp_lookup_fast c4k48:c4_klcp_k48 c4sk:c4_superkmer c4sk:c4_superkmer_subst1pct c5dict:c5_kmer_dictionary; do
   leg=${spec%%:*}; v=${spec##*:}
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/trace_$v" -o run -- python3 "$R/bench.py" --leg $leg --variants $v --no-pmc > "$O/trace_$v.json" 2> "$O/trace_$v.log"
 done
