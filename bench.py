@@ -617,6 +617,8 @@ def measure_traffic(args, plan, child_args):
                 if any(mk in name for mk in MARKER_KERNELS):
                     group += 1
                     continue
+                if "sblock_build_kernel" in name:   # (the streaming layout, built once on the handle's first -S call: construction, not a query's traffic)
+                    continue
                 if 0 <= group < len(plan) and ("fmsi::" in name or "rocprim::" in name):   # (the library's kernels and the sorts it calls; not torch's fill of the next variant's buffer)
                     kk = per_variant[group]["kernels"].setdefault(name, {"FETCH_SIZE": 0.0, "WRITE_SIZE": 0.0, "dispatches": 0})
                     kk[counter] += val * 1024.0   # the counters are in KiB
