@@ -182,12 +182,13 @@ def _reads_agree(fm, dev, k, L, n_reads, subst_ppm, flags_a, flags_b, seed=7):
 @pytest.fixture(scope="module")
 def human_mixed(product_built):
     """ONE handle for the at-scale tests that want the hard text: n = 2.8 x 10^9 rows, 60 % of the positions ON, a fifth of the 2048-base
-    segments copies of 50 consensus segments at 1 % divergence, with the kLCP array and the pair layout (building it takes longer than
+    segments copies of 50 consensus segments at 1 % divergence, with the kLCP array, a 16-deep prefix table (what bench.py's kLCP legs use: entries
+    of <= 3 rows carry signatures, so the S-block kernel's absence certificates fire) and the pair layout (building it takes longer than
     either test's queries; the dictionaries a test adds stay on it)."""
     fm = product_built
     n, k = 2_800_000_000, 31
     with fm.builder_chain(0):
-        dev = fm.DeviceIndex.build_synthetic(n, 777, k, with_klcp=True, prefix_len=13, repeats=(200, 50, 10), mask_permille=600).enable_pair_layout()
+        dev = fm.DeviceIndex.build_synthetic(n, 777, k, with_klcp=True, prefix_len=16, repeats=(200, 50, 10), mask_permille=600).enable_pair_layout()
     yield dev
     dev.close()
     fm.trim_scratch(0)
@@ -211,7 +212,7 @@ def test_stream_kernel_at_human_scale(fm, human_mixed):
       * uniform runs (three numbers in the kernel's arguments) and ragged runs (the run table, tasks that end inside reads);
       * the first 34 reads (10^5 windows): == the ORACLE's ternaries (C restatement on the downloaded index incl. kLCP) and == the REAL
         reference's `-S` record loop (query_kmers<or>(..., has_klcp=true)) on the index written in its own file format;
-      * ORDERS (`lookup -S`: the round-2 kernel) == the oracle's orders on the sample, == the LF walk on all windows."""
+      * ORDERS (`lookup -S`: the kernel's ORD instantiation) == the oracle's orders on the sample, == the LF walk on all windows."""
     import os
     import tempfile
     import bench_cpu
@@ -238,8 +239,11 @@ def test_stream_kernel_at_human_scale(fm, human_mixed):
         flag = fm.MODE_ALL if mode_all else fm.MODE_OR
         for rw, tag in ((wins, "uniform"), (wins_r, "ragged")):
             walk = dev.query_runs(packed, n_reads * L, starts, rw, k, flag | fm.STRICT | fm.NO_PREFIX_TABLE)
-            got, cn = dev.query_stream(packed, n_reads * L, starts, rw, k, flag | fm.STRICT, counters=True)     # (13-deep table, double-stranded entries)
+            got, cn = dev.query_stream(packed, n_reads * L, starts, rw, k, flag | fm.STRICT, counters=True)     # (16-deep table: certificates)
             assert np.array_equal(got, walk), (mode_all, tag, np.nonzero(got != walk)[0][:10])
+            # both strands of every window, yet far fewer table requests than windows: absent (t + 4)-mers settled a dozen windows each
+            assert int(cn[4]) < 0.6 * int(rw.sum()), (int(cn[4]), int(rw.sum()))
+            assert np.array_equal(dev.query_stream(packed, n_reads * L, starts, rw, k, flag | fm.STRICT | fm.KERNEL_REFILL), walk), (mode_all, tag)   # (the first kernel: no certificates)
             assert np.array_equal(dev.query_stream(packed, n_reads * L, starts, rw, k, flag | fm.STRICT | fm.NO_PREFIX_TABLE), walk), (mode_all, tag)
             f, r = fm.decode_strict(got)
             # a streamed window costs about one LF step where the read follows the text: far fewer steps than fresh searches of k bases
@@ -256,7 +260,7 @@ def test_stream_kernel_at_human_scale(fm, human_mixed):
     fa, ra = strict[True]
     assert ((fo == 1) | (ro == 1)).mean() > 0.15 and ((fo == 0) | (ro == 0)).mean() > 0.05 and ((fo == -1) & (ro == -1)).mean() > 0.4
     assert (fo != fa).sum() + (ro != ra).sum() > 100          # the modes differ on this mask (intervals with mixed bits)
-    # ---- lookup -S (ORDERS): the round-2 kernel ----
+    # ---- lookup -S (ORDERS) ----
     _, _, of, orr = orc.ternaries_bulk(sample_text, n_sample, k, False, orders=True)
     got = dev.query_stream(packed, n_reads * L, starts, wins, k, fm.ORDERS | fm.STRICT)
     assert np.array_equal(got[:n_sample, 0], of) and np.array_equal(got[:n_sample, 1], orr)
