@@ -812,6 +812,7 @@ extern "C" int fmsi_cli_query(int argc, char** argv, int output_orders_i) {
     const bool want_dict = dict_possible && opt.full_tables;
     const bool want_bg_dict = dict_possible && !opt.full_tables && opt.background_dict;
     int t = std::min(k, want_dict ? 12 : (opt.full_tables ? 16 : 14));
+    if (const char* e = std::getenv("FMSI_HIP_CLI_TABLE_DEPTH")) t = std::min(k, std::max(0, std::atoi(e)));   // (measurements)
     while (t > 0 && (1ull << (2 * t)) > 4 * index_rows) --t;
 
     // ---- one replicated handle per device (the index is read-only, the batches are independent) ---------------
