@@ -159,7 +159,7 @@ __global__ __launch_bounds__(256) void stream_compact_uniform_bits_kernel(const 
     out[g] = word;
 }
 
-enum : uint32_t { SS_IDLE = 0, SS_LOOKUP = 1, SS_LF = 2, SS_HAVE = 3, SS_EXTSCAN = 4, SS_EXTLF = 5, SS_CERT = 6 };
+enum : uint32_t { SS_IDLE = 0, SS_LOOKUP = 1, SS_LF = 2, SS_HAVE = 3, SS_EXTSCAN = 4, SS_EXTLF = 5, SS_CERT = 6, SS_DONE = 7 };
 
 struct StreamCounters {
     uint32_t lf_steps = 0, blocks = 0, probes = 0, searches = 0, lookups = 0, klcp_words = 0;
@@ -911,11 +911,12 @@ __global__ __launch_bounds__(256, 4) void query_stream2_kernel(DevIndex ix, cons
             st = SS_LF;
         }
     };
-    auto end_task = [&]() {
-        if (ORD) {
-            st = SS_IDLE;
-            return;
-        }
+    // A finished task's results stay in the lane's planes (SS_DONE) until the lane draws its next task or the wave ends: ONE code site writes
+    // them, and in a wave of one task per lane it runs once -- the state machine's branches each ended tasks in place before, and in a wave
+    // whose lanes finish in different rounds (reads with substitutions) the hundred instructions of the byte spread ran round after round.
+    auto end_task = [&]() { st = SS_DONE; };
+    auto flush_task = [&]() {
+        if (ORD) return;
         uint64_t p0, p1, p2, p3;
         if (strict) {   // byte = (f + 1) | (r + 1) << 2
             p0 = rf_lo; p1 = rf_hi; p2 = rr_lo; p3 = rr_hi;
@@ -929,7 +930,6 @@ __global__ __launch_bounds__(256, 4) void query_stream2_kernel(DevIndex ix, cons
         dst[1] = result_bytes16(p0, p1, p2, p3, 1);
         dst[2] = result_bytes16(p0, p1, p2, p3, 2);
         dst[3] = result_bytes16(p0, p1, p2, p3, 3);
-        st = SS_IDLE;
     };
     auto begin_pass1 = [&]() {
         pass = 1;
@@ -1089,11 +1089,12 @@ __global__ __launch_bounds__(256, 4) void query_stream2_kernel(DevIndex ix, cons
 
     for (;;) {
         {   // idle lanes draw the wave's next tasks (ballot + prefix rank, no atomics); a task's record is three 16-byte loads per 64 windows
-            const bool want = st == SS_IDLE;
-            const uint64_t m = __ballot(want);
+            const bool want = st == SS_IDLE || st == SS_DONE;
+            const uint64_t m = next < end ? __ballot(want) : 0ull;   // (nothing left to draw: the finished lanes keep their results for the end)
             if (m) {
                 const uint64_t cand = next + lanes_below(m);
                 if (want && cand < end) {
+                    if (st == SS_DONE) flush_task();
                     if (UNI) {   // (n_tasks < 2^32: the host checks)
                         const uint32_t r = static_cast<uint32_t>(cand) / u.tpr, j = static_cast<uint32_t>(cand) - r * u.tpr;
                         const uint64_t base = u.start0 + static_cast<uint64_t>(r) * u.stride + 64ull * j;
@@ -1133,7 +1134,7 @@ __global__ __launch_bounds__(256, 4) void query_stream2_kernel(DevIndex ix, cons
                 next += static_cast<uint64_t>(__popcll(m));
             }
         }
-        if (!__any(st != SS_IDLE)) break;
+        if (!__any(st != SS_IDLE && st != SS_DONE)) break;
         // ---- this round's reads ----
         const bool lk = PTABLE && (st == SS_LOOKUP || st == SS_CERT);
         const bool need_line = st == SS_LF || st == SS_HAVE || st == SS_EXTLF;
@@ -1302,6 +1303,7 @@ __global__ __launch_bounds__(256, 4) void query_stream2_kernel(DevIndex ix, cons
         }
         __builtin_amdgcn_wave_barrier();   // (the next round's staging must not overtake this round's reads of the lines)
     }
+    if (st == SS_DONE) flush_task();
     if (COUNT) {
         uint32_t v[6] = {cn.lf_steps, cn.blocks, cn.probes, cn.searches, cn.lookups, cn.klcp_words};
 #pragma unroll
