@@ -159,7 +159,7 @@ __global__ __launch_bounds__(256) void stream_compact_uniform_bits_kernel(const 
     out[g] = word;
 }
 
-enum : uint32_t { SS_IDLE = 0, SS_LOOKUP = 1, SS_LF = 2, SS_HAVE = 3, SS_EXTSCAN = 4, SS_EXTLF = 5, SS_CERT = 6, SS_DONE = 7 };
+enum : uint32_t { SS_IDLE = 0, SS_LOOKUP = 1, SS_LF = 2, SS_HAVE = 3, SS_EXTSCAN = 4, SS_EXTLF = 5, SS_CERT = 6, SS_DONE = 7, SS_PASS1 = 8, SS_FRESH_CERT = 9, SS_FRESH_PLAIN = 10 };
 
 struct StreamCounters {
     uint32_t lf_steps = 0, blocks = 0, probes = 0, searches = 0, lookups = 0, klcp_words = 0;
@@ -931,7 +931,12 @@ __global__ __launch_bounds__(256, 4) void query_stream2_kernel(DevIndex ix, cons
         dst[2] = result_bytes16(p0, p1, p2, p3, 2);
         dst[3] = result_bytes16(p0, p1, p2, p3, 3);
     };
-    auto begin_pass1 = [&]() {
+    // The set-up work between windows has ONE code site each, at the top of the round loop: the state machine's branches only name it --
+    // SS_PASS1 (pass 0 is over), SS_FRESH_CERT / SS_FRESH_PLAIN (cut the k-mer of window widx from the task's bases and start a search, with
+    // or without a certificate first).  In a wave whose lanes are in different states a round runs every branch some lane is in; what the
+    // branches share is better run once.
+    auto begin_pass1 = [&]() { st = SS_PASS1; };
+    auto begin_pass1_now = [&]() {
         pass = 1;
         cur_rc = !cur_rc;
         aff_end = cur_rc ? -kAffFar : kAffFar;
@@ -951,8 +956,7 @@ __global__ __launch_bounds__(256, 4) void query_stream2_kernel(DevIndex ix, cons
             widx = 63u - static_cast<uint32_t>(__clzll(static_cast<long long>(todo)));
             todo &= ~(1ull << widx);
         }
-        load_kmer();
-        fresh(true);   // (pass 1 visits the windows pass 0 left undecided: mostly windows that are in the text on neither strand)
+        st = SS_FRESH_CERT;   // (pass 1 visits the windows pass 0 left undecided: mostly windows that are in the text on neither strand)
     };
     auto window_done = [&](int res, uint32_t ord = 0u) {
         if (!strict && pass == 0 && n > 1u) {
@@ -997,8 +1001,7 @@ __global__ __launch_bounds__(256, 4) void query_stream2_kernel(DevIndex ix, cons
             cur_rc = true;
             aff_end = -kAffFar;
             widx = 0;
-            load_kmer();
-            fresh();
+            st = SS_FRESH_PLAIN;
             return false;
         }
         if (pass == 0) {
@@ -1041,10 +1044,10 @@ __global__ __launch_bounds__(256, 4) void query_stream2_kernel(DevIndex ix, cons
         widx = nw;
         if (adjacent) {
             if (have) return true;
+            fresh(true);
         } else {
-            load_kmer();
+            st = have ? SS_FRESH_PLAIN : SS_FRESH_CERT;
         }
-        fresh(!have);
         return false;
     };
     // a certificate said so: the current window and the cert_d windows the pass would visit after it have empty intervals on this strand
@@ -1083,11 +1086,11 @@ __global__ __launch_bounds__(256, 4) void query_stream2_kernel(DevIndex ix, cons
                 todo &= ~(1ull << widx);
             }
         }
-        load_kmer();
-        fresh(true);
+        st = SS_FRESH_CERT;
     };
 
     for (;;) {
+        if (st == SS_PASS1) begin_pass1_now();
         {   // idle lanes draw the wave's next tasks (ballot + prefix rank, no atomics); a task's record is three 16-byte loads per 64 windows
             const bool want = st == SS_IDLE || st == SS_DONE;
             const uint64_t m = next < end ? __ballot(want) : 0ull;   // (nothing left to draw: the finished lanes keep their results for the end)
@@ -1128,11 +1131,15 @@ __global__ __launch_bounds__(256, 4) void query_stream2_kernel(DevIndex ix, cons
                     rf_lo = rf_hi = rr_lo = rr_hi = 0;
                     first_dead = false;
                     widx = n - 1u;
-                    load_kmer();
-                    fresh();
+                    st = SS_FRESH_PLAIN;
                 }
                 next += static_cast<uint64_t>(__popcll(m));
             }
+        }
+        if (st == SS_FRESH_CERT || st == SS_FRESH_PLAIN) {
+            const bool with_cert = st == SS_FRESH_CERT;
+            load_kmer();
+            fresh(with_cert);
         }
         if (!__any(st != SS_IDLE && st != SS_DONE)) break;
         // ---- this round's reads ----
