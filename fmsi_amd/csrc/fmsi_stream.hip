@@ -676,7 +676,7 @@ __global__ __launch_bounds__(256) void query_stream_kernel(DevIndex ix, const ui
 // Control flow -- tasks of <= 64 windows, pass 0 on one strand, pass 1 over the undecided windows of the other, the reverse-complement
 // probe of the task's last window -- is the kernel's above, and so are the answers (tests/test_gpu_stream.py: stream2 == stream == runs).
 // ORDERS (`lookup -S`) and 33 <= k <= 64 stay with the kernel above.
-constexpr uint32_t kStreamNoCert = 1u << 30, kStreamCertPlain = 1u << 31;   // internal bits of the kernel's flags word (FMSI_HIP_STREAM_CERT=0 / 1: measurements)
+constexpr uint32_t kStreamNoCert = 1u << 30, kStreamCertPlain = 1u << 31, kStreamUtil = 1u << 29;   // internal bits of the kernel's flags word (FMSI_HIP_STREAM_CERT=0 / 1: measurements)
 constexpr uint32_t kSRows = 192;
 constexpr uint32_t kSDwords = 32;
 constexpr uint32_t kSPitch = 9;   // uint4 per staged line in LDS: 144 bytes
@@ -870,6 +870,7 @@ __global__ __launch_bounds__(256, 4) void query_stream2_kernel(DevIndex ix, cons
     uint32_t scan_i = 0, scan_j = 0;
     int t = 0;
     StreamCounters cn;
+    uint32_t util_rounds = 0, util_busy = 0;
 
     auto kmer_base = [&](int tt) -> uint32_t {   // base tt of the current window's k-mer on the current strand
         if (WIDE) return !cur_rc ? task_base(s0, s1, s2, s3, widx + static_cast<uint32_t>(tt))
@@ -1142,6 +1143,10 @@ __global__ __launch_bounds__(256, 4) void query_stream2_kernel(DevIndex ix, cons
             fresh(with_cert);
         }
         if (!__any(st != SS_IDLE && st != SS_DONE)) break;
+        if (COUNT && (flags & kStreamUtil)) {   // (FMSI_HIP_STREAM_UTIL: lane-rounds of the wave and the busy ones among them, in counters 6 and 7)
+            util_rounds++;
+            util_busy += (st != SS_IDLE && st != SS_DONE) ? 1u : 0u;
+        }
         // ---- this round's reads ----
         const bool lk = PTABLE && (st == SS_LOOKUP || st == SS_CERT);
         const bool need_line = st == SS_LF || st == SS_HAVE || st == SS_EXTLF;
@@ -1311,6 +1316,17 @@ __global__ __launch_bounds__(256, 4) void query_stream2_kernel(DevIndex ix, cons
         __builtin_amdgcn_wave_barrier();   // (the next round's staging must not overtake this round's reads of the lines)
     }
     if (st == SS_DONE) flush_task();
+    if (COUNT && (flags & kStreamUtil)) {
+        uint32_t x = util_busy, y = util_rounds;
+        for (int off = 32; off > 0; off >>= 1) {
+            x += __shfl_down(x, off, 64);
+            y += __shfl_down(y, off, 64);
+        }
+        if ((threadIdx.x & 63) == 0) {
+            atomicAdd(&counters[6], static_cast<unsigned long long>(y));
+            atomicAdd(&counters[7], static_cast<unsigned long long>(x));
+        }
+    }
     if (COUNT) {
         uint32_t v[6] = {cn.lf_steps, cn.blocks, cn.probes, cn.searches, cn.lookups, cn.klcp_words};
 #pragma unroll
@@ -1332,7 +1348,9 @@ void launch_stream2(fmsi_hip_index* idx, const TaskRec* recs, uint64_t n_tasks, 
     const uint64_t waves = (n_tasks + chunk - 1) / chunk;
     const uint32_t blocks = static_cast<uint32_t>((waves + 3) / 4);
     static const char* cert_env = std::getenv("FMSI_HIP_STREAM_CERT");   // (measurements: 0 = no certificates, 1 = always at offset 0)
-    flags &= ~(kStreamNoCert | kStreamCertPlain);
+    flags &= ~(kStreamNoCert | kStreamCertPlain | kStreamUtil);
+    static const char* util_env = std::getenv("FMSI_HIP_STREAM_UTIL");   // (measurements: counters 6 / 7 = lane-rounds / busy lane-rounds)
+    if (util_env) flags |= kStreamUtil;
     if (cert_env && cert_env[0] == '0') flags |= kStreamNoCert;
     if (cert_env && cert_env[0] == '1') flags |= kStreamCertPlain;
     if (uni)

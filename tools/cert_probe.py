@@ -46,7 +46,8 @@ if len(sys.argv) > 1 and sys.argv[1] == "--child":
             torch.cuda.synchronize()
             nl, ms = idx.profile_read(reset=True); idx.profile(False)
             print(f"  {name:34s} {fname:14s} {ms / nl:7.3f} ms  {nw / (ms / nl) / 1e6:6.1f} G windows/s   per window: table requests {c[4] / nw:.3f}  LF steps {c[0] / nw:.3f}  "
-                  f"lines {(c[1] - c[4]) / nw:.3f}  searches {c[3] / nw:.3f}", flush=True)
+                  f"lines {(c[1] - c[4]) / nw:.3f}  searches {c[3] / nw:.3f}" +
+                  (f"  rounds per 64 windows {c[6] / nw:.1f}, busy lanes {c[7] / max(c[6], 1):.2f}" if os.environ.get("FMSI_HIP_STREAM_UTIL") else ""), flush=True)
     sys.exit(0)
 
 n = sys.argv[1] if len(sys.argv) > 1 else "4e8"
