@@ -776,7 +776,7 @@ def run_leg(args):
     args.stream_via = "klcp" if klcp_only else "runs"
     args.accel = "tables" if klcp_only else "dict"   # (the legs say themselves which structures their handle keeps)
     if klcp_only:
-        args.prefix_len = 16   # (the kLCP kernel's fresh searches start from its 16-deep prefix table, as in the earlier rounds' runs)
+        args.prefix_len = int(os.environ.get("FMSI_BENCH_KLCP_TABLE", "16"))   # (the kLCP kernel's fresh searches and certificates: its 16-deep prefix table)
     c = open_ctx(args)
     k = args.k
     resolve_accelerators(args, n, k, stream_mode)

@@ -1352,6 +1352,10 @@ void launch_stream2(fmsi_hip_index* idx, const TaskRec* recs, uint64_t n_tasks, 
     static const char* util_env = std::getenv("FMSI_HIP_STREAM_UTIL");   // (measurements: counters 6 / 7 = lane-rounds / busy lane-rounds)
     if (util_env) flags |= kStreamUtil;
     if (cert_env && cert_env[0] == '0') flags |= kStreamNoCert;
+    // A certificate can only come from an entry that is empty or carries signatures (<= 3 rows): with n / 4^t rows per key on average that is
+    // nearly every entry at 0.65 (t = 16 at human scale), 73 % at 2.6 (t = 15), a quarter at 5 -- and one in a thousand at 10 (the CLI's
+    // 14-deep table), where a certificate is a wasted request per failed window.  Break-even (a success spares a dozen requests) is near 7.5.
+    if (PTABLE && !cert_env && static_cast<double>(idx->n) > 7.0 * static_cast<double>(1ull << (2u * idx->dev.ptable_len))) flags |= kStreamNoCert;
     if (cert_env && cert_env[0] == '1') flags |= kStreamCertPlain;
     if (uni)
         hipLaunchKernelGGL((query_stream2_kernel<COUNT, PTABLE, true, WIDE, ORD>), dim3(blocks), dim3(256), 0, s, idx->dev,
