@@ -814,6 +814,18 @@ extern "C" int fmsi_cli_query(int argc, char** argv, int output_orders_i) {
     int t = std::min(k, want_dict ? 12 : (opt.full_tables ? 16 : 14));
     if (const char* e = std::getenv("FMSI_HIP_CLI_TABLE_DEPTH")) t = std::min(k, std::max(0, std::atoi(e)));   // (measurements)
     while (t > 0 && (1ull << (2 * t)) > 4 * index_rows) --t;
+    // Which kernel walks the reads.  -S asks for the kLCP array; WITHOUT -S the reference searches every window afresh -- but the interval a
+    // streamed step reaches is the interval the fresh search finds (src/fms_index.h:106-115), so when the index HAS its .klcp file the windows
+    // can be streamed all the same: identical per-strand answers (the predictor's replay below stays the mode's own), one block read per window
+    // of a read that follows the text instead of k - t LF steps (human scale, 997 M windows: device stage 0.21 -> 0.03 s for the default mode,
+    // 0.27 -> 0.06 s for -O).  `--tables auto` does so; FMSI_HIP_CLI_STREAM=0 keeps the searches (A/B runs).
+    static const char* stream_env = std::getenv("FMSI_HIP_CLI_STREAM");
+    const bool stream_without_S = !opt.has_klcp && klcp_file && !general && !opt.tables_given && k <= 64 && !(stream_env && stream_env[0] == '0');
+    const bool stream_kernel = load_klcp || stream_without_S;
+    // ... and the streaming kernel's absence certificates need table keys of few rows (fmsi_stream.hip: off above 7 rows per key): one level
+    // more than the default where that decides it (human scale: 15 -- 2.6 rows per key, 8.6 GB -- instead of 14)
+    if (stream_kernel && !std::getenv("FMSI_HIP_CLI_TABLE_DEPTH") && !opt.tables_given)
+        while (t >= 14 && t < 16 && t < k && static_cast<double>(index_rows) > 7.0 * static_cast<double>(1ull << (2 * t)) && (1ull << (2 * (t + 1))) <= 4 * index_rows) ++t;
 
     // ---- one replicated handle per device (the index is read-only, the batches are independent) ---------------
     struct DeviceCtx {
@@ -860,7 +872,7 @@ extern "C" int fmsi_cli_query(int argc, char** argv, int output_orders_i) {
     auto setup = [&](DeviceCtx& c, bool first) -> bool {
         int rc_create = FMSI_HIP_ENOMEM;
         for (;;) {
-            rc_create = fmsi_hip_index_load(opt.index_prefix.c_str(), load_klcp, c.device, std::max(t, 0), &c.dev);
+            rc_create = fmsi_hip_index_load(opt.index_prefix.c_str(), stream_kernel, c.device, std::max(t, 0), &c.dev);
             if (rc_create != FMSI_HIP_ENOMEM || t <= 0 || !first) break;
             std::cerr << "WARNING: not enough device memory for a prefix table of depth " << t << ", trying " << std::max(t - 2, 0) << std::endl;
             t = std::max(t - 2, 0);
@@ -882,7 +894,7 @@ extern "C" int fmsi_cli_query(int argc, char** argv, int output_orders_i) {
             if (!c.have_dict)
                 std::cerr << "WARNING: the k-mer dictionary is off on device " << c.device << " (" << fmsi_hip_last_error() << "); results are unaffected" << std::endl;
         }
-        if (!load_klcp && !general && !c.have_dict && !wide && fmsi_hip_index_enable_pair_layout(c.dev) != 0) {
+        if (!stream_kernel && !general && !c.have_dict && !wide && fmsi_hip_index_enable_pair_layout(c.dev) != 0) {
             c.error = fmsi_hip_last_error();
             return false;
         }
@@ -1072,7 +1084,7 @@ extern "C" int fmsi_cli_query(int argc, char** argv, int output_orders_i) {
                             check(fmsi_hip_query_runs_fn(cp->dev, P->packed.data(), P->lower.empty() ? nullptr : P->lower.data(), P->bases, P->run_start.data(), P->run_windows.data(), P->run_start.size(), nw, k,
                                                          opt.fn, opt.fn_r, opt.fn_s, FMSI_HIP_OUT_BITS, dst, nullptr, nullptr),
                                   "fmsi_hip_query_runs_fn");
-                        else if (opt.has_klcp && !cp->have_dict && !bg_dict && !rows64)   // -S: kLCP streaming kernel (query_kmers_streaming, src/fms_index.h:181-254)
+                        else if (stream_kernel && !cp->have_dict && !bg_dict && !rows64)   // -S: kLCP streaming kernel (query_kmers_streaming, src/fms_index.h:181-254)
                             check(fmsi_hip_query_stream(handle, P->packed.data(), P->bases, P->run_start.data(), P->run_windows.data(),
                                                         P->run_start.size(), nw, k, flags, dst, nullptr, nullptr),
                                   "fmsi_hip_query_stream");
