@@ -147,8 +147,10 @@ int usage_query(bool lookup) {
     std::cerr << "  --threads INT - host threads for packing and formatting [default: available CPUs, at most 16]" << std::endl;
     std::cerr << "  --stats      - print timings to stderr" << std::endl;
     std::cerr << "  --tables auto|background|full|compact|candidates - device-side accelerators (results unaffected).  auto [default]: a prefix" << std::endl;
-    std::cerr << "                 table of up to 14 bases, which keeps the device about level with this program's reader and loads fastest" << std::endl;
-    std::cerr << "                 (query files of 8 GB and more get `background`); background: the same, and the k-mer dictionary is built" << std::endl;
+    std::cerr << "                 table of up to 14 bases (15 where that makes the streaming kernel's shortcuts possible), which keeps the device" << std::endl;
+    std::cerr << "                 ahead of this program's reader and loads fastest; an index with its kLCP file streams its windows with or" << std::endl;
+    std::cerr << "                 without -S -- the answers are the same (query files of 8 GB and more get `background`); background: the same," << std::endl;
+    std::cerr << "                 and the k-mer dictionary is built" << std::endl;
     std::cerr << "                 beside the first batches, which the LF walk answers -- every batch after it stands goes to the dictionary;" << std::endl;
     std::cerr << "                 full: the dictionary before the first batch -- one 128-byte read per k-mer, about 13 bytes of HBM per" << std::endl;
     std::cerr << "                 distinct k-mer, the fastest device path for isolated k-mers (also for -S); compact: the super-k-mer" << std::endl;
