@@ -15,6 +15,13 @@
 // costs ONE block read + ONE kLCP word instead of k block reads.  Tasks are staged by a preparation kernel as
 // 64-byte records (128 bases of sequence + output index), prefetched one iteration ahead and handed out with
 // ballot + mbcnt prefix ranks.
+//
+// Two kernels live here.  query_stream_kernel (rounds 1-2, the text above: 64-byte blocks + separate kLCP words) is kept for A/B runs
+// (FMSI_HIP_KERNEL_REFILL / FMSI_HIP_STREAM_V1) and for a handle without the room for the S-block layout.  query_stream2_kernel (round 3:
+// 128-byte S-blocks that carry the kLCP plane, lines fetched cooperatively through LDS; round 4: ABSENCE CERTIFICATES -- a fresh search that
+// follows a failed window first asks the prefix table for a (t + 4)-mer that the next k - t - 4 windows share, and a string the text does
+// not hold settles them all with one request -- the strand probe on the task's first window, `lookup -S` (ORD) and 33 <= k <= 64 (WIDE)
+// as instantiations) is what fmsi_hip_query_stream runs, and what the `fmsi` binary runs for every read when the index has its kLCP file.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -658,7 +665,7 @@ __global__ __launch_bounds__(256) void query_stream_kernel(DevIndex ix, const ui
 }
 
 // ======================================================================================================================
-// Round 3: the streaming kernel for k <= 32 presence queries over a layout of its own ("S-blocks").
+// Round 3: the streaming kernel over a layout of its own ("S-blocks"); round 4: certificates, orders, k up to 64 (further down).
 //
 // What bound the kernel above (SQ counters + tools/gather_bench): a streamed window cost its lane FOUR 16-byte loads
 // of its own 64-byte block plus one or two 8-byte kLCP words -- the memory path charges per load instruction and distinct line, so
@@ -675,7 +682,6 @@ __global__ __launch_bounds__(256) void query_stream_kernel(DevIndex ix, const ui
 //   * a task's results live in registers (two bit planes per strand) and leave as one 64-byte line per task.
 // Control flow -- tasks of <= 64 windows, pass 0 on one strand, pass 1 over the undecided windows of the other, the reverse-complement
 // probe of the task's last window -- is the kernel's above, and so are the answers (tests/test_gpu_stream.py: stream2 == stream == runs).
-// ORDERS (`lookup -S`) and 33 <= k <= 64 stay with the kernel above.
 constexpr uint32_t kStreamNoCert = 1u << 30, kStreamCertPlain = 1u << 31, kStreamUtil = 1u << 29;   // internal bits of the kernel's flags word (FMSI_HIP_STREAM_CERT=0 / 1: measurements)
 constexpr uint32_t kSRows = 192;
 constexpr uint32_t kSDwords = 32;
