@@ -493,6 +493,35 @@ def test_bench_defaults():
         sys.argv = argv
 
 
+def test_bench_compact_line_of_the_final_record_keeps_every_leg():
+    """Round 4's final record has 18 legs (the kLCP kernel's `lookup -S` and k = 48 legs among them): its compact form is the committed
+    last line, every leg keeps name / value / ms / frac / hbm_frac / matches_reference, and it is what compact_line() makes of the full one."""
+    import importlib.util
+    import json
+    import sys
+    spec = importlib.util.spec_from_file_location("bench_mod3", REPO / "bench.py")
+    m = importlib.util.module_from_spec(spec)
+    argv = sys.argv
+    try:
+        sys.argv = ["bench.py"]
+        spec.loader.exec_module(m)
+    finally:
+        sys.argv = argv
+    lines = (REPO / "profiles" / "r04zzz_bench_default.json").read_text().splitlines()
+    full, last = json.loads(lines[0]), lines[-1]
+    assert len(last) <= m.COMPACT_LIMIT and m.compact_line(full) == last
+    d = json.loads(last)
+    names = [c["name"] for c in d["configs"]]
+    assert len(names) == len(full["configs"]) == 18
+    for want in ("c4_klcp", "c4_klcp_subst1pct", "c4_klcp_lookup", "c4_klcp_lookup_fast", "c4_klcp_k48", "c4_superkmer", "c3_superkmer", "e2e_or", "e2e_all_S"):
+        assert want in names, want
+    for c in d["configs"]:
+        assert c["matches_reference"] is True and c["value"] > 0 and c["ms"] > 0, c
+        if c["name"].startswith("c4_") or c["name"].startswith("c3") or c["name"].startswith("c5"):
+            assert 0 < c["frac"] < 1 and 0 < c["hbm_frac"] < 1, c
+    assert d["roofline"]["kernel"].startswith("sk_kmers_kernel") and len(d["roofline"]["lf_path"]) == 3 and d["cpu_baseline"]["kind"] == "reference"
+
+
 def test_bench_compact_line_fits_the_drivers_tail():
     """The driver keeps the last 8 KB of bench.py's stdout and parses the LAST line (round 3's 28-KB line was cut: `parsed: null`).
     bench.compact_line() of round 3's full record -- 13 legs -- and of the same record with twice the legs must stay below 4 KB, be valid
