@@ -823,7 +823,7 @@ extern "C" int fmsi_cli_query(int argc, char** argv, int output_orders_i) {
     // 0.27 -> 0.06 s for -O).  `--tables auto` does so; FMSI_HIP_CLI_STREAM=0 keeps the searches (A/B runs).
     static const char* stream_env = std::getenv("FMSI_HIP_CLI_STREAM");
     const bool stream_without_S = !opt.has_klcp && klcp_file && !general && !opt.tables_given && k <= 64 && !(stream_env && stream_env[0] == '0');
-    const bool stream_kernel = load_klcp || stream_without_S;
+    bool stream_kernel = load_klcp || stream_without_S;   // (without -S: only as long as the kLCP file loads -- the reference would never open it)
     // ... and the streaming kernel's absence certificates need table keys of few rows (fmsi_stream.hip: off above 7 rows per key): one level
     // more than the default where that decides it (human scale: 15 -- 2.6 rows per key, 8.6 GB -- instead of 14)
     if (stream_kernel && !std::getenv("FMSI_HIP_CLI_TABLE_DEPTH") && !opt.tables_given)
@@ -875,6 +875,11 @@ extern "C" int fmsi_cli_query(int argc, char** argv, int output_orders_i) {
         int rc_create = FMSI_HIP_ENOMEM;
         for (;;) {
             rc_create = fmsi_hip_index_load(opt.index_prefix.c_str(), stream_kernel, c.device, std::max(t, 0), &c.dev);
+            if (rc_create != 0 && rc_create != FMSI_HIP_ENOMEM && first && stream_kernel && !load_klcp) {
+                // a kLCP file that does not load must not fail a run that never asked for it: the searches of round 3 answer instead
+                stream_kernel = false;
+                continue;
+            }
             if (rc_create != FMSI_HIP_ENOMEM || t <= 0 || !first) break;
             std::cerr << "WARNING: not enough device memory for a prefix table of depth " << t << ", trying " << std::max(t - 2, 0) << std::endl;
             t = std::max(t - 2, 0);

@@ -150,6 +150,38 @@ def test_cli_equals_reference_golden(fm, name, kind, mode):
     assert out == golden_out(name, kind, mode)
 
 
+@pytest.mark.parametrize("name", ["sars_k31", "sars_k13", "repeats_k40"])
+def test_cli_streams_without_S_and_survives_a_bad_klcp_file(fm, tmp_path, monkeypatch, name):
+    """Since round 4 `fmsi query` / `lookup` WITHOUT -S stream their windows through the kLCP kernel when the index has its .klcp file
+    (the interval a streamed step reaches is the fresh search's: src/fms_index.h:106-115) -- the bytes stay the reference's, with the
+    streaming on (default), off (FMSI_HIP_CLI_STREAM=0), and with a .klcp file that does not load: the reference never opens that file
+    without -S, so such a run must answer all the same (by the searches), while -S on it fails."""
+    import shutil
+    k, kinds = CLI_DATASETS[name]
+    kind = kinds[0]
+    q = str(query_file(name, kind))
+    for mode in ("or", "all", "lookup"):
+        want = golden_out(name, kind, mode)
+        for env in (None, "0"):
+            if env is None:
+                monkeypatch.delenv("FMSI_HIP_CLI_STREAM", raising=False)
+            else:
+                monkeypatch.setenv("FMSI_HIP_CLI_STREAM", env)
+            rc, out, err = fm.run_cli([*MODES[mode][0], "--stats", "-k", str(k), "-q", q, index_prefix(name)])
+            assert rc == 0 and out == want, (mode, env, err.decode()[-300:])
+    monkeypatch.delenv("FMSI_HIP_CLI_STREAM", raising=False)
+    bad = str(tmp_path / "bad")
+    for part in ("ac_gt", "ac", "gt", "mask", "klcp", "misc"):
+        shutil.copy(f"{index_prefix(name)}.fmsi.{part}", f"{bad}.fmsi.{part}")
+    with open(f"{bad}.fmsi.klcp", "r+b") as f:
+        f.truncate(9)
+    for mode in ("or", "all", "lookup"):
+        rc, out, err = fm.run_cli([*MODES[mode][0], "-k", str(k), "-q", q, bad])
+        assert rc == 0 and out == golden_out(name, kind, mode), (mode, err.decode()[-300:])
+    rc, out, err = fm.run_cli(["query", "-S", "-k", str(k), "-q", q, bad])
+    assert rc != 0
+
+
 @pytest.mark.parametrize("name,kind,mode,tables", [(*c, t) for c in CASES for t in ("full", "compact", "candidates", "background")
                                                    if c[2] in ("or", "all") or (t in ("full", "compact", "background") and c[2] in ("or_S", "all_S"))])
 def test_cli_with_full_tables_equals_reference_golden(fm, name, kind, mode, tables):
