@@ -24,6 +24,9 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <atomic>
+#include <cerrno>
+#include <mutex>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -270,6 +273,10 @@ struct DevBuf {
     }
     template <class T>
     T* as() { return static_cast<T*>(p); }
+    void drop() {
+        if (p) (void)dev_free(p);
+        p = nullptr;
+    }
     void* release() {
         void* q = p;
         p = nullptr;
@@ -1288,29 +1295,113 @@ int fmsi_hip_index_download_text(const fmsi_hip_index* idx, uint64_t* words) {
 namespace fmsi {
 namespace {
 
-struct Mapped {
+struct Mapped {   // a file of the index: mapped for its headers (a few pages are ever touched), open for the payload's reads (upload_files)
     const uint8_t* data = nullptr;
     size_t size = 0;
+    int fd = -1;
     ~Mapped() {
         if (data) munmap(const_cast<uint8_t*>(data), size);
+        if (fd >= 0) ::close(fd);
     }
     bool open_file(const std::string& path) {
-        const int fd = ::open(path.c_str(), O_RDONLY);
+        fd = ::open(path.c_str(), O_RDONLY);
         if (fd < 0) return false;
         struct stat st;
         bool ok = fstat(fd, &st) == 0 && st.st_size > 0;
         if (ok) {
-            void* p = mmap(nullptr, static_cast<size_t>(st.st_size), PROT_READ, MAP_PRIVATE | MAP_POPULATE, fd, 0);
+            void* p = mmap(nullptr, static_cast<size_t>(st.st_size), PROT_READ, MAP_PRIVATE, fd, 0);
             ok = p != MAP_FAILED;
             if (ok) {
                 data = static_cast<const uint8_t*>(p);
                 size = static_cast<size_t>(st.st_size);
             }
         }
-        ::close(fd);
         return ok;
     }
 };
+
+// The payloads' way into HBM.  One hipMemcpy from the mapping moves 11 GB/s -- the runtime stages pageable memory through one buffer on
+// one thread, which also takes the mapping's page faults --, a third of the whole load at human scale (1.4 GB: 0.13 s).  Here a few
+// threads read() pieces of the files into page-locked slots of their own (no mapping, no faults: the page cache's pages are copied once)
+// and enqueue each piece's copy; a slot is reused when its copy is done.  The link's rate, not one core's (tools/micro/upload_bench.hip:
+// 16 threads read 1.4 GB in 0.024 s, the link moves it in 0.028 s).  All copies go to the default stream: a stream of its own per thread
+// cost more than the whole upload (hipStreamCreate: 20 ms, 150 ms the first time on a box).
+struct UploadJob {
+    int fd;
+    uint64_t file_off;
+    char* dst;   // device
+    uint64_t bytes;
+};
+int upload_files(const std::vector<UploadJob>& jobs, int device) {
+    constexpr uint64_t kPiece = 4ull << 20;
+    struct Piece {
+        const UploadJob* job;
+        uint64_t off, len;
+    };
+    std::vector<Piece> pieces;
+    for (const UploadJob& j : jobs)
+        for (uint64_t o = 0; o < j.bytes; o += kPiece) pieces.push_back({&j, o, std::min(kPiece, j.bytes - o)});
+    if (pieces.empty()) return 0;
+    const unsigned threads = static_cast<unsigned>(std::max<size_t>(1, std::min<size_t>({8u, std::max(1u, std::thread::hardware_concurrency()), pieces.size()})));
+    std::atomic<size_t> next{0};
+    std::atomic<int> failed{0};
+    std::string first_error;
+    std::mutex err_m;
+    auto fail = [&](const std::string& what) {
+        std::lock_guard<std::mutex> lk(err_m);
+        if (!failed.exchange(1)) first_error = what;
+    };
+    auto work = [&] {
+        if (hipSetDevice(device) != hipSuccess) return fail("hipSetDevice failed in an upload thread");
+        const hipStream_t stream = nullptr;
+        void* slot[2] = {nullptr, nullptr};
+        hipEvent_t done[2] = {nullptr, nullptr};
+        bool busy[2] = {false, false};
+        bool ok = true;
+        for (int i = 0; ok && i < 2; ++i)
+            ok = hipHostMalloc(&slot[i], kPiece, hipHostMallocDefault) == hipSuccess && hipEventCreateWithFlags(&done[i], hipEventDisableTiming) == hipSuccess;
+        if (!ok) fail("page-locked staging for the index upload could not be set up");
+        unsigned turn = 0;
+        for (size_t i; ok && !failed.load() && (i = next.fetch_add(1)) < pieces.size(); turn ^= 1u) {
+            const Piece& pc = pieces[i];
+            if (busy[turn] && hipEventSynchronize(done[turn]) != hipSuccess) {
+                fail("hipEventSynchronize failed in the index upload");
+                break;
+            }
+            uint64_t got = 0;
+            while (got < pc.len) {
+                const ssize_t r = pread(pc.job->fd, static_cast<char*>(slot[turn]) + got, pc.len - got, static_cast<off_t>(pc.job->file_off + pc.off + got));
+                if (r < 0 && errno == EINTR) continue;
+                if (r <= 0) break;
+                got += static_cast<uint64_t>(r);
+            }
+            if (got != pc.len) {
+                fail("short read of an index file");
+                break;
+            }
+            if (hipMemcpyAsync(pc.job->dst + pc.off, slot[turn], pc.len, hipMemcpyHostToDevice, stream) != hipSuccess || hipEventRecord(done[turn], stream) != hipSuccess) {
+                fail("hipMemcpyAsync failed in the index upload");
+                break;
+            }
+            busy[turn] = true;
+        }
+        for (int i = 0; i < 2; ++i) {
+            if (busy[i] && hipEventSynchronize(done[i]) != hipSuccess) fail("index upload: hipEventSynchronize failed");
+            if (done[i]) (void)hipEventDestroy(done[i]);
+            if (slot[i]) (void)hipHostFree(slot[i]);
+        }
+    };
+    std::vector<std::thread> pool;
+    for (unsigned t = 1; t < threads; ++t) pool.emplace_back(work);
+    work();
+    for (std::thread& th : pool) th.join();
+    if (failed.load()) {
+        (void)hipGetLastError();
+        set_last_error(first_error);
+        return first_error.rfind("short read", 0) == 0 ? FMSI_HIP_EIO : FMSI_HIP_EHIP;
+    }
+    return 0;
+}
 
 struct Span {   // a run of u64 words inside a mapped file
     const uint8_t* p = nullptr;
@@ -1489,7 +1580,9 @@ int load_fail(int code, const std::string& msg) {
 }  // namespace
 }  // namespace fmsi
 
-extern "C" int fmsi_hip_index_load(const char* prefix_c, int use_klcp, int device, int prefix_len, fmsi_hip_index** out) {
+extern "C" int fmsi_hip_index_load(const char* prefix_c, int load_flags, int device, int prefix_len, fmsi_hip_index** out) {
+    const int use_klcp = load_flags & FMSI_HIP_LOAD_KLCP;
+    const bool async_table = (load_flags & FMSI_HIP_LOAD_ASYNC_TABLE) != 0;
     ::fmsi::ScratchScope scratch_scope_(device);   // (devpool.h: the outermost builder returns the block cache to the driver)
     if (!prefix_c || !out) return load_fail(FMSI_HIP_EINVAL, "null argument");
     TraceRange trace_range("fmsi: load index files into HBM");
@@ -1558,21 +1651,52 @@ extern "C" int fmsi_hip_index_load(const char* prefix_c, int use_klcp, int devic
     if (rc) return rc;
     FMSI_HIP_ON_DEVICE(device);
     clock.mark("device selected (HIP init)");
+    // FMSI_HIP_LOAD_ASYNC_TABLE: the stream the table's signatures will be written on is created beside the upload (creating a stream
+    // takes 20 ms, 150 ms the first time on a box: tools/micro/upload_bench.hip)
+    hipStream_t bg_stream = nullptr;
+    std::thread bg_stream_maker;
+    if (async_table && prefix_len > 0)
+        bg_stream_maker = std::thread([&bg_stream, device] {
+            if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&bg_stream, hipStreamNonBlocking) != hipSuccess) {
+                (void)hipGetLastError();
+                bg_stream = nullptr;
+            }
+        });
+    struct JoinMaker {
+        std::thread& t;
+        hipStream_t& s;
+        bool handed_over = false;
+        ~JoinMaker() {
+            if (t.joinable()) t.join();
+            if (s && !handed_over) (void)hipStreamDestroy(s);
+        }
+    } join_maker{bg_stream_maker, bg_stream};
 
     // ---- payloads to the device (two zero words of padding behind each) -----------------------------------------------------
     const uint64_t n_words = (n + 63) >> 6, n_blocks = ((n + kBlockRows - 1) >> kBlockRowsLog2) + 1;
     DevBuf d_acgt, d_ac, d_gt, d_bt, d_btnr, d_btnrp, d_invert, d_binom, d_space, d_mask, d_gtoff, d_pc, d_corrupt, d_klcp;
-    auto upload = [&](DevBuf& b, const Span& s) -> int {
+    std::vector<UploadJob> jobs;
+    auto upload = [&](DevBuf& b, const Span& s, const Mapped& f) -> int {
         int r = b.alloc((s.words + 2) * 8);
         if (r) return r;
         FMSI_HIP_TRY(hipMemsetAsync(static_cast<char*>(b.p) + s.words * 8, 0, 16, 0));
-        if (s.words) FMSI_HIP_TRY(hipMemcpyAsync(b.p, s.p, s.words * 8, hipMemcpyHostToDevice, 0));
+        if (s.words) jobs.push_back({f.fd, static_cast<uint64_t>(s.p - f.data), static_cast<char*>(b.p), s.words * 8});
         return 0;
     };
-    if ((rc = upload(d_bt, bt)) || (rc = upload(d_btnr, btnr)) || (rc = upload(d_btnrp, btnrp)) || (rc = upload(d_invert, invert)) || (rc = upload(d_acgt, acgt)) ||
-        (rc = upload(d_ac, ac)) || (rc = upload(d_gt, gt)))
+    if ((rc = upload(d_bt, bt, f_mask)) || (rc = upload(d_btnr, btnr, f_mask)) || (rc = upload(d_btnrp, btnrp, f_mask)) || (rc = upload(d_invert, invert, f_mask)) ||
+        (rc = upload(d_acgt, acgt, f_acgt)) || (rc = upload(d_ac, ac, f_ac)) || (rc = upload(d_gt, gt, f_gt)))
         return rc;
-    if (with_klcp && (rc = upload(d_klcp, klcp))) return rc;
+    if (with_klcp && (rc = upload(d_klcp, klcp, f_klcp))) return rc;
+    clock.mark("device buffers, first fill");
+    if (std::getenv("FMSI_HIP_LOAD_SERIAL_UPLOAD")) {   // (A/B runs: one copy per part straight from the mapping, as rounds 2-4 did)
+        for (const UploadJob& j : jobs) {
+            const Mapped* f = j.fd == f_mask.fd ? &f_mask : j.fd == f_acgt.fd ? &f_acgt : j.fd == f_ac.fd ? &f_ac : j.fd == f_gt.fd ? &f_gt : &f_klcp;
+            FMSI_HIP_TRY(hipMemcpyAsync(j.dst, f->data + j.file_off, j.bytes, hipMemcpyHostToDevice, 0));
+        }
+    } else if ((rc = upload_files(jobs, device))) {
+        return rc;
+    }
+    clock.mark("payloads read and copied");
     std::vector<uint64_t> h_binom(64 * 64);
     uint8_t h_space[64];
     rrr_tables(h_binom.data(), h_space);
@@ -1584,7 +1708,7 @@ extern "C" int fmsi_hip_index_load(const char* prefix_c, int use_klcp, int devic
     FMSI_HIP_TRY(hipMemsetAsync(d_corrupt.p, 0, 4, 0));
     FMSI_HIP_TRY(hipMemsetAsync(d_pc.p, 0, (n_words + 1) * 4, 0));
 
-    clock.mark("payloads uploaded");
+    clock.mark("small tables, work buffers");
     // ---- mask: RRR-63 -> plain words ---------------------------------------------------------------------------------------------
     {
         const uint64_t waves = (n_rrr_blocks + 63) / 64;
@@ -1593,6 +1717,7 @@ extern "C" int fmsi_hip_index_load(const char* prefix_c, int use_klcp, int devic
                            n_rrr_blocks, n_super, d_mask.as<uint64_t>(), n_words, d_corrupt.as<uint32_t>());
         FMSI_HIP_TRY(hipGetLastError());
     }
+    clock.mark("mask decoded (first kernel of this module)");
     // ---- where every word's G/T bits start in `gt` --------------------------------------------------------------------------------
     hipLaunchKernelGGL(word_popcount_kernel, dim3(grid_for(n_words)), dim3(256), 0, 0, d_acgt.as<uint64_t>(), n_words, n, d_pc.as<uint32_t>());
     FMSI_HIP_TRY(hipGetLastError());
@@ -1610,6 +1735,7 @@ extern "C" int fmsi_hip_index_load(const char* prefix_c, int use_klcp, int devic
         if (gt_total != gt.bits || n - gt_total != ac.bits)
             return load_fail(FMSI_HIP_EIO, "index not correctly loaded: popcount(ac_gt) != |gt| (" + base + ".ac_gt / .ac / .gt are not one index's)");
     }
+    clock.mark("word offsets (scan)");
     // ---- the blocks -----------------------------------------------------------------------------------------------------------------
     DevBuf blocks, cnts, cnts_scanned, mcounts, mrank;
     const size_t blocks_bytes = n_blocks * kBlockBytes;
@@ -1643,7 +1769,7 @@ extern "C" int fmsi_hip_index_load(const char* prefix_c, int use_klcp, int devic
             static_cast<uint64_t>(totals.a) + totals.c + totals.g != counts[3])
             return load_fail(FMSI_HIP_EIO, "index not correctly loaded: " + base + ".misc's counts are not those of the bit-vectors");
     }
-    clock.mark("mask decoded, blocks laid out");
+    clock.mark("blocks laid out");
     auto* idx = new fmsi_hip_index();
     idx->device = device;
     idx->n = n;
@@ -1674,11 +1800,28 @@ extern "C" int fmsi_hip_index_load(const char* prefix_c, int use_klcp, int devic
     idx->dev.C3 = static_cast<uint32_t>(counts[3]);
     for (int c = 0; c < 4; ++c) idx->counts64[c] = counts[c];
     idx->dollar64 = dollar;
-    if (prefix_len > 0 && (rc = build_prefix_table(idx, prefix_len))) {
+    // the temporaries go before the table (a freed block is waited for, devpool.hip: behind the signature pass that would be the whole pass)
+    for (DevBuf* b : {&d_acgt, &d_ac, &d_gt, &d_bt, &d_btnr, &d_btnrp, &d_invert, &d_binom, &d_space, &d_mask, &d_gtoff, &d_pc, &d_corrupt, &scan_temp, &cnts,
+                      &cnts_scanned, &mcounts})
+        b->drop();
+    if (async_table && prefix_len > 0) {
+        // ... and so does whatever else would wait for the device on the handle's first query: the streaming layout
+        if (with_klcp) (void)fmsi_hip_index_enable_stream_layout(idx);
+        if (bg_stream_maker.joinable()) bg_stream_maker.join();
+        idx->bg_stream = bg_stream;
+        join_maker.handed_over = true;
+        clock.mark("temporaries freed, streaming layout");
+    }
+    if (prefix_len > 0 && (rc = build_prefix_table(idx, prefix_len, async_table && !clock.on))) {
         fmsi_hip_index_destroy(idx);
         return rc;
     }
     clock.mark("prefix table");
     *out = idx;
     return 0;
+}
+
+extern "C" int fmsi_hip_index_wait_background(fmsi_hip_index* idx) {
+    if (!idx) return FMSI_HIP_EINVAL;
+    return ::fmsi::wait_background(idx);
 }

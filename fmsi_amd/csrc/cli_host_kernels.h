@@ -98,6 +98,51 @@ inline int64_t valid_prefix(const char* s, int64_t n) {
     return i;
 }
 
+// One k-mer, k <= 32 characters at s -> its 2-bit word (base t in bits [2t, 2t + 1]: what fmsi_hip_query_kmers takes); false when one of the
+// k characters is not ACGTacgt.  Reads 32 bytes at s whatever k is: the caller keeps them inside its buffer.
+inline bool kmer_all_valid32(const char* s, int k) {
+    const __m128i fold = _mm_set1_epi8(static_cast<char>(0xDF));
+    const __m128i a = _mm_set1_epi8('A'), c = _mm_set1_epi8('C'), g = _mm_set1_epi8('G'), t = _mm_set1_epi8('T');
+    const __m128i v0 = _mm_and_si128(_mm_loadu_si128(reinterpret_cast<const __m128i*>(s)), fold);
+    const __m128i v1 = _mm_and_si128(_mm_loadu_si128(reinterpret_cast<const __m128i*>(s + 16)), fold);
+    const __m128i ok0 = _mm_or_si128(_mm_or_si128(_mm_cmpeq_epi8(v0, a), _mm_cmpeq_epi8(v0, c)), _mm_or_si128(_mm_cmpeq_epi8(v0, g), _mm_cmpeq_epi8(v0, t)));
+    const __m128i ok1 = _mm_or_si128(_mm_or_si128(_mm_cmpeq_epi8(v1, a), _mm_cmpeq_epi8(v1, c)), _mm_or_si128(_mm_cmpeq_epi8(v1, g), _mm_cmpeq_epi8(v1, t)));
+    const uint32_t ok = static_cast<uint32_t>(_mm_movemask_epi8(ok0)) | (static_cast<uint32_t>(_mm_movemask_epi8(ok1)) << 16);
+    const uint32_t want = k >= 32 ? 0xFFFFFFFFu : (1u << k) - 1u;
+    return (ok & want) == want;
+}
+__attribute__((target("bmi2"))) inline bool kmer_word_bmi2(const char* s, int k, uint64_t* out) {
+    if (!kmer_all_valid32(s, k)) return false;
+    uint64_t w = 0;
+    for (int q = 0; q < 4; ++q) w |= __builtin_ia32_pext_di(codes_of8(s + 8 * q), 0x0303030303030303ull) << (16 * q);
+    *out = k >= 32 ? w : w & ((1ull << (2 * k)) - 1ull);
+    return true;
+}
+inline bool kmer_word_plain(const char* s, int k, uint64_t* out) {
+    if (!kmer_all_valid32(s, k)) return false;
+    uint64_t w = 0;
+    for (int q = 0; q < 4; ++q) {
+        uint64_t x = codes_of8(s + 8 * q);
+        x = (x | (x >> 6)) & 0x000F000F000F000Full;
+        x = (x | (x >> 12)) & 0x000000FF000000FFull;
+        x = (x | (x >> 24)) & 0xFFFFull;
+        w |= x << (16 * q);
+    }
+    *out = k >= 32 ? w : w & ((1ull << (2 * k)) - 1ull);
+    return true;
+}
+// the same one character at a time (the last bytes of a buffer, where 32 bytes cannot be read)
+inline bool kmer_word_tail(const char* s, int k, uint64_t* out) {
+    uint64_t w = 0;
+    for (int j = 0; j < k; ++j) {
+        const uint8_t code = kCode.t[static_cast<unsigned char>(s[j])];
+        if (code == 4) return false;
+        w |= static_cast<uint64_t>(code) << (2 * j);
+    }
+    *out = w;
+    return true;
+}
+
 inline int fwd_of(uint8_t b) { return static_cast<int>(b & 3) - 1; }
 inline int rc_of(uint8_t b) { return static_cast<int>((b >> 2) & 3) - 1; }
 

@@ -26,6 +26,7 @@
 #include <thread>
 #include <vector>
 
+#include "cli_host_kernels.h"
 #include "fastx.h"
 
 namespace fmsi {
@@ -87,6 +88,11 @@ public:
         not_full_.notify_one();
         return true;
     }
+    void set_cap(size_t cap) {   // (the producer's call: a larger bound lets it run further ahead)
+        std::lock_guard<std::mutex> lk(m_);
+        cap_ = cap;
+        not_full_.notify_all();
+    }
     void close() {       // producer: no more items; consumer: stop the producer
         std::lock_guard<std::mutex> lk(m_);
         closed_ = true;
@@ -116,8 +122,54 @@ struct RecRef {   // views: into the mapped query file, the batch's arena (multi
     uint64_t seq_len;
     uint32_t name_len;
 };
+// ---- records of ONE k-mer each (`>name\nKMER\n`: k-mer lists, the shape of BASELINE's isolated-query configurations) --------------------
+// Such a file is 40 bytes of text per window, where a read file is one: the per-record work decides, so it is done ONCE, by the thread
+// that parses the range -- the k-mer is validated and packed into the 8-byte word fmsi_hip_query_kmers takes, and the record's output line
+// ("name\t?\n") is written with the answer left open; what remains behind the device is one byte per record to fill in.  No RecRef, no
+// run table, no op list.  The buffers are recycled (a fresh 20 MB block per part would be page faults of the whole team on one address space).
+struct KmerPart {
+    std::unique_ptr<char[]> text;     // the part's output lines
+    size_t text_cap = 0, text_len = 0;
+    std::vector<uint64_t> kmers;      // record i's k-mer
+    std::vector<uint32_t> at;         // ... and the offset of its answer character in `text`
+    void reset(size_t text_bytes, size_t recs) {
+        if (text_cap < text_bytes) {
+            text.reset(new char[text_bytes]);
+            text_cap = text_bytes;
+        }
+        text_len = 0;
+        kmers.clear();
+        at.clear();
+        kmers.reserve(recs);
+        at.reserve(recs);
+    }
+};
+class KmerPartPool {
+public:
+    static std::unique_ptr<KmerPart> get() {
+        std::lock_guard<std::mutex> lk(mutex());
+        auto& v = parts();
+        if (v.empty()) return std::make_unique<KmerPart>();
+        auto p = std::move(v.back());
+        v.pop_back();
+        return p;
+    }
+    static void put(std::unique_ptr<KmerPart> p) {
+        if (!p) return;
+        std::lock_guard<std::mutex> lk(mutex());
+        if (parts().size() < 512) parts().push_back(std::move(p));
+    }
+
+private:
+    static std::mutex& mutex() { static std::mutex m; return m; }
+    static std::vector<std::unique_ptr<KmerPart>>& parts() { static auto* v = new std::vector<std::unique_ptr<KmerPart>>; return *v; }
+};
+
 struct RawBatch {   // never moved or copied: its records point into its own text (a short std::string lives INSIDE the object)
     RawBatch() = default;
+    ~RawBatch() {
+        for (auto& p : kparts) KmerPartPool::put(std::move(p));
+    }
     RawBatch(const RawBatch&) = delete;
     RawBatch& operator=(const RawBatch&) = delete;
     std::string text;                                 // ordinary reader: names and sequences, as read
@@ -125,6 +177,10 @@ struct RawBatch {   // never moved or copied: its records point into its own tex
     std::shared_ptr<char[]> inflated;                 // block-gzip reader: the decompressed bytes the views look into
     std::vector<RecRef> recs;
     uint64_t seq_bytes = 0;
+    // a batch of one-k-mer records (kmer_k != 0): the parts in file order instead of `recs`
+    int kmer_k = 0;
+    uint64_t kmer_recs = 0;
+    std::vector<std::unique_ptr<KmerPart>> kparts;
 };
 
 // ---- block-parallel reader ---------------------------------------------------------------------------------------
@@ -239,6 +295,70 @@ bool parse_range(const unsigned char* d, size_t lo, size_t hi, FastxViewParser::
     // records -- then the next part starts where the sequential parse would start a record, too.
     return fastq ? r.clean_end() : !r.saw_fastq();
 }
+// All records of d[lo, hi) (lo at a record start) if every one of them is `>name[ comment]\n` + exactly k characters of ACGTacgt + `\n`
+// (the last line of the file may lack its '\n'), followed by the next '>' or the end of the range: false at the first record of any other
+// shape (a sequence of another length or on several lines, an invalid character, '\r', a blank line, a FASTQ record) -- the caller then
+// parses the range by the ordinary rules.  For the records it accepts this IS the ordinary parse (src/kseq.h:183-226: name = the header up
+// to the first white space, the sequence its one line) and the record loop's walk (src/main.cpp:328-373: one chunk of one window; the line
+// printed is name, '\t', the answer, '\n').  `limit` = end of the readable bytes behind d (>= hi).
+struct KmerPackBmi2 {
+    __attribute__((target("bmi2"))) bool operator()(const char* s, int k, uint64_t* w) const { return kmer_word_bmi2(s, k, w); }
+};
+struct KmerPackPlain {
+    bool operator()(const char* s, int k, uint64_t* w) const { return kmer_word_plain(s, k, w); }
+};
+template <class PackFn>
+__attribute__((always_inline)) inline bool parse_kmer_records(const unsigned char* d, size_t lo, size_t hi, size_t limit, int k, KmerPart& part, PackFn pack) {
+    part.reset(hi - lo + 8, (hi - lo) / (static_cast<size_t>(k) + 3) + 1);   // a line out is shorter than its record
+    char* out = part.text.get();
+    size_t p = lo;
+    const size_t ku = static_cast<size_t>(k);
+    while (p < hi) {
+        if (d[p] != '>') return false;
+        size_t q = p + 1;
+        while (q < hi && d[q] > ' ') ++q;   // (white space of isspace(): ' ', \t \n \v \f \r -- all <= ' '; other control characters: the ordinary parse)
+        if (q >= hi) return false;
+        if (d[q] != ' ' && d[q] != '\n' && d[q] != '\t') return false;
+        const size_t name_len = q - (p + 1);
+        size_t nl = q;
+        if (d[q] != '\n') {
+            const void* e = std::memchr(d + q, '\n', hi - q);
+            if (!e) return false;
+            nl = static_cast<size_t>(static_cast<const unsigned char*>(e) - d);
+        }
+        const size_t s = nl + 1;
+        if (s + ku > hi) return false;
+        if (s + ku < hi) {
+            if (d[s + ku] != '\n') return false;
+            if (s + ku + 1 < hi && d[s + ku + 1] != '>') return false;
+        }
+        uint64_t w;
+        const bool valid = s + 32 <= limit ? pack(reinterpret_cast<const char*>(d + s), k, &w) : kmer_word_tail(reinterpret_cast<const char*>(d + s), k, &w);
+        if (!valid) return false;
+        std::memcpy(out, d + p + 1, name_len);
+        out += name_len;
+        *out++ = '\t';
+        part.at.push_back(static_cast<uint32_t>(out - part.text.get()));
+        *out++ = '0';
+        *out++ = '\n';
+        part.kmers.push_back(w);
+        p = s + ku + 1;
+    }
+    part.text_len = static_cast<size_t>(out - part.text.get());
+    return true;
+}
+__attribute__((target("bmi2"))) bool parse_kmer_range_bmi2(const unsigned char* d, size_t lo, size_t hi, size_t limit, int k, KmerPart& part) {
+    return parse_kmer_records(d, lo, hi, limit, k, part, KmerPackBmi2());
+}
+bool parse_kmer_range_plain(const unsigned char* d, size_t lo, size_t hi, size_t limit, int k, KmerPart& part) {
+    return parse_kmer_records(d, lo, hi, limit, k, part, KmerPackPlain());
+}
+inline bool parse_kmer_range(const unsigned char* d, size_t lo, size_t hi, size_t limit, int k, KmerPart& part) {
+    static const bool bmi2 = __builtin_cpu_supports("bmi2") && !std::getenv("FMSI_HIP_NO_BMI2");
+    if (hi - lo >= (size_t(1) << 32)) return false;   // (32-bit offsets into the part's text)
+    return bmi2 ? parse_kmer_range_bmi2(d, lo, hi, limit, k, part) : parse_kmer_range_plain(d, lo, hi, limit, k, part);
+}
+
 class QueryReader {
 public:
     using clock = std::chrono::steady_clock;
@@ -259,6 +379,9 @@ public:
         reader_thread = std::thread([this] { run(); });
     }
     bool started() const { return reader_thread.joinable(); }
+    // before start(): records of exactly one k-mer (k <= 32) may be handed on as k-mer batches (RawBatch::kmer_k) -- presence modes only
+    void allow_kmer_batches(int k) { kmer_k = k; }
+    uint64_t kmer_batches = 0;
     void join() {
         if (reader_thread.joinable()) reader_thread.join();
     }
@@ -278,6 +401,28 @@ private:
     BgzfFile bgzf;
     bool parallel_read = false, parallel_fastq = false;
     std::thread reader_thread;
+    int kmer_k = 0;
+    bool kmer_streak = true;   // the last range was k-mer records (or none was tried yet): the next one is cut for the whole team
+
+    // the range d[cuts[0], cuts.back()) as a k-mer batch, if every part of it is one-k-mer records
+    bool try_kmer_batch(const unsigned char* d, const std::vector<size_t>& cuts, size_t limit, RawBatch& nb) {
+        if (!kmer_k) return false;
+        const size_t parts = cuts.size() - 1;
+        nb.kparts.resize(parts);
+        for (auto& kp : nb.kparts) kp = KmerPartPool::get();
+        std::vector<char> ok(parts, 1);
+        parallel_for(static_cast<unsigned>(parts), [&](unsigned w) { ok[w] = parse_kmer_range(d, cuts[w], cuts[w + 1], limit, kmer_k, *nb.kparts[w]) ? 1 : 0; });
+        kmer_streak = std::find(ok.begin(), ok.end(), 0) == ok.end();
+        if (!kmer_streak) {
+            for (auto& kp : nb.kparts) KmerPartPool::put(std::move(kp));
+            nb.kparts.clear();
+            return false;
+        }
+        nb.kmer_k = kmer_k;
+        for (const auto& kp : nb.kparts) nb.kmer_recs += kp->kmers.size();
+        if (kmer_batches++ == 0) raw_q.set_cap(40);   // 40 bytes of text per window: the parse is the long stage, let it run ahead of the index load
+        return true;
+    }
 
     void run() {
     try {
@@ -285,11 +430,11 @@ private:
         auto t0 = clock::now();
         size_t resume_at = 0;   // block-parallel reader: where the ordinary reader takes over (a '+' line was met)
         if (parallel_read) {
-            const unsigned workers = std::max(1u, std::min(8u, team / 2));
             const unsigned char* d = mapped.data;
             size_t pos = 0;
             bool serial = false;
             while (pos < mapped.size && !serial) {
+                const unsigned workers = kmer_k && kmer_streak && !parallel_fastq ? std::max(1u, team) : std::max(1u, std::min(8u, team / 2));
                 // a range of about a batch, ending at a record start (or the end of the file)
                 size_t end = mapped.size;
                 const uint64_t range_bytes = (parallel_fastq ? 2 : 1) * opt.batch_windows;   // (a FASTQ file is half qualities)
@@ -306,6 +451,15 @@ private:
                 std::vector<uint64_t> seq_bytes(parts, 0);
                 std::vector<char> clean(parts, 1);
                 auto nb = std::make_unique<RawBatch>();
+                if (!parallel_fastq && try_kmer_batch(d, cuts, mapped.size, *nb)) {
+                    pos = end;
+                    parallel_read_bytes = pos;
+                    if (nb->kmer_recs == 0) continue;
+                    read_s += std::chrono::duration<double>(clock::now() - t0).count();
+                    if (!raw_q.push(std::move(nb))) return;
+                    t0 = clock::now();
+                    continue;
+                }
                 nb->arenas.resize(parts);
                 parallel_for(static_cast<unsigned>(parts), [&](unsigned w) {   // (joins its threads and passes a worker's exception on)
                     clean[w] = parse_range(d, cuts[w], cuts[w + 1], nb->arenas[w], recs[w], seq_bytes[w], parallel_fastq) ? 1 : 0;
@@ -347,7 +501,6 @@ private:
         // parsed like a range of a mapped plain file.  Anything unusual -- a member that is not BGZF, a CRC that does not match, a
         // part that does not end between two records -- hands the stream to the ordinary reader at the last byte given out.
         if (bgzf) {
-            const unsigned workers = std::max(1u, std::min(8u, team / 2));
             size_t at = 0;             // compressed offset of the next member
             uint64_t consumed = 0;     // uncompressed bytes handed on in batches
             std::string carry;
@@ -402,6 +555,7 @@ private:
                     continue;
                 }
                 grow = 1;
+                const unsigned workers = kmer_k && kmer_streak && !fastq ? std::max(1u, team) : std::max(1u, std::min(8u, team / 2));
                 std::vector<size_t> cuts{0};
                 for (unsigned w = 1; w < workers; ++w) {
                     const size_t c = next_record_start(d, cut / workers * w, cut, fastq);
@@ -413,6 +567,16 @@ private:
                 std::vector<uint64_t> seq_bytes(parts, 0);
                 std::vector<char> clean(parts, 1);
                 auto nb = std::make_unique<RawBatch>();
+                if (!fastq && try_kmer_batch(d, cuts, len, *nb)) {   // (the lines are copies: the inflated bytes are not needed behind this point)
+                    carry.assign(seg.get() + cut, len - cut);
+                    consumed += cut;
+                    parallel_read_bytes = consumed;
+                    if (nb->kmer_recs == 0) continue;
+                    read_s += std::chrono::duration<double>(clock::now() - t0).count();
+                    if (!raw_q.push(std::move(nb))) return;
+                    t0 = clock::now();
+                    continue;
+                }
                 nb->arenas.resize(parts);
                 nb->inflated = seg;
                 parallel_for(static_cast<unsigned>(parts), [&](unsigned w) {

@@ -82,8 +82,10 @@ __device__ __forceinline__ uint32_t mask_bit(const DevIndex& ix, uint32_t row) {
     return (w[(row & (kBlockRows - 1u)) >> 5] >> (row & 31u)) & 1u;
 }
 
-// Prefix-table entry -> interval [i, j).  Packed format (ptable_packed != 0): x = i; y = hint << 31 | tag << 30 | hints << 26 | ...
-//   tag 0: y's low 26 bits = j - i (< 2^26)
+// Prefix-table entry -> interval [i, j).  Packed format (ptable_packed != 0): x = i; y = tag << 30 | ... (bit 31 zero)
+//   tag 0: y = j - i (< 2^30).  An interval of 1..3 rows may stand in this form, too -- without signatures, the interval itself: that is
+//          how the entries are while the signatures are still being written beside the first queries (build_prefix_table, fmsi_hip.hip;
+//          an entry is one aligned 8-byte store, a reader sees the one form or the other)
 //   tag 1: 1..3 rows; y = 1 << 30 | rows << 24 | sig2 << 16 | sig1 << 8 | sig0, where sig_m = the four text symbols
 //          preceding the suffix of row i + m (c1 << 6 | c2 << 4 | c3 << 2 | c4, c1 = BWT[row] = the next base the
 //          backward search consumes).  If the query still has >= 4 bases to go (have4) and its next four (q4, same
@@ -91,18 +93,14 @@ __device__ __forceinline__ uint32_t mask_bit(const DevIndex& ix, uint32_t row) {
 //          get_range_with_pattern() would return an empty range either way (src/fms_index.h:117-124), so it is returned
 //          empty right here and the block reads of those steps never happen.  A row whose preceding text is shorter
 //          than four symbols carries an arbitrary signature (a false match only costs the ordinary steps).
-//   (bits 31, 29..26 of y: zero.  Round 4's first kLCP kernel kept five bits about the entry of the key's reverse complement there -- "that
-//   t-mer does not occur", "which bases precede its rows" -- to spare pass 1 the other strand's lookups; the absence certificates of
-//   fmsi_stream.hip settle those windows a dozen at a time and the bits no longer changed a request count: removed)
-constexpr uint32_t kTableHintMask = 0xBC000000u;   // bits 31, 29..26
 __device__ __forceinline__ void decode_table_entry(uint32_t x, uint32_t y, uint32_t packed, bool have4, uint32_t q4, uint32_t& i, uint32_t& j) {
     i = x;
     if (!packed) {
         j = y;
         return;
     }
-    if (((y >> 30) & 1u) == 0u) {
-        j = x + (y & 0x03FFFFFFu);
+    if ((y >> 30) == 0u) {
+        j = x + y;
         return;
     }
     const uint32_t rows = (y >> 24) & 3u;

@@ -1316,6 +1316,7 @@ void drop_kmer_dict(fmsi_hip_index* idx) {
 }  // namespace
 
 extern "C" int fmsi_hip_index_enable_dict(fmsi_hip_index* idx, uint32_t flags) {
+    if (idx) (void)::fmsi::wait_background(idx);   // (the prefix table's signature pass, when it runs beside the first queries)
     ::fmsi::ScratchScope scratch_scope_(idx ? idx->device : -1);   // (devpool.h: the outermost builder returns the block cache to the driver)
     if (!idx) return FMSI_HIP_EINVAL;
     const bool want_sk = (flags & (FMSI_HIP_DICT_SUPERKMER | FMSI_HIP_DICT_SUPERKMER_ONLY)) != 0u;

@@ -383,66 +383,95 @@ __global__ __launch_bounds__(256) void pack_results_kernel(const uint8_t* __rest
     }
 }
 
-// one level of the prefix table: entry idx of level L = LF step with base (idx & 3) on entry idx >> 2 of level L-1
-__global__ __launch_bounds__(256) void ptable_level_kernel(DevIndex ix, const uint2* __restrict__ prev, uint2* __restrict__ cur,
-                                                           uint64_t count) {
+// one level of the prefix table: entry idx of level L = LF step with base (idx & 3) on entry idx >> 2 of level L-1.
+// FINAL: the last level leaves as (i, length) -- the packed format's tag-0 form, decode_table_entry -- and the longest interval is
+// taken on the way (one atomic per workgroup: a launch of 2^28 waves with an atomic each spent 48 ms on that one address)
+template <bool FINAL>
+__global__ __launch_bounds__(256) void ptable_level_kernel(DevIndex ix, const uint2* __restrict__ prev, uint2* __restrict__ cur, uint64_t count,
+                                                           uint32_t* __restrict__ max_len) {
+    __shared__ uint32_t s_max[4];
     const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;   // a launch holds < 2^32 threads; level 16 has 2^32 entries
+    uint32_t m = 0;
     for (uint64_t idx = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; idx < count; idx += stride) {
         uint2 e = prev ? prev[idx >> 2] : make_uint2(0u, ix.n);
         if (e.x != e.y) {
             uint32_t dummy = 0;
             lf_step(ix, static_cast<uint32_t>(idx & 3u), e.x, e.y, dummy);
         }
+        if (FINAL) {
+            e.y -= e.x;
+            m = max(m, e.y);
+        }
         cur[idx] = e;
     }
-}
-
-// longest interval of the final level (decides whether the packed entry format fits: lengths < 2^26)
-__global__ __launch_bounds__(256) void ptable_maxlen_kernel(const uint2* __restrict__ tab, uint64_t count, uint32_t* __restrict__ max_len) {
-    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
-    uint32_t m = 0;
-    for (uint64_t idx = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; idx < count; idx += stride) {
-        const uint2 e = tab[idx];
-        m = max(m, e.y - e.x);
+    if (FINAL) {
+        for (int off = 32; off > 0; off >>= 1) m = max(m, static_cast<uint32_t>(__shfl_down(static_cast<int>(m), off, 64)));
+        if ((threadIdx.x & 63) == 0) s_max[threadIdx.x >> 6] = m;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            m = max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3]));
+            if (m) atomicMax(max_len, m);
+        }
     }
-    for (int off = 32; off > 0; off >>= 1) m = max(m, static_cast<uint32_t>(__shfl_down(static_cast<int>(m), off, 64)));
-    if ((threadIdx.x & 63) == 0 && m) atomicMax(max_len, m);
 }
 
-// (i, j) -> packed entries (decode_table_entry): intervals of 1..3 rows get the signatures of their rows
-__global__ __launch_bounds__(256) void ptable_pack_kernel(DevIndex ix, uint2* __restrict__ tab, uint64_t count) {
+// (i, length) -> (i, j): the unpacked format, for a table with an interval of 2^30 rows and more (a text that is mostly one letter)
+__global__ __launch_bounds__(256) void ptable_unpack_kernel(uint2* __restrict__ tab, uint64_t count) {
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
+    for (uint64_t idx = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; idx < count; idx += stride) {
+        uint2 e = tab[idx];
+        e.y += e.x;
+        tab[idx] = e;
+    }
+}
+
+// (i, length) -> the entries of 1..3 rows get the signatures of their rows (decode_table_entry), in place, each entry one 8-byte store:
+// a kernel that reads the table meanwhile sees an entry in the one form or the other, and both say the same interval
+__global__ __launch_bounds__(256) void ptable_sign_kernel(DevIndex ix, uint2* __restrict__ tab, uint64_t count) {
     const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
     for (uint64_t idx = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; idx < count; idx += stride) {
         const uint2 e = tab[idx];
-        const uint32_t len = e.y - e.x;
-        uint32_t y = len;
-        if (len >= 1u && len <= 3u) {
-            y = (1u << 30) | (len << 24);
-            for (uint32_t m = 0; m < len; ++m) {
-                uint32_t row = e.x + m, sig = 0;
-                bool alive = true;
-                for (int step = 0; step < 4; ++step) {
-                    uint32_t c = 0;
-                    if (alive && row != ix.dollar) {
-                        const uint32_t* blk = reinterpret_cast<const uint32_t*>(ix.blocks) + (static_cast<size_t>(row >> kBlockRowsLog2) << 4);
-                        const uint32_t o = row & (kBlockRows - 1u), w = o >> 5, sh = o & 31u;
-                        c = (((blk[4 + w] >> sh) & 1u) << 1) | ((blk[8 + w] >> sh) & 1u);   // access(), src/fms_index.h:88-95
-                        uint32_t a = row, b = row + 1u, dummy = 0;
-                        lf_step(ix, c, a, b, dummy);
-                        row = a;
-                    } else {
-                        alive = false;   // the text starts here: no such k-mer; any signature will do
-                    }
-                    sig = (sig << 2) | c;
+        const uint32_t len = e.y;
+        if (len < 1u || len > 3u) continue;   // (a signed entry has bit 30 set)
+        uint32_t y = (1u << 30) | (len << 24);
+        for (uint32_t m = 0; m < len; ++m) {
+            uint32_t row = e.x + m, sig = 0;
+            bool alive = true;
+            for (int step = 0; step < 4; ++step) {
+                uint32_t c = 0;
+                if (alive && row != ix.dollar) {
+                    const uint32_t* blk = reinterpret_cast<const uint32_t*>(ix.blocks) + (static_cast<size_t>(row >> kBlockRowsLog2) << 4);
+                    const uint32_t o = row & (kBlockRows - 1u), w = o >> 5, sh = o & 31u;
+                    c = (((blk[4 + w] >> sh) & 1u) << 1) | ((blk[8 + w] >> sh) & 1u);   // access(), src/fms_index.h:88-95
+                    uint32_t a = row, b = row + 1u, dummy = 0;
+                    lf_step(ix, c, a, b, dummy);
+                    row = a;
+                } else {
+                    alive = false;   // the text starts here: no such k-mer; any signature will do
                 }
-                y |= sig << (8u * m);
+                sig = (sig << 2) | c;
             }
+            y |= sig << (8u * m);
         }
         tab[idx] = make_uint2(e.x, y);
     }
 }
 
-int build_prefix_table(fmsi_hip_index* idx, int t) {
+// the signatures may be written beside the first queries (FMSI_HIP_LOAD_ASYNC_TABLE: `fmsi query`, whose run at human scale is over in
+// the time the pass takes): whoever changes or reads the table as a whole waits for them here
+int wait_background(fmsi_hip_index* idx) {
+    if (!idx || !idx->bg_pending) return 0;
+    ::fmsi::DeviceGuard device_guard_(idx->device);
+    const hipError_t e = hipStreamSynchronize(idx->bg_stream);
+    idx->bg_pending = false;
+    if (e != hipSuccess) {
+        set_last_error(std::string("prefix table signatures: ") + hipGetErrorString(e));
+        return FMSI_HIP_EHIP;
+    }
+    return 0;
+}
+
+int build_prefix_table(fmsi_hip_index* idx, int t, bool sign_in_background) {
     if (t <= 0) return 0;
     TraceRange trace_range("fmsi: build prefix table");
     if (t > 16) {
@@ -451,68 +480,65 @@ int build_prefix_table(fmsi_hip_index* idx, int t) {
     }
     const uint64_t final_count = 1ull << (2 * t);
     uint2 *a = nullptr, *b = nullptr;
+    uint32_t* d_max = nullptr;
     // +64 B so that reading the whole line of the last entry stays inside the allocation
     if (dev_malloc(reinterpret_cast<void**>(&a), final_count * sizeof(uint2) + 64) != hipSuccess) {
         (void)hipGetLastError();
         set_last_error("hipMalloc failed for the prefix table (" + std::to_string(final_count * sizeof(uint2) >> 20) + " MiB)");
         return FMSI_HIP_ENOMEM;
     }
-    if (t > 1) {
-        if (dev_malloc(reinterpret_cast<void**>(&b), (final_count / 4) * sizeof(uint2) + 64) != hipSuccess) {
-            (void)dev_free(a);
-            set_last_error("hipMalloc failed for the prefix table");
-            return FMSI_HIP_ENOMEM;
-        }
-    }
+    auto fail = [&](int code, const std::string& msg) {
+        (void)dev_free(a);
+        if (b) (void)dev_free(b);
+        if (d_max) (void)dev_free(d_max);
+        set_last_error(msg);
+        return code;
+    };
+    if (t > 1 && dev_malloc(reinterpret_cast<void**>(&b), (final_count / 4) * sizeof(uint2) + 64) != hipSuccess) return fail(FMSI_HIP_ENOMEM, "hipMalloc failed for the prefix table");
+    if (dev_malloc(reinterpret_cast<void**>(&d_max), 4) != hipSuccess || hipMemsetAsync(d_max, 0, 4, 0) != hipSuccess) return fail(FMSI_HIP_ENOMEM, "hipMalloc failed");
     // levels alternate between the two buffers so that the last level lands in `a`
     uint2* bufs[2] = {a, b};
     int cur = (t % 2 == 1) ? 0 : 1;
     const uint2* prev = nullptr;
     for (int level = 1; level <= t; ++level) {
         const uint64_t count = 1ull << (2 * level);
-        const uint32_t blocks = static_cast<uint32_t>(std::min<uint64_t>((count + 255) / 256, 1u << 22));
-        hipLaunchKernelGGL(ptable_level_kernel, dim3(blocks), dim3(256), 0, 0, idx->dev, prev, bufs[cur], count);
-        if (hipGetLastError() != hipSuccess) {
-            (void)dev_free(a);
-            if (b) (void)dev_free(b);
-            set_last_error("prefix table build: kernel launch failed");
-            return FMSI_HIP_EHIP;
+        if (level < t) {
+            const uint32_t blocks = static_cast<uint32_t>(std::min<uint64_t>((count + 255) / 256, 1u << 22));
+            hipLaunchKernelGGL((ptable_level_kernel<false>), dim3(blocks), dim3(256), 0, 0, idx->dev, prev, bufs[cur], count, d_max);
+        } else {
+            const uint32_t blocks = static_cast<uint32_t>(std::min<uint64_t>((count + 255) / 256, 1u << 14));
+            hipLaunchKernelGGL((ptable_level_kernel<true>), dim3(blocks), dim3(256), 0, 0, idx->dev, prev, bufs[cur], count, d_max);
         }
+        if (hipGetLastError() != hipSuccess) return fail(FMSI_HIP_EHIP, "prefix table build: kernel launch failed");
         prev = bufs[cur];
         cur ^= 1;
     }
-    hipError_t e = hipDeviceSynchronize();
+    uint32_t h_max = 0;
+    hipError_t e = hipMemcpy(&h_max, d_max, 4, hipMemcpyDeviceToHost);   // (waits for the levels)
+    if (e != hipSuccess) return fail(FMSI_HIP_EHIP, std::string("prefix table build: ") + hipGetErrorString(e));
     if (b) (void)dev_free(b);
-    if (e != hipSuccess) {
-        (void)dev_free(a);
-        set_last_error(std::string("prefix table build: ") + hipGetErrorString(e));
-        return FMSI_HIP_EHIP;
-    }
+    b = nullptr;
+    (void)dev_free(d_max);
+    d_max = nullptr;
     // packed entries with next-base signatures, unless some interval is too long for the 30-bit length field
-    {
-        uint32_t* d_max = nullptr;
-        uint32_t h_max = 0;
-        const uint32_t blocks = static_cast<uint32_t>(std::min<uint64_t>((final_count + 255) / 256, 1u << 20));
-        if (dev_malloc(reinterpret_cast<void**>(&d_max), 4) != hipSuccess || hipMemset(d_max, 0, 4) != hipSuccess) {
-            (void)dev_free(a);
-            set_last_error("hipMalloc failed");
-            return FMSI_HIP_ENOMEM;
+    const uint32_t blocks = static_cast<uint32_t>(std::min<uint64_t>((final_count + 255) / 256, 1u << 20));
+    idx->dev.ptable_packed = h_max < (1u << 30) ? 1u : 0u;
+    if (!idx->dev.ptable_packed) {
+        hipLaunchKernelGGL(ptable_unpack_kernel, dim3(blocks), dim3(256), 0, 0, a, final_count);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipDeviceSynchronize();
+        if (e != hipSuccess) return fail(FMSI_HIP_EHIP, std::string("prefix table: ") + hipGetErrorString(e));
+    } else {
+        if (sign_in_background && !idx->bg_stream && hipStreamCreateWithFlags(&idx->bg_stream, hipStreamNonBlocking) != hipSuccess) {
+            (void)hipGetLastError();
+            idx->bg_stream = nullptr;
         }
-        hipLaunchKernelGGL(ptable_maxlen_kernel, dim3(blocks), dim3(256), 0, 0, a, final_count, d_max);
-        hipError_t e2 = hipMemcpy(&h_max, d_max, 4, hipMemcpyDeviceToHost);
-        (void)dev_free(d_max);
-        idx->dev.ptable_packed = 0;
-        if (e2 == hipSuccess && h_max < (1u << 26)) {
-            hipLaunchKernelGGL(ptable_pack_kernel, dim3(blocks), dim3(256), 0, 0, idx->dev, a, final_count);
-            e2 = hipGetLastError();
-            if (e2 == hipSuccess) e2 = hipDeviceSynchronize();
-            idx->dev.ptable_packed = 1;
-        }
-        if (e2 != hipSuccess) {
-            (void)dev_free(a);
-            set_last_error(std::string("prefix table packing: ") + hipGetErrorString(e2));
-            return FMSI_HIP_EHIP;
-        }
+        const bool bg = sign_in_background && idx->bg_stream;
+        hipLaunchKernelGGL(ptable_sign_kernel, dim3(blocks), dim3(256), 0, bg ? idx->bg_stream : static_cast<hipStream_t>(0), idx->dev, a, final_count);
+        e = hipGetLastError();
+        if (e == hipSuccess && !bg) e = hipDeviceSynchronize();
+        if (e != hipSuccess) return fail(FMSI_HIP_EHIP, std::string("prefix table signatures: ") + hipGetErrorString(e));
+        idx->bg_pending = bg;
     }
     idx->d_ptable = a;
     idx->dev.ptable = a;
@@ -588,7 +614,7 @@ int launch_query(fmsi_hip_index* idx, const uint64_t* d_kmers, uint64_t n_window
     }
     // AUTO on a handle with the pair layout and no usable table: a LARGE batch takes the batch-sorted walk (3.8 G k-mers/s at human scale
     // where the per-k-mer pair kernel does 2.1 G; its sort and its per-batch top levels do not pay below a few million k-mers); a handle
-    // without the room for its scratch (about 50 bytes per k-mer) keeps the pair kernel
+    // without the room for its scratch (about 66 bytes per k-mer of a sub-batch of 2^26: 4.5 GB, fmsi_sorted.hip) keeps the pair kernel
     const bool sorted_auto = !dict && !sk_iso && kernel == FMSI_HIP_KERNEL_AUTO && !use_table && idx->d_pblocks && n_windows >= (1ull << 22) &&
                              sorted_walk_applies(idx, k, (flags & ~FMSI_HIP_KERNEL_MASK) | FMSI_HIP_KERNEL_SORTED);
     const bool sorted = !dict && !sk_iso && (sorted_auto || sorted_walk_applies(idx, k, flags));
@@ -619,7 +645,7 @@ int launch_query(fmsi_hip_index* idx, const uint64_t* d_kmers, uint64_t n_window
         else rc = launch_skdict_kmers(idx, d_kmers, n_windows, flags, o8, d_counters, s);
         if (rc) return rc;
     } else if (sorted) {
-        rc = launch_sorted_query(idx, d_kmers, n_windows, k, flags, o8, d_counters, s);
+        rc = launch_sorted_query(idx, d_kmers, n_windows, k, flags, o8, d_counters, s, sorted_auto);
         if (rc == FMSI_HIP_ENOMEM && sorted_auto) {   // (nothing was launched: the scratch is claimed first)
             (void)hipGetLastError();
             launch_pair_query(idx, d_kmers, n_windows, k, flags, false, o8, o64, d_counters, s);
@@ -880,6 +906,8 @@ uint64_t fmsi_hip_scratch_bytes(int device) {
 void fmsi_hip_index_destroy(fmsi_hip_index* idx) {
     if (!idx) return;
     ::fmsi::DeviceGuard device_guard_(idx->device);
+    (void)wait_background(idx);
+    if (idx->bg_stream) (void)hipStreamDestroy(idx->bg_stream);
     for (void* p : {idx->d_sk, idx->d_sk_aux[0], idx->d_sk_aux[1], idx->d_sk_aux[2], idx->d_sk_aux[3]})
         if (p) (void)dev_free(p);
     for (void* p : {idx->d_super, idx->d_blocks, idx->d_mrank, idx->d_ptable, idx->d_klcp, idx->d_sblocks, idx->d_text2, idx->d_stable, idx->d_vtable, idx->d_in, idx->d_aux, idx->d_out,
@@ -896,6 +924,25 @@ void fmsi_hip_index_destroy(fmsi_hip_index* idx) {
     }
     delete idx;
     (void)dev_trim();   // (what this handle's construction left in the block cache goes back to the driver with it)
+}
+
+int fmsi_hip_index_release_scratch(fmsi_hip_index* idx) {
+    if (!idx) return FMSI_HIP_EINVAL;
+    FMSI_HIP_ON_DEVICE(idx->device);
+    FMSI_HIP_TRY(hipDeviceSynchronize());   // (whatever still reads or writes them)
+    struct Buf {
+        void** p;
+        size_t* cap;
+    };
+    for (const Buf& b : {Buf{&idx->d_in, &idx->d_in_cap}, Buf{&idx->d_aux, &idx->d_aux_cap}, Buf{&idx->d_out, &idx->d_out_cap}, Buf{&idx->d_kmers, &idx->d_kmers_cap},
+                         Buf{&idx->d_tasks, &idx->d_tasks_cap}, Buf{&idx->d_bytes, &idx->d_bytes_cap}, Buf{&idx->d_case, &idx->d_case_cap},
+                         Buf{&idx->d_sorted, &idx->d_sorted_cap}}) {
+        if (*b.p) (void)dev_free(*b.p);
+        *b.p = nullptr;
+        *b.cap = 0;
+    }
+    (void)dev_trim();
+    return 0;
 }
 
 int fmsi_hip_index_get_info(const fmsi_hip_index* idx, fmsi_hip_index_info* info) {

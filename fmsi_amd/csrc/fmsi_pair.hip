@@ -1404,16 +1404,14 @@ __global__ __launch_bounds__(256) void verify_fill_kernel(const uint2* __restric
         const uint32_t ch = static_cast<uint8_t>(c) | 0x20u;
         return ch == 'a' ? 0u : (ch == 'c' ? 1u : (ch == 'g' ? 2u : 3u));
     };
-    auto rows_of = [](uint2 e) -> uint32_t { return (e.y >> 30) == 1u ? ((e.y >> 24) & 3u) : e.y; };   // 8-byte format: tag 0 = length (hint bits cleared below)
+    auto rows_of = [](uint2 e) -> uint32_t { return (e.y >> 30) == 1u ? ((e.y >> 24) & 3u) : e.y; };   // 8-byte format: tag 0 = length
     for (uint64_t idx = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; idx < count; idx += stride) {
         uint2 e = tab[idx];
-        e.y &= ~kTableHintMask;   // (the prefix table's hints about the other strand are the streaming kernel's: bits 26-28 are mask bits here)
         uint32_t cand[7] = {0, 0, 0, 0, 0, 0, 0};
         const uint32_t nf = rows_of(e);
         bool done = false;
         if (bases_mode && nf <= max_total) {
             uint2 er = tab[revcomp_2bit(idx, static_cast<int>(T))];
-            er.y &= ~kTableHintMask;
             const uint32_t nr = rows_of(er);
             if (nf + nr <= max_total) {
                 // narrow: nf in bits 24-25, nr in bits 22-23, mask bits from bit 26; wide: nf bits 0-2, nr bits 3-5, mask bits from bit 8
@@ -1477,6 +1475,7 @@ __global__ __launch_bounds__(256) void verify_fill_kernel(const uint2* __restric
 }  // namespace fmsi
 
 extern "C" int fmsi_hip_index_enable_verify(fmsi_hip_index* idx) {
+    if (idx) (void)::fmsi::wait_background(idx);   // (the prefix table's signature pass, when it runs beside the first queries)
     ::fmsi::ScratchScope scratch_scope_(idx ? idx->device : -1);   // (devpool.h: the outermost builder returns the block cache to the driver)
     if (!idx) return FMSI_HIP_EINVAL;
     FMSI_HIP_NARROW_ONLY(idx, "this accelerator");

@@ -619,10 +619,15 @@ bool sorted_walk_applies(const fmsi_hip_index* idx, int k, uint32_t flags) {
     return (flags & FMSI_HIP_KERNEL_MASK) == FMSI_HIP_KERNEL_SORTED && idx->d_pblocks && !idx->wide && k >= 1 && k <= 32 && !(flags & FMSI_HIP_ORDERS);
 }
 
-int launch_sorted_query(fmsi_hip_index* idx, const uint64_t* d_kmers, uint64_t n, int k, uint32_t flags, uint8_t* o8, unsigned long long* d_counters, hipStream_t s) {
-    // sub-batches: item values are 32 bits (2 q + strand) and one radix sort takes < 2^32 items
+int launch_sorted_query(fmsi_hip_index* idx, const uint64_t* d_kmers, uint64_t n, int k, uint32_t flags, uint8_t* o8, unsigned long long* d_counters, hipStream_t s,
+                        bool chosen_by_auto) {
+    // sub-batches: item values are 32 bits (2 q + strand) and one radix sort takes < 2^32 items.  The scratch stays on the handle (d_sorted):
+    // about 66 bytes per k-mer of a sub-batch -- two items per k-mer, each 2 keys x 8 + 2 values x 4 + 8 hand-over bytes + a ternary -- plus the
+    // per-batch top levels (up to 537 MB) and rocPRIM's temporary: 17-18 GB for 2^28 k-mers.  A caller that asked for this kernel gets
+    // that sub-batch; one that left the choice to the library (AUTO) is not surprised by it: 2^26 k-mers, 4.5 GB,
+    // released again by fmsi_hip_index_release_scratch.
     static const char* sub_env = std::getenv("FMSI_HIP_SORTED_SUB");   // (tests: k-mers per sub-batch)
-    const uint64_t kSub = sub_env ? std::max<uint64_t>(1, std::strtoull(sub_env, nullptr, 10)) : (1ull << 28);
+    const uint64_t kSub = sub_env ? std::max<uint64_t>(1, std::strtoull(sub_env, nullptr, 10)) : (chosen_by_auto ? 1ull << 26 : 1ull << 28);
     for (uint64_t at = 0; at < n; at += kSub) {
         const uint64_t m = std::min(kSub, n - at);
         const int rc = d_counters ? launch_sorted_t<true>(idx, d_kmers + at, m, k, flags, o8 + at, d_counters, s)

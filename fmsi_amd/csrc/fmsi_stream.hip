@@ -1462,13 +1462,21 @@ extern "C" int fmsi_hip_query_stream(fmsi_hip_index* idx, const uint64_t* packed
     // for A/B runs) -- since round 4 also for ORDERS (`lookup -S`) and 33 <= k <= 64
     static const bool force_v1 = std::getenv("FMSI_HIP_STREAM_V1") != nullptr;
     bool v2 = !force_v1 && (flags & FMSI_HIP_KERNEL_MASK) != FMSI_HIP_KERNEL_REFILL;
+    if (v2 && !idx->d_sblocks && idx->stream_layout_failed) v2 = false;
     if (v2 && !idx->d_sblocks) {
         // built here on the handle's first such call (a kernel on the null stream and a device synchronisation: this ONE call is not
-        // asynchronous on `stream`; fmsi_hip_index_enable_stream_layout at load time avoids that).  A handle without the room for the
-        // layout (2/3 byte per row) keeps streaming through the first kernel -- the same answers, slower
-        if (fmsi_hip_index_enable_stream_layout(idx) != 0) {
+        // asynchronous on `stream`; fmsi_hip_index_enable_stream_layout at load time avoids that).  A handle without the ROOM for the
+        // layout (2/3 byte per row) keeps streaming through the first kernel -- the same answers, slower; that is remembered (no second
+        // attempt with every batch) and said once.  Any other failure is the call's.
+        const int rc_layout = fmsi_hip_index_enable_stream_layout(idx);
+        if (rc_layout == FMSI_HIP_ENOMEM) {
             (void)hipGetLastError();
+            idx->stream_layout_failed = true;
+            fprintf(stderr, "WARNING: not enough device memory for the streaming layout (%llu MiB); streaming through the first kernel (same answers, slower)\n",
+                    static_cast<unsigned long long>((((idx->n + kSRows - 1) / kSRows + 1) * kSDwords * 4) >> 20));
             v2 = false;
+        } else if (rc_layout != 0) {
+            return rc_layout;
         }
     }
     // run_start / run_windows are HOST arrays in every mode (one entry per run); per run the device gets its first base,

@@ -129,11 +129,14 @@ struct fmsi_hip_index {
     void* d_blocks = nullptr;
     void* d_mrank = nullptr;
     void* d_ptable = nullptr;
+    hipStream_t bg_stream = nullptr;   // the table's signature pass when it runs beside the first queries (build_prefix_table), else null
+    bool bg_pending = false;
     int fn_kind = 0;             // demasking function of the current fmsi_hip_query_runs_fn call (FMSI_HIP_FN_*) and its bounds
     uint64_t fn_r = 0, fn_s = 0;
     void* d_klcp = nullptr;      // plain kLCP bit-vector (n bits, u64 words), when present
     void* d_sblocks = nullptr;   // streaming layout (fmsi_stream.hip): 128-byte blocks of 192 rows with the kLCP plane, built on first use
     uint64_t n_sblocks = 0;
+    bool stream_layout_failed = false;   // no room for it: fmsi_hip_query_stream keeps the first kernel and does not try again
     // optional pair layout (fmsi_pair.hip): 128-B blocks for two-base LF steps
     void* d_pblocks = nullptr;
     void* d_sbt = nullptr;
@@ -180,8 +183,10 @@ struct fmsi_hip_index {
 };
 
 namespace fmsi {
-// builds the optional prefix table on the device (fmsi_hip.hip)
-int build_prefix_table(fmsi_hip_index* idx, int t);
+// builds the optional prefix table on the device (fmsi_hip.hip); sign_in_background: the signatures of its short entries are written on a
+// stream of their own while the handle already answers -- wait_background() before anything that reads or replaces the table as a whole
+int build_prefix_table(fmsi_hip_index* idx, int t, bool sign_in_background = false);
+int wait_background(fmsi_hip_index* idx);
 
 // two-base-step kernel over the pair layout (fmsi_pair.hip); requires idx->d_pblocks
 void launch_pair_query(fmsi_hip_index* idx, const uint64_t* d_kmers, uint64_t n, int k, uint32_t flags, bool use_table, uint8_t* o8,
@@ -221,7 +226,8 @@ int build_prefix_table_wide(fmsi_hip_index* idx, int t);   // (at most 14 deep: 
 
 // FMSI_HIP_KERNEL_SORTED (fmsi_sorted.hip): the batch's strand searches sorted and walked in lock-step over the pair layout
 bool sorted_walk_applies(const fmsi_hip_index* idx, int k, uint32_t flags);
-int launch_sorted_query(fmsi_hip_index* idx, const uint64_t* d_kmers, uint64_t n, int k, uint32_t flags, uint8_t* o8, unsigned long long* d_counters, hipStream_t s);
+int launch_sorted_query(fmsi_hip_index* idx, const uint64_t* d_kmers, uint64_t n, int k, uint32_t flags, uint8_t* o8, unsigned long long* d_counters, hipStream_t s,
+                        bool chosen_by_auto = false);
 
 // the k-mer dictionary answers this call (presence modes, the index's k, no NO_PREFIX_TABLE) -- and its launch; h_runs as for
 // launch_phased_query.  The lookup kernel packs FMSI_HIP_OUT_BITS output itself.

@@ -460,6 +460,55 @@ inline bool same_state(const StrandPredictor& a, const StrandPredictor& b) {
     return a.score == b.score && a.result_scores[0] == b.result_scores[0] && a.result_scores[1] == b.result_scores[1] && a.previous == b.previous;
 }
 
+// The same step for presence bytes as a table: what a window's pair of strand results (the STRICT byte's low nibble) does under either
+// strand order -- the difference log_result() adds to the scores, the new `previous`, the character printed.  Filled from replay_single()
+// itself.  The loop below is the predictor's recurrence and nothing else: two table reads that do not depend on the state, one select by
+// predict_swap(), two clipped adds -- about 2 ns per window where the general loop (copy, compare, run search) takes 8-16: isolated
+// k-mers have no runs of equal inputs to skip, and a file of 10^8 of them is 10^8 sequential steps.
+struct PredictorSteps {
+    int32_t e[2][2][16];   // [mode all][swap][nibble] = (diff & 0xFF) | previous << 8 | out << 16
+    PredictorSteps() {
+        for (int all = 0; all < 2; ++all)
+            for (int swap = 0; swap < 2; ++swap)
+                for (int in = 0; in < 16; ++in) {
+                    StrandPredictor p;
+                    p.score = swap ? -1 : 1;   // (previous == -1: predict_swap() is score < 0, and no result score is touched)
+                    const int64_t got = replay_single(p, all ? Mode::All : Mode::Or, false, fwd_of(static_cast<uint8_t>(in)), rc_of(static_cast<uint8_t>(in)));
+                    const int diff = p.score - (swap ? -1 : 1);
+                    e[all][swap][in] = (diff & 0xFF) | (p.previous << 8) | (static_cast<int32_t>(got == 1) << 16);
+                }
+    }
+};
+const PredictorSteps kPredictorSteps;
+
+void replay_presence_tight(uint8_t* b, uint64_t n, StrandPredictor& p, Mode mode) {
+    uint64_t w = 0;
+    for (; w < n && p.previous == -1; ++w) {   // (the very first window: no result score is updated)
+        const uint8_t in = b[w];
+        b[w] = static_cast<uint8_t>(replay_single(p, mode, false, fwd_of(in), rc_of(in)) == 1);
+    }
+    const int32_t(*T)[16] = kPredictorSteps.e[mode == Mode::All ? 1 : 0];
+    int score = p.score, rs0 = p.result_scores[0], rs1 = p.result_scores[1], prev = p.previous;
+    for (; w < n; ++w) {
+        const unsigned in = b[w] & 15u;
+        const int32_t e0 = T[0][in], e1 = T[1][in];
+        const int rsp = prev ? rs1 : rs0;
+        const int sel = rsp ? rsp : score;
+        const int32_t e = sel < 0 ? e1 : e0;
+        const int diff = static_cast<int8_t>(e & 0xFF);
+        score = StrandPredictor::clipped(score + diff);
+        const int nrs = StrandPredictor::clipped(rsp + diff);
+        rs1 = prev ? nrs : rs1;
+        rs0 = prev ? rs0 : nrs;
+        prev = (e >> 8) & 1;
+        b[w] = static_cast<uint8_t>(e >> 16);
+    }
+    p.score = score;
+    p.result_scores[0] = rs0;
+    p.result_scores[1] = rs1;
+    p.previous = prev;
+}
+
 // strict results (both strands per window) -> final per-window values, in the order the reference visits them
 void replay_batch(Prepared& P, StrandPredictor& predictor, Mode mode, bool orders, bool streaming, int k, unsigned team, bool wide_orders = false) {
     if (!streaming) {
@@ -644,6 +693,43 @@ void format_orders(const Prepared& P, unsigned team, std::vector<std::string>& p
     });
 }
 
+// a k-mer batch (cli_reader.h: records of one k-mer each, their lines written by the parser): the answers go into the lines, one character
+// per record, slices of 2^16 records dealt out to the team
+void patch_kmer_lines(Prepared& P, unsigned team) {
+    struct Slice {
+        KmerPart* part;
+        size_t lo, hi;
+        uint64_t first;   // result index of the part's record `lo`
+    };
+    std::vector<Slice> slices;
+    uint64_t first = 0;
+    for (auto& kp : P.raw.kparts) {
+        const size_t n = kp->kmers.size();
+        for (size_t lo = 0; lo < n; lo += size_t(1) << 16) slices.push_back({kp.get(), lo, std::min(n, lo + (size_t(1) << 16)), first + lo});
+        first += n;
+    }
+    if (slices.empty()) return;
+    team = static_cast<unsigned>(std::max<size_t>(1, std::min<size_t>(team, slices.size())));
+    std::atomic<size_t> next{0};
+    parallel_for(team, [&](unsigned) {
+        for (size_t t; (t = next.fetch_add(1, std::memory_order_relaxed)) < slices.size();) {
+            const Slice& sl = slices[t];
+            char* text = sl.part->text.get();
+            const uint32_t* at = sl.part->at.data();
+            if (P.packed_bits) {
+                const uint64_t* bits = P.bits.data();
+                for (size_t i = sl.lo; i < sl.hi; ++i) {
+                    const uint64_t w = sl.first + (i - sl.lo);
+                    text[at[i]] = static_cast<char>('0' + ((bits[w >> 6] >> (w & 63)) & 1u));
+                }
+            } else {
+                const uint8_t* b = P.bytes.data() + sl.first;
+                for (size_t i = sl.lo; i < sl.hi; ++i) text[at[i]] = static_cast<char>('0' + (b[i - sl.lo] != 0));
+            }
+        }
+    });
+}
+
 void check(int rc, const char* what) {
     if (rc != 0) throw std::runtime_error(std::string(what) + ": " + fmsi_hip_last_error());
 }
@@ -746,6 +832,7 @@ extern "C" int fmsi_cli_query(int argc, char** argv, int output_orders_i) {
 
     using clock = std::chrono::steady_clock;
     auto t_start = clock::now();
+    const double epoch_start = std::chrono::duration<double>(std::chrono::system_clock::now().time_since_epoch()).count();
     if (opt.devices.empty()) opt.devices.push_back(opt.device);
     const unsigned team = opt.threads ? opt.threads : std::min(16u, available_cpus());
 
@@ -762,10 +849,6 @@ extern "C" int fmsi_cli_query(int argc, char** argv, int output_orders_i) {
         raw_q.abort();
         query_reader.join();
     };
-    {
-        struct stat st;
-        if (opt.query_fn == "-" || stat(opt.query_fn.c_str(), &st) == 0) start_reader();
-    }
 
     // the index: its scalars from the files' headers now (the checks of ms_query, src/main.cpp:302-320), its payload straight into
     // HBM below (fmsi_hip_index_load: RRR decode and block layout on the device)
@@ -789,6 +872,15 @@ extern "C" int fmsi_cli_query(int argc, char** argv, int output_orders_i) {
         return usage_query(output_orders);
     }
     if (k == 0) k = index_k;
+    // (the header checks above are a few file reads; the reader starts here, before the index's payload is touched)
+    // Records of exactly one k-mer -- the query files of BASELINE's isolated-k-mer configurations -- take a path of their own from the
+    // parser on (cli_reader.h: KmerPart; fmsi_hip_query_kmers): presence modes, k <= 32.  FMSI_HIP_CLI_KMER_BATCHES=0: the general path (A/B runs).
+    {
+        static const char* kmer_env = std::getenv("FMSI_HIP_CLI_KMER_BATCHES");
+        if (!output_orders && !general && k >= 1 && k <= 32 && !(kmer_env && kmer_env[0] == '0')) query_reader.allow_kmer_batches(k);
+        struct stat st;
+        if (opt.query_fn == "-" || stat(opt.query_fn.c_str(), &st) == 0) start_reader();
+    }
 
     // private accelerators (results unchanged).  How much of them: end to end this program moves 3-4 G windows/s at human scale
     // with a 14-deep prefix table -- the device stage (LF walk at about 5 G k-mers/s) is then the longest, just ahead of write()
@@ -874,7 +966,10 @@ extern "C" int fmsi_cli_query(int argc, char** argv, int output_orders_i) {
     auto setup = [&](DeviceCtx& c, bool first) -> bool {
         int rc_create = FMSI_HIP_ENOMEM;
         for (;;) {
-            rc_create = fmsi_hip_index_load(opt.index_prefix.c_str(), stream_kernel, c.device, std::max(t, 0), &c.dev);
+            // (the table's signatures are written beside the first batches: FMSI_HIP_LOAD_ASYNC_TABLE, include/fmsi_hip.h)
+            static const bool sync_table = std::getenv("FMSI_HIP_CLI_SYNC_TABLE") != nullptr;   // (A/B runs)
+            rc_create = fmsi_hip_index_load(opt.index_prefix.c_str(), (stream_kernel ? FMSI_HIP_LOAD_KLCP : 0) | (sync_table ? 0 : FMSI_HIP_LOAD_ASYNC_TABLE), c.device,
+                                            std::max(t, 0), &c.dev);
             if (rc_create != 0 && rc_create != FMSI_HIP_ENOMEM && first && stream_kernel && !load_klcp) {
                 // a kLCP file that does not load must not fail a run that never asked for it: the searches of round 3 answer instead
                 stream_kernel = false;
@@ -980,6 +1075,7 @@ extern "C" int fmsi_cli_query(int argc, char** argv, int output_orders_i) {
     struct OutBuf {
         std::vector<char> bits;             // presence modes: the whole batch
         std::vector<std::string> parts;     // lookup: one piece per formatting thread
+        std::unique_ptr<Prepared> kmer_batch;   // a k-mer batch: its parts' lines are the output (kept until they are written)
     };
     auto write_all = [](const char* p, size_t n) {
         while (n) {
@@ -1000,11 +1096,14 @@ extern "C" int fmsi_cli_query(int argc, char** argv, int output_orders_i) {
                 auto t1 = clock::now();
                 {
                     TraceRange write_range("fmsi: write");
-                    if (output_orders)
+                    if (b->kmer_batch)
+                        for (const auto& kp : b->kmer_batch->raw.kparts) write_all(kp->text.get(), kp->text_len);
+                    else if (output_orders)
                         for (const std::string& s : b->parts) write_all(s.data(), s.size());
                     else write_all(b->bits.data(), b->bits.size());
                 }
                 write_s += std::chrono::duration<double>(clock::now() - t1).count();
+                b->kmer_batch.reset();   // (its parts go back to the parser's pool)
                 (void)spare_q.push(std::move(b));
             }
         } catch (...) {
@@ -1018,12 +1117,15 @@ extern "C" int fmsi_cli_query(int argc, char** argv, int output_orders_i) {
             for (int i = 0; i < 2; ++i) (void)spare_q.push(std::make_unique<OutBuf>());
             std::unique_ptr<Prepared> P;
             while (out_q.pop(P)) {
-                const size_t n = output_orders ? 0 : P->rec_out[P->raw.recs.size()];
+                const size_t n = output_orders || P->raw.kmer_k ? 0 : P->rec_out[P->raw.recs.size()];
                 std::unique_ptr<OutBuf> b;
                 if (!spare_q.pop(b)) break;   // the sink failed
                 auto t0 = clock::now();
                 trace_push("fmsi: format");
-                if (output_orders) {
+                if (P->raw.kmer_k) {
+                    patch_kmer_lines(*P, team);
+                    b->kmer_batch = std::move(P);
+                } else if (output_orders) {
                     format_orders(*P, team, b->parts);
                 } else {
                     b->bits.resize(n);
@@ -1067,7 +1169,20 @@ extern "C" int fmsi_cli_query(int argc, char** argv, int output_orders_i) {
                     auto P = std::make_unique<Prepared>(std::move(raw));
                     auto t0 = clock::now();
                     trace_push("fmsi: pack batch");
-                    prepare_batch(*P, k, worker_team, general && k % 2 == 0);
+                    const bool kmer_batch = P->raw.kmer_k != 0;
+                    if (kmer_batch) {   // the parser packed the k-mers: the parts' words side by side in page-locked memory, nothing else
+                        P->windows = P->raw.kmer_recs;
+                        P->packed.resize(P->windows + 1);
+                        std::vector<uint64_t> part_at(P->raw.kparts.size() + 1, 0);
+                        for (size_t i = 0; i < P->raw.kparts.size(); ++i) part_at[i + 1] = part_at[i] + P->raw.kparts[i]->kmers.size();
+                        const unsigned copiers = static_cast<unsigned>(std::max<size_t>(1, std::min<size_t>(worker_team, P->raw.kparts.size())));
+                        parallel_for(copiers, [&](unsigned t) {
+                            for (size_t i = t; i < P->raw.kparts.size(); i += copiers)
+                                std::memcpy(P->packed.data() + part_at[i], P->raw.kparts[i]->kmers.data(), P->raw.kparts[i]->kmers.size() * 8);
+                        });
+                    } else {
+                        prepare_batch(*P, k, worker_team, general && k % 2 == 0);
+                    }
                     trace_pop();
                     auto t1 = clock::now(), td = t1;
                     const uint64_t nw = P->windows;
@@ -1087,7 +1202,9 @@ extern "C" int fmsi_cli_query(int argc, char** argv, int output_orders_i) {
                         const bool bg_dict = !cp->have_dict && cp->dict_ready.load(std::memory_order_acquire);
                         fmsi_hip_index* const handle = bg_dict ? cp->dict_dev : cp->dev;
                         if (bg_dict) ++cp->dict_batches;
-                        if (general)   // -f and|xor|r-s: f(ones, total) of both strands (query_kmers<general>, src/fms_index.h:316-327)
+                        if (kmer_batch)   // isolated k-mers (query_kmers_single, src/fms_index.h:263-331; under -S a chunk of one window, :181-254: the same)
+                            check(fmsi_hip_query_kmers(handle, P->packed.data(), nw, k, flags, dst, nullptr, nullptr), "fmsi_hip_query_kmers");
+                        else if (general)   // -f and|xor|r-s: f(ones, total) of both strands (query_kmers<general>, src/fms_index.h:316-327)
                             check(fmsi_hip_query_runs_fn(cp->dev, P->packed.data(), P->lower.empty() ? nullptr : P->lower.data(), P->bases, P->run_start.data(), P->run_windows.data(), P->run_start.size(), nw, k,
                                                          opt.fn, opt.fn_r, opt.fn_s, FMSI_HIP_OUT_BITS, dst, nullptr, nullptr),
                                   "fmsi_hip_query_runs_fn");
@@ -1144,7 +1261,10 @@ extern "C" int fmsi_cli_query(int argc, char** argv, int output_orders_i) {
             auto t2 = clock::now();
             if (strict) {
                 TraceRange replay_range("fmsi: predictor replay");
-                replay_batch(*P, predictor, opt.mode, output_orders, load_klcp, k, team, rows64);
+                // (a k-mer batch under -S: every record is one chunk of one window, whose streaming step IS the single step -- the first strand's
+                // result, the second's if that does not settle it, log_result of the two: src/fms_index.h:181-254 against :263-331)
+                if (P->raw.kmer_k) replay_presence_tight(P->bytes.data(), P->windows, predictor, opt.mode);
+                else replay_batch(*P, predictor, opt.mode, output_orders, load_klcp, k, team, rows64);
             }
             replay_s += std::chrono::duration<double>(clock::now() - t2).count();
             total_windows += P->windows;
@@ -1182,11 +1302,15 @@ extern "C" int fmsi_cli_query(int argc, char** argv, int output_orders_i) {
         fprintf(stderr,
                 "{\"windows\": %llu, \"total_seconds\": %.6f, \"load_seconds\": %.6f, \"device_seconds\": %.6f, \"read_seconds\": %.6f, "
                 "\"prepare_seconds\": %.6f, \"replay_seconds\": %.6f, \"format_seconds\": %.6f, \"write_seconds\": %.6f, \"threads\": %u, "
-                "\"devices\": %zu, \"strict\": %s, \"block_parallel_read_bytes\": %llu, \"dictionary\": \"%s\", \"dictionary_batches\": %llu}\n",
+                "\"devices\": %zu, \"strict\": %s, \"block_parallel_read_bytes\": %llu, \"dictionary\": \"%s\", \"dictionary_batches\": %llu, \"kmer_batches\": %llu, "
+                "\"epoch_start\": %.6f, \"epoch_end\": %.6f}\n",
                 static_cast<unsigned long long>(total_windows), total, load, gpu_s, query_reader.read_s, prep_s, replay_s, format_s, write_s, team,
                 ctx.size(), strict ? "true" : "false", static_cast<unsigned long long>(query_reader.parallel_read_bytes),
                 ctx[0].have_dict ? "before the first batch" : (want_bg_dict && !rows64 ? "beside the queries" : "none"),
-                static_cast<unsigned long long>(ctx[0].dict_batches));
+                static_cast<unsigned long long>(ctx[0].dict_batches), static_cast<unsigned long long>(query_reader.kmer_batches),
+                // (wall-clock stamps of this function's first and last line: what the process spends before and behind them -- the loader,
+                // the runtime's start-up, the teardown of its mappings and of the device context -- is the parent's to see)
+                epoch_start, std::chrono::duration<double>(std::chrono::system_clock::now().time_since_epoch()).count());
     }
     // (the `fmsi` binary exits right behind this call, main.cpp: it neither tears the device down nor waits for a dictionary that is still
     // being built when the input has ended)

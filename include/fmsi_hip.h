@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define FMSI_HIP_ABI_VERSION 7   /* 7: FMSI_HIP_KERNEL_SORTED; 6: FMSI_HIP_DICT_SUPERKMER + fmsi_hip_index_info.sk_*, fmsi_hip_index_enable_stream_layout, FMSI_HIP_NO_DICT_CHAIN; 5: fmsi_hip_keep_scratch; 4: fmsi_hip_query_runs_fn (`-f and|xor|r-s`); 2: fmsi_hip_index_info.candidate_entry_bytes, fmsi_hip_comm_*, fmsi_hip_gather; 3: FMSI_HIP_OUT_BITS, fmsi_hip_index_load, fmsi_hip_trim_scratch, fmsi_hip_index_enable_dict + fmsi_hip_index_info.dict_*, fmsi_hip_index_build_synthetic_spec */
+#define FMSI_HIP_ABI_VERSION 8   /* 8: FMSI_HIP_LOAD_ASYNC_TABLE, fmsi_hip_index_wait_background, fmsi_hip_index_release_scratch; 7: FMSI_HIP_KERNEL_SORTED; 6: FMSI_HIP_DICT_SUPERKMER + fmsi_hip_index_info.sk_*, fmsi_hip_index_enable_stream_layout, FMSI_HIP_NO_DICT_CHAIN; 5: fmsi_hip_keep_scratch; 4: fmsi_hip_query_runs_fn (`-f and|xor|r-s`); 2: fmsi_hip_index_info.candidate_entry_bytes, fmsi_hip_comm_*, fmsi_hip_gather; 3: FMSI_HIP_OUT_BITS, fmsi_hip_index_load, fmsi_hip_trim_scratch, fmsi_hip_index_enable_dict + fmsi_hip_index_info.dict_*, fmsi_hip_index_build_synthetic_spec */
 
 /* error codes */
 #define FMSI_HIP_OK 0
@@ -152,12 +152,26 @@ int fmsi_hip_device_count(void);
 int fmsi_hip_index_create(const fmsi_index_view* view, int device, fmsi_hip_index** out);
 void fmsi_hip_index_destroy(fmsi_hip_index* idx);
 int fmsi_hip_index_get_info(const fmsi_hip_index* idx, fmsi_hip_index_info* info);
+/* Returns the handle's staging and scratch buffers to the driver (the copies of host-pointer calls' inputs and outputs, the window and
+ * task arrays, the batch-sorted walk's sort buffers -- about 66 bytes per k-mer of its sub-batch: 4.5 GB when FMSI_HIP_KERNEL_AUTO chose
+ * it, 17-18 GB for an explicit FMSI_HIP_KERNEL_SORTED on 2^28 k-mers and more).  They are grow-only otherwise and stay until the handle is
+ * destroyed; the next call allocates what it needs again.  Waits for the device. */
+int fmsi_hip_index_release_scratch(fmsi_hip_index* idx);
 
 /* load_index() (src/fms_index.h:502-526) straight into HBM: the files' payloads are uploaded as they are and the device decodes the
  * rrr_vector<63> mask and interleaves the blocks itself -- the same handle as fmsi_host_index_load + fmsi_hip_index_create give, dword
  * for dword, without the host-side decode and layout pass (what the CLI's load time mostly was).  use_klcp: take <prefix>.fmsi.klcp if
- * it exists.  Malformed / missing files: FMSI_HIP_EIO.  Indexes of 2^32 rows and more take the host path internally. */
+ * it exists.  Malformed / missing files: FMSI_HIP_EIO.  Indexes of 2^32 rows and more take the host path internally.
+ * `use_klcp` is a set of flags: bit 0 as above; FMSI_HIP_LOAD_ASYNC_TABLE -- the handle is returned as soon as the prefix table's
+ * intervals stand, and the signatures of its entries of 1..3 rows (the shortcut that ends a search four bases early, the streaming
+ * kernel's absence certificates) are written on a stream of the library's own BESIDE the caller's first queries: two thirds of the
+ * table's construction (0.11 of 0.17 s at human scale, t = 15).  Results never depend on it -- an entry is rewritten by one aligned
+ * 8-byte store and both of its forms give the same interval; queries in that time are just not yet at full speed.  Calls that read the
+ * table as a whole (fmsi_hip_index_enable_verify / _dict, fmsi_hip_index_destroy) wait for the pass; so does fmsi_hip_index_wait_background. */
+#define FMSI_HIP_LOAD_KLCP 0x1
+#define FMSI_HIP_LOAD_ASYNC_TABLE 0x2
 int fmsi_hip_index_load(const char* prefix, int use_klcp, int device, int prefix_len, fmsi_hip_index** out);
+int fmsi_hip_index_wait_background(fmsi_hip_index* idx);
 
 /* On-device construction -- counterpart of construct<T>() (src/fms_index.h:397-460) producing the device layout
  * directly: 2-bit text -> GPU suffix sort -> BWT / SA-transformed mask / kLCP -> interleaved blocks.

@@ -22,6 +22,11 @@ sys.path.insert(0, str(REPO))
 REF_CLI = REPO / "oracle" / "_ref" / "fmsi_ref"
 
 SPEC = {"len": 100_000_000, "seed": 2024, "k": 31, "mask_permille": 600}
+# `make_scale_md5.py 1e9`: the same text at 10^9 bases (the reference's qsufsort: ~16 min and 17 GB here) -> md5_scale_1e9.json
+OUT = "md5_scale.json"
+if len(sys.argv) > 1:
+    SPEC = dict(SPEC, len=int(float(sys.argv[1])))
+    OUT = f"md5_scale_{sys.argv[1]}.json"
 
 
 def main():
@@ -44,7 +49,7 @@ def main():
             out["md5"][part] = hashlib.md5(data).hexdigest()
             out["bytes"][part] = len(data)
         out["misc"] = open(f"{fa}.fmsi.misc").read().split()
-    (HERE / "idx" / "md5_scale.json").write_text(json.dumps(out, indent=1) + "\n")
+    (HERE / "idx" / OUT).write_text(json.dumps(out, indent=1) + "\n")
     print(json.dumps(out, indent=1))
 
 

@@ -134,5 +134,54 @@ int main() {
         if (!same_state(a, b) || std::memcmp(want.data(), P.orders.data(), nw * 8) != 0) return fail("lookup replay", it, nw);
     }
     printf("cli host kernels OK\n");
+    // the predictor's recurrence as a table (k-mer batches) against replay_single(), window by window, from every kind of state
+    for (size_t it = 0; it < 400; ++it) {
+        const size_t n = 1 + rng() % 5000;
+        const Mode mode = it % 2 ? Mode::All : Mode::Or;
+        std::vector<uint8_t> in(n), a, bb;
+        const int style = static_cast<int>(rng() % 4);
+        for (auto& x : in) {
+            int f, r;
+            if (style == 0) { f = static_cast<int>(rng() % 3) - 1; r = static_cast<int>(rng() % 3) - 1; }
+            else if (style == 1) { f = rng() % 2 ? 1 : -1; r = -1; if (rng() % 7 == 0) std::swap(f, r); }
+            else if (style == 2) { f = -1; r = rng() % 3 ? -1 : static_cast<int>(rng() % 2); }
+            else { f = static_cast<int>(rng() % 2); r = static_cast<int>(rng() % 2); }
+            x = static_cast<uint8_t>((f + 1) | ((r + 1) << 2));
+        }
+        StrandPredictor p0;
+        if (it % 3) {   // a state from the middle of a run (otherwise: the initial one, previous == -1)
+            p0.score = static_cast<int>(rng() % 15) - 7;
+            p0.result_scores[0] = static_cast<int>(rng() % 15) - 7;
+            p0.result_scores[1] = static_cast<int>(rng() % 15) - 7;
+            p0.previous = static_cast<int>(rng() % 2);
+        }
+        StrandPredictor pa = p0, pb = p0;
+        a = in;
+        for (size_t w = 0; w < n; ++w) a[w] = static_cast<uint8_t>(replay_single(pa, mode, false, fwd_of(in[w]), rc_of(in[w])) == 1);
+        bb = in;
+        replay_presence_tight(bb.data(), n, pb, mode);
+        if (a != bb || !same_state(pa, pb)) return fail("replay_presence_tight", it, n);
+    }
+    // one k-mer of text -> its 2-bit word (PEXT and plain and the tail form), invalid characters refused
+    for (size_t it = 0; it < 20000; ++it) {
+        const int k = 1 + static_cast<int>(rng() % 32);
+        std::string s(64, 'A');
+        for (auto& c : s) c = "ACGTacgt"[rng() % 8];
+        const int bad = rng() % 4 == 0 ? static_cast<int>(rng() % 40) : -1;
+        if (bad >= 0) s[static_cast<size_t>(bad)] = "NnX@[`{\n\xC1\x01 >"[rng() % 12];
+        uint64_t want = 0, a = 0, b = 0, c = 0;
+        bool want_ok = true;
+        for (int j = 0; j < k; ++j) {
+            const uint8_t code = kCode.t[static_cast<unsigned char>(s[static_cast<size_t>(j)])];
+            if (code == 4) want_ok = false;
+            want |= static_cast<uint64_t>(code & 3) << (2 * j);
+        }
+        const bool oa = kmer_word_plain(s.data(), k, &a), oc = kmer_word_tail(s.data(), k, &c);
+        if (oa != want_ok || oc != want_ok || (want_ok && (a != want || c != want))) return fail("kmer_word_plain/tail", it, static_cast<size_t>(k));
+        if (__builtin_cpu_supports("bmi2")) {
+            const bool ob = kmer_word_bmi2(s.data(), k, &b);
+            if (ob != want_ok || (want_ok && b != want)) return fail("kmer_word_bmi2", it, static_cast<size_t>(k));
+        }
+    }
     return 0;
 }

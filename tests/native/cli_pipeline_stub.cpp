@@ -83,6 +83,11 @@ int fmsi_hip_index_enable_verify(fmsi_hip_index*) { return 0; }
 int fmsi_hip_sync(fmsi_hip_index*, void*) { return 0; }
 void fmsi_hip_keep_scratch(int) {}
 int fmsi_hip_trim_scratch(int) { return 0; }
+int fmsi_hip_query_kmers(fmsi_hip_index*, const uint64_t* kmers, uint64_t n_kmers, int k, uint32_t flags, void* out, uint64_t*, void*) {
+    if (flags & FMSI_HIP_OUT_BITS) std::memset(out, 0, ((flags & FMSI_HIP_STRICT) ? (n_kmers + 15) / 16 : (n_kmers + 63) / 64) * 8);
+    for (uint64_t q = 0; q < n_kmers; ++q) answer(kmers + q, 0, k, flags, 0, out, q);   // (the k-mer's word is a one-window sequence)
+    return 0;
+}
 int fmsi_hip_query_runs(fmsi_hip_index*, const uint64_t* seq, uint64_t, const uint64_t* run_start, const uint32_t* run_windows, uint64_t n_runs,
                         uint64_t n_windows, int k, uint32_t flags, void* out, uint64_t*, void*) {
     return run_all(seq, run_start, run_windows, n_runs, n_windows, k, flags, 0, out);

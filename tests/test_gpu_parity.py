@@ -2,13 +2,14 @@
 libfmsi_hip.so (and through the `fmsi` CLI), against the CPU oracle and the committed golden outputs of
 the real reference.  Everything is integer work: the bar is bit-exact.
 """
+import json
 import random
 
 import numpy as np
 import pytest
 
 import oracle_py
-from conftest import CLI_DATASETS, DATASETS, FN_CASES, GOLDEN, MODES, REPO, bgzf_bytes, golden_fn_out, golden_out, index_prefix, messy_fasta, mixed_kmers, query_file, revcomp, synthetic_ms
+from conftest import CLI_DATASETS, DATASETS, FN_CASES, GOLDEN, MODES, REPO, bgzf_bytes, ms_of, golden_fn_out, golden_out, index_prefix, messy_fasta, mixed_kmers, query_file, revcomp, synthetic_ms
 
 pytestmark = pytest.mark.gpu
 
@@ -615,6 +616,64 @@ def test_block_parallel_reader_equals_the_ordinary_one(fm, oracle_built, tmp_pat
     rc, ref, err = oracle_py.run_cli(checker, [a for a in args if a not in ("--batch", "4096")])
     assert rc == 0 and got == ref
     assert got.count(b"\n") > (100 if fastq_at != 0 else 50)
+
+
+@pytest.mark.parametrize("mode", ["or", "all", "or_S", "all_S"])
+@pytest.mark.parametrize("name,k,shape", [("sars_k31", 31, "pure"), ("sars_k13", 13, "odd"), ("mixed_k11", 11, "pure"), ("mixed_k11", 11, "no_tail"), ("both_strands", 13, "odd")])
+def test_cli_kmer_batches_equal_the_reference(fm, oracle_built, tmp_path, monkeypatch, name, k, shape, mode):
+    """A query file of ONE k-mer per record -- the shape of BASELINE's isolated-k-mer configurations -- takes a path of its own through
+    `fmsi query` (cli_reader.h KmerPart: parsed, validated, packed and its output line written in one pass; fmsi_hip_query_kmers; the
+    predictor's recurrence as a table): byte-identical to the real reference's record loop (src/main.cpp:328-373) and to the general
+    path, in the four presence modes -- `-S` on a one-window chunk is the single step, src/fms_index.h:181-254 -- incl. a non-max-ones
+    mask under -O, where what is printed depends on the predictor's state, and files where records of other shapes (CRLF, N, shorter,
+    longer, two lines, blank lines, FASTQ) send their range back to the ordinary rules."""
+    if name == "both_strands":   # a text with reverse-complemented copies of its own pieces under a random mask: k-mers on both strands with different bits
+        rng = random.Random(77)
+        base = "".join(rng.choice("ACGT") for _ in range(30000))
+        pieces = [base]
+        for _ in range(12):
+            p0 = rng.randrange(0, len(base) - 3000)
+            pieces.append(revcomp(base[p0:p0 + rng.choice([500, 1500, 3000])]))
+        ms = "".join(ch if rng.random() < 0.6 else ch.lower() for ch in "".join(pieces))
+        ms = ms[: len(ms) - (k - 1)] + ms[len(ms) - (k - 1):].lower()
+        prefix = str(tmp_path / "both")
+        oracle_py.Oracle.construct(ms, k, use_klcp=True).dump(prefix)
+    else:
+        prefix = index_prefix(name)
+        ms = ms_of(name)
+    up = ms.upper()
+    rng = random.Random(k * 7 + len(shape))
+    recs = []
+    for i in range(20000):
+        p0 = rng.randrange(0, len(up) - k)
+        s = up[p0:p0 + k] if rng.random() < 0.6 else "".join(rng.choice("ACGT") for _ in range(k))
+        if rng.random() < 0.3:
+            s = s[::-1].translate(str.maketrans("ACGT", "TGCA"))
+        if rng.random() < 0.1:
+            s = s.lower()
+        head = f"{i}" if rng.random() < 0.7 else f"q{i} comment >x"
+        rec = f">{head}\n{s}\n"
+        if shape == "odd" and i % 1511 == 1510:
+            rec = rng.choice([f">{head}\r\n{s}\r\n", f">{head}\n{s[:3]}N{s[4:]}\n", f">{head}\n{s[:-1]}\n", f">{head}\n{s}AC\n", f">{head}\n{s[:6]}\n{s[6:]}\n",
+                              f">{head}\n{s}\n\n", f"@{head}\n{s}\n+\n{'I' * k}\n"])
+        recs.append(rec)
+    text = "".join(recs)
+    q = tmp_path / "kmers.fa"
+    q.write_bytes((text.rstrip("\n") if shape == "no_tail" else text).encode())
+    args = [*MODES[mode][0], "-k", str(k), "--stats", "-q", str(q), prefix]
+    checker = oracle_py.REF_CLI if oracle_py.ref_available() else oracle_py.ORACLE_CLI
+    rc, ref, err = oracle_py.run_cli(checker, [a for a in args if a != "--stats"])
+    assert rc == 0, err.decode()
+    monkeypatch.setenv("FMSI_HIP_READER_MIN_BYTES", "1")
+    for opts in ([], ["--batch", "20000", "--threads", "5"], ["--tables", "full"]):
+        rc, got, err = fm.run_cli(args[:1] + opts + args[1:])
+        assert rc == 0, err.decode()
+        assert got == ref, (opts, mode)
+        stats = json.loads([l for l in err.decode().splitlines() if l.startswith("{")][-1])
+        assert stats["kmer_batches"] > 0 and stats["windows"] >= 19900
+    monkeypatch.setenv("FMSI_HIP_CLI_KMER_BATCHES", "0")
+    rc, general, err = fm.run_cli(args)
+    assert rc == 0 and general == ref and b'"kmer_batches": 0' in err
 
 
 @pytest.mark.parametrize("shape", ["four_line", "four_line_crlf", "wrapped_adversarial", "truncated_tail", "short_quality_inside", "no_final_newline"])

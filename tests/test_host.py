@@ -6,6 +6,7 @@ that the product fails LOUDLY without a GPU instead of falling back to anything.
 import ctypes as C
 import re
 import random
+import json
 import os
 import subprocess
 
@@ -28,7 +29,7 @@ def test_library_exports_every_declared_symbol(product_built):
     assert len(names) >= 18
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/fmsi_hip.h but not exported"
-    assert lib.fmsi_hip_abi_version() == 7
+    assert lib.fmsi_hip_abi_version() == 8
 
 
 def test_no_oracle_in_product():
@@ -353,6 +354,50 @@ def test_cli_host_pipeline_under_sanitizers(tmp_path, sanitizer):
             assert res.returncode == 0
             outs.add(res.stdout)
             assert len(outs) == 1 and len(res.stdout) > 10000, (mode, tag)
+    # ---- records of ONE k-mer each (cli_reader.h: KmerPart): the parser packs the k-mer and writes the record's line, the answer is filled
+    # in behind the device.  The output is the general path's (FMSI_HIP_CLI_KMER_BATCHES=0), whatever the batch size and the team, for
+    # files of that shape alone, with header comments, without the last newline -- and for files where a record of another shape sends
+    # its range back to the ordinary rules (CRLF, N, a short or long or two-line sequence, a blank line, a FASTQ record, a lower-case k-mer
+    # is fine): some ranges are k-mer batches then, some are not, and the predictor's state crosses them.
+    k = 13
+    up = ms.upper()
+
+    def kmer_records(n, odd_every=0, tail_newline=True):
+        recs = []
+        for i in range(n):
+            p0 = rng.randrange(0, len(up) - k)
+            s = up[p0:p0 + k] if rng.random() < 0.5 else "".join(rng.choice("ACGT") for _ in range(k))
+            if rng.random() < 0.1:
+                s = s.lower()
+            head = f"{i}" if rng.random() < 0.7 else f"name_{i} a comment >x @y\tz"
+            if i == 7:
+                head = ""
+            rec = f">{head}\n{s}\n"
+            if odd_every and i % odd_every == odd_every - 1:
+                rec = rng.choice([f">{head}\r\n{s}\r\n", f">{head}\n{s[:5]}N{s[6:]}\n", f">{head}\n{s[:-1]}\n", f">{head}\n{s}A\n", f">{head}\n{s[:6]}\n{s[6:]}\n",
+                                  f">{head}\n{s}\n\n", f"@{head}\n{s}\n+\n{'I' * k}\n", f">{head}\n\n", f">{head}\v\n{s}\n"])
+            recs.append(rec)
+        text = "".join(recs)
+        return (text if tail_newline else text.rstrip("\n")).encode()
+
+    kfiles = {"pure": kmer_records(6000), "no_tail": kmer_records(3000, tail_newline=False), "odd": kmer_records(6000, odd_every=997), "odd_often": kmer_records(3000, odd_every=40)}
+    for tag, data in kfiles.items():
+        plain, gz = tmp_path / f"k_{tag}.fa", tmp_path / f"k_{tag}.fa.gz"
+        plain.write_bytes(data)
+        gz.write_bytes(bgzf_bytes(data, block=3000))
+        for mode in (["query"], ["query", "-O"], ["query", "-S", "-O"], ["lookup"]):
+            general = subprocess.run([str(exe), *mode, "-q", str(plain), prefix], capture_output=True, env={**env, "FMSI_HIP_CLI_KMER_BATCHES": "0"})
+            assert general.returncode == 0 and general.stdout.count(b"\n") >= 3000, (tag, mode, general.stderr.decode()[-2000:])
+            for q in (plain, gz):
+                for opts in ([], ["--batch", "4096", "--threads", "3"], ["--batch", "30000", "--threads", "7", "--devices", "0,0"]):
+                    res = subprocess.run([str(exe), *mode, *opts, "--stats", "-q", str(q), prefix], capture_output=True, env=env)
+                    assert res.returncode == 0, (tag, mode, opts, res.stderr.decode()[-3000:])
+                    assert res.stdout == general.stdout, (tag, mode, q.name, opts)
+                    stats = json.loads([l for l in res.stderr.decode().splitlines() if l.startswith("{")][-1])
+                    if mode[0] != "query":
+                        assert stats["kmer_batches"] == 0
+                    elif tag in ("pure", "no_tail") or (tag == "odd" and opts and opts[1] == "4096"):
+                        assert stats["kmer_batches"] > 0, (tag, mode, opts)   # (the path was taken: at least by the ranges without an odd record)
 
 
 def test_threaded_rrr_decode_under_tsan_and_corrupt_mask(oracle_built, tmp_path):

@@ -66,8 +66,36 @@ def write_fasta(path: Path, packed: np.ndarray, n_reads: int, read_len: int, fir
             f.write(out)
 
 
+def write_kmer_fasta(path: Path, kmers: np.ndarray, k: int, first: int) -> None:
+    """One k-mer per record (BASELINE configs 2 / 3 / 5's shape: `>INDEX\nKMER\n`), names = the record's number in decimal; rows of one
+    name width are built as one 2-d byte array (no Python loop over records)."""
+    lut4 = np.frombuffer(b"ACGT", dtype=np.uint8)[(np.arange(256)[:, None] >> (2 * np.arange(4))) & 3].astype(np.uint8)   # byte -> its four bases
+    n = len(kmers)
+    with open(path, "ab") as f:
+        lo = first
+        while lo < first + n:
+            d = len(str(lo))
+            hi = min(first + n, 10 ** d)
+            for c0 in range(lo, hi, 4_000_000):
+                c1 = min(hi, c0 + 4_000_000)
+                m = c1 - c0
+                rows = np.empty((m, d + k + 3), dtype=np.uint8)
+                rows[:, 0] = ord(">")
+                idx = np.arange(c0, c1, dtype=np.int64)
+                for j in range(d):
+                    rows[:, d - j] = (idx // 10 ** j % 10 + 48).astype(np.uint8)
+                rows[:, d + 1] = 10
+                rows[:, d + 2:d + 2 + k] = lut4[kmers[c0 - first:c1 - first].view(np.uint8).reshape(m, 8)].reshape(m, 32)[:, :k]
+                rows[:, -1] = 10
+                f.write(rows.tobytes())
+            lo = hi
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
+    ap.add_argument("--kmer-records", type=int, default=0,
+                    help="after the reads: a second query file of this many records of ONE k-mer each (half present, drawn on the device), through --kmer-modes")
+    ap.add_argument("--kmer-modes", default="or,all")
     ap.add_argument("--n", type=int, default=100_000_000)
     ap.add_argument("--reads", type=int, default=20_000)
     ap.add_argument("--read-len", type=int, default=10_000)
@@ -99,6 +127,7 @@ def main() -> None:
 
     fasta = work / "reads.fa"
     fasta.unlink(missing_ok=True)
+    fasta.touch()
     t0 = time.time()
     step = max(1, (1 << 30) // a.read_len)           # <= 1 G bases per device draw
     for r0 in range(0, a.reads, step):
@@ -136,6 +165,21 @@ def main() -> None:
         report["compressed_bytes"] = gz.stat().st_size
         report["compress_seconds"] = round(time.time() - t0, 3)
         report["compress"] = a.compress
+    kfasta = work / "kmers.fa"
+    if a.kmer_records:
+        if a.k > 32:
+            raise SystemExit("--kmer-records needs k <= 32")
+        t0 = time.time()
+        kfasta.unlink(missing_ok=True)
+        for r0 in range(0, a.kmer_records, 1 << 25):
+            nr = min(1 << 25, a.kmer_records - r0)
+            d = torch.empty(nr, dtype=torch.int64, device="cuda")
+            dev.synthetic_queries_dev(a.k, 42, r0, nr, d.data_ptr(), torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            write_kmer_fasta(kfasta, d.cpu().numpy().view(np.uint64), a.k, r0)
+            del d
+        report["kmer_fasta_bytes"] = kfasta.stat().st_size
+        report["kmer_fasta_seconds"] = round(time.time() - t0, 3)
     dev.close()
     del dev
     torch.cuda.empty_cache()
@@ -149,48 +193,65 @@ def main() -> None:
     ref_cli = REPO / "oracle" / "_ref" / "fmsi_ref"
     windows_per_read = max(0, a.read_len - a.k + 1)
 
-    for mode in a.modes.split(","):
-        # "or+--threads+8": mode `or` with extra arguments; "NAME=value+or": with an environment variable
-        parts = mode.split("+")
-        env = dict(os.environ)
-        while "=" in parts[0] and not parts[0].startswith("-"):
-            key, _, val = parts.pop(0).partition("=")
-            env[key] = val
-        args = MODES[parts[0]] + parts[1:]
-        outp = work / f"out_{parts[0]}.txt"
-        t0 = time.time()
-        with open(outp, "wb") as so:
-            p = subprocess.run([str(fm.CLI_PATH), *args, "--stats", "-q", str(fasta), prefix], stdout=so, stderr=subprocess.PIPE, env=env)
-        wall = time.time() - t0
-        entry = {"rc": p.returncode, "wall_seconds": round(wall, 3)}
-        for line in p.stderr.decode().splitlines():
-            if line.startswith("{"):
-                entry.update(json.loads(line))
-            elif "FMSI_HIP_VERBOSE" in env:
-                print("   ", line, flush=True)
-        if p.returncode != 0:
-            entry["stderr"] = p.stderr.decode()[-400:]
-        w = entry.get("windows", 0)
-        if w:
-            entry["windows_per_s_wall"] = round(w / wall)
-            entry["windows_per_s_after_load"] = round(w / max(1e-9, entry["total_seconds"] - entry["load_seconds"]))
-        entry["output_bytes"] = outp.stat().st_size
-        # reference on the sample: identical bytes?
-        ref_args = [x for x in MODES[parts[0]] if x not in ("--fast", "--tables", "full", "background", "--devices", "0,0")]
-        if ref_cli.exists() and a.ref_reads:
+    def run_modes(mode_list, fasta, sample, units_per_record, n_ref_records, dest):
+        for mode in mode_list:
+            # "or+--threads+8": mode `or` with extra arguments; "NAME=value+or": with an environment variable
+            parts = mode.split("+")
+            env = dict(os.environ)
+            while "=" in parts[0] and not parts[0].startswith("-"):
+                key, _, val = parts.pop(0).partition("=")
+                env[key] = val
+            args = MODES[parts[0]] + parts[1:]
+            outp = work / f"out_{parts[0]}.txt"
             t0 = time.time()
-            r = subprocess.run([str(ref_cli), *ref_args, "-k", str(a.k), "-q", str(sample), prefix], capture_output=True)
-            ref_s = time.time() - t0
-            g = subprocess.run([str(fm.CLI_PATH), *args, "-q", str(sample), prefix], capture_output=True, env=env)
-            entry["sample_identical_to_reference"] = bool(r.returncode == 0 and r.stdout == g.stdout)
-            entry["reference_windows_per_s"] = round(a.ref_reads * windows_per_read / ref_s)
-            with open(outp, "rb") as f:
-                head = f.read(len(r.stdout))
-            entry["full_run_prefix_identical"] = bool(head == r.stdout)
-        report["modes"][mode] = entry
-        print(mode, json.dumps(entry), flush=True)
-        outp.unlink()
+            with open(outp, "wb") as so:
+                p = subprocess.run([str(fm.CLI_PATH), *args, "--stats", "-q", str(fasta), prefix], stdout=so, stderr=subprocess.PIPE, env=env)
+            t1 = time.time()
+            wall = t1 - t0
+            entry = {"rc": p.returncode, "wall_seconds": round(wall, 3)}
+            for line in p.stderr.decode().splitlines():
+                if line.startswith("{"):
+                    entry.update(json.loads(line))
+                elif "FMSI_HIP_VERBOSE" in env:
+                    print("   ", line, flush=True)
+            if p.returncode != 0:
+                entry["stderr"] = p.stderr.decode()[-400:]
+            if "epoch_start" in entry:   # what the process spends outside the command's function: start-up (loader, runtime) and teardown
+                entry["startup_seconds"] = round(entry.pop("epoch_start") - t0, 3)
+                entry["teardown_seconds"] = round(t1 - entry.pop("epoch_end"), 3)
+            w = entry.get("windows", 0)
+            if w:
+                entry["windows_per_s_wall"] = round(w / wall)
+                entry["windows_per_s_after_load"] = round(w / max(1e-9, entry["total_seconds"] - entry["load_seconds"]))
+            entry["output_bytes"] = outp.stat().st_size
+            # reference on the sample: identical bytes?
+            ref_args = [x for x in MODES[parts[0]] if x not in ("--fast", "--tables", "full", "background", "--devices", "0,0")]
+            if ref_cli.exists() and n_ref_records:
+                t0 = time.time()
+                r = subprocess.run([str(ref_cli), *ref_args, "-k", str(a.k), "-q", str(sample), prefix], capture_output=True)
+                ref_s = time.time() - t0
+                g = subprocess.run([str(fm.CLI_PATH), *args, "-q", str(sample), prefix], capture_output=True, env=env)
+                entry["sample_identical_to_reference"] = bool(r.returncode == 0 and r.stdout == g.stdout)
+                entry["reference_windows_per_s"] = round(n_ref_records * units_per_record / ref_s)
+                with open(outp, "rb") as f:
+                    head = f.read(len(r.stdout))
+                entry["full_run_prefix_identical"] = bool(head == r.stdout)
+            dest[mode] = entry
+            print(mode, json.dumps(entry), flush=True)
+            outp.unlink()
 
+
+    if a.reads:
+        run_modes(a.modes.split(","), fasta, sample, windows_per_read, a.ref_reads, report["modes"])
+    if a.kmer_records:
+        ksample = work / "ksample.fa"
+        n_ref = min(a.kmer_records, 20000)
+        with open(kfasta, "rb") as f, open(ksample, "wb") as g:
+            for _ in range(2 * n_ref):
+                g.write(f.readline())
+        report["kmer_records"] = a.kmer_records
+        report["kmer_modes"] = {}
+        run_modes(a.kmer_modes.split(","), kfasta, ksample, 1, n_ref, report["kmer_modes"])
     print(json.dumps(report))
     if a.out:
         Path(a.out).parent.mkdir(parents=True, exist_ok=True)
