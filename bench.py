@@ -61,6 +61,8 @@ def parse_args(argv=None):
                     help="e2e: the whole `fmsi query` process (tools/e2e_bench.py: index files and a FASTA of --reads reads of --read-len bases in "
                          "/dev/shm, the CLI with --stats, a sample against the real reference) -- SURVEY 8(d)(ii); N = 1 only")
     ap.add_argument("--reads", type=int, default=100000, help="e2e workload: reads in the query file")
+    ap.add_argument("--e2e-kmer-records", type=int, default=100_000_000,
+                    help="e2e legs: records of the second query file, ONE k-mer each (BASELINE configs 2 / 3 / 5's shape: 100 M random queries); 0 = none")
     ap.add_argument("--n", "--index-bases", dest="n", type=float, default=2.8e9, help="superstring length in bases (human scale: 2.8e9)")
     ap.add_argument("--batch", type=float, default=float(1 << 27), help="query windows per step and GPU")
     ap.add_argument("--k", type=int, default=31)
@@ -115,7 +117,7 @@ def parse_args(argv=None):
                     help="do not measure roofline.traffic in this run (child runs of this script under rocprofv3 --pmc, FETCH_SIZE and "
                          "WRITE_SIZE in separate passes)")
     ap.add_argument("--no-config-legs", action="store_true", help="skip the `configs` legs (BASELINE configs 2, 3, 4 and the whole process)")
-    ap.add_argument("--legs", default="c2,c3,c3sk,c4,c4k,c4k48,c4sk,c5dict,e2e", help="which `configs` legs to run")
+    ap.add_argument("--legs", default="c2,c3,c3sk,c4,c4k,c4k16,c4k48,c4sk,c5dict,e2e", help="which `configs` legs to run")
     ap.add_argument("--leg", default=None, help=argparse.SUPPRESS)          # child mode: one leg, a JSON list on stdout
     ap.add_argument("--variants", default=None, help="with --leg: only these variants of the leg (comma-separated names), e.g. for a rocprofv3 run of one")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)   # child mode under rocprofv3: the plan's launches, nothing printed
@@ -664,10 +666,12 @@ def base_child_args(args, n, batch):
 # ======================================================================================================================================
 # the whole process
 # ======================================================================================================================================
-def e2e_report(args, modes="or,all,all_S"):
+def e2e_report(args, modes="or,all,all_S", kmer_records=0, kmer_modes="or,all"):
     import subprocess
     cmd = [sys.executable, str(REPO / "tools" / "e2e_bench.py"), "--n", str(int(args.n)), "--reads", str(args.reads), "--read-len", str(args.read_len),
            "--k", str(args.k), "--modes", modes, "--ref-reads", "20"]
+    if kmer_records and args.k <= 32:
+        cmd += ["--kmer-records", str(int(kmer_records)), "--kmer-modes", kmer_modes]
     res = subprocess.run(cmd, capture_output=True, text=True)
     report = None
     for l in res.stdout.splitlines():
@@ -676,12 +680,17 @@ def e2e_report(args, modes="or,all,all_S"):
     if res.returncode != 0 or report is None:
         sys.stderr.write(res.stderr[-2000:])
         raise RuntimeError("tools/e2e_bench.py failed")
-    modes_out = {name: {"wall_seconds": e["wall_seconds"], "process_seconds": e.get("total_seconds"), "load_seconds": e.get("load_seconds"),
-                        "windows_per_s_whole_process": e.get("windows_per_s_wall"), "windows_per_s_after_load": e.get("windows_per_s_after_load"),
-                        "stages": {s: e.get(s) for s in ("read_seconds", "prepare_seconds", "device_seconds", "replay_seconds", "format_seconds", "write_seconds") if e.get(s) is not None},
-                        "dictionary": e.get("dictionary"),
-                        "identical_to_reference_on_sample": e.get("sample_identical_to_reference"), "reference_windows_per_s": e.get("reference_windows_per_s")}
-                 for name, e in report["modes"].items()}
+    def digest(e):
+        return {"wall_seconds": e["wall_seconds"], "process_seconds": e.get("total_seconds"), "load_seconds": e.get("load_seconds"),
+                "windows_per_s_whole_process": e.get("windows_per_s_wall"), "windows_per_s_after_load": e.get("windows_per_s_after_load"),
+                "stages": {s: e.get(s) for s in ("read_seconds", "prepare_seconds", "device_seconds", "replay_seconds", "format_seconds", "write_seconds",
+                                                 "startup_seconds", "teardown_seconds") if e.get(s) is not None},
+                "dictionary": e.get("dictionary"), "kmer_batches": e.get("kmer_batches"), "windows": e.get("windows"),
+                "identical_to_reference_on_sample": e.get("sample_identical_to_reference") and e.get("full_run_prefix_identical"),
+                "reference_windows_per_s": e.get("reference_windows_per_s")}
+    modes_out = {name: digest(e) for name, e in report["modes"].items()}
+    for name, e in (report.get("kmer_modes") or {}).items():   # the query file of one k-mer per record (configs 2 / 3 / 5's shape)
+        modes_out["isolated_" + name] = digest(e)
     return report, modes_out
 
 
@@ -710,12 +719,14 @@ LEG_SPECS = {
     "c3": (1.4e9, "kmers", float(1 << 27), 8, [("c3", "dict", 0)]),
     "c4": (2.8e9, "stream", float(1 << 27), 8, [("c4_dict_chain", "runs_chain", 0), ("c4_dict_chain_subst1pct", "runs_chain", 10000),
                                                  ("c4_dict_plain", "runs_plain", 0), ("c4_dict_plain_subst1pct", "runs_plain", 10000)]),
-    # the kLCP kernel on a handle of its own: blocks, kLCP array, S-blocks and the 16-deep prefix table -- no dictionary (round 3 timed it on the
-    # chained dictionary's 93-GB handle)
+    # the kLCP kernel on a handle of its own: blocks, kLCP array, S-blocks and the prefix table at the depth the `fmsi` binary takes for a
+    # streaming run at this scale (query_cli.cpp: t = 15, 8.6 GB -- an 11 GB handle) -- no dictionary
     "c4k": (2.8e9, "stream", float(1 << 27), 8, [("c4_klcp", "klcp", 0), ("c4_klcp_subst1pct", "klcp", 10000),
                                                   # `fmsi lookup -S` (k-mer orders: src/fms_index.h:147-157 inside :181-254) on the same handle: both strands'
                                                   # orders as the CLI asks for them (it replays the strand predictor), and --fast's one order per window
                                                   ("c4_klcp_lookup", "klcp_orders", 0), ("c4_klcp_lookup_fast", "klcp_orders_fast", 0)]),
+    # the same kernel on the 16-deep table (34 GB; rounds 3-4 timed all kLCP legs there): what the extra 26 GB buy over the depth the `fmsi` binary takes
+    "c4k16": (2.8e9, "stream", float(1 << 27), 8, [("c4_klcp_t16", "klcp", 0), ("c4_klcp_t16_subst1pct", "klcp", 10000)]),
     # `fmsi query -S -O` with k = 48 (the reference's __uint128_t k-mers, src/main.cpp:223-230): an index of its own, the same read mix
     "c4k48": (2.8e9, "stream", float(1 << 27), 8, [("c4_klcp_k48", "klcp", 0)]),
     # the same reads through the super-k-mer dictionary ALONE (FMSI_HIP_DICT_SUPERKMER_ONLY: the k-mer dictionary is released after the
@@ -737,7 +748,8 @@ LEG_TEXT = {
           "every 31-mer window, fmsi query -S -O answers",
 }
 LEG_TEXT["c4sk"] = LEG_TEXT["c4"]
-LEG_TEXT["c4k"] = LEG_TEXT["c4"]
+LEG_TEXT["c4k"] = LEG_TEXT["c4"] + "; prefix table at the depth the `fmsi` binary takes for a streaming run (15: an 11 GB handle)"
+LEG_TEXT["c4k16"] = LEG_TEXT["c4"] + "; 16-deep prefix table (a 37 GB handle: rounds 3-4's form of the kLCP legs)"
 LEG_TEXT["c4k48"] = LEG_TEXT["c4"].replace("k=31", "k=48").replace("31-mer", "48-mer")
 LEG_K = {"c4k48": 48}
 LEG_TEXT["c3sk"] = LEG_TEXT["c3"].replace("k-mer dictionary", "super-k-mer dictionary ALONE (the handle holds no k-mer dictionary: every k-mer is a one-window read, its minimizer's bucket "
@@ -770,13 +782,14 @@ def run_leg(args):
     args.n, args.batch, args.workload = float(n), batch, workload
     stream_mode = workload == "stream"
     sk_only = name.endswith("sk")
-    klcp_only = name in ("c4k", "c4k48")
+    klcp_only = name in ("c4k", "c4k16", "c4k48")
     if name in LEG_K:
         args.k = LEG_K[name]
     args.stream_via = "klcp" if klcp_only else "runs"
     args.accel = "tables" if klcp_only else "dict"   # (the legs say themselves which structures their handle keeps)
     if klcp_only:
-        args.prefix_len = int(os.environ.get("FMSI_BENCH_KLCP_TABLE", "16"))   # (the kLCP kernel's fresh searches and certificates: its 16-deep prefix table)
+        # (the kLCP kernel's fresh searches and certificates go through the prefix table: at the CLI's depth -- what ships --, c4k16 at 16)
+        args.prefix_len = int(os.environ.get("FMSI_BENCH_KLCP_TABLE", "16" if name == "c4k16" else "15"))
     c = open_ctx(args)
     k = args.k
     resolve_accelerators(args, n, k, stream_mode)
@@ -854,19 +867,24 @@ def run_config_legs(args):
         t0 = time.time()
         if name == "e2e":
             try:
-                report, modes = e2e_report(args)
-                for mode_name, cli in (("or", "fmsi query"), ("all", "fmsi query -O"), ("all_S", "fmsi query -S -O")):
+                report, modes = e2e_report(args, kmer_records=args.e2e_kmer_records)
+                for mode_name, cli in (("or", "fmsi query"), ("all", "fmsi query -O"), ("all_S", "fmsi query -S -O"), ("isolated_or", "fmsi query"), ("isolated_all", "fmsi query -O")):
                     e = modes.get(mode_name)
                     if not e:
                         continue
-                    out.append({"name": f"e2e_{mode_name}", "config": f"whole process `{cli} -q <{report['fasta_bytes'] / 1e9:.2f} GB FASTA: {args.reads} reads of {args.read_len} bases> "
+                    isolated = mode_name.startswith("isolated_")
+                    what = (f"<{report['kmer_fasta_bytes'] / 1e9:.2f} GB FASTA: {report['kmer_records']} records of ONE {args.k}-mer each, half present (configs 2 / 3 / 5's query shape)>"
+                            if isolated else f"<{report['fasta_bytes'] / 1e9:.2f} GB FASTA: {args.reads} reads of {args.read_len} bases>")
+                    out.append({"name": f"e2e_{mode_name}", "config": f"whole process `{cli} -q {what} "
                                                                       f"<index of {int(args.n)} rows, {report['index_bytes'] / 1e9:.2f} GB of .fmsi.* files in /dev/shm>`, output to a file, default options; "
                                                                       f"wall time of the process incl. index load, parse, device, print (SURVEY 8(d)(ii), src/main.cpp:238-375)",
-                                "value": e["windows_per_s_whole_process"], "unit": "k-mers/s", "ms": round(e["wall_seconds"] * 1e3, 1), "windows": report["modes"][mode_name].get("windows"),
+                                "value": e["windows_per_s_whole_process"], "unit": "k-mers/s", "ms": round(e["wall_seconds"] * 1e3, 1), "windows": e.get("windows"),
                                 "load_seconds": e["load_seconds"], "windows_per_s_after_load": e["windows_per_s_after_load"], "stages": e["stages"], "dictionary": e["dictionary"],
+                                "kmer_batches": e.get("kmer_batches"),
                                 "kernel": None, "avg_kernel_ms": None, "algorithmic_bytes": None, "frac": None, "traffic": None,
                                 "matches_reference": e["identical_to_reference_on_sample"],
-                                "reference": f"the reference CLI on the first 20 reads of the same file, same index files: {e['reference_windows_per_s']} windows/s on one core; byte-identical output"})
+                                "reference": f"the reference CLI on the first {'20000 records' if isolated else '20 reads'} of the same file, same index files: {e['reference_windows_per_s']} windows/s on one core; "
+                                             f"byte-identical output (that sample, and the same prefix of the full run's output)"})
             except Exception as e:
                 out.append({"name": "e2e", "error": repr(e)})
             out[-1]["leg_seconds"] = round(time.time() - t0, 1)

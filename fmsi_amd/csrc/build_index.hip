@@ -1295,7 +1295,7 @@ int fmsi_hip_index_download_text(const fmsi_hip_index* idx, uint64_t* words) {
 namespace fmsi {
 namespace {
 
-struct Mapped {   // a file of the index: mapped for its headers (a few pages are ever touched), open for the payload's reads (upload_files)
+struct Mapped {   // a file of the index: mapped for its headers (a few pages are ever touched), open for the payload's reads (UploadTeam)
     const uint8_t* data = nullptr;
     size_t size = 0;
     int fd = -1;
@@ -1332,26 +1332,48 @@ struct UploadJob {
     char* dst;   // device
     uint64_t bytes;
 };
-int upload_files(const std::vector<UploadJob>& jobs, int device) {
-    constexpr uint64_t kPiece = 4ull << 20;
+class UploadTeam {   // start(): the threads begin; finish(): all pieces are in HBM (or the first error)
+public:
+    void start(const std::vector<UploadJob>& jobs, int device) {
+        constexpr uint64_t kPiece = 4ull << 20;
+        for (const UploadJob& j : jobs)
+            for (uint64_t o = 0; o < j.bytes; o += kPiece) pieces_.push_back({&j, o, std::min(kPiece, j.bytes - o)});
+        if (pieces_.empty()) return;
+        const unsigned threads = static_cast<unsigned>(std::max<size_t>(1, std::min<size_t>({8u, std::max(1u, std::thread::hardware_concurrency()), pieces_.size()})));
+        for (unsigned t = 0; t < threads; ++t) pool_.emplace_back([this, device] { work(device); });
+    }
+    int finish() {
+        for (std::thread& th : pool_) th.join();
+        pool_.clear();
+        if (failed_.load()) {
+            (void)hipGetLastError();
+            set_last_error(first_error_);
+            return first_error_.rfind("short read", 0) == 0 ? FMSI_HIP_EIO : FMSI_HIP_EHIP;
+        }
+        return 0;
+    }
+    ~UploadTeam() {
+        failed_.store(1);   // (an early return of the load: the threads stop at their next piece)
+        for (std::thread& th : pool_) th.join();
+    }
+
+private:
     struct Piece {
         const UploadJob* job;
         uint64_t off, len;
     };
-    std::vector<Piece> pieces;
-    for (const UploadJob& j : jobs)
-        for (uint64_t o = 0; o < j.bytes; o += kPiece) pieces.push_back({&j, o, std::min(kPiece, j.bytes - o)});
-    if (pieces.empty()) return 0;
-    const unsigned threads = static_cast<unsigned>(std::max<size_t>(1, std::min<size_t>({8u, std::max(1u, std::thread::hardware_concurrency()), pieces.size()})));
-    std::atomic<size_t> next{0};
-    std::atomic<int> failed{0};
-    std::string first_error;
-    std::mutex err_m;
-    auto fail = [&](const std::string& what) {
-        std::lock_guard<std::mutex> lk(err_m);
-        if (!failed.exchange(1)) first_error = what;
-    };
-    auto work = [&] {
+    std::vector<Piece> pieces_;
+    std::vector<std::thread> pool_;
+    std::atomic<size_t> next_{0};
+    std::atomic<int> failed_{0};
+    std::string first_error_;
+    std::mutex err_m_;
+    void fail(const std::string& what) {
+        std::lock_guard<std::mutex> lk(err_m_);
+        if (!failed_.exchange(1)) first_error_ = what;
+    }
+    void work(int device) {
+        constexpr uint64_t kPiece = 4ull << 20;
         if (hipSetDevice(device) != hipSuccess) return fail("hipSetDevice failed in an upload thread");
         const hipStream_t stream = nullptr;
         void* slot[2] = {nullptr, nullptr};
@@ -1362,8 +1384,8 @@ int upload_files(const std::vector<UploadJob>& jobs, int device) {
             ok = hipHostMalloc(&slot[i], kPiece, hipHostMallocDefault) == hipSuccess && hipEventCreateWithFlags(&done[i], hipEventDisableTiming) == hipSuccess;
         if (!ok) fail("page-locked staging for the index upload could not be set up");
         unsigned turn = 0;
-        for (size_t i; ok && !failed.load() && (i = next.fetch_add(1)) < pieces.size(); turn ^= 1u) {
-            const Piece& pc = pieces[i];
+        for (size_t i; ok && !failed_.load() && (i = next_.fetch_add(1)) < pieces_.size(); turn ^= 1u) {
+            const Piece& pc = pieces_[i];
             if (busy[turn] && hipEventSynchronize(done[turn]) != hipSuccess) {
                 fail("hipEventSynchronize failed in the index upload");
                 break;
@@ -1390,18 +1412,8 @@ int upload_files(const std::vector<UploadJob>& jobs, int device) {
             if (done[i]) (void)hipEventDestroy(done[i]);
             if (slot[i]) (void)hipHostFree(slot[i]);
         }
-    };
-    std::vector<std::thread> pool;
-    for (unsigned t = 1; t < threads; ++t) pool.emplace_back(work);
-    work();
-    for (std::thread& th : pool) th.join();
-    if (failed.load()) {
-        (void)hipGetLastError();
-        set_last_error(first_error);
-        return first_error.rfind("short read", 0) == 0 ? FMSI_HIP_EIO : FMSI_HIP_EHIP;
     }
-    return 0;
-}
+};
 
 struct Span {   // a run of u64 words inside a mapped file
     const uint8_t* p = nullptr;
@@ -1676,10 +1688,10 @@ extern "C" int fmsi_hip_index_load(const char* prefix_c, int load_flags, int dev
     const uint64_t n_words = (n + 63) >> 6, n_blocks = ((n + kBlockRows - 1) >> kBlockRowsLog2) + 1;
     DevBuf d_acgt, d_ac, d_gt, d_bt, d_btnr, d_btnrp, d_invert, d_binom, d_space, d_mask, d_gtoff, d_pc, d_corrupt, d_klcp;
     std::vector<UploadJob> jobs;
+    jobs.reserve(8);   // (the upload's pieces point into it)
     auto upload = [&](DevBuf& b, const Span& s, const Mapped& f) -> int {
         int r = b.alloc((s.words + 2) * 8);
         if (r) return r;
-        FMSI_HIP_TRY(hipMemsetAsync(static_cast<char*>(b.p) + s.words * 8, 0, 16, 0));
         if (s.words) jobs.push_back({f.fd, static_cast<uint64_t>(s.p - f.data), static_cast<char*>(b.p), s.words * 8});
         return 0;
     };
@@ -1687,16 +1699,22 @@ extern "C" int fmsi_hip_index_load(const char* prefix_c, int load_flags, int dev
         (rc = upload(d_acgt, acgt, f_acgt)) || (rc = upload(d_ac, ac, f_ac)) || (rc = upload(d_gt, gt, f_gt)))
         return rc;
     if (with_klcp && (rc = upload(d_klcp, klcp, f_klcp))) return rc;
-    clock.mark("device buffers, first fill");
-    if (std::getenv("FMSI_HIP_LOAD_SERIAL_UPLOAD")) {   // (A/B runs: one copy per part straight from the mapping, as rounds 2-4 did)
-        for (const UploadJob& j : jobs) {
-            const Mapped* f = j.fd == f_mask.fd ? &f_mask : j.fd == f_acgt.fd ? &f_acgt : j.fd == f_ac.fd ? &f_ac : j.fd == f_gt.fd ? &f_gt : &f_klcp;
-            FMSI_HIP_TRY(hipMemcpyAsync(j.dst, f->data + j.file_off, j.bytes, hipMemcpyHostToDevice, 0));
-        }
-    } else if ((rc = upload_files(jobs, device))) {
-        return rc;
+    clock.mark("device buffers");
+    const bool serial_upload = std::getenv("FMSI_HIP_LOAD_SERIAL_UPLOAD") != nullptr;   // (A/B runs: one copy per part straight from the mapping, as rounds 2-4 did)
+    UploadTeam upload_team;   // (declared behind the buffers it fills: its threads are gone before any of them is freed)
+    if (!serial_upload) upload_team.start(jobs, device);
+    // While the payloads travel, everything of the load that does not need them: the process's first kernel launch (the runtime loads
+    // its own fill kernels then: 50 ms), this library's code objects (loaded at the first use of a kernel of theirs: 10-20 ms each), the
+    // small tables and the work buffers.
+    {
+        struct Pad {
+            DevBuf* b;
+            const Span* s;
+        };
+        for (const Pad& pd : {Pad{&d_bt, &bt}, Pad{&d_btnr, &btnr}, Pad{&d_btnrp, &btnrp}, Pad{&d_invert, &invert}, Pad{&d_acgt, &acgt}, Pad{&d_ac, &ac}, Pad{&d_gt, &gt}})
+            FMSI_HIP_TRY(hipMemsetAsync(static_cast<char*>(pd.b->p) + pd.s->words * 8, 0, 16, 0));
+        if (with_klcp) FMSI_HIP_TRY(hipMemsetAsync(static_cast<char*>(d_klcp.p) + klcp.words * 8, 0, 16, 0));
     }
-    clock.mark("payloads read and copied");
     std::vector<uint64_t> h_binom(64 * 64);
     uint8_t h_space[64];
     rrr_tables(h_binom.data(), h_space);
@@ -1707,8 +1725,22 @@ extern "C" int fmsi_hip_index_load(const char* prefix_c, int load_flags, int dev
     FMSI_HIP_TRY(hipMemcpyAsync(d_space.p, h_space, 64, hipMemcpyHostToDevice, 0));
     FMSI_HIP_TRY(hipMemsetAsync(d_corrupt.p, 0, 4, 0));
     FMSI_HIP_TRY(hipMemsetAsync(d_pc.p, 0, (n_words + 1) * 4, 0));
-
-    clock.mark("small tables, work buffers");
+    {
+        hipFuncAttributes attr;
+        (void)hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(&rrr_decode_kernel));   // (this file's code object)
+        if (prefix_len > 0) warm_table_module();
+        if (with_klcp) warm_stream_module();
+        (void)hipGetLastError();
+    }
+    if (serial_upload) {
+        for (const UploadJob& j : jobs) {
+            const Mapped* f = j.fd == f_mask.fd ? &f_mask : j.fd == f_acgt.fd ? &f_acgt : j.fd == f_ac.fd ? &f_ac : j.fd == f_gt.fd ? &f_gt : &f_klcp;
+            FMSI_HIP_TRY(hipMemcpyAsync(j.dst, f->data + j.file_off, j.bytes, hipMemcpyHostToDevice, 0));
+        }
+    } else if ((rc = upload_team.finish())) {
+        return rc;
+    }
+    clock.mark("payloads read and copied (beside: first fill, code objects)");
     // ---- mask: RRR-63 -> plain words ---------------------------------------------------------------------------------------------
     {
         const uint64_t waves = (n_rrr_blocks + 63) / 64;

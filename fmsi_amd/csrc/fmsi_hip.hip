@@ -459,6 +459,12 @@ __global__ __launch_bounds__(256) void ptable_sign_kernel(DevIndex ix, uint2* __
 
 // the signatures may be written beside the first queries (FMSI_HIP_LOAD_ASYNC_TABLE: `fmsi query`, whose run at human scale is over in
 // the time the pass takes): whoever changes or reads the table as a whole waits for them here
+void warm_table_module() {
+    hipFuncAttributes attr;
+    (void)hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(&ptable_level_kernel<true>));
+    (void)hipGetLastError();
+}
+
 int wait_background(fmsi_hip_index* idx) {
     if (!idx || !idx->bg_pending) return 0;
     ::fmsi::DeviceGuard device_guard_(idx->device);

@@ -1399,6 +1399,14 @@ void launch_stream(fmsi_hip_index* idx, const TaskRec* recs, uint64_t n_tasks, i
 }  // namespace
 }  // namespace fmsi
 
+namespace fmsi {
+void warm_stream_module() {
+    hipFuncAttributes attr;
+    (void)hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(&sblock_build_kernel));
+    (void)hipGetLastError();
+}
+}  // namespace fmsi
+
 using namespace fmsi;
 
 // The streaming layout of a handle with a kLCP array (idempotent; fmsi_hip_query_stream builds it on first use): 128 bytes per 192 rows.

@@ -187,6 +187,10 @@ namespace fmsi {
 // stream of their own while the handle already answers -- wait_background() before anything that reads or replaces the table as a whole
 int build_prefix_table(fmsi_hip_index* idx, int t, bool sign_in_background = false);
 int wait_background(fmsi_hip_index* idx);
+// have the runtime load the code object of fmsi_hip.hip / fmsi_stream.hip now (it does so at the first use of one of their kernels, 10-20 ms
+// each): the index load calls these while its payloads are still on their way
+void warm_table_module();
+void warm_stream_module();
 
 // two-base-step kernel over the pair layout (fmsi_pair.hip); requires idx->d_pblocks
 void launch_pair_query(fmsi_hip_index* idx, const uint64_t* d_kmers, uint64_t n, int k, uint32_t flags, bool use_table, uint8_t* o8,

@@ -18,6 +18,21 @@
 
 #define FMSI_AMD_VERSION "0.4.0-mi355x.1"
 
+// fmsi_cli_set_exit_hook: the command's output is complete -- flush, (in the forked child:) close the output and tell the parent, and leave
+static int g_done_fd = -1;
+static void leave_now(int rc) {
+    std::cout.flush();
+    std::cerr.flush();
+    std::fflush(nullptr);
+    if (g_done_fd >= 0) {
+        close(STDOUT_FILENO);
+        close(STDERR_FILENO);
+        const unsigned char code = static_cast<unsigned char>(rc);
+        while (write(g_done_fd, &code, 1) < 0 && errno == EINTR) {}
+    }
+    _exit(rc);
+}
+
 static int usage() {
     std::cerr << std::endl;
     std::cerr << "Program: FMSI (MI355X query path) - k-mer membership queries on masked-superstring indexes." << std::endl;
@@ -41,12 +56,24 @@ int main(int argc, char* argv[]) {
         // in the process writes its output when the process is finalised: rocprofv3 / rocprofiler-sdk and rocTX (trace.h's ranges),
         // sanitizers, gcov.  Then the command tears down what it built (and waits for a dictionary still being built beside the queries)
         // and the ordinary exit runs the atexit handlers and library destructors.
+        // Who that is: a profiler is known by what it puts into the environment (rocprofv3: ROCP_TOOL_LIBRARIES, its tool library preloaded),
+        // a sanitizer or gcov by how THIS binary was compiled.  (Rounds 2-4 took any LD_PRELOAD and any ASAN_OPTIONS for one -- on a pool whose
+        // launcher preloads a guard library into every process that made the quick exit dead code.)
         bool full_exit = false;
-        for (const char* v : {"ROCP_TOOL_LIBRARIES", "ROCPROFILER_REGISTER_FORCE_LOAD", "HSA_TOOLS_LIB", "LD_PRELOAD", "ASAN_OPTIONS", "TSAN_OPTIONS",
-                              "UBSAN_OPTIONS", "GCOV_PREFIX", "FMSI_HIP_CLI_FULL_EXIT"}) {
+#if defined(__SANITIZE_ADDRESS__) || defined(__SANITIZE_THREAD__)
+        full_exit = true;
+#elif defined(__has_feature)
+#if __has_feature(address_sanitizer) || __has_feature(thread_sanitizer) || __has_feature(memory_sanitizer)
+        full_exit = true;
+#endif
+#endif
+        for (const char* v : {"ROCP_TOOL_LIBRARIES", "ROCPROFILER_REGISTER_FORCE_LOAD", "HSA_TOOLS_LIB", "GCOV_PREFIX", "FMSI_HIP_CLI_FULL_EXIT"}) {
             const char* e = std::getenv(v);
             if (e && *e) full_exit = true;
         }
+        if (const char* pre = std::getenv("LD_PRELOAD"))
+            for (const char* tool : {"rocprof", "roctracer", "roctx", "rocsys", "omnitrace", "rocpd"})
+                if (std::strstr(pre, tool)) full_exit = true;
         if (!full_exit) setenv("FMSI_HIP_CLI_NO_TEARDOWN", "1", 0);
         // ... and even left to the operating system, that teardown is 0.11 s + 0.01 s per GB of HBM + what the host side mapped (measured at
         // human scale: 0.14-0.28 s of a 0.7-0.9 s run) in which the caller waits for nothing it wants.  So the command runs in a CHILD, forked
@@ -77,21 +104,18 @@ int main(int argc, char* argv[]) {
                 _exit(WIFEXITED(status) ? WEXITSTATUS(status) : 1);
             } else {
                 close(done_pipe[0]);
+                g_done_fd = done_pipe[1];
             }
         }
-        const int rc = fmsi_cli_query(argc - 1, argv + 1, op == "lookup" ? 1 : 0);
-        std::cout.flush();
-        std::cerr.flush();
-        std::fflush(nullptr);
-        if (child == 0) {
-            close(STDOUT_FILENO);
-            close(STDERR_FILENO);
-            const unsigned char code = static_cast<unsigned char>(rc);
-            while (write(done_pipe[1], &code, 1) < 0 && errno == EINTR) {}
-            _exit(rc);
+        if (!full_exit) fmsi_cli_set_exit_hook(leave_now);   // (called at the command's last line, before anything is released)
+        const int rc = fmsi_cli_query(argc - 1, argv + 1, op == "lookup" ? 1 : 0);   // (comes back on usage errors and under full_exit)
+        if (full_exit && !std::getenv("FMSI_HIP_CLI_NO_TEARDOWN")) {
+            std::cout.flush();
+            std::cerr.flush();
+            std::fflush(nullptr);
+            std::exit(rc);
         }
-        if (full_exit && !std::getenv("FMSI_HIP_CLI_NO_TEARDOWN")) std::exit(rc);
-        _exit(rc);
+        leave_now(rc);
     }
     if (op == "index") return fmsi_cli_index(argc - 1, argv + 1);
     if (op == "export") return fmsi_cli_export(argc - 1, argv + 1);

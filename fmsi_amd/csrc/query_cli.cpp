@@ -481,11 +481,14 @@ struct PredictorSteps {
 };
 const PredictorSteps kPredictorSteps;
 
+// WRITE: b[w] keeps its strand nibble and gets the character's bit on top (bit 7), so that a stretch can be walked again from another state
+template <bool WRITE>
 void replay_presence_tight(uint8_t* b, uint64_t n, StrandPredictor& p, Mode mode) {
     uint64_t w = 0;
     for (; w < n && p.previous == -1; ++w) {   // (the very first window: no result score is updated)
-        const uint8_t in = b[w];
-        b[w] = static_cast<uint8_t>(replay_single(p, mode, false, fwd_of(in), rc_of(in)) == 1);
+        const uint8_t in = b[w] & 15u;
+        const uint8_t out = static_cast<uint8_t>(replay_single(p, mode, false, fwd_of(in), rc_of(in)) == 1);
+        if (WRITE) b[w] = static_cast<uint8_t>(in | (out << 7));
     }
     const int32_t(*T)[16] = kPredictorSteps.e[mode == Mode::All ? 1 : 0];
     int score = p.score, rs0 = p.result_scores[0], rs1 = p.result_scores[1], prev = p.previous;
@@ -501,12 +504,56 @@ void replay_presence_tight(uint8_t* b, uint64_t n, StrandPredictor& p, Mode mode
         rs1 = prev ? nrs : rs1;
         rs0 = prev ? rs0 : nrs;
         prev = (e >> 8) & 1;
-        b[w] = static_cast<uint8_t>(e >> 16);
+        if (WRITE) b[w] = static_cast<uint8_t>(in | ((e >> 16) << 7));
     }
     p.score = score;
     p.result_scores[0] = rs0;
     p.result_scores[1] = rs1;
     p.previous = prev;
+}
+
+// ... and the batch cut into one stretch per thread.  The recurrence is sequential, but its state is four small saturating numbers: walked
+// from ANY state, the scores of two runs over the same inputs close in on each other whenever one of them is clipped, and after a few
+// hundred windows of ordinary input they are the same run.  So every thread but the first warms a predictor up over the kWarm windows in
+// front of its stretch (from the zero state) and walks its stretch from there; afterwards the stretches are taken in order: where the
+// state a stretch was started from IS the state its predecessor ended in, its results stand -- it was the sequential walk; where not
+// (inputs that never move the scores, such as a long run of absent k-mers), the stretch is walked again from the true state, one thread,
+// as without any of this.  Exact either way; `reruns` says how often the guess failed.
+uint64_t replay_presence_team(uint8_t* b, uint64_t n, StrandPredictor& p, Mode mode, unsigned team) {
+    constexpr uint64_t kWarm = 4096;
+    const unsigned parts = static_cast<unsigned>(std::min<uint64_t>(team, n / (16 * kWarm)));
+    if (parts < 2) {
+        replay_presence_tight<true>(b, n, p, mode);
+        return 0;
+    }
+    std::vector<StrandPredictor> from(parts), to(parts);
+    auto lo_of = [&](unsigned t) { return n / parts * t; };
+    auto hi_of = [&](unsigned t) { return t + 1 == parts ? n : n / parts * (t + 1); };
+    from[0] = p;
+    parallel_for(parts, [&](unsigned t) {   // (the warm-ups read what the stretches in front of them will write: first all of the one, then the other)
+        if (!t) return;
+        StrandPredictor q;
+        q.previous = 0;
+        replay_presence_tight<false>(b + lo_of(t) - kWarm, kWarm, q, mode);
+        from[t] = q;
+    });
+    parallel_for(parts, [&](unsigned t) {
+        StrandPredictor q = from[t];
+        replay_presence_tight<true>(b + lo_of(t), hi_of(t) - lo_of(t), q, mode);
+        to[t] = q;
+    });
+    uint64_t reruns = 0;
+    StrandPredictor cur = to[0];
+    for (unsigned t = 1; t < parts; ++t) {
+        if (same_state(cur, from[t])) {
+            cur = to[t];
+        } else {
+            replay_presence_tight<true>(b + lo_of(t), hi_of(t) - lo_of(t), cur, mode);
+            ++reruns;
+        }
+    }
+    p = cur;
+    return reruns;
 }
 
 // strict results (both strands per window) -> final per-window values, in the order the reference visits them
@@ -724,7 +771,7 @@ void patch_kmer_lines(Prepared& P, unsigned team) {
                 }
             } else {
                 const uint8_t* b = P.bytes.data() + sl.first;
-                for (size_t i = sl.lo; i < sl.hi; ++i) text[at[i]] = static_cast<char>('0' + (b[i - sl.lo] != 0));
+                for (size_t i = sl.lo; i < sl.hi; ++i) text[at[i]] = static_cast<char>('0' + (b[i - sl.lo] >> 7));   // (replay_presence_team's bit)
             }
         }
     });
@@ -738,6 +785,11 @@ void check(int rc, const char* what) {
 }  // namespace fmsi
 
 using namespace fmsi;
+
+namespace {
+void (*g_exit_hook)(int) = nullptr;
+}
+extern "C" void fmsi_cli_set_exit_hook(void (*hook)(int)) { g_exit_hook = hook; }
 
 extern "C" int fmsi_cli_query(int argc, char** argv, int output_orders_i) {
     // the command is a chain of builder calls in a process of its own: they share the library's block cache (include/fmsi_hip.h)
@@ -840,6 +892,7 @@ extern "C" int fmsi_cli_query(int argc, char** argv, int output_orders_i) {
     // (only when the file is there: a missing query file must fail where the reference's OpenFile() does -- after the index
     // checks, uncaught, src/parser.h:22 -- so that case keeps the old order)
     double gpu_s = 0, prep_s = 0, replay_s = 0, format_s = 0, write_s = 0;
+    uint64_t replay_reruns = 0;   // (k-mer batches: stretches of the predictor's replay that had to be walked again, replay_presence_team)
     BoundedQueue<std::unique_ptr<RawBatch>> raw_q(2);
     BoundedQueue<std::unique_ptr<Prepared>> out_q(2);
     std::exception_ptr writer_err;
@@ -1263,7 +1316,7 @@ extern "C" int fmsi_cli_query(int argc, char** argv, int output_orders_i) {
                 TraceRange replay_range("fmsi: predictor replay");
                 // (a k-mer batch under -S: every record is one chunk of one window, whose streaming step IS the single step -- the first strand's
                 // result, the second's if that does not settle it, log_result of the two: src/fms_index.h:181-254 against :263-331)
-                if (P->raw.kmer_k) replay_presence_tight(P->bytes.data(), P->windows, predictor, opt.mode);
+                if (P->raw.kmer_k) replay_reruns += replay_presence_team(P->bytes.data(), P->windows, predictor, opt.mode, team);
                 else replay_batch(*P, predictor, opt.mode, output_orders, load_klcp, k, team, rows64);
             }
             replay_s += std::chrono::duration<double>(clock::now() - t2).count();
@@ -1303,11 +1356,12 @@ extern "C" int fmsi_cli_query(int argc, char** argv, int output_orders_i) {
                 "{\"windows\": %llu, \"total_seconds\": %.6f, \"load_seconds\": %.6f, \"device_seconds\": %.6f, \"read_seconds\": %.6f, "
                 "\"prepare_seconds\": %.6f, \"replay_seconds\": %.6f, \"format_seconds\": %.6f, \"write_seconds\": %.6f, \"threads\": %u, "
                 "\"devices\": %zu, \"strict\": %s, \"block_parallel_read_bytes\": %llu, \"dictionary\": \"%s\", \"dictionary_batches\": %llu, \"kmer_batches\": %llu, "
-                "\"epoch_start\": %.6f, \"epoch_end\": %.6f}\n",
+                "\"replay_reruns\": %llu, \"epoch_start\": %.6f, \"epoch_end\": %.6f}\n",
                 static_cast<unsigned long long>(total_windows), total, load, gpu_s, query_reader.read_s, prep_s, replay_s, format_s, write_s, team,
                 ctx.size(), strict ? "true" : "false", static_cast<unsigned long long>(query_reader.parallel_read_bytes),
                 ctx[0].have_dict ? "before the first batch" : (want_bg_dict && !rows64 ? "beside the queries" : "none"),
                 static_cast<unsigned long long>(ctx[0].dict_batches), static_cast<unsigned long long>(query_reader.kmer_batches),
+                static_cast<unsigned long long>(replay_reruns),
                 // (wall-clock stamps of this function's first and last line: what the process spends before and behind them -- the loader,
                 // the runtime's start-up, the teardown of its mappings and of the device context -- is the parent's to see)
                 epoch_start, std::chrono::duration<double>(std::chrono::system_clock::now().time_since_epoch()).count());
@@ -1316,6 +1370,7 @@ extern "C" int fmsi_cli_query(int argc, char** argv, int output_orders_i) {
     // being built when the input has ended)
     if (!std::getenv("FMSI_HIP_CLI_NO_TEARDOWN")) destroy_all();
     else {
+        if (g_exit_hook) g_exit_hook(exit_code);   // (the `fmsi` binary: does not come back)
         for (DeviceCtx& c : ctx)
             if (c.dict_builder.joinable()) {
                 c.dict_builder.detach();

@@ -422,6 +422,11 @@ uint64_t fmsi_host_pack_2bit(const char* seq, uint64_t len, uint64_t* words);
 /* The `fmsi query` / `fmsi lookup` command (ms_query, src/main.cpp:238-375) on the GPU; argv as the
  * reference's sub-command sees it (argv[0] = "query").  Returns the process exit code. */
 int fmsi_cli_query(int argc, char** argv, int output_orders);
+/* A process that ends with the command (the `fmsi` binary) may register what is to happen the moment the command's output is complete --
+ * written, stdout still open -- instead of the return: hook(exit_code) is called from fmsi_cli_query's last line BEFORE its mappings,
+ * buffers and device handles are released (unmapping a query file of gigabytes and freeing the batches is 0.1-0.3 s that a process about
+ * to exit need not spend); a hook that returns lets the call end the ordinary way.  NULL (default): none. */
+void fmsi_cli_set_exit_hook(void (*hook)(int exit_code));
 
 #ifdef __cplusplus
 }

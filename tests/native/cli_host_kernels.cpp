@@ -159,8 +159,39 @@ int main() {
         a = in;
         for (size_t w = 0; w < n; ++w) a[w] = static_cast<uint8_t>(replay_single(pa, mode, false, fwd_of(in[w]), rc_of(in[w])) == 1);
         bb = in;
-        replay_presence_tight(bb.data(), n, pb, mode);
-        if (a != bb || !same_state(pa, pb)) return fail("replay_presence_tight", it, n);
+        replay_presence_tight<true>(bb.data(), n, pb, mode);
+        for (size_t w = 0; w < n; ++w)
+            if ((bb[w] & 15u) != in[w] || (bb[w] >> 7) != a[w]) return fail("replay_presence_tight", it, w);
+        if (!same_state(pa, pb)) return fail("replay_presence_tight (state)", it, n);
+    }
+    // ... and cut into stretches walked side by side from warmed-up states (replay_presence_team): the sequential walk's results whatever the
+    // inputs are -- random ones, where the guesses hold, and runs that never move the scores, where stretches are walked again
+    for (size_t it = 0; it < 24; ++it) {
+        const size_t n = 300000 + rng() % 400000;
+        const Mode mode = it % 2 ? Mode::All : Mode::Or;
+        std::vector<uint8_t> in(n);
+        const int style = static_cast<int>(it % 4);
+        for (size_t w = 0; w < n; ++w) {
+            int f, r;
+            if (style == 0) { f = static_cast<int>(rng() % 3) - 1; r = static_cast<int>(rng() % 3) - 1; }
+            else if (style == 1) { if (rng() % 2) { f = r = -1; } else { f = 1; r = -1; if (rng() % 2) std::swap(f, r); } }
+            else if (style == 2) { f = r = -1; if (w % 100000 < 50) f = 1; }                 // absent k-mers nearly throughout: the scores stand still
+            else { f = r = 0; if ((w / 70000) % 2) { f = static_cast<int>(rng() % 3) - 1; } }   // stretches of (0, 0), stretches of noise
+            in[w] = static_cast<uint8_t>((f + 1) | ((r + 1) << 2));
+        }
+        StrandPredictor p0;
+        if (it % 3) {
+            p0.score = static_cast<int>(rng() % 15) - 7;
+            p0.result_scores[0] = static_cast<int>(rng() % 15) - 7;
+            p0.result_scores[1] = static_cast<int>(rng() % 15) - 7;
+            p0.previous = static_cast<int>(rng() % 2);
+        }
+        StrandPredictor pa = p0, pb = p0;
+        std::vector<uint8_t> a = in, bb = in;
+        replay_presence_tight<true>(a.data(), n, pa, mode);
+        const uint64_t reruns = replay_presence_team(bb.data(), n, pb, mode, 2 + static_cast<unsigned>(it % 5));
+        if (a != bb || !same_state(pa, pb)) return fail("replay_presence_team", it, static_cast<size_t>(reruns));
+        if (style == 1 && reruns != 0) return fail("replay_presence_team: a guess failed on random k-mers", it, static_cast<size_t>(reruns));
     }
     // one k-mer of text -> its 2-bit word (PEXT and plain and the tail form), invalid characters refused
     for (size_t it = 0; it < 20000; ++it) {

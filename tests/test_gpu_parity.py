@@ -670,7 +670,9 @@ def test_cli_kmer_batches_equal_the_reference(fm, oracle_built, tmp_path, monkey
         assert rc == 0, err.decode()
         assert got == ref, (opts, mode)
         stats = json.loads([l for l in err.decode().splitlines() if l.startswith("{")][-1])
-        assert stats["kmer_batches"] > 0 and stats["windows"] >= 19900
+        assert stats["windows"] >= 19900
+        if shape != "odd" or opts[:1] == ["--batch"]:   # (the path was taken -- with small ranges also by the ranges between two odd records)
+            assert stats["kmer_batches"] > 0, (opts, mode)
     monkeypatch.setenv("FMSI_HIP_CLI_KMER_BATCHES", "0")
     rc, general, err = fm.run_cli(args)
     assert rc == 0 and general == ref and b'"kmer_batches": 0' in err
