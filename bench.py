@@ -152,6 +152,14 @@ def open_ctx(args):
     c.rank = int(os.environ.get("RANK", "0"))
     c.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     c.multi = c.world > 1 or args.force_dist   # the multi-rank code path
+    # one process per GPU of ONE node: more ranks than devices is a launch error, said once and before any rank waits for another
+    # (a rank without a device of its own would otherwise die inside the process group's set-up, or -- worse -- share GPU 0 and report
+    # N times the rate of one GPU).  FMSI_BENCH_SHARE_GPU=1: the tests' two ranks on one device.
+    n_dev = fm.device_count()
+    if (c.world > n_dev or c.local_rank >= n_dev) and not os.environ.get("FMSI_BENCH_SHARE_GPU"):
+        if c.rank == 0:
+            print(f"bench.py: {c.world} ranks were launched but this node has {n_dev} HIP device(s): one rank per GPU -- run with --gpus <= {n_dev}", file=sys.stderr)
+        sys.exit(2)
     if c.multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")

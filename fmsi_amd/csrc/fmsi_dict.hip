@@ -1322,7 +1322,13 @@ extern "C" int fmsi_hip_index_enable_dict(fmsi_hip_index* idx, uint32_t flags) {
     const bool want_sk = (flags & (FMSI_HIP_DICT_SUPERKMER | FMSI_HIP_DICT_SUPERKMER_ONLY)) != 0u;
     if (!want_sk) return enable_dict_impl(idx, flags & (FMSI_HIP_DICT_SPARSE | FMSI_HIP_DICT_CHAIN));
     FMSI_HIP_NARROW_ONLY(idx, "the super-k-mer dictionary");
-    if (idx->sk.bits) return 0;
+    if (idx->sk.bits) {   // (the records stand: _ONLY on such a handle still lets the k-mer dictionary go)
+        if ((flags & FMSI_HIP_DICT_SUPERKMER_ONLY) && idx->dict.levels) {
+            FMSI_HIP_ON_DEVICE(idx->device);
+            drop_kmer_dict(idx);
+        }
+        return 0;
+    }
     int rc = enable_dict_impl(idx, (flags & FMSI_HIP_DICT_SPARSE) | FMSI_HIP_DICT_CHAIN);   // (its per-position answers are what the records are made of)
     if (rc) return rc;
     if (!idx->dict.posans) {

@@ -824,8 +824,11 @@ struct UniformRuns {
 };
 // WIDE (33 <= k <= 64): no k-mer register -- the bases of the current window come from the task's 128 bases, as in the first kernel.
 // ORD (`lookup -S`, kmer_order_if_present of fms_index.h:151-157 in the loops of :181-254): a window's strand result is the mask rank of its
-// interval's first row when a row of the interval is masked; the caller's array is filled with -1 BEFORE the kernel (one streaming pass) and
-// the kernel stores the orders it finds (8 bytes each, straight to their place: no result planes for them, no slots, no compaction).
+// interval's first row when a row of the interval is masked.  The kernel stores the orders it finds the moment it finds them (8 bytes each,
+// straight to their place: no slots, no compaction) and keeps, as for the presence modes, which windows had one in the result planes; when
+// a task is over the WAVE writes the -1 of every strand result without an order -- lane l the task's window l, the finished lanes' planes
+// handed round by readlane: a read that is not in the text leaves as whole lines of -1.  (Round 4 filled the caller's array with -1 before
+// the kernel: a pass of its own over 16 bytes per window, 0.5 of the leg's 4.1 ms.)
 template <bool COUNT, bool PTABLE, bool UNI, bool WIDE, bool ORD>
 __global__ __launch_bounds__(256, 4) void query_stream2_kernel(DevIndex ix, const uint4* __restrict__ sblocks, const uint64_t* __restrict__ klcp,
                                                             const TaskRec* __restrict__ tasks, uint64_t n_tasks, int k, uint32_t flags, uint32_t chunk,
@@ -938,6 +941,33 @@ __global__ __launch_bounds__(256, 4) void query_stream2_kernel(DevIndex ix, cons
         dst[2] = result_bytes16(p0, p1, p2, p3, 2);
         dst[3] = result_bytes16(p0, p1, p2, p3, 3);
     };
+    // ORD: the -1s of the tasks that are over, by the whole wave (wave-uniform call); their lanes are free then
+    auto lane64 = [](uint64_t v, int lane) -> uint64_t {
+        const uint32_t lo = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(static_cast<uint32_t>(v)), lane));
+        const uint32_t hi = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(static_cast<uint32_t>(v >> 32)), lane));
+        return (static_cast<uint64_t>(hi) << 32) | lo;
+    };
+    auto flush_orders = [&]() {
+        uint64_t dm = __ballot(st == SS_DONE);
+        const uint64_t mine_f = rf_hi & ~rf_lo, mine_r = rr_hi & ~rr_lo;   // windows with an order (strand result + 1 == 2)
+        while (dm) {
+            const int owner = __ffsll(static_cast<unsigned long long>(dm)) - 1;
+            dm &= dm - 1;
+            const uint64_t f1 = lane64(mine_f, owner), r1 = lane64(mine_r, owner), ob = lane64(obase, owner);
+            const uint32_t nn = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(n), owner));
+            if (ln < nn) {
+                const bool fh = (f1 >> ln) & 1ull, rh = (r1 >> ln) & 1ull;
+                if (strict) {
+                    long long* p = out_orders + 2ull * (ob + ln);
+                    if (!fh) __builtin_nontemporal_store(-1ll, p);
+                    if (!rh) __builtin_nontemporal_store(-1ll, p + 1);
+                } else if (!(fh | rh)) {
+                    __builtin_nontemporal_store(-1ll, out_orders + ob + ln);
+                }
+            }
+        }
+        if (st == SS_DONE) st = SS_IDLE;
+    };
     // The set-up work between windows has ONE code site each, at the top of the round loop: the state machine's branches only name it --
     // SS_PASS1 (pass 0 is over), SS_FRESH_CERT / SS_FRESH_PLAIN (cut the k-mer of window widx from the task's bases and start a search, with
     // or without a certificate first).  In a wave whose lanes are in different states a round runs every branch some lane is in; what the
@@ -987,11 +1017,11 @@ __global__ __launch_bounds__(256, 4) void query_stream2_kernel(DevIndex ix, cons
         if (pass == 0) {
             if (v & 1u) rf_lo |= bit;
             if (v & 2u) rf_hi |= bit;
-        } else if (!ORD) {
+        } else {
             if (v & 1u) rr_lo |= bit;
             if (v & 2u) rr_hi |= bit;
         }
-        if (ORD && res == 1) {   // (every other strand result is the -1 the array holds already)
+        if (ORD && res == 1) {   // (every other strand result is a -1: flush_orders)
             if (strict) out_orders[2ull * (obase + widx) + pass] = static_cast<long long>(ord);
             else out_orders[obase + widx] = static_cast<long long>(ord);   // (pass 1 visits a window only when pass 0 had no order for it)
         }
@@ -1098,6 +1128,7 @@ __global__ __launch_bounds__(256, 4) void query_stream2_kernel(DevIndex ix, cons
 
     for (;;) {
         if (st == SS_PASS1) begin_pass1_now();
+        if (ORD) flush_orders();
         {   // idle lanes draw the wave's next tasks (ballot + prefix rank, no atomics); a task's record is three 16-byte loads per 64 windows
             const bool want = st == SS_IDLE || st == SS_DONE;
             const uint64_t m = next < end ? __ballot(want) : 0ull;   // (nothing left to draw: the finished lanes keep their results for the end)
@@ -1321,6 +1352,7 @@ __global__ __launch_bounds__(256, 4) void query_stream2_kernel(DevIndex ix, cons
         }
         __builtin_amdgcn_wave_barrier();   // (the next round's staging must not overtake this round's reads of the lines)
     }
+    if (ORD) flush_orders();
     if (st == SS_DONE) flush_task();
     if (COUNT && (flags & kStreamUtil)) {
         uint32_t x = util_busy, y = util_rounds;
@@ -1582,9 +1614,9 @@ extern "C" int fmsi_hip_query_stream(fmsi_hip_index* idx, const uint64_t* packed
     long long* o64 = static_cast<long long*>(d_out);
     if (v2) {
         const UniformRuns* up = cut_in_kernel ? &uni : nullptr;
-        const bool ord = flags & FMSI_HIP_ORDERS;
-        if (ord)   // every strand result without an order is -1: the array is filled first, the kernel stores the orders it finds
-            FMSI_HIP_TRY(hipMemsetAsync(d_out, 0xFF, out_bytes, s));
+        const bool ord = flags & FMSI_HIP_ORDERS;   // (every strand result without an order is -1: the kernel writes those, too -- flush_orders)
+        static const bool prefill = std::getenv("FMSI_HIP_STREAM_ORD_PREFILL") != nullptr;   // (A/B runs: round 4's pass over the array before the kernel as well)
+        if (ord && prefill) FMSI_HIP_TRY(hipMemsetAsync(d_out, 0xFF, out_bytes, s));
         if (k > 32) {
             if (ord) launch_stream2_variant<true, true>(idx, d_cnt != nullptr, use_table, d_rec, n_tasks, k, flags, d_slots, o64, d_cnt, s, up);
             else launch_stream2_variant<true, false>(idx, d_cnt != nullptr, use_table, d_rec, n_tasks, k, flags, d_slots, o64, d_cnt, s, up);

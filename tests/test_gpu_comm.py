@@ -133,3 +133,83 @@ def test_one_rank_under_torchrun_is_as_fast_as_the_plain_run(fm):
     # kernel sharing the GPU with the lookup kernel (0.5 ms of every 2.9 ms step; the lookup kernel runs 4-5 % slower beside it).  With the
     # kernels on the legacy default stream -- where RCCL's gather orders itself against them -- it was 0.90: see open_ctx in bench.py.
     assert ratio > 0.90, vals
+
+
+TWO_RANK_SCRIPT = r"""
+import os, sys, json
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+import torch
+import torch.distributed as dist
+import fmsi_amd as fm
+from fmsi_amd import sharding
+
+rank, world, pg, out = int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], sys.argv[5]
+dist.init_process_group("gloo", init_method=f"file://{pg}", world_size=world, rank=rank)
+k, n, nq = 31, 30_000_000, 1 << 21
+torch.cuda.set_device(0)                      # every rank on THE one device of the box
+s = torch.cuda.current_stream().cuda_stream
+dev = fm.DeviceIndex.build_synthetic(n, 99, k, prefix_len=12, mask_permille=700).enable_pair_layout()   # the index is replicated: each rank builds its own
+d_all = torch.empty(nq, dtype=torch.int64, device="cuda")
+dev.synthetic_queries_dev(k, 7, 0, nq, d_all.data_ptr(), s)             # the same seeded global batch on every rank
+torch.cuda.synchronize()
+flags = fm.MODE_ALL | fm.STRICT | fm.OUT_BITS
+a, b = sharding.shard_range(nq // 16, rank, world)                        # shards in WORDS of the packed output (16 STRICT nibbles each)
+d_words = torch.zeros(b - a, dtype=torch.int64, device="cuda")
+dev.query_kmers_dev(d_all[16 * a:].data_ptr(), 16 * (b - a), k, flags, d_words.data_ptr(), stream=s)
+torch.cuda.synchronize()
+got = sharding.gather_to_root(d_words.cpu(), nq // 16, dst=0)             # rank order = output order
+if rank == 0:
+    d_ref = torch.zeros(nq // 16, dtype=torch.int64, device="cuda")
+    dev.query_kmers_dev(d_all.data_ptr(), nq, k, flags, d_ref.data_ptr(), stream=s)
+    torch.cuda.synchronize()
+    same = bool(torch.equal(got, d_ref.cpu()))
+    by = fm.unpack_bits(got.numpy().view(np.uint64), nq, fm.STRICT)
+    f, r = fm.decode_strict(by)
+    json.dump({"same": same, "present": float(((f == 1) | (r == 1)).mean()), "absent": float(((f == -1) & (r == -1)).mean())}, open(out, "w"))
+dist.barrier()
+dist.destroy_process_group()
+"""
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_two_ranks_with_the_real_kernels_on_one_gpu(fm, tmp_path, world):
+    """Everything of the N > 1 path but RCCL's own transfer, on hardware: `world` processes, each with a replicated index on
+    the box's one GPU, each answers its contiguous shard of the same seeded global batch through fmsi_hip_query_kmers (STRICT, bit-packed),
+    the words are gathered to rank 0 in rank order (gloo: RCCL refuses two ranks on one device) and equal what ONE process answers for the
+    whole batch."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    repo = Path(__file__).resolve().parent.parent
+    script = tmp_path / "two_ranks.py"
+    script.write_text(TWO_RANK_SCRIPT)
+    out = tmp_path / "result.json"
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, str(script), str(repo), str(r), str(world), str(tmp_path / "pg"), str(out)], env=env, stderr=subprocess.PIPE) for r in range(world)]
+    errs = [p.communicate(timeout=600)[1] for p in procs]
+    assert all(p.returncode == 0 for p in procs), [e.decode()[-1500:] for e in errs]
+    res = json.loads(out.read_text())
+    assert res["same"] is True and 0.3 < res["present"] < 0.7 and res["absent"] > 0.3, res
+
+
+def test_bench_refuses_more_ranks_than_devices(fm):
+    """`bench.py --gpus 2` launched as the driver launches N > 1, on a box with one device: every rank ends at once with a message and a
+    non-zero code -- no rank waits for a peer that has no GPU, no two ranks quietly share device 0."""
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    if fm.device_count() > 1:
+        pytest.skip("a multi-GPU box: nothing to refuse")
+    repo = Path(__file__).resolve().parent.parent
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    res = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29533",
+                          str(repo / "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], capture_output=True, text=True, timeout=300, env=env, cwd=str(repo))
+    assert res.returncode != 0
+    assert "one rank per GPU" in res.stderr and "1 HIP device" in res.stderr, res.stderr[-2000:]
+    assert not [l for l in res.stdout.splitlines() if l.startswith("{")]

@@ -313,6 +313,69 @@ def test_mixed_mask_at_human_scale(fm, human_mixed):
         _reads_agree(fm, dev, k, 3000, 512, 10000, mode | fm.STRICT | fm.NO_SUPERKMER, mode | fm.STRICT)                   # == k-mer dictionary
 
 
+def test_headline_kernel_at_headline_size(fm, human_mixed):
+    """What bench.py's headline runs -- isolated 31-mers on a handle that keeps the super-k-mer dictionary ALONE (`sk_kmers_kernel`: a lane
+    per k-mer, one bucket read, no LF step) -- held against the checkers at the headline's size and on the hard text: n = 2.8 x 10^9 rows,
+    60 % mask, repeat families (their minimizers are heavy, their buckets overflow: the aux dictionary's path).  2^22 seeded k-mers through
+    fmsi_hip_query_kmers in OR and ALL, STRICT: the bytes == the table-less two-base LF walk strand by strand on all of them, == the
+    oracle's ternaries (src/fms_index.h:263-331 both strands) and the real reference's printed bits on 10^5; the cheaper schedule and the
+    bit-packed form agree; and the counters say which path answered: no LF step, more bucket reads than k-mers (the aux lookups)."""
+    import torch
+    import bench_cpu
+    k, nq, sample = 31, 1 << 22, 100_000
+    dev = human_mixed
+    dev.enable_dict(superkmer=True)            # (a no-op when test_mixed_mask_at_human_scale ran before this one)
+    dev.enable_dict(superkmer_only=True)       # the k-mer dictionary goes: the records answer isolated k-mers, too
+    info = dev.info
+    assert int(info.dict_bytes) == 0 and int(info.sk_bytes) > 0
+    assert int(info.sk_aux_keys) > 100_000 and int(info.sk_overflowed_buckets) > 0 and int(info.sk_heavy_minimizers) > 1000
+    s = torch.cuda.current_stream().cuda_stream
+    d_kmers = torch.empty(nq, dtype=torch.int64, device="cuda")
+    dev.synthetic_queries_dev(k, 4242, 0, nq, d_kmers.data_ptr(), s)
+    torch.cuda.synchronize()
+    text = kmers_text(d_kmers[:sample].cpu().numpy().view(np.uint64), k)
+    orc = bench_cpu.oracle_from_index(dev, k, with_klcp=False)
+    strict = {}
+    for mode_name, mode in (("or", fm.MODE_OR), ("all", fm.MODE_ALL)):
+        d_out = torch.empty(nq, dtype=torch.uint8, device="cuda")
+        d_cnt = torch.zeros(fm.N_COUNTERS, dtype=torch.int64, device="cuda")
+        dev.query_kmers_dev(d_kmers.data_ptr(), nq, k, mode | fm.STRICT, d_out.data_ptr(), d_cnt.data_ptr(), s)
+        torch.cuda.synchronize()
+        got, cn = d_out.cpu().numpy(), d_cnt.cpu().numpy()
+        assert int(cn[0]) == 0 and int(cn[6]) == nq and int(cn[4]) > nq + 1000, cn      # no LF step; bucket reads = records' + the aux dictionary's
+        walk = device_answers(fm, dev, d_kmers, nq, k, mode | fm.STRICT | fm.KERNEL_PAIR | fm.NO_PREFIX_TABLE)
+        assert np.array_equal(got, walk), (mode_name, np.nonzero(got != walk)[0][:10])
+        f, r = fm.decode_strict(got)
+        of, orr = orc.ternaries_bulk(text, sample, k, mode_name == "all")
+        assert np.array_equal(f[:sample], of) and np.array_equal(r[:sample], orr), mode_name
+        fast = device_answers(fm, dev, d_kmers, nq, k, mode)
+        want = (np.where(f != -1, f, r) == 1) if mode_name == "all" else ((f == 1) | (r == 1))
+        assert np.array_equal(fast.astype(bool), want), mode_name
+        for fl, st in ((mode | fm.OUT_BITS, 0), (mode | fm.STRICT | fm.OUT_BITS, fm.STRICT)):
+            d_bits = torch.zeros(fm.packed_words(nq, st), dtype=torch.int64, device="cuda")
+            dev.query_kmers_dev(d_kmers.data_ptr(), nq, k, fl, d_bits.data_ptr(), stream=s)
+            torch.cuda.synchronize()
+            assert np.array_equal(fm.unpack_bits(d_bits.cpu().numpy().view(np.uint64), nq, st), got if st else fast), (mode_name, st)
+        strict[mode_name] = (f, r)
+    fo, ro = strict["or"]
+    fa, ra = strict["all"]
+    assert 0.3 < ((fo == 1) | (ro == 1) | (fo == 0) | (ro == 0)).mean() < 0.7 and (fo != fa).sum() + (ro != ra).sum() > 1000   # present and absent, and the modes differ
+    if oracle_py.ref_available():
+        with tempfile.TemporaryDirectory(dir="/dev/shm") as d:
+            orc.dump(f"{d}/x")
+            ref = oracle_py.Reference.load(f"{d}/x")
+            for mode_name, omode in (("or", oracle_py.MODE_OR), ("all", oracle_py.MODE_ALL)):
+                f, r = strict[mode_name]
+                _, bits = ref.time_isolated_kmers(text, sample, k, omode)
+                if mode_name == "or":
+                    assert np.array_equal(bits.astype(bool), ((f == 1) | (r == 1))[:sample])
+                else:   # -O on a non-max-ones mask: what is printed depends on the strand searched first -- where the strands agree it does not
+                    same = (f[:sample] == r[:sample]) | (f[:sample] == -1) | (r[:sample] == -1)
+                    assert np.array_equal(bits.astype(bool)[same], (np.where(f != -1, f, r) == 1)[:sample][same])
+            ref.close()
+    orc.close()
+
+
 def test_adversarial_text_at_1e9_rows(fm):
     """A text of 10^9 bases that is NOT i.i.d.: megabase homopolymers, tandem repeats of 2..6-base units, a family of 10^5 copies of one
     300-base consensus at 1 % divergence, on a random background with a 60 % mask -- through the on-device builder (prefix doubling over
