@@ -1001,8 +1001,11 @@ def compact_line(line):
     def size(o):
         return len(json.dumps(o, separators=(",", ":")))
     # never above the limit: shed the least important fields first
-    for drop in (("configs", "kernel"), ("roofline", "bytes_per_kmer"), ("roofline", "blocks_per_kmer"), ("config", "gather", "alt"), ("cpu_baseline", "cpu_model"),
-                 ("cpu_baseline", "tuned_value"), ("configs", "hbm_gb"), ("configs", "kernel_ms"), ("configs", "ms"), ("configs", "frac")):
+    # (a leg keeps name, value, hbm_frac, hbm_gb -- the structure it was measured on --, the whole-process legs after_load / load_s, and matches_reference to the last)
+    for drop in (("configs", "kernel"), ("configs", "kernel_ms"), ("configs", "dictionary"), ("roofline", "bytes_per_kmer"), ("roofline", "blocks_per_kmer"),
+                 ("config", "gather", "alt"), ("cpu_baseline", "cpu_model"), ("cpu_baseline", "tuned_value"), ("configs", "ms"), ("configs", "frac"),
+                 ("roofline", "launches"), ("config", "positive_fraction"), ("config", "index_build_seconds"), ("config", "accelerator_bytes"),
+                 ("configs", "load_s"), ("configs", "hbm_gb")):
         if size(out) <= COMPACT_LIMIT:
             break
         tgt = out.get(drop[0])

@@ -500,47 +500,63 @@ private:
         // stream after the other; a stretch ends where its last record starts (the rest is carried into the next one) and is
         // parsed like a range of a mapped plain file.  Anything unusual -- a member that is not BGZF, a CRC that does not match, a
         // part that does not end between two records -- hands the stream to the ordinary reader at the last byte given out.
-        if (bgzf) {
-            size_t at = 0;             // compressed offset of the next member
+        // ---- any other stream (an ordinary gzip file, stdin, a small file): the same stretches, their bytes read by the ordinary
+        // reader's own zlib handle (one thread inflates -- that is gzip -- but the team parses; a stretch that is not plain records
+        // goes back into the reader and the ordinary rules take the stream from its first byte).
+        const bool stream_stretches = !parallel_read && !bgzf && !std::getenv("FMSI_HIP_SERIAL_READER") && !std::getenv("FMSI_HIP_NO_STREAM_STRETCHES");
+        if (bgzf || stream_stretches) {
+            size_t at = 0;             // (block-gzip) compressed offset of the next member
             uint64_t consumed = 0;     // uncompressed bytes handed on in batches
             std::string carry;
             bool eof = false, serial = false, first = true, fastq = false;
             uint64_t grow = 1;   // a record longer than a stretch: the next stretch is twice as long (so that carrying it along stays linear)
+            std::shared_ptr<char[]> seg;
+            size_t len = 0;
             while (!serial && !(eof && carry.empty())) {
                 const uint64_t range_bytes = (fastq ? 2 : 1) * opt.batch_windows * grow;
-                std::vector<BgzfFile::Member> ms;
-                std::vector<size_t> offs;
-                size_t bytes = 0;
-                while (!eof && bytes < range_bytes) {
-                    if (at >= bgzf.size()) {
-                        eof = true;
-                        break;
+                if (bgzf) {
+                    std::vector<BgzfFile::Member> ms;
+                    std::vector<size_t> offs;
+                    size_t bytes = 0;
+                    while (!eof && bytes < range_bytes) {
+                        if (at >= bgzf.size()) {
+                            eof = true;
+                            break;
+                        }
+                        BgzfFile::Member m;
+                        if (!bgzf.member(at, &m)) {
+                            serial = true;
+                            break;
+                        }
+                        offs.push_back(bytes);
+                        ms.push_back(m);
+                        bytes += m.isize;
+                        at = m.next;
                     }
-                    BgzfFile::Member m;
-                    if (!bgzf.member(at, &m)) {
+                    if (serial) break;
+                    len = carry.size() + bytes;
+                    seg.reset(new char[len + 1]);
+                    std::memcpy(seg.get(), carry.data(), carry.size());
+                    // (inflating is by far the longest piece of work on this path: the whole team takes it)
+                    const unsigned inflaters = static_cast<unsigned>(std::max<size_t>(1, std::min<size_t>(team, ms.size())));
+                    std::vector<char> ok(inflaters, 1);
+                    parallel_for(inflaters, [&](unsigned t) {
+                        for (size_t i = t; i < ms.size(); i += inflaters)
+                            if (!bgzf.inflate(ms[i], seg.get() + carry.size() + offs[i])) ok[t] = 0;
+                    });
+                    if (std::find(ok.begin(), ok.end(), 0) != ok.end()) {
                         serial = true;
                         break;
                     }
-                    offs.push_back(bytes);
-                    ms.push_back(m);
-                    bytes += m.isize;
-                    at = m.next;
+                } else {
+                    seg.reset(new char[carry.size() + range_bytes + 1]);
+                    std::memcpy(seg.get(), carry.data(), carry.size());
+                    const size_t got = reader->read_raw(seg.get() + carry.size(), range_bytes);
+                    eof = got < range_bytes;
+                    len = carry.size() + got;
                 }
-                if (serial) break;
-                const size_t len = carry.size() + bytes;
-                std::shared_ptr<char[]> seg(new char[len + 1]);
-                std::memcpy(seg.get(), carry.data(), carry.size());
-                // (inflating is by far the longest piece of work on this path: the whole team takes it)
-                const unsigned inflaters = static_cast<unsigned>(std::max<size_t>(1, std::min<size_t>(team, ms.size())));
-                std::vector<char> ok(inflaters, 1);
-                parallel_for(inflaters, [&](unsigned t) {
-                    for (size_t i = t; i < ms.size(); i += inflaters)
-                        if (!bgzf.inflate(ms[i], seg.get() + carry.size() + offs[i])) ok[t] = 0;
-                });
-                if (std::find(ok.begin(), ok.end(), 0) != ok.end()) {
-                    serial = true;
-                    break;
-                }
+                // (from here on `seg[0, len)` = the carried tail + the new bytes; whatever ends the loop with serial = true before the
+                // stretch's records were handed on leaves all of it to the ordinary reader)
                 const unsigned char* d = reinterpret_cast<const unsigned char*>(seg.get());
                 if (first && len) {
                     if (d[0] == '@') fastq = true;
@@ -552,6 +568,7 @@ private:
                 if (cut == 0 && !eof) {   // one record longer than the stretch: read on
                     carry.assign(seg.get(), len);
                     grow *= 2;
+                    len = 0;
                     continue;
                 }
                 grow = 1;
@@ -567,10 +584,11 @@ private:
                 std::vector<uint64_t> seq_bytes(parts, 0);
                 std::vector<char> clean(parts, 1);
                 auto nb = std::make_unique<RawBatch>();
-                if (!fastq && try_kmer_batch(d, cuts, len, *nb)) {   // (the lines are copies: the inflated bytes are not needed behind this point)
+                if (!fastq && try_kmer_batch(d, cuts, len, *nb)) {   // (the lines are copies: the stretch's bytes are not needed behind this point)
                     carry.assign(seg.get() + cut, len - cut);
                     consumed += cut;
                     parallel_read_bytes = consumed;
+                    len = 0;
                     if (nb->kmer_recs == 0) continue;
                     read_s += std::chrono::duration<double>(clock::now() - t0).count();
                     if (!raw_q.push(std::move(nb))) return;
@@ -596,6 +614,7 @@ private:
                 carry.assign(seg.get() + cut, len - cut);
                 consumed += cut;
                 parallel_read_bytes = consumed;
+                len = 0;
                 if (nb->recs.empty()) continue;
                 read_s += std::chrono::duration<double>(clock::now() - t0).count();
                 if (!raw_q.push(std::move(nb))) return;
@@ -606,7 +625,13 @@ private:
                 raw_q.close();
                 return;
             }
-            reader->skip(consumed);
+            if (bgzf) {
+                reader->skip(consumed);
+            } else if (len) {
+                reader->unread(seg.get(), len);       // (the stretch that was not plain records, its carried tail in front)
+            } else {
+                reader->unread(carry.data(), carry.size());
+            }
         }
         // ordinary reader: names and sequences are appended to the batch's text, which moves as it grows -- the records hold
         // offsets until the batch is complete

@@ -41,6 +41,36 @@ void FastxReader::skip(uint64_t bytes) {
     begin_ = end_ = 0;
 }
 
+size_t FastxReader::read_raw(char* dst, size_t n) {
+    size_t got = 0;
+    if (begin_ < end_) {   // (what unread() put back)
+        got = std::min(n, end_ - begin_);
+        std::memcpy(dst, buf_ + begin_, got);
+        begin_ += got;
+    }
+    while (fp_ && got < n && !eof_) {
+        const int r = gzread(fp_, dst + got, static_cast<unsigned>(std::min<size_t>(n - got, size_t(1) << 30)));
+        if (r <= 0) {
+            eof_ = true;
+            break;
+        }
+        got += static_cast<size_t>(r);
+    }
+    return got;
+}
+
+void FastxReader::unread(const char* data, size_t n) {
+    if (!fp_) return;
+    std::vector<unsigned char> held(buf_ + begin_, buf_ + end_);   // (bytes not yet consumed stay behind the returned ones)
+    own_.resize(std::max<size_t>(kBufSize, n + held.size()));
+    std::memcpy(own_.data(), data, n);
+    if (!held.empty()) std::memcpy(own_.data() + n, held.data(), held.size());
+    buf_ = own_.data();
+    begin_ = 0;
+    end_ = n + held.size();
+    if (end_) eof_ = false;   // (the stream may have ended while read_raw() was at it: what came back is still to be read; fill_() finds the end again)
+}
+
 BgzfFile::~BgzfFile() {
     if (data_) munmap(const_cast<unsigned char*>(data_), size_);
 }

@@ -43,6 +43,12 @@ public:
     // file mode, before the first record is read: go on from `bytes` into the UNCOMPRESSED stream (what a reader that took the
     // first part of the stream itself has consumed)
     void skip(uint64_t bytes);
+    // file mode, before the first record is read: the next bytes of the UNCOMPRESSED stream as they are, up to n of them (fewer: the stream
+    // ended) -- and back again: bytes handed out that their taker could not use are read by next() / next_append() before anything else.
+    // (How the CLI parses gzip files and stdin: stretches of the stream cut at record starts and parsed by several threads, like a
+    // block-gzip file's; a stretch that is not plain records goes back and the ordinary rules take the stream from there.)
+    size_t read_raw(char* dst, size_t n);
+    void unread(const char* data, size_t n);
 
     std::string name;
     std::string seq;

@@ -425,19 +425,22 @@ __global__ __launch_bounds__(256) void ptable_unpack_kernel(uint2* __restrict__ 
     }
 }
 
-// (i, length) -> the entries of 1..3 rows get the signatures of their rows (decode_table_entry), in place, each entry one 8-byte store:
-// a kernel that reads the table meanwhile sees an entry in the one form or the other, and both say the same interval
+// (i, length) -> the entries of 1..5 rows get the signatures of their rows (decode_table_entry: four symbols each for 1..3 rows, three for
+// 4 and 5), in place, each entry one 8-byte store: a kernel that reads the table meanwhile sees an entry in the one form or the other, and
+// both say the same interval
 __global__ __launch_bounds__(256) void ptable_sign_kernel(DevIndex ix, uint2* __restrict__ tab, uint64_t count) {
     const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
     for (uint64_t idx = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; idx < count; idx += stride) {
         const uint2 e = tab[idx];
         const uint32_t len = e.y;
-        if (len < 1u || len > 3u) continue;   // (a signed entry has bit 30 set)
-        uint32_t y = (1u << 30) | (len << 24);
+        if (len < 1u || len > 5u) continue;   // (a signed entry has bit 30 or 31 set)
+        const bool wide = len <= 3u;          // four symbols per row, else three
+        const int steps = wide ? 4 : 3;
+        uint32_t y = wide ? ((1u << 30) | (len << 24)) : ((len - 2u) << 30);
         for (uint32_t m = 0; m < len; ++m) {
             uint32_t row = e.x + m, sig = 0;
             bool alive = true;
-            for (int step = 0; step < 4; ++step) {
+            for (int step = 0; step < steps; ++step) {
                 uint32_t c = 0;
                 if (alive && row != ix.dollar) {
                     const uint32_t* blk = reinterpret_cast<const uint32_t*>(ix.blocks) + (static_cast<size_t>(row >> kBlockRowsLog2) << 4);
@@ -451,14 +454,12 @@ __global__ __launch_bounds__(256) void ptable_sign_kernel(DevIndex ix, uint2* __
                 }
                 sig = (sig << 2) | c;
             }
-            y |= sig << (8u * m);
+            y |= sig << ((wide ? 8u : 6u) * m);
         }
         tab[idx] = make_uint2(e.x, y);
     }
 }
 
-// the signatures may be written beside the first queries (FMSI_HIP_LOAD_ASYNC_TABLE: `fmsi query`, whose run at human scale is over in
-// the time the pass takes): whoever changes or reads the table as a whole waits for them here
 void warm_table_module() {
     hipFuncAttributes attr;
     (void)hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(&ptable_level_kernel<true>));

@@ -278,7 +278,9 @@ __global__ __launch_bounds__(256) void pair_lookup_kernel(PairIndex ix, const ui
             }
             return nf == 0u ? 0u : 2u;
         }
-        decode_table_entry(ex, ey, ix.ptable_packed, t >= 3, t >= 3 ? static_cast<uint32_t>(cur >> (2 * (t - 3))) & 0xFFu : 0u, i, j);
+        // (a candidate-table copy of an entry of 4 or 5 rows is a plain interval whose three-symbol signatures ride in the third word)
+        const uint32_t ysig = (verify && (ey >> 30) == 0u && (cand0 >> 31)) ? cand0 : ey;
+        decode_table_entry(ex, ysig, ix.ptable_packed, t >= 3, t >= 3 ? static_cast<uint32_t>(cur >> (2 * (t - 3))) & 0xFFu : 0u, i, j);
         if (sub == 0u) n_lookups++;
         if (i == j) return 0u;
         if (!(verify && (ey >> 30) == 1u)) return 1u;
@@ -529,7 +531,7 @@ __global__ __launch_bounds__(256) void lookup_lane_kernel(PairIndex ix, const ui
             }
             return nf == 0u ? 0u : 2u;
         }
-        decode_table_entry(ex, ey, 1u, t >= 3, t >= 3 ? static_cast<uint32_t>(cur >> (2 * (t - 3))) & 0xFFu : 0u, i, j);
+        decode_table_entry(ex, ((ey >> 30) == 0u && (cand0 >> 31)) ? cand0 : ey, 1u, t >= 3, t >= 3 ? static_cast<uint32_t>(cur >> (2 * (t - 3))) & 0xFFu : 0u, i, j);
         if (i == j) return 0u;
         if ((ey >> 30) != 1u) return 1u;
         const uint32_t rows = (ey >> 24) & 3u;
@@ -1407,11 +1409,16 @@ __global__ __launch_bounds__(256) void verify_fill_kernel(const uint2* __restric
     auto rows_of = [](uint2 e) -> uint32_t { return (e.y >> 30) == 1u ? ((e.y >> 24) & 3u) : e.y; };   // 8-byte format: tag 0 = length
     for (uint64_t idx = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; idx < count; idx += stride) {
         uint2 e = tab[idx];
+        // (the 8-byte table's entries of 4 and 5 rows -- tags 2 and 3, three-symbol signatures -- are plain intervals here: in this table tag 2 is
+        // the double-stranded entry)
+        auto plain = [](uint2 t) -> uint2 { return (t.y >> 30) >= 2u ? make_uint2(t.x, 2u + (t.y >> 30)) : t; };
+        const uint32_t signed_y = e.y;   // (... and their signatures ride where such an entry has no candidate: the third word, bit 31 set)
+        e = plain(e);
         uint32_t cand[7] = {0, 0, 0, 0, 0, 0, 0};
         const uint32_t nf = rows_of(e);
         bool done = false;
         if (bases_mode && nf <= max_total) {
-            uint2 er = tab[revcomp_2bit(idx, static_cast<int>(T))];
+            const uint2 er = plain(tab[revcomp_2bit(idx, static_cast<int>(T))]);
             const uint32_t nr = rows_of(er);
             if (nf + nr <= max_total) {
                 // narrow: nf in bits 24-25, nr in bits 22-23, mask bits from bit 26; wide: nf bits 0-2, nr bits 3-5, mask bits from bit 8
@@ -1461,6 +1468,7 @@ __global__ __launch_bounds__(256) void verify_fill_kernel(const uint2* __restric
             }
             e.y = y;   // (the 8-byte table stays as it is: the mask bits live in the lookup kernel's copy)
         }
+        if (!done && (signed_y >> 31)) cand[0] = signed_y;
         if (wide) {   // (no side array: an interval entry's third candidate sits where a double-stranded entry has its fourth)
             vtable[2 * idx] = make_uint4(e.x, e.y, cand[0], cand[1]);
             vtable[2 * idx + 1] = done ? make_uint4(cand[3], cand[4], cand[5], cand[6]) : make_uint4(cand[2], 0, 0, 0);

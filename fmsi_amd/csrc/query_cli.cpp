@@ -971,6 +971,7 @@ extern "C" int fmsi_cli_query(int argc, char** argv, int output_orders_i) {
     bool stream_kernel = load_klcp || stream_without_S;   // (without -S: only as long as the kLCP file loads -- the reference would never open it)
     // ... and the streaming kernel's absence certificates need table keys of few rows (fmsi_stream.hip: off above 7 rows per key): one level
     // more than the default where that decides it (human scale: 15 -- 2.6 rows per key, 8.6 GB -- instead of 14)
+    const int t_before_raise = t;
     if (stream_kernel && !std::getenv("FMSI_HIP_CLI_TABLE_DEPTH") && !opt.tables_given)
         while (t >= 14 && t < 16 && t < k && static_cast<double>(index_rows) > 7.0 * static_cast<double>(1ull << (2 * t)) && (1ull << (2 * (t + 1))) <= 4 * index_rows) ++t;
 
@@ -978,6 +979,7 @@ extern "C" int fmsi_cli_query(int argc, char** argv, int output_orders_i) {
     struct DeviceCtx {
         int device = 0;
         fmsi_hip_index* dev = nullptr;
+        bool stream = false;   // this handle has the kLCP array: its reads go through the streaming kernel
         bool have_dict = false;
         // the dictionary built beside the queries (--tables background / large inputs): a second handle, published when it stands
         fmsi_hip_index* dict_dev = nullptr;
@@ -1018,19 +1020,40 @@ extern "C" int fmsi_cli_query(int argc, char** argv, int output_orders_i) {
     // the others follow) and the optional ones are left out; only a failure of the index proper is an error.
     auto setup = [&](DeviceCtx& c, bool first) -> bool {
         int rc_create = FMSI_HIP_ENOMEM;
+        // (a device other than the first starts from what the first one settled on and may go further down by itself: what it streams
+        // with and how deep its table is are its own, DeviceCtx::stream)
+        int tt = t;
+        bool st = stream_kernel;
         for (;;) {
             // (the table's signatures are written beside the first batches: FMSI_HIP_LOAD_ASYNC_TABLE, include/fmsi_hip.h)
             static const bool sync_table = std::getenv("FMSI_HIP_CLI_SYNC_TABLE") != nullptr;   // (A/B runs)
-            rc_create = fmsi_hip_index_load(opt.index_prefix.c_str(), (stream_kernel ? FMSI_HIP_LOAD_KLCP : 0) | (sync_table ? 0 : FMSI_HIP_LOAD_ASYNC_TABLE), c.device,
-                                            std::max(t, 0), &c.dev);
-            if (rc_create != 0 && rc_create != FMSI_HIP_ENOMEM && first && stream_kernel && !load_klcp) {
+            rc_create = fmsi_hip_index_load(opt.index_prefix.c_str(), (st ? FMSI_HIP_LOAD_KLCP : 0) | (sync_table ? 0 : FMSI_HIP_LOAD_ASYNC_TABLE), c.device, std::max(tt, 0), &c.dev);
+            if (rc_create != 0 && rc_create != FMSI_HIP_ENOMEM && st && !load_klcp) {
                 // a kLCP file that does not load must not fail a run that never asked for it: the searches of round 3 answer instead
-                stream_kernel = false;
+                st = false;
                 continue;
             }
-            if (rc_create != FMSI_HIP_ENOMEM || t <= 0 || !first) break;
-            std::cerr << "WARNING: not enough device memory for a prefix table of depth " << t << ", trying " << std::max(t - 2, 0) << std::endl;
-            t = std::max(t - 2, 0);
+            if (rc_create != FMSI_HIP_ENOMEM) break;
+            // Not enough device memory.  In this order: the depth a streaming run was raised to goes back to the one chosen before; a run
+            // that streams without having been asked to (no -S) lets the kLCP array and the streaming layout go and answers by the plain
+            // searches, as round 3 did; then the table shrinks, two levels at a time.
+            if (st && tt > t_before_raise) {
+                std::cerr << "WARNING: not enough device memory for a prefix table of depth " << tt << ", trying " << t_before_raise << std::endl;
+                tt = t_before_raise;
+            } else if (st && !load_klcp) {
+                std::cerr << "WARNING: not enough device memory to stream the windows through the kLCP kernel; taking the plain searches (same answers)" << std::endl;
+                st = false;
+            } else if (tt > 0) {
+                std::cerr << "WARNING: not enough device memory for a prefix table of depth " << tt << ", trying " << std::max(tt - 2, 0) << std::endl;
+                tt = std::max(tt - 2, 0);
+            } else {
+                break;
+            }
+        }
+        c.stream = st;
+        if (first) {
+            t = tt;
+            stream_kernel = st;
         }
         if (rc_create != 0) {
             c.error = rc_create == FMSI_HIP_EIO ? "index files" : fmsi_hip_last_error();
@@ -1049,7 +1072,7 @@ extern "C" int fmsi_cli_query(int argc, char** argv, int output_orders_i) {
             if (!c.have_dict)
                 std::cerr << "WARNING: the k-mer dictionary is off on device " << c.device << " (" << fmsi_hip_last_error() << "); results are unaffected" << std::endl;
         }
-        if (!stream_kernel && !general && !c.have_dict && !wide && fmsi_hip_index_enable_pair_layout(c.dev) != 0) {
+        if (!c.stream && !general && !c.have_dict && !wide && fmsi_hip_index_enable_pair_layout(c.dev) != 0) {
             c.error = fmsi_hip_last_error();
             return false;
         }
@@ -1261,7 +1284,7 @@ extern "C" int fmsi_cli_query(int argc, char** argv, int output_orders_i) {
                             check(fmsi_hip_query_runs_fn(cp->dev, P->packed.data(), P->lower.empty() ? nullptr : P->lower.data(), P->bases, P->run_start.data(), P->run_windows.data(), P->run_start.size(), nw, k,
                                                          opt.fn, opt.fn_r, opt.fn_s, FMSI_HIP_OUT_BITS, dst, nullptr, nullptr),
                                   "fmsi_hip_query_runs_fn");
-                        else if (stream_kernel && !cp->have_dict && !bg_dict && !rows64)   // -S: kLCP streaming kernel (query_kmers_streaming, src/fms_index.h:181-254)
+                        else if (cp->stream && !cp->have_dict && !bg_dict && !rows64)   // -S: kLCP streaming kernel (query_kmers_streaming, src/fms_index.h:181-254)
                             check(fmsi_hip_query_stream(handle, P->packed.data(), P->bases, P->run_start.data(), P->run_windows.data(),
                                                         P->run_start.size(), nw, k, flags, dst, nullptr, nullptr),
                                   "fmsi_hip_query_stream");

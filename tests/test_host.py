@@ -6,6 +6,7 @@ that the product fails LOUDLY without a GPU instead of falling back to anything.
 import ctypes as C
 import re
 import random
+import gzip
 import json
 import os
 import subprocess
@@ -331,9 +332,10 @@ def test_cli_host_pipeline_under_sanitizers(tmp_path, sanitizer):
     mixed = messy_fasta(ms, rng, fastq_at=150)
     files = {}
     for tag, data in (("fa", fasta), ("fq", mixed)):
-        files[tag] = [tmp_path / f"q_{tag}.txt", tmp_path / f"q_{tag}.txt.gz"]
+        files[tag] = [tmp_path / f"q_{tag}.txt", tmp_path / f"q_{tag}.txt.gz", tmp_path / f"q_{tag}.plain.gz"]
         files[tag][0].write_bytes(data)
         files[tag][1].write_bytes(bgzf_bytes(data, block=900))
+        files[tag][2].write_bytes(gzip.compress(data, 1))   # one ordinary gzip member: stretches of the stream, parsed by the team (and stdin below)
     env = {**os.environ, "FMSI_HIP_READER_MIN_BYTES": "1", "TSAN_OPTIONS": "halt_on_error=1", "ASAN_OPTIONS": "detect_leaks=0"}
     prefix = str(GOLDEN / "idx" / "sars_k13")
     # a last batch whose whole text fits a std::string's inline buffer (the ordinary reader's batches hold views into their own text:
@@ -353,6 +355,10 @@ def test_cli_host_pipeline_under_sanitizers(tmp_path, sanitizer):
             res = subprocess.run([str(exe), *mode, "-q", str(paths[0]), prefix], capture_output=True, env={**env, "FMSI_HIP_SERIAL_READER": "1"})
             assert res.returncode == 0
             outs.add(res.stdout)
+            for opts in ([], ["--batch", "3000", "--threads", "4"]):   # the same bytes through a pipe
+                res = subprocess.run([str(exe), *mode, *opts, "-q", "-", prefix], input=paths[0].read_bytes(), capture_output=True, env=env)
+                assert res.returncode == 0, (mode, tag, opts, res.stderr.decode()[-2000:])
+                outs.add(res.stdout)
             assert len(outs) == 1 and len(res.stdout) > 10000, (mode, tag)
     # ---- records of ONE k-mer each (cli_reader.h: KmerPart): the parser packs the k-mer and writes the record's line, the answer is filled
     # in behind the device.  The output is the general path's (FMSI_HIP_CLI_KMER_BATCHES=0), whatever the batch size and the team, for
@@ -382,17 +388,18 @@ def test_cli_host_pipeline_under_sanitizers(tmp_path, sanitizer):
 
     kfiles = {"pure": kmer_records(6000), "no_tail": kmer_records(3000, tail_newline=False), "odd": kmer_records(6000, odd_every=997), "odd_often": kmer_records(3000, odd_every=40)}
     for tag, data in kfiles.items():
-        plain, gz = tmp_path / f"k_{tag}.fa", tmp_path / f"k_{tag}.fa.gz"
+        plain, gz, zgz = tmp_path / f"k_{tag}.fa", tmp_path / f"k_{tag}.fa.gz", tmp_path / f"k_{tag}.plain.gz"
         plain.write_bytes(data)
         gz.write_bytes(bgzf_bytes(data, block=3000))
+        zgz.write_bytes(gzip.compress(data, 1))
         for mode in (["query"], ["query", "-O"], ["query", "-S", "-O"], ["lookup"]):
             general = subprocess.run([str(exe), *mode, "-q", str(plain), prefix], capture_output=True, env={**env, "FMSI_HIP_CLI_KMER_BATCHES": "0"})
             assert general.returncode == 0 and general.stdout.count(b"\n") >= 3000, (tag, mode, general.stderr.decode()[-2000:])
-            for q in (plain, gz):
+            for q in (plain, gz, zgz, "-"):
                 for opts in ([], ["--batch", "4096", "--threads", "3"], ["--batch", "30000", "--threads", "7", "--devices", "0,0"]):
-                    res = subprocess.run([str(exe), *mode, *opts, "--stats", "-q", str(q), prefix], capture_output=True, env=env)
+                    res = subprocess.run([str(exe), *mode, *opts, "--stats", "-q", str(q), prefix], capture_output=True, env=env, input=data if q == "-" else None)
                     assert res.returncode == 0, (tag, mode, opts, res.stderr.decode()[-3000:])
-                    assert res.stdout == general.stdout, (tag, mode, q.name, opts)
+                    assert res.stdout == general.stdout, (tag, mode, str(q), opts)
                     stats = json.loads([l for l in res.stderr.decode().splitlines() if l.startswith("{")][-1])
                     if mode[0] != "query":
                         assert stats["kmer_batches"] == 0
@@ -539,8 +546,9 @@ def test_bench_defaults():
 
 
 def test_bench_compact_line_of_the_final_record_keeps_every_leg():
-    """Round 4's final record has 18 legs (the kLCP kernel's `lookup -S` and k = 48 legs among them): its compact form is the committed
-    last line, every leg keeps name / value / ms / frac / hbm_frac / matches_reference, and it is what compact_line() makes of the full one."""
+    """Round 5's record has 22 legs (the kLCP kernel at the CLI's table depth and at 16, the whole-process legs incl. the query file of one
+    k-mer per record): its compact form is the committed one, below the limit with every leg, and every leg keeps name / value /
+    matches_reference and says what it was measured on -- `hbm_gb` of the handle, or `load_s` and `after_load` of the process."""
     import importlib.util
     import json
     import sys
@@ -552,18 +560,23 @@ def test_bench_compact_line_of_the_final_record_keeps_every_leg():
         spec.loader.exec_module(m)
     finally:
         sys.argv = argv
-    lines = (REPO / "profiles" / "r04zzz_bench_default.json").read_text().splitlines()
-    full, last = json.loads(lines[0]), lines[-1]
+    full = json.loads((REPO / "profiles" / "r05h_bench_default_full.json").read_text())
+    last = (REPO / "profiles" / "r05h_bench_default_compact.json").read_text().strip()
     assert len(last) <= m.COMPACT_LIMIT and m.compact_line(full) == last
     d = json.loads(last)
     names = [c["name"] for c in d["configs"]]
-    assert len(names) == len(full["configs"]) == 18
-    for want in ("c4_klcp", "c4_klcp_subst1pct", "c4_klcp_lookup", "c4_klcp_lookup_fast", "c4_klcp_k48", "c4_superkmer", "c3_superkmer", "e2e_or", "e2e_all_S"):
+    assert len(names) == len(full["configs"]) == 22
+    for want in ("c4_klcp", "c4_klcp_subst1pct", "c4_klcp_lookup", "c4_klcp_lookup_fast", "c4_klcp_t16", "c4_klcp_k48", "c4_superkmer", "c3_superkmer", "e2e_or", "e2e_all_S",
+                 "e2e_isolated_or", "e2e_isolated_all"):
         assert want in names, want
     for c in d["configs"]:
-        assert c["matches_reference"] is True and c["value"] > 0 and c["ms"] > 0, c
-        if c["name"].startswith("c4_") or c["name"].startswith("c3") or c["name"].startswith("c5"):
-            assert 0 < c["frac"] < 1 and 0 < c["hbm_frac"] < 1, c
+        assert c["matches_reference"] is True and c["value"] > 0, c
+        if c["name"].startswith("e2e"):
+            assert c["load_s"] > 0 and c["after_load"] > c["value"], c
+        else:
+            assert c["hbm_gb"] > 0, c
+            if not c["name"].startswith("c2"):
+                assert 0 < c["hbm_frac"] < 1, c
     assert d["roofline"]["kernel"].startswith("sk_kmers_kernel") and len(d["roofline"]["lf_path"]) == 3 and d["cpu_baseline"]["kind"] == "reference"
 
 
