@@ -279,9 +279,15 @@ size_t last_record_start(const unsigned char* d, size_t len, bool fastq) {
 }
 
 // all records of d[lo, hi) (lo at a record start) as views (FastxViewParser: the ordinary reader's rules)
-bool parse_range(const unsigned char* d, size_t lo, size_t hi, FastxViewParser::Arena& arena, std::vector<RecRef>& recs, uint64_t& seq_bytes,
+bool parse_range(const unsigned char* d, size_t lo, size_t hi, FastxViewParser::Arena& arena_out, std::vector<RecRef>& recs_out, uint64_t& seq_bytes_out,
                  bool fastq = false) {
+    // (the callers' per-part results sit side by side -- vector headers and counters of eight threads on one or two cache lines -- and a
+    // record is a push_back and an add: everything stays local until the part is done)
     FastxViewParser r(d + lo, hi - lo);
+    FastxViewParser::Arena arena;
+    std::vector<RecRef> recs;
+    recs.reserve((hi - lo) / 256 + 16);
+    uint64_t seq_bytes = 0;
     for (;;) {
         RecRef rr;
         size_t name_len, seq_len;
@@ -291,6 +297,9 @@ bool parse_range(const unsigned char* d, size_t lo, size_t hi, FastxViewParser::
         recs.push_back(rr);
         seq_bytes += seq_len;
     }
+    arena_out = std::move(arena);
+    recs_out = std::move(recs);
+    seq_bytes_out += seq_bytes;
     // FASTA file: clean = no '+' line was met (then '>' lines are record starts).  FASTQ file: clean = the part ended between two
     // records -- then the next part starts where the sequential parse would start a record, too.
     return fastq ? r.clean_end() : !r.saw_fastq();

@@ -269,7 +269,7 @@ struct Prepared {
     PinVec<int64_t> orders;               // lookup: device results, then the final order per window
 };
 
-struct TeamPlan {   // what one thread of the team found in its records
+struct alignas(128) TeamPlan {   // what one thread of the team found in its records (a cache line pair of its own: the team's plans are neighbours in one array)
     std::vector<Op> ops;
     std::vector<uint32_t> rec_nops;
     std::vector<uint64_t> rec_windows, rec_symbols;
@@ -619,50 +619,107 @@ void replay_batch(Prepared& P, StrandPredictor& predictor, Mode mode, bool order
         int16_t sums[2][2];   // [swap][first, second]
         bool order_matters;
     };
-    std::vector<Chunk> chunks;
-    for (size_t r = 0; r + 1 < P.rec_ops.size(); ++r) {
+    // the chunks of run `o` of record r as src/main.cpp:340-354 cuts them
+    auto for_chunks_of = [&](size_t r, auto&& fn) {
         const uint64_t L = P.raw.recs[r].seq_len;
         const int64_t max_chunk = k + std::max<int64_t>(10, std::min<int64_t>(400, 2 * static_cast<int64_t>(std::sqrt(static_cast<int64_t>(L)))));   // src/main.cpp:330-331
         uint64_t w = P.rec_first[r];
         for (uint64_t o = P.rec_ops[r]; o < P.rec_ops[r + 1]; ++o) {
             if (!P.ops[o].is_run) continue;
-            // chunks of the run as src/main.cpp:340-354 cuts them
             int64_t current_length = static_cast<int64_t>(P.ops[o].count) + k - 1;
             while (current_length >= k) {
                 const int64_t chunk_length = std::min<int64_t>(current_length, max_chunk);
                 const uint64_t n = static_cast<uint64_t>(chunk_length - k + 1);
-                if (orders) replay_streaming_chunk(predictor, mode, orders, P, w, n);
-                else chunks.push_back(Chunk{w, static_cast<uint32_t>(n), {{0, 0}, {0, 0}}, false});
+                fn(w, n);
                 w += n;
                 current_length -= static_cast<int64_t>(n);
             }
         }
+    };
+    const size_t nrec = P.rec_ops.empty() ? 0 : P.rec_ops.size() - 1;
+    if (orders) {
+        for (size_t r = 0; r < nrec; ++r) for_chunks_of(r, [&](uint64_t w, uint64_t n) { replay_streaming_chunk(predictor, mode, orders, P, w, n); });
+        return;
     }
-    if (orders || chunks.empty()) return;
+    // (A) by the team: the records' chunks listed -- a read of 150 bases is five of them, a batch of such reads millions: one thread's list
+    // was 0.2 s per 7 x 10^8 windows --, then their sums and output bytes
     const bool maximized_ones = mode == Mode::All;
-    const size_t nc = chunks.size();
-    team = static_cast<unsigned>(std::max<size_t>(1, std::min<size_t>(team, nc / 256 + 1)));
-    parallel_for(team, [&](unsigned t) {
-        for (size_t c = nc / team * t, hi = t + 1 == team ? nc : nc / team * (t + 1); c < hi; ++c) {
-            Chunk& ch = chunks[c];
-            uint8_t* b = P.bytes.data() + ch.w0;
-            int sums[2][2];
-            ch.order_matters = chunk_sums(b, ch.n, maximized_ones, sums);
-            for (int sw = 0; sw < 2; ++sw)
-                for (int j = 0; j < 2; ++j) ch.sums[sw][j] = static_cast<int16_t>(sums[sw][j]);
-            if (!ch.order_matters) chunk_output(b, ch.n, maximized_ones);
-        }
+    const unsigned listers = static_cast<unsigned>(std::max<size_t>(1, std::min<size_t>(team, nrec / 4096 + 1)));
+    std::vector<std::vector<Chunk>> listed(listers);
+    std::vector<char> any_matters(listers, 0);
+    parallel_for(listers, [&](unsigned t) {
+        std::vector<Chunk> mine;   // (local until done: the lists' headers are neighbours)
+        const size_t lo = nrec / listers * t, hi = t + 1 == listers ? nrec : nrec / listers * (t + 1);
+        mine.reserve((hi - lo) * 2 + 16);
+        bool matters = false;
+        for (size_t r = lo; r < hi; ++r)
+            for_chunks_of(r, [&](uint64_t w, uint64_t n) {
+                Chunk ch{w, static_cast<uint32_t>(n), {{0, 0}, {0, 0}}, false};
+                uint8_t* b = P.bytes.data() + w;
+                int sums[2][2];
+                ch.order_matters = chunk_sums(b, ch.n, maximized_ones, sums);
+                for (int sw = 0; sw < 2; ++sw)
+                    for (int j = 0; j < 2; ++j) ch.sums[sw][j] = static_cast<int16_t>(sums[sw][j]);
+                if (!ch.order_matters) chunk_output(b, ch.n, maximized_ones);
+                matters |= ch.order_matters;
+                mine.push_back(ch);
+            });
+        any_matters[t] = matters ? 1 : 0;
+        listed[t] = std::move(mine);
     });
-    for (Chunk& ch : chunks) {
-        if (ch.order_matters) {   // (non-max-ones masks under -O only)
-            replay_streaming_chunk(predictor, mode, false, P, ch.w0, ch.n);
-            continue;
-        }
-        const bool swap = predictor.predict_swap();
+    auto step = [](StrandPredictor& p, const Chunk& ch) {
+        const bool swap = p.predict_swap();
         const int first_sum = ch.sums[swap][0], second_sum = ch.sums[swap][1];
-        if (swap) predictor.log_result(second_sum, first_sum);
-        else predictor.log_result(first_sum, second_sum);
+        if (swap) p.log_result(second_sum, first_sum);
+        else p.log_result(first_sum, second_sum);
+    };
+    // (B) the predictor over the chunks, in order.  A chunk whose output depends on the strand order (non-max-ones masks under -O) needs
+    // the predictor's decision at that point: with one of those in the batch it is the plain walk.
+    if (std::find(any_matters.begin(), any_matters.end(), 1) != any_matters.end()) {
+        for (auto& list : listed)
+            for (Chunk& ch : list) {
+                if (ch.order_matters) replay_streaming_chunk(predictor, mode, false, P, ch.w0, ch.n);
+                else step(predictor, ch);
+            }
+        return;
     }
+    // Otherwise all that is left is the state the predictor ends in -- and that is replay_presence_team's situation: every list but the
+    // first is walked from a state warmed up over the 4096 chunks in front of it; where that state IS the one the list before ended in, the
+    // walk stands, where not it is done again from the true state.  (7 x 10^8 windows of 150-base reads under -S: 3 x 10^7 chunks, 0.3 s of
+    // one thread.)
+    constexpr size_t kWarm = 4096;
+    std::vector<StrandPredictor> from(listers), to(listers);
+    from[0] = predictor;
+    parallel_for(listers, [&](unsigned t) {
+        StrandPredictor q = from[0];
+        if (t) {
+            q = StrandPredictor();
+            q.previous = 0;
+            size_t need = kWarm;   // the last kWarm chunks in front of list t (they may lie in several lists)
+            unsigned first_list = t;
+            size_t first_at = 0;
+            while (need && first_list > 0) {
+                --first_list;
+                const size_t have = listed[first_list].size();
+                first_at = have > need ? have - need : 0;
+                need -= have - first_at;
+            }
+            for (unsigned l = first_list; l < t; ++l)
+                for (size_t c = l == first_list ? first_at : 0; c < listed[l].size(); ++c) step(q, listed[l][c]);
+            from[t] = q;
+        }
+        for (const Chunk& ch : listed[t]) step(q, ch);
+        to[t] = q;
+    });
+    StrandPredictor cur = to[0];
+    for (unsigned t = 1; t < listers; ++t) {
+        if (same_state(cur, from[t])) {
+            cur = to[t];
+        } else {
+            for (const Chunk& ch : listed[t]) step(cur, ch);
+        }
+    }
+    predictor = cur;
 }
 
 // ---- formatting ----------------------------------------------------------------------------------

@@ -214,5 +214,56 @@ int main() {
             if (ob != want_ok || (want_ok && b != want)) return fail("kmer_word_bmi2", it, static_cast<size_t>(k));
         }
     }
+    // -S replay of a batch of short reads (replay_batch, streaming): the chunks listed and summed by the team, the predictor's state walked
+    // list by list from warmed-up states -- the same bytes and the same final state as with one thread, whatever the strand results are:
+    // without windows whose output depends on the strand order (the state walk alone), and with them (the plain walk)
+    for (size_t it = 0; it < 12; ++it) {
+        const int k = 13;
+        const Mode mode = it % 2 ? Mode::All : Mode::Or;
+        const bool with_order_windows = it % 4 >= 2;
+        const size_t nrec = 60000 + rng() % 20000;
+        auto build = [&](Prepared& P, std::vector<RecRef>& recs) {
+            uint64_t w = 0;
+            P.rec_ops.push_back(0);
+            for (size_t r = 0; r < nrec; ++r) {
+                const uint64_t L = 20 + (r * 2654435761ull) % 300;
+                recs.push_back(RecRef{nullptr, nullptr, L, 0});
+                P.rec_first.push_back(w);
+                const uint64_t windows = L - k + 1;
+                if (r % 7 == 3) {   // an invalid character in the middle: two runs and a fill
+                    const uint64_t a = windows / 2;
+                    if (a) P.ops.push_back({a, true});
+                    P.ops.push_back({static_cast<uint64_t>(k), false});
+                    w += a;
+                } else {
+                    P.ops.push_back({windows, true});
+                    w += windows;
+                }
+                P.rec_ops.push_back(P.ops.size());
+            }
+            P.rec_first.push_back(w);
+            P.windows = w;
+        };
+        Prepared A, B;
+        build(A, A.raw.recs);
+        build(B, B.raw.recs);
+        A.bytes.resize(A.windows);
+        std::mt19937_64 gen(it * 77 + 1);
+        for (uint64_t w = 0; w < A.windows; ++w) {
+            int f, r;
+            const uint64_t x = gen();
+            if ((w / 5000) % 3 == 0) { f = r = -1; }                                   // stretches that never move the scores
+            else if (x % 2) { f = 1; r = -1; if (x % 8 < 3) std::swap(f, r); }
+            else { f = r = static_cast<int>(x % 3) - 1; }
+            if (with_order_windows && x % 1000 == 7) { f = 0; r = 1; }
+            A.bytes[w] = static_cast<uint8_t>((f + 1) | ((r + 1) << 2));
+        }
+        B.bytes = A.bytes;
+        StrandPredictor pa, pb;
+        if (it % 3) { pa.score = 3; pa.result_scores[0] = -2; pa.result_scores[1] = 5; pa.previous = 1; pb = pa; }
+        replay_batch(A, pa, mode, false, true, k, 1);
+        replay_batch(B, pb, mode, false, true, k, 2 + static_cast<unsigned>(it % 7));
+        if (A.bytes != B.bytes || !same_state(pa, pb)) return fail("replay_batch -S by the team", it, static_cast<size_t>(A.windows));
+    }
     return 0;
 }

@@ -96,6 +96,7 @@ def main() -> None:
     ap.add_argument("--kmer-records", type=int, default=0,
                     help="after the reads: a second query file of this many records of ONE k-mer each (half present, drawn on the device), through --kmer-modes")
     ap.add_argument("--kmer-modes", default="or,all")
+    ap.add_argument("--keep", action="store_true", help="leave the index files and the query files in --dir (further runs by hand)")
     ap.add_argument("--n", type=int, default=100_000_000)
     ap.add_argument("--reads", type=int, default=20_000)
     ap.add_argument("--read-len", type=int, default=10_000)
@@ -261,9 +262,10 @@ def main() -> None:
     if a.out:
         Path(a.out).parent.mkdir(parents=True, exist_ok=True)
         Path(a.out).write_text(json.dumps(report, indent=1) + "\n")
-    for f in work.iterdir():
-        f.unlink()
-    work.rmdir()
+    if not a.keep:
+        for f in work.iterdir():
+            f.unlink()
+        work.rmdir()
 
 
 if __name__ == "__main__":
