@@ -3,6 +3,7 @@
 // reference's CLI (index construction, set operations, export, ...) is out of scope of this build and
 // says so instead of silently doing something different.
 #include <signal.h>
+#include <sys/prctl.h>
 #include <sys/wait.h>
 #include <unistd.h>
 
@@ -84,6 +85,7 @@ int main(int argc, char* argv[]) {
         int done_pipe[2] = {-1, -1};
         pid_t child = -1;
         if (!full_exit && !std::getenv("FMSI_HIP_CLI_NO_FORK") && pipe(done_pipe) == 0) {
+            const pid_t parent_pid = getpid();
             child = fork();
             if (child < 0) {
                 close(done_pipe[0]);
@@ -105,6 +107,10 @@ int main(int argc, char* argv[]) {
             } else {
                 close(done_pipe[0]);
                 g_done_fd = done_pipe[1];
+                // the child lives and dies with the process the caller knows: whatever ends the parent early (a `timeout`, a kill of that one
+                // PID) ends the child, too -- and when the parent leaves in the ordinary way the child is past its output and only tearing down
+                prctl(PR_SET_PDEATHSIG, SIGKILL);
+                if (getppid() != parent_pid) _exit(1);   // (the parent was gone before the request stood)
             }
         }
         if (!full_exit) fmsi_cli_set_exit_hook(leave_now);   // (called at the command's last line, before anything is released)
