@@ -161,6 +161,18 @@ inline uint64_t run_end(const uint8_t* p, uint64_t from, uint64_t n, uint8_t v) 
     return e;
 }
 
+// the same over the bytes' LOW NIBBLES (a replayed byte keeps its strand nibble and carries the printed bit on top: replay_presence_tight)
+inline uint64_t run_end_nibble(const uint8_t* p, uint64_t from, uint64_t n, uint8_t nib) {
+    uint64_t e = from;
+    const __m128i want = _mm_set1_epi8(static_cast<char>(nib)), low = _mm_set1_epi8(0x0F);
+    for (; e + 16 <= n; e += 16) {
+        const unsigned same = static_cast<unsigned>(_mm_movemask_epi8(_mm_cmpeq_epi8(_mm_and_si128(_mm_loadu_si128(reinterpret_cast<const __m128i*>(p + e)), low), want)));
+        if (same != 0xFFFFu) return e + static_cast<uint64_t>(__builtin_ctz(~same & 0xFFFFu));
+    }
+    while (e < n && (p[e] & 15u) == nib) ++e;
+    return e;
+}
+
 // One -S chunk of strict result bytes, 16 windows a step.  With F = f + 1 = b & 3 and R = r + 1 = (b >> 2) & 3 (0, 1, 2 for -1, 0, 1):
 // the first strand searched settles a window when it says 1, or 0 under -O (replay_streaming_chunk above); the window prints 1
 // when the settling strand says 1, or -- unsettled -- when the other one does.  sums[swap] = {sum of the first strand's results,

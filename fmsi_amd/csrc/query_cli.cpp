@@ -266,6 +266,8 @@ struct Prepared {
     PinVec<uint8_t> bytes;                // device results, then (after the replay) the final 0/1 per window ...
     PinVec<uint64_t> bits;                // ... or, when nothing is replayed, one BIT per window straight from the device (FMSI_HIP_OUT_BITS)
     bool packed_bits = false;
+    bool bit7 = false;                    // `bytes` after the replay: the printed bit in bit 7 on top of the strand nibble (replay_presence_team), else 0 / 1
+    uint64_t replay_reruns = 0;
     PinVec<int64_t> orders;               // lookup: device results, then the final order per window
 };
 
@@ -482,7 +484,9 @@ struct PredictorSteps {
 const PredictorSteps kPredictorSteps;
 
 // WRITE: b[w] keeps its strand nibble and gets the character's bit on top (bit 7), so that a stretch can be walked again from another state
-template <bool WRITE>
+// RUNS: windows of reads -- runs of equal strand results are taken out of the loop (below); isolated k-mers have none, and the test for them
+// alone doubled the step's cost there (4.5 -> 10 ns on the build container's core): their batches take the plain loop
+template <bool WRITE, bool RUNS>
 void replay_presence_tight(uint8_t* b, uint64_t n, StrandPredictor& p, Mode mode) {
     uint64_t w = 0;
     for (; w < n && p.previous == -1; ++w) {   // (the very first window: no result score is updated)
@@ -499,12 +503,30 @@ void replay_presence_tight(uint8_t* b, uint64_t n, StrandPredictor& p, Mode mode
         const int sel = rsp ? rsp : score;
         const int32_t e = sel < 0 ? e1 : e0;
         const int diff = static_cast<int8_t>(e & 0xFF);
+        const int score_was = score;
         score = StrandPredictor::clipped(score + diff);
         const int nrs = StrandPredictor::clipped(rsp + diff);
+        const bool unchanged = score == score_was && nrs == rsp && prev == ((e >> 8) & 1);   // (a zero difference, or scores that are saturated)
         rs1 = prev ? nrs : rs1;
         rs0 = prev ? rs0 : nrs;
         prev = (e >> 8) & 1;
-        if (WRITE) b[w] = static_cast<uint8_t>(in | ((e >> 16) << 7));
+        const uint8_t done = static_cast<uint8_t>(in | ((e >> 16) << 7));
+        if (WRITE) b[w] = done;
+        // ... then every following window with the same pair of strand results leaves it unchanged, too, and prints the same: reads that lie
+        // on one strand and absent reads are such runs (the general loop's skip: 0.05 s instead of 2.9 s per 10^9 windows of 10-kb reads)
+        // (only runs of eight and more are taken out of the loop: among isolated k-mers equal neighbours come in twos and threes, and a
+        // mispredicted branch per window costs more than the steps it saves)
+        // (... and the test is ONE branch that is almost never taken there: whether the step changed the state is a coin toss on such input)
+        if (RUNS && w + 9 <= n) {
+            uint64_t x;
+            std::memcpy(&x, b + w + 1, 8);
+            const uint64_t differ = ((x & 0x0F0F0F0F0F0F0F0Full) ^ (0x0101010101010101ull * in)) | static_cast<uint64_t>(!unchanged);
+            if (__builtin_expect(differ == 0, 0)) {
+                const uint64_t run = run_end_nibble(b, w + 9, n, static_cast<uint8_t>(in));
+                if (WRITE) std::memset(b + w + 1, done, run - (w + 1));
+                w = run - 1;
+            }
+        }
     }
     p.score = score;
     p.result_scores[0] = rs0;
@@ -519,11 +541,12 @@ void replay_presence_tight(uint8_t* b, uint64_t n, StrandPredictor& p, Mode mode
 // state a stretch was started from IS the state its predecessor ended in, its results stand -- it was the sequential walk; where not
 // (inputs that never move the scores, such as a long run of absent k-mers), the stretch is walked again from the true state, one thread,
 // as without any of this.  Exact either way; `reruns` says how often the guess failed.
+template <bool RUNS>
 uint64_t replay_presence_team(uint8_t* b, uint64_t n, StrandPredictor& p, Mode mode, unsigned team) {
     constexpr uint64_t kWarm = 4096;
     const unsigned parts = static_cast<unsigned>(std::min<uint64_t>(team, n / (16 * kWarm)));
     if (parts < 2) {
-        replay_presence_tight<true>(b, n, p, mode);
+        replay_presence_tight<true, RUNS>(b, n, p, mode);
         return 0;
     }
     std::vector<StrandPredictor> from(parts), to(parts);
@@ -534,12 +557,12 @@ uint64_t replay_presence_team(uint8_t* b, uint64_t n, StrandPredictor& p, Mode m
         if (!t) return;
         StrandPredictor q;
         q.previous = 0;
-        replay_presence_tight<false>(b + lo_of(t) - kWarm, kWarm, q, mode);
+        replay_presence_tight<false, RUNS>(b + lo_of(t) - kWarm, kWarm, q, mode);
         from[t] = q;
     });
     parallel_for(parts, [&](unsigned t) {
         StrandPredictor q = from[t];
-        replay_presence_tight<true>(b + lo_of(t), hi_of(t) - lo_of(t), q, mode);
+        replay_presence_tight<true, RUNS>(b + lo_of(t), hi_of(t) - lo_of(t), q, mode);
         to[t] = q;
     });
     uint64_t reruns = 0;
@@ -548,7 +571,7 @@ uint64_t replay_presence_team(uint8_t* b, uint64_t n, StrandPredictor& p, Mode m
         if (same_state(cur, from[t])) {
             cur = to[t];
         } else {
-            replay_presence_tight<true>(b + lo_of(t), hi_of(t) - lo_of(t), cur, mode);
+            replay_presence_tight<true, RUNS>(b + lo_of(t), hi_of(t) - lo_of(t), cur, mode);
             ++reruns;
         }
     }
@@ -565,19 +588,10 @@ void replay_batch(Prepared& P, StrandPredictor& predictor, Mode mode, bool order
         // and takes the same decision -- such runs (reads that lie on one strand, absent reads) are skipped over.
         const uint64_t nw = P.windows;
         uint64_t w = 0;
-        if (!orders) {
-            uint8_t* b = P.bytes.data();
-            while (w < nw) {
-                const uint8_t in = b[w];
-                const StrandPredictor before = predictor;
-                const uint8_t got = static_cast<uint8_t>(replay_single(predictor, mode, false, fwd_of(in), rc_of(in)) == 1);
-                b[w++] = got;
-                if (same_state(before, predictor)) {
-                    const uint64_t e = run_end(b, w, nw, in);
-                    std::memset(b + w, got, e - w);
-                    w = e;
-                }
-            }
+        if (!orders) {   // (the recurrence as a table, runs skipped, stretches walked side by side by the team: replay_presence_team)
+            P.replay_reruns += P.raw.kmer_k ? replay_presence_team<false>(P.bytes.data(), nw, predictor, mode, team)
+                                            : replay_presence_team<true>(P.bytes.data(), nw, predictor, mode, team);
+            P.bit7 = true;
             return;
         }
         // lookup.  What a window prints is its first strand's order if that strand has the k-mer, else the second's
@@ -745,7 +759,8 @@ void format_bits(const Prepared& P, unsigned team, char* out) {   // out: P.rec_
                         expand_bits(P.bits.data(), w, c, dst);
                     } else {
                         const uint8_t* src = P.bytes.data() + w;
-                        for (uint64_t i = 0; i < c; ++i) dst[i] = static_cast<char>('0' + (src[i] != 0));
+                        if (P.bit7) for (uint64_t i = 0; i < c; ++i) dst[i] = static_cast<char>('0' + (src[i] >> 7));
+                        else for (uint64_t i = 0; i < c; ++i) dst[i] = static_cast<char>('0' + (src[i] != 0));
                     }
                     w += c;
                 } else {
@@ -828,7 +843,8 @@ void patch_kmer_lines(Prepared& P, unsigned team) {
                 }
             } else {
                 const uint8_t* b = P.bytes.data() + sl.first;
-                for (size_t i = sl.lo; i < sl.hi; ++i) text[at[i]] = static_cast<char>('0' + (b[i - sl.lo] >> 7));   // (replay_presence_team's bit)
+                if (P.bit7) for (size_t i = sl.lo; i < sl.hi; ++i) text[at[i]] = static_cast<char>('0' + (b[i - sl.lo] >> 7));   // (replay_presence_team's bit)
+                else for (size_t i = sl.lo; i < sl.hi; ++i) text[at[i]] = static_cast<char>('0' + (b[i - sl.lo] != 0));
             }
         }
     });
@@ -1396,8 +1412,8 @@ extern "C" int fmsi_cli_query(int argc, char** argv, int output_orders_i) {
                 TraceRange replay_range("fmsi: predictor replay");
                 // (a k-mer batch under -S: every record is one chunk of one window, whose streaming step IS the single step -- the first strand's
                 // result, the second's if that does not settle it, log_result of the two: src/fms_index.h:181-254 against :263-331)
-                if (P->raw.kmer_k) replay_reruns += replay_presence_team(P->bytes.data(), P->windows, predictor, opt.mode, team);
-                else replay_batch(*P, predictor, opt.mode, output_orders, load_klcp, k, team, rows64);
+                replay_batch(*P, predictor, opt.mode, output_orders, load_klcp && !P->raw.kmer_k, k, team, rows64);
+                replay_reruns += P->replay_reruns;
             }
             replay_s += std::chrono::duration<double>(clock::now() - t2).count();
             total_windows += P->windows;

@@ -159,7 +159,8 @@ int main() {
         a = in;
         for (size_t w = 0; w < n; ++w) a[w] = static_cast<uint8_t>(replay_single(pa, mode, false, fwd_of(in[w]), rc_of(in[w])) == 1);
         bb = in;
-        replay_presence_tight<true>(bb.data(), n, pb, mode);
+        if (it % 2) replay_presence_tight<true, true>(bb.data(), n, pb, mode);
+        else replay_presence_tight<true, false>(bb.data(), n, pb, mode);
         for (size_t w = 0; w < n; ++w)
             if ((bb[w] & 15u) != in[w] || (bb[w] >> 7) != a[w]) return fail("replay_presence_tight", it, w);
         if (!same_state(pa, pb)) return fail("replay_presence_tight (state)", it, n);
@@ -188,8 +189,9 @@ int main() {
         }
         StrandPredictor pa = p0, pb = p0;
         std::vector<uint8_t> a = in, bb = in;
-        replay_presence_tight<true>(a.data(), n, pa, mode);
-        const uint64_t reruns = replay_presence_team(bb.data(), n, pb, mode, 2 + static_cast<unsigned>(it % 5));
+        replay_presence_tight<true, false>(a.data(), n, pa, mode);
+        const uint64_t reruns = it % 3 ? replay_presence_team<true>(bb.data(), n, pb, mode, 2 + static_cast<unsigned>(it % 5))
+                                       : replay_presence_team<false>(bb.data(), n, pb, mode, 2 + static_cast<unsigned>(it % 5));
         if (a != bb || !same_state(pa, pb)) return fail("replay_presence_team", it, static_cast<size_t>(reruns));
         if (style == 1 && reruns != 0) return fail("replay_presence_team: a guess failed on random k-mers", it, static_cast<size_t>(reruns));
     }

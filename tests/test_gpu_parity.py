@@ -183,8 +183,10 @@ def test_cli_streams_without_S_and_survives_a_bad_klcp_file(fm, tmp_path, monkey
     assert rc != 0
 
 
+# (`full` in every presence mode; `compact`, `background` and `candidates` in the two that differ most -- the default mode and `-S -O` resp. `-O`: the suite has a time limit)
 @pytest.mark.parametrize("name,kind,mode,tables", [(*c, t) for c in CASES for t in ("full", "compact", "candidates", "background")
-                                                   if c[2] in ("or", "all") or (t in ("full", "compact", "background") and c[2] in ("or_S", "all_S"))])
+                                                   if (t == "full" and c[2] in ("or", "all", "or_S", "all_S")) or (t in ("compact", "background") and c[2] in ("or", "all_S")) or
+                                                   (t == "candidates" and c[2] in ("or", "all"))])
 def test_cli_with_full_tables_equals_reference_golden(fm, name, kind, mode, tables):
     """--tables full (the k-mer dictionary, the configuration bench.py measures; with it `-S` presence queries take the dictionary
     too), --tables compact (the super-k-mer dictionary alone where 23 <= k <= 32, the k-mer dictionary elsewhere) and --tables candidates (16-deep prefix table + candidate tables) change the device path of the presence modes and not
@@ -194,8 +196,9 @@ def test_cli_with_full_tables_equals_reference_golden(fm, name, kind, mode, tabl
     rc, out, err = fm.run_cli([*MODES[mode][0], "--tables", tables, "-k", str(k), "-q", str(query_file(name, kind)), index_prefix(name)])
     assert rc == 0, err.decode()
     assert out == golden_out(name, kind, mode)
-    rc, out, err = fm.run_cli([*MODES[mode][0], "--tables", "huge", "-k", str(k), "-q", str(query_file(name, kind)), index_prefix(name)])
-    assert rc == 1 and out == b""
+    if tables == "full" and mode == "or":
+        rc, out, err = fm.run_cli([*MODES[mode][0], "--tables", "huge", "-k", str(k), "-q", str(query_file(name, kind)), index_prefix(name)])
+        assert rc == 1 and out == b""
 
 
 @pytest.mark.parametrize("mode", ["or", "or_S", "all", "all_S"])
@@ -211,7 +214,7 @@ def test_cli_fast_mode(fm, mode):
 
 @pytest.mark.parametrize("mode", list(MODES))
 @pytest.mark.parametrize("name,kind", [("sars_k13", "rand"), ("mixed_k11", "rand"), ("repeats_k40", "rand"), ("integration_a", "edge")])
-@pytest.mark.parametrize("threads,batch", [(1, 1024), (3, 5000), (16, 1 << 26)])
+@pytest.mark.parametrize("threads,batch", [(1, 1024), (5, 5000)])
 def test_cli_pipeline_is_batch_and_thread_invariant(fm, name, kind, mode, threads, batch):
     """The host pipeline (reader -> team packing -> device -> replay -> team formatting) must not change a byte whatever
     the batch cut and the team size: the predictor state crosses batches, runs are re-packed word aligned, and the
