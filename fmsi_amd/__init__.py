@@ -31,6 +31,7 @@ KERNEL_PAIR = 0x30
 KERNEL_PHASED = 0x40
 KERNEL_DICT = 0x50
 KERNEL_SORTED = 0x60
+LOAD_KLCP, LOAD_ASYNC_TABLE = 0x1, 0x2
 DICT_SPARSE = 0x1
 DICT_CHAIN = 0x2
 DICT_SUPERKMER = 0x4
@@ -145,6 +146,8 @@ def lib() -> C.CDLL:
     L.fmsi_hip_index_enable_verify.argtypes = [vp]
     L.fmsi_hip_index_enable_dict.argtypes = [vp, u32]
     L.fmsi_hip_index_load.argtypes = [C.c_char_p, i32, i32, i32, C.POINTER(vp)]
+    L.fmsi_hip_index_wait_background.argtypes = [vp]
+    L.fmsi_hip_index_release_scratch.argtypes = [vp]
     L.fmsi_hip_trim_scratch.argtypes = [i32]
     L.fmsi_hip_keep_scratch.argtypes = [i32]
     L.fmsi_hip_keep_scratch.restype = None
@@ -401,11 +404,22 @@ class DeviceIndex:
         return cls(host.view, device, keepalive=host)
 
     @classmethod
-    def load(cls, prefix: str, use_klcp: bool = False, device: int = 0, prefix_len: int = 0):
-        """load_index() straight into HBM (fmsi_hip_index_load): RRR decode and block layout on the device."""
+    def load(cls, prefix: str, use_klcp: bool = False, device: int = 0, prefix_len: int = 0, async_table: bool = False):
+        """load_index() straight into HBM (fmsi_hip_index_load): RRR decode and block layout on the device.  async_table
+        (FMSI_HIP_LOAD_ASYNC_TABLE): the handle comes back when the prefix table's intervals stand; the signatures of its short
+        entries are written beside the first queries (wait_background() waits for them)."""
         h = C.c_void_p()
-        _check(lib().fmsi_hip_index_load(os.fsencode(prefix), int(use_klcp), device, prefix_len, C.byref(h)))
+        _check(lib().fmsi_hip_index_load(os.fsencode(prefix), (LOAD_KLCP if use_klcp else 0) | (LOAD_ASYNC_TABLE if async_table else 0), device, prefix_len, C.byref(h)))
         return cls(None, device, _handle=h)
+
+    def wait_background(self):
+        _check(lib().fmsi_hip_index_wait_background(self._h))
+        return self
+
+    def release_scratch(self):
+        """Return the handle's staging / scratch buffers to the driver (fmsi_hip_index_release_scratch); info.device_bytes does not count them."""
+        _check(lib().fmsi_hip_index_release_scratch(self._h))
+        return self
 
     # -- host-pointer calls (library stages through its own device buffers) --
     def query_kmers(self, kmers: np.ndarray, k: int, flags: int = MODE_OR, counters: bool = False):

@@ -251,6 +251,53 @@ def test_device_load_equals_host_load(fm, name):
     assert e.value.code == fm.E_IO
 
 
+def test_load_with_the_table_signed_beside_the_queries(fm, tmp_path):
+    """FMSI_HIP_LOAD_ASYNC_TABLE (what the `fmsi` binary asks for): the handle comes back when the prefix table's intervals stand and the
+    signatures of its entries of 1..5 rows are written on a stream of the library's own while the caller already queries -- an entry is
+    rewritten by one aligned 8-byte store and both of its forms give the same interval.  10^8 rows, a 13-deep table (1.5 rows per key:
+    most entries get signatures): isolated k-mers, reads through the kLCP kernel (its certificates read the entries) and `lookup` orders
+    sent the moment the load returns, again after wait_background(), and through a handle loaded the ordinary way -- the same bytes; then
+    release_scratch() gives the staging buffers back and the handle answers as before."""
+    import torch
+    n, k = 100_000_000, 31
+    built = fm.DeviceIndex.build_synthetic(n, 4242, k, with_klcp=True, mask_permille=700)
+    prefix = str(tmp_path / "idx")
+    built.write_files(prefix)
+    s = torch.cuda.current_stream().cuda_stream
+    nq, L, n_reads = 1 << 21, 3000, 512
+    d_kmers = torch.empty(nq, dtype=torch.int64, device="cuda")
+    built.synthetic_queries_dev(k, 11, 0, nq, d_kmers.data_ptr(), s)
+    d_reads = torch.empty((n_reads * L) // 32 + 2, dtype=torch.int64, device="cuda")
+    built.synthetic_reads_dev(L, 5, 0, n_reads, d_reads.data_ptr(), 10000, s)
+    torch.cuda.synchronize()
+    packed = d_reads.cpu().numpy().view(np.uint64)
+    kmers = d_kmers.cpu().numpy().view(np.uint64)
+    starts = np.arange(n_reads, dtype=np.uint64) * np.uint64(L)
+    wins = np.full(n_reads, L - k + 1, dtype=np.uint32)
+    built.close()
+
+    def answers(dev):
+        return (dev.query_kmers(kmers, k, fm.MODE_ALL | fm.STRICT), dev.query_stream(packed, n_reads * L, starts, wins, k, fm.MODE_OR | fm.STRICT),
+                dev.query_kmers(kmers[:200_000], k, fm.ORDERS | fm.STRICT))
+
+    quick = fm.DeviceIndex.load(prefix, use_klcp=True, prefix_len=13, async_table=True)
+    first = answers(quick)            # (the signature pass is most likely still running)
+    quick.wait_background()
+    second = answers(quick)
+    plain = fm.DeviceIndex.load(prefix, use_klcp=True, prefix_len=13)
+    want = answers(plain)
+    for a, b, c in zip(first, second, want):
+        assert np.array_equal(a, c) and np.array_equal(b, c)
+    f, r = fm.decode_strict(want[0])
+    assert 0.4 < ((f == 1) | (r == 1) | (f == 0) | (r == 0)).mean() < 0.6
+    before = int(quick.info.device_bytes)
+    quick.release_scratch()
+    assert int(quick.info.device_bytes) == before
+    assert np.array_equal(quick.query_kmers(kmers[:50_000], k, fm.MODE_ALL | fm.STRICT), want[0][:50_000])
+    quick.close()
+    plain.close()
+
+
 def test_device_load_at_scale_and_corrupt_files(fm, oracle_built, tmp_path):
     """1.2 M rows with a mixed mask (many superblocks, threaded host decode vs the device's), every row count n % 63 / n % 64 /
     n % 128 boundary in a sweep of small sizes, and corrupt .mask images are FMSI_HIP_EIO on this path too."""

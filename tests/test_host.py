@@ -560,8 +560,8 @@ def test_bench_compact_line_of_the_final_record_keeps_every_leg():
         spec.loader.exec_module(m)
     finally:
         sys.argv = argv
-    full = json.loads((REPO / "profiles" / "r05h_bench_default_full.json").read_text())
-    last = (REPO / "profiles" / "r05h_bench_default_compact.json").read_text().strip()
+    full = json.loads((REPO / "profiles" / "r05m_bench_default_full.json").read_text())
+    last = (REPO / "profiles" / "r05m_bench_default_compact.json").read_text().strip()
     assert len(last) <= m.COMPACT_LIMIT and m.compact_line(full) == last
     d = json.loads(last)
     names = [c["name"] for c in d["configs"]]
