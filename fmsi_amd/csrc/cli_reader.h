@@ -130,18 +130,21 @@ struct RecRef {   // views: into the mapped query file, the batch's arena (multi
 struct KmerPart {
     std::unique_ptr<char[]> text;     // the part's output lines
     size_t text_cap = 0, text_len = 0;
-    std::vector<uint64_t> kmers;      // record i's k-mer
-    std::vector<uint32_t> at;         // ... and the offset of its answer character in `text`
+    std::unique_ptr<uint64_t[]> kmers;   // record i's k-mer
+    std::unique_ptr<uint32_t[]> at;      // ... and the offset of its answer character in `text`
+    size_t cap = 0, n = 0;               // (plain arrays: nothing clears or counts them but the parser)
     void reset(size_t text_bytes, size_t recs) {
         if (text_cap < text_bytes) {
             text.reset(new char[text_bytes]);
             text_cap = text_bytes;
         }
+        if (cap < recs) {
+            kmers.reset(new uint64_t[recs]);
+            at.reset(new uint32_t[recs]);
+            cap = recs;
+        }
         text_len = 0;
-        kmers.clear();
-        at.clear();
-        kmers.reserve(recs);
-        at.reserve(recs);
+        n = 0;
     }
 };
 class KmerPartPool {
@@ -318,7 +321,11 @@ struct KmerPackPlain {
 };
 template <class PackFn>
 __attribute__((always_inline)) inline bool parse_kmer_records(const unsigned char* d, size_t lo, size_t hi, size_t limit, int k, KmerPart& part, PackFn pack) {
-    part.reset(hi - lo + 8, (hi - lo) / (static_cast<size_t>(k) + 3) + 1);   // a line out is shorter than its record
+    const size_t max_recs = (hi - lo) / (static_cast<size_t>(k) + 3) + 1;
+    part.reset(hi - lo + 64, max_recs);   // a line out is shorter than its record (+ the slack of the 16-byte name copy)
+    uint64_t* kmers_out = part.kmers.get();   // (plain arrays: a push_back is two more branches per record)
+    uint32_t* at_out = part.at.get();
+    size_t n_recs = 0;
     char* out = part.text.get();
     size_t p = lo;
     const size_t ku = static_cast<size_t>(k);
@@ -344,15 +351,19 @@ __attribute__((always_inline)) inline bool parse_kmer_records(const unsigned cha
         uint64_t w;
         const bool valid = s + 32 <= limit ? pack(reinterpret_cast<const char*>(d + s), k, &w) : kmer_word_tail(reinterpret_cast<const char*>(d + s), k, &w);
         if (!valid) return false;
-        std::memcpy(out, d + p + 1, name_len);
+        // (a name of up to 16 characters -- a read id, a number -- is one fixed 16-byte copy: the bytes behind it are readable, the k-mer's line
+        // follows, and writable, the line's own tail and the slack)
+        if (name_len <= 16 && s + 32 <= limit) std::memcpy(out, d + p + 1, 16);
+        else std::memcpy(out, d + p + 1, name_len);
         out += name_len;
         *out++ = '\t';
-        part.at.push_back(static_cast<uint32_t>(out - part.text.get()));
+        at_out[n_recs] = static_cast<uint32_t>(out - part.text.get());
         *out++ = '0';
         *out++ = '\n';
-        part.kmers.push_back(w);
+        kmers_out[n_recs++] = w;
         p = s + ku + 1;
     }
+    part.n = n_recs;
     part.text_len = static_cast<size_t>(out - part.text.get());
     return true;
 }
@@ -428,7 +439,7 @@ private:
             return false;
         }
         nb.kmer_k = kmer_k;
-        for (const auto& kp : nb.kparts) nb.kmer_recs += kp->kmers.size();
+        for (const auto& kp : nb.kparts) nb.kmer_recs += kp->n;
         if (kmer_batches++ == 0) raw_q.set_cap(40);   // 40 bytes of text per window: the parse is the long stage, let it run ahead of the index load
         return true;
     }
@@ -446,7 +457,10 @@ private:
                 const unsigned workers = kmer_k && kmer_streak && !parallel_fastq ? std::max(1u, team) : std::max(1u, std::min(8u, team / 2));
                 // a range of about a batch, ending at a record start (or the end of the file)
                 size_t end = mapped.size;
-                const uint64_t range_bytes = (parallel_fastq ? 2 : 1) * opt.batch_windows;   // (a FASTQ file is half qualities)
+                // (a FASTQ file is half qualities; a k-mer list is 40 bytes of text per window: its ranges are larger, so that a batch is not over
+                // before the threads that parse it have all started)
+                static const uint64_t kmer_mult = std::getenv("FMSI_HIP_CLI_KMER_RANGE") ? std::max(1, atoi(std::getenv("FMSI_HIP_CLI_KMER_RANGE"))) : 1;
+                const uint64_t range_bytes = (parallel_fastq ? 2 : 1) * opt.batch_windows * (kmer_k && kmer_streak && kmer_batches ? kmer_mult : 1);
                 if (mapped.size - pos > range_bytes + (range_bytes >> 3))
                     end = next_record_start(d, pos + range_bytes, mapped.size, parallel_fastq);
                 std::vector<size_t> cuts{pos};

@@ -823,7 +823,7 @@ void patch_kmer_lines(Prepared& P, unsigned team) {
     std::vector<Slice> slices;
     uint64_t first = 0;
     for (auto& kp : P.raw.kparts) {
-        const size_t n = kp->kmers.size();
+        const size_t n = kp->n;
         for (size_t lo = 0; lo < n; lo += size_t(1) << 16) slices.push_back({kp.get(), lo, std::min(n, lo + (size_t(1) << 16)), first + lo});
         first += n;
     }
@@ -834,7 +834,7 @@ void patch_kmer_lines(Prepared& P, unsigned team) {
         for (size_t t; (t = next.fetch_add(1, std::memory_order_relaxed)) < slices.size();) {
             const Slice& sl = slices[t];
             char* text = sl.part->text.get();
-            const uint32_t* at = sl.part->at.data();
+            const uint32_t* at = sl.part->at.get();
             if (P.packed_bits) {
                 const uint64_t* bits = P.bits.data();
                 for (size_t i = sl.lo; i < sl.hi; ++i) {
@@ -1323,11 +1323,11 @@ extern "C" int fmsi_cli_query(int argc, char** argv, int output_orders_i) {
                         P->windows = P->raw.kmer_recs;
                         P->packed.resize(P->windows + 1);
                         std::vector<uint64_t> part_at(P->raw.kparts.size() + 1, 0);
-                        for (size_t i = 0; i < P->raw.kparts.size(); ++i) part_at[i + 1] = part_at[i] + P->raw.kparts[i]->kmers.size();
+                        for (size_t i = 0; i < P->raw.kparts.size(); ++i) part_at[i + 1] = part_at[i] + P->raw.kparts[i]->n;
                         const unsigned copiers = static_cast<unsigned>(std::max<size_t>(1, std::min<size_t>(worker_team, P->raw.kparts.size())));
                         parallel_for(copiers, [&](unsigned t) {
                             for (size_t i = t; i < P->raw.kparts.size(); i += copiers)
-                                std::memcpy(P->packed.data() + part_at[i], P->raw.kparts[i]->kmers.data(), P->raw.kparts[i]->kmers.size() * 8);
+                                std::memcpy(P->packed.data() + part_at[i], P->raw.kparts[i]->kmers.get(), P->raw.kparts[i]->n * 8);
                         });
                     } else {
                         prepare_batch(*P, k, worker_team, general && k % 2 == 0);
