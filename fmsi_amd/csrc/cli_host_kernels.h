@@ -62,9 +62,15 @@ void pack_run_plain(const char* s, uint64_t len, uint64_t* dst) {   // the same 
     }
     pack_tail(s, i, len, dst);
 }
-inline void pack_run(const char* s, uint64_t len, uint64_t* dst) {
+// PEXT / PDEP or the plain forms.  Read ONCE, by the command's main thread before it starts any other (host_kernels_init): getenv() beside a
+// setenv() in another thread -- the HIP runtime sets variables while it starts up -- is a race glibc does not forgive.
+inline bool use_bmi2() {
     static const bool bmi2 = __builtin_cpu_supports("bmi2") && !std::getenv("FMSI_HIP_NO_BMI2");
-    if (bmi2) pack_run_bmi2(s, len, dst);
+    return bmi2;
+}
+inline void host_kernels_init() { (void)use_bmi2(); }
+inline void pack_run(const char* s, uint64_t len, uint64_t* dst) {
+    if (use_bmi2()) pack_run_bmi2(s, len, dst);
     else pack_run_plain(s, len, dst);
 }
 
@@ -281,8 +287,7 @@ void expand_bits_plain(const uint64_t* words, uint64_t first, uint64_t count, ch
     for (; i < count; ++i) dst[i] = static_cast<char>('0' + ((words[(first + i) >> 6] >> ((first + i) & 63)) & 1));
 }
 inline void expand_bits(const uint64_t* words, uint64_t first, uint64_t count, char* dst) {
-    static const bool bmi2 = __builtin_cpu_supports("bmi2") && !std::getenv("FMSI_HIP_NO_BMI2");
-    if (bmi2) expand_bits_bmi2(words, first, count, dst);
+    if (use_bmi2()) expand_bits_bmi2(words, first, count, dst);
     else expand_bits_plain(words, first, count, dst);
 }
 

@@ -374,9 +374,8 @@ bool parse_kmer_range_plain(const unsigned char* d, size_t lo, size_t hi, size_t
     return parse_kmer_records(d, lo, hi, limit, k, part, KmerPackPlain());
 }
 inline bool parse_kmer_range(const unsigned char* d, size_t lo, size_t hi, size_t limit, int k, KmerPart& part) {
-    static const bool bmi2 = __builtin_cpu_supports("bmi2") && !std::getenv("FMSI_HIP_NO_BMI2");
     if (hi - lo >= (size_t(1) << 32)) return false;   // (32-bit offsets into the part's text)
-    return bmi2 ? parse_kmer_range_bmi2(d, lo, hi, limit, k, part) : parse_kmer_range_plain(d, lo, hi, limit, k, part);
+    return use_bmi2() ? parse_kmer_range_bmi2(d, lo, hi, limit, k, part) : parse_kmer_range_plain(d, lo, hi, limit, k, part);
 }
 
 class QueryReader {
@@ -390,9 +389,14 @@ public:
     }
     // opens the file -- throws std::invalid_argument like OpenFile(), src/parser.h:22 -- and starts reading on a thread of its own
     void start() {
+    // (every switch of the environment is read HERE, on the caller's thread, before the reader's exists: see host_kernels_init)
+    host_kernels_init();
+    env_serial = std::getenv("FMSI_HIP_SERIAL_READER") != nullptr;
+    env_no_stretches = std::getenv("FMSI_HIP_NO_STREAM_STRETCHES") != nullptr;
+    if (const char* e = std::getenv("FMSI_HIP_CLI_KMER_RANGE")) kmer_mult = static_cast<uint64_t>(std::max(1, atoi(e)));
     reader = std::make_unique<FastxReader>(opt.query_fn);   // throws std::invalid_argument like OpenFile(), src/parser.h:22
     parallel_read = map_plain_fasta(opt.query_fn, mapped, &parallel_fastq);
-    if (!parallel_read && opt.query_fn != "-" && !std::getenv("FMSI_HIP_SERIAL_READER")) {
+    if (!parallel_read && opt.query_fn != "-" && !env_serial) {
         const char* min_env = std::getenv("FMSI_HIP_READER_MIN_BYTES");
         (void)bgzf.open(opt.query_fn, min_env ? static_cast<size_t>(std::max(1ll, atoll(min_env))) : (size_t(1) << 20));
     }
@@ -421,6 +425,8 @@ private:
     BgzfFile bgzf;
     bool parallel_read = false, parallel_fastq = false;
     std::thread reader_thread;
+    bool env_serial = false, env_no_stretches = false;
+    uint64_t kmer_mult = 1;   // (FMSI_HIP_CLI_KMER_RANGE, measurements: ranges of k-mer records this many times the batch size)
     int kmer_k = 0;
     bool kmer_streak = true;   // the last range was k-mer records (or none was tried yet): the next one is cut for the whole team
 
@@ -459,7 +465,6 @@ private:
                 size_t end = mapped.size;
                 // (a FASTQ file is half qualities; a k-mer list is 40 bytes of text per window: its ranges are larger, so that a batch is not over
                 // before the threads that parse it have all started)
-                static const uint64_t kmer_mult = std::getenv("FMSI_HIP_CLI_KMER_RANGE") ? std::max(1, atoi(std::getenv("FMSI_HIP_CLI_KMER_RANGE"))) : 1;
                 const uint64_t range_bytes = (parallel_fastq ? 2 : 1) * opt.batch_windows * (kmer_k && kmer_streak && kmer_batches ? kmer_mult : 1);
                 if (mapped.size - pos > range_bytes + (range_bytes >> 3))
                     end = next_record_start(d, pos + range_bytes, mapped.size, parallel_fastq);
@@ -526,7 +531,7 @@ private:
         // ---- any other stream (an ordinary gzip file, stdin, a small file): the same stretches, their bytes read by the ordinary
         // reader's own zlib handle (one thread inflates -- that is gzip -- but the team parses; a stretch that is not plain records
         // goes back into the reader and the ordinary rules take the stream from its first byte).
-        const bool stream_stretches = !parallel_read && !bgzf && !std::getenv("FMSI_HIP_SERIAL_READER") && !std::getenv("FMSI_HIP_NO_STREAM_STRETCHES");
+        const bool stream_stretches = !parallel_read && !bgzf && !env_serial && !env_no_stretches;
         if (bgzf || stream_stretches) {
             size_t at = 0;             // (block-gzip) compressed offset of the next member
             uint64_t consumed = 0;     // uncompressed bytes handed on in batches
