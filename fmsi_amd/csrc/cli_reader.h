@@ -13,6 +13,7 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <cstdint>
@@ -20,6 +21,7 @@
 #include <cstring>
 #include <deque>
 #include <exception>
+#include <functional>
 #include <memory>
 #include <mutex>
 #include <string>
@@ -32,27 +34,127 @@
 namespace fmsi {
 namespace {
 
+// The team: threads that stay.  parallel_for() used to start team - 1 threads per call and join them -- 20 to 30 us each, five such calls per
+// batch (parse, copy, replay twice, patch), and a batch of k-mer records is 4 ms of work for sixteen: measured by making the batches four times
+// as large, every stage of the k-mer path took half the time or less (read 0.22 -> 0.14 s, format 0.07 -> 0.02 s, replay 0.20 -> 0.07 s per 10^8
+// records).  Now the shares of a call are tasks for a pool that lives as long as the process; the caller takes share 0 and then helps with
+// whatever is queued until its own shares are done.  Shares are leaves: none of them calls parallel_for().
+class TeamPool {
+public:
+    static TeamPool& get() {
+        static TeamPool* p = new TeamPool;   // (never destroyed: the process ends with its threads)
+        return *p;
+    }
+    struct Job {
+        std::atomic<unsigned> left{0};
+        std::mutex m;
+        std::condition_variable cv;
+    };
+    using Task = std::function<void()>;
+    void submit(Task t) {
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            q_.push_back(std::move(t));
+            if (idle_ == 0 && threads_ < kMaxThreads) {
+                ++threads_;
+                try {
+                    std::thread([this] { worker(); }).detach();
+                } catch (...) {   // (no thread to be had: the callers run the queue themselves, help_until_done)
+                    --threads_;
+                }
+            }
+        }
+        cv_.notify_one();
+    }
+    // the caller of parallel_for() takes queued tasks -- its own or anybody's -- while its job has shares outstanding
+    void help_until_done(Job& job) {
+        for (;;) {
+            if (job.left.load(std::memory_order_acquire) == 0) return;
+            Task t;
+            {
+                std::lock_guard<std::mutex> lk(m_);
+                if (!q_.empty()) {
+                    t = std::move(q_.front());
+                    q_.pop_front();
+                }
+            }
+            if (t) {
+                t();
+                continue;
+            }
+            // (nothing queued: the caller's outstanding shares are in other threads' hands, and the last of them notifies.  No timed wait: GCC 11's
+            // ThreadSanitizer does not know pthread_cond_clockwait and takes the mutex for held across it)
+            std::unique_lock<std::mutex> lk(job.m);
+            job.cv.wait(lk, [&] { return job.left.load(std::memory_order_acquire) == 0; });
+            return;
+        }
+    }
+
+private:
+    static constexpr unsigned kMaxThreads = 64;
+    std::mutex m_;
+    std::condition_variable cv_;
+    std::deque<Task> q_;
+    unsigned threads_ = 0, idle_ = 0;
+    void worker() {
+        for (;;) {
+            Task t;
+            {
+                std::unique_lock<std::mutex> lk(m_);
+                ++idle_;
+                cv_.wait(lk, [&] { return !q_.empty(); });
+                --idle_;
+                t = std::move(q_.front());
+                q_.pop_front();
+            }
+            t();
+        }
+    }
+};
+
+inline bool team_spawns_threads() {   // (FMSI_HIP_CLI_SPAWN_THREADS; read first on the main thread: host_kernels_init's rule)
+    static const bool v = std::getenv("FMSI_HIP_CLI_SPAWN_THREADS") != nullptr;
+    return v;
+}
+
 template <class F>
 void parallel_for(unsigned team, F&& fn) {   // fn(t) for t in [0, team); t = 0 runs on the caller
     if (team <= 1) {
         fn(0u);
         return;
     }
-    std::vector<std::thread> th;
+    const bool spawn = team_spawns_threads();   // (A/B runs: a thread per share and call, as rounds 1-4)
     std::vector<std::exception_ptr> err(team);
-    th.reserve(team - 1);
-    unsigned started = 1;
-    try {
-        for (; started < team; ++started)
-            th.emplace_back([&, started] {
-                try { fn(started); } catch (...) { err[started] = std::current_exception(); }
+    if (spawn) {
+        std::vector<std::thread> th;
+        th.reserve(team - 1);
+        unsigned started = 1;
+        try {
+            for (; started < team; ++started)
+                th.emplace_back([&, started] {
+                    try { fn(started); } catch (...) { err[started] = std::current_exception(); }
+                });
+        } catch (...) {   // a thread that cannot be started: its share and the rest run on the caller
+        }
+        for (unsigned t = started; t < team; ++t)
+            try { fn(t); } catch (...) { err[t] = std::current_exception(); }
+        try { fn(0u); } catch (...) { err[0] = std::current_exception(); }
+        for (auto& x : th) x.join();
+    } else {
+        TeamPool& pool = TeamPool::get();
+        // (the job's counter and condition variable outlive the call through the shares' references: the last share may still be inside
+        // notify_all() when the caller, who saw the count reach zero, is gone; fn and err are the caller's and are done with by then)
+        auto job = std::make_shared<TeamPool::Job>();
+        job->left.store(team - 1, std::memory_order_relaxed);
+        for (unsigned t = 1; t < team; ++t)
+            pool.submit([&fn, &err, job, t] {
+                try { fn(t); } catch (...) { err[t] = std::current_exception(); }
+                std::lock_guard<std::mutex> lk(job->m);
+                if (job->left.fetch_sub(1, std::memory_order_acq_rel) == 1) job->cv.notify_all();
             });
-    } catch (...) {   // a thread that cannot be started: its share and the rest run on the caller
+        try { fn(0u); } catch (...) { err[0] = std::current_exception(); }
+        pool.help_until_done(*job);
     }
-    for (unsigned t = started; t < team; ++t)
-        try { fn(t); } catch (...) { err[t] = std::current_exception(); }
-    try { fn(0u); } catch (...) { err[0] = std::current_exception(); }
-    for (auto& x : th) x.join();
     for (auto& e : err)
         if (e) std::rethrow_exception(e);
 }
@@ -391,6 +493,7 @@ public:
     void start() {
     // (every switch of the environment is read HERE, on the caller's thread, before the reader's exists: see host_kernels_init)
     host_kernels_init();
+    (void)team_spawns_threads();
     env_serial = std::getenv("FMSI_HIP_SERIAL_READER") != nullptr;
     env_no_stretches = std::getenv("FMSI_HIP_NO_STREAM_STRETCHES") != nullptr;
     if (const char* e = std::getenv("FMSI_HIP_CLI_KMER_RANGE")) kmer_mult = static_cast<uint64_t>(std::max(1, atoi(e)));

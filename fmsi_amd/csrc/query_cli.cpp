@@ -870,6 +870,8 @@ extern "C" int fmsi_cli_query(int argc, char** argv, int output_orders_i) {
         KeepScratch() { fmsi_hip_keep_scratch(1); }
         ~KeepScratch() { fmsi_hip_keep_scratch(0); }
     } keep_scratch_;
+    host_kernels_init();          // (every environment switch of the host side is read here, before a second thread exists)
+    (void)team_spawns_threads();
     const bool output_orders = output_orders_i != 0;
     Options opt;
     opt.output_orders = output_orders;
