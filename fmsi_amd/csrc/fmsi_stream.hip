@@ -166,7 +166,81 @@ __global__ __launch_bounds__(256) void stream_compact_uniform_bits_kernel(const 
     out[g] = word;
 }
 
-enum : uint32_t { SS_IDLE = 0, SS_LOOKUP = 1, SS_LF = 2, SS_HAVE = 3, SS_EXTSCAN = 4, SS_EXTLF = 5, SS_CERT = 6, SS_DONE = 7, SS_PASS1 = 8, SS_FRESH_CERT = 9, SS_FRESH_PLAIN = 10 };
+// ---- the S-block kernel's slots: a task's FOUR RESULT PLANES (32 bytes: bit w of plane p = bit p of window w's result byte) ----
+// Round 5: the kernel no longer spreads a finished task's planes to 64 result bytes itself (some 280 vector instructions per task -- and in a
+// wave whose tasks end in different rounds the whole wave ran them in each of those rounds); the passes below, which read the slots anyway,
+// take the bits they need.
+__device__ __forceinline__ uint32_t spread4(uint32_t nib) { return ((nib & 0xFu) * 0x00204081u) & 0x01010101u; }
+// expands the 16 bits [16 d, 16 d + 16) of four bit planes to 16 result bytes (plane p contributes bit p of each byte)
+__device__ __forceinline__ uint4 result_bytes16(uint64_t p0, uint64_t p1, uint64_t p2, uint64_t p3, uint32_t d) {
+    const uint32_t a = static_cast<uint32_t>(p0 >> (16u * d)) & 0xFFFFu, b = static_cast<uint32_t>(p1 >> (16u * d)) & 0xFFFFu;
+    const uint32_t c = static_cast<uint32_t>(p2 >> (16u * d)) & 0xFFFFu, e = static_cast<uint32_t>(p3 >> (16u * d)) & 0xFFFFu;
+    uint4 r;
+    r.x = spread4(a) | (spread4(b) << 1) | (spread4(c) << 2) | (spread4(e) << 3);
+    r.y = spread4(a >> 4) | (spread4(b >> 4) << 1) | (spread4(c >> 4) << 2) | (spread4(e >> 4) << 3);
+    r.z = spread4(a >> 8) | (spread4(b >> 8) << 1) | (spread4(c >> 8) << 2) | (spread4(e >> 8) << 3);
+    r.w = spread4(a >> 12) | (spread4(b >> 12) << 1) | (spread4(c >> 12) << 2) | (spread4(e >> 12) << 3);
+    return r;
+}
+__device__ __forceinline__ void store_piece(uint8_t* dst, const uint4& v, uint32_t cnt) {   // cnt of the 16 bytes, at any alignment
+    if (cnt >= 16u) {
+        __builtin_memcpy(dst, &v, 16);
+    } else {
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+        for (uint32_t b = 0; b < cnt; ++b) dst[b] = static_cast<uint8_t>(w[b >> 2] >> (8u * (b & 3u)));
+    }
+}
+// planes -> the caller's result bytes: four threads per task, 16 windows each
+__global__ __launch_bounds__(256) void stream_planes_bytes_kernel(const uint64_t* __restrict__ planes, const TaskRec* __restrict__ rec, uint64_t n_tasks,
+                                                                  uint8_t* __restrict__ out) {
+    const uint64_t g = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    const uint64_t t = g >> 2;
+    const uint32_t d = static_cast<uint32_t>(g & 3u);
+    if (t >= n_tasks) return;
+    const uint32_t n = rec[t].n;
+    if (16u * d >= n) return;
+    const uint64_t* p = planes + 4 * t;
+    store_piece(out + rec[t].out + 16u * d, result_bytes16(p[0], p[1], p[2], p[3], d), n - 16u * d);
+}
+// ... of UNIFORM runs (run r = tasks [r * tpr, (r + 1) * tpr), windows [r * wpr, (r + 1) * wpr)): no look at the records
+__global__ __launch_bounds__(256) void stream_planes_bytes_uniform_kernel(const uint64_t* __restrict__ planes, uint32_t wpr, uint32_t tpr, uint64_t n_pieces,
+                                                                          uint8_t* __restrict__ out) {
+    const uint64_t g = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (g >= n_pieces) return;
+    const uint32_t ppr = tpr * 4u;   // 16-window pieces per run
+    const uint64_t r = g / ppr;
+    const uint32_t piece = static_cast<uint32_t>(g - r * ppr), at = piece * 16u;
+    if (at >= wpr) return;
+    const uint64_t* p = planes + 4 * (r * tpr + (piece >> 2));
+    store_piece(out + r * wpr + at, result_bytes16(p[0], p[1], p[2], p[3], piece & 3u), wpr - at);
+}
+// ... and FMSI_HIP_OUT_BITS without STRICT (one bit per window: plane 0): a thread per 64-bit word of the output, which is one or two tasks'
+// plane words shifted together, or, where runs end inside it, a few such pieces
+__global__ __launch_bounds__(256) void stream_planes_bits_uniform_kernel(const uint64_t* __restrict__ planes, uint32_t wpr, uint32_t tpr, uint64_t n_windows,
+                                                                         unsigned long long* __restrict__ out) {
+    const uint64_t g = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    const uint64_t q0 = g << 6;
+    if (q0 >= n_windows) return;
+    uint64_t r = q0 / wpr;
+    uint32_t w = static_cast<uint32_t>(q0 - r * wpr);
+    const uint32_t want = static_cast<uint32_t>(min(static_cast<uint64_t>(64u), n_windows - q0));
+    unsigned long long word = 0;
+    for (uint32_t got = 0; got < want;) {
+        const uint32_t o = w & 63u;
+        const uint32_t take = min(min(want - got, 64u - o), wpr - w);   // to the end of the word, of the task's plane, of the run
+        const uint64_t bits = (planes[4 * (r * tpr + (w >> 6))] >> o) & (take == 64u ? ~0ull : ((1ull << take) - 1ull));
+        word |= bits << got;
+        got += take;
+        w += take;
+        if (w == wpr) {
+            w = 0;
+            ++r;
+        }
+    }
+    out[g] = word;
+}
+
+enum : uint32_t { SS_IDLE = 0, SS_LOOKUP = 1, SS_LF = 2, SS_HAVE = 3, SS_EXTSCAN = 4, SS_EXTLF = 5, SS_CERT = 6, SS_DONE = 7, SS_PASS1 = 8, SS_FRESH_CERT = 9, SS_FRESH_PLAIN = 10, SS_DIED = 11 };
 
 struct StreamCounters {
     uint32_t lf_steps = 0, blocks = 0, probes = 0, searches = 0, lookups = 0, klcp_words = 0;
@@ -802,18 +876,6 @@ __device__ __forceinline__ SPiece spiece_global(const uint32_t* __restrict__ B, 
     return x;
 }
 
-// expands the 16 bits [16 d, 16 d + 16) of four bit planes to 16 result bytes (plane p contributes bit p of each byte)
-__device__ __forceinline__ uint32_t spread4(uint32_t nib) { return ((nib & 0xFu) * 0x00204081u) & 0x01010101u; }
-__device__ __forceinline__ uint4 result_bytes16(uint64_t p0, uint64_t p1, uint64_t p2, uint64_t p3, uint32_t d) {
-    const uint32_t a = static_cast<uint32_t>(p0 >> (16u * d)) & 0xFFFFu, b = static_cast<uint32_t>(p1 >> (16u * d)) & 0xFFFFu;
-    const uint32_t c = static_cast<uint32_t>(p2 >> (16u * d)) & 0xFFFFu, e = static_cast<uint32_t>(p3 >> (16u * d)) & 0xFFFFu;
-    uint4 r;
-    r.x = spread4(a) | (spread4(b) << 1) | (spread4(c) << 2) | (spread4(e) << 3);
-    r.y = spread4(a >> 4) | (spread4(b >> 4) << 1) | (spread4(c >> 4) << 2) | (spread4(e >> 4) << 3);
-    r.z = spread4(a >> 8) | (spread4(b >> 8) << 1) | (spread4(c >> 8) << 2) | (spread4(e >> 8) << 3);
-    r.w = spread4(a >> 12) | (spread4(b >> 12) << 1) | (spread4(c >> 12) << 2) | (spread4(e >> 12) << 3);
-    return r;
-}
 
 // UNI: reads of one length -- run r is the u.wpr windows from base u.start0 + r * u.stride -- are cut into tasks HERE (a division and five
 // 8-byte loads when a lane draws a task) instead of by a preparation pass that writes a 64-byte record per task for this kernel to read.
@@ -834,9 +896,9 @@ __global__ __launch_bounds__(256, 4) void query_stream2_kernel(DevIndex ix, cons
                                                             const TaskRec* __restrict__ tasks, uint64_t n_tasks, int k, uint32_t flags, uint32_t chunk,
                                                             uint4* __restrict__ slots, long long* __restrict__ out_orders,
                                                             unsigned long long* __restrict__ counters, UniformRuns u) {
-    __shared__ uint4 s_line[4][64 * kSPitch];
+    extern __shared__ uint4 s_line[];   // [waves of the workgroup][64 * kSPitch]
     const uint32_t ln = threadIdx.x & 63u;
-    uint4* my_wave_lines = s_line[threadIdx.x >> 6];
+    uint4* my_wave_lines = s_line + (threadIdx.x >> 6) * (64u * kSPitch);
     const uint32_t* L = reinterpret_cast<const uint32_t*>(my_wave_lines + ln * kSPitch);   // this lane's staged line
     const uint32_t mode_all = ORD ? 0u : (flags & FMSI_HIP_MODE_ALL);   // (orders: a strand decides a window when it HAS an order -- OR's schedule)
     const uint32_t strict = flags & FMSI_HIP_STRICT;
@@ -935,11 +997,9 @@ __global__ __launch_bounds__(256, 4) void query_stream2_kernel(DevIndex ix, cons
             p0 = mode_all ? (((rf_lo | rf_hi) & f1) | (~(rf_lo | rf_hi) & r1)) : (f1 | r1);   // ALL: (f != -1 ? f : r) == 1; OR: f == 1 || r == 1
             p1 = p2 = p3 = 0;
         }
-        uint4* dst = slots + (task_id << 2);
-        dst[0] = result_bytes16(p0, p1, p2, p3, 0);
-        dst[1] = result_bytes16(p0, p1, p2, p3, 1);
-        dst[2] = result_bytes16(p0, p1, p2, p3, 2);
-        dst[3] = result_bytes16(p0, p1, p2, p3, 3);
+        uint4* dst = slots + (task_id << 1);   // (the planes as they are: stream_planes_* make bytes or bits of them)
+        dst[0] = make_uint4(static_cast<uint32_t>(p0), static_cast<uint32_t>(p0 >> 32), static_cast<uint32_t>(p1), static_cast<uint32_t>(p1 >> 32));
+        dst[1] = make_uint4(static_cast<uint32_t>(p2), static_cast<uint32_t>(p2 >> 32), static_cast<uint32_t>(p3), static_cast<uint32_t>(p3 >> 32));
     };
     // ORD: the -1s of the tasks that are over, by the whole wave (wave-uniform call); their lanes are free then
     auto lane64 = [](uint64_t v, int lane) -> uint64_t {
@@ -1127,6 +1187,13 @@ __global__ __launch_bounds__(256, 4) void query_stream2_kernel(DevIndex ix, cons
     };
 
     for (;;) {
+        // a search that ended with an empty interval in the last round (a table entry without rows, an LF step, a streamed step): the window is
+        // absent on this strand, on to the next -- ONE code site for the three (a wave whose lanes are in different states runs every site some
+        // lane is in, and this one is some ninety vector instructions and a hundred scalar ones)
+        if (st == SS_DIED) {
+            window_done(-1);
+            advance(false);
+        }
         if (st == SS_PASS1) begin_pass1_now();
         if (ORD) flush_orders();
         {   // idle lanes draw the wave's next tasks (ballot + prefix rank, no atomics); a task's record is three 16-byte loads per 64 windows
@@ -1244,12 +1311,8 @@ __global__ __launch_bounds__(256, 4) void query_stream2_kernel(DevIndex ix, cons
             uint32_t q4 = 0;
             if (t >= 3) q4 = kmer_base(t - 3) | (kmer_base(t - 2) << 2) | (kmer_base(t - 1) << 4) | (kmer_base(t) << 6);
             decode_table_entry(ent.x, ent.y, ix.ptable_packed, t >= 3, q4, i, j);
-            if (i == j) {
-                window_done(-1);
-                advance(false);
-            } else {
-                st = t < 0 ? SS_HAVE : SS_LF;
-            }
+            if (i == j) st = SS_DIED;
+            else st = t < 0 ? SS_HAVE : SS_LF;
         } else if (st == SS_LF) {
             do_lf = true;
             c = kmer_base(t);
@@ -1332,19 +1395,14 @@ __global__ __launch_bounds__(256, 4) void query_stream2_kernel(DevIndex ix, cons
             j = base + rj;
             if (COUNT) cn.lf_steps++;
             if (st == SS_LF) {
-                if (i == j) {
-                    window_done(-1);
-                    advance(false);
-                } else if (--t < 0) {
-                    st = SS_HAVE;
-                }
+                if (i == j) st = SS_DIED;
+                else if (--t < 0) st = SS_HAVE;
             } else {
                 if (i == j) {
                     // a streamed step with an empty interval: the window's new base -- its first on the forward strand, its last on the other -- is
                     // one the text does not have there; the windows that hold it end k - 1 windows on in the pass' order
                     aff_end = !cur_rc ? static_cast<int>(widx) - (k - 1) : static_cast<int>(widx) + (k - 1);
-                    window_done(-1);
-                    advance(false);
+                    st = SS_DIED;
                 } else {
                     st = SS_HAVE;
                 }
@@ -1384,7 +1442,13 @@ void launch_stream2(fmsi_hip_index* idx, const TaskRec* recs, uint64_t n_tasks, 
     static const char* chunk_env = std::getenv("FMSI_HIP_STREAM_CHUNK");   // (measurements: tasks per wave)
     if (chunk_env) chunk = std::max(1, std::atoi(chunk_env));
     const uint64_t waves = (n_tasks + chunk - 1) / chunk;
-    const uint32_t blocks = static_cast<uint32_t>((waves + 3) / 4);
+    // ONE wave per workgroup (round 5; rounds 3-4: four).  A wave lasts as long as the slowest of its 64 tasks and a workgroup as long as the
+    // slowest of its waves: with four, the device kept the three that were done -- their LDS, their wave slots -- until the fourth was
+    // (kLCP kernel at t = 15, 2^27 windows: 57 -> 61 G windows/s on the clean mix, 40 -> 48 G with substitutions; FMSI_HIP_STREAM_WPB for A/B runs)
+    static const char* wpb_env = std::getenv("FMSI_HIP_STREAM_WPB");
+    const uint32_t wpb = wpb_env ? static_cast<uint32_t>(std::min(4, std::max(1, std::atoi(wpb_env)))) : 1u;
+    const uint32_t blocks = static_cast<uint32_t>((waves + wpb - 1) / wpb);
+    const uint32_t lds = wpb * 64u * kSPitch * static_cast<uint32_t>(sizeof(uint4));
     static const char* cert_env = std::getenv("FMSI_HIP_STREAM_CERT");   // (measurements: 0 = no certificates, 1 = always at offset 0)
     flags &= ~(kStreamNoCert | kStreamCertPlain | kStreamUtil);
     static const char* util_env = std::getenv("FMSI_HIP_STREAM_UTIL");   // (measurements: counters 6 / 7 = lane-rounds / busy lane-rounds)
@@ -1396,11 +1460,11 @@ void launch_stream2(fmsi_hip_index* idx, const TaskRec* recs, uint64_t n_tasks, 
     if (PTABLE && !cert_env && static_cast<double>(idx->n) > 7.0 * static_cast<double>(1ull << (2u * idx->dev.ptable_len))) flags |= kStreamNoCert;
     if (cert_env && cert_env[0] == '1') flags |= kStreamCertPlain;
     if (uni)
-        hipLaunchKernelGGL((query_stream2_kernel<COUNT, PTABLE, true, WIDE, ORD>), dim3(blocks), dim3(256), 0, s, idx->dev,
+        hipLaunchKernelGGL((query_stream2_kernel<COUNT, PTABLE, true, WIDE, ORD>), dim3(blocks), dim3(64u * wpb), lds, s, idx->dev,
                            static_cast<const uint4*>(idx->d_sblocks), static_cast<const uint64_t*>(idx->d_klcp), recs, n_tasks, k, flags,
                            static_cast<uint32_t>(chunk), slots, o64, d_counters, *uni);
     else
-        hipLaunchKernelGGL((query_stream2_kernel<COUNT, PTABLE, false, WIDE, ORD>), dim3(blocks), dim3(256), 0, s, idx->dev,
+        hipLaunchKernelGGL((query_stream2_kernel<COUNT, PTABLE, false, WIDE, ORD>), dim3(blocks), dim3(64u * wpb), lds, s, idx->dev,
                            static_cast<const uint4*>(idx->d_sblocks), static_cast<const uint64_t*>(idx->d_klcp), recs, n_tasks, k, flags,
                            static_cast<uint32_t>(chunk), slots, o64, d_counters, UniformRuns{});
 }
@@ -1583,7 +1647,7 @@ extern "C" int fmsi_hip_query_stream(fmsi_hip_index* idx, const uint64_t* packed
     if ((rc = ensure_cap(&idx->d_tasks, &idx->d_tasks_cap, meta_bytes + 2 * n_tasks * sizeof(TaskRec)))) return rc;
     auto* d_meta = static_cast<uint64_t*>(idx->d_tasks);
     auto* d_rec = reinterpret_cast<TaskRec*>(static_cast<char*>(idx->d_tasks) + meta_bytes);
-    auto* d_slots = reinterpret_cast<uint4*>(d_rec + n_tasks);   // one 64-byte line of result bytes per task
+    auto* d_slots = reinterpret_cast<uint4*>(d_rec + n_tasks);   // per task: one 64-byte line of result bytes (first kernel), or its four result planes (32 bytes)
     if (meta) {
         FMSI_HIP_TRY(hipMemcpyAsync(d_meta, meta, meta_words * 8, hipMemcpyHostToDevice, s));
         if ((rc = meta_commit(idx, meta_slot, s))) return rc;
@@ -1643,7 +1707,22 @@ extern "C" int fmsi_hip_query_stream(fmsi_hip_index* idx, const uint64_t* packed
     const uint32_t tpr = uniform ? static_cast<uint32_t>((wpr + kTaskWindows - 1) / kTaskWindows) : 0u;
     const bool run_wise = uniform && !(flags & FMSI_HIP_ORDERS) && wpr < (1ull << 31);   // (reads of one length: a copy per run)
     const bool bits_here = run_wise && pack.on && !(caller_flags & FMSI_HIP_STRICT);       // ... straight to the packed words
-    if (bits_here) {
+    const uint64_t* d_planes = reinterpret_cast<const uint64_t*>(d_slots);   // (the S-block kernel's slots)
+    if (v2 && bits_here) {
+        const uint64_t words = (n_windows + 63) / 64;
+        hipLaunchKernelGGL(stream_planes_bits_uniform_kernel, dim3(static_cast<uint32_t>((words + 255) / 256)), dim3(256), 0, s, d_planes,
+                           static_cast<uint32_t>(wpr), tpr, n_windows, static_cast<unsigned long long*>(d_out));
+        FMSI_HIP_TRY(hipGetLastError());
+    } else if (v2 && run_wise) {
+        const uint64_t pieces = n_tasks * 4;
+        hipLaunchKernelGGL(stream_planes_bytes_uniform_kernel, dim3(static_cast<uint32_t>((pieces + 255) / 256)), dim3(256), 0, s, d_planes,
+                           static_cast<uint32_t>(wpr), tpr, pieces, pack.bytes);
+        FMSI_HIP_TRY(hipGetLastError());
+    } else if (v2 && !(flags & FMSI_HIP_ORDERS)) {
+        const uint64_t threads = n_tasks * 4;
+        hipLaunchKernelGGL(stream_planes_bytes_kernel, dim3(static_cast<uint32_t>((threads + 255) / 256)), dim3(256), 0, s, d_planes, d_rec, n_tasks, pack.bytes);
+        FMSI_HIP_TRY(hipGetLastError());
+    } else if (bits_here) {
         const uint64_t words = (n_windows + 63) / 64;
         hipLaunchKernelGGL(stream_compact_uniform_bits_kernel, dim3(static_cast<uint32_t>((words + 255) / 256)), dim3(256), 0, s,
                            reinterpret_cast<const uint8_t*>(d_slots), static_cast<uint32_t>(wpr), tpr, n_windows, static_cast<unsigned long long*>(d_out));

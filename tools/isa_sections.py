@@ -61,7 +61,7 @@ def main():
             break
         m = loc_re.match(line)
         if m:
-            f, ln = files.get(int(m.group(1)), "?"), int(m.group(2))
+            f, ln = files.get(int(m.group(1)), "?").rsplit("/", 1)[-1], int(m.group(2))   # (file 0 of a translation unit carries its path)
             cur_helper = None
             if f == body_file:
                 hit = [n for n, a, b in sections if a <= ln <= b]
