@@ -902,6 +902,7 @@ __global__ __launch_bounds__(256, 4) void query_stream2_kernel(DevIndex ix, cons
     const uint32_t* L = reinterpret_cast<const uint32_t*>(my_wave_lines + ln * kSPitch);   // this lane's staged line
     const uint32_t mode_all = ORD ? 0u : (flags & FMSI_HIP_MODE_ALL);   // (orders: a strand decides a window when it HAS an order -- OR's schedule)
     const uint32_t strict = flags & FMSI_HIP_STRICT;
+    const bool pair16 = ORD && strict && (reinterpret_cast<uintptr_t>(out_orders) & 15u) == 0u;   // (STRICT orders: a window's two are one aligned 16 bytes)
     const uint64_t wave = (static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
     uint64_t next = wave * chunk;
     const uint64_t end = min(n_tasks, next + static_cast<uint64_t>(chunk));
@@ -1018,9 +1019,16 @@ __global__ __launch_bounds__(256, 4) void query_stream2_kernel(DevIndex ix, cons
             if (ln < nn) {
                 const bool fh = (f1 >> ln) & 1ull, rh = (r1 >> ln) & 1ull;
                 if (strict) {
+                    // (a window's pair is 16 bytes; the stores are what this mode costs -- the memory path counts requests -- so a pair without
+                    // an order is ONE store, and a pair whose forward order pass 0 stored has its -1 already: window_done)
                     long long* p = out_orders + 2ull * (ob + ln);
-                    if (!fh) __builtin_nontemporal_store(-1ll, p);
-                    if (!rh) __builtin_nontemporal_store(-1ll, p + 1);
+                    if (pair16 && !fh && !rh) {
+                        typedef long long ll2 __attribute__((ext_vector_type(2)));
+                        __builtin_nontemporal_store(ll2{-1ll, -1ll}, reinterpret_cast<ll2*>(p));
+                    } else {
+                        if (!fh) __builtin_nontemporal_store(-1ll, p);
+                        if (!rh && !(pair16 && fh)) __builtin_nontemporal_store(-1ll, p + 1);
+                    }
                 } else if (!(fh | rh)) {
                     __builtin_nontemporal_store(-1ll, out_orders + ob + ln);
                 }
@@ -1082,7 +1090,10 @@ __global__ __launch_bounds__(256, 4) void query_stream2_kernel(DevIndex ix, cons
             if (v & 2u) rr_hi |= bit;
         }
         if (ORD && res == 1) {   // (every other strand result is a -1: flush_orders)
-            if (strict) out_orders[2ull * (obase + widx) + pass] = static_cast<long long>(ord);
+            if (strict && pair16 && pass == 0) {   // the pair at once, the other strand's -1 on trust: an order of pass 1 comes later and over it
+                typedef long long ll2 __attribute__((ext_vector_type(2)));
+                *reinterpret_cast<ll2*>(out_orders + 2ull * (obase + widx)) = ll2{static_cast<long long>(ord), -1ll};
+            } else if (strict) out_orders[2ull * (obase + widx) + pass] = static_cast<long long>(ord);
             else out_orders[obase + widx] = static_cast<long long>(ord);   // (pass 1 visits a window only when pass 0 had no order for it)
         }
     };
