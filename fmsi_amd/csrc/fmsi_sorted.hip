@@ -47,9 +47,14 @@ namespace {
 
 constexpr uint32_t kLinePitch = 9;      // uint4 per staged line: 144 bytes
 constexpr uint32_t kJoin = 3;           // waves of the first launch whose survivors one wave of the second launch takes
-// rocPRIM's radix sort without its merge-sort path (the one it takes between 1 K and 1 M items): on ROCm 7.2 / gfx950 that path returned
-// pairs in an order that changed from run to run for a (begin_bit, end_bit) = (32, 64) sort over double buffers -- 2 000 ... 40 000 items
-// came back wrong, 600 and 2^28 right (tools/sorted_debug.py) -- so every size above one block goes through the onesweep passes
+// rocPRIM's radix sort without its merge-sort path (the one it takes between 1 K and 1 M items).  On ROCm 7.2 (rocPRIM 4.2) / gfx950 that path
+// is wrong for a sort over double buffers whose bit range does not start at bit 0: tools/micro/rocprim_sort_repro.hip, plain rocPRIM and a host
+// check -- (begin_bit, end_bit) = (32, 64) and (40, 64) over 2 000 ... 1 000 000 pairs come back out of order, differently from run to run, below
+// 300 000 with keys and values torn apart; 600 and 3 000 000 pairs are right, every range from bit 0 is right ((0, 44), (0, 60), (0, 64): what the
+// index builder and the dictionaries ask for), and with the limit at 0 -- onesweep passes for every size above one block -- all of it is right
+// (profiles/r05q_rocprim_sort_repro.txt).  This file is the only one that sorts from a bit above 0.
+#include <rocprim/rocprim_version.hpp>
+static_assert(ROCPRIM_VERSION_MAJOR >= 4, "radix_sort_config<SingleSortConfig, MergeSortConfig, OnesweepConfig, MergeSortLimit> as rocPRIM 4 (ROCm 7) has it; check the alias below against another release");
 using SortConfig = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, 0>;
 
 #define SW_TRY(expr)                                                                                       \
