@@ -336,7 +336,9 @@ def test_cli_host_pipeline_under_sanitizers(tmp_path, sanitizer):
         files[tag][0].write_bytes(data)
         files[tag][1].write_bytes(bgzf_bytes(data, block=900))
         files[tag][2].write_bytes(gzip.compress(data, 1))   # one ordinary gzip member: stretches of the stream, parsed by the team (and stdin below)
-    env = {**os.environ, "FMSI_HIP_READER_MIN_BYTES": "1", "TSAN_OPTIONS": "halt_on_error=1", "ASAN_OPTIONS": "detect_leaks=0"}
+    # (atexit_sleep_ms: the sanitizer sleeps a SECOND at exit while other threads live -- the team's pool threads always do, idle, in a pool that is
+    # never destroyed -- and this test starts the program some three hundred times)
+    env = {**os.environ, "FMSI_HIP_READER_MIN_BYTES": "1", "TSAN_OPTIONS": "halt_on_error=1 atexit_sleep_ms=20", "ASAN_OPTIONS": "detect_leaks=0"}
     prefix = str(GOLDEN / "idx" / "sars_k13")
     # a last batch whose whole text fits a std::string's inline buffer (the ordinary reader's batches hold views into their own text:
     # moving such a batch once left the views dangling -- found by the differential fuzzer, kept here for the sanitizers)
