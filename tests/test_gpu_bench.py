@@ -20,14 +20,14 @@ def fm(product_built):
 
 def test_default_bench_line_is_parseable_by_the_driver(fm):
     """`python bench.py --steps 2 --warmup 1` -- the driver's command but for the step counts and with one leg of every kind instead of
-    all twenty, on an index of 10^9 rows (the suite has a time limit; the driver's own run is at 2.8 x 10^9 and carries them all): the headline, the LF-walk legs, the CPU baseline, a
+    all twenty, on an index of 5 x 10^8 rows (the suite has a time limit; the driver's own run is at 2.8 x 10^9 and carries them all): the headline, the LF-walk legs, the CPU baseline, a
     cache-resident leg and the whole-process legs incl. the query file of one k-mer per record.  The last line
     is below 4 KB, parses, and carries `roofline` (with the LF-walk legs) and `cpu_baseline`; the line before it is the full record and
     agrees with it."""
     # (the rocprofv3 --pmc grandchildren are switched off here: they rebuild every leg's handle twice more -- a minute of the suite's time --
     # and change nothing about the line's shape but `roofline.traffic`, which the driver's own run carries)
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", FMSI_BENCH_NO_PMC="1")
-    res = subprocess.run([sys.executable, str(REPO / "bench.py"), "--steps", "2", "--warmup", "1", "--n", "1000000000", "--legs", "c2,e2e", "--reads", "20000", "--e2e-kmer-records", "4000000", "--cpu-sample", "200000"],
+    res = subprocess.run([sys.executable, str(REPO / "bench.py"), "--steps", "2", "--warmup", "1", "--n", "500000000", "--legs", "c2,e2e", "--reads", "20000", "--e2e-kmer-records", "4000000", "--cpu-sample", "200000"],
                          capture_output=True, text=True, timeout=1500, env=env, cwd=str(REPO))
     assert res.returncode == 0, res.stderr[-3000:]
     lines = [l for l in res.stdout.splitlines() if l.strip()]

@@ -137,6 +137,7 @@ def test_lf_step_counter_equals_oracle(fm, oracle_built):
     assert np.array_equal(out_n, out) and int(cn_n[0]) == want["lf_steps"] and int(cn_n[4]) == 0
 
 
+EXTENDED = bool(__import__("os").environ.get("FMSI_TEST_EXTENDED"))
 CASES = [(n, kind, mode) for n, (k, kinds) in CLI_DATASETS.items() for kind in kinds for mode in MODES]
 
 
@@ -184,9 +185,10 @@ def test_cli_streams_without_S_and_survives_a_bad_klcp_file(fm, tmp_path, monkey
 
 
 # (`full` in every presence mode; `compact`, `background` and `candidates` in the two that differ most -- the default mode and `-S -O` resp. `-O`: the suite has a time limit)
+# (FMSI_TEST_EXTENDED=1: every query file of every data set for `compact` / `background` / `candidates` as well; by default those take each data set's first)
 @pytest.mark.parametrize("name,kind,mode,tables", [(*c, t) for c in CASES for t in ("full", "compact", "candidates", "background")
-                                                   if (t == "full" and c[2] in ("or", "all", "or_S", "all_S")) or (t in ("compact", "background") and c[2] in ("or", "all_S")) or
-                                                   (t == "candidates" and c[2] in ("or", "all"))])
+                                                   if ((t == "full" and c[2] in ("or", "all", "or_S", "all_S")) or (t in ("compact", "background") and c[2] in ("or", "all_S")) or
+                                                       (t == "candidates" and c[2] in ("or", "all"))) and (EXTENDED or t == "full" or c[1] == CLI_DATASETS[c[0]][1][0])])
 def test_cli_with_full_tables_equals_reference_golden(fm, name, kind, mode, tables):
     """--tables full (the k-mer dictionary, the configuration bench.py measures; with it `-S` presence queries take the dictionary
     too), --tables compact (the super-k-mer dictionary alone where 23 <= k <= 32, the k-mer dictionary elsewhere) and --tables candidates (16-deep prefix table + candidate tables) change the device path of the presence modes and not
@@ -212,9 +214,11 @@ def test_cli_fast_mode(fm, mode):
     assert rc == 0 and out == golden_out("mixed_k11", "rand", "or")
 
 
-@pytest.mark.parametrize("mode", list(MODES))
-@pytest.mark.parametrize("name,kind", [("sars_k13", "rand"), ("mixed_k11", "rand"), ("repeats_k40", "rand"), ("integration_a", "edge")])
-@pytest.mark.parametrize("threads,batch", [(1, 1024), (5, 5000)])
+# (one thread and 1 K batches in the two modes whose replay crosses batches the hardest, every mode with five threads: the suite has a time limit;
+# FMSI_TEST_EXTENDED=1 runs the full product)
+@pytest.mark.parametrize("name,kind,mode,threads,batch",
+                         [(n, kd, m, t, b) for m in MODES for (n, kd) in [("sars_k13", "rand"), ("mixed_k11", "rand"), ("repeats_k40", "rand"), ("integration_a", "edge")]
+                          for (t, b) in [(1, 1024), (5, 5000)] if EXTENDED or t == 5 or m in ("all_S", "lookup")])
 def test_cli_pipeline_is_batch_and_thread_invariant(fm, name, kind, mode, threads, batch):
     """The host pipeline (reader -> team packing -> device -> replay -> team formatting) must not change a byte whatever
     the batch cut and the team size: the predictor state crosses batches, runs are re-packed word aligned, and the
@@ -799,7 +803,8 @@ def test_lookup_replay_on_large_batches(fm, oracle_built, tmp_path, name, k):
     assert sum(len(l.split(b"\t")[1].split(b",")) for l in ref.splitlines()) > 1_500_000
 
 
-@pytest.mark.parametrize("name,kind,fn", FN_CASES)
+# (FMSI_TEST_EXTENDED=1: all six functions on every query file; by default `0-0` and `1-1000` -- the ranges' two ends, whose code is `1-1` / `2-3`'s -- take each data set's first file)
+@pytest.mark.parametrize("name,kind,fn", [c for c in FN_CASES if EXTENDED or c[2] not in ("0-0", "1-1000") or c[1] == CLI_DATASETS[c[0]][1][0]])
 def test_cli_general_functions_equal_reference_golden(fm, name, kind, fn):
     """`fmsi query -f and|xor|r-s` (f-masked superstrings: query_mode::general, src/fms_index.h:316-327) reproduces the real
     reference's stdout byte for byte -- k = 3 .. 64, masks of every kind, repeats (totals above 1), the reference's own golden
