@@ -658,7 +658,9 @@ void replay_batch(Prepared& P, StrandPredictor& predictor, Mode mode, bool order
     // (A) by the team: the records' chunks listed -- a read of 150 bases is five of them, a batch of such reads millions: one thread's list
     // was 0.2 s per 7 x 10^8 windows --, then their sums and output bytes
     const bool maximized_ones = mode == Mode::All;
-    const unsigned listers = static_cast<unsigned>(std::max<size_t>(1, std::min<size_t>(team, nrec / 4096 + 1)));
+    // (a share is records: enough of them for the lists not to be crumbs -- 4096 short reads -- or enough windows, 2^20: a batch of 10-kb reads is
+    // 6 700 records and 6 x 10^7 windows, and by the records' count alone two threads did the team's work, 0.2 s per 10^9 windows)
+    const unsigned listers = static_cast<unsigned>(std::max<size_t>(1, std::min<size_t>({static_cast<size_t>(team), nrec, std::max<size_t>(nrec / 4096, P.windows >> 20) + 1})));
     std::vector<std::vector<Chunk>> listed(listers);
     std::vector<char> any_matters(listers, 0);
     parallel_for(listers, [&](unsigned t) {
