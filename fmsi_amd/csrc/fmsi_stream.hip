@@ -759,7 +759,7 @@ __global__ __launch_bounds__(256) void query_stream_kernel(DevIndex ix, const ui
 constexpr uint32_t kStreamNoCert = 1u << 30, kStreamCertPlain = 1u << 31, kStreamUtil = 1u << 29;   // internal bits of the kernel's flags word (FMSI_HIP_STREAM_CERT=0 / 1: measurements)
 constexpr uint32_t kSRows = 192;
 constexpr uint32_t kSDwords = 32;
-constexpr uint32_t kSPitch = 9;   // uint4 per staged line in LDS: 144 bytes
+constexpr uint32_t kSPitch = 8;   // uint4 per staged line in LDS: 128 bytes (LineView: where its pieces are)
 
 // S-blocks from the single-step blocks + the plain kLCP words; one thread per S-block
 __global__ __launch_bounds__(256) void sblock_build_kernel(const uint32_t* __restrict__ blocks, const uint32_t* __restrict__ mrank, uint64_t n_blocks,
@@ -849,16 +849,26 @@ __device__ __forceinline__ uint32_t spiece_rank(const SPiece& x, uint32_t c, uin
 __device__ __forceinline__ uint32_t spiece_mask_rank(const SPiece& x, uint32_t p, uint32_t q) {
     return x.mrank + x.msub + static_cast<uint32_t>(__popcll(x.mw & below64(p - 64u * q)));
 }
-// from the staged line (dword pointer into LDS)
-__device__ __forceinline__ SPiece spiece_lds(const uint32_t* L, uint32_t c, uint32_t q) {
+// A lane's staged line in LDS.  The lines arrive by LDS-direct loads (global_load_lds_dwordx4: sixteen bytes per lane straight from memory into
+// LDS at wave base + 16 x lane -- no registers, no ds_write), so where a piece lands is the loading lane's number: load instruction g
+// (0..7) brings the lines of owners g, g + 8, ..., g + 56, lane (grp, p) of it piece p ^ g of owner g + 8 grp.  Line `owner` is then the
+// 128 bytes at 1024 (owner & 7) + 128 (owner >> 3) with its piece q in slot q ^ (owner & 7): the owners' reads of one dword spread over
+// sixteen bank quads, four lanes each -- what the 144-byte pitch of rounds 3-4 gave -- in 8 KB per wave instead of 9.
+struct LineView {
+    const char* wave_base;   // the wave's 8 KB
+    uint32_t at;             // this lane's line + its swizzle key in the piece bits: a dword d is at (at ^ 4 d)
+    __device__ __forceinline__ uint32_t dw(uint32_t d) const { return *reinterpret_cast<const uint32_t*>(wave_base + (at ^ (d << 2))); }
+    __device__ __forceinline__ uint64_t u64(uint32_t d) const { return *reinterpret_cast<const uint64_t*>(wave_base + (at ^ (d << 2))); }   // (d even)
+};
+__device__ __forceinline__ SPiece spiece_lds(const LineView& L, uint32_t c, uint32_t q) {
     SPiece x;
-    x.cnt = L[c];
-    x.sub = q ? (L[3u + q] >> (8u * c)) & 0xFFu : 0u;
-    x.hw = *reinterpret_cast<const uint64_t*>(L + 8u + 2u * q);
-    x.lw = *reinterpret_cast<const uint64_t*>(L + 14u + 2u * q);
-    x.mrank = L[6];
-    x.msub = q ? (L[7] >> (8u * (q - 1u))) & 0xFFu : 0u;
-    x.mw = *reinterpret_cast<const uint64_t*>(L + 20u + 2u * q);
+    x.cnt = L.dw(c);
+    x.sub = q ? (L.dw(3u + q) >> (8u * c)) & 0xFFu : 0u;
+    x.hw = L.u64(8u + 2u * q);
+    x.lw = L.u64(14u + 2u * q);
+    x.mrank = L.dw(6);
+    x.msub = q ? (L.dw(7) >> (8u * (q - 1u))) & 0xFFu : 0u;
+    x.mw = L.u64(20u + 2u * q);
     return x;
 }
 // straight from memory (the second line of a straddling interval: few lanes, small loads)
@@ -899,7 +909,7 @@ __global__ __launch_bounds__(256, 4) void query_stream2_kernel(DevIndex ix, cons
     extern __shared__ uint4 s_line[];   // [waves of the workgroup][64 * kSPitch]
     const uint32_t ln = threadIdx.x & 63u;
     uint4* my_wave_lines = s_line + (threadIdx.x >> 6) * (64u * kSPitch);
-    const uint32_t* L = reinterpret_cast<const uint32_t*>(my_wave_lines + ln * kSPitch);   // this lane's staged line
+    const LineView L{reinterpret_cast<const char*>(my_wave_lines), 1024u * (ln & 7u) + 128u * (ln >> 3) + 16u * (ln & 7u)};   // this lane's staged line
     const uint32_t mode_all = ORD ? 0u : (flags & FMSI_HIP_MODE_ALL);   // (orders: a strand decides a window when it HAS an order -- OR's schedule)
     const uint32_t strict = flags & FMSI_HIP_STRICT;
     const bool pair16 = ORD && strict && (reinterpret_cast<uintptr_t>(out_orders) & 15u) == 0u;   // (STRICT orders: a window's two are one aligned 16 bytes)
@@ -1291,18 +1301,15 @@ __global__ __launch_bounds__(256, 4) void query_stream2_kernel(DevIndex ix, cons
             if (COUNT) cn.klcp_words += scan_i + scan_j;
         }
         const uint64_t line_mask = __ballot(need_line);
-        if (line_mask) {   // eight lanes per line, eight lines per instruction
-            const uint32_t piece = ln & 7u, grp = ln >> 3;
-            uint4 v[8];
+        if (line_mask) {   // eight lanes per line, eight lines per instruction, straight into LDS (LineView)
+            const uint32_t grp = ln >> 3;
 #pragma unroll
             for (uint32_t g = 0; g < 8; ++g) {
-                const uint32_t owner = 8u * g + grp;
+                const uint32_t owner = g + 8u * grp;
                 const uint32_t bo = static_cast<uint32_t>(__shfl(static_cast<int>(bi), static_cast<int>(owner), 64));
-                v[g] = make_uint4(0, 0, 0, 0);
-                if ((line_mask >> owner) & 1ull) v[g] = sblocks[(static_cast<size_t>(bo) << 3) + piece];
+                if ((line_mask >> owner) & 1ull)
+                    __builtin_amdgcn_global_load_lds(sblocks + ((static_cast<size_t>(bo) << 3) + ((ln & 7u) ^ g)), s_line + ((threadIdx.x >> 6) * (64u * kSPitch) + 64u * g), 16, 0, 0);
             }
-#pragma unroll
-            for (uint32_t g = 0; g < 8; ++g) my_wave_lines[(8u * g + grp) * kSPitch + piece] = v[g];
         }
         if (COUNT) cn.blocks += (need_line ? 1u : 0u) + (two ? 1u : 0u) + (lk ? 1u : 0u);   // ([1] counts table lines too, [4] says how many)
         __builtin_amdgcn_wave_barrier();
@@ -1339,9 +1346,9 @@ __global__ __launch_bounds__(256, 4) void query_stream2_kernel(DevIndex ix, cons
             int res;
             uint32_t ord = 0;
             if (mode_all) {
-                res = static_cast<int>((L[20u + (pi_off >> 5)] >> (pi_off & 31u)) & 1u);
+                res = static_cast<int>((L.dw(20u + (pi_off >> 5)) >> (pi_off & 31u)) & 1u);
             } else if (!ORD && j - i == 1u) {
-                res = static_cast<int>((L[20u + (pi_off >> 5)] >> (pi_off & 31u)) & 1u);
+                res = static_cast<int>((L.dw(20u + (pi_off >> 5)) >> (pi_off & 31u)) & 1u);
             } else {
                 const uint32_t qi = s_quarter(pi_off), qj = s_quarter(pj_off);
                 const uint32_t lo_r = spiece_mask_rank(spiece_lds(L, 0, qi), pi_off, qi);
@@ -1350,8 +1357,8 @@ __global__ __launch_bounds__(256, 4) void query_stream2_kernel(DevIndex ix, cons
                 ord = lo_r;   // kmer_order (fms_index.h:147-149): the mask rank of the interval's first row
             }
             // klcp[i - 1]: the bit before the block when i is its first row; klcp[j - 1]: row j - 1 is row pj_off - 1 of block bj
-            const uint32_t ki = i == 0u ? 0u : (pi_off == 0u ? (L[7] >> 31) : (L[26u + ((pi_off - 1u) >> 5)] >> ((pi_off - 1u) & 31u)) & 1u);
-            const uint32_t kjw = two ? B[26u + ((pj_off - 1u) >> 5)] : L[26u + ((pj_off - 1u) >> 5)];
+            const uint32_t ki = i == 0u ? 0u : (pi_off == 0u ? (L.dw(7) >> 31) : (L.dw(26u + ((pi_off - 1u) >> 5)) >> ((pi_off - 1u) & 31u)) & 1u);
+            const uint32_t kjw = two ? B[26u + ((pj_off - 1u) >> 5)] : L.dw(26u + ((pj_off - 1u) >> 5));
             const uint32_t kj = (kjw >> ((pj_off - 1u) & 31u)) & 1u;
             window_done(res, ord);
             if (advance(true)) {
