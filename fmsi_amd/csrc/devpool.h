@@ -30,6 +30,9 @@ hipError_t dev_free(void* p);
 // returns the cached blocks of the current device to the driver; the bytes they held
 size_t dev_trim();
 size_t dev_cached_bytes();
+// waits for the current device now if a block parked on it has not been waited for yet (the wait its next owner would take at the hand-out):
+// for a caller about to enqueue long work that such a hand-out should not have to sit out
+void dev_settle();
 void dev_keep_scratch(bool on);
 bool dev_keeps_scratch();
 

@@ -1,6 +1,7 @@
 #include "devpool.h"
 
 #include <atomic>
+#include <cstdint>
 #include <map>
 #include <mutex>
 #include <unordered_map>
@@ -18,8 +19,16 @@ struct Live {
 struct Pool {
     std::mutex m;
     std::unordered_map<void*, Live> live;                    // blocks handed out (>= kMinCached only)
-    std::multimap<size_t, void*> cached[kMaxDevices];        // per device: size -> freed block
+    struct Parked {
+        void* p;
+        uint64_t seq;   // the device's free count when the block was parked
+    };
+    std::multimap<size_t, Parked> cached[kMaxDevices];       // per device: size -> freed block
     size_t cached_bytes[kMaxDevices] = {};
+    // hipFree waits for the device before it releases memory, and a parked block must offer its next owner the same: work enqueued on
+    // the first owner's stream may still read or write it.  The wait is taken when a block is handed out AGAIN -- once for every block
+    // parked until then -- not with every free (rounds 2-4: a device-wide wait per pooled free, whether or not anybody took the block)
+    uint64_t free_seq[kMaxDevices] = {}, waited_seq[kMaxDevices] = {};
 };
 Pool& pool() {
     static Pool* p = new Pool;   // (never destroyed: handles may be freed during process exit)
@@ -50,8 +59,8 @@ size_t trim_locked(Pool& P, int d) {
     size_t freed = 0;
     if (P.cached[d].empty()) return 0;
     on_device(d, [&] {
-        for (auto& e : P.cached[d]) {
-            (void)hipFree(e.second);
+        for (auto& e : P.cached[d]) {   // (hipFree waits for the device itself)
+            (void)hipFree(e.second.p);
             freed += e.first;
         }
     });
@@ -80,11 +89,23 @@ hipError_t dev_malloc(void** p, size_t bytes) {
     std::lock_guard<std::mutex> lk(P.m);
     auto it = P.cached[d].lower_bound(bytes);
     if (it != P.cached[d].end() && it->first <= bytes + bytes / 4) {   // (best fit, at most a quarter more than asked for)
-        *p = it->second;
-        P.live[*p] = Live{it->first, d};
-        P.cached_bytes[d] -= it->first;
+        const Pool::Parked blk = it->second;
+        const size_t blk_bytes = it->first;
+        P.cached_bytes[d] -= blk_bytes;
         P.cached[d].erase(it);
-        return hipSuccess;
+        hipError_t w = hipSuccess;
+        if (blk.seq > P.waited_seq[d]) {   // parked since the device was last waited for: whatever its first owner enqueued must be over
+            const uint64_t upto = P.free_seq[d];
+            on_device(d, [&] { w = hipDeviceSynchronize(); });
+            if (w == hipSuccess) P.waited_seq[d] = upto;
+        }
+        if (w == hipSuccess) {
+            *p = blk.p;
+            P.live[*p] = Live{blk_bytes, d};
+            return hipSuccess;
+        }
+        (void)hipGetLastError();   // a device that cannot be waited for: the block goes back to the driver, not to another owner
+        on_device(d, [&] { (void)hipFree(blk.p); });
     }
     hipError_t e = hipMalloc(p, bytes);
     if (e != hipSuccess && !P.cached[d].empty()) {   // the cache may hold what this allocation needs
@@ -109,19 +130,8 @@ hipError_t dev_free(void* p) {
         }
     }
     if (l.device < 0) return hipFree(p);
-    // hipFree waits for the device before it releases memory; a parked block must offer the same -- the next owner may be another
-    // handle, another stream or a stream-0 builder while a kernel enqueued on the first owner's stream still reads or writes it
-    // (host-pointer query calls are asynchronous, and ensure_cap frees a staging buffer right behind them)
-    hipError_t e = hipSuccess;
-    on_device(l.device, [&] { e = hipDeviceSynchronize(); });
-    if (e != hipSuccess) {   // a device that cannot be waited for: the block is not handed to anybody else
-        (void)hipGetLastError();
-        hipError_t f = hipSuccess;
-        on_device(l.device, [&] { f = hipFree(p); });
-        return f;
-    }
-    std::lock_guard<std::mutex> lk(P.m);
-    P.cached[l.device].emplace(l.bytes, p);
+    std::lock_guard<std::mutex> lk(P.m);   // (parked as it is: dev_malloc waits for the device before anybody gets it -- the Pool's comment)
+    P.cached[l.device].emplace(l.bytes, Pool::Parked{p, ++P.free_seq[l.device]});
     P.cached_bytes[l.device] += l.bytes;
     return hipSuccess;
 }
@@ -130,6 +140,16 @@ size_t dev_trim() {
     Pool& P = pool();
     std::lock_guard<std::mutex> lk(P.m);
     return trim_locked(P, current_device());
+}
+
+void dev_settle() {
+    Pool& P = pool();
+    const int d = current_device();
+    std::lock_guard<std::mutex> lk(P.m);
+    if (P.free_seq[d] == P.waited_seq[d] || P.cached[d].empty()) return;
+    const uint64_t upto = P.free_seq[d];
+    if (hipDeviceSynchronize() == hipSuccess) P.waited_seq[d] = upto;
+    else (void)hipGetLastError();
 }
 
 size_t dev_cached_bytes() {

@@ -541,6 +541,9 @@ int build_prefix_table(fmsi_hip_index* idx, int t, bool sign_in_background) {
             idx->bg_stream = nullptr;
         }
         const bool bg = sign_in_background && idx->bg_stream;
+        // (the load's temporaries and this table's upper levels are parked blocks, and whoever is handed one waits for the device first: let that
+        // wait be now, on a device with nothing to do, not the first batch's behind the pass)
+        if (bg) dev_settle();
         hipLaunchKernelGGL(ptable_sign_kernel, dim3(blocks), dim3(256), 0, bg ? idx->bg_stream : static_cast<hipStream_t>(0), idx->dev, a, final_count);
         e = hipGetLastError();
         if (e == hipSuccess && !bg) e = hipDeviceSynchronize();
