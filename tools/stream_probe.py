@@ -39,7 +39,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "--child":
     torch.cuda.synchronize()
     nl, ms = idx.profile_read(reset=True); idx.profile(False)
     util = f"  lane-rounds/window {c[6] / nw:.3f} busy {c[7] / max(c[6], 1):.3f}" if os.environ.get("FMSI_HIP_STREAM_UTIL") else ""
-    print(f"{ms / nl:7.3f} ms {nw / (ms / nl) / 1e6:6.1f} G/s  req/window {c[1] / nw:.3f} (table {c[4] / nw:.3f} LF {c[0] / nw:.3f} searches {c[3] / nw:.3f} c5/task {c[5] / (nw / 64):.3f}){util}  sum {digest:012x}", flush=True)
+    print(f"{ms / nl:7.3f} ms {nw / (ms / nl) / 1e6:6.1f} G/s  req/window {c[1] / nw:.3f} (table {c[4] / nw:.3f} LF {c[0] / nw:.3f} searches {c[3] / nw:.3f}){util}  sum {digest:012x}", flush=True)
     sys.exit(0)
 
 ap = argparse.ArgumentParser()
