@@ -249,3 +249,45 @@ def test_stream_layout_boundaries(fm, oracle_built, tmp_path, k):
                 r = "".join(rng.choice("ACGT") if rng.random() < 0.03 else ch for ch in r)
             reads.append(r)
         run_case(fm, orc, dev, reads, k, check_orders=False)
+
+
+def test_stream_orders_into_an_output_that_is_not_16_byte_aligned(fm, oracle_built):
+    """`lookup -S` on the device stores a window's two strand orders as ONE 16-byte store where it can; an output array whose pairs are
+    not 16-byte aligned (a device pointer 8 bytes into an allocation) takes the 8-byte stores, and the same orders arrive."""
+    import torch
+    name = "sars_k31"
+    k = DATASETS[name][0]
+    dev = fm.DeviceIndex.from_files(index_prefix(name), use_klcp=True, prefix_len=5)
+    ms = ms_of(name).upper()
+    rng = random.Random(5)
+    reads = []
+    for i in range(40):
+        L = rng.choice([k, 64 + k, 150, 400])
+        p = rng.randrange(0, len(ms) - L)
+        r = ms[p:p + L]
+        if i % 2:
+            r = revcomp(r)
+        if i % 3 == 0:
+            r = "".join(rng.choice("ACGT") if rng.random() < 0.03 else ch for ch in r)
+        reads.append(r)
+    reads += ["".join(rng.choice("ACGT") for _ in range(300)) for _ in range(3)]
+    seq = "".join(reads)
+    words = fm.pack_sequence(seq.encode())
+    starts, wins, pos = [], [], 0
+    for r in reads:
+        starts.append(pos)
+        wins.append(len(r) - k + 1)
+        pos += len(r)
+    n = sum(wins)
+    want = dev.query_stream(words, len(seq), starts, wins, k, fm.ORDERS | fm.STRICT)
+    d_seq = torch.from_numpy(words.view(np.int64).copy()).cuda()
+    s = torch.cuda.current_stream().cuda_stream
+    for shift in (0, 1):   # int64 elements into a 16-byte aligned allocation
+        out = torch.full((2 * n + 4,), 7, dtype=torch.int64, device="cuda")
+        assert out.data_ptr() % 16 == 0
+        dev.query_stream_dev(d_seq.data_ptr(), len(seq), np.asarray(starts, dtype=np.uint64), np.asarray(wins, dtype=np.uint32), k, fm.ORDERS | fm.STRICT,
+                             out.data_ptr() + 8 * shift, 0, s)
+        torch.cuda.synchronize()
+        got = out.cpu().numpy()
+        assert np.array_equal(got[shift:shift + 2 * n].reshape(n, 2), want), shift
+        assert np.all(got[:shift] == 7) and np.all(got[shift + 2 * n:] == 7)   # (nothing written outside the array)
