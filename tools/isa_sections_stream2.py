@@ -15,8 +15,7 @@ def at(pattern, start=k0):
 marks = [("set-up before the loop", k0),
          ("loop top: died searches (window_done + advance)", at(r"^    for \(;;\) \{")),
          ("loop top: pass-1 start, flush_orders", at(r"if \(st == SS_PASS1\) begin_pass1_now\(\);")),
-         ("loop top: drawn task's bases cut", at(r"if \(st == SS_DRAWN\) \{")),
-         ("loop top: draw (ticket, task cut, loads, flush_task)", at(r"idle lanes draw the wave's next tasks")),
+         ("loop top: draw (task cut, loads, flush_task)", at(r"idle lanes draw the wave's next tasks")),
          ("loop top: fresh (k-mer of the window)", at(r"if \(st == SS_FRESH_CERT \|\| st == SS_FRESH_PLAIN\) \{")),
          ("reads: table entry, kLCP words", at(r"---- this round's reads ----")),
          ("reads: cooperative line fetch + LDS staging", at(r"const uint64_t line_mask = __ballot\(need_line\);")),
