@@ -1020,7 +1020,7 @@ __global__ __launch_bounds__(256, 4) void query_stream2_kernel(DevIndex ix, cons
     };
     auto flush_orders = [&]() {
         uint64_t dm = __ballot(st == SS_DONE);
-        const uint64_t mine_f = rf_hi & ~rf_lo, mine_r = rr_hi & ~rr_lo;   // windows with an order (strand result + 1 == 2)
+        const uint64_t mine_f = rf_hi, mine_r = rr_hi;   // windows with an order (strand result + 1 == 2; ORD keeps no low planes: window_done)
         while (dm) {
             const int owner = __ffsll(static_cast<unsigned long long>(dm)) - 1;
             dm &= dm - 1;
@@ -1092,11 +1092,13 @@ __global__ __launch_bounds__(256, 4) void query_stream2_kernel(DevIndex ix, cons
         }
         const uint64_t bit = 1ull << widx;
         const uint32_t v = static_cast<uint32_t>(res + 1);
+        // (ORD: "present without an order" and "absent" print the same -1 and decide nothing, so the low planes stay empty -- and out of the
+        // registers: with them the ORD instantiation spilled its pass-0 planes to scratch, a memory request per window on a kernel bound by requests)
         if (pass == 0) {
-            if (v & 1u) rf_lo |= bit;
+            if (!ORD && (v & 1u)) rf_lo |= bit;
             if (v & 2u) rf_hi |= bit;
         } else {
-            if (v & 1u) rr_lo |= bit;
+            if (!ORD && (v & 1u)) rr_lo |= bit;
             if (v & 2u) rr_hi |= bit;
         }
         if (ORD && res == 1) {   // (every other strand result is a -1: flush_orders)
