@@ -117,7 +117,9 @@ def parse_args(argv=None):
                     help="do not measure roofline.traffic in this run (child runs of this script under rocprofv3 --pmc, FETCH_SIZE and "
                          "WRITE_SIZE in separate passes)")
     ap.add_argument("--no-config-legs", action="store_true", help="skip the `configs` legs (BASELINE configs 2, 3, 4 and the whole process)")
-    ap.add_argument("--legs", default="c2,c3,c3sk,c4,c4k,c4k16,c4k48,c4sk,c5dict,e2e", help="which `configs` legs to run")
+    # (the whole-process legs first: a process that starts right after others released tens of GB of HBM sits out the driver's wipe in its first
+    # hipMalloc -- DESIGN.md 3.7 / 8 -- and behind twenty leg processes that was 0.1-0.2 s of a 0.4 s run on some boxes)
+    ap.add_argument("--legs", default="e2e,c2,c3,c3sk,c4,c4k,c4k16,c4k48,c4sk,c5dict", help="which `configs` legs to run, in this order")
     ap.add_argument("--leg", default=None, help=argparse.SUPPRESS)          # child mode: one leg, a JSON list on stdout
     ap.add_argument("--variants", default=None, help="with --leg: only these variants of the leg (comma-separated names), e.g. for a rocprofv3 run of one")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)   # child mode under rocprofv3: the plan's launches, nothing printed
