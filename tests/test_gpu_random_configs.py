@@ -42,8 +42,7 @@ def random_ms(rng, n, k):
     return "".join(c if rng.random() < 0.6 else c.lower() for c in s)
 
 
-# (FMSI_TEST_EXTENDED=1: 150 configurations; the GPU suite has a time limit)
-CONFIGS = list(range(150 if __import__("os").environ.get("FMSI_TEST_EXTENDED") else 120))
+CONFIGS = list(range(150))
 
 
 @pytest.mark.parametrize("seed", CONFIGS)

@@ -330,8 +330,7 @@ def test_cli_index_query_export_beyond_2_to_32_bases(product_built):
         shutil.rmtree(d, ignore_errors=True)
 
 
-# (FMSI_TEST_EXTENDED=1: four functions; by default `xor` and `2-3` -- a function of the ones' parity and a range -- : the kernel is one template over the row width)
-@pytest.mark.parametrize("name,kind,fn", [c for c in FN_CASES if c[2] in (("and", "xor", "1-1", "2-3") if os.environ.get("FMSI_TEST_EXTENDED") else ("xor", "2-3"))])
+@pytest.mark.parametrize("name,kind,fn", [c for c in FN_CASES if c[2] in ("and", "xor", "1-1", "2-3")])
 def test_cli_demasking_functions_with_wide_rows(fm, name, kind, fn):
     """`fmsi query -f and|xor|r-s` over 64-bit rows (the kernel of fmsi_fn.hip is a template over the row width, too): the reference's
     golden output, k <= 32 and k = 40, 64 alike."""
