@@ -2,8 +2,10 @@
 //   * a plain file is mapped and parsed in place by several threads (ranges cut at record starts; names and single-line sequences stay
 //     views of the mapping),
 //   * a block-gzip file has its members inflated side by side, stretch after stretch, each parsed the same way,
-//   * anything else -- gzip, stdin, a FASTQ file that cannot be cut safely -- goes through the ordinary reader (fastx.cpp, the
-//     reference's kseq rules), which also takes over wherever the two above have to stop.
+//   * an ordinary gzip file is inflated by the team, too (pgunzip.h: chunks of the one deflate stream entered at block starts found in its
+//     middle), stretch after stretch, each parsed the same way,
+//   * anything else -- stdin, a FASTQ file that cannot be cut safely -- goes through the ordinary reader (fastx.cpp, the
+//     reference's kseq rules), which also takes over wherever the three above have to stop.
 // Every path yields the sequential parse of the reference (src/kseq.h:183-226, src/parser.h:14-27), batch after batch in file order.
 #pragma once
 
@@ -30,6 +32,7 @@
 
 #include "cli_host_kernels.h"
 #include "fastx.h"
+#include "pgunzip.h"
 
 namespace fmsi {
 namespace {
@@ -501,7 +504,10 @@ public:
     parallel_read = map_plain_fasta(opt.query_fn, mapped, &parallel_fastq);
     if (!parallel_read && opt.query_fn != "-" && !env_serial) {
         const char* min_env = std::getenv("FMSI_HIP_READER_MIN_BYTES");
-        (void)bgzf.open(opt.query_fn, min_env ? static_cast<size_t>(std::max(1ll, atoll(min_env))) : (size_t(1) << 20));
+        const size_t min_bytes = min_env ? static_cast<size_t>(std::max(1ll, atoll(min_env))) : (size_t(1) << 20);
+        (void)bgzf.open(opt.query_fn, min_bytes);
+        if (!bgzf && !std::getenv("FMSI_HIP_NO_PARALLEL_GUNZIP") && pgz.open(opt.query_fn, min_bytes))
+            if (const char* e = std::getenv("FMSI_HIP_PGZ_CHUNK_BYTES")) pgz.set_chunk_bytes(static_cast<size_t>(std::max(1ll, atoll(e))));   // (tests: many chunks of a small file)
     }
         reader_thread = std::thread([this] { run(); });
     }
@@ -514,6 +520,8 @@ public:
     }
     double read_s = 0;                  // time spent reading (not waiting for the queue)
     uint64_t parallel_read_bytes = 0;   // (--stats: how far the block-parallel readers got before they had to hand over, if they did)
+    uint64_t pgz_bytes = 0, pgz_rounds = 0, pgz_marker_symbols = 0;   // (--stats: what the team's inflate of an ordinary gzip file took)
+    bool pgz_gave_up = false;
     std::exception_ptr reader_err;
 
 private:
@@ -526,6 +534,7 @@ private:
     std::unique_ptr<FastxReader> reader;
     MappedFile mapped;
     BgzfFile bgzf;
+    ParallelGunzip pgz;
     bool parallel_read = false, parallel_fastq = false;
     std::thread reader_thread;
     bool env_serial = false, env_no_stretches = false;
@@ -682,7 +691,21 @@ private:
                 } else {
                     seg.reset(new char[carry.size() + range_bytes + 1]);
                     std::memcpy(seg.get(), carry.data(), carry.size());
-                    const size_t got = reader->read_raw(seg.get() + carry.size(), range_bytes);
+                    // (an ordinary gzip file: the team inflates it, pgunzip.h; where that reader gives up -- a stream it does not take, a
+                    // trailer that does not match -- zlib goes on from the byte it got to, as it would have from the start)
+                    size_t got = 0;
+                    if (pgz && !pgz.failed()) {
+                        got = pgz.read(seg.get() + carry.size(), range_bytes, team,
+                                       [](unsigned n, const std::function<void(unsigned)>& fn) { parallel_for(n, fn); });
+                        pgz_bytes = pgz.delivered();
+                        pgz_rounds = pgz.stats.rounds;
+                        pgz_marker_symbols = pgz.stats.marker_symbols;
+                        if (pgz.failed()) {
+                            pgz_gave_up = true;
+                            reader->skip(pgz.delivered());
+                        }
+                    }
+                    if (!pgz || pgz.failed()) got += reader->read_raw(seg.get() + carry.size() + got, range_bytes - got);
                     eof = got < range_bytes;
                     len = carry.size() + got;
                 }
@@ -759,8 +782,10 @@ private:
             if (bgzf) {
                 reader->skip(consumed);
             } else if (len) {
+                if (pgz && !pgz.failed()) reader->skip(pgz.delivered());   // (the ordinary reader has not read a byte yet)
                 reader->unread(seg.get(), len);       // (the stretch that was not plain records, its carried tail in front)
             } else {
+                if (pgz && !pgz.failed()) reader->skip(pgz.delivered());
                 reader->unread(carry.data(), carry.size());
             }
         }

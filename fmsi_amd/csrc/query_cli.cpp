@@ -1455,10 +1455,11 @@ extern "C" int fmsi_cli_query(int argc, char** argv, int output_orders_i) {
         fprintf(stderr,
                 "{\"windows\": %llu, \"total_seconds\": %.6f, \"load_seconds\": %.6f, \"device_seconds\": %.6f, \"read_seconds\": %.6f, "
                 "\"prepare_seconds\": %.6f, \"replay_seconds\": %.6f, \"format_seconds\": %.6f, \"write_seconds\": %.6f, \"threads\": %u, "
-                "\"devices\": %zu, \"strict\": %s, \"block_parallel_read_bytes\": %llu, \"dictionary\": \"%s\", \"dictionary_batches\": %llu, \"kmer_batches\": %llu, "
+                "\"devices\": %zu, \"strict\": %s, \"block_parallel_read_bytes\": %llu, \"parallel_gunzip_bytes\": %llu, \"parallel_gunzip_rounds\": %llu, \"parallel_gunzip_gave_up\": %s, \"dictionary\": \"%s\", \"dictionary_batches\": %llu, \"kmer_batches\": %llu, "
                 "\"replay_reruns\": %llu, \"epoch_start\": %.6f, \"epoch_end\": %.6f}\n",
                 static_cast<unsigned long long>(total_windows), total, load, gpu_s, query_reader.read_s, prep_s, replay_s, format_s, write_s, team,
                 ctx.size(), strict ? "true" : "false", static_cast<unsigned long long>(query_reader.parallel_read_bytes),
+                static_cast<unsigned long long>(query_reader.pgz_bytes), static_cast<unsigned long long>(query_reader.pgz_rounds), query_reader.pgz_gave_up ? "true" : "false",
                 ctx[0].have_dict ? "before the first batch" : (want_bg_dict && !rows64 ? "beside the queries" : "none"),
                 static_cast<unsigned long long>(ctx[0].dict_batches), static_cast<unsigned long long>(query_reader.kmer_batches),
                 static_cast<unsigned long long>(replay_reruns),

@@ -419,6 +419,16 @@ int fmsi_host_layout_build(const fmsi_index_view* view, uint32_t* blocks /* n_bl
  * len/32 + 2 words).  Returns the index of the first invalid character or len. */
 uint64_t fmsi_host_pack_2bit(const char* seq, uint64_t len, uint64_t* words);
 
+/* The query side's parallel reader of ORDINARY gzip files (one member of many deflate blocks; the reference reads them through
+ * zlib's gzread on one thread: src/parser.h:14-27, src/kseq.h:75-93) on its own, for tests and measurements: inflates the file at
+ * `path` with `threads` threads (pgunzip.h: block starts found in the middle of the stream, chunks decoded with an unknown window,
+ * zlib from the first block boundary whose window is known) into out[0, cap) -- bytes beyond cap are decoded, checked and dropped
+ * (out may be NULL) -- and sets *out_len to the length of what it decoded.  chunk_bytes: compressed bytes per chunk (0: its own
+ * schedule).  stats7 (optional): rounds, chunks, chunks passed over (a start that was none), chunks that found no start, symbols
+ * decoded with an unknown window, bytes decoded by zlib, members.  Returns 0, 1 when the reader gave up at *out_len (a stream that is
+ * not what it takes: the CLI lets zlib go on from there), -1 when the file is not a gzip file. */
+int fmsi_host_gunzip(const char* path, int threads, uint64_t chunk_bytes, unsigned char* out, uint64_t cap, uint64_t* out_len, uint64_t* stats7);
+
 /* The `fmsi query` / `fmsi lookup` command (ms_query, src/main.cpp:238-375) on the GPU; argv as the
  * reference's sub-command sees it (argv[0] = "query").  Returns the process exit code. */
 int fmsi_cli_query(int argc, char** argv, int output_orders);

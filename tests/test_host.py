@@ -322,7 +322,7 @@ def test_cli_host_pipeline_under_sanitizers(tmp_path, sanitizer):
     src = REPO / "fmsi_amd" / "csrc"
     exe = tmp_path / "cli_stub"
     res = subprocess.run(["g++", "-std=c++17", "-O1", "-g", f"-fsanitize={sanitizer}", "-fno-omit-frame-pointer", f"-I{REPO / 'include'}",
-                          str(REPO / "tests" / "native" / "cli_pipeline_stub.cpp"), *(str(src / f) for f in ("query_cli.cpp", "fastx.cpp", "trace.cpp", "host_index.cpp",
+                          str(REPO / "tests" / "native" / "cli_pipeline_stub.cpp"), *(str(src / f) for f in ("query_cli.cpp", "fastx.cpp", "pgunzip.cpp", "trace.cpp", "host_index.cpp",
                                                                                                             "layout.cpp", "index_writer.cpp")),
                           "-o", str(exe), "-lz", "-lpthread", "-ldl"], capture_output=True, text=True)
     assert res.returncode == 0, res.stderr[-3000:]
@@ -361,7 +361,44 @@ def test_cli_host_pipeline_under_sanitizers(tmp_path, sanitizer):
                 res = subprocess.run([str(exe), *mode, *opts, "-q", "-", prefix], input=paths[0].read_bytes(), capture_output=True, env=env)
                 assert res.returncode == 0, (mode, tag, opts, res.stderr.decode()[-2000:])
                 outs.add(res.stdout)
+            # the ordinary gzip member again, inflated by the team in MANY chunks (pgunzip.h: block starts found inside the stream, chunks decoded
+            # with an unknown window, zlib from the first known one), and with that reader switched off
+            for extra in ({"FMSI_HIP_PGZ_CHUNK_BYTES": "1500"}, {"FMSI_HIP_PGZ_CHUNK_BYTES": "6000"}, {"FMSI_HIP_NO_PARALLEL_GUNZIP": "1"}):
+                res = subprocess.run([str(exe), *mode, "--batch", "5000", "--threads", "6", "--stats", "-q", str(paths[2]), prefix], capture_output=True, env={**env, **extra})
+                assert res.returncode == 0, (mode, tag, extra, res.stderr.decode()[-2000:])
+                outs.add(res.stdout)
+                stats = json.loads([l for l in res.stderr.decode().splitlines() if l.startswith("{")][-1])
+                if "FMSI_HIP_PGZ_CHUNK_BYTES" in extra and tag == "fa":
+                    assert stats["parallel_gunzip_bytes"] == len(paths[0].read_bytes()) and stats["parallel_gunzip_rounds"] >= 2 and not stats["parallel_gunzip_gave_up"], stats
+                elif "FMSI_HIP_PGZ_CHUNK_BYTES" in extra:   # (the file with FASTQ records in it: the stretches stop at the first of them and the ordinary reader goes on)
+                    assert 0 < stats["parallel_gunzip_bytes"] <= len(paths[0].read_bytes()) and not stats["parallel_gunzip_gave_up"], stats
+                else:
+                    assert stats["parallel_gunzip_bytes"] == 0
             assert len(outs) == 1 and len(res.stdout) > 10000, (mode, tag)
+    # ---- gzip files that are not what the team's reader takes -- a wrong CRC, a stream cut short, bytes behind the member, a flipped byte inside --
+    # give what zlib alone gives for them (the reader hands over at the last round that stood)
+    good = gzip.compress(fasta, 6)
+    broken = {"crc": good[:-8] + bytes([good[-8] ^ 1]) + good[-7:], "cut": good[:len(good) * 2 // 3], "tail": good + b"junk" * 10,
+              "flip": good[:len(good) // 2] + bytes([good[len(good) // 2] ^ 0x40]) + good[len(good) // 2 + 1:], "two": gzip.compress(fasta[:40000], 9) + gzip.compress(fasta[40000:], 1)}
+    for tag, data in broken.items():
+        q = tmp_path / f"broken_{tag}.gz"
+        q.write_bytes(data)
+        outs = {}
+        for name, extra in (("zlib", {"FMSI_HIP_NO_PARALLEL_GUNZIP": "1"}), ("one", {}), ("many", {"FMSI_HIP_PGZ_CHUNK_BYTES": "2000"})):
+            res = subprocess.run([str(exe), "query", "-O", "--batch", "4000", "--threads", "5", "--stats", "-q", str(q), prefix], capture_output=True, env={**env, **extra})
+            outs[name] = (res.returncode, res.stdout)
+            stats = json.loads([l for l in res.stderr.decode().splitlines() if l.startswith("{")][-1])
+            if name != "zlib":
+                assert stats["parallel_gunzip_gave_up"] == (tag != "two"), (tag, name, stats)
+        # (a stream that FAILS -- crc, cut, flip -- loses zlib's last buffer of output, which at this size is all of it: the rounds that stood before
+        # the failing one were handed out, as the reference's 16-KiB reads hand out what precedes the failing one, src/kseq.h:75-93)
+        assert outs["zlib"] == outs["one"] and outs["many"][0] == outs["zlib"][0] == 0, tag
+        whole_lines = outs["zlib"][1][:outs["zlib"][1].rfind(b"\n") + 1]
+        assert outs["many"][1].startswith(whole_lines), tag
+        if tag in ("tail", "two"):
+            assert outs["many"] == outs["zlib"] and len(outs["zlib"][1]) > 1000, tag
+        else:
+            assert len(outs["many"][1]) > 1000, tag
     # ---- records of ONE k-mer each (cli_reader.h: KmerPart): the parser packs the k-mer and writes the record's line, the answer is filled
     # in behind the device.  The output is the general path's (FMSI_HIP_CLI_KMER_BATCHES=0), whatever the batch size and the team, for
     # files of that shape alone, with header comments, without the last newline -- and for files where a record of another shape sends

@@ -24,7 +24,7 @@ def main() -> None:
     with tempfile.TemporaryDirectory() as d:
         exe = Path(d) / "cli_stub"
         res = subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-omit-frame-pointer", f"-I{REPO / 'include'}",
-                              str(REPO / "tests" / "native" / "cli_pipeline_stub.cpp"), *(str(src / f) for f in ("query_cli.cpp", "fastx.cpp", "trace.cpp", "host_index.cpp",
+                              str(REPO / "tests" / "native" / "cli_pipeline_stub.cpp"), *(str(src / f) for f in ("query_cli.cpp", "fastx.cpp", "pgunzip.cpp", "trace.cpp", "host_index.cpp",
                                                                                                                 "layout.cpp", "index_writer.cpp")),
                               "-o", str(exe), "-lz", "-lpthread", "-ldl"], capture_output=True, text=True)
         if res.returncode != 0:
