@@ -10,6 +10,7 @@
 #include <zlib.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -895,9 +896,21 @@ bool ParallelGunzip::round(unsigned team, const Runner& run) {
     const size_t b0 = static_cast<size_t>(next_bit_ >> 3);
     if (b0 >= size_) return false;
     const size_t left = size_ - b0;
-    // compressed bytes per chunk: small first rounds (the stages behind wait for the first bytes), 8 MiB from the fourth on
-    size_t cb = chunk_bytes_ ? chunk_bytes_ : std::min<size_t>(size_t(8) << 20, size_t(1) << (20 + std::min<uint64_t>(stats.rounds, 3)));
-    const unsigned n = static_cast<unsigned>(std::max<size_t>(1, std::min<size_t>(std::max(1u, team), (left + cb - 1) / cb)));
+    // chunks of 1 MiB of compressed bytes in the first round, one per thread (the stages behind wait for the first bytes), then of 2 MiB, FOUR per
+    // thread, taken by the threads as they fall free: text like DNA never gives a chunk a known window, so a small chunk costs no more than a
+    // large one (3 ms of looking for its start), and chunks that differ in length or decoder -- the round's first is zlib's -- no longer leave
+    // threads waiting for the longest (one chunk per thread: 2.6 GB/s with 16 threads, 4.0 with 32 on the same cores)
+    const size_t cb = chunk_bytes_ ? chunk_bytes_ : (stats.rounds ? size_t(2) << 20 : size_t(1) << 20);
+    const unsigned per_thread = stats.rounds ? 4u : 1u;
+    const unsigned n = static_cast<unsigned>(std::max<size_t>(1, std::min<size_t>(static_cast<size_t>(std::max(1u, team)) * per_thread, (left + cb - 1) / cb)));
+    const unsigned workers = std::min(n, std::max(1u, team));
+    // fn(i) for every i in [0, count), the workers taking the next index as they finish one
+    auto each = [&](unsigned count, const std::function<void(unsigned)>& fn) {
+        std::atomic<unsigned> next{0};
+        run(std::min(workers, std::max(1u, count)), [&](unsigned) {
+            for (unsigned i; (i = next.fetch_add(1, std::memory_order_relaxed)) < count;) fn(i);
+        });
+    };
     const size_t round_end_byte = std::min(size_, b0 + static_cast<size_t>(n) * cb);
     const uint64_t round_end_bit = round_end_byte == size_ ? ~uint64_t(0) : static_cast<uint64_t>(round_end_byte) * 8u;   // (the last round ends with the stream)
     static const bool dbg = std::getenv("FMSI_HIP_PGZ_DEBUG") != nullptr;
@@ -930,7 +943,7 @@ bool ParallelGunzip::round(unsigned team, const Runner& run) {
         ~GiveBack() { f(); }
     } give_back_at_exit{give_back};
     // ---- where the chunks begin
-    run(n, [&](unsigned i) {
+    each(n, [&](unsigned i) {
         if (i == 0) return;
         const auto ta = clk::now();
         Finder f;
@@ -949,7 +962,7 @@ bool ParallelGunzip::round(unsigned team, const Runner& run) {
         for (unsigned j = i + 1; j < n; ++j)
             if (ch[j].has_start) later[i].push_back(ch[j].start_bit);
     // ---- the chunks, side by side
-    run(n, [&](unsigned i) {
+    each(n, [&](unsigned i) {
         Chunk& c = ch[i];
         if (!c.has_start) return;
         StopRule stop{&later[i], 0, round_end_bit};
@@ -1056,7 +1069,7 @@ bool ParallelGunzip::round(unsigned team, const Runner& run) {
     }
     // ---- the markers' bytes and the CRCs of the pieces, side by side
     std::vector<char> ok(chain.size(), 1);
-    run(static_cast<unsigned>(chain.size()), [&](unsigned k) {
+    each(static_cast<unsigned>(chain.size()), [&](unsigned k) {
         Chunk& c = ch[chain[k]];
         if (c.mk.q && !resolve(c, 0, c.mk.q, c.out.p.get())) ok[k] = 0;
         size_t from = 0;

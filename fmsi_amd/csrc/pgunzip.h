@@ -56,7 +56,7 @@ public:
         uint64_t plain_bytes = 0;      // output decoded by zlib
         uint64_t members = 0;
     } stats;
-    // (tests: compressed bytes per chunk; 0 = the schedule of its own, 1 MiB doubling to 8 MiB)
+    // (tests: compressed bytes per chunk; 0 = the schedule of its own: 1 MiB per thread in the first round, then four chunks of 2 MiB per thread)
     void set_chunk_bytes(size_t b) { chunk_bytes_ = b; }
 
 private:

@@ -120,7 +120,7 @@ def test_equals_zlib_on_every_kind_of_stream(lib, texts, tmp_path):
             assert st["marker_symbols"] + st["plain_bytes"] == len(want)
     # the decoder of unknown windows did work: small chunks of a stream of dynamic blocks start in its middle
     rc, out, n, st = gunzip(lib, tmp_path / "fasta6.gz", 8, 1 << 15, len(fa))
-    assert st["marker_symbols"] > len(fa) // 2 and st["rounds"] > 2 and st["chunks"] > st["rounds"] * 4
+    assert st["marker_symbols"] > len(fa) // 2 and st["rounds"] >= 2 and st["chunks"] > st["rounds"] * 4
     # bytes beyond the room are decoded, checked and counted
     rc, out, n, st = gunzip(lib, tmp_path / "fasta6.gz", 4, 1 << 16, 1000)
     assert rc == 0 and n == len(fa) and out == fa[:1000]

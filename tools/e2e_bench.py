@@ -107,6 +107,7 @@ def main() -> None:
     ap.add_argument("--out", default=None, help="write the JSON report here")
     ap.add_argument("--compress", choices=["none", "bgzf", "gzip"], default="none",
                     help="query file as block-gzip (members of 64 KiB, level 1: read by several threads) or as one ordinary gzip member")
+    ap.add_argument("--compress-level", type=int, default=1, help="zlib's level for --compress gzip (gzip's own default is 6)")
     a = ap.parse_args()
 
     import torch
@@ -148,7 +149,7 @@ def main() -> None:
         gz = work / "reads.fa.gz"
         with open(fasta, "rb") as f, open(gz, "wb") as g:
             if a.compress == "gzip":
-                c = zlib.compressobj(1, zlib.DEFLATED, 31)
+                c = zlib.compressobj(a.compress_level, zlib.DEFLATED, 31)
                 while chunk := f.read(1 << 24):
                     g.write(c.compress(chunk))
                 g.write(c.flush())
