@@ -261,7 +261,7 @@ struct Tables {
         for (unsigned i = 144; i < 256; ++i) l[i] = 9;
         for (unsigned i = 256; i < 280; ++i) l[i] = 7;
         for (unsigned i = 280; i < 288; ++i) l[i] = 8;
-        fixed_lit.build(l, 288, Huff::LENS, 9);
+        fixed_lit.build(l, 288, Huff::LENS, 10);
         uint8_t dl[32];
         for (unsigned i = 0; i < 32; ++i) dl[i] = 5;
         fixed_dist.build(dl, 32, Huff::DISTS, 5);
@@ -273,7 +273,25 @@ struct Tables {
 struct MarkerOut {
     std::vector<uint16_t> s;
     size_t q = 0;
-    size_t marker_end = 0;   // one behind the last marker written
+    // Is there a marker among the last kWin symbols?  Looked for from the end, block after block: while the window is unknown one is found within
+    // a few symbols, and the one time none is the 64 KiB are read once.  (The copies used to OR what they moved and branch on it: a branch on
+    // the data in the loop's hottest path.)
+    bool window_known() const {
+        if (q < kWin) return false;
+        const uint16_t* p = s.data();
+        size_t i = q;
+        while (i > q - kWin && (i & 7u)) {
+            if (p[--i] & kMarker) return false;
+        }
+        while (i >= q - kWin + 8) {
+            i -= 8;
+            if (_mm_movemask_epi8(_mm_loadu_si128(reinterpret_cast<const __m128i*>(p + i))) & 0xAAAA) return false;
+        }
+        while (i > q - kWin) {
+            if (p[--i] & kMarker) return false;
+        }
+        return true;
+    }
     void room(size_t n) {
         if (q + n > s.size()) s.resize(std::max(s.size() * 2, q + n + (size_t(1) << 16)));
     }
@@ -320,7 +338,6 @@ BlockEnd decode_block_markers(BitReader& br, Tables& tb, MarkerOut& out, size_t 
     const uint32_t* lt = lit->t.data();
     const uint32_t* dt = dist->t.data();
     const uint64_t lmask = (1u << lpb) - 1u, dmask = (1u << dpb) - 1u;
-    constexpr uint64_t kMarkers4 = 0x8000800080008000ull;
     for (;;) {
         // ---- the fast loop: while 16 bytes of input and 320 symbols of room are there for certain (no bit of the reader's can run out)
         out.room(4096);
@@ -333,7 +350,6 @@ BlockEnd decode_block_markers(BitReader& br, Tables& tb, MarkerOut& out, size_t 
             uint16_t* const o0 = out.s.data();
             uint16_t* o = o0 + out.q;
             uint16_t* const o_stop = o0 + std::min(out.s.size() - 320, limit);
-            size_t marker_end = out.marker_end;
             int state = 0;   // 1: end of block, 2: error
 #define PGZ_REFILL()                                   \
     do {                                               \
@@ -400,25 +416,24 @@ BlockEnd decode_block_markers(BitReader& br, Tables& tb, MarkerOut& out, size_t 
                 uint16_t* const oe = o + len;
                 if (dd <= q) {
                     const uint16_t* src = o - dd;
-                    if (dd >= 4) {   // four symbols at a time (up to three beyond the match: room is there, and what the OR sees of them is text of the window anyway)
-                        uint64_t acc = 0;
-                        do {
-                            uint64_t v;
-                            std::memcpy(&v, src, 8);
-                            std::memcpy(o, &v, 8);
-                            acc |= v;
-                            src += 4;
-                            o += 4;
-                        } while (o < oe);
-                        if (acc & kMarkers4) marker_end = q + len;
+                    if (dd >= 8) {
+                        // sixteen symbols whatever the length (eight at a time: a source at least eight back is written before it is read; room for
+                        // what goes beyond the match is there), more only for the rare long match: no branch on the length in the common case
+                        _mm_storeu_si128(reinterpret_cast<__m128i*>(o), _mm_loadu_si128(reinterpret_cast<const __m128i*>(src)));
+                        _mm_storeu_si128(reinterpret_cast<__m128i*>(o + 8), _mm_loadu_si128(reinterpret_cast<const __m128i*>(src + 8)));
+                        if (len > 16) {
+                            src += 16;
+                            o += 16;
+                            do {
+                                _mm_storeu_si128(reinterpret_cast<__m128i*>(o), _mm_loadu_si128(reinterpret_cast<const __m128i*>(src)));
+                                src += 8;
+                                o += 8;
+                            } while (o < oe);
+                        }
                     } else {
-                        uint16_t acc = 0;
                         do {
-                            const uint16_t v = *src++;
-                            acc |= v;
-                            *o++ = v;
+                            *o++ = *src++;
                         } while (o < oe);
-                        if (acc & kMarker) marker_end = q + len;
                     }
                     o = oe;
                 } else {   // into the window this chunk was not given
@@ -427,7 +442,6 @@ BlockEnd decode_block_markers(BitReader& br, Tables& tb, MarkerOut& out, size_t 
                         o0[at] = dd > at ? static_cast<uint16_t>(kMarker | (kWin + at - dd)) : o0[at - dd];
                     }
                     o = oe;
-                    marker_end = q + len;   // (a copy that starts in the unknown window: its first symbol is a marker)
                 }
             }
 #undef PGZ_REFILL
@@ -437,7 +451,6 @@ BlockEnd decode_block_markers(BitReader& br, Tables& tb, MarkerOut& out, size_t 
             br.buf = buf;
             br.cnt = cnt;
             out.q = static_cast<size_t>(o - o0);
-            out.marker_end = marker_end;
             if (state == 2) return kBlockError;
             if (state == 1) break;
             if (out.q >= limit) return kBlockDone;
@@ -465,15 +478,11 @@ BlockEnd decode_block_markers(BitReader& br, Tables& tb, MarkerOut& out, size_t 
         out.room(len);
         uint16_t* o = out.s.data();
         const size_t q = out.q;
-        uint16_t acc = 0;
         for (uint32_t i = 0; i < len; ++i) {
             const size_t at = q + i;
-            const uint16_t v = dd > at ? static_cast<uint16_t>(kMarker | (kWin + at - dd)) : o[at - dd];   // dd <= 32768: the index is in [0, kWin)
-            acc |= v;
-            o[at] = v;
+            o[at] = dd > at ? static_cast<uint16_t>(kMarker | (kWin + at - dd)) : o[at - dd];   // dd <= 32768: the index is in [0, kWin)
         }
         out.q = q + len;
-        if (acc & kMarker) out.marker_end = out.q;
         if (out.q >= limit) return kBlockDone;
     }
     if (br.overrun) return kBlockError;
@@ -788,7 +797,7 @@ void decode_unknown(const unsigned char* d, size_t size, StopRule& stop, Chunk& 
             c.out.len = mk.q;
             return;
         }
-        if (fresh_member || (mk.q - mk.marker_end >= kWin)) {   // the window is known from here on: a new member has none, 32 KiB without a marker are one
+        if (fresh_member || mk.window_known()) {   // the window is known from here on: a new member has none, 32 KiB without a marker are one
             std::vector<unsigned char> dict;
             if (!fresh_member) {
                 dict.resize(kWin);
@@ -831,7 +840,6 @@ struct Finder {
         // the block itself (up to 2^17 symbols of it)
         br.init(d, size, bit);
         trial.q = 0;
-        trial.marker_end = 0;
         return decode_block_markers(br, tb, trial, size_t(1) << 17) != kBlockError;
     }
     // the first block start in [from_bit, to_bit), or ~0
