@@ -676,10 +676,12 @@ def base_child_args(args, n, batch):
 # ======================================================================================================================================
 # the whole process
 # ======================================================================================================================================
-def e2e_report(args, modes="or,all,all_S", kmer_records=0, kmer_modes="or,all"):
+def e2e_report(args, modes="or,all,all_S", kmer_records=0, kmer_modes="or,all", gz_modes=""):
     import subprocess
     cmd = [sys.executable, str(REPO / "tools" / "e2e_bench.py"), "--n", str(int(args.n)), "--reads", str(args.reads), "--read-len", str(args.read_len),
            "--k", str(args.k), "--modes", modes, "--ref-reads", "20"]
+    if gz_modes:
+        cmd += ["--gz-modes", gz_modes, "--compress-level", "1"]
     if kmer_records and args.k <= 32:
         cmd += ["--kmer-records", str(int(kmer_records)), "--kmer-modes", kmer_modes]
     res = subprocess.run(cmd, capture_output=True, text=True)
@@ -701,6 +703,8 @@ def e2e_report(args, modes="or,all,all_S", kmer_records=0, kmer_modes="or,all"):
     modes_out = {name: digest(e) for name, e in report["modes"].items()}
     for name, e in (report.get("kmer_modes") or {}).items():   # the query file of one k-mer per record (configs 2 / 3 / 5's shape)
         modes_out["isolated_" + name] = digest(e)
+    for name, e in (report.get("gz_modes") or {}).items():     # the reads file as one ordinary gzip member
+        modes_out[("zlib_" if "NO_PARALLEL_GUNZIP" in name else "") + name.split("+")[-1] + "_gz"] = digest(e)
     return report, modes_out
 
 
@@ -877,20 +881,25 @@ def run_config_legs(args):
         t0 = time.time()
         if name == "e2e":
             try:
-                report, modes = e2e_report(args, kmer_records=args.e2e_kmer_records)
-                for mode_name, cli in (("or", "fmsi query"), ("all", "fmsi query -O"), ("all_S", "fmsi query -S -O"), ("isolated_or", "fmsi query"), ("isolated_all", "fmsi query -O")):
+                report, modes = e2e_report(args, kmer_records=args.e2e_kmer_records, gz_modes="or,FMSI_HIP_NO_PARALLEL_GUNZIP=1+or")
+                for mode_name, cli in (("or", "fmsi query"), ("all", "fmsi query -O"), ("all_S", "fmsi query -S -O"), ("isolated_or", "fmsi query"), ("isolated_all", "fmsi query -O"),
+                                       ("or_gz", "fmsi query"), ("zlib_or_gz", "FMSI_HIP_NO_PARALLEL_GUNZIP=1 fmsi query")):
                     e = modes.get(mode_name)
                     if not e:
                         continue
                     isolated = mode_name.startswith("isolated_")
+                    gz = mode_name.endswith("_gz")
                     what = (f"<{report['kmer_fasta_bytes'] / 1e9:.2f} GB FASTA: {report['kmer_records']} records of ONE {args.k}-mer each, half present (configs 2 / 3 / 5's query shape)>"
                             if isolated else f"<{report['fasta_bytes'] / 1e9:.2f} GB FASTA: {args.reads} reads of {args.read_len} bases>")
+                    if gz:
+                        what = (f"<the same reads as ONE ordinary gzip member (zlib level {report['gz']['level']}, {report['gz']['compressed_bytes'] / 1e9:.2f} GB): "
+                                + ("zlib on one thread, as the reference reads it (src/parser.h:14-27)>" if mode_name.startswith("zlib_") else "inflated by the team, pgunzip.h>"))
                     out.append({"name": f"e2e_{mode_name}", "config": f"whole process `{cli} -q {what} "
                                                                       f"<index of {int(args.n)} rows, {report['index_bytes'] / 1e9:.2f} GB of .fmsi.* files in /dev/shm>`, output to a file, default options; "
                                                                       f"wall time of the process incl. index load, parse, device, print (SURVEY 8(d)(ii), src/main.cpp:238-375)",
                                 "value": e["windows_per_s_whole_process"], "unit": "k-mers/s", "ms": round(e["wall_seconds"] * 1e3, 1), "windows": e.get("windows"),
                                 "load_seconds": e["load_seconds"], "windows_per_s_after_load": e["windows_per_s_after_load"], "stages": e["stages"], "dictionary": e["dictionary"],
-                                "kmer_batches": e.get("kmer_batches"),
+                                "kmer_batches": e.get("kmer_batches"), **({"compact_last": True} if gz else {}),
                                 "kernel": None, "avg_kernel_ms": None, "algorithmic_bytes": None, "frac": None, "traffic": None,
                                 "matches_reference": e["identical_to_reference_on_sample"],
                                 "reference": f"the reference CLI on the first {'20000 records' if isolated else '20 reads'} of the same file, same index files: {e['reference_windows_per_s']} windows/s on one core; "
@@ -982,10 +991,14 @@ def compact_line(line):
             out["cpu_baseline"] = c3
     else:
         out["cpu_baseline"] = None
+    extra_legs = []   # (legs that enter the compact line only where it has room left: the full record has them)
     if line.get("configs"):
         legs = []
         for l in line["configs"]:
             if not isinstance(l, dict):
+                continue
+            if l.get("compact_last"):
+                extra_legs.append({"name": l.get("name"), "value": None if l.get("value") is None else int(float("%.5g" % l["value"])), "matches_reference": l.get("matches_reference")})
                 continue
             if "error" in l and "value" not in l:
                 legs.append({"name": l.get("name"), "error": str(l["error"])[:60]})
@@ -1020,6 +1033,11 @@ def compact_line(line):
             tgt.pop(drop[-1], None)
     while size(out) > COMPACT_LIMIT and out.get("configs"):
         out["configs"].pop()
+    for leg in extra_legs:
+        out["configs"].append(leg)
+        if size(out) > COMPACT_LIMIT:
+            out["configs"].pop()
+            break
     return json.dumps(out, separators=(",", ":"))
 
 

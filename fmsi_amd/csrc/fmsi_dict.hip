@@ -1518,7 +1518,11 @@ __global__ __launch_bounds__(256) void sk_kmers_kernel(SkIndex sk, DictIndex aux
 // isolated k-mers (8 bytes each) through the records: fmsi_hip_query_kmers on a handle without the k-mer dictionary
 int launch_skdict_kmers(fmsi_hip_index* idx, const uint64_t* d_kmers, uint64_t n, uint32_t flags, uint8_t* o8, unsigned long long* d_counters, hipStream_t s) {
     uint64_t chunk = n / (256ull * 8 * 8);
-    chunk = std::min<uint64_t>(std::max<uint64_t>(chunk, 128), 4096) & ~127ull;
+    static const uint64_t chunk_max = [] {   // (FMSI_HIP_SK_KMERS_CHUNK: measurements)
+        const char* e = std::getenv("FMSI_HIP_SK_KMERS_CHUNK");
+        return e ? std::min<uint64_t>(std::max<uint64_t>(static_cast<uint64_t>(atoll(e)), 128), 4096) : 4096ull;
+    }();
+    chunk = std::min<uint64_t>(std::max<uint64_t>(chunk, 128), chunk_max) & ~127ull;
     const uint64_t waves = (n + chunk - 1) / chunk;
     const dim3 grid(static_cast<uint32_t>((waves + 3) / 4)), block(256);
     if (d_counters) hipLaunchKernelGGL((sk_kmers_kernel<true>), grid, block, 0, s, idx->sk, idx->sk_aux, d_kmers, n, flags, static_cast<uint32_t>(chunk), o8, d_counters);

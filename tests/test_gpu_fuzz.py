@@ -70,9 +70,14 @@ def one_case(fm, tmp_path, seed: int, checker):
         import gzip
         data = gzip.compress(data)
     q.write_bytes(data)
-    # odd seeds: also files this small go through the block-parallel readers (mapped plain files, block-gzip members)
+    # odd seeds: also files this small go through the block-parallel readers (mapped plain files, block-gzip members, and -- pgunzip.h -- the
+    # one member of an ordinary gzip file, inflated in many chunks on two thirds of those seeds)
+    os.environ.pop("FMSI_HIP_PGZ_CHUNK_BYTES", None)
     if seed % 2:
         os.environ["FMSI_HIP_READER_MIN_BYTES"] = "1"
+        chunk = random.Random(seed ^ 0x5A17).choice([None, "200", "1500"])
+        if chunk:
+            os.environ["FMSI_HIP_PGZ_CHUNK_BYTES"] = chunk
     else:
         os.environ.pop("FMSI_HIP_READER_MIN_BYTES", None)
     modes = [m for m in MODES if use_klcp or "-S" not in m]
@@ -94,6 +99,7 @@ def one_case(fm, tmp_path, seed: int, checker):
         assert rc == 0, (seed, mode, opts, err.decode()[-600:])
         assert got == want, (seed, k, len(ms), mode, opts, packing)
     os.environ.pop("FMSI_HIP_READER_MIN_BYTES", None)
+    os.environ.pop("FMSI_HIP_PGZ_CHUNK_BYTES", None)
 
 
 @pytest.mark.parametrize("seed", range(12))   # (tools/fuzz_cli.py runs as many as one likes: 5 575 seeds were clean over rounds 2-4; the suite has a time limit)

@@ -107,7 +107,10 @@ def main() -> None:
     ap.add_argument("--out", default=None, help="write the JSON report here")
     ap.add_argument("--compress", choices=["none", "bgzf", "gzip"], default="none",
                     help="query file as block-gzip (members of 64 KiB, level 1: read by several threads) or as one ordinary gzip member")
-    ap.add_argument("--compress-level", type=int, default=1, help="zlib's level for --compress gzip (gzip's own default is 6)")
+    ap.add_argument("--compress-level", type=int, default=1, help="zlib's level for --compress gzip / --gz-modes (gzip's own default is 6)")
+    ap.add_argument("--gz-modes", default="",
+                    help="after the modes on the plain file: the reads file as ONE ordinary gzip member (zlib, --compress-level) through these modes -- the "
+                         "team's inflate, pgunzip.h; a mode with FMSI_HIP_NO_PARALLEL_GUNZIP=1+ in front is zlib on one thread, as the reference reads it")
     a = ap.parse_args()
 
     import torch
@@ -250,6 +253,20 @@ def main() -> None:
 
     if a.reads:
         run_modes(a.modes.split(","), fasta, sample, windows_per_read, a.ref_reads, report["modes"])
+    if a.reads and a.gz_modes and a.compress == "none":
+        import zlib
+        t0 = time.time()
+        gz = work / "reads.fa.gz"
+        with open(fasta, "rb") as f, open(gz, "wb") as g:
+            c = zlib.compressobj(a.compress_level, zlib.DEFLATED, 31)
+            while chunk := f.read(1 << 24):
+                g.write(c.compress(chunk))
+            g.write(c.flush())
+        report["gz"] = {"compressed_bytes": gz.stat().st_size, "compress_seconds": round(time.time() - t0, 2), "level": a.compress_level}
+        report["gz_modes"] = {}
+        run_modes(a.gz_modes.split(","), gz, sample, windows_per_read, a.ref_reads, report["gz_modes"])
+        if not a.keep:
+            gz.unlink()
     if a.kmer_records:
         ksample = work / "ksample.fa"
         n_ref = min(a.kmer_records, 20000)
