@@ -466,8 +466,21 @@ void warm_table_module() {
     (void)hipGetLastError();
 }
 
+void start_deferred_sign(fmsi_hip_index* idx) {
+    if (!idx || !idx->sign_deferred) return;
+    idx->sign_deferred = false;
+    if (!idx->d_ptable || !idx->bg_stream) return;
+    ::fmsi::DeviceGuard device_guard_(idx->device);
+    const uint64_t final_count = 1ull << (2 * idx->prefix_len);
+    const uint32_t blocks = static_cast<uint32_t>(std::min<uint64_t>((final_count + 255) / 256, 1u << 20));
+    hipLaunchKernelGGL(ptable_sign_kernel, dim3(blocks), dim3(256), 0, idx->bg_stream, idx->dev, static_cast<uint2*>(idx->d_ptable), final_count);
+    if (hipGetLastError() == hipSuccess) idx->bg_pending = true;   // (a launch that fails leaves the intervals: every answer stays what it is)
+}
+
 int wait_background(fmsi_hip_index* idx) {
-    if (!idx || !idx->bg_pending) return 0;
+    if (!idx) return 0;
+    start_deferred_sign(idx);   // (whoever waits wants the table in its final form)
+    if (!idx->bg_pending) return 0;
     ::fmsi::DeviceGuard device_guard_(idx->device);
     const hipError_t e = hipStreamSynchronize(idx->bg_stream);
     idx->bg_pending = false;
@@ -544,11 +557,17 @@ int build_prefix_table(fmsi_hip_index* idx, int t, bool sign_in_background) {
         // (the load's temporaries and this table's upper levels are parked blocks, and whoever is handed one waits for the device first: let that
         // wait be now, on a device with nothing to do, not the first batch's behind the pass)
         if (bg) dev_settle();
-        hipLaunchKernelGGL(ptable_sign_kernel, dim3(blocks), dim3(256), 0, bg ? idx->bg_stream : static_cast<hipStream_t>(0), idx->dev, a, final_count);
-        e = hipGetLastError();
-        if (e == hipSuccess && !bg) e = hipDeviceSynchronize();
-        if (e != hipSuccess) return fail(FMSI_HIP_EHIP, std::string("prefix table signatures: ") + hipGetErrorString(e));
-        idx->bg_pending = bg;
+        static const bool sign_at_load = std::getenv("FMSI_HIP_SIGN_AT_LOAD") != nullptr;   // (A/B runs: round 5's start of the pass, right here)
+        if (bg && !sign_at_load) {
+            idx->sign_deferred = true;   // started by the first streaming call / after kSignAfterLookups k-mers: start_deferred_sign
+            idx->lookups_unsigned = 0;
+        } else {
+            hipLaunchKernelGGL(ptable_sign_kernel, dim3(blocks), dim3(256), 0, bg ? idx->bg_stream : static_cast<hipStream_t>(0), idx->dev, a, final_count);
+            e = hipGetLastError();
+            if (e == hipSuccess && !bg) e = hipDeviceSynchronize();
+            if (e != hipSuccess) return fail(FMSI_HIP_EHIP, std::string("prefix table signatures: ") + hipGetErrorString(e));
+            idx->bg_pending = bg;
+        }
     }
     idx->d_ptable = a;
     idx->dev.ptable = a;
@@ -916,6 +935,7 @@ uint64_t fmsi_hip_scratch_bytes(int device) {
 void fmsi_hip_index_destroy(fmsi_hip_index* idx) {
     if (!idx) return;
     ::fmsi::DeviceGuard device_guard_(idx->device);
+    idx->sign_deferred = false;   // (a pass that never started is not started to be waited for)
     (void)wait_background(idx);
     if (idx->bg_stream) (void)hipStreamDestroy(idx->bg_stream);
     for (void* p : {idx->d_sk, idx->d_sk_aux[0], idx->d_sk_aux[1], idx->d_sk_aux[2], idx->d_sk_aux[3]})
@@ -1046,12 +1066,24 @@ int fmsi_hip_query_kmers(fmsi_hip_index* idx, const uint64_t* kmers, uint64_t n_
     if (n_kmers == 0) return 0;
     int rc = check_query_args(idx, kmers, out, k, 32);
     if (rc) return rc;
-    return run_query(idx, 0, kmers, n_kmers * 8, nullptr, n_kmers, k, flags, out, counters, stream);
+    rc = run_query(idx, 0, kmers, n_kmers * 8, nullptr, n_kmers, k, flags, out, counters, stream);
+    if (!rc) ::fmsi::note_lookups(idx, n_kmers);   // (a table still waiting for its signatures: index_priv.h)
+    return rc;
 }
 
+static int query_runs_impl(fmsi_hip_index* idx, const uint64_t* packed_seq, uint64_t seq_bases, const uint64_t* run_start,
+                           const uint32_t* run_windows, uint64_t n_runs, uint64_t n_windows, int k, uint32_t flags, void* out,
+                           uint64_t* counters, void* stream);
 int fmsi_hip_query_runs(fmsi_hip_index* idx, const uint64_t* packed_seq, uint64_t seq_bases, const uint64_t* run_start,
                         const uint32_t* run_windows, uint64_t n_runs, uint64_t n_windows, int k, uint32_t flags, void* out,
                         uint64_t* counters, void* stream) {
+    const int rc = query_runs_impl(idx, packed_seq, seq_bases, run_start, run_windows, n_runs, n_windows, k, flags, out, counters, stream);
+    if (!rc && idx) ::fmsi::note_lookups(idx, n_windows);
+    return rc;
+}
+static int query_runs_impl(fmsi_hip_index* idx, const uint64_t* packed_seq, uint64_t seq_bases, const uint64_t* run_start,
+                           const uint32_t* run_windows, uint64_t n_runs, uint64_t n_windows, int k, uint32_t flags, void* out,
+                           uint64_t* counters, void* stream) {
     if (n_windows == 0 || n_runs == 0) return 0;
     int rc = check_query_args(idx, packed_seq, out, k, 1 << 20);
     if (rc) return rc;

@@ -131,6 +131,10 @@ struct fmsi_hip_index {
     void* d_ptable = nullptr;
     hipStream_t bg_stream = nullptr;   // the table's signature pass when it runs beside the first queries (build_prefix_table), else null
     bool bg_pending = false;
+    // FMSI_HIP_LOAD_ASYNC_TABLE: the pass has not been started yet -- it starts with the handle's first streaming call (whose certificates are
+    // what the signatures are mostly for) or once kSignAfterLookups k-mers have been looked up through the table (start_deferred_sign)
+    bool sign_deferred = false;
+    uint64_t lookups_unsigned = 0;
     int fn_kind = 0;             // demasking function of the current fmsi_hip_query_runs_fn call (FMSI_HIP_FN_*) and its bounds
     uint64_t fn_r = 0, fn_s = 0;
     void* d_klcp = nullptr;      // plain kLCP bit-vector (n bits, u64 words), when present
@@ -187,6 +191,14 @@ namespace fmsi {
 // stream of their own while the handle already answers -- wait_background() before anything that reads or replaces the table as a whole
 int build_prefix_table(fmsi_hip_index* idx, int t, bool sign_in_background = false);
 int wait_background(fmsi_hip_index* idx);
+// round 6: the background pass is not started by the load but by what profits from it.  At human scale it is 0.17 s of device time for a
+// 15-deep table; a query file of 10^8 isolated k-mers is 0.05 s of lookups, which ran at a third of their rate beside it (device stage
+// 0.12-0.20 s, the `fmsi` binary's run 0.44-0.66 s where it is 0.40 without the pass) and gain nothing a pass that long can pay for.
+void start_deferred_sign(fmsi_hip_index* idx);
+constexpr uint64_t kSignAfterLookups = 250000000ull;
+inline void note_lookups(fmsi_hip_index* idx, uint64_t n) {
+    if (idx->sign_deferred && (idx->lookups_unsigned += n) >= kSignAfterLookups) start_deferred_sign(idx);
+}
 // have the runtime load the code object of fmsi_hip.hip / fmsi_stream.hip now (it does so at the first use of one of their kernels, 10-20 ms
 // each): the index load calls these while its payloads are still on their way
 void warm_table_module();
