@@ -483,6 +483,21 @@ inline bool parse_kmer_range(const unsigned char* d, size_t lo, size_t hi, size_
     return use_bmi2() ? parse_kmer_range_bmi2(d, lo, hi, limit, k, part) : parse_kmer_range_plain(d, lo, hi, limit, k, part);
 }
 
+// a stretch's bytes: from 4 MiB on aligned to 2 MiB and advised for huge pages (the team writes a fresh 64 MB of them per stretch -- inflated
+// members, the gzip reader's copies --, which in 4-KiB pages is 16 000 page faults)
+inline std::shared_ptr<char[]> alloc_stretch(size_t bytes) {
+    constexpr size_t kHuge = size_t(2) << 20;
+    if (bytes >= 2 * kHuge) {
+        void* p = nullptr;
+        const size_t rounded = (bytes + kHuge - 1) / kHuge * kHuge;
+        if (posix_memalign(&p, kHuge, rounded) == 0) {
+            (void)madvise(p, rounded, MADV_HUGEPAGE);
+            return std::shared_ptr<char[]>(static_cast<char*>(p), [](char* q) { std::free(q); });
+        }
+    }
+    return std::shared_ptr<char[]>(new char[bytes]);
+}
+
 class QueryReader {
 public:
     using clock = std::chrono::steady_clock;
@@ -675,7 +690,7 @@ private:
                     }
                     if (serial) break;
                     len = carry.size() + bytes;
-                    seg.reset(new char[len + 1]);
+                    seg = alloc_stretch(len + 1);
                     std::memcpy(seg.get(), carry.data(), carry.size());
                     // (inflating is by far the longest piece of work on this path: the whole team takes it)
                     const unsigned inflaters = static_cast<unsigned>(std::max<size_t>(1, std::min<size_t>(team, ms.size())));
@@ -689,7 +704,7 @@ private:
                         break;
                     }
                 } else {
-                    seg.reset(new char[carry.size() + range_bytes + 1]);
+                    seg = alloc_stretch(carry.size() + range_bytes + 1);
                     std::memcpy(seg.get(), carry.data(), carry.size());
                     // (an ordinary gzip file: the team inflates it, pgunzip.h; where that reader gives up -- a stream it does not take, a
                     // trailer that does not match -- zlib goes on from the byte it got to, as it would have from the start)

@@ -15,6 +15,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <new>
 
 namespace fmsi {
 namespace {
@@ -271,14 +272,16 @@ struct Tables {
 
 // output with an unknown window: 16-bit symbols
 struct MarkerOut {
-    std::vector<uint16_t> s;
+    PgzBuf b;
     size_t q = 0;
+    uint16_t* data() const { return reinterpret_cast<uint16_t*>(b.data()); }
+    size_t size() const { return b.cap() / 2; }
     // Is there a marker among the last kWin symbols?  Looked for from the end, block after block: while the window is unknown one is found within
     // a few symbols, and the one time none is the 64 KiB are read once.  (The copies used to OR what they moved and branch on it: a branch on
     // the data in the loop's hottest path.)
     bool window_known() const {
         if (q < kWin) return false;
-        const uint16_t* p = s.data();
+        const uint16_t* p = data();
         size_t i = q;
         while (i > q - kWin && (i & 7u)) {
             if (p[--i] & kMarker) return false;
@@ -293,7 +296,7 @@ struct MarkerOut {
         return true;
     }
     void room(size_t n) {
-        if (q + n > s.size()) s.resize(std::max(s.size() * 2, q + n + (size_t(1) << 16)));
+        if (q + n > size()) b.grow(std::max(b.cap() * 2, (q + n) * 2 + (size_t(1) << 17)), q * 2);
     }
 };
 
@@ -314,7 +317,7 @@ BlockEnd decode_block_markers(BitReader& br, Tables& tb, MarkerOut& out, size_t 
         size_t at = br.pos - br.cnt / 8;
         if (at + len > br.size) return kBlockError;
         out.room(len);
-        for (uint32_t i = 0; i < len; ++i) out.s[out.q++] = br.d[at + i];
+        for (uint32_t i = 0; i < len; ++i) out.data()[out.q++] = br.d[at + i];
         br.init(br.d, br.size, static_cast<uint64_t>(at + len) * 8u);
         return final ? kBlockFinal : kBlockDone;
     }
@@ -347,9 +350,9 @@ BlockEnd decode_block_markers(BitReader& br, Tables& tb, MarkerOut& out, size_t 
             const size_t pos_end = br.size - 16;
             uint64_t buf = br.buf;
             unsigned cnt = br.cnt;
-            uint16_t* const o0 = out.s.data();
+            uint16_t* const o0 = out.data();
             uint16_t* o = o0 + out.q;
-            uint16_t* const o_stop = o0 + std::min(out.s.size() - 320, limit);
+            uint16_t* const o_stop = o0 + std::min(out.size() - 320, limit);
             int state = 0;   // 1: end of block, 2: error
 #define PGZ_REFILL()                                   \
     do {                                               \
@@ -463,7 +466,7 @@ BlockEnd decode_block_markers(BitReader& br, Tables& tb, MarkerOut& out, size_t 
         br.drop(e & 15u);
         if (e & Huff::kLit) {
             out.room(1);
-            out.s[out.q++] = static_cast<uint16_t>(e >> 16);
+            out.data()[out.q++] = static_cast<uint16_t>(e >> 16);
             if (br.overrun) return kBlockError;
             if (out.q >= limit) return kBlockDone;
             continue;
@@ -476,7 +479,7 @@ BlockEnd decode_block_markers(BitReader& br, Tables& tb, MarkerOut& out, size_t 
         const uint32_t dd = (de >> 16) + br.take((de >> 8) & 15u);
         if (br.overrun) return kBlockError;
         out.room(len);
-        uint16_t* o = out.s.data();
+        uint16_t* o = out.data();
         const size_t q = out.q;
         for (uint32_t i = 0; i < len; ++i) {
             const size_t at = q + i;
@@ -636,16 +639,13 @@ struct MemberEnd {
     uint32_t crc, isize;
 };
 
-struct ByteBuf {   // (not a vector: no zero fill of what zlib is about to write)
-    std::unique_ptr<unsigned char[]> p;
-    size_t len = 0, cap = 0;
+struct ByteBuf {
+    PgzBuf b;
+    size_t len = 0;
+    unsigned char* data() const { return b.data(); }
+    size_t cap() const { return b.cap(); }
     void reserve(size_t n) {
-        if (n <= cap) return;
-        const size_t nc = std::max(n, cap + cap / 2);
-        std::unique_ptr<unsigned char[]> np(new unsigned char[nc]);
-        if (len) std::memcpy(np.get(), p.get(), len);
-        p = std::move(np);
-        cap = nc;
+        if (n > b.cap()) b.grow(std::max(n, b.cap() + b.cap() / 2), len);
     }
 };
 
@@ -716,9 +716,9 @@ void zlib_phase(const unsigned char* d, size_t size, uint64_t bit, const unsigne
     for (;;) {
         const size_t in_left = size - static_cast<size_t>(zs.next_in - d);
         zs.avail_in = static_cast<uInt>(std::min<size_t>(in_left, size_t(1) << 30));
-        if (c.out.cap - c.out.len < (size_t(1) << 16)) c.out.reserve(c.out.cap + (c.out.cap >> 1) + (size_t(1) << 20));
-        const size_t room = std::min<size_t>(c.out.cap - c.out.len, size_t(1) << 30);
-        zs.next_out = c.out.p.get() + c.out.len;
+        if (c.out.cap() - c.out.len < (size_t(1) << 16)) c.out.reserve(c.out.cap() + (c.out.cap() >> 1) + (size_t(1) << 20));
+        const size_t room = std::min<size_t>(c.out.cap() - c.out.len, size_t(1) << 30);
+        zs.next_out = c.out.data() + c.out.len;
         zs.avail_out = static_cast<uInt>(room);
         const int rc = inflate(&zs, Z_BLOCK);
         c.out.len += room - zs.avail_out;
@@ -801,7 +801,7 @@ void decode_unknown(const unsigned char* d, size_t size, StopRule& stop, Chunk& 
             std::vector<unsigned char> dict;
             if (!fresh_member) {
                 dict.resize(kWin);
-                for (uint32_t i = 0; i < kWin; ++i) dict[i] = static_cast<unsigned char>(mk.s[mk.q - kWin + i]);
+                for (uint32_t i = 0; i < kWin; ++i) dict[i] = static_cast<unsigned char>(mk.data()[mk.q - kWin + i]);
             }
             c.out.reserve(mk.q + expect);
             c.out.len = mk.q;
@@ -861,6 +861,37 @@ struct Finder {
 };
 
 }  // namespace
+
+PgzBuf::~PgzBuf() { std::free(p_); }
+
+PgzBuf& PgzBuf::operator=(PgzBuf&& o) noexcept {
+    if (this != &o) {
+        std::free(p_);
+        p_ = o.p_;
+        cap_ = o.cap_;
+        o.p_ = nullptr;
+        o.cap_ = 0;
+    }
+    return *this;
+}
+
+void PgzBuf::grow(size_t bytes, size_t keep) {
+    if (bytes <= cap_) return;
+    constexpr size_t kHuge = size_t(2) << 20;
+    void* np = nullptr;
+    if (bytes >= 2 * kHuge) {
+        bytes = (bytes + kHuge - 1) / kHuge * kHuge;
+        if (posix_memalign(&np, kHuge, bytes) != 0) np = nullptr;
+        else (void)madvise(np, bytes, MADV_HUGEPAGE);
+    } else {
+        np = std::malloc(bytes);
+    }
+    if (!np) throw std::bad_alloc();
+    if (keep) std::memcpy(np, p_, std::min(keep, cap_));
+    std::free(p_);
+    p_ = np;
+    cap_ = bytes;
+}
 
 ParallelGunzip::~ParallelGunzip() {
     if (mapped_ && data_) munmap(const_cast<unsigned char*>(data_), size_);
@@ -931,19 +962,18 @@ bool ParallelGunzip::round(unsigned team, const Runner& run) {
     ch[0].has_start = true;
     for (unsigned i = 0; i < n; ++i) {
         if (i && !sym_pool_.empty()) {   // (chunk 0 knows its window: no symbols)
-            ch[i].mk.s = std::move(sym_pool_.back());
+            ch[i].mk.b = std::move(sym_pool_.back());
             sym_pool_.pop_back();
         }
         if (!byte_pool_.empty()) {
-            ch[i].out.p = std::move(byte_pool_.back().first);
-            ch[i].out.cap = byte_pool_.back().second;
+            ch[i].out.b = std::move(byte_pool_.back());
             byte_pool_.pop_back();
         }
     }
     auto give_back = [&] {   // (whatever ends the round: the buffers that were not handed out stay with the reader)
         for (Chunk& c : ch) {
-            if (c.mk.s.capacity()) sym_pool_.push_back(std::move(c.mk.s));
-            if (c.out.p) byte_pool_.emplace_back(std::move(c.out.p), c.out.cap);
+            if (c.mk.b.cap()) sym_pool_.push_back(std::move(c.mk.b));
+            if (c.out.b.cap()) byte_pool_.push_back(std::move(c.out.b));
         }
     };
     struct GiveBack {
@@ -1005,7 +1035,7 @@ bool ParallelGunzip::round(unsigned team, const Runner& run) {
     }
     std::vector<unsigned char> win = window_;
     auto resolve = [](const Chunk& c, size_t from, size_t to, unsigned char* dst) -> bool {   // the markers [from, to) of c -> dst[0, to - from)
-        const uint16_t* s = c.mk.s.data();
+        const uint16_t* s = c.mk.data();
         const size_t wl = c.window_before.size();
         const unsigned char* w = c.window_before.data();
         uint32_t bad = 0;
@@ -1069,9 +1099,9 @@ bool ParallelGunzip::round(unsigned team, const Runner& run) {
         nw.resize(at + (total - from));
         if (from < m) {
             if (!resolve(c, from, m, nw.data() + at)) return false;
-            std::memcpy(nw.data() + at + (m - from), c.out.p.get() + m, total - m);
+            std::memcpy(nw.data() + at + (m - from), c.out.data() + m, total - m);
         } else if (total > from) {
-            std::memcpy(nw.data() + at, c.out.p.get() + from, total - from);
+            std::memcpy(nw.data() + at, c.out.data() + from, total - from);
         }
         win.swap(nw);
     }
@@ -1079,10 +1109,10 @@ bool ParallelGunzip::round(unsigned team, const Runner& run) {
     std::vector<char> ok(chain.size(), 1);
     each(static_cast<unsigned>(chain.size()), [&](unsigned k) {
         Chunk& c = ch[chain[k]];
-        if (c.mk.q && !resolve(c, 0, c.mk.q, c.out.p.get())) ok[k] = 0;
+        if (c.mk.q && !resolve(c, 0, c.mk.q, c.out.data())) ok[k] = 0;
         size_t from = 0;
         auto piece = [&](size_t to) {
-            c.crc_pieces.emplace_back(crc32_of(0u, c.out.p.get() + from, to - from), to - from);
+            c.crc_pieces.emplace_back(crc32_of(0u, c.out.data() + from, to - from), to - from);
             from = to;
         };
         for (const MemberEnd& me : c.member_ends) piece(me.out_off);
@@ -1131,8 +1161,7 @@ bool ParallelGunzip::round(unsigned team, const Runner& run) {
         if (!c.total()) continue;
         Piece p;   // (the bytes stay where zlib wrote them)
         p.len = c.total();
-        p.cap = c.out.cap;
-        p.p = std::move(c.out.p);
+        p.buf = std::move(c.out.b);
         ready_.push_back(std::move(p));
     }
     return true;
@@ -1158,7 +1187,7 @@ size_t ParallelGunzip::read(char* dst, size_t n, unsigned team, const Runner& ru
         }
         Piece& p = ready_.front();
         const size_t take = std::min(n - got, p.len - p.from);
-        segs.push_back({p.p.get() + p.from, dst + got, take});
+        segs.push_back({p.buf.data() + p.from, dst + got, take});
         p.from += take;
         got += take;
         if (p.from == p.len) {
@@ -1177,7 +1206,7 @@ size_t ParallelGunzip::read(char* dst, size_t n, unsigned team, const Runner& ru
             if (at >= hi) break;
         }
     });
-    for (Piece& p : spent) byte_pool_.emplace_back(std::move(p.p), p.cap);
+    for (Piece& p : spent) byte_pool_.push_back(std::move(p.buf));
     if (done_ && ready_.empty()) {   // nothing more to decode: the buffers go
         byte_pool_.clear();
         sym_pool_.clear();
