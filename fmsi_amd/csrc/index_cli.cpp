@@ -22,6 +22,11 @@
 #include "../../include/fmsi_hip.h"
 #include "common.h"
 #include "fastx.h"
+#include "pgunzip.h"
+
+#include <algorithm>
+#include <thread>
+#include <vector>
 
 namespace {
 
@@ -91,6 +96,8 @@ int run_index(int argc, char** argv) {
         }
     } map;
     fmsi::FastxViewParser::Arena arena;
+    fmsi::PgzBuf inflated;   // a gzip file's text, inflated by several threads (pgunzip.h)
+    size_t inflated_len = 0;
     {
         const int fd = open(fn.c_str(), O_RDONLY);
         struct stat st;
@@ -100,6 +107,30 @@ int run_index(int argc, char** argv) {
                 map.data = static_cast<const unsigned char*>(p);
                 map.size = static_cast<size_t>(st.st_size);
                 if (map.data[0] == 0x1f && map.data[1] == 0x8b) {   // gzip
+                    // An ordinary gzip file of a megabyte and more is inflated by several threads (a human-scale superstring is 0.8 GB of
+                    // gzip: 8 s of zlib's one thread in front of a build of 2.3 s) and parsed like a mapped plain file; a stream that
+                    // reader does not take (pgunzip.h), or FMSI_HIP_NO_PARALLEL_GUNZIP, leaves the file to the ordinary reader below.
+                    fmsi::ParallelGunzip pgz;
+                    if (!std::getenv("FMSI_HIP_NO_PARALLEL_GUNZIP") && pgz.open(fn, size_t(1) << 20)) {
+                        const unsigned team = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+                        const fmsi::ParallelGunzip::Runner run = [](unsigned n, const std::function<void(unsigned)>& f) {
+                            std::vector<std::thread> th;
+                            for (unsigned t = 1; t < n; ++t) th.emplace_back([&f, t] { f(t); });
+                            f(0);
+                            for (auto& x : th) x.join();
+                        };
+                        // (the trailer's length field is the text's length modulo 2^32: a first guess at the room)
+                        const size_t isize = map.data[map.size - 4] | (static_cast<size_t>(map.data[map.size - 3]) << 8) | (static_cast<size_t>(map.data[map.size - 2]) << 16) |
+                                             (static_cast<size_t>(map.data[map.size - 1]) << 24);
+                        inflated.grow(std::max(isize, map.size * 3) + (size_t(1) << 20), 0);
+                        for (;;) {
+                            if (inflated.cap() - inflated_len < (size_t(64) << 20)) inflated.grow(inflated.cap() + inflated.cap() / 2, inflated_len);
+                            const size_t got = pgz.read(reinterpret_cast<char*>(inflated.data()) + inflated_len, inflated.cap() - inflated_len, team, run);
+                            inflated_len += got;
+                            if (got == 0) break;
+                        }
+                        if (pgz.failed()) inflated_len = 0;   // (whatever it is: zlib reads the file from its first byte, as it always did)
+                    }
                     munmap(p, map.size);
                     map.data = nullptr;
                 }
@@ -107,8 +138,8 @@ int run_index(int argc, char** argv) {
         }
         if (fd >= 0) close(fd);
     }
-    if (map.data) {
-        fmsi::FastxViewParser parser(map.data, map.size);
+    if (map.data || inflated_len) {
+        fmsi::FastxViewParser parser(map.data ? map.data : inflated.data(), map.data ? map.size : inflated_len);
         const char *name, *seq;
         size_t name_len;
         if (!parser.next(arena, &name, &name_len, &seq, &ms_len))
