@@ -16,11 +16,13 @@
 #include <unistd.h>
 #include <sys/mman.h>
 #include <fcntl.h>
+#include <linux/falloc.h>
 
 #include <sched.h>
 
 #include <algorithm>
 #include <atomic>
+#include <cctype>
 #include <charconv>
 #include <chrono>
 #include <cmath>
@@ -866,6 +868,114 @@ void (*g_exit_hook)(int) = nullptr;
 }
 extern "C" void fmsi_cli_set_exit_hook(void (*hook)(int)) { g_exit_hook = hook; }
 
+namespace {
+// stdout is a regular file: the pages of its first gigabytes are allocated WHILE THE INDEX LOADS -- fallocate(KEEP_SIZE): beyond the end of
+// the file, its size untouched -- by a thread that stops the moment the sink writes its first byte.  One thread's write() into a tmpfs file
+// is the longest stage of this program (0.15-0.18 s per GB of output: 1 GB per 10^9 windows), and 0.065 s of that is the allocation of the
+// file's pages, which costs the same when nobody is waiting for it: write() into pages that stand takes 0.085 s per GB (tools/micro/
+// write_bench.cpp; beside a writer that is writing the same call makes both slower -- the inode's lock -- hence the stop).  What was allocated
+// and not written is given back at the end.  FMSI_HIP_NO_OUT_PREALLOC: off.
+// How many bytes will a presence query print for this file?  From its first megabyte: per record the name, a tab, a character per window, a
+// newline -- 0.997 of the file for reads of 10 kb, a quarter of it for records of one 31-mer.  It has to be about right: pages allocated and
+// not written are given back at the end, where somebody waits for it (a k-mer file taken for reads: 2 GB of them, + 0.1 s).  A compressed
+// file has no first megabyte of text to look at: none (0).
+uint64_t estimate_output_bytes(const std::string& path, uint64_t file_bytes, int k) {
+    const int fd = open(path.c_str(), O_RDONLY);
+    if (fd < 0) return 0;
+    std::vector<char> buf(size_t(1) << 20);
+    const ssize_t got = pread(fd, buf.data(), buf.size(), 0);
+    close(fd);
+    if (got < 2 || (static_cast<unsigned char>(buf[0]) == 0x1f && static_cast<unsigned char>(buf[1]) == 0x8b)) return 0;
+    if (buf[0] != '>' && buf[0] != '@') return 0;
+    const bool fastq = buf[0] == '@';
+    const char* p = buf.data();
+    const char* const end = p + got;
+    uint64_t in = 0, out = 0;
+    while (p < end) {
+        const char* const rec = p;
+        const char* nl = static_cast<const char*>(std::memchr(p, '\n', static_cast<size_t>(end - p)));
+        if (!nl) break;
+        size_t name = 0;
+        for (const char* q = p + 1; q < nl && !std::isspace(static_cast<unsigned char>(*q)); ++q) ++name;
+        p = nl + 1;
+        uint64_t bases = 0;
+        bool whole = false;
+        if (fastq) {   // sequence, '+', quality: one line each
+            const char* a = static_cast<const char*>(std::memchr(p, '\n', static_cast<size_t>(end - p)));
+            const char* b = a ? static_cast<const char*>(std::memchr(a + 1, '\n', static_cast<size_t>(end - a - 1))) : nullptr;
+            const char* c = b ? static_cast<const char*>(std::memchr(b + 1, '\n', static_cast<size_t>(end - b - 1))) : nullptr;
+            if (c) {
+                bases = static_cast<uint64_t>(a - p);
+                p = c + 1;
+                whole = true;
+            }
+        } else {
+            while (p < end && *p != '>') {
+                const char* a = static_cast<const char*>(std::memchr(p, '\n', static_cast<size_t>(end - p)));
+                if (!a) break;
+                bases += static_cast<uint64_t>(a - p);
+                p = a + 1;
+            }
+            whole = p < end || static_cast<uint64_t>(got) == file_bytes;
+        }
+        if (!whole) break;
+        in += static_cast<uint64_t>(p - rec);
+        out += name + 2 + (bases >= static_cast<uint64_t>(k) ? bases - static_cast<uint64_t>(k) + 1 : 0);
+    }
+    if (in == 0) return 0;
+    return static_cast<uint64_t>(static_cast<double>(file_bytes) * static_cast<double>(out) / static_cast<double>(in) * 1.01) + (uint64_t(1) << 20);
+}
+
+class OutPrealloc {
+public:
+    ~OutPrealloc() { finish(); }
+    void start(uint64_t estimate) {
+        if (std::getenv("FMSI_HIP_NO_OUT_PREALLOC") || estimate == 0) return;
+        struct stat st;
+        if (fstat(STDOUT_FILENO, &st) != 0 || !S_ISREG(st.st_mode)) return;
+        const int fl = fcntl(STDOUT_FILENO, F_GETFL);
+        if (fl < 0 || (fl & O_APPEND)) return;   // (`>>`: somebody else may append to that file, too, and the end of it is not this program's to trim)
+        const off_t at = lseek(STDOUT_FILENO, 0, SEEK_CUR);
+        if (at < 0 || at < st.st_size) return;   // (writing into the middle of a file that is there: its pages are, too)
+        base_ = at;
+        end_.store(at, std::memory_order_relaxed);
+        const uint64_t want = std::min<uint64_t>(estimate, kMost);
+        active_ = true;
+        th_ = std::thread([this, want] {
+            for (uint64_t off = 0; off < want && !stop_.load(std::memory_order_acquire); off += kPiece) {
+                const off_t len = static_cast<off_t>(std::min<uint64_t>(kPiece, want - off));
+                if (fallocate(STDOUT_FILENO, FALLOC_FL_KEEP_SIZE, base_ + static_cast<off_t>(off), len) != 0) break;   // (a file system without it, no room: nothing lost)
+                end_.store(base_ + static_cast<off_t>(off) + len, std::memory_order_release);
+            }
+        });
+    }
+    void writing_starts() { stop_.store(true, std::memory_order_release); }
+    void finish() {   // behind the last write (or on any way out): what stands beyond the end of the output goes back
+        if (!active_) return;
+        active_ = false;
+        stop_.store(true, std::memory_order_release);
+        if (th_.joinable()) th_.join();
+        struct stat st;
+        off_t pos = lseek(STDOUT_FILENO, 0, SEEK_CUR);
+        if (fstat(STDOUT_FILENO, &st) == 0) pos = std::max(pos, st.st_size);
+        const off_t end = end_.load(std::memory_order_acquire);
+        if (pos >= 0 && end > pos) {
+            // (tmpfs frees pages beyond the end by the hole; ext4 ignores a hole out there and frees them when the file is cut to the size it has)
+            (void)fallocate(STDOUT_FILENO, FALLOC_FL_PUNCH_HOLE | FALLOC_FL_KEEP_SIZE, pos, end - pos);
+            (void)!ftruncate(STDOUT_FILENO, pos);
+        }
+    }
+
+private:
+    static constexpr uint64_t kPiece = 32ull << 20, kMost = 3ull << 30;   // (what a load of 0.2 s has the time for)
+    std::thread th_;
+    std::atomic<bool> stop_{false};
+    std::atomic<off_t> end_{0};
+    off_t base_ = 0;
+    bool active_ = false;
+};
+}  // namespace
+
 extern "C" int fmsi_cli_query(int argc, char** argv, int output_orders_i) {
     // the command is a chain of builder calls in a process of its own: they share the library's block cache (include/fmsi_hip.h)
     struct KeepScratch {
@@ -973,6 +1083,7 @@ extern "C" int fmsi_cli_query(int argc, char** argv, int output_orders_i) {
     BoundedQueue<std::unique_ptr<RawBatch>> raw_q(2);
     BoundedQueue<std::unique_ptr<Prepared>> out_q(2);
     std::exception_ptr writer_err;
+    OutPrealloc out_prealloc;   // (declared before the reader: whatever ends this function gives the unwritten pages back)
     QueryReader query_reader(opt.query_fn, opt.batch_windows, team, raw_q);
     auto start_reader = [&] { query_reader.start(); };
     auto stop_reader = [&] {   // every way out below: the reader must not stay blocked on a full queue
@@ -1009,7 +1120,10 @@ extern "C" int fmsi_cli_query(int argc, char** argv, int output_orders_i) {
         static const char* kmer_env = std::getenv("FMSI_HIP_CLI_KMER_BATCHES");
         if (!output_orders && !general && k >= 1 && k <= 32 && !(kmer_env && kmer_env[0] == '0')) query_reader.allow_kmer_batches(k);
         struct stat st;
-        if (opt.query_fn == "-" || stat(opt.query_fn.c_str(), &st) == 0) start_reader();
+        if (opt.query_fn == "-" || stat(opt.query_fn.c_str(), &st) == 0) {
+            start_reader();
+            if (!output_orders && opt.query_fn != "-" && S_ISREG(st.st_mode)) out_prealloc.start(estimate_output_bytes(opt.query_fn, static_cast<uint64_t>(st.st_size), k));
+        }
     }
 
     // private accelerators (results unchanged).  How much of them: end to end this program moves 3-4 G windows/s at human scale
@@ -1246,6 +1360,7 @@ extern "C" int fmsi_cli_query(int argc, char** argv, int output_orders_i) {
             std::fflush(stdout);   // (nothing of this program's is in stdio's buffer, but whatever is goes first)
             std::unique_ptr<OutBuf> b;
             while (sink_q.pop(b)) {
+                out_prealloc.writing_starts();
                 auto t1 = clock::now();
                 {
                     TraceRange write_range("fmsi: write");
@@ -1440,6 +1555,7 @@ extern "C" int fmsi_cli_query(int argc, char** argv, int output_orders_i) {
     query_reader.join();
     writer_thread.join();
     sink_thread.join();
+    out_prealloc.finish();
     for (const std::exception_ptr& ep : {query_reader.reader_err, writer_err, sink_err, worker_err}) {
         if (!ep) continue;
         try {

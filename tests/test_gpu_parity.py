@@ -153,6 +153,39 @@ def test_cli_equals_reference_golden(fm, name, kind, mode):
     assert out == golden_out(name, kind, mode)
 
 
+def test_cli_output_to_a_file_on_tmpfs(fm, tmp_path):
+    """stdout redirected to a regular file (round 6, OutPrealloc in query_cli.cpp: the file's pages are allocated beyond its end while the index
+    loads, and what is not written is given back): on tmpfs -- where the whole-process benchmarks write -- and on the test directory's file system the
+    bytes are the pipe's, truncating and appending, and no unwritten pages stay allocated behind the end of the file."""
+    import os
+    import subprocess
+    import tempfile
+    name, kind = "sars_k31", CLI_DATASETS["sars_k31"][1][0]
+    k = CLI_DATASETS[name][0]
+    q = str(query_file(name, kind))
+    for mode in ("or", "all"):
+        want = golden_out(name, kind, mode)
+        for where in ("/dev/shm", str(tmp_path)):
+            if not os.path.isdir(where):
+                continue
+            for how in ("wb", "ab"):
+                with tempfile.NamedTemporaryFile(dir=where, delete=False) as f:
+                    path = f.name
+                try:
+                    head = b"kept\n" if how == "ab" else b""
+                    with open(path, "wb") as f:
+                        f.write(head)
+                    with open(path, how) as so:
+                        res = subprocess.run([str(fm.CLI_PATH), *MODES[mode][0], "-k", str(k), "-q", q, index_prefix(name)], stdout=so, stderr=subprocess.PIPE)
+                    assert res.returncode == 0, res.stderr.decode()[-400:]
+                    with open(path, "rb") as f:
+                        assert f.read() == head + want, (mode, where, how)
+                    st = os.stat(path)
+                    assert st.st_blocks * 512 <= st.st_size + (1 << 20), (mode, where, how, st.st_blocks * 512, st.st_size)
+                finally:
+                    os.unlink(path)
+
+
 @pytest.mark.parametrize("name", ["sars_k31", "sars_k13", "repeats_k40"])
 def test_cli_streams_without_S_and_survives_a_bad_klcp_file(fm, tmp_path, monkeypatch, name):
     """Since round 4 `fmsi query` / `lookup` WITHOUT -S stream their windows through the kLCP kernel when the index has its .klcp file

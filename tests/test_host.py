@@ -375,6 +375,21 @@ def test_cli_host_pipeline_under_sanitizers(tmp_path, sanitizer):
                 else:
                     assert stats["parallel_gunzip_bytes"] == 0
             assert len(outs) == 1 and len(res.stdout) > 10000, (mode, tag)
+    # ---- stdout is a regular file: the pages of its first gigabytes are allocated beyond its end while the index loads (OutPrealloc) and what
+    # was not written is given back -- the bytes are the pipe's, appended where the caller asked for it, and nothing stays allocated behind them
+    want = subprocess.run([str(exe), "query", "-O", "-q", str(files["fa"][0]), prefix], capture_output=True, env=env)
+    assert want.returncode == 0 and len(want.stdout) > 10000
+    for how in ("truncate", "append", "off"):
+        target = tmp_path / f"out_{how}.txt"
+        head = b"what was there\n" if how == "append" else b""
+        target.write_bytes(head)
+        with open(target, "ab" if how == "append" else "wb") as so:
+            res = subprocess.run([str(exe), "query", "-O", "-q", str(files["fa"][0]), prefix], stdout=so, stderr=subprocess.PIPE,
+                                 env={**env, **({"FMSI_HIP_NO_OUT_PREALLOC": "1"} if how == "off" else {})})
+        assert res.returncode == 0, res.stderr.decode()[-2000:]
+        assert target.read_bytes() == head + want.stdout, how
+        st = os.stat(target)
+        assert st.st_blocks * 512 <= st.st_size + (1 << 20), (how, st.st_blocks * 512, st.st_size)   # (no gigabyte of unwritten pages left behind the end)
     # ---- gzip files that are not what the team's reader takes -- a wrong CRC, a stream cut short, bytes behind the member, a flipped byte inside --
     # give what zlib alone gives for them (the reader hands over at the last round that stood)
     good = gzip.compress(fasta, 6)
