@@ -21,6 +21,9 @@ namespace fmsi {
 namespace {
 
 constexpr uint32_t kWin = 32768;
+// A chunk's text may be this long and no longer: text that deflates fifty-fold and more (a megabase of one letter) would otherwise make a round
+// of 64 chunks hold tens of gigabytes; such a round fails and zlib -- which inflates that kind of stream at a gigabyte a second -- goes on.
+constexpr size_t kMaxChunkText = size_t(96) << 20;
 constexpr uint16_t kMarker = 0x8000;   // symbol = kMarker | index into the window the chunk was not given (kWin - 1: the byte right in front)
 
 constexpr uint16_t kLenBase[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
@@ -717,11 +720,15 @@ void zlib_phase(const unsigned char* d, size_t size, uint64_t bit, const unsigne
         const size_t in_left = size - static_cast<size_t>(zs.next_in - d);
         zs.avail_in = static_cast<uInt>(std::min<size_t>(in_left, size_t(1) << 30));
         if (c.out.cap() - c.out.len < (size_t(1) << 16)) c.out.reserve(c.out.cap() + (c.out.cap() >> 1) + (size_t(1) << 20));
-        const size_t room = std::min<size_t>(c.out.cap() - c.out.len, size_t(1) << 30);
+        const size_t room = std::min<size_t>(c.out.cap() - c.out.len, size_t(16) << 20);
         zs.next_out = c.out.data() + c.out.len;
         zs.avail_out = static_cast<uInt>(room);
         const int rc = inflate(&zs, Z_BLOCK);
         c.out.len += room - zs.avail_out;
+        if (c.out.len > kMaxChunkText) {
+            c.error = true;
+            break;
+        }
         if (rc == Z_STREAM_END) {
             uint64_t nb = 0;
             if (!cross_member(d, size, static_cast<size_t>(zs.next_in - d), c.out.len, c, &nb)) {
@@ -769,8 +776,8 @@ void decode_unknown(const unsigned char* d, size_t size, StopRule& stop, Chunk& 
     br.init(d, size, c.start_bit);
     MarkerOut& mk = c.mk;
     for (;;) {
-        const BlockEnd be = decode_block_markers(br, tb, mk);
-        if (be == kBlockError) {
+        const BlockEnd be = decode_block_markers(br, tb, mk, kMaxChunkText + 1);
+        if (be == kBlockError || mk.q > kMaxChunkText) {
             c.error = true;
             return;
         }

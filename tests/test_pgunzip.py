@@ -145,6 +145,12 @@ def test_gives_up_where_zlib_would(lib, texts, tmp_path):
             m = min(len(out), len(reach))   # (zlib fed in pieces loses the output of the piece it fails in: either may be the longer one)
             assert rc == 1 and out[:m] == reach[:m], (name, th, ch, rc, n)
             assert name == "flipped_byte" or (fa + fa).startswith(out), (name, th, ch)
+    # text that deflates a thousand-fold: a chunk's text has a bound (96 MB: a round of 64 chunks must not hold tens of gigabytes), the round
+    # fails and zlib -- fast on such a stream -- is asked to go on from the byte the reader got to
+    bomb = tmp_path / "bomb.gz"
+    bomb.write_bytes(deflate(b">x\n" + b"ACGT" * (30 << 20) + b"\n", 6))
+    rc, out, n, st = gunzip(lib, bomb, 4, 0, 1024)
+    assert rc == 1 and n == 0, (rc, n, st)
     # not a gzip file at all / a header that asks for zlib's own checks
     for name, data in (("plain", fa[:10000]), ("header_crc", member(raw, fa, 2)[:10] + b"\0\0" + member(raw, fa)[10:]), ("reserved_flag", member(raw, fa, 0x20)), ("short", b"\x1f\x8b")):
         p = tmp_path / f"{name}.bin"
