@@ -466,6 +466,14 @@ void warm_table_module() {
     (void)hipGetLastError();
 }
 
+uint64_t sign_after_windows() {
+    static const uint64_t v = [] {
+        const char* e = std::getenv("FMSI_HIP_SIGN_AFTER_WINDOWS");
+        return e ? static_cast<uint64_t>(std::max(0ll, atoll(e))) : 4000000000ull;
+    }();
+    return v;
+}
+
 void start_deferred_sign(fmsi_hip_index* idx) {
     if (!idx || !idx->sign_deferred) return;
     idx->sign_deferred = false;
@@ -560,7 +568,7 @@ int build_prefix_table(fmsi_hip_index* idx, int t, bool sign_in_background) {
         static const bool sign_at_load = std::getenv("FMSI_HIP_SIGN_AT_LOAD") != nullptr;   // (A/B runs: round 5's start of the pass, right here)
         if (bg && !sign_at_load) {
             idx->sign_deferred = true;   // started by the first streaming call / after kSignAfterLookups k-mers: start_deferred_sign
-            idx->lookups_unsigned = 0;
+            idx->lookups_unsigned = idx->streamed_unsigned = 0;
         } else {
             hipLaunchKernelGGL(ptable_sign_kernel, dim3(blocks), dim3(256), 0, bg ? idx->bg_stream : static_cast<hipStream_t>(0), idx->dev, a, final_count);
             e = hipGetLastError();

@@ -1696,9 +1696,9 @@ extern "C" int fmsi_hip_query_stream(fmsi_hip_index* idx, const uint64_t* packed
     }
     const bool use_table = idx->d_ptable && !(flags & FMSI_HIP_NO_PREFIX_TABLE) && k >= idx->prefix_len;
     long long* o64 = static_cast<long long*>(d_out);
-    // (a table loaded with FMSI_HIP_LOAD_ASYNC_TABLE gets its signatures from here on, beside this call and the next ones: the certificates
-    // are what they are for -- behind every allocation of the call, so that none of them waits for the pass)
-    if (use_table) ::fmsi::start_deferred_sign(idx);
+    // (a table loaded with FMSI_HIP_LOAD_ASYNC_TABLE gets its signatures once enough windows have been streamed for the pass to pay for itself,
+    // note_streamed -- then beside this call and the next ones, behind every allocation of the call, so that none of them waits for the pass)
+    if (use_table) ::fmsi::note_streamed(idx, n_windows);
     if (v2) {
         const UniformRuns* up = cut_in_kernel ? &uni : nullptr;
         const bool ord = flags & FMSI_HIP_ORDERS;   // (every strand result without an order is -1: the kernel writes those, too -- flush_orders)

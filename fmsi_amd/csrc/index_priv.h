@@ -134,7 +134,7 @@ struct fmsi_hip_index {
     // FMSI_HIP_LOAD_ASYNC_TABLE: the pass has not been started yet -- it starts with the handle's first streaming call (whose certificates are
     // what the signatures are mostly for) or once kSignAfterLookups k-mers have been looked up through the table (start_deferred_sign)
     bool sign_deferred = false;
-    uint64_t lookups_unsigned = 0;
+    uint64_t lookups_unsigned = 0, streamed_unsigned = 0;
     int fn_kind = 0;             // demasking function of the current fmsi_hip_query_runs_fn call (FMSI_HIP_FN_*) and its bounds
     uint64_t fn_r = 0, fn_s = 0;
     void* d_klcp = nullptr;      // plain kLCP bit-vector (n bits, u64 words), when present
@@ -198,6 +198,14 @@ void start_deferred_sign(fmsi_hip_index* idx);
 constexpr uint64_t kSignAfterLookups = 250000000ull;
 inline void note_lookups(fmsi_hip_index* idx, uint64_t n) {
     if (idx->sign_deferred && (idx->lookups_unsigned += n) >= kSignAfterLookups) start_deferred_sign(idx);
+}
+// ... and streamed windows wait for it longer still: the pass is 0.17 s of device time at human scale, the kLCP kernel without its certificates
+// answers 10^9 windows of the benchmark's read mix in 0.055 s instead of 0.017 s -- the pass has paid for itself after 4.4 x 10^9 windows, and a
+// job shorter than that is faster without it (the `fmsi` binary on 10^9 windows: device stage 0.10-0.16 s beside the pass, 0.06-0.09 s without;
+// FMSI_HIP_SIGN_AFTER_WINDOWS sets the mark, 0 = the first streaming call as at the start of round 6)
+uint64_t sign_after_windows();
+inline void note_streamed(fmsi_hip_index* idx, uint64_t n) {
+    if (idx->sign_deferred && (idx->streamed_unsigned += n) > sign_after_windows()) start_deferred_sign(idx);
 }
 // have the runtime load the code object of fmsi_hip.hip / fmsi_stream.hip now (it does so at the first use of one of their kernels, 10-20 ms
 // each): the index load calls these while its payloads are still on their way

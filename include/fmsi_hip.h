@@ -165,9 +165,10 @@ int fmsi_hip_index_release_scratch(fmsi_hip_index* idx);
  * `use_klcp` is a set of flags: bit 0 as above; FMSI_HIP_LOAD_ASYNC_TABLE -- the handle is returned as soon as the prefix table's
  * intervals stand, and the signatures of its entries of 1..3 rows (the shortcut that ends a search four bases early, the streaming
  * kernel's absence certificates) are written on a stream of the library's own BESIDE the caller's queries: two thirds of the
- * table's construction (0.11 of 0.17 s at human scale, t = 15).  The pass starts with the handle's first fmsi_hip_query_stream call --
- * the certificates are what it is mostly for -- or once 2.5 x 10^8 k-mers / windows have gone through the other query calls (a shorter
- * job of isolated k-mers is over before the pass could pay for itself, and runs at a third of its rate beside it).  Results never depend on it -- an entry is rewritten by one aligned
+ * table's construction (0.11 of 0.17 s at human scale, t = 15).  The pass starts once it can pay for itself: after 4 x 10^9 windows
+ * streamed through fmsi_hip_query_stream (its certificates save 0.04 s per 10^9 windows of a mixed read file, the pass costs 0.17 s of
+ * device time beside which the queries run at half their rate) or 2.5 x 10^8 k-mers / windows through the other query calls; a shorter
+ * job never runs it, and fmsi_hip_index_wait_background runs it at once.  Results never depend on it -- an entry is rewritten by one aligned
  * 8-byte store and both of its forms give the same interval; queries in that time are just not yet at full speed.  Calls that read the
  * table as a whole (fmsi_hip_index_enable_verify / _dict, fmsi_hip_index_destroy) wait for the pass; so does fmsi_hip_index_wait_background. */
 #define FMSI_HIP_LOAD_KLCP 0x1
