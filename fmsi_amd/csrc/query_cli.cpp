@@ -582,6 +582,82 @@ uint64_t replay_presence_team(uint8_t* b, uint64_t n, StrandPredictor& p, Mode m
 }
 
 // strict results (both strands per window) -> final per-window values, in the order the reference visits them
+// lookup, a stretch of n windows: the pairs in[2 w], in[2 w + 1] -> out[w] (out may be `in` itself: a window's place is never behind its pair's;
+// or null: only the predictor is walked)
+void replay_orders_tight(const int64_t* in, int64_t* out, uint64_t n, StrandPredictor& predictor, Mode mode, bool wide_orders) {
+    auto cls = [](int64_t x, int64_t y) {
+        return (static_cast<int>(x) >= 0 ? 1 : 0) | (x >= 0 ? 2 : 0) | (static_cast<int>(y) >= 0 ? 4 : 0) | (y >= 0 ? 8 : 0);
+    };
+    uint64_t w = 0;
+    while (w < n) {
+        const int64_t f = in[2 * w], r = in[2 * w + 1];
+        const StrandPredictor before = predictor;
+        const int64_t got = replay_single(predictor, mode, true, f, r);
+        if (out) out[w] = got;
+        ++w;
+        if (wide_orders || !same_state(before, predictor)) continue;
+        const int c0 = cls(f, r);
+        const bool swap = predictor.predict_swap();
+        while (w < n && cls(in[2 * w], in[2 * w + 1]) == c0) {
+            const int64_t first = swap ? in[2 * w + 1] : in[2 * w], second = swap ? in[2 * w] : in[2 * w + 1];
+            if (out) out[w] = static_cast<int>(first) >= 0 ? first : second;
+            ++w;
+        }
+    }
+}
+
+// ... and the batch by the team: stretches walked side by side from warmed-up states, exact (a stretch whose guessed state is not the one its
+// predecessor ended in is walked again from that one); the results stand beside the pairs until all pairs are read, then move to o[0, n)
+uint64_t replay_orders_team(int64_t* o, uint64_t n, StrandPredictor& p, Mode mode, unsigned team, bool wide_orders) {
+    constexpr uint64_t kWarm = 4096, kMaxBack = uint64_t(1) << 20;
+    const unsigned parts = static_cast<unsigned>(std::min<uint64_t>(team, n / (16 * kWarm)));
+    if (parts < 2) {
+        replay_orders_tight(o, o, n, p, mode, wide_orders);
+        return 0;
+    }
+    static thread_local std::vector<int64_t> chosen;   // (the one thread that replays: batches come in order)
+    if (chosen.size() < n) chosen.resize(n);
+    int64_t* const c = chosen.data();
+    std::vector<StrandPredictor> from(parts), to(parts);
+    auto lo_of = [&](unsigned t) { return n / parts * t; };
+    auto hi_of = [&](unsigned t) { return t + 1 == parts ? n : n / parts * (t + 1); };
+    from[0] = p;
+    parallel_for(parts, [&](unsigned t) {
+        StrandPredictor q = from[0];
+        if (t) {
+            // (the warm-up reaches back until it has seen windows that move EVERY score: absent windows move none, a read on the forward strand
+            // moves the score and result_scores[1], one on the other strand the score and result_scores[0] -- and a read is 10^4 windows)
+            const uint64_t lo = lo_of(t), floor = lo > kMaxBack ? lo - kMaxBack : 0;
+            uint64_t from_w = lo, seen_f = 0, seen_r = 0;
+            while (from_w > floor && (lo - from_w < kWarm || seen_f < 64 || seen_r < 64)) {
+                --from_w;
+                const bool f_in = static_cast<int>(o[2 * from_w]) >= 0;
+                seen_f += f_in;
+                seen_r += !f_in && o[2 * from_w + 1] >= 0;
+            }
+            q = StrandPredictor();
+            q.previous = 0;
+            replay_orders_tight(o + 2 * from_w, nullptr, lo - from_w, q, mode, wide_orders);
+            from[t] = q;
+        }
+        replay_orders_tight(o + 2 * lo_of(t), c + lo_of(t), hi_of(t) - lo_of(t), q, mode, wide_orders);
+        to[t] = q;
+    });
+    uint64_t reruns = 0;
+    StrandPredictor cur = to[0];
+    for (unsigned t = 1; t < parts; ++t) {
+        if (same_state(cur, from[t])) {
+            cur = to[t];
+        } else {
+            replay_orders_tight(o + 2 * lo_of(t), c + lo_of(t), hi_of(t) - lo_of(t), cur, mode, wide_orders);
+            ++reruns;
+        }
+    }
+    p = cur;
+    parallel_for(parts, [&](unsigned t) { std::memcpy(o + lo_of(t), c + lo_of(t), (hi_of(t) - lo_of(t)) * sizeof(int64_t)); });
+    return reruns;
+}
+
 void replay_batch(Prepared& P, StrandPredictor& predictor, Mode mode, bool orders, bool streaming, int k, unsigned team, bool wide_orders = false) {
     if (!streaming) {
         // One predictor step per window, in output order == result order; fills do not touch the predictor.  The
@@ -589,7 +665,6 @@ void replay_batch(Prepared& P, StrandPredictor& predictor, Mode mode, bool order
         // the same input (the same pair of strand results; for lookup the same pair of signs) leaves it unchanged too
         // and takes the same decision -- such runs (reads that lie on one strand, absent reads) are skipped over.
         const uint64_t nw = P.windows;
-        uint64_t w = 0;
         if (!orders) {   // (the recurrence as a table, runs skipped, stretches walked side by side by the team: replay_presence_team)
             P.replay_reruns += P.raw.kmer_k ? replay_presence_team<false>(P.bytes.data(), nw, predictor, mode, team)
                                             : replay_presence_team<true>(P.bytes.data(), nw, predictor, mode, team);
@@ -605,22 +680,11 @@ void replay_batch(Prepared& P, StrandPredictor& predictor, Mode mode, bool order
         // (Measured and dropped, profiles/README.md r02n: signs by the team, predictor over the sign bytes, choice by the team --
         // three passes over 16 bytes per window cost more than this one: 2.0 against 1.0 s per 10^9 windows at 1.4 G rows, 3.9
         // against 2.9 s at 2.8 G rows, where every other present k-mer's order is above 2^31 and equal neighbours are rare.)
-        int64_t* o = P.orders.data();
-        auto cls = [](int64_t x, int64_t y) {
-            return (static_cast<int>(x) >= 0 ? 1 : 0) | (x >= 0 ? 2 : 0) | (static_cast<int>(y) >= 0 ? 4 : 0) | (y >= 0 ? 8 : 0);
-        };
-        while (w < nw) {
-            const int64_t f = o[2 * w], r = o[2 * w + 1];
-            const StrandPredictor before = predictor;
-            o[w++] = replay_single(predictor, mode, true, f, r);
-            if (wide_orders || !same_state(before, predictor)) continue;
-            const int c0 = cls(f, r);
-            const bool swap = predictor.predict_swap();
-            while (w < nw && cls(o[2 * w], o[2 * w + 1]) == c0) {
-                const int64_t first = swap ? o[2 * w + 1] : o[2 * w], second = swap ? o[2 * w] : o[2 * w + 1];
-                o[w++] = static_cast<int>(first) >= 0 ? first : second;
-            }
-        }
+        // (Round 6: the walk is cut into one stretch per thread, each started from a predictor warmed up over the windows in front of it
+        // and kept where that state IS the one its predecessor ended in -- replay_presence_team's scheme, here with the pairs read from
+        // the batch and the chosen orders written beside them until every stretch has read its pairs: `fmsi lookup` on 997 M windows
+        // spent 2.9 s of its 3.7 s in this one-thread loop.)
+        P.replay_reruns += replay_orders_team(P.orders.data(), nw, predictor, mode, team, wide_orders);
         return;
     }
     // -S: the predictor steps once per CHUNK (src/fms_index.h:181-254), on the sums of the chunk's strand results.
@@ -777,42 +841,107 @@ void format_bits(const Prepared& P, unsigned team, char* out) {   // out: P.rec_
     });
 }
 
-// lookup: comma separated integers (src/main.cpp:341-342,361-365); every thread formats a range of records
-void format_orders(const Prepared& P, unsigned team, std::vector<std::string>& parts) {
+// lookup: comma separated integers (src/main.cpp:341-342,361-365); every thread formats a range of records.
+// Round 6: straight into a buffer with room for the worst case (no string that checks its capacity per number, no std::to_chars into a
+// temporary): an order is at most ten digits below 2^32 rows -- its digit count from a comparison ladder, the digits two at a time from a table,
+// written backwards into place.  997 M orders (6.3 GB of text) were 30-50 core-seconds of the team, the longest item of `fmsi lookup`.
+struct OrderText {
+    PgzBuf buf;       // (pgunzip.h's buffer: not zero-filled, huge pages)
+    size_t len = 0;
+};
+inline char* put_order(char* p, int64_t v) {
+    static const char kPairs[] =
+        "00010203040506070809101112131415161718192021222324252627282930313233343536373839404142434445464748495051525354555657585960616263646566676869707172737475767778798081828384858687888990919293949596979899";
+    if (v < 0) {   // (-1, or whatever an index of 2^32 rows and more makes of a negative int)
+        *p++ = '-';
+        v = -v;
+    }
+    uint64_t u = static_cast<uint64_t>(v);
+    unsigned nd = 1;
+    if (u >= 10) {
+        if (u < 100) nd = 2;
+        else if (u < 1000) nd = 3;
+        else if (u < 10000) nd = 4;
+        else if (u < 100000) nd = 5;
+        else if (u < 1000000) nd = 6;
+        else if (u < 10000000) nd = 7;
+        else if (u < 100000000) nd = 8;
+        else if (u < 1000000000ull) nd = 9;
+        else {
+            nd = 10;
+            for (uint64_t t = 10000000000ull; u >= t && nd < 20; t *= 10) ++nd;
+        }
+    }
+    char* const end = p + nd;
+    char* q = end;
+    while (u >= 100) {
+        const unsigned r = static_cast<unsigned>(u % 100);
+        u /= 100;
+        q -= 2;
+        std::memcpy(q, kPairs + 2 * r, 2);
+    }
+    if (u >= 10) std::memcpy(q - 2, kPairs + 2 * u, 2);
+    else q[-1] = static_cast<char>('0' + u);
+    return end;
+}
+void format_orders(const Prepared& P, unsigned team, std::vector<OrderText>& parts, bool wide_orders) {
     const size_t nrec = P.raw.recs.size();
     team = static_cast<unsigned>(std::max<size_t>(1, std::min<size_t>(team, nrec / 64 + 1)));
-    parts.resize(team);   // (the strings keep their capacity from batch to batch)
+    parts.resize(team);   // (the buffers keep their room from batch to batch)
     const uint64_t total = P.rec_first[nrec] + nrec;   // balance by windows (+1 per record)
+    (void)wide_orders;
+    const size_t per_order = 21;   // the longest int64 and the comma (room that is not written is not touched: the buffer is not cleared)
     parallel_for(team, [&](unsigned t) {
-        std::string& s = parts[t];
+        OrderText& ot = parts[t];
         const uint64_t lo = total / team * t, hi = t + 1 == team ? total + 1 : total / team * (t + 1);
-        s.clear();
-        if (s.capacity() < (hi - lo) * 8) s.reserve((hi - lo) * 8);   // (about 7 characters per order at human scale; grows if that is short)
-        char num[24];
+        // room for the worst case of this share: every window an order of full length, every filled window "-1,", the names and the record ends
+        size_t room = 64;
+        size_t r0 = nrec, r1 = nrec;
         for (size_t r = 0; r < nrec; ++r) {
             const uint64_t key = P.rec_first[r] + r;
             if (key < lo) continue;
-            if (key >= hi) break;
+            if (key >= hi) {
+                r1 = r;
+                break;
+            }
+            if (r0 == nrec) r0 = r;
+            uint64_t windows = 0;
+            for (uint64_t o = P.rec_ops[r]; o < P.rec_ops[r + 1]; ++o) windows += P.ops[o].count;
+            room += P.raw.recs[r].name_len + 2 + windows * per_order;
+        }
+        if (r0 == nrec) r1 = nrec;
+        ot.buf.grow(room, 0);
+        char* const base = reinterpret_cast<char*>(ot.buf.data());
+        char* p = base;
+        for (size_t r = r0; r < r1; ++r) {
             const RecRef& rr = P.raw.recs[r];
-            s.append(rr.name, rr.name_len);
-            s += '\t';
+            std::memcpy(p, rr.name, rr.name_len);
+            p += rr.name_len;
+            *p++ = '\t';
             bool first = true;
             uint64_t w = P.rec_first[r];
             for (uint64_t o = P.rec_ops[r]; o < P.rec_ops[r + 1]; ++o) {
-                for (uint64_t i = 0; i < P.ops[o].count; ++i) {
-                    if (!first) s += ',';
-                    first = false;
-                    if (P.ops[o].is_run) {
-                        const auto res = std::to_chars(num, num + sizeof num, P.orders[w + i]);
-                        s.append(num, static_cast<size_t>(res.ptr - num));
-                    } else {
-                        s += "-1";
+                const uint64_t count = P.ops[o].count;
+                if (P.ops[o].is_run) {
+                    const int64_t* v = P.orders.data() + w;
+                    for (uint64_t i = 0; i < count; ++i) {
+                        if (!first) *p++ = ',';
+                        first = false;
+                        p = put_order(p, v[i]);
+                    }
+                    w += count;
+                } else {
+                    for (uint64_t i = 0; i < count; ++i) {
+                        if (!first) *p++ = ',';
+                        first = false;
+                        *p++ = '-';
+                        *p++ = '1';
                     }
                 }
-                if (P.ops[o].is_run) w += P.ops[o].count;
             }
-            s += '\n';
+            *p++ = '\n';
         }
+        ot.len = static_cast<size_t>(p - base);
     });
 }
 
@@ -879,7 +1008,7 @@ namespace {
 // newline -- 0.997 of the file for reads of 10 kb, a quarter of it for records of one 31-mer.  It has to be about right: pages allocated and
 // not written are given back at the end, where somebody waits for it (a k-mer file taken for reads: 2 GB of them, + 0.1 s).  A compressed
 // file has no first megabyte of text to look at: none (0).
-uint64_t estimate_output_bytes(const std::string& path, uint64_t file_bytes, int k) {
+uint64_t estimate_output_bytes(const std::string& path, uint64_t file_bytes, int k, unsigned bytes_per_window = 1) {
     const int fd = open(path.c_str(), O_RDONLY);
     if (fd < 0) return 0;
     std::vector<char> buf(size_t(1) << 20);
@@ -920,7 +1049,7 @@ uint64_t estimate_output_bytes(const std::string& path, uint64_t file_bytes, int
         }
         if (!whole) break;
         in += static_cast<uint64_t>(p - rec);
-        out += name + 2 + (bases >= static_cast<uint64_t>(k) ? bases - static_cast<uint64_t>(k) + 1 : 0);
+        out += name + 2 + (bases >= static_cast<uint64_t>(k) ? bases - static_cast<uint64_t>(k) + 1 : 0) * bytes_per_window;
     }
     if (in == 0) return 0;
     return static_cast<uint64_t>(static_cast<double>(file_bytes) * static_cast<double>(out) / static_cast<double>(in) * 1.01) + (uint64_t(1) << 20);
@@ -1122,7 +1251,10 @@ extern "C" int fmsi_cli_query(int argc, char** argv, int output_orders_i) {
         struct stat st;
         if (opt.query_fn == "-" || stat(opt.query_fn.c_str(), &st) == 0) {
             start_reader();
-            if (!output_orders && opt.query_fn != "-" && S_ISREG(st.st_mode)) out_prealloc.start(estimate_output_bytes(opt.query_fn, static_cast<uint64_t>(st.st_size), k));
+            // (`lookup` prints an order and a comma per window: about six characters on a file of which half is in the text; what the estimate
+            // is short of is simply not allocated early, what it is over is given back)
+            if (opt.query_fn != "-" && S_ISREG(st.st_mode))
+                out_prealloc.start(estimate_output_bytes(opt.query_fn, static_cast<uint64_t>(st.st_size), k, output_orders ? 6u : 1u));
         }
     }
 
@@ -1341,7 +1473,7 @@ extern "C" int fmsi_cli_query(int argc, char** argv, int output_orders_i) {
     // a shared mapping of the grown file -- the team's page faults on one address space cost 2-3x the write() they replace.)
     struct OutBuf {
         std::vector<char> bits;             // presence modes: the whole batch
-        std::vector<std::string> parts;     // lookup: one piece per formatting thread
+        std::vector<OrderText> parts;       // lookup: one piece per formatting thread
         std::unique_ptr<Prepared> kmer_batch;   // a k-mer batch: its parts' lines are the output (kept until they are written)
     };
     auto write_all = [](const char* p, size_t n) {
@@ -1367,7 +1499,7 @@ extern "C" int fmsi_cli_query(int argc, char** argv, int output_orders_i) {
                     if (b->kmer_batch)
                         for (const auto& kp : b->kmer_batch->raw.kparts) write_all(kp->text.get(), kp->text_len);
                     else if (output_orders)
-                        for (const std::string& s : b->parts) write_all(s.data(), s.size());
+                        for (const OrderText& ot : b->parts) write_all(reinterpret_cast<const char*>(ot.buf.data()), ot.len);
                     else write_all(b->bits.data(), b->bits.size());
                 }
                 write_s += std::chrono::duration<double>(clock::now() - t1).count();
@@ -1394,7 +1526,7 @@ extern "C" int fmsi_cli_query(int argc, char** argv, int output_orders_i) {
                     patch_kmer_lines(*P, team);
                     b->kmer_batch = std::move(P);
                 } else if (output_orders) {
-                    format_orders(*P, team, b->parts);
+                    format_orders(*P, team, b->parts, rows64);
                 } else {
                     b->bits.resize(n);
                     format_bits(*P, team, b->bits.data());
