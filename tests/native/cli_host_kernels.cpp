@@ -4,6 +4,7 @@
 // functions; links libfmsi_hip.so for the symbols that file refers to (none is called).  Built with ASan + UBSan by tests/test_host.py.
 #include "../../fmsi_amd/csrc/query_cli.cpp"
 
+#include <charconv>
 #include <random>
 
 using namespace fmsi;
@@ -132,6 +133,23 @@ int main() {
         for (uint64_t w = 0; w < nw; ++w) want[w] = replay_single(a, Mode::Or, true, P.orders[2 * w], P.orders[2 * w + 1]);
         replay_batch(P, b, Mode::Or, true, false, 31, it % 2 ? 5u : 1u, wide);
         if (!same_state(a, b) || std::memcmp(want.data(), P.orders.data(), nw * 8) != 0) return fail("lookup replay", it, nw);
+    }
+    // the lookup formatter's integers (put_order: digit pairs from a table, written backwards into place) against std::to_chars: every power
+    // of ten and its neighbours, the ends of int and int64, random values of every width, -1 and other negatives
+    {
+        std::vector<int64_t> vals = {0, -1, -2, -14, 9, 10, 11, 99, 100, 101, INT32_MAX, static_cast<int64_t>(INT32_MAX) + 1, UINT32_MAX, static_cast<int64_t>(UINT32_MAX) + 1, INT64_MAX, INT64_MIN + 1};
+        for (int64_t t = 10; t > 0 && t < INT64_MAX / 10; t *= 10)
+            for (int64_t d : {-1, 0, 1}) vals.push_back(t + d);
+        for (int i = 0; i < 200000; ++i) {
+            const uint64_t x = rng();
+            vals.push_back(static_cast<int64_t>(x >> (x % 64)) * (i % 17 == 0 ? -1 : 1));
+        }
+        for (int64_t v : vals) {
+            char a[32], b[32];
+            char* pa = put_order(a, v);
+            const auto rb = std::to_chars(b, b + sizeof b, v);
+            if (pa - a != rb.ptr - b || std::memcmp(a, b, static_cast<size_t>(pa - a)) != 0) return fail("put_order", static_cast<size_t>(v & 0xFFFF), static_cast<size_t>(pa - a));
+        }
     }
     printf("cli host kernels OK\n");
     // the predictor's recurrence as a table (k-mer batches) against replay_single(), window by window, from every kind of state
