@@ -30,6 +30,7 @@ MODES = {
     "all_S": ["query", "-S", "-O"],
     "all_S_fast": ["query", "-S", "-O", "--fast"],
     "lookup": ["lookup"],
+    "lookup_S": ["lookup", "-S"],
     # f-masked superstrings (query_mode::general): f(ones, total) over both strands, no replay
     "xor": ["query", "-f", "xor"],
     "and": ["query", "-f", "and"],
