@@ -33,6 +33,7 @@
 #include <deque>
 #include <exception>
 #include <fstream>
+#include <functional>
 #include <iostream>
 #include <map>
 #include <memory>
@@ -1017,16 +1018,29 @@ namespace {
 // and not written is given back at the end.  FMSI_HIP_NO_OUT_PREALLOC: off.
 // How many bytes will a presence query print for this file?  From its first megabyte: per record the name, a tab, a character per window, a
 // newline -- 0.997 of the file for reads of 10 kb, a quarter of it for records of one 31-mer.  It has to be about right: pages allocated and
-// not written are given back at the end, where somebody waits for it (a k-mer file taken for reads: 2 GB of them, + 0.1 s).  A compressed
-// file has no first megabyte of text to look at: none (0).
+// not written are given back at the end, where somebody waits for it (a k-mer file taken for reads: 2 GB of them, + 0.1 s).
 uint64_t estimate_output_bytes(const std::string& path, uint64_t file_bytes, int k, unsigned bytes_per_window = 1) {
     const int fd = open(path.c_str(), O_RDONLY);
     if (fd < 0) return 0;
     std::vector<char> buf(size_t(1) << 20);
-    const ssize_t got = pread(fd, buf.data(), buf.size(), 0);
+    ssize_t got = pread(fd, buf.data(), buf.size(), 0);
     close(fd);
-    if (got < 2 || (static_cast<unsigned char>(buf[0]) == 0x1f && static_cast<unsigned char>(buf[1]) == 0x8b)) return 0;
-    if (buf[0] != '>' && buf[0] != '@') return 0;
+    if (got >= 2 && static_cast<unsigned char>(buf[0]) == 0x1f && static_cast<unsigned char>(buf[1]) == 0x8b) {
+        // a gzip / block-gzip file: its first four megabytes of text through zlib (a few milliseconds), and the file's text taken to be as many
+        // times its size as those were of the compressed bytes they came from
+        gzFile g = gzopen(path.c_str(), "rb");
+        if (!g) return 0;
+        (void)gzbuffer(g, 1u << 16);
+        buf.resize(size_t(4) << 20);
+        const int n = gzread(g, buf.data(), static_cast<unsigned>(buf.size()));
+        const z_off_t used = gzoffset(g);
+        (void)gzclose(g);
+        if (n <= 0 || used <= 0) return 0;
+        got = n;
+        if (static_cast<uint64_t>(used) < file_bytes) file_bytes = static_cast<uint64_t>(static_cast<double>(file_bytes) * static_cast<double>(n) / static_cast<double>(used));
+        else file_bytes = static_cast<uint64_t>(n);   // (the whole file was those four megabytes, or less)
+    }
+    if (got < 2 || (buf[0] != '>' && buf[0] != '@')) return 0;
     const bool fastq = buf[0] == '@';
     const char* p = buf.data();
     const char* const end = p + got;
@@ -1069,8 +1083,8 @@ uint64_t estimate_output_bytes(const std::string& path, uint64_t file_bytes, int
 class OutPrealloc {
 public:
     ~OutPrealloc() { finish(); }
-    void start(uint64_t estimate) {
-        if (std::getenv("FMSI_HIP_NO_OUT_PREALLOC") || estimate == 0) return;
+    void start(std::function<uint64_t()> estimate) {   // (the estimate is made by the thread itself: a compressed file's costs a few milliseconds of zlib)
+        if (std::getenv("FMSI_HIP_NO_OUT_PREALLOC")) return;
         struct stat st;
         if (fstat(STDOUT_FILENO, &st) != 0 || !S_ISREG(st.st_mode)) return;
         const int fl = fcntl(STDOUT_FILENO, F_GETFL);
@@ -1079,9 +1093,9 @@ public:
         if (at < 0 || at < st.st_size) return;   // (writing into the middle of a file that is there: its pages are, too)
         base_ = at;
         end_.store(at, std::memory_order_relaxed);
-        const uint64_t want = std::min<uint64_t>(estimate, kMost);
         active_ = true;
-        th_ = std::thread([this, want] {
+        th_ = std::thread([this, estimate] {
+            const uint64_t want = std::min<uint64_t>(estimate(), kMost);
             for (uint64_t off = 0; off < want && !stop_.load(std::memory_order_acquire); off += kPiece) {
                 const off_t len = static_cast<off_t>(std::min<uint64_t>(kPiece, want - off));
                 if (fallocate(STDOUT_FILENO, FALLOC_FL_KEEP_SIZE, base_ + static_cast<off_t>(off), len) != 0) break;   // (a file system without it, no room: nothing lost)
@@ -1265,7 +1279,7 @@ extern "C" int fmsi_cli_query(int argc, char** argv, int output_orders_i) {
             // (`lookup` prints an order and a comma per window: about six characters on a file of which half is in the text; what the estimate
             // is short of is simply not allocated early, what it is over is given back)
             if (opt.query_fn != "-" && S_ISREG(st.st_mode))
-                out_prealloc.start(estimate_output_bytes(opt.query_fn, static_cast<uint64_t>(st.st_size), k, output_orders ? 6u : 1u));
+                out_prealloc.start([path = opt.query_fn, bytes = static_cast<uint64_t>(st.st_size), k, per = output_orders ? 6u : 1u] { return estimate_output_bytes(path, bytes, k, per); });
         }
     }
 

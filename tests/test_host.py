@@ -379,12 +379,13 @@ def test_cli_host_pipeline_under_sanitizers(tmp_path, sanitizer):
     # was not written is given back -- the bytes are the pipe's, appended where the caller asked for it, and nothing stays allocated behind them
     want = subprocess.run([str(exe), "query", "-O", "-q", str(files["fa"][0]), prefix], capture_output=True, env=env)
     assert want.returncode == 0 and len(want.stdout) > 10000
-    for how in ("truncate", "append", "off"):
+    for how in ("truncate", "append", "off", "gzip", "bgzf"):
         target = tmp_path / f"out_{how}.txt"
         head = b"what was there\n" if how == "append" else b""
         target.write_bytes(head)
+        source = files["fa"][2] if how == "gzip" else files["fa"][1] if how == "bgzf" else files["fa"][0]   # (a compressed file: its text's length estimated from its first megabytes)
         with open(target, "ab" if how == "append" else "wb") as so:
-            res = subprocess.run([str(exe), "query", "-O", "-q", str(files["fa"][0]), prefix], stdout=so, stderr=subprocess.PIPE,
+            res = subprocess.run([str(exe), "query", "-O", "-q", str(source), prefix], stdout=so, stderr=subprocess.PIPE,
                                  env={**env, **({"FMSI_HIP_NO_OUT_PREALLOC": "1"} if how == "off" else {})})
         assert res.returncode == 0, res.stderr.decode()[-2000:]
         assert target.read_bytes() == head + want.stdout, how
